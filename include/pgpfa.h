@@ -1,0 +1,131 @@
+/*
+ * pgpfa.h - C-ABI of libpgpfa_hip.so: the MI355X (gfx950) implementation of the
+ * Poisson-GPFA EM hot path.
+ *
+ * The reference (mackelab/poisson-gpfa) is pure Python and has no FFI; the boundary it
+ * exposes is the call surface of funs/inference.py, funs/learning.py and funs/engine.py.
+ * Every entry point below names the reference function (file:line under the reference
+ * tree) whose arithmetic it replaces.  The host mirror of that call surface lives in
+ * poisson-gpfa_amd/funs/ and binds these symbols with ctypes.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all host arrays are caller-owned, C-contiguous.
+ *   - every function returns 0 on success, non-zero on failure; pgpfa_last_error()
+ *     returns the message of the last failure on the calling thread.
+ *   - doubles everywhere (the reference computes in float64); spike counts are packed
+ *     to uint8 on upload (counts above 255 are rejected).
+ *   - one context = one GPU = one host thread at a time; no callbacks into the caller.
+ *   - trial index lists are int32, relative to the count tensor uploaded into the
+ *     context; a NULL list means "all trials".
+ *   - sizes: q neurons (ydim), p latents (xdim), T bins, R trials, n = p*T.
+ *   - vector layouts are the reference's: xbar[k*T+t] = X[k][t] (inference.py:129),
+ *     vecCd = [C[:,0],...,C[:,p-1], d] (util.py:560-574).
+ */
+#ifndef PGPFA_H
+#define PGPFA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pgpfa_ctx pgpfa_ctx;
+
+/* ---- library ------------------------------------------------------------------ */
+const char* pgpfa_last_error(void);
+int pgpfa_version(void);
+int pgpfa_device_count(int* count);
+
+/* ---- context ------------------------------------------------------------------ */
+/* One fit = one context: sizes of experiment.data (engine.py:131-135), binSize in ms. */
+int pgpfa_create(pgpfa_ctx** out, int device, int q, int p, int T, int R, double bin_ms);
+int pgpfa_destroy(pgpfa_ctx* ctx);
+/* Options: "newton_xtol" (1e-5), "newton_max_iter" (50), "use_mfma" (1), "keep_vsmgp" (1),
+ * "chunk_trials" (0 = auto), "eps_noise" (1e-3, util.py:599). */
+int pgpfa_set_option(pgpfa_ctx* ctx, const char* key, double value);
+/* Info: "chunk_trials", "n_pad", "last_newton_factorizations", "last_estep_ms",
+ * "last_chol_ms", "last_chol_flops", "hbm_bytes_allocated", ... */
+int pgpfa_get_info(pgpfa_ctx* ctx, const char* key, double* value);
+
+/* ---- data ---------------------------------------------------------------------- */
+/* experiment.data[r]['Y'] for all r, as one [R][q][T] tensor (inference.py:96-97). */
+int pgpfa_upload_counts_f64(pgpfa_ctx* ctx, const double* Y);
+int pgpfa_upload_counts_u8(pgpfa_ctx* ctx, const uint8_t* Y);
+/* params = {'C': [q][p], 'd': [q], 'tau': [p] seconds} (engine.py:40-44).  Builds the p Gram
+ * matrices (util.makeK_big, util.py:599-619) and their inverses (inference.py:82) on device. */
+int pgpfa_set_params(pgpfa_ctx* ctx, const double* C, const double* d, const double* tau_s);
+int pgpfa_get_gram(pgpfa_ctx* ctx, double* K /* [p][T][T] */);
+int pgpfa_get_gram_inverse(pgpfa_ctx* ctx, double* Kinv /* [p][T][T] */);
+
+/* ---- Laplace callbacks (inference.py:12-65) -------------------------------------- */
+/* negLogPosteriorUnNorm and _grad at caller-supplied points X[n][p][T] for trials idx[n]. */
+int pgpfa_laplace_eval(pgpfa_ctx* ctx, int n, const int32_t* idx, const double* X,
+                       double* f /* [n] */, double* grad /* [n][p][T] or NULL */);
+/* negLogPosteriorUnNorm_hess for one trial, dense [pT][pT] latent-major. */
+int pgpfa_laplace_hessian(pgpfa_ctx* ctx, int trial, const double* X, double* H);
+
+/* ---- Laplace E-step (inference.laplace, inference.py:67-185) ---------------------- */
+/* Mode finding + posterior covariance blocks for the listed trials.  warm_start != 0
+ * starts from the modes resident in the context (prevOptimRes, inference.py:99-102),
+ * otherwise from zeros.  obj_sum = sum over the listed trials of the objective at the
+ * mode (the reference returns -obj_sum/numTrials, inference.py:175,183).
+ * iters/status (may be NULL): Newton factorizations per trial, 0 = converged. */
+int pgpfa_estep_laplace(pgpfa_ctx* ctx, int n, const int32_t* idx, int warm_start,
+                        double* obj_sum, int32_t* iters, int32_t* status);
+int pgpfa_set_modes(pgpfa_ctx* ctx, int n, const int32_t* idx, const double* X /* [n][p][T] */);
+int pgpfa_get_post_mean(pgpfa_ctx* ctx, int n, const int32_t* idx, double* out /* [n][p][T] */);
+int pgpfa_get_post_vsm(pgpfa_ctx* ctx, int n, const int32_t* idx, double* out /* [n][T][p][p] */);
+/* post_vsmGP in the reference's (T,T,p) layout (inference.py:164-167). */
+int pgpfa_get_post_vsmgp(pgpfa_ctx* ctx, int n, const int32_t* idx, double* out /* [n][T][T][p] */);
+/* post_cov of one trial, recomputed on demand (inference.py:130-131,161-162). */
+int pgpfa_get_post_cov(pgpfa_ctx* ctx, int trial, double* out /* [pT][pT] */);
+/* Upload E-step results produced elsewhere (e.g. a reference infRes dict) for the M-step. */
+int pgpfa_set_posterior(pgpfa_ctx* ctx, int n, const int32_t* idx, const double* post_mean,
+                        const double* post_vsm, const double* post_vsmgp /* [n][T][T][p] */);
+
+/* ---- M-step ----------------------------------------------------------------------- */
+/* MStepObservationCost(_grad) (learning.py:20-91) over the trials of the last E-step /
+ * pgpfa_set_posterior call; with prior_center != NULL adds |v-center|^2 * inv_s2 / 2 and its
+ * gradient ('useDiag' prior of learning.py:445-534).  Multi-GPU: all-reduced over ranks. */
+int pgpfa_mstep_cd_costgrad(pgpfa_ctx* ctx, const double* vecCd, const double* prior_center,
+                            double inv_s2, double* cost, double* grad /* [q*(p+1)] */);
+/* makePrecomp (learning.py:145-173): PautoSum[p][T][T] over the same trials (all-reduced). */
+int pgpfa_mstep_precomp(pgpfa_ctx* ctx, double* num_trials);
+int pgpfa_get_pautosum(pgpfa_ctx* ctx, double* out /* [p][T][T] */);
+/* MStepGPtimescaleCost(_grad) (learning.py:175-255) for latent k at log-gamma = logp. */
+int pgpfa_mstep_tau_costgrad(pgpfa_ctx* ctx, int k, double logp, double* cost, double* grad);
+
+/* ---- dual variational E-step (inference.py:188-432) -------------------------------- */
+/* dualProblem and dualProblem_grad for one trial at lambda[q*T] (structured: never forms
+ * C_big or diag(lambda)). */
+int pgpfa_dual_costgrad(pgpfa_ctx* ctx, int trial, const double* lam, double* cost,
+                        double* grad /* [q*T] or NULL */);
+/* VIPostMean / VIPostCov blocks at lambda for the listed trials; fills the same posterior
+ * slots as the Laplace E-step and returns sum of negLogPosteriorUnNorm at the VI mean. */
+int pgpfa_dual_finalize(pgpfa_ctx* ctx, int n, const int32_t* idx, const double* lam /* [n][q*T] */,
+                        double* nlp_sum);
+
+/* ---- multi-GPU (trial sharding; RCCL over xGMI) -------------------------------------- */
+int pgpfa_comm_unique_id(char* id128 /* 128 bytes */);
+int pgpfa_comm_init(pgpfa_ctx* ctx, const char* id128, int rank, int nranks);
+int pgpfa_comm_allreduce_host(pgpfa_ctx* ctx, double* buf, int count);
+
+/* ---- test / bench hooks ---------------------------------------------------------------- */
+/* Batched SPD factor (+ optional inverse) of caller matrices through the production kernels:
+ * A[batch][n][n] symmetric in, Cholesky factor L (lower, row-major) out; inv (may be NULL)
+ * receives A^-1.  Used by the parity tests and by bench.py's roofline leg. */
+int pgpfa_test_potrf(pgpfa_ctx* ctx, int batch, int n, const double* A, double* L, double* inv);
+/* C = alpha*A*B^T + beta*C, column-major, through the production MFMA GEMM (use_mfma=1) or
+ * the scalar check kernel (use_mfma=0). */
+int pgpfa_test_gemm_nt(pgpfa_ctx* ctx, int M, int N, int K, double alpha, const double* A,
+                       const double* B, double beta, double* C);
+/* Times `reps` launches of the dominant kernel (batched trailing SYRK update, K=512) with HIP
+ * events on the context stream; returns average ms per launch and the flops of one launch. */
+int pgpfa_bench_syrk(pgpfa_ctx* ctx, int batch, int n, int k, int reps, double* ms_per_launch,
+                     double* flops_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PGPFA_H */

@@ -1,0 +1,271 @@
+// Batched dense SPD factor / solve / transposed-triangular-inverse on top of gemm.h.
+//
+// Storage: one column-major (ld x ld) slab per slot; only the lower triangle is referenced by the
+// factorisation.  npad (multiple of 128) rows/cols are active; rows >= n are identity padding.
+//
+//   chol_factor      blocked right-looking Cholesky, 128-wide diagonal blocks inside 512-wide
+//                    super-panels: potrf_diag (one workgroup per slot, LDS-resident 128x128 block,
+//                    also emits the block's triangular inverse) -> TRSM as GEMM against that inverse
+//                    -> SYRK trailing update restricted to the super-panel; one K=512 SYRK update of
+//                    the rest per super-panel keeps the trailing matrix traffic at n^3/(6*512)*16 B.
+//   chol_solve       forward/backward substitution with the factor (Newton step), one workgroup per
+//                    slot; HBM-bound on one read of L per sweep.
+//   chol_inverse_t   Mt = L^-T (upper triangular) into a second slab, left-to-right over block
+//                    columns with two NT GEMMs per column; Sigma blocks then follow as Mt Mt^T.
+#pragma once
+#include "gemm.h"
+
+namespace pgpfa {
+
+constexpr int NB = 128;     // diagonal block / GEMM tile
+constexpr int NSUP = 512;   // super-panel width
+
+// --------------------------------------------------------------------------------------------------
+// 128x128 diagonal block: Cholesky in LDS, write L back, invert in place, write L^-1 to Dinv.
+// info[slot] is set to (k0 + j + 1) at the first non-positive pivot.
+// --------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void potrf_diag_kernel(double* __restrict__ H, long long sH, int ld, int k0,
+                                                          double* __restrict__ Dinv, long long sD,
+                                                          const int* __restrict__ slots, int* __restrict__ info) {
+  __shared__ double S[NB * NB];     // column-major S[c*128 + r]
+  __shared__ double dg[NB];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const long long slot = slots ? slots[blockIdx.x] : blockIdx.x;
+  double* Hs = H + slot * sH + (size_t)k0 * ld + k0;
+  double* Ds = Dinv + slot * sD + (size_t)(k0 / NB) * NB * NB;
+
+  for (int e = tid; e < NB * NB; e += 512) {
+    const int r = e & (NB - 1), c = e >> 7;
+    S[e] = (r >= c) ? Hs[(size_t)c * ld + r] : 0.0;
+  }
+  __syncthreads();
+
+  for (int j = 0; j < NB; ++j) {
+    const double djj = S[j * NB + j];          // untouched during step j (sqrt kept in dg[])
+    double d = sqrt(djj);
+    if (!(djj > 0.0)) {                          // also catches NaN
+      if (tid == 0 && info[slot] == 0) info[slot] = k0 + j + 1;
+      d = 1.0;
+    }
+    const double rd = 1.0 / d;
+    if (tid == 0) dg[j] = d;
+    for (int r = j + 1 + tid; r < NB; r += 512) S[j * NB + r] *= rd;
+    __syncthreads();
+    // trailing update, one wave per column c (8 waves)
+    for (int c = j + 1 + wave; c < NB; c += 8) {
+      const double lcj = S[j * NB + c];
+      for (int r = c + lane; r < NB; r += 64) S[c * NB + r] -= S[j * NB + r] * lcj;
+    }
+    __syncthreads();
+  }
+  if (tid < NB) S[tid * NB + tid] = dg[tid];
+  __syncthreads();
+  // write L (lower part; zeros above the diagonal inside the block are harmless and keep the
+  // block well defined for kernels that read whole tiles)
+  for (int e = tid; e < NB * NB; e += 512) {
+    const int r = e & (NB - 1), c = e >> 7;
+    if (r >= c) Hs[(size_t)c * ld + r] = S[e];
+  }
+  __syncthreads();
+  // in-place inverse of the lower-triangular block, last column first
+  for (int j = NB - 1; j >= 0; --j) {
+    const double inv = 1.0 / S[j * NB + j];
+    double v = 0.0;
+    const int i = tid;
+    if (i < NB && i > j) {
+      for (int m = j + 1; m <= i; ++m) v += S[m * NB + i] * S[j * NB + m];
+    }
+    __syncthreads();
+    if (i < NB) {
+      if (i > j) S[j * NB + i] = -v * inv;
+      else if (i == j) S[j * NB + j] = inv;
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < NB * NB; e += 512) Ds[e] = S[e];   // upper part is exact zeros
+}
+
+// Mt[jblk, jblk] = Dinv[jb]^T
+__global__ void diag_transpose_kernel(double* __restrict__ Mt, long long sM, int ld, int k0,
+                                      const double* __restrict__ Dinv, long long sD, const int* __restrict__ slots) {
+  const long long slot = slots ? slots[blockIdx.x] : blockIdx.x;
+  double* M = Mt + slot * sM + (size_t)k0 * ld + k0;
+  const double* D = Dinv + slot * sD + (size_t)(k0 / NB) * NB * NB;
+  for (int e = threadIdx.x; e < NB * NB; e += blockDim.x) {
+    const int r = e & (NB - 1), c = e >> 7;
+    M[(size_t)c * ld + r] = D[r * NB + c];
+  }
+}
+
+// --------------------------------------------------------------------------------------------------
+// Newton step solve: v <- -(L L^T)^-1 v for each slot, one workgroup (256 threads) per slot.
+// Also returns dec[slot] = -g.delta (Newton decrement squared) and smax[slot] = max |delta|.
+// v lives in global memory (ld doubles per slot); rows >= n hold zeros.
+// --------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void chol_solve_kernel(const double* __restrict__ H, long long sH, int ld, int npad,
+                                                          const double* __restrict__ Dinv, long long sD,
+                                                          const double* __restrict__ G, double* __restrict__ V,
+                                                          long long sV, const int* __restrict__ slots,
+                                                          double* __restrict__ dec, double* __restrict__ smax, int n) {
+  __shared__ double yk[NB];
+  __shared__ double zk[NB];
+  __shared__ double red[8];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const long long slot = slots ? slots[blockIdx.x] : blockIdx.x;
+  const double* L = H + slot * sH;
+  const double* D = Dinv + slot * sD;
+  const double* g = G + slot * sV;
+  double* v = V + slot * sV;
+  const int nblk = npad / NB;
+
+  for (int i = tid; i < npad; i += 256) v[i] = (i < n) ? g[i] : 0.0;
+  __syncthreads();
+  // forward: y = L^-1 g
+  for (int kb = 0; kb < nblk; ++kb) {
+    const int k0 = kb * NB;
+    if (tid < NB) yk[tid] = v[k0 + tid];
+    __syncthreads();
+    if (tid < NB) {
+      const double* Dk = D + (size_t)kb * NB * NB;
+      double s = 0.0;
+      for (int c = 0; c <= tid; ++c) s += Dk[c * NB + tid] * yk[c];
+      zk[tid] = s;
+      v[k0 + tid] = s;
+    }
+    __syncthreads();
+    for (int i = k0 + NB + tid; i < npad; i += 256) {
+      const double* Lp = L + (size_t)k0 * ld + i;
+      double s = 0.0;
+#pragma unroll 8
+      for (int c = 0; c < NB; ++c) s += Lp[(size_t)c * ld] * zk[c];
+      v[i] -= s;
+    }
+    __syncthreads();
+  }
+  // backward: x = L^-T y
+  for (int kb = nblk - 1; kb >= 0; --kb) {
+    const int k0 = kb * NB;
+    for (int c = wave; c < NB; c += 4) {
+      const double* Lc = L + (size_t)(k0 + c) * ld;
+      double s = 0.0;
+      for (int i = k0 + NB + lane; i < npad; i += 64) s += Lc[i] * v[i];
+      for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+      if (lane == 0) zk[c] = v[k0 + c] - s;
+    }
+    __syncthreads();
+    if (tid < NB) {
+      const double* Dk = D + (size_t)kb * NB * NB;
+      double s = 0.0;
+      for (int c = tid; c < NB; ++c) s += Dk[tid * NB + c] * zk[c];   // (Dinv^T)[tid][c] = Dinv[c][tid]
+      v[k0 + tid] = s;
+    }
+    __syncthreads();
+  }
+  // delta = -x ; dec = -g.delta = g.x ; smax = max|x|
+  double d = 0.0, m = 0.0;
+  for (int i = tid; i < n; i += 256) {
+    const double x = v[i];
+    d += g[i] * x;
+    m = fmax(m, fabs(x));
+    v[i] = -x;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    d += __shfl_down(d, off);
+    m = fmax(m, __shfl_down(m, off));
+  }
+  if (lane == 0) { red[wave] = d; red[4 + wave] = m; }
+  __syncthreads();
+  if (tid == 0) {
+    dec[slot] = red[0] + red[1] + red[2] + red[3];
+    smax[slot] = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
+  }
+}
+
+struct CholWS {
+  double* H; long long sH;        // factor slabs
+  double* Mt; long long sM;       // L^-T slabs (strictly-lower part must be zero)
+  double* Dinv; long long sD;     // inverted diagonal blocks, (npad/128) x 128 x 128 per slot
+  double* P; long long sP;        // npad x 128 scratch per slot
+  int* info;                      // per slot
+  int ld, npad;
+};
+
+inline hipError_t chol_factor(hipStream_t st, bool mfma, const CholWS& w, const int* slots, int nb) {
+  const int np = w.npad, ld = w.ld;
+  for (int c0 = 0; c0 < np; c0 += NSUP) {
+    const int c1 = (c0 + NSUP < np) ? c0 + NSUP : np;
+    for (int k0 = c0; k0 < c1; k0 += NB) {
+      hipLaunchKernelGGL(potrf_diag_kernel, dim3(nb), dim3(512), 0, st, w.H, w.sH, ld, k0, w.Dinv, w.sD, slots, w.info);
+      const int r0 = k0 + NB;
+      if (r0 >= np) break;
+      GemmP g{};
+      // TRSM: L[r0:, k0:k0+128] = A[r0:, k0:k0+128] * Linv_kk^T   (in place, beta = 0)
+      g.A = w.H + (size_t)k0 * ld + r0; g.sA = w.sH; g.lda = ld;
+      g.B = w.Dinv + (size_t)(k0 / NB) * NB * NB; g.sB = w.sD; g.ldb = NB;
+      g.C = w.H + (size_t)k0 * ld + r0; g.sC = w.sH; g.ldc = ld;
+      g.M = np - r0; g.N = NB; g.K = NB; g.alpha = 1.0; g.beta = 0.0;
+      g.slots = slots; g.nbatch = nb; g.mode = GEMM_FULL; g.kflags = 0;
+      hipError_t e = gemm_launch(st, mfma, false, g);
+      if (e != hipSuccess) return e;
+      if (r0 < c1) {
+        // SYRK inside the super-panel: C[r0:, r0:c1] -= L[r0:, k0:k0+128] L[r0:c1, k0:k0+128]^T
+        GemmP s{};
+        s.A = w.H + (size_t)k0 * ld + r0; s.sA = w.sH; s.lda = ld;
+        s.B = s.A; s.sB = w.sH; s.ldb = ld;
+        s.C = w.H + (size_t)r0 * ld + r0; s.sC = w.sH; s.ldc = ld;
+        s.M = np - r0; s.N = c1 - r0; s.K = NB; s.alpha = -1.0; s.beta = 1.0;
+        s.slots = slots; s.nbatch = nb; s.mode = GEMM_LOWER; s.kflags = KF_MASK_DIAG;
+        e = gemm_launch(st, mfma, false, s);
+        if (e != hipSuccess) return e;
+      }
+    }
+    if (c1 < np) {
+      // trailing update with the whole super-panel: C[c1:, c1:] -= L[c1:, c0:c1] L[c1:, c0:c1]^T
+      GemmP s{};
+      s.A = w.H + (size_t)c0 * ld + c1; s.sA = w.sH; s.lda = ld;
+      s.B = s.A; s.sB = w.sH; s.ldb = ld;
+      s.C = w.H + (size_t)c1 * ld + c1; s.sC = w.sH; s.ldc = ld;
+      s.M = np - c1; s.N = np - c1; s.K = c1 - c0; s.alpha = -1.0; s.beta = 1.0;
+      s.slots = slots; s.nbatch = nb; s.mode = GEMM_LOWER; s.kflags = KF_MASK_DIAG;
+      hipError_t e = gemm_launch(st, mfma, false, s);
+      if (e != hipSuccess) return e;
+    }
+  }
+  return hipGetLastError();
+}
+
+// Mt = L^-T (upper triangular, npad x npad).  For block column j:
+//   P = Mt[0:j0, 0:j0] * L[jblk, 0:j0]^T        (k from the row tile on: Mt is upper triangular)
+//   Mt[0:j0, jblk] = -P * Linv_jj^T ;  Mt[jblk, jblk] = Linv_jj^T
+inline hipError_t chol_inverse_t(hipStream_t st, bool mfma, const CholWS& w, const int* slots, int nb) {
+  const int np = w.npad, ld = w.ld;
+  for (int j0 = 0; j0 < np; j0 += NB) {
+    hipLaunchKernelGGL(diag_transpose_kernel, dim3(nb), dim3(256), 0, st, w.Mt, w.sM, ld, j0, w.Dinv, w.sD, slots);
+    if (j0 == 0) continue;
+    GemmP a{};
+    a.A = w.Mt; a.sA = w.sM; a.lda = ld;
+    a.B = w.H + j0; a.sB = w.sH; a.ldb = ld;            // rows jblk of L, columns 0..j0
+    a.C = w.P; a.sC = w.sP; a.ldc = np;
+    a.M = j0; a.N = NB; a.K = j0; a.alpha = 1.0; a.beta = 0.0;
+    a.slots = slots; a.nbatch = nb; a.mode = GEMM_FULL; a.kflags = KF_BEGIN_ROW;
+    hipError_t e = gemm_launch(st, mfma, false, a);
+    if (e != hipSuccess) return e;
+    GemmP b{};
+    b.A = w.P; b.sA = w.sP; b.lda = np;
+    b.B = w.Dinv + (size_t)(j0 / NB) * NB * NB; b.sB = w.sD; b.ldb = NB;
+    b.C = w.Mt + (size_t)j0 * ld; b.sC = w.sM; b.ldc = ld;
+    b.M = j0; b.N = NB; b.K = NB; b.alpha = -1.0; b.beta = 0.0;
+    b.slots = slots; b.nbatch = nb; b.mode = GEMM_FULL; b.kflags = 0;
+    e = gemm_launch(st, mfma, false, b);
+    if (e != hipSuccess) return e;
+  }
+  return hipGetLastError();
+}
+
+// flops of one factorisation / one transposed inverse of an npad-sized system (for reporting)
+inline double chol_factor_flops(double n) { return n * n * n / 3.0; }
+
+}  // namespace pgpfa

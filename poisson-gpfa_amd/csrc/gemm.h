@@ -1,0 +1,275 @@
+// Batched FP64 "NT" GEMM for gfx950:  C[b] = beta*C[b] + alpha * A[b] * op(B[b])
+// column-major everywhere; A is M x K (lda); B is N x K (ldb) when TRANSB=0 ("NT": C = A B^T)
+// or K x N (ldb) when TRANSB=1 ("NN").
+//
+// This one kernel carries every O(n^3) step of the E-step (trailing SYRK updates of the blocked
+// Cholesky, TRSM-as-GEMM against the inverted diagonal block, the triangular inverse, the
+// selected products Sigma_kk = L^-T L^-1 restricted to diagonal blocks) - see chol.h.
+//
+// CDNA4 mapping: 256 threads = 4 waves per 128x128 C tile, each wave owns a 64x64 sub-tile as
+// 4x4 v_mfma_f64_16x16x4_f64 accumulators (128 VGPRs).  A and B panels are staged k-major in
+// LDS ([k][row], row stride 144 doubles so the two 16-lane halves of a ds_read_b64 group land on
+// disjoint bank halves), double-buffered, one barrier per 16-deep K step.  The MFMA is issued as
+// D = Bfrag x Afrag so that the lane index (lane&15) runs along the memory-contiguous row index
+// of C: every accumulator store is 16 lanes x 8 B contiguous.
+// FP64 MFMA on gfx950 runs at the vector FP64 rate (78.6 TFLOP/s chip peak), i.e. 64 cycles per
+// 16x16x4 instruction per SIMD, so one LDS fragment read per MFMA is far below the LDS roof and the
+// kernel is MFMA-issue bound by construction.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace pgpfa {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+enum : int {
+  GEMM_FULL = 0,        // all tilesM x tilesN tiles
+  GEMM_LOWER = 1,       // only tiles with ti >= tj (C, row/col origins coincide)
+};
+enum : int {
+  KF_BEGIN_ROW = 1,     // A is upper-triangular in tile units: k starts at ti*128
+  KF_END_ROW = 2,       // A is lower-triangular in tile units: k ends at (ti+1)*128
+  KF_MASK_DIAG = 4,     // on tiles with ti == tj store only i >= j
+  KF_BEGIN_MAXRC = 8,   // both operands upper-triangular: k starts at max(ti,tj)*128
+};
+
+struct GemmP {
+  const double* A; long long sA; int lda;
+  const double* B; long long sB; int ldb;
+  double* C; long long sC; int ldc;
+  int M, N, K;
+  double alpha, beta;
+  const int* slots;     // batch b -> slot (NULL: identity); pointers advance by slot*stride
+  int nbatch;
+  int mode, kflags;
+  int tilesM, tilesN, ntiles;
+};
+
+__device__ __forceinline__ void gemm_decode_tile(const GemmP& g, int tile, int& ti, int& tj) {
+  if (g.mode == GEMM_FULL) {
+    ti = tile % g.tilesM;
+    tj = tile / g.tilesM;
+  } else {
+    // column tj holds tilesM - tj tiles (ti = tj .. tilesM-1)
+    int tjj = 0, rem = tile;
+    while (rem >= g.tilesM - tjj) { rem -= g.tilesM - tjj; ++tjj; }
+    tj = tjj;
+    ti = tjj + rem;
+  }
+}
+
+constexpr int GBM = 128, GBN = 128, GBK = 16, GLS = 144;   // LDS row stride in doubles
+
+template <int TRANSB>
+__global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP g) {
+  __shared__ __attribute__((aligned(16))) double As[2][GBK][GLS];
+  __shared__ __attribute__((aligned(16))) double Bs[2][GBK][GLS];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // batch fastest: blocks of one trial share an XCD (id % 8 == slot % 8 when nbatch % 8 == 0)
+  const int bid = blockIdx.x;
+  const int b = bid % g.nbatch;
+  const int tile = bid / g.nbatch;
+  int ti, tj;
+  gemm_decode_tile(g, tile, ti, tj);
+  const long long slot = g.slots ? g.slots[b] : b;
+  const double* A = g.A + slot * g.sA;
+  const double* B = g.B + slot * g.sB;
+  double* C = g.C + slot * g.sC;   // may alias A (in-place TRSM): no restrict
+
+  const int i0 = ti * GBM, j0 = tj * GBN;
+  int kb = 0, ke = g.K;
+  if (g.kflags & KF_BEGIN_ROW) kb = i0;
+  if (g.kflags & KF_BEGIN_MAXRC) kb = (i0 > j0 ? i0 : j0);
+  if (g.kflags & KF_END_ROW) ke = (i0 + GBM < g.K ? i0 + GBM : g.K);
+  if (kb > ke) kb = ke;
+
+  const bool a_vec = ((((size_t)A) & 15) == 0) && ((g.lda & 1) == 0);
+  const bool b_vec = ((((size_t)B) & 15) == 0) && ((g.ldb & 1) == 0);
+
+  // staging registers: 4 x double2 per operand per thread
+  double ra[8], rb[8];
+
+  auto load_tiles = [&](int k0) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int u = tid + 256 * s;
+      {  // A: [k][row] ; unit -> k = u>>6, rows 2*(u&63), +1
+        const int k = u >> 6, r2 = (u & 63) * 2;
+        const double* src = A + (size_t)(k0 + k) * g.lda + (i0 + r2);
+        if (a_vec) {
+          const double2 v = *reinterpret_cast<const double2*>(src);
+          ra[2 * s] = v.x; ra[2 * s + 1] = v.y;
+        } else {
+          ra[2 * s] = src[0]; ra[2 * s + 1] = src[1];
+        }
+      }
+      if (TRANSB == 0) {
+        const int k = u >> 6, r2 = (u & 63) * 2;
+        const double* src = B + (size_t)(k0 + k) * g.ldb + (j0 + r2);
+        if (b_vec) {
+          const double2 v = *reinterpret_cast<const double2*>(src);
+          rb[2 * s] = v.x; rb[2 * s + 1] = v.y;
+        } else {
+          rb[2 * s] = src[0]; rb[2 * s + 1] = src[1];
+        }
+      } else {  // B is K x N: unit -> n = u&127, k pair = u>>7
+        const int nn = u & 127, k2 = (u >> 7) * 2;
+        const double* src = B + (size_t)(j0 + nn) * g.ldb + (k0 + k2);
+        if (b_vec) {
+          const double2 v = *reinterpret_cast<const double2*>(src);
+          rb[2 * s] = v.x; rb[2 * s + 1] = v.y;
+        } else {
+          rb[2 * s] = src[0]; rb[2 * s + 1] = src[1];
+        }
+      }
+    }
+  };
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int u = tid + 256 * s;
+      {
+        const int k = u >> 6, r2 = (u & 63) * 2;
+        *reinterpret_cast<double2*>(&As[buf][k][r2]) = make_double2(ra[2 * s], ra[2 * s + 1]);
+      }
+      if (TRANSB == 0) {
+        const int k = u >> 6, r2 = (u & 63) * 2;
+        *reinterpret_cast<double2*>(&Bs[buf][k][r2]) = make_double2(rb[2 * s], rb[2 * s + 1]);
+      } else {
+        const int nn = u & 127, k2 = (u >> 7) * 2;
+        Bs[buf][k2][nn] = rb[2 * s];
+        Bs[buf][k2 + 1][nn] = rb[2 * s + 1];
+      }
+    }
+  };
+
+  double4_t acc[4][4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+  // a wave whose 64x64 sub-tile lies entirely outside C still stages and syncs, but skips MFMAs
+  const bool wave_live = (i0 + wm * 64 < g.M) && (j0 + wn * 64 < g.N) &&
+                         !((g.mode == GEMM_LOWER) && (i0 + wm * 64 + 63 < j0 + wn * 64));
+
+  const int nk = (ke - kb) / GBK;
+  if (nk > 0) {
+    load_tiles(kb);
+    store_tiles(0);
+  }
+  __syncthreads();
+  const int l15 = lane & 15, l4 = lane >> 4;
+  for (int it = 0; it < nk; ++it) {
+    const int buf = it & 1;
+    if (it + 1 < nk) load_tiles(kb + (it + 1) * GBK);
+    if (wave_live) {
+#pragma unroll
+      for (int kk = 0; kk < GBK; kk += 4) {
+        double af[4], bf[4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) af[mi] = As[buf][kk + l4][wm * 64 + mi * 16 + l15];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) bf[ni] = Bs[buf][kk + l4][wn * 64 + ni * 16 + l15];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[ni], af[mi], acc[mi][ni], 0, 0, 0);
+      }
+    }
+    if (it + 1 < nk) store_tiles(buf ^ 1);
+    __syncthreads();
+  }
+
+  if (!wave_live) return;
+  // D[row = l4 + 4r][col = l15]: row <-> j (B index), col <-> i (A index)
+  const bool mask_diag = (g.kflags & KF_MASK_DIAG) && (ti == tj);
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int i = i0 + wm * 64 + mi * 16 + l15;
+    if (i >= g.M) continue;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = j0 + wn * 64 + ni * 16 + l4 + 4 * r;
+        if (j >= g.N) continue;
+        if (mask_diag && i < j) continue;
+        double* dst = C + (size_t)j * g.ldc + i;
+        double v = g.alpha * acc[mi][ni][r];
+        if (g.beta != 0.0) v += g.beta * (*dst);
+        *dst = v;
+      }
+    }
+  }
+}
+
+// Scalar check kernel: one thread per C element, same argument struct and masks.  Used only to
+// validate the MFMA path (option use_mfma = 0); never the default.
+template <int TRANSB>
+__global__ void gemm_check_kernel(GemmP g) {
+  const int bid = blockIdx.x;
+  const int b = bid % g.nbatch;
+  const int tile = bid / g.nbatch;
+  int ti, tj;
+  gemm_decode_tile(g, tile, ti, tj);
+  const long long slot = g.slots ? g.slots[b] : b;
+  const double* A = g.A + slot * g.sA;
+  const double* B = g.B + slot * g.sB;
+  double* C = g.C + slot * g.sC;
+  const int i0 = ti * GBM, j0 = tj * GBN;
+  int kb = 0, ke = g.K;
+  if (g.kflags & KF_BEGIN_ROW) kb = i0;
+  if (g.kflags & KF_BEGIN_MAXRC) kb = (i0 > j0 ? i0 : j0);
+  if (g.kflags & KF_END_ROW) ke = (i0 + GBM < g.K ? i0 + GBM : g.K);
+  const bool mask_diag = (g.kflags & KF_MASK_DIAG) && (ti == tj);
+  for (int e = threadIdx.x; e < GBM * GBN; e += blockDim.x) {
+    const int i = i0 + (e % GBM), j = j0 + (e / GBM);
+    if (i >= g.M || j >= g.N) continue;
+    if (mask_diag && i < j) continue;
+    if (g.mode == GEMM_LOWER && (i / 64) * 64 + 63 < (j / 64) * 64) continue;
+    double s = 0.0;
+    for (int k = kb; k < ke; ++k) {
+      const double a = A[(size_t)k * g.lda + i];
+      const double bb = TRANSB ? B[(size_t)j * g.ldb + k] : B[(size_t)k * g.ldb + j];
+      s += a * bb;
+    }
+    double* dst = C + (size_t)j * g.ldc + i;
+    double v = g.alpha * s;
+    if (g.beta != 0.0) v += g.beta * (*dst);
+    *dst = v;
+  }
+}
+
+inline int gemm_count_tiles(int mode, int tilesM, int tilesN) {
+  if (mode == GEMM_FULL) return tilesM * tilesN;
+  int n = 0;
+  for (int tj = 0; tj < tilesN && tj < tilesM; ++tj) n += tilesM - tj;
+  return n;
+}
+
+// Host launcher.  K, and every k range implied by kflags, must be a multiple of 16.
+inline hipError_t gemm_launch(hipStream_t st, bool use_mfma, bool transb, GemmP g) {
+  g.tilesM = (g.M + GBM - 1) / GBM;
+  g.tilesN = (g.N + GBN - 1) / GBN;
+  g.ntiles = gemm_count_tiles(g.mode, g.tilesM, g.tilesN);
+  if (g.ntiles <= 0 || g.nbatch <= 0 || g.M <= 0 || g.N <= 0) return hipSuccess;
+  const long long blocks = (long long)g.ntiles * g.nbatch;
+  dim3 grid((unsigned)blocks);
+  if (use_mfma) {
+    if (transb) hipLaunchKernelGGL(gemm_mfma_kernel<1>, grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL(gemm_mfma_kernel<0>, grid, dim3(256), 0, st, g);
+  } else {
+    if (transb) hipLaunchKernelGGL(gemm_check_kernel<1>, grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL(gemm_check_kernel<0>, grid, dim3(256), 0, st, g);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace pgpfa

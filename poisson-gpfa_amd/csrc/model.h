@@ -1,0 +1,601 @@
+// Model-specific streaming kernels of the Poisson-GPFA EM hot path (gfx950).
+// Each kernel cites the reference expression it evaluates (file:line under the reference tree).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pgpfa {
+
+// --------------------------------------------------------------------------------------------------
+// Gram matrices.  util.makeK_big util.py:599-619:
+//   K[k][i][j] = (1-eps) * exp(-0.5 * ((i*bin - j*bin)^2 / (tau_k*1000)^2)) + eps*[i==j]
+// written into a (Tp x Tp) slab per latent with identity padding (rows/cols >= T).
+// --------------------------------------------------------------------------------------------------
+__global__ void gram_tau_kernel(double* __restrict__ K, int Tp, int T, const double* __restrict__ tau, double bin, double eps) {
+  const int k = blockIdx.y;
+  const int j = blockIdx.x;
+  double* Kk = K + (size_t)k * Tp * Tp + (size_t)j * Tp;
+  const double den = (tau[k] * 1000.0) * (tau[k] * 1000.0);
+  for (int i = threadIdx.x; i < Tp; i += blockDim.x) {
+    double v;
+    if (i < T && j < T) {
+      const double dt = (double)i * bin - (double)j * bin;
+      v = (1.0 - eps) * exp(-0.5 * ((dt * dt) / den));
+      if (i == j) v += eps;
+    } else {
+      v = (i == j) ? 1.0 : 0.0;
+    }
+    Kk[i] = v;
+  }
+}
+
+// learning.MStepGPtimescaleCost learning.py:183-185 (gamma = exp(p), lags in bins):
+//   temp = (1-eps)*exp(-exp(p)/2 * difSq) ; K = temp + eps*I ; dKdgamma = -0.5*temp*difSq
+__global__ void gram_gamma_kernel(double* __restrict__ K, double* __restrict__ M, int Tp, int T, double logp, double eps) {
+  const int j = blockIdx.x;
+  const double g = exp(logp);
+  for (int i = threadIdx.x; i < Tp; i += blockDim.x) {
+    double kv, mv;
+    if (i < T && j < T) {
+      const double dd = (double)(i - j);
+      const double dsq = dd * dd;
+      const double temp = (1.0 - eps) * exp(-g / 2.0 * dsq);
+      kv = temp + (i == j ? eps : 0.0);
+      mv = -0.5 * temp * dsq;
+    } else {
+      kv = (i == j) ? 1.0 : 0.0;
+      mv = 0.0;
+    }
+    K[(size_t)j * Tp + i] = kv;
+    M[(size_t)j * Tp + i] = mv;
+  }
+}
+
+// copy the lower triangle onto the upper one (slab of size n, ld)
+__global__ void symmetrize_kernel(double* __restrict__ A, long long sA, int ld, int n) {
+  double* a = A + (size_t)blockIdx.y * sA;
+  const int j = blockIdx.x;
+  for (int i = j + 1 + threadIdx.x; i < n; i += blockDim.x) a[(size_t)i * ld + j] = a[(size_t)j * ld + i];
+}
+
+// sum_i log(diag(L)) * 2 for one slab
+__global__ void logdet_kernel(const double* __restrict__ L, int ld, int n, double* __restrict__ out) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += log(L[(size_t)i * ld + i]);
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = 2.0 * red[0];
+}
+
+// deterministic two-stage dot product of two equally laid out arrays: part[blockIdx.x]
+__global__ void dot_part_kernel(const double* __restrict__ A, const double* __restrict__ B, long long n, double* __restrict__ part) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) s += A[i] * B[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+__global__ void sum_part_kernel(const double* __restrict__ part, int n, double* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += part[i];
+    out[0] = s;
+  }
+}
+
+// --------------------------------------------------------------------------------------------------
+// Poisson likelihood pass (inference.py:22-26, 38-43, 56-63 in structured form), per trial:
+//   h = C X + d ; e = exp(h) ; f_lik = sum(e - y*h) ; G = C^T (e - y)  (p x T)
+//   W[t] = C^T diag(e[:,t]) C  (p x p per bin)
+// Block = 64 bins (lanes) x KY latents.  Phase A: the block's threads share out a chunk of 32
+// neurons and leave e and e-y in LDS; phase B: thread (t,k) accumulates G[k][t] and row k of W[t]
+// with wave-uniform (scalar) reads of C.  Spike counts are read as packed uint8, coalesced over t.
+// --------------------------------------------------------------------------------------------------
+struct PoissonArgs {
+  const uint8_t* Y;      // [R][q][T]
+  const double* C;       // [q][p]
+  const double* d;       // [q]
+  const double* X; long long sX;   // per slot [p][T]
+  double* G; long long sG;         // per slot [p][T] (likelihood part)
+  double* W; long long sW;         // per slot [T][p][p]
+  double* fpart;                   // [slot][ntile]
+  const int* slots;                // list of slots to process
+  const int* trial_of_slot;
+  int q, p, T, ntile, full;
+};
+
+constexpr int PNC = 32;
+
+template <int PMAX>
+__global__ void poisson_pass_kernel(PoissonArgs a) {
+  constexpr int NK = (PMAX > 16) ? 2 : 1;
+  __shared__ double E[PNC][64];
+  __shared__ double Rr[PNC][64];
+  __shared__ double xs[PMAX][64];
+  __shared__ double fred[16];
+  const int tx = threadIdx.x, ty = threadIdx.y, KY = blockDim.y;
+  const int slot = a.slots[blockIdx.y];
+  const int trial = a.trial_of_slot[slot];
+  const int t = blockIdx.x * 64 + tx;
+  const bool valid = t < a.T;
+  const int p = a.p, q = a.q, T = a.T;
+  const double* X = a.X + (size_t)slot * a.sX;
+  const uint8_t* Y = a.Y + (size_t)trial * q * T;
+
+  for (int l = ty; l < p; l += KY) xs[l][tx] = valid ? X[(size_t)l * T + t] : 0.0;
+  __syncthreads();
+
+  double g[NK];
+  double w[NK][PMAX];
+#pragma unroll
+  for (int j = 0; j < NK; ++j) {
+    g[j] = 0.0;
+#pragma unroll
+    for (int l = 0; l < PMAX; ++l) w[j][l] = 0.0;
+  }
+  double facc = 0.0;
+
+  for (int n0 = 0; n0 < q; n0 += PNC) {
+    for (int nn = ty; nn < PNC; nn += KY) {
+      const int n = n0 + nn;
+      double e = 0.0, r = 0.0;
+      if (n < q && valid) {
+        double h = a.d[n];
+        const double* Cn = a.C + (size_t)n * p;
+        for (int l = 0; l < p; ++l) h += Cn[l] * xs[l][tx];
+        e = exp(h);
+        const double y = (double)Y[(size_t)n * T + t];
+        r = e - y;
+        facc += e - y * h;
+      }
+      E[nn][tx] = e;
+      Rr[nn][tx] = r;
+    }
+    __syncthreads();
+    if (a.full) {
+#pragma unroll
+      for (int j = 0; j < NK; ++j) {
+        const int k = __builtin_amdgcn_readfirstlane(ty + j * KY);
+        if (k < p) {
+          const int nmax = (q - n0 < PNC) ? q - n0 : PNC;
+          for (int nn = 0; nn < nmax; ++nn) {
+            const double* Cn = a.C + (size_t)(n0 + nn) * p;
+            const double cnk = Cn[k];
+            g[j] += cnk * Rr[nn][tx];
+            const double ce = cnk * E[nn][tx];
+#pragma unroll
+            for (int l = 0; l < PMAX; ++l)
+              if (l <= k) w[j][l] += ce * Cn[l];
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  if (a.full && valid) {
+    double* G = a.G + (size_t)slot * a.sG;
+    double* W = a.W + (size_t)slot * a.sW + (size_t)t * p * p;
+#pragma unroll
+    for (int j = 0; j < NK; ++j) {
+      const int k = ty + j * KY;
+      if (k < p) {
+        G[(size_t)k * T + t] = g[j];
+#pragma unroll
+        for (int l = 0; l < PMAX; ++l)
+          if (l <= k) {
+            W[k * p + l] = w[j][l];
+            W[l * p + k] = w[j][l];
+          }
+      }
+    }
+  }
+  // deterministic block reduction of the objective partial: lanes, then waves in order
+  for (int off = 32; off > 0; off >>= 1) facc += __shfl_down(facc, off);
+  if (tx == 0) fred[ty] = facc;
+  __syncthreads();
+  if (tx == 0 && ty == 0) {
+    double s = 0.0;
+    for (int i = 0; i < KY; ++i) s += fred[i];
+    a.fpart[(size_t)slot * a.ntile + blockIdx.x] = s;
+  }
+}
+
+// flik[slot] = sum_tile fpart[slot][tile]
+__global__ void sum_tiles_kernel(const double* __restrict__ fpart, int ntile, const int* __restrict__ slots, int nslots, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nslots) return;
+  const int slot = slots[i];
+  double s = 0.0;
+  for (int b = 0; b < ntile; ++b) s += fpart[(size_t)slot * ntile + b];
+  out[slot] = s;
+}
+
+// --------------------------------------------------------------------------------------------------
+// Prior mat-vec: out[slot][k][t] = sum_s Kinv[k][t][s] * in[slot][k][s]   (K^-1 x, inference.py:27,44)
+// Kinv slabs are (Tp x Tp) symmetric; the read runs down a column so lanes (t) are contiguous.
+// grid = (p, nslots), block = 256.
+// --------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void prior_matvec_kernel(const double* __restrict__ Kinv, int Tp, int T, int p,
+                                                            const double* __restrict__ in, long long sIn,
+                                                            double* __restrict__ out, long long sOut,
+                                                            const int* __restrict__ slots) {
+  extern __shared__ double xin[];
+  const int k = blockIdx.x;
+  const int slot = slots[blockIdx.y];
+  const double* x = in + (size_t)slot * sIn + (size_t)k * T;
+  for (int s = threadIdx.x; s < T; s += 256) xin[s] = x[s];
+  __syncthreads();
+  const double* Kk = Kinv + (size_t)k * Tp * Tp;
+  for (int t = threadIdx.x; t < T; t += 256) {
+    double acc = 0.0;
+    for (int s = 0; s < T; ++s) acc += Kk[(size_t)s * Tp + t] * xin[s];
+    out[(size_t)slot * sOut + (size_t)k * T + t] = acc;
+  }
+}
+
+// three dot products per slot: r[slot] = {a.b, c.b', c.d'} -> used for x^T K^-1 x, delta^T K^-1 x, delta^T K^-1 delta
+__global__ __launch_bounds__(256) void dots3_kernel(const double* __restrict__ X, long long sX, const double* __restrict__ KX, long long sKX,
+                                                     const double* __restrict__ D, long long sD, const double* __restrict__ KD, long long sKD,
+                                                     int n, const int* __restrict__ slots, double* __restrict__ qxx, double* __restrict__ qdx,
+                                                     double* __restrict__ qdd) {
+  __shared__ double red[3][4];
+  const int slot = slots[blockIdx.x];
+  const double* x = X + (size_t)slot * sX;
+  const double* kx = KX + (size_t)slot * sKX;
+  const double* dd = D ? D + (size_t)slot * sD : nullptr;
+  const double* kd = KD ? KD + (size_t)slot * sKD : nullptr;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    s0 += x[i] * kx[i];
+    if (dd) { s1 += dd[i] * kx[i]; s2 += dd[i] * kd[i]; }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    s0 += __shfl_down(s0, off); s1 += __shfl_down(s1, off); s2 += __shfl_down(s2, off);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { red[0][wave] = s0; red[1][wave] = s1; red[2][wave] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    qxx[slot] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    if (dd) {
+      qdx[slot] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+      qdd[slot] = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+    }
+  }
+}
+
+// total gradient for the solve: Gt[slot][i] = Gl[slot][i] + KX[slot][i]
+__global__ void grad_total_kernel(const double* __restrict__ Gl, long long sG, const double* __restrict__ KX, long long sKX,
+                                  double* __restrict__ Gt, long long sGt, int n, const int* __restrict__ slots) {
+  const int slot = slots[blockIdx.y];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) Gt[(size_t)slot * sGt + i] = Gl[(size_t)slot * sG + i] + KX[(size_t)slot * sKX + i];
+}
+
+// Xt = X + alpha[slot] * delta
+__global__ void make_try_kernel(const double* __restrict__ X, long long sX, const double* __restrict__ D, long long sD,
+                                const double* __restrict__ alpha, double* __restrict__ Xt, long long sXt, int n,
+                                const int* __restrict__ slots) {
+  const int slot = slots[blockIdx.y];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) Xt[(size_t)slot * sXt + i] = X[(size_t)slot * sX + i] + alpha[slot] * D[(size_t)slot * sD + i];
+}
+
+// accepted slots: X <- Xt ; KX <- KX + alpha*KD ; Gl <- Glt ; W <- Wt
+__global__ void commit_kernel(double* __restrict__ X, const double* __restrict__ Xt, double* __restrict__ KX,
+                              const double* __restrict__ KD, double* __restrict__ Gl, const double* __restrict__ Glt,
+                              long long sV, double* __restrict__ W, const double* __restrict__ Wt, long long sW,
+                              const double* __restrict__ alpha, int n, int nw, const int* __restrict__ slots) {
+  const size_t slot = slots[blockIdx.y];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    X[slot * sV + i] = Xt[slot * sV + i];
+    KX[slot * sV + i] += alpha[slot] * KD[slot * sV + i];
+    Gl[slot * sV + i] = Glt[slot * sV + i];
+  }
+  for (int j = i; j < nw; j += gridDim.x * blockDim.x) W[slot * sW + j] = Wt[slot * sW + j];
+}
+
+// --------------------------------------------------------------------------------------------------
+// Hessian assembly (inference.py:50-65, structured): lower triangle of
+//   H[(k,t),(l,s)] = [k==l] Kinv[k][t][s] + [t==s] W[t][k][l]     (latent-major index i = k*T + t)
+// plus identity padding for rows/cols >= n.  grid = (npad, nslots): one block per column.
+// --------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void assemble_h_kernel(double* __restrict__ H, long long sH, int ld, int npad, int n, int T, int Tp, int p,
+                                                          const double* __restrict__ Kinv, const double* __restrict__ W, long long sW,
+                                                          const int* __restrict__ slots) {
+  const int j = blockIdx.x;
+  const size_t slot = slots[blockIdx.y];
+  double* col = H + slot * sH + (size_t)j * ld;
+  if (j >= n) {
+    for (int i = j + threadIdx.x; i < npad; i += 256) col[i] = (i == j) ? 1.0 : 0.0;
+    return;
+  }
+  const int kj = j / T, tj = j - kj * T;
+  const double* Kcol = Kinv + (size_t)kj * Tp * Tp + (size_t)tj * Tp;   // Kinv[kj][:, tj] (symmetric)
+  const double* Wt = W + slot * sW + (size_t)tj * p * p;
+  for (int i = j + threadIdx.x; i < npad; i += 256) {
+    double v = 0.0;
+    if (i < n) {
+      const int ki = i / T, ti = i - ki * T;
+      if (ki == kj) v = Kcol[ti];
+      if (ti == tj) v += Wt[ki * p + kj];
+    }
+    col[i] = v;
+  }
+}
+
+// dense symmetric H (n x n, row-major == column-major) for one slot -> host-visible buffer (a6 getter)
+__global__ void dense_h_kernel(double* __restrict__ out, int n, int T, int Tp, int p, const double* __restrict__ Kinv,
+                               const double* __restrict__ W) {
+  const int j = blockIdx.x;
+  const int kj = j / T, tj = j - kj * T;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int ki = i / T, ti = i - ki * T;
+    double v = 0.0;
+    if (ki == kj) v = Kinv[(size_t)kj * Tp * Tp + (size_t)tj * Tp + ti];
+    if (ti == tj) v += W[(size_t)tj * p * p + ki * p + kj];
+    out[(size_t)j * n + i] = v;
+  }
+}
+
+// --------------------------------------------------------------------------------------------------
+// post_vsm (inference.py:169-172): vsm[t][k][l] = Sigma[(k,t),(l,t)] = sum_i Mt[(k,t), i] Mt[(l,t), i]
+// with Mt = L^-T (upper triangular).  Block = 64 bins x KY latents, columns i streamed in chunks of 16
+// through LDS; output indexed by trial.
+// --------------------------------------------------------------------------------------------------
+template <int PMAX>
+__global__ void post_vsm_kernel(const double* __restrict__ Mt, long long sM, int ld, int npad, int T, int p,
+                                double* __restrict__ vsm, const int* __restrict__ slots, const int* __restrict__ trial_of_slot) {
+  constexpr int NK = (PMAX > 16) ? 2 : 1;
+  constexpr int VIC = (PMAX <= 8) ? 16 : (PMAX <= 16 ? 8 : 4);   // 64 KB of LDS at most
+  __shared__ double A[VIC][PMAX][64];
+  const int tx = threadIdx.x, ty = threadIdx.y, KY = blockDim.y;
+  const int slot = slots[blockIdx.y];
+  const int trial = trial_of_slot[slot];
+  const int t0 = blockIdx.x * 64;
+  const int t = t0 + tx;
+  const bool valid = t < T;
+  const double* M = Mt + (size_t)slot * sM;
+  double acc[NK][PMAX];
+#pragma unroll
+  for (int j = 0; j < NK; ++j)
+#pragma unroll
+    for (int l = 0; l < PMAX; ++l) acc[j][l] = 0.0;
+
+  const int istart = (t0 / VIC) * VIC;          // row (0,t0) is the first with entries at column t0
+  for (int i0 = istart; i0 < npad; i0 += VIC) {
+#pragma unroll
+    for (int j = 0; j < NK; ++j) {
+      const int k = ty + j * KY;
+      if (k < p) {
+        const int row = k * T + t;
+#pragma unroll
+        for (int ii = 0; ii < VIC; ++ii) A[ii][k][tx] = valid ? M[(size_t)(i0 + ii) * ld + row] : 0.0;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NK; ++j) {
+      const int k = ty + j * KY;
+      if (k < p) {
+#pragma unroll
+        for (int ii = 0; ii < VIC; ++ii) {
+          const double ak = A[ii][k][tx];
+#pragma unroll
+          for (int l = 0; l < PMAX; ++l)
+            if (l <= k) acc[j][l] += ak * A[ii][l][tx];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (valid) {
+    double* out = vsm + ((size_t)trial * T + t) * p * p;
+#pragma unroll
+    for (int j = 0; j < NK; ++j) {
+      const int k = ty + j * KY;
+      if (k < p) {
+#pragma unroll
+        for (int l = 0; l < PMAX; ++l)
+          if (l <= k) { out[k * p + l] = acc[j][l]; out[l * p + k] = acc[j][l]; }
+      }
+    }
+  }
+}
+
+// (T,T,p) reference layout of post_vsmGP (inference.py:164-167) from the device layout [p][T][T]
+__global__ void vsmgp_to_ref_kernel(const double* __restrict__ src, double* __restrict__ dst, int T, int p) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t tot = (size_t)T * T * p;
+  if (e >= tot) return;
+  const int k = e % p;
+  const size_t ab = e / p;          // a*T + b
+  dst[e] = src[(size_t)k * T * T + ab];
+}
+__global__ void vsmgp_from_ref_kernel(const double* __restrict__ src, double* __restrict__ dst, int T, int p) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t tot = (size_t)T * T * p;
+  if (e >= tot) return;
+  const int k = e % p;
+  const size_t ab = e / p;
+  dst[(size_t)k * T * T + ab] = src[e];
+}
+
+// learning.makePrecomp learning.py:162-166: PautoSum[k] = sum_r (Sigma_r^{kk} + m_rk m_rk^T), into (Tp x Tp) slabs
+__global__ void pautosum_kernel(const double* __restrict__ vsmgp, const double* __restrict__ mean, const int* __restrict__ trials,
+                                int ntr, int T, int Tp, int p, double* __restrict__ P) {
+  const int k = blockIdx.y;
+  const int b = blockIdx.x;               // column
+  for (int a = threadIdx.x; a < Tp; a += blockDim.x) {
+    double s = 0.0;
+    if (a < T && b < T) {
+      for (int i = 0; i < ntr; ++i) {
+        const size_t r = trials[i];
+        const double* m = mean + (r * p + k) * T;
+        s += vsmgp[((r * p + k) * T + b) * T + a] + m[a] * m[b];
+      }
+    }
+    P[(size_t)k * Tp * Tp + (size_t)b * Tp + a] = s;
+  }
+}
+
+// --------------------------------------------------------------------------------------------------
+// (C,d) M-step pass, learning.MStepObservationCost(_grad) learning.py:20-91:
+//   hh = c_n.m_t + d_n ; rho = c_n^T V_t c_n ; yhat = exp(hh + rho/2)
+//   cost_n = sum (y*hh - yhat) ; dd_n = sum (y - yhat) ; dC_n = sum (y - yhat) m_t - yhat V_t c_n
+// Lanes are NEURONS, so every per-neuron sum stays in one thread's registers (no cross-lane
+// reduction); m_t and V_t are wave-uniform and arrive through scalar loads.  Work items are
+// (trial, 32-bin tile); partial sums per block are reduced in a fixed order afterwards.
+// --------------------------------------------------------------------------------------------------
+struct CdArgs {
+  const uint8_t* Y; const double* mean; const double* vsm; const double* vec;   // vecCd
+  const int* trials; int ntr;
+  double* part;          // [gridDim.y][p+2][q]
+  int q, p, T, ntt;      // ntt = tiles per trial
+};
+constexpr int CTT = 32;
+
+template <int PMAX>
+__global__ void mstep_cd_kernel(CdArgs a) {
+  constexpr int NK = (PMAX > 16) ? 2 : 1;
+  __shared__ double YH[CTT][64];
+  __shared__ double RS[CTT][64];
+  __shared__ double red[2][16][64];
+  const int lane = threadIdx.x, ty = threadIdx.y, KY = blockDim.y;
+  const int n = blockIdx.x * 64 + lane;
+  const bool live = n < a.q;
+  const int p = a.p, q = a.q, T = a.T;
+  double c[PMAX];
+#pragma unroll
+  for (int l = 0; l < PMAX; ++l) c[l] = (live && l < p) ? a.vec[(size_t)l * q + n] : 0.0;
+  const double dn = live ? a.vec[(size_t)p * q + n] : 0.0;
+  double acc[NK];
+#pragma unroll
+  for (int j = 0; j < NK; ++j) acc[j] = 0.0;
+  double cost = 0.0, dd = 0.0;
+
+  const int nitems = a.ntr * a.ntt;
+  for (int item = blockIdx.y; item < nitems; item += gridDim.y) {
+    const size_t r = a.trials[item / a.ntt];
+    const int t0 = (item % a.ntt) * CTT;
+    const double* mean = a.mean + r * p * T;
+    const double* vsm = a.vsm + r * T * p * p;
+    const uint8_t* Y = a.Y + r * q * T;
+    for (int tt = ty; tt < CTT; tt += KY) {
+      const int t = __builtin_amdgcn_readfirstlane(t0 + tt);
+      double yh = 0.0, rs = 0.0;
+      if (t < T && live) {
+        const double* V = vsm + (size_t)t * p * p;
+        double hh = dn, rho = 0.0;
+        for (int k = 0; k < p; ++k) {
+          double u = 0.0;
+#pragma unroll
+          for (int l = 0; l < PMAX; ++l)
+            if (l < p) u += V[k * p + l] * c[l];
+          double ck = 0.0;
+#pragma unroll
+          for (int l = 0; l < PMAX; ++l)
+            if (l == k) ck = c[l];
+          hh += ck * mean[(size_t)k * T + t];
+          rho += ck * u;
+        }
+        yh = exp(hh + 0.5 * rho);
+        const double y = (double)Y[(size_t)n * T + t];
+        rs = y - yh;
+        cost += y * hh - yh;
+        dd += rs;
+      }
+      YH[tt][lane] = yh;
+      RS[tt][lane] = rs;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NK; ++j) {
+      const int k = __builtin_amdgcn_readfirstlane(ty + j * KY);
+      if (k < p) {
+        const int tmax = (T - t0 < CTT) ? T - t0 : CTT;
+        for (int tt = 0; tt < tmax; ++tt) {
+          const int t = t0 + tt;
+          const double* Vk = vsm + (size_t)t * p * p + (size_t)k * p;
+          double u = 0.0;
+#pragma unroll
+          for (int l = 0; l < PMAX; ++l)
+            if (l < p) u += Vk[l] * c[l];
+          acc[j] += RS[tt][lane] * mean[(size_t)k * T + t] - YH[tt][lane] * u;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // combine cost/dd over ty in a fixed order, write the block's partials
+  red[0][ty][lane] = cost;
+  red[1][ty][lane] = dd;
+  __syncthreads();
+  double* part = a.part + (size_t)blockIdx.y * (p + 2) * q;
+  if (live) {
+#pragma unroll
+    for (int j = 0; j < NK; ++j) {
+      const int k = ty + j * KY;
+      if (k < p) part[(size_t)k * q + n] = acc[j];
+    }
+    if (ty == 0) {
+      double sc = 0.0, sd = 0.0;
+      for (int i = 0; i < KY; ++i) { sc += red[0][i][lane]; sd += red[1][i][lane]; }
+      part[(size_t)p * q + n] = sd;
+      part[(size_t)(p + 1) * q + n] = sc;
+    }
+  }
+}
+
+// out[e] = sum_b part[b][e]
+__global__ void reduce_parts_kernel(const double* __restrict__ part, int nb, int len, double* __restrict__ out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= len) return;
+  double s = 0.0;
+  for (int b = 0; b < nb; ++b) s += part[(size_t)b * len + e];
+  out[e] = s;
+}
+
+// counts: double [R][q][T] -> uint8 with validation (non-negative integers <= 255)
+__global__ void pack_counts_kernel(const double* __restrict__ src, uint8_t* __restrict__ dst, size_t n, int* __restrict__ bad) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double v = src[i];
+  if (!(v >= 0.0) || v > 255.0 || v != floor(v)) { atomicExch(bad, 1); dst[i] = 0; return; }
+  dst[i] = (uint8_t)v;
+}
+
+__global__ void fill_kernel(double* __restrict__ p, size_t n, double v) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+// gather / scatter of per-trial vectors between persistent [R][len] storage and slot storage [B][stride]
+__global__ void gather_rows_kernel(const double* __restrict__ src, int len, double* __restrict__ dst, long long sDst,
+                                   const int* __restrict__ trial_of_slot, int zero) {
+  const int slot = blockIdx.y;
+  const size_t r = trial_of_slot[slot];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < len) dst[(size_t)slot * sDst + i] = zero ? 0.0 : src[r * len + i];
+}
+__global__ void scatter_rows_kernel(const double* __restrict__ src, long long sSrc, int len, double* __restrict__ dst,
+                                    const int* __restrict__ trial_of_slot) {
+  const int slot = blockIdx.y;
+  const size_t r = trial_of_slot[slot];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < len) dst[r * len + i] = src[(size_t)slot * sSrc + i];
+}
+
+}  // namespace pgpfa

@@ -1,0 +1,1218 @@
+// libpgpfa_hip.so - C-ABI (include/pgpfa.h) + host-side orchestration of the HIP kernels.
+// One context = one GPU = one stream.  All heavy state (counts, modes, posterior blocks,
+// factor slabs) stays resident in HBM between calls.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "../../include/pgpfa.h"
+#include "chol.h"
+#include "gemm.h"
+#include "model.h"
+
+using namespace pgpfa;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return 1;
+}
+
+#define HIPC(expr)                                                                         \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess) return fail("%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+  } while (0)
+#define CHK(expr)            \
+  do {                       \
+    int _r = (expr);         \
+    if (_r != 0) return _r;  \
+  } while (0)
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+struct Prof {
+  bool on = false;
+  std::vector<hipEvent_t> pool;
+  size_t used = 0;
+  struct Rec { int tag; size_t e0, e1; double flops; };
+  std::vector<Rec> recs;
+  std::map<int, double> ms, flops, count;
+};
+enum { TAG_GEMM = 0, TAG_POTRF = 1, TAG_SOLVE = 2, TAG_POISSON = 3, TAG_ASSEMBLE = 4, TAG_VSM = 5, TAG_CD = 6, TAG_N };
+
+}  // namespace
+
+struct pgpfa_ctx {
+  int device = 0, q = 0, p = 0, T = 0, R = 0, n = 0, npad = 0, ld = 0, Tp = 0;
+  double bin = 10.0, eps = 1e-3;
+  hipStream_t st = nullptr;
+  // options
+  double xtol = 1e-5;
+  int max_iter = 50;
+  bool mfma = true;
+  int chunk_opt = 0;
+  // persistent device state
+  uint8_t* Y = nullptr;
+  double *C = nullptr, *d = nullptr, *tau = nullptr;
+  double *Kpad = nullptr, *Kinv = nullptr;      // [p][Tp][Tp]
+  double* Xmode = nullptr;                       // [R][p][T]   post_mean / warm start
+  double* vsm = nullptr;                         // [R][T][p][p]
+  double* vsmgp = nullptr;                       // [R][p][T][T]
+  double* Pauto = nullptr;                       // [p][Tp][Tp]
+  double *vec = nullptr, *cdpart = nullptr, *cdout = nullptr;
+  int* last_trials = nullptr;                    // device list of the trials of the last E-step
+  std::vector<int> last_trials_h;
+  bool have_counts = false, have_params = false, have_post = false, have_precomp = false;
+  double n_trials_global = 0.0;
+  // chunk workspace
+  int B = 0;
+  CholWS ws{};
+  double *Xc = nullptr, *Xt = nullptr, *KX = nullptr, *KD = nullptr, *Gl = nullptr, *Glt = nullptr, *Gt = nullptr, *Dl = nullptr;
+  double *W = nullptr, *Wt = nullptr, *fpart = nullptr;
+  double *sc_f = nullptr, *sc_qxx = nullptr, *sc_qdx = nullptr, *sc_qdd = nullptr, *sc_dec = nullptr, *sc_smax = nullptr, *sc_alpha = nullptr;
+  int *trial_of_slot = nullptr, *list_a = nullptr, *list_b = nullptr, *ident = nullptr;
+  // small workspace for the T x T systems (Kinv, tau M-step): p slots of Tp
+  CholWS kws{};
+  double *tK = nullptr, *tM = nullptr, *tA1 = nullptr, *tA2 = nullptr, *tscal = nullptr, *tpart = nullptr;
+  // pinned host staging
+  double* hbuf = nullptr; size_t hbuf_len = 0;
+  int* hibuf = nullptr; size_t hibuf_len = 0;
+  // stats
+  std::map<std::string, double> info;
+  std::vector<void*> allocs;
+  size_t bytes = 0;
+  Prof prof;
+  // comm
+  ncclComm_t comm = nullptr;
+  int rank = 0, nranks = 1;
+  double* commbuf = nullptr; size_t commbuf_len = 0;
+};
+
+namespace {
+
+template <typename T>
+int dmalloc(pgpfa_ctx* c, T** out, size_t count, bool zero = false) {
+  void* p = nullptr;
+  const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess) return fail("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+  if (zero) {
+    e = hipMemsetAsync(p, 0, bytes, c->st);
+    if (e != hipSuccess) return fail("hipMemset failed: %s", hipGetErrorString(e));
+  }
+  c->allocs.push_back(p);
+  c->bytes += bytes;
+  *out = reinterpret_cast<T*>(p);
+  return 0;
+}
+
+int ensure_hbuf(pgpfa_ctx* c, size_t len) {
+  if (len <= c->hbuf_len) return 0;
+  if (c->hbuf) hipHostFree(c->hbuf);
+  c->hbuf = nullptr;
+  HIPC(hipHostMalloc((void**)&c->hbuf, len * sizeof(double)));
+  c->hbuf_len = len;
+  return 0;
+}
+int ensure_hibuf(pgpfa_ctx* c, size_t len) {
+  if (len <= c->hibuf_len) return 0;
+  if (c->hibuf) hipHostFree(c->hibuf);
+  c->hibuf = nullptr;
+  HIPC(hipHostMalloc((void**)&c->hibuf, len * sizeof(int)));
+  c->hibuf_len = len;
+  return 0;
+}
+
+// ---- profiling (HIP events on the context stream; summed on demand) -------------------------------
+void prof_begin(pgpfa_ctx* c, int tag, double flops) {
+  Prof& P = c->prof;
+  if (!P.on) return;
+  while (P.pool.size() < P.used + 2) {
+    hipEvent_t e;
+    hipEventCreate(&e);
+    P.pool.push_back(e);
+  }
+  hipEventRecord(P.pool[P.used], c->st);
+  P.recs.push_back({tag, P.used, P.used + 1, flops});
+  P.used += 2;
+}
+void prof_end(pgpfa_ctx* c) {
+  Prof& P = c->prof;
+  if (!P.on) return;
+  hipEventRecord(P.pool[P.recs.back().e1], c->st);
+}
+void prof_collect(pgpfa_ctx* c) {
+  Prof& P = c->prof;
+  if (!P.on) return;
+  hipStreamSynchronize(c->st);
+  for (auto& r : P.recs) {
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, P.pool[r.e0], P.pool[r.e1]);
+    P.ms[r.tag] += ms;
+    P.flops[r.tag] += r.flops;
+    P.count[r.tag] += 1;
+  }
+  P.recs.clear();
+  P.used = 0;
+}
+
+// algorithmic flops of one GEMM launch (useful multiply-adds x2, triangular structure respected)
+double gemm_flops(const GemmP& g) {
+  const double M = g.M, N = g.N, K = g.K;
+  double per;
+  if (g.mode == GEMM_LOWER) {
+    // trapezoid i >= j, j < N <= M
+    const double elems = N * (M - N) + N * (N + 1) / 2.0;
+    per = 2.0 * K * elems;
+  } else if (g.kflags & KF_BEGIN_ROW) {
+    per = 2.0 * N * (M * K - M * (M - 1) / 2.0);         // row i uses k >= i
+  } else if (g.kflags & KF_BEGIN_MAXRC) {
+    per = 0.0;
+    // sum_{i,j} (K - max(i,j)) : for M == N == K this is ~ K^3/3 * 2
+    const double m = std::min(M, N);
+    per = 2.0 * (M * N * K - (m * (m - 1) * (m + 1) / 3.0 + (M > N ? N * (M - N) * (M + N - 1) / 2.0 : M * (N - M) * (M + N - 1) / 2.0)));
+  } else {
+    per = 2.0 * M * N * K;
+  }
+  return per * g.nbatch;
+}
+
+int gemm(pgpfa_ctx* c, bool transb, GemmP g) {
+  prof_begin(c, TAG_GEMM, gemm_flops(g));
+  hipError_t e = gemm_launch(c->st, c->mfma, transb, g);
+  prof_end(c);
+  if (e != hipSuccess) return fail("gemm launch failed: %s", hipGetErrorString(e));
+  return 0;
+}
+
+// chol_factor / chol_inverse_t with per-launch profiling (same sequence as chol.h's plain versions)
+int factor(pgpfa_ctx* c, const CholWS& w, const int* slots, int nb) {
+  const int np = w.npad, ld = w.ld;
+  for (int c0 = 0; c0 < np; c0 += NSUP) {
+    const int c1 = std::min(c0 + NSUP, np);
+    for (int k0 = c0; k0 < c1; k0 += NB) {
+      prof_begin(c, TAG_POTRF, 2.0 * nb * (double)NB * NB * NB / 3.0);
+      hipLaunchKernelGGL(potrf_diag_kernel, dim3(nb), dim3(512), 0, c->st, w.H, w.sH, ld, k0, w.Dinv, w.sD, slots, w.info);
+      prof_end(c);
+      const int r0 = k0 + NB;
+      if (r0 >= np) break;
+      GemmP g{};
+      g.A = w.H + (size_t)k0 * ld + r0; g.sA = w.sH; g.lda = ld;
+      g.B = w.Dinv + (size_t)(k0 / NB) * NB * NB; g.sB = w.sD; g.ldb = NB;
+      g.C = w.H + (size_t)k0 * ld + r0; g.sC = w.sH; g.ldc = ld;
+      g.M = np - r0; g.N = NB; g.K = NB; g.alpha = 1.0; g.beta = 0.0;
+      g.slots = slots; g.nbatch = nb; g.mode = GEMM_FULL; g.kflags = 0;
+      CHK(gemm(c, false, g));
+      if (r0 < c1) {
+        GemmP s{};
+        s.A = w.H + (size_t)k0 * ld + r0; s.sA = w.sH; s.lda = ld;
+        s.B = s.A; s.sB = w.sH; s.ldb = ld;
+        s.C = w.H + (size_t)r0 * ld + r0; s.sC = w.sH; s.ldc = ld;
+        s.M = np - r0; s.N = c1 - r0; s.K = NB; s.alpha = -1.0; s.beta = 1.0;
+        s.slots = slots; s.nbatch = nb; s.mode = GEMM_LOWER; s.kflags = KF_MASK_DIAG;
+        CHK(gemm(c, false, s));
+      }
+    }
+    if (c1 < np) {
+      GemmP s{};
+      s.A = w.H + (size_t)c0 * ld + c1; s.sA = w.sH; s.lda = ld;
+      s.B = s.A; s.sB = w.sH; s.ldb = ld;
+      s.C = w.H + (size_t)c1 * ld + c1; s.sC = w.sH; s.ldc = ld;
+      s.M = np - c1; s.N = np - c1; s.K = c1 - c0; s.alpha = -1.0; s.beta = 1.0;
+      s.slots = slots; s.nbatch = nb; s.mode = GEMM_LOWER; s.kflags = KF_MASK_DIAG;
+      CHK(gemm(c, false, s));
+    }
+  }
+  HIPC(hipGetLastError());
+  return 0;
+}
+
+int inverse_t(pgpfa_ctx* c, const CholWS& w, const int* slots, int nb) {
+  const int np = w.npad, ld = w.ld;
+  for (int j0 = 0; j0 < np; j0 += NB) {
+    hipLaunchKernelGGL(diag_transpose_kernel, dim3(nb), dim3(256), 0, c->st, w.Mt, w.sM, ld, j0, w.Dinv, w.sD, slots);
+    if (j0 == 0) continue;
+    GemmP a{};
+    a.A = w.Mt; a.sA = w.sM; a.lda = ld;
+    a.B = w.H + j0; a.sB = w.sH; a.ldb = ld;
+    a.C = w.P; a.sC = w.sP; a.ldc = np;
+    a.M = j0; a.N = NB; a.K = j0; a.alpha = 1.0; a.beta = 0.0;
+    a.slots = slots; a.nbatch = nb; a.mode = GEMM_FULL; a.kflags = KF_BEGIN_ROW;
+    CHK(gemm(c, false, a));
+    GemmP b{};
+    b.A = w.P; b.sA = w.sP; b.lda = np;
+    b.B = w.Dinv + (size_t)(j0 / NB) * NB * NB; b.sB = w.sD; b.ldb = NB;
+    b.C = w.Mt + (size_t)j0 * ld; b.sC = w.sM; b.ldc = ld;
+    b.M = j0; b.N = NB; b.K = NB; b.alpha = -1.0; b.beta = 0.0;
+    b.slots = slots; b.nbatch = nb; b.mode = GEMM_FULL; b.kflags = 0;
+    CHK(gemm(c, false, b));
+  }
+  HIPC(hipGetLastError());
+  return 0;
+}
+
+// allocate a factor workspace: nslots slabs of ld x ld (+ Mt), diagonal inverses, scratch panel
+int alloc_cholws(pgpfa_ctx* c, CholWS* w, int nslots, int npad, bool with_mt) {
+  w->npad = npad;
+  w->ld = npad;
+  const size_t slab = (size_t)npad * npad;
+  const size_t slack = (size_t)256 * npad;
+  w->sH = slab; w->sM = slab; w->sD = (size_t)npad * NB; w->sP = (size_t)npad * NB;
+  CHK(dmalloc(c, &w->H, slab * nslots + slack));
+  if (with_mt) CHK(dmalloc(c, &w->Mt, slab * nslots + slack, true)); else w->Mt = nullptr;
+  CHK(dmalloc(c, &w->Dinv, w->sD * nslots + slack));
+  CHK(dmalloc(c, &w->P, w->sP * nslots + slack));
+  CHK(dmalloc(c, &w->info, nslots, true));
+  return 0;
+}
+
+size_t per_slot_bytes(const pgpfa_ctx* c) {
+  const size_t ld = c->ld;
+  size_t dbl = 2 * ld * ld + 2 * ld * NB + 8 * ld + 2 * (size_t)c->T * c->p * c->p + ((c->T + 63) / 64) + 16;
+  return dbl * sizeof(double);
+}
+
+int ensure_workspace(pgpfa_ctx* c) {
+  if (c->B > 0) return 0;
+  size_t free_b = 0, total_b = 0;
+  HIPC(hipMemGetInfo(&free_b, &total_b));
+  const size_t per = per_slot_bytes(c);
+  size_t budget = (size_t)(0.85 * (double)free_b);
+  long long B = (long long)(budget / per);
+  if (c->chunk_opt > 0) B = std::min<long long>(B, c->chunk_opt);
+  B = std::min<long long>(B, c->R);
+  if (B >= 16) B = B / 8 * 8;
+  if (B >= 1) {
+    const long long nchunks = (c->R + B - 1) / B;
+    long long Bb = (c->R + nchunks - 1) / nchunks;
+    if (Bb >= 16) Bb = std::min<long long>(B, (Bb + 7) / 8 * 8);
+    B = Bb;
+  }
+  if (B < 1) return fail("not enough device memory for one trial slab (%zu bytes needed, %zu free)", per, free_b);
+  c->B = (int)B;
+  CHK(alloc_cholws(c, &c->ws, c->B, c->npad, true));
+  const size_t ld = c->ld, nB = c->B;
+  CHK(dmalloc(c, &c->Xc, ld * nB)); CHK(dmalloc(c, &c->Xt, ld * nB));
+  CHK(dmalloc(c, &c->KX, ld * nB)); CHK(dmalloc(c, &c->KD, ld * nB));
+  CHK(dmalloc(c, &c->Gl, ld * nB)); CHK(dmalloc(c, &c->Glt, ld * nB));
+  CHK(dmalloc(c, &c->Gt, ld * nB)); CHK(dmalloc(c, &c->Dl, ld * nB, true));
+  const size_t wlen = (size_t)c->T * c->p * c->p;
+  CHK(dmalloc(c, &c->W, wlen * nB)); CHK(dmalloc(c, &c->Wt, wlen * nB));
+  CHK(dmalloc(c, &c->fpart, (size_t)((c->T + 63) / 64) * nB));
+  CHK(dmalloc(c, &c->sc_f, nB)); CHK(dmalloc(c, &c->sc_qxx, nB)); CHK(dmalloc(c, &c->sc_qdx, nB));
+  CHK(dmalloc(c, &c->sc_qdd, nB)); CHK(dmalloc(c, &c->sc_dec, nB)); CHK(dmalloc(c, &c->sc_smax, nB));
+  CHK(dmalloc(c, &c->sc_alpha, nB));
+  CHK(dmalloc(c, &c->trial_of_slot, nB)); CHK(dmalloc(c, &c->list_a, nB)); CHK(dmalloc(c, &c->list_b, nB));
+  CHK(dmalloc(c, &c->ident, nB));
+  std::vector<int> id(c->B);
+  for (int i = 0; i < c->B; ++i) id[i] = i;
+  HIPC(hipMemcpyAsync(c->ident, id.data(), sizeof(int) * c->B, hipMemcpyHostToDevice, c->st));
+  HIPC(hipStreamSynchronize(c->st));
+  c->info["chunk_trials"] = c->B;
+  return 0;
+}
+
+int upload_list(pgpfa_ctx* c, int* dst, const std::vector<int>& v) {
+  if (v.empty()) return 0;
+  CHK(ensure_hibuf(c, v.size()));
+  // staged through pinned memory; the stream sync in callers orders reuse of the staging buffer
+  std::memcpy(c->hibuf, v.data(), v.size() * sizeof(int));
+  HIPC(hipMemcpyAsync(dst, c->hibuf, v.size() * sizeof(int), hipMemcpyHostToDevice, c->st));
+  HIPC(hipStreamSynchronize(c->st));
+  return 0;
+}
+
+int download(pgpfa_ctx* c, double* host, const double* dev, size_t n) {
+  HIPC(hipMemcpyAsync(host, dev, n * sizeof(double), hipMemcpyDeviceToHost, c->st));
+  HIPC(hipStreamSynchronize(c->st));
+  return 0;
+}
+int upload(pgpfa_ctx* c, double* dev, const double* host, size_t n) {
+  HIPC(hipMemcpyAsync(dev, host, n * sizeof(double), hipMemcpyHostToDevice, c->st));
+  HIPC(hipStreamSynchronize(c->st));
+  return 0;
+}
+
+template <typename F>
+void dispatch_pmax(int p, F&& f) {
+  if (p <= 4) f(std::integral_constant<int, 4>{});
+  else if (p <= 8) f(std::integral_constant<int, 8>{});
+  else if (p <= 16) f(std::integral_constant<int, 16>{});
+  else f(std::integral_constant<int, 32>{});
+}
+
+// Poisson pass over the slots in d_list (nl of them): X source -> G/W destinations, flik per slot
+int poisson(pgpfa_ctx* c, const int* d_list, int nl, const double* X, double* G, double* W, double* flik, int full) {
+  PoissonArgs a{};
+  a.Y = c->Y; a.C = c->C; a.d = c->d;
+  a.X = X; a.sX = c->ld; a.G = G; a.sG = c->ld; a.W = W; a.sW = (long long)c->T * c->p * c->p;
+  a.fpart = c->fpart; a.slots = d_list; a.trial_of_slot = c->trial_of_slot;
+  a.q = c->q; a.p = c->p; a.T = c->T; a.ntile = (c->T + 63) / 64; a.full = full;
+  const int KY = std::min(c->p, 16);
+  dim3 grid(a.ntile, nl), block(64, KY);
+  const double fl = (double)nl * c->q * c->T * (4.0 * c->p + (full ? c->p * (c->p + 1.0) : 0.0));
+  prof_begin(c, TAG_POISSON, fl);
+  dispatch_pmax(c->p, [&](auto pm) { hipLaunchKernelGGL(poisson_pass_kernel<decltype(pm)::value>, grid, block, 0, c->st, a); });
+  prof_end(c);
+  hipLaunchKernelGGL(sum_tiles_kernel, dim3((nl + 255) / 256), dim3(256), 0, c->st, c->fpart, a.ntile, d_list, nl, flik);
+  HIPC(hipGetLastError());
+  return 0;
+}
+
+int prior_mv(pgpfa_ctx* c, const int* d_list, int nl, const double* in, double* out) {
+  hipLaunchKernelGGL(prior_matvec_kernel, dim3(c->p, nl), dim3(256), c->T * sizeof(double), c->st, c->Kinv, c->Tp, c->T, c->p,
+                     in, (long long)c->ld, out, (long long)c->ld, d_list);
+  HIPC(hipGetLastError());
+  return 0;
+}
+
+int assemble(pgpfa_ctx* c, const int* d_list, int nl) {
+  prof_begin(c, TAG_ASSEMBLE, 0.0);
+  hipLaunchKernelGGL(assemble_h_kernel, dim3(c->npad, nl), dim3(256), 0, c->st, c->ws.H, c->ws.sH, c->ld, c->npad, c->n, c->T, c->Tp,
+                     c->p, c->Kinv, c->W, (long long)c->T * c->p * c->p, d_list);
+  prof_end(c);
+  HIPC(hipGetLastError());
+  return 0;
+}
+
+// Kinv (and logdet) of the p Gram slabs currently in Kpad, through the production factor kernels
+int build_kinv(pgpfa_ctx* c) {
+  const size_t slab = (size_t)c->Tp * c->Tp;
+  HIPC(hipMemcpyAsync(c->kws.H, c->Kpad, slab * c->p * sizeof(double), hipMemcpyDeviceToDevice, c->st));
+  HIPC(hipMemsetAsync(c->kws.info, 0, sizeof(int) * c->p, c->st));
+  CHK(factor(c, c->kws, nullptr, c->p));
+  CHK(inverse_t(c, c->kws, nullptr, c->p));
+  GemmP g{};
+  g.A = c->kws.Mt; g.sA = c->kws.sM; g.lda = c->Tp;
+  g.B = c->kws.Mt; g.sB = c->kws.sM; g.ldb = c->Tp;
+  g.C = c->Kinv; g.sC = slab; g.ldc = c->Tp;
+  g.M = c->Tp; g.N = c->Tp; g.K = c->Tp; g.alpha = 1.0; g.beta = 0.0;
+  g.slots = nullptr; g.nbatch = c->p; g.mode = GEMM_FULL; g.kflags = KF_BEGIN_MAXRC;
+  CHK(gemm(c, false, g));
+  std::vector<int> info(c->p);
+  HIPC(hipMemcpyAsync(info.data(), c->kws.info, sizeof(int) * c->p, hipMemcpyDeviceToHost, c->st));
+  HIPC(hipStreamSynchronize(c->st));
+  for (int k = 0; k < c->p; ++k)
+    if (info[k] != 0) return fail("GP Gram matrix of latent %d is not positive definite (pivot %d)", k, info[k]);
+  return 0;
+}
+
+int allreduce_dev(pgpfa_ctx* c, double* buf, size_t count) {
+  if (c->nranks <= 1 || !c->comm) return 0;
+  ncclResult_t r = ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, c->comm, c->st);
+  if (r != ncclSuccess) return fail("ncclAllReduce failed: %s", ncclGetErrorString(r));
+  return 0;
+}
+
+struct Trials {
+  std::vector<int> v;
+};
+int resolve_trials(pgpfa_ctx* c, int n, const int32_t* idx, Trials* out) {
+  if (idx == nullptr) {
+    out->v.resize(c->R);
+    for (int i = 0; i < c->R; ++i) out->v[i] = i;
+    return 0;
+  }
+  if (n < 1) return fail("empty trial list");
+  out->v.assign(idx, idx + n);
+  for (int i = 0; i < n; ++i)
+    if (idx[i] < 0 || idx[i] >= c->R) return fail("trial index %d out of range [0,%d)", idx[i], c->R);
+  return 0;
+}
+
+}  // namespace
+
+// The GEMM addresses A, B and C with one slot index; post_vsmGP is indexed by trial, so the slot
+// result goes through a slot-indexed staging slab and is scattered afterwards.
+namespace {
+__global__ void scatter_vsmgp_kernel(const double* __restrict__ src, long long sSrc, double* __restrict__ dst, int T, int p, int k,
+                                     const int* __restrict__ trial_of_slot) {
+  const int slot = blockIdx.y;
+  const size_t r = trial_of_slot[slot];
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < (size_t)T * T) dst[(r * p + k) * T * T + e] = src[(size_t)slot * sSrc + e];
+}
+}  // namespace
+
+extern "C" {
+
+const char* pgpfa_last_error(void) { return g_err.c_str(); }
+int pgpfa_version(void) { return 100; }
+
+int pgpfa_device_count(int* count) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) { *count = 0; return fail("hipGetDeviceCount: %s", hipGetErrorString(e)); }
+  *count = n;
+  return 0;
+}
+
+int pgpfa_create(pgpfa_ctx** out, int device, int q, int p, int T, int R, double bin_ms) {
+  if (!out) return fail("null out pointer");
+  *out = nullptr;
+  if (q < 1 || p < 1 || T < 1 || R < 1) return fail("invalid sizes q=%d p=%d T=%d R=%d", q, p, T, R);
+  if (p > 32) return fail("p=%d latents not supported (max 32)", p);
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev < 1) return fail("no HIP device available (%s)", hipGetErrorString(e));
+  if (device < 0 || device >= ndev) return fail("device %d out of range (%d devices)", device, ndev);
+  HIPC(hipSetDevice(device));
+  pgpfa_ctx* c = new pgpfa_ctx();
+  c->device = device; c->q = q; c->p = p; c->T = T; c->R = R; c->bin = bin_ms;
+  c->n = p * T;
+  c->npad = round_up(c->n, NB);
+  c->ld = c->npad;
+  c->Tp = round_up(T, NB);
+  hipError_t se = hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking);
+  if (se != hipSuccess) { delete c; return fail("hipStreamCreate: %s", hipGetErrorString(se)); }
+  int rc = 0;
+  const size_t slab = (size_t)c->Tp * c->Tp;
+  rc |= dmalloc(c, &c->Y, (size_t)R * q * T);
+  rc |= dmalloc(c, &c->C, (size_t)q * p); rc |= dmalloc(c, &c->d, q); rc |= dmalloc(c, &c->tau, p);
+  rc |= dmalloc(c, &c->Kpad, slab * p); rc |= dmalloc(c, &c->Kinv, slab * p);
+  rc |= dmalloc(c, &c->Xmode, (size_t)R * c->n, true);
+  rc |= dmalloc(c, &c->vsm, (size_t)R * T * p * p, true);
+  rc |= dmalloc(c, &c->vsmgp, (size_t)R * p * T * T, true);
+  rc |= dmalloc(c, &c->Pauto, slab * p, true);
+  rc |= dmalloc(c, &c->vec, (size_t)q * (p + 1));
+  rc |= dmalloc(c, &c->cdpart, (size_t)1024 * (p + 2) * q);
+  rc |= dmalloc(c, &c->cdout, (size_t)(p + 2) * q + 8);
+  rc |= dmalloc(c, &c->last_trials, R);
+  rc |= alloc_cholws(c, &c->kws, p, c->Tp, true);
+  rc |= dmalloc(c, &c->tK, slab); rc |= dmalloc(c, &c->tM, slab); rc |= dmalloc(c, &c->tA1, slab); rc |= dmalloc(c, &c->tA2, slab);
+  rc |= dmalloc(c, &c->tscal, 16); rc |= dmalloc(c, &c->tpart, 1024);
+  if (rc) { pgpfa_destroy(c); return 1; }
+  e = hipStreamSynchronize(c->st);
+  if (e != hipSuccess) { pgpfa_destroy(c); return fail("sync: %s", hipGetErrorString(e)); }
+  c->info["n_pad"] = c->npad;
+  *out = c;
+  return 0;
+}
+
+int pgpfa_destroy(pgpfa_ctx* c) {
+  if (!c) return 0;
+  hipSetDevice(c->device);
+  if (c->st) hipStreamSynchronize(c->st);
+  if (c->comm) ncclCommDestroy(c->comm);
+  for (void* p : c->allocs) hipFree(p);
+  if (c->hbuf) hipHostFree(c->hbuf);
+  if (c->hibuf) hipHostFree(c->hibuf);
+  for (auto e : c->prof.pool) hipEventDestroy(e);
+  if (c->st) hipStreamDestroy(c->st);
+  delete c;
+  return 0;
+}
+
+int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
+  if (!c || !key) return fail("null argument");
+  const std::string k(key);
+  if (k == "newton_xtol") c->xtol = v;
+  else if (k == "newton_max_iter") c->max_iter = (int)v;
+  else if (k == "use_mfma") c->mfma = (v != 0.0);
+  else if (k == "chunk_trials") { if (c->B > 0) return fail("chunk_trials must be set before the first E-step"); c->chunk_opt = (int)v; }
+  else if (k == "eps_noise") c->eps = v;
+  else if (k == "profile") {
+    c->prof.on = (v != 0.0);
+    c->prof.ms.clear(); c->prof.flops.clear(); c->prof.count.clear(); c->prof.recs.clear(); c->prof.used = 0;
+  } else return fail("unknown option '%s'", key);
+  return 0;
+}
+
+int pgpfa_get_info(pgpfa_ctx* c, const char* key, double* value) {
+  if (!c || !key || !value) return fail("null argument");
+  const std::string k(key);
+  static const char* tags[TAG_N] = {"gemm", "potrf", "solve", "poisson", "assemble", "vsm", "cd"};
+  if (k.rfind("prof_", 0) == 0) {
+    prof_collect(c);
+    for (int t = 0; t < TAG_N; ++t) {
+      const std::string base = std::string("prof_") + tags[t];
+      if (k == base + "_ms") { *value = c->prof.ms[t]; return 0; }
+      if (k == base + "_flops") { *value = c->prof.flops[t]; return 0; }
+      if (k == base + "_launches") { *value = c->prof.count[t]; return 0; }
+    }
+    return fail("unknown info key '%s'", key);
+  }
+  if (k == "hbm_bytes_allocated") { *value = (double)c->bytes; return 0; }
+  if (k == "n_trials_global") { *value = c->n_trials_global; return 0; }
+  auto it = c->info.find(k);
+  if (it == c->info.end()) return fail("unknown info key '%s'", key);
+  *value = it->second;
+  return 0;
+}
+
+int pgpfa_upload_counts_u8(pgpfa_ctx* c, const uint8_t* Y) {
+  if (!c || !Y) return fail("null argument");
+  HIPC(hipSetDevice(c->device));
+  HIPC(hipMemcpyAsync(c->Y, Y, (size_t)c->R * c->q * c->T, hipMemcpyHostToDevice, c->st));
+  HIPC(hipStreamSynchronize(c->st));
+  c->have_counts = true;
+  return 0;
+}
+
+int pgpfa_upload_counts_f64(pgpfa_ctx* c, const double* Y) {
+  if (!c || !Y) return fail("null argument");
+  HIPC(hipSetDevice(c->device));
+  const size_t n = (size_t)c->R * c->q * c->T;
+  // staged in pieces through a temporary device buffer
+  const size_t piece = std::min<size_t>(n, (size_t)1 << 26);
+  double* tmp = nullptr;
+  int* bad = nullptr;
+  HIPC(hipMalloc((void**)&tmp, piece * sizeof(double)));
+  hipError_t e = hipMalloc((void**)&bad, sizeof(int));
+  if (e != hipSuccess) { hipFree(tmp); return fail("hipMalloc: %s", hipGetErrorString(e)); }
+  hipMemsetAsync(bad, 0, sizeof(int), c->st);
+  for (size_t off = 0; off < n; off += piece) {
+    const size_t m = std::min(piece, n - off);
+    hipMemcpyAsync(tmp, Y + off, m * sizeof(double), hipMemcpyHostToDevice, c->st);
+    hipLaunchKernelGGL(pack_counts_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->st, tmp, c->Y + off, m, bad);
+    hipStreamSynchronize(c->st);
+  }
+  int hbad = 0;
+  hipMemcpy(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost);
+  hipFree(tmp);
+  hipFree(bad);
+  HIPC(hipGetLastError());
+  if (hbad) return fail("spike counts must be integers in [0,255]");
+  c->have_counts = true;
+  return 0;
+}
+
+int pgpfa_set_params(pgpfa_ctx* c, const double* C, const double* d, const double* tau_s) {
+  if (!c || !C || !d || !tau_s) return fail("null argument");
+  HIPC(hipSetDevice(c->device));
+  for (int k = 0; k < c->p; ++k)
+    if (!(tau_s[k] > 0.0) || !std::isfinite(tau_s[k])) return fail("tau[%d] = %g must be positive and finite", k, tau_s[k]);
+  CHK(upload(c, c->C, C, (size_t)c->q * c->p));
+  CHK(upload(c, c->d, d, c->q));
+  CHK(upload(c, c->tau, tau_s, c->p));
+  hipLaunchKernelGGL(gram_tau_kernel, dim3(c->Tp, c->p), dim3(256), 0, c->st, c->Kpad, c->Tp, c->T, c->tau, c->bin, c->eps);
+  HIPC(hipGetLastError());
+  CHK(build_kinv(c));
+  c->have_params = true;
+  return 0;
+}
+
+static int get_slabs(pgpfa_ctx* c, const double* src, double* out) {
+  for (int k = 0; k < c->p; ++k) {
+    HIPC(hipMemcpy2DAsync(out + (size_t)k * c->T * c->T, (size_t)c->T * sizeof(double), src + (size_t)k * c->Tp * c->Tp,
+                          (size_t)c->Tp * sizeof(double), (size_t)c->T * sizeof(double), c->T, hipMemcpyDeviceToHost, c->st));
+  }
+  HIPC(hipStreamSynchronize(c->st));
+  return 0;
+}
+int pgpfa_get_gram(pgpfa_ctx* c, double* K) {
+  if (!c || !K) return fail("null argument");
+  if (!c->have_params) return fail("set_params has not been called");
+  HIPC(hipSetDevice(c->device));
+  return get_slabs(c, c->Kpad, K);
+}
+int pgpfa_get_gram_inverse(pgpfa_ctx* c, double* Kinv) {
+  if (!c || !Kinv) return fail("null argument");
+  if (!c->have_params) return fail("set_params has not been called");
+  HIPC(hipSetDevice(c->device));
+  return get_slabs(c, c->Kinv, Kinv);
+}
+
+static int ready(pgpfa_ctx* c) {
+  if (!c) return fail("null context");
+  if (!c->have_counts) return fail("spike counts have not been uploaded");
+  if (!c->have_params) return fail("set_params has not been called");
+  HIPC(hipSetDevice(c->device));
+  return ensure_workspace(c);
+}
+
+// load X[nb][p][T] host points into the chunk slots and bind slot -> trial
+static int load_points(pgpfa_ctx* c, const std::vector<int>& trials, int c0, int nb, const double* X) {
+  std::vector<int> tos(trials.begin() + c0, trials.begin() + c0 + nb);
+  CHK(upload_list(c, c->trial_of_slot, tos));
+  HIPC(hipMemcpy2DAsync(c->Xc, (size_t)c->ld * sizeof(double), X + (size_t)c0 * c->n, (size_t)c->n * sizeof(double),
+                        (size_t)c->n * sizeof(double), nb, hipMemcpyHostToDevice, c->st));
+  return 0;
+}
+
+int pgpfa_laplace_eval(pgpfa_ctx* c, int n, const int32_t* idx, const double* X, double* f, double* grad) {
+  CHK(ready(c));
+  if (!X || !f) return fail("null argument");
+  Trials tr;
+  CHK(resolve_trials(c, n, idx, &tr));
+  const int N = (int)tr.v.size();
+  for (int c0 = 0; c0 < N; c0 += c->B) {
+    const int nb = std::min(c->B, N - c0);
+    CHK(load_points(c, tr.v, c0, nb, X));
+    CHK(prior_mv(c, c->ident, nb, c->Xc, c->KX));
+    hipLaunchKernelGGL(dots3_kernel, dim3(nb), dim3(256), 0, c->st, c->Xc, (long long)c->ld, c->KX, (long long)c->ld, (const double*)nullptr,
+                       0LL, (const double*)nullptr, 0LL, c->n, c->ident, c->sc_qxx, c->sc_qdx, c->sc_qdd);
+    CHK(poisson(c, c->ident, nb, c->Xc, c->Gl, c->W, c->sc_f, 1));
+    CHK(ensure_hbuf(c, 2 * (size_t)nb));
+    HIPC(hipMemcpyAsync(c->hbuf, c->sc_f, nb * sizeof(double), hipMemcpyDeviceToHost, c->st));
+    HIPC(hipMemcpyAsync(c->hbuf + nb, c->sc_qxx, nb * sizeof(double), hipMemcpyDeviceToHost, c->st));
+    if (grad) {
+      hipLaunchKernelGGL(grad_total_kernel, dim3((c->n + 255) / 256, nb), dim3(256), 0, c->st, c->Gl, (long long)c->ld, c->KX,
+                         (long long)c->ld, c->Gt, (long long)c->ld, c->n, c->ident);
+      HIPC(hipMemcpy2DAsync(grad + (size_t)c0 * c->n, (size_t)c->n * sizeof(double), c->Gt, (size_t)c->ld * sizeof(double),
+                            (size_t)c->n * sizeof(double), nb, hipMemcpyDeviceToHost, c->st));
+    }
+    HIPC(hipStreamSynchronize(c->st));
+    for (int s = 0; s < nb; ++s) f[c0 + s] = c->hbuf[s] + 0.5 * c->hbuf[nb + s];
+  }
+  return 0;
+}
+
+int pgpfa_laplace_hessian(pgpfa_ctx* c, int trial, const double* X, double* H) {
+  CHK(ready(c));
+  if (!X || !H) return fail("null argument");
+  if (trial < 0 || trial >= c->R) return fail("trial %d out of range", trial);
+  std::vector<int> tr{trial};
+  CHK(load_points(c, tr, 0, 1, X));
+  CHK(poisson(c, c->ident, 1, c->Xc, c->Gl, c->W, c->sc_f, 1));
+  // dense n x n into the (unused) Mt slab of slot 0 would break its zero pattern: use the H slab
+  hipLaunchKernelGGL(dense_h_kernel, dim3(c->n), dim3(256), 0, c->st, c->ws.H, c->n, c->T, c->Tp, c->p, c->Kinv, c->W);
+  HIPC(hipGetLastError());
+  return download(c, H, c->ws.H, (size_t)c->n * c->n);
+}
+
+int pgpfa_set_modes(pgpfa_ctx* c, int n, const int32_t* idx, const double* X) {
+  if (!c || !X) return fail("null argument");
+  HIPC(hipSetDevice(c->device));
+  Trials tr;
+  CHK(resolve_trials(c, n, idx, &tr));
+  for (size_t i = 0; i < tr.v.size(); ++i)
+    HIPC(hipMemcpyAsync(c->Xmode + (size_t)tr.v[i] * c->n, X + i * c->n, c->n * sizeof(double), hipMemcpyHostToDevice, c->st));
+  HIPC(hipStreamSynchronize(c->st));
+  return 0;
+}
+
+static int remember_trials(pgpfa_ctx* c, const std::vector<int>& v) {
+  c->last_trials_h = v;
+  CHK(upload_list(c, c->last_trials, v));
+  c->have_post = true;
+  c->have_precomp = false;
+  return 0;
+}
+
+int pgpfa_estep_laplace(pgpfa_ctx* c, int n, const int32_t* idx, int warm_start, double* obj_sum, int32_t* iters, int32_t* status) {
+  CHK(ready(c));
+  Trials tr;
+  CHK(resolve_trials(c, n, idx, &tr));
+  const int N = (int)tr.v.size();
+  const auto t_begin = std::chrono::steady_clock::now();
+  const int nvec = c->n, p = c->p, T = c->T;
+  const long long ld = c->ld;
+  double total = 0.0;
+  double n_fact = 0.0;
+  int max_it_seen = 0;
+  std::vector<double> f(c->B), qxx(c->B), qdx(c->B), qdd(c->B), dec(c->B), smax(c->B), alpha(c->B), ftry(c->B);
+  std::vector<int> its(c->B), stat(c->B), info(c->B);
+
+  for (int c0 = 0; c0 < N; c0 += c->B) {
+    const int nb = std::min(c->B, N - c0);
+    std::vector<int> tos(tr.v.begin() + c0, tr.v.begin() + c0 + nb);
+    CHK(upload_list(c, c->trial_of_slot, tos));
+    HIPC(hipMemsetAsync(c->ws.info, 0, sizeof(int) * nb, c->st));
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((nvec + 255) / 256, nb), dim3(256), 0, c->st, c->Xmode, nvec, c->Xc, ld, c->trial_of_slot,
+                       warm_start ? 0 : 1);
+    // objective, gradient pieces and curvature blocks at the start point
+    CHK(prior_mv(c, c->ident, nb, c->Xc, c->KX));
+    hipLaunchKernelGGL(dots3_kernel, dim3(nb), dim3(256), 0, c->st, c->Xc, ld, c->KX, ld, (const double*)nullptr, 0LL,
+                       (const double*)nullptr, 0LL, nvec, c->ident, c->sc_qxx, c->sc_qdx, c->sc_qdd);
+    CHK(poisson(c, c->ident, nb, c->Xc, c->Gl, c->W, c->sc_f, 1));
+    CHK(download(c, f.data(), c->sc_f, nb));
+    CHK(download(c, qxx.data(), c->sc_qxx, nb));
+    std::vector<int> active(nb);
+    for (int s = 0; s < nb; ++s) { active[s] = s; f[s] += 0.5 * qxx[s]; its[s] = 0; stat[s] = 1; }
+
+    for (int iter = 0; iter < c->max_iter && !active.empty(); ++iter) {
+      const int na = (int)active.size();
+      CHK(upload_list(c, c->list_a, active));
+      CHK(assemble(c, c->list_a, na));
+      CHK(factor(c, c->ws, c->list_a, na));
+      n_fact += na;
+      hipLaunchKernelGGL(grad_total_kernel, dim3((nvec + 255) / 256, na), dim3(256), 0, c->st, c->Gl, ld, c->KX, ld, c->Gt, ld, nvec, c->list_a);
+      prof_begin(c, TAG_SOLVE, 2.0 * na * (double)c->npad * c->npad);
+      hipLaunchKernelGGL(chol_solve_kernel, dim3(na), dim3(256), 0, c->st, c->ws.H, c->ws.sH, c->ld, c->npad, c->ws.Dinv, c->ws.sD, c->Gt, c->Dl,
+                         ld, c->list_a, c->sc_dec, c->sc_smax, nvec);
+      prof_end(c);
+      CHK(prior_mv(c, c->list_a, na, c->Dl, c->KD));
+      hipLaunchKernelGGL(dots3_kernel, dim3(na), dim3(256), 0, c->st, c->Xc, ld, c->KX, ld, c->Dl, ld, c->KD, ld, nvec, c->list_a, c->sc_qxx,
+                         c->sc_qdx, c->sc_qdd);
+      HIPC(hipGetLastError());
+      CHK(download(c, dec.data(), c->sc_dec, nb));
+      CHK(download(c, smax.data(), c->sc_smax, nb));
+      CHK(download(c, qxx.data(), c->sc_qxx, nb));
+      CHK(download(c, qdx.data(), c->sc_qdx, nb));
+      CHK(download(c, qdd.data(), c->sc_qdd, nb));
+      HIPC(hipMemcpyAsync(info.data(), c->ws.info, sizeof(int) * nb, hipMemcpyDeviceToHost, c->st));
+      HIPC(hipStreamSynchronize(c->st));
+
+      // backtracking line search on the objective (rounding-noise slack as in the oracle)
+      std::vector<int> pending;
+      for (int s : active) {
+        its[s] += 1;
+        if (info[s] != 0 || !std::isfinite(dec[s])) { stat[s] = 3; continue; }
+        alpha[s] = 1.0;
+        pending.push_back(s);
+      }
+      for (int ls = 0; ls < 40 && !pending.empty(); ++ls) {
+        const int np_ = (int)pending.size();
+        CHK(upload_list(c, c->list_b, pending));
+        CHK(upload(c, c->sc_alpha, alpha.data(), nb));
+        hipLaunchKernelGGL(make_try_kernel, dim3((nvec + 255) / 256, np_), dim3(256), 0, c->st, c->Xc, ld, c->Dl, ld, c->sc_alpha, c->Xt, ld, nvec,
+                           c->list_b);
+        CHK(poisson(c, c->list_b, np_, c->Xt, c->Glt, c->Wt, c->sc_f, 1));
+        CHK(download(c, ftry.data(), c->sc_f, nb));
+        std::vector<int> acc, rej;
+        for (int s : pending) {
+          const double a = alpha[s];
+          const double ft = ftry[s] + 0.5 * (qxx[s] + 2.0 * a * qdx[s] + a * a * qdd[s]);
+          const double slack = 1e-12 * (1.0 + std::fabs(f[s]));
+          if (std::isfinite(ft) && ft <= f[s] - 1e-4 * a * dec[s] + slack) {
+            f[s] = ft;
+            acc.push_back(s);
+          } else {
+            alpha[s] = 0.5 * a;
+            rej.push_back(s);
+          }
+        }
+        if (!acc.empty()) {
+          const int nacc = (int)acc.size();
+          CHK(upload_list(c, c->list_b, acc));
+          const int nw = T * p * p;
+          hipLaunchKernelGGL(commit_kernel, dim3((nvec + 255) / 256, nacc), dim3(256), 0, c->st, c->Xc, c->Xt, c->KX, c->KD, c->Gl, c->Glt, ld,
+                             c->W, c->Wt, (long long)nw, c->sc_alpha, nvec, nw, c->list_b);
+          HIPC(hipGetLastError());
+        }
+        pending.swap(rej);
+      }
+      for (int s : pending) stat[s] = 2;   // line search exhausted
+      std::vector<int> next;
+      for (int s : active) {
+        if (stat[s] == 2 || stat[s] == 3) continue;
+        if (alpha[s] * smax[s] < c->xtol) { stat[s] = 0; continue; }
+        next.push_back(s);
+      }
+      active.swap(next);
+      max_it_seen = std::max(max_it_seen, iter + 1);
+    }
+
+    // posterior covariance blocks at the mode
+    CHK(assemble(c, c->ident, nb));
+    CHK(factor(c, c->ws, c->ident, nb));
+    n_fact += nb;
+    CHK(inverse_t(c, c->ws, c->ident, nb));
+    for (int k = 0; k < p; ++k) {
+      const int kal = (k * T) / 16 * 16;
+      GemmP g{};
+      g.A = c->ws.Mt + (size_t)kal * c->ld + (size_t)k * T; g.sA = c->ws.sM; g.lda = c->ld;
+      g.B = g.A; g.sB = c->ws.sM; g.ldb = c->ld;
+      g.C = c->ws.H; g.sC = c->ws.sH; g.ldc = T;        // slot-indexed staging: the factor slab is free now
+      g.M = T; g.N = T; g.K = c->npad - kal; g.alpha = 1.0; g.beta = 0.0;
+      g.slots = c->ident; g.nbatch = nb; g.mode = GEMM_FULL; g.kflags = 0;
+      CHK(gemm(c, false, g));
+      hipLaunchKernelGGL(scatter_vsmgp_kernel, dim3((unsigned)(((size_t)T * T + 255) / 256), nb), dim3(256), 0, c->st, c->ws.H, c->ws.sH, c->vsmgp,
+                         T, p, k, c->trial_of_slot);
+    }
+    {
+      const int KY = std::min(p, 16);
+      prof_begin(c, TAG_VSM, (double)nb * c->npad * c->npad * p);
+      dispatch_pmax(p, [&](auto pm) {
+        hipLaunchKernelGGL(post_vsm_kernel<decltype(pm)::value>, dim3((T + 63) / 64, nb), dim3(64, KY), 0, c->st, c->ws.Mt, c->ws.sM, c->ld, c->npad,
+                           T, p, c->vsm, c->ident, c->trial_of_slot);
+      });
+      prof_end(c);
+    }
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3((nvec + 255) / 256, nb), dim3(256), 0, c->st, c->Xc, ld, nvec, c->Xmode, c->trial_of_slot);
+    HIPC(hipMemcpyAsync(info.data(), c->ws.info, sizeof(int) * nb, hipMemcpyDeviceToHost, c->st));
+    HIPC(hipStreamSynchronize(c->st));
+    HIPC(hipGetLastError());
+    for (int s = 0; s < nb; ++s) {
+      if (info[s] != 0 && stat[s] == 0) stat[s] = 3;
+      total += f[s];
+      if (iters) iters[c0 + s] = its[s];
+      if (status) status[c0 + s] = stat[s];
+    }
+  }
+  CHK(remember_trials(c, tr.v));
+  if (obj_sum) *obj_sum = total;
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  c->info["last_estep_ms"] = ms;
+  c->info["last_newton_factorizations"] = n_fact;
+  c->info["last_newton_max_iter"] = max_it_seen;
+  return 0;
+}
+
+static int get_rows(pgpfa_ctx* c, int n, const int32_t* idx, const double* src, size_t len, double* out) {
+  if (!c || !out) return fail("null argument");
+  HIPC(hipSetDevice(c->device));
+  Trials tr;
+  CHK(resolve_trials(c, n, idx, &tr));
+  for (size_t i = 0; i < tr.v.size(); ++i)
+    HIPC(hipMemcpyAsync(out + i * len, src + (size_t)tr.v[i] * len, len * sizeof(double), hipMemcpyDeviceToHost, c->st));
+  HIPC(hipStreamSynchronize(c->st));
+  return 0;
+}
+int pgpfa_get_post_mean(pgpfa_ctx* c, int n, const int32_t* idx, double* out) { return get_rows(c, n, idx, c ? c->Xmode : nullptr, c ? (size_t)c->n : 0, out); }
+int pgpfa_get_post_vsm(pgpfa_ctx* c, int n, const int32_t* idx, double* out) {
+  return get_rows(c, n, idx, c ? c->vsm : nullptr, c ? (size_t)c->T * c->p * c->p : 0, out);
+}
+
+int pgpfa_get_post_vsmgp(pgpfa_ctx* c, int n, const int32_t* idx, double* out) {
+  if (!c || !out) return fail("null argument");
+  HIPC(hipSetDevice(c->device));
+  Trials tr;
+  CHK(resolve_trials(c, n, idx, &tr));
+  const size_t len = (size_t)c->T * c->T * c->p;
+  double* tmp = nullptr;
+  HIPC(hipMalloc((void**)&tmp, len * sizeof(double)));
+  for (size_t i = 0; i < tr.v.size(); ++i) {
+    hipLaunchKernelGGL(vsmgp_to_ref_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, c->st, c->vsmgp + (size_t)tr.v[i] * len, tmp, c->T, c->p);
+    hipMemcpyAsync(out + i * len, tmp, len * sizeof(double), hipMemcpyDeviceToHost, c->st);
+    hipStreamSynchronize(c->st);
+  }
+  hipFree(tmp);
+  HIPC(hipGetLastError());
+  return 0;
+}
+
+int pgpfa_get_post_cov(pgpfa_ctx* c, int trial, double* out) {
+  CHK(ready(c));
+  if (!out) return fail("null argument");
+  if (trial < 0 || trial >= c->R) return fail("trial %d out of range", trial);
+  std::vector<int> tr{trial};
+  CHK(upload_list(c, c->trial_of_slot, tr));
+  HIPC(hipMemsetAsync(c->ws.info, 0, sizeof(int), c->st));
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((c->n + 255) / 256, 1), dim3(256), 0, c->st, c->Xmode, c->n, c->Xc, (long long)c->ld, c->trial_of_slot, 0);
+  CHK(poisson(c, c->ident, 1, c->Xc, c->Gl, c->W, c->sc_f, 1));
+  CHK(assemble(c, c->ident, 1));
+  CHK(factor(c, c->ws, c->ident, 1));
+  CHK(inverse_t(c, c->ws, c->ident, 1));
+  GemmP g{};
+  g.A = c->ws.Mt; g.sA = c->ws.sM; g.lda = c->ld;
+  g.B = c->ws.Mt; g.sB = c->ws.sM; g.ldb = c->ld;
+  g.C = c->ws.H; g.sC = c->ws.sH; g.ldc = c->ld;
+  g.M = c->npad; g.N = c->npad; g.K = c->npad; g.alpha = 1.0; g.beta = 0.0;
+  g.slots = c->ident; g.nbatch = 1; g.mode = GEMM_FULL; g.kflags = KF_BEGIN_MAXRC;
+  CHK(gemm(c, false, g));
+  HIPC(hipMemcpy2DAsync(out, (size_t)c->n * sizeof(double), c->ws.H, (size_t)c->ld * sizeof(double), (size_t)c->n * sizeof(double), c->n,
+                        hipMemcpyDeviceToHost, c->st));
+  HIPC(hipStreamSynchronize(c->st));
+  return 0;
+}
+
+int pgpfa_set_posterior(pgpfa_ctx* c, int n, const int32_t* idx, const double* post_mean, const double* post_vsm, const double* post_vsmgp) {
+  if (!c || !post_mean || !post_vsm) return fail("null argument");
+  HIPC(hipSetDevice(c->device));
+  Trials tr;
+  CHK(resolve_trials(c, n, idx, &tr));
+  const size_t lm = c->n, lv = (size_t)c->T * c->p * c->p, lg = (size_t)c->T * c->T * c->p;
+  double* tmp = nullptr;
+  if (post_vsmgp) HIPC(hipMalloc((void**)&tmp, lg * sizeof(double)));
+  for (size_t i = 0; i < tr.v.size(); ++i) {
+    const size_t r = tr.v[i];
+    hipMemcpyAsync(c->Xmode + r * lm, post_mean + i * lm, lm * sizeof(double), hipMemcpyHostToDevice, c->st);
+    hipMemcpyAsync(c->vsm + r * lv, post_vsm + i * lv, lv * sizeof(double), hipMemcpyHostToDevice, c->st);
+    if (post_vsmgp) {
+      hipMemcpyAsync(tmp, post_vsmgp + i * lg, lg * sizeof(double), hipMemcpyHostToDevice, c->st);
+      hipLaunchKernelGGL(vsmgp_from_ref_kernel, dim3((unsigned)((lg + 255) / 256)), dim3(256), 0, c->st, tmp, c->vsmgp + r * lg, c->T, c->p);
+      hipStreamSynchronize(c->st);
+    }
+  }
+  hipStreamSynchronize(c->st);
+  if (tmp) hipFree(tmp);
+  HIPC(hipGetLastError());
+  return remember_trials(c, tr.v);
+}
+
+// ---- M-step ------------------------------------------------------------------------------------------
+int pgpfa_mstep_cd_costgrad(pgpfa_ctx* c, const double* vecCd, const double* prior_center, double inv_s2, double* cost, double* grad) {
+  if (!c || !vecCd || !cost || !grad) return fail("null argument");
+  if (!c->have_counts) return fail("spike counts have not been uploaded");
+  if (!c->have_post) return fail("no E-step result resident: run an E-step or pgpfa_set_posterior first");
+  HIPC(hipSetDevice(c->device));
+  const int q = c->q, p = c->p, T = c->T;
+  const int len = (p + 2) * q;
+  CHK(upload(c, c->vec, vecCd, (size_t)q * (p + 1)));
+  CdArgs a{};
+  a.Y = c->Y; a.mean = c->Xmode; a.vsm = c->vsm; a.vec = c->vec;
+  a.trials = c->last_trials; a.ntr = (int)c->last_trials_h.size();
+  a.part = c->cdpart; a.q = q; a.p = p; a.T = T; a.ntt = (T + CTT - 1) / CTT;
+  const int nitems = a.ntr * a.ntt;
+  const int nby = std::max(1, std::min(1024, nitems));
+  const int KY = std::min(p, 16);
+  prof_begin(c, TAG_CD, (double)a.ntr * q * T * (4.0 * p * p + 4.0 * p));
+  dispatch_pmax(p, [&](auto pm) {
+    hipLaunchKernelGGL(mstep_cd_kernel<decltype(pm)::value>, dim3((q + 63) / 64, nby), dim3(64, KY), 0, c->st, a);
+  });
+  prof_end(c);
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3((len + 255) / 256), dim3(256), 0, c->st, c->cdpart, nby, len, c->cdout);
+  HIPC(hipGetLastError());
+  // append the local trial count, all-reduce [sums | count] over ranks
+  const double cnt = (double)a.ntr;
+  HIPC(hipMemcpyAsync(c->cdout + len, &cnt, sizeof(double), hipMemcpyHostToDevice, c->st));
+  CHK(allreduce_dev(c, c->cdout, (size_t)len + 1));
+  CHK(ensure_hbuf(c, (size_t)len + 1));
+  CHK(download(c, c->hbuf, c->cdout, (size_t)len + 1));
+  const double Rtot = c->hbuf[len];
+  c->n_trials_global = Rtot;
+  double fsum = 0.0;
+  for (int nn = 0; nn < q; ++nn) fsum += c->hbuf[(size_t)(p + 1) * q + nn];
+  double cst = -fsum / Rtot;
+  for (int i = 0; i < q * (p + 1); ++i) grad[i] = -c->hbuf[i] / Rtot;
+  if (prior_center) {
+    double s = 0.0;
+    for (int i = 0; i < q * (p + 1); ++i) {
+      const double dv = vecCd[i] - prior_center[i];
+      s += dv * dv;
+      grad[i] += inv_s2 * dv;
+    }
+    cst += 0.5 * inv_s2 * s;
+  }
+  *cost = cst;
+  return 0;
+}
+
+int pgpfa_mstep_precomp(pgpfa_ctx* c, double* num_trials) {
+  if (!c) return fail("null context");
+  if (!c->have_post) return fail("no E-step result resident");
+  HIPC(hipSetDevice(c->device));
+  const int ntr = (int)c->last_trials_h.size();
+  hipLaunchKernelGGL(pautosum_kernel, dim3(c->Tp, c->p), dim3(128), 0, c->st, c->vsmgp, c->Xmode, c->last_trials, ntr, c->T, c->Tp, c->p, c->Pauto);
+  HIPC(hipGetLastError());
+  const size_t len = (size_t)c->Tp * c->Tp * c->p;
+  CHK(allreduce_dev(c, c->Pauto, len));
+  double cnt = (double)ntr;
+  if (c->nranks > 1) {
+    HIPC(hipMemcpyAsync(c->tscal, &cnt, sizeof(double), hipMemcpyHostToDevice, c->st));
+    CHK(allreduce_dev(c, c->tscal, 1));
+    CHK(download(c, &cnt, c->tscal, 1));
+  }
+  HIPC(hipStreamSynchronize(c->st));
+  c->n_trials_global = cnt;
+  c->have_precomp = true;
+  if (num_trials) *num_trials = cnt;
+  return 0;
+}
+
+int pgpfa_get_pautosum(pgpfa_ctx* c, double* out) {
+  if (!c || !out) return fail("null argument");
+  if (!c->have_precomp) return fail("pgpfa_mstep_precomp has not been called");
+  HIPC(hipSetDevice(c->device));
+  return get_slabs(c, c->Pauto, out);
+}
+
+static int dot_slabs(pgpfa_ctx* c, const double* A, const double* B, size_t n, double* out_dev) {
+  const int nbk = 256;
+  hipLaunchKernelGGL(dot_part_kernel, dim3(nbk), dim3(256), 0, c->st, A, B, (long long)n, c->tpart);
+  hipLaunchKernelGGL(sum_part_kernel, dim3(1), dim3(64), 0, c->st, c->tpart, nbk, out_dev);
+  HIPC(hipGetLastError());
+  return 0;
+}
+
+int pgpfa_mstep_tau_costgrad(pgpfa_ctx* c, int k, double logp, double* cost, double* grad) {
+  if (!c || !cost || !grad) return fail("null argument");
+  if (!c->have_precomp) return fail("pgpfa_mstep_precomp has not been called");
+  if (k < 0 || k >= c->p) return fail("latent %d out of range", k);
+  if (!std::isfinite(logp)) return fail("log-gamma is not finite");
+  HIPC(hipSetDevice(c->device));
+  const int Tp = c->Tp;
+  const size_t slab = (size_t)Tp * Tp;
+  const double* P = c->Pauto + (size_t)k * slab;
+  hipLaunchKernelGGL(gram_gamma_kernel, dim3(Tp), dim3(256), 0, c->st, c->tK, c->tM, Tp, c->T, logp, c->eps);
+  HIPC(hipMemcpyAsync(c->kws.H, c->tK, slab * sizeof(double), hipMemcpyDeviceToDevice, c->st));
+  HIPC(hipMemsetAsync(c->kws.info, 0, sizeof(int), c->st));
+  CHK(factor(c, c->kws, nullptr, 1));
+  hipLaunchKernelGGL(logdet_kernel, dim3(1), dim3(256), 0, c->st, c->kws.H, Tp, Tp, c->tscal + 0);
+  CHK(inverse_t(c, c->kws, nullptr, 1));
+  GemmP g{};
+  g.A = c->kws.Mt; g.sA = 0; g.lda = Tp; g.B = c->kws.Mt; g.sB = 0; g.ldb = Tp;
+  g.C = c->tK; g.sC = 0; g.ldc = Tp;                       // tK <- Kinv
+  g.M = Tp; g.N = Tp; g.K = Tp; g.alpha = 1.0; g.beta = 0.0; g.slots = nullptr; g.nbatch = 1; g.mode = GEMM_FULL; g.kflags = KF_BEGIN_MAXRC;
+  CHK(gemm(c, false, g));
+  GemmP a1 = g;                                            // A1 = Kinv * M   (M symmetric)
+  a1.A = c->tK; a1.B = c->tM; a1.C = c->tA1; a1.kflags = 0;
+  CHK(gemm(c, false, a1));
+  GemmP a2 = g;                                            // A2 = P * Kinv   (Kinv symmetric)
+  a2.A = P; a2.B = c->tK; a2.C = c->tA2; a2.kflags = 0;
+  CHK(gemm(c, false, a2));
+  CHK(dot_slabs(c, c->tK, P, slab, c->tscal + 1));         // tr(Kinv P)
+  CHK(dot_slabs(c, c->tK, c->tM, slab, c->tscal + 2));     // tr(Kinv M)
+  CHK(dot_slabs(c, c->tA1, c->tA2, slab, c->tscal + 3));   // tr(Kinv M Kinv P)
+  double h[4];
+  int info = 0;
+  HIPC(hipMemcpyAsync(h, c->tscal, 4 * sizeof(double), hipMemcpyDeviceToHost, c->st));
+  HIPC(hipMemcpyAsync(&info, c->kws.info, sizeof(int), hipMemcpyDeviceToHost, c->st));
+  HIPC(hipStreamSynchronize(c->st));
+  if (info != 0) return fail("timescale Gram matrix not positive definite at log-gamma=%g (pivot %d)", logp, info);
+  const double R = c->n_trials_global;
+  *cost = 0.5 * R * h[0] + 0.5 * h[1];                                    // learning.py:212-214
+  const double dE = -0.5 * R * h[2] + 0.5 * h[3];                          // learning.py:253
+  *grad = -dE * std::exp(logp);                                            // learning.py:255
+  return 0;
+}
+
+// ---- dual variational: declared in the header, implemented in a later milestone ------------------------
+int pgpfa_dual_costgrad(pgpfa_ctx*, int, const double*, double*, double*) { return fail("dual variational E-step: not implemented yet"); }
+int pgpfa_dual_finalize(pgpfa_ctx*, int, const int32_t*, const double*, double*) { return fail("dual variational E-step: not implemented yet"); }
+
+// ---- multi-GPU ---------------------------------------------------------------------------------------------
+int pgpfa_comm_unique_id(char* id128) {
+  if (!id128) return fail("null argument");
+  ncclUniqueId id;
+  ncclResult_t r = ncclGetUniqueId(&id);
+  if (r != ncclSuccess) return fail("ncclGetUniqueId failed: %s", ncclGetErrorString(r));
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 bytes");
+  std::memcpy(id128, &id, 128);
+  return 0;
+}
+
+int pgpfa_comm_init(pgpfa_ctx* c, const char* id128, int rank, int nranks) {
+  if (!c || !id128) return fail("null argument");
+  if (nranks < 1 || rank < 0 || rank >= nranks) return fail("invalid rank %d of %d", rank, nranks);
+  HIPC(hipSetDevice(c->device));
+  ncclUniqueId id;
+  std::memcpy(&id, id128, 128);
+  ncclResult_t r = ncclCommInitRank(&c->comm, nranks, id, rank);
+  if (r != ncclSuccess) { c->comm = nullptr; return fail("ncclCommInitRank failed: %s", ncclGetErrorString(r)); }
+  c->rank = rank;
+  c->nranks = nranks;
+  return 0;
+}
+
+int pgpfa_comm_allreduce_host(pgpfa_ctx* c, double* buf, int count) {
+  if (!c || !buf || count < 0) return fail("invalid argument");
+  if (c->nranks <= 1) return 0;
+  HIPC(hipSetDevice(c->device));
+  if ((size_t)count > c->commbuf_len) {
+    CHK(dmalloc(c, &c->commbuf, (size_t)count));
+    c->commbuf_len = count;
+  }
+  CHK(upload(c, c->commbuf, buf, count));
+  CHK(allreduce_dev(c, c->commbuf, count));
+  return download(c, buf, c->commbuf, count);
+}
+
+// ---- test / bench hooks ----------------------------------------------------------------------------------------
+int pgpfa_test_potrf(pgpfa_ctx* c, int batch, int n, const double* A, double* L, double* inv) {
+  if (!c || !A || !L) return fail("null argument");
+  if (batch < 1 || n < 1) return fail("invalid sizes");
+  HIPC(hipSetDevice(c->device));
+  const int np = round_up(n, NB);
+  CholWS w{};
+  const size_t mark = c->allocs.size();
+  CHK(alloc_cholws(c, &w, batch, np, true));
+  const size_t slab = (size_t)np * np;
+  std::vector<double> h(slab * batch, 0.0);
+  for (int b = 0; b < batch; ++b) {
+    double* s = h.data() + slab * b;
+    for (int j = 0; j < np; ++j)
+      for (int i = 0; i < np; ++i) s[(size_t)j * np + i] = (i < n && j < n) ? A[((size_t)b * n + i) * n + j] : (i == j ? 1.0 : 0.0);
+  }
+  int rc = upload(c, w.H, h.data(), slab * batch);
+  if (!rc) rc = factor(c, w, nullptr, batch);
+  if (!rc) rc = download(c, h.data(), w.H, slab * batch);
+  if (!rc) {
+    for (int b = 0; b < batch; ++b)
+      for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) L[((size_t)b * n + i) * n + j] = (j <= i) ? h[slab * b + (size_t)j * np + i] : 0.0;
+  }
+  if (!rc && inv) {
+    rc = inverse_t(c, w, nullptr, batch);
+    GemmP g{};
+    g.A = w.Mt; g.sA = w.sM; g.lda = np; g.B = w.Mt; g.sB = w.sM; g.ldb = np;
+    g.C = w.H; g.sC = w.sH; g.ldc = np; g.M = np; g.N = np; g.K = np; g.alpha = 1.0; g.beta = 0.0;
+    g.slots = nullptr; g.nbatch = batch; g.mode = GEMM_FULL; g.kflags = KF_BEGIN_MAXRC;
+    if (!rc) rc = gemm(c, false, g);
+    if (!rc) rc = download(c, h.data(), w.H, slab * batch);
+    if (!rc)
+      for (int b = 0; b < batch; ++b)
+        for (int i = 0; i < n; ++i)
+          for (int j = 0; j < n; ++j) inv[((size_t)b * n + i) * n + j] = h[slab * b + (size_t)j * np + i];
+  }
+  std::vector<int> info(batch, 0);
+  if (!rc) {
+    hipMemcpy(info.data(), w.info, sizeof(int) * batch, hipMemcpyDeviceToHost);
+    for (int b = 0; b < batch; ++b)
+      if (info[b] != 0) rc = fail("matrix %d is not positive definite (pivot %d)", b, info[b]);
+  }
+  hipStreamSynchronize(c->st);
+  while (c->allocs.size() > mark) { hipFree(c->allocs.back()); c->allocs.pop_back(); }
+  return rc;
+}
+
+int pgpfa_test_gemm_nt(pgpfa_ctx* c, int M, int N, int K, double alpha, const double* A, const double* B, double beta, double* C) {
+  if (!c || !A || !B || !C) return fail("null argument");
+  if (K % 16 != 0) return fail("K must be a multiple of 16");
+  HIPC(hipSetDevice(c->device));
+  const int Mp = round_up(M, 128), Np = round_up(N, 128);
+  double *dA = nullptr, *dB = nullptr, *dC = nullptr;
+  const size_t mark = c->allocs.size();
+  CHK(dmalloc(c, &dA, (size_t)Mp * K, true));
+  CHK(dmalloc(c, &dB, (size_t)Np * K, true));
+  CHK(dmalloc(c, &dC, (size_t)Mp * N + 16, true));
+  HIPC(hipMemcpy2DAsync(dA, (size_t)Mp * 8, A, (size_t)M * 8, (size_t)M * 8, K, hipMemcpyHostToDevice, c->st));
+  HIPC(hipMemcpy2DAsync(dB, (size_t)Np * 8, B, (size_t)N * 8, (size_t)N * 8, K, hipMemcpyHostToDevice, c->st));
+  HIPC(hipMemcpy2DAsync(dC, (size_t)Mp * 8, C, (size_t)M * 8, (size_t)M * 8, N, hipMemcpyHostToDevice, c->st));
+  GemmP g{};
+  g.A = dA; g.lda = Mp; g.B = dB; g.ldb = Np; g.C = dC; g.ldc = Mp; g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta;
+  g.nbatch = 1; g.mode = GEMM_FULL;
+  int rc = gemm(c, false, g);
+  if (!rc) {
+    hipError_t e = hipMemcpy2DAsync(C, (size_t)M * 8, dC, (size_t)Mp * 8, (size_t)M * 8, N, hipMemcpyDeviceToHost, c->st);
+    if (e != hipSuccess) rc = fail("copy back: %s", hipGetErrorString(e));
+  }
+  hipStreamSynchronize(c->st);
+  while (c->allocs.size() > mark) { hipFree(c->allocs.back()); c->allocs.pop_back(); }
+  return rc;
+}
+
+int pgpfa_bench_syrk(pgpfa_ctx* c, int batch, int n, int k, int reps, double* ms_per_launch, double* flops_per_launch) {
+  if (!c || !ms_per_launch || !flops_per_launch) return fail("null argument");
+  if (n % 128 != 0 || k % 16 != 0 || batch < 1 || reps < 1) return fail("n must be a multiple of 128 and k of 16");
+  HIPC(hipSetDevice(c->device));
+  const size_t mark = c->allocs.size();
+  double *dC = nullptr, *dA = nullptr;
+  CHK(dmalloc(c, &dC, (size_t)n * n * batch));
+  CHK(dmalloc(c, &dA, (size_t)n * k * batch));
+  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)(((size_t)n * n * batch + 255) / 256)), dim3(256), 0, c->st, dC, (size_t)n * n * batch, 1.0);
+  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)(((size_t)n * k * batch + 255) / 256)), dim3(256), 0, c->st, dA, (size_t)n * k * batch, 1e-3);
+  GemmP s{};
+  s.A = dA; s.sA = (long long)n * k; s.lda = n; s.B = dA; s.sB = s.sA; s.ldb = n;
+  s.C = dC; s.sC = (long long)n * n; s.ldc = n; s.M = n; s.N = n; s.K = k; s.alpha = -1e-6; s.beta = 1.0;
+  s.nbatch = batch; s.mode = GEMM_LOWER; s.kflags = KF_MASK_DIAG;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  int rc = 0;
+  for (int i = 0; i < 2 && !rc; ++i) rc = gemm_launch(c->st, c->mfma, false, s) != hipSuccess;
+  hipEventRecord(e0, c->st);
+  for (int i = 0; i < reps && !rc; ++i) rc = gemm_launch(c->st, c->mfma, false, s) != hipSuccess;
+  hipEventRecord(e1, c->st);
+  hipEventSynchronize(e1);
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, e0, e1);
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  *ms_per_launch = ms / reps;
+  *flops_per_launch = gemm_flops(s);
+  while (c->allocs.size() > mark) { hipFree(c->allocs.back()); c->allocs.pop_back(); }
+  if (rc) return fail("syrk bench launch failed");
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,300 @@
+"""ctypes binding of libpgpfa_hip.so (C-ABI declared in include/pgpfa.h).
+
+The product path has NO CPU fallback: if the shared library is missing, or no MI355X is
+visible, every compute entry point raises.  Build the library with
+``python -c "import __graft_entry__ as g; g.build()"`` (hipcc --offload-arch=gfx950).
+"""
+import ctypes as ct
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'libpgpfa_hip.so')
+
+c_double_p = ct.POINTER(ct.c_double)
+c_int32_p = ct.POINTER(ct.c_int32)
+c_uint8_p = ct.POINTER(ct.c_uint8)
+
+# name -> (argtypes); every function returns int except where noted
+_SIGNATURES = {
+    'pgpfa_version': [],
+    'pgpfa_device_count': [ct.POINTER(ct.c_int)],
+    'pgpfa_create': [ct.POINTER(ct.c_void_p), ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_double],
+    'pgpfa_destroy': [ct.c_void_p],
+    'pgpfa_set_option': [ct.c_void_p, ct.c_char_p, ct.c_double],
+    'pgpfa_get_info': [ct.c_void_p, ct.c_char_p, c_double_p],
+    'pgpfa_upload_counts_f64': [ct.c_void_p, c_double_p],
+    'pgpfa_upload_counts_u8': [ct.c_void_p, c_uint8_p],
+    'pgpfa_set_params': [ct.c_void_p, c_double_p, c_double_p, c_double_p],
+    'pgpfa_get_gram': [ct.c_void_p, c_double_p],
+    'pgpfa_get_gram_inverse': [ct.c_void_p, c_double_p],
+    'pgpfa_laplace_eval': [ct.c_void_p, ct.c_int, c_int32_p, c_double_p, c_double_p, c_double_p],
+    'pgpfa_laplace_hessian': [ct.c_void_p, ct.c_int, c_double_p, c_double_p],
+    'pgpfa_estep_laplace': [ct.c_void_p, ct.c_int, c_int32_p, ct.c_int, c_double_p, c_int32_p, c_int32_p],
+    'pgpfa_set_modes': [ct.c_void_p, ct.c_int, c_int32_p, c_double_p],
+    'pgpfa_get_post_mean': [ct.c_void_p, ct.c_int, c_int32_p, c_double_p],
+    'pgpfa_get_post_vsm': [ct.c_void_p, ct.c_int, c_int32_p, c_double_p],
+    'pgpfa_get_post_vsmgp': [ct.c_void_p, ct.c_int, c_int32_p, c_double_p],
+    'pgpfa_get_post_cov': [ct.c_void_p, ct.c_int, c_double_p],
+    'pgpfa_set_posterior': [ct.c_void_p, ct.c_int, c_int32_p, c_double_p, c_double_p, c_double_p],
+    'pgpfa_mstep_cd_costgrad': [ct.c_void_p, c_double_p, c_double_p, ct.c_double, c_double_p, c_double_p],
+    'pgpfa_mstep_precomp': [ct.c_void_p, c_double_p],
+    'pgpfa_get_pautosum': [ct.c_void_p, c_double_p],
+    'pgpfa_mstep_tau_costgrad': [ct.c_void_p, ct.c_int, ct.c_double, c_double_p, c_double_p],
+    'pgpfa_dual_costgrad': [ct.c_void_p, ct.c_int, c_double_p, c_double_p, c_double_p],
+    'pgpfa_dual_finalize': [ct.c_void_p, ct.c_int, c_int32_p, c_double_p, c_double_p],
+    'pgpfa_comm_unique_id': [ct.c_char_p],
+    'pgpfa_comm_init': [ct.c_void_p, ct.c_char_p, ct.c_int, ct.c_int],
+    'pgpfa_comm_allreduce_host': [ct.c_void_p, c_double_p, ct.c_int],
+    'pgpfa_test_potrf': [ct.c_void_p, ct.c_int, ct.c_int, c_double_p, c_double_p, c_double_p],
+    'pgpfa_test_gemm_nt': [ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, ct.c_double, c_double_p, c_double_p, ct.c_double, c_double_p],
+    'pgpfa_bench_syrk': [ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, ct.c_int, c_double_p, c_double_p],
+}
+EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ['pgpfa_last_error'])
+
+_lib = None
+
+
+class HipBackendError(RuntimeError):
+    """Raised when the HIP library is missing, no GPU is visible, or a C-ABI call fails."""
+
+
+def load_library():
+    """Load libpgpfa_hip.so and attach prototypes.  Works without a GPU (symbols only)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipBackendError(
+            'libpgpfa_hip.so not found at %s - build it with __graft_entry__.build(); '
+            'this package has no CPU fallback' % LIB_PATH)
+    lib = ct.CDLL(LIB_PATH)
+    for name, argtypes in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = ct.c_int
+    lib.pgpfa_last_error.argtypes = []
+    lib.pgpfa_last_error.restype = ct.c_char_p
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise HipBackendError(load_library().pgpfa_last_error().decode('utf-8', 'replace'))
+
+
+def device_count():
+    n = ct.c_int(0)
+    rc = load_library().pgpfa_device_count(ct.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def dptr(a):
+    return a.ctypes.data_as(c_double_p)
+
+
+def iptr(a):
+    return None if a is None else a.ctypes.data_as(c_int32_p)
+
+
+def as_f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def as_idx(idx):
+    if idx is None:
+        return None
+    return np.ascontiguousarray(idx, dtype=np.int32)
+
+
+class Context:
+    """Thin RAII wrapper over pgpfa_ctx."""
+
+    def __init__(self, q, p, T, R, bin_ms, device=0):
+        lib = load_library()
+        if device_count() < 1:
+            raise HipBackendError('no HIP device visible: the Poisson-GPFA hot path runs on MI355X only '
+                                  '(there is no CPU fallback)')
+        self.lib = lib
+        self.q, self.p, self.T, self.R = int(q), int(p), int(T), int(R)
+        self.n = self.p * self.T
+        h = ct.c_void_p()
+        check(lib.pgpfa_create(ct.byref(h), int(device), self.q, self.p, self.T, self.R, float(bin_ms)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.pgpfa_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- options / info --------------------------------------------------------------
+    def set_option(self, key, value):
+        check(self.lib.pgpfa_set_option(self.h, key.encode(), float(value)))
+
+    def info(self, key):
+        v = ct.c_double(0.0)
+        check(self.lib.pgpfa_get_info(self.h, key.encode(), ct.byref(v)))
+        return v.value
+
+    # -- data ---------------------------------------------------------------------------
+    def upload_counts(self, Y):
+        Y = np.asarray(Y)
+        if Y.shape != (self.R, self.q, self.T):
+            raise ValueError('counts must have shape (R,q,T)=%s, got %s' % ((self.R, self.q, self.T), Y.shape))
+        if Y.dtype == np.uint8:
+            Y = np.ascontiguousarray(Y)
+            check(self.lib.pgpfa_upload_counts_u8(self.h, Y.ctypes.data_as(c_uint8_p)))
+        else:
+            Y = as_f64(Y)
+            check(self.lib.pgpfa_upload_counts_f64(self.h, dptr(Y)))
+
+    def set_params(self, C, d, tau):
+        C, d, tau = as_f64(C), as_f64(d).reshape(-1), as_f64(tau).reshape(-1)
+        if C.shape != (self.q, self.p) or d.shape != (self.q,) or tau.shape != (self.p,):
+            raise ValueError('parameter shapes do not match the context (q=%d, p=%d)' % (self.q, self.p))
+        check(self.lib.pgpfa_set_params(self.h, dptr(C), dptr(d), dptr(tau)))
+
+    def gram(self):
+        K = np.empty((self.p, self.T, self.T))
+        check(self.lib.pgpfa_get_gram(self.h, dptr(K)))
+        return K
+
+    def gram_inverse(self):
+        K = np.empty((self.p, self.T, self.T))
+        check(self.lib.pgpfa_get_gram_inverse(self.h, dptr(K)))
+        return K
+
+    # -- Laplace ---------------------------------------------------------------------------
+    def _n_idx(self, idx):
+        return (self.R, None) if idx is None else (len(idx), as_idx(idx))
+
+    def laplace_eval(self, idx, X, want_grad=True):
+        n, ii = self._n_idx(idx)
+        X = as_f64(X).reshape(n, self.n)
+        f = np.empty(n)
+        g = np.empty((n, self.p, self.T)) if want_grad else None
+        check(self.lib.pgpfa_laplace_eval(self.h, n, iptr(ii), dptr(X), dptr(f), dptr(g) if want_grad else None))
+        return f, g
+
+    def laplace_hessian(self, trial, X):
+        X = as_f64(X).reshape(self.n)
+        H = np.empty((self.n, self.n))
+        check(self.lib.pgpfa_laplace_hessian(self.h, int(trial), dptr(X), dptr(H)))
+        return H
+
+    def estep_laplace(self, idx=None, warm_start=False):
+        n, ii = self._n_idx(idx)
+        obj = ct.c_double(0.0)
+        iters = np.zeros(n, dtype=np.int32)
+        status = np.zeros(n, dtype=np.int32)
+        check(self.lib.pgpfa_estep_laplace(self.h, n, iptr(ii), 1 if warm_start else 0, ct.byref(obj), iptr(iters), iptr(status)))
+        return obj.value, iters, status
+
+    def set_modes(self, idx, X):
+        n, ii = self._n_idx(idx)
+        X = as_f64(X).reshape(n, self.n)
+        check(self.lib.pgpfa_set_modes(self.h, n, iptr(ii), dptr(X)))
+
+    def post_mean(self, idx=None):
+        n, ii = self._n_idx(idx)
+        out = np.empty((n, self.p, self.T))
+        check(self.lib.pgpfa_get_post_mean(self.h, n, iptr(ii), dptr(out)))
+        return out
+
+    def post_vsm(self, idx=None):
+        n, ii = self._n_idx(idx)
+        out = np.empty((n, self.T, self.p, self.p))
+        check(self.lib.pgpfa_get_post_vsm(self.h, n, iptr(ii), dptr(out)))
+        return out
+
+    def post_vsmgp(self, idx=None):
+        n, ii = self._n_idx(idx)
+        out = np.empty((n, self.T, self.T, self.p))
+        check(self.lib.pgpfa_get_post_vsmgp(self.h, n, iptr(ii), dptr(out)))
+        return out
+
+    def post_cov(self, trial):
+        out = np.empty((self.n, self.n))
+        check(self.lib.pgpfa_get_post_cov(self.h, int(trial), dptr(out)))
+        return out
+
+    def set_posterior(self, idx, post_mean, post_vsm, post_vsmgp=None):
+        n, ii = self._n_idx(idx)
+        m = as_f64(post_mean).reshape(n, self.n)
+        v = as_f64(post_vsm).reshape(n, self.T * self.p * self.p)
+        g = None if post_vsmgp is None else as_f64(post_vsmgp).reshape(n, self.T * self.T * self.p)
+        check(self.lib.pgpfa_set_posterior(self.h, n, iptr(ii), dptr(m), dptr(v), None if g is None else dptr(g)))
+
+    # -- M-step --------------------------------------------------------------------------------
+    def mstep_cd_costgrad(self, vec, prior_center=None, inv_s2=0.0):
+        vec = as_f64(vec).reshape(-1)
+        cost = ct.c_double(0.0)
+        grad = np.empty(self.q * (self.p + 1))
+        pc = None if prior_center is None else as_f64(prior_center).reshape(-1)
+        check(self.lib.pgpfa_mstep_cd_costgrad(self.h, dptr(vec), None if pc is None else dptr(pc), float(inv_s2),
+                                               ct.byref(cost), dptr(grad)))
+        return cost.value, grad
+
+    def mstep_precomp(self):
+        n = ct.c_double(0.0)
+        check(self.lib.pgpfa_mstep_precomp(self.h, ct.byref(n)))
+        return n.value
+
+    def pautosum(self):
+        out = np.empty((self.p, self.T, self.T))
+        check(self.lib.pgpfa_get_pautosum(self.h, dptr(out)))
+        return out
+
+    def mstep_tau_costgrad(self, k, logp):
+        cost, grad = ct.c_double(0.0), ct.c_double(0.0)
+        check(self.lib.pgpfa_mstep_tau_costgrad(self.h, int(k), float(logp), ct.byref(cost), ct.byref(grad)))
+        return cost.value, grad.value
+
+    # -- comm --------------------------------------------------------------------------------------
+    def comm_init(self, uid, rank, nranks):
+        check(self.lib.pgpfa_comm_init(self.h, uid, int(rank), int(nranks)))
+
+    def allreduce_host(self, arr):
+        a = as_f64(arr).reshape(-1).copy()
+        check(self.lib.pgpfa_comm_allreduce_host(self.h, dptr(a), a.size))
+        return a.reshape(np.shape(arr))
+
+    # -- test hooks ----------------------------------------------------------------------------------
+    def test_potrf(self, A, want_inverse=True):
+        A = as_f64(A)
+        if A.ndim == 2:
+            A = A[None]
+        b, n, _ = A.shape
+        L = np.empty_like(A)
+        inv = np.empty_like(A) if want_inverse else None
+        check(self.lib.pgpfa_test_potrf(self.h, b, n, dptr(A), dptr(L), dptr(inv) if want_inverse else None))
+        return L, inv
+
+    def test_gemm_nt(self, A, B, C=None, alpha=1.0, beta=0.0):
+        """C = alpha*A@B.T + beta*C with A (M,K), B (N,K) given row-major; passed column-major."""
+        A, B = as_f64(A), as_f64(B)
+        M, K = A.shape
+        N = B.shape[0]
+        Ccm = np.zeros((N, M)) if C is None else as_f64(np.asarray(C).T)     # column-major (M,N) == row-major (N,M)
+        Acm, Bcm = as_f64(A.T), as_f64(B.T)                                   # column-major (M,K) == row-major (K,M)
+        check(self.lib.pgpfa_test_gemm_nt(self.h, M, N, K, float(alpha), dptr(Acm), dptr(Bcm), float(beta), dptr(Ccm)))
+        return Ccm.T.copy()
+
+    def bench_syrk(self, batch, n, k, reps):
+        ms, fl = ct.c_double(0.0), ct.c_double(0.0)
+        check(self.lib.pgpfa_bench_syrk(self.h, int(batch), int(n), int(k), int(reps), ct.byref(ms), ct.byref(fl)))
+        return ms.value, fl.value
+
+
+def comm_unique_id():
+    buf = ct.create_string_buffer(128)
+    check(load_library().pgpfa_comm_unique_id(buf))
+    return buf.raw

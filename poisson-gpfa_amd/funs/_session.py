@@ -1,0 +1,212 @@
+"""Device sessions: one per (experiment, xdim).  Keeps the spike-count tensor, the modes and the
+posterior blocks resident in HBM between E-step and M-step calls, and hands lazy views back to
+callers that still want the reference's list-of-arrays ``infRes``.
+
+Trial sharding (multi-GPU): when the process was launched one-rank-per-GPU (RANK / WORLD_SIZE /
+LOCAL_RANK in the environment, as torch.distributed.run sets them) every rank holds the full
+count tensor (uint8, small) and processes a contiguous slice of each trial list; M-step sufficient
+statistics are summed with an RCCL all-reduce inside the C-ABI.
+"""
+import os
+import time
+import weakref
+
+import numpy as np
+
+from . import _hip
+
+
+# ----------------------------------------------------------------------------------------------
+# process-wide communicator description (rank, world size, unique id exchange)
+# ----------------------------------------------------------------------------------------------
+class _World:
+    def __init__(self):
+        self.rank = int(os.environ.get('RANK', '0'))
+        self.size = int(os.environ.get('WORLD_SIZE', '1'))
+        self.local_rank = int(os.environ.get('LOCAL_RANK', str(self.rank)))
+        self.enabled = self.size > 1 and os.environ.get('PGPFA_DISABLE_COMM', '0') != '1'
+        self._serial = 0
+
+    def device(self):
+        return self.local_rank if self.enabled else int(os.environ.get('PGPFA_DEVICE', '0'))
+
+    def exchange_unique_id(self):
+        """Rank 0 creates the RCCL unique id and publishes it through a file; the other ranks of
+        this single-node job poll for it.  The file name is keyed by the launcher's pid (shared
+        parent of all ranks), MASTER_PORT and a per-process serial so that repeated sessions and
+        stale files of earlier runs cannot collide."""
+        self._serial += 1
+        base = os.environ.get('PGPFA_RDZV_DIR', '/tmp')
+        key = 'pgpfa_uid_%s_%s_%d_%d' % (os.environ.get('MASTER_PORT', '0'),
+                                        os.environ.get('TORCHELASTIC_RUN_ID', 'none'), os.getppid(), self._serial)
+        path = os.path.join(base, key)
+        if self.rank == 0:
+            uid = _hip.comm_unique_id()
+            tmp = path + '.tmp'
+            with open(tmp, 'wb') as fh:
+                fh.write(uid)
+            os.replace(tmp, path)
+            return uid, path
+        deadline = time.time() + float(os.environ.get('PGPFA_RDZV_TIMEOUT', '300'))
+        while time.time() < deadline:
+            if os.path.exists(path):
+                with open(path, 'rb') as fh:
+                    uid = fh.read()
+                if len(uid) == 128:
+                    return uid, path
+            time.sleep(0.01)
+        raise _hip.HipBackendError('timed out waiting for the RCCL unique id at %s' % path)
+
+
+WORLD = _World()
+
+
+def shard_slice(n_items, rank, size):
+    """Contiguous block partition of range(n_items): the first (n_items % size) ranks get one more."""
+    base, rem = divmod(n_items, size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+# ----------------------------------------------------------------------------------------------
+# lazy, device-backed sequences (duck-type the reference's per-trial lists)
+# ----------------------------------------------------------------------------------------------
+class LazyTrialList:
+    """Behaves like the reference's list of per-trial arrays; entry i is fetched from HBM on first use."""
+
+    def __init__(self, n, fetch):
+        self._n = n
+        self._fetch = fetch
+        self._cache = {}
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(self._n))]
+        if i < 0:
+            i += self._n
+        if not 0 <= i < self._n:
+            raise IndexError(i)
+        if i not in self._cache:
+            self._cache[i] = self._fetch(i)
+        return self._cache[i]
+
+    def __iter__(self):
+        return (self[i] for i in range(self._n))
+
+
+class DeviceInfRes(dict):
+    """infRes dict of inference.laplace / dualVariational (inference.py:176-180) whose four entries
+    are lazy views of device-resident results.  Carries the session and the trial list so that
+    learning.updateParams* can run the M-step without the data ever leaving HBM."""
+
+    def __init__(self, session, trial_idx, local_pos):
+        super().__init__()
+        self.session = session
+        self.trial_idx = np.asarray(trial_idx, dtype=np.int32)       # trials this rank processed
+        self.stamp = session.post_stamp
+        ctx = session.ctx
+        n = len(self.trial_idx)
+        tid = self.trial_idx
+        self.local_positions = local_pos                              # positions in the caller's trial list
+        self['post_mean'] = LazyTrialList(n, lambda i: ctx.post_mean(tid[i:i + 1])[0])
+        self['post_vsm'] = LazyTrialList(n, lambda i: ctx.post_vsm(tid[i:i + 1])[0])
+        self['post_vsmGP'] = LazyTrialList(n, lambda i: ctx.post_vsmgp(tid[i:i + 1])[0])
+        self['post_cov'] = LazyTrialList(n, lambda i: self._cov(i))
+
+    def _cov(self, i):
+        if self.session.post_stamp != self.stamp:
+            raise _hip.HipBackendError('post_cov of a superseded E-step was requested: it is recomputed on demand '
+                                       'from the resident mode, which a later E-step has overwritten')
+        return self.session.ctx.post_cov(int(self.trial_idx[i]))
+
+
+class DeviceOptimRes(LazyTrialList):
+    """lapOptimRes (inference.py:92,127): the modes, flattened; resident on device for warm starts."""
+
+    def __init__(self, session, trial_idx):
+        tid = np.asarray(trial_idx, dtype=np.int32)
+        ctx = session.ctx
+        super().__init__(len(tid), lambda i: ctx.post_mean(tid[i:i + 1])[0].reshape(-1))
+        self.session = session
+        self.trial_idx = tid
+        self.stamp = session.mode_stamp
+
+
+# ----------------------------------------------------------------------------------------------
+class Session:
+    def __init__(self, Y, p, bin_ms):
+        R, q, T = Y.shape
+        self.R, self.q, self.T, self.p = R, q, T, p
+        self.ctx = _hip.Context(q, p, T, R, bin_ms, device=WORLD.device())
+        self.ctx.upload_counts(Y)
+        self.post_stamp = 0
+        self.mode_stamp = 0
+        self.rank, self.size = 0, 1
+        if WORLD.enabled:
+            uid, path = WORLD.exchange_unique_id()
+            self.ctx.comm_init(uid, WORLD.rank, WORLD.size)
+            self.rank, self.size = WORLD.rank, WORLD.size
+            # first collective doubles as the barrier after which rank 0 may remove the file
+            self.ctx.allreduce_host(np.zeros(1))
+            if WORLD.rank == 0:
+                try:
+                    os.remove(path)
+                except OSError:
+                    pass
+
+    def set_params(self, params):
+        self.ctx.set_params(params['C'], params['d'], params['tau'])
+
+    def local_slice(self, n_items):
+        return shard_slice(n_items, self.rank, self.size) if self.size > 1 else (0, n_items)
+
+    def allreduce(self, arr):
+        return self.ctx.allreduce_host(arr) if self.size > 1 else np.asarray(arr, dtype=np.float64)
+
+
+_sessions = weakref.WeakKeyDictionary()
+
+
+def _stack_counts(experiment):
+    Y = np.stack([np.asarray(tr['Y']) for tr in experiment.data])
+    if Y.min() >= 0 and Y.max() <= 255 and np.all(Y == np.floor(Y)):
+        return Y.astype(np.uint8)
+    return Y.astype(np.float64)
+
+
+def session_for(experiment, p):
+    """Return (session, trial indices of `experiment` inside the session's count tensor).
+
+    Sub-sampled experiments produced by funs.util.subsampleTrials carry `_pgpfa_parent` and
+    `batchTrIdx`, so minibatches reuse the parent's resident tensor instead of re-uploading."""
+    parent = getattr(experiment, '_pgpfa_parent', None)
+    if parent is not None and hasattr(experiment, 'batchTrIdx'):
+        sess, _ = session_for(parent, p)
+        return sess, np.asarray(experiment.batchTrIdx, dtype=np.int32)
+    per_exp = _sessions.get(experiment)
+    if per_exp is None:
+        per_exp = {}
+        _sessions[experiment] = per_exp
+    n_trials = len(experiment.data)
+    sess = per_exp.get(p)
+    if sess is None or sess.R != n_trials:
+        Y = _stack_counts(experiment)
+        sess = Session(Y, p, float(experiment.binSize))
+        per_exp[p] = sess
+    return sess, np.arange(n_trials, dtype=np.int32)
+
+
+def drop_sessions(experiment=None):
+    """Free device memory held for `experiment` (or for every experiment)."""
+    if experiment is None:
+        for per_exp in list(_sessions.values()):
+            for s in per_exp.values():
+                s.ctx.close()
+        _sessions.clear()
+    elif experiment in _sessions:
+        for s in _sessions[experiment].values():
+            s.ctx.close()
+        del _sessions[experiment]

@@ -1,0 +1,192 @@
+"""EM orchestration with the reference's constructor surface (funs/engine.py:107-128 of
+mackelab/poisson-gpfa): `PPGPFAfit(experiment, initParams, ...)` runs batch or online (stochastic) EM,
+E-step and M-step evaluations on the GPU, and leaves the reference's result attributes
+(engine.py:453-474) on the object.  Plotting methods are not part of the hot path."""
+import copy
+import time
+
+import numpy as np
+
+from . import inference
+from . import learning
+from . import util
+
+
+def _banner(rows):
+    print('+-------------------- Fit Options --------------------+')
+    for label, value in rows:
+        print('| ' + label + (str(value) + ' |').rjust(53 - len(label)))
+    print('+-----------------------------------------------------+')
+
+
+def _copy_params(params):
+    return {'C': np.array(params['C'], dtype=np.float64), 'd': np.array(params['d'], dtype=np.float64).reshape(-1),
+            'tau': np.array(params['tau'], dtype=np.float64).reshape(-1)}
+
+
+class PPGPFAfit():
+    """Poisson-GPFA fit of binned population spike counts by (online) EM.
+
+    Arguments and defaults are those of the reference (engine.py:107-128).  Result attributes:
+    optimParams, paramSeq, infRes (of the last batch processed), posteriorLikelihood,
+    variationalLowerBound, learningDetails, inferenceTime, learningTime, tauSeq, ... (engine.py:453-474).
+    """
+
+    def __init__(self, experiment, initParams=None, xdim=2, inferenceMethod='laplace', maxEMiter=50, optimLogLamb=False,
+                 CdOptimMethod='TNC', tauOptimMethod='TNC', verbose=False, EMmode='Online', batchSize=5,
+                 onlineParamUpdateMethod='diag', hessTol=None, stepPow=0.75, updateCdJointly=True, fullyUpdateTau=False,
+                 extractAllTraj=False, extractAllTraj_trueParams=False, getPredictionErr=False, CdMaxIter=None,
+                 tauMaxIter=None, *, quiet=False):
+        if EMmode not in ('Batch', 'Online'):
+            raise ValueError("EMmode must be 'Batch' or 'Online'")
+        if inferenceMethod not in ('laplace', 'variational'):
+            raise ValueError("inferenceMethod must be 'laplace' or 'variational'")
+        self.experiment = experiment
+        ydim, T = np.shape(experiment.data[0]['Y'])
+        numTrials = len(experiment.data)
+        if initParams is None:
+            initParams = util.initializeParams(xdim, ydim, experiment)
+        else:
+            xdim = np.shape(initParams['C'])[1]
+
+        posteriorLikelihood, variationalLowerBound, learningDetails = [], [], []
+        params = initParams
+        paramSeq = [initParams]
+        learningTime, inferenceTime = [], []
+        rows = [('Dimensionality of Latent State: ', xdim), ('Dimensionality of Observed State (# neurons): ', ydim),
+                ('EM mode: ', EMmode), ('Max EM iterations: ', maxEMiter), ('Inference Method: ', inferenceMethod)]
+
+        def e_step(exp_, params_, prev):
+            if inferenceMethod == 'laplace':
+                infRes_, nll_, opt_ = inference.laplace(experiment=exp_, params=params_, prevOptimRes=prev, verbose=verbose)
+                return infRes_, nll_, None, opt_
+            infRes_, nll_, vlb_, opt_ = inference.dualVariational(experiment=exp_, params=params_, optimizeLogLambda=optimLogLamb,
+                                                                 prevOptimRes=prev, verbose=verbose)
+            return infRes_, nll_, vlb_, opt_
+
+        def report(i, nll, vlb):
+            if quiet:
+                return
+            if vlb is None:
+                util.Printer('Iteration: %3d of %3d, nPLL: = %.4f' % (i + 1, maxEMiter, nll))
+            else:
+                util.Printer('Iteration: %3d of %3d, nPLL: = %.4f, VLB = %.4f' % (i + 1, maxEMiter, nll, vlb))
+
+        infRes = None
+        if EMmode == 'Batch':                                   # reference engine.py:154-240
+            if not quiet:
+                _banner(rows)
+            optimRes = None
+            for i in range(maxEMiter):
+                before = time.time()
+                infRes, nll, vlb, optimRes = e_step(experiment, params, optimRes)      # warm start after iteration 0
+                posteriorLikelihood.append(nll)
+                if vlb is not None:
+                    variationalLowerBound.append(vlb)
+                inferenceTime.append(time.time() - before)
+                before = time.time()
+                params, learnDet = learning.updateParams(oldParams=params, infRes=infRes, experiment=experiment,
+                                                         CdOptimMethod=CdOptimMethod)
+                learningTime.append(time.time() - before)
+                learningDetails.append(learnDet)
+                paramSeq.append(params)
+                report(i, nll, vlb)
+
+        if EMmode == 'Online':                                  # reference engine.py:243-449
+            if not quiet:
+                _banner(rows + [('Online Param Update Method: ', '`' + str(onlineParamUpdateMethod) + '`'),
+                                ('Batch size (trials): ', batchSize)])
+            gamma = np.linspace(0, 1, maxEMiter)
+            step_cd = 1 / (np.arange(maxEMiter) + 1) ** stepPow
+            step_tau = 1 / (np.arange(maxEMiter) + 1) ** stepPow
+            size = xdim * ydim + ydim if updateCdJointly else xdim * ydim
+            self.invPriorCovs = [np.diag(np.ones(size))]
+            self.cumHess = [np.diag(np.ones(size))]
+            for n in range(maxEMiter):
+                sub = util.subsampleTrials(experiment, batchSize)
+                before = time.time()
+                infRes, nll, vlb, _ = e_step(sub, params, None)                      # cold start every time (engine.py:298-301)
+                posteriorLikelihood.append(nll)
+                if vlb is not None:
+                    variationalLowerBound.append(vlb)
+                inferenceTime.append(time.time() - before)
+                before = time.time()
+                if onlineParamUpdateMethod in ('balancingGamma', 'sequentialAverage', 'fullyUpdateAll'):
+                    newParams, learnDet = learning.updateParams(oldParams=params, infRes=infRes, experiment=sub,
+                                                                CdOptimMethod=CdOptimMethod, CdMaxIter=CdMaxIter,
+                                                                tauMaxIter=None, verbose=verbose)
+                    nextParams = newParams                                           # aliasing as in engine.py:325-341
+                    if onlineParamUpdateMethod == 'balancingGamma':
+                        for key in ('C', 'd', 'tau'):
+                            nextParams[key] = gamma[n] * params[key] + (1 - gamma[n]) * newParams[key]
+                    elif onlineParamUpdateMethod == 'sequentialAverage':
+                        for key in ('C', 'd', 'tau'):
+                            nextParams[key] = (params[key] + newParams[key]) / 2
+                elif onlineParamUpdateMethod == 'diag':
+                    newParams, learnDet, priorCov = learning.updateParamsWithPrior(
+                        oldParams=params, infRes=infRes, experiment=sub, CdOptimMethod=CdOptimMethod,
+                        tauOptimMethod=tauOptimMethod, regularizer_stepsize_Cd=step_cd[n],
+                        regularizer_stepsize_tau=step_tau[n], prevInvPriorCov=self.invPriorCovs[-1], covOpts='useDiag',
+                        verbose=verbose, updateCdJointly=updateCdJointly, hessTol=hessTol)
+                    nextParams = newParams
+                    self.invPriorCovs.append(priorCov)
+                else:
+                    raise NotImplementedError("onlineParamUpdateMethod '%s': the finite-difference-Hessian variants "
+                                              "('hess', 'grad') are outside the GPU hot path" % onlineParamUpdateMethod)
+                learningTime.append(time.time() - before)
+                if fullyUpdateTau:
+                    nextParams['tau'] = newParams['tau']
+                report(n, nll, vlb)
+                learningDetails.append(learnDet)
+                params = nextParams
+                paramSeq.append(params)
+            self.onlineParamUpdateMethod = onlineParamUpdateMethod
+
+        self.xdim, self.ydim, self.T = xdim, ydim, T
+        self.trialDur, self.binSize, self.numTrials = experiment.trialDur, experiment.binSize, numTrials
+        self.maxEMiter, self.EMmode, self.inferenceMethod = maxEMiter, EMmode, inferenceMethod
+        self.initParams, self.paramSeq, self.optimParams = initParams, paramSeq, params
+        self.posteriorLikelihood, self.variationalLowerBound = posteriorLikelihood, variationalLowerBound
+        self.learningDetails, self.infRes = learningDetails, infRes
+        self.learningTime, self.inferenceTime = np.asarray(learningTime), np.asarray(inferenceTime)
+        self.CdOptimMethod, self.optimLogLamb = CdOptimMethod, optimLogLamb
+        self.processParamResults()
+        if not quiet:
+            print()
+        if extractAllTraj:
+            self.extractTrajectories(method=inferenceMethod)
+        if extractAllTraj_trueParams:
+            self.extractTrajWithTrueParams(method=inferenceMethod)
+        if getPredictionErr:
+            raise NotImplementedError('leave-one-neuron-out prediction is a listed follow-up (SURVEY 8f-2)')
+
+    # -- light-weight summaries of the parameter path (subset of reference engine.py:541-597) ----------------
+    def processParamResults(self):
+        n = self.maxEMiter
+        self.tauSeq = np.zeros([self.xdim, n])
+        self.CabsoluteValue = np.zeros(n)
+        for i in range(n):
+            self.tauSeq[:, i] = np.asarray(self.paramSeq[i]['tau']).reshape(-1)
+            self.CabsoluteValue[i] = float(np.sum(np.asarray(self.paramSeq[i]['C']) ** 2))
+        if hasattr(self.experiment, 'params'):
+            self.subspaceAngleC = [util.subspaceAngle(self.experiment.params['C'], self.paramSeq[i]['C']) for i in range(n)]
+
+    def extractTrajectories(self, method='laplace'):
+        """One more E-step over all trials with the fitted parameters (reference engine.py:523-532)."""
+        if method == 'laplace':
+            self.infRes, self.nll_all_traj, _ = inference.laplace(self.experiment, copy.copy(self.optimParams))
+        else:
+            self.infRes, self.nll_all_traj, self.vlb_all_traj, _ = inference.dualVariational(
+                self.experiment, copy.copy(self.optimParams), optimizeLogLambda=self.optimLogLamb)
+
+    def extractTrajWithTrueParams(self, method='laplace'):
+        if method == 'laplace':
+            self.infRes_trueParams, self.nll_trueParams_all_traj, _ = inference.laplace(self.experiment, copy.copy(self.experiment.params))
+        else:
+            (self.infRes_trueParams, self.nll_trueParams_all_traj, self.vlb_trueParams_all_traj, _) = inference.dualVariational(
+                self.experiment, copy.copy(self.experiment.params), optimizeLogLambda=self.optimLogLamb)
+
+    def orthonormalizeTrajectories(self):
+        """x_tilde = D V^T x with C = U D V^T (reference engine.py:514-521)."""
+        _, D, Vt = np.linalg.svd(np.asarray(self.optimParams['C']), full_matrices=False)
+        self.x_tilde = np.asarray([np.diag(D) @ Vt @ self.infRes['post_mean'][tr] for tr in range(len(self.infRes['post_mean']))])

@@ -1,0 +1,97 @@
+"""E-step entry points with the reference's call surface (funs/inference.py of
+mackelab/poisson-gpfa), executed by hand-written HIP kernels on MI355X.
+
+    laplace(experiment, params, prevOptimRes=None, returnOptimRes=True, verbose=False,
+            optimMethod='Newton-CG')                         # reference inference.py:67-185
+    negLogPosteriorUnNorm / _grad / _hess                     # reference inference.py:12-65
+
+The three callbacks keep the reference's positional signature (xbar, ybar, C_big, d_big,
+K_bigInv, xdim, ydim) but are also offered in the structured form the device evaluates
+(`laplace_objective`), because the Kronecker "big" matrices are never formed here.
+"""
+import numpy as np
+
+from . import _hip
+from ._session import DeviceInfRes, DeviceOptimRes, session_for
+
+STATUS_TEXT = {0: 'converged', 1: 'iteration limit reached', 2: 'line search failed', 3: 'Hessian not positive definite'}
+
+
+def _prepare(experiment, params):
+    C = np.asarray(params['C'], dtype=np.float64)
+    ydim, xdim = C.shape
+    # the reference flattens tau in place inside util.makeK_big (util.py:602); keep that side effect
+    params['tau'] = np.ndarray.flatten(np.asarray(params['tau'], dtype=np.float64))
+    sess, trial_idx = session_for(experiment, xdim)
+    if sess.q != ydim:
+        raise ValueError("params['C'] has %d rows but the experiment has %d neurons" % (ydim, sess.q))
+    sess.set_params(params)
+    return sess, trial_idx
+
+
+def laplace(experiment, params, prevOptimRes=None, returnOptimRes=True, verbose=False, optimMethod='Newton-CG'):
+    """Laplace approximation of every trial's latent posterior (reference inference.py:67-185).
+
+    Returns (infRes, -mean objective at the modes[, lapOptimRes]) exactly like the reference.  The
+    mode search is a damped Newton iteration with a dense Cholesky solve per step on the GPU, run
+    to |step|_inf < 1e-5 (tighter than the reference's scipy Newton-CG stop, xtol=1e-5 on the mean
+    |step|); `optimMethod` is accepted for signature compatibility only.  infRes entries are lazy
+    device-backed sequences; 'post_cov' is recomputed on access.
+    """
+    sess, trial_idx = _prepare(experiment, params)
+    n_all = len(trial_idx)
+    lo, hi = sess.local_slice(n_all)
+    mine = trial_idx[lo:hi]
+    warm = False
+    if prevOptimRes is not None:
+        resident = (isinstance(prevOptimRes, DeviceOptimRes) and prevOptimRes.session is sess
+                    and prevOptimRes.stamp == sess.mode_stamp and np.array_equal(prevOptimRes.trial_idx, mine))
+        if not resident:
+            if len(prevOptimRes) == n_all:
+                X = np.stack([np.asarray(prevOptimRes[i], dtype=np.float64).reshape(-1) for i in range(lo, hi)])
+            elif len(prevOptimRes) == len(mine):
+                X = np.stack([np.asarray(x, dtype=np.float64).reshape(-1) for x in prevOptimRes])
+            else:
+                raise ValueError('prevOptimRes has %d entries for %d trials' % (len(prevOptimRes), n_all))
+            if len(mine):
+                sess.ctx.set_modes(mine, X)
+        warm = True
+    if len(mine):
+        obj, iters, status = sess.ctx.estep_laplace(mine, warm_start=warm)
+    else:
+        obj, iters, status = 0.0, np.zeros(0, np.int32), np.zeros(0, np.int32)
+    sess.post_stamp += 1
+    sess.mode_stamp += 1
+    if verbose:
+        for i, (it, st) in enumerate(zip(iters, status)):
+            print('laplace inference trajectory of trial %d: %d Newton factorizations, %s' % (lo + i + 1, it, STATUS_TEXT.get(int(st), '?')))
+    tot = sess.allreduce(np.array([obj, float(len(mine))]))
+    post_lik = tot[0] / n_all
+    infRes = DeviceInfRes(sess, mine, (lo, hi))
+    infRes.newton_iters = iters
+    infRes.newton_status = status
+    if returnOptimRes:
+        return infRes, -post_lik, DeviceOptimRes(sess, mine)
+    return infRes, -post_lik
+
+
+# ------------------------------------------------------------------------------------------------
+# callbacks (reference inference.py:12-65) - structured form
+# ------------------------------------------------------------------------------------------------
+def laplace_objective(experiment, params, X, trials=None, grad=True):
+    """negLogPosteriorUnNorm (and _grad) at latent trajectories X[n][xdim][T] for the given trials."""
+    sess, trial_idx = _prepare(experiment, params)
+    idx = trial_idx if trials is None else trial_idx[np.asarray(trials)]
+    return sess.ctx.laplace_eval(idx, X, want_grad=grad)
+
+
+def laplace_hessian(experiment, params, X, trial=0):
+    """negLogPosteriorUnNorm_hess for one trial: dense (xdim*T, xdim*T), latent-major."""
+    sess, trial_idx = _prepare(experiment, params)
+    return sess.ctx.laplace_hessian(int(trial_idx[trial]), X)
+
+
+def dualVariational(experiment, params, optimizeLogLambda=False, prevOptimRes=None, returnOptimRes=True, verbose=False):
+    """Dual variational E-step (reference inference.py:259-432)."""
+    raise _hip.HipBackendError('dualVariational: the HIP dual-variational E-step is not built yet '
+                               '(SURVEY 8a row a8); there is no CPU fallback')

@@ -1,0 +1,237 @@
+"""M-step entry points with the reference's call surface (funs/learning.py of
+mackelab/poisson-gpfa).  Cost and gradient evaluations run as HIP kernels over the E-step results
+that are already resident in HBM; the outer optimisers are the same scipy.optimize drivers, called
+with the same methods and options as the reference, so early-stopping behaviour carries over.
+
+    updateParams(oldParams, infRes, experiment, CdOptimMethod='BFGS', CdMaxIter=None,
+                 tauMaxIter=None, verbose=False)                       # reference learning.py:295-309
+    updateParamsWithPrior(...)  with covOpts='useDiag'                   # reference learning.py:833-866
+"""
+import numpy as np
+import scipy.optimize as op
+
+from . import _hip
+from . import util
+from ._session import DeviceInfRes, session_for
+
+EPS_NOISE = 0.001      # reference learning.py:286,822
+
+
+def _resident_session(infRes, experiment, xdim):
+    """Make sure the posterior the caller passes is the one resident on the device."""
+    if isinstance(infRes, DeviceInfRes):
+        sess = infRes.session
+        if infRes.stamp != sess.post_stamp:
+            raise _hip.HipBackendError('this infRes belongs to a superseded E-step; run the M-step right after '
+                                       'the E-step that produced it (device results are overwritten in place)')
+        return sess
+    # foreign infRes (e.g. produced by the reference): upload it
+    sess, trial_idx = session_for(experiment, xdim)
+    lo, hi = sess.local_slice(len(trial_idx))
+    pm = np.stack([np.asarray(infRes['post_mean'][i]) for i in range(lo, hi)])
+    pv = np.stack([np.asarray(infRes['post_vsm'][i]) for i in range(lo, hi)])
+    pg = np.stack([np.asarray(infRes['post_vsmGP'][i]) for i in range(lo, hi)])
+    sess.ctx.set_posterior(trial_idx[lo:hi], pm, pv, pg)
+    sess.post_stamp += 1
+    return sess
+
+
+class _CostGradCache:
+    """scipy calls fun and jac separately at the same point: evaluate once on the device."""
+
+    def __init__(self, evaluate):
+        self._evaluate = evaluate
+        self._x = None
+        self._val = None
+        self.n_eval = 0
+
+    def _get(self, x):
+        x = np.asarray(x, dtype=np.float64)
+        if self._x is None or not np.array_equal(x, self._x):
+            self._val = self._evaluate(x)
+            self._x = x.copy()
+            self.n_eval += 1
+        return self._val
+
+    def fun(self, x, *args):
+        return self._get(x)[0]
+
+    def jac(self, x, *args):
+        return self._get(x)[1]
+
+
+# ------------------------------------------------------------------------------------------------
+# (C, d)
+# ------------------------------------------------------------------------------------------------
+def MStepObservationCost(vecCd, xdim, ydim, experiment, infRes):
+    """reference learning.py:20-49"""
+    sess = _resident_session(infRes, experiment, xdim)
+    return sess.ctx.mstep_cd_costgrad(vecCd)[0]
+
+
+def MStepObservationCost_grad(vecCd, xdim, ydim, experiment, infRes):
+    """reference learning.py:51-91"""
+    sess = _resident_session(infRes, experiment, xdim)
+    return sess.ctx.mstep_cd_costgrad(vecCd)[1]
+
+
+def learnLTparams(oldParams, infRes, experiment, CdOptimMethod, CdMaxIter=None, verbose=False):
+    """reference learning.py:93-141: same scipy call (method, options) on device-evaluated cost/grad."""
+    ydim, xdim = np.shape(oldParams['C'])
+    sess = _resident_session(infRes, experiment, xdim)
+    cache = _CostGradCache(lambda v: sess.ctx.mstep_cd_costgrad(v))
+    xinit = util.CdtoVecCd(oldParams['C'], oldParams['d'])
+    resCd = op.minimize(fun=cache.fun, x0=xinit, jac=cache.jac, method=CdOptimMethod,
+                        options={'disp': verbose, 'maxiter': CdMaxIter})
+    if verbose:
+        print('Cd optimization successful.' if resCd.success else 'Cd optimization unsuccessful.')
+    newC, newd = util.vecCdtoCd(resCd.x, xdim, ydim)
+    return newC, newd, resCd.fun
+
+
+def learnLTparamsWithPrior(oldParams, infRes, experiment, CdOptimMethod, regularizer_stepsize_Cd, prevInvPriorCov,
+                           covOpts='useDiag', updateCdJointly=True, hessTol=1e-5, verbose=False):
+    """reference learning.py:536-676, 'useDiag' prior with joint (C,d) update (the engine default)."""
+    if covOpts != 'useDiag' or not updateCdJointly:
+        raise NotImplementedError("only covOpts='useDiag' with updateCdJointly=True is built for the GPU path "
+                                  "(the finite-difference Hessian variants are outside the hot path)")
+    ydim, xdim = np.shape(oldParams['C'])
+    sess = _resident_session(infRes, experiment, xdim)
+    old = util.CdtoVecCd(oldParams['C'], oldParams['d'])
+    inv_s2 = 1.0 / regularizer_stepsize_Cd ** 2
+    invPriorCov = -np.diag(np.ones(xdim * ydim + ydim)) / (regularizer_stepsize_Cd ** 2)       # learning.py:580-581
+    cache = _CostGradCache(lambda v: sess.ctx.mstep_cd_costgrad(v, old, inv_s2))
+    kw = dict(fun=cache.fun, x0=old, jac=cache.jac, method=CdOptimMethod, options={'disp': verbose, 'gtol': 1e-10})
+    if CdOptimMethod == 'L-BFGS-B':
+        kw['bounds'] = [(None, None)] * (xdim * ydim + ydim)
+    resCd = op.minimize(**kw)
+    if verbose:
+        print('Cd optimization successful.' if resCd.success else 'Cd optimization unsuccessful.')
+    newC, newd = util.vecCdtoCd(resCd.x, xdim, ydim)
+    return newC, newd, resCd.fun, invPriorCov
+
+
+# ------------------------------------------------------------------------------------------------
+# GP timescales
+# ------------------------------------------------------------------------------------------------
+class DevicePrecomp(list):
+    """makePrecomp result (reference learning.py:145-173) kept on the device; entry k is a small dict
+    with the reference's keys, 'PautoSum' fetched lazily."""
+
+    def __init__(self, sess, T):
+        super().__init__()
+        self.session = sess
+        self.numTrials = sess.ctx.mstep_precomp()
+        self.stamp = sess.post_stamp
+        self._P = None
+        for k in range(sess.p):
+            self.append({'T': T, 'numTrials': self.numTrials, 'latent': k, 'precomp': self})
+
+    def pautosum(self):
+        if self._P is None:
+            self._P = self.session.ctx.pautosum()
+        return self._P
+
+
+def makePrecomp(infRes, experiment=None, xdim=None):
+    """reference learning.py:145-173 (PautoSum_k = sum_r Sigma_r^kk + m_rk m_rk^T), on device."""
+    if isinstance(infRes, DeviceInfRes):
+        sess = infRes.session
+        if infRes.stamp != sess.post_stamp:
+            raise _hip.HipBackendError('this infRes belongs to a superseded E-step')
+    else:
+        if experiment is None:
+            raise ValueError('makePrecomp needs the experiment for a foreign infRes')
+        sess = _resident_session(infRes, experiment, xdim if xdim is not None else np.shape(infRes['post_mean'][0])[0])
+    return DevicePrecomp(sess, sess.T)
+
+
+def _tau_eval(precomp_k, p):
+    pc = precomp_k['precomp']
+    return pc.session.ctx.mstep_tau_costgrad(precomp_k['latent'], float(np.asarray(p).reshape(-1)[0]))
+
+
+def MStepGPtimescaleCost(p, precomp, epsNoise):
+    """reference learning.py:175-214"""
+    return _tau_eval(precomp, p)[0]
+
+
+def MStepGPtimescaleCost_grad(p, precomp, epsNoise):
+    """reference learning.py:216-255"""
+    return np.array([_tau_eval(precomp, p)[1]])
+
+
+def learnGPparams(oldParams, infRes, experiment):
+    """reference learning.py:257-293: per latent scipy BFGS (gtol 1e-8) from p0 = log(1/tau_bins^2)."""
+    xdim = np.shape(oldParams['C'])[1]
+    sess = _resident_session(infRes, experiment, xdim)
+    binSize = experiment.binSize
+    oldTau = np.asarray(oldParams['tau'], dtype=np.float64) * 1000 / binSize
+    precomp = DevicePrecomp(sess, sess.T)
+    tempTau = np.zeros(xdim)
+    details = [[]] * xdim
+    for xd in range(xdim):
+        initp = np.log(1 / oldTau[xd] ** 2)
+        cache = _CostGradCache(lambda v, k=xd: sess.ctx.mstep_tau_costgrad(k, float(np.asarray(v).reshape(-1)[0])))
+        res = op.minimize(fun=cache.fun, x0=initp, jac=lambda v, c=cache: np.array([c.jac(v)]),
+                          options={'disp': False, 'gtol': 1e-8})
+        details[xd] = res
+        tempTau[xd] = (1 / np.exp(res.x[0])) ** 0.5
+    return tempTau * binSize / 1000, details
+
+
+def learnGPparamsWithPrior(oldParams, infRes, experiment, tauOptimMethod, regularizer_stepsize_tau):
+    """reference learning.py:771-830.  The regulariser 0.5*(tau-tau_old)^2/s^2 (tau in seconds) is added to
+    the device cost; its gradient is added WITHOUT the chain-rule factor, exactly as the reference does
+    (learning.py:733-734,769), because the optimiser trajectory - and so the result - depends on it."""
+    xdim = np.shape(oldParams['C'])[1]
+    sess = _resident_session(infRes, experiment, xdim)
+    binSize = experiment.binSize
+    tau_old = np.asarray(oldParams['tau'], dtype=np.float64)
+    oldTau = tau_old * 1000 / binSize
+    DevicePrecomp(sess, sess.T)
+    s = regularizer_stepsize_tau
+    tempTau = np.zeros(xdim)
+    details = [[]] * xdim
+    for xd in range(xdim):
+        initp = np.log(1 / oldTau[xd] ** 2)
+
+        def evaluate(v, k=xd):
+            pv = float(np.asarray(v).reshape(-1)[0])
+            cost, grad = sess.ctx.mstep_tau_costgrad(k, pv)
+            tau = binSize / 1000 * (1 / np.exp(pv)) ** 0.5
+            return cost + 0.5 * (tau - tau_old[k]) ** 2 / s ** 2, grad + (tau - tau_old[k]) / s ** 2
+
+        cache = _CostGradCache(evaluate)
+        res = op.minimize(fun=cache.fun, x0=initp, jac=lambda v, c=cache: np.array([c.jac(v)]),
+                          options={'disp': False, 'gtol': 1e-10}, method=tauOptimMethod)
+        details[xd] = res
+        tempTau[xd] = (1 / np.exp(np.asarray(res.x).reshape(-1)[0])) ** 0.5
+    return tempTau * binSize / 1000, details
+
+
+# ------------------------------------------------------------------------------------------------
+def updateParams(oldParams, infRes, experiment, CdOptimMethod='BFGS', CdMaxIter=None, tauMaxIter=None, verbose=False):
+    """reference learning.py:295-309"""
+    if verbose:
+        print('Learning C,d...')
+    newC, newd, obsOptimDetails = learnLTparams(oldParams, infRes, experiment, CdOptimMethod, CdMaxIter, verbose)
+    if verbose:
+        print('Learning GP timescale constants')
+    newTau, dynOptimDetails = learnGPparams(oldParams, infRes, experiment)
+    return {'C': newC, 'd': newd, 'tau': newTau}, {'Cd': obsOptimDetails, 'tau': dynOptimDetails}
+
+
+def updateParamsWithPrior(oldParams, infRes, experiment, CdOptimMethod, tauOptimMethod, regularizer_stepsize_Cd,
+                          regularizer_stepsize_tau, prevInvPriorCov, covOpts='useHessian', verbose=False,
+                          updateCdJointly=True, hessTol=1e-5):
+    """reference learning.py:833-866 (covOpts='useDiag' is what the engine's default 'diag' mode passes)."""
+    if verbose:
+        print('Learning C,d...')
+    newC, newd, obsOptimDetails, invPriorCov = learnLTparamsWithPrior(
+        oldParams, infRes, experiment, CdOptimMethod, regularizer_stepsize_Cd, prevInvPriorCov,
+        covOpts=covOpts, updateCdJointly=updateCdJointly, hessTol=hessTol, verbose=verbose)
+    if verbose:
+        print('Learning GP timescale constants')
+    newTau, dynOptimDetails = learnGPparamsWithPrior(oldParams, infRes, experiment, tauOptimMethod, regularizer_stepsize_tau)
+    return {'C': newC, 'd': newd, 'tau': newTau}, {'Cd': obsOptimDetails, 'tau': dynOptimDetails}, invPriorCov

@@ -1,0 +1,176 @@
+"""Host utilities on either side of the hot path, with the names of the reference's funs/util.py:
+vec layout helpers, the builders (Gram matrices come from the device kernel), trial subsampling with
+the reference's RNG stream, the synthetic population generator and the Poisson-PCA initialiser.
+Plotting, CRCNS/Matlab loaders and cross-validation helpers of the reference are outside the hot
+path and are not provided."""
+import copy
+import sys
+
+import numpy as np
+
+from . import _hip
+
+
+class Printer:
+    """One-line progress output (reference util.py:121-128)."""
+
+    def __init__(self, data):
+        sys.stdout.write('\r\x1b[K' + str(data))
+        sys.stdout.flush()
+
+    @staticmethod
+    def stdout(message):
+        sys.stdout.write(message)
+        sys.stdout.write('\b' * len(message))
+
+
+# -- vec(C, d) layout (reference util.py:560-592) ----------------------------------------------------
+def CdtoVecCd(C, d):
+    C = np.asarray(C, dtype=np.float64)
+    d = np.asarray(d, dtype=np.float64).reshape(-1)
+    return np.concatenate((C.T.ravel(), d))
+
+
+def vecCdtoCd(vecCd, xdim, ydim):
+    m = np.asarray(vecCd, dtype=np.float64).reshape(xdim + 1, ydim)
+    return m[:xdim].T, m[xdim]
+
+
+# -- builders (reference util.py:594-619) ---------------------------------------------------------------
+def makeCd_big(params, T):
+    """Kronecker expansion of (C, d).  Only for small diagnostics: the device path never forms it."""
+    C_big = np.kron(params['C'], np.eye(T)).T
+    d_big = np.kron(np.ndarray.flatten(np.asarray(params['d'])), np.ones(T)).T
+    return C_big, d_big
+
+
+def makeK_big(params, trialDur, binSize, epsNoise=0.001):
+    """Per-latent RBF Gram matrices K (xdim,T,T) from the device kernel, and their block-diagonal K_big."""
+    ydim, xdim = np.shape(params['C'])
+    params['tau'] = np.ndarray.flatten(np.asarray(params['tau'], dtype=np.float64))
+    T = int(trialDur / binSize)
+    ctx = _hip.Context(ydim, xdim, T, 1, float(binSize))
+    try:
+        ctx.set_option('eps_noise', epsNoise)
+        ctx.set_params(np.asarray(params['C'], dtype=np.float64), np.zeros(ydim), params['tau'])
+        K = ctx.gram()
+    finally:
+        ctx.close()
+    K_big = np.zeros((xdim * T, xdim * T))
+    for xd in range(xdim):
+        K_big[xd * T:(xd + 1) * T, xd * T:(xd + 1) * T] = K[xd]
+    return K_big, K
+
+
+# -- minibatches (reference util.py:449-473) ---------------------------------------------------------------
+def subsampleTrials(experiment, batchSize):
+    """Same draw from the global legacy RNG as the reference (np.random.choice without replacement);
+    the returned shallow copy remembers its parent so the device keeps using the resident counts."""
+    numTrials = len(experiment.data)
+    batchTrIdx = np.random.choice(numTrials, batchSize, replace=False)
+    sub = copy.copy(experiment)
+    sub.data = [experiment.data[i] for i in batchTrIdx]
+    sub.numTrials = batchSize
+    sub.batchTrIdx = batchTrIdx
+    sub._pgpfa_parent = getattr(experiment, '_pgpfa_parent', experiment)
+    if hasattr(experiment, 'batchTrIdx') and getattr(experiment, '_pgpfa_parent', None) is not None:
+        sub.batchTrIdx = np.asarray(experiment.batchTrIdx)[batchTrIdx]
+    return sub
+
+
+def seenTrials(experiment, seenIdx):
+    idx = np.asarray(seenIdx).flatten()
+    seen = copy.copy(experiment)
+    seen.data = [experiment.data[i] for i in idx]
+    seen.numTrials = len(seen.data)
+    return seen
+
+
+# -- synthetic population (distributions of reference util.py:705-750) ---------------------------------------
+class dataset:
+    """Trials of population spike counts sampled from  x_k ~ GP(0, K(tau_k)),  y ~ Poisson(exp(Cx+d)).
+
+    Attributes as in the reference: data (list of {'X','Y'}), xdim, ydim, T, trialDur, binSize, numTrials,
+    seed, params.  `sampler='reference'` reproduces the reference's global-RNG stream bit for bit
+    (multivariate_normal on the (xdim*T)^2 covariance: small sizes only); `sampler='cholesky'` draws the
+    same distributions per latent through T x T factors from numpy's Generator (for the large configs).
+    """
+
+    def __init__(self, trialDur=1000, binSize=10, drawSameX=False, numTrials=20, xdim=3, ydim=30, seed=12, dOffset=-1,
+                 fixTau=False, fixedTau=None, params=None, model='pgpfa', sampler='reference', verbose=False):
+        if model != 'pgpfa':
+            raise NotImplementedError("only model='pgpfa' is on the hot path")
+        self.trialDur, self.binSize, self.drawSameX = trialDur, binSize, drawSameX
+        self.numTrials, self.xdim, self.ydim, self.seed = numTrials, xdim, ydim, seed
+        self.T = int(trialDur / binSize)
+        T = self.T
+        np.random.seed(seed)
+        if params is None:
+            params = {'C': np.random.rand(ydim, xdim) - 0.5,
+                      'd': np.random.rand(ydim) * (-2) + dOffset,
+                      'tau': np.abs(np.random.rand(xdim)) + 0.01}
+            if fixTau:
+                params['tau'] = np.asarray(fixedTau, dtype=np.float64)
+        self.params = params
+        tau = np.asarray(params['tau'], dtype=np.float64).reshape(-1)
+        t = np.arange(T, dtype=np.float64) * binSize
+        dsq = (t[:, None] - t[None, :]) ** 2
+        K = np.stack([0.999 * np.exp(-0.5 * (dsq / (tk * 1000.0) ** 2)) + 0.001 * np.eye(T) for tk in tau])
+        offset = np.asarray(params['d'], dtype=np.float64)[:, None]
+        data = []
+        if sampler == 'reference':
+            K_big = np.zeros((xdim * T, xdim * T))
+            for k in range(xdim):
+                K_big[k * T:(k + 1) * T, k * T:(k + 1) * T] = K[k]
+            draw = lambda: np.reshape(np.random.multivariate_normal(np.zeros(T * xdim), K_big, 1), [xdim, T])
+            pois = lambda lam: np.random.poisson(lam=lam)
+        elif sampler == 'cholesky':
+            rng = np.random.default_rng(seed)
+            Lk = np.linalg.cholesky(K)
+            draw = lambda: np.einsum('kts,ks->kt', Lk, rng.standard_normal((xdim, T)))
+            pois = lambda lam: rng.poisson(lam)
+        else:
+            raise ValueError("sampler must be 'reference' or 'cholesky'")
+        X0 = draw() if drawSameX else None
+        for i in range(numTrials):
+            X = X0 if drawSameX else draw()
+            data.append({'X': X, 'Y': pois(np.exp(params['C'] @ X + offset))})
+            if verbose:
+                Printer('Sampling trial %d ...' % (i + 1))
+        self.data = data
+
+    def getAllRaster(self):
+        self.all_raster = np.concatenate([tr['Y'] for tr in self.data], axis=1)
+        return self.all_raster
+
+    def getAvgFiringRate(self):
+        self.avgFR = float(np.mean(self.getAllRaster()) / self.binSize * 1000.0)
+        return self.avgFR
+
+
+def initializeParams(xdim, ydim, experiment=None):
+    """Poisson-PCA initialiser (reference util.py:505-558): moment-matched log-rate covariance ->
+    leading eigenvectors -> C; d = log mean rate; tau ~ U(0.1, 0.6) s from the global RNG."""
+    if experiment is None:
+        return {'C': np.random.rand(ydim, xdim) * 2 - 1, 'd': np.random.randn(ydim) * 2 - 2, 'tau': np.random.rand(xdim) * 0.5}
+    spikes = np.concatenate([np.asarray(tr['Y'], dtype=np.float64) for tr in experiment.data], axis=1)
+    meanY = np.mean(spikes, 1) + 1e-10
+    covY = np.cov(spikes)
+    outer = np.outer(meanY, meanY)
+    lamb = np.log(np.abs(covY + outer - np.diag(meanY))) - np.log(outer)
+    evals, evecs = np.linalg.eig(lamb)
+    order = np.argsort(evals)[::-1]
+    return {'C': evecs[:, order][:, :xdim], 'd': np.log(meanY), 'tau': np.random.rand(xdim) * 0.5 + 0.1}
+
+
+def subspaceAngle(F, G):
+    """Largest principal angle between the column spaces of F and G (reference util.py:338-367),
+    columns scaled by their maximum entry first as the reference does."""
+    F = np.array(F, dtype=np.float64)
+    G = np.array(G, dtype=np.float64)
+    F = F / np.max(F, axis=0)
+    G = G / np.max(G, axis=0)
+    QF, _ = np.linalg.qr(F)
+    QG, _ = np.linalg.qr(G)
+    s = np.linalg.svd(QF.T @ QG, compute_uv=False)
+    return float(np.max(np.arccos(np.minimum(s, 1.0))))

@@ -1,0 +1,144 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/pgpfa.h declares, the
+host utilities reproduce the reference's layouts and RNG streams, the product fails loudly without a
+GPU, and the trial-sharding arithmetic (2 ranks, gloo) reproduces the unsharded statistics."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+from oracle import pgpfa_oracle as orc
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as ge
+    ge.build()
+    from funs import _hip
+    lib = _hip.load_library()
+    header = open(os.path.join(ROOT, 'include', 'pgpfa.h')).read()
+    declared = sorted(set(re.findall(r'\b(pgpfa_[a-z0-9_]+)\s*\(', header)))
+    assert declared, 'no declarations parsed'
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert sorted(_hip.EXPORTED_SYMBOLS) == declared
+    assert lib.pgpfa_version() >= 100
+
+
+def test_no_gpu_means_loud_failure():
+    """No CPU fallback: without a device the context constructor raises."""
+    from funs import _hip
+    if _hip.device_count() > 0:
+        pytest.skip('a GPU is visible')
+    with pytest.raises(_hip.HipBackendError):
+        _hip.Context(4, 2, 10, 2, 10.0)
+    from funs import inference
+    from conftest import Experiment
+    exp = Experiment([np.zeros((4, 10)), np.zeros((4, 10))], 10.0)
+    with pytest.raises(_hip.HipBackendError):
+        inference.laplace(exp, {'C': np.zeros((4, 2)), 'd': np.zeros(4), 'tau': np.ones(2) * 0.1})
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'poisson-gpfa_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h')):
+                src = open(os.path.join(dirpath, f)).read()
+                assert 'pgpfa_oracle' not in src and 'import oracle' not in src and 'from oracle' not in src, f
+
+
+def test_vec_layout_matches_reference(c1):
+    from funs import util
+    g = load_golden('c1_callbacks.npz')
+    v = util.CdtoVecCd(c1['init_C'], c1['init_d'])
+    assert np.array_equal(v, g['vecCd0'])
+    C, d = util.vecCdtoCd(v, 3, 30)
+    assert np.array_equal(C, c1['init_C']) and np.array_equal(d, c1['init_d'])
+
+
+def test_dataset_generator_reproduces_reference_stream(c1):
+    """util.dataset() defaults == config 1; the reference sampler must give the golden counts bit for bit."""
+    from funs import util
+    ds = util.dataset()
+    Y = np.stack([tr['Y'] for tr in ds.data])
+    assert np.array_equal(Y, c1['Y'])
+    assert np.array_equal(ds.params['C'], c1['true_C']) and np.array_equal(ds.params['d'], c1['true_d'])
+    np.random.seed(0)
+    init = util.initializeParams(3, 30, ds)
+    assert np.max(np.abs(init['C'] - c1['init_C'])) <= 1e-12
+    assert np.max(np.abs(init['d'] - c1['init_d'])) <= 1e-14
+    assert np.array_equal(init['tau'], c1['init_tau'])
+    big = util.dataset(trialDur=400, numTrials=3, xdim=2, ydim=6, seed=3, sampler='cholesky')
+    assert big.data[0]['Y'].shape == (6, 40) and big.T == 40
+
+
+def test_subsample_stream_matches_reference(c1_experiment):
+    from funs import util
+    g = load_golden('c1_em_online.npz')
+    np.random.seed(1)
+    for it in range(4):
+        sub = util.subsampleTrials(c1_experiment, 5)
+        assert np.array_equal(sub.batchTrIdx, g['batchTrIdx'][it])
+        assert sub._pgpfa_parent is c1_experiment and sub.numTrials == 5
+        assert all(sub.data[i] is c1_experiment.data[j] for i, j in enumerate(sub.batchTrIdx))
+
+
+def test_shard_slices_partition():
+    from funs._session import shard_slice
+    for n in (0, 1, 7, 20, 1024, 1025):
+        for size in (1, 2, 3, 8):
+            cuts = [shard_slice(n, r, size) for r in range(size)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            assert all(cuts[i][1] == cuts[i + 1][0] for i in range(size - 1))
+            lens = [b - a for a, b in cuts]
+            assert max(lens) - min(lens) <= 1
+
+
+_WORKER = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, 'poisson-gpfa_amd'))
+from oracle import pgpfa_oracle as orc
+from funs._session import shard_slice
+rank, size = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+dist.init_process_group('gloo', rank=rank, world_size=size)
+g = np.load(os.path.join({root!r}, 'tests', 'golden', 'c1_dataset.npz'))
+Ys = [g['Y'][r].astype(float) for r in range(6)]
+params = {{'C': g['init_C'], 'd': g['init_d'], 'tau': g['init_tau']}}
+lo, hi = shard_slice(len(Ys), rank, size)
+mine = Ys[lo:hi]
+res, nll, _ = orc.laplace(mine, params, 10.0, mode='exact', return_cov=False)
+v = orc.cd_to_vec(params['C'], params['d']) * 1.01
+f, dC, dd = orc.mstep_cd_terms(v, mine, res['post_mean'], res['post_vsm'], 3, 30)
+P, n = orc.make_precomp(res)
+buf = torch.from_numpy(np.concatenate([[-nll * len(mine), len(mine), f], dC.ravel(), dd, P.ravel()]))
+dist.all_reduce(buf)
+if rank == 0:
+    np.save(os.environ['OUT'], buf.numpy())
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_gloo_sharded_statistics_equal_unsharded(tmp_path):
+    """Trial-sharded sufficient statistics (objective sum, (C,d) cost/grad sums, PautoSum) summed over
+    2 gloo ranks equal the unsharded ones up to summation order - the contract the RCCL path relies on."""
+    script = tmp_path / 'worker.py'
+    script.write_text(_WORKER.format(root=ROOT))
+    out = tmp_path / 'reduced.npy'
+    env = dict(os.environ, OUT=str(out), OMP_NUM_THREADS='2')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+           '--master-port', '29617', str(script)]
+    subprocess.run(cmd, check=True, env=env, timeout=550)
+    red = np.load(out)
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'c1_dataset.npz'))
+    Ys = [g['Y'][r].astype(float) for r in range(6)]
+    params = {'C': g['init_C'], 'd': g['init_d'], 'tau': g['init_tau']}
+    res, nll, _ = orc.laplace(Ys, params, 10.0, mode='exact', return_cov=False)
+    v = orc.cd_to_vec(params['C'], params['d']) * 1.01
+    f, dC, dd = orc.mstep_cd_terms(v, Ys, res['post_mean'], res['post_vsm'], 3, 30)
+    P, n = orc.make_precomp(res)
+    ref = np.concatenate([[-nll * 6, 6, f], dC.ravel(), dd, P.ravel()])
+    assert np.max(np.abs(red - ref) / (1.0 + np.abs(ref))) <= 1e-10

@@ -1,0 +1,163 @@
+"""End-to-end parity of the HIP path with the oracle and the golden vectors captured from the
+reference.  GPU only; everything goes through the drop-in `funs` surface or the C-ABI wrapper.
+Tolerances: vs the polished/exact mode 1e-8; vs the reference's own early-stopped
+answers max|dx| <= 5e-3, |dnll| <= 1e-4, max|dvecCd| <= 1e-4 (one M-step), |dlog gamma| <= 1e-5;
+full EM nll 1e-3 abs, parameters 1e-3 rel."""
+import numpy as np
+import pytest
+
+from conftest import Experiment, load_golden
+from oracle import pgpfa_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(1e-300, np.max(np.abs(b)))
+
+
+@pytest.fixture(scope='module')
+def funs_mod():
+    import funs
+    return funs
+
+
+def test_estep_c1_vs_polished_and_reference(funs_mod, c1, c1_experiment):
+    g = load_golden('c1_laplace.npz')
+    params = {k: v.copy() for k, v in c1['init'].items()}
+    infRes, nll, opt = funs_mod.inference.laplace(c1_experiment, params)
+    assert np.all(infRes.newton_status == 0)
+    pm = np.stack([infRes['post_mean'][r] for r in range(20)])
+    # polished modes of the reference's own objective
+    assert np.max(np.abs(pm.reshape(20, -1) - g['polished'])) <= 1e-8
+    # the reference's early-stopped answers
+    assert np.max(np.abs(pm - g['post_mean'])) <= 5e-3
+    assert abs(nll - float(g['nll'])) <= 1e-4
+    # covariance blocks: vs the oracle at the exact mode (tight) and vs the reference (loose)
+    res, nll_o, _ = orc.laplace(c1['Ys'], c1['init'], c1['binSize'], mode='exact', return_cov=True)
+    assert abs(nll - nll_o) <= 1e-9 * abs(nll_o)
+    for r in (0, 7, 19):
+        assert rel(infRes['post_vsm'][r], res['post_vsm'][r]) <= 1e-8
+        assert rel(infRes['post_vsmGP'][r], res['post_vsmGP'][r]) <= 1e-8
+        assert rel(infRes['post_vsm'][r], g['post_vsm'][r]) <= 1e-3
+    assert rel(infRes['post_cov'][0], res['post_cov'][0]) <= 1e-8
+    assert infRes['post_cov'][0].shape == (300, 300)
+    assert len(opt) == 20 and opt[3].shape == (300,)
+    # properties: symmetry / positive definiteness of the posterior covariance
+    S = infRes['post_cov'][5]
+    assert np.max(np.abs(S - S.T)) <= 1e-12 and np.min(np.linalg.eigvalsh(S)) > 0
+
+
+def test_estep_warm_start_and_subset(funs_mod, c1, c1_experiment):
+    params = {k: v.copy() for k, v in c1['init'].items()}
+    infRes, nll, opt = funs_mod.inference.laplace(c1_experiment, params)
+    cold_iters = infRes.newton_iters.copy()
+    # warm start from resident modes: converges in at most 2 factorizations, same answer
+    infRes2, nll2, _ = funs_mod.inference.laplace(c1_experiment, params, prevOptimRes=opt)
+    assert np.max(infRes2.newton_iters) <= 2 < np.max(cold_iters)
+    assert abs(nll2 - nll) <= 1e-10 * abs(nll)
+    # warm start from host arrays (what a caller holding the reference's lapOptimRes would pass)
+    host = [np.asarray(infRes2['post_mean'][r]).reshape(-1) + 1e-3 for r in range(20)]
+    infRes3, nll3, _ = funs_mod.inference.laplace(c1_experiment, params, prevOptimRes=host)
+    assert abs(nll3 - nll) <= 1e-10 * abs(nll)
+    # a minibatch through util.subsampleTrials reuses the resident counts
+    np.random.seed(4)
+    sub = funs_mod.util.subsampleTrials(c1_experiment, 5)
+    infS, nllS, _ = funs_mod.inference.laplace(sub, params)
+    Ys = [c1['Ys'][i] for i in sub.batchTrIdx]
+    _, nll_o, _ = orc.laplace(Ys, c1['init'], c1['binSize'], mode='exact', return_cov=False)
+    assert abs(nllS - nll_o) <= 1e-9 * abs(nll_o)
+
+
+def test_mstep_results_vs_reference(funs_mod, c1, c1_experiment):
+    """One full M-step (TNC for C,d; BFGS for tau) after our E-step, against the reference's result."""
+    g = load_golden('c1_mstep.npz')
+    params = {k: v.copy() for k, v in c1['init'].items()}
+    infRes, nll, _ = funs_mod.inference.laplace(c1_experiment, params)
+    new, det = funs_mod.learning.updateParams(params, infRes, c1_experiment, CdOptimMethod='TNC')
+    v = orc.cd_to_vec(new['C'], new['d'])
+    assert np.max(np.abs(v - orc.cd_to_vec(g['newC'], g['newd']))) <= 1e-4
+    assert np.max(np.abs(v - g['tight_vec'])) <= 1e-3
+    assert np.max(np.abs(np.log(new['tau']) - np.log(g['newTau']))) <= 1e-5
+    # the same M-step through the oracle on the oracle's exact E-step: same optimiser, same inputs
+    res, _, _ = orc.laplace(c1['Ys'], c1['init'], c1['binSize'], mode='exact', return_cov=False)
+    C_o, d_o, _, _ = orc.learn_cd(c1['init'], c1['Ys'], res, 'TNC')
+    tau_o, _ = orc.learn_tau(c1['init'], res, c1['binSize'])
+    assert np.max(np.abs(v - orc.cd_to_vec(C_o, d_o))) <= 1e-5
+    assert np.max(np.abs(np.log(new['tau']) - np.log(tau_o))) <= 1e-7
+
+
+def test_mstep_accepts_reference_style_infres(funs_mod, c1, c1_experiment):
+    """A plain dict infRes (as the reference produces) is uploaded and gives the same cost."""
+    lap = load_golden('c1_laplace.npz')
+    res, _, _ = orc.laplace(c1['Ys'], c1['init'], c1['binSize'], mode='exact', return_cov=False)
+    g = load_golden('c1_mstep.npz')
+    cost = funs_mod.learning.MStepObservationCost(g['v1'], 3, 30, c1_experiment, res)
+    cref = orc.mstep_cd_cost(g['v1'], c1['Ys'], res['post_mean'], res['post_vsm'], 3, 30)
+    assert abs(cost - cref) <= 1e-10 * abs(cref)
+    del lap
+
+
+def test_batch_em_vs_reference(funs_mod, c1, c1_experiment):
+    g = load_golden('c1_em_batch.npz')
+    init = {k: v.copy() for k, v in c1['init'].items()}
+    fit = funs_mod.engine.PPGPFAfit(c1_experiment, initParams=init, inferenceMethod='laplace', EMmode='Batch',
+                                    maxEMiter=5, quiet=True)
+    assert np.max(np.abs(np.asarray(fit.posteriorLikelihood) - g['nll'])) <= 1e-3
+    for i in range(1, 6):
+        assert rel(fit.paramSeq[i]['C'], g['seq_C'][i]) <= 1e-3
+        assert rel(fit.paramSeq[i]['d'], g['seq_d'][i]) <= 1e-3
+        assert rel(fit.paramSeq[i]['tau'], g['seq_tau'][i]) <= 1e-3
+    assert len(fit.inferenceTime) == 5 and len(fit.learningTime) == 5
+    assert fit.tauSeq.shape == (3, 5)
+    # monotone E-step objective across EM iterations on this data set (reference shows the same)
+    assert np.all(np.diff(fit.posteriorLikelihood) > 0)
+
+
+def test_online_em_vs_reference(funs_mod, c1, c1_experiment):
+    g = load_golden('c1_em_online.npz')
+    init = {k: v.copy() for k, v in c1['init'].items()}
+    np.random.seed(1)
+    fit = funs_mod.engine.PPGPFAfit(c1_experiment, initParams=init, inferenceMethod='laplace', EMmode='Online',
+                                    maxEMiter=4, batchSize=5, onlineParamUpdateMethod='diag', quiet=True)
+    assert np.max(np.abs(np.asarray(fit.posteriorLikelihood) - g['nll'])) <= 1e-3
+    assert rel(fit.paramSeq[-1]['C'], g['seq_C'][-1]) <= 1e-3
+    assert rel(fit.paramSeq[-1]['d'], g['seq_d'][-1]) <= 1e-3
+    assert rel(fit.paramSeq[-1]['tau'], g['seq_tau'][-1]) <= 2e-3
+
+
+def test_c2_size_spot_check(funs_mod):
+    """(100 neurons, 5 latents, T=200): n = 1000 crosses the 512-wide super-panel logic."""
+    g = load_golden('c2_spot.npz')
+    Ys = [g['Y'][r].astype(float) for r in range(2)]
+    exp = Experiment(Ys, float(g['binSize']))
+    params = {'C': g['init_C'].copy(), 'd': g['init_d'].copy(), 'tau': g['init_tau'].copy()}
+    infRes, nll, _ = funs_mod.inference.laplace(exp, params)
+    assert np.all(infRes.newton_status == 0)
+    for r in range(2):
+        assert np.max(np.abs(infRes['post_mean'][r] - g['post_mean'][r])) <= 5e-3
+        assert rel(infRes['post_vsm'][r], g['post_vsm'][r]) <= 1e-3
+        d = np.stack([np.diag(infRes['post_vsmGP'][r][:, :, k]) for k in range(5)])
+        assert rel(d, g['post_vsmGP_diag'][r]) <= 1e-3
+    assert abs(nll - float(g['nll'])) <= 1e-4 * max(1.0, abs(float(g['nll'])))
+    res, nll_o, _ = orc.laplace(Ys[:1], params, float(g['binSize']), mode='exact', return_cov=False)
+    assert np.max(np.abs(infRes['post_mean'][0] - res['post_mean'][0])) <= 1e-7
+    assert rel(infRes['post_vsm'][0], res['post_vsm'][0]) <= 1e-8
+
+
+def test_ragged_sizes_and_single_trial(funs_mod):
+    """Odd sizes: T not a multiple of anything, q < 32, p = 1 and p = 7, a single trial."""
+    for (q, p, T, R, seed) in ((5, 1, 37, 1, 2), (13, 7, 41, 3, 5), (70, 4, 130, 2, 9)):
+        params_true, Ys, _ = orc.synth_dataset(q, p, T, R, seed=seed, dOffset=0.0)
+        exp = Experiment(Ys, 10.0)
+        rng = np.random.default_rng(seed)
+        params = {'C': 0.3 * rng.standard_normal((q, p)), 'd': np.log(np.mean(np.concatenate(Ys, 1), 1) + 0.1),
+                  'tau': 0.1 + 0.4 * rng.random(p)}
+        infRes, nll, _ = funs_mod.inference.laplace(exp, params)
+        res, nll_o, _ = orc.laplace(Ys, params, 10.0, mode='exact', return_cov=False)
+        assert np.all(infRes.newton_status == 0)
+        assert abs(nll - nll_o) <= 1e-9 * max(1.0, abs(nll_o))
+        for r in range(R):
+            assert np.max(np.abs(infRes['post_mean'][r] - res['post_mean'][r])) <= 1e-7
+            assert rel(infRes['post_vsm'][r], res['post_vsm'][r]) <= 1e-8
+            assert rel(infRes['post_vsmGP'][r], res['post_vsmGP'][r]) <= 1e-8
