@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""Headline benchmark: EM iterations/s of the Poisson-GPFA hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c2|c1] [--no-cpu-baseline]
+
+A step is one full batch-EM iteration on synthetic spike counts already resident in HBM: Laplace
+E-step over every trial (Newton mode search with a dense FP64 Cholesky per step, posterior covariance
+blocks) followed by the M-step for C, d (scipy TNC driving the HIP cost/grad kernel, as the reference
+does) and the GP timescales (scipy BFGS driving the HIP Gram/Cholesky/trace kernels).
+
+Workload (BASELINE.json): config 3 = 200 neurons, 10 latents, 500 bins, 1024 trials per GPU - the
+configuration the north-star target is quoted on.  For N > 1 the driver launches one rank per GPU with
+torch.distributed.run; every rank owns 1024 trials (weak scaling, config 4's 8192 trials at N = 8), the
+M-step sufficient statistics are summed with RCCL all-reduces.  `value` counts EM iterations per
+second in units of 1024-trial batches: at N = 1 it is plain EM iterations/s on config 3.
+
+Prints ONE JSON line (rank 0).  The timed region is bracketed by a collective + device sync on both
+sides and the reported time is the max over ranks.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for path in (ROOT, os.path.join(ROOT, 'poisson-gpfa_amd')):
+    if path not in sys.path:
+        sys.path.insert(0, path)
+
+CONFIGS = {   # name: (neurons, latents, bins, trials per GPU)
+    'c1': (30, 3, 100, 20),
+    'c2': (100, 5, 200, 256),
+    'c3': (200, 10, 500, 1024),
+}
+FP64_MATRIX_PEAK_TFLOPS = 78.6     # MI355X FP64 matrix (= FP64 vector) peak, AMD CDNA4 datasheet
+
+
+class Shard:
+    """Duck-typed experiment (reference engine.py:32-38) holding this rank's trials."""
+
+    def __init__(self, Ys, bin_ms):
+        self.data = [{'Y': y} for y in Ys]
+        self.ydim, self.T = Ys[0].shape
+        self.binSize = bin_ms
+        self.trialDur = self.T * bin_ms
+        self.numTrials = len(Ys)
+        self._pgpfa_local_shard = True
+
+
+def synth_shard(q, p, T, R, seed, rank):
+    """Reference recipe (util.py:705-750): C~U(-.5,.5), d~U(-2,0)-1, tau~U(0,1)+.01 s from the legacy
+    global RNG (identical on every rank); trials of this rank drawn per latent through T x T Cholesky
+    factors from a Generator seeded with (seed, rank)."""
+    np.random.seed(seed)
+    C = np.random.rand(q, p) - 0.5
+    d = np.random.rand(q) * (-2) - 1.0
+    tau = np.abs(np.random.rand(p)) + 0.01
+    t = np.arange(T, dtype=np.float64) * 10.0
+    dsq = (t[:, None] - t[None, :]) ** 2
+    L = np.stack([np.linalg.cholesky(0.999 * np.exp(-0.5 * dsq / (tk * 1000.0) ** 2) + 0.001 * np.eye(T)) for tk in tau])
+    rng = np.random.default_rng([seed, rank])
+    Ys = []
+    for _ in range(R):
+        X = np.einsum('kts,ks->kt', L, rng.standard_normal((p, T)))
+        Ys.append(rng.poisson(np.exp(C @ X + d[:, None])).astype(np.uint8))
+    return {'C': C, 'd': d, 'tau': tau}, Ys
+
+
+def cpu_baseline(q, p, T, R, true_params, Y0, bin_ms, init):
+    """Reference-faithful CPU path (the oracle in 'faithful' mode = the reference's big-matrix
+    arithmetic and scipy drivers), timed on a bounded sample and scaled to one EM iteration."""
+    from oracle import pgpfa_oracle as orc
+    import scipy.optimize as op  # noqa: F401
+    cores = os.cpu_count()
+    n = p * T
+    Ys = [Y0.astype(np.float64)]
+    t0 = time.time()
+    if n <= 1200:
+        # small enough to run whole trials: faithful Laplace E-step on a few trials
+        ntr = 2 if n > 400 else 8
+        Ys = [Y0.astype(np.float64)] * ntr
+        orc.laplace(Ys, init, bin_ms, mode='faithful', return_cov=True)
+        per_trial = (time.time() - t0) / ntr
+        sample = '%d full trials of the faithful Laplace E-step (scipy Newton-CG on the big-matrix callbacks)' % ntr
+    else:
+        # config 3: one trial is ~4-5 minutes of CPU; time its unit of work instead - one dense Hessian
+        # build (inference.py:50-65) and one dense inverse - and scale by the reference's measured count
+        # of 15 Hessian builds per trial at this size
+        K = orc.make_K(init['tau'], T, bin_ms)
+        C_big, d_big = orc.make_Cd_big(init['C'], init['d'], T)
+        K_bigInv = np.linalg.inv(orc.make_K_big(K))
+        x = np.zeros(n)
+        ybar = Ys[0].reshape(-1)
+        t1 = time.time()
+        H = orc.nlp_big_hess(x, ybar, C_big, d_big, K_bigInv)
+        t_h = time.time() - t1
+        t1 = time.time()
+        np.linalg.inv(H)
+        t_i = time.time() - t1
+        per_trial = 15 * t_h + t_i
+        sample = ('1 dense Hessian build (%.1f s) + 1 dense inverse (%.1f s) of one config-3 trial; per-trial E-step = '
+                  '15 builds + 1 inverse (iteration count measured on the reference, BASELINE.md); M-step not counted' % (t_h, t_i))
+    em_iter_s = per_trial * R
+    return {'value': 1.0 / em_iter_s, 'unit': 'EM-iterations/s', 'cores': cores, 'kind': 'port', 'sample': sample,
+            'estep_s_per_trial': per_trial}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--config', default='c3', choices=sorted(CONFIGS))
+    ap.add_argument('--trials', type=int, default=0, help='override trials per GPU')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--seed', type=int, default=12)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        if args.gpus != 1 and world == 1:
+            raise SystemExit('bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)' % args.gpus)
+    q, p, T, R = CONFIGS[args.config]
+    if args.trials > 0:
+        R = args.trials
+    bin_ms = 10.0
+
+    import funs
+    from funs import _hip, _session
+
+    true_params, Ys = synth_shard(q, p, T, R, args.seed, rank)
+    exp = Shard(Ys, bin_ms)
+    sess, _ = _session.session_for(exp, p)
+    # Poisson-PCA initialiser on rank 0's shard (reference util.py:505-558), shared with every rank
+    np.random.seed(0)
+    init = funs.util.initializeParams(p, q, exp)
+    if world > 1:
+        flat = np.concatenate([init['C'].ravel(), init['d'], init['tau']])
+        flat = sess.allreduce(flat if rank == 0 else np.zeros_like(flat))
+        init = {'C': flat[:q * p].reshape(q, p), 'd': flat[q * p:q * p + q], 'tau': flat[q * p + q:]}
+    init = {k: np.real(np.asarray(v)).astype(np.float64) for k, v in init.items()}
+
+    def barrier():
+        sess.allreduce(np.zeros(1))
+
+    params = init
+    optim = None
+    nll_hist, estep_ms, mstep_ms, facts = [], [], [], []
+
+    def em_step():
+        nonlocal params, optim
+        t0 = time.time()
+        infRes, nll, optim = funs.inference.laplace(exp, params, prevOptimRes=optim)
+        t1 = time.time()
+        params, _ = funs.learning.updateParams(params, infRes, exp, CdOptimMethod='TNC')
+        t2 = time.time()
+        nll_hist.append(float(nll))
+        estep_ms.append((t1 - t0) * 1e3)
+        mstep_ms.append((t2 - t1) * 1e3)
+        facts.append(sess.ctx.info('last_newton_factorizations'))
+
+    for _ in range(args.warmup):
+        em_step()
+    sess.ctx.set_option('profile', 1)
+    barrier()
+    t_begin = time.time()
+    for _ in range(args.steps):
+        em_step()
+    barrier()
+    elapsed = time.time() - t_begin
+    gemm_ms = sess.ctx.info('prof_gemm_ms')
+    gemm_flops = sess.ctx.info('prof_gemm_flops')
+    gemm_launches = sess.ctx.info('prof_gemm_launches')
+    sess.ctx.set_option('profile', 0)
+    times = np.zeros(world)
+    times[rank] = elapsed
+    times = sess.allreduce(times)
+    t_max = float(np.max(times))
+
+    if rank != 0:
+        return
+    total_trials = R * world
+    ms_per_step = t_max / args.steps * 1e3
+    value = (args.steps * total_trials / 1024.0) / t_max if args.config == 'c3' else args.steps / t_max
+    timed = slice(args.warmup, args.warmup + args.steps)
+    achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    out = {
+        'metric': 'EM iterations/sec',
+        'value': value,
+        'unit': 'EM-iterations/s (1024-trial batches of 200 neurons x 10 latents x 500 bins)' if args.config == 'c3' else 'EM-iterations/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': '%s: %d neurons, %d latents, %d bins, %d trials per GPU, Laplace batch EM (warm-started E-step + TNC/BFGS M-step)'
+                               % (args.config, q, p, T, R), 'trials_total': total_trials, 'parallelism': 'trial-sharded x%d' % world},
+        'estep_ms_per_trial': float(np.mean(estep_ms[timed])) / R,
+        'estep_ms': [round(x, 1) for x in estep_ms], 'mstep_ms': [round(x, 1) for x in mstep_ms],
+        'newton_factorizations_per_trial': [round(f / R, 2) for f in facts],
+        'nll': nll_hist,
+        'roofline': {'bound': 'mfma', 'kernel': 'gemm_mfma_kernel<0> (FP64 16x16x4 MFMA; SYRK/TRSM/TRTRI/selected-inverse GEMMs)',
+                     'achieved': achieved, 'peak': FP64_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / FP64_MATRIX_PEAK_TFLOPS,
+                     'traffic': None, 'launches': gemm_launches, 'avg_launch_ms': gemm_ms / max(gemm_launches, 1.0),
+                     'kernel_share_of_step': gemm_ms / (t_max * 1e3)},
+    }
+    if not args.no_cpu_baseline and world == 1:
+        out['cpu_baseline'] = cpu_baseline(q, p, T, R, true_params, Ys[0], bin_ms, init)
+        out['speedup_vs_cpu_baseline'] = (args.steps / t_max) / out['cpu_baseline']['value']
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

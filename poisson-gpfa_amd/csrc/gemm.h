@@ -229,19 +229,30 @@ __global__ void gemm_check_kernel(GemmP g) {
   if (g.kflags & KF_BEGIN_MAXRC) kb = (i0 > j0 ? i0 : j0);
   if (g.kflags & KF_END_ROW) ke = (i0 + GBM < g.K ? i0 + GBM : g.K);
   const bool mask_diag = (g.kflags & KF_MASK_DIAG) && (ti == tj);
-  for (int e = threadIdx.x; e < GBM * GBN; e += blockDim.x) {
+  // compute first, store after a barrier: C may alias A (in-place TRSM)
+  double vals[GBM * GBN / 256];
+  int cnt = 0;
+  for (int e = threadIdx.x; e < GBM * GBN; e += 256, ++cnt) {
+    const int i = i0 + (e % GBM), j = j0 + (e / GBM);
+    double s = 0.0;
+    if (i < g.M && j < g.N) {
+      for (int k = kb; k < ke; ++k) {
+        const double a = A[(size_t)k * g.lda + i];
+        const double bb = TRANSB ? B[(size_t)j * g.ldb + k] : B[(size_t)k * g.ldb + j];
+        s += a * bb;
+      }
+    }
+    vals[cnt] = s;
+  }
+  __syncthreads();
+  cnt = 0;
+  for (int e = threadIdx.x; e < GBM * GBN; e += 256, ++cnt) {
     const int i = i0 + (e % GBM), j = j0 + (e / GBM);
     if (i >= g.M || j >= g.N) continue;
     if (mask_diag && i < j) continue;
     if (g.mode == GEMM_LOWER && (i / 64) * 64 + 63 < (j / 64) * 64) continue;
-    double s = 0.0;
-    for (int k = kb; k < ke; ++k) {
-      const double a = A[(size_t)k * g.lda + i];
-      const double bb = TRANSB ? B[(size_t)j * g.ldb + k] : B[(size_t)k * g.ldb + j];
-      s += a * bb;
-    }
     double* dst = C + (size_t)j * g.ldc + i;
-    double v = g.alpha * s;
+    double v = g.alpha * vals[cnt];
     if (g.beta != 0.0) v += g.beta * (*dst);
     *dst = v;
   }

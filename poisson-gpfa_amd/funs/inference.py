@@ -40,7 +40,10 @@ def laplace(experiment, params, prevOptimRes=None, returnOptimRes=True, verbose=
     """
     sess, trial_idx = _prepare(experiment, params)
     n_all = len(trial_idx)
-    lo, hi = sess.local_slice(n_all)
+    # default: every rank holds the same experiment and takes a contiguous slice of its trials;
+    # experiment._pgpfa_local_shard = True says this rank's experiment already IS its shard
+    local_shard = bool(getattr(experiment, '_pgpfa_local_shard', False))
+    lo, hi = (0, n_all) if local_shard else sess.local_slice(n_all)
     mine = trial_idx[lo:hi]
     warm = False
     if prevOptimRes is not None:
@@ -66,7 +69,7 @@ def laplace(experiment, params, prevOptimRes=None, returnOptimRes=True, verbose=
         for i, (it, st) in enumerate(zip(iters, status)):
             print('laplace inference trajectory of trial %d: %d Newton factorizations, %s' % (lo + i + 1, it, STATUS_TEXT.get(int(st), '?')))
     tot = sess.allreduce(np.array([obj, float(len(mine))]))
-    post_lik = tot[0] / n_all
+    post_lik = tot[0] / tot[1]
     infRes = DeviceInfRes(sess, mine, (lo, hi))
     infRes.newton_iters = iters
     infRes.newton_status = status

@@ -1,8 +1,10 @@
 """End-to-end parity of the HIP path with the oracle and the golden vectors captured from the
 reference.  GPU only; everything goes through the drop-in `funs` surface or the C-ABI wrapper.
-Tolerances (SURVEY.md 8c): vs the polished/exact mode 1e-8; vs the reference's own early-stopped
-answers max|dx| <= 5e-3, |dnll| <= 1e-4, max|dvecCd| <= 1e-4 (one M-step), |dlog gamma| <= 1e-5;
-full EM nll 1e-3 abs, parameters 1e-3 rel."""
+Tolerances: vs the polished/exact mode 1e-8 (SURVEY.md 8c); vs the reference's own early-stopped
+answers max|dx| <= 5e-3, |dnll| <= 1e-4, max|dvecCd| <= 5e-4 (one M-step), |dlog gamma| <= 1e-5; full EM
+vs the exactly-converged oracle path nll 1e-5 abs / parameters 1e-4 rel, vs the reference's path nll
+1e-2 abs (8e-6 rel) / parameters 5e-3 rel - the reference sits that far from the converged path itself
+(measured: 3.5e-3 and 2.1e-3, tests/golden/make_exact_paths.py)."""
 import numpy as np
 import pytest
 
@@ -70,21 +72,23 @@ def test_estep_warm_start_and_subset(funs_mod, c1, c1_experiment):
 
 
 def test_mstep_results_vs_reference(funs_mod, c1, c1_experiment):
-    """One full M-step (TNC for C,d; BFGS for tau) after our E-step, against the reference's result."""
+    """One full M-step (TNC for C,d; BFGS for tau) after our E-step."""
     g = load_golden('c1_mstep.npz')
     params = {k: v.copy() for k, v in c1['init'].items()}
     infRes, nll, _ = funs_mod.inference.laplace(c1_experiment, params)
     new, det = funs_mod.learning.updateParams(params, infRes, c1_experiment, CdOptimMethod='TNC')
     v = orc.cd_to_vec(new['C'], new['d'])
-    assert np.max(np.abs(v - orc.cd_to_vec(g['newC'], g['newd']))) <= 1e-4
-    assert np.max(np.abs(v - g['tight_vec'])) <= 1e-3
-    assert np.max(np.abs(np.log(new['tau']) - np.log(g['newTau']))) <= 1e-5
-    # the same M-step through the oracle on the oracle's exact E-step: same optimiser, same inputs
+    # identical inputs, identical optimiser: the oracle's M-step on the oracle's exact E-step
     res, _, _ = orc.laplace(c1['Ys'], c1['init'], c1['binSize'], mode='exact', return_cov=False)
     C_o, d_o, _, _ = orc.learn_cd(c1['init'], c1['Ys'], res, 'TNC')
     tau_o, _ = orc.learn_tau(c1['init'], res, c1['binSize'])
     assert np.max(np.abs(v - orc.cd_to_vec(C_o, d_o))) <= 1e-5
     assert np.max(np.abs(np.log(new['tau']) - np.log(tau_o))) <= 1e-7
+    # the reference's own result: its E-step modes are early-stopped (max|dx| up to 3e-3, BASELINE.md),
+    # which moves the (C,d) optimum by ~1e-4; TNC's own stop adds 1.6e-5
+    assert np.max(np.abs(v - orc.cd_to_vec(g['newC'], g['newd']))) <= 5e-4
+    assert np.max(np.abs(v - g['tight_vec'])) <= 1e-3
+    assert np.max(np.abs(np.log(new['tau']) - np.log(g['newTau']))) <= 1e-5
 
 
 def test_mstep_accepts_reference_style_infres(funs_mod, c1, c1_experiment):
@@ -100,30 +104,49 @@ def test_mstep_accepts_reference_style_infres(funs_mod, c1, c1_experiment):
 
 def test_batch_em_vs_reference(funs_mod, c1, c1_experiment):
     g = load_golden('c1_em_batch.npz')
+    ex = load_golden('c1_em_exact.npz')
     init = {k: v.copy() for k, v in c1['init'].items()}
     fit = funs_mod.engine.PPGPFAfit(c1_experiment, initParams=init, inferenceMethod='laplace', EMmode='Batch',
                                     maxEMiter=5, quiet=True)
-    assert np.max(np.abs(np.asarray(fit.posteriorLikelihood) - g['nll'])) <= 1e-3
+    nll = np.asarray(fit.posteriorLikelihood)
+    # (1) the exactly-converged EM path (oracle, exact E-step, same scipy M-step drivers): tight
+    assert np.max(np.abs(nll - ex['nll'])) <= 1e-5
     for i in range(1, 6):
-        assert rel(fit.paramSeq[i]['C'], g['seq_C'][i]) <= 1e-3
-        assert rel(fit.paramSeq[i]['d'], g['seq_d'][i]) <= 1e-3
+        assert rel(fit.paramSeq[i]['C'], ex['seq_C'][i]) <= 1e-4
+        assert rel(fit.paramSeq[i]['d'], ex['seq_d'][i]) <= 1e-4
+        assert rel(fit.paramSeq[i]['tau'], ex['seq_tau'][i]) <= 1e-5
+    # (2) the reference's own path: it carries the reference's early-stopping slack, measured at
+    #     3.5e-3 in nPLL and 2.1e-3 (rel) in C against path (1) after 4 iterations
+    assert np.max(np.abs(nll - g['nll'])) <= 1e-2
+    for i in range(1, 6):
+        assert rel(fit.paramSeq[i]['C'], g['seq_C'][i]) <= 5e-3
+        assert rel(fit.paramSeq[i]['d'], g['seq_d'][i]) <= 5e-3
         assert rel(fit.paramSeq[i]['tau'], g['seq_tau'][i]) <= 1e-3
     assert len(fit.inferenceTime) == 5 and len(fit.learningTime) == 5
     assert fit.tauSeq.shape == (3, 5)
-    # monotone E-step objective across EM iterations on this data set (reference shows the same)
+    # monotone E-step objective across EM iterations on this data set (the reference shows the same)
     assert np.all(np.diff(fit.posteriorLikelihood) > 0)
 
 
 def test_online_em_vs_reference(funs_mod, c1, c1_experiment):
     g = load_golden('c1_em_online.npz')
+    ex = load_golden('c1_em_exact.npz')
     init = {k: v.copy() for k, v in c1['init'].items()}
     np.random.seed(1)
     fit = funs_mod.engine.PPGPFAfit(c1_experiment, initParams=init, inferenceMethod='laplace', EMmode='Online',
                                     maxEMiter=4, batchSize=5, onlineParamUpdateMethod='diag', quiet=True)
-    assert np.max(np.abs(np.asarray(fit.posteriorLikelihood) - g['nll'])) <= 1e-3
-    assert rel(fit.paramSeq[-1]['C'], g['seq_C'][-1]) <= 1e-3
-    assert rel(fit.paramSeq[-1]['d'], g['seq_d'][-1]) <= 1e-3
-    assert rel(fit.paramSeq[-1]['tau'], g['seq_tau'][-1]) <= 2e-3
+    nll = np.asarray(fit.posteriorLikelihood)
+    # Online 'diag' runs TNC with gtol=1e-10 on (C,d) and on each tau, the latter with the reference's
+    # inconsistent cost/gradient pair (learning.py:733-734): the stopping point is decided by rounding
+    # noise, so two correct implementations differ by ~1e-5 rel in the parameters (measured: 1e-5 in C,
+    # 3.5e-5 in tau, 4e-5 abs in nPLL - against the exact oracle path and the reference alike).
+    for ref_nll, ref_C, ref_d, ref_tau in ((ex['online_nll'], ex['online_seq_C'], ex['online_seq_d'], ex['online_seq_tau']),
+                                           (g['nll'], g['seq_C'], g['seq_d'], g['seq_tau'])):
+        assert np.max(np.abs(nll - ref_nll)) <= 5e-4
+        for i in range(1, 5):
+            assert rel(fit.paramSeq[i]['C'], ref_C[i]) <= 2e-4
+            assert rel(fit.paramSeq[i]['d'], ref_d[i]) <= 2e-4
+            assert rel(fit.paramSeq[i]['tau'], ref_tau[i]) <= 5e-4
 
 
 def test_c2_size_spot_check(funs_mod):
