@@ -149,7 +149,7 @@ def main():
 
     params = init
     optim = None
-    nll_hist, estep_ms, mstep_ms, facts = [], [], [], []
+    nll_hist, estep_ms, mstep_ms, facts, solves = [], [], [], [], []
 
     def em_step():
         nonlocal params, optim
@@ -162,6 +162,7 @@ def main():
         estep_ms.append((t1 - t0) * 1e3)
         mstep_ms.append((t2 - t1) * 1e3)
         facts.append(sess.ctx.info('last_newton_factorizations'))
+        solves.append(sess.ctx.info('last_newton_solves'))
 
     for _ in range(args.warmup):
         em_step()
@@ -198,7 +199,8 @@ def main():
                                % (args.config, q, p, T, R), 'trials_total': total_trials, 'parallelism': 'trial-sharded x%d' % world},
         'estep_ms_per_trial': float(np.mean(estep_ms[timed])) / R,
         'estep_ms': [round(x, 1) for x in estep_ms], 'mstep_ms': [round(x, 1) for x in mstep_ms],
-        'newton_factorizations_per_trial': [round(f / R, 2) for f in facts],
+        'factorizations_per_trial': [round(f / R, 2) for f in facts],
+        'newton_solves_per_trial': [round(f / R, 2) for f in solves],
         'nll': nll_hist,
         'roofline': {'bound': 'mfma', 'kernel': 'gemm_mfma_kernel<0> (FP64 16x16x4 MFMA; SYRK/TRSM/TRTRI/selected-inverse GEMMs)',
                      'achieved': achieved, 'peak': FP64_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / FP64_MATRIX_PEAK_TFLOPS,

@@ -42,7 +42,8 @@ int pgpfa_device_count(int* count);
 int pgpfa_create(pgpfa_ctx** out, int device, int q, int p, int T, int R, double bin_ms);
 int pgpfa_destroy(pgpfa_ctx* ctx);
 /* Options: "newton_xtol" (1e-5), "newton_max_iter" (50), "use_mfma" (1), "keep_vsmgp" (1),
- * "chunk_trials" (0 = auto), "eps_noise" (1e-3, util.py:599). */
+ * "chunk_trials" (0 = auto), "eps_noise" (1e-3, util.py:599), "chord" (1: reuse the first factor for
+ * chord steps), "chord_xtol" (1e-9), "chord_rho" (0.3), "chord_max_step" (0.1), "profile" (0). */
 int pgpfa_set_option(pgpfa_ctx* ctx, const char* key, double value);
 /* Info: "chunk_trials", "n_pad", "last_newton_factorizations", "last_estep_ms",
  * "last_chol_ms", "last_chol_flops", "hbm_bytes_allocated", ... */
@@ -70,7 +71,8 @@ int pgpfa_laplace_hessian(pgpfa_ctx* ctx, int trial, const double* X, double* H)
  * starts from the modes resident in the context (prevOptimRes, inference.py:99-102),
  * otherwise from zeros.  obj_sum = sum over the listed trials of the objective at the
  * mode (the reference returns -obj_sum/numTrials, inference.py:175,183).
- * iters/status (may be NULL): Newton factorizations per trial, 0 = converged. */
+ * iters/status (may be NULL): Cholesky factorizations per trial (Newton + the final one at the
+ * mode), status 0 = converged. */
 int pgpfa_estep_laplace(pgpfa_ctx* ctx, int n, const int32_t* idx, int warm_start,
                         double* obj_sum, int32_t* iters, int32_t* status);
 int pgpfa_set_modes(pgpfa_ctx* ctx, int n, const int32_t* idx, const double* X /* [n][p][T] */);

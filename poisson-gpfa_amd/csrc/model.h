@@ -453,108 +453,81 @@ __global__ void pautosum_kernel(const double* __restrict__ vsmgp, const double* 
 
 // --------------------------------------------------------------------------------------------------
 // (C,d) M-step pass, learning.MStepObservationCost(_grad) learning.py:20-91:
-//   hh = c_n.m_t + d_n ; rho = c_n^T V_t c_n ; yhat = exp(hh + rho/2)
-//   cost_n = sum (y*hh - yhat) ; dd_n = sum (y - yhat) ; dC_n = sum (y - yhat) m_t - yhat V_t c_n
-// Lanes are NEURONS, so every per-neuron sum stays in one thread's registers (no cross-lane
-// reduction); m_t and V_t are wave-uniform and arrive through scalar loads.  Work items are
-// (trial, 32-bin tile); partial sums per block are reduced in a fixed order afterwards.
+//   hh = c_n.m_t + d_n ; u = V_t c_n ; rho = c_n.u ; yhat = exp(hh + rho/2)
+//   cost_n = sum (y*hh - yhat) ; dd_n = sum (y - yhat) ; dC_n = sum (y - yhat) m_t - yhat u
+// Lanes are NEURONS: every per-neuron sum stays in one thread's registers; m_t and V_t are
+// wave-uniform and arrive through scalar loads.  Wave ty of a block handles bins t = ty, ty+KY, ...
+// of the trials the block owns.  PW is the unrolled latent width (>= p; c is zero padded, so the
+// extra columns multiply finite neighbouring data by exact zeros and no per-element guard is needed;
+// the buffers carry 64 doubles of slack for the over-read).
 // --------------------------------------------------------------------------------------------------
 struct CdArgs {
   const uint8_t* Y; const double* mean; const double* vsm; const double* vec;   // vecCd
   const int* trials; int ntr;
   double* part;          // [gridDim.y][p+2][q]
-  int q, p, T, ntt;      // ntt = tiles per trial
+  int q, p, T;
 };
-constexpr int CTT = 32;
+constexpr int CD_KY = 8;
 
-template <int PMAX>
-__global__ void mstep_cd_kernel(CdArgs a) {
-  constexpr int NK = (PMAX > 16) ? 2 : 1;
-  __shared__ double YH[CTT][64];
-  __shared__ double RS[CTT][64];
-  __shared__ double red[2][16][64];
-  const int lane = threadIdx.x, ty = threadIdx.y, KY = blockDim.y;
+template <int PW>
+__global__ __launch_bounds__(64 * CD_KY) void mstep_cd_kernel(CdArgs a) {
+  __shared__ double red[CD_KY][PW + 2][64];
+  const int lane = threadIdx.x;
+  const int ty = __builtin_amdgcn_readfirstlane(threadIdx.y);
   const int n = blockIdx.x * 64 + lane;
   const bool live = n < a.q;
   const int p = a.p, q = a.q, T = a.T;
-  double c[PMAX];
+  double c[PW], acc[PW];
 #pragma unroll
-  for (int l = 0; l < PMAX; ++l) c[l] = (live && l < p) ? a.vec[(size_t)l * q + n] : 0.0;
+  for (int l = 0; l < PW; ++l) {
+    c[l] = (live && l < p) ? a.vec[(size_t)l * q + n] : 0.0;
+    acc[l] = 0.0;
+  }
   const double dn = live ? a.vec[(size_t)p * q + n] : 0.0;
-  double acc[NK];
-#pragma unroll
-  for (int j = 0; j < NK; ++j) acc[j] = 0.0;
   double cost = 0.0, dd = 0.0;
 
-  const int nitems = a.ntr * a.ntt;
-  for (int item = blockIdx.y; item < nitems; item += gridDim.y) {
-    const size_t r = a.trials[item / a.ntt];
-    const int t0 = (item % a.ntt) * CTT;
+  for (int it = blockIdx.y; it < a.ntr; it += gridDim.y) {
+    const size_t r = a.trials[it];
     const double* mean = a.mean + r * p * T;
     const double* vsm = a.vsm + r * T * p * p;
-    const uint8_t* Y = a.Y + r * q * T;
-    for (int tt = ty; tt < CTT; tt += KY) {
-      const int t = __builtin_amdgcn_readfirstlane(t0 + tt);
-      double yh = 0.0, rs = 0.0;
-      if (t < T && live) {
-        const double* V = vsm + (size_t)t * p * p;
-        double hh = dn, rho = 0.0;
-        for (int k = 0; k < p; ++k) {
-          double u = 0.0;
+    const uint8_t* Y = a.Y + (r * q + (live ? n : 0)) * T;
+    for (int t = ty; t < T; t += CD_KY) {
+      const double* V = vsm + (size_t)t * p * p;
+      double u[PW];
+      double hh = dn, rho = 0.0;
 #pragma unroll
-          for (int l = 0; l < PMAX; ++l)
-            if (l < p) u += V[k * p + l] * c[l];
-          double ck = 0.0;
+      for (int k = 0; k < PW; ++k) {
+        const double* Vk = V + (k < p ? k : 0) * p;          // rows >= p are multiplied by c[k] = 0
+        double s = 0.0;
 #pragma unroll
-          for (int l = 0; l < PMAX; ++l)
-            if (l == k) ck = c[l];
-          hh += ck * mean[(size_t)k * T + t];
-          rho += ck * u;
-        }
-        yh = exp(hh + 0.5 * rho);
-        const double y = (double)Y[(size_t)n * T + t];
-        rs = y - yh;
-        cost += y * hh - yh;
-        dd += rs;
+        for (int l = 0; l < PW; ++l) s += Vk[l] * c[l];
+        u[k] = s;
+        rho += c[k] * s;
+        hh += c[k] * mean[(size_t)(k < p ? k : 0) * T + t];
       }
-      YH[tt][lane] = yh;
-      RS[tt][lane] = rs;
-    }
-    __syncthreads();
+      const double yh = exp(hh + 0.5 * rho);
+      const double y = (double)Y[t];
+      const double rs = y - yh;
+      cost += y * hh - yh;
+      dd += rs;
 #pragma unroll
-    for (int j = 0; j < NK; ++j) {
-      const int k = __builtin_amdgcn_readfirstlane(ty + j * KY);
-      if (k < p) {
-        const int tmax = (T - t0 < CTT) ? T - t0 : CTT;
-        for (int tt = 0; tt < tmax; ++tt) {
-          const int t = t0 + tt;
-          const double* Vk = vsm + (size_t)t * p * p + (size_t)k * p;
-          double u = 0.0;
-#pragma unroll
-          for (int l = 0; l < PMAX; ++l)
-            if (l < p) u += Vk[l] * c[l];
-          acc[j] += RS[tt][lane] * mean[(size_t)k * T + t] - YH[tt][lane] * u;
-        }
-      }
+      for (int k = 0; k < PW; ++k) acc[k] += rs * mean[(size_t)(k < p ? k : 0) * T + t] - yh * u[k];
     }
-    __syncthreads();
   }
-  // combine cost/dd over ty in a fixed order, write the block's partials
-  red[0][ty][lane] = cost;
-  red[1][ty][lane] = dd;
-  __syncthreads();
-  double* part = a.part + (size_t)blockIdx.y * (p + 2) * q;
-  if (live) {
+  // fixed-order combine over the KY waves of the block
 #pragma unroll
-    for (int j = 0; j < NK; ++j) {
-      const int k = ty + j * KY;
-      if (k < p) part[(size_t)k * q + n] = acc[j];
-    }
-    if (ty == 0) {
-      double sc = 0.0, sd = 0.0;
-      for (int i = 0; i < KY; ++i) { sc += red[0][i][lane]; sd += red[1][i][lane]; }
-      part[(size_t)p * q + n] = sd;
-      part[(size_t)(p + 1) * q + n] = sc;
+  for (int k = 0; k < PW; ++k) red[ty][k][lane] = acc[k];
+  red[ty][PW][lane] = dd;
+  red[ty][PW + 1][lane] = cost;
+  __syncthreads();
+  if (live) {
+    double* part = a.part + (size_t)blockIdx.y * (p + 2) * q;
+    for (int row = ty; row < p + 2; row += CD_KY) {
+      const int src = row < p ? row : PW + (row - p);
+      double s = 0.0;
+#pragma unroll
+      for (int w = 0; w < CD_KY; ++w) s += red[w][src][lane];
+      part[(size_t)row * q + n] = s;
     }
   }
 }

@@ -67,7 +67,10 @@ struct pgpfa_ctx {
   hipStream_t st = nullptr;
   // options
   double xtol = 1e-5;
-  int max_iter = 50;
+  int max_iter = 60;
+  bool chord = true;
+  double chord_xtol = 1e-9, chord_rho = 0.3, chord_max_step = 0.1;
+  int chord_max = 25;
   bool mfma = true;
   int chunk_opt = 0;
   // persistent device state
@@ -352,6 +355,25 @@ int upload(pgpfa_ctx* c, double* dev, const double* host, size_t n) {
   return 0;
 }
 
+// exact (or nearest) unrolled latent width for the kernels that pad with zeros instead of guarding
+template <typename F>
+void dispatch_pw(int p, F&& f) {
+  switch (p) {
+    case 1: f(std::integral_constant<int, 1>{}); break;
+    case 2: f(std::integral_constant<int, 2>{}); break;
+    case 3: f(std::integral_constant<int, 3>{}); break;
+    case 4: f(std::integral_constant<int, 4>{}); break;
+    case 5: f(std::integral_constant<int, 5>{}); break;
+    case 6: f(std::integral_constant<int, 6>{}); break;
+    case 7: case 8: f(std::integral_constant<int, 8>{}); break;
+    case 9: case 10: f(std::integral_constant<int, 10>{}); break;
+    case 11: case 12: f(std::integral_constant<int, 12>{}); break;
+    case 13: case 14: case 15: case 16: f(std::integral_constant<int, 16>{}); break;
+    case 17: case 18: case 19: case 20: f(std::integral_constant<int, 20>{}); break;
+    default: f(std::integral_constant<int, 32>{}); break;
+  }
+}
+
 template <typename F>
 void dispatch_pmax(int p, F&& f) {
   if (p <= 4) f(std::integral_constant<int, 4>{});
@@ -489,8 +511,8 @@ int pgpfa_create(pgpfa_ctx** out, int device, int q, int p, int T, int R, double
   rc |= dmalloc(c, &c->Y, (size_t)R * q * T);
   rc |= dmalloc(c, &c->C, (size_t)q * p); rc |= dmalloc(c, &c->d, q); rc |= dmalloc(c, &c->tau, p);
   rc |= dmalloc(c, &c->Kpad, slab * p); rc |= dmalloc(c, &c->Kinv, slab * p);
-  rc |= dmalloc(c, &c->Xmode, (size_t)R * c->n, true);
-  rc |= dmalloc(c, &c->vsm, (size_t)R * T * p * p, true);
+  rc |= dmalloc(c, &c->Xmode, (size_t)R * c->n + 64, true);
+  rc |= dmalloc(c, &c->vsm, (size_t)R * T * p * p + 2048, true);
   rc |= dmalloc(c, &c->vsmgp, (size_t)R * p * T * T, true);
   rc |= dmalloc(c, &c->Pauto, slab * p, true);
   rc |= dmalloc(c, &c->vec, (size_t)q * (p + 1));
@@ -528,6 +550,11 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
   if (k == "newton_xtol") c->xtol = v;
   else if (k == "newton_max_iter") c->max_iter = (int)v;
   else if (k == "use_mfma") c->mfma = (v != 0.0);
+  else if (k == "chord") c->chord = (v != 0.0);
+  else if (k == "chord_xtol") c->chord_xtol = v;
+  else if (k == "chord_rho") c->chord_rho = v;
+  else if (k == "chord_max_step") c->chord_max_step = v;
+  else if (k == "chord_max") c->chord_max = (int)v;
   else if (k == "chunk_trials") { if (c->B > 0) return fail("chunk_trials must be set before the first E-step"); c->chunk_opt = (int)v; }
   else if (k == "eps_noise") c->eps = v;
   else if (k == "profile") {
@@ -718,7 +745,7 @@ int pgpfa_estep_laplace(pgpfa_ctx* c, int n, const int32_t* idx, int warm_start,
   const int nvec = c->n, p = c->p, T = c->T;
   const long long ld = c->ld;
   double total = 0.0;
-  double n_fact = 0.0;
+  double n_fact = 0.0, n_solve = 0.0;
   int max_it_seen = 0;
   std::vector<double> f(c->B), qxx(c->B), qdx(c->B), qdd(c->B), dec(c->B), smax(c->B), alpha(c->B), ftry(c->B);
   std::vector<int> its(c->B), stat(c->B), info(c->B);
@@ -740,12 +767,28 @@ int pgpfa_estep_laplace(pgpfa_ctx* c, int n, const int32_t* idx, int warm_start,
     std::vector<int> active(nb);
     for (int s = 0; s < nb; ++s) { active[s] = s; f[s] += 0.5 * qxx[s]; its[s] = 0; stat[s] = 1; }
 
+    // Newton with factor reuse: a slot factors H at its current point only when it has no factor yet or
+    // its chord steps (steps with the stale factor, still descent directions since that factor is SPD)
+    // contract too slowly; otherwise the resident factor is reused: one HBM-bound solve instead of n^3/3.
+    std::vector<char> has_factor(nb, 0), fresh(nb, 0), refactor(nb, 0);
+    std::vector<double> prev_step(nb, 0.0);
+    std::vector<int> n_chord(nb, 0);
     for (int iter = 0; iter < c->max_iter && !active.empty(); ++iter) {
       const int na = (int)active.size();
+      std::vector<int> need;
+      for (int s : active) {
+        if (!has_factor[s] || refactor[s] || !c->chord) need.push_back(s);
+        fresh[s] = 0;
+      }
+      if (!need.empty()) {
+        CHK(upload_list(c, c->list_a, need));
+        CHK(assemble(c, c->list_a, (int)need.size()));
+        CHK(factor(c, c->ws, c->list_a, (int)need.size()));
+        n_fact += (double)need.size();
+        for (int s : need) { has_factor[s] = 1; fresh[s] = 1; refactor[s] = 0; n_chord[s] = 0; its[s] += 1; }
+      }
+      n_solve += na;
       CHK(upload_list(c, c->list_a, active));
-      CHK(assemble(c, c->list_a, na));
-      CHK(factor(c, c->ws, c->list_a, na));
-      n_fact += na;
       hipLaunchKernelGGL(grad_total_kernel, dim3((nvec + 255) / 256, na), dim3(256), 0, c->st, c->Gl, ld, c->KX, ld, c->Gt, ld, nvec, c->list_a);
       prof_begin(c, TAG_SOLVE, 2.0 * na * (double)c->npad * c->npad);
       hipLaunchKernelGGL(chol_solve_kernel, dim3(na), dim3(256), 0, c->st, c->ws.H, c->ws.sH, c->ld, c->npad, c->ws.Dinv, c->ws.sD, c->Gt, c->Dl,
@@ -766,7 +809,6 @@ int pgpfa_estep_laplace(pgpfa_ctx* c, int n, const int32_t* idx, int warm_start,
       // backtracking line search on the objective (rounding-noise slack as in the oracle)
       std::vector<int> pending;
       for (int s : active) {
-        its[s] += 1;
         if (info[s] != 0 || !std::isfinite(dec[s])) { stat[s] = 3; continue; }
         alpha[s] = 1.0;
         pending.push_back(s);
@@ -806,7 +848,19 @@ int pgpfa_estep_laplace(pgpfa_ctx* c, int n, const int32_t* idx, int warm_start,
       std::vector<int> next;
       for (int s : active) {
         if (stat[s] == 2 || stat[s] == 3) continue;
-        if (alpha[s] * smax[s] < c->xtol) { stat[s] = 0; continue; }
+        const double step = alpha[s] * smax[s];
+        if (fresh[s]) {
+          // true Newton step: quadratic convergence, the error after the step is ~step^2
+          if (step < c->xtol) { stat[s] = 0; continue; }
+          if (step > c->chord_max_step) refactor[s] = 1;      // still far from the mode: keep factoring
+        } else {
+          // chord step: linear convergence with ratio rho, the error after the step is ~rho/(1-rho)*step
+          const double rho = prev_step[s] > 0.0 ? step / prev_step[s] : 1.0;
+          n_chord[s] += 1;
+          if (step < c->chord_xtol && rho < 0.5) { stat[s] = 0; continue; }
+          if (rho > c->chord_rho || n_chord[s] >= c->chord_max) refactor[s] = 1;
+        }
+        prev_step[s] = step;
         next.push_back(s);
       }
       active.swap(next);
@@ -817,6 +871,7 @@ int pgpfa_estep_laplace(pgpfa_ctx* c, int n, const int32_t* idx, int warm_start,
     CHK(assemble(c, c->ident, nb));
     CHK(factor(c, c->ws, c->ident, nb));
     n_fact += nb;
+    for (int s = 0; s < nb; ++s) its[s] += 1;
     CHK(inverse_t(c, c->ws, c->ident, nb));
     for (int k = 0; k < p; ++k) {
       const int kal = (k * T) / 16 * 16;
@@ -855,6 +910,7 @@ int pgpfa_estep_laplace(pgpfa_ctx* c, int n, const int32_t* idx, int warm_start,
   const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   c->info["last_estep_ms"] = ms;
   c->info["last_newton_factorizations"] = n_fact;
+  c->info["last_newton_solves"] = n_solve;
   c->info["last_newton_max_iter"] = max_it_seen;
   return 0;
 }
@@ -953,13 +1009,11 @@ int pgpfa_mstep_cd_costgrad(pgpfa_ctx* c, const double* vecCd, const double* pri
   CdArgs a{};
   a.Y = c->Y; a.mean = c->Xmode; a.vsm = c->vsm; a.vec = c->vec;
   a.trials = c->last_trials; a.ntr = (int)c->last_trials_h.size();
-  a.part = c->cdpart; a.q = q; a.p = p; a.T = T; a.ntt = (T + CTT - 1) / CTT;
-  const int nitems = a.ntr * a.ntt;
-  const int nby = std::max(1, std::min(1024, nitems));
-  const int KY = std::min(p, 16);
-  prof_begin(c, TAG_CD, (double)a.ntr * q * T * (4.0 * p * p + 4.0 * p));
-  dispatch_pmax(p, [&](auto pm) {
-    hipLaunchKernelGGL(mstep_cd_kernel<decltype(pm)::value>, dim3((q + 63) / 64, nby), dim3(64, KY), 0, c->st, a);
+  a.part = c->cdpart; a.q = q; a.p = p; a.T = T;
+  const int nby = std::max(1, std::min(1024, a.ntr));
+  prof_begin(c, TAG_CD, (double)a.ntr * q * T * (2.0 * p * p + 8.0 * p));
+  dispatch_pw(p, [&](auto pw) {
+    hipLaunchKernelGGL(mstep_cd_kernel<decltype(pw)::value>, dim3((q + 63) / 64, nby), dim3(64, CD_KY), 0, c->st, a);
   });
   prof_end(c);
   hipLaunchKernelGGL(reduce_parts_kernel, dim3((len + 255) / 256), dim3(256), 0, c->st, c->cdpart, nby, len, c->cdout);
