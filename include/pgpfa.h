@@ -43,7 +43,7 @@ int pgpfa_create(pgpfa_ctx** out, int device, int q, int p, int T, int R, double
 int pgpfa_destroy(pgpfa_ctx* ctx);
 /* Options: "newton_xtol" (1e-5), "newton_max_iter" (50), "use_mfma" (1), "keep_vsmgp" (1),
  * "chunk_trials" (0 = auto), "eps_noise" (1e-3, util.py:599), "chord" (1: reuse the first factor for
- * chord steps), "chord_xtol" (1e-9), "chord_rho" (0.3), "chord_max_step" (0.1), "profile" (0). */
+ * chord steps), "chord_xtol" (1e-9), "chord_rho" (0.6), "chord_max_step" (1.0), "profile" (0). */
 int pgpfa_set_option(pgpfa_ctx* ctx, const char* key, double value);
 /* Info: "chunk_trials", "n_pad", "last_newton_factorizations", "last_estep_ms",
  * "last_chol_ms", "last_chol_flops", "hbm_bytes_allocated", ... */

@@ -314,7 +314,7 @@ __global__ void commit_kernel(double* __restrict__ X, const double* __restrict__
 // --------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void assemble_h_kernel(double* __restrict__ H, long long sH, int ld, int npad, int n, int T, int Tp, int p,
                                                           const double* __restrict__ Kinv, const double* __restrict__ W, long long sW,
-                                                          const int* __restrict__ slots) {
+                                                          const int* __restrict__ slots, double diag_scale) {
   const int j = blockIdx.x;
   const size_t slot = slots[blockIdx.y];
   double* col = H + slot * sH + (size_t)j * ld;
@@ -331,6 +331,7 @@ __global__ __launch_bounds__(256) void assemble_h_kernel(double* __restrict__ H,
       const int ki = i / T, ti = i - ki * T;
       if (ki == kj) v = Kcol[ti];
       if (ti == tj) v += Wt[ki * p + kj];
+      if (i == j) v *= diag_scale;        // VIPostCov jitter (inference.py:190); 1.0 for Laplace
     }
     col[i] = v;
   }
@@ -539,6 +540,76 @@ __global__ void reduce_parts_kernel(const double* __restrict__ part, int nb, int
   double s = 0.0;
   for (int b = 0; b < nb; ++b) s += part[(size_t)b * len + e];
   out[e] = s;
+}
+
+// --------------------------------------------------------------------------------------------------
+// Dual variational E-step (inference.py:188-256), structured: with lmy = lambda - y,
+//   v = C_big lmy  ->  v[k][t] = sum_n C[n][k] lmy[n][t]            (p x T)
+//   W[t] = C^T diag(lambda[:,t]) C                                   (posterior precision blocks)
+//   partial sums  sB = sum d_n lmy[n][t] ,  sD = sum lambda (log lambda - 1)
+// grid = (ceil(T/64), nslots), block = 64 threads (one bin each).
+// --------------------------------------------------------------------------------------------------
+__global__ void dual_prep_kernel(const uint8_t* __restrict__ Y, const double* __restrict__ C, const double* __restrict__ d,
+                                 const double* __restrict__ lam, long long sLam, double* __restrict__ V, long long sV,
+                                 double* __restrict__ W, long long sW, double* __restrict__ part, int ntile,
+                                 const int* __restrict__ slots, const int* __restrict__ trial_of_slot, int q, int p, int T) {
+  const int slot = slots[blockIdx.y];
+  const size_t trial = trial_of_slot[slot];
+  const int t = blockIdx.x * 64 + threadIdx.x;
+  double sB = 0.0, sD = 0.0;
+  if (t < T) {
+    const double* L = lam + (size_t)slot * sLam;
+    const uint8_t* Yr = Y + trial * q * T;
+    double* Wt = W + (size_t)slot * sW + (size_t)t * p * p;
+    for (int k = 0; k < p; ++k) {
+      double vk = 0.0;
+      for (int n = 0; n < q; ++n) vk += C[(size_t)n * p + k] * (L[(size_t)n * T + t] - (double)Yr[(size_t)n * T + t]);
+      V[(size_t)slot * sV + (size_t)k * T + t] = vk;
+      for (int l = 0; l <= k; ++l) {
+        double w = 0.0;
+        for (int n = 0; n < q; ++n) w += C[(size_t)n * p + k] * C[(size_t)n * p + l] * L[(size_t)n * T + t];
+        Wt[k * p + l] = w;
+        Wt[l * p + k] = w;
+      }
+    }
+    for (int n = 0; n < q; ++n) {
+      const double l = L[(size_t)n * T + t];
+      sB += d[n] * (l - (double)Yr[(size_t)n * T + t]);
+      sD += l * (log(l) - 1.0);
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) { sB += __shfl_down(sB, off); sD += __shfl_down(sD, off); }
+  if (threadIdx.x == 0) {
+    part[((size_t)slot * ntile + blockIdx.x) * 2 + 0] = sB;
+    part[((size_t)slot * ntile + blockIdx.x) * 2 + 1] = sD;
+  }
+}
+
+// dualProblem_grad (inference.py:218): g[n][t] = sum_k C[n][k] (Kv)[k][t] - d_n + log(lambda) - 0.5 c_n^T Sigma_t c_n
+__global__ void dual_grad_kernel(const double* __restrict__ C, const double* __restrict__ d, const double* __restrict__ lam,
+                                 const double* __restrict__ KV, const double* __restrict__ vsm_t, double* __restrict__ grad,
+                                 int q, int p, int T) {
+  const int t = blockIdx.x * 64 + threadIdx.x;
+  const int n = blockIdx.y;
+  if (t >= T) return;
+  const double* S = vsm_t + (size_t)t * p * p;
+  const double* Cn = C + (size_t)n * p;
+  double lin = 0.0, quad = 0.0;
+  for (int k = 0; k < p; ++k) {
+    lin += Cn[k] * KV[(size_t)k * T + t];
+    double u = 0.0;
+    for (int l = 0; l < p; ++l) u += S[k * p + l] * Cn[l];
+    quad += Cn[k] * u;
+  }
+  grad[(size_t)n * T + t] = lin - d[n] + log(lam[(size_t)n * T + t]) - 0.5 * quad;
+}
+
+// x = -Kv  (VIPostMean, inference.py:193-194)
+__global__ void negate_rows_kernel(const double* __restrict__ src, long long sSrc, double* __restrict__ dst, long long sDst, int n,
+                                   const int* __restrict__ slots) {
+  const int slot = slots[blockIdx.y];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[(size_t)slot * sDst + i] = -src[(size_t)slot * sSrc + i];
 }
 
 // counts: double [R][q][T] -> uint8 with validation (non-negative integers <= 255)

@@ -69,8 +69,8 @@ struct pgpfa_ctx {
   double xtol = 1e-5;
   int max_iter = 60;
   bool chord = true;
-  double chord_xtol = 1e-9, chord_rho = 0.3, chord_max_step = 0.1;
-  int chord_max = 25;
+  double chord_xtol = 1e-9, chord_rho = 0.6, chord_max_step = 1.0;
+  int chord_max = 40;
   bool mfma = true;
   int chunk_opt = 0;
   // persistent device state
@@ -91,6 +91,7 @@ struct pgpfa_ctx {
   CholWS ws{};
   double *Xc = nullptr, *Xt = nullptr, *KX = nullptr, *KD = nullptr, *Gl = nullptr, *Glt = nullptr, *Gt = nullptr, *Dl = nullptr;
   double *W = nullptr, *Wt = nullptr, *fpart = nullptr;
+  double *lamd = nullptr, *dgrad = nullptr, *dpart = nullptr;   // dual variational scratch
   double *sc_f = nullptr, *sc_qxx = nullptr, *sc_qdx = nullptr, *sc_qdd = nullptr, *sc_dec = nullptr, *sc_smax = nullptr, *sc_alpha = nullptr;
   int *trial_of_slot = nullptr, *list_a = nullptr, *list_b = nullptr, *ident = nullptr;
   // small workspace for the T x T systems (Kinv, tau M-step): p slots of Tp
@@ -400,17 +401,17 @@ int poisson(pgpfa_ctx* c, const int* d_list, int nl, const double* X, double* G,
   return 0;
 }
 
-int prior_mv(pgpfa_ctx* c, const int* d_list, int nl, const double* in, double* out) {
-  hipLaunchKernelGGL(prior_matvec_kernel, dim3(c->p, nl), dim3(256), c->T * sizeof(double), c->st, c->Kinv, c->Tp, c->T, c->p,
+int prior_mv(pgpfa_ctx* c, const int* d_list, int nl, const double* in, double* out, const double* mat = nullptr) {
+  hipLaunchKernelGGL(prior_matvec_kernel, dim3(c->p, nl), dim3(256), c->T * sizeof(double), c->st, mat ? mat : c->Kinv, c->Tp, c->T, c->p,
                      in, (long long)c->ld, out, (long long)c->ld, d_list);
   HIPC(hipGetLastError());
   return 0;
 }
 
-int assemble(pgpfa_ctx* c, const int* d_list, int nl) {
+int assemble(pgpfa_ctx* c, const int* d_list, int nl, double diag_scale = 1.0) {
   prof_begin(c, TAG_ASSEMBLE, 0.0);
   hipLaunchKernelGGL(assemble_h_kernel, dim3(c->npad, nl), dim3(256), 0, c->st, c->ws.H, c->ws.sH, c->ld, c->npad, c->n, c->T, c->Tp,
-                     c->p, c->Kinv, c->W, (long long)c->T * c->p * c->p, d_list);
+                     c->p, c->Kinv, c->W, (long long)c->T * c->p * c->p, d_list, diag_scale);
   prof_end(c);
   HIPC(hipGetLastError());
   return 0;
@@ -736,6 +737,39 @@ static int remember_trials(pgpfa_ctx* c, const std::vector<int>& v) {
   return 0;
 }
 
+
+// H (from the W blocks of slots [0,nb), diagonal scaled by diag_scale) -> factor -> L^-T -> post_vsmGP and
+// post_vsm of the trials bound to the slots.  Shared by the Laplace and the dual-variational E-step.
+static int posterior_blocks(pgpfa_ctx* c, int nb, double diag_scale, bool want_vsmgp) {
+  const int T = c->T, p = c->p;
+  CHK(assemble(c, c->ident, nb, diag_scale));
+  CHK(factor(c, c->ws, c->ident, nb));
+  CHK(inverse_t(c, c->ws, c->ident, nb));
+  if (want_vsmgp) {
+    for (int k = 0; k < p; ++k) {
+      const int kal = (k * T) / 16 * 16;
+      GemmP g{};
+      g.A = c->ws.Mt + (size_t)kal * c->ld + (size_t)k * T; g.sA = c->ws.sM; g.lda = c->ld;
+      g.B = g.A; g.sB = c->ws.sM; g.ldb = c->ld;
+      g.C = c->ws.H; g.sC = c->ws.sH; g.ldc = T;        // slot-indexed staging: the factor slab is free now
+      g.M = T; g.N = T; g.K = c->npad - kal; g.alpha = 1.0; g.beta = 0.0;
+      g.slots = c->ident; g.nbatch = nb; g.mode = GEMM_FULL; g.kflags = 0;
+      CHK(gemm(c, false, g));
+      hipLaunchKernelGGL(scatter_vsmgp_kernel, dim3((unsigned)(((size_t)T * T + 255) / 256), nb), dim3(256), 0, c->st, c->ws.H, c->ws.sH, c->vsmgp,
+                         T, p, k, c->trial_of_slot);
+    }
+  }
+  const int KY = std::min(p, 16);
+  prof_begin(c, TAG_VSM, (double)nb * c->npad * c->npad * p);
+  dispatch_pmax(p, [&](auto pm) {
+    hipLaunchKernelGGL(post_vsm_kernel<decltype(pm)::value>, dim3((T + 63) / 64, nb), dim3(64, KY), 0, c->st, c->ws.Mt, c->ws.sM, c->ld, c->npad,
+                       T, p, c->vsm, c->ident, c->trial_of_slot);
+  });
+  prof_end(c);
+  HIPC(hipGetLastError());
+  return 0;
+}
+
 int pgpfa_estep_laplace(pgpfa_ctx* c, int n, const int32_t* idx, int warm_start, double* obj_sum, int32_t* iters, int32_t* status) {
   CHK(ready(c));
   Trials tr;
@@ -868,32 +902,9 @@ int pgpfa_estep_laplace(pgpfa_ctx* c, int n, const int32_t* idx, int warm_start,
     }
 
     // posterior covariance blocks at the mode
-    CHK(assemble(c, c->ident, nb));
-    CHK(factor(c, c->ws, c->ident, nb));
+    CHK(posterior_blocks(c, nb, 1.0, true));
     n_fact += nb;
     for (int s = 0; s < nb; ++s) its[s] += 1;
-    CHK(inverse_t(c, c->ws, c->ident, nb));
-    for (int k = 0; k < p; ++k) {
-      const int kal = (k * T) / 16 * 16;
-      GemmP g{};
-      g.A = c->ws.Mt + (size_t)kal * c->ld + (size_t)k * T; g.sA = c->ws.sM; g.lda = c->ld;
-      g.B = g.A; g.sB = c->ws.sM; g.ldb = c->ld;
-      g.C = c->ws.H; g.sC = c->ws.sH; g.ldc = T;        // slot-indexed staging: the factor slab is free now
-      g.M = T; g.N = T; g.K = c->npad - kal; g.alpha = 1.0; g.beta = 0.0;
-      g.slots = c->ident; g.nbatch = nb; g.mode = GEMM_FULL; g.kflags = 0;
-      CHK(gemm(c, false, g));
-      hipLaunchKernelGGL(scatter_vsmgp_kernel, dim3((unsigned)(((size_t)T * T + 255) / 256), nb), dim3(256), 0, c->st, c->ws.H, c->ws.sH, c->vsmgp,
-                         T, p, k, c->trial_of_slot);
-    }
-    {
-      const int KY = std::min(p, 16);
-      prof_begin(c, TAG_VSM, (double)nb * c->npad * c->npad * p);
-      dispatch_pmax(p, [&](auto pm) {
-        hipLaunchKernelGGL(post_vsm_kernel<decltype(pm)::value>, dim3((T + 63) / 64, nb), dim3(64, KY), 0, c->st, c->ws.Mt, c->ws.sM, c->ld, c->npad,
-                           T, p, c->vsm, c->ident, c->trial_of_slot);
-      });
-      prof_end(c);
-    }
     hipLaunchKernelGGL(scatter_rows_kernel, dim3((nvec + 255) / 256, nb), dim3(256), 0, c->st, c->Xc, ld, nvec, c->Xmode, c->trial_of_slot);
     HIPC(hipMemcpyAsync(info.data(), c->ws.info, sizeof(int) * nb, hipMemcpyDeviceToHost, c->st));
     HIPC(hipStreamSynchronize(c->st));
@@ -1122,9 +1133,121 @@ int pgpfa_mstep_tau_costgrad(pgpfa_ctx* c, int k, double logp, double* cost, dou
   return 0;
 }
 
-// ---- dual variational: declared in the header, implemented in a later milestone ------------------------
-int pgpfa_dual_costgrad(pgpfa_ctx*, int, const double*, double*, double*) { return fail("dual variational E-step: not implemented yet"); }
-int pgpfa_dual_finalize(pgpfa_ctx*, int, const int32_t*, const double*, double*) { return fail("dual variational E-step: not implemented yet"); }
+// ---- dual variational E-step (inference.py:188-432) ----------------------------------------------------
+static int ensure_lambda(pgpfa_ctx* c) {
+  if (c->lamd) return 0;
+  CHK(dmalloc(c, &c->lamd, (size_t)c->B * c->q * c->T));
+  CHK(dmalloc(c, &c->dgrad, (size_t)c->q * c->T));
+  CHK(dmalloc(c, &c->dpart, (size_t)c->B * ((c->T + 63) / 64) * 2 + 16));
+  return 0;
+}
+
+// lambda of the slots [0,nb) (already on device) -> v (into Xt), W, Kv (into KD); returns per-slot scalars
+static int dual_common(pgpfa_ctx* c, int nb, std::vector<double>* sB, std::vector<double>* sD, std::vector<double>* vKv) {
+  const int q = c->q, p = c->p, T = c->T, ntile = (T + 63) / 64;
+  const long long ld = c->ld;
+  hipLaunchKernelGGL(dual_prep_kernel, dim3(ntile, nb), dim3(64), 0, c->st, c->Y, c->C, c->d, c->lamd, (long long)q * T, c->Xt, ld, c->W,
+                     (long long)T * p * p, c->dpart, ntile, c->ident, c->trial_of_slot, q, p, T);
+  CHK(prior_mv(c, c->ident, nb, c->Xt, c->KD, c->Kpad));            // K v
+  hipLaunchKernelGGL(dots3_kernel, dim3(nb), dim3(256), 0, c->st, c->Xt, ld, c->KD, ld, (const double*)nullptr, 0LL, (const double*)nullptr, 0LL,
+                     c->n, c->ident, c->sc_qxx, c->sc_qdx, c->sc_qdd);
+  HIPC(hipGetLastError());
+  std::vector<double> part((size_t)nb * ntile * 2);
+  CHK(download(c, part.data(), c->dpart, part.size()));
+  vKv->resize(nb);
+  CHK(download(c, vKv->data(), c->sc_qxx, nb));
+  sB->assign(nb, 0.0);
+  sD->assign(nb, 0.0);
+  for (int s = 0; s < nb; ++s)
+    for (int b = 0; b < ntile; ++b) {
+      (*sB)[s] += part[((size_t)s * ntile + b) * 2];
+      (*sD)[s] += part[((size_t)s * ntile + b) * 2 + 1];
+    }
+  return 0;
+}
+
+int pgpfa_dual_costgrad(pgpfa_ctx* c, int trial, const double* lam, double* cost, double* grad) {
+  CHK(ready(c));
+  if (!lam || !cost) return fail("null argument");
+  if (trial < 0 || trial >= c->R) return fail("trial %d out of range", trial);
+  CHK(ensure_lambda(c));
+  const int q = c->q, p = c->p, T = c->T;
+  for (size_t i = 0; i < (size_t)q * T; ++i)
+    if (!(lam[i] > 0.0)) return fail("lambda must be positive (entry %zu = %g)", i, lam[i]);
+  std::vector<int> tr{trial};
+  CHK(upload_list(c, c->trial_of_slot, tr));
+  CHK(upload(c, c->lamd, lam, (size_t)q * T));
+  std::vector<double> sB, sD, vKv;
+  CHK(dual_common(c, 1, &sB, &sD, &vKv));
+  HIPC(hipMemsetAsync(c->ws.info, 0, sizeof(int), c->st));
+  CHK(assemble(c, c->ident, 1, 1.0 + 1e-6));                          // inference.py:190
+  CHK(factor(c, c->ws, c->ident, 1));
+  hipLaunchKernelGGL(logdet_kernel, dim3(1), dim3(256), 0, c->st, c->ws.H, c->ld, c->npad, c->tscal + 8);
+  double logdetH = 0.0;
+  int info = 0;
+  HIPC(hipMemcpyAsync(&logdetH, c->tscal + 8, sizeof(double), hipMemcpyDeviceToHost, c->st));
+  HIPC(hipMemcpyAsync(&info, c->ws.info, sizeof(int), hipMemcpyDeviceToHost, c->st));
+  HIPC(hipStreamSynchronize(c->st));
+  if (info != 0) return fail("dual problem: posterior precision not positive definite (pivot %d)", info);
+  // A + B + C + D of inference.py:203-213 ; C = 0.5*logdet(Sigma) = -0.5*logdet(precision + jitter)
+  *cost = 0.5 * vKv[0] - sB[0] - 0.5 * logdetH + sD[0];
+  if (grad) {
+    CHK(inverse_t(c, c->ws, c->ident, 1));
+    const int KY = std::min(p, 16);
+    dispatch_pmax(p, [&](auto pm) {
+      hipLaunchKernelGGL(post_vsm_kernel<decltype(pm)::value>, dim3((T + 63) / 64, 1), dim3(64, KY), 0, c->st, c->ws.Mt, c->ws.sM, c->ld, c->npad,
+                         T, p, c->vsm, c->ident, c->trial_of_slot);
+    });
+    hipLaunchKernelGGL(dual_grad_kernel, dim3((T + 63) / 64, q), dim3(64), 0, c->st, c->C, c->d, c->lamd, c->KD,
+                       c->vsm + (size_t)trial * T * p * p, c->dgrad, q, p, T);
+    HIPC(hipGetLastError());
+    CHK(download(c, grad, c->dgrad, (size_t)q * T));
+  }
+  return 0;
+}
+
+int pgpfa_dual_finalize(pgpfa_ctx* c, int n, const int32_t* idx, const double* lam, double* nlp_sum) {
+  CHK(ready(c));
+  if (!lam) return fail("null argument");
+  CHK(ensure_lambda(c));
+  Trials tr;
+  CHK(resolve_trials(c, n, idx, &tr));
+  const int N = (int)tr.v.size();
+  const int q = c->q;
+  const long long ld = c->ld;
+  double total = 0.0;
+  std::vector<double> f(c->B), qxx(c->B);
+  std::vector<int> info(c->B);
+  for (int c0 = 0; c0 < N; c0 += c->B) {
+    const int nb = std::min(c->B, N - c0);
+    std::vector<int> tos(tr.v.begin() + c0, tr.v.begin() + c0 + nb);
+    CHK(upload_list(c, c->trial_of_slot, tos));
+    CHK(upload(c, c->lamd, lam + (size_t)c0 * q * c->T, (size_t)nb * q * c->T));
+    HIPC(hipMemsetAsync(c->ws.info, 0, sizeof(int) * nb, c->st));
+    std::vector<double> sB, sD, vKv;
+    CHK(dual_common(c, nb, &sB, &sD, &vKv));
+    // posterior mean -K C_big (lambda - y) (inference.py:194) and covariance blocks (inference.py:188-191)
+    hipLaunchKernelGGL(negate_rows_kernel, dim3((c->n + 255) / 256, nb), dim3(256), 0, c->st, c->KD, ld, c->Xc, ld, c->n, c->ident);
+    CHK(posterior_blocks(c, nb, 1.0 + 1e-6, true));
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3((c->n + 255) / 256, nb), dim3(256), 0, c->st, c->Xc, ld, c->n, c->Xmode, c->trial_of_slot);
+    // negLogPosteriorUnNorm at the VI mean (inference.py:333)
+    CHK(prior_mv(c, c->ident, nb, c->Xc, c->KX));
+    hipLaunchKernelGGL(dots3_kernel, dim3(nb), dim3(256), 0, c->st, c->Xc, ld, c->KX, ld, (const double*)nullptr, 0LL, (const double*)nullptr, 0LL,
+                       c->n, c->ident, c->sc_qxx, c->sc_qdx, c->sc_qdd);
+    CHK(poisson(c, c->ident, nb, c->Xc, c->Gl, c->Wt, c->sc_f, 0));
+    CHK(download(c, f.data(), c->sc_f, nb));
+    CHK(download(c, qxx.data(), c->sc_qxx, nb));
+    HIPC(hipMemcpyAsync(info.data(), c->ws.info, sizeof(int) * nb, hipMemcpyDeviceToHost, c->st));
+    HIPC(hipStreamSynchronize(c->st));
+    for (int s = 0; s < nb; ++s) {
+      if (info[s] != 0) return fail("dual finalize: posterior precision of trial %d not positive definite", tos[s]);
+      total += f[s] + 0.5 * qxx[s];
+    }
+  }
+  CHK(remember_trials(c, tr.v));
+  if (nlp_sum) *nlp_sum = total;
+  return 0;
+}
 
 // ---- multi-GPU ---------------------------------------------------------------------------------------------
 int pgpfa_comm_unique_id(char* id128) {

@@ -233,6 +233,21 @@ class Context:
         g = None if post_vsmgp is None else as_f64(post_vsmgp).reshape(n, self.T * self.T * self.p)
         check(self.lib.pgpfa_set_posterior(self.h, n, iptr(ii), dptr(m), dptr(v), None if g is None else dptr(g)))
 
+    # -- dual variational ---------------------------------------------------------------------
+    def dual_costgrad(self, trial, lam, want_grad=True):
+        lam = as_f64(lam).reshape(-1)
+        cost = ct.c_double(0.0)
+        grad = np.empty(self.q * self.T) if want_grad else None
+        check(self.lib.pgpfa_dual_costgrad(self.h, int(trial), dptr(lam), ct.byref(cost), dptr(grad) if want_grad else None))
+        return cost.value, grad
+
+    def dual_finalize(self, idx, lam):
+        n, ii = self._n_idx(idx)
+        lam = as_f64(lam).reshape(n, self.q * self.T)
+        tot = ct.c_double(0.0)
+        check(self.lib.pgpfa_dual_finalize(self.h, n, iptr(ii), dptr(lam), ct.byref(tot)))
+        return tot.value
+
     # -- M-step --------------------------------------------------------------------------------
     def mstep_cd_costgrad(self, vec, prior_center=None, inv_s2=0.0):
         vec = as_f64(vec).reshape(-1)

@@ -184,3 +184,55 @@ def test_ragged_sizes_and_single_trial(funs_mod):
             assert np.max(np.abs(infRes['post_mean'][r] - res['post_mean'][r])) <= 1e-7
             assert rel(infRes['post_vsm'][r], res['post_vsm'][r]) <= 1e-8
             assert rel(infRes['post_vsmGP'][r], res['post_vsmGP'][r]) <= 1e-8
+
+
+def test_dual_variational_vs_reference(funs_mod):
+    """a8: dual cost/gradient at the reference's probe (1e-9 rel) and one full dual E-step on the toy
+    (20 neurons, 2 latents, T=50) against the reference and the oracle (same L-BFGS-B calls)."""
+    from funs import _hip
+    g = load_golden('var_toy.npz')
+    Ys = [g['Y'][r].astype(float) for r in range(g['Y'].shape[0])]
+    exp = Experiment(Ys, float(g['binSize']))
+    params = {'C': g['init_C'].copy(), 'd': g['init_d'].copy(), 'tau': g['init_tau'].copy()}
+    ctx = _hip.Context(20, 2, 50, len(Ys), float(g['binSize']))
+    try:
+        ctx.upload_counts(g['Y'])
+        ctx.set_params(params['C'], params['d'], params['tau'])
+        cost, grad = ctx.dual_costgrad(0, g['lam_probe'])
+        assert abs(cost - float(g['dual_cost'])) <= 1e-9 * abs(float(g['dual_cost']))
+        assert rel(grad, g['dual_grad']) <= 1e-9
+    finally:
+        ctx.close()
+    infRes, nll, vlb, opt = funs_mod.inference.dualVariational(exp, params)
+    # the reference's own numbers (L-BFGS-B stops on factr=1e7: f-tolerance 2e-9*|f|)
+    assert abs(vlb - float(g['estep_vlb'])) <= 1e-3
+    assert abs(nll - float(g['estep_nll'])) <= 1e-3
+    for r in (0, 4, 9):
+        assert np.max(np.abs(infRes['post_mean'][r] - g['estep_post_mean'][r])) <= 2e-3
+        assert rel(infRes['post_vsm'][r], g['estep_post_vsm'][r]) <= 2e-3
+    # same lambda in -> same posterior out (finalize only), tight: the reference's optimal lambda
+    ctx = _hip.Context(20, 2, 50, len(Ys), float(g['binSize']))
+    try:
+        ctx.upload_counts(g['Y'])
+        ctx.set_params(params['C'], params['d'], params['tau'])
+        nlp = ctx.dual_finalize(None, g['estep_lambda'])
+        assert abs(-nlp / len(Ys) - float(g['estep_nll'])) <= 1e-8 * abs(float(g['estep_nll']))
+        assert rel(ctx.post_mean(), g['estep_post_mean']) <= 1e-9
+        assert rel(ctx.post_vsm(), g['estep_post_vsm']) <= 1e-8
+    finally:
+        ctx.close()
+    # log-lambda variant runs and lands on a comparable bound
+    infRes2, nll2, vlb2, _ = funs_mod.inference.dualVariational(exp, params, optimizeLogLambda=True)
+    assert abs(vlb2 - vlb) <= 5e-2
+
+
+def test_variational_batch_em_vs_reference(funs_mod):
+    g = load_golden('var_toy.npz')
+    Ys = [g['Y'][r].astype(float) for r in range(g['Y'].shape[0])]
+    exp = Experiment(Ys, float(g['binSize']))
+    init = {'C': g['init_C'].copy(), 'd': g['init_d'].copy(), 'tau': g['init_tau'].copy()}
+    fit = funs_mod.engine.PPGPFAfit(exp, initParams=init, inferenceMethod='variational', EMmode='Batch', maxEMiter=3, quiet=True)
+    # SURVEY 8c: vlb 1e-3 abs per E-step; compounding through 3 EM iterations: 1e-2
+    assert np.max(np.abs(np.asarray(fit.variationalLowerBound) - g['bounded_vlb'])) <= 1e-2
+    assert np.max(np.abs(np.asarray(fit.posteriorLikelihood) - g['bounded_nll'])) <= 1e-2
+    assert rel(fit.paramSeq[-1]['C'], g['bounded_seq_C'][-1]) <= 5e-3
