@@ -97,6 +97,8 @@ int pgpfa_mstep_precomp(pgpfa_ctx* ctx, double* num_trials);
 int pgpfa_get_pautosum(pgpfa_ctx* ctx, double* out /* [p][T][T] */);
 /* MStepGPtimescaleCost(_grad) (learning.py:175-255) for latent k at log-gamma = logp. */
 int pgpfa_mstep_tau_costgrad(pgpfa_ctx* ctx, int k, double logp, double* cost, double* grad);
+/* The same for all p latents at once (one batched factorisation): logp[p] -> cost[p], grad[p]. */
+int pgpfa_mstep_tau_costgrad_batch(pgpfa_ctx* ctx, const double* logp, double* cost, double* grad);
 
 /* ---- dual variational E-step (inference.py:188-432) -------------------------------- */
 /* dualProblem and dualProblem_grad for one trial at lambda[q*T] (structured: never forms
@@ -126,6 +128,9 @@ int pgpfa_test_gemm_nt(pgpfa_ctx* ctx, int M, int N, int K, double alpha, const 
  * events on the context stream; returns average ms per launch and the flops of one launch. */
 int pgpfa_bench_syrk(pgpfa_ctx* ctx, int batch, int n, int k, int reps, double* ms_per_launch,
                      double* flops_per_launch);
+/* Sustained v_mfma_f64_16x16x4_f64 rate of the device (register-only loop): the practical MFMA
+ * ceiling under the clock the chip holds, reported next to the datasheet peak. */
+int pgpfa_bench_mfma_peak(pgpfa_ctx* ctx, int iters, double* tflops);
 
 #ifdef __cplusplus
 }

@@ -58,6 +58,27 @@ __device__ __forceinline__ void gemm_decode_tile(const GemmP& g, int tile, int& 
   }
 }
 
+// Block id -> (batch entry, tile).  The hardware deals consecutive block ids round-robin over the 8
+// XCDs (each with a private L2), so batch entries are grouped by 8: XCD x walks the tiles of entry
+// 8g+x in order.  The ~64 blocks resident on one XCD then belong to one trial and share its A/B panels
+// in that XCD's L2 (and the 256 MB Infinity Cache), instead of every block streaming private panels
+// from HBM.  Placement only affects speed, never results.
+__device__ __forceinline__ void gemm_decode_block(const GemmP& g, int bid, int& b, int& tile) {
+  const int full = g.nbatch >> 3;                 // complete groups of 8 entries
+  const int per_group = g.ntiles << 3;
+  const int grp = bid / per_group;
+  if (grp < full) {
+    const int r = bid - grp * per_group;
+    tile = r >> 3;
+    b = (grp << 3) + (r & 7);
+  } else {
+    const int m = g.nbatch - (full << 3);         // remainder group of m < 8 entries
+    const int r = bid - full * per_group;
+    tile = r / m;
+    b = (full << 3) + (r - tile * m);
+  }
+}
+
 constexpr int GBM = 128, GBN = 128, GBK = 16, GLS = 144;   // LDS row stride in doubles
 
 template <int TRANSB>
@@ -70,10 +91,8 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP g) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
 
-  // batch fastest: blocks of one trial share an XCD (id % 8 == slot % 8 when nbatch % 8 == 0)
-  const int bid = blockIdx.x;
-  const int b = bid % g.nbatch;
-  const int tile = bid / g.nbatch;
+  int b, tile;
+  gemm_decode_block(g, blockIdx.x, b, tile);
   int ti, tj;
   gemm_decode_tile(g, tile, ti, tj);
   const long long slot = g.slots ? g.slots[b] : b;
@@ -214,9 +233,8 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP g) {
 // validate the MFMA path (option use_mfma = 0); never the default.
 template <int TRANSB>
 __global__ void gemm_check_kernel(GemmP g) {
-  const int bid = blockIdx.x;
-  const int b = bid % g.nbatch;
-  const int tile = bid / g.nbatch;
+  int b, tile;
+  gemm_decode_block(g, blockIdx.x, b, tile);
   int ti, tj;
   gemm_decode_tile(g, tile, ti, tj);
   const long long slot = g.slots ? g.slots[b] : b;
@@ -256,6 +274,23 @@ __global__ void gemm_check_kernel(GemmP g) {
     if (g.beta != 0.0) v += g.beta * (*dst);
     *dst = v;
   }
+}
+
+// Register-only FP64 MFMA loop: measures the sustained v_mfma_f64_16x16x4_f64 rate of the chip (no
+// memory traffic), i.e. the practical ceiling of gemm_mfma_kernel under the clock the chip holds.
+__global__ __launch_bounds__(256) void mfma_peak_kernel(double* out, int iters) {
+  double4_t acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  double a = 1.0 + threadIdx.x * 1e-6, b = 1.0 - threadIdx.x * 1e-6;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
 inline int gemm_count_tiles(int mode, int tilesM, int tilesN) {

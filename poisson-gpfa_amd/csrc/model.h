@@ -51,6 +51,67 @@ __global__ void gram_gamma_kernel(double* __restrict__ K, double* __restrict__ M
   }
 }
 
+// batched over latents: K/M slabs of latent blockIdx.y at log-gamma logp[blockIdx.y]
+__global__ void gram_gamma_batch_kernel(double* __restrict__ K, double* __restrict__ M, int Tp, int T, const double* __restrict__ logp, double eps) {
+  const int j = blockIdx.x;
+  const size_t off = (size_t)blockIdx.y * Tp * Tp;
+  const double g = exp(logp[blockIdx.y]);
+  for (int i = threadIdx.x; i < Tp; i += blockDim.x) {
+    double kv, mv;
+    if (i < T && j < T) {
+      const double dd = (double)(i - j);
+      const double dsq = dd * dd;
+      const double temp = (1.0 - eps) * exp(-g / 2.0 * dsq);
+      kv = temp + (i == j ? eps : 0.0);
+      mv = -0.5 * temp * dsq;
+    } else {
+      kv = (i == j) ? 1.0 : 0.0;
+      mv = 0.0;
+    }
+    K[off + (size_t)j * Tp + i] = kv;
+    M[off + (size_t)j * Tp + i] = mv;
+  }
+}
+
+// out[blockIdx.x] = 2 * sum_i log L_ii of slab blockIdx.x
+__global__ void logdet_batch_kernel(const double* __restrict__ L, long long sL, int ld, int n, double* __restrict__ out) {
+  __shared__ double red[256];
+  const double* Ls = L + (size_t)blockIdx.x * sL;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += log(Ls[(size_t)i * ld + i]);
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = 2.0 * red[0];
+}
+
+// batched dot of equally laid out slabs: part[blockIdx.y][blockIdx.x]; then sum_part_batch
+__global__ void dot_part_batch_kernel(const double* __restrict__ A, long long sA, const double* __restrict__ B, long long sB, long long n,
+                                      double* __restrict__ part) {
+  __shared__ double red[256];
+  const double* a = A + (size_t)blockIdx.y * sA;
+  const double* b = B + (size_t)blockIdx.y * sB;
+  double s = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) s += a[i] * b[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = red[0];
+}
+__global__ void sum_part_batch_kernel(const double* __restrict__ part, int nper, double* __restrict__ out, int nbatch) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nbatch) return;
+  double s = 0.0;
+  for (int i = 0; i < nper; ++i) s += part[(size_t)b * nper + i];
+  out[b] = s;
+}
+
 // copy the lower triangle onto the upper one (slab of size n, ld)
 __global__ void symmetrize_kernel(double* __restrict__ A, long long sA, int ld, int n) {
   double* a = A + (size_t)blockIdx.y * sA;

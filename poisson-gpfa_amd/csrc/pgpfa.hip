@@ -521,8 +521,8 @@ int pgpfa_create(pgpfa_ctx** out, int device, int q, int p, int T, int R, double
   rc |= dmalloc(c, &c->cdout, (size_t)(p + 2) * q + 8);
   rc |= dmalloc(c, &c->last_trials, R);
   rc |= alloc_cholws(c, &c->kws, p, c->Tp, true);
-  rc |= dmalloc(c, &c->tK, slab); rc |= dmalloc(c, &c->tM, slab); rc |= dmalloc(c, &c->tA1, slab); rc |= dmalloc(c, &c->tA2, slab);
-  rc |= dmalloc(c, &c->tscal, 16); rc |= dmalloc(c, &c->tpart, 1024);
+  rc |= dmalloc(c, &c->tK, slab * p); rc |= dmalloc(c, &c->tM, slab * p); rc |= dmalloc(c, &c->tA1, slab * p); rc |= dmalloc(c, &c->tA2, slab * p);
+  rc |= dmalloc(c, &c->tscal, 16 + 8 * (size_t)p); rc |= dmalloc(c, &c->tpart, 1024 + 64 * (size_t)p);
   if (rc) { pgpfa_destroy(c); return 1; }
   e = hipStreamSynchronize(c->st);
   if (e != hipSuccess) { pgpfa_destroy(c); return fail("sync: %s", hipGetErrorString(e)); }
@@ -1133,6 +1133,59 @@ int pgpfa_mstep_tau_costgrad(pgpfa_ctx* c, int k, double logp, double* cost, dou
   return 0;
 }
 
+
+int pgpfa_mstep_tau_costgrad_batch(pgpfa_ctx* c, const double* logp, double* cost, double* grad) {
+  if (!c || !logp || !cost || !grad) return fail("null argument");
+  if (!c->have_precomp) return fail("pgpfa_mstep_precomp has not been called");
+  HIPC(hipSetDevice(c->device));
+  const int Tp = c->Tp, p = c->p;
+  const size_t slab = (size_t)Tp * Tp;
+  for (int k = 0; k < p; ++k)
+    if (!std::isfinite(logp[k])) return fail("log-gamma[%d] is not finite", k);
+  double* dlogp = c->tscal + 16;                    // [p]
+  double* dres = c->tscal + 16 + p;                 // [4][p]: logdet, tr(KinvP), tr(KinvM), tr(KinvMKinvP)
+  CHK(upload(c, dlogp, logp, p));
+  hipLaunchKernelGGL(gram_gamma_batch_kernel, dim3(Tp, p), dim3(256), 0, c->st, c->tK, c->tM, Tp, c->T, dlogp, c->eps);
+  HIPC(hipMemcpyAsync(c->kws.H, c->tK, slab * p * sizeof(double), hipMemcpyDeviceToDevice, c->st));
+  HIPC(hipMemsetAsync(c->kws.info, 0, sizeof(int) * p, c->st));
+  CHK(factor(c, c->kws, nullptr, p));
+  hipLaunchKernelGGL(logdet_batch_kernel, dim3(p), dim3(256), 0, c->st, c->kws.H, (long long)slab, Tp, Tp, dres);
+  CHK(inverse_t(c, c->kws, nullptr, p));
+  GemmP g{};
+  g.A = c->kws.Mt; g.sA = slab; g.lda = Tp; g.B = c->kws.Mt; g.sB = slab; g.ldb = Tp;
+  g.C = c->tK; g.sC = slab; g.ldc = Tp;                       // tK <- Kinv
+  g.M = Tp; g.N = Tp; g.K = Tp; g.alpha = 1.0; g.beta = 0.0; g.slots = nullptr; g.nbatch = p; g.mode = GEMM_FULL; g.kflags = KF_BEGIN_MAXRC;
+  CHK(gemm(c, false, g));
+  GemmP a1 = g;                                              // A1 = Kinv * M
+  a1.A = c->tK; a1.B = c->tM; a1.C = c->tA1; a1.kflags = 0;
+  CHK(gemm(c, false, a1));
+  GemmP a2 = g;                                              // A2 = P * Kinv
+  a2.A = c->Pauto; a2.B = c->tK; a2.C = c->tA2; a2.kflags = 0;
+  CHK(gemm(c, false, a2));
+  const int nbk = 64;
+  auto bdot = [&](const double* A, const double* B, double* out) {
+    hipLaunchKernelGGL(dot_part_batch_kernel, dim3(nbk, p), dim3(256), 0, c->st, A, (long long)slab, B, (long long)slab, (long long)slab, c->tpart);
+    hipLaunchKernelGGL(sum_part_batch_kernel, dim3(1), dim3(64), 0, c->st, c->tpart, nbk, out, p);
+  };
+  bdot(c->tK, c->Pauto, dres + p);
+  bdot(c->tK, c->tM, dres + 2 * p);
+  bdot(c->tA1, c->tA2, dres + 3 * p);
+  HIPC(hipGetLastError());
+  std::vector<double> h(4 * (size_t)p);
+  std::vector<int> info(p);
+  HIPC(hipMemcpyAsync(h.data(), dres, 4 * p * sizeof(double), hipMemcpyDeviceToHost, c->st));
+  HIPC(hipMemcpyAsync(info.data(), c->kws.info, sizeof(int) * p, hipMemcpyDeviceToHost, c->st));
+  HIPC(hipStreamSynchronize(c->st));
+  const double R = c->n_trials_global;
+  for (int k = 0; k < p; ++k) {
+    if (info[k] != 0) return fail("timescale Gram matrix of latent %d not positive definite at log-gamma=%g", k, logp[k]);
+    cost[k] = 0.5 * R * h[k] + 0.5 * h[p + k];
+    const double dE = -0.5 * R * h[2 * p + k] + 0.5 * h[3 * p + k];
+    grad[k] = -dE * std::exp(logp[k]);
+  }
+  return 0;
+}
+
 // ---- dual variational E-step (inference.py:188-432) ----------------------------------------------------
 static int ensure_lambda(pgpfa_ctx* c) {
   if (c->lamd) return 0;
@@ -1358,6 +1411,29 @@ int pgpfa_test_gemm_nt(pgpfa_ctx* c, int M, int N, int K, double alpha, const do
   hipStreamSynchronize(c->st);
   while (c->allocs.size() > mark) { hipFree(c->allocs.back()); c->allocs.pop_back(); }
   return rc;
+}
+
+int pgpfa_bench_mfma_peak(pgpfa_ctx* c, int iters, double* tflops) {
+  if (!c || !tflops || iters < 1) return fail("invalid argument");
+  HIPC(hipSetDevice(c->device));
+  const int blocks = 256 * 8;                      // 8 waves per SIMD worth of blocks in flight
+  double* out = nullptr;
+  HIPC(hipMalloc((void**)&out, (size_t)blocks * 256 * sizeof(double)));
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, c->st, out, iters);
+  hipEventRecord(e0, c->st);
+  hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, c->st, out, iters);
+  hipEventRecord(e1, c->st);
+  hipEventSynchronize(e1);
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, e0, e1);
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  hipFree(out);
+  HIPC(hipGetLastError());
+  const double flops = (double)blocks * 4.0 * iters * 8.0 * 2048.0;   // 4 waves/block, 8 MFMAs/iter, 2*16*16*4 flops
+  *tflops = flops / (ms * 1e-3) / 1e12;
+  return 0;
 }
 
 int pgpfa_bench_syrk(pgpfa_ctx* c, int batch, int n, int k, int reps, double* ms_per_launch, double* flops_per_launch) {

@@ -42,6 +42,7 @@ _SIGNATURES = {
     'pgpfa_mstep_precomp': [ct.c_void_p, c_double_p],
     'pgpfa_get_pautosum': [ct.c_void_p, c_double_p],
     'pgpfa_mstep_tau_costgrad': [ct.c_void_p, ct.c_int, ct.c_double, c_double_p, c_double_p],
+    'pgpfa_mstep_tau_costgrad_batch': [ct.c_void_p, c_double_p, c_double_p, c_double_p],
     'pgpfa_dual_costgrad': [ct.c_void_p, ct.c_int, c_double_p, c_double_p, c_double_p],
     'pgpfa_dual_finalize': [ct.c_void_p, ct.c_int, c_int32_p, c_double_p, c_double_p],
     'pgpfa_comm_unique_id': [ct.c_char_p],
@@ -50,6 +51,7 @@ _SIGNATURES = {
     'pgpfa_test_potrf': [ct.c_void_p, ct.c_int, ct.c_int, c_double_p, c_double_p, c_double_p],
     'pgpfa_test_gemm_nt': [ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, ct.c_double, c_double_p, c_double_p, ct.c_double, c_double_p],
     'pgpfa_bench_syrk': [ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, ct.c_int, c_double_p, c_double_p],
+    'pgpfa_bench_mfma_peak': [ct.c_void_p, ct.c_int, c_double_p],
 }
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ['pgpfa_last_error'])
 
@@ -273,6 +275,12 @@ class Context:
         check(self.lib.pgpfa_mstep_tau_costgrad(self.h, int(k), float(logp), ct.byref(cost), ct.byref(grad)))
         return cost.value, grad.value
 
+    def mstep_tau_costgrad_batch(self, logp):
+        logp = as_f64(logp).reshape(-1)
+        cost, grad = np.empty(self.p), np.empty(self.p)
+        check(self.lib.pgpfa_mstep_tau_costgrad_batch(self.h, dptr(logp), dptr(cost), dptr(grad)))
+        return cost, grad
+
     # -- comm --------------------------------------------------------------------------------------
     def comm_init(self, uid, rank, nranks):
         check(self.lib.pgpfa_comm_init(self.h, uid, int(rank), int(nranks)))
@@ -302,6 +310,11 @@ class Context:
         Acm, Bcm = as_f64(A.T), as_f64(B.T)                                   # column-major (M,K) == row-major (K,M)
         check(self.lib.pgpfa_test_gemm_nt(self.h, M, N, K, float(alpha), dptr(Acm), dptr(Bcm), float(beta), dptr(Ccm)))
         return Ccm.T.copy()
+
+    def bench_mfma_peak(self, iters=20000):
+        tf = ct.c_double(0.0)
+        check(self.lib.pgpfa_bench_mfma_peak(self.h, int(iters), ct.byref(tf)))
+        return tf.value
 
     def bench_syrk(self, batch, n, k, reps):
         ms, fl = ct.c_double(0.0), ct.c_double(0.0)

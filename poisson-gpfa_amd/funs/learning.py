@@ -161,19 +161,70 @@ def MStepGPtimescaleCost_grad(p, precomp, epsNoise):
     return np.array([_tau_eval(precomp, p)[1]])
 
 
+TAU_SOLVER = 'lockstep'      # 'lockstep' (all latents per device evaluation) or 'scipy' (the reference's BFGS calls)
+
+
+def _lockstep_minimize(evaluate, p0, gtol=1e-8, xtol=1e-10, max_iter=60):
+    """Minimise xdim independent smooth 1-D costs f_k(p_k) together: every iteration is ONE batched device
+    evaluation of all (f_k, f_k').  Safeguarded secant iteration on the gradient with a bracketing fallback;
+    stops per latent on |f'| <= gtol (scipy BFGS's criterion, learning.py:283-288) or |step| <= xtol."""
+    p = np.array(p0, dtype=np.float64)
+    k = p.size
+    f, g = evaluate(p)
+    nfev = 1
+    done = np.abs(g) <= gtol
+    lo = np.where(g < 0, p, -np.inf)          # g < 0: minimum lies to the right
+    hi = np.where(g > 0, p, np.inf)
+    p_prev, g_prev = p.copy(), g.copy()
+    step = -np.sign(g) * 0.25
+    for _ in range(max_iter):
+        if np.all(done):
+            break
+        p_new = np.where(done, p, p + step)
+        have_lo, have_hi = np.isfinite(lo), np.isfinite(hi)
+        both = have_lo & have_hi
+        outside = both & ((p_new <= lo) | (p_new >= hi))
+        p_new = np.where(outside & ~done, 0.5 * (lo + hi), p_new)
+        f_new, g_new = evaluate(p_new)
+        nfev += 1
+        lo = np.where((g_new < 0) & ~done, np.maximum(lo, p_new), lo)
+        hi = np.where((g_new > 0) & ~done, np.minimum(hi, p_new), hi)
+        dp = p_new - p
+        with np.errstate(divide='ignore', invalid='ignore'):
+            curv = (g_new - g) / dp
+        sec = np.where((curv > 0) & np.isfinite(curv), -g_new / curv, -np.sign(g_new) * np.minimum(2.0 * np.abs(dp), 1.0))
+        sec = np.clip(sec, -1.0, 1.0)
+        newly = (~done) & ((np.abs(g_new) <= gtol) | (np.abs(dp) <= xtol))
+        p_prev, g_prev = np.where(done, p_prev, p), np.where(done, g_prev, g)
+        p, f, g = np.where(done, p, p_new), np.where(done, f, f_new), np.where(done, g, g_new)
+        step = np.where(done | newly, 0.0, sec)
+        done = done | newly
+    return p, f, g, nfev, done
+
+
 def learnGPparams(oldParams, infRes, experiment):
-    """reference learning.py:257-293: per latent scipy BFGS (gtol 1e-8) from p0 = log(1/tau_bins^2)."""
+    """reference learning.py:257-293: minimise each latent's timescale cost from p0 = log(1/tau_bins^2) to
+    |grad| <= 1e-8.  The xdim problems are independent and one-dimensional, so by default they are solved in
+    lockstep (one batched Gram/Cholesky/trace evaluation of all latents per iteration); TAU_SOLVER='scipy'
+    runs the reference's per-latent scipy BFGS calls on the same device callbacks instead."""
     xdim = np.shape(oldParams['C'])[1]
     sess = _resident_session(infRes, experiment, xdim)
     binSize = experiment.binSize
     oldTau = np.asarray(oldParams['tau'], dtype=np.float64) * 1000 / binSize
-    precomp = DevicePrecomp(sess, sess.T)
-    tempTau = np.zeros(xdim)
+    DevicePrecomp(sess, sess.T)
+    initp = np.log(1 / oldTau ** 2)
     details = [[]] * xdim
+    if TAU_SOLVER == 'lockstep':
+        pv, fv, gv, nfev, ok = _lockstep_minimize(sess.ctx.mstep_tau_costgrad_batch, initp)
+        for xd in range(xdim):
+            details[xd] = op.OptimizeResult(x=np.array([pv[xd]]), fun=fv[xd], jac=np.array([gv[xd]]), nfev=nfev,
+                                            success=bool(ok[xd]), message='lockstep secant')
+        tempTau = (1 / np.exp(pv)) ** 0.5
+        return tempTau * binSize / 1000, details
+    tempTau = np.zeros(xdim)
     for xd in range(xdim):
-        initp = np.log(1 / oldTau[xd] ** 2)
         cache = _CostGradCache(lambda v, k=xd: sess.ctx.mstep_tau_costgrad(k, float(np.asarray(v).reshape(-1)[0])))
-        res = op.minimize(fun=cache.fun, x0=initp, jac=lambda v, c=cache: np.array([c.jac(v)]),
+        res = op.minimize(fun=cache.fun, x0=initp[xd], jac=lambda v, c=cache: np.array([c.jac(v)]),
                           options={'disp': False, 'gtol': 1e-8})
         details[xd] = res
         tempTau[xd] = (1 / np.exp(res.x[0])) ** 0.5

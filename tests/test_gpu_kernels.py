@@ -178,3 +178,32 @@ def test_mstep_tau_costgrad_vs_golden(hip, c1):
 def test_library_reports_info(small_ctx):
     assert small_ctx.info('n_pad') == 128
     assert small_ctx.info('hbm_bytes_allocated') > 0
+
+
+def test_tau_batch_equals_single_and_lockstep_matches_bfgs(hip, c1):
+    """Batched tau cost/grad == per-latent evaluation; the lockstep solver lands on scipy BFGS's optimum."""
+    import funs
+    from conftest import Experiment
+    res, _, _ = orc.laplace(c1['Ys'], c1['init'], c1['binSize'], mode='exact', return_cov=False)
+    ctx = hip.Context(30, 3, 100, 20, c1['binSize'])
+    try:
+        ctx.upload_counts(c1['Y'])
+        ctx.set_params(c1['init_C'], c1['init_d'], c1['init_tau'])
+        ctx.set_posterior(None, np.stack(res['post_mean']), np.stack(res['post_vsm']), np.stack(res['post_vsmGP']))
+        ctx.mstep_precomp()
+        logp = np.array([-6.0, -7.5, -5.2])
+        cb, gb = ctx.mstep_tau_costgrad_batch(logp)
+        for k in range(3):
+            c1_, g1_ = ctx.mstep_tau_costgrad(k, logp[k])
+            assert abs(cb[k] - c1_) <= 1e-12 * abs(c1_) and abs(gb[k] - g1_) <= 1e-10 * max(1.0, abs(g1_))
+    finally:
+        ctx.close()
+    exp = Experiment(c1['Ys'], c1['binSize'])
+    tau_o, _ = orc.learn_tau(c1['init'], res, c1['binSize'])
+    for solver in ('lockstep', 'scipy'):
+        funs.learning.TAU_SOLVER = solver
+        try:
+            tau, det = funs.learning.learnGPparams(c1['init'], res, exp)
+        finally:
+            funs.learning.TAU_SOLVER = 'lockstep'
+        assert np.max(np.abs(np.log(tau) - np.log(tau_o))) <= 1e-7, solver
