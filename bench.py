@@ -149,7 +149,7 @@ def main():
 
     params = init
     optim = None
-    nll_hist, estep_ms, mstep_ms, facts, solves = [], [], [], [], []
+    nll_hist, estep_ms, mstep_ms, facts, solves, pcgs = [], [], [], [], [], []
 
     def em_step():
         nonlocal params, optim
@@ -163,6 +163,7 @@ def main():
         mstep_ms.append((t2 - t1) * 1e3)
         facts.append(sess.ctx.info('last_newton_factorizations'))
         solves.append(sess.ctx.info('last_newton_solves'))
+        pcgs.append(sess.ctx.info('last_pcg_iterations'))
 
     for _ in range(args.warmup):
         em_step()
@@ -201,6 +202,7 @@ def main():
         'estep_ms': [round(x, 1) for x in estep_ms], 'mstep_ms': [round(x, 1) for x in mstep_ms],
         'factorizations_per_trial': [round(f / R, 2) for f in facts],
         'newton_solves_per_trial': [round(f / R, 2) for f in solves],
+        'pcg_iterations_per_trial': [round(f / R, 2) for f in pcgs],
         'nll': nll_hist,
         'roofline': {'bound': 'mfma', 'kernel': 'gemm_mfma_kernel<0> (FP64 16x16x4 MFMA; SYRK/TRSM/TRTRI/selected-inverse GEMMs)',
                      'achieved': achieved, 'peak': FP64_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / FP64_MATRIX_PEAK_TFLOPS,

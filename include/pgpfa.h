@@ -124,6 +124,9 @@ int pgpfa_test_potrf(pgpfa_ctx* ctx, int batch, int n, const double* A, double* 
  * the scalar check kernel (use_mfma=0). */
 int pgpfa_test_gemm_nt(pgpfa_ctx* ctx, int M, int N, int K, double alpha, const double* A,
                        const double* B, double beta, double* C);
+/* The same with B given as K x N column-major (C = alpha*A*B + beta*C): the multi-RHS sweep form. */
+int pgpfa_test_gemm_nn(pgpfa_ctx* ctx, int M, int N, int K, double alpha, const double* A,
+                       const double* B, double beta, double* C);
 /* Times `reps` launches of the dominant kernel (batched trailing SYRK update, K=512) with HIP
  * events on the context stream; returns average ms per launch and the flops of one launch. */
 int pgpfa_bench_syrk(pgpfa_ctx* ctx, int batch, int n, int k, int reps, double* ms_per_launch,

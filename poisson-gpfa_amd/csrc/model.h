@@ -673,6 +673,148 @@ __global__ void negate_rows_kernel(const double* __restrict__ src, long long sSr
   if (i < n) dst[(size_t)slot * sDst + i] = -src[(size_t)slot * sSrc + i];
 }
 
+// --------------------------------------------------------------------------------------------------
+// Shared-preconditioner Newton-PCG pieces.
+// Wbar[t] = mean over the listed slots of W[slot][t]   (p x p per bin) -> written into slot `dst` of Wdst
+// --------------------------------------------------------------------------------------------------
+__global__ void mean_w_kernel(const double* __restrict__ W, long long sW, const int* __restrict__ slots, int nslots, int len,
+                              double* __restrict__ out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= len) return;
+  double s = 0.0;
+  for (int i = 0; i < nslots; ++i) s += W[(size_t)slots[i] * sW + e];
+  out[e] = s / (double)nslots;
+}
+
+// transpose a (npad x npad) lower factor slab into an upper slab U = L^T, and its 128x128 diagonal
+// inverses into DinvT[k] = Dinv[k]^T (one slot)
+__global__ void transpose_lower_kernel(const double* __restrict__ L, double* __restrict__ U, int ld, int npad) {
+  __shared__ double tile[32][33];
+  const int bi = blockIdx.x * 32, bj = blockIdx.y * 32;
+  if (bi < bj) return;                                    // only tiles on/below the diagonal hold data
+  for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+    const int i = bi + threadIdx.x, j = bj + r;
+    tile[r][threadIdx.x] = (i < npad && j < npad && i >= j) ? L[(size_t)j * ld + i] : 0.0;
+  }
+  __syncthreads();
+  for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+    const int j = bj + threadIdx.x, i = bi + r;           // U[j][i] = L[i][j], stored column-major: U[i*ld + j]
+    if (i < npad && j < npad) U[(size_t)i * ld + j] = tile[threadIdx.x][r];
+  }
+}
+__global__ void transpose_diag_blocks_kernel(const double* __restrict__ D, double* __restrict__ DT) {
+  const double* d = D + (size_t)blockIdx.x * 128 * 128;
+  double* t = DT + (size_t)blockIdx.x * 128 * 128;
+  for (int e = threadIdx.x; e < 128 * 128; e += blockDim.x) {
+    const int r = e & 127, c = e >> 7;
+    t[(size_t)r * 128 + c] = d[(size_t)c * 128 + r];
+  }
+}
+
+// q = W p  added onto q (which already holds Kinv p):  q[(k,t)] += sum_l W[t][k][l] p[(l,t)]
+// then pq[slot] = p.q ; block per slot
+__global__ __launch_bounds__(256) void pcg_hessvec_dot_kernel(const double* __restrict__ W, long long sW, const double* __restrict__ P,
+                                                              double* __restrict__ Q, long long sV, int T, int p, int n,
+                                                              const int* __restrict__ slots, double* __restrict__ pq) {
+  __shared__ double red[4];
+  const size_t slot = slots[blockIdx.x];
+  const double* w = W + slot * sW;
+  const double* pv = P + slot * sV;
+  double* q = Q + slot * sV;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int k = i / T, t = i - k * T;
+    const double* wt = w + (size_t)t * p * p + (size_t)k * p;
+    double s = q[i];
+    for (int l = 0; l < p; ++l) s += wt[l] * pv[(size_t)l * T + t];
+    q[i] = s;
+    acc += s * pv[i];
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) pq[slot] = red[0] + red[1] + red[2] + red[3];
+}
+
+// alpha = rz/pq ; x += alpha p ; r -= alpha q   (block per slot)
+__global__ __launch_bounds__(256) void pcg_update_xr_kernel(double* __restrict__ X, double* __restrict__ R, const double* __restrict__ P,
+                                                            const double* __restrict__ Q, long long sV, int n, const int* __restrict__ slots,
+                                                            const double* __restrict__ rz, const double* __restrict__ pq) {
+  const size_t slot = slots[blockIdx.x];
+  const double d = pq[slot];
+  const double alpha = (d > 0.0) ? rz[slot] / d : 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    X[slot * sV + i] += alpha * P[slot * sV + i];
+    R[slot * sV + i] -= alpha * Q[slot * sV + i];
+  }
+}
+
+// rz_new = r.z ; beta = rz_new/rz (0 on the first call: first != 0) ; p = z + beta p ; rz = rz_new ; also rr = r.r
+__global__ __launch_bounds__(256) void pcg_update_p_kernel(const double* __restrict__ R, const double* __restrict__ Z, double* __restrict__ P,
+                                                           long long sV, int n, const int* __restrict__ slots, double* __restrict__ rz,
+                                                           double* __restrict__ rr, int first) {
+  __shared__ double red[2][4];
+  __shared__ double beta_s;
+  const size_t slot = slots[blockIdx.x];
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const double r = R[slot * sV + i];
+    a += r * Z[slot * sV + i];
+    b += r * r;
+  }
+  for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double rzn = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    const double old = rz[slot];
+    beta_s = (first || !(old > 0.0)) ? 0.0 : rzn / old;
+    rz[slot] = rzn;
+    rr[slot] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  }
+  __syncthreads();
+  const double beta = beta_s;
+  for (int i = threadIdx.x; i < n; i += 256) P[slot * sV + i] = Z[slot * sV + i] + beta * P[slot * sV + i];
+}
+
+// r = -g ; x = 0  (rows >= n of every vector are kept at zero)
+__global__ void pcg_init_kernel(const double* __restrict__ G, double* __restrict__ R, double* __restrict__ X, long long sV, int n, int npad,
+                                const int* __restrict__ slots) {
+  const size_t slot = slots[blockIdx.y];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < npad) {
+    R[slot * sV + i] = (i < n) ? -G[slot * sV + i] : 0.0;
+    X[slot * sV + i] = 0.0;
+  }
+}
+
+// dec = -g.x ; smax = max|x|   (block per slot)
+__global__ __launch_bounds__(256) void step_stats_kernel(const double* __restrict__ G, const double* __restrict__ X, long long sV, int n,
+                                                         const int* __restrict__ slots, double* __restrict__ dec, double* __restrict__ smax) {
+  __shared__ double red[2][4];
+  const size_t slot = slots[blockIdx.x];
+  double d = 0.0, m = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const double x = X[slot * sV + i];
+    d -= G[slot * sV + i] * x;
+    m = fmax(m, fabs(x));
+  }
+  for (int off = 32; off > 0; off >>= 1) { d += __shfl_down(d, off); m = fmax(m, __shfl_down(m, off)); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = d; red[1][threadIdx.x >> 6] = m; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    dec[slot] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    smax[slot] = fmax(fmax(red[1][0], red[1][1]), fmax(red[1][2], red[1][3]));
+  }
+}
+
+// copy rows of the listed slots: dst[slot] = src[slot] (n entries)
+__global__ void copy_rows_kernel(const double* __restrict__ src, double* __restrict__ dst, long long sV, int n, const int* __restrict__ slots) {
+  const size_t slot = slots[blockIdx.y];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[slot * sV + i] = src[slot * sV + i];
+}
+
 // counts: double [R][q][T] -> uint8 with validation (non-negative integers <= 255)
 __global__ void pack_counts_kernel(const double* __restrict__ src, uint8_t* __restrict__ dst, size_t n, int* __restrict__ bad) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

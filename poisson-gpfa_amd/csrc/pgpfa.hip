@@ -92,6 +92,13 @@ struct pgpfa_ctx {
   double *Xc = nullptr, *Xt = nullptr, *KX = nullptr, *KD = nullptr, *Gl = nullptr, *Glt = nullptr, *Gt = nullptr, *Dl = nullptr;
   double *W = nullptr, *Wt = nullptr, *fpart = nullptr;
   double *lamd = nullptr, *dgrad = nullptr, *dpart = nullptr;   // dual variational scratch
+  // shared-preconditioner Newton-PCG: one factor per chunk (mean-trial Hessian), PCG vectors per slot
+  CholWS sws{};
+  double *sU = nullptr, *sDinvT = nullptr, *Wbar = nullptr;
+  double *Rv = nullptr, *Zv = nullptr, *Pv = nullptr, *Qv = nullptr;
+  double *sc_rz = nullptr, *sc_pq = nullptr, *sc_rr = nullptr, *sc_rr0 = nullptr;
+  bool shared_pcg = true;
+  int shared_min = 16, pcg_inner = 8, pcg_inner_max = 16, pcg_outer_max = 12;
   double *sc_f = nullptr, *sc_qxx = nullptr, *sc_qdx = nullptr, *sc_qdd = nullptr, *sc_dec = nullptr, *sc_smax = nullptr, *sc_alpha = nullptr;
   int *trial_of_slot = nullptr, *list_a = nullptr, *list_b = nullptr, *ident = nullptr;
   // small workspace for the T x T systems (Kinv, tau M-step): p slots of Tp
@@ -289,9 +296,11 @@ int alloc_cholws(pgpfa_ctx* c, CholWS* w, int nslots, int npad, bool with_mt) {
   return 0;
 }
 
+size_t ld_bytes(const pgpfa_ctx* c) { return (size_t)c->ld * c->ld * sizeof(double); }
+
 size_t per_slot_bytes(const pgpfa_ctx* c) {
   const size_t ld = c->ld;
-  size_t dbl = 2 * ld * ld + 2 * ld * NB + 8 * ld + 2 * (size_t)c->T * c->p * c->p + ((c->T + 63) / 64) + 16;
+  size_t dbl = 2 * ld * ld + 2 * ld * NB + 12 * ld + 2 * (size_t)c->T * c->p * c->p + ((c->T + 63) / 64) + 32;
   return dbl * sizeof(double);
 }
 
@@ -301,24 +310,36 @@ int ensure_workspace(pgpfa_ctx* c) {
   HIPC(hipMemGetInfo(&free_b, &total_b));
   const size_t per = per_slot_bytes(c);
   size_t budget = (size_t)(0.85 * (double)free_b);
+  {
+    const size_t shared = (2 * ld_bytes(c) + 640 * (size_t)c->ld * sizeof(double) * 4);
+    budget = budget > shared ? budget - shared : 0;
+  }
   long long B = (long long)(budget / per);
   if (c->chunk_opt > 0) B = std::min<long long>(B, c->chunk_opt);
-  B = std::min<long long>(B, c->R);
-  if (B >= 16) B = B / 8 * 8;
-  if (B >= 1) {
-    const long long nchunks = (c->R + B - 1) / B;
-    long long Bb = (c->R + nchunks - 1) / nchunks;
-    if (Bb >= 16) Bb = std::min<long long>(B, (Bb + 7) / 8 * 8);
-    B = Bb;
+  if (B >= c->R) {
+    B = c->R;                                        // everything in one chunk
+  } else if (B >= 16) {
+    B = B / 8 * 8;                                   // groups of 8 slots map onto the 8 XCDs
+    const long long nchunks = (c->R + B - 1) / B;    // balance the chunks
+    const long long Bb = ((c->R + nchunks - 1) / nchunks + 7) / 8 * 8;
+    B = std::min(B, Bb);
   }
   if (B < 1) return fail("not enough device memory for one trial slab (%zu bytes needed, %zu free)", per, free_b);
   c->B = (int)B;
   CHK(alloc_cholws(c, &c->ws, c->B, c->npad, true));
   const size_t ld = c->ld, nB = c->B;
+  const size_t nBs = nB + 128;                    // slack: multi-RHS GEMM tiles read up to 127 slots past the end
   CHK(dmalloc(c, &c->Xc, ld * nB)); CHK(dmalloc(c, &c->Xt, ld * nB));
   CHK(dmalloc(c, &c->KX, ld * nB)); CHK(dmalloc(c, &c->KD, ld * nB));
   CHK(dmalloc(c, &c->Gl, ld * nB)); CHK(dmalloc(c, &c->Glt, ld * nB));
-  CHK(dmalloc(c, &c->Gt, ld * nB)); CHK(dmalloc(c, &c->Dl, ld * nB, true));
+  CHK(dmalloc(c, &c->Gt, ld * nB)); CHK(dmalloc(c, &c->Dl, ld * nBs, true));
+  CHK(dmalloc(c, &c->Rv, ld * nBs, true)); CHK(dmalloc(c, &c->Zv, ld * nBs, true));
+  CHK(dmalloc(c, &c->Pv, ld * nBs, true)); CHK(dmalloc(c, &c->Qv, ld * nBs, true));
+  CHK(alloc_cholws(c, &c->sws, 1, c->npad, false));
+  CHK(dmalloc(c, &c->sU, ld * ld + 256 * ld, true));
+  CHK(dmalloc(c, &c->sDinvT, ld * NB + 256 * ld));
+  CHK(dmalloc(c, &c->Wbar, (size_t)c->T * c->p * c->p));
+  CHK(dmalloc(c, &c->sc_rz, nB)); CHK(dmalloc(c, &c->sc_pq, nB)); CHK(dmalloc(c, &c->sc_rr, nB)); CHK(dmalloc(c, &c->sc_rr0, nB));
   const size_t wlen = (size_t)c->T * c->p * c->p;
   CHK(dmalloc(c, &c->W, wlen * nB)); CHK(dmalloc(c, &c->Wt, wlen * nB));
   CHK(dmalloc(c, &c->fpart, (size_t)((c->T + 63) / 64) * nB));
@@ -552,6 +573,9 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
   else if (k == "newton_max_iter") c->max_iter = (int)v;
   else if (k == "use_mfma") c->mfma = (v != 0.0);
   else if (k == "chord") c->chord = (v != 0.0);
+  else if (k == "shared_pcg") c->shared_pcg = (v != 0.0);
+  else if (k == "shared_min") c->shared_min = (int)v;
+  else if (k == "pcg_inner") c->pcg_inner = (int)v;
   else if (k == "chord_xtol") c->chord_xtol = v;
   else if (k == "chord_rho") c->chord_rho = v;
   else if (k == "chord_max_step") c->chord_max_step = v;
@@ -738,6 +762,67 @@ static int remember_trials(pgpfa_ctx* c, const std::vector<int>& v) {
 }
 
 
+// Z <- (L L^T)^-1 Z for the nb slot vectors at once, L = the shared factor (1 slab): both triangular
+// sweeps are blocked by 128 and run as multi-RHS GEMMs (N = slots), so the factor is read from L2/MALL,
+// not once per trial from HBM.
+static int shared_solve(pgpfa_ctx* c, int nb, double* Z) {
+  const int np = c->npad, ld = c->ld, nblk = np / NB;
+  for (int kb = 0; kb < nblk; ++kb) {                       // forward: L y = b
+    const int k0 = kb * NB;
+    GemmP a{};
+    a.A = c->sws.Dinv + (size_t)kb * NB * NB; a.sA = 0; a.lda = NB;
+    a.B = Z + k0; a.sB = 0; a.ldb = ld;
+    a.C = Z + k0; a.sC = 0; a.ldc = ld;
+    a.M = NB; a.N = nb; a.K = NB; a.alpha = 1.0; a.beta = 0.0; a.slots = nullptr; a.nbatch = 1; a.mode = GEMM_FULL; a.kflags = 0;
+    CHK(gemm(c, true, a));
+    if (k0 + NB < np) {
+      GemmP u{};
+      u.A = c->sws.H + (size_t)k0 * ld + (k0 + NB); u.sA = 0; u.lda = ld;
+      u.B = Z + k0; u.sB = 0; u.ldb = ld;
+      u.C = Z + k0 + NB; u.sC = 0; u.ldc = ld;
+      u.M = np - k0 - NB; u.N = nb; u.K = NB; u.alpha = -1.0; u.beta = 1.0; u.slots = nullptr; u.nbatch = 1; u.mode = GEMM_FULL; u.kflags = 0;
+      CHK(gemm(c, true, u));
+    }
+  }
+  for (int kb = nblk - 1; kb >= 0; --kb) {                  // backward: L^T x = y, with U = L^T stored explicitly
+    const int k0 = kb * NB;
+    GemmP a{};
+    a.A = c->sDinvT + (size_t)kb * NB * NB; a.sA = 0; a.lda = NB;
+    a.B = Z + k0; a.sB = 0; a.ldb = ld;
+    a.C = Z + k0; a.sC = 0; a.ldc = ld;
+    a.M = NB; a.N = nb; a.K = NB; a.alpha = 1.0; a.beta = 0.0; a.slots = nullptr; a.nbatch = 1; a.mode = GEMM_FULL; a.kflags = 0;
+    CHK(gemm(c, true, a));
+    if (k0 > 0) {
+      GemmP u{};
+      u.A = c->sU + (size_t)k0 * ld; u.sA = 0; u.lda = ld;    // U[0:k0, k0:k0+128]
+      u.B = Z + k0; u.sB = 0; u.ldb = ld;
+      u.C = Z; u.sC = 0; u.ldc = ld;
+      u.M = k0; u.N = nb; u.K = NB; u.alpha = -1.0; u.beta = 1.0; u.slots = nullptr; u.nbatch = 1; u.mode = GEMM_FULL; u.kflags = 0;
+      CHK(gemm(c, true, u));
+    }
+  }
+  return 0;
+}
+
+// factor of the mean-trial Hessian  Kinv + scatter(mean_r W_r[t])  of the slots [0,nb)
+static int shared_factor(pgpfa_ctx* c, int nb) {
+  const int len = c->T * c->p * c->p;
+  hipLaunchKernelGGL(mean_w_kernel, dim3((len + 255) / 256), dim3(256), 0, c->st, c->W, (long long)len, c->ident, nb, len, c->Wbar);
+  hipLaunchKernelGGL(assemble_h_kernel, dim3(c->npad, 1), dim3(256), 0, c->st, c->sws.H, c->sws.sH, c->ld, c->npad, c->n, c->T, c->Tp, c->p,
+                     c->Kinv, c->Wbar, 0LL, c->ident, 1.0);
+  HIPC(hipMemsetAsync(c->sws.info, 0, sizeof(int), c->st));
+  CHK(factor(c, c->sws, nullptr, 1));
+  hipLaunchKernelGGL(transpose_lower_kernel, dim3((c->npad + 31) / 32, (c->npad + 31) / 32), dim3(32, 8), 0, c->st, c->sws.H, c->sU, c->ld, c->npad);
+  hipLaunchKernelGGL(transpose_diag_blocks_kernel, dim3(c->npad / NB), dim3(256), 0, c->st, c->sws.Dinv, c->sDinvT);
+  int info = 0;
+  HIPC(hipMemcpyAsync(&info, c->sws.info, sizeof(int), hipMemcpyDeviceToHost, c->st));
+  HIPC(hipStreamSynchronize(c->st));
+  HIPC(hipGetLastError());
+  if (info != 0) return fail("shared preconditioner not positive definite (pivot %d)", info);
+  return 0;
+}
+
+
 // H (from the W blocks of slots [0,nb), diagonal scaled by diag_scale) -> factor -> L^-T -> post_vsmGP and
 // post_vsm of the trials bound to the slots.  Shared by the Laplace and the dual-variational E-step.
 static int posterior_blocks(pgpfa_ctx* c, int nb, double diag_scale, bool want_vsmgp) {
@@ -779,7 +864,7 @@ int pgpfa_estep_laplace(pgpfa_ctx* c, int n, const int32_t* idx, int warm_start,
   const int nvec = c->n, p = c->p, T = c->T;
   const long long ld = c->ld;
   double total = 0.0;
-  double n_fact = 0.0, n_solve = 0.0;
+  double n_fact = 0.0, n_solve = 0.0, n_pcg = 0.0, n_shared = 0.0;
   int max_it_seen = 0;
   std::vector<double> f(c->B), qxx(c->B), qdx(c->B), qdd(c->B), dec(c->B), smax(c->B), alpha(c->B), ftry(c->B);
   std::vector<int> its(c->B), stat(c->B), info(c->B);
@@ -800,10 +885,125 @@ int pgpfa_estep_laplace(pgpfa_ctx* c, int n, const int32_t* idx, int warm_start,
     CHK(download(c, qxx.data(), c->sc_qxx, nb));
     std::vector<int> active(nb);
     for (int s = 0; s < nb; ++s) { active[s] = s; f[s] += 0.5 * qxx[s]; its[s] = 0; stat[s] = 1; }
+    std::vector<int> leftovers;
 
-    // Newton with factor reuse: a slot factors H at its current point only when it has no factor yet or
-    // its chord steps (steps with the stale factor, still descent directions since that factor is SPD)
-    // contract too slowly; otherwise the resident factor is reused: one HBM-bound solve instead of n^3/3.
+    // backtracking line search along Dl for the slots in `cand` (objective with rounding-noise slack as in
+    // the oracle); needs dec/qxx/qdx/qdd of those slots on the host.  Accepted slots are committed
+    // (X, K^-1 x, likelihood gradient, W); returns the slots whose search was exhausted.
+    auto line_search = [&](const std::vector<int>& cand, std::vector<int>* failed) -> int {
+      std::vector<int> pending;
+      for (int s : cand) { alpha[s] = 1.0; pending.push_back(s); }
+      for (int ls = 0; ls < 40 && !pending.empty(); ++ls) {
+        const int np_ = (int)pending.size();
+        CHK(upload_list(c, c->list_b, pending));
+        CHK(upload(c, c->sc_alpha, alpha.data(), nb));
+        hipLaunchKernelGGL(make_try_kernel, dim3((nvec + 255) / 256, np_), dim3(256), 0, c->st, c->Xc, ld, c->Dl, ld, c->sc_alpha, c->Xt, ld, nvec,
+                           c->list_b);
+        CHK(poisson(c, c->list_b, np_, c->Xt, c->Glt, c->Wt, c->sc_f, 1));
+        CHK(download(c, ftry.data(), c->sc_f, nb));
+        std::vector<int> acc, rej;
+        for (int s : pending) {
+          const double a = alpha[s];
+          const double ft = ftry[s] + 0.5 * (qxx[s] + 2.0 * a * qdx[s] + a * a * qdd[s]);
+          const double slack = 1e-12 * (1.0 + std::fabs(f[s]));
+          if (std::isfinite(ft) && ft <= f[s] - 1e-4 * a * dec[s] + slack) {
+            f[s] = ft;
+            acc.push_back(s);
+          } else {
+            alpha[s] = 0.5 * a;
+            rej.push_back(s);
+          }
+        }
+        if (!acc.empty()) {
+          const int nacc = (int)acc.size();
+          CHK(upload_list(c, c->list_b, acc));
+          const int nw = T * p * p;
+          hipLaunchKernelGGL(commit_kernel, dim3((nvec + 255) / 256, nacc), dim3(256), 0, c->st, c->Xc, c->Xt, c->KX, c->KD, c->Gl, c->Glt, ld,
+                             c->W, c->Wt, (long long)nw, c->sc_alpha, nvec, nw, c->list_b);
+          HIPC(hipGetLastError());
+        }
+        pending.swap(rej);
+      }
+      *failed = pending;
+      return 0;
+    };
+
+    // ---- phase 1: inexact Newton, all slots in lockstep, PCG on H_r delta = -g preconditioned by ONE shared factor
+    // (the mean-trial Hessian: cond(P^-1 H_r) stays below ~4, measured).  Every preconditioner application is two
+    // multi-RHS triangular sweeps run as GEMMs over the slots; no per-trial factorisation in this phase.
+    if (c->shared_pcg && nb >= c->shared_min) {
+      CHK(shared_factor(c, nb));
+      n_shared += 1;
+      int inner = c->pcg_inner;
+      std::vector<double> rr(nb), rr0(nb);
+      for (int outer = 0; outer < c->pcg_outer_max && !active.empty(); ++outer) {
+        const int na = (int)active.size();
+        CHK(upload_list(c, c->list_a, active));
+        hipLaunchKernelGGL(grad_total_kernel, dim3((nvec + 255) / 256, na), dim3(256), 0, c->st, c->Gl, ld, c->KX, ld, c->Gt, ld, nvec, c->list_a);
+        hipLaunchKernelGGL(pcg_init_kernel, dim3((c->npad + 255) / 256, na), dim3(256), 0, c->st, c->Gt, c->Rv, c->Dl, ld, nvec, c->npad, c->list_a);
+        HIPC(hipMemcpyAsync(c->Zv, c->Rv, (size_t)nb * ld * sizeof(double), hipMemcpyDeviceToDevice, c->st));
+        CHK(shared_solve(c, nb, c->Zv));
+        hipLaunchKernelGGL(pcg_update_p_kernel, dim3(na), dim3(256), 0, c->st, c->Rv, c->Zv, c->Pv, ld, nvec, c->list_a, c->sc_rz, c->sc_rr0, 1);
+        for (int it = 0; it < inner; ++it) {
+          CHK(prior_mv(c, c->list_a, na, c->Pv, c->Qv));
+          hipLaunchKernelGGL(pcg_hessvec_dot_kernel, dim3(na), dim3(256), 0, c->st, c->W, (long long)T * p * p, c->Pv, c->Qv, ld, T, p, nvec,
+                             c->list_a, c->sc_pq);
+          hipLaunchKernelGGL(pcg_update_xr_kernel, dim3(na), dim3(256), 0, c->st, c->Dl, c->Rv, c->Pv, c->Qv, ld, nvec, c->list_a, c->sc_rz, c->sc_pq);
+          HIPC(hipMemcpyAsync(c->Zv, c->Rv, (size_t)nb * ld * sizeof(double), hipMemcpyDeviceToDevice, c->st));
+          CHK(shared_solve(c, nb, c->Zv));
+          hipLaunchKernelGGL(pcg_update_p_kernel, dim3(na), dim3(256), 0, c->st, c->Rv, c->Zv, c->Pv, ld, nvec, c->list_a, c->sc_rz, c->sc_rr, 0);
+        }
+        n_pcg += (double)na * inner;
+        hipLaunchKernelGGL(step_stats_kernel, dim3(na), dim3(256), 0, c->st, c->Gt, c->Dl, ld, nvec, c->list_a, c->sc_dec, c->sc_smax);
+        CHK(prior_mv(c, c->list_a, na, c->Dl, c->KD));
+        hipLaunchKernelGGL(dots3_kernel, dim3(na), dim3(256), 0, c->st, c->Xc, ld, c->KX, ld, c->Dl, ld, c->KD, ld, nvec, c->list_a, c->sc_qxx,
+                           c->sc_qdx, c->sc_qdd);
+        HIPC(hipGetLastError());
+        CHK(download(c, dec.data(), c->sc_dec, nb));
+        CHK(download(c, smax.data(), c->sc_smax, nb));
+        CHK(download(c, qxx.data(), c->sc_qxx, nb));
+        CHK(download(c, qdx.data(), c->sc_qdx, nb));
+        CHK(download(c, qdd.data(), c->sc_qdd, nb));
+        CHK(download(c, rr.data(), c->sc_rr, nb));
+        CHK(download(c, rr0.data(), c->sc_rr0, nb));
+        std::vector<int> cand, next, failed;
+        for (int s : active) {
+          if (!(dec[s] > 0.0) || !std::isfinite(dec[s]) || !std::isfinite(smax[s])) continue;   // leave to the fallback
+          cand.push_back(s);
+        }
+        CHK(line_search(cand, &failed));
+        std::vector<char> bad(nb, 0);
+        for (int s : failed) bad[s] = 1;
+        for (int s : cand) {
+          if (bad[s]) continue;
+          // inexact Newton: the error after the step is ~ max(eta, |step|) * |step|, eta = achieved relative residual
+          const double eta = rr0[s] > 0.0 ? std::sqrt(rr[s] / rr0[s]) : 0.0;
+          const double step = alpha[s] * smax[s];
+          if (alpha[s] == 1.0 && 10.0 * step * std::max(eta, step) < c->chord_xtol) { stat[s] = 0; continue; }
+          next.push_back(s);
+        }
+        // slots with a non-descent direction or an exhausted search drop to the per-trial fallback below
+        std::vector<int> fallback;
+        {
+          std::vector<char> in_cand(nb, 0);
+          for (int s : cand) in_cand[s] = 1;
+          for (int s : active) if (!in_cand[s] || bad[s]) fallback.push_back(s);
+        }
+        active.swap(next);
+        leftovers.insert(leftovers.end(), fallback.begin(), fallback.end());
+        inner = std::min(c->pcg_inner_max, inner + 2);
+        max_it_seen = std::max(max_it_seen, outer + 1);
+      }
+      // anything still active after the outer cap also goes to the fallback
+      leftovers.insert(leftovers.end(), active.begin(), active.end());
+      active = leftovers;
+      std::sort(active.begin(), active.end());
+    }
+
+    // ---- phase 1b (fallback, and the only path when shared_pcg is off or the chunk is tiny): per-trial Newton with
+    // factor reuse.  A slot factors H at its current point only when it has no factor yet or its chord steps (steps
+    // with the stale factor, still descent directions since that factor is SPD) contract too slowly; otherwise the
+    // resident factor is reused: one HBM-bound solve instead of n^3/3 flops.
     std::vector<char> has_factor(nb, 0), fresh(nb, 0), refactor(nb, 0);
     std::vector<double> prev_step(nb, 0.0);
     std::vector<int> n_chord(nb, 0);
@@ -840,45 +1040,13 @@ int pgpfa_estep_laplace(pgpfa_ctx* c, int n, const int32_t* idx, int warm_start,
       HIPC(hipMemcpyAsync(info.data(), c->ws.info, sizeof(int) * nb, hipMemcpyDeviceToHost, c->st));
       HIPC(hipStreamSynchronize(c->st));
 
-      // backtracking line search on the objective (rounding-noise slack as in the oracle)
-      std::vector<int> pending;
+      std::vector<int> cand, failed;
       for (int s : active) {
         if (info[s] != 0 || !std::isfinite(dec[s])) { stat[s] = 3; continue; }
-        alpha[s] = 1.0;
-        pending.push_back(s);
+        cand.push_back(s);
       }
-      for (int ls = 0; ls < 40 && !pending.empty(); ++ls) {
-        const int np_ = (int)pending.size();
-        CHK(upload_list(c, c->list_b, pending));
-        CHK(upload(c, c->sc_alpha, alpha.data(), nb));
-        hipLaunchKernelGGL(make_try_kernel, dim3((nvec + 255) / 256, np_), dim3(256), 0, c->st, c->Xc, ld, c->Dl, ld, c->sc_alpha, c->Xt, ld, nvec,
-                           c->list_b);
-        CHK(poisson(c, c->list_b, np_, c->Xt, c->Glt, c->Wt, c->sc_f, 1));
-        CHK(download(c, ftry.data(), c->sc_f, nb));
-        std::vector<int> acc, rej;
-        for (int s : pending) {
-          const double a = alpha[s];
-          const double ft = ftry[s] + 0.5 * (qxx[s] + 2.0 * a * qdx[s] + a * a * qdd[s]);
-          const double slack = 1e-12 * (1.0 + std::fabs(f[s]));
-          if (std::isfinite(ft) && ft <= f[s] - 1e-4 * a * dec[s] + slack) {
-            f[s] = ft;
-            acc.push_back(s);
-          } else {
-            alpha[s] = 0.5 * a;
-            rej.push_back(s);
-          }
-        }
-        if (!acc.empty()) {
-          const int nacc = (int)acc.size();
-          CHK(upload_list(c, c->list_b, acc));
-          const int nw = T * p * p;
-          hipLaunchKernelGGL(commit_kernel, dim3((nvec + 255) / 256, nacc), dim3(256), 0, c->st, c->Xc, c->Xt, c->KX, c->KD, c->Gl, c->Glt, ld,
-                             c->W, c->Wt, (long long)nw, c->sc_alpha, nvec, nw, c->list_b);
-          HIPC(hipGetLastError());
-        }
-        pending.swap(rej);
-      }
-      for (int s : pending) stat[s] = 2;   // line search exhausted
+      CHK(line_search(cand, &failed));
+      for (int s : failed) stat[s] = 2;   // line search exhausted
       std::vector<int> next;
       for (int s : active) {
         if (stat[s] == 2 || stat[s] == 3) continue;
@@ -922,6 +1090,8 @@ int pgpfa_estep_laplace(pgpfa_ctx* c, int n, const int32_t* idx, int warm_start,
   c->info["last_estep_ms"] = ms;
   c->info["last_newton_factorizations"] = n_fact;
   c->info["last_newton_solves"] = n_solve;
+  c->info["last_pcg_iterations"] = n_pcg;
+  c->info["last_shared_factorizations"] = n_shared;
   c->info["last_newton_max_iter"] = max_it_seen;
   return 0;
 }
@@ -1387,7 +1557,7 @@ int pgpfa_test_potrf(pgpfa_ctx* c, int batch, int n, const double* A, double* L,
   return rc;
 }
 
-int pgpfa_test_gemm_nt(pgpfa_ctx* c, int M, int N, int K, double alpha, const double* A, const double* B, double beta, double* C) {
+static int test_gemm(pgpfa_ctx* c, bool transb, int M, int N, int K, double alpha, const double* A, const double* B, double beta, double* C) {
   if (!c || !A || !B || !C) return fail("null argument");
   if (K % 16 != 0) return fail("K must be a multiple of 16");
   HIPC(hipSetDevice(c->device));
@@ -1398,12 +1568,13 @@ int pgpfa_test_gemm_nt(pgpfa_ctx* c, int M, int N, int K, double alpha, const do
   CHK(dmalloc(c, &dB, (size_t)Np * K, true));
   CHK(dmalloc(c, &dC, (size_t)Mp * N + 16, true));
   HIPC(hipMemcpy2DAsync(dA, (size_t)Mp * 8, A, (size_t)M * 8, (size_t)M * 8, K, hipMemcpyHostToDevice, c->st));
-  HIPC(hipMemcpy2DAsync(dB, (size_t)Np * 8, B, (size_t)N * 8, (size_t)N * 8, K, hipMemcpyHostToDevice, c->st));
+  if (!transb) HIPC(hipMemcpy2DAsync(dB, (size_t)Np * 8, B, (size_t)N * 8, (size_t)N * 8, K, hipMemcpyHostToDevice, c->st));
+  else HIPC(hipMemcpyAsync(dB, B, (size_t)K * N * 8, hipMemcpyHostToDevice, c->st));       // K x N column-major, ldb = K
   HIPC(hipMemcpy2DAsync(dC, (size_t)Mp * 8, C, (size_t)M * 8, (size_t)M * 8, N, hipMemcpyHostToDevice, c->st));
   GemmP g{};
-  g.A = dA; g.lda = Mp; g.B = dB; g.ldb = Np; g.C = dC; g.ldc = Mp; g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta;
+  g.A = dA; g.lda = Mp; g.B = dB; g.ldb = transb ? K : Np; g.C = dC; g.ldc = Mp; g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta;
   g.nbatch = 1; g.mode = GEMM_FULL;
-  int rc = gemm(c, false, g);
+  int rc = gemm(c, transb, g);
   if (!rc) {
     hipError_t e = hipMemcpy2DAsync(C, (size_t)M * 8, dC, (size_t)Mp * 8, (size_t)M * 8, N, hipMemcpyDeviceToHost, c->st);
     if (e != hipSuccess) rc = fail("copy back: %s", hipGetErrorString(e));
@@ -1411,6 +1582,13 @@ int pgpfa_test_gemm_nt(pgpfa_ctx* c, int M, int N, int K, double alpha, const do
   hipStreamSynchronize(c->st);
   while (c->allocs.size() > mark) { hipFree(c->allocs.back()); c->allocs.pop_back(); }
   return rc;
+}
+
+int pgpfa_test_gemm_nt(pgpfa_ctx* c, int M, int N, int K, double alpha, const double* A, const double* B, double beta, double* C) {
+  return test_gemm(c, false, M, N, K, alpha, A, B, beta, C);
+}
+int pgpfa_test_gemm_nn(pgpfa_ctx* c, int M, int N, int K, double alpha, const double* A, const double* B, double beta, double* C) {
+  return test_gemm(c, true, M, N, K, alpha, A, B, beta, C);
 }
 
 int pgpfa_bench_mfma_peak(pgpfa_ctx* c, int iters, double* tflops) {

@@ -42,6 +42,22 @@ def test_gemm_nt(small_ctx, M, N, K, mfma):
     assert rel(C, ref) <= 1e-13 * K
 
 
+@pytest.mark.parametrize('M,N,K', [(128, 128, 16), (260, 70, 128), (64, 300, 48)])
+@pytest.mark.parametrize('mfma', [1, 0])
+def test_gemm_nn(small_ctx, M, N, K, mfma):
+    """The K x N (multi-RHS) operand form used by the shared-factor triangular sweeps."""
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((M, K))
+    B = rng.standard_normal((K, N)) + np.arange(N)[None, :] * 0.01
+    C0 = rng.standard_normal((M, N))
+    small_ctx.set_option('use_mfma', mfma)
+    try:
+        C = small_ctx.test_gemm_nn(A, B, C0, alpha=-1.0, beta=1.0)
+    finally:
+        small_ctx.set_option('use_mfma', 1)
+    assert rel(C, C0 - A @ B) <= 1e-13 * K
+
+
 @pytest.mark.parametrize('n,batch', [(100, 3), (128, 2), (300, 2), (700, 2), (1100, 1)])
 @pytest.mark.parametrize('mfma', [1, 0])
 def test_potrf_and_inverse(small_ctx, n, batch, mfma):

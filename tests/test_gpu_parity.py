@@ -50,13 +50,35 @@ def test_estep_c1_vs_polished_and_reference(funs_mod, c1, c1_experiment):
     assert np.max(np.abs(S - S.T)) <= 1e-12 and np.min(np.linalg.eigvalsh(S)) > 0
 
 
+@pytest.mark.parametrize('shared', [1, 0])
+def test_estep_newton_variants_agree(c1, shared):
+    """Shared-preconditioner Newton-PCG and the per-trial factor/chord Newton reach the same modes."""
+    from funs import _hip
+    g = load_golden('c1_laplace.npz')
+    ctx = _hip.Context(30, 3, 100, 20, c1['binSize'])
+    try:
+        ctx.upload_counts(c1['Y'])
+        ctx.set_option('shared_pcg', shared)
+        ctx.set_params(c1['init_C'], c1['init_d'], c1['init_tau'])
+        obj, iters, status = ctx.estep_laplace()
+        assert np.all(status == 0)
+        assert np.max(np.abs(ctx.post_mean().reshape(20, -1) - g['polished'])) <= 1e-8
+        if shared:
+            assert ctx.info('last_pcg_iterations') > 0 and np.all(iters == 1)
+        else:
+            assert ctx.info('last_pcg_iterations') == 0 and np.all(iters >= 2)
+    finally:
+        ctx.close()
+
+
 def test_estep_warm_start_and_subset(funs_mod, c1, c1_experiment):
     params = {k: v.copy() for k, v in c1['init'].items()}
     infRes, nll, opt = funs_mod.inference.laplace(c1_experiment, params)
-    cold_iters = infRes.newton_iters.copy()
-    # warm start from resident modes: converges in at most 2 factorizations, same answer
+    cold_work = infRes.session.ctx.info('last_pcg_iterations') + infRes.session.ctx.info('last_newton_solves')
+    # warm start from resident modes: much less Newton work, at most 2 factorizations per trial, same answer
     infRes2, nll2, _ = funs_mod.inference.laplace(c1_experiment, params, prevOptimRes=opt)
-    assert np.max(infRes2.newton_iters) <= 2 < np.max(cold_iters)
+    warm_work = infRes2.session.ctx.info('last_pcg_iterations') + infRes2.session.ctx.info('last_newton_solves')
+    assert np.max(infRes2.newton_iters) <= 2 and warm_work < 0.6 * cold_work
     assert abs(nll2 - nll) <= 1e-10 * abs(nll)
     # warm start from host arrays (what a caller holding the reference's lapOptimRes would pass)
     host = [np.asarray(infRes2['post_mean'][r]).reshape(-1) + 1e-3 for r in range(20)]
