@@ -311,7 +311,7 @@ int ensure_workspace(pgpfa_ctx* c) {
   const size_t per = per_slot_bytes(c);
   size_t budget = (size_t)(0.85 * (double)free_b);
   {
-    const size_t shared = (2 * ld_bytes(c) + 640 * (size_t)c->ld * sizeof(double) * 4);
+    const size_t shared = (3 * ld_bytes(c) + 1024 * (size_t)c->ld * sizeof(double) * 4);
     budget = budget > shared ? budget - shared : 0;
   }
   long long B = (long long)(budget / per);
@@ -335,7 +335,7 @@ int ensure_workspace(pgpfa_ctx* c) {
   CHK(dmalloc(c, &c->Gt, ld * nB)); CHK(dmalloc(c, &c->Dl, ld * nBs, true));
   CHK(dmalloc(c, &c->Rv, ld * nBs, true)); CHK(dmalloc(c, &c->Zv, ld * nBs, true));
   CHK(dmalloc(c, &c->Pv, ld * nBs, true)); CHK(dmalloc(c, &c->Qv, ld * nBs, true));
-  CHK(alloc_cholws(c, &c->sws, 1, c->npad, false));
+  CHK(alloc_cholws(c, &c->sws, 1, c->npad, true));
   CHK(dmalloc(c, &c->sU, ld * ld + 256 * ld, true));
   CHK(dmalloc(c, &c->sDinvT, ld * NB + 256 * ld));
   CHK(dmalloc(c, &c->Wbar, (size_t)c->T * c->p * c->p));
@@ -762,49 +762,21 @@ static int remember_trials(pgpfa_ctx* c, const std::vector<int>& v) {
 }
 
 
-// Z <- (L L^T)^-1 Z for the nb slot vectors at once, L = the shared factor (1 slab): both triangular
-// sweeps are blocked by 128 and run as multi-RHS GEMMs (N = slots), so the factor is read from L2/MALL,
-// not once per trial from HBM.
-static int shared_solve(pgpfa_ctx* c, int nb, double* Z) {
-  const int np = c->npad, ld = c->ld, nblk = np / NB;
-  for (int kb = 0; kb < nblk; ++kb) {                       // forward: L y = b
-    const int k0 = kb * NB;
-    GemmP a{};
-    a.A = c->sws.Dinv + (size_t)kb * NB * NB; a.sA = 0; a.lda = NB;
-    a.B = Z + k0; a.sB = 0; a.ldb = ld;
-    a.C = Z + k0; a.sC = 0; a.ldc = ld;
-    a.M = NB; a.N = nb; a.K = NB; a.alpha = 1.0; a.beta = 0.0; a.slots = nullptr; a.nbatch = 1; a.mode = GEMM_FULL; a.kflags = 0;
-    CHK(gemm(c, true, a));
-    if (k0 + NB < np) {
-      GemmP u{};
-      u.A = c->sws.H + (size_t)k0 * ld + (k0 + NB); u.sA = 0; u.lda = ld;
-      u.B = Z + k0; u.sB = 0; u.ldb = ld;
-      u.C = Z + k0 + NB; u.sC = 0; u.ldc = ld;
-      u.M = np - k0 - NB; u.N = nb; u.K = NB; u.alpha = -1.0; u.beta = 1.0; u.slots = nullptr; u.nbatch = 1; u.mode = GEMM_FULL; u.kflags = 0;
-      CHK(gemm(c, true, u));
-    }
-  }
-  for (int kb = nblk - 1; kb >= 0; --kb) {                  // backward: L^T x = y, with U = L^T stored explicitly
-    const int k0 = kb * NB;
-    GemmP a{};
-    a.A = c->sDinvT + (size_t)kb * NB * NB; a.sA = 0; a.lda = NB;
-    a.B = Z + k0; a.sB = 0; a.ldb = ld;
-    a.C = Z + k0; a.sC = 0; a.ldc = ld;
-    a.M = NB; a.N = nb; a.K = NB; a.alpha = 1.0; a.beta = 0.0; a.slots = nullptr; a.nbatch = 1; a.mode = GEMM_FULL; a.kflags = 0;
-    CHK(gemm(c, true, a));
-    if (k0 > 0) {
-      GemmP u{};
-      u.A = c->sU + (size_t)k0 * ld; u.sA = 0; u.lda = ld;    // U[0:k0, k0:k0+128]
-      u.B = Z + k0; u.sB = 0; u.ldb = ld;
-      u.C = Z; u.sC = 0; u.ldc = ld;
-      u.M = k0; u.N = nb; u.K = NB; u.alpha = -1.0; u.beta = 1.0; u.slots = nullptr; u.nbatch = 1; u.mode = GEMM_FULL; u.kflags = 0;
-      CHK(gemm(c, true, u));
-    }
-  }
-  return 0;
+// Z <- P^-1 R for the nb slot vectors at once: the shared preconditioner is ONE matrix, so its explicit
+// inverse is formed once per chunk (shared_factor) and applied to all right-hand sides with a single
+// multi-RHS GEMM (N = slots) - the same 2 n^2 flops per vector as two triangular sweeps, in one launch,
+// with P^-1 (one 200 MB slab at config 3) served from L2 / Infinity Cache.
+static int shared_solve(pgpfa_ctx* c, int nb, const double* R, double* Z) {
+  GemmP g{};
+  g.A = c->sU; g.sA = 0; g.lda = c->ld;                      // P^-1, symmetric
+  g.B = R; g.sB = 0; g.ldb = c->ld;                          // K x N column-major: slot vectors
+  g.C = Z; g.sC = 0; g.ldc = c->ld;
+  g.M = c->npad; g.N = nb; g.K = c->npad; g.alpha = 1.0; g.beta = 0.0;
+  g.slots = nullptr; g.nbatch = 1; g.mode = GEMM_FULL; g.kflags = 0;
+  return gemm(c, true, g);
 }
 
-// factor of the mean-trial Hessian  Kinv + scatter(mean_r W_r[t])  of the slots [0,nb)
+// explicit inverse of the mean-trial Hessian  P = Kinv + scatter(mean_r W_r[t])  of the slots [0,nb)
 static int shared_factor(pgpfa_ctx* c, int nb) {
   const int len = c->T * c->p * c->p;
   hipLaunchKernelGGL(mean_w_kernel, dim3((len + 255) / 256), dim3(256), 0, c->st, c->W, (long long)len, c->ident, nb, len, c->Wbar);
@@ -812,8 +784,13 @@ static int shared_factor(pgpfa_ctx* c, int nb) {
                      c->Kinv, c->Wbar, 0LL, c->ident, 1.0);
   HIPC(hipMemsetAsync(c->sws.info, 0, sizeof(int), c->st));
   CHK(factor(c, c->sws, nullptr, 1));
-  hipLaunchKernelGGL(transpose_lower_kernel, dim3((c->npad + 31) / 32, (c->npad + 31) / 32), dim3(32, 8), 0, c->st, c->sws.H, c->sU, c->ld, c->npad);
-  hipLaunchKernelGGL(transpose_diag_blocks_kernel, dim3(c->npad / NB), dim3(256), 0, c->st, c->sws.Dinv, c->sDinvT);
+  CHK(inverse_t(c, c->sws, nullptr, 1));
+  GemmP g{};
+  g.A = c->sws.Mt; g.sA = 0; g.lda = c->ld; g.B = c->sws.Mt; g.sB = 0; g.ldb = c->ld;
+  g.C = c->sU; g.sC = 0; g.ldc = c->ld;
+  g.M = c->npad; g.N = c->npad; g.K = c->npad; g.alpha = 1.0; g.beta = 0.0;
+  g.slots = nullptr; g.nbatch = 1; g.mode = GEMM_FULL; g.kflags = KF_BEGIN_MAXRC;
+  CHK(gemm(c, false, g));
   int info = 0;
   HIPC(hipMemcpyAsync(&info, c->sws.info, sizeof(int), hipMemcpyDeviceToHost, c->st));
   HIPC(hipStreamSynchronize(c->st));
@@ -821,7 +798,6 @@ static int shared_factor(pgpfa_ctx* c, int nb) {
   if (info != 0) return fail("shared preconditioner not positive definite (pivot %d)", info);
   return 0;
 }
-
 
 // H (from the W blocks of slots [0,nb), diagonal scaled by diag_scale) -> factor -> L^-T -> post_vsmGP and
 // post_vsm of the trials bound to the slots.  Shared by the Laplace and the dual-variational E-step.
@@ -941,16 +917,14 @@ int pgpfa_estep_laplace(pgpfa_ctx* c, int n, const int32_t* idx, int warm_start,
         CHK(upload_list(c, c->list_a, active));
         hipLaunchKernelGGL(grad_total_kernel, dim3((nvec + 255) / 256, na), dim3(256), 0, c->st, c->Gl, ld, c->KX, ld, c->Gt, ld, nvec, c->list_a);
         hipLaunchKernelGGL(pcg_init_kernel, dim3((c->npad + 255) / 256, na), dim3(256), 0, c->st, c->Gt, c->Rv, c->Dl, ld, nvec, c->npad, c->list_a);
-        HIPC(hipMemcpyAsync(c->Zv, c->Rv, (size_t)nb * ld * sizeof(double), hipMemcpyDeviceToDevice, c->st));
-        CHK(shared_solve(c, nb, c->Zv));
+        CHK(shared_solve(c, nb, c->Rv, c->Zv));
         hipLaunchKernelGGL(pcg_update_p_kernel, dim3(na), dim3(256), 0, c->st, c->Rv, c->Zv, c->Pv, ld, nvec, c->list_a, c->sc_rz, c->sc_rr0, 1);
         for (int it = 0; it < inner; ++it) {
           CHK(prior_mv(c, c->list_a, na, c->Pv, c->Qv));
           hipLaunchKernelGGL(pcg_hessvec_dot_kernel, dim3(na), dim3(256), 0, c->st, c->W, (long long)T * p * p, c->Pv, c->Qv, ld, T, p, nvec,
                              c->list_a, c->sc_pq);
           hipLaunchKernelGGL(pcg_update_xr_kernel, dim3(na), dim3(256), 0, c->st, c->Dl, c->Rv, c->Pv, c->Qv, ld, nvec, c->list_a, c->sc_rz, c->sc_pq);
-          HIPC(hipMemcpyAsync(c->Zv, c->Rv, (size_t)nb * ld * sizeof(double), hipMemcpyDeviceToDevice, c->st));
-          CHK(shared_solve(c, nb, c->Zv));
+          CHK(shared_solve(c, nb, c->Rv, c->Zv));
           hipLaunchKernelGGL(pcg_update_p_kernel, dim3(na), dim3(256), 0, c->st, c->Rv, c->Zv, c->Pv, ld, nvec, c->list_a, c->sc_rz, c->sc_rr, 0);
         }
         n_pcg += (double)na * inner;
