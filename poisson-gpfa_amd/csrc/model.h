@@ -517,11 +517,11 @@ __global__ void pautosum_kernel(const double* __restrict__ vsmgp, const double* 
 // (C,d) M-step pass, learning.MStepObservationCost(_grad) learning.py:20-91:
 //   hh = c_n.m_t + d_n ; u = V_t c_n ; rho = c_n.u ; yhat = exp(hh + rho/2)
 //   cost_n = sum (y*hh - yhat) ; dd_n = sum (y - yhat) ; dC_n = sum (y - yhat) m_t - yhat u
-// Lanes are NEURONS: every per-neuron sum stays in one thread's registers; m_t and V_t are
-// wave-uniform and arrive through scalar loads.  Wave ty of a block handles bins t = ty, ty+KY, ...
-// of the trials the block owns.  PW is the unrolled latent width (>= p; c is zero padded, so the
-// extra columns multiply finite neighbouring data by exact zeros and no per-element guard is needed;
-// the buffers carry 64 doubles of slack for the over-read).
+// Lanes are NEURONS: every per-neuron sum stays in one thread's registers (no cross-lane reduction).
+// A block owns 64 neurons and walks (trial, bin-tile) items; per item the V_t blocks, the means and the
+// packed counts of the tile are staged in LDS with coalesced loads (V_t re-laid out to a PW x PW stride
+// and zero padded, so the inner loops are fully unrolled with compile-time offsets), then wave ty handles
+// bins ty, ty+8, ... of the tile reading V_t / m_t as LDS broadcasts.
 // --------------------------------------------------------------------------------------------------
 struct CdArgs {
   const uint8_t* Y; const double* mean; const double* vsm; const double* vec;   // vecCd
@@ -530,13 +530,20 @@ struct CdArgs {
   int q, p, T;
 };
 constexpr int CD_KY = 8;
+template <int PW> struct CdTile { static constexpr int TT = (PW <= 10) ? 64 : (PW <= 16) ? 32 : (PW <= 20) ? 16 : 8; };
 
 template <int PW>
 __global__ __launch_bounds__(64 * CD_KY) void mstep_cd_kernel(CdArgs a) {
-  __shared__ double red[CD_KY][PW + 2][64];
+  constexpr int TT = CdTile<PW>::TT;
+  constexpr int YS = TT + 4;                      // byte row stride of the count tile (bank spread)
+  __shared__ __attribute__((aligned(16))) double Vt[TT][PW * PW];
+  __shared__ double Mt[PW][TT];
+  __shared__ uint8_t Yt[64 * YS];
   const int lane = threadIdx.x;
   const int ty = __builtin_amdgcn_readfirstlane(threadIdx.y);
-  const int n = blockIdx.x * 64 + lane;
+  const int tid = ty * 64 + lane;
+  const int n0 = blockIdx.x * 64;
+  const int n = n0 + lane;
   const bool live = n < a.q;
   const int p = a.p, q = a.q, T = a.T;
   double c[PW], acc[PW];
@@ -548,47 +555,67 @@ __global__ __launch_bounds__(64 * CD_KY) void mstep_cd_kernel(CdArgs a) {
   const double dn = live ? a.vec[(size_t)p * q + n] : 0.0;
   double cost = 0.0, dd = 0.0;
 
-  for (int it = blockIdx.y; it < a.ntr; it += gridDim.y) {
-    const size_t r = a.trials[it];
+  const int ntt = (T + TT - 1) / TT;
+  const int nitems = a.ntr * ntt;
+  for (int item = blockIdx.y; item < nitems; item += gridDim.y) {
+    const size_t r = a.trials[item / ntt];
+    const int t0 = (item % ntt) * TT;
+    const int tn = (T - t0 < TT) ? T - t0 : TT;
     const double* mean = a.mean + r * p * T;
-    const double* vsm = a.vsm + r * T * p * p;
-    const uint8_t* Y = a.Y + (r * q + (live ? n : 0)) * T;
-    for (int t = ty; t < T; t += CD_KY) {
-      const double* V = vsm + (size_t)t * p * p;
+    const double* vsm = a.vsm + (r * T + t0) * p * p;
+    const uint8_t* Y = a.Y + r * q * T;
+    __syncthreads();                               // previous tile fully consumed
+    for (int e = tid; e < TT * PW * PW; e += 64 * CD_KY) {
+      const int t = e / (PW * PW), kl = e - t * (PW * PW);
+      const int k = kl / PW, l = kl - k * PW;
+      Vt[t][kl] = (t < tn && k < p && l < p) ? vsm[(size_t)t * p * p + k * p + l] : 0.0;
+    }
+    for (int e = tid; e < PW * TT; e += 64 * CD_KY) {
+      const int k = e / TT, t = e - k * TT;
+      Mt[k][t] = (k < p && t < tn) ? mean[(size_t)k * T + t0 + t] : 0.0;
+    }
+    for (int e = tid; e < 64 * TT; e += 64 * CD_KY) {
+      const int nn = e / TT, t = e - nn * TT;
+      Yt[nn * YS + t] = (n0 + nn < q && t < tn) ? Y[(size_t)(n0 + nn) * T + t0 + t] : 0;
+    }
+    __syncthreads();
+    for (int t = ty; t < tn; t += CD_KY) {
       double u[PW];
       double hh = dn, rho = 0.0;
 #pragma unroll
       for (int k = 0; k < PW; ++k) {
-        const double* Vk = V + (k < p ? k : 0) * p;          // rows >= p are multiplied by c[k] = 0
         double s = 0.0;
 #pragma unroll
-        for (int l = 0; l < PW; ++l) s += Vk[l] * c[l];
+        for (int l = 0; l < PW; ++l) s += Vt[t][k * PW + l] * c[l];
         u[k] = s;
         rho += c[k] * s;
-        hh += c[k] * mean[(size_t)(k < p ? k : 0) * T + t];
+        hh += c[k] * Mt[k][t];
       }
       const double yh = exp(hh + 0.5 * rho);
-      const double y = (double)Y[t];
+      const double y = (double)Yt[lane * YS + t];
       const double rs = y - yh;
-      cost += y * hh - yh;
-      dd += rs;
+      if (live) {
+        cost += y * hh - yh;
+        dd += rs;
 #pragma unroll
-      for (int k = 0; k < PW; ++k) acc[k] += rs * mean[(size_t)(k < p ? k : 0) * T + t] - yh * u[k];
+        for (int k = 0; k < PW; ++k) acc[k] += rs * Mt[k][t] - yh * u[k];
+      }
     }
   }
-  // fixed-order combine over the KY waves of the block
+  // fixed-order combine over the KY waves of the block, one output row at a time
+  __shared__ double red[CD_KY][64];
+  double* part = a.part + (size_t)blockIdx.y * (p + 2) * q;
 #pragma unroll
-  for (int k = 0; k < PW; ++k) red[ty][k][lane] = acc[k];
-  red[ty][PW][lane] = dd;
-  red[ty][PW + 1][lane] = cost;
-  __syncthreads();
-  if (live) {
-    double* part = a.part + (size_t)blockIdx.y * (p + 2) * q;
-    for (int row = ty; row < p + 2; row += CD_KY) {
-      const int src = row < p ? row : PW + (row - p);
+  for (int k = 0; k < PW + 2; ++k) {
+    const double v = (k < PW) ? acc[k < PW ? k : 0] : (k == PW ? dd : cost);
+    __syncthreads();
+    red[ty][lane] = v;
+    __syncthreads();
+    if (ty == (k % CD_KY) && live && (k >= PW || k < p)) {
       double s = 0.0;
 #pragma unroll
-      for (int w = 0; w < CD_KY; ++w) s += red[w][src][lane];
+      for (int w = 0; w < CD_KY; ++w) s += red[w][lane];
+      const int row = (k < PW) ? k : p + (k - PW);
       part[(size_t)row * q + n] = s;
     }
   }

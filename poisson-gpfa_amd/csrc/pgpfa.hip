@@ -1165,7 +1165,8 @@ int pgpfa_mstep_cd_costgrad(pgpfa_ctx* c, const double* vecCd, const double* pri
   a.Y = c->Y; a.mean = c->Xmode; a.vsm = c->vsm; a.vec = c->vec;
   a.trials = c->last_trials; a.ntr = (int)c->last_trials_h.size();
   a.part = c->cdpart; a.q = q; a.p = p; a.T = T;
-  const int nby = std::max(1, std::min(1024, a.ntr));
+  const int nchunk = (q + 63) / 64;
+  const int nby = std::max(1, std::min(a.ntr * 4, std::max(64, 1024 / nchunk)));
   prof_begin(c, TAG_CD, (double)a.ntr * q * T * (2.0 * p * p + 8.0 * p));
   dispatch_pw(p, [&](auto pw) {
     hipLaunchKernelGGL(mstep_cd_kernel<decltype(pw)::value>, dim3((q + 63) / 64, nby), dim3(64, CD_KY), 0, c->st, a);
