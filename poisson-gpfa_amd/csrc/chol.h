@@ -191,6 +191,7 @@ struct CholWS {
   double* P; long long sP;        // npad x 128 scratch per slot
   int* info;                      // per slot
   int ld, npad;
+  int nact = 0;                   // active rows (multiple of 64, <= npad); 0 = npad
 };
 
 inline hipError_t chol_factor(hipStream_t st, bool mfma, const CholWS& w, const int* slots, int nb) {

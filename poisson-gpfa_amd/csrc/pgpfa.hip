@@ -218,6 +218,7 @@ int gemm(pgpfa_ctx* c, bool transb, GemmP g) {
 // chol_factor / chol_inverse_t with per-launch profiling (same sequence as chol.h's plain versions)
 int factor(pgpfa_ctx* c, const CholWS& w, const int* slots, int nb) {
   const int np = w.npad, ld = w.ld;
+  const int na = (w.nact > 0 && w.nact <= np) ? w.nact : np;   // rows >= na are identity padding: never updated
   for (int c0 = 0; c0 < np; c0 += NSUP) {
     const int c1 = std::min(c0 + NSUP, np);
     for (int k0 = c0; k0 < c1; k0 += NB) {
@@ -230,25 +231,25 @@ int factor(pgpfa_ctx* c, const CholWS& w, const int* slots, int nb) {
       g.A = w.H + (size_t)k0 * ld + r0; g.sA = w.sH; g.lda = ld;
       g.B = w.Dinv + (size_t)(k0 / NB) * NB * NB; g.sB = w.sD; g.ldb = NB;
       g.C = w.H + (size_t)k0 * ld + r0; g.sC = w.sH; g.ldc = ld;
-      g.M = np - r0; g.N = NB; g.K = NB; g.alpha = 1.0; g.beta = 0.0;
+      g.M = na - r0; g.N = NB; g.K = NB; g.alpha = 1.0; g.beta = 0.0;
       g.slots = slots; g.nbatch = nb; g.mode = GEMM_FULL; g.kflags = 0;
-      CHK(gemm(c, false, g));
-      if (r0 < c1) {
+      if (g.M > 0) CHK(gemm(c, false, g));
+      if (r0 < c1 && r0 < na) {
         GemmP s{};
         s.A = w.H + (size_t)k0 * ld + r0; s.sA = w.sH; s.lda = ld;
         s.B = s.A; s.sB = w.sH; s.ldb = ld;
         s.C = w.H + (size_t)r0 * ld + r0; s.sC = w.sH; s.ldc = ld;
-        s.M = np - r0; s.N = c1 - r0; s.K = NB; s.alpha = -1.0; s.beta = 1.0;
+        s.M = na - r0; s.N = std::min(c1, na) - r0; s.K = NB; s.alpha = -1.0; s.beta = 1.0;
         s.slots = slots; s.nbatch = nb; s.mode = GEMM_LOWER; s.kflags = KF_MASK_DIAG;
         CHK(gemm(c, false, s));
       }
     }
-    if (c1 < np) {
+    if (c1 < na) {
       GemmP s{};
       s.A = w.H + (size_t)c0 * ld + c1; s.sA = w.sH; s.lda = ld;
       s.B = s.A; s.sB = w.sH; s.ldb = ld;
       s.C = w.H + (size_t)c1 * ld + c1; s.sC = w.sH; s.ldc = ld;
-      s.M = np - c1; s.N = np - c1; s.K = c1 - c0; s.alpha = -1.0; s.beta = 1.0;
+      s.M = na - c1; s.N = na - c1; s.K = c1 - c0; s.alpha = -1.0; s.beta = 1.0;
       s.slots = slots; s.nbatch = nb; s.mode = GEMM_LOWER; s.kflags = KF_MASK_DIAG;
       CHK(gemm(c, false, s));
     }
@@ -259,6 +260,7 @@ int factor(pgpfa_ctx* c, const CholWS& w, const int* slots, int nb) {
 
 int inverse_t(pgpfa_ctx* c, const CholWS& w, const int* slots, int nb) {
   const int np = w.npad, ld = w.ld;
+  const int na = (w.nact > 0 && w.nact <= np) ? w.nact : np;   // rows >= na of Mt are identity padding
   for (int j0 = 0; j0 < np; j0 += NB) {
     hipLaunchKernelGGL(diag_transpose_kernel, dim3(nb), dim3(256), 0, c->st, w.Mt, w.sM, ld, j0, w.Dinv, w.sD, slots);
     if (j0 == 0) continue;
@@ -266,14 +268,14 @@ int inverse_t(pgpfa_ctx* c, const CholWS& w, const int* slots, int nb) {
     a.A = w.Mt; a.sA = w.sM; a.lda = ld;
     a.B = w.H + j0; a.sB = w.sH; a.ldb = ld;
     a.C = w.P; a.sC = w.sP; a.ldc = np;
-    a.M = j0; a.N = NB; a.K = j0; a.alpha = 1.0; a.beta = 0.0;
+    a.M = std::min(j0, na); a.N = NB; a.K = j0; a.alpha = 1.0; a.beta = 0.0;
     a.slots = slots; a.nbatch = nb; a.mode = GEMM_FULL; a.kflags = KF_BEGIN_ROW;
     CHK(gemm(c, false, a));
     GemmP b{};
     b.A = w.P; b.sA = w.sP; b.lda = np;
     b.B = w.Dinv + (size_t)(j0 / NB) * NB * NB; b.sB = w.sD; b.ldb = NB;
     b.C = w.Mt + (size_t)j0 * ld; b.sC = w.sM; b.ldc = ld;
-    b.M = j0; b.N = NB; b.K = NB; b.alpha = -1.0; b.beta = 0.0;
+    b.M = std::min(j0, na); b.N = NB; b.K = NB; b.alpha = -1.0; b.beta = 0.0;
     b.slots = slots; b.nbatch = nb; b.mode = GEMM_FULL; b.kflags = 0;
     CHK(gemm(c, false, b));
   }
@@ -327,6 +329,7 @@ int ensure_workspace(pgpfa_ctx* c) {
   if (B < 1) return fail("not enough device memory for one trial slab (%zu bytes needed, %zu free)", per, free_b);
   c->B = (int)B;
   CHK(alloc_cholws(c, &c->ws, c->B, c->npad, true));
+  c->ws.nact = round_up(c->n, 64);
   const size_t ld = c->ld, nB = c->B;
   const size_t nBs = nB + 128;                    // slack: multi-RHS GEMM tiles read up to 127 slots past the end
   CHK(dmalloc(c, &c->Xc, ld * nB)); CHK(dmalloc(c, &c->Xt, ld * nB));
@@ -336,6 +339,7 @@ int ensure_workspace(pgpfa_ctx* c) {
   CHK(dmalloc(c, &c->Rv, ld * nBs, true)); CHK(dmalloc(c, &c->Zv, ld * nBs, true));
   CHK(dmalloc(c, &c->Pv, ld * nBs, true)); CHK(dmalloc(c, &c->Qv, ld * nBs, true));
   CHK(alloc_cholws(c, &c->sws, 1, c->npad, true));
+  c->sws.nact = round_up(c->n, 64);
   CHK(dmalloc(c, &c->sU, ld * ld + 256 * ld, true));
   CHK(dmalloc(c, &c->sDinvT, ld * NB + 256 * ld));
   CHK(dmalloc(c, &c->Wbar, (size_t)c->T * c->p * c->p));
@@ -461,7 +465,7 @@ int build_kinv(pgpfa_ctx* c) {
 }
 
 int allreduce_dev(pgpfa_ctx* c, double* buf, size_t count) {
-  if (c->nranks <= 1 || !c->comm) return 0;
+  if (!c->comm) return 0;
   ncclResult_t r = ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, c->comm, c->st);
   if (r != ncclSuccess) return fail("ncclAllReduce failed: %s", ncclGetErrorString(r));
   return 0;
@@ -493,7 +497,10 @@ __global__ void scatter_vsmgp_kernel(const double* __restrict__ src, long long s
   const int slot = blockIdx.y;
   const size_t r = trial_of_slot[slot];
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < (size_t)T * T) dst[(r * p + k) * T * T + e] = src[(size_t)slot * sSrc + e];
+  if (e < (size_t)T * T) {
+    const size_t a = e % T, b = e / T;                 // column-major (a,b); only a >= b was computed
+    dst[(r * p + k) * T * T + e] = (a >= b) ? src[(size_t)slot * sSrc + e] : src[(size_t)slot * sSrc + a * T + b];
+  }
 }
 }  // namespace
 
@@ -542,6 +549,7 @@ int pgpfa_create(pgpfa_ctx** out, int device, int q, int p, int T, int R, double
   rc |= dmalloc(c, &c->cdout, (size_t)(p + 2) * q + 8);
   rc |= dmalloc(c, &c->last_trials, R);
   rc |= alloc_cholws(c, &c->kws, p, c->Tp, true);
+  c->kws.nact = round_up(T, 64);
   rc |= dmalloc(c, &c->tK, slab * p); rc |= dmalloc(c, &c->tM, slab * p); rc |= dmalloc(c, &c->tA1, slab * p); rc |= dmalloc(c, &c->tA2, slab * p);
   rc |= dmalloc(c, &c->tscal, 16 + 8 * (size_t)p); rc |= dmalloc(c, &c->tpart, 1024 + 64 * (size_t)p);
   if (rc) { pgpfa_destroy(c); return 1; }
@@ -814,7 +822,9 @@ static int posterior_blocks(pgpfa_ctx* c, int nb, double diag_scale, bool want_v
       g.B = g.A; g.sB = c->ws.sM; g.ldb = c->ld;
       g.C = c->ws.H; g.sC = c->ws.sH; g.ldc = T;        // slot-indexed staging: the factor slab is free now
       g.M = T; g.N = T; g.K = c->npad - kal; g.alpha = 1.0; g.beta = 0.0;
-      g.slots = c->ident; g.nbatch = nb; g.mode = GEMM_FULL; g.kflags = 0;
+      // lower tiles only (the scatter mirrors them); Mt is upper triangular, so tile (ti,tj) starts its k range
+      // at max(ti,tj)*128 relative to the first column kept (kal <= k*T)
+      g.slots = c->ident; g.nbatch = nb; g.mode = GEMM_LOWER; g.kflags = KF_BEGIN_MAXRC;
       CHK(gemm(c, false, g));
       hipLaunchKernelGGL(scatter_vsmgp_kernel, dim3((unsigned)(((size_t)T * T + 255) / 256), nb), dim3(256), 0, c->st, c->ws.H, c->ws.sH, c->vsmgp,
                          T, p, k, c->trial_of_slot);
@@ -1209,7 +1219,7 @@ int pgpfa_mstep_precomp(pgpfa_ctx* c, double* num_trials) {
   const size_t len = (size_t)c->Tp * c->Tp * c->p;
   CHK(allreduce_dev(c, c->Pauto, len));
   double cnt = (double)ntr;
-  if (c->nranks > 1) {
+  if (c->comm) {
     HIPC(hipMemcpyAsync(c->tscal, &cnt, sizeof(double), hipMemcpyHostToDevice, c->st));
     CHK(allreduce_dev(c, c->tscal, 1));
     CHK(download(c, &cnt, c->tscal, 1));
@@ -1473,7 +1483,7 @@ int pgpfa_comm_init(pgpfa_ctx* c, const char* id128, int rank, int nranks) {
 
 int pgpfa_comm_allreduce_host(pgpfa_ctx* c, double* buf, int count) {
   if (!c || !buf || count < 0) return fail("invalid argument");
-  if (c->nranks <= 1) return 0;
+  if (!c->comm) return 0;
   HIPC(hipSetDevice(c->device));
   if ((size_t)count > c->commbuf_len) {
     CHK(dmalloc(c, &c->commbuf, (size_t)count));

@@ -24,7 +24,9 @@ class _World:
         self.rank = int(os.environ.get('RANK', '0'))
         self.size = int(os.environ.get('WORLD_SIZE', '1'))
         self.local_rank = int(os.environ.get('LOCAL_RANK', str(self.rank)))
-        self.enabled = self.size > 1 and os.environ.get('PGPFA_DISABLE_COMM', '0') != '1'
+        # PGPFA_FORCE_COMM=1 builds the RCCL communicator even for a single rank (exercises the same code path)
+        self.enabled = (self.size > 1 or os.environ.get('PGPFA_FORCE_COMM', '0') == '1') and \
+            os.environ.get('PGPFA_DISABLE_COMM', '0') != '1'
         self._serial = 0
 
     def device(self):
@@ -145,10 +147,12 @@ class Session:
         self.post_stamp = 0
         self.mode_stamp = 0
         self.rank, self.size = 0, 1
+        self.comm_ready = False
         if WORLD.enabled:
             uid, path = WORLD.exchange_unique_id()
             self.ctx.comm_init(uid, WORLD.rank, WORLD.size)
             self.rank, self.size = WORLD.rank, WORLD.size
+            self.comm_ready = True
             # first collective doubles as the barrier after which rank 0 may remove the file
             self.ctx.allreduce_host(np.zeros(1))
             if WORLD.rank == 0:
@@ -161,10 +165,10 @@ class Session:
         self.ctx.set_params(params['C'], params['d'], params['tau'])
 
     def local_slice(self, n_items):
-        return shard_slice(n_items, self.rank, self.size) if self.size > 1 else (0, n_items)
+        return shard_slice(n_items, self.rank, self.size)
 
     def allreduce(self, arr):
-        return self.ctx.allreduce_host(arr) if self.size > 1 else np.asarray(arr, dtype=np.float64)
+        return self.ctx.allreduce_host(arr) if self.comm_ready else np.asarray(arr, dtype=np.float64)
 
 
 _sessions = weakref.WeakKeyDictionary()

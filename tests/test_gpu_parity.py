@@ -258,3 +258,37 @@ def test_variational_batch_em_vs_reference(funs_mod):
     assert np.max(np.abs(np.asarray(fit.variationalLowerBound) - g['bounded_vlb'])) <= 1e-2
     assert np.max(np.abs(np.asarray(fit.posteriorLikelihood) - g['bounded_nll'])) <= 1e-2
     assert rel(fit.paramSeq[-1]['C'], g['bounded_seq_C'][-1]) <= 5e-3
+
+
+def test_rccl_path_single_rank(c1):
+    """The multi-GPU code path (unique-id file rendezvous, ncclCommInitRank, device all-reduce inside the
+    M-step entry points) on a 1-rank communicator: results must equal the communicator-free run."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = r'''
+import os, sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'poisson-gpfa_amd')); sys.path.insert(0, os.path.join(%r, 'tests'))
+import funs
+from conftest import Experiment
+d = np.load(os.path.join(%r, 'tests', 'golden', 'c1_dataset.npz'))
+Ys = [d['Y'][r].astype(float) for r in range(20)]
+exp = Experiment(Ys, 10.0)
+init = {'C': d['init_C'].copy(), 'd': d['init_d'].copy(), 'tau': d['init_tau'].copy()}
+fit = funs.engine.PPGPFAfit(exp, initParams=init, EMmode='Batch', maxEMiter=2, quiet=True)
+from funs._session import session_for
+sess, _ = session_for(exp, 3)
+print('COMM', sess.comm_ready, sess.size)
+print('RESULT', repr(list(fit.posteriorLikelihood)), repr(fit.paramSeq[-1]['tau'].tolist()))
+''' % (ROOT, ROOT, ROOT, ROOT)
+    outs = []
+    for force in ('0', '1'):
+        env = dict(os.environ, PGPFA_FORCE_COMM=force, RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_PORT='29655')
+        res = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        lines = res.stdout.splitlines()
+        comm = [l for l in lines if l.startswith('COMM')][0]
+        assert comm == ('COMM True 1' if force == '1' else 'COMM False 1'), comm
+        outs.append([l for l in lines if l.startswith('RESULT')][0])
+    assert outs[0] == outs[1]
