@@ -36,6 +36,21 @@ CONFIGS = {   # name: (neurons, latents, bins, trials per GPU)
     'c3': (200, 10, 500, 1024),
 }
 FP64_MATRIX_PEAK_TFLOPS = 78.6     # MI355X FP64 matrix (= FP64 vector) peak, AMD CDNA4 datasheet
+PMC_SUMMARY = os.path.join(ROOT, 'profiles', 'r01_c3_pmc_hbm_traffic.json')   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+
+
+def pmc_traffic_per_launch(kernel_prefix):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (separate FETCH_SIZE and
+    WRITE_SIZE runs of this same command, FETCH doubled as MI355X_MICROARCH.md prescribes); None if absent."""
+    try:
+        with open(PMC_SUMMARY) as fh:
+            d = json.load(fh)
+        for k, v in d.items():
+            if k.startswith(kernel_prefix):
+                return v['hbm_bytes_per_launch']
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
 
 
 class Shard:
@@ -206,7 +221,9 @@ def main():
         'nll': nll_hist,
         'roofline': {'bound': 'mfma', 'kernel': 'gemm_mfma_kernel<0> (FP64 16x16x4 MFMA; SYRK/TRSM/TRTRI/selected-inverse GEMMs)',
                      'achieved': achieved, 'peak': FP64_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / FP64_MATRIX_PEAK_TFLOPS,
-                     'traffic': None, 'launches': gemm_launches, 'avg_launch_ms': gemm_ms / max(gemm_launches, 1.0),
+                     'traffic': pmc_traffic_per_launch('void pgpfa::gemm_mfma_kernel<0>') if args.config == 'c3' else None,
+                     'traffic_unit': 'HBM bytes per launch (PMC, profiles/r01_c3_pmc_hbm_traffic.json)',
+                     'algorithmic_flops_per_launch': gemm_flops / max(gemm_launches, 1.0), 'launches': gemm_launches, 'avg_launch_ms': gemm_ms / max(gemm_launches, 1.0),
                      'kernel_share_of_step': gemm_ms / (t_max * 1e3)},
     }
     if not args.no_cpu_baseline and world == 1:
