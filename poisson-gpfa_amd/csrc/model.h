@@ -419,7 +419,8 @@ __global__ void dense_h_kernel(double* __restrict__ out, int n, int T, int Tp, i
 // --------------------------------------------------------------------------------------------------
 template <int PMAX>
 __global__ void post_vsm_kernel(const double* __restrict__ Mt, long long sM, int ld, int npad, int T, int p,
-                                double* __restrict__ vsm, const int* __restrict__ slots, const int* __restrict__ trial_of_slot) {
+                                double* __restrict__ vsm, const int* __restrict__ slots, const int* __restrict__ trial_of_slot,
+                                int full_range) {
   constexpr int NK = (PMAX > 16) ? 2 : 1;
   constexpr int VIC = (PMAX <= 8) ? 16 : (PMAX <= 16 ? 8 : 4);   // 64 KB of LDS at most
   __shared__ double A[VIC][PMAX][64];
@@ -436,7 +437,7 @@ __global__ void post_vsm_kernel(const double* __restrict__ Mt, long long sM, int
 #pragma unroll
     for (int l = 0; l < PMAX; ++l) acc[j][l] = 0.0;
 
-  const int istart = (t0 / VIC) * VIC;          // row (0,t0) is the first with entries at column t0
+  const int istart = full_range ? 0 : (t0 / VIC) * VIC;   // triangular Mt: row (0,t0) is the first with entries at column t0
   for (int i0 = istart; i0 < npad; i0 += VIC) {
 #pragma unroll
     for (int j = 0; j < NK; ++j) {
@@ -840,6 +841,217 @@ __global__ void copy_rows_kernel(const double* __restrict__ src, double* __restr
   const size_t slot = slots[blockIdx.y];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[slot * sV + i] = src[slot * sV + i];
+}
+
+// --------------------------------------------------------------------------------------------------
+// Low-rank covariance engine.  K_k = eps*I + F_k F_k^T with F_k (T x r_k) from a pivoted Cholesky of
+// the RBF part (numerically low rank: eigenvalues decay like a Gaussian), so with W = blockdiag_t(W_t),
+//   G = (I + eps W)^-1 ,  Wt = W G   (p x p per bin, symmetric)
+//   Sigma = H^-1 = eps G + G F (I_r + F^T Wt F)^-1 F^T G                    (Woodbury, exact)
+// and every O(n^3) step of the covariance phase becomes O(T r^2) / O(r^3), r = sum_k r_k << n = pT.
+// --------------------------------------------------------------------------------------------------
+
+// Pivoted Cholesky of (1-eps)*RBF_k, one workgroup per latent.  F: [p][Tf x Tf] column-major slabs
+// (column j of latent k at F + k*Tf*Tf + j*Tf), rows >= T and unused columns are zero.  rank[k] out.
+__global__ __launch_bounds__(256) void rbf_pivchol_kernel(double* __restrict__ F, int Tf, int T, const double* __restrict__ tau, double bin,
+                                                          double eps, double tol, int rmax, int* __restrict__ rank) {
+  extern __shared__ double sh[];              // d[T] | frow[rmax] | red_val[256] ; then int red_idx[256]
+  double* d = sh;
+  double* frow = sh + T;
+  double* rv = frow + rmax;
+  int* ri = reinterpret_cast<int*>(rv + 256);
+  __shared__ int piv_s;
+  __shared__ double dpiv_s;
+  const int k = blockIdx.x, tid = threadIdx.x;
+  double* Fk = F + (size_t)k * Tf * Tf;
+  const double den = (tau[k] * 1000.0) * (tau[k] * 1000.0);
+  for (size_t e = tid; e < (size_t)Tf * Tf; e += 256) Fk[e] = 0.0;
+  for (int t = tid; t < T; t += 256) d[t] = 1.0 - eps;
+  __syncthreads();
+  int j = 0;
+  for (; j < rmax; ++j) {
+    double best = -1.0; int bi = 0;
+    for (int t = tid; t < T; t += 256) if (d[t] > best) { best = d[t]; bi = t; }
+    rv[tid] = best; ri[tid] = bi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (tid < o && (rv[tid + o] > rv[tid] || (rv[tid + o] == rv[tid] && ri[tid + o] < ri[tid]))) { rv[tid] = rv[tid + o]; ri[tid] = ri[tid + o]; }
+      __syncthreads();
+    }
+    if (tid == 0) { piv_s = ri[0]; dpiv_s = rv[0]; }
+    __syncthreads();
+    const int piv = piv_s;
+    const double dp = dpiv_s;
+    if (!(dp > tol)) break;
+    for (int m = tid; m < j; m += 256) frow[m] = Fk[(size_t)m * Tf + piv];
+    __syncthreads();
+    const double rs = 1.0 / sqrt(dp);
+    for (int t = tid; t < T; t += 256) {
+      const double dt = (double)t * bin - (double)piv * bin;
+      double v = (1.0 - eps) * exp(-0.5 * ((dt * dt) / den));
+      for (int m = 0; m < j; ++m) v -= Fk[(size_t)m * Tf + t] * frow[m];
+      v *= rs;
+      Fk[(size_t)j * Tf + t] = v;
+      d[t] = (t == piv) ? 0.0 : d[t] - v * v;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) rank[k] = j;
+}
+
+// per (slot, bin): G = (I + eps W)^-1 and Wt = W G.  One thread per matrix, matrices in dynamic LDS.
+__global__ void bin_blocks_kernel(const double* __restrict__ W, long long sW, double* __restrict__ G, double* __restrict__ Wt, long long sO,
+                                  int T, int p, double eps, const int* __restrict__ slots, int nslots) {
+  extern __shared__ double sm[];
+  const int pp = p * p, stride = 2 * pp + 1;
+  double* A = sm + (size_t)threadIdx.x * stride;   // A: I + eps W -> L -> L^-1 ; Gm = result
+  double* Gm = A + pp;
+  const long long item = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (item >= (long long)nslots * T) return;
+  const int slot = slots[item / T];
+  const int t = (int)(item % T);
+  const double* w = W + (size_t)slot * sW + (size_t)t * pp;
+  for (int i = 0; i < p; ++i)
+    for (int j2 = 0; j2 < p; ++j2) A[i * p + j2] = eps * w[i * p + j2] + (i == j2 ? 1.0 : 0.0);
+  // Cholesky (lower, in place)
+  for (int j2 = 0; j2 < p; ++j2) {
+    double dj = A[j2 * p + j2];
+    for (int m = 0; m < j2; ++m) dj -= A[j2 * p + m] * A[j2 * p + m];
+    dj = sqrt(dj);
+    A[j2 * p + j2] = dj;
+    for (int i = j2 + 1; i < p; ++i) {
+      double v = A[i * p + j2];
+      for (int m = 0; m < j2; ++m) v -= A[i * p + m] * A[j2 * p + m];
+      A[i * p + j2] = v / dj;
+    }
+  }
+  // invert L in place (lower)
+  for (int j2 = 0; j2 < p; ++j2) {
+    A[j2 * p + j2] = 1.0 / A[j2 * p + j2];
+    for (int i = j2 + 1; i < p; ++i) {
+      double v = 0.0;
+      for (int m = j2; m < i; ++m) v -= A[i * p + m] * A[m * p + j2];
+      A[i * p + j2] = v / A[i * p + i];
+    }
+  }
+  // (column j2 reads L[i][m], m >= j2, and L[i][i], i > j2, which are still un-inverted at that point)
+  // G = L^-T L^-1
+  double* g = G + (size_t)slot * sO + (size_t)t * pp;
+  double* wt = Wt + (size_t)slot * sO + (size_t)t * pp;
+  for (int i = 0; i < p; ++i)
+    for (int j2 = 0; j2 <= i; ++j2) {
+      double v = 0.0;
+      for (int m = i; m < p; ++m) v += A[m * p + i] * A[m * p + j2];
+      Gm[i * p + j2] = v;
+      Gm[j2 * p + i] = v;
+    }
+  for (int i = 0; i < p; ++i)
+    for (int j2 = 0; j2 < p; ++j2) {
+      g[i * p + j2] = Gm[i * p + j2];
+      double v = 0.0;
+      for (int m = 0; m < p; ++m) v += w[i * p + m] * Gm[m * p + j2];
+      wt[i * p + j2] = v;
+    }
+}
+
+// B = I + F^T Wt F (lower triangle, ld = rpad) per slot.  16x16 output tiles; tile (bi,bj) lies inside one latent
+// pair (k,l) because rank offsets are multiples of 16 (blk_lat[b] = latent of block b, -1 = padding).
+// grid = (ntile_pairs, nslots), block = 256 (one output each); bins streamed through LDS in chunks of 64.
+__global__ __launch_bounds__(256) void assemble_b_kernel(double* __restrict__ Bm, long long sB, int ldb, int nblk,
+                                                         const double* __restrict__ F, int Tf, int T, int p,
+                                                         const int* __restrict__ blk_lat, const int* __restrict__ blk_col,
+                                                         const double* __restrict__ Wt, long long sW, const int* __restrict__ slots) {
+  __shared__ double Fa[64][17];
+  __shared__ double Fb[64][17];
+  __shared__ double wv[64];
+  // decode the lower-triangular tile pair
+  int bi = 0, rem = blockIdx.x;
+  while (rem > bi) { rem -= bi + 1; ++bi; }
+  const int bj = rem;                                   // bj <= bi
+  const size_t slot = slots[blockIdx.y];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;    // output (row bi*16+ty... see below)
+  const int ka = blk_lat[bi], kb = blk_lat[bj];
+  double* out = Bm + slot * sB;
+  const int row = bi * 16 + tx, col = bj * 16 + ty;     // tx along rows: contiguous stores
+  if (ka < 0 || kb < 0) {                               // padding block: identity
+    if (row >= col) out[(size_t)col * ldb + row] = (row == col) ? 1.0 : 0.0;
+    return;
+  }
+  const double* FA = F + (size_t)ka * Tf * Tf + (size_t)blk_col[bi] * Tf;   // 16 columns of F_ka
+  const double* FB = F + (size_t)kb * Tf * Tf + (size_t)blk_col[bj] * Tf;
+  const double* w = Wt + slot * sW + (size_t)ka * p + kb;                    // + t*p*p
+  double acc = 0.0;
+  for (int t0 = 0; t0 < T; t0 += 64) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * 16; e += 256) {
+      const int tt = e & 63, cc = e >> 6;
+      const int t = t0 + tt;
+      Fa[tt][cc] = (t < T) ? FA[(size_t)cc * Tf + t] : 0.0;
+      Fb[tt][cc] = (t < T) ? FB[(size_t)cc * Tf + t] : 0.0;
+    }
+    if (threadIdx.x < 64) wv[threadIdx.x] = (t0 + threadIdx.x < T) ? w[(size_t)(t0 + threadIdx.x) * p * p] : 0.0;
+    __syncthreads();
+#pragma unroll 8
+    for (int tt = 0; tt < 64; ++tt) acc += Fa[tt][tx] * wv[tt] * Fb[tt][ty];
+  }
+  if (row >= col) out[(size_t)col * ldb + row] = acc + (row == col ? 1.0 : 0.0);
+}
+
+// vsm[t] <- eps*G_t + G_t * Bt_t * G_t in place (Bt_t already in vsm, trial indexed); one thread per (slot,t)
+__global__ void vsm_finish_kernel(double* __restrict__ vsm, const double* __restrict__ G, long long sG, int T, int p, double eps,
+                                  const int* __restrict__ slots, const int* __restrict__ trial_of_slot, int nslots) {
+  extern __shared__ double sm[];
+  const int pp = p * p;
+  double* tmp = sm + (size_t)threadIdx.x * (pp + 1);
+  const long long item = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (item >= (long long)nslots * T) return;
+  const int slot = slots[item / T];
+  const int t = (int)(item % T);
+  const double* g = G + (size_t)slot * sG + (size_t)t * pp;
+  double* v = vsm + ((size_t)trial_of_slot[slot] * T + t) * pp;
+  for (int i = 0; i < p; ++i)
+    for (int j = 0; j < p; ++j) {
+      double s = 0.0;
+      for (int m = 0; m < p; ++m) s += v[i * p + m] * g[m * p + j];
+      tmp[i * p + j] = s;                                  // Bt G
+    }
+  for (int i = 0; i < p; ++i)
+    for (int j = 0; j < p; ++j) {
+      double s = eps * g[i * p + j];
+      for (int m = 0; m < p; ++m) s += g[i * p + m] * tmp[m * p + j];
+      v[i * p + j] = s;
+    }
+}
+
+// Ymix[t + b*ldo] = sum_k' G_t[k][k'] * Yt[(k',t) + b*ldy]   for latent k (lanes along t)
+__global__ void mix_y_kernel(const double* __restrict__ Yt, long long sY, int ldy, const double* __restrict__ G, long long sG,
+                             double* __restrict__ out, long long sO, int ldo, int T, int p, int k, int rpad, const int* __restrict__ slots) {
+  const size_t slot = slots[blockIdx.z];
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  if (t >= ldo) return;
+  double s = 0.0;
+  if (t < T) {
+    const double* g = G + slot * sG + (size_t)t * p * p + (size_t)k * p;
+    const double* y = Yt + slot * sY + (size_t)b * ldy + t;
+    for (int kk = 0; kk < p; ++kk) s += g[kk] * y[(size_t)kk * T];
+  }
+  out[slot * sO + (size_t)b * ldo + t] = s;               // rows >= T are zero
+  (void)rpad;
+}
+
+// vsmGP scatter for the low-rank engine: dst = mirror(src) + eps*G_t[k][k] on the diagonal
+__global__ void scatter_vsmgp_lr_kernel(const double* __restrict__ src, long long sSrc, int lds, double* __restrict__ dst, int T, int p, int k,
+                                        const double* __restrict__ G, long long sG, double eps, const int* __restrict__ trial_of_slot) {
+  const int slot = blockIdx.y;
+  const size_t r = trial_of_slot[slot];
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < (size_t)T * T) {
+    const size_t a = e % T, b = e / T;
+    double v = (a >= b) ? src[(size_t)slot * sSrc + b * lds + a] : src[(size_t)slot * sSrc + a * lds + b];
+    if (a == b) v += eps * G[(size_t)slot * sG + a * p * p + (size_t)k * p + k];
+    dst[(r * p + k) * T * T + e] = v;
+  }
 }
 
 // counts: double [R][q][T] -> uint8 with validation (non-negative integers <= 255)

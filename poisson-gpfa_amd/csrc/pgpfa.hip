@@ -97,6 +97,16 @@ struct pgpfa_ctx {
   double *sU = nullptr, *sDinvT = nullptr, *Wbar = nullptr;
   double *Rv = nullptr, *Zv = nullptr, *Pv = nullptr, *Qv = nullptr;
   double *sc_rz = nullptr, *sc_pq = nullptr, *sc_rr = nullptr, *sc_rr0 = nullptr;
+  // low-rank covariance engine
+  double* Flr = nullptr;                          // [p][Tp x Tp] pivoted-Cholesky factors of the RBF part
+  double* Gbin = nullptr;                         // [B][T][p][p]
+  int *d_rank = nullptr, *d_blk_lat = nullptr, *d_blk_col = nullptr;
+  std::vector<int> rk, roff;                      // ranks padded to 16, offsets
+  int rtot = 0, rpad = 0;
+  int cov_mode = 0;                               // 0 auto, 1 dense, 2 low-rank
+  double lr_tol = 1e-13;
+  bool mt_dirty = false;                          // low-rank use scribbled over the Mt slabs' zero triangle
+  bool last_cov_lowrank = false;
   bool shared_pcg = true;
   int shared_min = 16, pcg_inner = 8, pcg_inner_max = 16, pcg_outer_max = 12;
   double *sc_f = nullptr, *sc_qxx = nullptr, *sc_qdx = nullptr, *sc_qdd = nullptr, *sc_dec = nullptr, *sc_smax = nullptr, *sc_alpha = nullptr;
@@ -302,7 +312,7 @@ size_t ld_bytes(const pgpfa_ctx* c) { return (size_t)c->ld * c->ld * sizeof(doub
 
 size_t per_slot_bytes(const pgpfa_ctx* c) {
   const size_t ld = c->ld;
-  size_t dbl = 2 * ld * ld + 2 * ld * NB + 12 * ld + 2 * (size_t)c->T * c->p * c->p + ((c->T + 63) / 64) + 32;
+  size_t dbl = 2 * ld * ld + 2 * ld * NB + 12 * ld + 3 * (size_t)c->T * c->p * c->p + ((c->T + 63) / 64) + 32;
   return dbl * sizeof(double);
 }
 
@@ -343,6 +353,7 @@ int ensure_workspace(pgpfa_ctx* c) {
   CHK(dmalloc(c, &c->sU, ld * ld + 256 * ld, true));
   CHK(dmalloc(c, &c->sDinvT, ld * NB + 256 * ld));
   CHK(dmalloc(c, &c->Wbar, (size_t)c->T * c->p * c->p));
+  CHK(dmalloc(c, &c->Gbin, (size_t)c->T * c->p * c->p * nB));
   CHK(dmalloc(c, &c->sc_rz, nB)); CHK(dmalloc(c, &c->sc_pq, nB)); CHK(dmalloc(c, &c->sc_rr, nB)); CHK(dmalloc(c, &c->sc_rr0, nB));
   const size_t wlen = (size_t)c->T * c->p * c->p;
   CHK(dmalloc(c, &c->W, wlen * nB)); CHK(dmalloc(c, &c->Wt, wlen * nB));
@@ -464,6 +475,35 @@ int build_kinv(pgpfa_ctx* c) {
   return 0;
 }
 
+
+// pivoted-Cholesky factors of the RBF part of every Gram matrix and the block tables of the r x r system
+int build_lowrank(pgpfa_ctx* c) {
+  const int p = c->p, T = c->T, Tp = c->Tp;
+  const int rmax = std::min(T, Tp);
+  const size_t shm = ((size_t)T + rmax + 256) * sizeof(double) + 256 * sizeof(int);
+  hipLaunchKernelGGL(rbf_pivchol_kernel, dim3(p), dim3(256), shm, c->st, c->Flr, Tp, T, c->tau, c->bin, c->eps, c->lr_tol, rmax, c->d_rank);
+  HIPC(hipGetLastError());
+  std::vector<int> r(p);
+  HIPC(hipMemcpyAsync(r.data(), c->d_rank, sizeof(int) * p, hipMemcpyDeviceToHost, c->st));
+  HIPC(hipStreamSynchronize(c->st));
+  c->rk.assign(p, 0);
+  c->roff.assign(p + 1, 0);
+  for (int k = 0; k < p; ++k) {
+    c->rk[k] = round_up(std::max(r[k], 1), 16);
+    c->roff[k + 1] = c->roff[k] + c->rk[k];
+  }
+  c->rtot = c->roff[p];
+  c->rpad = round_up(c->rtot, NB);
+  const int nblk = c->rpad / 16;
+  std::vector<int> lat(nblk, -1), col(nblk, 0);
+  for (int k = 0; k < p; ++k)
+    for (int b = c->roff[k] / 16; b < c->roff[k + 1] / 16; ++b) { lat[b] = k; col[b] = b * 16 - c->roff[k]; }
+  CHK(upload_list(c, c->d_blk_lat, lat));
+  CHK(upload_list(c, c->d_blk_col, col));
+  c->info["lowrank_rtot"] = c->rtot;
+  return 0;
+}
+
 int allreduce_dev(pgpfa_ctx* c, double* buf, size_t count) {
   if (!c->comm) return 0;
   ncclResult_t r = ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, c->comm, c->st);
@@ -544,6 +584,8 @@ int pgpfa_create(pgpfa_ctx** out, int device, int q, int p, int T, int R, double
   rc |= dmalloc(c, &c->vsm, (size_t)R * T * p * p + 2048, true);
   rc |= dmalloc(c, &c->vsmgp, (size_t)R * p * T * T, true);
   rc |= dmalloc(c, &c->Pauto, slab * p, true);
+  rc |= dmalloc(c, &c->Flr, slab * p + 256 * (size_t)c->Tp, true);
+  rc |= dmalloc(c, &c->d_rank, p); rc |= dmalloc(c, &c->d_blk_lat, (size_t)p * c->Tp / 16 + 64); rc |= dmalloc(c, &c->d_blk_col, (size_t)p * c->Tp / 16 + 64);
   rc |= dmalloc(c, &c->vec, (size_t)q * (p + 1));
   rc |= dmalloc(c, &c->cdpart, (size_t)1024 * (p + 2) * q);
   rc |= dmalloc(c, &c->cdout, (size_t)(p + 2) * q + 8);
@@ -582,6 +624,8 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
   else if (k == "use_mfma") c->mfma = (v != 0.0);
   else if (k == "chord") c->chord = (v != 0.0);
   else if (k == "shared_pcg") c->shared_pcg = (v != 0.0);
+  else if (k == "cov_mode") c->cov_mode = (int)v;
+  else if (k == "lowrank_tol") c->lr_tol = v;
   else if (k == "shared_min") c->shared_min = (int)v;
   else if (k == "pcg_inner") c->pcg_inner = (int)v;
   else if (k == "chord_xtol") c->chord_xtol = v;
@@ -667,6 +711,7 @@ int pgpfa_set_params(pgpfa_ctx* c, const double* C, const double* d, const doubl
   hipLaunchKernelGGL(gram_tau_kernel, dim3(c->Tp, c->p), dim3(256), 0, c->st, c->Kpad, c->Tp, c->T, c->tau, c->bin, c->eps);
   HIPC(hipGetLastError());
   CHK(build_kinv(c));
+  CHK(build_lowrank(c));
   c->have_params = true;
   return 0;
 }
@@ -809,8 +854,17 @@ static int shared_factor(pgpfa_ctx* c, int nb) {
 
 // H (from the W blocks of slots [0,nb), diagonal scaled by diag_scale) -> factor -> L^-T -> post_vsmGP and
 // post_vsm of the trials bound to the slots.  Shared by the Laplace and the dual-variational E-step.
-static int posterior_blocks(pgpfa_ctx* c, int nb, double diag_scale, bool want_vsmgp) {
+static int ensure_mt_clean(pgpfa_ctx* c) {
+  if (!c->mt_dirty) return 0;
+  HIPC(hipMemsetAsync(c->ws.Mt, 0, (size_t)c->ws.sM * c->B * sizeof(double), c->st));
+  c->mt_dirty = false;
+  return 0;
+}
+
+static int posterior_blocks_dense(pgpfa_ctx* c, int nb, double diag_scale, bool want_vsmgp) {
   const int T = c->T, p = c->p;
+  CHK(ensure_mt_clean(c));
+  c->last_cov_lowrank = false;
   CHK(assemble(c, c->ident, nb, diag_scale));
   CHK(factor(c, c->ws, c->ident, nb));
   CHK(inverse_t(c, c->ws, c->ident, nb));
@@ -834,11 +888,103 @@ static int posterior_blocks(pgpfa_ctx* c, int nb, double diag_scale, bool want_v
   prof_begin(c, TAG_VSM, (double)nb * c->npad * c->npad * p);
   dispatch_pmax(p, [&](auto pm) {
     hipLaunchKernelGGL(post_vsm_kernel<decltype(pm)::value>, dim3((T + 63) / 64, nb), dim3(64, KY), 0, c->st, c->ws.Mt, c->ws.sM, c->ld, c->npad,
-                       T, p, c->vsm, c->ident, c->trial_of_slot);
+                       T, p, c->vsm, c->ident, c->trial_of_slot, 0);
   });
   prof_end(c);
   HIPC(hipGetLastError());
   return 0;
+}
+
+
+// Covariance blocks through the low-rank form of the prior (see model.h): per slot an r x r SPD system
+// B = I + F^T Wt F instead of the n x n Hessian.  Uses the dense engine's slabs as scratch (ld = rpad views).
+static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp) {
+  const int T = c->T, p = c->p, Tp = c->Tp, pp = p * p;
+  const int rpad = c->rpad;
+  const long long sW = (long long)T * pp;
+  c->last_cov_lowrank = true;
+  // a. per-bin blocks G = (I + eps W)^-1, Wt = W G
+  {
+    int th = (int)(48 * 1024 / ((2 * pp + 1) * sizeof(double)));
+    th = std::max(1, std::min(64, th));
+    const long long items = (long long)nb * T;
+    hipLaunchKernelGGL(bin_blocks_kernel, dim3((unsigned)((items + th - 1) / th)), dim3(th), (size_t)th * (2 * pp + 1) * sizeof(double), c->st,
+                       c->W, sW, c->Gbin, c->Wt, sW, T, p, c->eps, c->ident, nb);
+  }
+  // b. B = I + F^T Wt F into the factor slabs viewed with ld = rpad; factor; L^-T
+  CholWS lw = c->ws;
+  lw.ld = rpad; lw.npad = rpad; lw.nact = round_up(c->rtot, 64);
+  const int nblk16 = rpad / 16, npairs = nblk16 * (nblk16 + 1) / 2;
+  hipLaunchKernelGGL(assemble_b_kernel, dim3(npairs, nb), dim3(256), 0, c->st, lw.H, lw.sH, rpad, nblk16, c->Flr, Tp, T, p, c->d_blk_lat,
+                     c->d_blk_col, c->Wt, sW, c->ident);
+  HIPC(hipGetLastError());
+  HIPC(hipMemsetAsync(c->ws.info, 0, sizeof(int) * nb, c->st));
+  CHK(factor(c, lw, c->ident, nb));
+  c->mt_dirty = true;
+  HIPC(hipMemset2DAsync(lw.Mt, (size_t)lw.sM * sizeof(double), 0, (size_t)rpad * rpad * sizeof(double), nb, c->st));
+  CHK(inverse_t(c, lw, c->ident, nb));
+  // c. Yt = F Mts  (n x rpad, ld = c->ld) into the factor slab (the factor itself is dead now)
+  for (int k = 0; k < p; ++k) {
+    GemmP g{};
+    g.A = c->Flr + (size_t)k * Tp * Tp; g.sA = 0; g.lda = Tp;
+    g.B = lw.Mt + c->roff[k]; g.sB = lw.sM; g.ldb = rpad;          // rows roff[k].. of Mts, K x N column-major
+    g.C = lw.H + (size_t)k * T; g.sC = lw.sH; g.ldc = c->ld;
+    g.M = T; g.N = rpad; g.K = c->rk[k]; g.alpha = 1.0; g.beta = 0.0;
+    g.slots = c->ident; g.nbatch = nb; g.mode = GEMM_FULL; g.kflags = 0;
+    CHK(gemm(c, true, g));
+  }
+  // d. post_vsm[t] = eps G_t + G_t (Y_t^T Y_t) G_t
+  {
+    const int KY = std::min(p, 16);
+    prof_begin(c, TAG_VSM, (double)nb * c->n * rpad * p);
+    dispatch_pmax(p, [&](auto pm) {
+      hipLaunchKernelGGL(post_vsm_kernel<decltype(pm)::value>, dim3((T + 63) / 64, nb), dim3(64, KY), 0, c->st, lw.H, lw.sH, c->ld, rpad,
+                         T, p, c->vsm, c->ident, c->trial_of_slot, 1);
+    });
+    prof_end(c);
+    int th = (int)(48 * 1024 / ((pp + 1) * sizeof(double)));
+    th = std::max(1, std::min(64, th));
+    const long long items = (long long)nb * T;
+    hipLaunchKernelGGL(vsm_finish_kernel, dim3((unsigned)((items + th - 1) / th)), dim3(th), (size_t)th * (pp + 1) * sizeof(double), c->st,
+                       c->vsm, c->Gbin, sW, T, p, c->eps, c->ident, c->trial_of_slot, nb);
+  }
+  // e. post_vsmGP_k = eps diag(G_t[k][k]) + Ymix_k Ymix_k^T,  Ymix_k[t][b] = sum_k' G_t[k][k'] Yt[(k',t)][b]
+  if (want_vsmgp) {
+    const size_t off_mix = (size_t)c->ld * rpad;
+    const size_t off_stage = off_mix + (size_t)Tp * rpad;
+    for (int k = 0; k < p; ++k) {
+      hipLaunchKernelGGL(mix_y_kernel, dim3((Tp + 63) / 64, rpad, nb), dim3(64), 0, c->st, lw.H, lw.sH, c->ld, c->Gbin, sW, lw.H + off_mix, lw.sH, Tp,
+                         T, p, k, rpad, c->ident);
+      GemmP g{};
+      g.A = lw.H + off_mix; g.sA = lw.sH; g.lda = Tp;
+      g.B = g.A; g.sB = lw.sH; g.ldb = Tp;
+      g.C = lw.H + off_stage; g.sC = lw.sH; g.ldc = T;
+      g.M = T; g.N = T; g.K = rpad; g.alpha = 1.0; g.beta = 0.0;
+      g.slots = c->ident; g.nbatch = nb; g.mode = GEMM_LOWER; g.kflags = 0;
+      CHK(gemm(c, false, g));
+      hipLaunchKernelGGL(scatter_vsmgp_lr_kernel, dim3((unsigned)(((size_t)T * T + 255) / 256), nb), dim3(256), 0, c->st, lw.H + off_stage, lw.sH, T,
+                         c->vsmgp, T, p, k, c->Gbin, sW, c->eps, c->trial_of_slot);
+    }
+  }
+  HIPC(hipGetLastError());
+  return 0;
+}
+
+// engine choice: the low-rank form pays when r << n (long timescales); the dense form is the general one
+static bool lowrank_pays(const pgpfa_ctx* c) {
+  const double n = c->n, r = c->rpad, T = c->T, p = c->p;
+  if (c->rpad * 2 > c->npad) return false;
+  const size_t need = (size_t)c->ld * c->rpad + (size_t)c->Tp * c->rpad + (size_t)T * T;
+  if (need > (size_t)c->ld * c->ld) return false;
+  const double dense = 0.72 * n * n * n;
+  const double lr = 6.0 * T * r * r + 0.7 * r * r * r + p * T * T * r;
+  return lr < 0.5 * dense;
+}
+
+static int posterior_blocks(pgpfa_ctx* c, int nb, double diag_scale, bool want_vsmgp) {
+  const bool lr = diag_scale == 1.0 && (c->cov_mode == 2 || (c->cov_mode == 0 && lowrank_pays(c)));
+  if (lr) return posterior_blocks_lowrank(c, nb, want_vsmgp);
+  return posterior_blocks_dense(c, nb, diag_scale, want_vsmgp);
 }
 
 int pgpfa_estep_laplace(pgpfa_ctx* c, int n, const int32_t* idx, int warm_start, double* obj_sum, int32_t* iters, int32_t* status) {
@@ -1076,6 +1222,7 @@ int pgpfa_estep_laplace(pgpfa_ctx* c, int n, const int32_t* idx, int warm_start,
   c->info["last_newton_solves"] = n_solve;
   c->info["last_pcg_iterations"] = n_pcg;
   c->info["last_shared_factorizations"] = n_shared;
+  c->info["last_cov_lowrank"] = c->last_cov_lowrank ? 1.0 : 0.0;
   c->info["last_newton_max_iter"] = max_it_seen;
   return 0;
 }
@@ -1122,6 +1269,7 @@ int pgpfa_get_post_cov(pgpfa_ctx* c, int trial, double* out) {
   HIPC(hipMemsetAsync(c->ws.info, 0, sizeof(int), c->st));
   hipLaunchKernelGGL(gather_rows_kernel, dim3((c->n + 255) / 256, 1), dim3(256), 0, c->st, c->Xmode, c->n, c->Xc, (long long)c->ld, c->trial_of_slot, 0);
   CHK(poisson(c, c->ident, 1, c->Xc, c->Gl, c->W, c->sc_f, 1));
+  CHK(ensure_mt_clean(c));
   CHK(assemble(c, c->ident, 1));
   CHK(factor(c, c->ws, c->ident, 1));
   CHK(inverse_t(c, c->ws, c->ident, 1));
@@ -1400,11 +1548,12 @@ int pgpfa_dual_costgrad(pgpfa_ctx* c, int trial, const double* lam, double* cost
   // A + B + C + D of inference.py:203-213 ; C = 0.5*logdet(Sigma) = -0.5*logdet(precision + jitter)
   *cost = 0.5 * vKv[0] - sB[0] - 0.5 * logdetH + sD[0];
   if (grad) {
+    CHK(ensure_mt_clean(c));
     CHK(inverse_t(c, c->ws, c->ident, 1));
     const int KY = std::min(p, 16);
     dispatch_pmax(p, [&](auto pm) {
       hipLaunchKernelGGL(post_vsm_kernel<decltype(pm)::value>, dim3((T + 63) / 64, 1), dim3(64, KY), 0, c->st, c->ws.Mt, c->ws.sM, c->ld, c->npad,
-                         T, p, c->vsm, c->ident, c->trial_of_slot);
+                         T, p, c->vsm, c->ident, c->trial_of_slot, 0);
     });
     hipLaunchKernelGGL(dual_grad_kernel, dim3((T + 63) / 64, q), dim3(64), 0, c->st, c->C, c->d, c->lamd, c->KD,
                        c->vsm + (size_t)trial * T * p * p, c->dgrad, q, p, T);

@@ -292,3 +292,49 @@ print('RESULT', repr(list(fit.posteriorLikelihood)), repr(fit.paramSeq[-1]['tau'
         assert comm == ('COMM True 1' if force == '1' else 'COMM False 1'), comm
         outs.append([l for l in lines if l.startswith('RESULT')][0])
     assert outs[0] == outs[1]
+
+
+@pytest.mark.parametrize('size', ['c1', 'ragged', 'c2'])
+def test_lowrank_covariance_engine_matches_dense(c1, size):
+    """The low-rank (K = eps I + F F^T) covariance engine against the dense one and the oracle."""
+    from funs import _hip
+    if size == 'c1':
+        Y, par, bin_ms = c1['Y'], c1['init'], c1['binSize']
+    elif size == 'ragged':
+        _, Ys, _ = orc.synth_dataset(13, 7, 41, 3, seed=5, dOffset=0.0)
+        Y = np.stack(Ys).astype(np.uint8)
+        rng = np.random.default_rng(5)
+        par = {'C': 0.3 * rng.standard_normal((13, 7)), 'd': np.log(Y.mean(axis=(0, 2)) + 0.1), 'tau': 0.1 + 0.4 * rng.random(7)}
+        bin_ms = 10.0
+    else:
+        g = load_golden('c2_spot.npz')
+        Y, par, bin_ms = g['Y'], {'C': g['init_C'], 'd': g['init_d'], 'tau': g['init_tau']}, float(g['binSize'])
+    R, q, T = Y.shape
+    p = par['C'].shape[1]
+    out = {}
+    for mode in (1, 2):
+        ctx = _hip.Context(q, p, T, R, bin_ms)
+        try:
+            ctx.upload_counts(Y)
+            ctx.set_option('cov_mode', mode)
+            ctx.set_params(par['C'], par['d'], par['tau'])
+            obj, iters, status = ctx.estep_laplace()
+            assert np.all(status == 0)
+            assert ctx.info('last_cov_lowrank') == (1.0 if mode == 2 else 0.0)
+            out[mode] = (obj, ctx.post_mean(), ctx.post_vsm(), ctx.post_vsmgp(), ctx.info('lowrank_rtot'))
+            if mode == 2:
+                # a dense request after low-rank use (post_cov) must still be right
+                cov = ctx.post_cov(0)
+                vs = out[2][2][0]
+                assert rel(np.stack([cov[t::T, t::T] for t in range(T)]), vs) <= 1e-8
+        finally:
+            ctx.close()
+    assert out[2][4] < p * T
+    assert abs(out[1][0] - out[2][0]) <= 1e-10 * abs(out[1][0])
+    assert rel(out[2][2], out[1][2]) <= 1e-9
+    assert rel(out[2][3], out[1][3]) <= 1e-9
+    Ys = [Y[r].astype(float) for r in range(min(R, 2))]
+    res, _, _ = orc.laplace(Ys, par, bin_ms, mode='exact', return_cov=False)
+    for r in range(len(Ys)):
+        assert rel(out[2][2][r], res['post_vsm'][r]) <= 1e-8
+        assert rel(out[2][3][r], res['post_vsmGP'][r]) <= 1e-8
