@@ -131,6 +131,9 @@ def main():
     ap.add_argument('--config', default='c3', choices=sorted(CONFIGS))
     ap.add_argument('--trials', type=int, default=0, help='override trials per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cd-method', default='newton', choices=['newton', 'TNC', 'BFGS', 'L-BFGS-B'],
+                    help="(C,d) M-step solver: 'newton' = device per-neuron Newton (exact minimiser of the reference's cost); "
+                         "'TNC' = the reference engine's default scipy driver on the same device cost/grad")
     ap.add_argument('--seed', type=int, default=12)
     args = ap.parse_args()
 
@@ -164,6 +167,7 @@ def main():
 
     params = init
     optim = None
+    cd_method = [args.cd_method]
     nll_hist, estep_ms, mstep_ms, facts, solves, pcgs = [], [], [], [], [], []
 
     def em_step():
@@ -171,7 +175,7 @@ def main():
         t0 = time.time()
         infRes, nll, optim = funs.inference.laplace(exp, params, prevOptimRes=optim)
         t1 = time.time()
-        params, _ = funs.learning.updateParams(params, infRes, exp, CdOptimMethod='TNC')
+        params, _ = funs.learning.updateParams(params, infRes, exp, CdOptimMethod=cd_method[0])
         t2 = time.time()
         nll_hist.append(float(nll))
         estep_ms.append((t1 - t0) * 1e3)
@@ -189,10 +193,21 @@ def main():
         em_step()
     barrier()
     elapsed = time.time() - t_begin
-    gemm_ms = sess.ctx.info('prof_gemm_ms')
-    gemm_flops = sess.ctx.info('prof_gemm_flops')
-    gemm_launches = sess.ctx.info('prof_gemm_launches')
+    prof = {}
+    for tag in ('gemm', 'cd', 'potrf', 'poisson', 'vsm', 'assemble', 'solve'):
+        prof[tag] = {'ms': sess.ctx.info('prof_%s_ms' % tag), 'flops': sess.ctx.info('prof_%s_flops' % tag),
+                     'launches': sess.ctx.info('prof_%s_launches' % tag)}
     sess.ctx.set_option('profile', 0)
+    gemm_ms, gemm_flops, gemm_launches = prof['gemm']['ms'], prof['gemm']['flops'], prof['gemm']['launches']
+    # one more (untimed) EM iteration with the reference engine's default (C,d) driver, for the record
+    tnc_ms = None
+    if world == 1 and args.cd_method != 'TNC':
+        cd_method[0] = 'TNC'
+        em_step()
+        tnc_ms = mstep_ms.pop()
+        estep_ms.pop(); nll_hist.pop(); facts.pop(); solves.pop(); pcgs.pop()
+        cd_method[0] = args.cd_method
+    sustained = sess.ctx.bench_mfma_peak(20000) if rank == 0 else None
     times = np.zeros(world)
     times[rank] = elapsed
     times = sess.allreduce(times)
@@ -211,17 +226,20 @@ def main():
         'unit': 'EM-iterations/s (1024-trial batches of 200 neurons x 10 latents x 500 bins)' if args.config == 'c3' else 'EM-iterations/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-        'config': {'workload': '%s: %d neurons, %d latents, %d bins, %d trials per GPU, Laplace batch EM (warm-started E-step + TNC/BFGS M-step)'
-                               % (args.config, q, p, T, R), 'trials_total': total_trials, 'parallelism': 'trial-sharded x%d' % world},
+        'config': {'workload': '%s: %d neurons, %d latents, %d bins, %d trials per GPU, Laplace batch EM (warm-started E-step; M-step: (C,d) by %s, tau by lockstep secant)'
+                               % (args.config, q, p, T, R, 'device per-neuron Newton' if args.cd_method == 'newton' else 'scipy ' + args.cd_method), 'trials_total': total_trials, 'parallelism': 'trial-sharded x%d' % world},
         'estep_ms_per_trial': float(np.mean(estep_ms[timed])) / R,
         'estep_ms': [round(x, 1) for x in estep_ms], 'mstep_ms': [round(x, 1) for x in mstep_ms],
         'factorizations_per_trial': [round(f / R, 2) for f in facts],
         'newton_solves_per_trial': [round(f / R, 2) for f in solves],
         'pcg_iterations_per_trial': [round(f / R, 2) for f in pcgs],
         'nll': nll_hist,
-        'roofline': {'bound': 'mfma', 'kernel': 'gemm_mfma_kernel<0> (FP64 16x16x4 MFMA; SYRK/TRSM/TRTRI/selected-inverse GEMMs)',
+        'mstep_ms_with_reference_default_TNC': tnc_ms,
+        'kernel_time_ms': {k: round(v['ms'], 1) for k, v in prof.items()},
+        'roofline': {'bound': 'mfma', 'kernel': 'gemm_mfma_kernel (FP64 16x16x4 MFMA: preconditioner applications, prior mat-vecs, factor/inverse/selected products)',
+                     'measured_sustained_mfma_tflops': sustained,
                      'achieved': achieved, 'peak': FP64_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / FP64_MATRIX_PEAK_TFLOPS,
-                     'traffic': pmc_traffic_per_launch('void pgpfa::gemm_mfma_kernel<0>') if args.config == 'c3' else None,
+                     'traffic': pmc_traffic_per_launch('void pgpfa::gemm_mfma_kernel') if args.config == 'c3' else None,
                      'traffic_unit': 'HBM bytes per launch (PMC, profiles/r01_c3_pmc_hbm_traffic.json)',
                      'algorithmic_flops_per_launch': gemm_flops / max(gemm_launches, 1.0), 'launches': gemm_launches, 'avg_launch_ms': gemm_ms / max(gemm_launches, 1.0),
                      'kernel_share_of_step': gemm_ms / (t_max * 1e3)},

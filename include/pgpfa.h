@@ -92,6 +92,13 @@ int pgpfa_set_posterior(pgpfa_ctx* ctx, int n, const int32_t* idx, const double*
  * gradient ('useDiag' prior of learning.py:445-534).  Multi-GPU: all-reduced over ranks. */
 int pgpfa_mstep_cd_costgrad(pgpfa_ctx* ctx, const double* vecCd, const double* prior_center,
                             double inv_s2, double* cost, double* grad /* [q*(p+1)] */);
+/* Device Newton solver for the same cost (separable over neurons: q convex problems of dimension p+1):
+ * one pass returns the per-neuron costs at vecCd, the Newton steps delta[(p+1)*q] (vecCd layout) and the
+ * Newton decrements dec[q]; pgpfa_mstep_cd_cost_per_neuron evaluates trial points for the line search. */
+int pgpfa_mstep_cd_newton_pass(pgpfa_ctx* ctx, const double* vecCd, const double* prior_center, double inv_s2,
+                               double* cost_n /* [q] */, double* delta /* [q*(p+1)] */, double* dec /* [q] */);
+int pgpfa_mstep_cd_cost_per_neuron(pgpfa_ctx* ctx, const double* vecCd, const double* prior_center, double inv_s2,
+                                   double* cost_n /* [q] */);
 /* makePrecomp (learning.py:145-173): PautoSum[p][T][T] over the same trials (all-reduced). */
 int pgpfa_mstep_precomp(pgpfa_ctx* ctx, double* num_trials);
 int pgpfa_get_pautosum(pgpfa_ctx* ctx, double* out /* [p][T][T] */);

@@ -622,6 +622,190 @@ __global__ __launch_bounds__(64 * CD_KY) void mstep_cd_kernel(CdArgs a) {
   }
 }
 
+// --------------------------------------------------------------------------------------------------
+// (C,d) M-step pass WITH per-neuron Hessians for the device Newton solver.  The cost of learning.py:20-49
+// is separable over neurons: q independent convex problems in theta_n = (c_n, d_n), dimension p+1.
+// With w = m_t + V_t c_n and yhat as above (per trial and bin, before the 1/R factor):
+//   grad_c += -(y m - yhat w) ; grad_d += -(y - yhat)
+//   H_cc  += yhat (w w^T + V_t) ; H_cd += yhat w ; H_dd += yhat
+// Same tiling as mstep_cd_kernel; per lane 1 + (p+1) + (p+1)(p+2)/2 accumulators.
+// part layout per block: [NH][q], NH = 1 + (p+1) + (p+1)(p+2)/2 : cost | grad (c.., d) | packed lower Hessian
+// --------------------------------------------------------------------------------------------------
+constexpr int CDH_KY = 4;      // 4 waves per block: the whole 512-register file per lane for the (p+1)(p+2)/2 Hessian accumulators
+template <int PW>
+__global__ __launch_bounds__(64 * CDH_KY) void mstep_cd_hess_kernel(CdArgs a) {
+  constexpr int TT = CdTile<PW>::TT;
+  constexpr int YS = TT + 4;
+  constexpr int D = PW + 1;
+  constexpr int NHW = D * (D + 1) / 2;
+  __shared__ __attribute__((aligned(16))) double Vt[TT][PW * PW];
+  __shared__ double Mt[PW][TT];
+  __shared__ uint8_t Yt[64 * YS];
+  const int lane = threadIdx.x;
+  const int ty = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  const int tid = ty * 64 + lane;
+  const int n0 = blockIdx.x * 64;
+  const int n = n0 + lane;
+  const bool live = n < a.q;
+  const int p = a.p, q = a.q, T = a.T;
+  double c[PW], gacc[D], hacc[NHW];
+#pragma unroll
+  for (int l = 0; l < PW; ++l) c[l] = (live && l < p) ? a.vec[(size_t)l * q + n] : 0.0;
+#pragma unroll
+  for (int l = 0; l < D; ++l) gacc[l] = 0.0;
+#pragma unroll
+  for (int l = 0; l < NHW; ++l) hacc[l] = 0.0;
+  const double dn = live ? a.vec[(size_t)p * q + n] : 0.0;
+  double cost = 0.0;
+
+  const int ntt = (T + TT - 1) / TT;
+  const int nitems = a.ntr * ntt;
+  for (int item = blockIdx.y; item < nitems; item += gridDim.y) {
+    const size_t r = a.trials[item / ntt];
+    const int t0 = (item % ntt) * TT;
+    const int tn = (T - t0 < TT) ? T - t0 : TT;
+    const double* mean = a.mean + r * p * T;
+    const double* vsm = a.vsm + (r * T + t0) * p * p;
+    const uint8_t* Y = a.Y + r * q * T;
+    __syncthreads();
+    for (int e = tid; e < TT * PW * PW; e += 64 * CDH_KY) {
+      const int t = e / (PW * PW), kl = e - t * (PW * PW);
+      const int k = kl / PW, l = kl - k * PW;
+      Vt[t][kl] = (t < tn && k < p && l < p) ? vsm[(size_t)t * p * p + k * p + l] : 0.0;
+    }
+    for (int e = tid; e < PW * TT; e += 64 * CDH_KY) {
+      const int k = e / TT, t = e - k * TT;
+      Mt[k][t] = (k < p && t < tn) ? mean[(size_t)k * T + t0 + t] : 0.0;
+    }
+    for (int e = tid; e < 64 * TT; e += 64 * CDH_KY) {
+      const int nn = e / TT, t = e - nn * TT;
+      Yt[nn * YS + t] = (n0 + nn < q && t < tn) ? Y[(size_t)(n0 + nn) * T + t0 + t] : 0;
+    }
+    __syncthreads();
+    for (int t = ty; t < tn; t += CDH_KY) {
+      double w[D];
+      double hh = dn, rho = 0.0;
+#pragma unroll
+      for (int k = 0; k < PW; ++k) {
+        double s = 0.0;
+#pragma unroll
+        for (int l = 0; l < PW; ++l) s += Vt[t][k * PW + l] * c[l];
+        rho += c[k] * s;
+        const double mk = Mt[k][t];
+        hh += c[k] * mk;
+        w[k] = mk + s;
+      }
+      w[PW] = 1.0;
+      const double yh = exp(hh + 0.5 * rho);
+      const double y = (double)Yt[lane * YS + t];
+      if (live) {
+        cost += y * hh - yh;
+#pragma unroll
+        for (int k = 0; k < PW; ++k) gacc[k] -= y * Mt[k][t] - yh * w[k];
+        gacc[PW] -= y - yh;
+        int idx = 0;
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+          const double ywi = yh * w[i];
+#pragma unroll
+          for (int j = 0; j <= i; ++j) {
+            double add = ywi * w[j];
+            if (i < PW) add += yh * Vt[t][i * PW + j];
+            hacc[idx] += add;
+            ++idx;
+          }
+        }
+      }
+    }
+  }
+  // fixed-order combine over the KY waves, one output row at a time
+  __shared__ double red[CDH_KY][64];
+  const int NH = 1 + (p + 1) + (p + 1) * (p + 2) / 2;
+  double* part = a.part + (size_t)blockIdx.y * NH * q;
+  auto emit = [&](double v, int row, bool keep) {
+    __syncthreads();
+    red[ty][lane] = v;
+    __syncthreads();
+    if (ty == (row & (CDH_KY - 1)) && live && keep) {
+      double s = 0.0;
+#pragma unroll
+      for (int w2 = 0; w2 < CDH_KY; ++w2) s += red[w2][lane];
+      part[(size_t)row * q + n] = s;
+    }
+  };
+  emit(cost, 0, true);
+#pragma unroll
+  for (int k = 0; k < D; ++k) {            // grad rows: c_0..c_{p-1}, d
+    const bool keep = (k < p) || (k == PW);
+    const int row = 1 + (k == PW ? p : k);
+    emit(gacc[k], keep ? row : 0, keep);
+  }
+  {
+    int idx = 0;
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = 0; j <= i; ++j) {
+        const bool keep = ((i < p) || (i == PW)) && ((j < p) || (j == PW));
+        const int ii = (i == PW) ? p : i, jj = (j == PW) ? p : j;       // index in the (p+1)-dim problem
+        const int row = 1 + (p + 1) + ii * (ii + 1) / 2 + jj;
+        emit(hacc[idx], keep ? row : 0, keep);
+        ++idx;
+      }
+  }
+}
+
+// per-neuron Newton step: solve H delta = -g (dimension p+1, Cholesky with a tiny ridge), one thread per neuron.
+// sums: [NH][q] as emitted above (not yet divided by R); prior: + inv_s2*(theta - center) on the gradient and
+// + inv_s2 on the Hessian diagonal.  Writes delta[(p+1)][q] (vecCd layout) and dec[q] = -g.delta.
+__global__ void cd_newton_step_kernel(const double* __restrict__ sums, int q, int p, double invR, const double* __restrict__ vec,
+                                      const double* __restrict__ center, double inv_s2, double* __restrict__ delta,
+                                      double* __restrict__ dec) {
+  extern __shared__ double sm[];
+  const int D = p + 1;
+  double* A = sm + (size_t)threadIdx.x * (D * D + 2 * D);
+  double* g = A + D * D;
+  double* x = g + D;
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= q) return;
+  for (int i = 0; i < D; ++i) {
+    double gi = sums[(size_t)(1 + i) * q + n] * invR;
+    if (center) gi += inv_s2 * (vec[(size_t)i * q + n] - center[(size_t)i * q + n]);
+    g[i] = gi;
+    for (int j = 0; j <= i; ++j) {
+      double h = sums[(size_t)(1 + D + i * (i + 1) / 2 + j) * q + n] * invR;
+      if (i == j) h += (center ? inv_s2 : 0.0);
+      A[i * D + j] = h;
+    }
+  }
+  // Cholesky (lower) with a relative ridge if a pivot is not positive
+  for (int j = 0; j < D; ++j) {
+    double dj = A[j * D + j];
+    for (int m = 0; m < j; ++m) dj -= A[j * D + m] * A[j * D + m];
+    if (!(dj > 1e-300)) dj = 1e-12 * fabs(A[j * D + j]) + 1e-300;
+    dj = sqrt(dj);
+    A[j * D + j] = dj;
+    for (int i = j + 1; i < D; ++i) {
+      double v = A[i * D + j];
+      for (int m = 0; m < j; ++m) v -= A[i * D + m] * A[j * D + m];
+      A[i * D + j] = v / dj;
+    }
+  }
+  for (int i = 0; i < D; ++i) {                      // forward: L y = -g
+    double v = -g[i];
+    for (int m = 0; m < i; ++m) v -= A[i * D + m] * x[m];
+    x[i] = v / A[i * D + i];
+  }
+  for (int i = D - 1; i >= 0; --i) {                 // backward: L^T delta = y
+    double v = x[i];
+    for (int m = i + 1; m < D; ++m) v -= A[m * D + i] * x[m];
+    x[i] = v / A[i * D + i];
+  }
+  double dd = 0.0;
+  for (int i = 0; i < D; ++i) { delta[(size_t)i * q + n] = x[i]; dd -= g[i] * x[i]; }
+  dec[n] = dd;
+}
+
 // out[e] = sum_b part[b][e]
 __global__ void reduce_parts_kernel(const double* __restrict__ part, int nb, int len, double* __restrict__ out) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1023,20 +1207,31 @@ __global__ void vsm_finish_kernel(double* __restrict__ vsm, const double* __rest
     }
 }
 
-// Ymix[t + b*ldo] = sum_k' G_t[k][k'] * Yt[(k',t) + b*ldy]   for latent k (lanes along t)
+// Ymix[t + b*ldo] = sum_k' G_t[k][k'] * Yt[(k',t) + b*ldy]   for latent k (lanes along t, 16 columns b per block)
 __global__ void mix_y_kernel(const double* __restrict__ Yt, long long sY, int ldy, const double* __restrict__ G, long long sG,
                              double* __restrict__ out, long long sO, int ldo, int T, int p, int k, int rpad, const int* __restrict__ slots) {
   const size_t slot = slots[blockIdx.z];
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int b = blockIdx.y;
+  const int b0 = blockIdx.y * 16;
   if (t >= ldo) return;
-  double s = 0.0;
-  if (t < T) {
-    const double* g = G + slot * sG + (size_t)t * p * p + (size_t)k * p;
-    const double* y = Yt + slot * sY + (size_t)b * ldy + t;
-    for (int kk = 0; kk < p; ++kk) s += g[kk] * y[(size_t)kk * T];
+  double* o = out + slot * sO + t;
+  if (t >= T) {
+    for (int b = b0; b < b0 + 16; ++b) o[(size_t)b * ldo] = 0.0;     // rows >= T are zero
+    return;
   }
-  out[slot * sO + (size_t)b * ldo + t] = s;               // rows >= T are zero
+  const double* g = G + slot * sG + (size_t)t * p * p + (size_t)k * p;
+  const double* y = Yt + slot * sY + t;
+  double acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = 0.0;
+  for (int kk = 0; kk < p; ++kk) {
+    const double gk = g[kk];
+    const double* yk = y + (size_t)kk * T;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] += gk * yk[(size_t)(b0 + j) * ldy];
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) o[(size_t)(b0 + j) * ldo] = acc[j];
   (void)rpad;
 }
 

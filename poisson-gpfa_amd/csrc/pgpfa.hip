@@ -82,6 +82,7 @@ struct pgpfa_ctx {
   double* vsmgp = nullptr;                       // [R][p][T][T]
   double* Pauto = nullptr;                       // [p][Tp][Tp]
   double *vec = nullptr, *cdpart = nullptr, *cdout = nullptr;
+  double *cdhpart = nullptr, *cdhout = nullptr, *cdcenter = nullptr, *cddelta = nullptr, *cddec = nullptr;   // Newton M-step
   int* last_trials = nullptr;                    // device list of the trials of the last E-step
   std::vector<int> last_trials_h;
   bool have_counts = false, have_params = false, have_post = false, have_precomp = false;
@@ -342,10 +343,11 @@ int ensure_workspace(pgpfa_ctx* c) {
   c->ws.nact = round_up(c->n, 64);
   const size_t ld = c->ld, nB = c->B;
   const size_t nBs = nB + 128;                    // slack: multi-RHS GEMM tiles read up to 127 slots past the end
-  CHK(dmalloc(c, &c->Xc, ld * nB)); CHK(dmalloc(c, &c->Xt, ld * nB));
-  CHK(dmalloc(c, &c->KX, ld * nB)); CHK(dmalloc(c, &c->KD, ld * nB));
-  CHK(dmalloc(c, &c->Gl, ld * nB)); CHK(dmalloc(c, &c->Glt, ld * nB));
-  CHK(dmalloc(c, &c->Gt, ld * nB)); CHK(dmalloc(c, &c->Dl, ld * nBs, true));
+  // all slot vectors: zero-initialised with slack (rows >= n stay zero; GEMM tiles over-read into finite data)
+  CHK(dmalloc(c, &c->Xc, ld * nBs, true)); CHK(dmalloc(c, &c->Xt, ld * nBs, true));
+  CHK(dmalloc(c, &c->KX, ld * nBs, true)); CHK(dmalloc(c, &c->KD, ld * nBs, true));
+  CHK(dmalloc(c, &c->Gl, ld * nBs, true)); CHK(dmalloc(c, &c->Glt, ld * nBs, true));
+  CHK(dmalloc(c, &c->Gt, ld * nBs, true)); CHK(dmalloc(c, &c->Dl, ld * nBs, true));
   CHK(dmalloc(c, &c->Rv, ld * nBs, true)); CHK(dmalloc(c, &c->Zv, ld * nBs, true));
   CHK(dmalloc(c, &c->Pv, ld * nBs, true)); CHK(dmalloc(c, &c->Qv, ld * nBs, true));
   CHK(alloc_cholws(c, &c->sws, 1, c->npad, true));
@@ -442,6 +444,17 @@ int prior_mv(pgpfa_ctx* c, const int* d_list, int nl, const double* in, double* 
                      in, (long long)c->ld, out, (long long)c->ld, d_list);
   HIPC(hipGetLastError());
   return 0;
+}
+
+// out[slot][k] = mat_k * in[slot][k] for ALL slots [0,nb) as one batched MFMA GEMM (batch = latents, N = slots)
+int prior_mv_all(pgpfa_ctx* c, int nb, const double* in, double* out, const double* mat = nullptr) {
+  GemmP g{};
+  g.A = mat ? mat : c->Kinv; g.sA = (long long)c->Tp * c->Tp; g.lda = c->Tp;
+  g.B = in; g.sB = c->T; g.ldb = c->ld;                 // latent k: rows k*T.. of every slot vector (K x N column-major)
+  g.C = out; g.sC = c->T; g.ldc = c->ld;
+  g.M = c->T; g.N = nb; g.K = round_up(c->T, 16); g.alpha = 1.0; g.beta = 0.0;
+  g.slots = nullptr; g.nbatch = c->p; g.mode = GEMM_FULL; g.kflags = 0;
+  return gemm(c, true, g);
 }
 
 int assemble(pgpfa_ctx* c, const int* d_list, int nl, double diag_scale = 1.0) {
@@ -590,6 +603,14 @@ int pgpfa_create(pgpfa_ctx** out, int device, int q, int p, int T, int R, double
   rc |= dmalloc(c, &c->cdpart, (size_t)1024 * (p + 2) * q);
   rc |= dmalloc(c, &c->cdout, (size_t)(p + 2) * q + 8);
   rc |= dmalloc(c, &c->last_trials, R);
+  {
+    const size_t NH = 1 + (size_t)(p + 1) + (size_t)(p + 1) * (p + 2) / 2;
+    rc |= dmalloc(c, &c->cdhpart, (size_t)128 * NH * q);
+    rc |= dmalloc(c, &c->cdhout, NH * q + 8);
+    rc |= dmalloc(c, &c->cdcenter, (size_t)q * (p + 1));
+    rc |= dmalloc(c, &c->cddelta, (size_t)q * (p + 1));
+    rc |= dmalloc(c, &c->cddec, q);
+  }
   rc |= alloc_cholws(c, &c->kws, p, c->Tp, true);
   c->kws.nact = round_up(T, 64);
   rc |= dmalloc(c, &c->tK, slab * p); rc |= dmalloc(c, &c->tM, slab * p); rc |= dmalloc(c, &c->tA1, slab * p); rc |= dmalloc(c, &c->tA2, slab * p);
@@ -953,7 +974,7 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp) {
     const size_t off_mix = (size_t)c->ld * rpad;
     const size_t off_stage = off_mix + (size_t)Tp * rpad;
     for (int k = 0; k < p; ++k) {
-      hipLaunchKernelGGL(mix_y_kernel, dim3((Tp + 63) / 64, rpad, nb), dim3(64), 0, c->st, lw.H, lw.sH, c->ld, c->Gbin, sW, lw.H + off_mix, lw.sH, Tp,
+      hipLaunchKernelGGL(mix_y_kernel, dim3((Tp + 63) / 64, rpad / 16, nb), dim3(64), 0, c->st, lw.H, lw.sH, c->ld, c->Gbin, sW, lw.H + off_mix, lw.sH, Tp,
                          T, p, k, rpad, c->ident);
       GemmP g{};
       g.A = lw.H + off_mix; g.sA = lw.sH; g.lda = Tp;
@@ -1076,7 +1097,7 @@ int pgpfa_estep_laplace(pgpfa_ctx* c, int n, const int32_t* idx, int warm_start,
         CHK(shared_solve(c, nb, c->Rv, c->Zv));
         hipLaunchKernelGGL(pcg_update_p_kernel, dim3(na), dim3(256), 0, c->st, c->Rv, c->Zv, c->Pv, ld, nvec, c->list_a, c->sc_rz, c->sc_rr0, 1);
         for (int it = 0; it < inner; ++it) {
-          CHK(prior_mv(c, c->list_a, na, c->Pv, c->Qv));
+          CHK(prior_mv_all(c, nb, c->Pv, c->Qv));
           hipLaunchKernelGGL(pcg_hessvec_dot_kernel, dim3(na), dim3(256), 0, c->st, c->W, (long long)T * p * p, c->Pv, c->Qv, ld, T, p, nvec,
                              c->list_a, c->sc_pq);
           hipLaunchKernelGGL(pcg_update_xr_kernel, dim3(na), dim3(256), 0, c->st, c->Dl, c->Rv, c->Pv, c->Qv, ld, nvec, c->list_a, c->sc_rz, c->sc_pq);
@@ -1085,7 +1106,7 @@ int pgpfa_estep_laplace(pgpfa_ctx* c, int n, const int32_t* idx, int warm_start,
         }
         n_pcg += (double)na * inner;
         hipLaunchKernelGGL(step_stats_kernel, dim3(na), dim3(256), 0, c->st, c->Gt, c->Dl, ld, nvec, c->list_a, c->sc_dec, c->sc_smax);
-        CHK(prior_mv(c, c->list_a, na, c->Dl, c->KD));
+        CHK(prior_mv_all(c, nb, c->Dl, c->KD));
         hipLaunchKernelGGL(dots3_kernel, dim3(na), dim3(256), 0, c->st, c->Xc, ld, c->KX, ld, c->Dl, ld, c->KD, ld, nvec, c->list_a, c->sc_qxx,
                            c->sc_qdx, c->sc_qdd);
         HIPC(hipGetLastError());
@@ -1354,6 +1375,80 @@ int pgpfa_mstep_cd_costgrad(pgpfa_ctx* c, const double* vecCd, const double* pri
     cst += 0.5 * inv_s2 * s;
   }
   *cost = cst;
+  return 0;
+}
+
+
+// One pass of the device Newton solver for the (C,d) M-step: cost, gradient and per-neuron Hessians at vecCd
+// (mstep_cd_hess_kernel), all-reduced over ranks, then the q independent (p+1)-dim Newton steps on device.
+int pgpfa_mstep_cd_newton_pass(pgpfa_ctx* c, const double* vecCd, const double* prior_center, double inv_s2, double* cost_n,
+                               double* delta, double* dec) {
+  if (!c || !vecCd || !cost_n || !delta || !dec) return fail("null argument");
+  if (!c->have_counts) return fail("spike counts have not been uploaded");
+  if (!c->have_post) return fail("no E-step result resident: run an E-step or pgpfa_set_posterior first");
+  if (c->p > 12) return fail("device Newton M-step supports up to 12 latents (p=%d): use a scipy method", c->p);
+  HIPC(hipSetDevice(c->device));
+  const int q = c->q, p = c->p, T = c->T, D = p + 1;
+  const int NH = 1 + D + D * (D + 1) / 2;
+  CHK(upload(c, c->vec, vecCd, (size_t)q * D));
+  if (prior_center) CHK(upload(c, c->cdcenter, prior_center, (size_t)q * D));
+  CdArgs a{};
+  a.Y = c->Y; a.mean = c->Xmode; a.vsm = c->vsm; a.vec = c->vec;
+  a.trials = c->last_trials; a.ntr = (int)c->last_trials_h.size();
+  a.part = c->cdhpart; a.q = q; a.p = p; a.T = T;
+  const int nby = std::max(1, std::min(a.ntr * 4, 128));
+  prof_begin(c, TAG_CD, (double)a.ntr * q * T * (3.0 * p * p + 12.0 * p));
+  dispatch_pw(p, [&](auto pw) {
+    constexpr int PW = decltype(pw)::value;
+    if constexpr (PW <= 12)
+      hipLaunchKernelGGL(mstep_cd_hess_kernel<PW>, dim3((q + 63) / 64, nby), dim3(64, CDH_KY), 0, c->st, a);
+  });
+  prof_end(c);
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3((NH * q + 255) / 256), dim3(256), 0, c->st, c->cdhpart, nby, NH * q, c->cdhout);
+  HIPC(hipGetLastError());
+  const double cnt = (double)a.ntr;
+  HIPC(hipMemcpyAsync(c->cdhout + (size_t)NH * q, &cnt, sizeof(double), hipMemcpyHostToDevice, c->st));
+  CHK(allreduce_dev(c, c->cdhout, (size_t)NH * q + 1));
+  double Rtot = 0.0;
+  CHK(download(c, &Rtot, c->cdhout + (size_t)NH * q, 1));
+  c->n_trials_global = Rtot;
+  const int th = 32;
+  hipLaunchKernelGGL(cd_newton_step_kernel, dim3((q + th - 1) / th), dim3(th), (size_t)th * (D * D + 2 * D) * sizeof(double), c->st, c->cdhout, q, p,
+                     1.0 / Rtot, c->vec, prior_center ? c->cdcenter : nullptr, inv_s2, c->cddelta, c->cddec);
+  HIPC(hipGetLastError());
+  CHK(ensure_hbuf(c, (size_t)q));
+  CHK(download(c, c->hbuf, c->cdhout, q));                 // row 0: sum (y*hh - yhat) per neuron
+  CHK(download(c, delta, c->cddelta, (size_t)q * D));
+  CHK(download(c, dec, c->cddec, q));
+  for (int n = 0; n < q; ++n) {
+    double cn = -c->hbuf[n] / Rtot;
+    if (prior_center) {
+      double s2 = 0.0;
+      for (int i = 0; i < D; ++i) { const double dv = vecCd[(size_t)i * q + n] - prior_center[(size_t)i * q + n]; s2 += dv * dv; }
+      cn += 0.5 * inv_s2 * s2;
+    }
+    cost_n[n] = cn;
+  }
+  return 0;
+}
+
+// per-neuron values of the (C,d) cost (for the Newton line search); same kernel as pgpfa_mstep_cd_costgrad
+int pgpfa_mstep_cd_cost_per_neuron(pgpfa_ctx* c, const double* vecCd, const double* prior_center, double inv_s2, double* cost_n) {
+  if (!c || !vecCd || !cost_n) return fail("null argument");
+  std::vector<double> grad((size_t)c->q * (c->p + 1));
+  double total = 0.0;
+  CHK(pgpfa_mstep_cd_costgrad(c, vecCd, nullptr, 0.0, &total, grad.data()));
+  const int q = c->q, p = c->p;
+  const double Rtot = c->n_trials_global;
+  for (int n = 0; n < q; ++n) {
+    double cn = -c->hbuf[(size_t)(p + 1) * q + n] / Rtot;   // hbuf still holds the reduced sums of that call
+    if (prior_center) {
+      double s2 = 0.0;
+      for (int i = 0; i <= p; ++i) { const double dv = vecCd[(size_t)i * q + n] - prior_center[(size_t)i * q + n]; s2 += dv * dv; }
+      cn += 0.5 * inv_s2 * s2;
+    }
+    cost_n[n] = cn;
+  }
   return 0;
 }
 

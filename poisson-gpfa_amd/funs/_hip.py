@@ -39,6 +39,8 @@ _SIGNATURES = {
     'pgpfa_get_post_cov': [ct.c_void_p, ct.c_int, c_double_p],
     'pgpfa_set_posterior': [ct.c_void_p, ct.c_int, c_int32_p, c_double_p, c_double_p, c_double_p],
     'pgpfa_mstep_cd_costgrad': [ct.c_void_p, c_double_p, c_double_p, ct.c_double, c_double_p, c_double_p],
+    'pgpfa_mstep_cd_newton_pass': [ct.c_void_p, c_double_p, c_double_p, ct.c_double, c_double_p, c_double_p, c_double_p],
+    'pgpfa_mstep_cd_cost_per_neuron': [ct.c_void_p, c_double_p, c_double_p, ct.c_double, c_double_p],
     'pgpfa_mstep_precomp': [ct.c_void_p, c_double_p],
     'pgpfa_get_pautosum': [ct.c_void_p, c_double_p],
     'pgpfa_mstep_tau_costgrad': [ct.c_void_p, ct.c_int, ct.c_double, c_double_p, c_double_p],
@@ -260,6 +262,22 @@ class Context:
         check(self.lib.pgpfa_mstep_cd_costgrad(self.h, dptr(vec), None if pc is None else dptr(pc), float(inv_s2),
                                                ct.byref(cost), dptr(grad)))
         return cost.value, grad
+
+    def mstep_cd_newton_pass(self, vec, prior_center=None, inv_s2=0.0):
+        vec = as_f64(vec).reshape(-1)
+        pc = None if prior_center is None else as_f64(prior_center).reshape(-1)
+        cost_n, dec = np.empty(self.q), np.empty(self.q)
+        delta = np.empty(self.q * (self.p + 1))
+        check(self.lib.pgpfa_mstep_cd_newton_pass(self.h, dptr(vec), None if pc is None else dptr(pc), float(inv_s2),
+                                                  dptr(cost_n), dptr(delta), dptr(dec)))
+        return cost_n, delta, dec
+
+    def mstep_cd_cost_per_neuron(self, vec, prior_center=None, inv_s2=0.0):
+        vec = as_f64(vec).reshape(-1)
+        pc = None if prior_center is None else as_f64(prior_center).reshape(-1)
+        cost_n = np.empty(self.q)
+        check(self.lib.pgpfa_mstep_cd_cost_per_neuron(self.h, dptr(vec), None if pc is None else dptr(pc), float(inv_s2), dptr(cost_n)))
+        return cost_n
 
     def mstep_precomp(self):
         n = ct.c_double(0.0)

@@ -75,10 +75,60 @@ def MStepObservationCost_grad(vecCd, xdim, ydim, experiment, infRes):
     return sess.ctx.mstep_cd_costgrad(vecCd)[1]
 
 
+def _newton_cd(sess, x0, prior_center=None, inv_s2=0.0, max_iter=50, xtol=1e-10, verbose=False):
+    """Exact minimiser of the (C,d) cost by q independent damped Newton iterations (the cost is separable over
+    neurons and convex in each (c_n, d_n)); every iteration is one device pass that returns per-neuron cost,
+    Newton step and decrement at the current point.  Each neuron backtracks on its own cost."""
+    ctx = sess.ctx
+    q, D = sess.q, sess.p + 1
+    theta = np.array(x0, dtype=np.float64).reshape(D, q)
+    cost, delta, dec = ctx.mstep_cd_newton_pass(theta.reshape(-1), prior_center, inv_s2)
+    n_pass = 1
+    for it in range(max_iter):
+        step = delta.reshape(D, q)
+        alpha = np.ones(q)
+        trial = theta + step
+        c_try, d_try, dec_try = ctx.mstep_cd_newton_pass(trial.reshape(-1), prior_center, inv_s2)
+        n_pass += 1
+        slack = 1e-13 * (1.0 + np.abs(cost))
+        ok = np.isfinite(c_try) & (c_try <= cost - 1e-4 * alpha * dec + slack)
+        ls = 0
+        while not np.all(ok) and ls < 40:
+            alpha = np.where(ok, alpha, 0.5 * alpha)
+            trial = theta + alpha[None, :] * step
+            c_bt = ctx.mstep_cd_cost_per_neuron(trial.reshape(-1), prior_center, inv_s2)
+            ok_new = np.isfinite(c_bt) & (c_bt <= cost - 1e-4 * alpha * dec + slack)
+            c_try = np.where(ok, c_try, c_bt)
+            newly = ok_new & ~ok
+            ok = ok | ok_new
+            ls += 1
+            if np.any(newly) and np.all(ok):
+                c_try, d_try, dec_try = ctx.mstep_cd_newton_pass(trial.reshape(-1), prior_center, inv_s2)   # step data at the accepted point
+                n_pass += 1
+        if not np.all(ok):                      # neurons whose search failed keep their current value
+            alpha = np.where(ok, alpha, 0.0)
+            trial = theta + alpha[None, :] * step
+            c_try, d_try, dec_try = ctx.mstep_cd_newton_pass(trial.reshape(-1), prior_center, inv_s2)
+            n_pass += 1
+        moved = np.max(np.abs(alpha[None, :] * step))
+        theta, cost, delta, dec = trial, c_try, d_try, dec_try
+        if verbose:
+            print('  newton (C,d) it %d: cost %.10g, max step %.3e' % (it + 1, cost.sum(), moved))
+        if moved < xtol:
+            break
+    return theta.reshape(-1), float(np.sum(cost)), n_pass
+
+
 def learnLTparams(oldParams, infRes, experiment, CdOptimMethod, CdMaxIter=None, verbose=False):
-    """reference learning.py:93-141: same scipy call (method, options) on device-evaluated cost/grad."""
+    """reference learning.py:93-141: same scipy call (method, options) on device-evaluated cost/grad.
+    CdOptimMethod='newton' (an addition) runs the device Newton solver instead: the exact minimiser of the
+    same cost, ~6 passes over the data instead of TNC's ~130 evaluations."""
     ydim, xdim = np.shape(oldParams['C'])
     sess = _resident_session(infRes, experiment, xdim)
+    if CdOptimMethod == 'newton':
+        x, fun, _ = _newton_cd(sess, util.CdtoVecCd(oldParams['C'], oldParams['d']), verbose=verbose)
+        newC, newd = util.vecCdtoCd(x, xdim, ydim)
+        return newC, newd, fun
     cache = _CostGradCache(lambda v: sess.ctx.mstep_cd_costgrad(v))
     xinit = util.CdtoVecCd(oldParams['C'], oldParams['d'])
     resCd = op.minimize(fun=cache.fun, x0=xinit, jac=cache.jac, method=CdOptimMethod,
@@ -100,6 +150,10 @@ def learnLTparamsWithPrior(oldParams, infRes, experiment, CdOptimMethod, regular
     old = util.CdtoVecCd(oldParams['C'], oldParams['d'])
     inv_s2 = 1.0 / regularizer_stepsize_Cd ** 2
     invPriorCov = -np.diag(np.ones(xdim * ydim + ydim)) / (regularizer_stepsize_Cd ** 2)       # learning.py:580-581
+    if CdOptimMethod == 'newton':
+        x, fun, _ = _newton_cd(sess, old, prior_center=old, inv_s2=inv_s2, verbose=verbose)
+        newC, newd = util.vecCdtoCd(x, xdim, ydim)
+        return newC, newd, fun, invPriorCov
     cache = _CostGradCache(lambda v: sess.ctx.mstep_cd_costgrad(v, old, inv_s2))
     kw = dict(fun=cache.fun, x0=old, jac=cache.jac, method=CdOptimMethod, options={'disp': verbose, 'gtol': 1e-10})
     if CdOptimMethod == 'L-BFGS-B':

@@ -338,3 +338,31 @@ def test_lowrank_covariance_engine_matches_dense(c1, size):
     for r in range(len(Ys)):
         assert rel(out[2][2][r], res['post_vsm'][r]) <= 1e-8
         assert rel(out[2][3][r], res['post_vsmGP'][r]) <= 1e-8
+
+
+def test_newton_mstep_reaches_the_tight_optimum(funs_mod, c1, c1_experiment):
+    """CdOptimMethod='newton' (device per-neuron Newton) lands on the tightly converged optimum of the same cost."""
+    g = load_golden('c1_mstep.npz')
+    lap = load_golden('c1_laplace.npz')
+    # on the reference's own E-step output: compare with the golden tight optimum (L-BFGS-B + BFGS to |grad| ~ 1e-7)
+    res = {'post_mean': list(lap['post_mean']), 'post_vsm': list(lap['post_vsm']),
+           'post_vsmGP': [np.zeros((100, 100, 3))] * 20}
+    C, d, cost = funs_mod.learning.learnLTparams(c1['init'], res, c1_experiment, 'newton')
+    v = orc.cd_to_vec(C, d)
+    assert np.max(np.abs(v - g['tight_vec'])) <= 2e-6
+    assert cost <= float(g['tight_cost']) + 1e-12 * abs(float(g['tight_cost']))
+    grad = orc.mstep_cd_grad(v, c1['Ys'], res['post_mean'], res['post_vsm'], 3, 30)
+    assert np.max(np.abs(grad)) <= 1e-9
+    # with the 'useDiag' prior of the online mode
+    C2, d2, cost2, _ = funs_mod.learning.learnLTparamsWithPrior(c1['init'], res, c1_experiment, 'newton', 0.7, None)
+    v2 = orc.cd_to_vec(C2, d2)
+    old = orc.cd_to_vec(c1['init_C'], c1['init_d'])
+    inv_prior = -np.eye(old.size) / 0.7 ** 2
+    gp = orc.mstep_cd_grad_prior(v2, old, inv_prior, c1['Ys'], res['post_mean'], res['post_vsm'], 3, 30)
+    assert np.max(np.abs(gp)) <= 1e-9
+    # full EM with the Newton M-step stays on the exactly-converged path (tolerances of the TNC comparison)
+    ex = load_golden('c1_em_exact.npz')
+    init = {k: v.copy() for k, v in c1['init'].items()}
+    fit = funs_mod.engine.PPGPFAfit(c1_experiment, initParams=init, EMmode='Batch', maxEMiter=3, CdOptimMethod='newton', quiet=True)
+    assert np.max(np.abs(np.asarray(fit.posteriorLikelihood) - ex['nll'][:3])) <= 1e-3
+    assert rel(fit.paramSeq[3]['C'], ex['seq_C'][3]) <= 2e-3
