@@ -106,6 +106,8 @@ struct pgpfa_ctx {
   int rtot = 0, rpad = 0;
   int cov_mode = 0;                               // 0 auto, 1 dense, 2 low-rank
   double lr_tol = 1e-13;
+  bool plan_lowrank = false;                      // current workspace plan
+  size_t slab_elems = 0, ws_mark = 0;
   bool mt_dirty = false;                          // low-rank use scribbled over the Mt slabs' zero triangle
   bool last_cov_lowrank = false;
   bool shared_pcg = true;
@@ -295,10 +297,10 @@ int inverse_t(pgpfa_ctx* c, const CholWS& w, const int* slots, int nb) {
 }
 
 // allocate a factor workspace: nslots slabs of ld x ld (+ Mt), diagonal inverses, scratch panel
-int alloc_cholws(pgpfa_ctx* c, CholWS* w, int nslots, int npad, bool with_mt) {
+int alloc_cholws(pgpfa_ctx* c, CholWS* w, int nslots, int npad, bool with_mt, size_t slab_elems = 0) {
   w->npad = npad;
   w->ld = npad;
-  const size_t slab = (size_t)npad * npad;
+  const size_t slab = slab_elems ? slab_elems : (size_t)npad * npad;
   const size_t slack = (size_t)256 * npad;
   w->sH = slab; w->sM = slab; w->sD = (size_t)npad * NB; w->sP = (size_t)npad * NB;
   CHK(dmalloc(c, &w->H, slab * nslots + slack));
@@ -309,24 +311,68 @@ int alloc_cholws(pgpfa_ctx* c, CholWS* w, int nslots, int npad, bool with_mt) {
   return 0;
 }
 
+// per-slot scratch (doubles) the low-rank covariance engine needs inside a factor slab
+size_t lowrank_slab_elems(const pgpfa_ctx* c) {
+  const size_t need = (size_t)c->ld * c->rpad + (size_t)c->Tp * c->rpad + (size_t)c->T * c->T;
+  return std::max(need, (size_t)c->rpad * c->rpad);
+}
+
+// engine choice: the low-rank form pays when r << n (long timescales); the dense form is the general one
+bool lowrank_pays(const pgpfa_ctx* c) {
+  const double n = c->n, r = c->rpad, T = c->T, p = c->p;
+  if (c->rpad < NB || c->rpad * 2 > c->npad) return false;
+  if (lowrank_slab_elems(c) > (size_t)c->ld * c->ld) return false;
+  const double dense = 0.72 * n * n * n;
+  const double lr = 6.0 * T * r * r + 0.7 * r * r * r + p * T * T * r;
+  return lr < 0.5 * dense;
+}
+
+bool want_lowrank(const pgpfa_ctx* c) { return c->cov_mode == 2 ? (c->rpad >= NB && lowrank_slab_elems(c) <= (size_t)c->ld * c->ld) : (c->cov_mode == 0 && lowrank_pays(c)); }
+
 size_t ld_bytes(const pgpfa_ctx* c) { return (size_t)c->ld * c->ld * sizeof(double); }
 
-size_t per_slot_bytes(const pgpfa_ctx* c) {
+size_t per_slot_bytes(const pgpfa_ctx* c, size_t slab_elems) {
   const size_t ld = c->ld;
-  size_t dbl = 2 * ld * ld + 2 * ld * NB + 12 * ld + 3 * (size_t)c->T * c->p * c->p + ((c->T + 63) / 64) + 32;
+  size_t dbl = 2 * slab_elems + 2 * ld * NB + 12 * ld + 3 * (size_t)c->T * c->p * c->p + ((c->T + 63) / 64) + 32;
   return dbl * sizeof(double);
 }
 
-int ensure_workspace(pgpfa_ctx* c) {
-  if (c->B > 0) return 0;
+// free every workspace allocation (everything allocated after the persistent state)
+int free_workspace(pgpfa_ctx* c) {
+  if (c->B == 0) return 0;
+  HIPC(hipStreamSynchronize(c->st));
+  while (c->allocs.size() > c->ws_mark) { hipFree(c->allocs.back()); c->allocs.pop_back(); }
+  c->B = 0;
+  c->lamd = c->dgrad = c->dpart = nullptr;
+  c->commbuf = nullptr; c->commbuf_len = 0;
+  c->mt_dirty = false;
+  return 0;
+}
+
+// Workspace plan.  "dense": factor slabs of ld x ld per slot (the general engine, per-trial fallback Newton, post_cov,
+// dual variational).  "low-rank": slabs only as large as the r x r systems and their products need, so that ~7x more
+// trials fit in one chunk.  Switching plans reallocates the workspace (persistent state is untouched).
+int ensure_workspace(pgpfa_ctx* c, bool plan_lr) {
+  const size_t slab = plan_lr ? (lowrank_slab_elems(c) + 1023) / 1024 * 1024 : (size_t)c->ld * c->ld;
+  if (c->B > 0 && c->plan_lowrank == plan_lr && slab <= c->slab_elems) return 0;
+  CHK(free_workspace(c));
+  c->ws_mark = c->allocs.size();
+  c->plan_lowrank = plan_lr;
   size_t free_b = 0, total_b = 0;
   HIPC(hipMemGetInfo(&free_b, &total_b));
-  const size_t per = per_slot_bytes(c);
   size_t budget = (size_t)(0.85 * (double)free_b);
   {
     const size_t shared = (3 * ld_bytes(c) + 1024 * (size_t)c->ld * sizeof(double) * 4);
     budget = budget > shared ? budget - shared : 0;
   }
+  // low-rank plan: head-room for rank growth between EM iterations (a re-plan costs seconds) - twice the need
+  // if every trial still fits in one chunk, 25 % otherwise
+  c->slab_elems = slab;
+  if (plan_lr) {
+    const size_t roomy = std::min((size_t)c->ld * c->ld, 2 * slab);
+    c->slab_elems = (budget / per_slot_bytes(c, roomy) >= (size_t)c->R) ? roomy : std::min((size_t)c->ld * c->ld, slab + slab / 4);
+  }
+  const size_t per = per_slot_bytes(c, c->slab_elems);
   long long B = (long long)(budget / per);
   if (c->chunk_opt > 0) B = std::min<long long>(B, c->chunk_opt);
   if (B >= c->R) {
@@ -339,7 +385,7 @@ int ensure_workspace(pgpfa_ctx* c) {
   }
   if (B < 1) return fail("not enough device memory for one trial slab (%zu bytes needed, %zu free)", per, free_b);
   c->B = (int)B;
-  CHK(alloc_cholws(c, &c->ws, c->B, c->npad, true));
+  CHK(alloc_cholws(c, &c->ws, c->B, c->npad, true, c->slab_elems));
   c->ws.nact = round_up(c->n, 64);
   const size_t ld = c->ld, nB = c->B;
   const size_t nBs = nB + 128;                    // slack: multi-RHS GEMM tiles read up to 127 slots past the end
@@ -370,6 +416,7 @@ int ensure_workspace(pgpfa_ctx* c) {
   HIPC(hipMemcpyAsync(c->ident, id.data(), sizeof(int) * c->B, hipMemcpyHostToDevice, c->st));
   HIPC(hipStreamSynchronize(c->st));
   c->info["chunk_trials"] = c->B;
+  c->info["plan_lowrank"] = c->plan_lowrank ? 1.0 : 0.0;
   return 0;
 }
 
@@ -763,7 +810,15 @@ static int ready(pgpfa_ctx* c) {
   if (!c->have_counts) return fail("spike counts have not been uploaded");
   if (!c->have_params) return fail("set_params has not been called");
   HIPC(hipSetDevice(c->device));
-  return ensure_workspace(c);
+  return ensure_workspace(c, false);
+}
+
+static int ready_estep(pgpfa_ctx* c, bool allow_lowrank) {
+  if (!c) return fail("null context");
+  if (!c->have_counts) return fail("spike counts have not been uploaded");
+  if (!c->have_params) return fail("set_params has not been called");
+  HIPC(hipSetDevice(c->device));
+  return ensure_workspace(c, allow_lowrank && want_lowrank(c));
 }
 
 // load X[nb][p][T] host points into the chunk slots and bind slot -> trial
@@ -776,7 +831,7 @@ static int load_points(pgpfa_ctx* c, const std::vector<int>& trials, int c0, int
 }
 
 int pgpfa_laplace_eval(pgpfa_ctx* c, int n, const int32_t* idx, const double* X, double* f, double* grad) {
-  CHK(ready(c));
+  CHK(ready_estep(c, c->B > 0 ? c->plan_lowrank : true));   // vectors only: any workspace plan serves
   if (!X || !f) return fail("null argument");
   Trials tr;
   CHK(resolve_trials(c, n, idx, &tr));
@@ -991,27 +1046,16 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp) {
   return 0;
 }
 
-// engine choice: the low-rank form pays when r << n (long timescales); the dense form is the general one
-static bool lowrank_pays(const pgpfa_ctx* c) {
-  const double n = c->n, r = c->rpad, T = c->T, p = c->p;
-  if (c->rpad * 2 > c->npad) return false;
-  const size_t need = (size_t)c->ld * c->rpad + (size_t)c->Tp * c->rpad + (size_t)T * T;
-  if (need > (size_t)c->ld * c->ld) return false;
-  const double dense = 0.72 * n * n * n;
-  const double lr = 6.0 * T * r * r + 0.7 * r * r * r + p * T * T * r;
-  return lr < 0.5 * dense;
-}
-
 static int posterior_blocks(pgpfa_ctx* c, int nb, double diag_scale, bool want_vsmgp) {
-  const bool lr = diag_scale == 1.0 && (c->cov_mode == 2 || (c->cov_mode == 0 && lowrank_pays(c)));
-  if (lr) return posterior_blocks_lowrank(c, nb, want_vsmgp);
+  if (c->plan_lowrank) {
+    if (diag_scale != 1.0) return fail("internal: jittered covariance requested under the low-rank workspace plan");
+    return posterior_blocks_lowrank(c, nb, want_vsmgp);
+  }
   return posterior_blocks_dense(c, nb, diag_scale, want_vsmgp);
 }
 
-int pgpfa_estep_laplace(pgpfa_ctx* c, int n, const int32_t* idx, int warm_start, double* obj_sum, int32_t* iters, int32_t* status) {
-  CHK(ready(c));
-  Trials tr;
-  CHK(resolve_trials(c, n, idx, &tr));
+static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow_lr, double* obj_sum, int32_t* iters, int32_t* status) {
+  CHK(ready_estep(c, allow_lr));
   const int N = (int)tr.v.size();
   const auto t_begin = std::chrono::steady_clock::now();
   const int nvec = c->n, p = c->p, T = c->T;
@@ -1084,7 +1128,7 @@ int pgpfa_estep_laplace(pgpfa_ctx* c, int n, const int32_t* idx, int warm_start,
     // ---- phase 1: inexact Newton, all slots in lockstep, PCG on H_r delta = -g preconditioned by ONE shared factor
     // (the mean-trial Hessian: cond(P^-1 H_r) stays below ~4, measured).  Every preconditioner application is two
     // multi-RHS triangular sweeps run as GEMMs over the slots; no per-trial factorisation in this phase.
-    if (c->shared_pcg && nb >= c->shared_min) {
+    if (c->shared_pcg && (nb >= c->shared_min || c->plan_lowrank)) {
       CHK(shared_factor(c, nb));
       n_shared += 1;
       int inner = c->pcg_inner;
@@ -1155,6 +1199,11 @@ int pgpfa_estep_laplace(pgpfa_ctx* c, int n, const int32_t* idx, int warm_start,
     // factor reuse.  A slot factors H at its current point only when it has no factor yet or its chord steps (steps
     // with the stale factor, still descent directions since that factor is SPD) contract too slowly; otherwise the
     // resident factor is reused: one HBM-bound solve instead of n^3/3 flops.
+    if (c->plan_lowrank && !active.empty()) {
+      // the per-trial fallback needs full-size factor slabs: leave these trials to the dense retry pass of the caller
+      for (int s : active) stat[s] = 4;
+      active.clear();
+    }
     std::vector<char> has_factor(nb, 0), fresh(nb, 0), refactor(nb, 0);
     std::vector<double> prev_step(nb, 0.0);
     std::vector<int> n_chord(nb, 0);
@@ -1235,7 +1284,6 @@ int pgpfa_estep_laplace(pgpfa_ctx* c, int n, const int32_t* idx, int warm_start,
       if (status) status[c0 + s] = stat[s];
     }
   }
-  CHK(remember_trials(c, tr.v));
   if (obj_sum) *obj_sum = total;
   const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   c->info["last_estep_ms"] = ms;
@@ -1245,6 +1293,48 @@ int pgpfa_estep_laplace(pgpfa_ctx* c, int n, const int32_t* idx, int warm_start,
   c->info["last_shared_factorizations"] = n_shared;
   c->info["last_cov_lowrank"] = c->last_cov_lowrank ? 1.0 : 0.0;
   c->info["last_newton_max_iter"] = max_it_seen;
+  return 0;
+}
+
+int pgpfa_estep_laplace(pgpfa_ctx* c, int n, const int32_t* idx, int warm_start, double* obj_sum, int32_t* iters, int32_t* status) {
+  if (!c) return fail("null context");
+  Trials tr;
+  CHK(resolve_trials(c, n, idx, &tr));
+  const int N = (int)tr.v.size();
+  std::vector<int32_t> it1(N), st1(N);
+  double obj = 0.0;
+  CHK(estep_impl(c, tr, warm_start, true, &obj, it1.data(), st1.data()));
+  // trials the low-rank plan could not finish (its shared-preconditioner Newton gave up on them and the per-trial
+  // fallback needs full-size slabs) are redone under the dense plan, warm-started from where they stopped
+  Trials retry;
+  std::vector<int> pos;
+  for (int i = 0; i < N; ++i)
+    if (st1[i] == 4) { retry.v.push_back(tr.v[i]); pos.push_back(i); }
+  if (!retry.v.empty()) {
+    // their partial objective is replaced: recompute the total from scratch for them
+    std::vector<int32_t> it2(retry.v.size()), st2(retry.v.size());
+    double obj_bad = 0.0, obj_redo = 0.0;
+    {
+      // objective of the unfinished trials as counted in the first pass
+      std::vector<double> X((size_t)retry.v.size() * c->n), fv(retry.v.size());
+      std::vector<int32_t> ridx(retry.v.begin(), retry.v.end());
+      CHK(pgpfa_get_post_mean(c, (int)ridx.size(), ridx.data(), X.data()));
+      CHK(pgpfa_laplace_eval(c, (int)ridx.size(), ridx.data(), X.data(), fv.data(), nullptr));
+      for (double v : fv) obj_bad += v;
+    }
+    CHK(estep_impl(c, retry, 1, false, &obj_redo, it2.data(), st2.data()));
+    obj += obj_redo - obj_bad;
+    for (size_t j = 0; j < pos.size(); ++j) { it1[pos[j]] += it2[j]; st1[pos[j]] = st2[j]; }
+    c->info["last_dense_retries"] = (double)retry.v.size();
+  } else {
+    c->info["last_dense_retries"] = 0.0;
+  }
+  CHK(remember_trials(c, tr.v));
+  if (obj_sum) *obj_sum = obj;
+  for (int i = 0; i < N; ++i) {
+    if (iters) iters[i] = it1[i];
+    if (status) status[i] = st1[i];
+  }
   return 0;
 }
 
