@@ -1249,6 +1249,40 @@ __global__ void scatter_vsmgp_lr_kernel(const double* __restrict__ src, long lon
   }
 }
 
+// block-diagonal F (n x rpad, ld) and F^T (rpad x n, ldt = rpad) from the per-latent factors; grid = (rk_max, p)
+__global__ void build_fbig_kernel(const double* __restrict__ F, int Tf, int T, const int* __restrict__ roff, double* __restrict__ Fbig,
+                                  int ld, double* __restrict__ FTbig, int ldt) {
+  const int k = blockIdx.y, a = blockIdx.x;
+  const int r0 = roff[k], r1 = roff[k + 1];
+  if (a >= r1 - r0) return;
+  const double* col = F + (size_t)k * Tf * Tf + (size_t)a * Tf;
+  for (int t = threadIdx.x; t < T; t += blockDim.x) {
+    const double v = col[t];
+    Fbig[(size_t)(r0 + a) * ld + (size_t)k * T + t] = v;
+    FTbig[((size_t)k * T + t) * ldt + r0 + a] = v;
+  }
+}
+
+// out[slot][(k,t)] = sum_k' Gb[t][k][k'] * (scale * a[slot][(k',t)] + b[slot][(k',t)])   (b may be null)
+// Gb is ONE set of per-bin p x p blocks shared by all slots; grid = (ceil(T/64), nslots), block = 64 (lanes = bins)
+__global__ void apply_bin_kernel(const double* __restrict__ Gb, const double* __restrict__ A, const double* __restrict__ B2, double scale,
+                                 double* __restrict__ out, long long sV, int T, int p) {
+  const size_t slot = blockIdx.y;
+  const int t = blockIdx.x * 64 + threadIdx.x;
+  if (t >= T) return;
+  const double* g = Gb + (size_t)t * p * p;
+  const double* a = A + slot * sV + t;
+  const double* b = B2 ? B2 + slot * sV + t : nullptr;
+  double* o = out + slot * sV + t;
+  double v[32];
+  for (int k = 0; k < p; ++k) v[k] = scale * a[(size_t)k * T] + (b ? b[(size_t)k * T] : 0.0);
+  for (int k = 0; k < p; ++k) {
+    double s = 0.0;
+    for (int kk = 0; kk < p; ++kk) s += g[k * p + kk] * v[kk];
+    o[(size_t)k * T] = s;
+  }
+}
+
 // counts: double [R][q][T] -> uint8 with validation (non-negative integers <= 255)
 __global__ void pack_counts_kernel(const double* __restrict__ src, uint8_t* __restrict__ dst, size_t n, int* __restrict__ bad) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -101,7 +101,8 @@ struct pgpfa_ctx {
   // low-rank covariance engine
   double* Flr = nullptr;                          // [p][Tp x Tp] pivoted-Cholesky factors of the RBF part
   double* Gbin = nullptr;                         // [B][T][p][p]
-  int *d_rank = nullptr, *d_blk_lat = nullptr, *d_blk_col = nullptr;
+  int *d_rank = nullptr, *d_blk_lat = nullptr, *d_blk_col = nullptr, *d_roff = nullptr;
+  double *Fbig = nullptr, *FTbig = nullptr, *Gbar = nullptr, *Wtbar = nullptr;   // low-rank shared preconditioner
   std::vector<int> rk, roff;                      // ranks padded to 16, offsets
   int rtot = 0, rpad = 0;
   int cov_mode = 0;                               // 0 auto, 1 dense, 2 low-rank
@@ -560,6 +561,15 @@ int build_lowrank(pgpfa_ctx* c) {
     for (int b = c->roff[k] / 16; b < c->roff[k + 1] / 16; ++b) { lat[b] = k; col[b] = b * 16 - c->roff[k]; }
   CHK(upload_list(c, c->d_blk_lat, lat));
   CHK(upload_list(c, c->d_blk_col, col));
+  CHK(upload_list(c, c->d_roff, c->roff));
+  if ((size_t)c->rpad <= (size_t)c->ld) {
+    HIPC(hipMemsetAsync(c->Fbig, 0, (size_t)c->ld * c->rpad * sizeof(double), c->st));
+    HIPC(hipMemsetAsync(c->FTbig, 0, (size_t)c->rpad * c->ld * sizeof(double), c->st));
+    int rkmax = 0;
+    for (int k = 0; k < p; ++k) rkmax = std::max(rkmax, c->rk[k]);
+    hipLaunchKernelGGL(build_fbig_kernel, dim3(rkmax, p), dim3(128), 0, c->st, c->Flr, Tp, T, c->d_roff, c->Fbig, c->ld, c->FTbig, c->rpad);
+    HIPC(hipGetLastError());
+  }
   c->info["lowrank_rtot"] = c->rtot;
   return 0;
 }
@@ -645,7 +655,9 @@ int pgpfa_create(pgpfa_ctx** out, int device, int q, int p, int T, int R, double
   rc |= dmalloc(c, &c->vsmgp, (size_t)R * p * T * T, true);
   rc |= dmalloc(c, &c->Pauto, slab * p, true);
   rc |= dmalloc(c, &c->Flr, slab * p + 256 * (size_t)c->Tp, true);
-  rc |= dmalloc(c, &c->d_rank, p); rc |= dmalloc(c, &c->d_blk_lat, (size_t)p * c->Tp / 16 + 64); rc |= dmalloc(c, &c->d_blk_col, (size_t)p * c->Tp / 16 + 64);
+  rc |= dmalloc(c, &c->d_rank, p); rc |= dmalloc(c, &c->d_roff, p + 1);
+  rc |= dmalloc(c, &c->Fbig, (size_t)c->ld * c->ld + 256 * (size_t)c->ld, true); rc |= dmalloc(c, &c->FTbig, (size_t)c->ld * c->ld + 256 * (size_t)c->ld, true);
+  rc |= dmalloc(c, &c->Gbar, (size_t)T * p * p + 64); rc |= dmalloc(c, &c->Wtbar, (size_t)T * p * p + 64); rc |= dmalloc(c, &c->d_blk_lat, (size_t)p * c->Tp / 16 + 64); rc |= dmalloc(c, &c->d_blk_col, (size_t)p * c->Tp / 16 + 64);
   rc |= dmalloc(c, &c->vec, (size_t)q * (p + 1));
   rc |= dmalloc(c, &c->cdpart, (size_t)1024 * (p + 2) * q);
   rc |= dmalloc(c, &c->cdout, (size_t)(p + 2) * q + 8);
@@ -891,11 +903,31 @@ static int remember_trials(pgpfa_ctx* c, const std::vector<int>& v) {
 }
 
 
-// Z <- P^-1 R for the nb slot vectors at once: the shared preconditioner is ONE matrix, so its explicit
-// inverse is formed once per chunk (shared_factor) and applied to all right-hand sides with a single
-// multi-RHS GEMM (N = slots) - the same 2 n^2 flops per vector as two triangular sweeps, in one launch,
-// with P^-1 (one 200 MB slab at config 3) served from L2 / Infinity Cache.
+// Z <- P^-1 R for the nb slot vectors at once.  Dense plan: the shared preconditioner is ONE matrix, its explicit
+// inverse is formed once per chunk and applied with a single multi-RHS GEMM.  Low-rank plan: the same matrix in
+// Woodbury form, P^-1 v = Gb (eps v + F Sb F^T Gb v), with Gb the per-bin blocks of the mean curvature and Sb the
+// inverse of the r x r system: two per-bin kernels and three thin GEMMs, no n x n matrix anywhere.
 static int shared_solve(pgpfa_ctx* c, int nb, const double* R, double* Z) {
+  if (c->plan_lowrank) {
+    const long long ld = c->ld;
+    const int rpad = c->rpad;
+    hipLaunchKernelGGL(apply_bin_kernel, dim3((c->T + 63) / 64, nb), dim3(64), 0, c->st, c->Gbar, R, (const double*)nullptr, 1.0, c->Xt, ld, c->T, c->p);
+    GemmP y{};                                               // Y = F^T (Gb R)          (rpad x nb)
+    y.A = c->FTbig; y.sA = 0; y.lda = rpad; y.B = c->Xt; y.sB = 0; y.ldb = c->ld; y.C = c->Glt; y.sC = 0; y.ldc = c->ld;
+    y.M = rpad; y.N = nb; y.K = c->npad; y.alpha = 1.0; y.beta = 0.0; y.slots = nullptr; y.nbatch = 1; y.mode = GEMM_FULL; y.kflags = 0;
+    CHK(gemm(c, true, y));
+    GemmP z{};                                               // Zs = Sb Y
+    z.A = c->sU; z.sA = 0; z.lda = rpad; z.B = c->Glt; z.sB = 0; z.ldb = c->ld; z.C = c->KD; z.sC = 0; z.ldc = c->ld;
+    z.M = rpad; z.N = nb; z.K = rpad; z.alpha = 1.0; z.beta = 0.0; z.slots = nullptr; z.nbatch = 1; z.mode = GEMM_FULL; z.kflags = 0;
+    CHK(gemm(c, true, z));
+    GemmP q{};                                               // Q = F Zs                (n x nb)
+    q.A = c->Fbig; q.sA = 0; q.lda = c->ld; q.B = c->KD; q.sB = 0; q.ldb = c->ld; q.C = c->Xt; q.sC = 0; q.ldc = c->ld;
+    q.M = c->n; q.N = nb; q.K = rpad; q.alpha = 1.0; q.beta = 0.0; q.slots = nullptr; q.nbatch = 1; q.mode = GEMM_FULL; q.kflags = 0;
+    CHK(gemm(c, true, q));
+    hipLaunchKernelGGL(apply_bin_kernel, dim3((c->T + 63) / 64, nb), dim3(64), 0, c->st, c->Gbar, R, c->Xt, c->eps, Z, ld, c->T, c->p);
+    HIPC(hipGetLastError());
+    return 0;
+  }
   GemmP g{};
   g.A = c->sU; g.sA = 0; g.lda = c->ld;                      // P^-1, symmetric
   g.B = R; g.sB = 0; g.ldb = c->ld;                          // K x N column-major: slot vectors
@@ -905,8 +937,42 @@ static int shared_solve(pgpfa_ctx* c, int nb, const double* R, double* Z) {
   return gemm(c, true, g);
 }
 
+// low-rank form of the shared preconditioner: Gb, Wtb from the mean curvature, Sb = (I + F^T Wtb F)^-1 (r x r, one slot)
+static int shared_factor_lowrank(pgpfa_ctx* c, int nb) {
+  const int T = c->T, p = c->p, pp = p * p, len = T * pp, rpad = c->rpad;
+  hipLaunchKernelGGL(mean_w_kernel, dim3((len + 255) / 256), dim3(256), 0, c->st, c->W, (long long)len, c->ident, nb, len, c->Wbar);
+  {
+    int th = (int)(48 * 1024 / ((2 * pp + 1) * sizeof(double)));
+    th = std::max(1, std::min(64, th));
+    hipLaunchKernelGGL(bin_blocks_kernel, dim3((unsigned)((T + th - 1) / th)), dim3(th), (size_t)th * (2 * pp + 1) * sizeof(double), c->st,
+                       c->Wbar, 0LL, c->Gbar, c->Wtbar, 0LL, T, p, c->eps, c->ident, 1);
+  }
+  CholWS lw = c->sws;
+  lw.ld = rpad; lw.npad = rpad; lw.nact = round_up(c->rtot, 64);
+  const int nblk16 = rpad / 16, npairs = nblk16 * (nblk16 + 1) / 2;
+  hipLaunchKernelGGL(assemble_b_kernel, dim3(npairs, 1), dim3(256), 0, c->st, lw.H, lw.sH, rpad, nblk16, c->Flr, c->Tp, T, p, c->d_blk_lat,
+                     c->d_blk_col, c->Wtbar, 0LL, c->ident);
+  HIPC(hipGetLastError());
+  HIPC(hipMemsetAsync(c->sws.info, 0, sizeof(int), c->st));
+  CHK(factor(c, lw, nullptr, 1));
+  HIPC(hipMemsetAsync(lw.Mt, 0, (size_t)rpad * rpad * sizeof(double), c->st));
+  CHK(inverse_t(c, lw, nullptr, 1));
+  GemmP g{};
+  g.A = lw.Mt; g.sA = 0; g.lda = rpad; g.B = lw.Mt; g.sB = 0; g.ldb = rpad;
+  g.C = c->sU; g.sC = 0; g.ldc = rpad;
+  g.M = rpad; g.N = rpad; g.K = rpad; g.alpha = 1.0; g.beta = 0.0;
+  g.slots = nullptr; g.nbatch = 1; g.mode = GEMM_FULL; g.kflags = KF_BEGIN_MAXRC;
+  CHK(gemm(c, false, g));
+  int info = 0;
+  HIPC(hipMemcpyAsync(&info, c->sws.info, sizeof(int), hipMemcpyDeviceToHost, c->st));
+  HIPC(hipStreamSynchronize(c->st));
+  if (info != 0) return fail("shared low-rank preconditioner not positive definite (pivot %d)", info);
+  return 0;
+}
+
 // explicit inverse of the mean-trial Hessian  P = Kinv + scatter(mean_r W_r[t])  of the slots [0,nb)
 static int shared_factor(pgpfa_ctx* c, int nb) {
+  if (c->plan_lowrank) return shared_factor_lowrank(c, nb);
   const int len = c->T * c->p * c->p;
   hipLaunchKernelGGL(mean_w_kernel, dim3((len + 255) / 256), dim3(256), 0, c->st, c->W, (long long)len, c->ident, nb, len, c->Wbar);
   hipLaunchKernelGGL(assemble_h_kernel, dim3(c->npad, 1), dim3(256), 0, c->st, c->sws.H, c->sws.sH, c->ld, c->npad, c->n, c->T, c->Tp, c->p,
