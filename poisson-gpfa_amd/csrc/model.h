@@ -1207,32 +1207,37 @@ __global__ void vsm_finish_kernel(double* __restrict__ vsm, const double* __rest
     }
 }
 
-// Ymix[t + b*ldo] = sum_k' G_t[k][k'] * Yt[(k',t) + b*ldy]   for latent k (lanes along t, 16 columns b per block)
-__global__ void mix_y_kernel(const double* __restrict__ Yt, long long sY, int ldy, const double* __restrict__ G, long long sG,
-                             double* __restrict__ out, long long sO, int ldo, int T, int p, int k, int rpad, const int* __restrict__ slots) {
+// In-place mixing of Yt (n x rpad, ld = ldy): for every bin t and column b the p-vector y = Yt[(.,t), b] is replaced
+// by G_t y.  Afterwards rows (k,.) of the slab ARE Ymix_k, so post_vsmGP_k = eps diag + Ymix_k Ymix_k^T reads its GEMM
+// operand straight from the slab (one pass over Yt instead of one per latent).
+// grid = (ceil(T/64), ceil(rpad/128), nslots), block = 256: lanes = bins, each wave 32 columns; G_t lives in registers.
+template <int PW>
+__global__ __launch_bounds__(256) void mix_inplace_kernel(double* __restrict__ Yt, long long sY, int ldy, const double* __restrict__ G, long long sG,
+                                                          int T, int p, int rpad, const int* __restrict__ slots) {
   const size_t slot = slots[blockIdx.z];
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int b0 = blockIdx.y * 16;
-  if (t >= ldo) return;
-  double* o = out + slot * sO + t;
-  if (t >= T) {
-    for (int b = b0; b < b0 + 16; ++b) o[(size_t)b * ldo] = 0.0;     // rows >= T are zero
-    return;
+  const int t = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int b0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 32;      // 4 waves per block, 32 columns each
+  if (t >= T || b0 >= rpad) return;
+  const double* gsrc = G + slot * sG + (size_t)t * p * p;
+  double g[PW * PW];                                               // G_t in registers (zero padded to PW x PW)
+#pragma unroll
+  for (int k = 0; k < PW; ++k)
+#pragma unroll
+    for (int kk = 0; kk < PW; ++kk) g[k * PW + kk] = (k < p && kk < p) ? gsrc[k * p + kk] : 0.0;
+  double* y = Yt + slot * sY + t;
+  const int b1 = (b0 + 32 < rpad) ? b0 + 32 : rpad;
+  for (int b = b0; b < b1; ++b) {
+    double v[PW];
+#pragma unroll
+    for (int k = 0; k < PW; ++k) v[k] = (k < p) ? y[(size_t)b * ldy + (size_t)k * T] : 0.0;
+#pragma unroll
+    for (int k = 0; k < PW; ++k) {
+      double s2 = 0.0;
+#pragma unroll
+      for (int kk = 0; kk < PW; ++kk) s2 += g[k * PW + kk] * v[kk];
+      if (k < p) y[(size_t)b * ldy + (size_t)k * T] = s2;
+    }
   }
-  const double* g = G + slot * sG + (size_t)t * p * p + (size_t)k * p;
-  const double* y = Yt + slot * sY + t;
-  double acc[16];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) acc[j] = 0.0;
-  for (int kk = 0; kk < p; ++kk) {
-    const double gk = g[kk];
-    const double* yk = y + (size_t)kk * T;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) acc[j] += gk * yk[(size_t)(b0 + j) * ldy];
-  }
-#pragma unroll
-  for (int j = 0; j < 16; ++j) o[(size_t)(b0 + j) * ldo] = acc[j];
-  (void)rpad;
 }
 
 // vsmGP scatter for the low-rank engine: dst = mirror(src) + eps*G_t[k][k] on the diagonal

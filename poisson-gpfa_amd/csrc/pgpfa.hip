@@ -321,14 +321,14 @@ size_t lowrank_slab_elems(const pgpfa_ctx* c) {
 // engine choice: the low-rank form pays when r << n (long timescales); the dense form is the general one
 bool lowrank_pays(const pgpfa_ctx* c) {
   const double n = c->n, r = c->rpad, T = c->T, p = c->p;
-  if (c->rpad < NB || c->rpad * 2 > c->npad) return false;
+  if (c->p > 16 || c->rpad < NB || c->rpad * 2 > c->npad) return false;
   if (lowrank_slab_elems(c) > (size_t)c->ld * c->ld) return false;
   const double dense = 0.72 * n * n * n;
   const double lr = 6.0 * T * r * r + 0.7 * r * r * r + p * T * T * r;
   return lr < 0.5 * dense;
 }
 
-bool want_lowrank(const pgpfa_ctx* c) { return c->cov_mode == 2 ? (c->rpad >= NB && lowrank_slab_elems(c) <= (size_t)c->ld * c->ld) : (c->cov_mode == 0 && lowrank_pays(c)); }
+bool want_lowrank(const pgpfa_ctx* c) { return c->cov_mode == 2 ? (c->p <= 16 && c->rpad >= NB && lowrank_slab_elems(c) <= (size_t)c->ld * c->ld) : (c->cov_mode == 0 && lowrank_pays(c)); }
 
 size_t ld_bytes(const pgpfa_ctx* c) { return (size_t)c->ld * c->ld * sizeof(double); }
 
@@ -1090,16 +1090,21 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp) {
     hipLaunchKernelGGL(vsm_finish_kernel, dim3((unsigned)((items + th - 1) / th)), dim3(th), (size_t)th * (pp + 1) * sizeof(double), c->st,
                        c->vsm, c->Gbin, sW, T, p, c->eps, c->ident, c->trial_of_slot, nb);
   }
-  // e. post_vsmGP_k = eps diag(G_t[k][k]) + Ymix_k Ymix_k^T,  Ymix_k[t][b] = sum_k' G_t[k][k'] Yt[(k',t)][b]
+  // e. post_vsmGP_k = eps diag(G_t[k][k]) + Ymix_k Ymix_k^T,  Ymix_k[t][b] = sum_k' G_t[k][k'] Yt[(k',t)][b]: Yt is mixed in
+  //    place once (it is not needed unmixed any more), then rows (k,.) of the slab are the GEMM operand of latent k
   if (want_vsmgp) {
-    const size_t off_mix = (size_t)c->ld * rpad;
-    const size_t off_stage = off_mix + (size_t)Tp * rpad;
+    dispatch_pw(p, [&](auto pw) {
+      constexpr int PW = decltype(pw)::value;
+      if constexpr (PW <= 16)
+        hipLaunchKernelGGL(mix_inplace_kernel<PW>, dim3((T + 63) / 64, (rpad + 127) / 128, nb), dim3(256), 0, c->st, lw.H, lw.sH, c->ld, c->Gbin, sW,
+                           T, p, rpad, c->ident);
+    });
+    if (p > 16) return fail("low-rank covariance engine supports up to 16 latents (p=%d)", p);
+    const size_t off_stage = (size_t)c->ld * rpad + (size_t)Tp * rpad;
     for (int k = 0; k < p; ++k) {
-      hipLaunchKernelGGL(mix_y_kernel, dim3((Tp + 63) / 64, rpad / 16, nb), dim3(64), 0, c->st, lw.H, lw.sH, c->ld, c->Gbin, sW, lw.H + off_mix, lw.sH, Tp,
-                         T, p, k, rpad, c->ident);
       GemmP g{};
-      g.A = lw.H + off_mix; g.sA = lw.sH; g.lda = Tp;
-      g.B = g.A; g.sB = lw.sH; g.ldb = Tp;
+      g.A = lw.H + (size_t)k * T; g.sA = lw.sH; g.lda = c->ld;
+      g.B = g.A; g.sB = lw.sH; g.ldb = c->ld;
       g.C = lw.H + off_stage; g.sC = lw.sH; g.ldc = T;
       g.M = T; g.N = T; g.K = rpad; g.alpha = 1.0; g.beta = 0.0;
       g.slots = c->ident; g.nbatch = nb; g.mode = GEMM_LOWER; g.kflags = 0;
