@@ -708,6 +708,7 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
   else if (k == "lowrank_tol") c->lr_tol = v;
   else if (k == "shared_min") c->shared_min = (int)v;
   else if (k == "pcg_inner") c->pcg_inner = (int)v;
+  else if (k == "pcg_outer_max") c->pcg_outer_max = (int)v;
   else if (k == "chord_xtol") c->chord_xtol = v;
   else if (k == "chord_rho") c->chord_rho = v;
   else if (k == "chord_max_step") c->chord_max_step = v;

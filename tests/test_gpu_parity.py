@@ -366,3 +366,31 @@ def test_newton_mstep_reaches_the_tight_optimum(funs_mod, c1, c1_experiment):
     fit = funs_mod.engine.PPGPFAfit(c1_experiment, initParams=init, EMmode='Batch', maxEMiter=3, CdOptimMethod='newton', quiet=True)
     assert np.max(np.abs(np.asarray(fit.posteriorLikelihood) - ex['nll'][:3])) <= 1e-3
     assert rel(fit.paramSeq[3]['C'], ex['seq_C'][3]) <= 2e-3
+
+
+def test_lowrank_plan_dense_retry(c1):
+    """When the shared-preconditioner Newton gives up under the low-rank workspace plan (forced here by allowing a
+    single outer iteration), the unfinished trials are redone under the dense plan and still reach the mode."""
+    from funs import _hip
+    g = load_golden('c1_laplace.npz')
+    ctx = _hip.Context(30, 3, 100, 20, c1['binSize'])
+    try:
+        ctx.upload_counts(c1['Y'])
+        ctx.set_option('cov_mode', 2)
+        ctx.set_option('pcg_outer_max', 1)
+        ctx.set_params(c1['init_C'], c1['init_d'], c1['init_tau'])
+        obj, iters, status = ctx.estep_laplace()
+        assert ctx.info('last_dense_retries') == 20
+        assert np.all(status == 0)
+        assert np.max(np.abs(ctx.post_mean().reshape(20, -1) - g['polished'])) <= 1e-8
+        res, nll_o, _ = orc.laplace(c1['Ys'][:3], c1['init'], c1['binSize'], mode='exact', return_cov=False)
+        assert rel(ctx.post_vsm()[:3], np.stack(res['post_vsm'])) <= 1e-8
+        _, nll_all, _ = orc.laplace(c1['Ys'], c1['init'], c1['binSize'], mode='exact', return_cov=False)
+        assert abs(-obj / 20 - nll_all) <= 1e-9 * abs(nll_all)
+        # and the next E-step goes back to the low-rank plan
+        ctx.set_option('pcg_outer_max', 12)
+        obj2, _, status2 = ctx.estep_laplace(warm_start=True)
+        assert ctx.info('last_dense_retries') == 0 and ctx.info('last_cov_lowrank') == 1.0
+        assert abs(obj2 - obj) <= 1e-9 * abs(obj)
+    finally:
+        ctx.close()
