@@ -40,17 +40,20 @@ PMC_SUMMARY = os.path.join(ROOT, 'profiles', 'r01_c3_pmc_hbm_traffic.json')   # 
 
 
 def pmc_traffic_per_launch(kernel_prefix):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (separate FETCH_SIZE and
-    WRITE_SIZE runs of this same command, FETCH doubled as MI355X_MICROARCH.md prescribes); None if absent."""
+    """HBM bytes per launch of the dominant kernel (all its template instantiations pooled) from the committed
+    PMC passes (separate FETCH_SIZE and WRITE_SIZE runs of this same command, FETCH doubled as
+    MI355X_MICROARCH.md prescribes); None if absent."""
     try:
         with open(PMC_SUMMARY) as fh:
             d = json.load(fh)
+        tot, calls = 0.0, 0
         for k, v in d.items():
             if k.startswith(kernel_prefix):
-                return v['hbm_bytes_per_launch']
+                tot += v['hbm_bytes_corrected']
+                calls += v['calls']
+        return tot / calls if calls else None
     except (OSError, ValueError, KeyError):
-        pass
-    return None
+        return None
 
 
 class Shard:
