@@ -40,9 +40,11 @@ struct GemmP {
   int M, N, K;
   double alpha, beta;
   const int* slots;     // batch b -> slot (NULL: identity); pointers advance by slot*stride
+  const int* krange;    // optional [tilesM][2]: k range (multiples of 16) of row tile ti - block-sparse A (NULL: kflags rule)
   int nbatch;
   int mode, kflags;
   int tilesM, tilesN, ntiles;
+  double flops_hint;    // algorithmic flops of the launch when the operands are block sparse (0: dense formula)
 };
 
 __device__ __forceinline__ void gemm_decode_tile(const GemmP& g, int tile, int& ti, int& tj) {
@@ -105,6 +107,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP g) {
   if (g.kflags & KF_BEGIN_ROW) kb = i0;
   if (g.kflags & KF_BEGIN_MAXRC) kb = (i0 > j0 ? i0 : j0);
   if (g.kflags & KF_END_ROW) ke = (i0 + GBM < g.K ? i0 + GBM : g.K);
+  if (g.krange) { kb = g.krange[2 * ti]; ke = g.krange[2 * ti + 1]; }
   if (kb > ke) kb = ke;
 
   const bool a_vec = ((((size_t)A) & 15) == 0) && ((g.lda & 1) == 0);
@@ -246,6 +249,7 @@ __global__ void gemm_check_kernel(GemmP g) {
   if (g.kflags & KF_BEGIN_ROW) kb = i0;
   if (g.kflags & KF_BEGIN_MAXRC) kb = (i0 > j0 ? i0 : j0);
   if (g.kflags & KF_END_ROW) ke = (i0 + GBM < g.K ? i0 + GBM : g.K);
+  if (g.krange) { kb = g.krange[2 * ti]; ke = g.krange[2 * ti + 1]; }
   const bool mask_diag = (g.kflags & KF_MASK_DIAG) && (ti == tj);
   // compute first, store after a barrier: C may alias A (in-place TRSM)
   double vals[GBM * GBN / 256];

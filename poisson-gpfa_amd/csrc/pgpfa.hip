@@ -102,6 +102,7 @@ struct pgpfa_ctx {
   double* Flr = nullptr;                          // [p][Tp x Tp] pivoted-Cholesky factors of the RBF part
   double* Gbin = nullptr;                         // [B][T][p][p]
   int *d_rank = nullptr, *d_blk_lat = nullptr, *d_blk_col = nullptr, *d_roff = nullptr;
+  int *d_kr_ft = nullptr, *d_kr_f = nullptr;     // per-row-tile k ranges of the block-diagonal F^T / F GEMMs
   double *Fbig = nullptr, *FTbig = nullptr, *Gbar = nullptr, *Wtbar = nullptr;   // low-rank shared preconditioner
   std::vector<int> rk, roff;                      // ranks padded to 16, offsets
   int rtot = 0, rpad = 0;
@@ -202,6 +203,7 @@ void prof_collect(pgpfa_ctx* c) {
 
 // algorithmic flops of one GEMM launch (useful multiply-adds x2, triangular structure respected)
 double gemm_flops(const GemmP& g) {
+  if (g.flops_hint > 0.0) return g.flops_hint;
   const double M = g.M, N = g.N, K = g.K;
   double per;
   if (g.mode == GEMM_LOWER) {
@@ -562,6 +564,28 @@ int build_lowrank(pgpfa_ctx* c) {
   CHK(upload_list(c, c->d_blk_lat, lat));
   CHK(upload_list(c, c->d_blk_col, col));
   CHK(upload_list(c, c->d_roff, c->roff));
+  {
+    // F^T (rpad x n): row tile ti holds rank rows [128 ti, 128 ti + 128) -> latents k1..k2 -> columns [k1*T, (k2+1)*T)
+    std::vector<int> krft(2 * (c->rpad / NB), 0), krf(2 * (c->npad / NB), 0);
+    auto latent_of_rank = [&](int r) { int k = 0; while (k + 1 < p && c->roff[k + 1] <= r) ++k; return k; };
+    for (int ti = 0; ti < c->rpad / NB; ++ti) {
+      const int r0 = ti * NB, r1 = std::min(ti * NB + NB, c->rtot) - 1;
+      if (r0 >= c->rtot) { krft[2 * ti] = 0; krft[2 * ti + 1] = 0; continue; }
+      const int k1 = latent_of_rank(r0), k2 = latent_of_rank(r1);
+      krft[2 * ti] = (k1 * T) / 16 * 16;
+      krft[2 * ti + 1] = std::min(c->npad, round_up((k2 + 1) * T, 16));
+    }
+    // F (n x rpad): row tile ti holds rows [128 ti, ..) -> latents k1..k2 -> rank columns [roff[k1], roff[k2+1])
+    for (int ti = 0; ti < c->npad / NB; ++ti) {
+      const int i0 = ti * NB, i1 = std::min(ti * NB + NB, c->n) - 1;
+      if (i0 >= c->n) { krf[2 * ti] = 0; krf[2 * ti + 1] = 0; continue; }
+      const int k1 = i0 / T, k2 = i1 / T;
+      krf[2 * ti] = c->roff[k1];
+      krf[2 * ti + 1] = c->roff[k2 + 1];
+    }
+    CHK(upload_list(c, c->d_kr_ft, krft));
+    CHK(upload_list(c, c->d_kr_f, krf));
+  }
   if ((size_t)c->rpad <= (size_t)c->ld) {
     HIPC(hipMemsetAsync(c->Fbig, 0, (size_t)c->ld * c->rpad * sizeof(double), c->st));
     HIPC(hipMemsetAsync(c->FTbig, 0, (size_t)c->rpad * c->ld * sizeof(double), c->st));
@@ -656,6 +680,7 @@ int pgpfa_create(pgpfa_ctx** out, int device, int q, int p, int T, int R, double
   rc |= dmalloc(c, &c->Pauto, slab * p, true);
   rc |= dmalloc(c, &c->Flr, slab * p + 256 * (size_t)c->Tp, true);
   rc |= dmalloc(c, &c->d_rank, p); rc |= dmalloc(c, &c->d_roff, p + 1);
+  rc |= dmalloc(c, &c->d_kr_ft, 2 * (size_t)(c->ld / NB + 2)); rc |= dmalloc(c, &c->d_kr_f, 2 * (size_t)(c->ld / NB + 2));
   rc |= dmalloc(c, &c->Fbig, (size_t)c->ld * c->ld + 256 * (size_t)c->ld, true); rc |= dmalloc(c, &c->FTbig, (size_t)c->ld * c->ld + 256 * (size_t)c->ld, true);
   rc |= dmalloc(c, &c->Gbar, (size_t)T * p * p + 64); rc |= dmalloc(c, &c->Wtbar, (size_t)T * p * p + 64); rc |= dmalloc(c, &c->d_blk_lat, (size_t)p * c->Tp / 16 + 64); rc |= dmalloc(c, &c->d_blk_col, (size_t)p * c->Tp / 16 + 64);
   rc |= dmalloc(c, &c->vec, (size_t)q * (p + 1));
@@ -916,6 +941,7 @@ static int shared_solve(pgpfa_ctx* c, int nb, const double* R, double* Z) {
     GemmP y{};                                               // Y = F^T (Gb R)          (rpad x nb)
     y.A = c->FTbig; y.sA = 0; y.lda = rpad; y.B = c->Xt; y.sB = 0; y.ldb = c->ld; y.C = c->Glt; y.sC = 0; y.ldc = c->ld;
     y.M = rpad; y.N = nb; y.K = c->npad; y.alpha = 1.0; y.beta = 0.0; y.slots = nullptr; y.nbatch = 1; y.mode = GEMM_FULL; y.kflags = 0;
+    y.krange = c->d_kr_ft; y.flops_hint = 2.0 * c->T * c->rtot * nb;      // block-diagonal operand: only T x r_k blocks are non-zero
     CHK(gemm(c, true, y));
     GemmP z{};                                               // Zs = Sb Y
     z.A = c->sU; z.sA = 0; z.lda = rpad; z.B = c->Glt; z.sB = 0; z.ldb = c->ld; z.C = c->KD; z.sC = 0; z.ldc = c->ld;
@@ -924,6 +950,7 @@ static int shared_solve(pgpfa_ctx* c, int nb, const double* R, double* Z) {
     GemmP q{};                                               // Q = F Zs                (n x nb)
     q.A = c->Fbig; q.sA = 0; q.lda = c->ld; q.B = c->KD; q.sB = 0; q.ldb = c->ld; q.C = c->Xt; q.sC = 0; q.ldc = c->ld;
     q.M = c->n; q.N = nb; q.K = rpad; q.alpha = 1.0; q.beta = 0.0; q.slots = nullptr; q.nbatch = 1; q.mode = GEMM_FULL; q.kflags = 0;
+    q.krange = c->d_kr_f; q.flops_hint = 2.0 * c->T * c->rtot * nb;
     CHK(gemm(c, true, q));
     hipLaunchKernelGGL(apply_bin_kernel, dim3((c->T + 63) / 64, nb), dim3(64), 0, c->st, c->Gbar, R, c->Xt, c->eps, Z, ld, c->T, c->p);
     HIPC(hipGetLastError());
