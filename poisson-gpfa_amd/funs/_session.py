@@ -28,6 +28,12 @@ class _World:
         self.enabled = (self.size > 1 or os.environ.get('PGPFA_FORCE_COMM', '0') == '1') and \
             os.environ.get('PGPFA_DISABLE_COMM', '0') != '1'
         self._serial = 0
+        if self.enabled:
+            # single-node job: keep RCCL's bootstrap on loopback and off InfiniBand probing (both can stall in
+            # containers without a routable interface); explicit user settings win
+            os.environ.setdefault('NCCL_SOCKET_IFNAME', 'lo')
+            os.environ.setdefault('NCCL_IB_DISABLE', '1')
+            os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
     def device(self):
         return self.local_rank if self.enabled else int(os.environ.get('PGPFA_DEVICE', '0'))
