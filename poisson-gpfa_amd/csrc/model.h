@@ -924,7 +924,8 @@ __global__ void transpose_diag_blocks_kernel(const double* __restrict__ D, doubl
 }
 
 // q = W p  added onto q (which already holds Kinv p):  q[(k,t)] += sum_l W[t][k][l] p[(l,t)]
-// then pq[slot] = p.q ; block per slot
+// then pq[slot] = p.q ; block per slot, thread per bin (W_t is one contiguous p*p block per thread)
+template <int PW>
 __global__ __launch_bounds__(256) void pcg_hessvec_dot_kernel(const double* __restrict__ W, long long sW, const double* __restrict__ P,
                                                               double* __restrict__ Q, long long sV, int T, int p, int n,
                                                               const int* __restrict__ slots, double* __restrict__ pq) {
@@ -934,18 +935,28 @@ __global__ __launch_bounds__(256) void pcg_hessvec_dot_kernel(const double* __re
   const double* pv = P + slot * sV;
   double* q = Q + slot * sV;
   double acc = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) {
-    const int k = i / T, t = i - k * T;
-    const double* wt = w + (size_t)t * p * p + (size_t)k * p;
-    double s = q[i];
-    for (int l = 0; l < p; ++l) s += wt[l] * pv[(size_t)l * T + t];
-    q[i] = s;
-    acc += s * pv[i];
+  for (int t = threadIdx.x; t < T; t += 256) {
+    const double* wt = w + (size_t)t * p * p;
+    double v[PW];
+#pragma unroll
+    for (int l = 0; l < PW; ++l) v[l] = (l < p) ? pv[(size_t)l * T + t] : 0.0;
+#pragma unroll
+    for (int k = 0; k < PW; ++k) {
+      if (k < p) {
+        double s = q[(size_t)k * T + t];
+#pragma unroll
+        for (int l = 0; l < PW; ++l)
+          if (l < p) s += wt[k * p + l] * v[l];
+        q[(size_t)k * T + t] = s;
+        acc += s * v[k];
+      }
+    }
   }
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) pq[slot] = red[0] + red[1] + red[2] + red[3];
+  (void)n;
 }
 
 // alpha = rz/pq ; x += alpha p ; r -= alpha q   (block per slot)
@@ -1140,45 +1151,46 @@ __global__ void bin_blocks_kernel(const double* __restrict__ W, long long sW, do
 
 // B = I + F^T Wt F (lower triangle, ld = rpad) per slot.  16x16 output tiles; tile (bi,bj) lies inside one latent
 // pair (k,l) because rank offsets are multiples of 16 (blk_lat[b] = latent of block b, -1 = padding).
-// grid = (ntile_pairs, nslots), block = 256 (one output each); bins streamed through LDS in chunks of 64.
-__global__ __launch_bounds__(256) void assemble_b_kernel(double* __restrict__ Bm, long long sB, int ldb, int nblk,
-                                                         const double* __restrict__ F, int Tf, int T, int p,
-                                                         const int* __restrict__ blk_lat, const int* __restrict__ blk_col,
-                                                         const double* __restrict__ Wt, long long sW, const int* __restrict__ slots) {
-  __shared__ double Fa[64][17];
-  __shared__ double Fb[64][17];
-  __shared__ double wv[64];
-  // decode the lower-triangular tile pair
+// One wave per tile on the FP64 MFMA: D[a][b] += sum over 4 bins of (F_k[t][a] * wt[t]) * F_l[t][b], i.e. the A
+// fragment is scaled by the per-bin weight in registers.  grid = (ntile_pairs, nslots), block = 64.
+typedef double mdouble4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(64) void assemble_b_kernel(double* __restrict__ Bm, long long sB, int ldb, int nblk,
+                                                        const double* __restrict__ F, int Tf, int T, int p,
+                                                        const int* __restrict__ blk_lat, const int* __restrict__ blk_col,
+                                                        const double* __restrict__ Wt, long long sW, const int* __restrict__ slots) {
   int bi = 0, rem = blockIdx.x;
   while (rem > bi) { rem -= bi + 1; ++bi; }
   const int bj = rem;                                   // bj <= bi
   const size_t slot = slots[blockIdx.y];
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;    // output (row bi*16+ty... see below)
+  const int lane = threadIdx.x;
+  const int l15 = lane & 15, l4 = lane >> 4;
   const int ka = blk_lat[bi], kb = blk_lat[bj];
   double* out = Bm + slot * sB;
-  const int row = bi * 16 + tx, col = bj * 16 + ty;     // tx along rows: contiguous stores
   if (ka < 0 || kb < 0) {                               // padding block: identity
-    if (row >= col) out[(size_t)col * ldb + row] = (row == col) ? 1.0 : 0.0;
+    for (int r = 0; r < 4; ++r) {
+      const int row = bi * 16 + l4 + 4 * r, col = bj * 16 + l15;
+      if (row >= col) out[(size_t)col * ldb + row] = (row == col) ? 1.0 : 0.0;
+    }
     return;
   }
-  const double* FA = F + (size_t)ka * Tf * Tf + (size_t)blk_col[bi] * Tf;   // 16 columns of F_ka
-  const double* FB = F + (size_t)kb * Tf * Tf + (size_t)blk_col[bj] * Tf;
-  const double* w = Wt + slot * sW + (size_t)ka * p + kb;                    // + t*p*p
-  double acc = 0.0;
-  for (int t0 = 0; t0 < T; t0 += 64) {
-    __syncthreads();
-    for (int e = threadIdx.x; e < 64 * 16; e += 256) {
-      const int tt = e & 63, cc = e >> 6;
-      const int t = t0 + tt;
-      Fa[tt][cc] = (t < T) ? FA[(size_t)cc * Tf + t] : 0.0;
-      Fb[tt][cc] = (t < T) ? FB[(size_t)cc * Tf + t] : 0.0;
-    }
-    if (threadIdx.x < 64) wv[threadIdx.x] = (t0 + threadIdx.x < T) ? w[(size_t)(t0 + threadIdx.x) * p * p] : 0.0;
-    __syncthreads();
-#pragma unroll 8
-    for (int tt = 0; tt < 64; ++tt) acc += Fa[tt][tx] * wv[tt] * Fb[tt][ty];
+  // A[i = l15][k = l4]: column (blk_col[bi] + l15) of F_ka at bin t0 + l4 ; B[k = l4][j = l15]: column of F_kb
+  const double* FA = F + (size_t)ka * Tf * Tf + (size_t)(blk_col[bi] + l15) * Tf + l4;
+  const double* FB = F + (size_t)kb * Tf * Tf + (size_t)(blk_col[bj] + l15) * Tf + l4;
+  const double* w = Wt + slot * sW + (size_t)ka * p + kb + (size_t)l4 * p * p;     // + t0*p*p
+  mdouble4 acc = {0.0, 0.0, 0.0, 0.0};
+  const int T4 = (T + 3) / 4 * 4;                       // F rows >= T are zero (slab is Tf >= T4 tall), wt guarded
+  for (int t0 = 0; t0 < T4; t0 += 4) {
+    const double wv = (t0 + l4 < T) ? w[(size_t)t0 * p * p] : 0.0;
+    const double a = FA[t0] * wv;
+    const double b = FB[t0];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
   }
-  if (row >= col) out[(size_t)col * ldb + row] = acc + (row == col ? 1.0 : 0.0);
+  // D[row = l4 + 4r][col = l15] = B[(bi*16 + row), (bj*16 + col)]
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = bi * 16 + l4 + 4 * r, col = bj * 16 + l15;
+    if (row >= col) out[(size_t)col * ldb + row] = acc[r] + (row == col ? 1.0 : 0.0);
+  }
 }
 
 // vsm[t] <- eps*G_t + G_t * Bt_t * G_t in place (Bt_t already in vsm, trial indexed); one thread per (slot,t)

@@ -482,7 +482,7 @@ int poisson(pgpfa_ctx* c, const int* d_list, int nl, const double* X, double* G,
   dim3 grid(a.ntile, nl), block(64, KY);
   const double fl = (double)nl * c->q * c->T * (4.0 * c->p + (full ? c->p * (c->p + 1.0) : 0.0));
   prof_begin(c, TAG_POISSON, fl);
-  dispatch_pmax(c->p, [&](auto pm) { hipLaunchKernelGGL(poisson_pass_kernel<decltype(pm)::value>, grid, block, 0, c->st, a); });
+  dispatch_pw(c->p, [&](auto pm) { hipLaunchKernelGGL(poisson_pass_kernel<decltype(pm)::value>, grid, block, 0, c->st, a); });
   prof_end(c);
   hipLaunchKernelGGL(sum_tiles_kernel, dim3((nl + 255) / 256), dim3(256), 0, c->st, c->fpart, a.ntile, d_list, nl, flik);
   HIPC(hipGetLastError());
@@ -978,7 +978,7 @@ static int shared_factor_lowrank(pgpfa_ctx* c, int nb) {
   CholWS lw = c->sws;
   lw.ld = rpad; lw.npad = rpad; lw.nact = round_up(c->rtot, 64);
   const int nblk16 = rpad / 16, npairs = nblk16 * (nblk16 + 1) / 2;
-  hipLaunchKernelGGL(assemble_b_kernel, dim3(npairs, 1), dim3(256), 0, c->st, lw.H, lw.sH, rpad, nblk16, c->Flr, c->Tp, T, p, c->d_blk_lat,
+  hipLaunchKernelGGL(assemble_b_kernel, dim3(npairs, 1), dim3(64), 0, c->st, lw.H, lw.sH, rpad, nblk16, c->Flr, c->Tp, T, p, c->d_blk_lat,
                      c->d_blk_col, c->Wtbar, 0LL, c->ident);
   HIPC(hipGetLastError());
   HIPC(hipMemsetAsync(c->sws.info, 0, sizeof(int), c->st));
@@ -1085,7 +1085,7 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp) {
   CholWS lw = c->ws;
   lw.ld = rpad; lw.npad = rpad; lw.nact = round_up(c->rtot, 64);
   const int nblk16 = rpad / 16, npairs = nblk16 * (nblk16 + 1) / 2;
-  hipLaunchKernelGGL(assemble_b_kernel, dim3(npairs, nb), dim3(256), 0, c->st, lw.H, lw.sH, rpad, nblk16, c->Flr, Tp, T, p, c->d_blk_lat,
+  hipLaunchKernelGGL(assemble_b_kernel, dim3(npairs, nb), dim3(64), 0, c->st, lw.H, lw.sH, rpad, nblk16, c->Flr, Tp, T, p, c->d_blk_lat,
                      c->d_blk_col, c->Wt, sW, c->ident);
   HIPC(hipGetLastError());
   HIPC(hipMemsetAsync(c->ws.info, 0, sizeof(int) * nb, c->st));
@@ -1241,8 +1241,10 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
         hipLaunchKernelGGL(pcg_update_p_kernel, dim3(na), dim3(256), 0, c->st, c->Rv, c->Zv, c->Pv, ld, nvec, c->list_a, c->sc_rz, c->sc_rr0, 1);
         for (int it = 0; it < inner; ++it) {
           CHK(prior_mv_all(c, nb, c->Pv, c->Qv));
-          hipLaunchKernelGGL(pcg_hessvec_dot_kernel, dim3(na), dim3(256), 0, c->st, c->W, (long long)T * p * p, c->Pv, c->Qv, ld, T, p, nvec,
-                             c->list_a, c->sc_pq);
+          dispatch_pw(p, [&](auto pw) {
+            hipLaunchKernelGGL(pcg_hessvec_dot_kernel<decltype(pw)::value>, dim3(na), dim3(256), 0, c->st, c->W, (long long)T * p * p, c->Pv, c->Qv,
+                               ld, T, p, nvec, c->list_a, c->sc_pq);
+          });
           hipLaunchKernelGGL(pcg_update_xr_kernel, dim3(na), dim3(256), 0, c->st, c->Dl, c->Rv, c->Pv, c->Qv, ld, nvec, c->list_a, c->sc_rz, c->sc_pq);
           CHK(shared_solve(c, nb, c->Rv, c->Zv));
           hipLaunchKernelGGL(pcg_update_p_kernel, dim3(na), dim3(256), 0, c->st, c->Rv, c->Zv, c->Pv, ld, nvec, c->list_a, c->sc_rz, c->sc_rr, 0);
