@@ -4,7 +4,7 @@
 // factorisation.  npad (multiple of 128) rows/cols are active; rows >= n are identity padding.
 //
 //   chol_factor      blocked right-looking Cholesky, 128-wide diagonal blocks inside 512-wide
-//                    super-panels: potrf_diag (one workgroup per slot, LDS-resident 128x128 block,
+//                    super-panels: potrf_diag (one workgroup per slot, register-resident 128x128 block,
 //                    also emits the block's triangular inverse) -> TRSM as GEMM against that inverse
 //                    -> SYRK trailing update restricted to the super-panel; one K=512 SYRK update of
 //                    the rest per super-panel keeps the trailing matrix traffic at n^3/(6*512)*16 B.
@@ -21,70 +21,119 @@ constexpr int NB = 128;     // diagonal block / GEMM tile
 constexpr int NSUP = 512;   // super-panel width
 
 // --------------------------------------------------------------------------------------------------
-// 128x128 diagonal block: Cholesky in LDS, write L back, invert in place, write L^-1 to Dinv.
-// info[slot] is set to (k0 + j + 1) at the first non-positive pivot.
+// 128x128 diagonal block: Cholesky and triangular inverse.  512 threads; thread (r = tid & 127, cg = tid >> 7)
+// owns row r, columns c = cg + 4m (m = 0..31) of the trailing matrix in 32 registers.  Step j broadcasts column j
+// through a double-buffered LDS line (one barrier per step) and every thread applies the rank-1 update to its
+// registers with no masks: registers of finished columns are dead (the finished column of L goes to an LDS copy),
+// and the steps are instantiated per quarter of the block so that the register range still alive is static.
+// The inverse runs row by row (forward substitution) with row i of L^-1 broadcast the same way.
+// Writes L back in place and L^-1 to Dinv[slot][k0/128]; info[slot] = (k0 + j + 1) at the first bad pivot.
 // --------------------------------------------------------------------------------------------------
+struct PotrfLds {
+  double L[NB * NB];            // column-major copy of the factor
+  double line[2][NB];           // broadcast lines, permuted: pos(i) = (i & 3) * 32 + (i >> 2)
+  double rd[2];                 // 1 / L[j][j] of the current step
+};
+
+__device__ __forceinline__ double pick8(const double* a, int k) {
+  const double v01 = (k & 1) ? a[1] : a[0], v23 = (k & 1) ? a[3] : a[2];
+  const double v45 = (k & 1) ? a[5] : a[4], v67 = (k & 1) ? a[7] : a[6];
+  const double v03 = (k & 2) ? v23 : v01, v47 = (k & 2) ? v67 : v45;
+  return (k & 4) ? v47 : v03;
+}
+
+template <int Q>
+__device__ __forceinline__ void potrf_diag_chol_steps(double (&a)[32], PotrfLds& S, int r, int cg, int pos_r,
+                                                       int* __restrict__ info, long long slot, int k0) {
+#pragma unroll 1
+  for (int j = 32 * Q; j < 32 * Q + 32; ++j) {
+    const bool own = (j & 3) == cg;
+    double* buf = S.line[j & 1];
+    if (own && r >= j) {
+      const double v = pick8(&a[8 * Q], (j >> 2) - 8 * Q);
+      buf[pos_r] = v;                             // column j, unscaled
+      if (r == j) {
+        double rd = rsqrt(v);
+        if (!(v > 0.0)) {                         // also catches NaN
+          if (info[slot] == 0) info[slot] = k0 + j + 1;
+          rd = 1.0;
+        }
+        S.rd[j & 1] = rd;
+      }
+    }
+    __syncthreads();
+    if (r >= j) {                                 // whole waves drop out as j advances
+      const double rd = S.rd[j & 1];
+      const double lr = buf[pos_r] * rd;          // L[r][j]  (r == j: a_jj / sqrt(a_jj))
+      if (own) S.L[j * NB + r] = lr;
+      const double nlr = -lr * rd;
+      const double* bp = buf + cg * 32;
+#pragma unroll
+      for (int m = 8 * Q; m < 32; ++m) a[m] = fma(nlr, bp[m], a[m]);
+    }
+  }
+}
+
+template <int Q>
+__device__ __forceinline__ void potrf_diag_inv_steps(double (&t)[32], PotrfLds& S, int r, int cg, double inv_lrr) {
+  constexpr int MEND = 8 * (Q + 1);               // columns beyond 32(Q+1) are still zero in this quarter
+#pragma unroll 1
+  for (int i = 32 * Q; i < 32 * Q + 32; ++i) {
+    double* xrow = S.line[i & 1];
+    if (r == i) {
+      double* xp = xrow + cg * 32;
+#pragma unroll
+      for (int m = 0; m < MEND; ++m) xp[m] = t[m];
+      if ((i & 3) == cg) xp[i >> 2] = inv_lrr;    // X[i][i]
+    }
+    __syncthreads();
+    if (r > i) {
+      const double lri = -S.L[i * NB + r] * inv_lrr;
+      const double* xp = xrow + cg * 32;
+#pragma unroll
+      for (int m = 0; m < MEND; ++m) t[m] = fma(lri, xp[m], t[m]);
+    }
+  }
+}
+
 __global__ __launch_bounds__(512) void potrf_diag_kernel(double* __restrict__ H, long long sH, int ld, int k0,
                                                           double* __restrict__ Dinv, long long sD,
                                                           const int* __restrict__ slots, int* __restrict__ info) {
-  __shared__ double S[NB * NB];     // column-major S[c*128 + r]
-  __shared__ double dg[NB];
+  __shared__ __attribute__((aligned(16))) PotrfLds S;
   const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int r = tid & (NB - 1);
+  const int cg = tid >> 7;                      // 0..3, uniform per wave
+  const int pos_r = (r & 3) * 32 + (r >> 2);
   const long long slot = slots ? slots[blockIdx.x] : blockIdx.x;
   double* Hs = H + slot * sH + (size_t)k0 * ld + k0;
   double* Ds = Dinv + slot * sD + (size_t)(k0 / NB) * NB * NB;
 
+  double a[32];
+#pragma unroll
+  for (int m = 0; m < 32; ++m) a[m] = Hs[(size_t)(cg + 4 * m) * ld + r];   // entries above the diagonal are never used
+  potrf_diag_chol_steps<0>(a, S, r, cg, pos_r, info, slot, k0);
+  potrf_diag_chol_steps<1>(a, S, r, cg, pos_r, info, slot, k0);
+  potrf_diag_chol_steps<2>(a, S, r, cg, pos_r, info, slot, k0);
+  potrf_diag_chol_steps<3>(a, S, r, cg, pos_r, info, slot, k0);
+  __syncthreads();
   for (int e = tid; e < NB * NB; e += 512) {
-    const int r = e & (NB - 1), c = e >> 7;
-    S[e] = (r >= c) ? Hs[(size_t)c * ld + r] : 0.0;
+    const int rr = e & (NB - 1), cc = e >> 7;
+    if (rr >= cc) Hs[(size_t)cc * ld + rr] = S.L[e];
   }
-  __syncthreads();
-
-  for (int j = 0; j < NB; ++j) {
-    const double djj = S[j * NB + j];          // untouched during step j (sqrt kept in dg[])
-    double d = sqrt(djj);
-    if (!(djj > 0.0)) {                          // also catches NaN
-      if (tid == 0 && info[slot] == 0) info[slot] = k0 + j + 1;
-      d = 1.0;
-    }
-    const double rd = 1.0 / d;
-    if (tid == 0) dg[j] = d;
-    for (int r = j + 1 + tid; r < NB; r += 512) S[j * NB + r] *= rd;
-    __syncthreads();
-    // trailing update, one wave per column c (8 waves)
-    for (int c = j + 1 + wave; c < NB; c += 8) {
-      const double lcj = S[j * NB + c];
-      for (int r = c + lane; r < NB; r += 64) S[c * NB + r] -= S[j * NB + r] * lcj;
-    }
-    __syncthreads();
+  // ---- X = L^-1 by rows: X[r][c] = -(1/L[r][r]) sum_{i=c}^{r-1} L[r][i] X[i][c]  (c < r),  X[r][r] = 1/L[r][r]
+  double t[32];
+#pragma unroll
+  for (int m = 0; m < 32; ++m) t[m] = 0.0;
+  const double inv_lrr = 1.0 / S.L[r * NB + r];
+  potrf_diag_inv_steps<0>(t, S, r, cg, inv_lrr);
+  potrf_diag_inv_steps<1>(t, S, r, cg, inv_lrr);
+  potrf_diag_inv_steps<2>(t, S, r, cg, inv_lrr);
+  potrf_diag_inv_steps<3>(t, S, r, cg, inv_lrr);
+#pragma unroll
+  for (int m = 0; m < 32; ++m) {
+    const int c = cg + 4 * m;
+    Ds[(size_t)c * NB + r] = (c < r) ? t[m] : (c == r ? inv_lrr : 0.0);
   }
-  if (tid < NB) S[tid * NB + tid] = dg[tid];
-  __syncthreads();
-  // write L (lower part; zeros above the diagonal inside the block are harmless and keep the
-  // block well defined for kernels that read whole tiles)
-  for (int e = tid; e < NB * NB; e += 512) {
-    const int r = e & (NB - 1), c = e >> 7;
-    if (r >= c) Hs[(size_t)c * ld + r] = S[e];
-  }
-  __syncthreads();
-  // in-place inverse of the lower-triangular block, last column first
-  for (int j = NB - 1; j >= 0; --j) {
-    const double inv = 1.0 / S[j * NB + j];
-    double v = 0.0;
-    const int i = tid;
-    if (i < NB && i > j) {
-      for (int m = j + 1; m <= i; ++m) v += S[m * NB + i] * S[j * NB + m];
-    }
-    __syncthreads();
-    if (i < NB) {
-      if (i > j) S[j * NB + i] = -v * inv;
-      else if (i == j) S[j * NB + j] = inv;
-    }
-    __syncthreads();
-  }
-  for (int e = tid; e < NB * NB; e += 512) Ds[e] = S[e];   // upper part is exact zeros
 }
 
 // Mt[jblk, jblk] = Dinv[jb]^T
