@@ -1149,48 +1149,94 @@ __global__ void bin_blocks_kernel(const double* __restrict__ W, long long sW, do
     }
 }
 
-// B = I + F^T Wt F (lower triangle, ld = rpad) per slot.  16x16 output tiles; tile (bi,bj) lies inside one latent
-// pair (k,l) because rank offsets are multiples of 16 (blk_lat[b] = latent of block b, -1 = padding).
-// One wave per tile on the FP64 MFMA: D[a][b] += sum over 4 bins of (F_k[t][a] * wt[t]) * F_l[t][b], i.e. the A
-// fragment is scaled by the per-bin weight in registers.  grid = (ntile_pairs, nslots), block = 64.
+// B = I + F^T Wt F (lower triangle) for the low-rank engine.  B is cut into 16-wide blocks that never straddle a
+// latent (ranks are padded to 16): block (bi, bj) is sum_t F_ka[t][a] Wt_t[ka][kb] F_kb[t][b].
+// One workgroup (4 waves, 2x2 MFMA tiles each) per 64x64 tile of B: 32-bin chunks of the two F column panels and
+// of the 4x4 table of per-bin weights are staged in LDS, the weight scales the A fragment in registers.  The A
+// operand is the column side, so the accumulator's lanes run along rows of B and the stores are contiguous
+// (Wt_t is symmetric).  grid = (tile pairs, slots), block = 256.
 typedef double mdouble4 __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(64) void assemble_b_kernel(double* __restrict__ Bm, long long sB, int ldb, int nblk,
-                                                        const double* __restrict__ F, int Tf, int T, int p,
-                                                        const int* __restrict__ blk_lat, const int* __restrict__ blk_col,
-                                                        const double* __restrict__ Wt, long long sW, const int* __restrict__ slots) {
+constexpr int AB_TK = 32;     // bins per LDS chunk
+constexpr int AB_LD = 81;     // LDS row stride of a staged panel (64 columns + pad; odd*... keeps writes conflict-free)
+__global__ __launch_bounds__(256) void assemble_b_kernel(double* __restrict__ Bm, long long sB, int ldb, int nblk,
+                                                         const double* __restrict__ F, int Tf, int T, int p,
+                                                         const int* __restrict__ blk_lat, const int* __restrict__ blk_col,
+                                                         const double* __restrict__ Wt, long long sW, const int* __restrict__ slots) {
+  __shared__ double FR[AB_TK * AB_LD];                   // row-side panel  [bin][column]
+  __shared__ double FC[AB_TK * AB_LD];                   // column-side panel
+  __shared__ double WL[AB_TK * 16];                      // weights [bin][row block * 4 + column block]
+  __shared__ int lat_r[4], lat_c[4], col_r[4], col_c[4];
   int bi = 0, rem = blockIdx.x;
   while (rem > bi) { rem -= bi + 1; ++bi; }
-  const int bj = rem;                                   // bj <= bi
+  const int bj = rem;                                    // bj <= bi, in units of 64
   const size_t slot = slots[blockIdx.y];
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
-  const int ka = blk_lat[bi], kb = blk_lat[bj];
-  double* out = Bm + slot * sB;
-  if (ka < 0 || kb < 0) {                               // padding block: identity
-    for (int r = 0; r < 4; ++r) {
-      const int row = bi * 16 + l4 + 4 * r, col = bj * 16 + l15;
-      if (row >= col) out[(size_t)col * ldb + row] = (row == col) ? 1.0 : 0.0;
-    }
-    return;
+  const int wr = wave >> 1, wc = wave & 1;
+  if (tid < 4) {
+    lat_r[tid] = blk_lat[bi * 4 + tid]; col_r[tid] = blk_col[bi * 4 + tid];
+    lat_c[tid] = blk_lat[bj * 4 + tid]; col_c[tid] = blk_col[bj * 4 + tid];
   }
-  // A[i = l15][k = l4]: column (blk_col[bi] + l15) of F_ka at bin t0 + l4 ; B[k = l4][j = l15]: column of F_kb
-  const double* FA = F + (size_t)ka * Tf * Tf + (size_t)(blk_col[bi] + l15) * Tf + l4;
-  const double* FB = F + (size_t)kb * Tf * Tf + (size_t)(blk_col[bj] + l15) * Tf + l4;
-  const double* w = Wt + slot * sW + (size_t)ka * p + kb + (size_t)l4 * p * p;     // + t0*p*p
-  mdouble4 acc = {0.0, 0.0, 0.0, 0.0};
-  const int T4 = (T + 3) / 4 * 4;                       // F rows >= T are zero (slab is Tf >= T4 tall), wt guarded
-  for (int t0 = 0; t0 < T4; t0 += 4) {
-    const double wv = (t0 + l4 < T) ? w[(size_t)t0 * p * p] : 0.0;
-    const double a = FA[t0] * wv;
-    const double b = FB[t0];
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-  }
-  // D[row = l4 + 4r][col = l15] = B[(bi*16 + row), (bj*16 + col)]
+  __syncthreads();
+  const int lt = tid & 31, lc = tid >> 5;                // staging: bin lt, columns lc + 8 i
+  const double* srcR[8];
+  const double* srcC[8];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int row = bi * 16 + l4 + 4 * r, col = bj * 16 + l15;
-    if (row >= col) out[(size_t)col * ldb + row] = acc[r] + (row == col ? 1.0 : 0.0);
+  for (int i = 0; i < 8; ++i) {
+    const int cc = lc + 8 * i, blk = cc >> 4;
+    srcR[i] = lat_r[blk] < 0 ? nullptr : F + (size_t)lat_r[blk] * Tf * Tf + (size_t)(col_r[blk] + (cc & 15)) * Tf + lt;
+    srcC[i] = lat_c[blk] < 0 ? nullptr : F + (size_t)lat_c[blk] * Tf * Tf + (size_t)(col_c[blk] + (cc & 15)) * Tf + lt;
   }
+  const double* wsrc[2];
+  int wt_bin[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int e = tid + 256 * i, pr = e & 15;
+    const int la = lat_r[pr >> 2], lb = lat_c[pr & 3];
+    wt_bin[i] = e >> 4;
+    wsrc[i] = (la < 0 || lb < 0) ? nullptr : Wt + slot * sW + (size_t)wt_bin[i] * p * p + (size_t)la * p + lb;
+  }
+  mdouble4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = mdouble4{0.0, 0.0, 0.0, 0.0};
+
+  for (int t0 = 0; t0 < T; t0 += AB_TK) {                // panel rows T..Tf are zero, weights are guarded
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      FR[lt * AB_LD + lc + 8 * i] = srcR[i] ? srcR[i][t0] : 0.0;
+      FC[lt * AB_LD + lc + 8 * i] = srcC[i] ? srcC[i][t0] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      WL[tid + 256 * i] = (wsrc[i] && t0 + wt_bin[i] < T) ? wsrc[i][(size_t)t0 * p * p] : 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < AB_TK / 4; ++kk) {
+      const int tt = kk * 4 + l4;
+      const double r0 = FR[tt * AB_LD + wr * 32 + l15], r1 = FR[tt * AB_LD + wr * 32 + 16 + l15];
+      const double c0 = FC[tt * AB_LD + wc * 32 + l15], c1 = FC[tt * AB_LD + wc * 32 + 16 + l15];
+      const double* wl = WL + tt * 16 + (2 * wr) * 4 + 2 * wc;
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(c0 * wl[0], r0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(c1 * wl[1], r0, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(c0 * wl[4], r1, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(c1 * wl[5], r1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // accumulator: i (A side, column of B) = l4 + 4 r, j (B side, row of B) = l15
+  double* out = Bm + slot * sB;
+#pragma unroll
+  for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = bi * 64 + wr * 32 + ri * 16 + l15;
+        const int col = bj * 64 + wc * 32 + ci * 16 + l4 + 4 * r;
+        if (row >= col) out[(size_t)col * ldb + row] = acc[ri][ci][r] + (row == col ? 1.0 : 0.0);
+      }
 }
 
 // vsm[t] <- eps*G_t + G_t * Bt_t * G_t in place (Bt_t already in vsm, trial indexed); one thread per (slot,t)

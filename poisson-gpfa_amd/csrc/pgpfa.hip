@@ -977,8 +977,8 @@ static int shared_factor_lowrank(pgpfa_ctx* c, int nb) {
   }
   CholWS lw = c->sws;
   lw.ld = rpad; lw.npad = rpad; lw.nact = round_up(c->rtot, 64);
-  const int nblk16 = rpad / 16, npairs = nblk16 * (nblk16 + 1) / 2;
-  hipLaunchKernelGGL(assemble_b_kernel, dim3(npairs, 1), dim3(64), 0, c->st, lw.H, lw.sH, rpad, nblk16, c->Flr, c->Tp, T, p, c->d_blk_lat,
+  const int nblk64 = rpad / 64, npairs = nblk64 * (nblk64 + 1) / 2;
+  hipLaunchKernelGGL(assemble_b_kernel, dim3(npairs, 1), dim3(256), 0, c->st, lw.H, lw.sH, rpad, nblk64, c->Flr, c->Tp, T, p, c->d_blk_lat,
                      c->d_blk_col, c->Wtbar, 0LL, c->ident);
   HIPC(hipGetLastError());
   HIPC(hipMemsetAsync(c->sws.info, 0, sizeof(int), c->st));
@@ -1084,8 +1084,8 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp) {
   // b. B = I + F^T Wt F into the factor slabs viewed with ld = rpad; factor; L^-T
   CholWS lw = c->ws;
   lw.ld = rpad; lw.npad = rpad; lw.nact = round_up(c->rtot, 64);
-  const int nblk16 = rpad / 16, npairs = nblk16 * (nblk16 + 1) / 2;
-  hipLaunchKernelGGL(assemble_b_kernel, dim3(npairs, nb), dim3(64), 0, c->st, lw.H, lw.sH, rpad, nblk16, c->Flr, Tp, T, p, c->d_blk_lat,
+  const int nblk64 = rpad / 64, npairs = nblk64 * (nblk64 + 1) / 2;
+  hipLaunchKernelGGL(assemble_b_kernel, dim3(npairs, nb), dim3(256), 0, c->st, lw.H, lw.sH, rpad, nblk64, c->Flr, Tp, T, p, c->d_blk_lat,
                      c->d_blk_col, c->Wt, sW, c->ident);
   HIPC(hipGetLastError());
   HIPC(hipMemsetAsync(c->ws.info, 0, sizeof(int) * nb, c->st));
