@@ -41,11 +41,13 @@ int pgpfa_device_count(int* count);
 /* One fit = one context: sizes of experiment.data (engine.py:131-135), binSize in ms. */
 int pgpfa_create(pgpfa_ctx** out, int device, int q, int p, int T, int R, double bin_ms);
 int pgpfa_destroy(pgpfa_ctx* ctx);
-/* Options: "newton_xtol" (1e-5), "newton_max_iter" (50), "use_mfma" (1), "keep_vsmgp" (1),
+/* Options: "newton_xtol" (1e-5), "newton_max_iter" (50), "use_mfma" (1),
  * "chunk_trials" (0 = auto), "eps_noise" (1e-3, util.py:599), "chord" (1: reuse the first factor for
  * chord steps), "chord_xtol" (1e-9), "chord_rho" (0.6), "chord_max_step" (1.0), "profile" (0),
  * "shared_pcg" (1: phase-1 Newton with the shared preconditioner), "shared_min" (16), "pcg_inner" (8),
- * "pcg_outer_max" (12), "cov_mode" (0 auto, 1 dense, 2 low-rank covariance engine), "lowrank_tol" (1e-13). */
+ * "pcg_outer_max" (12), "cov_mode" (0 auto, 1 dense, 2 low-rank covariance engine), "lowrank_tol" (1e-13),
+ * "keep_trial_vsmgp" (0: the low-rank engine accumulates sum_r post_vsmGP_r for the tau M-step and rebuilds
+ * per-trial T x T blocks only when pgpfa_get_post_vsmgp asks for them; 1: store them in every E-step). */
 int pgpfa_set_option(pgpfa_ctx* ctx, const char* key, double value);
 /* Info: "chunk_trials", "plan_lowrank", "n_pad", "lowrank_rtot", "last_estep_ms", "last_newton_factorizations",
  * "last_newton_solves", "last_pcg_iterations", "last_shared_factorizations", "last_cov_lowrank",

@@ -45,7 +45,29 @@ struct GemmP {
   int mode, kflags;
   int tilesM, tilesN, ntiles;
   double flops_hint;    // algorithmic flops of the launch when the operands are block sparse (0: dense formula)
+  // optional two-level batch: entry b = hi * nb_lo + lo; `slots` maps lo, hi adds its own strides (nb_lo = 0: one level)
+  int nb_lo;
+  long long sA_hi, sB_hi, sC_hi;
+  // optional segmented K (TRANSB = 0 only): column k of A/B lives at (k / kseg) * s?seg + (k % kseg) * ld, i.e. the K
+  // dimension runs over kseg-wide panels of consecutive slabs (kseg multiple of 16; 0: plain)
+  int kseg;
+  long long sAseg, sBseg;
 };
+
+__device__ __forceinline__ size_t gemm_koff(int kseg, long long sseg, int ld, int k) {
+  if (kseg == 0) return (size_t)k * ld;
+  const int seg = k / kseg;
+  return (size_t)seg * sseg + (size_t)(k - seg * kseg) * ld;
+}
+
+__device__ __forceinline__ void gemm_bind(const GemmP& g, int b, const double*& A, const double*& B, double*& C) {
+  int lo = b, hi = 0;
+  if (g.nb_lo > 0) { hi = b / g.nb_lo; lo = b - hi * g.nb_lo; }
+  const long long slot = g.slots ? g.slots[lo] : lo;
+  A = g.A + slot * g.sA + hi * g.sA_hi;
+  B = g.B + slot * g.sB + hi * g.sB_hi;
+  C = g.C + slot * g.sC + hi * g.sC_hi;
+}
 
 __device__ __forceinline__ void gemm_decode_tile(const GemmP& g, int tile, int& ti, int& tj) {
   if (g.mode == GEMM_FULL) {
@@ -97,10 +119,10 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP g) {
   gemm_decode_block(g, blockIdx.x, b, tile);
   int ti, tj;
   gemm_decode_tile(g, tile, ti, tj);
-  const long long slot = g.slots ? g.slots[b] : b;
-  const double* A = g.A + slot * g.sA;
-  const double* B = g.B + slot * g.sB;
-  double* C = g.C + slot * g.sC;   // may alias A (in-place TRSM): no restrict
+  const double* A;
+  const double* B;
+  double* C;                       // may alias A (in-place TRSM): no restrict
+  gemm_bind(g, b, A, B, C);
 
   const int i0 = ti * GBM, j0 = tj * GBN;
   int kb = 0, ke = g.K;
@@ -122,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP g) {
       const int u = tid + 256 * s;
       {  // A: [k][row] ; unit -> k = u>>6, rows 2*(u&63), +1
         const int k = u >> 6, r2 = (u & 63) * 2;
-        const double* src = A + (size_t)(k0 + k) * g.lda + (i0 + r2);
+        const double* src = A + gemm_koff(g.kseg, g.sAseg, g.lda, k0) + (size_t)k * g.lda + (i0 + r2);
         if (a_vec) {
           const double2 v = *reinterpret_cast<const double2*>(src);
           ra[2 * s] = v.x; ra[2 * s + 1] = v.y;
@@ -132,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP g) {
       }
       if (TRANSB == 0) {
         const int k = u >> 6, r2 = (u & 63) * 2;
-        const double* src = B + (size_t)(k0 + k) * g.ldb + (j0 + r2);
+        const double* src = B + gemm_koff(g.kseg, g.sBseg, g.ldb, k0) + (size_t)k * g.ldb + (j0 + r2);
         if (b_vec) {
           const double2 v = *reinterpret_cast<const double2*>(src);
           rb[2 * s] = v.x; rb[2 * s + 1] = v.y;
@@ -240,10 +262,10 @@ __global__ void gemm_check_kernel(GemmP g) {
   gemm_decode_block(g, blockIdx.x, b, tile);
   int ti, tj;
   gemm_decode_tile(g, tile, ti, tj);
-  const long long slot = g.slots ? g.slots[b] : b;
-  const double* A = g.A + slot * g.sA;
-  const double* B = g.B + slot * g.sB;
-  double* C = g.C + slot * g.sC;
+  const double* A;
+  const double* B;
+  double* C;
+  gemm_bind(g, b, A, B, C);
   const int i0 = ti * GBM, j0 = tj * GBN;
   int kb = 0, ke = g.K;
   if (g.kflags & KF_BEGIN_ROW) kb = i0;
@@ -259,8 +281,8 @@ __global__ void gemm_check_kernel(GemmP g) {
     double s = 0.0;
     if (i < g.M && j < g.N) {
       for (int k = kb; k < ke; ++k) {
-        const double a = A[(size_t)k * g.lda + i];
-        const double bb = TRANSB ? B[(size_t)j * g.ldb + k] : B[(size_t)k * g.ldb + j];
+        const double a = A[gemm_koff(g.kseg, g.sAseg, g.lda, k) + i];
+        const double bb = TRANSB ? B[(size_t)j * g.ldb + k] : B[gemm_koff(g.kseg, g.sBseg, g.ldb, k) + j];
         s += a * bb;
       }
     }
@@ -310,6 +332,7 @@ inline hipError_t gemm_launch(hipStream_t st, bool use_mfma, bool transb, GemmP 
   g.tilesN = (g.N + GBN - 1) / GBN;
   g.ntiles = gemm_count_tiles(g.mode, g.tilesM, g.tilesN);
   if (g.ntiles <= 0 || g.nbatch <= 0 || g.M <= 0 || g.N <= 0) return hipSuccess;
+  if (g.kseg != 0 && (transb || g.kseg % GBK != 0)) return hipErrorInvalidValue;
   const long long blocks = (long long)g.ntiles * g.nbatch;
   dim3 grid((unsigned)blocks);
   if (use_mfma) {

@@ -514,6 +514,45 @@ __global__ void pautosum_kernel(const double* __restrict__ vsmgp, const double* 
   }
 }
 
+// Sum-only form of the above for the low-rank engine (no per-trial T x T blocks are stored): the E-step accumulates
+//   Pacc[k] += sum_slots Ymix_k Ymix_k^T + eps * diag(sum_slots G_t[k][k])
+// from split-K partial products part[k][split] (lower triangle valid, ld = T); grid = (T, p), block = 128
+__global__ void pacc_reduce_kernel(const double* __restrict__ part, int nsplit, const double* __restrict__ G, long long sG, int nslots,
+                                   double eps, int T, int Tp, int p, double* __restrict__ Pacc) {
+  const int k = blockIdx.y, b = blockIdx.x;
+  double* P = Pacc + (size_t)k * Tp * Tp;
+  const double* src = part + (size_t)k * nsplit * T * T + (size_t)b * T;
+  for (int a = b + threadIdx.x; a < T; a += blockDim.x) {
+    double s = 0.0;
+    for (int i = 0; i < nsplit; ++i) s += src[(size_t)i * T * T + a];
+    if (a == b) {
+      double g = 0.0;
+      for (int sl = 0; sl < nslots; ++sl) g += G[(size_t)sl * sG + (size_t)a * p * p + (size_t)k * p + k];
+      s += eps * g;
+    }
+    P[(size_t)b * Tp + a] += s;
+    if (a != b) P[(size_t)a * Tp + b] += s;
+  }
+}
+
+// PautoSum[k] = Pacc[k] + sum_r m_rk m_rk^T  (same output layout as pautosum_kernel); grid = (Tp, p)
+__global__ void pauto_from_acc_kernel(const double* __restrict__ Pacc, const double* __restrict__ mean, const int* __restrict__ trials,
+                                      int ntr, int T, int Tp, int p, double* __restrict__ P) {
+  const int k = blockIdx.y;
+  const int b = blockIdx.x;
+  for (int a = threadIdx.x; a < Tp; a += blockDim.x) {
+    double s = 0.0;
+    if (a < T && b < T) {
+      s = Pacc[(size_t)k * Tp * Tp + (size_t)b * Tp + a];
+      for (int i = 0; i < ntr; ++i) {
+        const double* m = mean + ((size_t)trials[i] * p + k) * T;
+        s += m[a] * m[b];
+      }
+    }
+    P[(size_t)k * Tp * Tp + (size_t)b * Tp + a] = s;
+  }
+}
+
 // --------------------------------------------------------------------------------------------------
 // (C,d) M-step pass, learning.MStepObservationCost(_grad) learning.py:20-91:
 //   hh = c_n.m_t + d_n ; u = V_t c_n ; rho = c_n.u ; yhat = exp(hh + rho/2)

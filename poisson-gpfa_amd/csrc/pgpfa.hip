@@ -57,6 +57,7 @@ struct Prof {
   std::vector<Rec> recs;
   std::map<int, double> ms, flops, count;
 };
+constexpr int PACC_SPLITS = 64;   // split-K groups of the sum-only vsmGP product
 enum { TAG_GEMM = 0, TAG_POTRF = 1, TAG_SOLVE = 2, TAG_POISSON = 3, TAG_ASSEMBLE = 4, TAG_VSM = 5, TAG_CD = 6, TAG_N };
 
 }  // namespace
@@ -81,6 +82,15 @@ struct pgpfa_ctx {
   double* vsm = nullptr;                         // [R][T][p][p]
   double* vsmgp = nullptr;                       // [R][p][T][T]
   double* Pauto = nullptr;                       // [p][Tp][Tp]
+  // sum-only covariance output of the low-rank engine (option keep_trial_vsmgp = 0): the E-step accumulates
+  // sum_r Sigma_r^{kk} here instead of storing R x p blocks of T x T; per-trial blocks are rebuilt on request
+  double* Pacc = nullptr;                        // [p][Tp][Tp]
+  double* ppart = nullptr;                       // [p][PACC_SPLITS + 1][T x T] split-K partial products
+  bool keep_trial_vsmgp = false;
+  bool pacc_used = false, pacc_valid = false;
+  std::vector<char> vsmgp_ok;                    // per trial: c->vsmgp holds the blocks of the resident posterior
+  std::vector<double> hC, hd, htau;              // parameters as last set / as they were at the last E-step
+  std::vector<double> eC, ed, etau;
   double *vec = nullptr, *cdpart = nullptr, *cdout = nullptr;
   double *cdhpart = nullptr, *cdhout = nullptr, *cdcenter = nullptr, *cddelta = nullptr, *cddec = nullptr;   // Newton M-step
   int* last_trials = nullptr;                    // device list of the trials of the last E-step
@@ -678,6 +688,9 @@ int pgpfa_create(pgpfa_ctx** out, int device, int q, int p, int T, int R, double
   rc |= dmalloc(c, &c->vsm, (size_t)R * T * p * p + 2048, true);
   rc |= dmalloc(c, &c->vsmgp, (size_t)R * p * T * T, true);
   rc |= dmalloc(c, &c->Pauto, slab * p, true);
+  rc |= dmalloc(c, &c->Pacc, slab * p, true);
+  rc |= dmalloc(c, &c->ppart, (size_t)p * (PACC_SPLITS + 1) * T * T + 256);
+  c->vsmgp_ok.assign(R, 0);
   rc |= dmalloc(c, &c->Flr, slab * p + 256 * (size_t)c->Tp, true);
   rc |= dmalloc(c, &c->d_rank, p); rc |= dmalloc(c, &c->d_roff, p + 1);
   rc |= dmalloc(c, &c->d_kr_ft, 2 * (size_t)(c->ld / NB + 2)); rc |= dmalloc(c, &c->d_kr_f, 2 * (size_t)(c->ld / NB + 2));
@@ -731,6 +744,7 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
   else if (k == "shared_pcg") c->shared_pcg = (v != 0.0);
   else if (k == "cov_mode") c->cov_mode = (int)v;
   else if (k == "lowrank_tol") c->lr_tol = v;
+  else if (k == "keep_trial_vsmgp") c->keep_trial_vsmgp = (v != 0.0);
   else if (k == "shared_min") c->shared_min = (int)v;
   else if (k == "pcg_inner") c->pcg_inner = (int)v;
   else if (k == "pcg_outer_max") c->pcg_outer_max = (int)v;
@@ -814,6 +828,11 @@ int pgpfa_set_params(pgpfa_ctx* c, const double* C, const double* d, const doubl
   CHK(upload(c, c->C, C, (size_t)c->q * c->p));
   CHK(upload(c, c->d, d, c->q));
   CHK(upload(c, c->tau, tau_s, c->p));
+  {
+    // (the arguments may alias the stored copies: pgpfa_set_params(c, c->eC.data(), ...) restores a snapshot)
+    std::vector<double> nC(C, C + (size_t)c->q * c->p), nd(d, d + c->q), nt(tau_s, tau_s + c->p);
+    c->hC.swap(nC); c->hd.swap(nd); c->htau.swap(nt);
+  }
   hipLaunchKernelGGL(gram_tau_kernel, dim3(c->Tp, c->p), dim3(256), 0, c->st, c->Kpad, c->Tp, c->T, c->tau, c->bin, c->eps);
   HIPC(hipGetLastError());
   CHK(build_kinv(c));
@@ -917,6 +936,7 @@ int pgpfa_set_modes(pgpfa_ctx* c, int n, const int32_t* idx, const double* X) {
   for (size_t i = 0; i < tr.v.size(); ++i)
     HIPC(hipMemcpyAsync(c->Xmode + (size_t)tr.v[i] * c->n, X + i * c->n, c->n * sizeof(double), hipMemcpyHostToDevice, c->st));
   HIPC(hipStreamSynchronize(c->st));
+  c->pacc_valid = false;          // the accumulated covariance sum belonged to the modes just overwritten
   return 0;
 }
 
@@ -925,6 +945,7 @@ static int remember_trials(pgpfa_ctx* c, const std::vector<int>& v) {
   CHK(upload_list(c, c->last_trials, v));
   c->have_post = true;
   c->have_precomp = false;
+  c->pacc_valid = false;
   return 0;
 }
 
@@ -1068,7 +1089,7 @@ static int posterior_blocks_dense(pgpfa_ctx* c, int nb, double diag_scale, bool 
 
 // Covariance blocks through the low-rank form of the prior (see model.h): per slot an r x r SPD system
 // B = I + F^T Wt F instead of the n x n Hessian.  Uses the dense engine's slabs as scratch (ld = rpad views).
-static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp) {
+static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool accumulate) {
   const int T = c->T, p = c->p, Tp = c->Tp, pp = p * p;
   const int rpad = c->rpad;
   const long long sW = (long long)T * pp;
@@ -1128,27 +1149,51 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp) {
                            T, p, rpad, c->ident);
     });
     if (p > 16) return fail("low-rank covariance engine supports up to 16 latents (p=%d)", p);
-    const size_t off_stage = (size_t)c->ld * rpad + (size_t)Tp * rpad;
-    for (int k = 0; k < p; ++k) {
-      GemmP g{};
-      g.A = lw.H + (size_t)k * T; g.sA = lw.sH; g.lda = c->ld;
-      g.B = g.A; g.sB = lw.sH; g.ldb = c->ld;
-      g.C = lw.H + off_stage; g.sC = lw.sH; g.ldc = T;
-      g.M = T; g.N = T; g.K = rpad; g.alpha = 1.0; g.beta = 0.0;
-      g.slots = c->ident; g.nbatch = nb; g.mode = GEMM_LOWER; g.kflags = 0;
-      CHK(gemm(c, false, g));
-      hipLaunchKernelGGL(scatter_vsmgp_lr_kernel, dim3((unsigned)(((size_t)T * T + 255) / 256), nb), dim3(256), 0, c->st, lw.H + off_stage, lw.sH, T,
-                         c->vsmgp, T, p, k, c->Gbin, sW, c->eps, c->trial_of_slot);
+    if (accumulate) {
+      // sum-only output: Pacc[k] += sum over the chunk's slots of Ymix_k Ymix_k^T as ONE split-K product per launch -
+      // batch = (latent, group of `sps` consecutive slots), the K dimension walks the rpad-wide panels of the
+      // group's slabs - followed by a reduction of the partial products (+ the eps G_t[k][k] diagonals)
+      const int sps = std::max(1, (nb + PACC_SPLITS - 1) / PACC_SPLITS);
+      const int nfull = nb / sps, rem = nb - nfull * sps, nsplit = nfull + (rem ? 1 : 0);
+      auto launch = [&](int first_slot, int slots_per, int ngroups, int part_first) -> int {
+        GemmP g{};
+        g.A = lw.H + (size_t)first_slot * lw.sH; g.sA = (long long)slots_per * lw.sH; g.lda = c->ld;
+        g.B = g.A; g.sB = g.sA; g.ldb = c->ld;
+        g.C = c->ppart + (size_t)part_first * T * T; g.sC = (long long)T * T; g.ldc = T;
+        g.M = T; g.N = T; g.K = slots_per * rpad; g.alpha = 1.0; g.beta = 0.0;
+        g.slots = nullptr; g.nb_lo = ngroups; g.nbatch = ngroups * p;
+        g.sA_hi = T; g.sB_hi = T; g.sC_hi = (long long)nsplit * T * T;
+        g.kseg = rpad; g.sAseg = lw.sH; g.sBseg = lw.sH;
+        g.mode = GEMM_LOWER; g.kflags = 0;
+        return gemm(c, false, g);
+      };
+      if (nfull) CHK(launch(0, sps, nfull, 0));
+      if (rem) CHK(launch(nfull * sps, rem, 1, nfull));
+      hipLaunchKernelGGL(pacc_reduce_kernel, dim3(T, p), dim3(128), 0, c->st, c->ppart, nsplit, c->Gbin, sW, nb, c->eps, T, Tp, p, c->Pacc);
+      c->pacc_used = true;
+    } else {
+      const size_t off_stage = (size_t)c->ld * rpad + (size_t)Tp * rpad;
+      for (int k = 0; k < p; ++k) {
+        GemmP g{};
+        g.A = lw.H + (size_t)k * T; g.sA = lw.sH; g.lda = c->ld;
+        g.B = g.A; g.sB = lw.sH; g.ldb = c->ld;
+        g.C = lw.H + off_stage; g.sC = lw.sH; g.ldc = T;
+        g.M = T; g.N = T; g.K = rpad; g.alpha = 1.0; g.beta = 0.0;
+        g.slots = c->ident; g.nbatch = nb; g.mode = GEMM_LOWER; g.kflags = 0;
+        CHK(gemm(c, false, g));
+        hipLaunchKernelGGL(scatter_vsmgp_lr_kernel, dim3((unsigned)(((size_t)T * T + 255) / 256), nb), dim3(256), 0, c->st, lw.H + off_stage, lw.sH, T,
+                           c->vsmgp, T, p, k, c->Gbin, sW, c->eps, c->trial_of_slot);
+      }
     }
   }
   HIPC(hipGetLastError());
   return 0;
 }
 
-static int posterior_blocks(pgpfa_ctx* c, int nb, double diag_scale, bool want_vsmgp) {
+static int posterior_blocks(pgpfa_ctx* c, int nb, double diag_scale, bool want_vsmgp, bool accumulate = false) {
   if (c->plan_lowrank) {
     if (diag_scale != 1.0) return fail("internal: jittered covariance requested under the low-rank workspace plan");
-    return posterior_blocks_lowrank(c, nb, want_vsmgp);
+    return posterior_blocks_lowrank(c, nb, want_vsmgp, accumulate);
   }
   return posterior_blocks_dense(c, nb, diag_scale, want_vsmgp);
 }
@@ -1371,7 +1416,11 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
     }
 
     // posterior covariance blocks at the mode
-    CHK(posterior_blocks(c, nb, 1.0, true));
+    {
+      const bool sum_only = c->plan_lowrank && !c->keep_trial_vsmgp;
+      CHK(posterior_blocks(c, nb, 1.0, true, sum_only));
+      for (int t : tos) c->vsmgp_ok[t] = sum_only ? 0 : 1;
+    }
     n_fact += nb;
     for (int s = 0; s < nb; ++s) its[s] += 1;
     hipLaunchKernelGGL(scatter_rows_kernel, dim3((nvec + 255) / 256, nb), dim3(256), 0, c->st, c->Xc, ld, nvec, c->Xmode, c->trial_of_slot);
@@ -1404,6 +1453,10 @@ int pgpfa_estep_laplace(pgpfa_ctx* c, int n, const int32_t* idx, int warm_start,
   const int N = (int)tr.v.size();
   std::vector<int32_t> it1(N), st1(N);
   double obj = 0.0;
+  HIPC(hipSetDevice(c->device));
+  c->pacc_used = false; c->pacc_valid = false;
+  HIPC(hipMemsetAsync(c->Pacc, 0, (size_t)c->Tp * c->Tp * c->p * sizeof(double), c->st));
+  c->eC = c->hC; c->ed = c->hd; c->etau = c->htau;
   CHK(estep_impl(c, tr, warm_start, true, &obj, it1.data(), st1.data()));
   // trials the low-rank plan could not finish (its shared-preconditioner Newton gave up on them and the per-trial
   // fallback needs full-size slabs) are redone under the dense plan, warm-started from where they stopped
@@ -1431,6 +1484,7 @@ int pgpfa_estep_laplace(pgpfa_ctx* c, int n, const int32_t* idx, int warm_start,
     c->info["last_dense_retries"] = 0.0;
   }
   CHK(remember_trials(c, tr.v));
+  c->pacc_valid = c->pacc_used && retry.v.empty();
   if (obj_sum) *obj_sum = obj;
   for (int i = 0; i < N; ++i) {
     if (iters) iters[i] = it1[i];
@@ -1454,11 +1508,55 @@ int pgpfa_get_post_vsm(pgpfa_ctx* c, int n, const int32_t* idx, double* out) {
   return get_rows(c, n, idx, c ? c->vsm : nullptr, c ? (size_t)c->T * c->p * c->p : 0, out);
 }
 
+// Rebuild the per-trial T x T blocks of trials whose last E-step ran sum-only: covariance blocks at the resident
+// modes, under the parameters of that E-step (restored around the call when an M-step has moved on since).
+static int materialize_impl(pgpfa_ctx* c, const std::vector<int>& need) {
+  CHK(ready_estep(c, true));
+  const int N = (int)need.size();
+  std::vector<int> info(c->B);
+  for (int c0 = 0; c0 < N; c0 += c->B) {
+    const int nb = std::min(c->B, N - c0);
+    std::vector<int> tos(need.begin() + c0, need.begin() + c0 + nb);
+    CHK(upload_list(c, c->trial_of_slot, tos));
+    HIPC(hipMemsetAsync(c->ws.info, 0, sizeof(int) * nb, c->st));
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((c->n + 255) / 256, nb), dim3(256), 0, c->st, c->Xmode, c->n, c->Xc, (long long)c->ld,
+                       c->trial_of_slot, 0);
+    CHK(poisson(c, c->ident, nb, c->Xc, c->Gl, c->W, c->sc_f, 1));
+    CHK(posterior_blocks(c, nb, 1.0, true, false));
+    HIPC(hipMemcpyAsync(info.data(), c->ws.info, sizeof(int) * nb, hipMemcpyDeviceToHost, c->st));
+    HIPC(hipStreamSynchronize(c->st));
+    for (int s = 0; s < nb; ++s) {
+      if (info[s] != 0) return fail("posterior precision of trial %d is not positive definite at the resident mode", tos[s]);
+      c->vsmgp_ok[tos[s]] = 1;
+    }
+  }
+  return 0;
+}
+
+static int ensure_trial_vsmgp(pgpfa_ctx* c, const std::vector<int>& trials) {
+  std::vector<int> need;
+  for (int t : trials)
+    if (!c->vsmgp_ok[t] && std::find(need.begin(), need.end(), t) == need.end()) need.push_back(t);
+  if (need.empty()) return 0;
+  if (c->eC.empty()) return fail("post_vsmGP of trial %d is not resident: no E-step or pgpfa_set_posterior produced it", need[0]);
+  const bool moved = (c->hC != c->eC || c->hd != c->ed || c->htau != c->etau);
+  const std::vector<double> curC = c->hC, curd = c->hd, curtau = c->htau;
+  const std::vector<double> oldC = c->eC, oldd = c->ed, oldtau = c->etau;
+  if (moved) CHK(pgpfa_set_params(c, oldC.data(), oldd.data(), oldtau.data()));
+  int rc = materialize_impl(c, need);
+  if (moved) {
+    const int rc2 = pgpfa_set_params(c, curC.data(), curd.data(), curtau.data());
+    if (!rc) rc = rc2;
+  }
+  return rc;
+}
+
 int pgpfa_get_post_vsmgp(pgpfa_ctx* c, int n, const int32_t* idx, double* out) {
   if (!c || !out) return fail("null argument");
   HIPC(hipSetDevice(c->device));
   Trials tr;
   CHK(resolve_trials(c, n, idx, &tr));
+  CHK(ensure_trial_vsmgp(c, tr.v));
   const size_t len = (size_t)c->T * c->T * c->p;
   double* tmp = nullptr;
   HIPC(hipMalloc((void**)&tmp, len * sizeof(double)));
@@ -1519,6 +1617,7 @@ int pgpfa_set_posterior(pgpfa_ctx* c, int n, const int32_t* idx, const double* p
   hipStreamSynchronize(c->st);
   if (tmp) hipFree(tmp);
   HIPC(hipGetLastError());
+  for (int t : tr.v) c->vsmgp_ok[t] = 1;          // whatever the caller provided (or left) is the resident value
   return remember_trials(c, tr.v);
 }
 
@@ -1648,7 +1747,13 @@ int pgpfa_mstep_precomp(pgpfa_ctx* c, double* num_trials) {
   if (!c->have_post) return fail("no E-step result resident");
   HIPC(hipSetDevice(c->device));
   const int ntr = (int)c->last_trials_h.size();
-  hipLaunchKernelGGL(pautosum_kernel, dim3(c->Tp, c->p), dim3(128), 0, c->st, c->vsmgp, c->Xmode, c->last_trials, ntr, c->T, c->Tp, c->p, c->Pauto);
+  if (c->pacc_valid) {
+    hipLaunchKernelGGL(pauto_from_acc_kernel, dim3(c->Tp, c->p), dim3(128), 0, c->st, c->Pacc, c->Xmode, c->last_trials, ntr, c->T, c->Tp, c->p,
+                       c->Pauto);
+  } else {
+    CHK(ensure_trial_vsmgp(c, c->last_trials_h));
+    hipLaunchKernelGGL(pautosum_kernel, dim3(c->Tp, c->p), dim3(128), 0, c->st, c->vsmgp, c->Xmode, c->last_trials, ntr, c->T, c->Tp, c->p, c->Pauto);
+  }
   HIPC(hipGetLastError());
   const size_t len = (size_t)c->Tp * c->Tp * c->p;
   CHK(allreduce_dev(c, c->Pauto, len));
@@ -1872,6 +1977,7 @@ int pgpfa_dual_finalize(pgpfa_ctx* c, int n, const int32_t* idx, const double* l
     // posterior mean -K C_big (lambda - y) (inference.py:194) and covariance blocks (inference.py:188-191)
     hipLaunchKernelGGL(negate_rows_kernel, dim3((c->n + 255) / 256, nb), dim3(256), 0, c->st, c->KD, ld, c->Xc, ld, c->n, c->ident);
     CHK(posterior_blocks(c, nb, 1.0 + 1e-6, true));
+    for (int t : tos) c->vsmgp_ok[t] = 1;
     hipLaunchKernelGGL(scatter_rows_kernel, dim3((c->n + 255) / 256, nb), dim3(256), 0, c->st, c->Xc, ld, c->n, c->Xmode, c->trial_of_slot);
     // negLogPosteriorUnNorm at the VI mean (inference.py:333)
     CHK(prior_mv(c, c->ident, nb, c->Xc, c->KX));

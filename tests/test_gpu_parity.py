@@ -395,3 +395,44 @@ def test_lowrank_plan_dense_retry(c1):
         assert abs(obj2 - obj) <= 1e-9 * abs(obj)
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize('R_use', [20, 7])
+def test_sum_only_covariance_output_matches_per_trial_blocks(c1, R_use):
+    """keep_trial_vsmgp = 0 (default): the low-rank engine accumulates sum_r post_vsmGP_r inside the E-step (split-K
+    product over the slots) and rebuilds per-trial blocks on request - also after the parameters have moved on."""
+    from funs import _hip
+    idx = np.arange(R_use, dtype=np.int32)
+    ref = {}
+    for keep in (1, 0):
+        ctx = _hip.Context(30, 3, 100, 20, c1['binSize'])
+        try:
+            ctx.upload_counts(c1['Y'])
+            ctx.set_option('cov_mode', 2)
+            ctx.set_option('keep_trial_vsmgp', keep)
+            ctx.set_params(c1['init_C'], c1['init_d'], c1['init_tau'])
+            obj, _, status = ctx.estep_laplace(idx)
+            assert np.all(status == 0) and ctx.info('last_cov_lowrank') == 1.0
+            n = ctx.mstep_precomp()
+            assert n == R_use
+            P = ctx.pautosum()
+            if keep:
+                ref['P'], ref['gp'], ref['obj'] = P, ctx.post_vsmgp(idx), obj
+                continue
+            assert abs(obj - ref['obj']) <= 1e-12 * abs(obj)
+            assert rel(P, ref['P']) <= 1e-11
+            # the M-step moves the parameters; the blocks of the E-step above must still come back
+            ctx.set_params(c1['init_C'] * 1.1, c1['init_d'] - 0.05, c1['init_tau'] * 1.3)
+            K_new = ctx.gram()
+            gp = ctx.post_vsmgp(idx[::3])
+            assert rel(gp, ref['gp'][::3]) <= 1e-10
+            assert np.array_equal(ctx.gram(), K_new)            # current parameters restored
+            # general precomp path (sum over materialised blocks) after the fast path was invalidated
+            ctx.set_posterior(idx, ctx.post_mean(idx), ctx.post_vsm(idx), ctx.post_vsmgp(idx))
+            ctx.mstep_precomp()
+            assert rel(ctx.pautosum(), ref['P']) <= 1e-10
+        finally:
+            ctx.close()
+    res, _, _ = orc.laplace(c1['Ys'][:R_use], c1['init'], c1['binSize'], mode='exact', return_cov=False)
+    P_o, _ = orc.make_precomp(res)
+    assert rel(ref['P'], P_o) <= 1e-8
