@@ -1278,30 +1278,61 @@ __global__ __launch_bounds__(256) void assemble_b_kernel(double* __restrict__ Bm
       }
 }
 
-// vsm[t] <- eps*G_t + G_t * Bt_t * G_t in place (Bt_t already in vsm, trial indexed); one thread per (slot,t)
-__global__ void vsm_finish_kernel(double* __restrict__ vsm, const double* __restrict__ G, long long sG, int T, int p, double eps,
-                                  const int* __restrict__ slots, const int* __restrict__ trial_of_slot, int nslots) {
-  extern __shared__ double sm[];
+// vsm[t] <- eps*G_t + G_t * Bt_t * G_t in place (Bt_t already in vsm, trial indexed).  One thread per matrix ROW:
+// a block stages the V and G blocks of 256/PW consecutive bins of one slot in LDS (coalesced reads, re-laid out to
+// a zero-padded PW x PW stride so the loops are unrolled without guards), thread (bin, i) forms row i of Bt G, then
+// row i of eps G + G (Bt G), and writes its row back.  grid = (ceil(T / (256/PW)), nslots), block = 256, p <= PW.
+template <int PW>
+__global__ __launch_bounds__(256) void vsm_finish_kernel(double* __restrict__ vsm, const double* __restrict__ G, long long sG, int T, int p,
+                                                         double eps, const int* __restrict__ slots, const int* __restrict__ trial_of_slot) {
+  constexpr int PP = PW * PW, BT = 256 / PW;
+  __shared__ double Vs[BT * PP];
+  __shared__ double Gs[BT * PP];
   const int pp = p * p;
-  double* tmp = sm + (size_t)threadIdx.x * (pp + 1);
-  const long long item = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (item >= (long long)nslots * T) return;
-  const int slot = slots[item / T];
-  const int t = (int)(item % T);
-  const double* g = G + (size_t)slot * sG + (size_t)t * pp;
-  double* v = vsm + ((size_t)trial_of_slot[slot] * T + t) * pp;
-  for (int i = 0; i < p; ++i)
-    for (int j = 0; j < p; ++j) {
-      double s = 0.0;
-      for (int m = 0; m < p; ++m) s += v[i * p + m] * g[m * p + j];
-      tmp[i * p + j] = s;                                  // Bt G
+  const int slot = slots[blockIdx.y];
+  const int t0 = blockIdx.x * BT;
+  const int nt = min(BT, T - t0);
+  const double* gbase = G + (size_t)slot * sG + (size_t)t0 * pp;
+  double* vbase = vsm + ((size_t)trial_of_slot[slot] * T + t0) * pp;
+  if (p < PW)
+    for (int e = threadIdx.x; e < BT * PP; e += 256) { Vs[e] = 0.0; Gs[e] = 0.0; }
+  __syncthreads();
+  for (int e = threadIdx.x; e < nt * pp; e += 256) {
+    const int t = e / pp, idx = e - t * pp, i = idx / p, j = idx - i * p;
+    Vs[t * PP + i * PW + j] = vbase[e];
+    Gs[t * PP + i * PW + j] = gbase[e];
+  }
+  __syncthreads();
+  const int bt = threadIdx.x / PW, i = threadIdx.x - bt * PW;
+  const bool live = bt < nt && i < p;
+  const double* g = Gs + bt * PP;
+  double* v = Vs + bt * PP;
+  double row[PW], acc[PW];
+  if (live) {
+#pragma unroll
+    for (int m = 0; m < PW; ++m) row[m] = v[i * PW + m];
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+      double sacc = 0.0;
+#pragma unroll
+      for (int m = 0; m < PW; ++m) sacc += row[m] * g[m * PW + j];
+      acc[j] = sacc;
     }
-  for (int i = 0; i < p; ++i)
-    for (int j = 0; j < p; ++j) {
-      double s = eps * g[i * p + j];
-      for (int m = 0; m < p; ++m) s += g[i * p + m] * tmp[m * p + j];
-      v[i * p + j] = s;
+#pragma unroll
+    for (int j = 0; j < PW; ++j) v[i * PW + j] = acc[j];       // row i of Bt G (only this thread reads row i of V)
+  }
+  __syncthreads();
+  if (live) {
+#pragma unroll
+    for (int m = 0; m < PW; ++m) row[m] = g[i * PW + m];
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+      double sacc = eps * row[j];
+#pragma unroll
+      for (int m = 0; m < PW; ++m) sacc += row[m] * v[m * PW + j];
+      if (j < p) vbase[(size_t)bt * pp + i * p + j] = sacc;
     }
+  }
 }
 
 // In-place mixing of Yt (n x rpad, ld = ldy): for every bin t and column b the p-vector y = Yt[(.,t), b] is replaced
@@ -1366,22 +1397,48 @@ __global__ void build_fbig_kernel(const double* __restrict__ F, int Tf, int T, c
 }
 
 // out[slot][(k,t)] = sum_k' Gb[t][k][k'] * (scale * a[slot][(k',t)] + b[slot][(k',t)])   (b may be null)
-// Gb is ONE set of per-bin p x p blocks shared by all slots; grid = (ceil(T/64), nslots), block = 64 (lanes = bins)
-__global__ void apply_bin_kernel(const double* __restrict__ Gb, const double* __restrict__ A, const double* __restrict__ B2, double scale,
-                                 double* __restrict__ out, long long sV, int T, int p) {
-  const size_t slot = blockIdx.y;
-  const int t = blockIdx.x * 64 + threadIdx.x;
-  if (t >= T) return;
-  const double* g = Gb + (size_t)t * p * p;
-  const double* a = A + slot * sV + t;
-  const double* b = B2 ? B2 + slot * sV + t : nullptr;
-  double* o = out + slot * sV + t;
-  double v[32];
-  for (int k = 0; k < p; ++k) v[k] = scale * a[(size_t)k * T] + (b ? b[(size_t)k * T] : 0.0);
-  for (int k = 0; k < p; ++k) {
-    double s = 0.0;
-    for (int kk = 0; kk < p; ++kk) s += g[k * p + kk] * v[kk];
-    o[(size_t)k * T] = s;
+// Gb is ONE set of per-bin p x p blocks shared by all slots: a block stages the blocks of 64 bins in LDS once
+// (zero-padded PW x PW, odd stride) and its 4 waves walk APPLY_BIN_SLOTS slots with lanes = bins.
+// grid = (ceil(T/64), ceil(nslots / APPLY_BIN_SLOTS)), block = 256, p <= PW.
+constexpr int APPLY_BIN_SLOTS = 16;
+template <int PW>
+__global__ __launch_bounds__(256) void apply_bin_kernel(const double* __restrict__ Gb, const double* __restrict__ A, const double* __restrict__ B2,
+                                                        double scale, double* __restrict__ out, long long sV, int T, int p, int nslots) {
+  constexpr int PP = PW * PW, LD = PP + 1;
+  __shared__ double Gs[64 * LD];
+  const int pp = p * p;
+  const int t0 = blockIdx.x * 64;
+  const int nt = min(64, T - t0);
+  if (p < PW)
+    for (int e = threadIdx.x; e < 64 * LD; e += 256) Gs[e] = 0.0;
+  __syncthreads();
+  for (int e = threadIdx.x; e < nt * pp; e += 256) {
+    const int t = e / pp, idx = e - t * pp, i = idx / p, j = idx - i * p;
+    Gs[t * LD + i * PW + j] = Gb[(size_t)t0 * pp + e];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane >= nt) return;
+  const int t = t0 + lane;
+  const double* g = Gs + lane * LD;
+  const int s_end = min(nslots, (int)(blockIdx.y + 1) * APPLY_BIN_SLOTS);
+  for (int sl = blockIdx.y * APPLY_BIN_SLOTS + wave; sl < s_end; sl += 4) {
+    const double* a = A + (size_t)sl * sV + t;
+    const double* b = B2 ? B2 + (size_t)sl * sV + t : nullptr;
+    double* o = out + (size_t)sl * sV + t;
+    double v[PW];
+#pragma unroll
+    for (int k = 0; k < PW; ++k) {
+      v[k] = 0.0;
+      if (k < p) v[k] = scale * a[(size_t)k * T] + (b ? b[(size_t)k * T] : 0.0);
+    }
+#pragma unroll
+    for (int k = 0; k < PW; ++k) {
+      double acc = 0.0;
+#pragma unroll
+      for (int kk = 0; kk < PW; ++kk) acc += g[k * PW + kk] * v[kk];
+      if (k < p) o[(size_t)k * T] = acc;
+    }
   }
 }
 
@@ -1394,6 +1451,16 @@ __global__ void pack_counts_kernel(const double* __restrict__ src, uint8_t* __re
   dst[i] = (uint8_t)v;
 }
 
+// p[slot * stride + i] = v for i < n; grid = (ceil(n/1024), nslots), block = 256, 4 elements per thread
+__global__ void fill_slabs_kernel(double* __restrict__ p, long long stride, size_t n, double v) {
+  double* dst = p + (size_t)blockIdx.y * stride;
+  const size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const size_t i = base + 256 * u;
+    if (i < n) dst[i] = v;
+  }
+}
 __global__ void fill_kernel(double* __restrict__ p, size_t n, double v) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;

@@ -958,7 +958,15 @@ static int shared_solve(pgpfa_ctx* c, int nb, const double* R, double* Z) {
   if (c->plan_lowrank) {
     const long long ld = c->ld;
     const int rpad = c->rpad;
-    hipLaunchKernelGGL(apply_bin_kernel, dim3((c->T + 63) / 64, nb), dim3(64), 0, c->st, c->Gbar, R, (const double*)nullptr, 1.0, c->Xt, ld, c->T, c->p);
+    auto apply_bin = [&](const double* a, const double* b2, double scale, double* o) {
+      dispatch_pw(c->p, [&](auto pw) {
+        constexpr int PW = decltype(pw)::value;
+        if constexpr (PW <= 16)
+          hipLaunchKernelGGL(apply_bin_kernel<PW>, dim3((c->T + 63) / 64, (nb + APPLY_BIN_SLOTS - 1) / APPLY_BIN_SLOTS), dim3(256), 0, c->st, c->Gbar,
+                             a, b2, scale, o, ld, c->T, c->p, nb);
+      });
+    };
+    apply_bin(R, nullptr, 1.0, c->Xt);
     GemmP y{};                                               // Y = F^T (Gb R)          (rpad x nb)
     y.A = c->FTbig; y.sA = 0; y.lda = rpad; y.B = c->Xt; y.sB = 0; y.ldb = c->ld; y.C = c->Glt; y.sC = 0; y.ldc = c->ld;
     y.M = rpad; y.N = nb; y.K = c->npad; y.alpha = 1.0; y.beta = 0.0; y.slots = nullptr; y.nbatch = 1; y.mode = GEMM_FULL; y.kflags = 0;
@@ -973,7 +981,7 @@ static int shared_solve(pgpfa_ctx* c, int nb, const double* R, double* Z) {
     q.M = c->n; q.N = nb; q.K = rpad; q.alpha = 1.0; q.beta = 0.0; q.slots = nullptr; q.nbatch = 1; q.mode = GEMM_FULL; q.kflags = 0;
     q.krange = c->d_kr_f; q.flops_hint = 2.0 * c->T * c->rtot * nb;
     CHK(gemm(c, true, q));
-    hipLaunchKernelGGL(apply_bin_kernel, dim3((c->T + 63) / 64, nb), dim3(64), 0, c->st, c->Gbar, R, c->Xt, c->eps, Z, ld, c->T, c->p);
+    apply_bin(R, c->Xt, c->eps, Z);
     HIPC(hipGetLastError());
     return 0;
   }
@@ -1112,7 +1120,8 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool 
   HIPC(hipMemsetAsync(c->ws.info, 0, sizeof(int) * nb, c->st));
   CHK(factor(c, lw, c->ident, nb));
   c->mt_dirty = true;
-  HIPC(hipMemset2DAsync(lw.Mt, (size_t)lw.sM * sizeof(double), 0, (size_t)rpad * rpad * sizeof(double), nb, c->st));
+  hipLaunchKernelGGL(fill_slabs_kernel, dim3((unsigned)(((size_t)rpad * rpad + 1023) / 1024), nb), dim3(256), 0, c->st, lw.Mt, lw.sM,
+                     (size_t)rpad * rpad, 0.0);
   CHK(inverse_t(c, lw, c->ident, nb));
   // c. Yt = F Mts  (n x rpad, ld = c->ld) into the factor slab (the factor itself is dead now)
   for (int k = 0; k < p; ++k) {
@@ -1133,11 +1142,15 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool 
                          T, p, c->vsm, c->ident, c->trial_of_slot, 1);
     });
     prof_end(c);
-    int th = (int)(48 * 1024 / ((pp + 1) * sizeof(double)));
-    th = std::max(1, std::min(64, th));
-    const long long items = (long long)nb * T;
-    hipLaunchKernelGGL(vsm_finish_kernel, dim3((unsigned)((items + th - 1) / th)), dim3(th), (size_t)th * (pp + 1) * sizeof(double), c->st,
-                       c->vsm, c->Gbin, sW, T, p, c->eps, c->ident, c->trial_of_slot, nb);
+    if (p > 16) return fail("low-rank covariance engine supports up to 16 latents (p=%d)", p);
+    dispatch_pw(p, [&](auto pw) {
+      constexpr int PW = decltype(pw)::value;
+      if constexpr (PW <= 16) {
+        constexpr int BT = 256 / PW;
+        hipLaunchKernelGGL(vsm_finish_kernel<PW>, dim3((T + BT - 1) / BT, nb), dim3(256), 0, c->st, c->vsm, c->Gbin, sW, T, p, c->eps, c->ident,
+                           c->trial_of_slot);
+      }
+    });
   }
   // e. post_vsmGP_k = eps diag(G_t[k][k]) + Ymix_k Ymix_k^T,  Ymix_k[t][b] = sum_k' G_t[k][k'] Yt[(k',t)][b]: Yt is mixed in
   //    place once (it is not needed unmixed any more), then rows (k,.) of the slab are the GEMM operand of latent k
