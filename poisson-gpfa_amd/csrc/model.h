@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+typedef double mdouble4 __attribute__((ext_vector_type(4)));
+
 namespace pgpfa {
 
 // --------------------------------------------------------------------------------------------------
@@ -270,6 +272,133 @@ __global__ void poisson_pass_kernel(PoissonArgs a) {
     for (int i = 0; i < KY; ++i) s += fred[i];
     a.fpart[(size_t)slot * a.ntile + blockIdx.x] = s;
   }
+}
+
+// --------------------------------------------------------------------------------------------------
+// The same pass on the FP64 matrix cores (p <= 16).  Per wave one tile of 16 bins; neurons in tiles of 16:
+//   H tile   (neuron x bin)  = C16 . X + d           3 MFMAs (K = latents, padded to 4s)
+//   e = exp(H), r = e - y, f += e - y*h              element-wise on the accumulator registers
+//   W[bin][pair] += sum_n e[n][bin] * CCu[n][pair]   NT MFMAs per 4 neurons (pairs a >= b of C[n][a] C[n][b])
+//   G[bin][k]    += sum_n r[n][bin] * C16[n][k]      1 MFMA per 4 neurons
+// The accumulator layout of the H tile (lane = bin, register r = neurons 4r..4r+3 over the lane quads) IS the
+// A-fragment layout of the following products, so e and r never leave registers.  CCu / C16 are zero-padded
+// tables built once per parameter set (poisson_tables_kernel) and read from L2.  W tiles are staged in LDS and
+// leave as contiguous runs.  grid = (ceil(T/64), nslots), block = 256 (4 waves x 16 bins).
+// --------------------------------------------------------------------------------------------------
+__global__ void poisson_tables_kernel(const double* __restrict__ C, int q, int p, int qpad, int ncol, double* __restrict__ CCu,
+                                      double* __restrict__ C16) {
+  const int n = blockIdx.x;
+  for (int c = threadIdx.x; c < ncol; c += blockDim.x) {
+    int a = 0;
+    while ((a + 1) * (a + 2) / 2 <= c) ++a;
+    const int b = c - a * (a + 1) / 2;
+    CCu[(size_t)n * ncol + c] = (n < q && a < p) ? C[(size_t)n * p + a] * C[(size_t)n * p + b] : 0.0;
+  }
+  for (int l = threadIdx.x; l < 16; l += blockDim.x) C16[(size_t)n * 16 + l] = (n < q && l < p) ? C[(size_t)n * p + l] : 0.0;
+}
+
+template <int PW>
+__global__ __launch_bounds__(256) void poisson_mfma_kernel(PoissonArgs a, const double* __restrict__ CCu, const double* __restrict__ C16, int qpad) {
+  constexpr int NP = PW * (PW + 1) / 2, NT = (NP + 15) / 16, NC = NT * 16, KS = (PW + 3) / 4;
+  __shared__ double Wl[4][16 * PW * PW];
+  __shared__ double fred[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int slot = a.slots[blockIdx.y];
+  const int trial = a.trial_of_slot[slot];
+  const int p = a.p, q = a.q, T = a.T, pp = p * p;
+  const int sbase = blockIdx.x * 64 + wave * 16;
+  const int t = sbase + l15;
+  const bool valid_t = t < T;
+  const double* X = a.X + (size_t)slot * a.sX;
+  const uint8_t* Y = a.Y + (size_t)trial * q * T;
+
+  double xb[KS];
+#pragma unroll
+  for (int kk = 0; kk < KS; ++kk) {
+    const int l = l4 + 4 * kk;
+    xb[kk] = (l < p && valid_t) ? X[(size_t)l * T + t] : 0.0;
+  }
+  // LDS offsets of this lane's pair columns (c = tile*16 + l15 -> (pa, pb), pa >= pb); -1: padding column
+  int off1[NT], off2[NT];
+#pragma unroll
+  for (int tl = 0; tl < NT; ++tl) {
+    const int c = tl * 16 + l15;
+    int pa = 0;
+    while ((pa + 1) * (pa + 2) / 2 <= c) ++pa;
+    const int pb = c - pa * (pa + 1) / 2;
+    off1[tl] = (pa < p) ? pa * p + pb : -1;
+    off2[tl] = pb * p + pa;
+  }
+  mdouble4 accW[NT], accG = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int tl = 0; tl < NT; ++tl) accW[tl] = mdouble4{0.0, 0.0, 0.0, 0.0};
+  double facc = 0.0;
+
+  if (sbase < T) {
+    for (int nb0 = 0; nb0 < qpad; nb0 += 16) {
+      mdouble4 h;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = nb0 + l4 + 4 * r;
+        h[r] = (n < q) ? a.d[n] : 0.0;
+      }
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) h = __builtin_amdgcn_mfma_f64_16x16x4f64(C16[(size_t)(nb0 + l15) * 16 + l4 + 4 * kk], xb[kk], h, 0, 0, 0);
+      double e[4], rr[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = nb0 + l4 + 4 * r;
+        const bool ok = (n < q) && valid_t;
+        const double y = ok ? (double)Y[(size_t)n * T + t] : 0.0;
+        const double ev = ok ? exp(h[r]) : 0.0;
+        e[r] = ev;
+        rr[r] = ev - y;
+        facc += ok ? ev - y * h[r] : 0.0;
+      }
+      if (a.full) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const size_t nrow = (size_t)(nb0 + 4 * r + l4);
+#pragma unroll
+          for (int tl = 0; tl < NT; ++tl)
+            accW[tl] = __builtin_amdgcn_mfma_f64_16x16x4f64(e[r], CCu[nrow * NC + tl * 16 + l15], accW[tl], 0, 0, 0);
+          accG = __builtin_amdgcn_mfma_f64_16x16x4f64(rr[r], C16[nrow * 16 + l15], accG, 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (a.full) {
+    // accumulators: bin = l4 + 4 r, column = l15
+    double* Ws = Wl[wave];
+    if (sbase < T) {
+#pragma unroll
+      for (int tl = 0; tl < NT; ++tl)
+        if (off1[tl] >= 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            Ws[(l4 + 4 * r) * pp + off1[tl]] = accW[tl][r];
+            Ws[(l4 + 4 * r) * pp + off2[tl]] = accW[tl][r];
+          }
+        }
+    }
+    __syncthreads();
+    if (sbase < T) {
+      const int nbins = min(16, T - sbase);
+      double* W = a.W + (size_t)slot * a.sW + (size_t)sbase * pp;
+      for (int e2 = lane; e2 < nbins * pp; e2 += 64) W[e2] = Ws[e2];
+      if (l15 < p) {
+        double* G = a.G + (size_t)slot * a.sG + (size_t)l15 * T + sbase;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (sbase + l4 + 4 * r < T) G[l4 + 4 * r] = accG[r];
+      }
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) facc += __shfl_down(facc, off);
+  if (lane == 0) fred[wave] = facc;
+  __syncthreads();
+  if (threadIdx.x == 0) a.fpart[(size_t)slot * a.ntile + blockIdx.x] = (fred[0] + fred[1]) + (fred[2] + fred[3]);
 }
 
 // flik[slot] = sum_tile fpart[slot][tile]
@@ -1194,7 +1323,6 @@ __global__ void bin_blocks_kernel(const double* __restrict__ W, long long sW, do
 // of the 4x4 table of per-bin weights are staged in LDS, the weight scales the A fragment in registers.  The A
 // operand is the column side, so the accumulator's lanes run along rows of B and the stores are contiguous
 // (Wt_t is symmetric).  grid = (tile pairs, slots), block = 256.
-typedef double mdouble4 __attribute__((ext_vector_type(4)));
 constexpr int AB_TK = 32;     // bins per LDS chunk
 constexpr int AB_LD = 81;     // LDS row stride of a staged panel (64 columns + pad; odd*... keeps writes conflict-free)
 __global__ __launch_bounds__(256) void assemble_b_kernel(double* __restrict__ Bm, long long sB, int ldb, int nblk,

@@ -85,6 +85,8 @@ struct pgpfa_ctx {
   // sum-only covariance output of the low-rank engine (option keep_trial_vsmgp = 0): the E-step accumulates
   // sum_r Sigma_r^{kk} here instead of storing R x p blocks of T x T; per-trial blocks are rebuilt on request
   double* Pacc = nullptr;                        // [p][Tp][Tp]
+  double *CCu = nullptr, *C16 = nullptr;         // zero-padded pair-product / loading tables of the MFMA Poisson pass
+  int qpad = 0, ccu_cols = 0;
   double* ppart = nullptr;                       // [p][PACC_SPLITS + 1][T x T] split-K partial products
   bool keep_trial_vsmgp = false;
   bool pacc_used = false, pacc_valid = false;
@@ -492,7 +494,15 @@ int poisson(pgpfa_ctx* c, const int* d_list, int nl, const double* X, double* G,
   dim3 grid(a.ntile, nl), block(64, KY);
   const double fl = (double)nl * c->q * c->T * (4.0 * c->p + (full ? c->p * (c->p + 1.0) : 0.0));
   prof_begin(c, TAG_POISSON, fl);
-  dispatch_pw(c->p, [&](auto pm) { hipLaunchKernelGGL(poisson_pass_kernel<decltype(pm)::value>, grid, block, 0, c->st, a); });
+  if (c->CCu && c->mfma) {
+    dispatch_pw(c->p, [&](auto pm) {
+      constexpr int PW = decltype(pm)::value;
+      if constexpr (PW <= 16)
+        hipLaunchKernelGGL(poisson_mfma_kernel<PW>, grid, dim3(256), 0, c->st, a, c->CCu, c->C16, c->qpad);
+    });
+  } else {
+    dispatch_pw(c->p, [&](auto pm) { hipLaunchKernelGGL(poisson_pass_kernel<decltype(pm)::value>, grid, block, 0, c->st, a); });
+  }
   prof_end(c);
   hipLaunchKernelGGL(sum_tiles_kernel, dim3((nl + 255) / 256), dim3(256), 0, c->st, c->fpart, a.ntile, d_list, nl, flik);
   HIPC(hipGetLastError());
@@ -689,6 +699,14 @@ int pgpfa_create(pgpfa_ctx** out, int device, int q, int p, int T, int R, double
   rc |= dmalloc(c, &c->vsmgp, (size_t)R * p * T * T, true);
   rc |= dmalloc(c, &c->Pauto, slab * p, true);
   rc |= dmalloc(c, &c->Pacc, slab * p, true);
+  c->qpad = round_up(q, 16);
+  c->ccu_cols = round_up(p * (p + 1) / 2, 16);
+  if (p <= 16) {
+    // widths must match the kernel instantiation dispatch_pw picks for p
+    dispatch_pw(p, [&](auto pw) { constexpr int PW = decltype(pw)::value; c->ccu_cols = round_up(PW * (PW + 1) / 2, 16); });
+    rc |= dmalloc(c, &c->CCu, (size_t)c->qpad * c->ccu_cols + 64, true);
+    rc |= dmalloc(c, &c->C16, (size_t)c->qpad * 16 + 64, true);
+  }
   rc |= dmalloc(c, &c->ppart, (size_t)p * (PACC_SPLITS + 1) * T * T + 256);
   c->vsmgp_ok.assign(R, 0);
   rc |= dmalloc(c, &c->Flr, slab * p + 256 * (size_t)c->Tp, true);
@@ -834,6 +852,8 @@ int pgpfa_set_params(pgpfa_ctx* c, const double* C, const double* d, const doubl
     c->hC.swap(nC); c->hd.swap(nd); c->htau.swap(nt);
   }
   hipLaunchKernelGGL(gram_tau_kernel, dim3(c->Tp, c->p), dim3(256), 0, c->st, c->Kpad, c->Tp, c->T, c->tau, c->bin, c->eps);
+  if (c->CCu)
+    hipLaunchKernelGGL(poisson_tables_kernel, dim3(c->qpad), dim3(64), 0, c->st, c->C, c->q, c->p, c->qpad, c->ccu_cols, c->CCu, c->C16);
   HIPC(hipGetLastError());
   CHK(build_kinv(c));
   CHK(build_lowrank(c));

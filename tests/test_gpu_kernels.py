@@ -223,3 +223,35 @@ def test_tau_batch_equals_single_and_lockstep_matches_bfgs(hip, c1):
         finally:
             funs.learning.TAU_SOLVER = 'lockstep'
         assert np.max(np.abs(np.log(tau) - np.log(tau_o))) <= 1e-7, solver
+
+
+@pytest.mark.parametrize('q,p,T', [(13, 7, 41), (30, 3, 100), (50, 10, 70), (20, 16, 33)])
+def test_poisson_pass_mfma_matches_vector_kernel_and_oracle(hip, q, p, T):
+    """The matrix-core Poisson pass (objective, gradient, per-bin curvature blocks) against the vector kernel
+    (use_mfma = 0) and the oracle, at sizes that exercise every padding rule (neurons, latents, bins)."""
+    rng = np.random.default_rng(q * 100 + p)
+    R = 3
+    Y = rng.poisson(0.7, size=(R, q, T)).astype(np.uint8)
+    C = 0.4 * rng.standard_normal((q, p))
+    d = -0.5 + 0.3 * rng.standard_normal(q)
+    tau = 0.05 + 0.2 * rng.random(p)
+    X = 0.3 * rng.standard_normal((R, p, T))
+    out = {}
+    for mfma in (1, 0):
+        ctx = hip.Context(q, p, T, R, 10.0)
+        try:
+            ctx.upload_counts(Y)
+            ctx.set_option('use_mfma', mfma)
+            ctx.set_params(C, d, tau)
+            f, g = ctx.laplace_eval(np.arange(R), X)
+            H = ctx.laplace_hessian(1, X[1])
+            out[mfma] = (f, g, H)
+        finally:
+            ctx.close()
+    assert rel(out[1][0], out[0][0]) <= 1e-13
+    assert rel(out[1][1], out[0][1]) <= 1e-12
+    assert rel(out[1][2], out[0][2]) <= 1e-12
+    Kinv = np.linalg.inv(orc.make_K(tau, T, 10.0))
+    for r in range(R):
+        assert abs(out[1][0][r] - orc.nlp(X[r], Y[r].astype(float), C, d, Kinv)) <= 1e-10 * abs(out[1][0][r])
+        assert rel(out[1][1][r], orc.nlp_grad(X[r], Y[r].astype(float), C, d, Kinv)) <= 1e-9
