@@ -44,7 +44,9 @@ int pgpfa_destroy(pgpfa_ctx* ctx);
 /* Options: "newton_xtol" (1e-5), "newton_max_iter" (50), "use_mfma" (1),
  * "chunk_trials" (0 = auto), "eps_noise" (1e-3, util.py:599), "chord" (1: reuse the first factor for
  * chord steps), "chord_xtol" (1e-9), "chord_rho" (0.6), "chord_max_step" (1.0), "profile" (0),
- * "shared_pcg" (1: phase-1 Newton with the shared preconditioner), "shared_min" (16), "pcg_inner" (8),
+ * "shared_pcg" (1: phase-1 Newton with the shared preconditioner), "shared_min" (16), "pcg_inner" (16: cap on
+ * the inner PCG iterations of one outer Newton iteration), "pcg_eta0" (1e-2: relative residual of the first inner solve;
+ * later ones adapt to the predicted error),
  * "pcg_outer_max" (12), "cov_mode" (0 auto, 1 dense, 2 low-rank covariance engine), "lowrank_tol" (1e-13),
  * "keep_trial_vsmgp" (0: the low-rank engine accumulates sum_r post_vsmGP_r for the tau M-step and rebuilds
  * per-trial T x T blocks only when pgpfa_get_post_vsmgp asks for them; 1: store them in every E-step). */

@@ -52,6 +52,10 @@ struct GemmP {
   // dimension runs over kseg-wide panels of consecutive slabs (kseg multiple of 16; 0: plain)
   int kseg;
   long long sAseg, sBseg;
+  // optional split-K: with ksplit > 1 the hi index of the two-level batch selects the ksplit-th part of the tile's k
+  // range instead of moving A/B (sA_hi = sB_hi = 0); C then addresses partial products (gemm_splitk_reduce_kernel)
+  int ksplit;
+  int c_by_pos;         // C is indexed by batch position instead of slot (compact partial-product buffers)
 };
 
 __device__ __forceinline__ size_t gemm_koff(int kseg, long long sseg, int ld, int k) {
@@ -60,13 +64,24 @@ __device__ __forceinline__ size_t gemm_koff(int kseg, long long sseg, int ld, in
   return (size_t)seg * sseg + (size_t)(k - seg * kseg) * ld;
 }
 
-__device__ __forceinline__ void gemm_bind(const GemmP& g, int b, const double*& A, const double*& B, double*& C) {
+__device__ __forceinline__ int gemm_bind(const GemmP& g, int b, const double*& A, const double*& B, double*& C) {
   int lo = b, hi = 0;
   if (g.nb_lo > 0) { hi = b / g.nb_lo; lo = b - hi * g.nb_lo; }
   const long long slot = g.slots ? g.slots[lo] : lo;
   A = g.A + slot * g.sA + hi * g.sA_hi;
   B = g.B + slot * g.sB + hi * g.sB_hi;
-  C = g.C + slot * g.sC + hi * g.sC_hi;
+  C = g.C + (g.c_by_pos ? (long long)lo : slot) * g.sC + hi * g.sC_hi;
+  return hi;
+}
+
+// k range of one split-K part (multiples of 16)
+__device__ __forceinline__ void gemm_split_range(int ksplit, int part, int& kb, int& ke) {
+  if (ksplit <= 1) return;
+  const int len = ke - kb;
+  const int chunk = ((len + ksplit - 1) / ksplit + 15) / 16 * 16;
+  const int b0 = kb + part * chunk;
+  ke = (b0 + chunk < ke) ? b0 + chunk : ke;
+  kb = (b0 < ke) ? b0 : ke;
 }
 
 __device__ __forceinline__ void gemm_decode_tile(const GemmP& g, int tile, int& ti, int& tj) {
@@ -122,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP g) {
   const double* A;
   const double* B;
   double* C;                       // may alias A (in-place TRSM): no restrict
-  gemm_bind(g, b, A, B, C);
+  const int hi = gemm_bind(g, b, A, B, C);
 
   const int i0 = ti * GBM, j0 = tj * GBN;
   int kb = 0, ke = g.K;
@@ -131,6 +146,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP g) {
   if (g.kflags & KF_END_ROW) ke = (i0 + GBM < g.K ? i0 + GBM : g.K);
   if (g.krange) { kb = g.krange[2 * ti]; ke = g.krange[2 * ti + 1]; }
   if (kb > ke) kb = ke;
+  gemm_split_range(g.ksplit, hi, kb, ke);
 
   const bool a_vec = ((((size_t)A) & 15) == 0) && ((g.lda & 1) == 0);
   const bool b_vec = ((((size_t)B) & 15) == 0) && ((g.ldb & 1) == 0);
@@ -265,13 +281,15 @@ __global__ void gemm_check_kernel(GemmP g) {
   const double* A;
   const double* B;
   double* C;
-  gemm_bind(g, b, A, B, C);
+  const int hi = gemm_bind(g, b, A, B, C);
   const int i0 = ti * GBM, j0 = tj * GBN;
   int kb = 0, ke = g.K;
   if (g.kflags & KF_BEGIN_ROW) kb = i0;
   if (g.kflags & KF_BEGIN_MAXRC) kb = (i0 > j0 ? i0 : j0);
   if (g.kflags & KF_END_ROW) ke = (i0 + GBM < g.K ? i0 + GBM : g.K);
   if (g.krange) { kb = g.krange[2 * ti]; ke = g.krange[2 * ti + 1]; }
+  if (kb > ke) kb = ke;
+  gemm_split_range(g.ksplit, hi, kb, ke);
   const bool mask_diag = (g.kflags & KF_MASK_DIAG) && (ti == tj);
   // compute first, store after a barrier: C may alias A (in-place TRSM)
   double vals[GBM * GBN / 256];
@@ -300,6 +318,20 @@ __global__ void gemm_check_kernel(GemmP g) {
     if (g.beta != 0.0) v += g.beta * (*dst);
     *dst = v;
   }
+}
+
+// C[b] = beta*C[b] + sum_s part[s][b]  (part: [ksplit][nbatch][N][M] compact); grid = (ceil(M*N/256), nbatch)
+__global__ void gemm_splitk_reduce_kernel(const double* __restrict__ part, int ksplit, int M, int N, int nbatch, double* __restrict__ C,
+                                          long long sC, int ldc, const int* __restrict__ slots, double beta) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (size_t)M * N) return;
+  const int b = blockIdx.y;
+  const long long slot = slots ? slots[b] : b;
+  const size_t i = e % M, j = e / M;
+  double s = 0.0;
+  for (int k = 0; k < ksplit; ++k) s += part[((size_t)k * nbatch + b) * M * N + e];
+  double* dst = C + slot * sC + j * ldc + i;
+  *dst = (beta != 0.0) ? beta * (*dst) + s : s;
 }
 
 // Register-only FP64 MFMA loop: measures the sustained v_mfma_f64_16x16x4_f64 rate of the chip (no

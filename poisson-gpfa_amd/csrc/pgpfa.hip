@@ -85,6 +85,7 @@ struct pgpfa_ctx {
   // sum-only covariance output of the low-rank engine (option keep_trial_vsmgp = 0): the E-step accumulates
   // sum_r Sigma_r^{kk} here instead of storing R x p blocks of T x T; per-trial blocks are rebuilt on request
   double* Pacc = nullptr;                        // [p][Tp][Tp]
+  double* gemm_part = nullptr; size_t gemm_part_len = 0;   // split-K partial products of the thin GEMMs
   double *CCu = nullptr, *C16 = nullptr;         // zero-padded pair-product / loading tables of the MFMA Poisson pass
   int qpad = 0, ccu_cols = 0;
   double* ppart = nullptr;                       // [p][PACC_SPLITS + 1][T x T] split-K partial products
@@ -125,7 +126,8 @@ struct pgpfa_ctx {
   bool mt_dirty = false;                          // low-rank use scribbled over the Mt slabs' zero triangle
   bool last_cov_lowrank = false;
   bool shared_pcg = true;
-  int shared_min = 16, pcg_inner = 8, pcg_inner_max = 16, pcg_outer_max = 12;
+  int shared_min = 16, pcg_inner_min = 2, pcg_inner_max = 16, pcg_outer_max = 12;
+  double pcg_eta0 = 1e-2;
   double *sc_f = nullptr, *sc_qxx = nullptr, *sc_qdx = nullptr, *sc_qdd = nullptr, *sc_dec = nullptr, *sc_smax = nullptr, *sc_alpha = nullptr;
   int *trial_of_slot = nullptr, *list_a = nullptr, *list_b = nullptr, *ident = nullptr;
   // small workspace for the T x T systems (Kinv, tau M-step): p slots of Tp
@@ -237,7 +239,33 @@ double gemm_flops(const GemmP& g) {
 
 int gemm(pgpfa_ctx* c, bool transb, GemmP g) {
   prof_begin(c, TAG_GEMM, gemm_flops(g));
-  hipError_t e = gemm_launch(c->st, c->mfma, transb, g);
+  // Few output tiles and a long k loop (the thin multi-RHS products of the PCG iterations): the launch would occupy a
+  // fraction of the 256 CUs for the length of one k loop.  Cut k into parts run as extra batch entries, sum the
+  // partial products afterwards.
+  const int tiles = ((g.M + GBM - 1) / GBM) * ((g.N + GBN - 1) / GBN) * std::max(g.nbatch, 1);
+  int ksplit = 1;
+  // (block-sparse operands: the k loop a tile really runs is the one implied by the flop count)
+  const double k_eff = (g.flops_hint > 0.0 && g.M > 0 && g.N > 0) ? g.flops_hint / (2.0 * g.M * g.N * std::max(g.nbatch, 1)) : (double)g.K;
+  if (c->gemm_part && g.mode == GEMM_FULL && g.kflags == 0 && g.nb_lo == 0 && g.kseg == 0 && tiles > 0 && tiles < 384 && k_eff >= 256.0) {
+    ksplit = std::min(std::min(8, (int)(k_eff / 128.0)), (640 + tiles - 1) / tiles);
+    while (ksplit > 1 && (size_t)ksplit * g.nbatch * g.M * g.N > c->gemm_part_len) --ksplit;
+  }
+  hipError_t e;
+  if (ksplit > 1) {
+    GemmP s = g;
+    s.C = c->gemm_part; s.sC = (long long)g.M * g.N; s.ldc = g.M; s.beta = 0.0;
+    s.nb_lo = g.nbatch; s.nbatch = g.nbatch * ksplit; s.sA_hi = 0; s.sB_hi = 0; s.sC_hi = (long long)g.nbatch * g.M * g.N;
+    s.ksplit = ksplit;
+    s.c_by_pos = 1;                      // partial products are indexed by batch position, the operands by slot
+    e = gemm_launch(c->st, c->mfma, transb, s);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)(((size_t)g.M * g.N + 255) / 256), g.nbatch), dim3(256), 0, c->st, c->gemm_part,
+                         ksplit, g.M, g.N, g.nbatch, g.C, g.sC, g.ldc, g.slots, g.beta);
+      e = hipGetLastError();
+    }
+  } else {
+    e = gemm_launch(c->st, c->mfma, transb, g);
+  }
   prof_end(c);
   if (e != hipSuccess) return fail("gemm launch failed: %s", hipGetErrorString(e));
   return 0;
@@ -699,6 +727,8 @@ int pgpfa_create(pgpfa_ctx** out, int device, int q, int p, int T, int R, double
   rc |= dmalloc(c, &c->vsmgp, (size_t)R * p * T * T, true);
   rc |= dmalloc(c, &c->Pauto, slab * p, true);
   rc |= dmalloc(c, &c->Pacc, slab * p, true);
+  c->gemm_part_len = (size_t)16 << 20;
+  rc |= dmalloc(c, &c->gemm_part, c->gemm_part_len);
   c->qpad = round_up(q, 16);
   c->ccu_cols = round_up(p * (p + 1) / 2, 16);
   if (p <= 16) {
@@ -764,7 +794,8 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
   else if (k == "lowrank_tol") c->lr_tol = v;
   else if (k == "keep_trial_vsmgp") c->keep_trial_vsmgp = (v != 0.0);
   else if (k == "shared_min") c->shared_min = (int)v;
-  else if (k == "pcg_inner") c->pcg_inner = (int)v;
+  else if (k == "pcg_inner") c->pcg_inner_max = std::max(1, (int)v);
+  else if (k == "pcg_eta0") c->pcg_eta0 = v;
   else if (k == "pcg_outer_max") c->pcg_outer_max = (int)v;
   else if (k == "chord_xtol") c->chord_xtol = v;
   else if (k == "chord_rho") c->chord_rho = v;
@@ -1308,16 +1339,26 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
     if (c->shared_pcg && (nb >= c->shared_min || c->plan_lowrank)) {
       CHK(shared_factor(c, nb));
       n_shared += 1;
-      int inner = c->pcg_inner;
-      std::vector<double> rr(nb), rr0(nb);
+      std::vector<double> rr(nb), rr0(nb), err_pred(nb, -1.0);
       for (int outer = 0; outer < c->pcg_outer_max && !active.empty(); ++outer) {
+        // forcing term of this outer iteration (relative residual the inner solve is run to).  With e the predicted
+        // error of a slot's current iterate, solving beyond eta ~ e buys nothing (the Newton step itself leaves ~e^2),
+        // and when a looser solve already lands below the stopping tolerance that looser value is enough.
+        double eta_target = c->pcg_eta0;
+        for (int s : active) {
+          if (err_pred[s] < 0.0) continue;                       // first outer iteration of this slot
+          const double e = std::max(err_pred[s], 1e-300);
+          const double want = std::max(e, c->chord_xtol / (20.0 * e));
+          eta_target = std::min(eta_target, std::max(1e-9, std::min(c->pcg_eta0, want)));
+        }
         const int na = (int)active.size();
         CHK(upload_list(c, c->list_a, active));
         hipLaunchKernelGGL(grad_total_kernel, dim3((nvec + 255) / 256, na), dim3(256), 0, c->st, c->Gl, ld, c->KX, ld, c->Gt, ld, nvec, c->list_a);
         hipLaunchKernelGGL(pcg_init_kernel, dim3((c->npad + 255) / 256, na), dim3(256), 0, c->st, c->Gt, c->Rv, c->Dl, ld, nvec, c->npad, c->list_a);
         CHK(shared_solve(c, nb, c->Rv, c->Zv));
         hipLaunchKernelGGL(pcg_update_p_kernel, dim3(na), dim3(256), 0, c->st, c->Rv, c->Zv, c->Pv, ld, nvec, c->list_a, c->sc_rz, c->sc_rr0, 1);
-        for (int it = 0; it < inner; ++it) {
+        int done_inner = 0;
+        for (int it = 0; it < c->pcg_inner_max; ++it) {
           CHK(prior_mv_all(c, nb, c->Pv, c->Qv));
           dispatch_pw(p, [&](auto pw) {
             hipLaunchKernelGGL(pcg_hessvec_dot_kernel<decltype(pw)::value>, dim3(na), dim3(256), 0, c->st, c->W, (long long)T * p * p, c->Pv, c->Qv,
@@ -1326,8 +1367,16 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
           hipLaunchKernelGGL(pcg_update_xr_kernel, dim3(na), dim3(256), 0, c->st, c->Dl, c->Rv, c->Pv, c->Qv, ld, nvec, c->list_a, c->sc_rz, c->sc_pq);
           CHK(shared_solve(c, nb, c->Rv, c->Zv));
           hipLaunchKernelGGL(pcg_update_p_kernel, dim3(na), dim3(256), 0, c->st, c->Rv, c->Zv, c->Pv, ld, nvec, c->list_a, c->sc_rz, c->sc_rr, 0);
+          done_inner = it + 1;
+          if (done_inner >= c->pcg_inner_min) {
+            CHK(download(c, rr.data(), c->sc_rr, nb));
+            if (it == c->pcg_inner_min - 1) CHK(download(c, rr0.data(), c->sc_rr0, nb));
+            double worst = 0.0;
+            for (int s : active) worst = std::max(worst, rr0[s] > 0.0 ? std::sqrt(rr[s] / rr0[s]) : 0.0);
+            if (worst <= eta_target) break;
+          }
         }
-        n_pcg += (double)na * inner;
+        n_pcg += (double)na * done_inner;
         hipLaunchKernelGGL(step_stats_kernel, dim3(na), dim3(256), 0, c->st, c->Gt, c->Dl, ld, nvec, c->list_a, c->sc_dec, c->sc_smax);
         CHK(prior_mv_all(c, nb, c->Dl, c->KD));
         hipLaunchKernelGGL(dots3_kernel, dim3(na), dim3(256), 0, c->st, c->Xc, ld, c->KX, ld, c->Dl, ld, c->KD, ld, nvec, c->list_a, c->sc_qxx,
@@ -1354,6 +1403,7 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
           const double eta = rr0[s] > 0.0 ? std::sqrt(rr[s] / rr0[s]) : 0.0;
           const double step = alpha[s] * smax[s];
           if (alpha[s] == 1.0 && 10.0 * step * std::max(eta, step) < c->chord_xtol) { stat[s] = 0; continue; }
+          err_pred[s] = (alpha[s] == 1.0) ? step * std::max(eta, step) : step;
           next.push_back(s);
         }
         // slots with a non-descent direction or an exhausted search drop to the per-trial fallback below
@@ -1365,7 +1415,6 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
         }
         active.swap(next);
         leftovers.insert(leftovers.end(), fallback.begin(), fallback.end());
-        inner = std::min(c->pcg_inner_max, inner + 2);
         max_it_seen = std::max(max_it_seen, outer + 1);
       }
       // anything still active after the outer cap also goes to the fallback

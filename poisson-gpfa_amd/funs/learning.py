@@ -86,6 +86,12 @@ def _newton_cd(sess, x0, prior_center=None, inv_s2=0.0, max_iter=50, xtol=1e-10,
     n_pass = 1
     for it in range(max_iter):
         step = delta.reshape(D, q)
+        if np.max(np.abs(step)) < np.sqrt(xtol):
+            # quadratic regime: the error after this step is ~|step|^2 < xtol, so it is taken without spending
+            # another pass over the data on confirming it; the cost follows from the quadratic model
+            theta = theta + step
+            cost = cost - 0.5 * dec
+            break
         alpha = np.ones(q)
         trial = theta + step
         c_try, d_try, dec_try = ctx.mstep_cd_newton_pass(trial.reshape(-1), prior_center, inv_s2)
@@ -218,10 +224,12 @@ def MStepGPtimescaleCost_grad(p, precomp, epsNoise):
 TAU_SOLVER = 'lockstep'      # 'lockstep' (all latents per device evaluation) or 'scipy' (the reference's BFGS calls)
 
 
-def _lockstep_minimize(evaluate, p0, gtol=1e-8, xtol=1e-10, max_iter=60):
+def _lockstep_minimize(evaluate, p0, gtol=1e-8, xtol=1e-10, max_iter=60, curv0=None):
     """Minimise xdim independent smooth 1-D costs f_k(p_k) together: every iteration is ONE batched device
     evaluation of all (f_k, f_k').  Safeguarded secant iteration on the gradient with a bracketing fallback;
-    stops per latent on |f'| <= gtol (scipy BFGS's criterion, learning.py:283-288) or |step| <= xtol."""
+    stops per latent on |f'| <= gtol (scipy BFGS's criterion, learning.py:283-288) or |step| <= xtol.
+    curv0: optional per-latent curvature guesses (e.g. from the previous EM iteration) for the first step.
+    Returns (p, f, g, nfev, done, curv) with curv the last positive secant curvature seen per latent."""
     p = np.array(p0, dtype=np.float64)
     k = p.size
     f, g = evaluate(p)
@@ -231,6 +239,13 @@ def _lockstep_minimize(evaluate, p0, gtol=1e-8, xtol=1e-10, max_iter=60):
     hi = np.where(g > 0, p, np.inf)
     p_prev, g_prev = p.copy(), g.copy()
     step = -np.sign(g) * 0.25
+    curv_seen = np.full(k, np.nan)
+    if curv0 is not None:
+        c0 = np.asarray(curv0, dtype=np.float64)
+        good = np.isfinite(c0) & (c0 > 0)
+        with np.errstate(divide='ignore', invalid='ignore'):
+            step = np.where(good, np.clip(-g / c0, -1.0, 1.0), step)
+        curv_seen = np.where(good, c0, curv_seen)
     for _ in range(max_iter):
         if np.all(done):
             break
@@ -247,13 +262,21 @@ def _lockstep_minimize(evaluate, p0, gtol=1e-8, xtol=1e-10, max_iter=60):
         with np.errstate(divide='ignore', invalid='ignore'):
             curv = (g_new - g) / dp
         sec = np.where((curv > 0) & np.isfinite(curv), -g_new / curv, -np.sign(g_new) * np.minimum(2.0 * np.abs(dp), 1.0))
+        curv_seen = np.where((curv > 0) & np.isfinite(curv) & ~done, curv, curv_seen)
         sec = np.clip(sec, -1.0, 1.0)
         newly = (~done) & ((np.abs(g_new) <= gtol) | (np.abs(dp) <= xtol))
+        # secant step already below xtol with a trusted (positive) curvature: take it without paying an evaluation to
+        # confirm it (the error after it is second order in the step before)
+        tiny = (~done) & (~newly) & (curv > 0) & np.isfinite(curv) & (np.abs(sec) <= 10.0 * xtol)
         p_prev, g_prev = np.where(done, p_prev, p), np.where(done, g_prev, g)
         p, f, g = np.where(done, p, p_new), np.where(done, f, f_new), np.where(done, g, g_new)
+        p = np.where(tiny, p + sec, p)
+        f = np.where(tiny, f - 0.5 * g * g / np.where(tiny, curv, 1.0), f)
+        g = np.where(tiny, 0.0, g)
+        newly = newly | tiny
         step = np.where(done | newly, 0.0, sec)
         done = done | newly
-    return p, f, g, nfev, done
+    return p, f, g, nfev, done, curv_seen
 
 
 def learnGPparams(oldParams, infRes, experiment):
@@ -269,7 +292,10 @@ def learnGPparams(oldParams, infRes, experiment):
     initp = np.log(1 / oldTau ** 2)
     details = [[]] * xdim
     if TAU_SOLVER == 'lockstep':
-        pv, fv, gv, nfev, ok = _lockstep_minimize(sess.ctx.mstep_tau_costgrad_batch, initp)
+        # curvature of each latent's cost at the previous EM iteration's optimum seeds the first secant step
+        pv, fv, gv, nfev, ok, curv = _lockstep_minimize(sess.ctx.mstep_tau_costgrad_batch, initp,
+                                                        curv0=getattr(sess, '_tau_curv', None))
+        sess._tau_curv = curv
         for xd in range(xdim):
             details[xd] = op.OptimizeResult(x=np.array([pv[xd]]), fun=fv[xd], jac=np.array([gv[xd]]), nfev=nfev,
                                             success=bool(ok[xd]), message='lockstep secant')

@@ -25,7 +25,7 @@ def small_ctx(hip):
     ctx.close()
 
 
-@pytest.mark.parametrize('M,N,K', [(128, 128, 16), (200, 150, 64), (300, 70, 160), (64, 260, 32), (513, 129, 48)])
+@pytest.mark.parametrize('M,N,K', [(128, 128, 16), (200, 150, 64), (300, 70, 160), (64, 260, 32), (513, 129, 48), (130, 260, 784)])
 @pytest.mark.parametrize('mfma', [1, 0])
 def test_gemm_nt(small_ctx, M, N, K, mfma):
     """C = alpha A B^T + beta C, asymmetric operands (catches transposed fragment layouts)."""
@@ -42,10 +42,10 @@ def test_gemm_nt(small_ctx, M, N, K, mfma):
     assert rel(C, ref) <= 1e-13 * K
 
 
-@pytest.mark.parametrize('M,N,K', [(128, 128, 16), (260, 70, 128), (64, 300, 48)])
+@pytest.mark.parametrize('M,N,K', [(128, 128, 16), (260, 70, 128), (64, 300, 48), (200, 150, 512), (640, 130, 1040)])
 @pytest.mark.parametrize('mfma', [1, 0])
 def test_gemm_nn(small_ctx, M, N, K, mfma):
-    """The K x N (multi-RHS) operand form used by the shared-factor triangular sweeps."""
+    """The K x N (multi-RHS) operand form used by the shared-factor triangular sweeps (the long-K cases run split-K)."""
     rng = np.random.default_rng(M + N + K)
     A = rng.standard_normal((M, K))
     B = rng.standard_normal((K, N)) + np.arange(N)[None, :] * 0.01
