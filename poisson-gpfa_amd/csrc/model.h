@@ -1496,6 +1496,81 @@ __global__ __launch_bounds__(256) void mix_inplace_kernel(double* __restrict__ Y
   }
 }
 
+// Fused form of the two passes above plus vsm_finish: every p-vector y = Yt[(.,t), b] is replaced by G_t y AND the
+// per-bin blocks post_vsm[t] = eps G_t + sum_b (G_t y_b)(G_t y_b)^T are accumulated on the way (G_t symmetric, so this
+// is eps G + G (Y_t^T Y_t) G).  One read and one write of Yt instead of two reads and one write.
+// A block owns 64 bins (lanes) of one slot and ALL columns (its 4 waves take interleaved columns); G_t sits in LDS
+// (odd stride: each lane reads its own block conflict-free), the p(p+1)/2 accumulators in registers; the waves'
+// partial sums are folded into the LDS copy of G in turn (-> eps G + sum), which then leaves as one contiguous run.
+// grid = (ceil(T/64), nslots), block = 256, p <= PW <= 16.
+template <int PW>
+__global__ __launch_bounds__(256) void mix_vsm_kernel(double* __restrict__ Yt, long long sY, int ldy, const double* __restrict__ G, long long sG,
+                                                      int T, int p, int rpad, double eps, double* __restrict__ vsm,
+                                                      const int* __restrict__ slots, const int* __restrict__ trial_of_slot) {
+  constexpr int PP = PW * PW, LD = PP + 1, NPAIR = PW * (PW + 1) / 2;
+  __shared__ double Gs[64 * LD];
+  const int pp = p * p;
+  const int slot = slots[blockIdx.y];
+  const int t0 = blockIdx.x * 64;
+  const int nt = min(64, T - t0);
+  const double* gbase = G + (size_t)slot * sG + (size_t)t0 * pp;
+  if (p < PW)
+    for (int e = threadIdx.x; e < 64 * LD; e += 256) Gs[e] = 0.0;
+  __syncthreads();
+  for (int e = threadIdx.x; e < nt * pp; e += 256) {
+    const int t = e / pp, idx = e - t * pp, i = idx / p, j = idx - i * p;
+    Gs[t * LD + i * PW + j] = gbase[e];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool live = lane < nt;
+  double* g = Gs + lane * LD;
+  double acc[NPAIR];
+#pragma unroll
+  for (int i = 0; i < NPAIR; ++i) acc[i] = 0.0;
+  if (live) {
+    double* y = Yt + (size_t)slot * sY + t0 + lane;
+    for (int b = wave; b < rpad; b += 4) {
+      double v[PW], m[PW];
+#pragma unroll
+      for (int k = 0; k < PW; ++k) v[k] = (k < p) ? y[(size_t)b * ldy + (size_t)k * T] : 0.0;
+#pragma unroll
+      for (int k = 0; k < PW; ++k) {
+        double s2 = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < PW; ++kk) s2 += g[k * PW + kk] * v[kk];
+        m[k] = s2;
+        if (k < p) y[(size_t)b * ldy + (size_t)k * T] = s2;
+      }
+#pragma unroll
+      for (int a = 0; a < PW; ++a)
+#pragma unroll
+        for (int c2 = 0; c2 <= a; ++c2) acc[a * (a + 1) / 2 + c2] += m[a] * m[c2];
+    }
+  }
+  // fold the four waves' sums into the LDS block: wave 0 turns G into eps G + acc, the others add theirs
+  for (int w = 0; w < 4; ++w) {
+    __syncthreads();
+    if (wave == w && live) {
+#pragma unroll
+      for (int a = 0; a < PW; ++a)
+#pragma unroll
+        for (int c2 = 0; c2 <= a; ++c2) {
+          const double base = (w == 0) ? eps * g[a * PW + c2] : g[a * PW + c2];
+          const double val = base + acc[a * (a + 1) / 2 + c2];
+          g[a * PW + c2] = val;
+          g[c2 * PW + a] = val;
+        }
+    }
+  }
+  __syncthreads();
+  double* vbase = vsm + ((size_t)trial_of_slot[slot] * T + t0) * pp;
+  for (int e = threadIdx.x; e < nt * pp; e += 256) {
+    const int t = e / pp, idx = e - t * pp, i = idx / p, j = idx - i * p;
+    vbase[e] = Gs[t * LD + i * PW + j];
+  }
+}
+
 // vsmGP scatter for the low-rank engine: dst = mirror(src) + eps*G_t[k][k] on the diagonal
 __global__ void scatter_vsmgp_lr_kernel(const double* __restrict__ src, long long sSrc, int lds, double* __restrict__ dst, int T, int p, int k,
                                         const double* __restrict__ G, long long sG, double eps, const int* __restrict__ trial_of_slot) {

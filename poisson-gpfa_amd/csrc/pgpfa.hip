@@ -1184,8 +1184,20 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool 
     g.slots = c->ident; g.nbatch = nb; g.mode = GEMM_FULL; g.kflags = 0;
     CHK(gemm(c, true, g));
   }
-  // d. post_vsm[t] = eps G_t + G_t (Y_t^T Y_t) G_t
-  {
+  if (p > 16) return fail("low-rank covariance engine supports up to 16 latents (p=%d)", p);
+  if (want_vsmgp) {
+    // d+e. one pass over Yt: post_vsm[t] = eps G_t + sum_b (G_t y_b)(G_t y_b)^T, and Yt is mixed in place (y <- G_t y) so that
+    //      rows (k,.) of the slab become Ymix_k, the GEMM operand of post_vsmGP_k = eps diag(G_t[k][k]) + Ymix_k Ymix_k^T
+    prof_begin(c, TAG_VSM, (double)nb * c->n * rpad * (3.0 * p + 1.0));
+    dispatch_pw(p, [&](auto pw) {
+      constexpr int PW = decltype(pw)::value;
+      if constexpr (PW <= 16)
+        hipLaunchKernelGGL(mix_vsm_kernel<PW>, dim3((T + 63) / 64, nb), dim3(256), 0, c->st, lw.H, lw.sH, c->ld, c->Gbin, sW, T, p, rpad, c->eps,
+                           c->vsm, c->ident, c->trial_of_slot);
+    });
+    prof_end(c);
+  } else {
+    // d. post_vsm[t] = eps G_t + G_t (Y_t^T Y_t) G_t
     const int KY = std::min(p, 16);
     prof_begin(c, TAG_VSM, (double)nb * c->n * rpad * p);
     dispatch_pmax(p, [&](auto pm) {
@@ -1193,7 +1205,6 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool 
                          T, p, c->vsm, c->ident, c->trial_of_slot, 1);
     });
     prof_end(c);
-    if (p > 16) return fail("low-rank covariance engine supports up to 16 latents (p=%d)", p);
     dispatch_pw(p, [&](auto pw) {
       constexpr int PW = decltype(pw)::value;
       if constexpr (PW <= 16) {
@@ -1203,15 +1214,7 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool 
       }
     });
   }
-  // e. post_vsmGP_k = eps diag(G_t[k][k]) + Ymix_k Ymix_k^T,  Ymix_k[t][b] = sum_k' G_t[k][k'] Yt[(k',t)][b]: Yt is mixed in
-  //    place once (it is not needed unmixed any more), then rows (k,.) of the slab are the GEMM operand of latent k
   if (want_vsmgp) {
-    dispatch_pw(p, [&](auto pw) {
-      constexpr int PW = decltype(pw)::value;
-      if constexpr (PW <= 16)
-        hipLaunchKernelGGL(mix_inplace_kernel<PW>, dim3((T + 63) / 64, (rpad + 127) / 128, nb), dim3(256), 0, c->st, lw.H, lw.sH, c->ld, c->Gbin, sW,
-                           T, p, rpad, c->ident);
-    });
     if (p > 16) return fail("low-rank covariance engine supports up to 16 latents (p=%d)", p);
     if (accumulate) {
       // sum-only output: Pacc[k] += sum over the chunk's slots of Ymix_k Ymix_k^T as ONE split-K product per launch -

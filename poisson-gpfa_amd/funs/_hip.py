@@ -302,6 +302,7 @@ class Context:
 
     # -- comm --------------------------------------------------------------------------------------
     def comm_init(self, uid, rank, nranks):
+        warm_rccl_image()
         check(self.lib.pgpfa_comm_init(self.h, uid, int(rank), int(nranks)))
 
     def allreduce_host(self, arr):
@@ -351,7 +352,36 @@ class Context:
         return ms.value, fl.value
 
 
+_rccl_warmed = False
+
+
+def warm_rccl_image():
+    """RCCL's shared object carries ~0.5 GB of device code that ncclCommInitRank loads through page faults; on a
+    machine whose image has not been read yet that takes minutes.  One sequential read beforehand makes the first
+    communicator come up in seconds (no-op cost when the file is already cached)."""
+    global _rccl_warmed
+    if _rccl_warmed:
+        return
+    _rccl_warmed = True
+    try:
+        path = None
+        with open('/proc/self/maps') as fh:
+            for line in fh:
+                if 'librccl.so' in line:
+                    path = line.split()[-1]
+                    break
+        if path is None:
+            return
+        with open(path, 'rb', buffering=0) as fh:
+            while fh.read(16 << 20):
+                pass
+    except OSError:
+        pass
+
+
 def comm_unique_id():
+    load_library()
+    warm_rccl_image()
     buf = ct.create_string_buffer(128)
     check(load_library().pgpfa_comm_unique_id(buf))
     return buf.raw

@@ -1,8 +1,8 @@
 """End-to-end parity of the HIP path with the oracle and the golden vectors captured from the
 reference.  GPU only; everything goes through the drop-in `funs` surface or the C-ABI wrapper.
 Tolerances: vs the polished/exact mode 1e-8; vs the reference's own early-stopped
-answers max|dx| <= 5e-3, |dnll| <= 1e-4, max|dvecCd| <= 5e-4 (one M-step), |dlog gamma| <= 1e-5; full EM
-vs the exactly-converged oracle path nll 1e-5 abs / parameters 1e-4 rel, vs the reference's path nll
+answers max|dx| <= 5e-3, |dnll| <= 1e-4, max|dvecCd| <= 5e-4 (one M-step; 3e-5 vs the oracle's TNC on the exact E-step), |dlog gamma| <= 1e-5; full EM
+vs the exactly-converged oracle path nll 5e-5 abs (1e-9 rel before the first TNC M-step) / parameters 1e-4 rel, vs the reference's path nll
 1e-2 abs (8e-6 rel) / parameters 5e-3 rel - the reference sits that far from the converged path itself
 (measured: 3.5e-3 and 2.1e-3, tests/golden/make_exact_paths.py)."""
 import numpy as np
@@ -290,7 +290,7 @@ print('RESULT', repr(list(fit.posteriorLikelihood)), repr(fit.paramSeq[-1]['tau'
     outs = []
     for force in ('0', '1'):
         env = dict(os.environ, PGPFA_FORCE_COMM=force, RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_PORT='29655')
-        res = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=150)
+        res = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300)
         assert res.returncode == 0, res.stderr[-2000:]
         lines = res.stdout.splitlines()
         comm = [l for l in lines if l.startswith('COMM')][0]
