@@ -1677,6 +1677,27 @@ __global__ void gather_rows_kernel(const double* __restrict__ src, int len, doub
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < len) dst[(size_t)slot * sDst + i] = zero ? 0.0 : src[r * len + i];
 }
+// warm start with linear extrapolation of the mode over the last two E-steps of the trial (flag[slot] != 0):
+// dst = m + beta * (m - m_prev).  Over EM iterations the parameters drift smoothly and so do the modes.
+__global__ void gather_extrapolate_kernel(const double* __restrict__ mode, const double* __restrict__ prev, int len, double* __restrict__ dst,
+                                          long long sDst, const int* __restrict__ trial_of_slot, const int* __restrict__ flag, double beta) {
+  const int slot = blockIdx.y;
+  const size_t r = trial_of_slot[slot];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= len) return;
+  const double m = mode[r * len + i];
+  dst[(size_t)slot * sDst + i] = flag[slot] ? m + beta * (m - prev[r * len + i]) : m;
+}
+// mode <- new point; prev <- the mode it replaces where rotate[slot] != 0
+__global__ void scatter_rotate_kernel(const double* __restrict__ src, long long sSrc, int len, double* __restrict__ mode, double* __restrict__ prev,
+                                      const int* __restrict__ trial_of_slot, const int* __restrict__ rotate) {
+  const int slot = blockIdx.y;
+  const size_t r = trial_of_slot[slot];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= len) return;
+  if (rotate[slot]) prev[r * len + i] = mode[r * len + i];
+  mode[r * len + i] = src[(size_t)slot * sSrc + i];
+}
 __global__ void scatter_rows_kernel(const double* __restrict__ src, long long sSrc, int len, double* __restrict__ dst,
                                     const int* __restrict__ trial_of_slot) {
   const int slot = blockIdx.y;

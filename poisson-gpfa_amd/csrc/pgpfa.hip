@@ -79,6 +79,11 @@ struct pgpfa_ctx {
   double *C = nullptr, *d = nullptr, *tau = nullptr;
   double *Kpad = nullptr, *Kinv = nullptr;      // [p][Tp][Tp]
   double* Xmode = nullptr;                       // [R][p][T]   post_mean / warm start
+  double* Xprev = nullptr;                       // [R][p][T]   modes of the E-step before (warm-start extrapolation)
+  std::vector<int> mode_serial, prev_serial;     // E-step serial that produced Xmode / Xprev of a trial (-10: unknown)
+  int estep_serial = 0;
+  bool extrapolate = true;
+  double extrapolate_beta = 1.0;
   double* vsm = nullptr;                         // [R][T][p][p]
   double* vsmgp = nullptr;                       // [R][p][T][T]
   double* Pauto = nullptr;                       // [p][Tp][Tp]
@@ -723,6 +728,8 @@ int pgpfa_create(pgpfa_ctx** out, int device, int q, int p, int T, int R, double
   rc |= dmalloc(c, &c->C, (size_t)q * p); rc |= dmalloc(c, &c->d, q); rc |= dmalloc(c, &c->tau, p);
   rc |= dmalloc(c, &c->Kpad, slab * p); rc |= dmalloc(c, &c->Kinv, slab * p);
   rc |= dmalloc(c, &c->Xmode, (size_t)R * c->n + 64, true);
+  rc |= dmalloc(c, &c->Xprev, (size_t)R * c->n + 64, true);
+  c->mode_serial.assign(R, -10); c->prev_serial.assign(R, -10);
   rc |= dmalloc(c, &c->vsm, (size_t)R * T * p * p + 2048, true);
   rc |= dmalloc(c, &c->vsmgp, (size_t)R * p * T * T, true);
   rc |= dmalloc(c, &c->Pauto, slab * p, true);
@@ -793,6 +800,8 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
   else if (k == "cov_mode") c->cov_mode = (int)v;
   else if (k == "lowrank_tol") c->lr_tol = v;
   else if (k == "keep_trial_vsmgp") c->keep_trial_vsmgp = (v != 0.0);
+  else if (k == "extrapolate_start") c->extrapolate = (v != 0.0);
+  else if (k == "extrapolate_beta") c->extrapolate_beta = v;
   else if (k == "shared_min") c->shared_min = (int)v;
   else if (k == "pcg_inner") c->pcg_inner_max = std::max(1, (int)v);
   else if (k == "pcg_eta0") c->pcg_eta0 = v;
@@ -988,6 +997,7 @@ int pgpfa_set_modes(pgpfa_ctx* c, int n, const int32_t* idx, const double* X) {
     HIPC(hipMemcpyAsync(c->Xmode + (size_t)tr.v[i] * c->n, X + i * c->n, c->n * sizeof(double), hipMemcpyHostToDevice, c->st));
   HIPC(hipStreamSynchronize(c->st));
   c->pacc_valid = false;          // the accumulated covariance sum belonged to the modes just overwritten
+  for (int t_ : tr.v) c->mode_serial[t_] = -10;
   return 0;
 }
 
@@ -1282,8 +1292,23 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
     std::vector<int> tos(tr.v.begin() + c0, tr.v.begin() + c0 + nb);
     CHK(upload_list(c, c->trial_of_slot, tos));
     HIPC(hipMemsetAsync(c->ws.info, 0, sizeof(int) * nb, c->st));
-    hipLaunchKernelGGL(gather_rows_kernel, dim3((nvec + 255) / 256, nb), dim3(256), 0, c->st, c->Xmode, nvec, c->Xc, ld, c->trial_of_slot,
-                       warm_start ? 0 : 1);
+    {
+      std::vector<int> ext(nb, 0);
+      bool any = false;
+      if (warm_start && c->extrapolate)
+        for (int s = 0; s < nb; ++s) {
+          ext[s] = (c->mode_serial[tos[s]] == c->estep_serial - 1 && c->prev_serial[tos[s]] == c->estep_serial - 2) ? 1 : 0;
+          any = any || ext[s];
+        }
+      if (any) {
+        CHK(upload_list(c, c->list_a, ext));
+        hipLaunchKernelGGL(gather_extrapolate_kernel, dim3((nvec + 255) / 256, nb), dim3(256), 0, c->st, c->Xmode, c->Xprev, nvec, c->Xc, ld,
+                           c->trial_of_slot, c->list_a, c->extrapolate_beta);
+      } else {
+        hipLaunchKernelGGL(gather_rows_kernel, dim3((nvec + 255) / 256, nb), dim3(256), 0, c->st, c->Xmode, nvec, c->Xc, ld, c->trial_of_slot,
+                           warm_start ? 0 : 1);
+      }
+    }
     // objective, gradient pieces and curvature blocks at the start point
     CHK(prior_mv(c, c->ident, nb, c->Xc, c->KX));
     hipLaunchKernelGGL(dots3_kernel, dim3(nb), dim3(256), 0, c->st, c->Xc, ld, c->KX, ld, (const double*)nullptr, 0LL,
@@ -1508,7 +1533,22 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
     }
     n_fact += nb;
     for (int s = 0; s < nb; ++s) its[s] += 1;
-    hipLaunchKernelGGL(scatter_rows_kernel, dim3((nvec + 255) / 256, nb), dim3(256), 0, c->st, c->Xc, ld, nvec, c->Xmode, c->trial_of_slot);
+    {
+      // the mode a trial had before this E-step becomes its extrapolation base (once per E-step: a dense retry pass
+      // of the same E-step must not overwrite it with its own unfinished start point)
+      std::vector<int> rot(nb, 0);
+      for (int s = 0; s < nb; ++s) {
+        const int tr_ = tos[s];
+        if (c->mode_serial[tr_] != c->estep_serial) {
+          rot[s] = 1;
+          c->prev_serial[tr_] = c->mode_serial[tr_];
+          c->mode_serial[tr_] = c->estep_serial;
+        }
+      }
+      CHK(upload_list(c, c->list_a, rot));
+      hipLaunchKernelGGL(scatter_rotate_kernel, dim3((nvec + 255) / 256, nb), dim3(256), 0, c->st, c->Xc, ld, nvec, c->Xmode, c->Xprev,
+                         c->trial_of_slot, c->list_a);
+    }
     HIPC(hipMemcpyAsync(info.data(), c->ws.info, sizeof(int) * nb, hipMemcpyDeviceToHost, c->st));
     HIPC(hipStreamSynchronize(c->st));
     HIPC(hipGetLastError());
@@ -1540,6 +1580,7 @@ int pgpfa_estep_laplace(pgpfa_ctx* c, int n, const int32_t* idx, int warm_start,
   double obj = 0.0;
   HIPC(hipSetDevice(c->device));
   c->pacc_used = false; c->pacc_valid = false;
+  c->estep_serial += 1;
   HIPC(hipMemsetAsync(c->Pacc, 0, (size_t)c->Tp * c->Tp * c->p * sizeof(double), c->st));
   c->eC = c->hC; c->ed = c->hd; c->etau = c->htau;
   CHK(estep_impl(c, tr, warm_start, true, &obj, it1.data(), st1.data()));
@@ -1702,7 +1743,7 @@ int pgpfa_set_posterior(pgpfa_ctx* c, int n, const int32_t* idx, const double* p
   hipStreamSynchronize(c->st);
   if (tmp) hipFree(tmp);
   HIPC(hipGetLastError());
-  for (int t : tr.v) c->vsmgp_ok[t] = 1;          // whatever the caller provided (or left) is the resident value
+  for (int t : tr.v) { c->vsmgp_ok[t] = 1; c->mode_serial[t] = -10; }   // whatever the caller provided (or left) is the resident value
   return remember_trials(c, tr.v);
 }
 
@@ -2064,6 +2105,7 @@ int pgpfa_dual_finalize(pgpfa_ctx* c, int n, const int32_t* idx, const double* l
     CHK(posterior_blocks(c, nb, 1.0 + 1e-6, true));
     for (int t : tos) c->vsmgp_ok[t] = 1;
     hipLaunchKernelGGL(scatter_rows_kernel, dim3((c->n + 255) / 256, nb), dim3(256), 0, c->st, c->Xc, ld, c->n, c->Xmode, c->trial_of_slot);
+    for (int t_ : tos) c->mode_serial[t_] = -10;
     // negLogPosteriorUnNorm at the VI mean (inference.py:333)
     CHK(prior_mv(c, c->ident, nb, c->Xc, c->KX));
     hipLaunchKernelGGL(dots3_kernel, dim3(nb), dim3(256), 0, c->st, c->Xc, ld, c->KX, ld, (const double*)nullptr, 0LL, (const double*)nullptr, 0LL,
