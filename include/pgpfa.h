@@ -115,6 +115,10 @@ int pgpfa_get_pautosum(pgpfa_ctx* ctx, double* out /* [p][T][T] */);
 int pgpfa_mstep_tau_costgrad(pgpfa_ctx* ctx, int k, double logp, double* cost, double* grad);
 /* The same for all p latents at once (one batched factorisation): logp[p] -> cost[p], grad[p]. */
 int pgpfa_mstep_tau_costgrad_batch(pgpfa_ctx* ctx, const double* logp, double* cost, double* grad);
+/* m (1..4) candidate points per latent in one batched pass, candidate-major: logp[m][p] -> cost[m][p], grad[m][p].
+ * The pass is a latency-bound chain of small launches, so 4 candidates cost about as much as 1; the host-side
+ * root finder of learnGPparams brackets and interpolates with them instead of stepping serially. */
+int pgpfa_mstep_tau_costgrad_multi(pgpfa_ctx* ctx, int m, const double* logp, double* cost, double* grad);
 
 /* ---- dual variational E-step (inference.py:188-432) -------------------------------- */
 /* dualProblem and dualProblem_grad for one trial at lambda[q*T] (structured: never forms

@@ -91,11 +91,12 @@ __global__ void logdet_batch_kernel(const double* __restrict__ L, long long sL, 
 }
 
 // batched dot of equally laid out slabs: part[blockIdx.y][blockIdx.x]; then sum_part_batch
+// (bmod > 0: B is indexed by blockIdx.y % bmod - several batch entries share one B slab)
 __global__ void dot_part_batch_kernel(const double* __restrict__ A, long long sA, const double* __restrict__ B, long long sB, long long n,
-                                      double* __restrict__ part) {
+                                      double* __restrict__ part, int bmod) {
   __shared__ double red[256];
   const double* a = A + (size_t)blockIdx.y * sA;
-  const double* b = B + (size_t)blockIdx.y * sB;
+  const double* b = B + (size_t)(bmod > 0 ? blockIdx.y % bmod : blockIdx.y) * sB;
   double s = 0.0;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) s += a[i] * b[i];
   red[threadIdx.x] = s;

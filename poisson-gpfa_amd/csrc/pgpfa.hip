@@ -57,6 +57,7 @@ struct Prof {
   std::vector<Rec> recs;
   std::map<int, double> ms, flops, count;
 };
+constexpr int TAU_MULTI_MAX = 4;  // candidate points per latent in one batched timescale cost/gradient pass
 constexpr int PACC_SPLITS = 64;   // split-K groups of the sum-only vsmGP product
 enum { TAG_GEMM = 0, TAG_POTRF = 1, TAG_SOLVE = 2, TAG_POISSON = 3, TAG_ASSEMBLE = 4, TAG_VSM = 5, TAG_CD = 6, TAG_N };
 
@@ -763,10 +764,14 @@ int pgpfa_create(pgpfa_ctx** out, int device, int q, int p, int T, int R, double
     rc |= dmalloc(c, &c->cddelta, (size_t)q * (p + 1));
     rc |= dmalloc(c, &c->cddec, q);
   }
-  rc |= alloc_cholws(c, &c->kws, p, c->Tp, true);
+  rc |= alloc_cholws(c, &c->kws, p * TAU_MULTI_MAX, c->Tp, true);
   c->kws.nact = round_up(T, 64);
-  rc |= dmalloc(c, &c->tK, slab * p); rc |= dmalloc(c, &c->tM, slab * p); rc |= dmalloc(c, &c->tA1, slab * p); rc |= dmalloc(c, &c->tA2, slab * p);
-  rc |= dmalloc(c, &c->tscal, 16 + 8 * (size_t)p); rc |= dmalloc(c, &c->tpart, 1024 + 64 * (size_t)p);
+  {
+    const size_t nqmax = (size_t)p * TAU_MULTI_MAX;
+    rc |= dmalloc(c, &c->tK, slab * nqmax); rc |= dmalloc(c, &c->tM, slab * nqmax); rc |= dmalloc(c, &c->tA1, slab * nqmax);
+    rc |= dmalloc(c, &c->tA2, slab * nqmax);
+    rc |= dmalloc(c, &c->tscal, 16 + 8 * nqmax); rc |= dmalloc(c, &c->tpart, 1024 + 64 * nqmax);
+  }
   if (rc) { pgpfa_destroy(c); return 1; }
   e = hipStreamSynchronize(c->st);
   if (e != hipSuccess) { pgpfa_destroy(c); return fail("sync: %s", hipGetErrorString(e)); }
@@ -1954,56 +1959,65 @@ int pgpfa_mstep_tau_costgrad(pgpfa_ctx* c, int k, double logp, double* cost, dou
 }
 
 
-int pgpfa_mstep_tau_costgrad_batch(pgpfa_ctx* c, const double* logp, double* cost, double* grad) {
+// m candidate points per latent in ONE batched pass (queries ordered candidate-major: j = cand * p + latent).  The
+// pass is latency bound (a chain of ~30 small launches on T x T matrices), so evaluating 4 p matrices costs about
+// the same as p: the host-side root finder uses that to bracket and interpolate instead of stepping serially.
+int pgpfa_mstep_tau_costgrad_multi(pgpfa_ctx* c, int m, const double* logp, double* cost, double* grad) {
   if (!c || !logp || !cost || !grad) return fail("null argument");
+  if (m < 1 || m > TAU_MULTI_MAX) return fail("between 1 and %d candidates per latent (m=%d)", TAU_MULTI_MAX, m);
   if (!c->have_precomp) return fail("pgpfa_mstep_precomp has not been called");
   HIPC(hipSetDevice(c->device));
-  const int Tp = c->Tp, p = c->p;
+  const int Tp = c->Tp, p = c->p, nq = m * p;
   const size_t slab = (size_t)Tp * Tp;
-  for (int k = 0; k < p; ++k)
-    if (!std::isfinite(logp[k])) return fail("log-gamma[%d] is not finite", k);
-  double* dlogp = c->tscal + 16;                    // [p]
-  double* dres = c->tscal + 16 + p;                 // [4][p]: logdet, tr(KinvP), tr(KinvM), tr(KinvMKinvP)
-  CHK(upload(c, dlogp, logp, p));
-  hipLaunchKernelGGL(gram_gamma_batch_kernel, dim3(Tp, p), dim3(256), 0, c->st, c->tK, c->tM, Tp, c->T, dlogp, c->eps);
-  HIPC(hipMemcpyAsync(c->kws.H, c->tK, slab * p * sizeof(double), hipMemcpyDeviceToDevice, c->st));
-  HIPC(hipMemsetAsync(c->kws.info, 0, sizeof(int) * p, c->st));
-  CHK(factor(c, c->kws, nullptr, p));
-  hipLaunchKernelGGL(logdet_batch_kernel, dim3(p), dim3(256), 0, c->st, c->kws.H, (long long)slab, Tp, Tp, dres);
-  CHK(inverse_t(c, c->kws, nullptr, p));
+  for (int k = 0; k < nq; ++k)
+    if (!std::isfinite(logp[k])) return fail("log-gamma[%d] is not finite", k % p);
+  double* dlogp = c->tscal + 16;                     // [nq]
+  double* dres = c->tscal + 16 + nq;                 // [4][nq]: logdet, tr(KinvP), tr(KinvM), tr(KinvMKinvP)
+  CHK(upload(c, dlogp, logp, nq));
+  hipLaunchKernelGGL(gram_gamma_batch_kernel, dim3(Tp, nq), dim3(256), 0, c->st, c->tK, c->tM, Tp, c->T, dlogp, c->eps);
+  HIPC(hipMemcpyAsync(c->kws.H, c->tK, slab * nq * sizeof(double), hipMemcpyDeviceToDevice, c->st));
+  HIPC(hipMemsetAsync(c->kws.info, 0, sizeof(int) * nq, c->st));
+  CHK(factor(c, c->kws, nullptr, nq));
+  hipLaunchKernelGGL(logdet_batch_kernel, dim3(nq), dim3(256), 0, c->st, c->kws.H, (long long)slab, Tp, Tp, dres);
+  CHK(inverse_t(c, c->kws, nullptr, nq));
   GemmP g{};
   g.A = c->kws.Mt; g.sA = slab; g.lda = Tp; g.B = c->kws.Mt; g.sB = slab; g.ldb = Tp;
   g.C = c->tK; g.sC = slab; g.ldc = Tp;                       // tK <- Kinv
-  g.M = Tp; g.N = Tp; g.K = Tp; g.alpha = 1.0; g.beta = 0.0; g.slots = nullptr; g.nbatch = p; g.mode = GEMM_FULL; g.kflags = KF_BEGIN_MAXRC;
+  g.M = Tp; g.N = Tp; g.K = Tp; g.alpha = 1.0; g.beta = 0.0; g.slots = nullptr; g.nbatch = nq; g.mode = GEMM_FULL; g.kflags = KF_BEGIN_MAXRC;
   CHK(gemm(c, false, g));
   GemmP a1 = g;                                              // A1 = Kinv * M
   a1.A = c->tK; a1.B = c->tM; a1.C = c->tA1; a1.kflags = 0;
   CHK(gemm(c, false, a1));
-  GemmP a2 = g;                                              // A2 = P * Kinv
+  GemmP a2 = g;                                              // A2 = P * Kinv: P is per latent (lo index), Kinv / A2 per query
   a2.A = c->Pauto; a2.B = c->tK; a2.C = c->tA2; a2.kflags = 0;
+  a2.nb_lo = p; a2.sA_hi = 0; a2.sB_hi = (long long)p * slab; a2.sC_hi = (long long)p * slab;
   CHK(gemm(c, false, a2));
   const int nbk = 64;
-  auto bdot = [&](const double* A, const double* B, double* out) {
-    hipLaunchKernelGGL(dot_part_batch_kernel, dim3(nbk, p), dim3(256), 0, c->st, A, (long long)slab, B, (long long)slab, (long long)slab, c->tpart);
-    hipLaunchKernelGGL(sum_part_batch_kernel, dim3(1), dim3(64), 0, c->st, c->tpart, nbk, out, p);
+  auto bdot = [&](const double* A, const double* B, double* out, int bmod) {
+    hipLaunchKernelGGL(dot_part_batch_kernel, dim3(nbk, nq), dim3(256), 0, c->st, A, (long long)slab, B, (long long)slab, (long long)slab, c->tpart, bmod);
+    hipLaunchKernelGGL(sum_part_batch_kernel, dim3(1), dim3(64), 0, c->st, c->tpart, nbk, out, nq);
   };
-  bdot(c->tK, c->Pauto, dres + p);
-  bdot(c->tK, c->tM, dres + 2 * p);
-  bdot(c->tA1, c->tA2, dres + 3 * p);
+  bdot(c->tK, c->Pauto, dres + nq, p);
+  bdot(c->tK, c->tM, dres + 2 * nq, 0);
+  bdot(c->tA1, c->tA2, dres + 3 * nq, 0);
   HIPC(hipGetLastError());
-  std::vector<double> h(4 * (size_t)p);
-  std::vector<int> info(p);
-  HIPC(hipMemcpyAsync(h.data(), dres, 4 * p * sizeof(double), hipMemcpyDeviceToHost, c->st));
-  HIPC(hipMemcpyAsync(info.data(), c->kws.info, sizeof(int) * p, hipMemcpyDeviceToHost, c->st));
+  std::vector<double> h(4 * (size_t)nq);
+  std::vector<int> info(nq);
+  HIPC(hipMemcpyAsync(h.data(), dres, 4 * nq * sizeof(double), hipMemcpyDeviceToHost, c->st));
+  HIPC(hipMemcpyAsync(info.data(), c->kws.info, sizeof(int) * nq, hipMemcpyDeviceToHost, c->st));
   HIPC(hipStreamSynchronize(c->st));
   const double R = c->n_trials_global;
-  for (int k = 0; k < p; ++k) {
-    if (info[k] != 0) return fail("timescale Gram matrix of latent %d not positive definite at log-gamma=%g", k, logp[k]);
-    cost[k] = 0.5 * R * h[k] + 0.5 * h[p + k];
-    const double dE = -0.5 * R * h[2 * p + k] + 0.5 * h[3 * p + k];
+  for (int k = 0; k < nq; ++k) {
+    if (info[k] != 0) return fail("timescale Gram matrix of latent %d not positive definite at log-gamma=%g", k % p, logp[k]);
+    cost[k] = 0.5 * R * h[k] + 0.5 * h[nq + k];
+    const double dE = -0.5 * R * h[2 * nq + k] + 0.5 * h[3 * nq + k];
     grad[k] = -dE * std::exp(logp[k]);
   }
   return 0;
+}
+
+int pgpfa_mstep_tau_costgrad_batch(pgpfa_ctx* c, const double* logp, double* cost, double* grad) {
+  return pgpfa_mstep_tau_costgrad_multi(c, 1, logp, cost, grad);
 }
 
 // ---- dual variational E-step (inference.py:188-432) ----------------------------------------------------

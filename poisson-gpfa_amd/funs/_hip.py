@@ -45,6 +45,7 @@ _SIGNATURES = {
     'pgpfa_get_pautosum': [ct.c_void_p, c_double_p],
     'pgpfa_mstep_tau_costgrad': [ct.c_void_p, ct.c_int, ct.c_double, c_double_p, c_double_p],
     'pgpfa_mstep_tau_costgrad_batch': [ct.c_void_p, c_double_p, c_double_p, c_double_p],
+    'pgpfa_mstep_tau_costgrad_multi': [ct.c_void_p, ct.c_int, c_double_p, c_double_p, c_double_p],
     'pgpfa_dual_costgrad': [ct.c_void_p, ct.c_int, c_double_p, c_double_p, c_double_p],
     'pgpfa_dual_finalize': [ct.c_void_p, ct.c_int, c_int32_p, c_double_p, c_double_p],
     'pgpfa_comm_unique_id': [ct.c_char_p],
@@ -298,6 +299,14 @@ class Context:
         logp = as_f64(logp).reshape(-1)
         cost, grad = np.empty(self.p), np.empty(self.p)
         check(self.lib.pgpfa_mstep_tau_costgrad_batch(self.h, dptr(logp), dptr(cost), dptr(grad)))
+        return cost, grad
+
+    def mstep_tau_costgrad_multi(self, logp):
+        """logp[m][p] (m <= 4 candidate points per latent) -> cost[m][p], grad[m][p] in one batched pass."""
+        logp = as_f64(logp).reshape(-1, self.p)
+        m = logp.shape[0]
+        cost, grad = np.empty((m, self.p)), np.empty((m, self.p))
+        check(self.lib.pgpfa_mstep_tau_costgrad_multi(self.h, int(m), dptr(logp), dptr(cost), dptr(grad)))
         return cost, grad
 
     # -- comm --------------------------------------------------------------------------------------

@@ -279,6 +279,104 @@ def _lockstep_minimize(evaluate, p0, gtol=1e-8, xtol=1e-10, max_iter=60, curv0=N
     return p, f, g, nfev, done, curv_seen
 
 
+def _newton_poly_root(X, Y, lo, hi):
+    """Roots in (lo, hi) of the polynomials interpolating (X[:, j], Y[:, j]) (columns = independent problems, Y
+    changes sign between lo and hi): Newton divided differences, then bisection on the interpolant."""
+    n = X.shape[0]
+    coef = Y.copy()
+    for lvl in range(1, n):
+        coef[lvl:] = (coef[lvl:] - coef[lvl - 1:-1]) / (X[lvl:] - X[:n - lvl])
+
+    def poly(z):
+        v = coef[n - 1].copy()
+        for i in range(n - 2, -1, -1):
+            v = v * (z - X[i]) + coef[i]
+        return v
+    a, b = lo.copy(), hi.copy()
+    for _ in range(60):
+        mid = 0.5 * (a + b)
+        up = poly(mid) > 0
+        b = np.where(up, mid, b)
+        a = np.where(up, a, mid)
+    return 0.5 * (a + b)
+
+
+def _lockstep_multi(evaluate_multi, p0, d_hint=None, gtol=1e-8, xtol=1e-10, max_rounds=30, m=4):
+    """Roots of xdim independent increasing functions g_k = f_k' (f_k smooth, one minimum) found together with m
+    candidate points per latent per round; a round is ONE batched device pass (its cost is launch latency, nearly
+    independent of m).  Round 1 spreads its points along the displacement predicted from the previous EM
+    iteration (d_hint), later rounds place them in a shrinking cluster around the root of the cubic through the
+    samples next to the sign change; stops per latent on |g| <= gtol or when two successive root predictions
+    agree to xtol.  Returns (p, f, g, rounds, done)."""
+    p0 = np.array(p0, dtype=np.float64)
+    k = p0.size
+    if d_hint is not None:
+        d = np.asarray(d_hint, dtype=np.float64)
+        d = np.where(np.isfinite(d) & (np.abs(d) > 1e-6), np.clip(d, -1.0, 1.0), np.nan)
+    else:
+        d = np.full(k, np.nan)
+    hinted = np.isfinite(d)
+    Q = np.where(hinted[None, :], p0[None, :] + np.array([0.0, 0.6, 1.0, 1.5])[:, None] * np.where(hinted, d, 0.0)[None, :],
+                 p0[None, :] + 0.25 * np.array([-1.0, -1.0 / 3, 1.0 / 3, 1.0])[:, None])
+    Ps, Fs, Gs = np.empty((0, k)), np.empty((0, k)), np.empty((0, k))
+    done = np.zeros(k, dtype=bool)
+    root, pred_prev = p0.copy(), np.full(k, np.nan)
+    rounds = 0
+    offs = np.array([-1.5, -0.5, 0.5, 1.5])
+    for rounds in range(1, max_rounds + 1):
+        F, G = evaluate_multi(Q)
+        Ps, Fs, Gs = np.vstack([Ps, Q]), np.vstack([Fs, F]), np.vstack([Gs, G])
+        ib = np.argmin(np.abs(Gs), axis=0)
+        cols = np.arange(k)
+        best_p, best_g = Ps[ib, cols], Gs[ib, cols]
+        hit = (~done) & (np.abs(best_g) <= gtol)
+        root = np.where(hit, best_p, root)
+        done = done | hit
+        lo = np.max(np.where(Gs < 0, Ps, -np.inf), axis=0)
+        hi = np.min(np.where(Gs > 0, Ps, np.inf), axis=0)
+        brack = np.isfinite(lo) & np.isfinite(hi) & (hi > lo)
+        Qn = np.tile(root[None, :], (m, 1)) + 1e-7 * offs[:, None]        # finished latents: harmless filler
+        work = brack & ~done
+        if np.any(work):
+            w = np.where(work, hi - lo, 1.0)
+            mid = np.where(work, 0.5 * (lo + hi), 0.0)
+            order = np.argsort(np.abs(Ps - mid[None, :]), axis=0, kind='stable')[:4]
+            X, Y = np.take_along_axis(Ps, order, axis=0), np.take_along_axis(Gs, order, axis=0)
+            srt = np.argsort(X, axis=0)
+            X, Y = np.take_along_axis(X, srt, axis=0), np.take_along_axis(Y, srt, axis=0)
+            distinct = np.all(np.diff(X, axis=0) > 0, axis=0)
+            with np.errstate(all='ignore'):
+                r_poly = _newton_poly_root(X, Y, np.where(work, lo, 0.0), np.where(work, hi, 1.0))
+            glo = np.max(np.where((Gs < 0) & (Ps == lo[None, :]), Gs, -np.inf), axis=0)
+            ghi = np.min(np.where((Gs > 0) & (Ps == hi[None, :]), Gs, np.inf), axis=0)
+            with np.errstate(all='ignore'):
+                r_sec = lo - glo * (hi - lo) / (ghi - glo)
+            r = np.where(distinct & np.isfinite(r_poly), r_poly, r_sec)
+            r = np.where(np.isfinite(r) & (r > lo) & (r < hi), r, mid)
+            err = np.abs(r - pred_prev)
+            agree = work & np.isfinite(err) & (err <= xtol)
+            root = np.where(work, r, root)
+            done = done | agree | (work & (w <= 4.0 * xtol))
+            delta = np.where(np.isfinite(err), np.clip(2.0 * err, 4.0 * xtol, 0.02 * w), 0.02 * w)
+            cluster = r[None, :] + delta[None, :] * offs[:, None]
+            Qn = np.where((work & ~done)[None, :], cluster, Qn)
+            pred_prev = np.where(work, r, pred_prev)
+        loose = (~brack) & (~done)
+        if np.any(loose):
+            # no sign change yet: step out geometrically beyond the outermost sample on the downhill side
+            sgn = -np.sign(np.where(loose, best_g, 1.0))
+            far = np.where(sgn > 0, np.max(Ps, axis=0), np.min(Ps, axis=0))
+            span = np.maximum(np.max(Ps, axis=0) - np.min(Ps, axis=0), 0.1)
+            out = far[None, :] + (sgn * span)[None, :] * np.array([0.5, 1.0, 2.0, 4.0])[:, None]
+            Qn = np.where(loose[None, :], out, Qn)
+        if np.all(done):
+            break
+        Q = Qn
+    ib = np.argmin(np.abs(Ps - root[None, :]), axis=0)
+    cols = np.arange(k)
+    return root, Fs[ib, cols], Gs[ib, cols], rounds, done
+
+
 def learnGPparams(oldParams, infRes, experiment):
     """reference learning.py:257-293: minimise each latent's timescale cost from p0 = log(1/tau_bins^2) to
     |grad| <= 1e-8.  The xdim problems are independent and one-dimensional, so by default they are solved in
@@ -291,14 +389,20 @@ def learnGPparams(oldParams, infRes, experiment):
     DevicePrecomp(sess, sess.T)
     initp = np.log(1 / oldTau ** 2)
     details = [[]] * xdim
-    if TAU_SOLVER == 'lockstep':
-        # curvature of each latent's cost at the previous EM iteration's optimum seeds the first secant step
-        pv, fv, gv, nfev, ok, curv = _lockstep_minimize(sess.ctx.mstep_tau_costgrad_batch, initp,
-                                                        curv0=getattr(sess, '_tau_curv', None))
-        sess._tau_curv = curv
+    if TAU_SOLVER in ('lockstep', 'secant'):
+        if TAU_SOLVER == 'lockstep':
+            # 4 candidate points per latent per batched pass; the displacement of the previous EM iteration's M-step
+            # predicts where this one's optimum lies
+            pv, fv, gv, nfev, ok = _lockstep_multi(sess.ctx.mstep_tau_costgrad_multi, initp, d_hint=getattr(sess, '_tau_step', None))
+            sess._tau_step = pv - initp
+        else:
+            # one point per latent per pass: safeguarded secant, seeded with the curvature seen in the previous M-step
+            pv, fv, gv, nfev, ok, curv = _lockstep_minimize(sess.ctx.mstep_tau_costgrad_batch, initp,
+                                                            curv0=getattr(sess, '_tau_curv', None))
+            sess._tau_curv = curv
         for xd in range(xdim):
             details[xd] = op.OptimizeResult(x=np.array([pv[xd]]), fun=fv[xd], jac=np.array([gv[xd]]), nfev=nfev,
-                                            success=bool(ok[xd]), message='lockstep secant')
+                                            success=bool(ok[xd]), message='lockstep %s' % ('multi-point' if TAU_SOLVER == 'lockstep' else 'secant'))
         tempTau = (1 / np.exp(pv)) ** 0.5
         return tempTau * binSize / 1000, details
     tempTau = np.zeros(xdim)

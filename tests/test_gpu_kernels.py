@@ -212,11 +212,19 @@ def test_tau_batch_equals_single_and_lockstep_matches_bfgs(hip, c1):
         for k in range(3):
             c1_, g1_ = ctx.mstep_tau_costgrad(k, logp[k])
             assert abs(cb[k] - c1_) <= 1e-12 * abs(c1_) and abs(gb[k] - g1_) <= 1e-10 * max(1.0, abs(g1_))
+        # several candidate points per latent in one pass (candidate-major) == one pass per candidate set
+        cand = np.stack([logp, logp + 0.3, logp - 0.2, logp + 0.01])
+        cm, gm = ctx.mstep_tau_costgrad_multi(cand)
+        for j in range(4):
+            cj, gj = ctx.mstep_tau_costgrad_batch(cand[j])
+            assert np.max(np.abs(cm[j] - cj) / np.abs(cj)) <= 1e-12 and np.max(np.abs(gm[j] - gj)) <= 1e-9 * np.max(np.abs(gj))
+        with pytest.raises(hip.HipBackendError):
+            ctx.mstep_tau_costgrad_multi(np.zeros((5, 3)))
     finally:
         ctx.close()
     exp = Experiment(c1['Ys'], c1['binSize'])
     tau_o, _ = orc.learn_tau(c1['init'], res, c1['binSize'])
-    for solver in ('lockstep', 'scipy'):
+    for solver in ('lockstep', 'secant', 'scipy'):
         funs.learning.TAU_SOLVER = solver
         try:
             tau, det = funs.learning.learnGPparams(c1['init'], res, exp)
