@@ -106,6 +106,10 @@ int pgpfa_mstep_cd_costgrad(pgpfa_ctx* ctx, const double* vecCd, const double* p
  * Newton decrements dec[q]; pgpfa_mstep_cd_cost_per_neuron evaluates trial points for the line search. */
 int pgpfa_mstep_cd_newton_pass(pgpfa_ctx* ctx, const double* vecCd, const double* prior_center, double inv_s2,
                                double* cost_n /* [q] */, double* delta /* [q*(p+1)] */, double* dec /* [q] */);
+/* Chord pass: cost and gradient at vecCd (one cheap sweep), step from the per-neuron Hessians of the last
+ * pgpfa_mstep_cd_newton_pass (also across EM iterations: they stay SPD, the step stays a descent direction). */
+int pgpfa_mstep_cd_chord_pass(pgpfa_ctx* ctx, const double* vecCd, const double* prior_center, double inv_s2,
+                              double* cost_n /* [q] */, double* delta /* [q*(p+1)] */, double* dec /* [q] */);
 int pgpfa_mstep_cd_cost_per_neuron(pgpfa_ctx* ctx, const double* vecCd, const double* prior_center, double inv_s2,
                                    double* cost_n /* [q] */);
 /* makePrecomp (learning.py:145-173): PautoSum[p][T][T] over the same trials (all-reduced). */

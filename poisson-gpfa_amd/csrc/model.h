@@ -975,6 +975,17 @@ __global__ void cd_newton_step_kernel(const double* __restrict__ sums, int q, in
   dec[n] = dd;
 }
 
+// chord pass: put a fresh cost/gradient (layout of mstep_cd_kernel: rows 0..p-1 dC, p dd, p+1 cost; signs of the
+// maximised sum) into the cost/gradient rows of the Newton sums (rows 0 cost, 1..p+1 gradient of the minimised
+// function); the Hessian rows of the last full pass stay.  One thread per (row, neuron).
+__global__ void cd_chord_merge_kernel(const double* __restrict__ cg, int q, int p, double* __restrict__ sums) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (p + 2) * q) return;
+  const int row = e / q, n = e - row * q;
+  if (row == 0) sums[n] = cg[(size_t)(p + 1) * q + n];
+  else sums[(size_t)row * q + n] = -cg[(size_t)(row - 1) * q + n];
+}
+
 // out[e] = sum_b part[b][e]
 __global__ void reduce_parts_kernel(const double* __restrict__ part, int nb, int len, double* __restrict__ out) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;

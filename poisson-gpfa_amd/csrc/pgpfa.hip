@@ -95,6 +95,7 @@ struct pgpfa_ctx {
   double *CCu = nullptr, *C16 = nullptr;         // zero-padded pair-product / loading tables of the MFMA Poisson pass
   int qpad = 0, ccu_cols = 0;
   double* ppart = nullptr;                       // [p][PACC_SPLITS + 1][T x T] split-K partial products
+  bool cd_hess_valid = false; int cd_hess_ntr = 0;   // per-neuron Hessian sums of the last Newton pass are resident
   bool keep_trial_vsmgp = false;
   bool pacc_used = false, pacc_valid = false;
   std::vector<char> vsmgp_ok;                    // per trial: c->vsmgp holds the blocks of the resident posterior
@@ -1838,7 +1839,63 @@ int pgpfa_mstep_cd_newton_pass(pgpfa_ctx* c, const double* vecCd, const double* 
                      1.0 / Rtot, c->vec, prior_center ? c->cdcenter : nullptr, inv_s2, c->cddelta, c->cddec);
   HIPC(hipGetLastError());
   CHK(ensure_hbuf(c, (size_t)q));
+  c->cd_hess_valid = true;
+  c->cd_hess_ntr = a.ntr;
   CHK(download(c, c->hbuf, c->cdhout, q));                 // row 0: sum (y*hh - yhat) per neuron
+  CHK(download(c, delta, c->cddelta, (size_t)q * D));
+  CHK(download(c, dec, c->cddec, q));
+  for (int n = 0; n < q; ++n) {
+    double cn = -c->hbuf[n] / Rtot;
+    if (prior_center) {
+      double s2 = 0.0;
+      for (int i = 0; i < D; ++i) { const double dv = vecCd[(size_t)i * q + n] - prior_center[(size_t)i * q + n]; s2 += dv * dv; }
+      cn += 0.5 * inv_s2 * s2;
+    }
+    cost_n[n] = cn;
+  }
+  return 0;
+}
+
+// Chord variant of the pass above: cost and gradient are evaluated at vecCd (the cheap kernel), the per-neuron
+// Hessians are the ones of the last pgpfa_mstep_cd_newton_pass (still a descent direction: they are SPD).
+int pgpfa_mstep_cd_chord_pass(pgpfa_ctx* c, const double* vecCd, const double* prior_center, double inv_s2, double* cost_n,
+                              double* delta, double* dec) {
+  if (!c || !vecCd || !cost_n || !delta || !dec) return fail("null argument");
+  if (!c->have_counts) return fail("spike counts have not been uploaded");
+  if (!c->have_post) return fail("no E-step result resident: run an E-step or pgpfa_set_posterior first");
+  if (!c->cd_hess_valid) return fail("no per-neuron Hessians resident: call pgpfa_mstep_cd_newton_pass first");
+  HIPC(hipSetDevice(c->device));
+  const int q = c->q, p = c->p, T = c->T, D = p + 1;
+  const int NH = 1 + D + D * (D + 1) / 2;
+  const int len = (p + 2) * q;
+  CHK(upload(c, c->vec, vecCd, (size_t)q * D));
+  if (prior_center) CHK(upload(c, c->cdcenter, prior_center, (size_t)q * D));
+  CdArgs a{};
+  a.Y = c->Y; a.mean = c->Xmode; a.vsm = c->vsm; a.vec = c->vec;
+  a.trials = c->last_trials; a.ntr = (int)c->last_trials_h.size();
+  a.part = c->cdpart; a.q = q; a.p = p; a.T = T;
+  const int nchunk = (q + 63) / 64;
+  const int nby = std::max(1, std::min(a.ntr * 4, std::max(64, 1024 / nchunk)));
+  prof_begin(c, TAG_CD, (double)a.ntr * q * T * (2.0 * p * p + 8.0 * p));
+  dispatch_pw(p, [&](auto pw) {
+    hipLaunchKernelGGL(mstep_cd_kernel<decltype(pw)::value>, dim3((q + 63) / 64, nby), dim3(64, CD_KY), 0, c->st, a);
+  });
+  prof_end(c);
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3((len + 255) / 256), dim3(256), 0, c->st, c->cdpart, nby, len, c->cdout);
+  const double cnt = (double)a.ntr;
+  HIPC(hipMemcpyAsync(c->cdout + len, &cnt, sizeof(double), hipMemcpyHostToDevice, c->st));
+  CHK(allreduce_dev(c, c->cdout, (size_t)len + 1));
+  double Rtot = 0.0;
+  CHK(download(c, &Rtot, c->cdout + len, 1));
+  c->n_trials_global = Rtot;
+  hipLaunchKernelGGL(cd_chord_merge_kernel, dim3((len + 255) / 256), dim3(256), 0, c->st, c->cdout, q, p, c->cdhout);
+  const int th = 32;
+  hipLaunchKernelGGL(cd_newton_step_kernel, dim3((q + th - 1) / th), dim3(th), (size_t)th * (D * D + 2 * D) * sizeof(double), c->st, c->cdhout, q, p,
+                     1.0 / Rtot, c->vec, prior_center ? c->cdcenter : nullptr, inv_s2, c->cddelta, c->cddec);
+  HIPC(hipGetLastError());
+  (void)NH;
+  CHK(ensure_hbuf(c, (size_t)q));
+  CHK(download(c, c->hbuf, c->cdhout, q));
   CHK(download(c, delta, c->cddelta, (size_t)q * D));
   CHK(download(c, dec, c->cddec, q));
   for (int n = 0; n < q; ++n) {

@@ -40,6 +40,7 @@ _SIGNATURES = {
     'pgpfa_set_posterior': [ct.c_void_p, ct.c_int, c_int32_p, c_double_p, c_double_p, c_double_p],
     'pgpfa_mstep_cd_costgrad': [ct.c_void_p, c_double_p, c_double_p, ct.c_double, c_double_p, c_double_p],
     'pgpfa_mstep_cd_newton_pass': [ct.c_void_p, c_double_p, c_double_p, ct.c_double, c_double_p, c_double_p, c_double_p],
+    'pgpfa_mstep_cd_chord_pass': [ct.c_void_p, c_double_p, c_double_p, ct.c_double, c_double_p, c_double_p, c_double_p],
     'pgpfa_mstep_cd_cost_per_neuron': [ct.c_void_p, c_double_p, c_double_p, ct.c_double, c_double_p],
     'pgpfa_mstep_precomp': [ct.c_void_p, c_double_p],
     'pgpfa_get_pautosum': [ct.c_void_p, c_double_p],
@@ -271,6 +272,16 @@ class Context:
         delta = np.empty(self.q * (self.p + 1))
         check(self.lib.pgpfa_mstep_cd_newton_pass(self.h, dptr(vec), None if pc is None else dptr(pc), float(inv_s2),
                                                   dptr(cost_n), dptr(delta), dptr(dec)))
+        return cost_n, delta, dec
+
+    def mstep_cd_chord_pass(self, vec, prior_center=None, inv_s2=0.0):
+        """cost_n, Newton-like step and decrement at vec with the Hessians of the last mstep_cd_newton_pass."""
+        vec = as_f64(vec).reshape(-1)
+        pc = None if prior_center is None else as_f64(prior_center).reshape(-1)
+        cost_n, dec = np.empty(self.q), np.empty(self.q)
+        delta = np.empty(self.q * (self.p + 1))
+        check(self.lib.pgpfa_mstep_cd_chord_pass(self.h, dptr(vec), None if pc is None else dptr(pc), float(inv_s2),
+                                                 dptr(cost_n), dptr(delta), dptr(dec)))
         return cost_n, delta, dec
 
     def mstep_cd_cost_per_neuron(self, vec, prior_center=None, inv_s2=0.0):

@@ -22,14 +22,18 @@ orig_pass = sess.ctx.mstep_cd_newton_pass
 def cpass(*a):
     t0 = time.time(); r = orig_pass(*a); cnt['cd_ms'] = cnt.get('cd_ms', 0) + (time.time() - t0) * 1e3; cnt['cd'] = cnt.get('cd', 0) + 1; return r
 sess.ctx.mstep_cd_newton_pass = cpass
+orig_chord = sess.ctx.mstep_cd_chord_pass
+def cchord(*a):
+    t0 = time.time(); r = orig_chord(*a); cnt['cd_ms'] = cnt.get('cd_ms', 0) + (time.time() - t0) * 1e3; cnt['chord'] = cnt.get('chord', 0) + 1; return r
+sess.ctx.mstep_cd_chord_pass = cchord
 for it in range(5):
     infRes, nll, optim = funs.inference.laplace(exp, params, prevOptimRes=optim)
-    cnt.update(tau=0, tau_ms=0.0, cd=0, cd_ms=0.0)
+    cnt.update(tau=0, tau_ms=0.0, cd=0, cd_ms=0.0, chord=0)
     t0 = time.time()
     C, d, _ = learning.learnLTparams(params, infRes, exp, 'newton')
     t1 = time.time()
     tau, det = learning.learnGPparams(params, infRes, exp)
     t2 = time.time()
     params = {'C': C, 'd': d, 'tau': tau}
-    print('it', it, 'cd %.1f ms (%d passes, %.1f ms in passes)' % ((t1 - t0) * 1e3, cnt['cd'], cnt['cd_ms']),
+    print('it', it, 'cd %.1f ms (%d full + %d chord passes, %.1f ms in passes)' % ((t1 - t0) * 1e3, cnt['cd'], cnt['chord'], cnt['cd_ms']),
           'tau total %.1f ms (%d evals, %.1f ms in evals)' % ((t2 - t1) * 1e3, cnt['tau'], cnt['tau_ms']), flush=True)
