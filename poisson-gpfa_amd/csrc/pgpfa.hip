@@ -254,7 +254,7 @@ int gemm(pgpfa_ctx* c, bool transb, GemmP g) {
   // (block-sparse operands: the k loop a tile really runs is the one implied by the flop count)
   const double k_eff = (g.flops_hint > 0.0 && g.M > 0 && g.N > 0) ? g.flops_hint / (2.0 * g.M * g.N * std::max(g.nbatch, 1)) : (double)g.K;
   if (c->gemm_part && g.mode == GEMM_FULL && g.kflags == 0 && g.nb_lo == 0 && g.kseg == 0 && tiles > 0 && tiles < 384 && k_eff >= 256.0) {
-    ksplit = std::min(std::min(8, (int)(k_eff / 128.0)), (640 + tiles - 1) / tiles);
+    ksplit = std::min(std::min(8, (int)(k_eff / 64.0)), (640 + tiles - 1) / tiles);
     while (ksplit > 1 && (size_t)ksplit * g.nbatch * g.M * g.N > c->gemm_part_len) --ksplit;
   }
   hipError_t e;
