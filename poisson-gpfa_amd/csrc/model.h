@@ -115,13 +115,6 @@ __global__ void sum_part_batch_kernel(const double* __restrict__ part, int nper,
   out[b] = s;
 }
 
-// copy the lower triangle onto the upper one (slab of size n, ld)
-__global__ void symmetrize_kernel(double* __restrict__ A, long long sA, int ld, int n) {
-  double* a = A + (size_t)blockIdx.y * sA;
-  const int j = blockIdx.x;
-  for (int i = j + 1 + threadIdx.x; i < n; i += blockDim.x) a[(size_t)i * ld + j] = a[(size_t)j * ld + i];
-}
-
 // sum_i log(diag(L)) * 2 for one slab
 __global__ void logdet_kernel(const double* __restrict__ L, int ld, int n, double* __restrict__ out) {
   __shared__ double red[256];
@@ -1078,31 +1071,6 @@ __global__ void mean_w_kernel(const double* __restrict__ W, long long sW, const 
   out[e] = s / (double)nslots;
 }
 
-// transpose a (npad x npad) lower factor slab into an upper slab U = L^T, and its 128x128 diagonal
-// inverses into DinvT[k] = Dinv[k]^T (one slot)
-__global__ void transpose_lower_kernel(const double* __restrict__ L, double* __restrict__ U, int ld, int npad) {
-  __shared__ double tile[32][33];
-  const int bi = blockIdx.x * 32, bj = blockIdx.y * 32;
-  if (bi < bj) return;                                    // only tiles on/below the diagonal hold data
-  for (int r = threadIdx.y; r < 32; r += blockDim.y) {
-    const int i = bi + threadIdx.x, j = bj + r;
-    tile[r][threadIdx.x] = (i < npad && j < npad && i >= j) ? L[(size_t)j * ld + i] : 0.0;
-  }
-  __syncthreads();
-  for (int r = threadIdx.y; r < 32; r += blockDim.y) {
-    const int j = bj + threadIdx.x, i = bi + r;           // U[j][i] = L[i][j], stored column-major: U[i*ld + j]
-    if (i < npad && j < npad) U[(size_t)i * ld + j] = tile[threadIdx.x][r];
-  }
-}
-__global__ void transpose_diag_blocks_kernel(const double* __restrict__ D, double* __restrict__ DT) {
-  const double* d = D + (size_t)blockIdx.x * 128 * 128;
-  double* t = DT + (size_t)blockIdx.x * 128 * 128;
-  for (int e = threadIdx.x; e < 128 * 128; e += blockDim.x) {
-    const int r = e & 127, c = e >> 7;
-    t[(size_t)r * 128 + c] = d[(size_t)c * 128 + r];
-  }
-}
-
 // q = W p  added onto q (which already holds Kinv p):  q[(k,t)] += sum_l W[t][k][l] p[(l,t)]
 // then pq[slot] = p.q ; block per slot, thread per bin (W_t is one contiguous p*p block per thread)
 template <int PW>
@@ -1209,13 +1177,6 @@ __global__ __launch_bounds__(256) void step_stats_kernel(const double* __restric
     dec[slot] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
     smax[slot] = fmax(fmax(red[1][0], red[1][1]), fmax(red[1][2], red[1][3]));
   }
-}
-
-// copy rows of the listed slots: dst[slot] = src[slot] (n entries)
-__global__ void copy_rows_kernel(const double* __restrict__ src, double* __restrict__ dst, long long sV, int n, const int* __restrict__ slots) {
-  const size_t slot = slots[blockIdx.y];
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) dst[slot * sV + i] = src[slot * sV + i];
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -1475,42 +1436,10 @@ __global__ __launch_bounds__(256) void vsm_finish_kernel(double* __restrict__ vs
   }
 }
 
-// In-place mixing of Yt (n x rpad, ld = ldy): for every bin t and column b the p-vector y = Yt[(.,t), b] is replaced
-// by G_t y.  Afterwards rows (k,.) of the slab ARE Ymix_k, so post_vsmGP_k = eps diag + Ymix_k Ymix_k^T reads its GEMM
-// operand straight from the slab (one pass over Yt instead of one per latent).
-// grid = (ceil(T/64), ceil(rpad/128), nslots), block = 256: lanes = bins, each wave 32 columns; G_t lives in registers.
-template <int PW>
-__global__ __launch_bounds__(256) void mix_inplace_kernel(double* __restrict__ Yt, long long sY, int ldy, const double* __restrict__ G, long long sG,
-                                                          int T, int p, int rpad, const int* __restrict__ slots) {
-  const size_t slot = slots[blockIdx.z];
-  const int t = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int b0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 32;      // 4 waves per block, 32 columns each
-  if (t >= T || b0 >= rpad) return;
-  const double* gsrc = G + slot * sG + (size_t)t * p * p;
-  double g[PW * PW];                                               // G_t in registers (zero padded to PW x PW)
-#pragma unroll
-  for (int k = 0; k < PW; ++k)
-#pragma unroll
-    for (int kk = 0; kk < PW; ++kk) g[k * PW + kk] = (k < p && kk < p) ? gsrc[k * p + kk] : 0.0;
-  double* y = Yt + slot * sY + t;
-  const int b1 = (b0 + 32 < rpad) ? b0 + 32 : rpad;
-  for (int b = b0; b < b1; ++b) {
-    double v[PW];
-#pragma unroll
-    for (int k = 0; k < PW; ++k) v[k] = (k < p) ? y[(size_t)b * ldy + (size_t)k * T] : 0.0;
-#pragma unroll
-    for (int k = 0; k < PW; ++k) {
-      double s2 = 0.0;
-#pragma unroll
-      for (int kk = 0; kk < PW; ++kk) s2 += g[k * PW + kk] * v[kk];
-      if (k < p) y[(size_t)b * ldy + (size_t)k * T] = s2;
-    }
-  }
-}
-
-// Fused form of the two passes above plus vsm_finish: every p-vector y = Yt[(.,t), b] is replaced by G_t y AND the
-// per-bin blocks post_vsm[t] = eps G_t + sum_b (G_t y_b)(G_t y_b)^T are accumulated on the way (G_t symmetric, so this
-// is eps G + G (Y_t^T Y_t) G).  One read and one write of Yt instead of two reads and one write.
+// Mixing pass over Yt (n x rpad, ld = ldy) of the low-rank engine: every p-vector y = Yt[(.,t), b] is replaced by G_t y
+// - afterwards rows (k,.) of the slab ARE Ymix_k, the GEMM operand of post_vsmGP_k = eps diag + Ymix_k Ymix_k^T - AND
+// the per-bin blocks post_vsm[t] = eps G_t + sum_b (G_t y_b)(G_t y_b)^T are accumulated on the way (G_t symmetric, so
+// this is eps G + G (Y_t^T Y_t) G: what post_vsm_kernel + vsm_finish_kernel compute from the unmixed slab).
 // A block owns 64 bins (lanes) of one slot and ALL columns (its 4 waves take interleaved columns); G_t sits in LDS
 // (odd stride: each lane reads its own block conflict-free), the p(p+1)/2 accumulators in registers; the waves'
 // partial sums are folded into the LDS copy of G in turn (-> eps G + sum), which then leaves as one contiguous run.
