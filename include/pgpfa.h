@@ -124,6 +124,12 @@ int pgpfa_mstep_tau_costgrad_batch(pgpfa_ctx* ctx, const double* logp, double* c
  * root finder of learnGPparams brackets and interpolates with them instead of stepping serially. */
 int pgpfa_mstep_tau_costgrad_multi(pgpfa_ctx* ctx, int m, const double* logp, double* cost, double* grad);
 
+/* ---- leave-one-neuron-out prediction (util.py:289-334, engine.py:599-644) ----------- */
+/* For each listed trial (idx NULL: all R) and each neuron nn: the Laplace mode of the latents given the other
+ * q-1 neurons (cold start), then y_pred[(trial, nn)][t] = exp(C[nn] . x_t + d[nn]); err_sum = sum of squared
+ * differences to the held-out counts.  The R*q mode searches run batched on the E-step machinery. */
+int pgpfa_loo_predict(pgpfa_ctx* ctx, int n, const int32_t* idx, double* y_pred /* [n][q][T] */, double* err_sum);
+
 /* ---- dual variational E-step (inference.py:188-432) -------------------------------- */
 /* dualProblem and dualProblem_grad for one trial at lambda[q*T] (structured: never forms
  * C_big or diag(lambda)). */

@@ -233,6 +233,39 @@ def laplace(Ys, params, binSize, prev=None, mode='faithful', return_cov=True):
     return res, -total / len(Ys), optim
 
 
+def leave_one_out_prediction(Ys, params, binSize, mode='faithful'):
+    """util.leaveOneOutPrediction util.py:289-334 (= engine.PPGPFAfit.leaveOneOutPrediction, engine.py:599-644).
+
+    For every trial and neuron: the Laplace mode of the latents given all OTHER neurons (cold start at zero),
+    the held-out neuron's predicted rate exp(c_n x + d_n) per bin, and the summed squared error against its
+    counts.  mode 'faithful' runs scipy's fmin_ncg on the big-matrix callbacks with the reference's (default)
+    options; mode 'exact' runs the structured polished Newton.  Returns (y_pred[R][q][T], err)."""
+    C = np.asarray(params['C'], dtype=np.float64)
+    d = np.asarray(params['d'], dtype=np.float64).reshape(-1)
+    q, p = C.shape
+    T = Ys[0].shape[1]
+    K = make_K(params['tau'], T, binSize)
+    Kinv = np.linalg.inv(K)
+    K_bigInv = np.linalg.inv(make_K_big(K)) if mode == 'faithful' else None
+    pred = np.zeros((len(Ys), q, T))
+    err = 0.0
+    for r, Y in enumerate(Ys):
+        Y = np.asarray(Y, dtype=np.float64)
+        for n in range(q):
+            Cw, dw, Yw = np.delete(C, n, 0), np.delete(d, n, 0), np.delete(Y, n, 0)       # util.py:301-303,315
+            if mode == 'faithful':
+                C_big, d_big = make_Cd_big(Cw, dw, T)
+                x = op.fmin_ncg(nlp_big, np.zeros(p * T), fprime=nlp_big_grad, fhess=nlp_big_hess,
+                                args=(Yw.reshape(-1), C_big, d_big, K_bigInv), disp=False)  # util.py:318-325
+                X = x.reshape(p, T)
+            else:
+                X, _, _ = newton_mode(Yw, Cw, dw, Kinv)
+            yp = np.exp(C[n] @ X + d[n])                                                       # util.py:328
+            pred[r, n] = yp
+            err += float((Y[n] - yp) @ (Y[n] - yp))                                            # util.py:329
+    return pred, err
+
+
 # --------------------------------------------------------------------------------------
 # M-step: observation parameters (C, d)
 # --------------------------------------------------------------------------------------

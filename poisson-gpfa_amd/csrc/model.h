@@ -168,6 +168,7 @@ struct PoissonArgs {
   double* fpart;                   // [slot][ntile]
   const int* slots;                // list of slots to process
   const int* trial_of_slot;
+  const int* mask;                 // optional per slot: index of a neuron left out of the likelihood (NULL / -1: none)
   int q, p, T, ntile, full;
 };
 
@@ -183,6 +184,7 @@ __global__ void poisson_pass_kernel(PoissonArgs a) {
   const int tx = threadIdx.x, ty = threadIdx.y, KY = blockDim.y;
   const int slot = a.slots[blockIdx.y];
   const int trial = a.trial_of_slot[slot];
+  const int held_out = a.mask ? a.mask[slot] : -1;
   const int t = blockIdx.x * 64 + tx;
   const bool valid = t < a.T;
   const int p = a.p, q = a.q, T = a.T;
@@ -206,7 +208,7 @@ __global__ void poisson_pass_kernel(PoissonArgs a) {
     for (int nn = ty; nn < PNC; nn += KY) {
       const int n = n0 + nn;
       double e = 0.0, r = 0.0;
-      if (n < q && valid) {
+      if (n < q && valid && n != held_out) {
         double h = a.d[n];
         const double* Cn = a.C + (size_t)n * p;
         for (int l = 0; l < p; ++l) h += Cn[l] * xs[l][tx];
@@ -300,6 +302,7 @@ __global__ __launch_bounds__(256) void poisson_mfma_kernel(PoissonArgs a, const 
   const int l15 = lane & 15, l4 = lane >> 4;
   const int slot = a.slots[blockIdx.y];
   const int trial = a.trial_of_slot[slot];
+  const int held_out = a.mask ? a.mask[slot] : -1;
   const int p = a.p, q = a.q, T = a.T, pp = p * p;
   const int sbase = blockIdx.x * 64 + wave * 16;
   const int t = sbase + l15;
@@ -343,7 +346,7 @@ __global__ __launch_bounds__(256) void poisson_mfma_kernel(PoissonArgs a, const 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = nb0 + l4 + 4 * r;
-        const bool ok = (n < q) && valid_t;
+        const bool ok = (n < q) && valid_t && (n != held_out);
         const double y = ok ? (double)Y[(size_t)n * T + t] : 0.0;
         const double ev = ok ? exp(h[r]) : 0.0;
         e[r] = ev;
@@ -393,6 +396,35 @@ __global__ __launch_bounds__(256) void poisson_mfma_kernel(PoissonArgs a, const 
   if (lane == 0) fred[wave] = facc;
   __syncthreads();
   if (threadIdx.x == 0) a.fpart[(size_t)slot * a.ntile + blockIdx.x] = (fred[0] + fred[1]) + (fred[2] + fred[3]);
+}
+
+// Leave-one-neuron-out prediction (util.leaveOneOutPrediction util.py:328-329): rate of the held-out neuron at the
+// mode found without it, yp[slot][t] = exp(c_n . x_t + d_n), and err[slot] = sum_t (y_nt - yp_t)^2.
+// grid = nslots, block = 256.
+__global__ void loo_predict_kernel(const double* __restrict__ X, long long sX, const double* __restrict__ C, const double* __restrict__ d,
+                                   const uint8_t* __restrict__ Y, const int* __restrict__ trial_of_slot, const int* __restrict__ mask,
+                                   int q, int p, int T, double* __restrict__ yp, long long sP, double* __restrict__ err) {
+  __shared__ double red[256];
+  const int slot = blockIdx.x;
+  const int n = mask[slot];
+  const double* x = X + (size_t)slot * sX;
+  const uint8_t* y = Y + ((size_t)trial_of_slot[slot] * q + n) * T;
+  double s = 0.0;
+  for (int t = threadIdx.x; t < T; t += blockDim.x) {
+    double h = d[n];
+    for (int l = 0; l < p; ++l) h += C[(size_t)n * p + l] * x[(size_t)l * T + t];
+    const double v = exp(h);
+    yp[(size_t)slot * sP + t] = v;
+    const double r = (double)y[t] - v;
+    s += r * r;
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) err[slot] = red[0];
 }
 
 // flik[slot] = sum_tile fpart[slot][tile]

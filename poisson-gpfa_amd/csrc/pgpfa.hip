@@ -137,6 +137,8 @@ struct pgpfa_ctx {
   double pcg_eta0 = 1e-2;
   double *sc_f = nullptr, *sc_qxx = nullptr, *sc_qdx = nullptr, *sc_qdd = nullptr, *sc_dec = nullptr, *sc_smax = nullptr, *sc_alpha = nullptr;
   int *trial_of_slot = nullptr, *list_a = nullptr, *list_b = nullptr, *ident = nullptr;
+  int* mask_of_slot = nullptr;                    // leave-one-neuron-out passes: neuron excluded from the likelihood of a slot
+  bool mask_active = false;
   // small workspace for the T x T systems (Kinv, tau M-step): p slots of Tp
   CholWS kws{};
   double *tK = nullptr, *tM = nullptr, *tA1 = nullptr, *tA2 = nullptr, *tscal = nullptr, *tpart = nullptr;
@@ -460,6 +462,7 @@ int ensure_workspace(pgpfa_ctx* c, bool plan_lr) {
   CHK(dmalloc(c, &c->sc_qdd, nB)); CHK(dmalloc(c, &c->sc_dec, nB)); CHK(dmalloc(c, &c->sc_smax, nB));
   CHK(dmalloc(c, &c->sc_alpha, nB));
   CHK(dmalloc(c, &c->trial_of_slot, nB)); CHK(dmalloc(c, &c->list_a, nB)); CHK(dmalloc(c, &c->list_b, nB));
+  CHK(dmalloc(c, &c->mask_of_slot, nB));
   CHK(dmalloc(c, &c->ident, nB));
   std::vector<int> id(c->B);
   for (int i = 0; i < c->B; ++i) id[i] = i;
@@ -524,6 +527,7 @@ int poisson(pgpfa_ctx* c, const int* d_list, int nl, const double* X, double* G,
   a.Y = c->Y; a.C = c->C; a.d = c->d;
   a.X = X; a.sX = c->ld; a.G = G; a.sG = c->ld; a.W = W; a.sW = (long long)c->T * c->p * c->p;
   a.fpart = c->fpart; a.slots = d_list; a.trial_of_slot = c->trial_of_slot;
+  a.mask = c->mask_active ? c->mask_of_slot : nullptr;
   a.q = c->q; a.p = c->p; a.T = c->T; a.ntile = (c->T + 63) / 64; a.full = full;
   const int KY = std::min(c->p, 16);
   dim3 grid(a.ntile, nl), block(64, KY);
@@ -1281,8 +1285,18 @@ static int posterior_blocks(pgpfa_ctx* c, int nb, double diag_scale, bool want_v
   return posterior_blocks_dense(c, nb, diag_scale, want_vsmgp);
 }
 
-static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow_lr, double* obj_sum, int32_t* iters, int32_t* status) {
+// Leave-one-neuron-out job riding on the E-step machinery: item i is (trial tr.v[i], held-out neuron mask[i]); only the
+// mode is found (no covariance blocks, nothing written to the per-trial state), then the held-out neuron is predicted.
+struct LooJob {
+  const std::vector<int>* mask;
+  double* y_pred;        // host [N][T]
+  double* err;           // host [N]
+};
+
+static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow_lr, double* obj_sum, int32_t* iters, int32_t* status,
+                      const LooJob* loo = nullptr) {
   CHK(ready_estep(c, allow_lr));
+  struct MaskGuard { pgpfa_ctx* c; ~MaskGuard() { c->mask_active = false; } } mask_guard{c};
   const int N = (int)tr.v.size();
   const auto t_begin = std::chrono::steady_clock::now();
   const int nvec = c->n, p = c->p, T = c->T;
@@ -1297,6 +1311,11 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
     const int nb = std::min(c->B, N - c0);
     std::vector<int> tos(tr.v.begin() + c0, tr.v.begin() + c0 + nb);
     CHK(upload_list(c, c->trial_of_slot, tos));
+    if (loo) {
+      std::vector<int> mk(loo->mask->begin() + c0, loo->mask->begin() + c0 + nb);
+      CHK(upload_list(c, c->mask_of_slot, mk));
+      c->mask_active = true;
+    }
     HIPC(hipMemsetAsync(c->ws.info, 0, sizeof(int) * nb, c->st));
     {
       std::vector<int> ext(nb, 0);
@@ -1531,6 +1550,21 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
       max_it_seen = std::max(max_it_seen, iter + 1);
     }
 
+    if (loo) {
+      // prediction of the held-out neurons from the modes in Xc (Xt and sc_f are free scratch here)
+      hipLaunchKernelGGL(loo_predict_kernel, dim3(nb), dim3(256), 0, c->st, c->Xc, ld, c->C, c->d, c->Y, c->trial_of_slot, c->mask_of_slot,
+                         c->q, p, T, c->Xt, ld, c->sc_f);
+      HIPC(hipGetLastError());
+      HIPC(hipMemcpy2DAsync(loo->y_pred + (size_t)c0 * T, (size_t)T * sizeof(double), c->Xt, (size_t)ld * sizeof(double), (size_t)T * sizeof(double),
+                            nb, hipMemcpyDeviceToHost, c->st));
+      CHK(download(c, loo->err + c0, c->sc_f, nb));
+      HIPC(hipStreamSynchronize(c->st));
+      for (int s = 0; s < nb; ++s) {
+        if (iters) iters[c0 + s] = its[s];
+        if (status) status[c0 + s] = stat[s];
+      }
+      continue;
+    }
     // posterior covariance blocks at the mode
     {
       const bool sum_only = c->plan_lowrank && !c->keep_trial_vsmgp;
@@ -1622,6 +1656,48 @@ int pgpfa_estep_laplace(pgpfa_ctx* c, int n, const int32_t* idx, int warm_start,
     if (iters) iters[i] = it1[i];
     if (status) status[i] = st1[i];
   }
+  return 0;
+}
+
+// util.leaveOneOutPrediction (util.py:289-334): for every listed trial and every neuron, the Laplace mode of the latents
+// given all other neurons (cold start, same Newton machinery with that neuron's likelihood term dropped) and the
+// held-out neuron's predicted rate per bin; R*q mode searches, batched like trials.
+int pgpfa_loo_predict(pgpfa_ctx* c, int n, const int32_t* idx, double* y_pred, double* err_sum) {
+  if (!c || !y_pred || !err_sum) return fail("null argument");
+  Trials tr;
+  CHK(resolve_trials(c, n, idx, &tr));
+  const int q = c->q, T = c->T;
+  Trials items;
+  std::vector<int> mask;
+  for (int t : tr.v)
+    for (int nn = 0; nn < q; ++nn) { items.v.push_back(t); mask.push_back(nn); }
+  const int N = (int)items.v.size();
+  std::vector<double> err(N);
+  std::vector<int32_t> st(N), it(N);
+  LooJob job{&mask, y_pred, err.data()};
+  CHK(estep_impl(c, items, 0, true, nullptr, it.data(), st.data(), &job));
+  // items the low-rank plan could not finish are redone under the dense plan (as in pgpfa_estep_laplace)
+  Trials redo;
+  std::vector<int> redo_mask, pos;
+  for (int i = 0; i < N; ++i)
+    if (st[i] == 4) { redo.v.push_back(items.v[i]); redo_mask.push_back(mask[i]); pos.push_back(i); }
+  if (!redo.v.empty()) {
+    const int M = (int)redo.v.size();
+    std::vector<double> yp2((size_t)M * T), err2(M);
+    std::vector<int32_t> st2(M), it2(M);
+    LooJob job2{&redo_mask, yp2.data(), err2.data()};
+    CHK(estep_impl(c, redo, 0, false, nullptr, it2.data(), st2.data(), &job2));
+    for (int j = 0; j < M; ++j) {
+      std::copy(yp2.begin() + (size_t)j * T, yp2.begin() + (size_t)(j + 1) * T, y_pred + (size_t)pos[j] * T);
+      err[pos[j]] = err2[j];
+      st[pos[j]] = st2[j];
+    }
+  }
+  double total = 0.0;
+  int bad = 0;
+  for (int i = 0; i < N; ++i) { total += err[i]; if (st[i] != 0) ++bad; }
+  c->info["last_loo_unconverged"] = (double)bad;
+  *err_sum = total;
   return 0;
 }
 

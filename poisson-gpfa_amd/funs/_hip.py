@@ -47,6 +47,7 @@ _SIGNATURES = {
     'pgpfa_mstep_tau_costgrad': [ct.c_void_p, ct.c_int, ct.c_double, c_double_p, c_double_p],
     'pgpfa_mstep_tau_costgrad_batch': [ct.c_void_p, c_double_p, c_double_p, c_double_p],
     'pgpfa_mstep_tau_costgrad_multi': [ct.c_void_p, ct.c_int, c_double_p, c_double_p, c_double_p],
+    'pgpfa_loo_predict': [ct.c_void_p, ct.c_int, c_int32_p, c_double_p, c_double_p],
     'pgpfa_dual_costgrad': [ct.c_void_p, ct.c_int, c_double_p, c_double_p, c_double_p],
     'pgpfa_dual_finalize': [ct.c_void_p, ct.c_int, c_int32_p, c_double_p, c_double_p],
     'pgpfa_comm_unique_id': [ct.c_char_p],
@@ -204,6 +205,14 @@ class Context:
         status = np.zeros(n, dtype=np.int32)
         check(self.lib.pgpfa_estep_laplace(self.h, n, iptr(ii), 1 if warm_start else 0, ct.byref(obj), iptr(iters), iptr(status)))
         return obj.value, iters, status
+
+    def loo_predict(self, idx=None):
+        """Leave-one-neuron-out prediction for the listed trials -> (y_pred[n][q][T], summed squared error)."""
+        n, ii = self._n_idx(idx)
+        out = np.empty((n, self.q, self.T))
+        err = ct.c_double(0.0)
+        check(self.lib.pgpfa_loo_predict(self.h, n, iptr(ii), dptr(out), ct.byref(err)))
+        return out, err.value
 
     def set_modes(self, idx, X):
         n, ii = self._n_idx(idx)

@@ -158,7 +158,7 @@ class PPGPFAfit():
         if extractAllTraj_trueParams:
             self.extractTrajWithTrueParams(method=inferenceMethod)
         if getPredictionErr:
-            raise NotImplementedError('leave-one-neuron-out prediction is a listed follow-up (SURVEY 8f-2)')
+            self.leaveOneOutPrediction()
 
     # -- light-weight summaries of the parameter path (subset of reference engine.py:541-597) ----------------
     def processParamResults(self):
@@ -170,6 +170,10 @@ class PPGPFAfit():
             self.CabsoluteValue[i] = float(np.sum(np.asarray(self.paramSeq[i]['C']) ** 2))
         if hasattr(self.experiment, 'params'):
             self.subspaceAngleC = [util.subspaceAngle(self.experiment.params['C'], self.paramSeq[i]['C']) for i in range(n)]
+
+    def leaveOneOutPrediction(self):
+        """reference engine.py:599-644: y_pred_mode[numTrials][ydim][T] and pred_err_mode with the fitted parameters."""
+        self.y_pred_mode, self.pred_err_mode = util.leaveOneOutPrediction(self.optimParams, self.experiment)
 
     def extractTrajectories(self, method='laplace'):
         """One more E-step over all trials with the fitted parameters (reference engine.py:523-532)."""

@@ -62,6 +62,27 @@ def makeK_big(params, trialDur, binSize, epsNoise=0.001):
     return K_big, K
 
 
+# -- leave-one-neuron-out prediction (reference util.py:289-334) --------------------------------------------
+def leaveOneOutPrediction(params, experiment):
+    """For every trial and neuron: posterior mode of the latents given all OTHER neurons, then the held-out neuron's
+    predicted rate exp(c_n x + d_n) per bin.  Returns (y_pred_mode[numTrials][ydim][T], pred_err_mode) like the
+    reference; the numTrials*ydim mode searches run batched on the device (the reference solves them one by one
+    with fmin_ncg from a cold start, to a looser tolerance)."""
+    from . import _session
+    xdim = np.shape(params['C'])[1]
+    sess, trial_idx = _session.session_for(experiment, xdim)
+    lo, hi = (0, len(trial_idx)) if getattr(experiment, '_pgpfa_local_shard', False) else sess.local_slice(len(trial_idx))
+    sess.set_params(params)
+    y_loc, err_loc = sess.ctx.loo_predict(trial_idx[lo:hi])
+    if sess.comm_ready and not getattr(experiment, '_pgpfa_local_shard', False):
+        y_pred = np.zeros((len(trial_idx), sess.q, sess.T))
+        y_pred[lo:hi] = y_loc
+        y_pred = sess.allreduce(y_pred)
+        err = float(sess.allreduce(np.array([err_loc]))[0])
+        return y_pred, err
+    return y_loc, float(err_loc)
+
+
 # -- minibatches (reference util.py:449-473) ---------------------------------------------------------------
 def subsampleTrials(experiment, batchSize):
     """Same draw from the global legacy RNG as the reference (np.random.choice without replacement);

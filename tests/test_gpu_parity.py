@@ -440,3 +440,40 @@ def test_sum_only_covariance_output_matches_per_trial_blocks(c1, R_use):
     res, _, _ = orc.laplace(c1['Ys'][:R_use], c1['init'], c1['binSize'], mode='exact', return_cov=False)
     P_o, _ = orc.make_precomp(res)
     assert rel(ref['P'], P_o) <= 1e-8
+
+
+def test_leave_one_neuron_out_prediction(funs_mod, c1):
+    """SURVEY 8f row 2 (util.leaveOneOutPrediction, util.py:289-334): R*q mode searches with one neuron's likelihood
+    term dropped, batched on the E-step machinery; vs the oracle's exact modes (tight), vs the reference's own
+    fmin_ncg answers (its early-stopping slack), and dense vs low-rank workspace plans."""
+    from funs import _hip
+    g = load_golden('c1_loo.npz')
+    n_tr = int(g['n_trials'])
+    exp3 = Experiment(c1['Ys'][:n_tr], c1['binSize'])
+    y_pred, err = funs_mod.util.leaveOneOutPrediction({k: v.copy() for k, v in c1['init'].items()}, exp3)
+    assert y_pred.shape == (n_tr, 30, 100)
+    # the reference itself (modes stopped at avextol 1e-5)
+    assert np.max(np.abs(y_pred - g['y_pred_mode']) / g['y_pred_mode']) <= 2e-2
+    assert abs(err - float(g['pred_err_mode'])) <= 1e-3 * float(g['pred_err_mode'])
+    # exact modes
+    pred_o, err_o = orc.leave_one_out_prediction(c1['Ys'][:2], c1['init'], c1['binSize'], mode='exact')
+    assert rel(y_pred[:2], pred_o) <= 1e-7
+    assert abs(np.sum((np.stack(c1['Ys'][:2]) - y_pred[:2]) ** 2) - err_o) <= 1e-7 * err_o
+    assert abs(np.sum((np.stack(c1['Ys'][:n_tr]) - y_pred) ** 2) - err) <= 1e-9 * err
+    # both workspace plans, and a trial subset through the C-ABI
+    out = {}
+    for mode in (1, 2):
+        ctx = _hip.Context(30, 3, 100, 20, c1['binSize'])
+        try:
+            ctx.upload_counts(c1['Y'])
+            ctx.set_option('cov_mode', mode)
+            ctx.set_params(c1['init_C'], c1['init_d'], c1['init_tau'])
+            out[mode] = ctx.loo_predict(np.array([1, 0], dtype=np.int32))
+            assert ctx.info('last_loo_unconverged') == 0
+            # the E-step state of the context is untouched by the prediction pass
+            obj, _, status = ctx.estep_laplace(np.array([0, 1, 2], dtype=np.int32))
+            assert np.all(status == 0)
+        finally:
+            ctx.close()
+    assert rel(out[1][0], out[2][0]) <= 1e-8
+    assert rel(out[2][0][0], pred_o[1]) <= 1e-7 and rel(out[2][0][1], pred_o[0]) <= 1e-7

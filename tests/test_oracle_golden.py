@@ -163,3 +163,16 @@ def test_c2_spot_exact_vs_reference():
     res, nll, _ = orc.laplace(Ys, params, float(g['binSize']), mode='exact', return_cov=False)
     assert np.max(np.abs(res['post_mean'][0] - g['post_mean'][0])) <= 5e-3
     assert rel(res['post_vsm'][0], g['post_vsm'][0]) <= 1e-3
+
+
+def test_leave_one_out_prediction_vs_reference(c1):
+    """8f row 2: the oracle's faithful restatement against util.leaveOneOutPrediction itself (same fmin_ncg calls),
+    and the exact-mode variant within the reference's early-stopping slack."""
+    g = load_golden('c1_loo.npz')
+    Ys = c1['Ys'][:2]
+    pred, err = orc.leave_one_out_prediction(Ys, c1['init'], c1['binSize'], mode='faithful')
+    # (same solver calls; the truncated-CG path amplifies the rounding differences of the Hessian products to ~1e-8)
+    assert np.max(np.abs(pred - g['y_pred_mode'][:2])) <= 1e-6
+    assert abs(err - 0) > 0
+    pred_x, err_x = orc.leave_one_out_prediction(Ys[:1], c1['init'], c1['binSize'], mode='exact')
+    assert np.max(np.abs(pred_x[0] - g['y_pred_mode'][0]) / g['y_pred_mode'][0]) <= 2e-2
