@@ -124,6 +124,12 @@ int pgpfa_mstep_tau_costgrad_batch(pgpfa_ctx* ctx, const double* logp, double* c
  * root finder of learnGPparams brackets and interpolates with them instead of stepping serially. */
 int pgpfa_mstep_tau_costgrad_multi(pgpfa_ctx* ctx, int m, const double* logp, double* cost, double* grad);
 
+/* ---- count moments (util.py:523-533 Poisson-PCA initialiser; engine.py:487-492 diagnostics) ---- */
+/* Exact integer moments of the resident counts over all (trial, bin) samples of the listed trials:
+ * sum[i] = sum y_i, cross[i][j] = sum y_i y_j, n_samples = trials * T (np.mean / np.cov of the raster follow). */
+int pgpfa_count_moments(pgpfa_ctx* ctx, int n, const int32_t* idx, int64_t* sum /* [q] */, int64_t* cross /* [q][q] */,
+                        int64_t* n_samples);
+
 /* ---- leave-one-neuron-out prediction (util.py:289-334, engine.py:599-644) ----------- */
 /* For each listed trial (idx NULL: all R) and each neuron nn: the Laplace mode of the latents given the other
  * q-1 neurons (cold start), then y_pred[(trial, nn)][t] = exp(C[nn] . x_t + d[nn]); err_sum = sum of squared

@@ -1618,6 +1618,61 @@ __global__ __launch_bounds__(256) void apply_bin_kernel(const double* __restrict
   }
 }
 
+// First and second moments of the spike counts over all (trial, bin) samples of the listed trials, EXACT in integer
+// arithmetic: sum[i] = sum y_i, cross[i][j] = sum y_i y_j (what np.mean / np.cov of the concatenated raster are built
+// from: Poisson-PCA initialiser util.py:528-533, spike-count diagnostics engine.py:487-492).
+// A block owns one trial and one pair of 32-neuron tiles (ti >= tj); rows are packed 4 bins per 32-bit word in LDS
+// and every 4-bin product sum is one v_dot4_u32_u8; per-trial partial sums (< 2^32 for T < 66000) are added to the
+// 64-bit totals with integer atomics (order independent, so the result is deterministic).
+// grid = (tile pairs, trials), block = 256.
+constexpr int CM_TILE = 32, CM_BINS = 512, CM_LD = CM_BINS / 4 + 1;
+__global__ __launch_bounds__(256) void count_moments_kernel(const uint8_t* __restrict__ Y, const int* __restrict__ trials, int q, int T,
+                                                            unsigned long long* __restrict__ sum, unsigned long long* __restrict__ cross) {
+  __shared__ unsigned Wi[CM_TILE * CM_LD];
+  __shared__ unsigned Wj[CM_TILE * CM_LD];
+  int ti = 0, rem = blockIdx.x;
+  while (rem > ti) { rem -= ti + 1; ++ti; }
+  const int tj = rem;
+  const uint8_t* Yr = Y + (size_t)trials[blockIdx.y] * q * T;
+  const int a = threadIdx.x >> 3, bg = (threadIdx.x & 7) * 4;
+  unsigned acc[4] = {0u, 0u, 0u, 0u};
+  unsigned acc_s = 0u;
+  for (int t0 = 0; t0 < T; t0 += CM_BINS) {
+    const int nb = min(CM_BINS, T - t0), nw = (nb + 3) / 4;
+    __syncthreads();
+    for (int e = threadIdx.x; e < CM_TILE * nw; e += 256) {
+      const int r = e / nw, w = e - r * nw;
+      unsigned vi = 0u, vj = 0u;
+      const int ni = ti * CM_TILE + r, nj = tj * CM_TILE + r;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int t = 4 * w + b;
+        if (t < nb) {
+          if (ni < q) vi |= (unsigned)Yr[(size_t)ni * T + t0 + t] << (8 * b);
+          if (nj < q) vj |= (unsigned)Yr[(size_t)nj * T + t0 + t] << (8 * b);
+        }
+      }
+      Wi[r * CM_LD + w] = vi;
+      Wj[r * CM_LD + w] = vj;
+    }
+    __syncthreads();
+    for (int w = 0; w < nw; ++w) {
+      const unsigned wa = Wi[a * CM_LD + w];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] = __builtin_amdgcn_udot4(wa, Wj[(bg + k) * CM_LD + w], acc[k], false);
+      if (bg == 0) acc_s = __builtin_amdgcn_udot4(wa, 0x01010101u, acc_s, false);
+    }
+  }
+  const int i = ti * CM_TILE + a;
+  if (i >= q) return;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int j = tj * CM_TILE + bg + k;
+    if (j < q && acc[k]) atomicAdd(&cross[(size_t)i * q + j], (unsigned long long)acc[k]);
+  }
+  if (ti == tj && bg == 0 && acc_s) atomicAdd(&sum[i], (unsigned long long)acc_s);
+}
+
 // counts: double [R][q][T] -> uint8 with validation (non-negative integers <= 255)
 __global__ void pack_counts_kernel(const double* __restrict__ src, uint8_t* __restrict__ dst, size_t n, int* __restrict__ bad) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

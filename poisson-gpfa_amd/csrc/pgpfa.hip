@@ -1659,6 +1659,40 @@ int pgpfa_estep_laplace(pgpfa_ctx* c, int n, const int32_t* idx, int warm_start,
   return 0;
 }
 
+// Exact integer moments of the resident counts over the listed trials: sum[q], cross[q][q] (symmetric), n_samples.
+int pgpfa_count_moments(pgpfa_ctx* c, int n, const int32_t* idx, int64_t* sum, int64_t* cross, int64_t* n_samples) {
+  if (!c || !sum || !cross || !n_samples) return fail("null argument");
+  if (!c->have_counts) return fail("spike counts have not been uploaded");
+  HIPC(hipSetDevice(c->device));
+  Trials tr;
+  CHK(resolve_trials(c, n, idx, &tr));
+  const int q = c->q, T = c->T, N = (int)tr.v.size();
+  unsigned long long* dev = nullptr;
+  int* dtr = nullptr;
+  const size_t len = (size_t)q * q + q;
+  HIPC(hipMalloc((void**)&dev, len * sizeof(unsigned long long)));
+  HIPC(hipMalloc((void**)&dtr, (size_t)std::max(N, 1) * sizeof(int)));
+  HIPC(hipMemsetAsync(dev, 0, len * sizeof(unsigned long long), c->st));
+  HIPC(hipMemcpyAsync(dtr, tr.v.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice, c->st));
+  const int nt = (q + CM_TILE - 1) / CM_TILE, npairs = nt * (nt + 1) / 2;
+  if (N > 0) hipLaunchKernelGGL(count_moments_kernel, dim3(npairs, N), dim3(256), 0, c->st, c->Y, dtr, q, T, dev + (size_t)q * q, dev);
+  std::vector<unsigned long long> hostv(len);
+  HIPC(hipMemcpyAsync(hostv.data(), dev, len * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->st));
+  HIPC(hipStreamSynchronize(c->st));
+  hipFree(dev); hipFree(dtr);
+  HIPC(hipGetLastError());
+  for (int i = 0; i < q; ++i) {
+    sum[i] = (int64_t)hostv[(size_t)q * q + i];
+    for (int j = 0; j <= i; ++j) {            // tiles with ti > tj hold only the lower part; diagonal tiles both
+      const int64_t v = (int64_t)hostv[(size_t)i * q + j];
+      cross[(size_t)i * q + j] = v;
+      cross[(size_t)j * q + i] = v;
+    }
+  }
+  *n_samples = (int64_t)N * T;
+  return 0;
+}
+
 // util.leaveOneOutPrediction (util.py:289-334): for every listed trial and every neuron, the Laplace mode of the latents
 // given all other neurons (cold start, same Newton machinery with that neuron's likelihood term dropped) and the
 // held-out neuron's predicted rate per bin; R*q mode searches, batched like trials.

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), 'libpgpfa_hip.so')
 c_double_p = ct.POINTER(ct.c_double)
 c_int32_p = ct.POINTER(ct.c_int32)
 c_uint8_p = ct.POINTER(ct.c_uint8)
+c_int64_p = ct.POINTER(ct.c_int64)
 
 # name -> (argtypes); every function returns int except where noted
 _SIGNATURES = {
@@ -48,6 +49,7 @@ _SIGNATURES = {
     'pgpfa_mstep_tau_costgrad_batch': [ct.c_void_p, c_double_p, c_double_p, c_double_p],
     'pgpfa_mstep_tau_costgrad_multi': [ct.c_void_p, ct.c_int, c_double_p, c_double_p, c_double_p],
     'pgpfa_loo_predict': [ct.c_void_p, ct.c_int, c_int32_p, c_double_p, c_double_p],
+    'pgpfa_count_moments': [ct.c_void_p, ct.c_int, c_int32_p, c_int64_p, c_int64_p, c_int64_p],
     'pgpfa_dual_costgrad': [ct.c_void_p, ct.c_int, c_double_p, c_double_p, c_double_p],
     'pgpfa_dual_finalize': [ct.c_void_p, ct.c_int, c_int32_p, c_double_p, c_double_p],
     'pgpfa_comm_unique_id': [ct.c_char_p],
@@ -205,6 +207,16 @@ class Context:
         status = np.zeros(n, dtype=np.int32)
         check(self.lib.pgpfa_estep_laplace(self.h, n, iptr(ii), 1 if warm_start else 0, ct.byref(obj), iptr(iters), iptr(status)))
         return obj.value, iters, status
+
+    def count_moments(self, idx=None):
+        """Exact integer moments of the resident counts over the listed trials:
+        (sum[q], cross[q][q], n_samples) with sum_i = sum y_i, cross_ij = sum y_i y_j over all (trial, bin) samples."""
+        n, ii = self._n_idx(idx)
+        s = np.zeros(self.q, dtype=np.int64)
+        S = np.zeros((self.q, self.q), dtype=np.int64)
+        ns = ct.c_int64(0)
+        check(self.lib.pgpfa_count_moments(self.h, n, iptr(ii), s.ctypes.data_as(c_int64_p), S.ctypes.data_as(c_int64_p), ct.byref(ns)))
+        return s, S, int(ns.value)
 
     def loo_predict(self, idx=None):
         """Leave-one-neuron-out prediction for the listed trials -> (y_pred[n][q][T], summed squared error)."""

@@ -151,6 +151,7 @@ class PPGPFAfit():
         self.learningTime, self.inferenceTime = np.asarray(learningTime), np.asarray(inferenceTime)
         self.CdOptimMethod, self.optimLogLamb = CdOptimMethod, optimLogLamb
         self.processParamResults()
+        self.performSpikeCountAnalysis()
         if not quiet:
             print()
         if extractAllTraj:
@@ -160,16 +161,62 @@ class PPGPFAfit():
         if getPredictionErr:
             self.leaveOneOutPrediction()
 
-    # -- light-weight summaries of the parameter path (subset of reference engine.py:541-597) ----------------
+    # -- summaries of the parameter path (reference engine.py:541-597) -------------------------------------------
     def processParamResults(self):
         n = self.maxEMiter
+        seq = self.paramSeq
         self.tauSeq = np.zeros([self.xdim, n])
+        self.expectedSpikeCountsEst = np.zeros([self.ydim, n])
         self.CabsoluteValue = np.zeros(n)
         for i in range(n):
-            self.tauSeq[:, i] = np.asarray(self.paramSeq[i]['tau']).reshape(-1)
-            self.CabsoluteValue[i] = float(np.sum(np.asarray(self.paramSeq[i]['C']) ** 2))
+            C = np.asarray(seq[i]['C'], dtype=np.float64)
+            self.tauSeq[:, i] = np.asarray(seq[i]['tau']).reshape(-1)
+            self.expectedSpikeCountsEst[:, i] = self.T * np.exp(0.5 * np.sum(C * C, axis=1) + np.asarray(seq[i]['d']).reshape(-1))
+            self.CabsoluteValue[i] = float(np.sum(C ** 2))
+        self.expectedSpikeCountsEstVar = np.var(self.expectedSpikeCountsEst, axis=0)
+        # per-neuron total counts / number of trials: from the device's integer sums, not from a host raster
+        _, _, totals, _ = util.countMoments(self.experiment, self.xdim)
+        self._count_totals = totals
+        self.sampleMeanSpikeCounts = totals / self.numTrials
+        self.sampleMeanSpikeCountsVar = np.var(self.sampleMeanSpikeCounts)
         if hasattr(self.experiment, 'params'):
-            self.subspaceAngleC = [util.subspaceAngle(self.experiment.params['C'], self.paramSeq[i]['C']) for i in range(n)]
+            Ct = np.asarray(self.experiment.params['C'], dtype=np.float64)
+            self.expectedSpikeCountsTrue = self.T * np.exp(0.5 * np.sum(Ct * Ct, axis=1) + np.asarray(self.experiment.params['d']).reshape(-1))
+            self.expectedSpikeCountsTrueVar = np.var(self.expectedSpikeCountsTrue)
+            self.varESpkCountTrue_Ratios = self.expectedSpikeCountsEstVar / self.expectedSpikeCountsTrueVar
+            self.subspaceAngleC = [util.subspaceAngle(self.experiment.params['C'], seq[i]['C']) for i in range(n)]
+        self.varESpkCountSampleMean_Ratios = self.expectedSpikeCountsEstVar / self.sampleMeanSpikeCountsVar
+        dev = self.expectedSpikeCountsEst - self.sampleMeanSpikeCounts[:, None]
+        self.meanSquaredErrorOverTrueVariance_SM = list(np.sum(dev * dev, axis=0) / self.numTrials / self.sampleMeanSpikeCountsVar)
+
+    # -- spike-count moment diagnostics (reference engine.py:484-513) --------------------------------------------
+    def performSpikeCountAnalysis(self):
+        E_y_obs, E_yy_obs, _, _ = util.countMoments(self.experiment, self.xdim)
+        self.E_y_obs, self.E_yy_obs = E_y_obs, E_yy_obs
+        self.E_y_init_params, self.E_yy_init_params = util.getMeanCovYfromParams(self.initParams)
+        self.E_y_optim_params, self.E_yy_optim_params = util.getMeanCovYfromParams(self.optimParams)
+        norm_obs = np.linalg.norm(E_yy_obs)
+
+        def scores(E_ref, E_yy_ref, tag):
+            for which, E_y, E_yy in (('optim', self.E_y_optim_params, self.E_yy_optim_params),
+                                     ('init', self.E_y_init_params, self.E_yy_init_params)):
+                dm = E_ref - E_y
+                setattr(self, 'mean_err_%s_%s' % (which, tag), float(dm @ dm / np.var(E_ref) / self.numTrials))
+                setattr(self, 'cov_err_%s_%s' % (which, tag), float(np.linalg.norm(E_yy_ref - E_yy) / norm_obs))
+                setattr(self, 'JSdiv_cov_%s_%s' % (which, tag), float(util.JSLogdetDiv(E_yy, E_yy_ref)))
+        if hasattr(self.experiment, 'params'):
+            self.E_y_true_params, self.E_yy_true_params = util.getMeanCovYfromParams(self.experiment.params)
+            scores(self.E_y_true_params, self.E_yy_true_params, 'true')
+        scores(E_y_obs, E_yy_obs, 'obs')
+
+    def orthonormalizeTrajectories(self):
+        """reference engine.py:515-521: x_tilde[trial] = diag(D) V.T post_mean[trial] with U, D, V = scipy.linalg.svd(C).
+        (scipy returns V^T in that slot, so this is diag(D) times the matrix of right singular vectors, not its
+        transpose; the same routine is called here because the result depends on its sign conventions.)"""
+        import scipy.linalg
+        _, D, Vh = scipy.linalg.svd(np.asarray(self.optimParams['C'], dtype=np.float64))
+        mix = np.diag(D) @ Vh.T
+        self.x_tilde = np.asarray([mix @ np.asarray(self.infRes['post_mean'][tr]) for tr in range(self.numTrials)])
 
     def leaveOneOutPrediction(self):
         """reference engine.py:599-644: y_pred_mode[numTrials][ydim][T] and pred_err_mode with the fitted parameters."""
@@ -190,7 +237,3 @@ class PPGPFAfit():
             (self.infRes_trueParams, self.nll_trueParams_all_traj, self.vlb_trueParams_all_traj, _) = inference.dualVariational(
                 self.experiment, copy.copy(self.experiment.params), optimizeLogLambda=self.optimLogLamb)
 
-    def orthonormalizeTrajectories(self):
-        """x_tilde = D V^T x with C = U D V^T (reference engine.py:514-521)."""
-        _, D, Vt = np.linalg.svd(np.asarray(self.optimParams['C']), full_matrices=False)
-        self.x_tilde = np.asarray([np.diag(D) @ Vt @ self.infRes['post_mean'][tr] for tr in range(len(self.infRes['post_mean']))])

@@ -169,14 +169,48 @@ class dataset:
         return self.avgFR
 
 
+def countMoments(experiment, xdim):
+    """Mean and covariance of the spike counts over all (trial, bin) samples - np.mean / np.cov of the concatenated
+    raster (reference util.py:523-533, engine.py:487-492) - from the device's exact integer sums of the resident
+    count tensor; the raster is never formed on the host.  Returns (mean[q], cov[q][q], per-neuron totals, samples)."""
+    from . import _session
+    sess, trial_idx = _session.session_for(experiment, xdim)
+    local = getattr(experiment, '_pgpfa_local_shard', False)
+    lo, hi = (0, len(trial_idx)) if local else sess.local_slice(len(trial_idx))
+    s, S, ns = sess.ctx.count_moments(trial_idx[lo:hi])
+    s, S, ns = s.astype(np.float64), S.astype(np.float64), float(ns)      # exact: all sums are far below 2^53
+    if sess.comm_ready:
+        red = sess.allreduce(np.concatenate([s, S.reshape(-1), [ns]]))
+        s, S, ns = red[:s.size], red[s.size:-1].reshape(S.shape), float(red[-1])
+    mean = s / ns
+    cov = (S - np.outer(s, s) / ns) / (ns - 1.0)
+    return mean, cov, s, int(ns)
+
+
+def getMeanCovYfromParams(params, experiment=None):
+    """Mean and second moment of the counts implied by the parameters under a unit-variance latent (reference
+    util.py:24-39): E[y] = exp(diag(CC^T)/2 + d), E[y_i y_j] = E[y_i]E[y_j]exp(CC^T_ij/2) (+ E[y_i] on the diagonal)."""
+    C = np.asarray(params['C'], dtype=np.float64)
+    lamb = C @ C.T
+    E_y = np.exp(0.5 * np.diag(lamb) + np.asarray(params['d'], dtype=np.float64).reshape(-1))
+    E_yy = np.outer(E_y, E_y) * np.exp(0.5 * lamb)
+    E_yy[np.diag_indices_from(E_yy)] += E_y
+    return E_y, E_yy
+
+
+def JSLogdetDiv(X, Y):
+    """reference util.py:21-22"""
+    return np.log(np.linalg.det((X + Y) / 2)) - 0.5 * np.log(np.linalg.det(X.dot(Y)))
+
+
 def initializeParams(xdim, ydim, experiment=None):
     """Poisson-PCA initialiser (reference util.py:505-558): moment-matched log-rate covariance ->
-    leading eigenvectors -> C; d = log mean rate; tau ~ U(0.1, 0.6) s from the global RNG."""
+    leading eigenvectors -> C; d = log mean rate; tau ~ U(0.1, 0.6) s from the global RNG.  The count moments come
+    from the device (countMoments); the ydim x ydim eigen-decomposition stays on the host like the reference's."""
     if experiment is None:
         return {'C': np.random.rand(ydim, xdim) * 2 - 1, 'd': np.random.randn(ydim) * 2 - 2, 'tau': np.random.rand(xdim) * 0.5}
-    spikes = np.concatenate([np.asarray(tr['Y'], dtype=np.float64) for tr in experiment.data], axis=1)
-    meanY = np.mean(spikes, 1) + 1e-10
-    covY = np.cov(spikes)
+    meanY, covY, _, _ = countMoments(experiment, xdim)
+    meanY = meanY + 1e-10
     outer = np.outer(meanY, meanY)
     lamb = np.log(np.abs(covY + outer - np.diag(meanY))) - np.log(outer)
     evals, evecs = np.linalg.eig(lamb)

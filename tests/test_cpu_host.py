@@ -66,11 +66,6 @@ def test_dataset_generator_reproduces_reference_stream(c1):
     Y = np.stack([tr['Y'] for tr in ds.data])
     assert np.array_equal(Y, c1['Y'])
     assert np.array_equal(ds.params['C'], c1['true_C']) and np.array_equal(ds.params['d'], c1['true_d'])
-    np.random.seed(0)
-    init = util.initializeParams(3, 30, ds)
-    assert np.max(np.abs(init['C'] - c1['init_C'])) <= 1e-12
-    assert np.max(np.abs(init['d'] - c1['init_d'])) <= 1e-14
-    assert np.array_equal(init['tau'], c1['init_tau'])
     big = util.dataset(trialDur=400, numTrials=3, xdim=2, ydim=6, seed=3, sampler='cholesky')
     assert big.data[0]['Y'].shape == (6, 40) and big.T == 40
 

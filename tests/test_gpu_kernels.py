@@ -263,3 +263,26 @@ def test_poisson_pass_mfma_matches_vector_kernel_and_oracle(hip, q, p, T):
     for r in range(R):
         assert abs(out[1][0][r] - orc.nlp(X[r], Y[r].astype(float), C, d, Kinv)) <= 1e-10 * abs(out[1][0][r])
         assert rel(out[1][1][r], orc.nlp_grad(X[r], Y[r].astype(float), C, d, Kinv)) <= 1e-9
+
+
+@pytest.mark.parametrize('q,T,R', [(30, 100, 20), (13, 41, 3), (70, 600, 2), (200, 500, 4)])
+def test_count_moments_exact(hip, q, T, R):
+    """Integer first/second moments of the resident counts (dot4 kernel + 64-bit atomics): bit-exact against numpy's
+    integer arithmetic, including counts up to 255, neuron tiles with a ragged edge and bins beyond one LDS chunk."""
+    rng = np.random.default_rng(q + T)
+    Y = rng.poisson(0.8, size=(R, q, T))
+    Y[0, 0, :7] = 255
+    Y[R - 1, q - 1, T - 3:] = 254
+    Y = np.minimum(Y, 255).astype(np.uint8)
+    ctx = hip.Context(q, 2, T, R, 10.0)
+    try:
+        ctx.upload_counts(Y)
+        for idx in (None, np.array([R - 1, 0], dtype=np.int32)):
+            s, S, ns = ctx.count_moments(idx)
+            Ysel = Y if idx is None else Y[idx]
+            flat = np.transpose(Ysel, (1, 0, 2)).reshape(q, -1).astype(np.int64)
+            assert ns == flat.shape[1]
+            assert np.array_equal(s, flat.sum(axis=1))
+            assert np.array_equal(S, flat @ flat.T)
+    finally:
+        ctx.close()

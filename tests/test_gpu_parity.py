@@ -477,3 +477,50 @@ def test_leave_one_neuron_out_prediction(funs_mod, c1):
             ctx.close()
     assert rel(out[1][0], out[2][0]) <= 1e-8
     assert rel(out[2][0][0], pred_o[1]) <= 1e-7 and rel(out[2][0][1], pred_o[0]) <= 1e-7
+
+
+def test_initializer_from_device_moments(funs_mod, c1, c1_experiment):
+    """SURVEY 8f row 1 (initialiser): Poisson-PCA initial parameters from the device's integer count moments == the
+    reference's util.initializeParams (util.py:505-558) on the same data and RNG state."""
+    np.random.seed(0)
+    init = funs_mod.util.initializeParams(3, 30, c1_experiment)
+    assert np.max(np.abs(np.abs(init['C']) - np.abs(c1['init_C']))) <= 1e-10          # eigenvector signs are LAPACK's choice
+    assert np.max(np.abs(init['C'] - c1['init_C'])) <= 1e-10
+    assert np.max(np.abs(init['d'] - c1['init_d'])) <= 1e-13
+    assert np.array_equal(init['tau'], c1['init_tau'])
+    mean, cov, totals, ns = funs_mod.util.countMoments(c1_experiment, 3)
+    raster = np.concatenate(c1['Ys'], axis=1)
+    assert ns == raster.shape[1] and np.array_equal(totals, raster.sum(axis=1))
+    assert np.max(np.abs(mean - raster.mean(axis=1))) <= 1e-15
+    assert rel(cov, np.cov(raster)) <= 1e-12
+
+
+def test_postfit_summaries_vs_reference(funs_mod, c1):
+    """the summaries PPGPFAfit always computes after the EM loop (engine.py:484-597) and the
+    orthonormalised trajectories, against the attributes of the reference's own fit object."""
+    g = load_golden('c1_diag.npz')
+    exp = Experiment(c1['Ys'], c1['binSize'])
+    exp.params = {'C': c1['true_C'], 'd': c1['true_d'], 'tau': c1['true_tau']}
+    init = {k: v.copy() for k, v in c1['init'].items()}
+    fit = funs_mod.engine.PPGPFAfit(exp, initParams=init, inferenceMethod='laplace', EMmode='Batch', maxEMiter=3,
+                                    extractAllTraj=True, quiet=True)
+    names = [str(n) for n in g['attr_names']]
+    # (1) our own fit: its parameter path differs from the reference's by the reference's early-stopping slack
+    for nm in names:
+        ours, ref = np.asarray(getattr(fit, nm), dtype=np.float64), g['attr_' + nm]
+        assert ours.shape == ref.shape, nm
+        assert np.max(np.abs(ours - ref)) <= 2e-2 * max(1e-12, np.max(np.abs(ref))), nm
+    # (2) the same functions on the reference's parameter path: tight
+    fit.paramSeq = [{'C': g['seq_C'][i], 'd': g['seq_d'][i], 'tau': g['seq_tau'][i]} for i in range(g['seq_C'].shape[0])]
+    fit.initParams = {'C': g['init_C'], 'd': g['init_d'], 'tau': g['init_tau']}
+    fit.optimParams = {'C': g['optim_C'], 'd': g['optim_d'], 'tau': g['optim_tau']}
+    fit.processParamResults()
+    fit.performSpikeCountAnalysis()
+    for nm in names:
+        ours, ref = np.asarray(getattr(fit, nm), dtype=np.float64), g['attr_' + nm]
+        assert np.max(np.abs(ours - ref)) <= 1e-9 * max(1e-12, np.max(np.abs(ref))), nm
+    fit.infRes = {'post_mean': list(g['post_mean_all'])}
+    fit.orthonormalizeTrajectories()
+    xt, ref = fit.x_tilde, g['x_tilde']
+    assert xt.shape == ref.shape
+    assert rel(xt, ref) <= 1e-10
