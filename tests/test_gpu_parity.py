@@ -524,3 +524,49 @@ def test_postfit_summaries_vs_reference(funs_mod, c1):
     xt, ref = fit.x_tilde, g['x_tilde']
     assert xt.shape == ref.shape
     assert rel(xt, ref) <= 1e-10
+
+
+@pytest.mark.parametrize('p', [12, 16, 20])
+def test_wide_latent_dimensions(p):
+    """Latent widths at the edges of the kernel instantiations (p = 12: widest device-Newton M-step; 16: widest
+    matrix-core Poisson pass / low-rank engine; 20: config-5 width, vector Poisson pass + dense engine): E-step vs
+    the oracle's exact modes and covariance blocks, (C,d) and tau cost/gradient vs the oracle."""
+    from funs import _hip
+    q, T, R = 25, 30, 3
+    _, Ys, _ = orc.synth_dataset(q, p, T, R, seed=3, dOffset=0.0)
+    Y = np.stack(Ys).astype(np.uint8)
+    rng = np.random.default_rng(p)
+    par = {'C': 0.25 * rng.standard_normal((q, p)), 'd': np.log(Y.mean(axis=(0, 2)) + 0.1), 'tau': 0.05 + 0.1 * rng.random(p)}
+    res, nll_o, _ = orc.laplace([y.astype(float) for y in Ys], par, 10.0, mode='exact', return_cov=False)
+    ctx = _hip.Context(q, p, T, R, 10.0)
+    try:
+        ctx.upload_counts(Y)
+        ctx.set_params(par['C'], par['d'], par['tau'])
+        obj, _, status = ctx.estep_laplace()
+        assert np.all(status == 0)
+        assert abs(-obj / R - nll_o) <= 1e-9 * abs(nll_o)
+        assert np.max(np.abs(ctx.post_mean() - np.stack(res['post_mean']))) <= 1e-8
+        assert rel(ctx.post_vsm(), np.stack(res['post_vsm'])) <= 1e-8
+        assert rel(ctx.post_vsmgp(), np.stack(res['post_vsmGP'])) <= 1e-8
+        v = orc.cd_to_vec(par['C'], par['d']) + 0.01 * rng.standard_normal(q * (p + 1))
+        cost, grad = ctx.mstep_cd_costgrad(v)
+        pm, vs = [m for m in ctx.post_mean()], [m for m in ctx.post_vsm()]
+        Yf = [y.astype(float) for y in Ys]
+        assert abs(cost - orc.mstep_cd_cost(v, Yf, pm, vs, p, q)) <= 1e-10 * abs(cost)
+        assert rel(grad, orc.mstep_cd_grad(v, Yf, pm, vs, p, q)) <= 1e-9
+        ctx.mstep_precomp()
+        P_ref, _ = orc.make_precomp({'post_mean': pm, 'post_vsmGP': [m for m in ctx.post_vsmgp()]})
+        assert rel(ctx.pautosum(), P_ref) <= 1e-11
+        logp = np.log(1.0 / (par['tau'] * 100.0) ** 2)
+        cb, gb = ctx.mstep_tau_costgrad_batch(logp)
+        for k in (0, p - 1):
+            assert abs(cb[k] - orc.tau_cost(logp[k], P_ref[k], R)) <= 1e-9 * abs(cb[k])
+            assert abs(gb[k] - orc.tau_grad(logp[k], P_ref[k], R)[0]) <= 1e-7 * max(1.0, abs(gb[k]))
+        if p <= 12:
+            cost_n, delta, dec = ctx.mstep_cd_newton_pass(v)
+            assert abs(cost_n.sum() - cost) <= 1e-10 * abs(cost) and np.all(dec >= 0)
+        else:
+            with pytest.raises(_hip.HipBackendError):
+                ctx.mstep_cd_newton_pass(v)
+    finally:
+        ctx.close()
