@@ -76,9 +76,10 @@ int pgpfa_laplace_eval(pgpfa_ctx* ctx, int n, const int32_t* idx, const double* 
 int pgpfa_laplace_hessian(pgpfa_ctx* ctx, int trial, const double* X, double* H);
 
 /* ---- Laplace E-step (inference.laplace, inference.py:67-185) ---------------------- */
-/* Mode finding + posterior covariance blocks for the listed trials.  warm_start != 0
- * starts from the modes resident in the context (prevOptimRes, inference.py:99-102),
- * otherwise from zeros.  obj_sum = sum over the listed trials of the objective at the
+/* Mode finding + posterior covariance blocks for the listed trials.  warm_start = 1
+ * starts from the modes resident in the context (prevOptimRes, inference.py:99-102), 0 from
+ * zeros, 2 per trial from its resident mode if an earlier E-step produced one and from zeros
+ * otherwise (minibatches that revisit trials).  obj_sum = sum over the listed trials of the objective at the
  * mode (the reference returns -obj_sum/numTrials, inference.py:175,183).
  * iters/status (may be NULL): Cholesky factorizations per trial (Newton + the final one at the
  * mode), status 0 = converged. */

@@ -1705,16 +1705,21 @@ __global__ void gather_rows_kernel(const double* __restrict__ src, int len, doub
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < len) dst[(size_t)slot * sDst + i] = zero ? 0.0 : src[r * len + i];
 }
-// warm start with linear extrapolation of the mode over the last two E-steps of the trial (flag[slot] != 0):
-// dst = m + beta * (m - m_prev).  Over EM iterations the parameters drift smoothly and so do the modes.
-__global__ void gather_extrapolate_kernel(const double* __restrict__ mode, const double* __restrict__ prev, int len, double* __restrict__ dst,
-                                          long long sDst, const int* __restrict__ trial_of_slot, const int* __restrict__ flag, double beta) {
+// start point of a slot: how[slot] = 0 zero (cold), 1 the resident mode m, 2 the linear extrapolation m + beta (m - m_prev)
+// over the trial's last two E-steps (over EM iterations the parameters drift smoothly and so do the modes).
+__global__ void gather_start_kernel(const double* __restrict__ mode, const double* __restrict__ prev, int len, double* __restrict__ dst,
+                                    long long sDst, const int* __restrict__ trial_of_slot, const int* __restrict__ how, double beta) {
   const int slot = blockIdx.y;
   const size_t r = trial_of_slot[slot];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= len) return;
-  const double m = mode[r * len + i];
-  dst[(size_t)slot * sDst + i] = flag[slot] ? m + beta * (m - prev[r * len + i]) : m;
+  const int h = how[slot];
+  double v = 0.0;
+  if (h) {
+    v = mode[r * len + i];
+    if (h == 2) v += beta * (v - prev[r * len + i]);
+  }
+  dst[(size_t)slot * sDst + i] = v;
 }
 // mode <- new point; prev <- the mode it replaces where rotate[slot] != 0
 __global__ void scatter_rotate_kernel(const double* __restrict__ src, long long sSrc, int len, double* __restrict__ mode, double* __restrict__ prev,

@@ -1318,20 +1318,23 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
     }
     HIPC(hipMemsetAsync(c->ws.info, 0, sizeof(int) * nb, c->st));
     {
-      std::vector<int> ext(nb, 0);
+      // start points: cold (zero), the resident mode, or its extrapolation; warm_start = 2 takes the resident mode only
+      // for trials some earlier E-step has produced one for (minibatches revisiting trials) and starts the others cold
+      std::vector<int> how(nb, 0);
       bool any = false;
-      if (warm_start && c->extrapolate)
-        for (int s = 0; s < nb; ++s) {
-          ext[s] = (c->mode_serial[tos[s]] == c->estep_serial - 1 && c->prev_serial[tos[s]] == c->estep_serial - 2) ? 1 : 0;
-          any = any || ext[s];
-        }
+      for (int s = 0; s < nb && warm_start; ++s) {
+        const int tr_ = tos[s];
+        if (warm_start == 2 && c->mode_serial[tr_] < 0) continue;
+        how[s] = 1;
+        if (c->extrapolate && c->mode_serial[tr_] == c->estep_serial - 1 && c->prev_serial[tr_] == c->estep_serial - 2) how[s] = 2;
+        any = true;
+      }
       if (any) {
-        CHK(upload_list(c, c->list_a, ext));
-        hipLaunchKernelGGL(gather_extrapolate_kernel, dim3((nvec + 255) / 256, nb), dim3(256), 0, c->st, c->Xmode, c->Xprev, nvec, c->Xc, ld,
+        CHK(upload_list(c, c->list_a, how));
+        hipLaunchKernelGGL(gather_start_kernel, dim3((nvec + 255) / 256, nb), dim3(256), 0, c->st, c->Xmode, c->Xprev, nvec, c->Xc, ld,
                            c->trial_of_slot, c->list_a, c->extrapolate_beta);
       } else {
-        hipLaunchKernelGGL(gather_rows_kernel, dim3((nvec + 255) / 256, nb), dim3(256), 0, c->st, c->Xmode, nvec, c->Xc, ld, c->trial_of_slot,
-                           warm_start ? 0 : 1);
+        hipLaunchKernelGGL(gather_rows_kernel, dim3((nvec + 255) / 256, nb), dim3(256), 0, c->st, c->Xmode, nvec, c->Xc, ld, c->trial_of_slot, 1);
       }
     }
     // objective, gradient pieces and curvature blocks at the start point

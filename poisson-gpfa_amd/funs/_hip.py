@@ -205,7 +205,8 @@ class Context:
         obj = ct.c_double(0.0)
         iters = np.zeros(n, dtype=np.int32)
         status = np.zeros(n, dtype=np.int32)
-        check(self.lib.pgpfa_estep_laplace(self.h, n, iptr(ii), 1 if warm_start else 0, ct.byref(obj), iptr(iters), iptr(status)))
+        warm = 2 if warm_start == 'resident' else (1 if warm_start else 0)
+        check(self.lib.pgpfa_estep_laplace(self.h, n, iptr(ii), warm, ct.byref(obj), iptr(iters), iptr(status)))
         return obj.value, iters, status
 
     def count_moments(self, idx=None):

@@ -36,7 +36,7 @@ class PPGPFAfit():
                  CdOptimMethod='TNC', tauOptimMethod='TNC', verbose=False, EMmode='Online', batchSize=5,
                  onlineParamUpdateMethod='diag', hessTol=None, stepPow=0.75, updateCdJointly=True, fullyUpdateTau=False,
                  extractAllTraj=False, extractAllTraj_trueParams=False, getPredictionErr=False, CdMaxIter=None,
-                 tauMaxIter=None, *, quiet=False):
+                 tauMaxIter=None, *, quiet=False, onlineWarmStart=True):
         if EMmode not in ('Batch', 'Online'):
             raise ValueError("EMmode must be 'Batch' or 'Online'")
         if inferenceMethod not in ('laplace', 'variational'):
@@ -105,7 +105,10 @@ class PPGPFAfit():
             for n in range(maxEMiter):
                 sub = util.subsampleTrials(experiment, batchSize)
                 before = time.time()
-                infRes, nll, vlb, _ = e_step(sub, params, None)                      # cold start every time (engine.py:298-301)
+                # the reference starts every minibatch trial from zero (engine.py:298-301); with onlineWarmStart the
+                # trials a previous minibatch already visited start from the mode it left on the device (same fixed point)
+                prev = 'resident' if (onlineWarmStart and inferenceMethod == 'laplace') else None
+                infRes, nll, vlb, _ = e_step(sub, params, prev)
                 posteriorLikelihood.append(nll)
                 if vlb is not None:
                     variationalLowerBound.append(vlb)

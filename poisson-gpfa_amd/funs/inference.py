@@ -33,10 +33,12 @@ def laplace(experiment, params, prevOptimRes=None, returnOptimRes=True, verbose=
     """Laplace approximation of every trial's latent posterior (reference inference.py:67-185).
 
     Returns (infRes, -mean objective at the modes[, lapOptimRes]) exactly like the reference.  The
-    mode search is a damped Newton iteration with a dense Cholesky solve per step on the GPU, run
-    to |step|_inf < 1e-5 (tighter than the reference's scipy Newton-CG stop, xtol=1e-5 on the mean
-    |step|); `optimMethod` is accepted for signature compatibility only.  infRes entries are lazy
-    device-backed sequences; 'post_cov' is recomputed on access.
+    mode search is a batched inexact Newton iteration on the GPU (shared-preconditioner PCG),
+    run until the predicted error of the mode is below 1e-9 (far tighter than the reference's scipy Newton-CG
+    stop, xtol=1e-5 on the mean |step|); `optimMethod` is accepted for signature compatibility only.  infRes
+    entries are lazy device-backed sequences; 'post_cov' and 'post_vsmGP' are rebuilt on access.
+    prevOptimRes: the previous call's lapOptimRes (or host arrays) as in the reference; additionally the string
+    'resident' starts every trial from the mode an earlier E-step left on the device, if any (minibatch EM).
     """
     sess, trial_idx = _prepare(experiment, params)
     n_all = len(trial_idx)
@@ -46,7 +48,11 @@ def laplace(experiment, params, prevOptimRes=None, returnOptimRes=True, verbose=
     lo, hi = (0, n_all) if local_shard else sess.local_slice(n_all)
     mine = trial_idx[lo:hi]
     warm = False
-    if prevOptimRes is not None:
+    if isinstance(prevOptimRes, str):
+        if prevOptimRes != 'resident':
+            raise ValueError("prevOptimRes: expected a sequence of modes or 'resident'")
+        warm = 'resident'
+    elif prevOptimRes is not None:
         resident = (isinstance(prevOptimRes, DeviceOptimRes) and prevOptimRes.session is sess
                     and prevOptimRes.stamp == sess.mode_stamp and np.array_equal(prevOptimRes.trial_idx, mine))
         if not resident:

@@ -84,6 +84,24 @@ def test_estep_warm_start_and_subset(funs_mod, c1, c1_experiment):
     host = [np.asarray(infRes2['post_mean'][r]).reshape(-1) + 1e-3 for r in range(20)]
     infRes3, nll3, _ = funs_mod.inference.laplace(c1_experiment, params, prevOptimRes=host)
     assert abs(nll3 - nll) <= 1e-10 * abs(nll)
+    # 'resident': per trial, the mode an earlier E-step left on the device if there is one, zeros otherwise
+    from funs import _hip
+    ctx = _hip.Context(30, 3, 100, 20, c1['binSize'])
+    try:
+        ctx.upload_counts(c1['Y'])
+        ctx.set_params(c1['init_C'], c1['init_d'], c1['init_tau'])
+        ctx.estep_laplace(np.arange(0, 5, dtype=np.int32))
+        mixed = np.array([3, 4, 5, 6], dtype=np.int32)
+        obj_r, _, st_r = ctx.estep_laplace(mixed, warm_start='resident')
+        work = lambda: ctx.info('last_pcg_iterations') + ctx.info('last_newton_solves') + ctx.info('last_newton_factorizations')
+        work_r = work()
+        pm_r = ctx.post_mean(mixed)
+        obj_c, _, st_c = ctx.estep_laplace(mixed, warm_start=False)
+        assert np.all(st_r == 0) and np.all(st_c == 0)
+        assert abs(obj_r - obj_c) <= 1e-10 * abs(obj_c) and np.max(np.abs(pm_r - ctx.post_mean(mixed))) <= 1e-8
+        assert work_r < work()
+    finally:
+        ctx.close()
     # a minibatch through util.subsampleTrials reuses the resident counts
     np.random.seed(4)
     sub = funs_mod.util.subsampleTrials(c1_experiment, 5)
