@@ -737,7 +737,8 @@ int pgpfa_create(pgpfa_ctx** out, int device, int q, int p, int T, int R, double
   rc |= dmalloc(c, &c->Xprev, (size_t)R * c->n + 64, true);
   c->mode_serial.assign(R, -10); c->prev_serial.assign(R, -10);
   rc |= dmalloc(c, &c->vsm, (size_t)R * T * p * p + 2048, true);
-  rc |= dmalloc(c, &c->vsmgp, (size_t)R * p * T * T, true);
+  // c->vsmgp (R*p blocks of T x T: 20 GB at config 3) is allocated on first use: the low-rank engine's default
+  // sum-only output never touches it
   rc |= dmalloc(c, &c->Pauto, slab * p, true);
   rc |= dmalloc(c, &c->Pacc, slab * p, true);
   c->gemm_part_len = (size_t)16 << 20;
@@ -1131,6 +1132,11 @@ static int ensure_mt_clean(pgpfa_ctx* c) {
   return 0;
 }
 
+static int ensure_vsmgp_buffer(pgpfa_ctx* c) {
+  if (c->vsmgp) return 0;
+  return dmalloc(c, &c->vsmgp, (size_t)c->R * c->p * c->T * c->T, true);
+}
+
 static int posterior_blocks_dense(pgpfa_ctx* c, int nb, double diag_scale, bool want_vsmgp) {
   const int T = c->T, p = c->p;
   CHK(ensure_mt_clean(c));
@@ -1139,6 +1145,7 @@ static int posterior_blocks_dense(pgpfa_ctx* c, int nb, double diag_scale, bool 
   CHK(factor(c, c->ws, c->ident, nb));
   CHK(inverse_t(c, c->ws, c->ident, nb));
   if (want_vsmgp) {
+    CHK(ensure_vsmgp_buffer(c));
     for (int k = 0; k < p; ++k) {
       const int kal = (k * T) / 16 * 16;
       GemmP g{};
@@ -1259,6 +1266,7 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool 
       hipLaunchKernelGGL(pacc_reduce_kernel, dim3(T, p), dim3(128), 0, c->st, c->ppart, nsplit, c->Gbin, sW, nb, c->eps, T, Tp, p, c->Pacc);
       c->pacc_used = true;
     } else {
+      CHK(ensure_vsmgp_buffer(c));
       const size_t off_stage = (size_t)c->ld * rpad + (size_t)Tp * rpad;
       for (int k = 0; k < p; ++k) {
         GemmP g{};
@@ -1801,6 +1809,7 @@ int pgpfa_get_post_vsmgp(pgpfa_ctx* c, int n, const int32_t* idx, double* out) {
   HIPC(hipSetDevice(c->device));
   Trials tr;
   CHK(resolve_trials(c, n, idx, &tr));
+  CHK(ensure_vsmgp_buffer(c));
   CHK(ensure_trial_vsmgp(c, tr.v));
   const size_t len = (size_t)c->T * c->T * c->p;
   double* tmp = nullptr;
@@ -1848,6 +1857,7 @@ int pgpfa_set_posterior(pgpfa_ctx* c, int n, const int32_t* idx, const double* p
   CHK(resolve_trials(c, n, idx, &tr));
   const size_t lm = c->n, lv = (size_t)c->T * c->p * c->p, lg = (size_t)c->T * c->T * c->p;
   double* tmp = nullptr;
+  if (post_vsmgp) CHK(ensure_vsmgp_buffer(c));
   if (post_vsmgp) HIPC(hipMalloc((void**)&tmp, lg * sizeof(double)));
   for (size_t i = 0; i < tr.v.size(); ++i) {
     const size_t r = tr.v[i];
@@ -2052,6 +2062,7 @@ int pgpfa_mstep_precomp(pgpfa_ctx* c, double* num_trials) {
     hipLaunchKernelGGL(pauto_from_acc_kernel, dim3(c->Tp, c->p), dim3(128), 0, c->st, c->Pacc, c->Xmode, c->last_trials, ntr, c->T, c->Tp, c->p,
                        c->Pauto);
   } else {
+    CHK(ensure_vsmgp_buffer(c));
     CHK(ensure_trial_vsmgp(c, c->last_trials_h));
     hipLaunchKernelGGL(pautosum_kernel, dim3(c->Tp, c->p), dim3(128), 0, c->st, c->vsmgp, c->Xmode, c->last_trials, ntr, c->T, c->Tp, c->p, c->Pauto);
   }
