@@ -282,7 +282,7 @@ def test_variational_batch_em_vs_reference(funs_mod):
     assert rel(fit.paramSeq[-1]['C'], g['bounded_seq_C'][-1]) <= 5e-3
 
 
-@pytest.mark.timeout(400)
+@pytest.mark.timeout(700)
 def test_rccl_path_single_rank(c1):
     """The multi-GPU code path (unique-id file rendezvous, ncclCommInitRank, device all-reduce inside the
     M-step entry points) on a 1-rank communicator: results must equal the communicator-free run."""
