@@ -3,10 +3,11 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c2|c1] [--no-cpu-baseline]
 
-A step is one full batch-EM iteration on synthetic spike counts already resident in HBM: Laplace
-E-step over every trial (Newton mode search with a dense FP64 Cholesky per step, posterior covariance
-blocks) followed by the M-step for C, d (scipy TNC driving the HIP cost/grad kernel, as the reference
-does) and the GP timescales (scipy BFGS driving the HIP Gram/Cholesky/trace kernels).
+A step is one full batch-EM iteration on synthetic spike counts already resident in HBM: warm-started Laplace
+E-step over every trial (batched inexact Newton with the shared-preconditioner PCG, posterior covariance blocks by
+the low-rank engine) followed by the M-step for C, d (device per-neuron Newton; `--cd-method TNC` runs the reference
+engine's scipy driver on the HIP cost/grad kernel instead) and the GP timescales (4-point lockstep root finder on the
+batched HIP Gram/Cholesky/trace pass).
 
 Workload (BASELINE.json): config 3 = 200 neurons, 10 latents, 500 bins, 1024 trials per GPU - the
 configuration the north-star target is quoted on.  For N > 1 the driver launches one rank per GPU with
@@ -22,6 +23,12 @@ import json
 import os
 import sys
 import time
+
+if int(os.environ.get('WORLD_SIZE', '1')) > 1:
+    # one rank per GPU on one node: keep the ranks' host BLAS/OpenMP pools from oversubscribing the cores
+    _share = str(max(1, (os.cpu_count() or 8) // int(os.environ['WORLD_SIZE'])))
+    for _var in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS'):
+        os.environ.setdefault(_var, _share)
 
 import numpy as np
 
