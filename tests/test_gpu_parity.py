@@ -588,3 +588,40 @@ def test_wide_latent_dimensions(p):
                 ctx.mstep_cd_newton_pass(v)
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize('q,p,T,R', [(2, 1, 3, 1), (3, 2, 5, 2), (1, 1, 17, 3)])
+def test_tiny_problem_sizes(q, p, T, R):
+    """Degenerate sizes (a single latent / neuron / trial, a handful of bins): E-step and one M-step evaluation still
+    agree with the oracle (the host layer skips ranks whose shard is empty; the C-ABI itself refuses an empty list)."""
+    from funs import _hip
+    rng = np.random.default_rng(q * 100 + T)
+    Y = rng.poisson(1.0, size=(R, q, T)).astype(np.uint8)
+    par = {'C': 0.5 * rng.standard_normal((q, p)), 'd': -0.3 + 0.2 * rng.standard_normal(q), 'tau': 0.02 + 0.05 * rng.random(p)}
+    res, nll_o, _ = orc.laplace([y.astype(float) for y in Y], par, 10.0, mode='exact', return_cov=False)
+    ctx = _hip.Context(q, p, T, R, 10.0)
+    try:
+        ctx.upload_counts(Y)
+        ctx.set_params(par['C'], par['d'], par['tau'])
+        with pytest.raises(_hip.HipBackendError):                   # an empty trial list is refused loudly at the C-ABI
+            ctx.estep_laplace(np.zeros(0, dtype=np.int32))
+        obj, _, status = ctx.estep_laplace()
+        assert np.all(status == 0)
+        assert abs(-obj / R - nll_o) <= 1e-9 * max(1.0, abs(nll_o))
+        assert np.max(np.abs(ctx.post_mean() - np.stack(res['post_mean']))) <= 1e-8
+        assert rel(ctx.post_vsm(), np.stack(res['post_vsm'])) <= 1e-8
+        assert rel(ctx.post_vsmgp(), np.stack(res['post_vsmGP'])) <= 1e-8
+        v = orc.cd_to_vec(par['C'], par['d'])
+        cost, grad = ctx.mstep_cd_costgrad(v)
+        pm, vs = [m for m in ctx.post_mean()], [m for m in ctx.post_vsm()]
+        Yf = [y.astype(float) for y in Y]
+        assert abs(cost - orc.mstep_cd_cost(v, Yf, pm, vs, p, q)) <= 1e-10 * max(1.0, abs(cost))
+        assert rel(grad, orc.mstep_cd_grad(v, Yf, pm, vs, p, q)) <= 1e-9
+        y_pred, err = ctx.loo_predict()
+        if q > 1:
+            pred_o, err_o = orc.leave_one_out_prediction(Yf, par, 10.0, mode='exact')
+            assert rel(y_pred, pred_o) <= 1e-7
+        s, S, ns = ctx.count_moments()
+        assert ns == R * T and np.array_equal(s, Y.astype(np.int64).sum(axis=(0, 2)))
+    finally:
+        ctx.close()
