@@ -137,6 +137,56 @@ def cpu_baseline(q, p, T, R, true_params, Y0, bin_ms, init):
             'estep_s_per_trial': per_trial}
 
 
+def cpu_baseline_loo(params, Y0, bin_ms, y_pred0, searches):
+    """cpu_baseline leg of the leave-one-neuron-out workload: the oracle's faithful restatement of
+    util.leaveOneOutPrediction (fmin_ncg on the big-matrix callbacks) on the first neurons of trial 0."""
+    from oracle import pgpfa_oracle as orc
+    import scipy.optimize as op
+    C, d = params['C'], params['d']
+    q, p = C.shape
+    T = Y0.shape[1]
+    Y0 = np.asarray(Y0, dtype=np.float64)
+    t0 = time.time()
+    K_bigInv = np.linalg.inv(orc.make_K_big(orc.make_K(params['tau'], T, bin_ms)))
+    worst = 0.0
+    for n in range(searches):
+        Cw, dw, Yw = np.delete(C, n, 0), np.delete(d, n, 0), np.delete(Y0, n, 0)
+        C_big, d_big = orc.make_Cd_big(Cw, dw, T)
+        x = op.fmin_ncg(orc.nlp_big, np.zeros(p * T), fprime=orc.nlp_big_grad, fhess=orc.nlp_big_hess,
+                        args=(Yw.reshape(-1), C_big, d_big, K_bigInv), disp=False)
+        yp = np.exp(C[n] @ x.reshape(p, T) + d[n])
+        worst = max(worst, float(np.max(np.abs(yp - y_pred0[n]) / yp)))
+    per = (time.time() - t0) / searches
+    return {'kind': 'port', 'seconds_per_search': per, 'value': 1.0 / per, 'unit': 'mode searches/s', 'sample': '%d searches of trial 0' % searches,
+            'cores': os.cpu_count(), 'max_rel_diff_of_predictions': worst}
+
+
+def run_loo(args, q, p, T, R):
+    """Secondary workload: throughput of leave-one-neuron-out prediction, R*q held-out mode searches
+    with the generating parameters.  One JSON line; not the headline metric."""
+    import funs
+    from funs import _session
+    true_params, Ys = synth_shard(q, p, T, R, args.seed, 0)
+    exp = Shard(Ys, 10.0)
+    params = {k: np.asarray(v, dtype=np.float64) for k, v in true_params.items()}
+    sess, _ = _session.session_for(exp, p)
+    sess.set_params(params)
+    sess.ctx.loo_predict(np.array([0], dtype=np.int32))          # warm-up: workspace, code objects
+    t0 = time.time()
+    y_pred, err = funs.util.leaveOneOutPrediction(params, exp)
+    dt = time.time() - t0
+    out = {'metric': 'leave-one-neuron-out mode searches/s', 'value': R * q / dt, 'unit': 'mode searches/s', 'n_gpus': 1,
+           'higher_is_better': True, 'dtype': 'f64', 'data': 'synthetic',
+           'config': {'workload': '%s leave-one-neuron-out prediction: %d neurons, %d latents, %d bins, %d trials = %d cold mode searches'
+                                  % (args.config, q, p, T, R, R * q)},
+           'seconds': dt, 'pred_err_mode': err}
+    if not args.no_cpu_baseline:
+        k = 4 if p * T <= 400 else 2
+        out['cpu_baseline'] = cpu_baseline_loo(params, Ys[0], 10.0, y_pred[0], k)
+        out['speedup_vs_cpu_baseline'] = out['value'] / out['cpu_baseline']['value']
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -149,6 +199,8 @@ def main():
                     help="(C,d) M-step solver: 'newton' = device per-neuron Newton (exact minimiser of the reference's cost); "
                          "'TNC' = the reference engine's default scipy driver on the same device cost/grad")
     ap.add_argument('--seed', type=int, default=12)
+    ap.add_argument('--workload', default='em', choices=['em', 'loo'],
+                    help="'em' (default): the headline EM-iterations/s metric; 'loo': leave-one-neuron-out prediction throughput (1 GPU)")
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -160,6 +212,8 @@ def main():
     if args.trials > 0:
         R = args.trials
     bin_ms = 10.0
+    if args.workload == 'loo':
+        return run_loo(args, q, p, T, R)
 
     import funs
     from funs import _hip, _session
