@@ -294,7 +294,7 @@ def main():
         'unit': 'EM-iterations/s (1024-trial batches of 200 neurons x 10 latents x 500 bins)' if args.config == 'c3' else 'EM-iterations/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-        'config': {'workload': '%s: %d neurons, %d latents, %d bins, %d trials per GPU, Laplace batch EM (warm-started E-step; M-step: (C,d) by %s, tau by lockstep secant)'
+        'config': {'workload': '%s: %d neurons, %d latents, %d bins, %d trials per GPU, Laplace batch EM (warm-started E-step; M-step: (C,d) by %s, tau by the 4-point lockstep root finder)'
                                % (args.config, q, p, T, R, 'device per-neuron Newton' if args.cd_method == 'newton' else 'scipy ' + args.cd_method), 'trials_total': total_trials, 'parallelism': 'trial-sharded x%d' % world},
         'estep_ms_per_trial': float(np.mean(estep_ms[timed])) / R,
         'estep_ms': [round(x, 1) for x in estep_ms], 'mstep_ms': [round(x, 1) for x in mstep_ms],

@@ -19,6 +19,23 @@ from . import _hip
 # ----------------------------------------------------------------------------------------------
 # process-wide communicator description (rank, world size, unique id exchange)
 # ----------------------------------------------------------------------------------------------
+class _stdout_to_stderr:
+    """RCCL prints a version banner on the process's stdout (file descriptor 1) when the first communicator comes
+    up; callers that emit machine-readable output on stdout (bench.py: one JSON line) must not see it there."""
+
+    def __enter__(self):
+        import sys
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 class _World:
     def __init__(self):
         self.rank = int(os.environ.get('RANK', '0'))
@@ -155,12 +172,13 @@ class Session:
         self.rank, self.size = 0, 1
         self.comm_ready = False
         if WORLD.enabled:
-            uid, path = WORLD.exchange_unique_id()
-            self.ctx.comm_init(uid, WORLD.rank, WORLD.size)
-            self.rank, self.size = WORLD.rank, WORLD.size
-            self.comm_ready = True
-            # first collective doubles as the barrier after which rank 0 may remove the file
-            self.ctx.allreduce_host(np.zeros(1))
+            with _stdout_to_stderr():
+                uid, path = WORLD.exchange_unique_id()
+                self.ctx.comm_init(uid, WORLD.rank, WORLD.size)
+                self.rank, self.size = WORLD.rank, WORLD.size
+                self.comm_ready = True
+                # first collective doubles as the barrier after which rank 0 may remove the file
+                self.ctx.allreduce_host(np.zeros(1))
             if WORLD.rank == 0:
                 try:
                     os.remove(path)
