@@ -298,6 +298,7 @@ def main():
                                % (args.config, q, p, T, R, 'device per-neuron Newton' if args.cd_method == 'newton' else 'scipy ' + args.cd_method), 'trials_total': total_trials, 'parallelism': 'trial-sharded x%d' % world},
         'estep_ms_per_trial': float(np.mean(estep_ms[timed])) / R,
         'estep_ms': [round(x, 1) for x in estep_ms], 'mstep_ms': [round(x, 1) for x in mstep_ms],
+        'estep_ms_cold_start': round(estep_ms[0], 1), 'estep_ms_warm_mean': round(float(np.mean(estep_ms[timed])), 1),
         'factorizations_per_trial': [round(f / R, 2) for f in facts],
         'newton_solves_per_trial': [round(f / R, 2) for f in solves],
         'pcg_iterations_per_trial': [round(f / R, 2) for f in pcgs],
