@@ -333,21 +333,43 @@ __global__ __launch_bounds__(256) void poisson_mfma_kernel(PoissonArgs a, const 
   double facc = 0.0;
 
   if (sbase < T) {
+    // every global load of a neuron tile (offsets, counts, table fragments) is issued up front with clamped,
+    // branch-free addresses; invalid rows/bins are masked afterwards
+    const int tc = valid_t ? t : T - 1;
     for (int nb0 = 0; nb0 < qpad; nb0 += 16) {
-      mdouble4 h;
+      double dv[4];
+      unsigned yv[4];
+      double ch[KS];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = nb0 + l4 + 4 * r;
-        h[r] = (n < q) ? a.d[n] : 0.0;
+        const int nc = n < q ? n : q - 1;
+        dv[r] = a.d[nc];
+        yv[r] = Y[(size_t)nc * T + tc];
       }
 #pragma unroll
-      for (int kk = 0; kk < KS; ++kk) h = __builtin_amdgcn_mfma_f64_16x16x4f64(C16[(size_t)(nb0 + l15) * 16 + l4 + 4 * kk], xb[kk], h, 0, 0, 0);
+      for (int kk = 0; kk < KS; ++kk) ch[kk] = C16[(size_t)(nb0 + l15) * 16 + l4 + 4 * kk];
+      double bw[4][NT], bg[4];
+      if (a.full) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const size_t nrow = (size_t)(nb0 + 4 * r + l4);
+#pragma unroll
+          for (int tl = 0; tl < NT; ++tl) bw[r][tl] = CCu[nrow * NC + tl * 16 + l15];
+          bg[r] = C16[nrow * 16 + l15];
+        }
+      }
+      mdouble4 h;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h[r] = (nb0 + l4 + 4 * r < q) ? dv[r] : 0.0;
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) h = __builtin_amdgcn_mfma_f64_16x16x4f64(ch[kk], xb[kk], h, 0, 0, 0);
       double e[4], rr[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = nb0 + l4 + 4 * r;
         const bool ok = (n < q) && valid_t && (n != held_out);
-        const double y = ok ? (double)Y[(size_t)n * T + t] : 0.0;
+        const double y = ok ? (double)yv[r] : 0.0;
         const double ev = ok ? exp(h[r]) : 0.0;
         e[r] = ev;
         rr[r] = ev - y;
@@ -356,11 +378,9 @@ __global__ __launch_bounds__(256) void poisson_mfma_kernel(PoissonArgs a, const 
       if (a.full) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const size_t nrow = (size_t)(nb0 + 4 * r + l4);
 #pragma unroll
-          for (int tl = 0; tl < NT; ++tl)
-            accW[tl] = __builtin_amdgcn_mfma_f64_16x16x4f64(e[r], CCu[nrow * NC + tl * 16 + l15], accW[tl], 0, 0, 0);
-          accG = __builtin_amdgcn_mfma_f64_16x16x4f64(rr[r], C16[nrow * 16 + l15], accG, 0, 0, 0);
+          for (int tl = 0; tl < NT; ++tl) accW[tl] = __builtin_amdgcn_mfma_f64_16x16x4f64(e[r], bw[r][tl], accW[tl], 0, 0, 0);
+          accG = __builtin_amdgcn_mfma_f64_16x16x4f64(rr[r], bg[r], accG, 0, 0, 0);
         }
       }
     }
