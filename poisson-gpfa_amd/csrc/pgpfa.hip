@@ -109,6 +109,8 @@ struct pgpfa_ctx {
   double n_trials_global = 0.0;
   // chunk workspace
   int B = 0;
+  int want_slots = 0;                             // largest trial list an E-step-like call has asked for
+  bool B_capped = false;
   CholWS ws{};
   double *Xc = nullptr, *Xt = nullptr, *KX = nullptr, *KD = nullptr, *Gl = nullptr, *Glt = nullptr, *Gt = nullptr, *Dl = nullptr;
   double *W = nullptr, *Wt = nullptr, *fpart = nullptr;
@@ -406,7 +408,10 @@ int free_workspace(pgpfa_ctx* c) {
 // trials fit in one chunk.  Switching plans reallocates the workspace (persistent state is untouched).
 int ensure_workspace(pgpfa_ctx* c, bool plan_lr) {
   const size_t slab = plan_lr ? (lowrank_slab_elems(c) + 1023) / 1024 * 1024 : (size_t)c->ld * c->ld;
-  if (c->B > 0 && c->plan_lowrank == plan_lr && slab <= c->slab_elems) return 0;
+  // the chunk is sized for the largest trial list seen so far, not for all R resident trials: minibatch EM over a large
+  // resident set then keeps one chunk with generous rank head-room instead of re-planning as the ranks grow
+  const int target = (c->want_slots > 0) ? std::min(c->want_slots, c->R) : c->R;
+  if (c->B > 0 && c->plan_lowrank == plan_lr && slab <= c->slab_elems && (c->B >= target || c->B_capped)) return 0;
   CHK(free_workspace(c));
   c->ws_mark = c->allocs.size();
   c->plan_lowrank = plan_lr;
@@ -422,17 +427,18 @@ int ensure_workspace(pgpfa_ctx* c, bool plan_lr) {
   c->slab_elems = slab;
   if (plan_lr) {
     const size_t roomy = std::min((size_t)c->ld * c->ld, 2 * slab);
-    c->slab_elems = (budget / per_slot_bytes(c, roomy) >= (size_t)c->R) ? roomy : std::min((size_t)c->ld * c->ld, slab + slab / 4);
+    c->slab_elems = (budget / per_slot_bytes(c, roomy) >= (size_t)target) ? roomy : std::min((size_t)c->ld * c->ld, slab + slab / 4);
   }
   const size_t per = per_slot_bytes(c, c->slab_elems);
   long long B = (long long)(budget / per);
   if (c->chunk_opt > 0) B = std::min<long long>(B, c->chunk_opt);
-  if (B >= c->R) {
-    B = c->R;                                        // everything in one chunk
+  c->B_capped = B < target;                          // memory (or chunk_trials) bound: asking again would not give more
+  if (B >= target) {
+    B = target;                                      // everything in one chunk
   } else if (B >= 16) {
     B = B / 8 * 8;                                   // groups of 8 slots map onto the 8 XCDs
-    const long long nchunks = (c->R + B - 1) / B;    // balance the chunks
-    const long long Bb = ((c->R + nchunks - 1) / nchunks + 7) / 8 * 8;
+    const long long nchunks = (target + B - 1) / B;  // balance the chunks
+    const long long Bb = ((target + nchunks - 1) / nchunks + 7) / 8 * 8;
     B = std::min(B, Bb);
   }
   if (B < 1) return fail("not enough device memory for one trial slab (%zu bytes needed, %zu free)", per, free_b);
@@ -1303,6 +1309,7 @@ struct LooJob {
 
 static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow_lr, double* obj_sum, int32_t* iters, int32_t* status,
                       const LooJob* loo = nullptr) {
+  c->want_slots = std::max(c->want_slots, std::min((int)tr.v.size(), c->R));
   CHK(ready_estep(c, allow_lr));
   struct MaskGuard { pgpfa_ctx* c; ~MaskGuard() { c->mask_active = false; } } mask_guard{c};
   const int N = (int)tr.v.size();

@@ -407,6 +407,75 @@ def _lockstep_multi(evaluate_multi, p0, d_hint=None, gtol=1e-8, xtol=1e-10, max_
     return root, Fs[ib, cols], Gs[ib, cols], rounds, done
 
 
+class _ConcurrentScalarProblems:
+    """k independent scipy optimisations of scalar problems, one Python thread each, whose cost/gradient requests are
+    gathered into ONE batched device evaluation per round (the evaluation is a latency-bound chain of small launches:
+    k problems cost what one does).  Every optimiser sees exactly the call sequence it would see alone."""
+
+    def __init__(self, x_init, evaluate_batch):
+        import threading
+        self._threading = threading
+        self.evaluate_batch = evaluate_batch              # x[k] -> (f[k], g[k])
+        self.x = np.array(x_init, dtype=np.float64)
+        self.cond = threading.Condition()
+        self.pending, self.results = {}, {}
+        self.active = set(range(self.x.size))
+        self.generation = 0
+        self.error = None
+        self.rounds = 0
+
+    def _flush(self):                                     # lock held by the caller
+        for i, v in self.pending.items():
+            self.x[i] = v
+        try:
+            f, g = self.evaluate_batch(self.x.copy())
+            self.results = {i: (float(f[i]), float(g[i])) for i in self.pending}
+        except Exception as exc:                          # hand the failure to every waiting optimiser
+            self.error = exc
+            self.results = {}
+        self.pending = {}
+        self.rounds += 1
+        self.generation += 1
+        self.cond.notify_all()
+
+    def request(self, idx, value):
+        with self.cond:
+            self.pending[idx] = float(value)
+            gen = self.generation
+            if len(self.pending) == len(self.active):
+                self._flush()
+            else:
+                while self.generation == gen:
+                    self.cond.wait()
+            if self.error is not None:
+                raise self.error
+            return self.results[idx]
+
+    def run(self, solve_one):
+        """solve_one(idx, evaluate) -> result, with evaluate(v) -> (cost, grad) of problem idx at scalar v."""
+        out = [None] * self.x.size
+
+        def worker(idx):
+            try:
+                out[idx] = solve_one(idx, lambda v: self.request(idx, v))
+            except Exception as exc:
+                out[idx] = exc
+            finally:
+                with self.cond:
+                    self.active.discard(idx)
+                    if self.pending and len(self.pending) == len(self.active):
+                        self._flush()
+        threads = [self._threading.Thread(target=worker, args=(i,)) for i in range(self.x.size)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for r in out:
+            if isinstance(r, Exception):
+                raise r
+        return out
+
+
 def learnGPparams(oldParams, infRes, experiment):
     """reference learning.py:257-293: minimise each latent's timescale cost from p0 = log(1/tau_bins^2) to
     |grad| <= 1e-8.  The xdim problems are independent and one-dimensional, so by default they are solved in
@@ -435,13 +504,13 @@ def learnGPparams(oldParams, infRes, experiment):
                                             success=bool(ok[xd]), message='lockstep %s' % ('multi-point' if TAU_SOLVER == 'lockstep' else 'secant'))
         tempTau = (1 / np.exp(pv)) ** 0.5
         return tempTau * binSize / 1000, details
-    tempTau = np.zeros(xdim)
-    for xd in range(xdim):
-        cache = _CostGradCache(lambda v, k=xd: sess.ctx.mstep_tau_costgrad(k, float(np.asarray(v).reshape(-1)[0])))
-        res = op.minimize(fun=cache.fun, x0=initp[xd], jac=lambda v, c=cache: np.array([c.jac(v)]),
-                          options={'disp': False, 'gtol': 1e-8})
-        details[xd] = res
-        tempTau[xd] = (1 / np.exp(res.x[0])) ** 0.5
+    # TAU_SOLVER == 'scipy': the reference's per-latent BFGS calls, run concurrently so that their evaluations batch
+    def solve_one(xd, evaluate):
+        cache = _CostGradCache(lambda v: evaluate(float(np.asarray(v).reshape(-1)[0])))
+        return op.minimize(fun=cache.fun, x0=initp[xd], jac=lambda v, c=cache: np.array([c.jac(v)]),
+                           options={'disp': False, 'gtol': 1e-8})
+    details = _ConcurrentScalarProblems(initp, sess.ctx.mstep_tau_costgrad_batch).run(solve_one)
+    tempTau = np.array([(1 / np.exp(res.x[0])) ** 0.5 for res in details])
     return tempTau * binSize / 1000, details
 
 
@@ -456,22 +525,21 @@ def learnGPparamsWithPrior(oldParams, infRes, experiment, tauOptimMethod, regula
     oldTau = tau_old * 1000 / binSize
     DevicePrecomp(sess, sess.T)
     s = regularizer_stepsize_tau
-    tempTau = np.zeros(xdim)
-    details = [[]] * xdim
-    for xd in range(xdim):
-        initp = np.log(1 / oldTau[xd] ** 2)
+    initp = np.log(1 / oldTau ** 2)
 
-        def evaluate(v, k=xd):
+    # the xdim scipy optimisations (one per latent, as in the reference) run concurrently: their cost/gradient requests
+    # are served by one batched device pass per round
+    def solve_one(xd, evaluate):
+        def with_prior(v):
             pv = float(np.asarray(v).reshape(-1)[0])
-            cost, grad = sess.ctx.mstep_tau_costgrad(k, pv)
+            cost, grad = evaluate(pv)
             tau = binSize / 1000 * (1 / np.exp(pv)) ** 0.5
-            return cost + 0.5 * (tau - tau_old[k]) ** 2 / s ** 2, grad + (tau - tau_old[k]) / s ** 2
-
-        cache = _CostGradCache(evaluate)
-        res = op.minimize(fun=cache.fun, x0=initp, jac=lambda v, c=cache: np.array([c.jac(v)]),
-                          options={'disp': False, 'gtol': 1e-10}, method=tauOptimMethod)
-        details[xd] = res
-        tempTau[xd] = (1 / np.exp(np.asarray(res.x).reshape(-1)[0])) ** 0.5
+            return cost + 0.5 * (tau - tau_old[xd]) ** 2 / s ** 2, grad + (tau - tau_old[xd]) / s ** 2
+        cache = _CostGradCache(with_prior)
+        return op.minimize(fun=cache.fun, x0=initp[xd], jac=lambda v, c=cache: np.array([c.jac(v)]),
+                           options={'disp': False, 'gtol': 1e-10}, method=tauOptimMethod)
+    details = _ConcurrentScalarProblems(initp, sess.ctx.mstep_tau_costgrad_batch).run(solve_one)
+    tempTau = np.array([(1 / np.exp(np.asarray(res.x).reshape(-1)[0])) ** 0.5 for res in details])
     return tempTau * binSize / 1000, details
 
 
