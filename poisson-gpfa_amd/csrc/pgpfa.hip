@@ -422,12 +422,17 @@ int ensure_workspace(pgpfa_ctx* c, bool plan_lr) {
     const size_t shared = (3 * ld_bytes(c) + 1024 * (size_t)c->ld * sizeof(double) * 4);
     budget = budget > shared ? budget - shared : 0;
   }
-  // low-rank plan: head-room for rank growth between EM iterations (a re-plan costs seconds) - twice the need
-  // if every trial still fits in one chunk, 25 % otherwise
+  // low-rank plan: head-room for rank growth between EM iterations (a re-plan costs seconds of hipFree/hipMalloc).
+  // If the whole trial list fits in one chunk the slabs take what the memory budget allows (up to the dense size, so
+  // the plan never has to grow again while the low-rank form still pays); otherwise 25 % above the need.
   c->slab_elems = slab;
   if (plan_lr) {
-    const size_t roomy = std::min((size_t)c->ld * c->ld, 2 * slab);
-    c->slab_elems = (budget / per_slot_bytes(c, roomy) >= (size_t)target) ? roomy : std::min((size_t)c->ld * c->ld, slab + slab / 4);
+    const size_t dense = (size_t)c->ld * c->ld;
+    const size_t fixed = per_slot_bytes(c, 0);
+    const size_t per_budget = budget / (size_t)std::max(target, 1);
+    size_t fit = per_budget > fixed ? (per_budget - fixed) / (2 * sizeof(double)) : 0;     // per_slot_bytes is 16 B per slab element
+    fit = std::min(dense, fit / 1024 * 1024);
+    c->slab_elems = (fit >= slab) ? fit : std::min(dense, slab + slab / 4);
   }
   const size_t per = per_slot_bytes(c, c->slab_elems);
   long long B = (long long)(budget / per);
