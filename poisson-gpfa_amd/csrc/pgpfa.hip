@@ -431,7 +431,7 @@ int ensure_workspace(pgpfa_ctx* c, bool plan_lr) {
     const size_t fixed = per_slot_bytes(c, 0);
     const size_t per_budget = budget / (size_t)std::max(target, 1);
     size_t fit = per_budget > fixed ? (per_budget - fixed) / (2 * sizeof(double)) : 0;     // per_slot_bytes is 16 B per slab element
-    fit = std::min(dense, fit / 1024 * 1024);
+    fit = std::min(std::min(dense, 4 * slab), fit / 1024 * 1024);          // (4x the present need covers ranks doubling)
     c->slab_elems = (fit >= slab) ? fit : std::min(dense, slab + slab / 4);
   }
   const size_t per = per_slot_bytes(c, c->slab_elems);
@@ -1189,6 +1189,7 @@ static int posterior_blocks_dense(pgpfa_ctx* c, int nb, double diag_scale, bool 
 static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool accumulate) {
   const int T = c->T, p = c->p, Tp = c->Tp, pp = p * p;
   const int rpad = c->rpad;
+  const int ract = round_up(c->rtot, 16);          // columns of Yt that are not identically zero (rpad rounds to 128 for the factor)
   const long long sW = (long long)T * pp;
   c->last_cov_lowrank = true;
   // a. per-bin blocks G = (I + eps W)^-1, Wt = W G
@@ -1218,7 +1219,7 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool 
     g.A = c->Flr + (size_t)k * Tp * Tp; g.sA = 0; g.lda = Tp;
     g.B = lw.Mt + c->roff[k]; g.sB = lw.sM; g.ldb = rpad;          // rows roff[k].. of Mts, K x N column-major
     g.C = lw.H + (size_t)k * T; g.sC = lw.sH; g.ldc = c->ld;
-    g.M = T; g.N = rpad; g.K = c->rk[k]; g.alpha = 1.0; g.beta = 0.0;
+    g.M = T; g.N = ract; g.K = c->rk[k]; g.alpha = 1.0; g.beta = 0.0;
     g.slots = c->ident; g.nbatch = nb; g.mode = GEMM_FULL; g.kflags = 0;
     CHK(gemm(c, true, g));
   }
@@ -1230,7 +1231,7 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool 
     dispatch_pw(p, [&](auto pw) {
       constexpr int PW = decltype(pw)::value;
       if constexpr (PW <= 16)
-        hipLaunchKernelGGL(mix_vsm_kernel<PW>, dim3((T + 63) / 64, nb), dim3(256), 0, c->st, lw.H, lw.sH, c->ld, c->Gbin, sW, T, p, rpad, c->eps,
+        hipLaunchKernelGGL(mix_vsm_kernel<PW>, dim3((T + 63) / 64, nb), dim3(256), 0, c->st, lw.H, lw.sH, c->ld, c->Gbin, sW, T, p, ract, c->eps,
                            c->vsm, c->ident, c->trial_of_slot);
     });
     prof_end(c);
@@ -1239,7 +1240,7 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool 
     const int KY = std::min(p, 16);
     prof_begin(c, TAG_VSM, (double)nb * c->n * rpad * p);
     dispatch_pmax(p, [&](auto pm) {
-      hipLaunchKernelGGL(post_vsm_kernel<decltype(pm)::value>, dim3((T + 63) / 64, nb), dim3(64, KY), 0, c->st, lw.H, lw.sH, c->ld, rpad,
+      hipLaunchKernelGGL(post_vsm_kernel<decltype(pm)::value>, dim3((T + 63) / 64, nb), dim3(64, KY), 0, c->st, lw.H, lw.sH, c->ld, ract,
                          T, p, c->vsm, c->ident, c->trial_of_slot, 1);
     });
     prof_end(c);
@@ -1265,10 +1266,10 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool 
         g.A = lw.H + (size_t)first_slot * lw.sH; g.sA = (long long)slots_per * lw.sH; g.lda = c->ld;
         g.B = g.A; g.sB = g.sA; g.ldb = c->ld;
         g.C = c->ppart + (size_t)part_first * T * T; g.sC = (long long)T * T; g.ldc = T;
-        g.M = T; g.N = T; g.K = slots_per * rpad; g.alpha = 1.0; g.beta = 0.0;
+        g.M = T; g.N = T; g.K = slots_per * ract; g.alpha = 1.0; g.beta = 0.0;
         g.slots = nullptr; g.nb_lo = ngroups; g.nbatch = ngroups * p;
         g.sA_hi = T; g.sB_hi = T; g.sC_hi = (long long)nsplit * T * T;
-        g.kseg = rpad; g.sAseg = lw.sH; g.sBseg = lw.sH;
+        g.kseg = ract; g.sAseg = lw.sH; g.sBseg = lw.sH;    // ract columns of each slab, slabs sH apart
         g.mode = GEMM_LOWER; g.kflags = 0;
         return gemm(c, false, g);
       };
@@ -1284,7 +1285,7 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool 
         g.A = lw.H + (size_t)k * T; g.sA = lw.sH; g.lda = c->ld;
         g.B = g.A; g.sB = lw.sH; g.ldb = c->ld;
         g.C = lw.H + off_stage; g.sC = lw.sH; g.ldc = T;
-        g.M = T; g.N = T; g.K = rpad; g.alpha = 1.0; g.beta = 0.0;
+        g.M = T; g.N = T; g.K = ract; g.alpha = 1.0; g.beta = 0.0;
         g.slots = c->ident; g.nbatch = nb; g.mode = GEMM_LOWER; g.kflags = 0;
         CHK(gemm(c, false, g));
         hipLaunchKernelGGL(scatter_vsmgp_lr_kernel, dim3((unsigned)(((size_t)T * T + 255) / 256), nb), dim3(256), 0, c->st, lw.H + off_stage, lw.sH, T,
