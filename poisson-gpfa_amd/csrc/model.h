@@ -1123,12 +1123,62 @@ __global__ void mean_w_kernel(const double* __restrict__ W, long long sW, const 
   out[e] = s / (double)nslots;
 }
 
-// q = W p  added onto q (which already holds Kinv p):  q[(k,t)] += sum_l W[t][k][l] p[(l,t)]
-// then pq[slot] = p.q ; block per slot, thread per bin (W_t is one contiguous p*p block per thread)
+// q = W p  added onto q (which already holds Kinv p):  q[(k,t)] += sum_l W[t][k][l] p[(l,t)], and the partial
+// products pqpart[slot][tile] = sum over the tile's bins of p.q (summed in tile order by the consumer: deterministic).
+// A block owns 64 bins of one slot: the W_t blocks are staged in LDS with coalesced reads (odd row stride: each lane
+// then reads its own block conflict-free); lanes = bins, the 4 waves take the output rows k = w, w+4, ...
+// grid = (ceil(T/64), nslots), block = 256, p <= PW.
 template <int PW>
 __global__ __launch_bounds__(256) void pcg_hessvec_dot_kernel(const double* __restrict__ W, long long sW, const double* __restrict__ P,
-                                                              double* __restrict__ Q, long long sV, int T, int p, int n,
-                                                              const int* __restrict__ slots, double* __restrict__ pq) {
+                                                              double* __restrict__ Q, long long sV, int T, int p,
+                                                              const int* __restrict__ slots, double* __restrict__ pqpart) {
+  constexpr int PP = PW * PW, LD = PP + 1;
+  __shared__ double Ws[64 * LD];
+  __shared__ double red[4];
+  const int pp = p * p;
+  const size_t slot = slots[blockIdx.y];
+  const int t0 = blockIdx.x * 64;
+  const int nt = min(64, T - t0);
+  const double* wbase = W + slot * sW + (size_t)t0 * pp;
+  for (int e = threadIdx.x; e < nt * pp; e += 256) {
+    const int t = e / pp, idx = e - t * pp;
+    Ws[t * LD + idx] = wbase[e];                               // block of bin t keeps its p x p layout (stride LD)
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double acc = 0.0;
+  if (lane < nt) {
+    const int t = t0 + lane;
+    const double* pv = P + slot * sV + t;
+    double* q = Q + slot * sV + t;
+    const double* wt = Ws + lane * LD;
+    double v[PW];
+#pragma unroll
+    for (int l = 0; l < PW; ++l) v[l] = (l < p) ? pv[(size_t)l * T] : 0.0;
+    for (int k = wave; k < p; k += 4) {
+      double s2 = q[(size_t)k * T];
+#pragma unroll
+      for (int l = 0; l < PW; ++l)
+        if (l < p) s2 += wt[k * p + l] * v[l];
+      q[(size_t)k * T] = s2;
+      double vk = 0.0;
+#pragma unroll
+      for (int l = 0; l < PW; ++l) vk = (l == k) ? v[l] : vk;
+      acc += s2 * vk;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+  if (lane == 0) red[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) pqpart[slot * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// The same for wide latent states (p > 16: the staged tile would not fit in LDS): block per slot, thread per bin,
+// W_t read straight from memory; one partial product per slot (ntile = 1 for the consumer).
+template <int PW>
+__global__ __launch_bounds__(256) void pcg_hessvec_dot_wide_kernel(const double* __restrict__ W, long long sW, const double* __restrict__ P,
+                                                                   double* __restrict__ Q, long long sV, int T, int p,
+                                                                   const int* __restrict__ slots, double* __restrict__ pq) {
   __shared__ double red[4];
   const size_t slot = slots[blockIdx.x];
   const double* w = W + slot * sW;
@@ -1143,12 +1193,12 @@ __global__ __launch_bounds__(256) void pcg_hessvec_dot_kernel(const double* __re
 #pragma unroll
     for (int k = 0; k < PW; ++k) {
       if (k < p) {
-        double s = q[(size_t)k * T + t];
+        double s2 = q[(size_t)k * T + t];
 #pragma unroll
         for (int l = 0; l < PW; ++l)
-          if (l < p) s += wt[k * p + l] * v[l];
-        q[(size_t)k * T + t] = s;
-        acc += s * v[k];
+          if (l < p) s2 += wt[k * p + l] * v[l];
+        q[(size_t)k * T + t] = s2;
+        acc += s2 * v[k];
       }
     }
   }
@@ -1156,15 +1206,15 @@ __global__ __launch_bounds__(256) void pcg_hessvec_dot_kernel(const double* __re
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) pq[slot] = red[0] + red[1] + red[2] + red[3];
-  (void)n;
 }
 
-// alpha = rz/pq ; x += alpha p ; r -= alpha q   (block per slot)
+// alpha = rz/pq (pq = sum of the ntile partial products) ; x += alpha p ; r -= alpha q   (block per slot)
 __global__ __launch_bounds__(256) void pcg_update_xr_kernel(double* __restrict__ X, double* __restrict__ R, const double* __restrict__ P,
                                                             const double* __restrict__ Q, long long sV, int n, const int* __restrict__ slots,
-                                                            const double* __restrict__ rz, const double* __restrict__ pq) {
+                                                            const double* __restrict__ rz, const double* __restrict__ pqpart, int ntile) {
   const size_t slot = slots[blockIdx.x];
-  const double d = pq[slot];
+  double d = 0.0;
+  for (int i = 0; i < ntile; ++i) d += pqpart[slot * ntile + i];
   const double alpha = (d > 0.0) ? rz[slot] / d : 0.0;
   for (int i = threadIdx.x; i < n; i += 256) {
     X[slot * sV + i] += alpha * P[slot * sV + i];

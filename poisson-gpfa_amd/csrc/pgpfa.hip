@@ -465,7 +465,7 @@ int ensure_workspace(pgpfa_ctx* c, bool plan_lr) {
   CHK(dmalloc(c, &c->sDinvT, ld * NB + 256 * ld));
   CHK(dmalloc(c, &c->Wbar, (size_t)c->T * c->p * c->p));
   CHK(dmalloc(c, &c->Gbin, (size_t)c->T * c->p * c->p * nB));
-  CHK(dmalloc(c, &c->sc_rz, nB)); CHK(dmalloc(c, &c->sc_pq, nB)); CHK(dmalloc(c, &c->sc_rr, nB)); CHK(dmalloc(c, &c->sc_rr0, nB));
+  CHK(dmalloc(c, &c->sc_rz, nB)); CHK(dmalloc(c, &c->sc_pq, nB * (size_t)((c->T + 63) / 64))); CHK(dmalloc(c, &c->sc_rr, nB)); CHK(dmalloc(c, &c->sc_rr0, nB));
   const size_t wlen = (size_t)c->T * c->p * c->p;
   CHK(dmalloc(c, &c->W, wlen * nB)); CHK(dmalloc(c, &c->Wt, wlen * nB));
   CHK(dmalloc(c, &c->fpart, (size_t)((c->T + 63) / 64) * nB));
@@ -1437,11 +1437,20 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
         int done_inner = 0;
         for (int it = 0; it < c->pcg_inner_max; ++it) {
           CHK(prior_mv_all(c, nb, c->Pv, c->Qv));
+          int pq_tiles = 1;
           dispatch_pw(p, [&](auto pw) {
-            hipLaunchKernelGGL(pcg_hessvec_dot_kernel<decltype(pw)::value>, dim3(na), dim3(256), 0, c->st, c->W, (long long)T * p * p, c->Pv, c->Qv,
-                               ld, T, p, nvec, c->list_a, c->sc_pq);
+            constexpr int PW = decltype(pw)::value;
+            if constexpr (PW <= 16) {
+              pq_tiles = (T + 63) / 64;
+              hipLaunchKernelGGL(pcg_hessvec_dot_kernel<PW>, dim3(pq_tiles, na), dim3(256), 0, c->st, c->W, (long long)T * p * p, c->Pv,
+                                 c->Qv, ld, T, p, c->list_a, c->sc_pq);
+            } else {
+              hipLaunchKernelGGL(pcg_hessvec_dot_wide_kernel<PW>, dim3(na), dim3(256), 0, c->st, c->W, (long long)T * p * p, c->Pv, c->Qv, ld,
+                                 T, p, c->list_a, c->sc_pq);
+            }
           });
-          hipLaunchKernelGGL(pcg_update_xr_kernel, dim3(na), dim3(256), 0, c->st, c->Dl, c->Rv, c->Pv, c->Qv, ld, nvec, c->list_a, c->sc_rz, c->sc_pq);
+          hipLaunchKernelGGL(pcg_update_xr_kernel, dim3(na), dim3(256), 0, c->st, c->Dl, c->Rv, c->Pv, c->Qv, ld, nvec, c->list_a, c->sc_rz, c->sc_pq,
+                             pq_tiles);
           CHK(shared_solve(c, nb, c->Rv, c->Zv));
           hipLaunchKernelGGL(pcg_update_p_kernel, dim3(na), dim3(256), 0, c->st, c->Rv, c->Zv, c->Pv, ld, nvec, c->list_a, c->sc_rz, c->sc_rr, 0);
           done_inner = it + 1;

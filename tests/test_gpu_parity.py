@@ -580,6 +580,18 @@ def test_wide_latent_dimensions(p):
         for k in (0, p - 1):
             assert abs(cb[k] - orc.tau_cost(logp[k], P_ref[k], R)) <= 1e-9 * abs(cb[k])
             assert abs(gb[k] - orc.tau_grad(logp[k], P_ref[k], R)[0]) <= 1e-7 * max(1.0, abs(gb[k]))
+        # the shared-preconditioner PCG path at this width (tiny batches skip it by default)
+        ctx2 = _hip.Context(q, p, T, R, 10.0)
+        try:
+            ctx2.upload_counts(Y)
+            ctx2.set_option('shared_min', 1)
+            ctx2.set_params(par['C'], par['d'], par['tau'])
+            obj2, _, status2 = ctx2.estep_laplace()
+            assert np.all(status2 == 0) and ctx2.info('last_pcg_iterations') > 0
+            assert abs(obj2 - obj) <= 1e-10 * abs(obj)
+            assert np.max(np.abs(ctx2.post_mean() - np.stack(res['post_mean']))) <= 1e-8
+        finally:
+            ctx2.close()
         if p <= 12:
             cost_n, delta, dec = ctx.mstep_cd_newton_pass(v)
             assert abs(cost_n.sum() - cost) <= 1e-10 * abs(cost) and np.all(dec >= 0)
