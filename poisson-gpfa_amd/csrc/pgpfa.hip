@@ -1359,7 +1359,7 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
       }
     }
     // objective, gradient pieces and curvature blocks at the start point
-    CHK(prior_mv(c, c->ident, nb, c->Xc, c->KX));
+    CHK(prior_mv_all(c, nb, c->Xc, c->KX));
     hipLaunchKernelGGL(dots3_kernel, dim3(nb), dim3(256), 0, c->st, c->Xc, ld, c->KX, ld, (const double*)nullptr, 0LL,
                        (const double*)nullptr, 0LL, nvec, c->ident, c->sc_qxx, c->sc_qdx, c->sc_qdd);
     CHK(poisson(c, c->ident, nb, c->Xc, c->Gl, c->W, c->sc_f, 1));
@@ -2080,7 +2080,20 @@ int pgpfa_mstep_precomp(pgpfa_ctx* c, double* num_trials) {
   if (!c->have_post) return fail("no E-step result resident");
   HIPC(hipSetDevice(c->device));
   const int ntr = (int)c->last_trials_h.size();
-  if (c->pacc_valid) {
+  bool contiguous = ntr > 0 && ntr % 16 == 0;
+  for (int i = 1; i < ntr && contiguous; ++i) contiguous = (c->last_trials_h[i] == c->last_trials_h[0] + i);
+  if (c->pacc_valid && contiguous) {
+    // PautoSum[k] = Pacc[k] + M_k M_k^T with M_k = [m_rk]_r (T x ntr, the trials' mean rows side by side in Xmode): one GEMM
+    const size_t len = (size_t)c->Tp * c->Tp * c->p;
+    HIPC(hipMemcpyAsync(c->Pauto, c->Pacc, len * sizeof(double), hipMemcpyDeviceToDevice, c->st));
+    GemmP g{};
+    g.A = c->Xmode + (size_t)c->last_trials_h[0] * c->n; g.sA = c->T; g.lda = c->n;
+    g.B = g.A; g.sB = c->T; g.ldb = c->n;
+    g.C = c->Pauto; g.sC = (long long)c->Tp * c->Tp; g.ldc = c->Tp;
+    g.M = c->T; g.N = c->T; g.K = ntr; g.alpha = 1.0; g.beta = 1.0;
+    g.slots = nullptr; g.nbatch = c->p; g.mode = GEMM_FULL; g.kflags = 0;
+    CHK(gemm(c, false, g));
+  } else if (c->pacc_valid) {
     hipLaunchKernelGGL(pauto_from_acc_kernel, dim3(c->Tp, c->p), dim3(128), 0, c->st, c->Pacc, c->Xmode, c->last_trials, ntr, c->T, c->Tp, c->p,
                        c->Pauto);
   } else {

@@ -419,7 +419,7 @@ def test_lowrank_plan_dense_retry(c1):
         ctx.close()
 
 
-@pytest.mark.parametrize('R_use', [20, 7])
+@pytest.mark.parametrize('R_use', [20, 7, 16])
 def test_sum_only_covariance_output_matches_per_trial_blocks(c1, R_use):
     """keep_trial_vsmgp = 0 (default): the low-rank engine accumulates sum_r post_vsmGP_r inside the E-step (split-K
     product over the slots) and rebuilds per-trial blocks on request - also after the parameters have moved on."""
