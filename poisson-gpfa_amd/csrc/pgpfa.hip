@@ -119,7 +119,7 @@ struct pgpfa_ctx {
   CholWS sws{};
   double *sU = nullptr, *sDinvT = nullptr, *Wbar = nullptr;
   double *Rv = nullptr, *Zv = nullptr, *Pv = nullptr, *Qv = nullptr;
-  double *sc_rz = nullptr, *sc_pq = nullptr, *sc_rr = nullptr, *sc_rr0 = nullptr;
+  double *sc_rz = nullptr, *sc_pq = nullptr, *sc_rr = nullptr, *sc_rr0 = nullptr, *sc_pack = nullptr;
   // low-rank covariance engine
   double* Flr = nullptr;                          // [p][Tp x Tp] pivoted-Cholesky factors of the RBF part
   double* Gbin = nullptr;                         // [B][T][p][p]
@@ -465,12 +465,15 @@ int ensure_workspace(pgpfa_ctx* c, bool plan_lr) {
   CHK(dmalloc(c, &c->sDinvT, ld * NB + 256 * ld));
   CHK(dmalloc(c, &c->Wbar, (size_t)c->T * c->p * c->p));
   CHK(dmalloc(c, &c->Gbin, (size_t)c->T * c->p * c->p * nB));
-  CHK(dmalloc(c, &c->sc_rz, nB)); CHK(dmalloc(c, &c->sc_pq, nB * (size_t)((c->T + 63) / 64))); CHK(dmalloc(c, &c->sc_rr, nB)); CHK(dmalloc(c, &c->sc_rr0, nB));
+  CHK(dmalloc(c, &c->sc_rz, nB)); CHK(dmalloc(c, &c->sc_pq, nB * (size_t)((c->T + 63) / 64)));
+  // per-slot scalars the Newton drivers read back together: one contiguous block, one download
+  CHK(dmalloc(c, &c->sc_pack, 7 * nB));
+  c->sc_dec = c->sc_pack; c->sc_smax = c->sc_pack + nB; c->sc_qxx = c->sc_pack + 2 * nB; c->sc_qdx = c->sc_pack + 3 * nB;
+  c->sc_qdd = c->sc_pack + 4 * nB; c->sc_rr = c->sc_pack + 5 * nB; c->sc_rr0 = c->sc_pack + 6 * nB;
   const size_t wlen = (size_t)c->T * c->p * c->p;
   CHK(dmalloc(c, &c->W, wlen * nB)); CHK(dmalloc(c, &c->Wt, wlen * nB));
   CHK(dmalloc(c, &c->fpart, (size_t)((c->T + 63) / 64) * nB));
-  CHK(dmalloc(c, &c->sc_f, nB)); CHK(dmalloc(c, &c->sc_qxx, nB)); CHK(dmalloc(c, &c->sc_qdx, nB));
-  CHK(dmalloc(c, &c->sc_qdd, nB)); CHK(dmalloc(c, &c->sc_dec, nB)); CHK(dmalloc(c, &c->sc_smax, nB));
+  CHK(dmalloc(c, &c->sc_f, nB));
   CHK(dmalloc(c, &c->sc_alpha, nB));
   CHK(dmalloc(c, &c->trial_of_slot, nB)); CHK(dmalloc(c, &c->list_a, nB)); CHK(dmalloc(c, &c->list_b, nB));
   CHK(dmalloc(c, &c->mask_of_slot, nB));
@@ -1468,13 +1471,18 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
         hipLaunchKernelGGL(dots3_kernel, dim3(na), dim3(256), 0, c->st, c->Xc, ld, c->KX, ld, c->Dl, ld, c->KD, ld, nvec, c->list_a, c->sc_qxx,
                            c->sc_qdx, c->sc_qdd);
         HIPC(hipGetLastError());
-        CHK(download(c, dec.data(), c->sc_dec, nb));
-        CHK(download(c, smax.data(), c->sc_smax, nb));
-        CHK(download(c, qxx.data(), c->sc_qxx, nb));
-        CHK(download(c, qdx.data(), c->sc_qdx, nb));
-        CHK(download(c, qdd.data(), c->sc_qdd, nb));
-        CHK(download(c, rr.data(), c->sc_rr, nb));
-        CHK(download(c, rr0.data(), c->sc_rr0, nb));
+        {
+          const size_t nB = (size_t)c->B;
+          std::vector<double> pack(7 * nB);
+          CHK(download(c, pack.data(), c->sc_pack, 7 * nB));
+          std::copy(pack.begin(), pack.begin() + nb, dec.begin());
+          std::copy(pack.begin() + nB, pack.begin() + nB + nb, smax.begin());
+          std::copy(pack.begin() + 2 * nB, pack.begin() + 2 * nB + nb, qxx.begin());
+          std::copy(pack.begin() + 3 * nB, pack.begin() + 3 * nB + nb, qdx.begin());
+          std::copy(pack.begin() + 4 * nB, pack.begin() + 4 * nB + nb, qdd.begin());
+          std::copy(pack.begin() + 5 * nB, pack.begin() + 5 * nB + nb, rr.begin());
+          std::copy(pack.begin() + 6 * nB, pack.begin() + 6 * nB + nb, rr0.begin());
+        }
         std::vector<int> cand, next, failed;
         for (int s : active) {
           if (!(dec[s] > 0.0) || !std::isfinite(dec[s]) || !std::isfinite(smax[s])) continue;   // leave to the fallback
