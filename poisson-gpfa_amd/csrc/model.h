@@ -795,15 +795,24 @@ __global__ __launch_bounds__(64 * CD_KY) void mstep_cd_kernel(CdArgs a) {
     }
     __syncthreads();
     for (int t = ty; t < tn; t += CD_KY) {
+      // u = V_t c from the lower triangle only (V_t is symmetric): p(p+1)/2 LDS reads instead of p^2
       double u[PW];
       double hh = dn, rho = 0.0;
 #pragma unroll
-      for (int k = 0; k < PW; ++k) {
-        double s = 0.0;
+      for (int k = 0; k < PW; ++k) u[k] = 0.0;
 #pragma unroll
-        for (int l = 0; l < PW; ++l) s += Vt[t][k * PW + l] * c[l];
-        u[k] = s;
-        rho += c[k] * s;
+      for (int k = 0; k < PW; ++k) {
+#pragma unroll
+        for (int l = 0; l < k; ++l) {
+          const double v = Vt[t][k * PW + l];
+          u[k] += v * c[l];
+          u[l] += v * c[k];
+        }
+        u[k] += Vt[t][k * PW + k] * c[k];
+      }
+#pragma unroll
+      for (int k = 0; k < PW; ++k) {
+        rho += c[k] * u[k];
         hh += c[k] * Mt[k][t];
       }
       const double yh = exp(hh + 0.5 * rho);
@@ -899,15 +908,25 @@ __global__ __launch_bounds__(64 * CDH_KY) void mstep_cd_hess_kernel(CdArgs a) {
     for (int t = ty; t < tn; t += CDH_KY) {
       double w[D];
       double hh = dn, rho = 0.0;
+      // u = V_t c from the lower triangle only (V_t symmetric), accumulated in w
+#pragma unroll
+      for (int k = 0; k < PW; ++k) w[k] = 0.0;
 #pragma unroll
       for (int k = 0; k < PW; ++k) {
-        double s = 0.0;
 #pragma unroll
-        for (int l = 0; l < PW; ++l) s += Vt[t][k * PW + l] * c[l];
-        rho += c[k] * s;
+        for (int l = 0; l < k; ++l) {
+          const double v = Vt[t][k * PW + l];
+          w[k] += v * c[l];
+          w[l] += v * c[k];
+        }
+        w[k] += Vt[t][k * PW + k] * c[k];
+      }
+#pragma unroll
+      for (int k = 0; k < PW; ++k) {
+        rho += c[k] * w[k];
         const double mk = Mt[k][t];
         hh += c[k] * mk;
-        w[k] = mk + s;
+        w[k] += mk;
       }
       w[PW] = 1.0;
       const double yh = exp(hh + 0.5 * rho);
