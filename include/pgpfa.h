@@ -142,6 +142,10 @@ int pgpfa_loo_predict(pgpfa_ctx* ctx, int n, const int32_t* idx, double* y_pred 
  * C_big or diag(lambda)). */
 int pgpfa_dual_costgrad(pgpfa_ctx* ctx, int trial, const double* lam, double* cost,
                         double* grad /* [q*T] or NULL */);
+/* The same for a list of distinct trials at once, each at its own lambda: lam[n][q*T] -> cost[n], grad[n][q*T]
+ * (or NULL).  The dense factorisations of a chunk of trials are batched; inference.dualVariational drives the
+ * reference's per-trial L-BFGS-B runs concurrently so that one round of their requests is one call. */
+int pgpfa_dual_costgrad_batch(pgpfa_ctx* ctx, int n, const int32_t* idx, const double* lam, double* cost, double* grad);
 /* VIPostMean / VIPostCov blocks at lambda for the listed trials; fills the same posterior
  * slots as the Laplace E-step and returns sum of negLogPosteriorUnNorm at the VI mean. */
 int pgpfa_dual_finalize(pgpfa_ctx* ctx, int n, const int32_t* idx, const double* lam /* [n][q*T] */,

@@ -1121,6 +1121,29 @@ __global__ void dual_grad_kernel(const double* __restrict__ C, const double* __r
   grad[(size_t)n * T + t] = lin - d[n] + log(lam[(size_t)n * T + t]) - 0.5 * quad;
 }
 
+// the same for the slots [0, nslots) at once: grid = (ceil(T/64), q, nslots); lam / grad are [slot][q*T], KV [slot][ld],
+// the per-bin blocks Sigma_t of slot s sit in vsm[trial_of_slot[s]]
+__global__ void dual_grad_batch_kernel(const double* __restrict__ C, const double* __restrict__ d, const double* __restrict__ lam,
+                                       const double* __restrict__ KV, long long sKV, const double* __restrict__ vsm,
+                                       const int* __restrict__ trial_of_slot, double* __restrict__ grad, int q, int p, int T) {
+  const int t = blockIdx.x * 64 + threadIdx.x;
+  const int n = blockIdx.y;
+  const size_t slot = blockIdx.z;
+  if (t >= T) return;
+  const double* S = vsm + ((size_t)trial_of_slot[slot] * T + t) * p * p;
+  const double* Cn = C + (size_t)n * p;
+  const double* kv = KV + slot * sKV;
+  double lin = 0.0, quad = 0.0;
+  for (int k = 0; k < p; ++k) {
+    lin += Cn[k] * kv[(size_t)k * T + t];
+    double u = 0.0;
+    for (int l = 0; l < p; ++l) u += S[k * p + l] * Cn[l];
+    quad += Cn[k] * u;
+  }
+  const size_t e = slot * (size_t)q * T + (size_t)n * T + t;
+  grad[e] = lin - d[n] + log(lam[e]) - 0.5 * quad;
+}
+
 // x = -Kv  (VIPostMean, inference.py:193-194)
 __global__ void negate_rows_kernel(const double* __restrict__ src, long long sSrc, double* __restrict__ dst, long long sDst, int n,
                                    const int* __restrict__ slots) {

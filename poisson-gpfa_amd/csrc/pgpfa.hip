@@ -2248,7 +2248,7 @@ int pgpfa_mstep_tau_costgrad_batch(pgpfa_ctx* c, const double* logp, double* cos
 static int ensure_lambda(pgpfa_ctx* c) {
   if (c->lamd) return 0;
   CHK(dmalloc(c, &c->lamd, (size_t)c->B * c->q * c->T));
-  CHK(dmalloc(c, &c->dgrad, (size_t)c->q * c->T));
+  CHK(dmalloc(c, &c->dgrad, (size_t)c->B * c->q * c->T));
   CHK(dmalloc(c, &c->dpart, (size_t)c->B * ((c->T + 63) / 64) * 2 + 16));
   return 0;
 }
@@ -2314,6 +2314,60 @@ int pgpfa_dual_costgrad(pgpfa_ctx* c, int trial, const double* lam, double* cost
                        c->vsm + (size_t)trial * T * p * p, c->dgrad, q, p, T);
     HIPC(hipGetLastError());
     CHK(download(c, grad, c->dgrad, (size_t)q * T));
+  }
+  return 0;
+}
+
+// dualProblem / dualProblem_grad for a LIST of trials at once (each trial at its own lambda): the same arithmetic as
+// pgpfa_dual_costgrad, with the dense factorisations of a chunk of trials batched.  The per-trial scipy L-BFGS-B runs of
+// inference.dualVariational are driven concurrently so that one round of their requests is one call of this.
+int pgpfa_dual_costgrad_batch(pgpfa_ctx* c, int n, const int32_t* idx, const double* lam, double* cost, double* grad) {
+  CHK(ready(c));
+  if (!lam || !cost) return fail("null argument");
+  CHK(ensure_lambda(c));
+  Trials tr;
+  CHK(resolve_trials(c, n, idx, &tr));
+  const int N = (int)tr.v.size();
+  const int q = c->q, p = c->p, T = c->T;
+  const size_t m = (size_t)q * T;
+  for (size_t i = 0; i < (size_t)N * m; ++i)
+    if (!(lam[i] > 0.0)) return fail("lambda must be positive (trial %d, entry %zu = %g)", tr.v[i / m], i % m, lam[i]);
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < i; ++j)
+      if (tr.v[i] == tr.v[j]) return fail("trial %d listed twice (the per-trial covariance blocks are scratch space of this call)", tr.v[i]);
+  std::vector<double> logdet(c->B);
+  std::vector<int> info(c->B);
+  for (int c0 = 0; c0 < N; c0 += c->B) {
+    const int nb = std::min(c->B, N - c0);
+    std::vector<int> tos(tr.v.begin() + c0, tr.v.begin() + c0 + nb);
+    CHK(upload_list(c, c->trial_of_slot, tos));
+    CHK(upload(c, c->lamd, lam + (size_t)c0 * m, (size_t)nb * m));
+    std::vector<double> sB, sD, vKv;
+    CHK(dual_common(c, nb, &sB, &sD, &vKv));
+    HIPC(hipMemsetAsync(c->ws.info, 0, sizeof(int) * nb, c->st));
+    CHK(ensure_mt_clean(c));
+    CHK(assemble(c, c->ident, nb, 1.0 + 1e-6));                         // inference.py:190
+    CHK(factor(c, c->ws, c->ident, nb));
+    hipLaunchKernelGGL(logdet_batch_kernel, dim3(nb), dim3(256), 0, c->st, c->ws.H, (long long)c->ws.sH, c->ld, c->npad, c->sc_f);
+    CHK(download(c, logdet.data(), c->sc_f, nb));
+    HIPC(hipMemcpyAsync(info.data(), c->ws.info, sizeof(int) * nb, hipMemcpyDeviceToHost, c->st));
+    HIPC(hipStreamSynchronize(c->st));
+    for (int s2 = 0; s2 < nb; ++s2) {
+      if (info[s2] != 0) return fail("dual problem: posterior precision of trial %d not positive definite (pivot %d)", tos[s2], info[s2]);
+      cost[c0 + s2] = 0.5 * vKv[s2] - sB[s2] - 0.5 * logdet[s2] + sD[s2];
+    }
+    if (grad) {
+      CHK(inverse_t(c, c->ws, c->ident, nb));
+      const int KY = std::min(p, 16);
+      dispatch_pmax(p, [&](auto pm) {
+        hipLaunchKernelGGL(post_vsm_kernel<decltype(pm)::value>, dim3((T + 63) / 64, nb), dim3(64, KY), 0, c->st, c->ws.Mt, c->ws.sM, c->ld, c->npad,
+                           T, p, c->vsm, c->ident, c->trial_of_slot, 0);
+      });
+      hipLaunchKernelGGL(dual_grad_batch_kernel, dim3((T + 63) / 64, q, nb), dim3(64), 0, c->st, c->C, c->d, c->lamd, c->KD, (long long)c->ld, c->vsm,
+                         c->trial_of_slot, c->dgrad, q, p, T);
+      HIPC(hipGetLastError());
+      CHK(download(c, grad + (size_t)c0 * m, c->dgrad, (size_t)nb * m));
+    }
   }
   return 0;
 }

@@ -51,6 +51,7 @@ _SIGNATURES = {
     'pgpfa_loo_predict': [ct.c_void_p, ct.c_int, c_int32_p, c_double_p, c_double_p],
     'pgpfa_count_moments': [ct.c_void_p, ct.c_int, c_int32_p, c_int64_p, c_int64_p, c_int64_p],
     'pgpfa_dual_costgrad': [ct.c_void_p, ct.c_int, c_double_p, c_double_p, c_double_p],
+    'pgpfa_dual_costgrad_batch': [ct.c_void_p, ct.c_int, c_int32_p, c_double_p, c_double_p, c_double_p],
     'pgpfa_dual_finalize': [ct.c_void_p, ct.c_int, c_int32_p, c_double_p, c_double_p],
     'pgpfa_comm_unique_id': [ct.c_char_p],
     'pgpfa_comm_init': [ct.c_void_p, ct.c_char_p, ct.c_int, ct.c_int],
@@ -269,6 +270,15 @@ class Context:
         grad = np.empty(self.q * self.T) if want_grad else None
         check(self.lib.pgpfa_dual_costgrad(self.h, int(trial), dptr(lam), ct.byref(cost), dptr(grad) if want_grad else None))
         return cost.value, grad
+
+    def dual_costgrad_batch(self, idx, lam, want_grad=True):
+        """Dual cost (and gradient) of the listed distinct trials, each at its own lambda: lam[n][q*T] -> cost[n], grad[n][q*T]."""
+        n, ii = self._n_idx(idx)
+        lam = as_f64(lam).reshape(n, self.q * self.T)
+        cost = np.empty(n)
+        grad = np.empty((n, self.q * self.T)) if want_grad else None
+        check(self.lib.pgpfa_dual_costgrad_batch(self.h, n, iptr(ii), dptr(lam), dptr(cost), dptr(grad) if want_grad else None))
+        return cost, grad
 
     def dual_finalize(self, idx, lam):
         n, ii = self._n_idx(idx)

@@ -100,6 +100,80 @@ def laplace_hessian(experiment, params, X, trial=0):
     return sess.ctx.laplace_hessian(int(trial_idx[trial]), X)
 
 
+class _ConcurrentProblems:
+    """n independent optimisations, one Python thread each, whose cost/gradient requests are gathered into one batched
+    device evaluation per round.  Every optimiser sees exactly the call sequence it would see running alone."""
+
+    def __init__(self, n, evaluate_batch):
+        import threading
+        self._threading = threading
+        self.n = n
+        self.evaluate_batch = evaluate_batch          # (positions, [x...]) -> [(cost, grad)...]
+        self.cond = threading.Condition()
+        self.pending, self.results = {}, {}
+        self.active = set(range(n))
+        self.generation = 0
+        self.error = None
+        self.rounds = 0
+
+    def _flush(self):                                 # lock held by the caller
+        which = sorted(self.pending)
+        try:
+            res = self.evaluate_batch(which, [self.pending[i] for i in which])
+            self.results = dict(zip(which, res))
+        except Exception as exc:                      # hand the failure to every waiting optimiser
+            self.error = exc
+            self.results = {}
+        self.pending = {}
+        self.rounds += 1
+        self.generation += 1
+        self.cond.notify_all()
+
+    def request(self, idx, x):
+        with self.cond:
+            self.pending[idx] = x
+            gen = self.generation
+            if len(self.pending) == len(self.active):
+                self._flush()
+            else:
+                while self.generation == gen:
+                    self.cond.wait()
+            if self.error is not None:
+                raise self.error
+            return self.results[idx]
+
+    def run(self, solve_one):
+        out = [None] * self.n
+
+        def worker(idx):
+            try:
+                out[idx] = solve_one(idx, lambda x: self.request(idx, x))
+            except Exception as exc:
+                out[idx] = exc
+            finally:
+                with self.cond:
+                    self.active.discard(idx)
+                    if self.pending and len(self.pending) == len(self.active):
+                        self._flush()
+        import sys
+        threads = [self._threading.Thread(target=worker, args=(i,)) for i in range(self.n)]
+        # many runnable threads hand the interpreter lock around once per switch interval (5 ms by default): with dozens of
+        # optimisers that, not the device, would set the time of a round
+        interval = sys.getswitchinterval()
+        sys.setswitchinterval(1e-4)
+        try:
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+        finally:
+            sys.setswitchinterval(interval)
+        for r in out:
+            if isinstance(r, Exception):
+                raise r
+        return out
+
+
 def dualVariational(experiment, params, optimizeLogLambda=False, prevOptimRes=None, returnOptimRes=True, verbose=False):
     """Dual variational E-step (reference inference.py:259-432).
 
@@ -118,34 +192,45 @@ def dualVariational(experiment, params, optimizeLogLambda=False, prevOptimRes=No
     mine = trial_idx[lo:hi]
     m = sess.q * sess.T
     ctx = sess.ctx
-    lams, optim, vlb = [], [], 0.0
-    for j, trial in enumerate(mine):
+    # The reference solves the trials one after the other (inference.py:300-397), each with its own scipy L-BFGS-B run.
+    # Here every trial still gets exactly that run (same calls, same options, same start), but the runs execute
+    # concurrently - one Python thread per trial - and each round of their cost/gradient requests is served by ONE
+    # batched device evaluation (pgpfa_dual_costgrad_batch), instead of one dense factorisation at a time.
+    starts = []
+    for j in range(len(mine)):
+        if prevOptimRes is None:
+            starts.append(np.zeros(m) if optimizeLogLambda else np.zeros(m) + 0.5)
+        else:
+            starts.append(np.asarray(prevOptimRes[j] if len(prevOptimRes) == len(mine) else prevOptimRes[lo + j], dtype=np.float64))
+
+    def evaluate_batch(which, xs):
+        """which: positions in `mine`; xs: their optimiser variables -> list of (cost, grad in the optimiser's variable)"""
+        X = np.stack(xs)
+        lam = np.exp(X) if optimizeLogLambda else X
+        cost, grad = ctx.dual_costgrad_batch(mine[np.asarray(which)], lam)
+        if optimizeLogLambda:
+            grad = grad * lam
+        return [(float(cost[i]), grad[i]) for i in range(len(which))]
+
+    def solve_one(j, evaluate):
         if verbose:
             print('dual variational inference trajectory of trial %d...' % (lo + j + 1))
-        if prevOptimRes is None:
-            x0 = np.zeros(m) if optimizeLogLambda else np.zeros(m) + 0.5
-        else:
-            x0 = np.asarray(prevOptimRes[j] if len(prevOptimRes) == len(mine) else prevOptimRes[lo + j], dtype=np.float64)
         cache = {}
 
-        def evaluate(x, trial=int(trial)):
+        def cached(x):
             key = x.tobytes()
             if cache.get('k') != key:
-                lam = np.exp(x) if optimizeLogLambda else x
-                cost, grad = ctx.dual_costgrad(trial, lam)
-                cache['k'], cache['v'] = key, (cost, grad * lam if optimizeLogLambda else grad)
+                cache['k'], cache['v'] = key, evaluate(np.array(x, dtype=np.float64))
             return cache['v']
-
         if optimizeLogLambda:
-            out = op.fmin_l_bfgs_b(func=lambda x: evaluate(x)[0], x0=x0, fprime=lambda x: evaluate(x)[1], disp=False)
-            lam = np.exp(out[0])
-        else:
-            out = op.fmin_l_bfgs_b(func=lambda x: evaluate(x)[0], x0=x0, fprime=lambda x: evaluate(x)[1], approx_grad=False,
-                                   bounds=[(1e-10, None)] * m, factr=1e7, disp=False)
-            lam = out[0]
-        optim.append(out[0])
-        lams.append(lam)
-        vlb += out[1]
+            return op.fmin_l_bfgs_b(func=lambda x: cached(x)[0], x0=starts[j], fprime=lambda x: cached(x)[1], disp=False)
+        return op.fmin_l_bfgs_b(func=lambda x: cached(x)[0], x0=starts[j], fprime=lambda x: cached(x)[1], approx_grad=False,
+                                bounds=[(1e-10, None)] * m, factr=1e7, disp=False)
+
+    outs = _ConcurrentProblems(len(mine), evaluate_batch).run(solve_one) if len(mine) else []
+    optim = [out[0] for out in outs]
+    lams = [np.exp(out[0]) if optimizeLogLambda else out[0] for out in outs]
+    vlb = float(sum(out[1] for out in outs))
     nlp = ctx.dual_finalize(mine, np.stack(lams)) if len(mine) else 0.0
     sess.post_stamp += 1
     sess.mode_stamp += 1

@@ -465,11 +465,19 @@ class _ConcurrentScalarProblems:
                     self.active.discard(idx)
                     if self.pending and len(self.pending) == len(self.active):
                         self._flush()
+        import sys
         threads = [self._threading.Thread(target=worker, args=(i,)) for i in range(self.x.size)]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
+        # many runnable threads hand the interpreter lock around once per switch interval (5 ms by default): with dozens of
+        # optimisers that, not the device, would set the time of a round
+        interval = sys.getswitchinterval()
+        sys.setswitchinterval(1e-4)
+        try:
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+        finally:
+            sys.setswitchinterval(interval)
         for r in out:
             if isinstance(r, Exception):
                 raise r

@@ -245,6 +245,18 @@ def test_dual_variational_vs_reference(funs_mod):
         cost, grad = ctx.dual_costgrad(0, g['lam_probe'])
         assert abs(cost - float(g['dual_cost'])) <= 1e-9 * abs(float(g['dual_cost']))
         assert rel(grad, g['dual_grad']) <= 1e-9
+        # several trials at once, each at its own lambda == one call per trial
+        rng = np.random.default_rng(2)
+        idx = np.array([3, 0, 7], dtype=np.int32)
+        lam = 0.2 + rng.random((3, 20 * 50))
+        lam[1] = g['lam_probe']
+        cb, gb = ctx.dual_costgrad_batch(idx, lam)
+        for i, tr in enumerate(idx):
+            c1_, g1_ = ctx.dual_costgrad(int(tr), lam[i])
+            assert abs(cb[i] - c1_) <= 1e-12 * abs(c1_) and rel(gb[i], g1_) <= 1e-11
+        assert abs(cb[1] - float(g['dual_cost'])) <= 1e-9 * abs(float(g['dual_cost']))
+        with pytest.raises(_hip.HipBackendError):
+            ctx.dual_costgrad_batch(np.array([1, 1], dtype=np.int32), lam[:2])
     finally:
         ctx.close()
     infRes, nll, vlb, opt = funs_mod.inference.dualVariational(exp, params)

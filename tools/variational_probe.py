@@ -1,0 +1,36 @@
+"""Dual-variational E-step at config-2 dimensions: the per-trial scipy L-BFGS-B runs driven concurrently (batched device
+evaluations) vs the same runs one trial at a time."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'poisson-gpfa_amd')); sys.path.insert(0, ROOT)
+import numpy as np
+import scipy.optimize as op
+import bench, funs
+from funs import _session
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+q, p, T, _ = bench.CONFIGS['c2']
+true_params, Ys = bench.synth_shard(q, p, T, R, 12, 0)
+exp = bench.Shard(Ys, 10.0)
+params = {k: np.asarray(v, dtype=np.float64) for k, v in true_params.items()}
+params['tau'] = np.linspace(0.1, 0.5, p)
+sess, idx = _session.session_for(exp, p)
+sess.set_params(params)
+funs.inference.dualVariational(bench.Shard(Ys[:2], 10.0), params)            # warm-up
+t0 = time.time()
+infRes, nll, vlb, opt = funs.inference.dualVariational(exp, params)
+t_conc = time.time() - t0
+print('concurrent: %d trials in %.2f s  (nll %.4f, vlb %.4f)' % (R, t_conc, nll, vlb))
+# one trial at a time (what the driver did before): first 4 trials, scaled
+m = q * T
+ctx = sess.ctx
+t0 = time.time()
+nev = 0
+for tr in range(4):
+    def f(x, tr=tr):
+        global nev
+        nev += 1
+        return ctx.dual_costgrad(tr, x)
+    op.fmin_l_bfgs_b(func=lambda x: f(x)[0], x0=np.zeros(m) + 0.5, fprime=lambda x: f(x)[1], bounds=[(1e-10, None)] * m, factr=1e7, disp=False)
+t_ser = (time.time() - t0) / 4
+print('serial: %.2f s per trial (%d evaluations each, counting cost and gradient calls) -> %.1f s for %d trials; speed-up %.1fx'
+      % (t_ser, nev // 4, t_ser * R, R, t_ser * R / t_conc))
