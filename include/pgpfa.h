@@ -146,6 +146,13 @@ int pgpfa_dual_costgrad(pgpfa_ctx* ctx, int trial, const double* lam, double* co
  * (or NULL).  The dense factorisations of a chunk of trials are batched; inference.dualVariational drives the
  * reference's per-trial L-BFGS-B runs concurrently so that one round of their requests is one call. */
 int pgpfa_dual_costgrad_batch(pgpfa_ctx* ctx, int n, const int32_t* idx, const double* lam, double* cost, double* grad);
+/* The whole dual optimisation of the listed distinct trials on the device: one L-BFGS run (10 correction pairs, Armijo
+ * backtracking) per trial in rho = log(lambda) - the unconstrained form of the reference's optimizeLogLambda path
+ * (inference.py:222-256, 391-396) - all runs of a chunk in lockstep, every iteration one batched dual evaluation.
+ * Stops per trial on scipy's L-BFGS-B criteria (relative decrease <= factr * 2.2e-16, or max |gradient| <= pgtol).
+ * rho[n][q*T]: start in, optimum out; fopt[n]: dual optimum (inference.py:325/397); iters[n] may be NULL. */
+int pgpfa_dual_lbfgs(pgpfa_ctx* ctx, int n, const int32_t* idx, double* rho, int max_iter, double factr, double pgtol,
+                     double* fopt, int32_t* iters);
 /* VIPostMean / VIPostCov blocks at lambda for the listed trials; fills the same posterior
  * slots as the Laplace E-step and returns sum of negLogPosteriorUnNorm at the VI mean. */
 int pgpfa_dual_finalize(pgpfa_ctx* ctx, int n, const int32_t* idx, const double* lam /* [n][q*T] */,

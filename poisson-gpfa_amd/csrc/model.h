@@ -1144,6 +1144,78 @@ __global__ void dual_grad_batch_kernel(const double* __restrict__ C, const doubl
   grad[e] = lin - d[n] + log(lam[e]) - 0.5 * quad;
 }
 
+// ---- small batched vector kernels of the device L-BFGS (one optimisation per slot, vectors [slot][m]) ----------------
+// out[slot] = a[slot] . b[slot]; grid = nslots, block = 256 (fixed reduction tree: deterministic)
+__global__ __launch_bounds__(256) void bdot_kernel(const double* __restrict__ A, const double* __restrict__ B, size_t m, double* __restrict__ out) {
+  __shared__ double red[256];
+  const double* a = A + (size_t)blockIdx.x * m;
+  const double* b = B + (size_t)blockIdx.x * m;
+  double s = 0.0;
+  for (size_t i = threadIdx.x; i < m; i += 256) s += a[i] * b[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = red[0];
+}
+// out[slot] = max_i |a[slot][i]|
+__global__ __launch_bounds__(256) void bmaxabs_kernel(const double* __restrict__ A, size_t m, double* __restrict__ out) {
+  __shared__ double red[256];
+  const double* a = A + (size_t)blockIdx.x * m;
+  double s = 0.0;
+  for (size_t i = threadIdx.x; i < m; i += 256) s = fmax(s, fabs(a[i]));
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = red[0];
+}
+// y[slot] = beta[slot] * y[slot] + alpha[slot] * x[slot]   (beta NULL: 1); grid = (ceil(m/256), nslots)
+__global__ void baxpby_kernel(const double* __restrict__ alpha, const double* __restrict__ X, const double* __restrict__ beta,
+                              double* __restrict__ Y, size_t m) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const size_t e = (size_t)blockIdx.y * m + i;
+  Y[e] = (beta ? beta[blockIdx.y] : 1.0) * Y[e] + alpha[blockIdx.y] * X[e];
+}
+// z[slot] = x[slot] + t[slot] * d[slot]
+__global__ void bstep_kernel(const double* __restrict__ X, const double* __restrict__ D, const double* __restrict__ t, double* __restrict__ Z,
+                             size_t m) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const size_t e = (size_t)blockIdx.y * m + i;
+  Z[e] = X[e] + t[blockIdx.y] * D[e];
+}
+// dst[slot] = a[slot] - b[slot]  where take[slot] != 0 (other slots untouched)
+__global__ void bdiff_kernel(const double* __restrict__ A, const double* __restrict__ B, const int* __restrict__ take, double* __restrict__ dst,
+                             size_t m) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m || !take[blockIdx.y]) return;
+  const size_t e = (size_t)blockIdx.y * m + i;
+  dst[e] = A[e] - B[e];
+}
+// dst[slot] = src[slot] where take[slot] != 0
+__global__ void bcopy_kernel(const double* __restrict__ src, const int* __restrict__ take, double* __restrict__ dst, size_t m) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m || !take[blockIdx.y]) return;
+  const size_t e = (size_t)blockIdx.y * m + i;
+  dst[e] = src[e];
+}
+// lam = exp(rho)
+__global__ void exp_kernel(const double* __restrict__ rho, double* __restrict__ lam, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) lam[i] = exp(rho[i]);
+}
+// g_rho = g_lambda * lambda  (dualProblemRho_grad, inference.py:251-256)
+__global__ void chain_kernel(const double* __restrict__ glam, const double* __restrict__ lam, double* __restrict__ grho, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) grho[i] = glam[i] * lam[i];
+}
+
 // x = -Kv  (VIPostMean, inference.py:193-194)
 __global__ void negate_rows_kernel(const double* __restrict__ src, long long sSrc, double* __restrict__ dst, long long sDst, int n,
                                    const int* __restrict__ slots) {

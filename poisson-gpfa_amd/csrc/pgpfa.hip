@@ -2318,9 +2318,52 @@ int pgpfa_dual_costgrad(pgpfa_ctx* c, int trial, const double* lam, double* cost
   return 0;
 }
 
-// dualProblem / dualProblem_grad for a LIST of trials at once (each trial at its own lambda): the same arithmetic as
-// pgpfa_dual_costgrad, with the dense factorisations of a chunk of trials batched.  The per-trial scipy L-BFGS-B runs of
-// inference.dualVariational are driven concurrently so that one round of their requests is one call of this.
+// Dual cost (and gradient with respect to lambda, into c->dgrad) of the slots [0, nb) whose lambda is already in c->lamd and
+// whose trials are bound in c->trial_of_slot: the arithmetic of dualProblem / dualProblem_grad (inference.py:196-219) with
+// the dense factorisations of the chunk batched.
+static int dual_eval_slots(pgpfa_ctx* c, int nb, const std::vector<int>& tos, bool want_grad, double* cost) {
+  const int q = c->q, p = c->p, T = c->T;
+  std::vector<double> sB, sD, vKv, logdet(nb);
+  std::vector<int> info(nb);
+  CHK(dual_common(c, nb, &sB, &sD, &vKv));
+  HIPC(hipMemsetAsync(c->ws.info, 0, sizeof(int) * nb, c->st));
+  CHK(ensure_mt_clean(c));
+  CHK(assemble(c, c->ident, nb, 1.0 + 1e-6));                           // inference.py:190
+  CHK(factor(c, c->ws, c->ident, nb));
+  hipLaunchKernelGGL(logdet_batch_kernel, dim3(nb), dim3(256), 0, c->st, c->ws.H, (long long)c->ws.sH, c->ld, c->npad, c->sc_f);
+  CHK(download(c, logdet.data(), c->sc_f, nb));
+  HIPC(hipMemcpyAsync(info.data(), c->ws.info, sizeof(int) * nb, hipMemcpyDeviceToHost, c->st));
+  HIPC(hipStreamSynchronize(c->st));
+  for (int s2 = 0; s2 < nb; ++s2) {
+    if (info[s2] != 0) return fail("dual problem: posterior precision of trial %d not positive definite (pivot %d)", tos[s2], info[s2]);
+    // A + B + C + D of inference.py:203-213 ; C = 0.5*logdet(Sigma) = -0.5*logdet(precision + jitter)
+    cost[s2] = 0.5 * vKv[s2] - sB[s2] - 0.5 * logdet[s2] + sD[s2];
+  }
+  if (want_grad) {
+    CHK(inverse_t(c, c->ws, c->ident, nb));
+    const int KY = std::min(p, 16);
+    dispatch_pmax(p, [&](auto pm) {
+      hipLaunchKernelGGL(post_vsm_kernel<decltype(pm)::value>, dim3((T + 63) / 64, nb), dim3(64, KY), 0, c->st, c->ws.Mt, c->ws.sM, c->ld, c->npad,
+                         T, p, c->vsm, c->ident, c->trial_of_slot, 0);
+    });
+    hipLaunchKernelGGL(dual_grad_batch_kernel, dim3((T + 63) / 64, q, nb), dim3(64), 0, c->st, c->C, c->d, c->lamd, c->KD, (long long)c->ld, c->vsm,
+                       c->trial_of_slot, c->dgrad, q, p, T);
+    HIPC(hipGetLastError());
+  }
+  return 0;
+}
+
+static int check_distinct(const std::vector<int>& v) {
+  std::vector<int> s(v);
+  std::sort(s.begin(), s.end());
+  for (size_t i = 1; i < s.size(); ++i)
+    if (s[i] == s[i - 1]) return fail("trial %d listed twice (the per-trial covariance blocks are scratch space of this call)", s[i]);
+  return 0;
+}
+
+// dualProblem / dualProblem_grad for a LIST of trials at once (each trial at its own lambda).  The per-trial scipy
+// L-BFGS-B runs of inference.dualVariational (DUAL_SOLVER = 'scipy') are driven concurrently so that one round of their
+// requests is one call of this.
 int pgpfa_dual_costgrad_batch(pgpfa_ctx* c, int n, const int32_t* idx, const double* lam, double* cost, double* grad) {
   CHK(ready(c));
   if (!lam || !cost) return fail("null argument");
@@ -2328,45 +2371,193 @@ int pgpfa_dual_costgrad_batch(pgpfa_ctx* c, int n, const int32_t* idx, const dou
   Trials tr;
   CHK(resolve_trials(c, n, idx, &tr));
   const int N = (int)tr.v.size();
-  const int q = c->q, p = c->p, T = c->T;
-  const size_t m = (size_t)q * T;
+  const size_t m = (size_t)c->q * c->T;
   for (size_t i = 0; i < (size_t)N * m; ++i)
     if (!(lam[i] > 0.0)) return fail("lambda must be positive (trial %d, entry %zu = %g)", tr.v[i / m], i % m, lam[i]);
-  for (int i = 0; i < N; ++i)
-    for (int j = 0; j < i; ++j)
-      if (tr.v[i] == tr.v[j]) return fail("trial %d listed twice (the per-trial covariance blocks are scratch space of this call)", tr.v[i]);
-  std::vector<double> logdet(c->B);
-  std::vector<int> info(c->B);
+  CHK(check_distinct(tr.v));
   for (int c0 = 0; c0 < N; c0 += c->B) {
     const int nb = std::min(c->B, N - c0);
     std::vector<int> tos(tr.v.begin() + c0, tr.v.begin() + c0 + nb);
     CHK(upload_list(c, c->trial_of_slot, tos));
     CHK(upload(c, c->lamd, lam + (size_t)c0 * m, (size_t)nb * m));
-    std::vector<double> sB, sD, vKv;
-    CHK(dual_common(c, nb, &sB, &sD, &vKv));
-    HIPC(hipMemsetAsync(c->ws.info, 0, sizeof(int) * nb, c->st));
-    CHK(ensure_mt_clean(c));
-    CHK(assemble(c, c->ident, nb, 1.0 + 1e-6));                         // inference.py:190
-    CHK(factor(c, c->ws, c->ident, nb));
-    hipLaunchKernelGGL(logdet_batch_kernel, dim3(nb), dim3(256), 0, c->st, c->ws.H, (long long)c->ws.sH, c->ld, c->npad, c->sc_f);
-    CHK(download(c, logdet.data(), c->sc_f, nb));
-    HIPC(hipMemcpyAsync(info.data(), c->ws.info, sizeof(int) * nb, hipMemcpyDeviceToHost, c->st));
-    HIPC(hipStreamSynchronize(c->st));
-    for (int s2 = 0; s2 < nb; ++s2) {
-      if (info[s2] != 0) return fail("dual problem: posterior precision of trial %d not positive definite (pivot %d)", tos[s2], info[s2]);
-      cost[c0 + s2] = 0.5 * vKv[s2] - sB[s2] - 0.5 * logdet[s2] + sD[s2];
-    }
-    if (grad) {
-      CHK(inverse_t(c, c->ws, c->ident, nb));
-      const int KY = std::min(p, 16);
-      dispatch_pmax(p, [&](auto pm) {
-        hipLaunchKernelGGL(post_vsm_kernel<decltype(pm)::value>, dim3((T + 63) / 64, nb), dim3(64, KY), 0, c->st, c->ws.Mt, c->ws.sM, c->ld, c->npad,
-                           T, p, c->vsm, c->ident, c->trial_of_slot, 0);
-      });
-      hipLaunchKernelGGL(dual_grad_batch_kernel, dim3((T + 63) / 64, q, nb), dim3(64), 0, c->st, c->C, c->d, c->lamd, c->KD, (long long)c->ld, c->vsm,
-                         c->trial_of_slot, c->dgrad, q, p, T);
+    CHK(dual_eval_slots(c, nb, tos, grad != nullptr, cost + c0));
+    if (grad) CHK(download(c, grad + (size_t)c0 * m, c->dgrad, (size_t)nb * m));
+  }
+  return 0;
+}
+
+// The whole dual optimisation of a list of trials on the device: one L-BFGS run per trial in rho = log(lambda) (the
+// unconstrained form of the reference's optimizeLogLambda=True path, inference.py:222-256, 391-396), all runs of a chunk in
+// lockstep - every iteration is one batched dual evaluation plus per-slot two-loop recursions on device-resident vectors.
+// Backtracking (Armijo) line search; stops per trial on scipy's L-BFGS-B criteria: relative decrease <= factr * eps or
+// max |gradient| <= pgtol.  rho[n][q*T]: start in, optimum out; fopt[n]: dual optimum; iters[n] (may be NULL).
+int pgpfa_dual_lbfgs(pgpfa_ctx* c, int n, const int32_t* idx, double* rho, int max_iter, double factr, double pgtol, double* fopt,
+                     int32_t* iters) {
+  CHK(ready(c));
+  if (!rho || !fopt) return fail("null argument");
+  if (max_iter < 1) return fail("max_iter must be positive");
+  CHK(ensure_lambda(c));
+  Trials tr;
+  CHK(resolve_trials(c, n, idx, &tr));
+  CHK(check_distinct(tr.v));
+  const int N = (int)tr.v.size();
+  const size_t m = (size_t)c->q * c->T;
+  constexpr int HIST = 10;                                          // scipy's default m = 10 corrections
+  const int Bc = std::min(c->B, N);
+  // device vectors of this call (freed on return): X, G, D, Xn, Gn and the correction pairs
+  std::vector<double*> owned;
+  auto dalloc = [&](double** ptr, size_t count) -> int {
+    if (hipMalloc((void**)ptr, count * sizeof(double)) != hipSuccess) return fail("out of device memory for the L-BFGS state (%zu bytes)", count * sizeof(double));
+    owned.push_back(*ptr);
+    return 0;
+  };
+  struct Freer { std::vector<double*>& v; ~Freer() { for (double* q2 : v) hipFree(q2); } } freer{owned};
+  double *X, *G, *D, *Xn, *Gn, *S, *Yh, *scal;
+  const size_t vec = (size_t)Bc * m;
+  CHK(dalloc(&X, vec)); CHK(dalloc(&G, vec)); CHK(dalloc(&D, vec)); CHK(dalloc(&Xn, vec)); CHK(dalloc(&Gn, vec));
+  CHK(dalloc(&S, vec * HIST)); CHK(dalloc(&Yh, vec * HIST)); CHK(dalloc(&scal, 4 * (size_t)Bc));
+  int* take = nullptr;
+  HIPC(hipMalloc((void**)&take, sizeof(int) * Bc));
+  struct FreeI { int* q2; ~FreeI() { hipFree(q2); } } freei{take};
+  const dim3 vgrid((unsigned)((m + 255) / 256), 1);
+  const double eps = 2.220446049250313e-16;
+
+  for (int c0 = 0; c0 < N; c0 += Bc) {
+    const int nb = std::min(Bc, N - c0);
+    std::vector<int> tos(tr.v.begin() + c0, tr.v.begin() + c0 + nb);
+    CHK(upload_list(c, c->trial_of_slot, tos));
+    const dim3 grid(vgrid.x, nb);
+    auto bdot = [&](const double* A, const double* B2, std::vector<double>& out) -> int {
+      hipLaunchKernelGGL(bdot_kernel, dim3(nb), dim3(256), 0, c->st, A, B2, m, scal);
+      return download(c, out.data(), scal, nb);
+    };
+    auto upload_scal = [&](const std::vector<double>& v, int slot) -> int { return upload(c, scal + (size_t)slot * Bc, v.data(), nb); };
+    // f and the gradient with respect to rho at the device vector Xin (lambda = exp(rho) goes to c->lamd)
+    auto evaluate = [&](const double* Xin, double* Gout, std::vector<double>& f) -> int {
+      hipLaunchKernelGGL(exp_kernel, dim3((unsigned)((nb * m + 255) / 256)), dim3(256), 0, c->st, Xin, c->lamd, nb * m);
+      CHK(dual_eval_slots(c, nb, tos, true, f.data()));
+      hipLaunchKernelGGL(chain_kernel, dim3((unsigned)((nb * m + 255) / 256)), dim3(256), 0, c->st, c->dgrad, c->lamd, Gout, nb * m);
       HIPC(hipGetLastError());
-      CHK(download(c, grad + (size_t)c0 * m, c->dgrad, (size_t)nb * m));
+      return 0;
+    };
+    CHK(upload(c, X, rho + (size_t)c0 * m, (size_t)nb * m));
+    std::vector<double> f(nb), fn(nb), gd(nb), t(nb), tmp(nb), gmax(nb);
+    std::vector<std::vector<double>> rho_h(HIST, std::vector<double>(nb, 0.0)), alpha(HIST, std::vector<double>(nb, 0.0));
+    std::vector<int> nhist(nb, 0), head(nb, 0), done(nb, 0), its(nb, 0), flags(nb);
+    CHK(evaluate(X, G, f));
+    hipLaunchKernelGGL(bmaxabs_kernel, dim3(nb), dim3(256), 0, c->st, G, m, scal);
+    CHK(download(c, gmax.data(), scal, nb));
+    for (int s2 = 0; s2 < nb; ++s2) done[s2] = (gmax[s2] <= pgtol) ? 1 : 0;
+    int global_hist = 0;                                              // pairs are pushed in lockstep; per-slot validity via rho_h > 0
+
+    for (int it = 0; it < max_iter; ++it) {
+      bool any = false;
+      for (int s2 = 0; s2 < nb; ++s2) any = any || !done[s2];
+      if (!any) break;
+      // ---- direction D = -H G (two-loop recursion over the stored pairs; invalid pairs have rho_h = 0: no-ops)
+      HIPC(hipMemcpyAsync(D, G, (size_t)nb * m * sizeof(double), hipMemcpyDeviceToDevice, c->st));
+      const int used = std::min(global_hist, HIST);
+      for (int j = 0; j < used; ++j) {                              // newest -> oldest
+        const int i = (global_hist - 1 - j) % HIST;
+        CHK(bdot(S + (size_t)i * vec, D, tmp));
+        for (int s2 = 0; s2 < nb; ++s2) { alpha[i][s2] = rho_h[i][s2] * tmp[s2]; tmp[s2] = -alpha[i][s2]; }
+        CHK(upload_scal(tmp, 0));
+        hipLaunchKernelGGL(baxpby_kernel, grid, dim3(256), 0, c->st, scal, Yh + (size_t)i * vec, (const double*)nullptr, D, m);
+      }
+      if (used > 0) {                                               // initial scaling gamma = s.y / y.y of the newest pair
+        const int i = (global_hist - 1) % HIST;
+        CHK(bdot(Yh + (size_t)i * vec, Yh + (size_t)i * vec, tmp));
+        std::vector<double> gam(nb), zero(nb, 0.0);
+        for (int s2 = 0; s2 < nb; ++s2) gam[s2] = (rho_h[i][s2] > 0.0 && tmp[s2] > 0.0) ? 1.0 / (rho_h[i][s2] * tmp[s2]) : 1.0;
+        CHK(upload_scal(gam, 1));
+        CHK(upload_scal(zero, 0));
+        hipLaunchKernelGGL(baxpby_kernel, grid, dim3(256), 0, c->st, scal, D, scal + Bc, D, m);       // D <- gamma D
+      }
+      for (int j = used - 1; j >= 0; --j) {                         // oldest -> newest
+        const int i = (global_hist - 1 - j) % HIST;
+        CHK(bdot(Yh + (size_t)i * vec, D, tmp));
+        for (int s2 = 0; s2 < nb; ++s2) tmp[s2] = alpha[i][s2] - rho_h[i][s2] * tmp[s2];
+        CHK(upload_scal(tmp, 0));
+        hipLaunchKernelGGL(baxpby_kernel, grid, dim3(256), 0, c->st, scal, S + (size_t)i * vec, (const double*)nullptr, D, m);
+      }
+      {                                                             // D <- -D
+        std::vector<double> zero(nb, 0.0), neg(nb, -1.0);
+        CHK(upload_scal(zero, 0));
+        CHK(upload_scal(neg, 1));
+        hipLaunchKernelGGL(baxpby_kernel, grid, dim3(256), 0, c->st, scal, D, scal + Bc, D, m);
+      }
+      CHK(bdot(G, D, gd));
+      bool reset = false;
+      for (int s2 = 0; s2 < nb; ++s2)
+        if (!done[s2] && !(gd[s2] < 0.0)) reset = true;             // not a descent direction (stale pairs): restart from steepest descent
+      if (reset) {
+        global_hist = 0;
+        for (auto& r : rho_h) std::fill(r.begin(), r.end(), 0.0);
+        std::vector<double> zero(nb, 0.0), neg(nb, -1.0);
+        CHK(upload_scal(neg, 0));
+        CHK(upload_scal(zero, 1));
+        hipLaunchKernelGGL(baxpby_kernel, grid, dim3(256), 0, c->st, scal, G, scal + Bc, D, m);        // D <- -G
+        CHK(bdot(G, D, gd));
+      }
+      // ---- backtracking line search, all slots in lockstep (finished slots take t = 0)
+      hipLaunchKernelGGL(bmaxabs_kernel, dim3(nb), dim3(256), 0, c->st, D, m, scal + 2 * (size_t)Bc);
+      CHK(download(c, tmp.data(), scal + 2 * (size_t)Bc, nb));
+      std::vector<int> pending;
+      for (int s2 = 0; s2 < nb; ++s2) {
+        t[s2] = 0.0;
+        if (done[s2]) continue;
+        t[s2] = (global_hist == 0 && tmp[s2] > 1.0) ? 1.0 / tmp[s2] : 1.0;      // first step: at most unit length in the max norm
+        pending.push_back(s2);
+      }
+      std::vector<int> accepted(nb, 0);
+      for (int ls = 0; ls < 30 && !pending.empty(); ++ls) {
+        CHK(upload_scal(t, 0));
+        hipLaunchKernelGGL(bstep_kernel, grid, dim3(256), 0, c->st, X, D, scal, Xn, m);
+        CHK(evaluate(Xn, Gn, fn));
+        std::vector<int> rej;
+        for (int s2 : pending) {
+          if (std::isfinite(fn[s2]) && fn[s2] <= f[s2] + 1e-4 * t[s2] * gd[s2] + 1e-14 * (1.0 + std::fabs(f[s2]))) accepted[s2] = 1;
+          else { t[s2] *= 0.5; rej.push_back(s2); }
+        }
+        if (rej.empty()) break;
+        // slots accepted in this round keep their point: freeze it by re-deriving the same Xn next round (t unchanged)
+        pending.swap(rej);
+      }
+      for (int s2 : pending)
+        if (!accepted[s2]) { t[s2] = 0.0; done[s2] = 1; }            // search exhausted: stay (cannot improve at this precision)
+      if (!pending.empty() && std::any_of(pending.begin(), pending.end(), [&](int s2) { return !accepted[s2]; })) {
+        CHK(upload_scal(t, 0));
+        hipLaunchKernelGGL(bstep_kernel, grid, dim3(256), 0, c->st, X, D, scal, Xn, m);
+        CHK(evaluate(Xn, Gn, fn));
+      }
+      // ---- new correction pair s = Xn - X, y = Gn - G (slots that moved), convergence tests, commit
+      const int i_new = global_hist % HIST;
+      for (int s2 = 0; s2 < nb; ++s2) flags[s2] = (accepted[s2] && t[s2] > 0.0) ? 1 : 0;
+      HIPC(hipMemcpyAsync(take, flags.data(), sizeof(int) * nb, hipMemcpyHostToDevice, c->st));
+      HIPC(hipMemsetAsync(S + (size_t)i_new * vec, 0, (size_t)nb * m * sizeof(double), c->st));
+      HIPC(hipMemsetAsync(Yh + (size_t)i_new * vec, 0, (size_t)nb * m * sizeof(double), c->st));
+      hipLaunchKernelGGL(bdiff_kernel, grid, dim3(256), 0, c->st, Xn, X, take, S + (size_t)i_new * vec, m);
+      hipLaunchKernelGGL(bdiff_kernel, grid, dim3(256), 0, c->st, Gn, G, take, Yh + (size_t)i_new * vec, m);
+      CHK(bdot(S + (size_t)i_new * vec, Yh + (size_t)i_new * vec, tmp));
+      for (int s2 = 0; s2 < nb; ++s2) rho_h[i_new][s2] = (flags[s2] && tmp[s2] > 1e-300) ? 1.0 / tmp[s2] : 0.0;
+      global_hist += 1;
+      hipLaunchKernelGGL(bcopy_kernel, grid, dim3(256), 0, c->st, Xn, take, X, m);
+      hipLaunchKernelGGL(bcopy_kernel, grid, dim3(256), 0, c->st, Gn, take, G, m);
+      hipLaunchKernelGGL(bmaxabs_kernel, dim3(nb), dim3(256), 0, c->st, G, m, scal);
+      CHK(download(c, gmax.data(), scal, nb));
+      for (int s2 = 0; s2 < nb; ++s2) {
+        if (done[s2] || !flags[s2]) continue;
+        its[s2] = it + 1;
+        const double dec = f[s2] - fn[s2];
+        const double den = std::max(std::max(std::fabs(f[s2]), std::fabs(fn[s2])), 1.0);
+        f[s2] = fn[s2];
+        if (dec / den <= factr * eps || gmax[s2] <= pgtol) done[s2] = 1;
+      }
+    }
+    CHK(download(c, rho + (size_t)c0 * m, X, (size_t)nb * m));
+    for (int s2 = 0; s2 < nb; ++s2) {
+      fopt[c0 + s2] = f[s2];
+      if (iters) iters[c0 + s2] = its[s2];
     }
   }
   return 0;

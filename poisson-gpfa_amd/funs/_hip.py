@@ -52,6 +52,7 @@ _SIGNATURES = {
     'pgpfa_count_moments': [ct.c_void_p, ct.c_int, c_int32_p, c_int64_p, c_int64_p, c_int64_p],
     'pgpfa_dual_costgrad': [ct.c_void_p, ct.c_int, c_double_p, c_double_p, c_double_p],
     'pgpfa_dual_costgrad_batch': [ct.c_void_p, ct.c_int, c_int32_p, c_double_p, c_double_p, c_double_p],
+    'pgpfa_dual_lbfgs': [ct.c_void_p, ct.c_int, c_int32_p, c_double_p, ct.c_int, ct.c_double, ct.c_double, c_double_p, c_int32_p],
     'pgpfa_dual_finalize': [ct.c_void_p, ct.c_int, c_int32_p, c_double_p, c_double_p],
     'pgpfa_comm_unique_id': [ct.c_char_p],
     'pgpfa_comm_init': [ct.c_void_p, ct.c_char_p, ct.c_int, ct.c_int],
@@ -279,6 +280,15 @@ class Context:
         grad = np.empty((n, self.q * self.T)) if want_grad else None
         check(self.lib.pgpfa_dual_costgrad_batch(self.h, n, iptr(ii), dptr(lam), dptr(cost), dptr(grad) if want_grad else None))
         return cost, grad
+
+    def dual_lbfgs(self, idx, rho0, max_iter=15000, factr=1e7, pgtol=1e-5):
+        """Device L-BFGS on the dual in rho = log(lambda) for the listed trials -> (rho_opt[n][q*T], dual optimum[n], iterations[n])."""
+        n, ii = self._n_idx(idx)
+        rho = np.array(as_f64(rho0).reshape(n, self.q * self.T), copy=True)
+        fopt = np.empty(n)
+        iters = np.zeros(n, dtype=np.int32)
+        check(self.lib.pgpfa_dual_lbfgs(self.h, n, iptr(ii), dptr(rho), int(max_iter), float(factr), float(pgtol), dptr(fopt), iptr(iters)))
+        return rho, fopt, iters
 
     def dual_finalize(self, idx, lam):
         n, ii = self._n_idx(idx)

@@ -100,6 +100,11 @@ def laplace_hessian(experiment, params, X, trial=0):
     return sess.ctx.laplace_hessian(int(trial_idx[trial]), X)
 
 
+# 'device': the dual optimisations of all trials run as lockstep L-BFGS on the GPU (pgpfa_dual_lbfgs); 'scipy': the
+# reference's per-trial scipy L-BFGS-B calls (same options), driven concurrently with batched device evaluations
+DUAL_SOLVER = 'device'
+
+
 class _ConcurrentProblems:
     """n independent optimisations, one Python thread each, whose cost/gradient requests are gathered into one batched
     device evaluation per round.  Every optimiser sees exactly the call sequence it would see running alone."""
@@ -192,6 +197,27 @@ def dualVariational(experiment, params, optimizeLogLambda=False, prevOptimRes=No
     mine = trial_idx[lo:hi]
     m = sess.q * sess.T
     ctx = sess.ctx
+    if DUAL_SOLVER == 'device' and len(mine):
+        # all trials in lockstep on the device, in rho = log(lambda); same optimum as either of the reference's variants
+        if prevOptimRes is None:
+            rho0 = np.zeros((len(mine), m)) if optimizeLogLambda else np.full((len(mine), m), np.log(0.5))
+        else:
+            prev = np.stack([np.asarray(prevOptimRes[j] if len(prevOptimRes) == len(mine) else prevOptimRes[lo + j], dtype=np.float64)
+                             for j in range(len(mine))])
+            rho0 = prev if optimizeLogLambda else np.log(np.maximum(prev, 1e-300))
+        rho, fopt, iters = ctx.dual_lbfgs(mine, rho0)
+        lam_all = np.exp(rho)
+        optim = list(rho) if optimizeLogLambda else list(lam_all)
+        nlp = ctx.dual_finalize(mine, lam_all)
+        sess.post_stamp += 1
+        sess.mode_stamp += 1
+        tot = sess.allreduce(np.array([nlp, float(np.sum(fopt)), float(len(mine))]))
+        infRes = DeviceInfRes(sess, mine, (lo, hi))
+        infRes.dual_iterations = iters
+        if returnOptimRes:
+            return infRes, -tot[0] / tot[2], tot[1] / tot[2], optim
+        return infRes, -tot[0] / tot[2], tot[1] / tot[2]
+    # DUAL_SOLVER == 'scipy':
     # The reference solves the trials one after the other (inference.py:300-397), each with its own scipy L-BFGS-B run.
     # Here every trial still gets exactly that run (same calls, same options, same start), but the runs execute
     # concurrently - one Python thread per trial - and each round of their cost/gradient requests is served by ONE

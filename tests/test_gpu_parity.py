@@ -649,3 +649,29 @@ def test_tiny_problem_sizes(q, p, T, R):
         assert ns == R * T and np.array_equal(s, Y.astype(np.int64).sum(axis=(0, 2)))
     finally:
         ctx.close()
+
+
+def test_device_lbfgs_dual_solver_matches_scipy_driver(funs_mod):
+    """The lockstep device L-BFGS (rho = log lambda) against the reference-faithful scipy L-BFGS-B driver on the toy: the dual
+    is strictly convex, so both stop at the same optimum within their (identical) stopping tolerances."""
+    g = load_golden('var_toy.npz')
+    Ys = [g['Y'][r].astype(float) for r in range(g['Y'].shape[0])]
+    exp = Experiment(Ys, float(g['binSize']))
+    params = {'C': g['init_C'].copy(), 'd': g['init_d'].copy(), 'tau': g['init_tau'].copy()}
+    out = {}
+    for solver in ('device', 'scipy'):
+        funs_mod.inference.DUAL_SOLVER = solver
+        try:
+            out[solver] = funs_mod.inference.dualVariational(exp, params)
+        finally:
+            funs_mod.inference.DUAL_SOLVER = 'device'
+    (ir_d, nll_d, vlb_d, opt_d), (ir_s, nll_s, vlb_s, opt_s) = out['device'], out['scipy']
+    assert abs(vlb_d - vlb_s) <= 1e-4 and abs(nll_d - nll_s) <= 1e-4
+    assert abs(vlb_d - float(g['estep_vlb'])) <= 1e-3
+    assert len(opt_d) == len(opt_s) and opt_d[0].shape == opt_s[0].shape
+    for r in (0, 5, 9):
+        assert np.max(np.abs(ir_d['post_mean'][r] - ir_s['post_mean'][r])) <= 2e-3
+        assert rel(ir_d['post_vsm'][r], ir_s['post_vsm'][r]) <= 2e-3
+    # the dual optimum of the device solver is at least as low (it runs to the same relative-decrease test)
+    assert vlb_d <= vlb_s + 1e-5
+    assert np.all(ir_d.dual_iterations > 0)

@@ -18,8 +18,18 @@ sess.set_params(params)
 funs.inference.dualVariational(bench.Shard(Ys[:2], 10.0), params)            # warm-up
 t0 = time.time()
 infRes, nll, vlb, opt = funs.inference.dualVariational(exp, params)
-t_conc = time.time() - t0
-print('concurrent: %d trials in %.2f s  (nll %.4f, vlb %.4f)' % (R, t_conc, nll, vlb))
+t_dev = time.time() - t0
+print('device L-BFGS: %d trials in %.2f s  (nll %.4f, vlb %.4f, iterations %d..%d)' % (R, t_dev, nll, vlb, infRes.dual_iterations.min(),
+                                                                                      infRes.dual_iterations.max()))
+if os.environ.get('PROBE_SCIPY', '1') == '1':
+    funs.inference.DUAL_SOLVER = 'scipy'
+    t0 = time.time()
+    infRes, nll, vlb, opt = funs.inference.dualVariational(exp, params)
+    t_conc = time.time() - t0
+    funs.inference.DUAL_SOLVER = 'device'
+    print('concurrent scipy L-BFGS-B: %d trials in %.2f s  (nll %.4f, vlb %.4f)' % (R, t_conc, nll, vlb))
+else:
+    t_conc = t_dev
 # one trial at a time (what the driver did before): first 4 trials, scaled
 m = q * T
 ctx = sess.ctx
@@ -32,5 +42,5 @@ for tr in range(4):
         return ctx.dual_costgrad(tr, x)
     op.fmin_l_bfgs_b(func=lambda x: f(x)[0], x0=np.zeros(m) + 0.5, fprime=lambda x: f(x)[1], bounds=[(1e-10, None)] * m, factr=1e7, disp=False)
 t_ser = (time.time() - t0) / 4
-print('serial: %.2f s per trial (%d evaluations each, counting cost and gradient calls) -> %.1f s for %d trials; speed-up %.1fx'
-      % (t_ser, nev // 4, t_ser * R, R, t_ser * R / t_conc))
+print('serial scipy: %.2f s per trial (%d callback calls each) -> %.1f s for %d trials; device L-BFGS speed-up %.0fx'
+      % (t_ser, nev // 4, t_ser * R, R, t_ser * R / t_dev))
