@@ -50,6 +50,8 @@ int pgpfa_destroy(pgpfa_ctx* ctx);
  * "pcg_outer_max" (12), "cov_mode" (0 auto, 1 dense, 2 low-rank covariance engine), "lowrank_tol" (1e-13),
  * "keep_trial_vsmgp" (0: the low-rank engine accumulates sum_r post_vsmGP_r for the tau M-step and rebuilds
  * per-trial T x T blocks only when pgpfa_get_post_vsmgp asks for them; 1: store them in every E-step),
+ * "dual_lowrank" (0; 1: the dual-variational entry points may use the low-rank engine when it pays - log det through
+ * the r x r system - which evaluates the dual WITHOUT the reference's 1e-6 diagonal jitter, inference.py:190),
  * "extrapolate_start" (1: a warm-started E-step begins at m + beta (m - m_prev) for trials whose two previous
  * E-steps are resident), "extrapolate_beta" (1.0). */
 int pgpfa_set_option(pgpfa_ctx* ctx, const char* key, double value);

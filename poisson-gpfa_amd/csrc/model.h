@@ -1216,6 +1216,20 @@ __global__ void chain_kernel(const double* __restrict__ glam, const double* __re
   if (i < n) grho[i] = glam[i] * lam[i];
 }
 
+// out[row] = sum of the `len` consecutive entries of row `row`; grid = rows, block = 256
+__global__ __launch_bounds__(256) void sum_rows_kernel(const double* __restrict__ A, int len, double* __restrict__ out) {
+  __shared__ double red[256];
+  const double* a = A + (size_t)blockIdx.x * len;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < len; i += 256) s += a[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = red[0];
+}
 // x = -Kv  (VIPostMean, inference.py:193-194)
 __global__ void negate_rows_kernel(const double* __restrict__ src, long long sSrc, double* __restrict__ dst, long long sDst, int n,
                                    const int* __restrict__ slots) {
@@ -1452,8 +1466,9 @@ __global__ __launch_bounds__(256) void rbf_pivchol_kernel(double* __restrict__ F
 }
 
 // per (slot, bin): G = (I + eps W)^-1 and Wt = W G.  One thread per matrix, matrices in dynamic LDS.
+// (ldet, optional: ldet[item] = log det(I + eps W_t), item = list position * T + t)
 __global__ void bin_blocks_kernel(const double* __restrict__ W, long long sW, double* __restrict__ G, double* __restrict__ Wt, long long sO,
-                                  int T, int p, double eps, const int* __restrict__ slots, int nslots) {
+                                  int T, int p, double eps, const int* __restrict__ slots, int nslots, double* __restrict__ ldet) {
   extern __shared__ double sm[];
   const int pp = p * p, stride = 2 * pp + 1;
   double* A = sm + (size_t)threadIdx.x * stride;   // A: I + eps W -> L -> L^-1 ; Gm = result
@@ -1466,9 +1481,11 @@ __global__ void bin_blocks_kernel(const double* __restrict__ W, long long sW, do
   for (int i = 0; i < p; ++i)
     for (int j2 = 0; j2 < p; ++j2) A[i * p + j2] = eps * w[i * p + j2] + (i == j2 ? 1.0 : 0.0);
   // Cholesky (lower, in place)
+  double logdet = 0.0;
   for (int j2 = 0; j2 < p; ++j2) {
     double dj = A[j2 * p + j2];
     for (int m = 0; m < j2; ++m) dj -= A[j2 * p + m] * A[j2 * p + m];
+    logdet += log(dj);
     dj = sqrt(dj);
     A[j2 * p + j2] = dj;
     for (int i = j2 + 1; i < p; ++i) {
@@ -1477,6 +1494,7 @@ __global__ void bin_blocks_kernel(const double* __restrict__ W, long long sW, do
       A[i * p + j2] = v / dj;
     }
   }
+  if (ldet) ldet[item] = logdet;
   // invert L in place (lower)
   for (int j2 = 0; j2 < p; ++j2) {
     A[j2 * p + j2] = 1.0 / A[j2 * p + j2];

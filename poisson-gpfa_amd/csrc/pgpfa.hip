@@ -5,6 +5,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <limits>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -96,6 +97,8 @@ struct pgpfa_ctx {
   int qpad = 0, ccu_cols = 0;
   double* ppart = nullptr;                       // [p][PACC_SPLITS + 1][T x T] split-K partial products
   bool cd_hess_valid = false; int cd_hess_ntr = 0;   // per-neuron Hessian sums of the last Newton pass are resident
+  std::vector<double> logdetK;                  // log det of the p Gram matrices (from the factor in build_kinv)
+  bool dual_lowrank = false;                    // dual-variational entry points may use the low-rank engine (no diagonal jitter)
   bool keep_trial_vsmgp = false;
   bool pacc_used = false, pacc_valid = false;
   std::vector<char> vsmgp_ok;                    // per trial: c->vsmgp holds the blocks of the resident posterior
@@ -114,7 +117,7 @@ struct pgpfa_ctx {
   CholWS ws{};
   double *Xc = nullptr, *Xt = nullptr, *KX = nullptr, *KD = nullptr, *Gl = nullptr, *Glt = nullptr, *Gt = nullptr, *Dl = nullptr;
   double *W = nullptr, *Wt = nullptr, *fpart = nullptr;
-  double *lamd = nullptr, *dgrad = nullptr, *dpart = nullptr;   // dual variational scratch
+  double *lamd = nullptr, *dgrad = nullptr, *dpart = nullptr, *ldet_buf = nullptr;   // dual variational scratch
   // shared-preconditioner Newton-PCG: one factor per chunk (mean-trial Hessian), PCG vectors per slot
   CholWS sws{};
   double *sU = nullptr, *sDinvT = nullptr, *Wbar = nullptr;
@@ -397,7 +400,7 @@ int free_workspace(pgpfa_ctx* c) {
   HIPC(hipStreamSynchronize(c->st));
   while (c->allocs.size() > c->ws_mark) { hipFree(c->allocs.back()); c->allocs.pop_back(); }
   c->B = 0;
-  c->lamd = c->dgrad = c->dpart = nullptr;
+  c->lamd = c->dgrad = c->dpart = c->ldet_buf = nullptr;
   c->commbuf = nullptr; c->commbuf_len = 0;
   c->mt_dirty = false;
   return 0;
@@ -595,6 +598,9 @@ int build_kinv(pgpfa_ctx* c) {
   HIPC(hipMemcpyAsync(c->kws.H, c->Kpad, slab * c->p * sizeof(double), hipMemcpyDeviceToDevice, c->st));
   HIPC(hipMemsetAsync(c->kws.info, 0, sizeof(int) * c->p, c->st));
   CHK(factor(c, c->kws, nullptr, c->p));
+  c->logdetK.assign(c->p, 0.0);
+  hipLaunchKernelGGL(logdet_batch_kernel, dim3(c->p), dim3(256), 0, c->st, c->kws.H, (long long)c->kws.sH, c->Tp, c->Tp, c->tscal);
+  CHK(download(c, c->logdetK.data(), c->tscal, c->p));
   CHK(inverse_t(c, c->kws, nullptr, c->p));
   GemmP g{};
   g.A = c->kws.Mt; g.sA = c->kws.sM; g.lda = c->Tp;
@@ -825,6 +831,7 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
   else if (k == "cov_mode") c->cov_mode = (int)v;
   else if (k == "lowrank_tol") c->lr_tol = v;
   else if (k == "keep_trial_vsmgp") c->keep_trial_vsmgp = (v != 0.0);
+  else if (k == "dual_lowrank") c->dual_lowrank = (v != 0.0);
   else if (k == "extrapolate_start") c->extrapolate = (v != 0.0);
   else if (k == "extrapolate_beta") c->extrapolate_beta = v;
   else if (k == "shared_min") c->shared_min = (int)v;
@@ -1088,7 +1095,7 @@ static int shared_factor_lowrank(pgpfa_ctx* c, int nb) {
     int th = (int)(48 * 1024 / ((2 * pp + 1) * sizeof(double)));
     th = std::max(1, std::min(64, th));
     hipLaunchKernelGGL(bin_blocks_kernel, dim3((unsigned)((T + th - 1) / th)), dim3(th), (size_t)th * (2 * pp + 1) * sizeof(double), c->st,
-                       c->Wbar, 0LL, c->Gbar, c->Wtbar, 0LL, T, p, c->eps, c->ident, 1);
+                       c->Wbar, 0LL, c->Gbar, c->Wtbar, 0LL, T, p, c->eps, c->ident, 1, (double*)nullptr);
   }
   CholWS lw = c->sws;
   lw.ld = rpad; lw.npad = rpad; lw.nact = round_up(c->rtot, 64);
@@ -1189,7 +1196,9 @@ static int posterior_blocks_dense(pgpfa_ctx* c, int nb, double diag_scale, bool 
 
 // Covariance blocks through the low-rank form of the prior (see model.h): per slot an r x r SPD system
 // B = I + F^T Wt F instead of the n x n Hessian.  Uses the dense engine's slabs as scratch (ld = rpad views).
-static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool accumulate) {
+// logdet_out (optional, host, nb entries): log det of the posterior precision K^-1 + scatter(W) of every slot,
+//   = -sum_k log det K_k + sum_t log det(I + eps W_t) + log det(I + F^T Wt F)   (Sylvester; K_k = eps I + F_k F_k^T)
+static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool accumulate, double* logdet_out = nullptr) {
   const int T = c->T, p = c->p, Tp = c->Tp, pp = p * p;
   const int rpad = c->rpad;
   const int ract = round_up(c->rtot, 16);          // columns of Yt that are not identically zero (rpad rounds to 128 for the factor)
@@ -1201,7 +1210,7 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool 
     th = std::max(1, std::min(64, th));
     const long long items = (long long)nb * T;
     hipLaunchKernelGGL(bin_blocks_kernel, dim3((unsigned)((items + th - 1) / th)), dim3(th), (size_t)th * (2 * pp + 1) * sizeof(double), c->st,
-                       c->W, sW, c->Gbin, c->Wt, sW, T, p, c->eps, c->ident, nb);
+                       c->W, sW, c->Gbin, c->Wt, sW, T, p, c->eps, c->ident, nb, logdet_out ? c->ldet_buf : (double*)nullptr);
   }
   // b. B = I + F^T Wt F into the factor slabs viewed with ld = rpad; factor; L^-T
   CholWS lw = c->ws;
@@ -1212,6 +1221,16 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool 
   HIPC(hipGetLastError());
   HIPC(hipMemsetAsync(c->ws.info, 0, sizeof(int) * nb, c->st));
   CHK(factor(c, lw, c->ident, nb));
+  if (logdet_out) {
+    std::vector<double> a(nb), b2(nb);
+    hipLaunchKernelGGL(sum_rows_kernel, dim3(nb), dim3(256), 0, c->st, c->ldet_buf, T, c->sc_f);
+    CHK(download(c, a.data(), c->sc_f, nb));
+    hipLaunchKernelGGL(logdet_batch_kernel, dim3(nb), dim3(256), 0, c->st, lw.H, (long long)lw.sH, rpad, rpad, c->sc_f);
+    CHK(download(c, b2.data(), c->sc_f, nb));
+    double ldk = 0.0;
+    for (double v : c->logdetK) ldk += v;
+    for (int s2 = 0; s2 < nb; ++s2) logdet_out[s2] = -ldk + a[s2] + b2[s2];
+  }
   c->mt_dirty = true;
   hipLaunchKernelGGL(fill_slabs_kernel, dim3((unsigned)(((size_t)rpad * rpad + 1023) / 1024), nb), dim3(256), 0, c->st, lw.Mt, lw.sM,
                      (size_t)rpad * rpad, 0.0);
@@ -2250,6 +2269,7 @@ static int ensure_lambda(pgpfa_ctx* c) {
   CHK(dmalloc(c, &c->lamd, (size_t)c->B * c->q * c->T));
   CHK(dmalloc(c, &c->dgrad, (size_t)c->B * c->q * c->T));
   CHK(dmalloc(c, &c->dpart, (size_t)c->B * ((c->T + 63) / 64) * 2 + 16));
+  CHK(dmalloc(c, &c->ldet_buf, (size_t)c->B * c->T + 16));
   return 0;
 }
 
@@ -2321,11 +2341,36 @@ int pgpfa_dual_costgrad(pgpfa_ctx* c, int trial, const double* lam, double* cost
 // Dual cost (and gradient with respect to lambda, into c->dgrad) of the slots [0, nb) whose lambda is already in c->lamd and
 // whose trials are bound in c->trial_of_slot: the arithmetic of dualProblem / dualProblem_grad (inference.py:196-219) with
 // the dense factorisations of the chunk batched.
-static int dual_eval_slots(pgpfa_ctx* c, int nb, const std::vector<int>& tos, bool want_grad, double* cost) {
+// (tolerate: a slot whose precision is not positive definite or whose cost is not finite - a line-search trial point far
+// out - gets cost = +inf instead of failing the call)
+static int dual_eval_slots(pgpfa_ctx* c, int nb, const std::vector<int>& tos, bool want_grad, double* cost, bool tolerate = false) {
   const int q = c->q, p = c->p, T = c->T;
   std::vector<double> sB, sD, vKv, logdet(nb);
   std::vector<int> info(nb);
   CHK(dual_common(c, nb, &sB, &sD, &vKv));
+  if (c->plan_lowrank) {
+    // low-rank engine: log det through the r x r system, Sigma_t blocks from the per-bin pass over Yt.  The reference's
+    // jitter (diagonal of the precision scaled by 1 + 1e-6, inference.py:190) cannot be formed in this representation and is
+    // left out of cost AND gradient (a consistent pair: the dual of the model itself).  It is not a small effect on stiff GP
+    // priors - Sigma_ii H_ii reaches the hundreds, so the jitter moves the Sigma_t blocks by up to ~1 % - which is why the
+    // dense, jitter-faithful evaluation stays the default (option dual_lowrank).
+    CHK(posterior_blocks_lowrank(c, nb, false, false, logdet.data()));
+    HIPC(hipMemcpyAsync(info.data(), c->ws.info, sizeof(int) * nb, hipMemcpyDeviceToHost, c->st));
+    HIPC(hipStreamSynchronize(c->st));
+    for (int s2 = 0; s2 < nb; ++s2) {
+      cost[s2] = 0.5 * vKv[s2] - sB[s2] - 0.5 * logdet[s2] + sD[s2];
+      if (info[s2] != 0 || !std::isfinite(cost[s2])) {
+        if (!tolerate) return fail("dual problem: posterior precision of trial %d not positive definite (pivot %d)", tos[s2], info[s2]);
+        cost[s2] = std::numeric_limits<double>::infinity();
+      }
+    }
+    if (want_grad) {
+      hipLaunchKernelGGL(dual_grad_batch_kernel, dim3((T + 63) / 64, q, nb), dim3(64), 0, c->st, c->C, c->d, c->lamd, c->KD, (long long)c->ld,
+                         c->vsm, c->trial_of_slot, c->dgrad, q, p, T);
+      HIPC(hipGetLastError());
+    }
+    return 0;
+  }
   HIPC(hipMemsetAsync(c->ws.info, 0, sizeof(int) * nb, c->st));
   CHK(ensure_mt_clean(c));
   CHK(assemble(c, c->ident, nb, 1.0 + 1e-6));                           // inference.py:190
@@ -2335,9 +2380,12 @@ static int dual_eval_slots(pgpfa_ctx* c, int nb, const std::vector<int>& tos, bo
   HIPC(hipMemcpyAsync(info.data(), c->ws.info, sizeof(int) * nb, hipMemcpyDeviceToHost, c->st));
   HIPC(hipStreamSynchronize(c->st));
   for (int s2 = 0; s2 < nb; ++s2) {
-    if (info[s2] != 0) return fail("dual problem: posterior precision of trial %d not positive definite (pivot %d)", tos[s2], info[s2]);
     // A + B + C + D of inference.py:203-213 ; C = 0.5*logdet(Sigma) = -0.5*logdet(precision + jitter)
     cost[s2] = 0.5 * vKv[s2] - sB[s2] - 0.5 * logdet[s2] + sD[s2];
+    if (info[s2] != 0 || !std::isfinite(cost[s2])) {
+      if (!tolerate) return fail("dual problem: posterior precision of trial %d not positive definite (pivot %d)", tos[s2], info[s2]);
+      cost[s2] = std::numeric_limits<double>::infinity();
+    }
   }
   if (want_grad) {
     CHK(inverse_t(c, c->ws, c->ident, nb));
@@ -2365,12 +2413,14 @@ static int check_distinct(const std::vector<int>& v) {
 // L-BFGS-B runs of inference.dualVariational (DUAL_SOLVER = 'scipy') are driven concurrently so that one round of their
 // requests is one call of this.
 int pgpfa_dual_costgrad_batch(pgpfa_ctx* c, int n, const int32_t* idx, const double* lam, double* cost, double* grad) {
-  CHK(ready(c));
+  if (!c) return fail("null context");
   if (!lam || !cost) return fail("null argument");
-  CHK(ensure_lambda(c));
   Trials tr;
   CHK(resolve_trials(c, n, idx, &tr));
   const int N = (int)tr.v.size();
+  c->want_slots = std::max(c->want_slots, std::min(N, c->R));
+  CHK(ready_estep(c, c->dual_lowrank));
+  CHK(ensure_lambda(c));
   const size_t m = (size_t)c->q * c->T;
   for (size_t i = 0; i < (size_t)N * m; ++i)
     if (!(lam[i] > 0.0)) return fail("lambda must be positive (trial %d, entry %zu = %g)", tr.v[i / m], i % m, lam[i]);
@@ -2393,14 +2443,16 @@ int pgpfa_dual_costgrad_batch(pgpfa_ctx* c, int n, const int32_t* idx, const dou
 // max |gradient| <= pgtol.  rho[n][q*T]: start in, optimum out; fopt[n]: dual optimum; iters[n] (may be NULL).
 int pgpfa_dual_lbfgs(pgpfa_ctx* c, int n, const int32_t* idx, double* rho, int max_iter, double factr, double pgtol, double* fopt,
                      int32_t* iters) {
-  CHK(ready(c));
+  if (!c) return fail("null context");
   if (!rho || !fopt) return fail("null argument");
   if (max_iter < 1) return fail("max_iter must be positive");
-  CHK(ensure_lambda(c));
   Trials tr;
   CHK(resolve_trials(c, n, idx, &tr));
   CHK(check_distinct(tr.v));
   const int N = (int)tr.v.size();
+  c->want_slots = std::max(c->want_slots, std::min(N, c->R));
+  CHK(ready_estep(c, c->dual_lowrank));
+  CHK(ensure_lambda(c));
   const size_t m = (size_t)c->q * c->T;
   constexpr int HIST = 10;                                          // scipy's default m = 10 corrections
   const int Bc = std::min(c->B, N);
@@ -2435,7 +2487,7 @@ int pgpfa_dual_lbfgs(pgpfa_ctx* c, int n, const int32_t* idx, double* rho, int m
     // f and the gradient with respect to rho at the device vector Xin (lambda = exp(rho) goes to c->lamd)
     auto evaluate = [&](const double* Xin, double* Gout, std::vector<double>& f) -> int {
       hipLaunchKernelGGL(exp_kernel, dim3((unsigned)((nb * m + 255) / 256)), dim3(256), 0, c->st, Xin, c->lamd, nb * m);
-      CHK(dual_eval_slots(c, nb, tos, true, f.data()));
+      CHK(dual_eval_slots(c, nb, tos, true, f.data(), /*tolerate=*/true));
       hipLaunchKernelGGL(chain_kernel, dim3((unsigned)((nb * m + 255) / 256)), dim3(256), 0, c->st, c->dgrad, c->lamd, Gout, nb * m);
       HIPC(hipGetLastError());
       return 0;
@@ -2564,12 +2616,20 @@ int pgpfa_dual_lbfgs(pgpfa_ctx* c, int n, const int32_t* idx, double* rho, int m
 }
 
 int pgpfa_dual_finalize(pgpfa_ctx* c, int n, const int32_t* idx, const double* lam, double* nlp_sum) {
-  CHK(ready(c));
+  if (!c) return fail("null context");
   if (!lam) return fail("null argument");
-  CHK(ensure_lambda(c));
   Trials tr;
   CHK(resolve_trials(c, n, idx, &tr));
   const int N = (int)tr.v.size();
+  c->want_slots = std::max(c->want_slots, std::min(N, c->R));
+  CHK(ready_estep(c, c->dual_lowrank));
+  CHK(ensure_lambda(c));
+  // under the low-rank plan the blocks come without the reference's 1e-6 diagonal jitter (1e-6 relative), and - as in the
+  // Laplace E-step - only the sum over trials of post_vsmGP is accumulated unless keep_trial_vsmgp is set
+  const bool sum_only = c->plan_lowrank && !c->keep_trial_vsmgp;
+  c->pacc_used = false; c->pacc_valid = false;
+  HIPC(hipMemsetAsync(c->Pacc, 0, (size_t)c->Tp * c->Tp * c->p * sizeof(double), c->st));
+  c->eC = c->hC; c->ed = c->hd; c->etau = c->htau;
   const int q = c->q;
   const long long ld = c->ld;
   double total = 0.0;
@@ -2585,8 +2645,9 @@ int pgpfa_dual_finalize(pgpfa_ctx* c, int n, const int32_t* idx, const double* l
     CHK(dual_common(c, nb, &sB, &sD, &vKv));
     // posterior mean -K C_big (lambda - y) (inference.py:194) and covariance blocks (inference.py:188-191)
     hipLaunchKernelGGL(negate_rows_kernel, dim3((c->n + 255) / 256, nb), dim3(256), 0, c->st, c->KD, ld, c->Xc, ld, c->n, c->ident);
-    CHK(posterior_blocks(c, nb, 1.0 + 1e-6, true));
-    for (int t : tos) c->vsmgp_ok[t] = 1;
+    if (c->plan_lowrank) CHK(posterior_blocks(c, nb, 1.0, true, sum_only));
+    else CHK(posterior_blocks(c, nb, 1.0 + 1e-6, true));
+    for (int t : tos) c->vsmgp_ok[t] = sum_only ? 0 : 1;
     hipLaunchKernelGGL(scatter_rows_kernel, dim3((c->n + 255) / 256, nb), dim3(256), 0, c->st, c->Xc, ld, c->n, c->Xmode, c->trial_of_slot);
     for (int t_ : tos) c->mode_serial[t_] = -10;
     // negLogPosteriorUnNorm at the VI mean (inference.py:333)
@@ -2604,6 +2665,7 @@ int pgpfa_dual_finalize(pgpfa_ctx* c, int n, const int32_t* idx, const double* l
     }
   }
   CHK(remember_trials(c, tr.v));
+  c->pacc_valid = c->pacc_used;
   if (nlp_sum) *nlp_sum = total;
   return 0;
 }

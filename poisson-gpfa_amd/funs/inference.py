@@ -103,6 +103,7 @@ def laplace_hessian(experiment, params, X, trial=0):
 # 'device': the dual optimisations of all trials run as lockstep L-BFGS on the GPU (pgpfa_dual_lbfgs); 'scipy': the
 # reference's per-trial scipy L-BFGS-B calls (same options), driven concurrently with batched device evaluations
 DUAL_SOLVER = 'device'
+DUAL_LOWRANK = False
 
 
 class _ConcurrentProblems:
@@ -197,6 +198,10 @@ def dualVariational(experiment, params, optimizeLogLambda=False, prevOptimRes=No
     mine = trial_idx[lo:hi]
     m = sess.q * sess.T
     ctx = sess.ctx
+    # DUAL_LOWRANK lets the device solver evaluate the dual through the low-rank covariance engine when that pays (large
+    # xdim*T): it is the dual WITHOUT the reference's 1e-6 diagonal jitter (inference.py:190), which on stiff GP priors
+    # moves the posterior covariance blocks by up to ~1 % - hence off by default
+    ctx.set_option('dual_lowrank', 1 if (DUAL_SOLVER == 'device' and DUAL_LOWRANK) else 0)
     if DUAL_SOLVER == 'device' and len(mine):
         # all trials in lockstep on the device, in rho = log(lambda); same optimum as either of the reference's variants
         if prevOptimRes is None:

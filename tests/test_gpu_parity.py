@@ -675,3 +675,51 @@ def test_device_lbfgs_dual_solver_matches_scipy_driver(funs_mod):
     # the dual optimum of the device solver is at least as low (it runs to the same relative-decrease test)
     assert vlb_d <= vlb_s + 1e-5
     assert np.all(ir_d.dual_iterations > 0)
+
+
+def test_dual_evaluation_lowrank_engine(c1):
+    """Dual cost / gradient through the low-rank engine (log det via Sylvester's identity) against plain numpy on the
+    UNJITTERED dual (the engine cannot form the reference's 1e-6 diagonal jitter), and against the dense jitter-faithful
+    evaluation within the size of that jitter's effect; a full dual optimisation + posterior under both."""
+    from funs import _hip
+    rng = np.random.default_rng(4)
+    idx = np.array([0, 5, 11, 19], dtype=np.int32)
+    q, p, T = 30, 3, 100
+    lam = 0.05 + 0.5 * rng.random((4, q * T))
+    out = {}
+    for lowrank in (0, 1):
+        ctx = _hip.Context(q, p, T, 20, c1['binSize'])
+        try:
+            ctx.upload_counts(c1['Y'])
+            ctx.set_option('cov_mode', 2 if lowrank else 1)
+            ctx.set_option('dual_lowrank', lowrank)
+            ctx.set_params(c1['init_C'], c1['init_d'], c1['init_tau'])
+            cost, grad = ctx.dual_costgrad_batch(idx, lam)
+            assert ctx.info('plan_lowrank') == float(lowrank)
+            rho, fopt, iters = ctx.dual_lbfgs(idx, np.full((4, q * T), np.log(0.5)))
+            if not lowrank:
+                rho_ref = rho            # posterior blocks of both engines are compared at the same lambda
+            nlp = ctx.dual_finalize(idx, np.exp(rho_ref))
+            ctx.mstep_precomp()
+            out[lowrank] = (cost, grad, fopt, nlp, ctx.post_mean(idx), ctx.post_vsm(idx), ctx.pautosum())
+        finally:
+            ctx.close()
+    d, l = out[0], out[1]
+    # (1) plain numpy, no jitter: D(lam) = 0.5 v^T K v - d_big^T (lam - y) - 0.5 log det(K^-1 + C_big diag(lam) C_big^T) + sum lam (log lam - 1)
+    K_big = orc.make_K_big(orc.make_K(c1['init_tau'], T, c1['binSize']))
+    C_big, d_big = orc.make_Cd_big(c1['init_C'], c1['init_d'], T)
+    Kinv_big = np.linalg.inv(K_big)
+    for i, tr in enumerate(idx):
+        y = c1['Ys'][tr].reshape(-1)
+        v = C_big @ (lam[i] - y)
+        H = Kinv_big + (C_big * lam[i][None, :]) @ C_big.T
+        Sigma = np.linalg.inv(H)
+        ref_cost = 0.5 * v @ K_big @ v - d_big @ (lam[i] - y) - 0.5 * np.linalg.slogdet(H)[1] + np.sum(lam[i] * (np.log(lam[i]) - 1.0))
+        ref_grad = C_big.T @ (K_big @ v) - d_big + np.log(lam[i]) - 0.5 * np.einsum('im,ij,jm->m', C_big, Sigma, C_big)
+        assert abs(l[0][i] - ref_cost) <= 1e-9 * abs(ref_cost)
+        assert rel(l[1][i], ref_grad) <= 1e-8
+    # (2) the dense evaluation carries the reference's jitter: 0.5 * 1e-6 * sum_i Sigma_ii H_ii in the cost, up to ~1 % in the blocks
+    assert np.max(np.abs(l[0] - d[0]) / np.abs(d[0])) <= 2e-4
+    assert rel(l[1], d[1]) <= 5e-2
+    assert np.max(np.abs(l[2] - d[2]) / np.abs(d[2])) <= 2e-4
+    assert np.max(np.abs(l[4] - d[4])) <= 1e-9 and rel(l[5], d[5]) <= 3e-2 and rel(l[6], d[6]) <= 3e-2

@@ -8,7 +8,9 @@ import scipy.optimize as op
 import bench, funs
 from funs import _session
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-q, p, T, _ = bench.CONFIGS['c2']
+cfg = sys.argv[2] if len(sys.argv) > 2 else 'c2'
+funs.inference.DUAL_LOWRANK = (len(sys.argv) > 3 and sys.argv[3] == 'lowrank')
+q, p, T, _ = bench.CONFIGS[cfg]
 true_params, Ys = bench.synth_shard(q, p, T, R, 12, 0)
 exp = bench.Shard(Ys, 10.0)
 params = {k: np.asarray(v, dtype=np.float64) for k, v in true_params.items()}
@@ -19,8 +21,8 @@ funs.inference.dualVariational(bench.Shard(Ys[:2], 10.0), params)            # w
 t0 = time.time()
 infRes, nll, vlb, opt = funs.inference.dualVariational(exp, params)
 t_dev = time.time() - t0
-print('device L-BFGS: %d trials in %.2f s  (nll %.4f, vlb %.4f, iterations %d..%d)' % (R, t_dev, nll, vlb, infRes.dual_iterations.min(),
-                                                                                      infRes.dual_iterations.max()))
+print('device L-BFGS (%s, low-rank dual %s, plan_lowrank %d): %d trials in %.2f s  (nll %.4f, vlb %.4f, iterations %d..%d)' % (
+    cfg, funs.inference.DUAL_LOWRANK, sess.ctx.info('plan_lowrank'), R, t_dev, nll, vlb, infRes.dual_iterations.min(), infRes.dual_iterations.max()))
 if os.environ.get('PROBE_SCIPY', '1') == '1':
     funs.inference.DUAL_SOLVER = 'scipy'
     t0 = time.time()
@@ -35,12 +37,15 @@ m = q * T
 ctx = sess.ctx
 t0 = time.time()
 nev = 0
-for tr in range(4):
+nser = 4 if cfg != 'c3' else 0
+for tr in range(nser):
     def f(x, tr=tr):
         global nev
         nev += 1
         return ctx.dual_costgrad(tr, x)
     op.fmin_l_bfgs_b(func=lambda x: f(x)[0], x0=np.zeros(m) + 0.5, fprime=lambda x: f(x)[1], bounds=[(1e-10, None)] * m, factr=1e7, disp=False)
+if nser == 0:
+    sys.exit(0)
 t_ser = (time.time() - t0) / 4
 print('serial scipy: %.2f s per trial (%d callback calls each) -> %.1f s for %d trials; device L-BFGS speed-up %.0fx'
       % (t_ser, nev // 4, t_ser * R, R, t_ser * R / t_dev))
