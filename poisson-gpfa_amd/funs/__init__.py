@@ -7,6 +7,6 @@ works as with the reference when the directory that contains this package
 (`poisson-gpfa_amd/`) is on sys.path.  Compute goes through libpgpfa_hip.so (HIP, gfx950);
 there is no CPU fallback.
 """
-from . import util, inference, learning, engine  # noqa: F401
+from . import util, inference, learning, engine, mcmc  # noqa: F401
 
-__all__ = ['util', 'inference', 'learning', 'engine']
+__all__ = ['util', 'inference', 'learning', 'engine', 'mcmc']
