@@ -133,9 +133,23 @@ class PPGPFAfit():
                         verbose=verbose, updateCdJointly=updateCdJointly, hessTol=hessTol)
                     nextParams = newParams
                     self.invPriorCovs.append(priorCov)
+                elif onlineParamUpdateMethod == 'hess':                     # reference engine.py:354-368
+                    newParams, learnDet, priorCov = learning.updateParamsWithPrior(
+                        oldParams=params, infRes=infRes, experiment=sub, CdOptimMethod=CdOptimMethod,
+                        tauOptimMethod=tauOptimMethod, regularizer_stepsize_Cd=step_cd[n],
+                        regularizer_stepsize_tau=step_tau[n], prevInvPriorCov=self.invPriorCovs[-1], covOpts='useHessian',
+                        verbose=verbose, updateCdJointly=updateCdJointly, hessTol=hessTol)
+                    nextParams = newParams
+                    self.invPriorCovs.append(priorCov)
+                elif onlineParamUpdateMethod == 'grad':                     # reference engine.py:384-397
+                    newParams, learnDet, hess = learning.updateParamsWithGradDescent(
+                        oldParams=params, infRes=infRes, experiment=sub, stepSize=step_cd[n], cumHess=self.cumHess[-1],
+                        regularizer_stepsize_tau=step_tau[n], tauOptimMethod=tauOptimMethod, verbose=verbose,
+                        updateCdJointly=updateCdJointly, hessTol=hessTol)
+                    self.cumHess.append(self.cumHess[-1] + hess)
+                    nextParams = newParams
                 else:
-                    raise NotImplementedError("onlineParamUpdateMethod '%s': the finite-difference-Hessian variants "
-                                              "('hess', 'grad') are outside the GPU hot path" % onlineParamUpdateMethod)
+                    raise ValueError("unknown onlineParamUpdateMethod '%s'" % onlineParamUpdateMethod)
                 learningTime.append(time.time() - before)
                 if fullyUpdateTau:
                     nextParams['tau'] = newParams['tau']

@@ -175,12 +175,59 @@ def learnLTparams(oldParams, infRes, experiment, CdOptimMethod, CdMaxIter=None, 
     return newC, newd, resCd.fun
 
 
+def MStepObservationCostWithPrior(vecCd, oldParams, xdim, ydim, experiment, infRes, invPriorCov):
+    """reference learning.py:445-486: the (C,d) cost minus 0.5 (v - v_old)^T invPriorCov (v - v_old), invPriorCov a full
+    (negative definite) matrix; the data term runs on the device, the quadratic form on the host."""
+    sess = _resident_session(infRes, experiment, xdim)
+    dv = np.asarray(vecCd, dtype=np.float64) - util.CdtoVecCd(oldParams['C'], oldParams['d'])
+    return sess.ctx.mstep_cd_costgrad(vecCd)[0] - 0.5 * dv @ np.asarray(invPriorCov) @ dv
+
+
+def MStepObservationCostWithPrior_grad(vecCd, oldParams, xdim, ydim, experiment, infRes, invPriorCov):
+    """reference learning.py:488-534"""
+    sess = _resident_session(infRes, experiment, xdim)
+    dv = np.asarray(vecCd, dtype=np.float64) - util.CdtoVecCd(oldParams['C'], oldParams['d'])
+    return sess.ctx.mstep_cd_costgrad(vecCd)[1] - np.asarray(invPriorCov) @ dv
+
+
+def _learn_cd_full_prior(oldParams, infRes, experiment, CdOptimMethod, prevInvPriorCov, hessTol, verbose):
+    """covOpts='useHessian' (reference learning.py:546-549, 607-630): the new prior precision is minus the finite-difference
+    Jacobian of the regularised gradient at the old parameters (4 q(p+1) device cost/gradient passes), then the same scipy
+    call as the other variants with that full matrix."""
+    ydim, xdim = np.shape(oldParams['C'])
+    sess = _resident_session(infRes, experiment, xdim)
+    old = util.CdtoVecCd(oldParams['C'], oldParams['d'])
+    prev = np.asarray(prevInvPriorCov, dtype=np.float64)
+
+    def grad_prev(v):
+        return sess.ctx.mstep_cd_costgrad(v)[1] - prev @ (v - old)
+    invPriorCov = -util.approx_jacobian(old, grad_prev, hessTol)
+
+    def evaluate(v):
+        cost, grad = sess.ctx.mstep_cd_costgrad(v)
+        dv = v - old
+        return cost - 0.5 * dv @ invPriorCov @ dv, grad - invPriorCov @ dv
+    cache = _CostGradCache(evaluate)
+    kw = dict(fun=cache.fun, x0=old, jac=cache.jac, method=CdOptimMethod, options={'disp': verbose, 'gtol': 1e-10})
+    if CdOptimMethod == 'L-BFGS-B':
+        kw['bounds'] = [(None, None)] * (xdim * ydim + ydim)
+    resCd = op.minimize(**kw)
+    newC, newd = util.vecCdtoCd(resCd.x, xdim, ydim)
+    return newC, newd, resCd.fun, invPriorCov
+
+
 def learnLTparamsWithPrior(oldParams, infRes, experiment, CdOptimMethod, regularizer_stepsize_Cd, prevInvPriorCov,
                            covOpts='useDiag', updateCdJointly=True, hessTol=1e-5, verbose=False):
-    """reference learning.py:536-676, 'useDiag' prior with joint (C,d) update (the engine default)."""
-    if covOpts != 'useDiag' or not updateCdJointly:
-        raise NotImplementedError("only covOpts='useDiag' with updateCdJointly=True is built for the GPU path "
-                                  "(the finite-difference Hessian variants are outside the hot path)")
+    """reference learning.py:536-676 with joint (C,d) update: 'useDiag' (the engine default, prior on the device) and
+    'useHessian' (finite-difference prior precision, full matrix on the host)."""
+    if not updateCdJointly:
+        raise NotImplementedError('updateCdJointly=False raises in the reference itself (learning.py:393) and is not built')
+    if covOpts == 'useHessian':
+        if CdOptimMethod == 'newton':
+            raise ValueError("CdOptimMethod='newton' needs the diagonal prior of covOpts='useDiag'")
+        return _learn_cd_full_prior(oldParams, infRes, experiment, CdOptimMethod, prevInvPriorCov, hessTol, verbose)
+    if covOpts != 'useDiag':
+        raise ValueError("covOpts must be 'useDiag' or 'useHessian'")
     ydim, xdim = np.shape(oldParams['C'])
     sess = _resident_session(infRes, experiment, xdim)
     old = util.CdtoVecCd(oldParams['C'], oldParams['d'])
@@ -563,10 +610,36 @@ def updateParams(oldParams, infRes, experiment, CdOptimMethod='BFGS', CdMaxIter=
     return {'C': newC, 'd': newd, 'tau': newTau}, {'Cd': obsOptimDetails, 'tau': dynOptimDetails}
 
 
+def learnLTparamsGradDescent(oldParams, infRes, experiment, stepSize, cumHess, updateCdJointly=True, hessTol=1e-5):
+    """reference learning.py:874-907: one damped Newton-like step, vecCd <- vecCd - stepSize * h^-1 g with h the finite-difference
+    Jacobian of the gradient of Q = -cost (4 q(p+1) device passes)."""
+    if not updateCdJointly:
+        raise NotImplementedError('updateCdJointly=False raises in the reference itself (learning.py:393) and is not built')
+    ydim, xdim = np.shape(oldParams['C'])
+    sess = _resident_session(infRes, experiment, xdim)
+    vecCd = util.CdtoVecCd(oldParams['C'], oldParams['d'])
+
+    def q_grad(v):
+        return -sess.ctx.mstep_cd_costgrad(v)[1]
+    g = q_grad(vecCd)
+    h = util.approx_jacobian(vecCd, q_grad, hessTol)
+    newC, newd = util.vecCdtoCd(vecCd - stepSize * np.linalg.inv(h) @ g, xdim, ydim)
+    return newC, newd, h
+
+
+def updateParamsWithGradDescent(oldParams, infRes, experiment, stepSize, cumHess, regularizer_stepsize_tau, tauOptimMethod,
+                                updateCdJointly=True, verbose=False, hessTol=1e-5):
+    """reference learning.py:909-945 ('grad' online mode)"""
+    newC, newd, hess = learnLTparamsGradDescent(oldParams, infRes, experiment, stepSize, cumHess, updateCdJointly, hessTol)
+    newTau, dynOptimDetails = learnGPparamsWithPrior(oldParams, infRes, experiment, tauOptimMethod, regularizer_stepsize_tau)
+    return {'C': newC, 'd': newd, 'tau': newTau}, {'Cd': None, 'tau': dynOptimDetails}, hess
+
+
 def updateParamsWithPrior(oldParams, infRes, experiment, CdOptimMethod, tauOptimMethod, regularizer_stepsize_Cd,
                           regularizer_stepsize_tau, prevInvPriorCov, covOpts='useHessian', verbose=False,
                           updateCdJointly=True, hessTol=1e-5):
-    """reference learning.py:833-866 (covOpts='useDiag' is what the engine's default 'diag' mode passes)."""
+    """reference learning.py:833-866 (covOpts='useDiag' is what the engine's default 'diag' mode passes, 'useHessian' the
+    'hess' mode)."""
     if verbose:
         print('Learning C,d...')
     newC, newd, obsOptimDetails, invPriorCov = learnLTparamsWithPrior(

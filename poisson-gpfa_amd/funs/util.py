@@ -62,6 +62,30 @@ def makeK_big(params, trialDur, binSize, epsNoise=0.001):
     return K_big, K
 
 
+# -- finite-difference Jacobian (reference util.py:377-434) -------------------------------------------------
+def approx_jacobian(x, func, epsilon, *args):
+    """Jacobian of the vector function func at x by the reference's fourth-order central differences,
+    J[:, i] = (-f(x+2h) + 8 f(x+h) - 8 f(x-h) + f(x-2h)) / (12 h_i), with its step rule: h = epsilon / 2 (a scalar epsilon for
+    every coordinate) or, for epsilon None, EPS^(1/3) * max(|x|, 0.1) / 2 (statsmodels' _get_epsilon with s = 3)."""
+    x0 = np.atleast_1d(np.asarray(x, dtype=np.float64))
+    n = x0.size
+    if epsilon is None:
+        h = np.finfo(float).eps ** (1.0 / 3.0) * np.maximum(np.abs(x0), 0.1)
+    elif np.isscalar(epsilon):
+        h = np.full(n, float(epsilon))
+    else:
+        h = np.asarray(epsilon, dtype=np.float64)
+    h = h / 2.0
+    f0 = np.asarray(func(x0, *args))
+    jac = np.zeros((f0.size, n))
+    for i in range(n):
+        dx = np.zeros(n)
+        dx[i] = h[i]
+        jac[:, i] = (-np.asarray(func(x0 + 2 * dx, *args)) + 8 * np.asarray(func(x0 + dx, *args))
+                     - 8 * np.asarray(func(x0 - dx, *args)) + np.asarray(func(x0 - 2 * dx, *args))) / (12 * h[i])
+    return jac
+
+
 # -- leave-one-neuron-out prediction (reference util.py:289-334) --------------------------------------------
 def leaveOneOutPrediction(params, experiment):
     """For every trial and neuron: posterior mode of the latents given all OTHER neurons, then the held-out neuron's

@@ -740,3 +740,26 @@ def test_elliptical_slice_mcmc_chain_vs_reference(funs_mod, c1, c1_experiment):
     assert chain.shape == g['chain'].shape
     assert np.max(np.abs(chain - g['chain'])) <= 1e-9
     assert np.all(np.isfinite(chain)) and np.max(np.abs(np.diff(chain, axis=0))) > 0      # the chain moves
+
+
+@pytest.mark.parametrize('mode', ['hess', 'grad'])
+def test_online_em_finite_difference_variants_vs_reference(funs_mod, c1, c1_experiment, mode):
+    """The 'hess' / 'grad' online updates (engine.py:354-397): finite-difference Jacobians of the device gradient
+    (util.approx_jacobian's fourth-order rule) and full-matrix priors on the host, against the reference's own run."""
+    g = load_golden('c1_em_online_fd.npz')
+    init = {k: v.copy() for k, v in c1['init'].items()}
+    np.random.seed(1)
+    fit = funs_mod.engine.PPGPFAfit(c1_experiment, initParams=init, inferenceMethod='laplace', EMmode='Online', maxEMiter=3,
+                                    batchSize=5, onlineParamUpdateMethod=mode, CdOptimMethod='TNC', tauOptimMethod='TNC', quiet=True,
+                                    onlineWarmStart=False)
+    nll = np.asarray(fit.posteriorLikelihood)
+    # same slack as the 'diag' variant: the reference's early-stopped E-step modes and TNC's stopping noise
+    assert np.max(np.abs(nll - g[mode + '_nll'])) <= 5e-3
+    for i in range(1, 4):
+        assert rel(fit.paramSeq[i]['C'], g[mode + '_seq_C'][i]) <= 5e-3
+        assert rel(fit.paramSeq[i]['d'], g[mode + '_seq_d'][i]) <= 5e-3
+        assert rel(fit.paramSeq[i]['tau'], g[mode + '_seq_tau'][i]) <= 5e-3
+    if mode == 'hess':
+        assert rel(fit.invPriorCovs[1], g['hess_invPriorCov1']) <= 5e-3
+    else:
+        assert rel(fit.cumHess[1], g['grad_cumHess1']) <= 5e-3
