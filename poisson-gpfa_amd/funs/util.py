@@ -107,6 +107,50 @@ def leaveOneOutPrediction(params, experiment):
     return y_loc, float(err_loc)
 
 
+# -- latent-dimensionality cross-validation (reference util.py:180-275) -------------------------------------
+def splitTrainingTestDataset(experiment, numTrainingTrials, numTestTrials):
+    """First numTrainingTrials trials / the numTestTrials after them, as shallow copies (reference util.py:263-275)."""
+    if numTestTrials + numTrainingTrials > experiment.numTrials:
+        print('Error: Number of training trials and test trials must sum to less than the number of available trials.')
+    trainingSet, testSet = copy.copy(experiment), copy.copy(experiment)
+    trainingSet.data = experiment.data[:numTrainingTrials]
+    trainingSet.numTrials = numTrainingTrials
+    testSet.data = experiment.data[numTrainingTrials:numTrainingTrials + numTestTrials]
+    testSet.numTrials = numTestTrials
+    for part in (trainingSet, testSet):                   # the copies are data sets of their own on the device
+        part.__dict__.pop('_pgpfa_parent', None)
+        part.__dict__.pop('batchTrIdx', None)
+    return trainingSet, testSet
+
+
+class crossValidation:
+    """reference util.py:180-249: for xdim = 1..maxXdim fit on the training split and score the leave-one-neuron-out
+    prediction error on the test split; optimXdim is the arg-min.  learningMethod: 'batch', 'diag', 'hess' or 'grad'."""
+
+    def __init__(self, experiment, numTrainingTrials=10, numTestTrials=2, maxXdim=6, maxEMiter=3, batchSize=5,
+                 inferenceMethod='laplace', learningMethod='batch', quiet=True):
+        from . import engine
+        if learningMethod not in ('batch', 'diag', 'hess', 'grad'):
+            raise ValueError("learningMethod must be 'batch', 'diag', 'hess' or 'grad'")
+        trainingSet, testSet = splitTrainingTestDataset(experiment, numTrainingTrials, numTestTrials)
+        self.errs, self.fits = [], []
+        for xdimFit in range(1, maxXdim + 1):
+            initParams = initializeParams(xdimFit, trainingSet.ydim, trainingSet)
+            if learningMethod == 'batch':
+                fit = engine.PPGPFAfit(experiment=trainingSet, initParams=initParams, inferenceMethod=inferenceMethod,
+                                       EMmode='Batch', maxEMiter=maxEMiter, quiet=quiet)
+            else:
+                fit = engine.PPGPFAfit(experiment=trainingSet, initParams=initParams, inferenceMethod=inferenceMethod,
+                                       EMmode='Online', onlineParamUpdateMethod=learningMethod, maxEMiter=maxEMiter,
+                                       batchSize=batchSize, quiet=quiet)
+            _, predErr = leaveOneOutPrediction(fit.optimParams, testSet)
+            self.errs.append(predErr)
+            self.fits.append(fit)
+        self.inferenceMethod, self.learningMethod = inferenceMethod, learningMethod
+        self.optimXdim = int(np.argmin(self.errs)) + 1
+        self.maxXdim = maxXdim
+
+
 # -- minibatches (reference util.py:449-473) ---------------------------------------------------------------
 def subsampleTrials(experiment, batchSize):
     """Same draw from the global legacy RNG as the reference (np.random.choice without replacement);

@@ -763,3 +763,18 @@ def test_online_em_finite_difference_variants_vs_reference(funs_mod, c1, c1_expe
         assert rel(fit.invPriorCovs[1], g['hess_invPriorCov1']) <= 5e-3
     else:
         assert rel(fit.cumHess[1], g['grad_cumHess1']) <= 5e-3
+
+
+def test_cross_validation_driver_vs_reference(funs_mod, c1):
+    """util.crossValidation (util.py:180-249): fits for xdim = 1..3 on a training split, leave-one-neuron-out error on the
+    test split - against the reference's own run (same seed; its early-stopping slack applies)."""
+    g = load_golden('c1_cv.npz')
+    exp = Experiment(c1['Ys'], c1['binSize'])
+    exp.ydim, exp.numTrials = 30, 20
+    np.random.seed(0)
+    cv = funs_mod.util.crossValidation(exp, numTrainingTrials=10, numTestTrials=2, maxXdim=3, maxEMiter=2, learningMethod='batch')
+    assert cv.optimXdim == int(g['optimXdim'])
+    assert np.max(np.abs(np.asarray(cv.errs) - g['errs']) / g['errs']) <= 5e-3
+    assert rel(cv.fits[2].optimParams['tau'], g['tau_fit3']) <= 5e-3
+    tr, te = funs_mod.util.splitTrainingTestDataset(exp, 10, 2)
+    assert len(tr.data) == 10 and len(te.data) == 2 and te.data[0] is exp.data[10]
