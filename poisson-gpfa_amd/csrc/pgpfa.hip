@@ -11,6 +11,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <string>
 #include <type_traits>
@@ -52,10 +53,12 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 struct Prof {
   bool on = false;
-  std::vector<hipEvent_t> pool;
-  size_t used = 0;
-  struct Rec { int tag; size_t e0, e1; double flops; };
-  std::vector<Rec> recs;
+  int only_tag = -1;                 // >= 0: time launches of this tag only (option "profile" = 2: the GEMM kernel)
+  std::vector<hipEvent_t> pool;      // every event ever created (destroyed with the context)
+  std::vector<hipEvent_t> idle;      // events free for reuse
+  struct Rec { int tag; hipEvent_t e0, e1; double flops; };
+  std::deque<Rec> recs;              // launches whose events have not been read yet, oldest first
+  bool open = false;                 // prof_begin recorded, prof_end pending
   std::map<int, double> ms, flops, count;
 };
 constexpr int TAU_MULTI_MAX = 4;  // candidate points per latent in one batched timescale cost/gradient pass
@@ -197,36 +200,55 @@ int ensure_hibuf(pgpfa_ctx* c, size_t len) {
 }
 
 // ---- profiling (HIP events on the context stream; summed on demand) -------------------------------
-void prof_begin(pgpfa_ctx* c, int tag, double flops) {
-  Prof& P = c->prof;
-  if (!P.on) return;
-  while (P.pool.size() < P.used + 2) {
+// Finished launches are read back (hipEventQuery, no synchronisation) and their events recycled while the run goes on,
+// so the number of outstanding events stays bounded however long profiling stays switched on.
+void prof_harvest(Prof& P, bool all) {
+  while (!P.recs.empty()) {
+    Prof::Rec& r = P.recs.front();
+    if (!all && hipEventQuery(r.e1) != hipSuccess) break;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+      P.ms[r.tag] += ms;
+      P.flops[r.tag] += r.flops;
+      P.count[r.tag] += 1;
+    }
+    P.idle.push_back(r.e0);
+    P.idle.push_back(r.e1);
+    P.recs.pop_front();
+  }
+  (void)hipGetLastError();           // hipEventQuery reports hipErrorNotReady through the sticky error as well
+}
+hipEvent_t prof_event(Prof& P) {
+  if (P.idle.empty()) {
     hipEvent_t e;
     hipEventCreate(&e);
     P.pool.push_back(e);
+    return e;
   }
-  hipEventRecord(P.pool[P.used], c->st);
-  P.recs.push_back({tag, P.used, P.used + 1, flops});
-  P.used += 2;
+  hipEvent_t e = P.idle.back();
+  P.idle.pop_back();
+  return e;
+}
+void prof_begin(pgpfa_ctx* c, int tag, double flops) {
+  Prof& P = c->prof;
+  if (!P.on || (P.only_tag >= 0 && tag != P.only_tag)) return;
+  if (P.recs.size() >= 256 && (P.recs.size() & 63) == 0) prof_harvest(P, false);
+  Prof::Rec r{tag, prof_event(P), prof_event(P), flops};
+  hipEventRecord(r.e0, c->st);
+  P.recs.push_back(r);
+  P.open = true;
 }
 void prof_end(pgpfa_ctx* c) {
   Prof& P = c->prof;
-  if (!P.on) return;
-  hipEventRecord(P.pool[P.recs.back().e1], c->st);
+  if (!P.on || !P.open) return;
+  hipEventRecord(P.recs.back().e1, c->st);
+  P.open = false;
 }
 void prof_collect(pgpfa_ctx* c) {
   Prof& P = c->prof;
-  if (!P.on) return;
+  if (P.recs.empty()) return;
   hipStreamSynchronize(c->st);
-  for (auto& r : P.recs) {
-    float ms = 0.f;
-    hipEventElapsedTime(&ms, P.pool[r.e0], P.pool[r.e1]);
-    P.ms[r.tag] += ms;
-    P.flops[r.tag] += r.flops;
-    P.count[r.tag] += 1;
-  }
-  P.recs.clear();
-  P.used = 0;
+  prof_harvest(P, true);
 }
 
 // algorithmic flops of one GEMM launch (useful multiply-adds x2, triangular structure respected)
@@ -845,8 +867,13 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
   else if (k == "chunk_trials") { if (c->B > 0) return fail("chunk_trials must be set before the first E-step"); c->chunk_opt = (int)v; }
   else if (k == "eps_noise") c->eps = v;
   else if (k == "profile") {
+    // 0: off (the accumulated sums stay readable), 1: time every tagged launch, 2: GEMM launches only
+    if (v != 0.0) {
+      prof_collect(c);
+      c->prof.ms.clear(); c->prof.flops.clear(); c->prof.count.clear();
+    }
     c->prof.on = (v != 0.0);
-    c->prof.ms.clear(); c->prof.flops.clear(); c->prof.count.clear(); c->prof.recs.clear(); c->prof.used = 0;
+    c->prof.only_tag = (v == 2.0) ? TAG_GEMM : -1;
   } else return fail("unknown option '%s'", key);
   return 0;
 }
