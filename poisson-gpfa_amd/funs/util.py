@@ -180,9 +180,12 @@ class dataset:
     """Trials of population spike counts sampled from  x_k ~ GP(0, K(tau_k)),  y ~ Poisson(exp(Cx+d)).
 
     Attributes as in the reference: data (list of {'X','Y'}), xdim, ydim, T, trialDur, binSize, numTrials,
-    seed, params.  `sampler='reference'` reproduces the reference's global-RNG stream bit for bit
-    (multivariate_normal on the (xdim*T)^2 covariance: small sizes only); `sampler='cholesky'` draws the
-    same distributions per latent through T x T factors from numpy's Generator (for the large configs).
+    seed, params.  `sampler='reference'` reproduces the reference's global-RNG stream bit for bit: the
+    reference calls np.random.multivariate_normal on the (xdim*T)^2 covariance once per trial (util.py:738-741),
+    which repeats the same SVD of K_big every time; here the SVD is taken once and each trial is the same
+    standard_normal draw times the same sqrt(s) * v matrix - identical bits, without the per-trial
+    (xdim*T)^3 (minutes per trial at config 3).  `sampler='cholesky'` draws the same distributions per latent
+    through T x T factors from numpy's Generator (no (xdim*T)^2 matrix at all).
     """
 
     def __init__(self, trialDur=1000, binSize=10, drawSameX=False, numTrials=20, xdim=3, ydim=30, seed=12, dOffset=-1,
@@ -211,7 +214,14 @@ class dataset:
             K_big = np.zeros((xdim * T, xdim * T))
             for k in range(xdim):
                 K_big[k * T:(k + 1) * T, k * T:(k + 1) * T] = K[k]
-            draw = lambda: np.reshape(np.random.multivariate_normal(np.zeros(T * xdim), K_big, 1), [xdim, T])
+            _, sv, vt = np.linalg.svd(K_big)                       # what legacy multivariate_normal factors cov with
+            mix = np.sqrt(sv)[:, None] * vt
+            mean = np.zeros(T * xdim)
+
+            def draw():
+                x = np.dot(np.random.standard_normal((1, T * xdim)).reshape(-1, T * xdim), mix)
+                x += mean
+                return np.reshape(x, [xdim, T])
             pois = lambda lam: np.random.poisson(lam=lam)
         elif sampler == 'cholesky':
             rng = np.random.default_rng(seed)

@@ -68,6 +68,19 @@ def test_dataset_generator_reproduces_reference_stream(c1):
     assert np.array_equal(ds.params['C'], c1['true_C']) and np.array_equal(ds.params['d'], c1['true_d'])
     big = util.dataset(trialDur=400, numTrials=3, xdim=2, ydim=6, seed=3, sampler='cholesky')
     assert big.data[0]['Y'].shape == (6, 40) and big.T == 40
+    # the one-SVD sampler against numpy's own legacy multivariate_normal / poisson calls in the reference's order
+    # (util.py:705-750) at a size and seed the golden file does not cover, latents included
+    ds = util.dataset(trialDur=300, numTrials=4, xdim=3, ydim=7, seed=41)
+    np.random.seed(41)
+    C = np.random.rand(7, 3) - 0.5
+    d = np.random.rand(7) * (-2) - 1
+    tau = np.abs(np.random.rand(3)) + 0.01
+    from oracle import pgpfa_oracle as orc
+    K_big = orc.make_K_big(orc.make_K(tau, 30, 10.0))
+    for tr in ds.data:
+        X = np.reshape(np.random.multivariate_normal(np.zeros(90), K_big, 1), [3, 30])
+        Y = np.random.poisson(lam=np.exp(C @ X + d[:, None]))
+        assert np.allclose(tr['X'], X, rtol=0, atol=1e-12) and np.array_equal(tr['Y'], Y)
 
 
 def test_subsample_stream_matches_reference(c1_experiment):
