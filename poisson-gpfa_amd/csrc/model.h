@@ -1820,6 +1820,152 @@ __global__ __launch_bounds__(256) void apply_bin_kernel(const double* __restrict
   }
 }
 
+// ---- wide latent states (16 < p <= 32) of the low-rank engine ---------------------------------------------------
+// The per-bin p x p blocks no longer fit 64 bins at a time in LDS and p^2 accumulators no longer fit a lane, so the
+// three per-bin kernels above get a second shape: a block owns `bins` (8 or 4) consecutive bins, 32 threads per bin,
+// thread (bin, k) produces component / row k; the p-vectors being multiplied travel through LDS.  Runtime p, no
+// template; dynamic LDS = wide_lds_bytes(p, bins, arrays).
+constexpr int WIDE_MAX = 32;
+inline int wide_bins(int p) { return p <= 22 ? 8 : 4; }
+inline size_t wide_lds_bytes(int p, int bins, int blocks_per_bin) {
+  return ((size_t)bins * blocks_per_bin * (p * p + 1) + 2 * (size_t)bins * WIDE_MAX) * sizeof(double);
+}
+
+// apply_bin_kernel for wide p.  grid = (ceil(T/bins), ceil(nslots / APPLY_BIN_SLOTS)), block = bins*32
+__global__ void apply_bin_wide_kernel(const double* __restrict__ Gb, const double* __restrict__ A, const double* __restrict__ B2, double scale,
+                                      double* __restrict__ out, long long sV, int T, int p, int nslots, int bins) {
+  extern __shared__ double wsm[];
+  const int pp = p * p, LD = pp + 1;
+  double* Gs = wsm;
+  double* vs = wsm + (size_t)bins * LD;
+  const int t0 = blockIdx.x * bins;
+  const int nt = min(bins, T - t0);
+  for (int e = threadIdx.x; e < nt * pp; e += blockDim.x) {
+    const int t = e / pp;
+    Gs[t * LD + (e - t * pp)] = Gb[(size_t)t0 * pp + e];
+  }
+  __syncthreads();
+  const int bt = threadIdx.x >> 5, k = threadIdx.x & 31;
+  const bool live = bt < nt && k < p;
+  const int t = t0 + bt;
+  const double* g = Gs + bt * LD + k * p;
+  const int s_end = min(nslots, (int)(blockIdx.y + 1) * APPLY_BIN_SLOTS);
+  for (int sl = blockIdx.y * APPLY_BIN_SLOTS; sl < s_end; ++sl) {
+    if (live) {
+      const size_t off = (size_t)sl * sV + (size_t)k * T + t;
+      vs[bt * WIDE_MAX + k] = scale * A[off] + (B2 ? B2[off] : 0.0);
+    }
+    __syncthreads();
+    if (live) {
+      double acc = 0.0;
+      for (int kk = 0; kk < p; ++kk) acc += g[kk] * vs[bt * WIDE_MAX + kk];
+      out[(size_t)sl * sV + (size_t)k * T + t] = acc;
+    }
+    __syncthreads();
+  }
+}
+
+// mix_vsm_kernel for wide p: y <- G_t y for every column of the slab, post_vsm[t] = eps G_t + sum_b (G_t y_b)(G_t y_b)^T.
+// Thread (bin, a) owns row a of the accumulated block (columns c <= a).  grid = (ceil(T/bins), nslots), block = bins*32
+__global__ void mix_vsm_wide_kernel(double* __restrict__ Yt, long long sY, int ldy, const double* __restrict__ G, long long sG, int T, int p,
+                                    int rpad, double eps, double* __restrict__ vsm, const int* __restrict__ slots,
+                                    const int* __restrict__ trial_of_slot, int bins) {
+  extern __shared__ double wsm[];
+  const int pp = p * p, LD = pp + 1;
+  double* Gs = wsm;
+  double* vs = wsm + (size_t)bins * LD;
+  double* ms = vs + (size_t)bins * WIDE_MAX;
+  const int slot = slots[blockIdx.y];
+  const int t0 = blockIdx.x * bins;
+  const int nt = min(bins, T - t0);
+  const double* gbase = G + (size_t)slot * sG + (size_t)t0 * pp;
+  for (int e = threadIdx.x; e < nt * pp; e += blockDim.x) {
+    const int t = e / pp;
+    Gs[t * LD + (e - t * pp)] = gbase[e];
+  }
+  __syncthreads();
+  const int bt = threadIdx.x >> 5, a = threadIdx.x & 31;
+  const bool live = bt < nt && a < p;
+  const double* g = Gs + bt * LD + a * p;
+  double acc[WIDE_MAX];
+#pragma unroll
+  for (int c2 = 0; c2 < WIDE_MAX; ++c2) acc[c2] = 0.0;
+  double* y = Yt + (size_t)slot * sY + (size_t)a * T + t0 + bt;
+  for (int b = 0; b < rpad; ++b) {
+    if (live) vs[bt * WIDE_MAX + a] = y[(size_t)b * ldy];
+    __syncthreads();
+    double m = 0.0;
+    if (live) {
+      for (int kk = 0; kk < p; ++kk) m += g[kk] * vs[bt * WIDE_MAX + kk];
+      y[(size_t)b * ldy] = m;
+      ms[bt * WIDE_MAX + a] = m;
+    }
+    __syncthreads();
+    if (live) {
+#pragma unroll
+      for (int c2 = 0; c2 < WIDE_MAX; ++c2)
+        if (c2 <= a) acc[c2] += m * ms[bt * WIDE_MAX + c2];
+    }
+  }
+  if (live) {
+    double* v = vsm + ((size_t)trial_of_slot[slot] * T + t0 + bt) * pp;
+#pragma unroll
+    for (int c2 = 0; c2 < WIDE_MAX; ++c2)
+      if (c2 <= a) {
+        const double val = eps * g[c2] + acc[c2];
+        v[a * p + c2] = val;
+        v[c2 * p + a] = val;
+      }
+  }
+}
+
+// vsm_finish_kernel for wide p: vsm[t] <- eps G_t + G_t Bt_t G_t in place.  Thread (bin, i) owns row i.
+// grid = (ceil(T/bins), nslots), block = bins*32; LDS holds the V and the G blocks of the block's bins.
+__global__ void vsm_finish_wide_kernel(double* __restrict__ vsm, const double* __restrict__ G, long long sG, int T, int p, double eps,
+                                       const int* __restrict__ slots, const int* __restrict__ trial_of_slot, int bins) {
+  extern __shared__ double wsm[];
+  const int pp = p * p, LD = pp + 1;
+  double* Gs = wsm;
+  double* Vs = wsm + (size_t)bins * LD;
+  const int slot = slots[blockIdx.y];
+  const int t0 = blockIdx.x * bins;
+  const int nt = min(bins, T - t0);
+  const double* gbase = G + (size_t)slot * sG + (size_t)t0 * pp;
+  double* vbase = vsm + ((size_t)trial_of_slot[slot] * T + t0) * pp;
+  for (int e = threadIdx.x; e < nt * pp; e += blockDim.x) {
+    const int t = e / pp;
+    Gs[t * LD + (e - t * pp)] = gbase[e];
+    Vs[t * LD + (e - t * pp)] = vbase[e];
+  }
+  __syncthreads();
+  const int bt = threadIdx.x >> 5, i = threadIdx.x & 31;
+  const bool live = bt < nt && i < p;
+  const double* g = Gs + bt * LD;
+  double* v = Vs + bt * LD;
+  double row[WIDE_MAX];
+  if (live) {
+    // row i of Bt G (only this thread reads or writes row i of V)
+#pragma unroll
+    for (int j = 0; j < WIDE_MAX; ++j) {
+      double sacc = 0.0;
+      if (j < p)
+        for (int m = 0; m < p; ++m) sacc += v[i * p + m] * g[m * p + j];
+      row[j] = sacc;
+    }
+#pragma unroll
+    for (int j = 0; j < WIDE_MAX; ++j)
+      if (j < p) v[i * p + j] = row[j];
+  }
+  __syncthreads();
+  if (live) {
+    for (int j = 0; j < p; ++j) {
+      double sacc = eps * g[i * p + j];
+      for (int m = 0; m < p; ++m) sacc += g[i * p + m] * v[m * p + j];
+      vbase[(size_t)bt * pp + i * p + j] = sacc;
+    }
+  }
+}
+
 // First and second moments of the spike counts over all (trial, bin) samples of the listed trials, EXACT in integer
 // arithmetic: sum[i] = sum y_i, cross[i][j] = sum y_i y_j (what np.mean / np.cov of the concatenated raster are built
 // from: Poisson-PCA initialiser util.py:528-533, spike-count diagnostics engine.py:487-492).

@@ -399,14 +399,14 @@ size_t lowrank_slab_elems(const pgpfa_ctx* c) {
 // engine choice: the low-rank form pays when r << n (long timescales); the dense form is the general one
 bool lowrank_pays(const pgpfa_ctx* c) {
   const double n = c->n, r = c->rpad, T = c->T, p = c->p;
-  if (c->p > 16 || c->rpad < NB || c->rpad * 2 > c->npad) return false;
+  if (c->p > WIDE_MAX || c->rpad < NB || c->rpad * 2 > c->npad) return false;
   if (lowrank_slab_elems(c) > (size_t)c->ld * c->ld) return false;
   const double dense = 0.72 * n * n * n;
   const double lr = 6.0 * T * r * r + 0.7 * r * r * r + p * T * T * r;
   return lr < 0.5 * dense;
 }
 
-bool want_lowrank(const pgpfa_ctx* c) { return c->cov_mode == 2 ? (c->p <= 16 && c->rpad >= NB && lowrank_slab_elems(c) <= (size_t)c->ld * c->ld) : (c->cov_mode == 0 && lowrank_pays(c)); }
+bool want_lowrank(const pgpfa_ctx* c) { return c->cov_mode == 2 ? (c->p <= WIDE_MAX && c->rpad >= NB && lowrank_slab_elems(c) <= (size_t)c->ld * c->ld) : (c->cov_mode == 0 && lowrank_pays(c)); }
 
 size_t ld_bytes(const pgpfa_ctx* c) { return (size_t)c->ld * c->ld * sizeof(double); }
 
@@ -1081,9 +1081,14 @@ static int shared_solve(pgpfa_ctx* c, int nb, const double* R, double* Z) {
     auto apply_bin = [&](const double* a, const double* b2, double scale, double* o) {
       dispatch_pw(c->p, [&](auto pw) {
         constexpr int PW = decltype(pw)::value;
-        if constexpr (PW <= 16)
+        if constexpr (PW <= 16) {
           hipLaunchKernelGGL(apply_bin_kernel<PW>, dim3((c->T + 63) / 64, (nb + APPLY_BIN_SLOTS - 1) / APPLY_BIN_SLOTS), dim3(256), 0, c->st, c->Gbar,
                              a, b2, scale, o, ld, c->T, c->p, nb);
+        } else {
+          const int bins = wide_bins(c->p);
+          hipLaunchKernelGGL(apply_bin_wide_kernel, dim3((c->T + bins - 1) / bins, (nb + APPLY_BIN_SLOTS - 1) / APPLY_BIN_SLOTS), dim3(bins * 32),
+                             wide_lds_bytes(c->p, bins, 1), c->st, c->Gbar, a, b2, scale, o, ld, c->T, c->p, nb, bins);
+        }
       });
     };
     apply_bin(R, nullptr, 1.0, c->Xt);
@@ -1272,16 +1277,21 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool 
     g.slots = c->ident; g.nbatch = nb; g.mode = GEMM_FULL; g.kflags = 0;
     CHK(gemm(c, true, g));
   }
-  if (p > 16) return fail("low-rank covariance engine supports up to 16 latents (p=%d)", p);
+  if (p > WIDE_MAX) return fail("low-rank covariance engine supports up to %d latents (p=%d)", WIDE_MAX, p);
   if (want_vsmgp) {
     // d+e. one pass over Yt: post_vsm[t] = eps G_t + sum_b (G_t y_b)(G_t y_b)^T, and Yt is mixed in place (y <- G_t y) so that
     //      rows (k,.) of the slab become Ymix_k, the GEMM operand of post_vsmGP_k = eps diag(G_t[k][k]) + Ymix_k Ymix_k^T
     prof_begin(c, TAG_VSM, (double)nb * c->n * rpad * (3.0 * p + 1.0));
     dispatch_pw(p, [&](auto pw) {
       constexpr int PW = decltype(pw)::value;
-      if constexpr (PW <= 16)
+      if constexpr (PW <= 16) {
         hipLaunchKernelGGL(mix_vsm_kernel<PW>, dim3((T + 63) / 64, nb), dim3(256), 0, c->st, lw.H, lw.sH, c->ld, c->Gbin, sW, T, p, ract, c->eps,
                            c->vsm, c->ident, c->trial_of_slot);
+      } else {
+        const int bins = wide_bins(p);
+        hipLaunchKernelGGL(mix_vsm_wide_kernel, dim3((T + bins - 1) / bins, nb), dim3(bins * 32), wide_lds_bytes(p, bins, 1), c->st, lw.H, lw.sH,
+                           c->ld, c->Gbin, sW, T, p, ract, c->eps, c->vsm, c->ident, c->trial_of_slot, bins);
+      }
     });
     prof_end(c);
   } else {
@@ -1299,11 +1309,14 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool 
         constexpr int BT = 256 / PW;
         hipLaunchKernelGGL(vsm_finish_kernel<PW>, dim3((T + BT - 1) / BT, nb), dim3(256), 0, c->st, c->vsm, c->Gbin, sW, T, p, c->eps, c->ident,
                            c->trial_of_slot);
+      } else {
+        const int bins = wide_bins(p) / 2;                 // two staged blocks per bin
+        hipLaunchKernelGGL(vsm_finish_wide_kernel, dim3((T + bins - 1) / bins, nb), dim3(bins * 32), wide_lds_bytes(p, bins, 2), c->st, c->vsm,
+                           c->Gbin, sW, T, p, c->eps, c->ident, c->trial_of_slot, bins);
       }
     });
   }
   if (want_vsmgp) {
-    if (p > 16) return fail("low-rank covariance engine supports up to 16 latents (p=%d)", p);
     if (accumulate) {
       // sum-only output: Pacc[k] += sum over the chunk's slots of Ymix_k Ymix_k^T as ONE split-K product per launch -
       // batch = (latent, group of `sps` consecutive slots), the K dimension walks the rpad-wide panels of the

@@ -335,7 +335,7 @@ print('RESULT', repr(list(fit.posteriorLikelihood)), repr(fit.paramSeq[-1]['tau'
     assert there == here
 
 
-@pytest.mark.parametrize('size', ['c1', 'ragged', 'c2'])
+@pytest.mark.parametrize('size', ['c1', 'ragged', 'c2', 'wide20', 'wide27'])
 def test_lowrank_covariance_engine_matches_dense(c1, size):
     """The low-rank (K = eps I + F F^T) covariance engine against the dense one and the oracle."""
     from funs import _hip
@@ -346,6 +346,14 @@ def test_lowrank_covariance_engine_matches_dense(c1, size):
         Y = np.stack(Ys).astype(np.uint8)
         rng = np.random.default_rng(5)
         par = {'C': 0.3 * rng.standard_normal((13, 7)), 'd': np.log(Y.mean(axis=(0, 2)) + 0.1), 'tau': 0.1 + 0.4 * rng.random(7)}
+        bin_ms = 10.0
+    elif size in ('wide20', 'wide27'):
+        # more than 16 latents (config 5 has 20): the per-bin kernels of the low-rank engine switch to their wide shape
+        pw = int(size[4:])
+        _, Ys, _ = orc.synth_dataset(24, pw, 45, 3, seed=9, dOffset=0.0)
+        Y = np.stack(Ys).astype(np.uint8)
+        rng = np.random.default_rng(9)
+        par = {'C': 0.25 * rng.standard_normal((24, pw)), 'd': np.log(Y.mean(axis=(0, 2)) + 0.1), 'tau': (0.15 if pw == 20 else 0.5) + 0.3 * rng.random(pw)}
         bin_ms = 10.0
     else:
         g = load_golden('c2_spot.npz')
@@ -729,6 +737,42 @@ def test_dual_evaluation_lowrank_engine(c1):
     assert rel(l[1], d[1]) <= 5e-2
     assert np.max(np.abs(l[2] - d[2]) / np.abs(d[2])) <= 2e-4
     assert np.max(np.abs(l[4] - d[4])) <= 1e-9 and rel(l[5], d[5]) <= 3e-2 and rel(l[6], d[6]) <= 3e-2
+
+
+@pytest.mark.parametrize('pw', [20, 27])
+def test_dual_evaluation_lowrank_engine_wide_latent_state(pw):
+    """The same evaluation with more than 16 latents (config 5 asks for 20): cost and gradient of the unjittered dual
+    through the wide per-bin kernels of the low-rank engine, against plain numpy."""
+    from funs import _hip
+    q, T, R = 18, 40, 2
+    _, Ys, _ = orc.synth_dataset(q, pw, T, R, seed=21, dOffset=0.0)
+    Y = np.stack(Ys).astype(np.uint8)
+    rng = np.random.default_rng(21)
+    C, d, tau = 0.25 * rng.standard_normal((q, pw)), np.log(Y.mean(axis=(0, 2)) + 0.1), 0.5 + 0.3 * rng.random(pw)
+    lam = 0.05 + 0.5 * rng.random((R, q * T))
+    idx = np.arange(R, dtype=np.int32)
+    ctx = _hip.Context(q, pw, T, R, 10.0)
+    try:
+        ctx.upload_counts(Y)
+        ctx.set_option('cov_mode', 2)
+        ctx.set_option('dual_lowrank', 1)
+        ctx.set_params(C, d, tau)
+        cost, grad = ctx.dual_costgrad_batch(idx, lam)
+        assert ctx.info('plan_lowrank') == 1.0
+    finally:
+        ctx.close()
+    K_big = orc.make_K_big(orc.make_K(tau, T, 10.0))
+    C_big, d_big = orc.make_Cd_big(C, d, T)
+    Kinv_big = np.linalg.inv(K_big)
+    for i in range(R):
+        y = Ys[i].reshape(-1).astype(float)
+        v = C_big @ (lam[i] - y)
+        H = Kinv_big + (C_big * lam[i][None, :]) @ C_big.T
+        Sigma = np.linalg.inv(H)
+        ref_cost = 0.5 * v @ K_big @ v - d_big @ (lam[i] - y) - 0.5 * np.linalg.slogdet(H)[1] + np.sum(lam[i] * (np.log(lam[i]) - 1.0))
+        ref_grad = C_big.T @ (K_big @ v) - d_big + np.log(lam[i]) - 0.5 * np.einsum('im,ij,jm->m', C_big, Sigma, C_big)
+        assert abs(cost[i] - ref_cost) <= 1e-8 * abs(ref_cost)
+        assert rel(grad[i], ref_grad) <= 1e-7
 
 
 def test_elliptical_slice_mcmc_chain_vs_reference(funs_mod, c1, c1_experiment):
