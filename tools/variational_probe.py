@@ -1,6 +1,8 @@
-"""Dual-variational E-step at config-2 dimensions: the per-trial scipy L-BFGS-B runs driven concurrently (batched device
+"""Dual-variational E-step at config-2 (default), config-3 or config-5 dimensions (argv: trials, config, [lowrank]): the per-trial scipy L-BFGS-B runs driven concurrently (batched device
 evaluations) vs the same runs one trial at a time."""
-import os, sys, time
+import os, sys, time, faulthandler
+if os.environ.get('PROBE_WATCHDOG'):
+    faulthandler.dump_traceback_later(int(os.environ['PROBE_WATCHDOG']), exit=True)      # where is a slow run stuck
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'poisson-gpfa_amd')); sys.path.insert(0, ROOT)
 import numpy as np
@@ -10,7 +12,7 @@ from funs import _session
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 cfg = sys.argv[2] if len(sys.argv) > 2 else 'c2'
 funs.inference.DUAL_LOWRANK = (len(sys.argv) > 3 and sys.argv[3] == 'lowrank')
-q, p, T, _ = bench.CONFIGS[cfg]
+q, p, T, _ = dict(bench.CONFIGS, c5=(500, 20, 1000, 256))[cfg]       # c5: config 5's dimensions (variational, 256 trials per GPU at 8 GPUs)
 true_params, Ys = bench.synth_shard(q, p, T, R, 12, 0)
 exp = bench.Shard(Ys, 10.0)
 params = {k: np.asarray(v, dtype=np.float64) for k, v in true_params.items()}
@@ -37,7 +39,7 @@ m = q * T
 ctx = sess.ctx
 t0 = time.time()
 nev = 0
-nser = 4 if cfg != 'c3' else 0
+nser = 4 if cfg not in ('c3', 'c5') else 0
 for tr in range(nser):
     def f(x, tr=tr):
         global nev
