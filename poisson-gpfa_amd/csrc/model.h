@@ -988,6 +988,183 @@ __global__ __launch_bounds__(64 * CDH_KY) void mstep_cd_hess_kernel(CdArgs a) {
   }
 }
 
+// The same pass for wider latent states (12 < p <= 32), where the (p+1)(p+2)/2 Hessian accumulators no longer fit one
+// lane's registers: the rows of the packed Hessian are dealt round-robin to NG row groups, blockIdx.z selects the group,
+// and every group repeats the (cheap) per-bin preamble.  Group 0 also carries the cost and the gradient.  Same staging,
+// same part layout (each group writes its own rows).  grid = (ceil(q/64), nby, NG), block = (64, CDH_KY).
+template <int PW> struct CdGroups { static constexpr int NG = (PW <= 12) ? 1 : (PW <= 16) ? 2 : (PW <= 20) ? 3 : 8; };
+constexpr int cd_group_entries(int D, int NG, int G) {
+  int n = 0;
+  for (int i = 0; i < D; ++i)
+    if (i % NG == G) n += i + 1;
+  return n;
+}
+
+template <int PW, int NG, int G>
+__device__ __forceinline__ void cd_hess_rows_body(const CdArgs& a, double (*Vt)[PW * PW], double (*Mt)[CdTile<PW>::TT], uint8_t* Yt,
+                                                  double (*red)[64]) {
+  constexpr int TT = CdTile<PW>::TT;
+  constexpr int YS = TT + 4;
+  constexpr int D = PW + 1;
+  constexpr int NHG = cd_group_entries(D, NG, G);
+  const int lane = threadIdx.x;
+  const int ty = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  const int tid = ty * 64 + lane;
+  const int n0 = blockIdx.x * 64;
+  const int n = n0 + lane;
+  const bool live = n < a.q;
+  const int p = a.p, q = a.q, T = a.T;
+  double c[PW], gacc[G == 0 ? D : 1], hacc[NHG];
+#pragma unroll
+  for (int l = 0; l < PW; ++l) c[l] = (live && l < p) ? a.vec[(size_t)l * q + n] : 0.0;
+#pragma unroll
+  for (int l = 0; l < (G == 0 ? D : 1); ++l) gacc[l] = 0.0;
+#pragma unroll
+  for (int l = 0; l < NHG; ++l) hacc[l] = 0.0;
+  const double dn = live ? a.vec[(size_t)p * q + n] : 0.0;
+  double cost = 0.0;
+
+  const int ntt = (T + TT - 1) / TT;
+  const int nitems = a.ntr * ntt;
+  for (int item = blockIdx.y; item < nitems; item += gridDim.y) {
+    const size_t r = a.trials[item / ntt];
+    const int t0 = (item % ntt) * TT;
+    const int tn = (T - t0 < TT) ? T - t0 : TT;
+    const double* mean = a.mean + r * p * T;
+    const double* vsm = a.vsm + (r * T + t0) * p * p;
+    const uint8_t* Y = a.Y + r * q * T;
+    __syncthreads();
+    for (int e = tid; e < TT * PW * PW; e += 64 * CDH_KY) {
+      const int t = e / (PW * PW), kl = e - t * (PW * PW);
+      const int k = kl / PW, l = kl - k * PW;
+      Vt[t][kl] = (t < tn && k < p && l < p) ? vsm[(size_t)t * p * p + k * p + l] : 0.0;
+    }
+    for (int e = tid; e < PW * TT; e += 64 * CDH_KY) {
+      const int k = e / TT, t = e - k * TT;
+      Mt[k][t] = (k < p && t < tn) ? mean[(size_t)k * T + t0 + t] : 0.0;
+    }
+    for (int e = tid; e < 64 * TT; e += 64 * CDH_KY) {
+      const int nn = e / TT, t = e - nn * TT;
+      Yt[nn * YS + t] = (n0 + nn < q && t < tn) ? Y[(size_t)(n0 + nn) * T + t0 + t] : 0;
+    }
+    __syncthreads();
+    for (int t = ty; t < tn; t += CDH_KY) {
+      double w[D];
+      double hh = dn, rho = 0.0;
+#pragma unroll
+      for (int k = 0; k < PW; ++k) w[k] = 0.0;
+#pragma unroll
+      for (int k = 0; k < PW; ++k) {
+#pragma unroll
+        for (int l = 0; l < k; ++l) {
+          const double v = Vt[t][k * PW + l];
+          w[k] += v * c[l];
+          w[l] += v * c[k];
+        }
+        w[k] += Vt[t][k * PW + k] * c[k];
+      }
+#pragma unroll
+      for (int k = 0; k < PW; ++k) {
+        rho += c[k] * w[k];
+        const double mk = Mt[k][t];
+        hh += c[k] * mk;
+        w[k] += mk;
+      }
+      w[PW] = 1.0;
+      const double yh = exp(hh + 0.5 * rho);
+      const double y = (double)Yt[lane * YS + t];
+      if (live) {
+        if (G == 0) {
+          cost += y * hh - yh;
+#pragma unroll
+          for (int k = 0; k < PW; ++k) gacc[k] -= y * Mt[k][t] - yh * w[k];
+          gacc[G == 0 ? PW : 0] -= y - yh;
+        }
+        int idx = 0;
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+          if (i % NG != G) continue;
+          const double ywi = yh * w[i];
+#pragma unroll
+          for (int j = 0; j <= i; ++j) {
+            double add = ywi * w[j];
+            if (i < PW) add += yh * Vt[t][i * PW + j];
+            hacc[idx] += add;
+            ++idx;
+          }
+        }
+      }
+    }
+  }
+  const int NH = 1 + (p + 1) + (p + 1) * (p + 2) / 2;
+  double* part = a.part + (size_t)blockIdx.y * NH * q;
+  auto emit = [&](double v, int row, bool keep) {
+    __syncthreads();
+    red[ty][lane] = v;
+    __syncthreads();
+    if (ty == (row & (CDH_KY - 1)) && live && keep) {
+      double s = 0.0;
+#pragma unroll
+      for (int w2 = 0; w2 < CDH_KY; ++w2) s += red[w2][lane];
+      part[(size_t)row * q + n] = s;
+    }
+  };
+  if (G == 0) {
+    emit(cost, 0, true);
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      const bool keep = (k < p) || (k == PW);
+      const int row = 1 + (k == PW ? p : k);
+      emit(gacc[G == 0 ? k : 0], keep ? row : 0, keep);
+    }
+  }
+  {
+    int idx = 0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      if (i % NG != G) continue;
+#pragma unroll
+      for (int j = 0; j <= i; ++j) {
+        const bool keep = ((i < p) || (i == PW)) && ((j < p) || (j == PW));
+        const int ii = (i == PW) ? p : i, jj = (j == PW) ? p : j;
+        const int row = 1 + (p + 1) + ii * (ii + 1) / 2 + jj;
+        emit(hacc[idx], keep ? row : 0, keep);
+        ++idx;
+      }
+    }
+  }
+}
+
+template <int PW, int NG>
+__global__ __launch_bounds__(64 * CDH_KY) void mstep_cd_hess_rows_kernel(CdArgs a) {
+  constexpr int TT = CdTile<PW>::TT;
+  __shared__ __attribute__((aligned(16))) double Vt[TT][PW * PW];
+  __shared__ double Mt[PW][TT];
+  __shared__ uint8_t Yt[64 * (TT + 4)];
+  __shared__ double red[CDH_KY][64];
+  const int g = blockIdx.z;
+  if constexpr (NG == 2) {
+    if (g == 0) cd_hess_rows_body<PW, NG, 0>(a, Vt, Mt, Yt, red);
+    else cd_hess_rows_body<PW, NG, 1>(a, Vt, Mt, Yt, red);
+  } else if constexpr (NG == 3) {
+    if (g == 0) cd_hess_rows_body<PW, NG, 0>(a, Vt, Mt, Yt, red);
+    else if (g == 1) cd_hess_rows_body<PW, NG, 1>(a, Vt, Mt, Yt, red);
+    else cd_hess_rows_body<PW, NG, 2>(a, Vt, Mt, Yt, red);
+  } else {
+    static_assert(NG == 8, "row groups: 2, 3 or 8");
+    switch (g) {
+      case 0: cd_hess_rows_body<PW, NG, 0>(a, Vt, Mt, Yt, red); break;
+      case 1: cd_hess_rows_body<PW, NG, 1>(a, Vt, Mt, Yt, red); break;
+      case 2: cd_hess_rows_body<PW, NG, 2>(a, Vt, Mt, Yt, red); break;
+      case 3: cd_hess_rows_body<PW, NG, 3>(a, Vt, Mt, Yt, red); break;
+      case 4: cd_hess_rows_body<PW, NG, 4>(a, Vt, Mt, Yt, red); break;
+      case 5: cd_hess_rows_body<PW, NG, 5>(a, Vt, Mt, Yt, red); break;
+      case 6: cd_hess_rows_body<PW, NG, 6>(a, Vt, Mt, Yt, red); break;
+      default: cd_hess_rows_body<PW, NG, 7>(a, Vt, Mt, Yt, red); break;
+    }
+  }
+}
+
 // per-neuron Newton step: solve H delta = -g (dimension p+1, Cholesky with a tiny ridge), one thread per neuron.
 // sums: [NH][q] as emitted above (not yet divided by R); prior: + inv_s2*(theta - center) on the gradient and
 // + inv_s2 on the Hessian diagonal.  Writes delta[(p+1)][q] (vecCd layout) and dec[q] = -g.delta.

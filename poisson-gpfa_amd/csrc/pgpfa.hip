@@ -2020,7 +2020,7 @@ int pgpfa_mstep_cd_newton_pass(pgpfa_ctx* c, const double* vecCd, const double* 
   if (!c || !vecCd || !cost_n || !delta || !dec) return fail("null argument");
   if (!c->have_counts) return fail("spike counts have not been uploaded");
   if (!c->have_post) return fail("no E-step result resident: run an E-step or pgpfa_set_posterior first");
-  if (c->p > 12) return fail("device Newton M-step supports up to 12 latents (p=%d): use a scipy method", c->p);
+  if (c->p > 32) return fail("device Newton M-step supports up to 32 latents (p=%d): use a scipy method", c->p);
   HIPC(hipSetDevice(c->device));
   const int q = c->q, p = c->p, T = c->T, D = p + 1;
   const int NH = 1 + D + D * (D + 1) / 2;
@@ -2034,8 +2034,12 @@ int pgpfa_mstep_cd_newton_pass(pgpfa_ctx* c, const double* vecCd, const double* 
   prof_begin(c, TAG_CD, (double)a.ntr * q * T * (3.0 * p * p + 12.0 * p));
   dispatch_pw(p, [&](auto pw) {
     constexpr int PW = decltype(pw)::value;
-    if constexpr (PW <= 12)
+    if constexpr (PW <= 12) {
       hipLaunchKernelGGL(mstep_cd_hess_kernel<PW>, dim3((q + 63) / 64, nby), dim3(64, CDH_KY), 0, c->st, a);
+    } else {
+      constexpr int NG = CdGroups<PW>::NG;               // Hessian rows dealt to NG row groups (blockIdx.z)
+      hipLaunchKernelGGL((mstep_cd_hess_rows_kernel<PW, NG>), dim3((q + 63) / 64, nby, NG), dim3(64, CDH_KY), 0, c->st, a);
+    }
   });
   prof_end(c);
   hipLaunchKernelGGL(reduce_parts_kernel, dim3((NH * q + 255) / 256), dim3(256), 0, c->st, c->cdhpart, nby, NH * q, c->cdhout);
@@ -2046,7 +2050,7 @@ int pgpfa_mstep_cd_newton_pass(pgpfa_ctx* c, const double* vecCd, const double* 
   double Rtot = 0.0;
   CHK(download(c, &Rtot, c->cdhout + (size_t)NH * q, 1));
   c->n_trials_global = Rtot;
-  const int th = 32;
+  const int th = std::max(1, std::min(32, (int)(48 * 1024 / ((D * D + 2 * D) * sizeof(double)))));
   hipLaunchKernelGGL(cd_newton_step_kernel, dim3((q + th - 1) / th), dim3(th), (size_t)th * (D * D + 2 * D) * sizeof(double), c->st, c->cdhout, q, p,
                      1.0 / Rtot, c->vec, prior_center ? c->cdcenter : nullptr, inv_s2, c->cddelta, c->cddec);
   HIPC(hipGetLastError());
@@ -2101,7 +2105,7 @@ int pgpfa_mstep_cd_chord_pass(pgpfa_ctx* c, const double* vecCd, const double* p
   CHK(download(c, &Rtot, c->cdout + len, 1));
   c->n_trials_global = Rtot;
   hipLaunchKernelGGL(cd_chord_merge_kernel, dim3((len + 255) / 256), dim3(256), 0, c->st, c->cdout, q, p, c->cdhout);
-  const int th = 32;
+  const int th = std::max(1, std::min(32, (int)(48 * 1024 / ((D * D + 2 * D) * sizeof(double)))));
   hipLaunchKernelGGL(cd_newton_step_kernel, dim3((q + th - 1) / th), dim3(th), (size_t)th * (D * D + 2 * D) * sizeof(double), c->st, c->cdhout, q, p,
                      1.0 / Rtot, c->vec, prior_center ? c->cdcenter : nullptr, inv_s2, c->cddelta, c->cddec);
   HIPC(hipGetLastError());

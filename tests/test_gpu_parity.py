@@ -570,11 +570,12 @@ def test_postfit_summaries_vs_reference(funs_mod, c1):
     assert rel(xt, ref) <= 1e-10
 
 
-@pytest.mark.parametrize('p', [12, 16, 20])
+@pytest.mark.parametrize('p', [12, 16, 20, 27])
 def test_wide_latent_dimensions(p):
-    """Latent widths at the edges of the kernel instantiations (p = 12: widest device-Newton M-step; 16: widest
-    matrix-core Poisson pass / low-rank engine; 20: config-5 width, vector Poisson pass + dense engine): E-step vs
-    the oracle's exact modes and covariance blocks, (C,d) and tau cost/gradient vs the oracle."""
+    """Latent widths at the edges of the kernel instantiations (p = 12: widest single-pass Newton M-step kernel; 16:
+    widest matrix-core Poisson pass, Hessian rows in 2 groups; 20: config-5 width, vector Poisson pass, 3 row groups;
+    27: the 32-wide instantiations, 8 row groups): E-step vs the oracle's exact modes and covariance blocks, (C,d) and
+    tau cost/gradient vs the oracle, device Newton iterations down to a vanishing oracle gradient."""
     from funs import _hip
     q, T, R = 25, 30, 3
     _, Ys, _ = orc.synth_dataset(q, p, T, R, seed=3, dOffset=0.0)
@@ -618,12 +619,16 @@ def test_wide_latent_dimensions(p):
             assert np.max(np.abs(ctx2.post_mean() - np.stack(res['post_mean']))) <= 1e-8
         finally:
             ctx2.close()
-        if p <= 12:
+        cost_n, delta, dec = ctx.mstep_cd_newton_pass(v)
+        assert abs(cost_n.sum() - cost) <= 1e-10 * abs(cost) and np.all(dec >= 0)
+        g0 = np.max(np.abs(grad))
+        for _ in range(9):                                   # full Newton steps from a point 0.01 off (exact Newton in numpy needs 7-8 here)
+            v = v + delta.reshape(-1)
             cost_n, delta, dec = ctx.mstep_cd_newton_pass(v)
-            assert abs(cost_n.sum() - cost) <= 1e-10 * abs(cost) and np.all(dec >= 0)
-        else:
-            with pytest.raises(_hip.HipBackendError):
-                ctx.mstep_cd_newton_pass(v)
+        g_end = np.max(np.abs(orc.mstep_cd_grad(v, Yf, pm, vs, p, q)))
+        assert g_end <= 1e-10 * max(1.0, g0) and cost_n.sum() < cost
+        cost_c, delta_c, dec_c = ctx.mstep_cd_chord_pass(v)   # chord pass on the resident Hessians: same point, same cost
+        assert abs(cost_c.sum() - cost_n.sum()) <= 1e-12 * abs(cost_n.sum())
     finally:
         ctx.close()
 

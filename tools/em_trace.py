@@ -1,7 +1,7 @@
 """Per-iteration trace of the default bench workload (config 3, 1024 trials on one GPU): E/M wall time, PCG work,
 rank plan and the timescales, to see how the cost of an EM iteration moves as the parameters are learned.
 
-usage: python tools/em_trace.py [iterations]
+usage: python tools/em_trace.py [iterations [neurons latents bins trials]]
 """
 import os, sys, time
 import numpy as np
@@ -13,8 +13,9 @@ import funs
 from funs import _session
 
 n_it = int(sys.argv[1]) if len(sys.argv) > 1 else 12
-q, p, T, R = 200, 10, 500, 1024
-true_params, Ys = bench.synth_shard(q, p, T, R, 0, 0)
+q, p, T, R = (int(a) for a in sys.argv[2:6]) if len(sys.argv) > 5 else (200, 10, 500, 1024)
+seed = int(os.environ.get('TRACE_SEED', '0'))
+true_params, Ys = bench.synth_shard(q, p, T, R, seed, 0)
 exp = bench.Shard(Ys, 10.0)
 sess, _ = _session.session_for(exp, p)
 np.random.seed(0)
