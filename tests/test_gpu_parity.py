@@ -370,7 +370,9 @@ def test_lowrank_covariance_engine_matches_dense(c1, size):
             obj, iters, status = ctx.estep_laplace()
             assert np.all(status == 0)
             assert ctx.info('last_cov_lowrank') == (1.0 if mode == 2 else 0.0)
-            out[mode] = (obj, ctx.post_mean(), ctx.post_vsm(), ctx.post_vsmgp(), ctx.info('lowrank_rtot'))
+            ctx.mstep_precomp()                 # low-rank: from the sum-only accumulation inside the E-step
+            P_sum = ctx.pautosum()
+            out[mode] = (obj, ctx.post_mean(), ctx.post_vsm(), ctx.post_vsmgp(), ctx.info('lowrank_rtot'), P_sum)
             if mode == 2:
                 # a dense request after low-rank use (post_cov) must still be right
                 cov = ctx.post_cov(0)
@@ -382,6 +384,7 @@ def test_lowrank_covariance_engine_matches_dense(c1, size):
     assert abs(out[1][0] - out[2][0]) <= 1e-10 * abs(out[1][0])
     assert rel(out[2][2], out[1][2]) <= 1e-9
     assert rel(out[2][3], out[1][3]) <= 1e-9
+    assert rel(out[2][5], out[1][5]) <= 1e-9
     Ys = [Y[r].astype(float) for r in range(min(R, 2))]
     res, _, _ = orc.laplace(Ys, par, bin_ms, mode='exact', return_cov=False)
     for r in range(len(Ys)):
