@@ -138,6 +138,9 @@ struct pgpfa_ctx {
   double lr_tol = 1e-13;
   bool plan_lowrank = false;                      // current workspace plan
   size_t slab_elems = 0, ws_mark = 0;
+  // the chunk workspace lives in ONE device allocation that re-plans re-partition (hipFree + hipMalloc of ~10^11 bytes
+  // costs seconds); arena_mode: 0 = dmalloc is a plain hipMalloc, 1 = only measure, 2 = carve from the arena
+  char* arena = nullptr; size_t arena_cap = 0, arena_off = 0; int arena_mode = 0;
   bool mt_dirty = false;                          // low-rank use scribbled over the Mt slabs' zero triangle
   bool last_cov_lowrank = false;
   bool shared_pcg = true;
@@ -170,6 +173,18 @@ template <typename T>
 int dmalloc(pgpfa_ctx* c, T** out, size_t count, bool zero = false) {
   void* p = nullptr;
   const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+  if (c->arena_mode) {
+    const size_t aligned = (bytes + 255) & ~(size_t)255;
+    *out = nullptr;
+    if (c->arena_mode == 2) {
+      if (c->arena_off + aligned > c->arena_cap) return fail("workspace arena overflow (%zu + %zu > %zu bytes)", c->arena_off, aligned, c->arena_cap);
+      p = c->arena + c->arena_off;
+      if (zero && hipMemsetAsync(p, 0, bytes, c->st) != hipSuccess) return fail("hipMemset failed");
+      *out = reinterpret_cast<T*>(p);
+    }
+    c->arena_off += aligned;
+    return 0;
+  }
   hipError_t e = hipMalloc(&p, bytes);
   if (e != hipSuccess) return fail("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
   if (zero) {
@@ -442,7 +457,8 @@ int ensure_workspace(pgpfa_ctx* c, bool plan_lr) {
   c->plan_lowrank = plan_lr;
   size_t free_b = 0, total_b = 0;
   HIPC(hipMemGetInfo(&free_b, &total_b));
-  size_t budget = (size_t)(0.85 * (double)free_b);
+  const size_t avail = (size_t)(0.85 * (double)(free_b + c->arena_cap));     // the arena's bytes are ours to re-partition
+  size_t budget = avail;
   {
     const size_t shared = (3 * ld_bytes(c) + 1024 * (size_t)c->ld * sizeof(double) * 4);
     budget = budget > shared ? budget - shared : 0;
@@ -473,6 +489,8 @@ int ensure_workspace(pgpfa_ctx* c, bool plan_lr) {
   }
   if (B < 1) return fail("not enough device memory for one trial slab (%zu bytes needed, %zu free)", per, free_b);
   c->B = (int)B;
+  // pass 1 measures the plan, then the arena is grown if it has to be, pass 2 hands out the pointers
+  auto carve = [&]() -> int {
   CHK(alloc_cholws(c, &c->ws, c->B, c->npad, true, c->slab_elems));
   c->ws.nact = round_up(c->n, 64);
   const size_t ld = c->ld, nB = c->B;
@@ -503,6 +521,35 @@ int ensure_workspace(pgpfa_ctx* c, bool plan_lr) {
   CHK(dmalloc(c, &c->trial_of_slot, nB)); CHK(dmalloc(c, &c->list_a, nB)); CHK(dmalloc(c, &c->list_b, nB));
   CHK(dmalloc(c, &c->mask_of_slot, nB));
   CHK(dmalloc(c, &c->ident, nB));
+  return 0;
+  };
+  c->arena_mode = 1; c->arena_off = 0;
+  int rc_carve = carve();
+  c->arena_mode = 0;
+  if (rc_carve) return rc_carve;
+  const size_t need = c->arena_off + ((size_t)1 << 20);
+  if (need > c->arena_cap) {
+    if (c->arena) { HIPC(hipStreamSynchronize(c->st)); hipFree(c->arena); c->bytes -= c->arena_cap; }
+    c->arena = nullptr; c->arena_cap = 0;
+    // memory-bound plans take the whole allowance at once: the next plan (other ranks, other chunking) re-partitions it
+    size_t cap = c->B_capped ? std::max(need, avail) : need;
+    if (hipMalloc((void**)&c->arena, cap) != hipSuccess) {
+      (void)hipGetLastError();
+      cap = need;
+      if (hipMalloc((void**)&c->arena, cap) != hipSuccess) {
+        (void)hipGetLastError();
+        c->arena = nullptr; c->B = 0;
+        return fail("not enough device memory for the chunk workspace (%zu bytes needed, %zu free)", need, free_b);
+      }
+    }
+    c->arena_cap = cap;
+    c->bytes += cap;
+  }
+  c->arena_mode = 2; c->arena_off = 0;
+  rc_carve = carve();
+  c->arena_mode = 0;
+  if (rc_carve) { c->B = 0; return rc_carve; }
+  const size_t nB = c->B;
   std::vector<int> id(c->B);
   for (int i = 0; i < c->B; ++i) id[i] = i;
   HIPC(hipMemcpyAsync(c->ident, id.data(), sizeof(int) * c->B, hipMemcpyHostToDevice, c->st));
@@ -834,6 +881,7 @@ int pgpfa_destroy(pgpfa_ctx* c) {
   if (c->st) hipStreamSynchronize(c->st);
   if (c->comm) ncclCommDestroy(c->comm);
   for (void* p : c->allocs) hipFree(p);
+  if (c->arena) hipFree(c->arena);
   if (c->hbuf) hipHostFree(c->hbuf);
   if (c->hibuf) hipHostFree(c->hibuf);
   for (auto e : c->prof.pool) hipEventDestroy(e);

@@ -29,6 +29,6 @@ for it in range(n_it):
     t1 = time.time()
     params, _ = funs.learning.updateParams(params, infRes, exp, CdOptimMethod='newton')
     t2 = time.time()
-    print('it %2d: E %6.1f ms  M %5.1f ms  pcg/trial %5.1f  newton it max %2d  rtot %4d  chunk %4d  nll %.2f  tau %s' % (
-        it, (t1 - t0) * 1e3, (t2 - t1) * 1e3, c.info('last_pcg_iterations') / R, c.info('last_newton_max_iter'),
+    print('it %2d: E %6.1f ms  M %5.1f ms  pcg/trial %5.1f  newton it max %2d  dense retries %d  rtot %4d  chunk %4d  nll %.2f  tau %s' % (
+        it, (t1 - t0) * 1e3, (t2 - t1) * 1e3, c.info('last_pcg_iterations') / R, c.info('last_newton_max_iter'), c.info('last_dense_retries'),
         c.info('lowrank_rtot'), c.info('chunk_trials'), nll, np.sort(params['tau']).round(3)), flush=True)
