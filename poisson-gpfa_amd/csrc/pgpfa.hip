@@ -2567,10 +2567,13 @@ int pgpfa_dual_lbfgs(pgpfa_ctx* c, int n, const int32_t* idx, double* rho, int m
   const double eps = 2.220446049250313e-16;
 
   for (int c0 = 0; c0 < N; c0 += Bc) {
-    const int nb = std::min(Bc, N - c0);
+    const int nb0 = std::min(Bc, N - c0);
+    int nb = nb0;                                                     // live slots: finished trials are retired (compaction below)
     std::vector<int> tos(tr.v.begin() + c0, tr.v.begin() + c0 + nb);
+    std::vector<int> orig(nb);                                        // slot -> position in this chunk's trial list
+    for (int s2 = 0; s2 < nb; ++s2) orig[s2] = s2;
     CHK(upload_list(c, c->trial_of_slot, tos));
-    const dim3 grid(vgrid.x, nb);
+    dim3 grid(vgrid.x, nb);
     auto bdot = [&](const double* A, const double* B2, std::vector<double>& out) -> int {
       hipLaunchKernelGGL(bdot_kernel, dim3(nb), dim3(256), 0, c->st, A, B2, m, scal);
       return download(c, out.data(), scal, nb);
@@ -2697,11 +2700,46 @@ int pgpfa_dual_lbfgs(pgpfa_ctx* c, int n, const int32_t* idx, double* rho, int m
         f[s2] = fn[s2];
         if (dec / den <= factr * eps || gmax[s2] <= pgtol) done[s2] = 1;
       }
+      // ---- retire finished trials: once an eighth of the live slots are done, their results leave and the last live
+      // slots move into the holes (X, G and the stored pairs), so that every later evaluation only pays for trials
+      // that are still being optimised (the slowest trial takes several times the iterations of the median one)
+      int ndone = 0;
+      for (int s2 = 0; s2 < nb; ++s2) ndone += done[s2] ? 1 : 0;
+      if (ndone > 0 && ndone < nb && ndone >= std::max(1, nb / 8)) {
+        auto retire = [&](int s2) -> int {
+          CHK(download(c, rho + (size_t)(c0 + orig[s2]) * m, X + (size_t)s2 * m, m));
+          fopt[c0 + orig[s2]] = f[s2];
+          if (iters) iters[c0 + orig[s2]] = its[s2];
+          return 0;
+        };
+        int last = nb - 1;
+        for (int s2 = 0; s2 <= last; ++s2) {
+          if (!done[s2]) continue;
+          CHK(retire(s2));
+          while (last > s2 && done[last]) { CHK(retire(last)); --last; }
+          if (last > s2) {                                            // move live slot `last` into position s2
+            const size_t bytes = m * sizeof(double);
+            HIPC(hipMemcpyAsync(X + (size_t)s2 * m, X + (size_t)last * m, bytes, hipMemcpyDeviceToDevice, c->st));
+            HIPC(hipMemcpyAsync(G + (size_t)s2 * m, G + (size_t)last * m, bytes, hipMemcpyDeviceToDevice, c->st));
+            for (int h = 0; h < HIST; ++h) {
+              HIPC(hipMemcpyAsync(S + (size_t)h * vec + (size_t)s2 * m, S + (size_t)h * vec + (size_t)last * m, bytes, hipMemcpyDeviceToDevice, c->st));
+              HIPC(hipMemcpyAsync(Yh + (size_t)h * vec + (size_t)s2 * m, Yh + (size_t)h * vec + (size_t)last * m, bytes, hipMemcpyDeviceToDevice, c->st));
+              rho_h[h][s2] = rho_h[h][last];
+            }
+            f[s2] = f[last]; its[s2] = its[last]; done[s2] = 0; orig[s2] = orig[last]; tos[s2] = tos[last];
+          }
+          --last;
+        }
+        nb = last + 1;
+        tos.resize(nb);
+        CHK(upload_list(c, c->trial_of_slot, tos));
+        grid = dim3(vgrid.x, nb);
+      }
     }
-    CHK(download(c, rho + (size_t)c0 * m, X, (size_t)nb * m));
     for (int s2 = 0; s2 < nb; ++s2) {
-      fopt[c0 + s2] = f[s2];
-      if (iters) iters[c0 + s2] = its[s2];
+      CHK(download(c, rho + (size_t)(c0 + orig[s2]) * m, X + (size_t)s2 * m, m));
+      fopt[c0 + orig[s2]] = f[s2];
+      if (iters) iters[c0 + orig[s2]] = its[s2];
     }
   }
   return 0;
