@@ -146,6 +146,7 @@ struct pgpfa_ctx {
   bool shared_pcg = true;
   int shared_min = 16, pcg_inner_min = 2, pcg_inner_max = 16, pcg_outer_max = 12;
   double pcg_eta0 = 1e-2;
+  int splitk_target = 640;                       // thin GEMMs are cut along k until about this many workgroups are in flight
   double *sc_f = nullptr, *sc_qxx = nullptr, *sc_qdx = nullptr, *sc_qdd = nullptr, *sc_dec = nullptr, *sc_smax = nullptr, *sc_alpha = nullptr;
   int *trial_of_slot = nullptr, *list_a = nullptr, *list_b = nullptr, *ident = nullptr;
   int* mask_of_slot = nullptr;                    // leave-one-neuron-out passes: neuron excluded from the likelihood of a slot
@@ -298,7 +299,7 @@ int gemm(pgpfa_ctx* c, bool transb, GemmP g) {
   // (block-sparse operands: the k loop a tile really runs is the one implied by the flop count)
   const double k_eff = (g.flops_hint > 0.0 && g.M > 0 && g.N > 0) ? g.flops_hint / (2.0 * g.M * g.N * std::max(g.nbatch, 1)) : (double)g.K;
   if (c->gemm_part && g.mode == GEMM_FULL && g.kflags == 0 && g.nb_lo == 0 && g.kseg == 0 && tiles > 0 && tiles < 384 && k_eff >= 256.0) {
-    ksplit = std::min(std::min(8, (int)(k_eff / 64.0)), (640 + tiles - 1) / tiles);
+    ksplit = std::min(std::min(8, (int)(k_eff / 64.0)), (c->splitk_target + tiles - 1) / tiles);
     while (ksplit > 1 && (size_t)ksplit * g.nbatch * g.M * g.N > c->gemm_part_len) --ksplit;
   }
   hipError_t e;
@@ -907,6 +908,7 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
   else if (k == "shared_min") c->shared_min = (int)v;
   else if (k == "pcg_inner") c->pcg_inner_max = std::max(1, (int)v);
   else if (k == "pcg_eta0") c->pcg_eta0 = v;
+  else if (k == "splitk_target") c->splitk_target = std::max(1, (int)v);
   else if (k == "pcg_outer_max") c->pcg_outer_max = (int)v;
   else if (k == "chord_xtol") c->chord_xtol = v;
   else if (k == "chord_rho") c->chord_rho = v;

@@ -22,6 +22,9 @@ np.random.seed(0)
 params = {k: np.real(np.asarray(v)).astype(np.float64) for k, v in funs.util.initializeParams(p, q, exp).items()}
 optim = None
 c = sess.ctx
+for kv in filter(None, os.environ.get('TRACE_OPTS', '').split(',')):      # e.g. TRACE_OPTS=splitk_target=960,pcg_inner=12
+    k, v = kv.split('=')
+    c.set_option(k, float(v))
 print('true tau', np.sort(true_params['tau']).round(3))
 for it in range(n_it):
     t0 = time.time()
