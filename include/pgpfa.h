@@ -47,7 +47,7 @@ int pgpfa_destroy(pgpfa_ctx* ctx);
  * every tagged launch, 2 = around GEMM launches only; sums are read with pgpfa_get_info "prof_<family>_ms|_flops|_launches"),
  * "shared_pcg" (1: phase-1 Newton with the shared preconditioner), "shared_min" (16), "pcg_inner" (16: cap on
  * the inner PCG iterations of one outer Newton iteration), "pcg_eta0" (1e-2: relative residual of the first inner solve;
- * later ones adapt to the predicted error), "splitk_target" (640: thin GEMMs are cut along k until about this many
+ * later ones adapt to the predicted error), "splitk_target" (1280: thin GEMMs are cut along k until about this many
  * workgroups are in flight),
  * "pcg_outer_max" (12), "cov_mode" (0 auto, 1 dense, 2 low-rank covariance engine), "lowrank_tol" (1e-13),
  * "keep_trial_vsmgp" (0: the low-rank engine accumulates sum_r post_vsmGP_r for the tau M-step and rebuilds

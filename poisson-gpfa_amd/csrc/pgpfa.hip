@@ -146,7 +146,7 @@ struct pgpfa_ctx {
   bool shared_pcg = true;
   int shared_min = 16, pcg_inner_min = 2, pcg_inner_max = 16, pcg_outer_max = 12;
   double pcg_eta0 = 1e-2;
-  int splitk_target = 640;                       // thin GEMMs are cut along k until about this many workgroups are in flight
+  int splitk_target = 1280;                      // thin GEMMs are cut along k until about this many workgroups are in flight
   double *sc_f = nullptr, *sc_qxx = nullptr, *sc_qdx = nullptr, *sc_qdd = nullptr, *sc_dec = nullptr, *sc_smax = nullptr, *sc_alpha = nullptr;
   int *trial_of_slot = nullptr, *list_a = nullptr, *list_b = nullptr, *ident = nullptr;
   int* mask_of_slot = nullptr;                    // leave-one-neuron-out passes: neuron excluded from the likelihood of a slot
