@@ -830,3 +830,93 @@ def test_cross_validation_driver_vs_reference(funs_mod, c1):
     assert rel(cv.fits[2].optimParams['tau'], g['tau_fit3']) <= 5e-3
     tr, te = funs_mod.util.splitTrainingTestDataset(exp, 10, 2)
     assert len(tr.data) == 10 and len(te.data) == 2 and te.data[0] is exp.data[10]
+
+
+def test_config3_full_size_properties(funs_mod):
+    """Config 3's dimensions (200 neurons, 10 latents, 500 bins; 48 trials keep the host-side checks short): one dense
+    oracle evaluation of one trial is minutes of CPU at this size, so the result is pinned by properties that do not
+    depend on size - (1) stationarity: the gradient of the reference's log-posterior (inference.py:34-48, restated in
+    structured form on the host) vanishes at every returned mode; (2) the low-rank engine's covariance blocks equal the
+    dense engine's for the same trials; (3) additivity: PautoSum of the whole list = sum over two halves, modes independent
+    of the order and chunking of the list; (4) a warm restart at the modes returns the same objective; (5) the M-step
+    lands where the oracle's gradients of the reference's (C,d) and timescale costs vanish."""
+    import bench
+    from funs import _hip
+    q, p, T, R = 200, 10, 500, 48
+    true, Ys = bench.synth_shard(q, p, T, R, 12, 0)
+    Y = np.stack(Ys)
+    rng = np.random.default_rng(3)
+    par = {'C': true['C'] + 0.05 * rng.standard_normal((q, p)), 'd': true['d'] + 0.05 * rng.standard_normal(q),
+           'tau': np.linspace(0.1, 0.5, p)}
+    K = orc.make_K(par['tau'], T, 10.0)
+    Kinv = np.linalg.inv(K)
+    ctx = _hip.Context(q, p, T, R, 10.0)
+    try:
+        ctx.upload_counts(Y)
+        ctx.set_params(par['C'], par['d'], par['tau'])
+        obj, iters, status = ctx.estep_laplace()
+        assert np.all(status == 0) and ctx.info('last_cov_lowrank') == 1.0 and ctx.info('plan_lowrank') == 1.0
+        X = ctx.post_mean()
+        # (1) stationarity of every mode
+        for r in range(R):
+            g = par['C'].T @ (np.exp(par['C'] @ X[r] + par['d'][:, None]) - Y[r]) + np.einsum('kts,ks->kt', Kinv, X[r])
+            assert np.max(np.abs(g)) <= 1e-6
+        # objective = sum of the reference's negLogPosteriorUnNorm at the modes (inference.py:12-32)
+        f = 0.0
+        for r in range(R):
+            h = par['C'] @ X[r] + par['d'][:, None]
+            f += np.sum(np.exp(h)) - np.sum(Y[r] * h) + 0.5 * np.einsum('kt,kts,ks->', X[r], Kinv, X[r])
+        assert abs(obj - f) <= 1e-10 * abs(f)
+        vsm_lr = ctx.post_vsm()
+        ctx.mstep_precomp()
+        P_all = ctx.pautosum()
+        sub = np.array([0, 17, 47], dtype=np.int32)
+        gp_lr = ctx.post_vsmgp(sub)
+        # (4) warm restart: same objective, no movement
+        obj_w, _, status_w = ctx.estep_laplace(warm_start=True)
+        assert np.all(status_w == 0) and abs(obj_w - obj) <= 1e-11 * abs(obj)
+        assert np.max(np.abs(ctx.post_mean() - X)) <= 1e-7
+        # (5) M-step on the resident posterior
+        exp = Experiment([y.astype(float) for y in Ys], 10.0)
+    finally:
+        ctx.close()
+    # (2) dense engine on three of the trials
+    ctx = _hip.Context(q, p, T, 3, 10.0)
+    try:
+        ctx.upload_counts(Y[sub])
+        ctx.set_option('cov_mode', 1)
+        ctx.set_params(par['C'], par['d'], par['tau'])
+        _, _, st = ctx.estep_laplace()
+        assert np.all(st == 0) and ctx.info('last_cov_lowrank') == 0.0
+        assert np.max(np.abs(ctx.post_mean() - X[sub])) <= 1e-7
+        assert rel(vsm_lr[sub], ctx.post_vsm()) <= 1e-7
+        assert rel(gp_lr, ctx.post_vsmgp()) <= 1e-7
+    finally:
+        ctx.close()
+    # (3) additivity and order independence: reversed list, forced into chunks of 16
+    ctx = _hip.Context(q, p, T, R, 10.0)
+    try:
+        ctx.upload_counts(Y)
+        ctx.set_option('chunk_trials', 16)
+        ctx.set_params(par['C'], par['d'], par['tau'])
+        P_half = []
+        for idx in (np.arange(R // 2 - 1, -1, -1, dtype=np.int32), np.arange(R - 1, R // 2 - 1, -1, dtype=np.int32)):
+            o, _, st = ctx.estep_laplace(idx)
+            assert np.all(st == 0)
+            ctx.mstep_precomp()
+            P_half.append(ctx.pautosum())
+            assert np.max(np.abs(ctx.post_mean(idx) - X[idx])) <= 1e-7
+        assert rel(P_half[0] + P_half[1], P_all) <= 1e-9
+    finally:
+        ctx.close()
+    # (5) through the drop-in surface: E-step + M-step, then the oracle's gradients at the new parameters
+    infRes, nll, _ = funs_mod.inference.laplace(exp, par)
+    assert abs(-nll * R - obj) <= 1e-9 * abs(obj)
+    new, _ = funs_mod.learning.updateParams(par, infRes, exp, CdOptimMethod='newton')
+    pm = [infRes['post_mean'][r] for r in range(R)]
+    vs = [infRes['post_vsm'][r] for r in range(R)]
+    g_cd = orc.mstep_cd_grad(orc.cd_to_vec(new['C'], new['d']), [y.astype(float) for y in Ys], pm, vs, p, q)
+    assert np.max(np.abs(g_cd)) <= 1e-7
+    logp = np.log(1.0 / (new['tau'] * 100.0) ** 2)
+    for k in (0, 4, 9):
+        assert abs(orc.tau_grad(logp[k], P_all[k], R)[0]) <= 1e-6 * R
