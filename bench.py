@@ -263,6 +263,7 @@ def main():
     barrier()
     elapsed = time.time() - t_begin
     gemm_ms, gemm_flops, gemm_launches = (sess.ctx.info('prof_gemm_' + k) for k in ('ms', 'flops', 'launches'))
+    gemm_max_ms, gemm_max_flops = sess.ctx.info('prof_gemm_max_ms'), sess.ctx.info('prof_gemm_max_flops')
     sess.ctx.set_option('profile', 0)
 
     def drop_last():
@@ -318,7 +319,11 @@ def main():
                      'traffic': pmc_traffic_per_launch('void pgpfa::gemm_mfma_kernel') if args.config == 'c3' else None,
                      'traffic_unit': 'HBM bytes per launch (PMC, profiles/r01_c3_pmc_hbm_traffic.json)',
                      'algorithmic_flops_per_launch': gemm_flops / max(gemm_launches, 1.0), 'launches': gemm_launches, 'avg_launch_ms': gemm_ms / max(gemm_launches, 1.0),
-                     'kernel_share_of_step': gemm_ms / (t_max * 1e3)},
+                     'kernel_share_of_step': gemm_ms / (t_max * 1e3),
+                     # the longest single launch of the timed region (config 3: the segmented-K product sum_r Y~ Y~^T)
+                     'largest_launch': {'ms': gemm_max_ms, 'algorithmic_flops': gemm_max_flops,
+                                        'achieved': gemm_max_flops / (gemm_max_ms * 1e-3) / 1e12 if gemm_max_ms > 0 else 0.0,
+                                        'frac': gemm_max_flops / (gemm_max_ms * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS if gemm_max_ms > 0 else 0.0}},
     }
     if not args.no_cpu_baseline and world == 1:
         out['cpu_baseline'] = cpu_baseline(q, p, T, R, true_params, Ys[0], bin_ms, init)

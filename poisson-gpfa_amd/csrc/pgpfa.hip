@@ -60,6 +60,7 @@ struct Prof {
   std::deque<Rec> recs;              // launches whose events have not been read yet, oldest first
   bool open = false;                 // prof_begin recorded, prof_end pending
   std::map<int, double> ms, flops, count;
+  std::map<int, double> max_ms, max_flops;   // the longest single launch of each family and its algorithmic flops
 };
 constexpr int TAU_MULTI_MAX = 4;  // candidate points per latent in one batched timescale cost/gradient pass
 constexpr int PACC_SPLITS = 64;   // split-K groups of the sum-only vsmGP product
@@ -227,6 +228,7 @@ void prof_harvest(Prof& P, bool all) {
       P.ms[r.tag] += ms;
       P.flops[r.tag] += r.flops;
       P.count[r.tag] += 1;
+      if (ms > P.max_ms[r.tag]) { P.max_ms[r.tag] = ms; P.max_flops[r.tag] = r.flops; }
     }
     P.idle.push_back(r.e0);
     P.idle.push_back(r.e1);
@@ -920,7 +922,7 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
     // 0: off (the accumulated sums stay readable), 1: time every tagged launch, 2: GEMM launches only
     if (v != 0.0) {
       prof_collect(c);
-      c->prof.ms.clear(); c->prof.flops.clear(); c->prof.count.clear();
+      c->prof.ms.clear(); c->prof.flops.clear(); c->prof.count.clear(); c->prof.max_ms.clear(); c->prof.max_flops.clear();
     }
     c->prof.on = (v != 0.0);
     c->prof.only_tag = (v == 2.0) ? TAG_GEMM : -1;
@@ -939,6 +941,8 @@ int pgpfa_get_info(pgpfa_ctx* c, const char* key, double* value) {
       if (k == base + "_ms") { *value = c->prof.ms[t]; return 0; }
       if (k == base + "_flops") { *value = c->prof.flops[t]; return 0; }
       if (k == base + "_launches") { *value = c->prof.count[t]; return 0; }
+      if (k == base + "_max_ms") { *value = c->prof.max_ms[t]; return 0; }
+      if (k == base + "_max_flops") { *value = c->prof.max_flops[t]; return 0; }
     }
     return fail("unknown info key '%s'", key);
   }
