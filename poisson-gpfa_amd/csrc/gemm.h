@@ -16,7 +16,6 @@
 // 16x16x4 instruction per SIMD, so one LDS fragment read per MFMA is far below the LDS roof and the
 // kernel is MFMA-issue bound by construction.
 #pragma once
-#include <type_traits>
 #include <hip/hip_runtime.h>
 
 namespace pgpfa {
@@ -218,17 +217,6 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP g) {
   // a wave whose 64x64 sub-tile lies entirely outside C still stages and syncs, but skips MFMAs
   const bool wave_live = (i0 + wm * 64 < g.M) && (j0 + wn * 64 < g.N) &&
                          !((g.mode == GEMM_LOWER) && (i0 + wm * 64 + 63 < j0 + wn * 64));
-  // Diagonal tile of a LOWER product: the (0,1) wave's sub-tile lies above the diagonal, the (0,0) and (1,1) waves need
-  // only the 10 of their 16 MFMA tiles that touch the lower triangle, and the (1,0) wave needs all 16.  Re-balance: the
-  // diagonal waves skip their upper tiles, and the otherwise idle (0,1) wave takes every other k group of the (1,0)
-  // sub-tile (partial sums added through LDS at the end) - 10 | 8+8 | 10 units instead of 16 | 16 | 16 | 0.
-  const bool diag_tile = (g.mode == GEMM_LOWER) && (i0 == j0);
-  const bool pair_split = diag_tile && (i0 + 64 < g.M) && (j0 < g.N);
-  const bool helper = pair_split && wm == 0 && wn == 1;          // computes for the (1,0) sub-tile
-  const bool tri_only = diag_tile && wm == wn;
-  const int fm = helper ? 1 : wm, fn = helper ? 0 : wn;          // fragment origin in units of 64
-  const bool taker = pair_split && wm == 1 && wn == 0;
-  const bool halved = helper || taker;                           // these two waves do half of the k groups each
 
   const int nk = (ke - kb) / GBK;
   if (nk > 0) {
@@ -237,48 +225,28 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP g) {
   }
   __syncthreads();
   const int l15 = lane & 15, l4 = lane >> 4;
-  auto main_loop = [&](auto tri) {
-    constexpr bool TRI = decltype(tri)::value;
-    for (int it = 0; it < nk; ++it) {
-      const int buf = it & 1;
-      if (it + 1 < nk) load_tiles(kb + (it + 1) * GBK);
-      if (wave_live || helper) {
+  for (int it = 0; it < nk; ++it) {
+    const int buf = it & 1;
+    if (it + 1 < nk) load_tiles(kb + (it + 1) * GBK);
+    if (wave_live) {
 #pragma unroll
-        for (int kk = 0; kk < GBK; kk += 4) {
-          if (halved && ((kk >= GBK / 2) != helper)) continue;
-          double af[4], bf[4];
+      for (int kk = 0; kk < GBK; kk += 4) {
+        double af[4], bf[4];
 #pragma unroll
-          for (int mi = 0; mi < 4; ++mi) af[mi] = As[buf][kk + l4][fm * 64 + mi * 16 + l15];
+        for (int mi = 0; mi < 4; ++mi) af[mi] = As[buf][kk + l4][wm * 64 + mi * 16 + l15];
 #pragma unroll
-          for (int ni = 0; ni < 4; ++ni) bf[ni] = Bs[buf][kk + l4][fn * 64 + ni * 16 + l15];
+        for (int ni = 0; ni < 4; ++ni) bf[ni] = Bs[buf][kk + l4][wn * 64 + ni * 16 + l15];
 #pragma unroll
-          for (int mi = 0; mi < 4; ++mi)
+        for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-              if (!TRI || ni <= mi)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[ni], af[mi], acc[mi][ni], 0, 0, 0);
-        }
+          for (int ni = 0; ni < 4; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[ni], af[mi], acc[mi][ni], 0, 0, 0);
       }
-      if (it + 1 < nk) store_tiles(buf ^ 1);
-      __syncthreads();
     }
-  };
-  if (tri_only) main_loop(std::true_type{});
-  else main_loop(std::false_type{});
-
-  if (pair_split) {
-    // the helper's partial sums of the (1,0) sub-tile go through LDS (the A panel buffers are free now: 2*16*144 doubles)
-    double* xch = &As[0][0][0];
-    if (helper) {
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) xch[((mi * 4 + ni) * 4 + r) * 64 + lane] = acc[mi][ni][r];
-    }
+    if (it + 1 < nk) store_tiles(buf ^ 1);
     __syncthreads();
   }
+
   if (!wave_live) return;
   // D[row = l4 + 4r][col = l15]: row <-> j (B index), col <-> i (A index)
   const bool mask_diag = (g.kflags & KF_MASK_DIAG) && (ti == tj);
@@ -288,16 +256,13 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP g) {
     if (i >= g.M) continue;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
-      if (tri_only && ni > mi) continue;           // 16x16 tiles strictly above the diagonal: not computed, not stored
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int j = j0 + wn * 64 + ni * 16 + l4 + 4 * r;
         if (j >= g.N) continue;
         if (mask_diag && i < j) continue;
         double* dst = C + (size_t)j * g.ldc + i;
-        double s = acc[mi][ni][r];
-        if (taker) s += (&As[0][0][0])[((mi * 4 + ni) * 4 + r) * 64 + lane];
-        double v = g.alpha * s;
+        double v = g.alpha * acc[mi][ni][r];
         if (g.beta != 0.0) v += g.beta * (*dst);
         *dst = v;
       }
