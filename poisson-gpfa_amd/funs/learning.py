@@ -356,26 +356,41 @@ def _lockstep_minimize(evaluate, p0, gtol=1e-8, xtol=1e-10, max_iter=60, curv0=N
     return p, f, g, nfev, done, curv_seen
 
 
-def _newton_poly_root(X, Y, lo, hi):
+def _newton_poly_root(X, Y, lo, hi, active=None):
     """Roots in (lo, hi) of the polynomials interpolating (X[:, j], Y[:, j]) (columns = independent problems, Y
-    changes sign between lo and hi): Newton divided differences, then bisection on the interpolant."""
+    changes sign between lo and hi): Newton divided differences, then Newton's iteration on the interpolant kept inside
+    the shrinking bracket (a bisection step wherever Newton leaves it) - a handful of vector operations per solve;
+    this runs on the host between two device rounds of the timescale M-step."""
     n = X.shape[0]
     coef = Y.copy()
     for lvl in range(1, n):
         coef[lvl:] = (coef[lvl:] - coef[lvl - 1:-1]) / (X[lvl:] - X[:n - lvl])
 
     def poly(z):
+        """value and derivative (Horner on the Newton form)"""
         v = coef[n - 1].copy()
+        dv = np.zeros_like(v)
         for i in range(n - 2, -1, -1):
+            dv = dv * (z - X[i]) + v
             v = v * (z - X[i]) + coef[i]
-        return v
+        return v, dv
     a, b = lo.copy(), hi.copy()
-    for _ in range(60):
+    z = 0.5 * (a + b)
+    idle = np.zeros(z.shape, dtype=bool) if active is None else ~np.asarray(active, dtype=bool)   # columns nobody reads
+    for _ in range(80):
+        v, dv = poly(z)
+        up = v > 0
+        b = np.where(up, z, b)
+        a = np.where(up, a, z)
+        with np.errstate(all='ignore'):
+            zn = z - v / dv
         mid = 0.5 * (a + b)
-        up = poly(mid) > 0
-        b = np.where(up, mid, b)
-        a = np.where(up, a, mid)
-    return 0.5 * (a + b)
+        zn = np.where(np.isfinite(zn) & (zn >= a) & (zn <= b), zn, mid)
+        if np.all(idle | (np.abs(zn - z) <= 1e-14 * (1.0 + np.abs(z))) | (b - a <= 1e-14 * (1.0 + np.abs(z)))):
+            z = zn
+            break
+        z = zn
+    return z
 
 
 def _lockstep_multi(evaluate_multi, p0, d_hint=None, gtol=1e-8, xtol=1e-10, max_rounds=30, m=4):
@@ -423,7 +438,7 @@ def _lockstep_multi(evaluate_multi, p0, d_hint=None, gtol=1e-8, xtol=1e-10, max_
             X, Y = np.take_along_axis(X, srt, axis=0), np.take_along_axis(Y, srt, axis=0)
             distinct = np.all(np.diff(X, axis=0) > 0, axis=0)
             with np.errstate(all='ignore'):
-                r_poly = _newton_poly_root(X, Y, np.where(work, lo, 0.0), np.where(work, hi, 1.0))
+                r_poly = _newton_poly_root(X, Y, np.where(work, lo, 0.0), np.where(work, hi, 1.0), work)
             glo = np.max(np.where((Gs < 0) & (Ps == lo[None, :]), Gs, -np.inf), axis=0)
             ghi = np.min(np.where((Gs > 0) & (Ps == hi[None, :]), Gs, np.inf), axis=0)
             with np.errstate(all='ignore'):
