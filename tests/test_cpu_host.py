@@ -150,3 +150,54 @@ def test_two_rank_gloo_sharded_statistics_equal_unsharded(tmp_path):
     P, n = orc.make_precomp(res)
     ref = np.concatenate([[-nll * 6, 6, f], dC.ravel(), dd, P.ravel()])
     assert np.max(np.abs(red - ref) / (1.0 + np.abs(ref))) <= 1e-10
+
+
+def test_timescale_root_finder_host_logic():
+    """The host side of the lockstep timescale M-step (learning._lockstep_multi / _newton_poly_root) on analytic
+    stand-ins for the device cost/gradient: roots of ten independent convex problems found together, with and without
+    the displacement hint of the previous EM iteration, and the safeguarded Newton on the cubic interpolant against
+    plain bisection."""
+    from funs import learning
+    rng = np.random.default_rng(7)
+    k = 10
+    roots = rng.normal(-6.0, 1.0, k)
+    a = 1.0 + rng.random(k)
+
+    def evaluate(Q):                                   # f_k = a/2 d^2 + d^4/10, g_k = f_k'
+        d = Q - roots[None, :]
+        return 0.5 * a * d * d + 0.1 * d ** 4, a * d + 0.4 * d ** 3
+    for hint in (None, 0.3 * np.ones(k), -0.5 * np.ones(k)):
+        p0 = roots + 0.3 * rng.standard_normal(k)
+        pv, fv, gv, rounds, done = learning._lockstep_multi(evaluate, p0, d_hint=hint)
+        assert np.all(done) and rounds <= 8
+        assert np.max(np.abs(pv - roots)) <= 1e-9
+    # a start far from the optimum (no sign change among the first candidates): geometric stepping out, then bracketing
+    pv, _, _, rounds, done = learning._lockstep_multi(evaluate, roots + 3.0, d_hint=None)
+    assert np.all(done) and np.max(np.abs(pv - roots)) <= 1e-9 and rounds <= 12
+
+    def bisect(X, Y, lo, hi):
+        n = X.shape[0]
+        coef = Y.copy()
+        for lvl in range(1, n):
+            coef[lvl:] = (coef[lvl:] - coef[lvl - 1:-1]) / (X[lvl:] - X[:n - lvl])
+        lo, hi = lo.copy(), hi.copy()
+        for _ in range(80):
+            mid = 0.5 * (lo + hi)
+            v = coef[n - 1].copy()
+            for i in range(n - 2, -1, -1):
+                v = v * (mid - X[i]) + coef[i]
+            hi = np.where(v > 0, mid, hi)
+            lo = np.where(v > 0, lo, mid)
+        return 0.5 * (lo + hi)
+    for _ in range(50):
+        c3 = rng.normal(0.0, 0.5, k)
+        X = np.sort(roots[None, :] + rng.normal(0.0, 0.3, (4, k)), axis=0)
+        Y = a * (X - roots) + c3 * (X - roots) ** 3 + 0.3 * (X - roots) ** 2
+        lo = np.max(np.where(Y < 0, X, -np.inf), axis=0)
+        hi = np.min(np.where(Y > 0, X, np.inf), axis=0)
+        ok = np.isfinite(lo) & np.isfinite(hi) & (hi > lo)
+        if not ok.any():
+            continue
+        lo, hi = np.where(ok, lo, 0.0), np.where(ok, hi, 1.0)
+        r = learning._newton_poly_root(X, Y, lo, hi, ok)
+        assert np.max(np.abs(r - bisect(X, Y, lo, hi))[ok]) <= 1e-13
