@@ -1228,12 +1228,24 @@ __global__ void cd_chord_merge_kernel(const double* __restrict__ cg, int q, int 
 }
 
 // out[e] = sum_b part[b][e]
-__global__ void reduce_parts_kernel(const double* __restrict__ part, int nb, int len, double* __restrict__ out) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= len) return;
+// A block owns 32 consecutive elements; its 8 groups of 32 threads each sum every 8th part (a serial walk over all nb
+// parts by one thread is a chain of nb dependent-latency loads, ~1 us each), then the 8 group sums are added in a
+// fixed order through LDS - the result does not depend on scheduling.  grid = ceil(len/32), block = 256.
+__global__ __launch_bounds__(256) void reduce_parts_kernel(const double* __restrict__ part, int nb, int len, double* __restrict__ out) {
+  __shared__ double red[8][33];
+  const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int e = blockIdx.x * 32 + el;
   double s = 0.0;
-  for (int b = 0; b < nb; ++b) s += part[(size_t)b * len + e];
-  out[e] = s;
+  if (e < len)
+    for (int b = grp; b < nb; b += 8) s += part[(size_t)b * len + e];
+  red[grp][el] = s;
+  __syncthreads();
+  if (grp == 0 && e < len) {
+    double t = red[0][el];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) t += red[g][el];
+    out[e] = t;
+  }
 }
 
 // --------------------------------------------------------------------------------------------------

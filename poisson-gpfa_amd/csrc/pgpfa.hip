@@ -300,8 +300,10 @@ int gemm(pgpfa_ctx* c, bool transb, GemmP g) {
   int ksplit = 1;
   // (block-sparse operands: the k loop a tile really runs is the one implied by the flop count)
   const double k_eff = (g.flops_hint > 0.0 && g.M > 0 && g.N > 0) ? g.flops_hint / (2.0 * g.M * g.N * std::max(g.nbatch, 1)) : (double)g.K;
-  if (c->gemm_part && g.mode == GEMM_FULL && g.kflags == 0 && g.nb_lo == 0 && g.kseg == 0 && tiles > 0 && tiles < 384 && k_eff >= 256.0) {
-    ksplit = std::min(std::min(8, (int)(k_eff / 64.0)), (c->splitk_target + tiles - 1) / tiles);
+  if (c->gemm_part && g.mode == GEMM_FULL && g.kflags == 0 && g.nb_lo == 0 && g.kseg == 0 && tiles > 0 && tiles < 384 && k_eff >= 128.0) {
+    // (a lone workgroup per CU walks its k loop at the latency of one global load per 16-wide step: with a handful of
+    // tiles even a 128-long loop is worth cutting, down to parts of two steps)
+    ksplit = std::min(std::min(8, (int)(k_eff / (tiles < 64 ? 32.0 : 64.0))), (c->splitk_target + tiles - 1) / tiles);
     while (ksplit > 1 && (size_t)ksplit * g.nbatch * g.M * g.N > c->gemm_part_len) --ksplit;
   }
   hipError_t e;
@@ -2039,7 +2041,7 @@ int pgpfa_mstep_cd_costgrad(pgpfa_ctx* c, const double* vecCd, const double* pri
     hipLaunchKernelGGL(mstep_cd_kernel<decltype(pw)::value>, dim3((q + 63) / 64, nby), dim3(64, CD_KY), 0, c->st, a);
   });
   prof_end(c);
-  hipLaunchKernelGGL(reduce_parts_kernel, dim3((len + 255) / 256), dim3(256), 0, c->st, c->cdpart, nby, len, c->cdout);
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3((len + 31) / 32), dim3(256), 0, c->st, c->cdpart, nby, len, c->cdout);
   HIPC(hipGetLastError());
   // append the local trial count, all-reduce [sums | count] over ranks
   const double cnt = (double)a.ntr;
@@ -2096,7 +2098,7 @@ int pgpfa_mstep_cd_newton_pass(pgpfa_ctx* c, const double* vecCd, const double* 
     }
   });
   prof_end(c);
-  hipLaunchKernelGGL(reduce_parts_kernel, dim3((NH * q + 255) / 256), dim3(256), 0, c->st, c->cdhpart, nby, NH * q, c->cdhout);
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3((NH * q + 31) / 32), dim3(256), 0, c->st, c->cdhpart, nby, NH * q, c->cdhout);
   HIPC(hipGetLastError());
   const double cnt = (double)a.ntr;
   HIPC(hipMemcpyAsync(c->cdhout + (size_t)NH * q, &cnt, sizeof(double), hipMemcpyHostToDevice, c->st));
@@ -2151,7 +2153,7 @@ int pgpfa_mstep_cd_chord_pass(pgpfa_ctx* c, const double* vecCd, const double* p
     hipLaunchKernelGGL(mstep_cd_kernel<decltype(pw)::value>, dim3((q + 63) / 64, nby), dim3(64, CD_KY), 0, c->st, a);
   });
   prof_end(c);
-  hipLaunchKernelGGL(reduce_parts_kernel, dim3((len + 255) / 256), dim3(256), 0, c->st, c->cdpart, nby, len, c->cdout);
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3((len + 31) / 32), dim3(256), 0, c->st, c->cdpart, nby, len, c->cdout);
   const double cnt = (double)a.ntr;
   HIPC(hipMemcpyAsync(c->cdout + len, &cnt, sizeof(double), hipMemcpyHostToDevice, c->st));
   CHK(allreduce_dev(c, c->cdout, (size_t)len + 1));
