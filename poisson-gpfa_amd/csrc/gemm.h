@@ -45,6 +45,7 @@ struct GemmP {
   int mode, kflags;
   int tilesM, tilesN, ntiles;
   double flops_hint;    // algorithmic flops of the launch when the operands are block sparse (0: dense formula)
+  int k_loop_hint;      // longest k loop of a tile when krange is set (0: derive it from flops_hint / K); host-side use only
   // optional two-level batch: entry b = hi * nb_lo + lo; `slots` maps lo, hi adds its own strides (nb_lo = 0: one level)
   int nb_lo;
   long long sA_hi, sB_hi, sC_hi;

@@ -132,6 +132,7 @@ struct pgpfa_ctx {
   double* Gbin = nullptr;                         // [B][T][p][p]
   int *d_rank = nullptr, *d_blk_lat = nullptr, *d_blk_col = nullptr, *d_roff = nullptr;
   int *d_kr_ft = nullptr, *d_kr_f = nullptr;     // per-row-tile k ranges of the block-diagonal F^T / F GEMMs
+  int kr_ft_len = 0, kr_f_len = 0;               // longest of those ranges
   double *Fbig = nullptr, *FTbig = nullptr, *Gbar = nullptr, *Wtbar = nullptr;   // low-rank shared preconditioner
   std::vector<int> rk, roff;                      // ranks padded to 16, offsets
   int rtot = 0, rpad = 0;
@@ -299,7 +300,8 @@ int gemm(pgpfa_ctx* c, bool transb, GemmP g) {
   const int tiles = ((g.M + GBM - 1) / GBM) * ((g.N + GBN - 1) / GBN) * std::max(g.nbatch, 1);
   int ksplit = 1;
   // (block-sparse operands: the k loop a tile really runs is the one implied by the flop count)
-  const double k_eff = (g.flops_hint > 0.0 && g.M > 0 && g.N > 0) ? g.flops_hint / (2.0 * g.M * g.N * std::max(g.nbatch, 1)) : (double)g.K;
+  const double k_eff = g.k_loop_hint > 0 ? (double)g.k_loop_hint
+                       : (g.flops_hint > 0.0 && g.M > 0 && g.N > 0) ? g.flops_hint / (2.0 * g.M * g.N * std::max(g.nbatch, 1)) : (double)g.K;
   if (c->gemm_part && g.mode == GEMM_FULL && g.kflags == 0 && g.nb_lo == 0 && g.kseg == 0 && tiles > 0 && tiles < 384 && k_eff >= 128.0) {
     // (a lone workgroup per CU walks its k loop at the latency of one global load per 16-wide step: with a handful of
     // tiles even a 128-long loop is worth cutting, down to parts of two steps)
@@ -738,6 +740,11 @@ int build_lowrank(pgpfa_ctx* c) {
     }
     CHK(upload_list(c, c->d_kr_ft, krft));
     CHK(upload_list(c, c->d_kr_f, krf));
+    // longest k loop a tile of these block-sparse products runs (what the split-K decision should look at: the flop count
+    // under-states it, a row tile that spans several latents walks all their bins)
+    c->kr_ft_len = 0; c->kr_f_len = 0;
+    for (size_t i = 0; i + 1 < krft.size(); i += 2) c->kr_ft_len = std::max(c->kr_ft_len, krft[i + 1] - krft[i]);
+    for (size_t i = 0; i + 1 < krf.size(); i += 2) c->kr_f_len = std::max(c->kr_f_len, krf[i + 1] - krf[i]);
   }
   if ((size_t)c->rpad <= (size_t)c->ld) {
     HIPC(hipMemsetAsync(c->Fbig, 0, (size_t)c->ld * c->rpad * sizeof(double), c->st));
@@ -1151,7 +1158,7 @@ static int shared_solve(pgpfa_ctx* c, int nb, const double* R, double* Z) {
     GemmP y{};                                               // Y = F^T (Gb R)          (rpad x nb)
     y.A = c->FTbig; y.sA = 0; y.lda = rpad; y.B = c->Xt; y.sB = 0; y.ldb = c->ld; y.C = c->Glt; y.sC = 0; y.ldc = c->ld;
     y.M = rpad; y.N = nb; y.K = c->npad; y.alpha = 1.0; y.beta = 0.0; y.slots = nullptr; y.nbatch = 1; y.mode = GEMM_FULL; y.kflags = 0;
-    y.krange = c->d_kr_ft; y.flops_hint = 2.0 * c->T * c->rtot * nb;      // block-diagonal operand: only T x r_k blocks are non-zero
+    y.krange = c->d_kr_ft; y.k_loop_hint = c->kr_ft_len; y.flops_hint = 2.0 * c->T * c->rtot * nb;      // block-diagonal operand: only T x r_k blocks are non-zero
     CHK(gemm(c, true, y));
     GemmP z{};                                               // Zs = Sb Y
     z.A = c->sU; z.sA = 0; z.lda = rpad; z.B = c->Glt; z.sB = 0; z.ldb = c->ld; z.C = c->KD; z.sC = 0; z.ldc = c->ld;
@@ -1160,7 +1167,7 @@ static int shared_solve(pgpfa_ctx* c, int nb, const double* R, double* Z) {
     GemmP q{};                                               // Q = F Zs                (n x nb)
     q.A = c->Fbig; q.sA = 0; q.lda = c->ld; q.B = c->KD; q.sB = 0; q.ldb = c->ld; q.C = c->Xt; q.sC = 0; q.ldc = c->ld;
     q.M = c->n; q.N = nb; q.K = rpad; q.alpha = 1.0; q.beta = 0.0; q.slots = nullptr; q.nbatch = 1; q.mode = GEMM_FULL; q.kflags = 0;
-    q.krange = c->d_kr_f; q.flops_hint = 2.0 * c->T * c->rtot * nb;
+    q.krange = c->d_kr_f; q.k_loop_hint = c->kr_f_len; q.flops_hint = 2.0 * c->T * c->rtot * nb;
     CHK(gemm(c, true, q));
     apply_bin(R, c->Xt, c->eps, Z);
     HIPC(hipGetLastError());
