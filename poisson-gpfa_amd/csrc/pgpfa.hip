@@ -932,6 +932,19 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
     if (v != 0.0) {
       prof_collect(c);
       c->prof.ms.clear(); c->prof.flops.clear(); c->prof.count.clear(); c->prof.max_ms.clear(); c->prof.max_flops.clear();
+      // the events the run will cycle through are created and recorded once NOW: the runtime sets up its signal pools
+      // on first use (a one-off ~30 ms that would otherwise land somewhere inside the region being timed)
+      HIPC(hipSetDevice(c->device));
+      const size_t want = 2 * (256 + 64) + 2;
+      while (c->prof.pool.size() < want) {
+        hipEvent_t e;
+        HIPC(hipEventCreate(&e));
+        c->prof.pool.push_back(e);
+        c->prof.idle.push_back(e);
+      }
+      for (int rep = 0; rep < 8; ++rep)            // (the one-off was seen after ~2000 recordings, not at creation)
+        for (hipEvent_t e : c->prof.idle) HIPC(hipEventRecord(e, c->st));
+      HIPC(hipStreamSynchronize(c->st));
     }
     c->prof.on = (v != 0.0);
     c->prof.only_tag = (v == 2.0) ? TAG_GEMM : -1;
