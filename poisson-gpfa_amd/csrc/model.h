@@ -1721,18 +1721,23 @@ __global__ void bin_blocks_kernel(const double* __restrict__ W, long long sW, do
 // (Wt_t is symmetric).  grid = (tile pairs, slots), block = 256.
 constexpr int AB_TK = 32;     // bins per LDS chunk
 constexpr int AB_LD = 81;     // LDS row stride of a staged panel (64 columns + pad; odd*... keeps writes conflict-free)
+constexpr int AB_SLOTS = 2;   // slots per workgroup: the F panels are the same for every slot, only the weights differ,
+                              // so one staged chunk (one exposed global-load latency) feeds AB_SLOTS x 32 MFMAs per wave
+                              // (measured 2: -23 %; 3 and 4 lose resident workgroups to the extra accumulators)
 __global__ __launch_bounds__(256) void assemble_b_kernel(double* __restrict__ Bm, long long sB, int ldb, int nblk,
                                                          const double* __restrict__ F, int Tf, int T, int p,
                                                          const int* __restrict__ blk_lat, const int* __restrict__ blk_col,
-                                                         const double* __restrict__ Wt, long long sW, const int* __restrict__ slots) {
+                                                         const double* __restrict__ Wt, long long sW, const int* __restrict__ slots,
+                                                         int nslots) {
   __shared__ double FR[AB_TK * AB_LD];                   // row-side panel  [bin][column]
   __shared__ double FC[AB_TK * AB_LD];                   // column-side panel
-  __shared__ double WL[AB_TK * 16];                      // weights [bin][row block * 4 + column block]
+  __shared__ double WL[AB_SLOTS][AB_TK * 16];            // weights [slot][bin][row block * 4 + column block]
   __shared__ int lat_r[4], lat_c[4], col_r[4], col_c[4];
   int bi = 0, rem = blockIdx.x;
   while (rem > bi) { rem -= bi + 1; ++bi; }
   const int bj = rem;                                    // bj <= bi, in units of 64
-  const size_t slot = slots[blockIdx.y];
+  const int s_first = blockIdx.y * AB_SLOTS;
+  const int ns = min(AB_SLOTS, nslots - s_first);        // block-uniform
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
   const int wr = wave >> 1, wc = wave & 1;
@@ -1750,20 +1755,28 @@ __global__ __launch_bounds__(256) void assemble_b_kernel(double* __restrict__ Bm
     srcR[i] = lat_r[blk] < 0 ? nullptr : F + (size_t)lat_r[blk] * Tf * Tf + (size_t)(col_r[blk] + (cc & 15)) * Tf + lt;
     srcC[i] = lat_c[blk] < 0 ? nullptr : F + (size_t)lat_c[blk] * Tf * Tf + (size_t)(col_c[blk] + (cc & 15)) * Tf + lt;
   }
-  const double* wsrc[2];
+  // weights: element e = tid + 256 i of a slot's [bin][16] table; the same (bin, block pair) for every slot
+  long long woff[2];
   int wt_bin[2];
+  bool wok[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int e = tid + 256 * i, pr = e & 15;
     const int la = lat_r[pr >> 2], lb = lat_c[pr & 3];
     wt_bin[i] = e >> 4;
-    wsrc[i] = (la < 0 || lb < 0) ? nullptr : Wt + slot * sW + (size_t)wt_bin[i] * p * p + (size_t)la * p + lb;
+    wok[i] = !(la < 0 || lb < 0);
+    woff[i] = wok[i] ? (long long)wt_bin[i] * p * p + (long long)la * p + lb : 0;
   }
-  mdouble4 acc[2][2];
+  const double* wbase[AB_SLOTS];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int sl = 0; sl < AB_SLOTS; ++sl) wbase[sl] = Wt + (size_t)slots[s_first + (sl < ns ? sl : 0)] * sW;
+  mdouble4 acc[AB_SLOTS][2][2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = mdouble4{0.0, 0.0, 0.0, 0.0};
+  for (int sl = 0; sl < AB_SLOTS; ++sl)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[sl][i][j] = mdouble4{0.0, 0.0, 0.0, 0.0};
 
   for (int t0 = 0; t0 < T; t0 += AB_TK) {                // panel rows T..Tf are zero, weights are guarded
 #pragma unroll
@@ -1772,34 +1785,44 @@ __global__ __launch_bounds__(256) void assemble_b_kernel(double* __restrict__ Bm
       FC[lt * AB_LD + lc + 8 * i] = srcC[i] ? srcC[i][t0] : 0.0;
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-      WL[tid + 256 * i] = (wsrc[i] && t0 + wt_bin[i] < T) ? wsrc[i][(size_t)t0 * p * p] : 0.0;
+    for (int sl = 0; sl < AB_SLOTS; ++sl)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        WL[sl][tid + 256 * i] = (sl < ns && wok[i] && t0 + wt_bin[i] < T) ? wbase[sl][woff[i] + (long long)t0 * p * p] : 0.0;
     __syncthreads();
 #pragma unroll
     for (int kk = 0; kk < AB_TK / 4; ++kk) {
       const int tt = kk * 4 + l4;
       const double r0 = FR[tt * AB_LD + wr * 32 + l15], r1 = FR[tt * AB_LD + wr * 32 + 16 + l15];
       const double c0 = FC[tt * AB_LD + wc * 32 + l15], c1 = FC[tt * AB_LD + wc * 32 + 16 + l15];
-      const double* wl = WL + tt * 16 + (2 * wr) * 4 + 2 * wc;
-      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(c0 * wl[0], r0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(c1 * wl[1], r0, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(c0 * wl[4], r1, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(c1 * wl[5], r1, acc[1][1], 0, 0, 0);
+#pragma unroll
+      for (int sl = 0; sl < AB_SLOTS; ++sl) {
+        if (sl >= ns) break;
+        const double* wl = WL[sl] + tt * 16 + (2 * wr) * 4 + 2 * wc;
+        acc[sl][0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(c0 * wl[0], r0, acc[sl][0][0], 0, 0, 0);
+        acc[sl][0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(c1 * wl[1], r0, acc[sl][0][1], 0, 0, 0);
+        acc[sl][1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(c0 * wl[4], r1, acc[sl][1][0], 0, 0, 0);
+        acc[sl][1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(c1 * wl[5], r1, acc[sl][1][1], 0, 0, 0);
+      }
     }
     __syncthreads();
   }
   // accumulator: i (A side, column of B) = l4 + 4 r, j (B side, row of B) = l15
-  double* out = Bm + slot * sB;
 #pragma unroll
-  for (int ri = 0; ri < 2; ++ri)
+  for (int sl = 0; sl < AB_SLOTS; ++sl) {
+    if (sl >= ns) break;
+    double* out = Bm + (size_t)slots[s_first + sl] * sB;
 #pragma unroll
-    for (int ci = 0; ci < 2; ++ci)
+    for (int ri = 0; ri < 2; ++ri)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = bi * 64 + wr * 32 + ri * 16 + l15;
-        const int col = bj * 64 + wc * 32 + ci * 16 + l4 + 4 * r;
-        if (row >= col) out[(size_t)col * ldb + row] = acc[ri][ci][r] + (row == col ? 1.0 : 0.0);
-      }
+      for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = bi * 64 + wr * 32 + ri * 16 + l15;
+          const int col = bj * 64 + wc * 32 + ci * 16 + l4 + 4 * r;
+          if (row >= col) out[(size_t)col * ldb + row] = acc[sl][ri][ci][r] + (row == col ? 1.0 : 0.0);
+        }
+  }
 }
 
 // vsm[t] <- eps*G_t + G_t * Bt_t * G_t in place (Bt_t already in vsm, trial indexed).  One thread per matrix ROW:

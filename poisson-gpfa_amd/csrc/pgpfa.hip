@@ -1209,7 +1209,7 @@ static int shared_factor_lowrank(pgpfa_ctx* c, int nb) {
   lw.ld = rpad; lw.npad = rpad; lw.nact = round_up(c->rtot, 64);
   const int nblk64 = rpad / 64, npairs = nblk64 * (nblk64 + 1) / 2;
   hipLaunchKernelGGL(assemble_b_kernel, dim3(npairs, 1), dim3(256), 0, c->st, lw.H, lw.sH, rpad, nblk64, c->Flr, c->Tp, T, p, c->d_blk_lat,
-                     c->d_blk_col, c->Wtbar, 0LL, c->ident);
+                     c->d_blk_col, c->Wtbar, 0LL, c->ident, 1);
   HIPC(hipGetLastError());
   HIPC(hipMemsetAsync(c->sws.info, 0, sizeof(int), c->st));
   CHK(factor(c, lw, nullptr, 1));
@@ -1324,8 +1324,8 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool 
   CholWS lw = c->ws;
   lw.ld = rpad; lw.npad = rpad; lw.nact = round_up(c->rtot, 64);
   const int nblk64 = rpad / 64, npairs = nblk64 * (nblk64 + 1) / 2;
-  hipLaunchKernelGGL(assemble_b_kernel, dim3(npairs, nb), dim3(256), 0, c->st, lw.H, lw.sH, rpad, nblk64, c->Flr, Tp, T, p, c->d_blk_lat,
-                     c->d_blk_col, c->Wt, sW, c->ident);
+  hipLaunchKernelGGL(assemble_b_kernel, dim3(npairs, (nb + AB_SLOTS - 1) / AB_SLOTS), dim3(256), 0, c->st, lw.H, lw.sH, rpad, nblk64, c->Flr, Tp, T, p,
+                     c->d_blk_lat, c->d_blk_col, c->Wt, sW, c->ident, nb);
   HIPC(hipGetLastError());
   HIPC(hipMemsetAsync(c->ws.info, 0, sizeof(int) * nb, c->st));
   CHK(factor(c, lw, c->ident, nb));
