@@ -1778,18 +1778,33 @@ __global__ __launch_bounds__(256) void assemble_b_kernel(double* __restrict__ Bm
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[sl][i][j] = mdouble4{0.0, 0.0, 0.0, 0.0};
 
-  for (int t0 = 0; t0 < T; t0 += AB_TK) {                // panel rows T..Tf are zero, weights are guarded
+  // register staging of the next chunk: its global loads are in flight while the current chunk is multiplied
+  double pr[8], pc[8], pw[AB_SLOTS][2];
+  auto fetch = [&](int t0) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      FR[lt * AB_LD + lc + 8 * i] = srcR[i] ? srcR[i][t0] : 0.0;
-      FC[lt * AB_LD + lc + 8 * i] = srcC[i] ? srcC[i][t0] : 0.0;
+      pr[i] = srcR[i] ? srcR[i][t0] : 0.0;
+      pc[i] = srcC[i] ? srcC[i][t0] : 0.0;
     }
 #pragma unroll
     for (int sl = 0; sl < AB_SLOTS; ++sl)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
-        WL[sl][tid + 256 * i] = (sl < ns && wok[i] && t0 + wt_bin[i] < T) ? wbase[sl][woff[i] + (long long)t0 * p * p] : 0.0;
+        pw[sl][i] = (sl < ns && wok[i] && t0 + wt_bin[i] < T) ? wbase[sl][woff[i] + (long long)t0 * p * p] : 0.0;
+  };
+  fetch(0);
+  for (int t0 = 0; t0 < T; t0 += AB_TK) {                // panel rows T..Tf are zero, weights are guarded
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      FR[lt * AB_LD + lc + 8 * i] = pr[i];
+      FC[lt * AB_LD + lc + 8 * i] = pc[i];
+    }
+#pragma unroll
+    for (int sl = 0; sl < AB_SLOTS; ++sl)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) WL[sl][tid + 256 * i] = pw[sl][i];
     __syncthreads();
+    if (t0 + AB_TK < T) fetch(t0 + AB_TK);
 #pragma unroll
     for (int kk = 0; kk < AB_TK / 4; ++kk) {
       const int tt = kk * 4 + l4;
