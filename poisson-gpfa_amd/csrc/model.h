@@ -1713,6 +1713,87 @@ __global__ void bin_blocks_kernel(const double* __restrict__ W, long long sW, do
     }
 }
 
+// The same in registers for p <= PW <= 10: the LDS version above keeps 2 p^2 + 1 doubles per thread in LDS, which at p = 10
+// leaves 29 threads per workgroup and 3 waves per CU.  Here every loop is unrolled over the packed lower triangles, so
+// the factor, its inverse and G live in VGPRs (static indices only); W is re-read from memory (cache hits) for W G.
+// One thread per (slot, bin).  grid = ceil(nslots*T / 128), block = 128.
+template <int PW>
+__global__ __launch_bounds__(128) void bin_blocks_reg_kernel(const double* __restrict__ W, long long sW, double* __restrict__ G,
+                                                             double* __restrict__ Wt, long long sO, int T, int p, double eps,
+                                                             const int* __restrict__ slots, int nslots, double* __restrict__ ldet) {
+  constexpr int NP = PW * (PW + 1) / 2;
+  const long long item = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (item >= (long long)nslots * T) return;
+  const int slot = slots[item / T];
+  const int t = (int)(item % T);
+  const int pp = p * p;
+  const double* w = W + (size_t)slot * sW + (size_t)t * pp;
+  double L[NP];                                   // A = I + eps W (lower) -> Cholesky factor -> its inverse
+#pragma unroll
+  for (int i = 0; i < PW; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) L[i * (i + 1) / 2 + j] = ((i < p && j < p) ? eps * w[i * p + j] : 0.0) + (i == j ? 1.0 : 0.0);
+  double logdet = 0.0;
+#pragma unroll
+  for (int j = 0; j < PW; ++j) {
+    double dj = L[j * (j + 1) / 2 + j];
+#pragma unroll
+    for (int m = 0; m < j; ++m) dj -= L[j * (j + 1) / 2 + m] * L[j * (j + 1) / 2 + m];
+    logdet += log(dj);
+    dj = sqrt(dj);
+    L[j * (j + 1) / 2 + j] = dj;
+#pragma unroll
+    for (int i = j + 1; i < PW; ++i) {
+      double v = L[i * (i + 1) / 2 + j];
+#pragma unroll
+      for (int m = 0; m < j; ++m) v -= L[i * (i + 1) / 2 + m] * L[j * (j + 1) / 2 + m];
+      L[i * (i + 1) / 2 + j] = v / dj;
+    }
+  }
+  if (ldet) ldet[item] = logdet;
+  // invert L in place, column by column (column j reads L[i][m], m >= j, and L[i][i], i > j: still un-inverted then)
+#pragma unroll
+  for (int j = 0; j < PW; ++j) {
+    L[j * (j + 1) / 2 + j] = 1.0 / L[j * (j + 1) / 2 + j];
+#pragma unroll
+    for (int i = j + 1; i < PW; ++i) {
+      double v = 0.0;
+#pragma unroll
+      for (int m = j; m < i; ++m) v -= L[i * (i + 1) / 2 + m] * L[m * (m + 1) / 2 + j];
+      L[i * (i + 1) / 2 + j] = v / L[i * (i + 1) / 2 + i];
+    }
+  }
+  // G = L^-T L^-1 (lower)
+  double Gm[NP];
+#pragma unroll
+  for (int i = 0; i < PW; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {
+      double v = 0.0;
+#pragma unroll
+      for (int m = i; m < PW; ++m) v += L[m * (m + 1) / 2 + i] * L[m * (m + 1) / 2 + j];
+      Gm[i * (i + 1) / 2 + j] = v;
+    }
+  double* g = G + (size_t)slot * sO + (size_t)t * pp;
+  double* wt = Wt + (size_t)slot * sO + (size_t)t * pp;
+#pragma unroll
+  for (int i = 0; i < PW; ++i) {
+    double wrow[PW];
+#pragma unroll
+    for (int m = 0; m < PW; ++m) wrow[m] = (i < p && m < p) ? w[i * p + m] : 0.0;
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+      double v = 0.0;
+#pragma unroll
+      for (int m = 0; m < PW; ++m) v += wrow[m] * ((m >= j) ? Gm[m * (m + 1) / 2 + j] : Gm[j * (j + 1) / 2 + m]);
+      if (i < p && j < p) {
+        g[i * p + j] = (j <= i) ? Gm[i * (i + 1) / 2 + j] : Gm[j * (j + 1) / 2 + i];
+        wt[i * p + j] = v;
+      }
+    }
+  }
+}
+
 // B = I + F^T Wt F (lower triangle) for the low-rank engine.  B is cut into 16-wide blocks that never straddle a
 // latent (ranks are padded to 16): block (bi, bj) is sum_t F_ka[t][a] Wt_t[ka][kb] F_kb[t][b].
 // One workgroup (4 waves, 2x2 MFMA tiles each) per 64x64 tile of B: 32-bin chunks of the two F column panels and

@@ -1195,16 +1195,36 @@ static int shared_solve(pgpfa_ctx* c, int nb, const double* R, double* Z) {
   return gemm(c, true, g);
 }
 
+// per (slot, bin) blocks G = (I + eps W)^-1, Wt = W G [, log det]: register kernel up to 10 latents, LDS kernel beyond
+static int bin_blocks(pgpfa_ctx* c, const double* W, long long sW, double* G, double* Wt, long long sO, int nslots, double* ldet) {
+  const int T = c->T, p = c->p, pp = p * p;
+  const long long items = (long long)nslots * T;
+  bool done = false;
+  if (p <= 10) {
+    dispatch_pw(p, [&](auto pw) {
+      constexpr int PW = decltype(pw)::value;
+      if constexpr (PW <= 10) {
+        hipLaunchKernelGGL(bin_blocks_reg_kernel<PW>, dim3((unsigned)((items + 127) / 128)), dim3(128), 0, c->st, W, sW, G, Wt, sO, T, p, c->eps,
+                           c->ident, nslots, ldet);
+        done = true;
+      }
+    });
+  }
+  if (!done) {
+    int th = (int)(48 * 1024 / ((2 * pp + 1) * sizeof(double)));
+    th = std::max(1, std::min(64, th));
+    hipLaunchKernelGGL(bin_blocks_kernel, dim3((unsigned)((items + th - 1) / th)), dim3(th), (size_t)th * (2 * pp + 1) * sizeof(double), c->st, W, sW, G,
+                       Wt, sO, T, p, c->eps, c->ident, nslots, ldet);
+  }
+  HIPC(hipGetLastError());
+  return 0;
+}
+
 // low-rank form of the shared preconditioner: Gb, Wtb from the mean curvature, Sb = (I + F^T Wtb F)^-1 (r x r, one slot)
 static int shared_factor_lowrank(pgpfa_ctx* c, int nb) {
   const int T = c->T, p = c->p, pp = p * p, len = T * pp, rpad = c->rpad;
   hipLaunchKernelGGL(mean_w_kernel, dim3((len + 255) / 256), dim3(256), 0, c->st, c->W, (long long)len, c->ident, nb, len, c->Wbar);
-  {
-    int th = (int)(48 * 1024 / ((2 * pp + 1) * sizeof(double)));
-    th = std::max(1, std::min(64, th));
-    hipLaunchKernelGGL(bin_blocks_kernel, dim3((unsigned)((T + th - 1) / th)), dim3(th), (size_t)th * (2 * pp + 1) * sizeof(double), c->st,
-                       c->Wbar, 0LL, c->Gbar, c->Wtbar, 0LL, T, p, c->eps, c->ident, 1, (double*)nullptr);
-  }
+  CHK(bin_blocks(c, c->Wbar, 0LL, c->Gbar, c->Wtbar, 0LL, 1, nullptr));
   CholWS lw = c->sws;
   lw.ld = rpad; lw.npad = rpad; lw.nact = round_up(c->rtot, 64);
   const int nblk64 = rpad / 64, npairs = nblk64 * (nblk64 + 1) / 2;
@@ -1313,13 +1333,7 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool 
   const long long sW = (long long)T * pp;
   c->last_cov_lowrank = true;
   // a. per-bin blocks G = (I + eps W)^-1, Wt = W G
-  {
-    int th = (int)(48 * 1024 / ((2 * pp + 1) * sizeof(double)));
-    th = std::max(1, std::min(64, th));
-    const long long items = (long long)nb * T;
-    hipLaunchKernelGGL(bin_blocks_kernel, dim3((unsigned)((items + th - 1) / th)), dim3(th), (size_t)th * (2 * pp + 1) * sizeof(double), c->st,
-                       c->W, sW, c->Gbin, c->Wt, sW, T, p, c->eps, c->ident, nb, logdet_out ? c->ldet_buf : (double*)nullptr);
-  }
+  CHK(bin_blocks(c, c->W, sW, c->Gbin, c->Wt, sW, nb, logdet_out ? c->ldet_buf : nullptr));
   // b. B = I + F^T Wt F into the factor slabs viewed with ld = rpad; factor; L^-T
   CholWS lw = c->ws;
   lw.ld = rpad; lw.npad = rpad; lw.nact = round_up(c->rtot, 64);
