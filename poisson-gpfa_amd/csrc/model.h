@@ -1457,31 +1457,44 @@ __global__ __launch_bounds__(256) void pcg_hessvec_dot_kernel(const double* __re
   const int t0 = blockIdx.x * 64;
   const int nt = min(64, T - t0);
   const double* wbase = W + slot * sW + (size_t)t0 * pp;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // the lane's slice of p and its rows of q are requested first: those loads then travel together with the W tile's
+  // instead of starting after the barrier (a block is one short chain of dependent global accesses, so their
+  // latencies add up)
+  constexpr int NK = (PW + 3) / 4;
+  const bool live = lane < nt;
+  const double* pv = P + slot * sV + t0 + lane;
+  double* q = Q + slot * sV + t0 + lane;
+  double v[PW], qk[NK];
+#pragma unroll
+  for (int l = 0; l < PW; ++l) v[l] = (live && l < p) ? pv[(size_t)l * T] : 0.0;
+#pragma unroll
+  for (int i = 0; i < NK; ++i) {
+    const int k = wave + 4 * i;
+    qk[i] = (live && k < p) ? q[(size_t)k * T] : 0.0;
+  }
   for (int e = threadIdx.x; e < nt * pp; e += 256) {
     const int t = e / pp, idx = e - t * pp;
     Ws[t * LD + idx] = wbase[e];                               // block of bin t keeps its p x p layout (stride LD)
   }
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double acc = 0.0;
-  if (lane < nt) {
-    const int t = t0 + lane;
-    const double* pv = P + slot * sV + t;
-    double* q = Q + slot * sV + t;
+  if (live) {
     const double* wt = Ws + lane * LD;
-    double v[PW];
 #pragma unroll
-    for (int l = 0; l < PW; ++l) v[l] = (l < p) ? pv[(size_t)l * T] : 0.0;
-    for (int k = wave; k < p; k += 4) {
-      double s2 = q[(size_t)k * T];
+    for (int i = 0; i < NK; ++i) {
+      const int k = wave + 4 * i;
+      if (k < p) {
+        double s2 = qk[i];
 #pragma unroll
-      for (int l = 0; l < PW; ++l)
-        if (l < p) s2 += wt[k * p + l] * v[l];
-      q[(size_t)k * T] = s2;
-      double vk = 0.0;
+        for (int l = 0; l < PW; ++l)
+          if (l < p) s2 += wt[k * p + l] * v[l];
+        q[(size_t)k * T] = s2;
+        double vk = 0.0;
 #pragma unroll
-      for (int l = 0; l < PW; ++l) vk = (l == k) ? v[l] : vk;
-      acc += s2 * vk;
+        for (int l = 0; l < PW; ++l) vk = (l == k) ? v[l] : vk;
+        acc += s2 * vk;
+      }
     }
   }
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
