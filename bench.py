@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Headline benchmark: EM iterations/s of the Poisson-GPFA hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c2|c1] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c2|c1] [--no-cpu-baseline] [--cpu-trial]
+                    [--workload em|online|loo]
 
 A step is one full batch-EM iteration on synthetic spike counts already resident in HBM: warm-started Laplace
 E-step over every trial (batched inexact Newton with the shared-preconditioner PCG, posterior covariance blocks by
@@ -14,6 +15,14 @@ configuration the north-star target is quoted on.  For N > 1 the driver launches
 torch.distributed.run; every rank owns 1024 trials (weak scaling, config 4's 8192 trials at N = 8), the
 M-step sufficient statistics are summed with RCCL all-reduces.  `value` counts EM iterations per
 second in units of 1024-trial batches: at N = 1 it is plain EM iterations/s on config 3.
+
+`--gpus N` without a launcher (no RANK in the environment) starts the N ranks itself: the parent - which never touches the
+GPU - spawns N children of this script with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set, relays
+rank 0's JSON line and exits with the worst child status.  Under torch.distributed.run the ranks exist already.
+
+`--workload online` is BASELINE config 4: stochastic EM ('diag' updates, engine.py:288-448) over 8192 resident trials with
+minibatches of 1024; the minibatch is split over the ranks (strong scaling of one EM iteration), every rank holds the packed
+count tensor (0.8 GB).
 
 Prints ONE JSON line (rank 0).  The timed region is bracketed by a collective + device sync on both
 sides and the reported time is the max over ranks.
@@ -94,16 +103,22 @@ def synth_shard(q, p, T, R, seed, rank):
     return {'C': C, 'd': d, 'tau': tau}, Ys
 
 
-def cpu_baseline(q, p, T, R, true_params, Y0, bin_ms, init):
+def cpu_baseline(q, p, T, R, true_params, Y0, bin_ms, init, full_trial=False):
     """Reference-faithful CPU path (the oracle in 'faithful' mode = the reference's big-matrix
-    arithmetic and scipy drivers), timed on a bounded sample and scaled to one EM iteration."""
+    arithmetic and scipy drivers), timed on a bounded sample and scaled to one EM iteration.
+    full_trial (--cpu-trial): time ONE whole faithful trial whatever its size (config 3: minutes, ~9 GB)."""
     from oracle import pgpfa_oracle as orc
     import scipy.optimize as op  # noqa: F401
     cores = os.cpu_count()
     n = p * T
     Ys = [Y0.astype(np.float64)]
     t0 = time.time()
-    if n <= 1200:
+    if full_trial and n > 1200:
+        orc.laplace(Ys, init, bin_ms, mode='faithful', return_cov=True)
+        per_trial = time.time() - t0
+        sample = ('MEASURED: 1 full trial of the faithful Laplace E-step (scipy Newton-CG on the big-matrix callbacks + dense inverse, '
+                  'inference.py:119-131), %.1f s; scaled by the trial count (the reference loops trials sequentially); M-step not counted' % per_trial)
+    elif n <= 1200:
         # small enough to run whole trials: faithful Laplace E-step on a few trials
         ntr = 2 if n > 400 else 8
         Ys = [Y0.astype(np.float64)] * ntr
@@ -130,8 +145,9 @@ def cpu_baseline(q, p, T, R, true_params, Y0, bin_ms, init):
         np.linalg.inv(H)
         t_i = time.time() - t1
         per_trial = 15 * t_h + t_i
-        sample = ('2 dense Hessian builds (%.1f s each) + 1 dense inverse (%.1f s) of one config-3 trial; per-trial E-step = '
-                  '15 builds + 1 inverse (iteration count measured on the reference, BASELINE.md); M-step not counted' % (t_h, t_i))
+        sample = ('ESTIMATED from 2 dense Hessian builds (%.1f s each) + 1 dense inverse (%.1f s) of one config-3 trial; per-trial E-step = '
+                  '15 builds + 1 inverse (iteration count measured on the reference, BASELINE.md); M-step not counted; '
+                  '--cpu-trial times one whole faithful trial instead' % (t_h, t_i))
     em_iter_s = per_trial * R
     return {'value': 1.0 / em_iter_s, 'unit': 'EM-iterations/s', 'cores': cores, 'kind': 'port', 'sample': sample,
             'estep_s_per_trial': per_trial}
@@ -187,6 +203,97 @@ def run_loo(args, q, p, T, R):
     print(json.dumps(out))
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` with no launcher: start the N ranks as children (this parent never initialises the GPU -
+    a process that has must not be replaced by or fork into another program on this pool), relay rank 0's JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [pr.wait() for pr in procs]
+    sys.stdout.write(out.decode('utf-8', 'replace'))
+    sys.stdout.flush()
+    worst = max((abs(c) for c in codes), default=0)
+    if worst:
+        sys.stderr.write('bench.py: rank exit codes %s\n' % codes)
+    sys.exit(1 if worst else 0)
+
+
+def run_online(args, q, p, T, rank, world):
+    """BASELINE config 4: stochastic EM (engine.py:288-448, 'diag' updates) - every iteration draws a minibatch from the
+    resident trials with the reference's RNG call (util.py:459-473; same stream on every rank), each rank runs the Laplace
+    E-step on its slice of the minibatch, the M-step statistics are all-reduced, the prior-regularised M-step
+    (learning.py:833-866) runs replicated.  One JSON line."""
+    import funs
+    from funs import _session
+    Rres, batch = args.resident, args.batch
+    true_params, Ys = synth_shard(q, p, T, Rres, args.seed, 0)          # same trials on every rank
+    exp = Shard(Ys, 10.0)
+    exp._pgpfa_local_shard = False                                       # ranks slice each trial list
+    sess, _ = _session.session_for(exp, p)
+    np.random.seed(0)
+    params = funs.util.initializeParams(p, q, exp)
+    params = {k: np.real(np.asarray(v)).astype(np.float64) for k, v in params.items()}
+    np.random.seed(1)
+    prior = np.diag(np.ones(q * (p + 1)))
+    est, mst, nlls, pcgs, idx_sum = [], [], [], [], []
+    cd_method = args.cd_method
+    state = {'n': 0}
+
+    def step():
+        n = state['n']
+        sub = funs.util.subsampleTrials(exp, batch)
+        t0 = time.time()
+        infRes, nll, _ = funs.inference.laplace(sub, params_box[0], prevOptimRes='resident')
+        t1 = time.time()
+        sz = 1.0 / (n + 1) ** 0.75                                       # engine.py:275-278, stepPow = 0.75
+        new, _, pr = funs.learning.updateParamsWithPrior(params_box[0], infRes, sub, cd_method, 'TNC', sz, sz, prior_box[0], covOpts='useDiag')
+        t2 = time.time()
+        params_box[0], prior_box[0] = new, pr
+        est.append((t1 - t0) * 1e3); mst.append((t2 - t1) * 1e3); nlls.append(float(nll))
+        pcgs.append(sess.ctx.info('last_pcg_iterations') / max(1, len(infRes.trial_idx)))
+        idx_sum.append(int(np.sum(sub.batchTrIdx)))
+        state['n'] = n + 1
+    params_box, prior_box = [params], [prior]
+
+    def barrier():
+        sess.allreduce(np.zeros(1))
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t_begin = time.time()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.time() - t_begin
+    times = np.zeros(world)
+    times[rank] = elapsed
+    t_max = float(np.max(sess.allreduce(times)))
+    if rank != 0:
+        return
+    timed = slice(args.warmup, args.warmup + args.steps)
+    out = {'metric': 'EM iterations/sec', 'value': args.steps / t_max, 'unit': 'stochastic-EM iterations/s (minibatch %d of %d resident trials)' % (batch, Rres),
+           'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': t_max / args.steps * 1e3,
+           'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+           'config': {'workload': 'c4: %d neurons, %d latents, %d bins, %d resident trials, stochastic EM minibatch=%d split over %d GPU(s), '
+                                  "'diag' prior updates ((C,d) by %s, tau by scipy TNC as the reference engine)"
+                                  % (q, p, T, Rres, batch, world, 'device per-neuron Newton' if cd_method == 'newton' else 'scipy ' + cd_method),
+                      'parallelism': 'minibatch-sharded x%d' % world},
+           'estep_ms': [round(x, 1) for x in est], 'mstep_ms': [round(x, 1) for x in mst],
+           'estep_ms_per_trial': float(np.mean(est[timed])) / (batch / world), 'pcg_iterations_per_trial': [round(x, 1) for x in pcgs],
+           'nll': nlls, 'minibatch_index_checksums': idx_sum,
+           'lowrank_plan': sess.ctx.info('plan_lowrank'), 'lowrank_rtot': sess.ctx.info('lowrank_rtot'), 'chunk_trials': sess.ctx.info('chunk_trials')}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -199,21 +306,35 @@ def main():
                     help="(C,d) M-step solver: 'newton' = device per-neuron Newton (exact minimiser of the reference's cost); "
                          "'TNC' = the reference engine's default scipy driver on the same device cost/grad")
     ap.add_argument('--seed', type=int, default=12)
-    ap.add_argument('--workload', default='em', choices=['em', 'loo'],
-                    help="'em' (default): the headline EM-iterations/s metric; 'loo': leave-one-neuron-out prediction throughput (1 GPU)")
+    ap.add_argument('--workload', default='em', choices=['em', 'online', 'loo'],
+                    help="'em' (default): the headline EM-iterations/s metric (config 3); 'online': config 4, stochastic EM with "
+                         "minibatches over a larger resident set; 'loo': leave-one-neuron-out prediction throughput (1 GPU)")
+    ap.add_argument('--cpu-trial', action='store_true',
+                    help='cpu_baseline times ONE whole reference-faithful trial (config 3: ~5 minutes, ~9 GB) instead of the bounded sample')
+    ap.add_argument('--resident', type=int, default=8192, help="--workload online: trials resident in HBM (all ranks hold the counts)")
+    ap.add_argument('--batch', type=int, default=1024, help="--workload online: minibatch size (split over the ranks)")
+    ap.add_argument('--dry-run', action='store_true', help='launcher self-test: every rank reports its environment and exits (no GPU work)')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        return spawn_ranks(args.gpus)
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus:
-        if args.gpus != 1 and world == 1:
-            raise SystemExit('bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)' % args.gpus)
+        raise SystemExit('bench.py --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    if args.dry_run:
+        if rank == 0:
+            print(json.dumps({'dry_run': True, 'rank': rank, 'world': world, 'local_rank': int(os.environ.get('LOCAL_RANK', '0')),
+                              'master': '%s:%s' % (os.environ.get('MASTER_ADDR'), os.environ.get('MASTER_PORT')), 'ppid': os.getppid()}))
+        return
     q, p, T, R = CONFIGS[args.config]
     if args.trials > 0:
         R = args.trials
     bin_ms = 10.0
     if args.workload == 'loo':
         return run_loo(args, q, p, T, R)
+    if args.workload == 'online':
+        return run_online(args, q, p, T, rank, world)
 
     import funs
     from funs import _hip, _session
@@ -317,7 +438,8 @@ def main():
                      'measured_sustained_mfma_tflops': sustained,
                      'achieved': achieved, 'peak': FP64_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / FP64_MATRIX_PEAK_TFLOPS,
                      'traffic': pmc_traffic_per_launch('void pgpfa::gemm_mfma_kernel') if args.config == 'c3' else None,
-                     'traffic_unit': 'HBM bytes per launch (PMC, profiles/r01_c3_pmc_hbm_traffic.json)',
+                     'traffic_unit': 'HBM bytes per launch',
+                     'traffic_source': 'NOT measured in this run: committed rocprofv3 PMC passes of this command (%s), pooled over the GEMM instantiations' % os.path.relpath(PMC_SUMMARY, ROOT),
                      'algorithmic_flops_per_launch': gemm_flops / max(gemm_launches, 1.0), 'launches': gemm_launches, 'avg_launch_ms': gemm_ms / max(gemm_launches, 1.0),
                      'kernel_share_of_step': gemm_ms / (t_max * 1e3),
                      # the longest single launch of the timed region (config 3: the segmented-K product sum_r Y~ Y~^T)
@@ -326,8 +448,9 @@ def main():
                                         'frac': gemm_max_flops / (gemm_max_ms * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS if gemm_max_ms > 0 else 0.0}},
     }
     if not args.no_cpu_baseline and world == 1:
-        out['cpu_baseline'] = cpu_baseline(q, p, T, R, true_params, Ys[0], bin_ms, init)
+        out['cpu_baseline'] = cpu_baseline(q, p, T, R, true_params, Ys[0], bin_ms, init, full_trial=args.cpu_trial)
         out['speedup_vs_cpu_baseline'] = (args.steps / t_max) / out['cpu_baseline']['value']
+        out['speedup_vs_cpu_baseline_note'] = 'ratio to the cpu_baseline sample as described there (E-step only on the CPU side)'
     print(json.dumps(out))
 
 

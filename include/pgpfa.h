@@ -158,6 +158,11 @@ int pgpfa_dual_costgrad_batch(pgpfa_ctx* ctx, int n, const int32_t* idx, const d
  * rho[n][q*T]: start in, optimum out; fopt[n]: dual optimum (inference.py:325/397); iters[n] may be NULL. */
 int pgpfa_dual_lbfgs(pgpfa_ctx* ctx, int n, const int32_t* idx, double* rho, int max_iter, double factr, double pgtol,
                      double* fopt, int32_t* iters);
+/* VIPostMean (inference.py:193-194): mean[p*T] = -K_big C_big (lambda - ybar) for one trial, latent-major. */
+int pgpfa_dual_post_mean(pgpfa_ctx* ctx, int trial, const double* lam, double* mean);
+/* VIPostCov (inference.py:188-191) for one trial, dense [pT][pT] latent-major: prec = K_big^-1 + C_big diag(lambda) C_big^T
+ * (may be NULL) and cov = (prec + 1e-6 diag(diag(prec)))^-1. */
+int pgpfa_dual_post_cov(pgpfa_ctx* ctx, int trial, const double* lam, double* cov, double* prec);
 /* VIPostMean / VIPostCov blocks at lambda for the listed trials; fills the same posterior
  * slots as the Laplace E-step and returns sum of negLogPosteriorUnNorm at the VI mean. */
 int pgpfa_dual_finalize(pgpfa_ctx* ctx, int n, const int32_t* idx, const double* lam /* [n][q*T] */,

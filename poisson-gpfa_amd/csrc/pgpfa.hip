@@ -768,16 +768,26 @@ int allreduce_dev(pgpfa_ctx* c, double* buf, size_t count) {
 struct Trials {
   std::vector<int> v;
 };
-int resolve_trials(pgpfa_ctx* c, int n, const int32_t* idx, Trials* out) {
+// distinct = true for every entry point that writes per-trial state (two slots of one chunk scattering to the same
+// trial row would race, and the device list of the last E-step holds R entries)
+int resolve_trials(pgpfa_ctx* c, int n, const int32_t* idx, Trials* out, bool distinct = false) {
   if (idx == nullptr) {
     out->v.resize(c->R);
     for (int i = 0; i < c->R; ++i) out->v[i] = i;
     return 0;
   }
   if (n < 1) return fail("empty trial list");
-  out->v.assign(idx, idx + n);
   for (int i = 0; i < n; ++i)
     if (idx[i] < 0 || idx[i] >= c->R) return fail("trial index %d out of range [0,%d)", idx[i], c->R);
+  if (distinct) {
+    if (n > c->R) return fail("trial list of %d entries for %d resident trials", n, c->R);
+    std::vector<char> seen(c->R, 0);
+    for (int i = 0; i < n; ++i) {
+      if (seen[idx[i]]) return fail("trial %d listed twice", idx[i]);
+      seen[idx[i]] = 1;
+    }
+  }
+  out->v.assign(idx, idx + n);
   return 0;
 }
 
@@ -893,6 +903,7 @@ int pgpfa_destroy(pgpfa_ctx* c) {
   if (c->st) hipStreamSynchronize(c->st);
   if (c->comm) ncclCommDestroy(c->comm);
   for (void* p : c->allocs) hipFree(p);
+  if (c->vsmgp) hipFree(c->vsmgp);
   if (c->arena) hipFree(c->arena);
   if (c->hbuf) hipHostFree(c->hbuf);
   if (c->hibuf) hipHostFree(c->hibuf);
@@ -1127,7 +1138,7 @@ int pgpfa_set_modes(pgpfa_ctx* c, int n, const int32_t* idx, const double* X) {
   if (!c || !X) return fail("null argument");
   HIPC(hipSetDevice(c->device));
   Trials tr;
-  CHK(resolve_trials(c, n, idx, &tr));
+  CHK(resolve_trials(c, n, idx, &tr, true));
   for (size_t i = 0; i < tr.v.size(); ++i)
     HIPC(hipMemcpyAsync(c->Xmode + (size_t)tr.v[i] * c->n, X + i * c->n, c->n * sizeof(double), hipMemcpyHostToDevice, c->st));
   HIPC(hipStreamSynchronize(c->st));
@@ -1281,9 +1292,19 @@ static int ensure_mt_clean(pgpfa_ctx* c) {
   return 0;
 }
 
+// Per-trial T x T blocks live in an allocation of their own, freed only with the context: allocated lazily (often in the
+// middle of an E-step, i.e. after the workspace mark), it must not be swept up by free_workspace on a re-plan.
 static int ensure_vsmgp_buffer(pgpfa_ctx* c) {
   if (c->vsmgp) return 0;
-  return dmalloc(c, &c->vsmgp, (size_t)c->R * c->p * c->T * c->T, true);
+  const size_t bytes = (size_t)c->R * c->p * c->T * c->T * sizeof(double);
+  void* ptr = nullptr;
+  hipError_t e = hipMalloc(&ptr, bytes);
+  if (e != hipSuccess) { (void)hipGetLastError(); return fail("hipMalloc(%zu bytes) for the per-trial post_vsmGP blocks failed: %s", bytes, hipGetErrorString(e)); }
+  e = hipMemsetAsync(ptr, 0, bytes, c->st);
+  if (e != hipSuccess) { hipFree(ptr); return fail("hipMemset failed: %s", hipGetErrorString(e)); }
+  c->vsmgp = reinterpret_cast<double*>(ptr);
+  c->bytes += bytes;
+  return 0;
 }
 
 static int posterior_blocks_dense(pgpfa_ctx* c, int nb, double diag_scale, bool want_vsmgp) {
@@ -1804,7 +1825,7 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
 int pgpfa_estep_laplace(pgpfa_ctx* c, int n, const int32_t* idx, int warm_start, double* obj_sum, int32_t* iters, int32_t* status) {
   if (!c) return fail("null context");
   Trials tr;
-  CHK(resolve_trials(c, n, idx, &tr));
+  CHK(resolve_trials(c, n, idx, &tr, true));
   const int N = (int)tr.v.size();
   std::vector<int32_t> it1(N), st1(N);
   double obj = 0.0;
@@ -2033,7 +2054,7 @@ int pgpfa_set_posterior(pgpfa_ctx* c, int n, const int32_t* idx, const double* p
   if (!c || !post_mean || !post_vsm) return fail("null argument");
   HIPC(hipSetDevice(c->device));
   Trials tr;
-  CHK(resolve_trials(c, n, idx, &tr));
+  CHK(resolve_trials(c, n, idx, &tr, true));
   const size_t lm = c->n, lv = (size_t)c->T * c->p * c->p, lg = (size_t)c->T * c->T * c->p;
   double* tmp = nullptr;
   if (post_vsmgp) CHK(ensure_vsmgp_buffer(c));
@@ -2472,6 +2493,64 @@ int pgpfa_dual_costgrad(pgpfa_ctx* c, int trial, const double* lam, double* cost
   return 0;
 }
 
+// VIPostMean (inference.py:193-194): -K_big C_big (lambda - y) for one trial, latent-major [p*T].
+int pgpfa_dual_post_mean(pgpfa_ctx* c, int trial, const double* lam, double* mean) {
+  CHK(ready(c));
+  if (!lam || !mean) return fail("null argument");
+  if (trial < 0 || trial >= c->R) return fail("trial %d out of range", trial);
+  CHK(ensure_lambda(c));
+  const int q = c->q, T = c->T;
+  std::vector<int> tr{trial};
+  CHK(upload_list(c, c->trial_of_slot, tr));
+  CHK(upload(c, c->lamd, lam, (size_t)q * T));
+  std::vector<double> sB, sD, vKv;
+  CHK(dual_common(c, 1, &sB, &sD, &vKv));                              // KD <- K v,  v = C_big (lambda - y)
+  CHK(download(c, mean, c->KD, (size_t)c->n));
+  for (int i = 0; i < c->n; ++i) mean[i] = -mean[i];
+  return 0;
+}
+
+// VIPostCov (inference.py:188-191): prec = K_big^-1 + C_big diag(lambda) C_big^T (dense, latent-major; may be NULL) and
+// cov = (prec + 1e-6 diag(diag(prec)))^-1 for one trial.
+int pgpfa_dual_post_cov(pgpfa_ctx* c, int trial, const double* lam, double* cov, double* prec) {
+  CHK(ready(c));
+  if (!lam || !cov) return fail("null argument");
+  if (trial < 0 || trial >= c->R) return fail("trial %d out of range", trial);
+  CHK(ensure_lambda(c));
+  const int q = c->q, T = c->T;
+  for (size_t i = 0; i < (size_t)q * T; ++i)
+    if (!std::isfinite(lam[i])) return fail("lambda entry %zu is not finite", i);
+  std::vector<int> tr{trial};
+  CHK(upload_list(c, c->trial_of_slot, tr));
+  CHK(upload(c, c->lamd, lam, (size_t)q * T));
+  std::vector<double> sB, sD, vKv;
+  CHK(dual_common(c, 1, &sB, &sD, &vKv));                              // W <- C^T diag(lambda_t) C
+  if (prec) {
+    hipLaunchKernelGGL(dense_h_kernel, dim3(c->n), dim3(256), 0, c->st, c->ws.H, c->n, c->T, c->Tp, c->p, c->Kinv, c->W);
+    HIPC(hipGetLastError());
+    CHK(download(c, prec, c->ws.H, (size_t)c->n * c->n));
+  }
+  HIPC(hipMemsetAsync(c->ws.info, 0, sizeof(int), c->st));
+  CHK(ensure_mt_clean(c));
+  CHK(assemble(c, c->ident, 1, 1.0 + 1e-6));
+  CHK(factor(c, c->ws, c->ident, 1));
+  CHK(inverse_t(c, c->ws, c->ident, 1));
+  GemmP g{};
+  g.A = c->ws.Mt; g.sA = c->ws.sM; g.lda = c->ld;
+  g.B = c->ws.Mt; g.sB = c->ws.sM; g.ldb = c->ld;
+  g.C = c->ws.H; g.sC = c->ws.sH; g.ldc = c->ld;
+  g.M = c->npad; g.N = c->npad; g.K = c->npad; g.alpha = 1.0; g.beta = 0.0;
+  g.slots = c->ident; g.nbatch = 1; g.mode = GEMM_FULL; g.kflags = KF_BEGIN_MAXRC;
+  CHK(gemm(c, false, g));
+  int info = 0;
+  HIPC(hipMemcpyAsync(&info, c->ws.info, sizeof(int), hipMemcpyDeviceToHost, c->st));
+  HIPC(hipMemcpy2DAsync(cov, (size_t)c->n * sizeof(double), c->ws.H, (size_t)c->ld * sizeof(double), (size_t)c->n * sizeof(double), c->n,
+                        hipMemcpyDeviceToHost, c->st));
+  HIPC(hipStreamSynchronize(c->st));
+  if (info != 0) return fail("VIPostCov: posterior precision not positive definite (pivot %d)", info);
+  return 0;
+}
+
 // Dual cost (and gradient with respect to lambda, into c->dgrad) of the slots [0, nb) whose lambda is already in c->lamd and
 // whose trials are bound in c->trial_of_slot: the arithmetic of dualProblem / dualProblem_grad (inference.py:196-219) with
 // the dense factorisations of the chunk batched.
@@ -2550,7 +2629,7 @@ int pgpfa_dual_costgrad_batch(pgpfa_ctx* c, int n, const int32_t* idx, const dou
   if (!c) return fail("null context");
   if (!lam || !cost) return fail("null argument");
   Trials tr;
-  CHK(resolve_trials(c, n, idx, &tr));
+  CHK(resolve_trials(c, n, idx, &tr, true));
   const int N = (int)tr.v.size();
   c->want_slots = std::max(c->want_slots, std::min(N, c->R));
   CHK(ready_estep(c, c->dual_lowrank));
@@ -2581,7 +2660,7 @@ int pgpfa_dual_lbfgs(pgpfa_ctx* c, int n, const int32_t* idx, double* rho, int m
   if (!rho || !fopt) return fail("null argument");
   if (max_iter < 1) return fail("max_iter must be positive");
   Trials tr;
-  CHK(resolve_trials(c, n, idx, &tr));
+  CHK(resolve_trials(c, n, idx, &tr, true));
   CHK(check_distinct(tr.v));
   const int N = (int)tr.v.size();
   c->want_slots = std::max(c->want_slots, std::min(N, c->R));
@@ -2791,7 +2870,7 @@ int pgpfa_dual_finalize(pgpfa_ctx* c, int n, const int32_t* idx, const double* l
   if (!c) return fail("null context");
   if (!lam) return fail("null argument");
   Trials tr;
-  CHK(resolve_trials(c, n, idx, &tr));
+  CHK(resolve_trials(c, n, idx, &tr, true));
   const int N = (int)tr.v.size();
   c->want_slots = std::max(c->want_slots, std::min(N, c->R));
   CHK(ready_estep(c, c->dual_lowrank));

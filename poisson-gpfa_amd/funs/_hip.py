@@ -54,6 +54,8 @@ _SIGNATURES = {
     'pgpfa_dual_costgrad_batch': [ct.c_void_p, ct.c_int, c_int32_p, c_double_p, c_double_p, c_double_p],
     'pgpfa_dual_lbfgs': [ct.c_void_p, ct.c_int, c_int32_p, c_double_p, ct.c_int, ct.c_double, ct.c_double, c_double_p, c_int32_p],
     'pgpfa_dual_finalize': [ct.c_void_p, ct.c_int, c_int32_p, c_double_p, c_double_p],
+    'pgpfa_dual_post_mean': [ct.c_void_p, ct.c_int, c_double_p, c_double_p],
+    'pgpfa_dual_post_cov': [ct.c_void_p, ct.c_int, c_double_p, c_double_p, c_double_p],
     'pgpfa_comm_unique_id': [ct.c_char_p],
     'pgpfa_comm_init': [ct.c_void_p, ct.c_char_p, ct.c_int, ct.c_int],
     'pgpfa_comm_allreduce_host': [ct.c_void_p, c_double_p, ct.c_int],
@@ -271,6 +273,19 @@ class Context:
         grad = np.empty(self.q * self.T) if want_grad else None
         check(self.lib.pgpfa_dual_costgrad(self.h, int(trial), dptr(lam), ct.byref(cost), dptr(grad) if want_grad else None))
         return cost.value, grad
+
+    def dual_post_mean(self, trial, lam):
+        lam = as_f64(lam).reshape(-1)
+        out = np.empty(self.n)
+        check(self.lib.pgpfa_dual_post_mean(self.h, int(trial), dptr(lam), dptr(out)))
+        return out
+
+    def dual_post_cov(self, trial, lam, want_prec=True):
+        lam = as_f64(lam).reshape(-1)
+        cov = np.empty((self.n, self.n))
+        prec = np.empty((self.n, self.n)) if want_prec else None
+        check(self.lib.pgpfa_dual_post_cov(self.h, int(trial), dptr(lam), dptr(cov), dptr(prec) if want_prec else None))
+        return cov, prec
 
     def dual_costgrad_batch(self, idx, lam, want_grad=True):
         """Dual cost (and gradient) of the listed distinct trials, each at its own lambda: lam[n][q*T] -> cost[n], grad[n][q*T]."""

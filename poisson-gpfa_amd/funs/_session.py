@@ -136,16 +136,48 @@ class DeviceInfRes(dict):
         n = len(self.trial_idx)
         tid = self.trial_idx
         self.local_positions = local_pos                              # positions in the caller's trial list
-        self['post_mean'] = LazyTrialList(n, lambda i: ctx.post_mean(tid[i:i + 1])[0])
-        self['post_vsm'] = LazyTrialList(n, lambda i: ctx.post_vsm(tid[i:i + 1])[0])
-        self['post_vsmGP'] = LazyTrialList(n, lambda i: ctx.post_vsmgp(tid[i:i + 1])[0])
-        self['post_cov'] = LazyTrialList(n, lambda i: self._cov(i))
+        self['post_mean'] = LazyTrialList(n, lambda i: self._fresh(i, 'post_mean') and ctx.post_mean(tid[i:i + 1])[0])
+        self['post_vsm'] = LazyTrialList(n, lambda i: self._fresh(i, 'post_vsm') and ctx.post_vsm(tid[i:i + 1])[0])
+        self['post_vsmGP'] = LazyTrialList(n, lambda i: self._fresh(i, 'post_vsmGP') and ctx.post_vsmgp(tid[i:i + 1])[0])
+        self['post_cov'] = LazyTrialList(n, lambda i: self._fresh(i, 'post_cov') and ctx.post_cov(int(tid[i])))
 
-    def _cov(self, i):
-        if self.session.post_stamp != self.stamp:
-            raise _hip.HipBackendError('post_cov of a superseded E-step was requested: it is recomputed on demand '
-                                       'from the resident mode, which a later E-step has overwritten')
-        return self.session.ctx.post_cov(int(self.trial_idx[i]))
+    def _fresh(self, i, what):
+        """The reference returns immutable per-trial arrays; here entry i is a view of device memory that the next
+        E-step touching the same trial overwrites in place.  Reading it afterwards must fail, not return the newer
+        posterior under the old name (entries already fetched, or snapshotted with materialize(), stay valid)."""
+        if self.session.trial_stamp[self.trial_idx[i]] != self.stamp:
+            raise _hip.HipBackendError("infRes['%s'][%d] belongs to a superseded E-step: trial %d has been overwritten on the "
+                                       'device by a later one (call infRes.materialize() before running it to keep a host copy)'
+                                       % (what, i, int(self.trial_idx[i])))
+        return True
+
+    def materialize(self, keys=('post_mean', 'post_vsm')):
+        """Snapshot the listed entries to host arrays (bulk download) so that they survive later E-steps on the same
+        session, like the reference's per-trial arrays do."""
+        n = len(self.trial_idx)
+        if n == 0:
+            return self
+        fetch = {'post_mean': self.session.ctx.post_mean, 'post_vsm': self.session.ctx.post_vsm, 'post_vsmGP': self.session.ctx.post_vsmgp}
+        for key in keys:
+            lst = self[key]
+            missing = [i for i in range(n) if i not in lst._cache]
+            if not missing:
+                continue
+            for i in missing:
+                self._fresh(i, key)
+            step = max(1, (1 << 28) // max(1, {'post_mean': self.session.p * self.session.T, 'post_vsm': self.session.T * self.session.p ** 2,
+                                               'post_vsmGP': self.session.T ** 2 * self.session.p}[key] * 8))
+            for c0 in range(0, len(missing), step):
+                part = missing[c0:c0 + step]
+                arr = fetch[key](self.trial_idx[part])
+                for j, i in enumerate(part):
+                    lst._cache[i] = arr[j].copy()
+        return self
+
+    def host_bytes(self, keys=('post_mean', 'post_vsm')):
+        per = {'post_mean': self.session.p * self.session.T, 'post_vsm': self.session.T * self.session.p ** 2,
+               'post_vsmGP': self.session.T ** 2 * self.session.p}
+        return 8 * len(self.trial_idx) * sum(per[k] for k in keys)
 
 
 class DeviceOptimRes(LazyTrialList):
@@ -154,10 +186,17 @@ class DeviceOptimRes(LazyTrialList):
     def __init__(self, session, trial_idx):
         tid = np.asarray(trial_idx, dtype=np.int32)
         ctx = session.ctx
-        super().__init__(len(tid), lambda i: ctx.post_mean(tid[i:i + 1])[0].reshape(-1))
+        super().__init__(len(tid), lambda i: self._fresh(i) and ctx.post_mean(tid[i:i + 1])[0].reshape(-1))
         self.session = session
         self.trial_idx = tid
         self.stamp = session.mode_stamp
+        self.post_stamp = session.post_stamp
+
+    def _fresh(self, i):
+        if self.session.trial_stamp[self.trial_idx[i]] != self.post_stamp:
+            raise _hip.HipBackendError('lapOptimRes[%d] belongs to a superseded E-step: the mode of trial %d has been overwritten '
+                                       'on the device by a later one' % (i, int(self.trial_idx[i])))
+        return True
 
 
 # ----------------------------------------------------------------------------------------------
@@ -169,6 +208,7 @@ class Session:
         self.ctx.upload_counts(Y)
         self.post_stamp = 0
         self.mode_stamp = 0
+        self.trial_stamp = np.zeros(R, dtype=np.int64)      # post_stamp of the E-step that last wrote each trial's posterior
         self.rank, self.size = 0, 1
         self.comm_ready = False
         if WORLD.enabled:
@@ -187,6 +227,12 @@ class Session:
 
     def set_params(self, params):
         self.ctx.set_params(params['C'], params['d'], params['tau'])
+
+    def mark_written(self, trial_idx):
+        """An E-step (or an uploaded posterior) has just overwritten the device state of these trials."""
+        self.post_stamp += 1
+        self.mode_stamp += 1
+        self.trial_stamp[np.asarray(trial_idx, dtype=np.int64)] = self.post_stamp
 
     def local_slice(self, n_items):
         return shard_slice(n_items, self.rank, self.size)

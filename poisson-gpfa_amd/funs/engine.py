@@ -237,17 +237,31 @@ class PPGPFAfit():
 
     def leaveOneOutPrediction(self):
         """reference engine.py:599-644: y_pred_mode[numTrials][ydim][T] and pred_err_mode with the fitted parameters."""
+        self._keep_inf_res()                # (the held-out searches re-plan the chunk workspace; per-trial state stays)
         self.y_pred_mode, self.pred_err_mode = util.leaveOneOutPrediction(self.optimParams, self.experiment)
 
     def extractTrajectories(self, method='laplace'):
         """One more E-step over all trials with the fitted parameters (reference engine.py:523-532)."""
+        self._keep_inf_res()
         if method == 'laplace':
             self.infRes, self.nll_all_traj, _ = inference.laplace(self.experiment, copy.copy(self.optimParams))
         else:
             self.infRes, self.nll_all_traj, self.vlb_all_traj, _ = inference.dualVariational(
                 self.experiment, copy.copy(self.optimParams), optimizeLogLambda=self.optimLogLamb)
 
+    def _keep_inf_res(self, limit_bytes=4 << 30):
+        """self.infRes is a view of device state that the next E-step on the same trials overwrites; the reference's is a
+        list of host arrays that stays.  Before such an E-step, copy post_mean / post_vsm to the host (up to limit_bytes;
+        beyond that the entries stay lazy and reading a superseded one raises)."""
+        res = getattr(self, 'infRes', None)
+        if res is not None and hasattr(res, 'materialize') and res.host_bytes() <= limit_bytes:
+            try:
+                res.materialize()
+            except Exception:                       # already superseded: the lazy entries will say so when read
+                pass
+
     def extractTrajWithTrueParams(self, method='laplace'):
+        self._keep_inf_res()
         if method == 'laplace':
             self.infRes_trueParams, self.nll_trueParams_all_traj, _ = inference.laplace(self.experiment, copy.copy(self.experiment.params))
         else:

@@ -14,7 +14,29 @@ import numpy as np
 from . import _hip
 from ._session import DeviceInfRes, DeviceOptimRes, session_for
 
-STATUS_TEXT = {0: 'converged', 1: 'iteration limit reached', 2: 'line search failed', 3: 'Hessian not positive definite'}
+STATUS_TEXT = {0: 'converged', 1: 'iteration limit reached', 2: 'line search failed', 3: 'Hessian not positive definite',
+               4: 'left unfinished by the shared-preconditioner iteration'}
+
+
+class LaplaceConvergenceWarning(RuntimeWarning):
+    """Some trials stopped at the Newton iteration limit: their modes are the last iterates, not converged ones."""
+
+
+def _check_newton_status(status, first_trial=0):
+    """The reference ignores scipy's Newton-CG status (inference.py:127-129) - its failures are merely imprecise modes.
+    Here status 2 / 3 mean that no acceptable step exists or that the posterior precision is not positive definite at
+    the iterate (NaN / overflowing rates): such a trial's mode and covariance blocks are not a posterior and must not
+    be summed into the M-step statistics, so they raise; the iteration limit (1) only warns."""
+    status = np.asarray(status)
+    bad = np.flatnonzero((status == 2) | (status == 3) | (status == 4))
+    if bad.size:
+        raise _hip.HipBackendError('Laplace mode search failed for %d trial(s), first: trial %d (%s); parameters probably '
+                                   'give non-finite rates' % (bad.size, first_trial + int(bad[0]), STATUS_TEXT.get(int(status[bad[0]]), '?')))
+    slow = np.flatnonzero(status == 1)
+    if slow.size:
+        import warnings
+        warnings.warn('Laplace mode search hit the iteration limit for %d trial(s), first: trial %d; their modes are not '
+                      'converged' % (slow.size, first_trial + int(slow[0])), LaplaceConvergenceWarning, stacklevel=3)
 
 
 def _prepare(experiment, params):
@@ -69,8 +91,8 @@ def laplace(experiment, params, prevOptimRes=None, returnOptimRes=True, verbose=
         obj, iters, status = sess.ctx.estep_laplace(mine, warm_start=warm)
     else:
         obj, iters, status = 0.0, np.zeros(0, np.int32), np.zeros(0, np.int32)
-    sess.post_stamp += 1
-    sess.mode_stamp += 1
+    sess.mark_written(mine)
+    _check_newton_status(status, lo)
     if verbose:
         for i, (it, st) in enumerate(zip(iters, status)):
             print('laplace inference trajectory of trial %d: %d Newton factorizations, %s' % (lo + i + 1, it, STATUS_TEXT.get(int(st), '?')))
@@ -98,6 +120,199 @@ def laplace_hessian(experiment, params, X, trial=0):
     """negLogPosteriorUnNorm_hess for one trial: dense (xdim*T, xdim*T), latent-major."""
     sess, trial_idx = _prepare(experiment, params)
     return sess.ctx.laplace_hessian(int(trial_idx[trial]), X)
+
+
+# ------------------------------------------------------------------------------------------------
+# callbacks by the reference's names and positional signatures (inference.py:12-65, 188-256)
+# ------------------------------------------------------------------------------------------------
+# The reference's callers hand these functions the Kronecker "big" matrices (mcmc.py:25, util.py:319-326).  The device
+# never forms them: the small factors they were built from are read back out of their structure - C[n][k] =
+# C_big[k*T][n*T], d[n] = d_big[n*T] (util.py:594-597); K_big / K_bigInv are block diagonal with one RBF Gram matrix
+# (or its inverse) per latent, whose timescale in bins and noise level follow from two entries of a block
+# (util.py:599-619) - and checked against the matrices handed in; anything that is not such a structure raises.
+_BIG_CACHE = []          # [(C_big, d_big, Kmat, which, ybar bytes, ctx)] most recent first; arrays held so that ids stay valid
+_BIG_CACHE_MAX = 4
+
+
+def _unkron(C_big, d_big, ydim):
+    C_big = np.asarray(C_big, dtype=np.float64)
+    d_big = np.ndarray.flatten(np.asarray(d_big, dtype=np.float64))
+    T = int(len(d_big) // ydim)
+    if T < 1 or len(d_big) != ydim * T or C_big.ndim != 2 or C_big.shape[1] != ydim * T or C_big.shape[0] % T:
+        raise ValueError('C_big / d_big do not have the shapes of util.makeCd_big (xdim*T, ydim*T) / (ydim*T,)')
+    xdim = C_big.shape[0] // T
+    C = np.ascontiguousarray(C_big[::T, ::T].T)                      # (ydim, xdim)
+    d = np.ascontiguousarray(d_big[::T])
+    # spot check of the Kronecker structure (the full comparison would cost as much as the product the device avoids)
+    rng = np.random.RandomState(0)
+    rows, cols = rng.randint(0, C_big.shape[0], 64), rng.randint(0, C_big.shape[1], 64)
+    want = np.where(rows % T == cols % T, C[cols // T, rows // T], 0.0)
+    if not np.allclose(C_big[rows, cols], want, rtol=0, atol=1e-12 * (1.0 + np.abs(C).max())) or \
+            not np.allclose(d_big.reshape(ydim, T), d[:, None], rtol=0, atol=1e-12 * (1.0 + np.abs(d).max())):
+        raise ValueError('C_big / d_big are not Kronecker expansions of (C, d) (util.makeCd_big); only that structure is evaluated')
+    return C, d, xdim, T
+
+
+def _rbf_params(Kmat, xdim, T, inverse):
+    """(tau in bins, eps) per latent from the diagonal blocks of K_big (or K_bigInv), validated entry by entry."""
+    Kmat = np.asarray(Kmat, dtype=np.float64)
+    if Kmat.shape != (xdim * T, xdim * T):
+        raise ValueError('K_big / K_bigInv must be (xdim*T, xdim*T)')
+    taus, epss = [], []
+    lag2 = (np.arange(T)[:, None] - np.arange(T)[None, :]) ** 2
+    for k in range(xdim):
+        blk = Kmat[k * T:(k + 1) * T, k * T:(k + 1) * T]
+        K = np.linalg.inv(blk) if inverse else blk
+        k1 = K[0, 1] if T > 1 else 0.999
+        k2 = K[0, 2] if T > 2 else 0.0
+        if k1 > 1e-200 and k2 > 1e-200 and k2 < k1:
+            gamma = (np.log(k1) - np.log(k2)) / 1.5
+            one_m_eps = np.exp(np.log(k1) + 0.5 * gamma)
+        else:                                          # very short timescale: the second lag underflows; reference noise level
+            one_m_eps = 0.999
+            gamma = -2.0 * np.log(max(k1, 1e-300) / one_m_eps) if k1 > 0 else 1e3
+        if abs((1.0 - one_m_eps) - 1e-3) < 1e-7:
+            one_m_eps = 0.999                          # the reference's constant (util.py:599): drop the rounding of the read-back
+        # refine gamma over all usable lags of the first row (entries read back from an inverse carry ~cond * 1e-16 of noise;
+        # lag j determines gamma with that noise divided by j^2)
+        row = K[0, 1:]
+        lags = np.arange(1, T, dtype=np.float64)
+        use = row > 1e-3
+        if np.count_nonzero(use) >= 1:
+            est = -2.0 * (np.log(row[use]) - np.log(one_m_eps)) / lags[use] ** 2
+            w = (row[use] * lags[use] ** 2) ** 2
+            gamma = float(np.sum(w * est) / np.sum(w))
+        eps = 1.0 - one_m_eps
+        model = one_m_eps * np.exp(-0.5 * gamma * lag2) + eps * np.eye(T)
+        scale = np.abs(K).max()
+        if not (gamma > 0 and 0 < eps < 1) or not np.allclose(K, model, rtol=0, atol=1e-6 * scale):
+            raise ValueError('block %d of K_big%s is not an RBF Gram matrix of util.makeK_big; only that structure is evaluated'
+                             % (k, 'Inv' if inverse else ''))
+        taus.append(1.0 / np.sqrt(gamma))
+        epss.append(eps)
+    off = Kmat.copy()
+    for k in range(xdim):
+        off[k * T:(k + 1) * T, k * T:(k + 1) * T] = 0.0
+    if np.abs(off).max() > 1e-9 * np.abs(Kmat).max():
+        raise ValueError('K_big%s is not block diagonal over latents' % ('Inv' if inverse else ''))
+    if max(epss) - min(epss) > 1e-6:
+        raise ValueError('latents with different noise levels are not supported')
+    return np.asarray(taus), float(np.mean(epss))
+
+
+def _big_context(ybar, C_big, d_big, Kmat, ydim, inverse):
+    """One-trial device context for the big-matrix callbacks, cached on the identity of the matrices."""
+    ybar = np.ndarray.flatten(np.asarray(ybar, dtype=np.float64))
+    for i, ent in enumerate(_BIG_CACHE):
+        if ent[0] is C_big and ent[1] is d_big and ent[2] is Kmat and ent[3] == inverse:
+            if ent[4] != ybar.tobytes():
+                ent[5].upload_counts(ybar.reshape(1, ent[5].q, ent[5].T))
+                ent[4] = ybar.tobytes()
+            if i:
+                _BIG_CACHE.insert(0, _BIG_CACHE.pop(i))
+            return ent[5]
+    C, d, xdim, T = _unkron(C_big, d_big, ydim)
+    tau_bins, eps = _rbf_params(Kmat, xdim, T, inverse)
+    if len(ybar) != ydim * T:
+        raise ValueError('ybar must have ydim*T entries')
+    bin_ms = 10.0
+    ctx = _hip.Context(ydim, xdim, T, 1, bin_ms)
+    ctx.set_option('eps_noise', eps)
+    ctx.upload_counts(ybar.reshape(1, ydim, T))
+    ctx.set_params(C, d, tau_bins * bin_ms / 1000.0)
+    _BIG_CACHE.insert(0, [C_big, d_big, Kmat, inverse, ybar.tobytes(), ctx])
+    while len(_BIG_CACHE) > _BIG_CACHE_MAX:
+        _BIG_CACHE.pop()[5].close()
+    return ctx
+
+
+def negLogPosteriorUnNorm(xbar, ybar, C_big, d_big, K_bigInv, xdim, ydim):
+    """reference inference.py:12-32, evaluated on the device in structured form."""
+    ctx = _big_context(ybar, C_big, d_big, K_bigInv, ydim, True)
+    f, _ = ctx.laplace_eval(np.zeros(1, np.int32), np.ndarray.flatten(np.asarray(xbar, dtype=np.float64))[None, :], want_grad=False)
+    return float(f[0])
+
+
+def negLogPosteriorUnNorm_grad(xbar, ybar, C_big, d_big, K_bigInv, xdim, ydim):
+    """reference inference.py:34-48"""
+    ctx = _big_context(ybar, C_big, d_big, K_bigInv, ydim, True)
+    _, g = ctx.laplace_eval(np.zeros(1, np.int32), np.ndarray.flatten(np.asarray(xbar, dtype=np.float64))[None, :], want_grad=True)
+    return g.reshape(-1)
+
+
+def negLogPosteriorUnNorm_hess(xbar, ybar, C_big, d_big, K_bigInv, xdim, ydim):
+    """reference inference.py:50-65: dense (xdim*T, xdim*T)"""
+    ctx = _big_context(ybar, C_big, d_big, K_bigInv, ydim, True)
+    return ctx.laplace_hessian(0, np.ndarray.flatten(np.asarray(xbar, dtype=np.float64)))
+
+
+def _infer_T(C_big):
+    """T from the Kronecker structure of C_big = kron(C, I_T).T: entry (k*T+t, n*T+t') is non-zero only for t == t', so T
+    divides column - row of every non-zero entry (the dual callbacks do not receive xdim / ydim)."""
+    C_big = np.asarray(C_big)
+    rows = np.unique(np.linspace(0, C_big.shape[0] - 1, 8).astype(int))
+    g = 0
+    for r in rows:
+        nz = np.flatnonzero(C_big[r])
+        if len(nz):
+            g = int(np.gcd.reduce(np.append(np.abs(nz - r), g)))
+    T = g if g > 0 else C_big.shape[1]
+    if C_big.shape[0] % T or C_big.shape[1] % T:
+        raise ValueError('C_big is not a Kronecker expansion of util.makeCd_big')
+    return T
+
+
+_ZERO_D = {}
+
+
+def _zero_d_big(m):
+    """stand-in d_big (same object every time, so that the context cache hits) for callbacks that do not take one"""
+    if m not in _ZERO_D:
+        _ZERO_D[m] = np.zeros(m)
+    return _ZERO_D[m]
+
+
+def _dual_ctx(ybar, C_big, K_big, d_big):
+    m = np.asarray(C_big).shape[1]
+    return _big_context(ybar, C_big, d_big, K_big, m // _infer_T(C_big), False)
+
+
+def VIPostCov(K_bigInv, C_big, lamb):
+    """reference inference.py:188-191 -> (postCovariance, postPrecision), dense; the covariance carries the reference's
+    1e-6 relative jitter on the diagonal of the precision."""
+    m = np.asarray(C_big).shape[1]
+    ctx = _big_context(np.zeros(m), C_big, _zero_d_big(m), K_bigInv, m // _infer_T(C_big), True)
+    return ctx.dual_post_cov(0, lamb, want_prec=True)
+
+
+def VIPostMean(K_big, C_big, y_bar, lamb):
+    """reference inference.py:193-194: -K_big C_big (lamb - y_bar)"""
+    m = np.asarray(C_big).shape[1]
+    ctx = _big_context(y_bar, C_big, _zero_d_big(m), K_big, m // _infer_T(C_big), False)
+    return ctx.dual_post_mean(0, lamb)
+
+
+def dualProblem(lamb, ybar, C_big, K_big, K_bigInv, d_big):
+    """reference inference.py:196-213"""
+    ctx = _dual_ctx(ybar, C_big, K_big, d_big)
+    return ctx.dual_costgrad(0, lamb, want_grad=False)[0]
+
+
+def dualProblem_grad(lamb, ybar, C_big, K_big, K_bigInv, d_big):
+    """reference inference.py:215-219"""
+    ctx = _dual_ctx(ybar, C_big, K_big, d_big)
+    return ctx.dual_costgrad(0, lamb, want_grad=True)[1]
+
+
+def dualProblemRho(rho, ybar, C_big, K_big, K_bigInv, d_big):
+    """reference inference.py:222-247"""
+    return dualProblem(np.exp(np.asarray(rho, dtype=np.float64)), ybar, C_big, K_big, K_bigInv, d_big)
+
+
+def dualProblemRho_grad(rho, ybar, C_big, K_big, K_bigInv, d_big):
+    """reference inference.py:249-256"""
+    lam = np.exp(np.asarray(rho, dtype=np.float64))
+    return dualProblem_grad(lam, ybar, C_big, K_big, K_bigInv, d_big) * lam
 
 
 # 'device': the dual optimisations of all trials run as lockstep L-BFGS on the GPU (pgpfa_dual_lbfgs); 'scipy': the
@@ -214,8 +429,7 @@ def dualVariational(experiment, params, optimizeLogLambda=False, prevOptimRes=No
         lam_all = np.exp(rho)
         optim = list(rho) if optimizeLogLambda else list(lam_all)
         nlp = ctx.dual_finalize(mine, lam_all)
-        sess.post_stamp += 1
-        sess.mode_stamp += 1
+        sess.mark_written(mine)
         tot = sess.allreduce(np.array([nlp, float(np.sum(fopt)), float(len(mine))]))
         infRes = DeviceInfRes(sess, mine, (lo, hi))
         infRes.dual_iterations = iters
@@ -263,8 +477,7 @@ def dualVariational(experiment, params, optimizeLogLambda=False, prevOptimRes=No
     lams = [np.exp(out[0]) if optimizeLogLambda else out[0] for out in outs]
     vlb = float(sum(out[1] for out in outs))
     nlp = ctx.dual_finalize(mine, np.stack(lams)) if len(mine) else 0.0
-    sess.post_stamp += 1
-    sess.mode_stamp += 1
+    sess.mark_written(mine)
     tot = sess.allreduce(np.array([nlp, vlb, float(len(mine))]))
     infRes = DeviceInfRes(sess, mine, (lo, hi))
     if returnOptimRes:

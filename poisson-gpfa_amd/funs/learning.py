@@ -32,8 +32,14 @@ def _resident_session(infRes, experiment, xdim):
     pv = np.stack([np.asarray(infRes['post_vsm'][i]) for i in range(lo, hi)])
     pg = np.stack([np.asarray(infRes['post_vsmGP'][i]) for i in range(lo, hi)])
     sess.ctx.set_posterior(trial_idx[lo:hi], pm, pv, pg)
-    sess.post_stamp += 1
+    sess.mark_written(trial_idx[lo:hi])
     return sess
+
+
+def _trial_key(infRes):
+    """Identity of the trial list an infRes covers (None for a foreign infRes: uploaded whole)."""
+    idx = getattr(infRes, 'trial_idx', None)
+    return None if idx is None else np.asarray(idx).tobytes()
 
 
 class _CostGradCache:
@@ -75,7 +81,7 @@ def MStepObservationCost_grad(vecCd, xdim, ydim, experiment, infRes):
     return sess.ctx.mstep_cd_costgrad(vecCd)[1]
 
 
-def _newton_cd(sess, x0, prior_center=None, inv_s2=0.0, max_iter=50, xtol=1e-10, verbose=False):
+def _newton_cd(sess, x0, prior_center=None, inv_s2=0.0, max_iter=50, xtol=1e-10, verbose=False, hess_key=None):
     """Exact minimiser of the (C,d) cost by q independent damped Newton iterations (the cost is separable over
     neurons and convex in each (c_n, d_n)); every iteration is one device pass that returns per-neuron cost,
     step and decrement at the current point.  Each neuron backtracks on its own cost.
@@ -85,8 +91,11 @@ def _newton_cd(sess, x0, prior_center=None, inv_s2=0.0, max_iter=50, xtol=1e-10,
     - also across EM iterations).  With rho the relative staleness of those Hessians a chord step leaves an
     error ~rho*|step|, a full step ~|step|^2; the driver picks the cheaper pass that still contracts fast and
     stops as soon as the predicted error of the next iterate is below xtol (that last step is taken without a
-    confirming pass)."""
+    confirming pass).  hess_key identifies the trial list the cost sums over: Hessians left by a pass over another
+    list (another minibatch) are not trusted as a chord, the first pass is then a full one."""
     ctx = sess.ctx
+    if getattr(sess, '_cd_hess_key', None) != hess_key:
+        sess._cd_hess_resident = False
     q, D = sess.q, sess.p + 1
     RHO_OLD = 0.1                      # Hessians of the previous EM iteration (other posterior moments)
     theta = np.array(x0, dtype=np.float64).reshape(D, q)
@@ -98,6 +107,7 @@ def _newton_cd(sess, x0, prior_center=None, inv_s2=0.0, max_iter=50, xtol=1e-10,
         if want_full or not have:
             out = ctx.mstep_cd_newton_pass(point.reshape(-1), prior_center, inv_s2)
             sess._cd_hess_resident = True
+            sess._cd_hess_key = hess_key
             state['n_full'] += 1
             state['hess_at'] = point.copy()
             return out + (0.0,)
@@ -162,7 +172,7 @@ def learnLTparams(oldParams, infRes, experiment, CdOptimMethod, CdMaxIter=None, 
     ydim, xdim = np.shape(oldParams['C'])
     sess = _resident_session(infRes, experiment, xdim)
     if CdOptimMethod == 'newton':
-        x, fun, _ = _newton_cd(sess, util.CdtoVecCd(oldParams['C'], oldParams['d']), verbose=verbose)
+        x, fun, _ = _newton_cd(sess, util.CdtoVecCd(oldParams['C'], oldParams['d']), verbose=verbose, hess_key=_trial_key(infRes))
         newC, newd = util.vecCdtoCd(x, xdim, ydim)
         return newC, newd, fun
     cache = _CostGradCache(lambda v: sess.ctx.mstep_cd_costgrad(v))
@@ -234,7 +244,7 @@ def learnLTparamsWithPrior(oldParams, infRes, experiment, CdOptimMethod, regular
     inv_s2 = 1.0 / regularizer_stepsize_Cd ** 2
     invPriorCov = -np.diag(np.ones(xdim * ydim + ydim)) / (regularizer_stepsize_Cd ** 2)       # learning.py:580-581
     if CdOptimMethod == 'newton':
-        x, fun, _ = _newton_cd(sess, old, prior_center=old, inv_s2=inv_s2, verbose=verbose)
+        x, fun, _ = _newton_cd(sess, old, prior_center=old, inv_s2=inv_s2, verbose=verbose, hess_key=_trial_key(infRes))
         newC, newd = util.vecCdtoCd(x, xdim, ydim)
         return newC, newd, fun, invPriorCov
     cache = _CostGradCache(lambda v: sess.ctx.mstep_cd_costgrad(v, old, inv_s2))

@@ -98,6 +98,11 @@ def leaveOneOutPrediction(params, experiment):
     lo, hi = (0, len(trial_idx)) if getattr(experiment, '_pgpfa_local_shard', False) else sess.local_slice(len(trial_idx))
     sess.set_params(params)
     y_loc, err_loc = sess.ctx.loo_predict(trial_idx[lo:hi])
+    unconverged = int(sess.ctx.info('last_loo_unconverged'))
+    if unconverged:
+        import warnings
+        warnings.warn('leaveOneOutPrediction: %d of %d held-out mode searches did not converge; their predictions come from '
+                      'the last iterate' % (unconverged, (hi - lo) * sess.q), RuntimeWarning, stacklevel=2)
     if sess.comm_ready and not getattr(experiment, '_pgpfa_local_shard', False):
         y_pred = np.zeros((len(trial_idx), sess.q, sess.T))
         y_pred[lo:hi] = y_loc

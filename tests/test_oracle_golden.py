@@ -176,3 +176,24 @@ def test_leave_one_out_prediction_vs_reference(c1):
     assert abs(err - 0) > 0
     pred_x, err_x = orc.leave_one_out_prediction(Ys[:1], c1['init'], c1['binSize'], mode='exact')
     assert np.max(np.abs(pred_x[0] - g['y_pred_mode'][0]) / g['y_pred_mode'][0]) <= 2e-2
+
+
+def test_oracle_at_config3_dimensions_vs_reference_spot():
+    """c3_spot.npz (tests/golden/make_golden_c3.py): one trial at 200 neurons x 10 latents x 500 bins pushed through the real
+    reference's inference.laplace (~5 min there), then polished on the reference's own callbacks.  The oracle's structured exact
+    mode must land on the polished mode (1e-9) with its covariance blocks (1e-10 rel), and within the reference's own
+    early-stopping slack of the raw answer (measured 2.7e-5 / 3.4e-7)."""
+    g = load_golden('c3_spot.npz')
+    par = {'C': g['init_C'], 'd': g['init_d'], 'tau': g['init_tau']}
+    res, nll, _ = orc.laplace([g['Y'][0].astype(float)], par, float(g['binSize']), mode='exact', return_cov=False)
+    assert float(g['polished_grad_max']) <= 1e-10
+    assert np.max(np.abs(res['post_mean'][0].reshape(-1) - g['polished'])) <= 1e-9
+    assert abs(-nll - float(g['polished_f'])) <= 1e-12 * abs(float(g['polished_f']))
+    assert rel(res['post_vsm'][0], g['polished_vsm']) <= 1e-10
+    G = res['post_vsmGP'][0]
+    assert rel(np.stack([np.diag(G[:, :, k]) for k in range(10)]), g['polished_vsmGP_diag']) <= 1e-10
+    assert rel(G[::50, :, :], g['polished_vsmGP_rows']) <= 1e-10
+    # the reference's raw output (scipy Newton-CG stopped at xtol 1e-5 on the mean |step|)
+    assert np.max(np.abs(res['post_mean'][0] - g['post_mean'])) <= 5e-3
+    assert abs(nll - float(g['nll'])) <= 1e-4
+    assert rel(res['post_vsm'][0], g['post_vsm']) <= 1e-5
