@@ -313,6 +313,7 @@ def main():
                     help='cpu_baseline times ONE whole reference-faithful trial (config 3: ~5 minutes, ~9 GB) instead of the bounded sample')
     ap.add_argument('--resident', type=int, default=8192, help="--workload online: trials resident in HBM (all ranks hold the counts)")
     ap.add_argument('--batch', type=int, default=1024, help="--workload online: minibatch size (split over the ranks)")
+    ap.add_argument('--lean', action='store_true', help='skip the extra untimed iterations (per-family event breakdown, TNC M-step, MFMA peak probe): for runs under rocprofv3')
     ap.add_argument('--dry-run', action='store_true', help='launcher self-test: every rank reports its environment and exits (no GPU work)')
     args = ap.parse_args()
 
@@ -391,20 +392,22 @@ def main():
         estep_ms.pop(); mstep_ms.pop(); nll_hist.pop(); facts.pop(); solves.pop(); pcgs.pop()
 
     # one more (untimed) EM iteration with events around every tagged launch: the per-kernel-family breakdown
-    sess.ctx.set_option('profile', 1)
-    em_step()
-    prof = {tag: sess.ctx.info('prof_%s_ms' % tag) for tag in ('gemm', 'cd', 'potrf', 'poisson', 'vsm', 'assemble', 'solve')}
-    sess.ctx.set_option('profile', 0)
-    drop_last()
+    prof = {}
+    if not args.lean:
+        sess.ctx.set_option('profile', 1)
+        em_step()
+        prof = {tag: sess.ctx.info('prof_%s_ms' % tag) for tag in ('gemm', 'cd', 'potrf', 'poisson', 'vsm', 'assemble', 'solve')}
+        sess.ctx.set_option('profile', 0)
+        drop_last()
     # one more (untimed) EM iteration with the reference engine's default (C,d) driver, for the record
     tnc_ms = None
-    if world == 1 and args.cd_method != 'TNC':
+    if world == 1 and args.cd_method != 'TNC' and not args.lean:
         cd_method[0] = 'TNC'
         em_step()
         tnc_ms = mstep_ms[-1]
         drop_last()
         cd_method[0] = args.cd_method
-    sustained = sess.ctx.bench_mfma_peak(20000) if rank == 0 else None
+    sustained = sess.ctx.bench_mfma_peak(20000) if (rank == 0 and not args.lean) else None
     times = np.zeros(world)
     times[rank] = elapsed
     times = sess.allreduce(times)
