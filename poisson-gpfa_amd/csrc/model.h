@@ -743,6 +743,7 @@ struct CdArgs {
   const int* trials; int ntr;
   double* part;          // [gridDim.y][p+2][q]
   int q, p, T;
+  int dbg;               // timing experiments only (option cd_debug): bit 0 no exp, bit 1 no second product, bit 2 no first product, bit 3 no staging
 };
 constexpr int CD_KY = 8;
 template <int PW> struct CdTile { static constexpr int TT = (PW <= 10) ? 64 : (PW <= 16) ? 32 : (PW <= 20) ? 16 : 8; };

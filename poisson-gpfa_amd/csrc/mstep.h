@@ -1,0 +1,350 @@
+// (C,d) M-step cost / gradient pass on the FP64 matrix cores (learning.MStepObservationCost(_grad), learning.py:20-91).
+//
+// With theta_n = (c_n, d_n), V_t = post_vsm[t], m_t = post_mean[:,t]:
+//   hh = c_n.m_t + d_n ; rho = c_n^T V_t c_n ; yhat = exp(hh + rho/2)
+//   cost_n = sum_t (y hh - yhat) ; dC_n = sum_t (y - yhat) m_t - yhat V_t c_n ; dd_n = sum_t (y - yhat)
+// Everything that involves the counts is LINEAR in theta and independent of it otherwise:
+//   sum_t y hh = c_n . YM_n + d_n YS_n ,  YM_n = sum_t y_nt m_t ,  YS_n = sum_t y_nt     (cd_ym_kernel, once per E-step)
+// so one evaluation only needs yhat, and both of its contractions are GEMMs over the (trial, bin) axis:
+//   E[t][n]    = sum_c Phi[t][c] Theta[c][n]      Phi[t] = [ V_t[a][b], a >= b | m_t ] , Theta[.][n] = [ (1 or 1/2) c_na c_nb | c_n ]
+//   Out[c'][n] = sum_t Phi'[c'][t] yhat[t][n]     Phi' = [ V_t pairs | m_t | 1 ]  ->  A_n = sum_t yhat V_t, sum_t yhat m_t, sum_t yhat
+//   dC_n = YM_n - sum_t yhat m_t - A_n c_n ; dd_n = YS_n - sum_t yhat ; cost_n = c_n.YM_n + d_n YS_n - sum_t yhat
+// v_mfma_f64_16x16x4_f64 tiles: 16 bins x 16 neurons.  The accumulator layout of E (register r, lane (l15, l4) = bin 4r + l4,
+// neuron l15) IS the B-fragment layout of the second product (k = bin), so yhat never leaves registers.  A workgroup covers
+// ALL neurons (one wave per 16) of a staged Phi tile, so post_vsm is read from HBM once per evaluation; Theta lives in
+// registers for the whole kernel; Phi tiles are staged in LDS (row stride = 2 mod 32 doubles: the per-bin fragment reads of
+// the first product are conflict-free) with the next tile's global loads in flight in registers while the current one is
+// multiplied.  Per (16 bins, 16 neurons): KS + 4 NT MFMAs (p = 10: 17 + 20) against ~140 FP64 FMAs per (bin, neuron) of
+// the vector form - the same flops, but operands are reused from registers instead of being broadcast from LDS per FMA.
+#pragma once
+
+namespace pgpfa {
+
+template <int PW>
+struct CdM {
+  static constexpr int NP = PW * (PW + 1) / 2;          // pairs a >= b
+  static constexpr int NC = NP + PW + 1;                // Phi row: pairs | mean | 1
+  static constexpr int KS = (NP + PW + 3) / 4;          // k steps of the first product (d enters as accumulator init)
+  static constexpr int NT = (NC + 15) / 16;             // row tiles of the second product
+  static constexpr int S = ((NC - 2 + 31) / 32) * 32 + 2;   // LDS row stride (doubles), = 2 mod 32
+  static constexpr int BT = (PW <= 10) ? 64 : (PW <= 12) ? 32 : 16;   // bins per staged tile
+  static constexpr int MAXPF = (BT * NC + 511) / 512;   // prefetch registers per thread (blocks have 512 threads)
+  static constexpr int LDS_DOUBLES = BT * S + 32;       // one stage; the kernel double-buffers
+};
+
+// YM[k][n] = sum over the listed trials and bins of y_nt m_kt (k < p), YM[p][n] = sum y_nt: partial sums per block,
+// part[blockIdx.x][(p+1)][q].  grid = (nblocks), block = 256; a block walks trials, per trial bin tiles of 64: the count tile
+// [q][64] (coalesced 64-byte rows) and the mean tile [p][64] are staged in LDS, thread = neuron (q <= 256 per pass).
+__global__ __launch_bounds__(256) void cd_ym_kernel(const uint8_t* __restrict__ Y, const double* __restrict__ mean, const int* __restrict__ trials,
+                                                    int ntr, int q, int p, int T, double* __restrict__ part) {
+  __shared__ double ms[32][64];
+  __shared__ unsigned yt[256][17];                      // 64 counts of a neuron as 16 words (+1: bank spread)
+  double* out = part + (size_t)blockIdx.x * (p + 1) * q;
+  for (int n0 = 0; n0 < q; n0 += 256) {
+    const int n = n0 + threadIdx.x;
+    const int nrow = min(256, q - n0);
+    double acc[33];
+#pragma unroll
+    for (int k = 0; k < 33; ++k) acc[k] = 0.0;
+    for (int i = blockIdx.x; i < ntr; i += gridDim.x) {
+      const size_t r = trials[i];
+      for (int t0 = 0; t0 < T; t0 += 64) {
+        const int tn = min(64, T - t0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < p * 64; e += 256) {
+          const int k = e >> 6, t = e & 63;
+          ms[k][t] = (t < tn) ? mean[(r * p + k) * T + t0 + t] : 0.0;
+        }
+        for (int e = threadIdx.x; e < nrow * 64; e += 256) {
+          const int row = e >> 6, t = e & 63;
+          const unsigned v = (t < tn) ? Y[(r * q + n0 + row) * T + t0 + t] : 0u;
+          // pack 4 counts per word: lanes t, t+1, t+2, t+3 of a quad
+          unsigned w = v << (8 * (t & 3));
+          w |= __shfl_xor(w, 1);
+          w |= __shfl_xor(w, 2);
+          if ((t & 3) == 0) yt[row][t >> 2] = w;
+        }
+        __syncthreads();
+        if (n < q) {
+#pragma unroll 4
+          for (int w4 = 0; w4 < 16; ++w4) {
+            const unsigned w = yt[threadIdx.x][w4];
+            if (w == 0u) continue;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+              const double yv = (double)((w >> (8 * b)) & 255u);
+              const int t = 4 * w4 + b;
+#pragma unroll
+              for (int k = 0; k < 32; ++k)
+                if (k < p) acc[k] += yv * ms[k][t];
+              acc[32] += yv;
+            }
+          }
+        }
+      }
+    }
+    if (n < q) {
+#pragma unroll
+      for (int k = 0; k < 32; ++k)
+        if (k < p) out[(size_t)k * q + n] = acc[k];
+      out[(size_t)p * q + n] = acc[32];
+    }
+  }
+}
+
+// sums[(p+2)][q] (rows: -(sum yhat m + A c), -sum yhat, -sum yhat as written by mstep_cd_mfma_kernel and reduced over blocks)
+// += the count terms: rows k < p: YM[k][n]; row p: YS[n]; row p+1: c_n.YM_n + d_n YS_n
+__global__ void cd_add_ym_kernel(double* __restrict__ sums, const double* __restrict__ ym, const double* __restrict__ vec, int q, int p) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= q) return;
+  double lin = vec[(size_t)p * q + n] * ym[(size_t)p * q + n];
+  for (int k = 0; k < p; ++k) {
+    const double v = ym[(size_t)k * q + n];
+    sums[(size_t)k * q + n] += v;
+    lin += vec[(size_t)k * q + n] * v;
+  }
+  sums[(size_t)p * q + n] += ym[(size_t)p * q + n];
+  sums[(size_t)(p + 1) * q + n] += lin;
+}
+
+// grid = (groups, nby), block = (64, 8): the neuron tiles (16 neurons each, one per wave) are dealt to `groups`
+// workgroups of 8 waves (waves without a tile only help staging), so a wave may use 256 registers and two waves share a
+// SIMD's matrix pipe.  Phi tiles are double-buffered in LDS: one barrier per tile.
+// The last, partly filled 4-column k step of the first product and (when at most 4) the rows left over after the full
+// 16-row tiles of the second product are done on the vector ALU instead of a mostly empty MFMA (p = 10: 16 + 16 MFMAs
+// per 16 bins instead of 17 + 20).
+template <int PW>
+struct CdK {
+  using M = CdM<PW>;
+  static constexpr int KSM = (M::NP + PW) / 4;                       // full k steps
+  static constexpr int KV = (M::NP + PW) - 4 * KSM;                   // leftover columns (vector ALU)
+  static constexpr int NV0 = M::NC - 16 * (M::NC / 16);
+  static constexpr int NTM = (NV0 <= 4) ? M::NC / 16 : M::NC / 16 + 1;   // row tiles on the matrix cores
+  static constexpr int NV = (NV0 <= 4) ? NV0 : 0;                     // leftover rows (vector ALU)
+};
+
+template <int PW>
+__global__ __launch_bounds__(512) void mstep_cd_mfma_kernel(CdArgs a, int tiles_per_group) {
+  using M = CdM<PW>;
+  using K = CdK<PW>;
+  constexpr int NP = M::NP, NC = M::NC, S = M::S, BT = M::BT, MAXPF = M::MAXPF;
+  constexpr int KSM = K::KSM, KV = K::KV, NTM = K::NTM, NV = K::NV;
+  extern __shared__ double lds[];                       // Phi tile [BT][S] (+ slack)
+  const int lane = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int nthreads = 64 * blockDim.y, tid = wave * 64 + lane;
+  const int p = a.p, q = a.q, T = a.T, pp = p * p;
+  const int n0 = (blockIdx.x * tiles_per_group + wave) * 16;
+  const bool active_wave = wave < tiles_per_group && n0 < q;      // other waves only help staging
+  const int n = n0 + l15;
+  const bool live = active_wave && n < q;
+  const int nc = (n < q) ? n : q - 1;
+
+  // Theta fragments (B operand of the first product): th[kk] = Theta[c = l4 + 4 kk][n]; thv: the leftover columns
+  double th[KSM > 0 ? KSM : 1], thv[KV > 0 ? KV : 1];
+  {
+    double c[PW];
+#pragma unroll
+    for (int l = 0; l < PW; ++l) c[l] = (l < p) ? a.vec[(size_t)l * q + nc] : 0.0;
+    auto theta = [&](int col) {
+      double v = 0.0;
+      if (col < NP) {
+        int pa = 0;
+        while ((pa + 1) * (pa + 2) / 2 <= col) ++pa;
+        const int pb = col - pa * (pa + 1) / 2;
+        double ca = 0.0, cb = 0.0;
+#pragma unroll
+        for (int l = 0; l < PW; ++l) { ca = (l == pa) ? c[l] : ca; cb = (l == pb) ? c[l] : cb; }
+        v = (pa == pb ? 0.5 : 1.0) * ca * cb;
+      } else if (col - NP < PW) {
+#pragma unroll
+        for (int l = 0; l < PW; ++l) v = (l == col - NP) ? c[l] : v;
+      }
+      return v;
+    };
+#pragma unroll
+    for (int kk = 0; kk < KSM; ++kk) th[kk] = theta(l4 + 4 * kk);
+#pragma unroll
+    for (int i = 0; i < KV; ++i) thv[i] = theta(4 * KSM + i);
+  }
+  const double dn = a.vec[(size_t)p * q + nc];
+
+  // per-thread staging plan: element e = tid + i * nthreads of the [BT][NC] tile -> source kind / offset, LDS offset
+  int soff[MAXPF], loff[MAXPF];
+#pragma unroll
+  for (int i = 0; i < MAXPF; ++i) {
+    const int e = tid + i * nthreads;
+    soff[i] = -3; loff[i] = 0;
+    if (e < BT * NC) {
+      const int t = e / NC, col = e - t * NC;
+      loff[i] = t * S + col;
+      if (col < NP) {
+        int pa = 0;
+        while ((pa + 1) * (pa + 2) / 2 <= col) ++pa;
+        const int pb = col - pa * (pa + 1) / 2;
+        soff[i] = (pa < p) ? (t * pp + pa * p + pb) : -2;                       // >= 0: post_vsm element (bin t relative to the tile)
+      } else if (col < NP + PW) {
+        const int k = col - NP;
+        soff[i] = (k < p) ? -(16 + k * 64 + t) : -2;                             // <= -16: mean[k][t0 + t]   (t < 64)
+      } else {
+        soff[i] = -1;                                                            // the column of ones
+      }
+    }
+  }
+  mdouble4 acc[NTM > 0 ? NTM : 1];
+#pragma unroll
+  for (int tl = 0; tl < NTM; ++tl) acc[tl] = mdouble4{0.0, 0.0, 0.0, 0.0};
+  double accv[NV > 0 ? NV : 1];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) accv[i] = 0.0;
+
+  const int ntt = (T + BT - 1) / BT;
+  const int nitems = a.ntr * ntt;
+  double pf[MAXPF];
+  // (every load is issued unconditionally at a clamped, always valid address and masked afterwards: conditional loads make
+  // the compiler wait for each one before issuing the next, which serialises the memory latencies of a tile)
+  auto prefetch = [&](int itrial, int itile) {
+    const size_t r = a.trials[itrial];
+    const int t0 = itile * BT;
+    const int tn = (T - t0 < BT) ? T - t0 : BT;
+    const double* vsm = a.vsm + (r * T + t0) * pp;
+    const double* mean = a.mean + r * p * T + t0;
+    double raw[MAXPF];
+    bool ok[MAXPF];
+#pragma unroll
+    for (int i = 0; i < MAXPF; ++i) {
+      const int s = soff[i];
+      const int kt = -s - 16, k = kt >> 6, t = kt & 63;
+      const bool is_v = s >= 0, is_m = s <= -16;
+      ok[i] = is_v ? (s < tn * pp) : (is_m && t < tn);
+      const double* src = is_v ? vsm : mean;
+      const long long off = is_v ? (long long)s : (long long)k * T + t;
+      raw[i] = src[ok[i] ? off : 0];
+    }
+#pragma unroll
+    for (int i = 0; i < MAXPF; ++i) pf[i] = ok[i] ? raw[i] : (soff[i] == -1 ? 1.0 : 0.0);
+  };
+  // zero both stages once: the gap columns NC..S-1 of a row and the slack behind the last row are never staged
+  for (int e = tid; e < 2 * M::LDS_DOUBLES; e += nthreads) lds[e] = 0.0;
+  // items = (trial, tile) pairs, walked with stride gridDim.y; the pair of the current and of the next item is kept in
+  // scalar counters (no integer division in the loop)
+  const int step_tr = gridDim.y / ntt, step_ti = gridDim.y % ntt;
+  int item = blockIdx.y;
+  int c_tr = item / ntt, c_ti = item % ntt;
+  if (item < nitems) prefetch(c_tr, c_ti);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < MAXPF; ++i)
+    if (soff[i] != -3) lds[loff[i]] = pf[i];
+  __syncthreads();
+  int cur = 0;
+  for (; item < nitems; item += gridDim.y) {
+    const int t0 = c_ti * BT;
+    const int tn = (T - t0 < BT) ? T - t0 : BT;
+    const bool more = item + (int)gridDim.y < nitems;
+    c_tr += step_tr; c_ti += step_ti;
+    if (c_ti >= ntt) { c_ti -= ntt; c_tr += 1; }
+    if (more && !(a.dbg & 8)) prefetch(c_tr, c_ti);     // global loads in flight while this stage is multiplied
+    const double* st = lds + cur * M::LDS_DOUBLES;
+    if (active_wave) {
+#pragma unroll
+      for (int sub = 0; sub < BT / 16; ++sub) {
+        if (sub * 16 >= tn) break;
+        const double* row = st + (sub * 16 + l15) * S + l4;
+        // two partial accumulators: consecutive MFMAs do not wait for each other's result
+        mdouble4 h = {dn, dn, dn, dn}, h2 = {0.0, 0.0, 0.0, 0.0};
+        if (!(a.dbg & 4))
+#pragma unroll
+        for (int kk = 0; kk + 1 < KSM; kk += 2) {
+          h = __builtin_amdgcn_mfma_f64_16x16x4f64(row[4 * kk], th[kk], h, 0, 0, 0);
+          h2 = __builtin_amdgcn_mfma_f64_16x16x4f64(row[4 * kk + 4], th[kk + 1], h2, 0, 0, 0);
+        }
+        if constexpr (KSM & 1) h = __builtin_amdgcn_mfma_f64_16x16x4f64(row[4 * (KSM - 1)], th[KSM - 1], h, 0, 0, 0);
+        double yh[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double* bin = st + (sub * 16 + 4 * r + l4) * S;        // this lane's bin of register r
+          double hv = h[r] + h2[r];
+#pragma unroll
+          for (int i = 0; i < KV; ++i) hv += bin[4 * KSM + i] * thv[i];
+          const double e = (live && sub * 16 + 4 * r + l4 < tn) ? ((a.dbg & 1) ? 1.0 + 1e-3 * hv : exp(hv)) : 0.0;
+          yh[r] = e;
+#pragma unroll
+          for (int i = 0; i < NV; ++i) accv[i] += bin[16 * NTM + i] * e;
+        }
+        if (!(a.dbg & 2))
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double* col = st + (sub * 16 + 4 * r + l4) * S + l15;
+#pragma unroll
+          for (int tl = 0; tl < NTM; ++tl) acc[tl] = __builtin_amdgcn_mfma_f64_16x16x4f64(col[16 * tl], yh[r], acc[tl], 0, 0, 0);
+        }
+      }
+    }
+    if (more && !(a.dbg & 8)) {
+      // the other stage was fully consumed before the barrier that ended the previous iteration
+      double* nx = lds + (cur ^ 1) * M::LDS_DOUBLES;
+#pragma unroll
+      for (int i = 0; i < MAXPF; ++i)
+        if (soff[i] != -3) nx[loff[i]] = pf[i];
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  // epilogue: Out[c'][n] sits in the accumulators of the 4 lanes (l4 = 0..3) that share a neuron: c' = 16 tl + 4 r + l4
+  // (matrix-core rows), or as per-lane partial sums over the lane's bins (vector rows).  Every lane folds its entries into
+  // u = sum_t yhat m + A_n c_n (each pair entry feeds two components) and sum_t yhat with compile-time register indices,
+  // the 4 lanes are summed by two xor-shuffles (fixed order), lane l4 = 0 stores.
+  if (active_wave) {
+    double c[PW], u[PW];
+#pragma unroll
+    for (int l = 0; l < PW; ++l) { c[l] = (l < p) ? a.vec[(size_t)l * q + nc] : 0.0; u[l] = 0.0; }
+    double sy = 0.0;
+    auto fold = [&](int cr, double v) {
+      if (cr < NP) {
+        int pa = 0;
+        while ((pa + 1) * (pa + 2) / 2 <= cr) ++pa;
+        const int pb = cr - pa * (pa + 1) / 2;
+        double ca = 0.0, cb = 0.0;
+#pragma unroll
+        for (int l = 0; l < PW; ++l) { ca = (l == pa) ? c[l] : ca; cb = (l == pb) ? c[l] : cb; }
+        const double va = v * cb, vb = (pa != pb) ? v * ca : 0.0;
+#pragma unroll
+        for (int l = 0; l < PW; ++l) u[l] += ((l == pa) ? va : 0.0) + ((l == pb) ? vb : 0.0);
+      } else if (cr < NP + PW) {
+#pragma unroll
+        for (int l = 0; l < PW; ++l) u[l] += (l == cr - NP) ? v : 0.0;
+      } else if (cr == NP + PW) {
+        sy += v;
+      }
+    };
+#pragma unroll
+    for (int tl = 0; tl < NTM; ++tl)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) fold(16 * tl + 4 * r + l4, acc[tl][r]);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) fold(16 * NTM + i, accv[i]);
+#pragma unroll
+    for (int l = 0; l < PW; ++l) {
+      double w = u[l];
+      w += __shfl_xor(w, 16);
+      w += __shfl_xor(w, 32);
+      u[l] = w;
+    }
+    sy += __shfl_xor(sy, 16);
+    sy += __shfl_xor(sy, 32);
+    if (live && l4 == 0) {
+      double* part = a.part + (size_t)blockIdx.y * (p + 2) * q;
+#pragma unroll
+      for (int l = 0; l < PW; ++l)
+        if (l < p) part[(size_t)l * q + n] = -u[l];
+      part[(size_t)p * q + n] = -sy;
+      part[(size_t)(p + 1) * q + n] = -sy;
+    }
+  }
+}
+
+template <int PW>
+constexpr size_t cd_mfma_lds_bytes() { return 2 * (size_t)CdM<PW>::LDS_DOUBLES * sizeof(double); }
+
+}  // namespace pgpfa

@@ -21,6 +21,7 @@
 #include "chol.h"
 #include "gemm.h"
 #include "model.h"
+#include "mstep.h"
 
 using namespace pgpfa;
 
@@ -100,6 +101,8 @@ struct pgpfa_ctx {
   double *CCu = nullptr, *C16 = nullptr;         // zero-padded pair-product / loading tables of the MFMA Poisson pass
   int qpad = 0, ccu_cols = 0;
   double* ppart = nullptr;                       // [p][PACC_SPLITS + 1][T x T] split-K partial products
+  double *cdym = nullptr, *cdym_part = nullptr;   // count terms of the (C,d) cost: sum_t y m_t, sum_t y per neuron (per E-step)
+  bool cdym_valid = false, cd_mfma = true; int cd_debug = 0;
   bool cd_hess_valid = false; int cd_hess_ntr = 0;   // per-neuron Hessian sums of the last Newton pass are resident
   std::vector<double> logdetK;                  // log det of the p Gram matrices (from the factor in build_kinv)
   bool dual_lowrank = false;                    // dual-variational entry points may use the low-rank engine (no diagonal jitter)
@@ -872,6 +875,8 @@ int pgpfa_create(pgpfa_ctx** out, int device, int q, int p, int T, int R, double
   rc |= dmalloc(c, &c->vec, (size_t)q * (p + 1));
   rc |= dmalloc(c, &c->cdpart, (size_t)1024 * (p + 2) * q);
   rc |= dmalloc(c, &c->cdout, (size_t)(p + 2) * q + 8);
+  rc |= dmalloc(c, &c->cdym, (size_t)(p + 1) * q + 8);
+  rc |= dmalloc(c, &c->cdym_part, (size_t)128 * (p + 1) * q);
   rc |= dmalloc(c, &c->last_trials, R);
   {
     const size_t NH = 1 + (size_t)(p + 1) + (size_t)(p + 1) * (p + 2) / 2;
@@ -919,6 +924,8 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
   if (k == "newton_xtol") c->xtol = v;
   else if (k == "newton_max_iter") c->max_iter = (int)v;
   else if (k == "use_mfma") c->mfma = (v != 0.0);
+  else if (k == "cd_mfma") c->cd_mfma = (v != 0.0);
+  else if (k == "cd_debug") c->cd_debug = (int)v;
   else if (k == "chord") c->chord = (v != 0.0);
   else if (k == "shared_pcg") c->shared_pcg = (v != 0.0);
   else if (k == "cov_mode") c->cov_mode = (int)v;
@@ -1153,6 +1160,7 @@ static int remember_trials(pgpfa_ctx* c, const std::vector<int>& v) {
   c->have_post = true;
   c->have_precomp = false;
   c->pacc_valid = false;
+  c->cdym_valid = false;
   return 0;
 }
 
@@ -2077,6 +2085,56 @@ int pgpfa_set_posterior(pgpfa_ctx* c, int n, const int32_t* idx, const double* p
 }
 
 // ---- M-step ------------------------------------------------------------------------------------------
+// One (C,d) cost / gradient sweep over the trials of the last E-step at the parameters in c->vec: c->cdout <- per-neuron sums
+// [(p+2)][q] (rows 0..p-1: sum (y - yhat) m - yhat V c, row p: sum (y - yhat), row p+1: sum (y hh - yhat)).  Matrix-core kernel
+// up to 20 latents (mstep.h), the vector kernel beyond that or with option cd_mfma = 0.
+static int cd_sweep(pgpfa_ctx* c) {
+  const int q = c->q, p = c->p, T = c->T;
+  const int len = (p + 2) * q;
+  CdArgs a{};
+  a.Y = c->Y; a.mean = c->Xmode; a.vsm = c->vsm; a.vec = c->vec;
+  a.trials = c->last_trials; a.ntr = (int)c->last_trials_h.size();
+  a.part = c->cdpart; a.q = q; a.p = p; a.T = T; a.dbg = c->cd_debug;
+  const double flops = (double)a.ntr * q * T * (2.0 * p * p + 8.0 * p);
+  if (c->mfma && c->cd_mfma && p <= 10) {
+    if (!c->cdym_valid) {
+      const int nbk = std::max(1, std::min(128, a.ntr));
+      hipLaunchKernelGGL(cd_ym_kernel, dim3(nbk), dim3(256), 0, c->st, c->Y, c->Xmode, c->last_trials, a.ntr, q, p, T,
+                         c->cdym_part);
+      hipLaunchKernelGGL(reduce_parts_kernel, dim3(((p + 1) * q + 31) / 32), dim3(256), 0, c->st, c->cdym_part, nbk, (p + 1) * q, c->cdym);
+      HIPC(hipGetLastError());
+      c->cdym_valid = true;
+    }
+    int nby = 1;
+    prof_begin(c, TAG_CD, flops);
+    dispatch_pw(p, [&](auto pw) {
+      constexpr int PW = decltype(pw)::value;
+      if constexpr (PW <= 10) {
+        const int ntt = (T + CdM<PW>::BT - 1) / CdM<PW>::BT;
+        const int tiles = (q + 15) / 16, groups = (tiles + 7) / 8, tpg = (tiles + groups - 1) / groups;
+        nby = std::max(1, std::min(a.ntr * ntt, std::max(64, 512 / groups)));      // one resident workgroup per CU: about one round of blocks
+        const int waves = 8;
+        hipLaunchKernelGGL(mstep_cd_mfma_kernel<PW>, dim3(groups, nby), dim3(64, waves), cd_mfma_lds_bytes<PW>(), c->st, a, tpg);
+      }
+    });
+    prof_end(c);
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3((len + 31) / 32), dim3(256), 0, c->st, c->cdpart, nby, len, c->cdout);
+    hipLaunchKernelGGL(cd_add_ym_kernel, dim3((q + 127) / 128), dim3(128), 0, c->st, c->cdout, c->cdym, c->vec, q, p);
+    HIPC(hipGetLastError());
+    return 0;
+  }
+  const int nchunk = (q + 63) / 64;
+  const int nby = std::max(1, std::min(a.ntr * 4, std::max(64, 1024 / nchunk)));
+  prof_begin(c, TAG_CD, flops);
+  dispatch_pw(p, [&](auto pw) {
+    hipLaunchKernelGGL(mstep_cd_kernel<decltype(pw)::value>, dim3((q + 63) / 64, nby), dim3(64, CD_KY), 0, c->st, a);
+  });
+  prof_end(c);
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3((len + 31) / 32), dim3(256), 0, c->st, c->cdpart, nby, len, c->cdout);
+  HIPC(hipGetLastError());
+  return 0;
+}
+
 int pgpfa_mstep_cd_costgrad(pgpfa_ctx* c, const double* vecCd, const double* prior_center, double inv_s2, double* cost, double* grad) {
   if (!c || !vecCd || !cost || !grad) return fail("null argument");
   if (!c->have_counts) return fail("spike counts have not been uploaded");
@@ -2085,21 +2143,10 @@ int pgpfa_mstep_cd_costgrad(pgpfa_ctx* c, const double* vecCd, const double* pri
   const int q = c->q, p = c->p, T = c->T;
   const int len = (p + 2) * q;
   CHK(upload(c, c->vec, vecCd, (size_t)q * (p + 1)));
-  CdArgs a{};
-  a.Y = c->Y; a.mean = c->Xmode; a.vsm = c->vsm; a.vec = c->vec;
-  a.trials = c->last_trials; a.ntr = (int)c->last_trials_h.size();
-  a.part = c->cdpart; a.q = q; a.p = p; a.T = T;
-  const int nchunk = (q + 63) / 64;
-  const int nby = std::max(1, std::min(a.ntr * 4, std::max(64, 1024 / nchunk)));
-  prof_begin(c, TAG_CD, (double)a.ntr * q * T * (2.0 * p * p + 8.0 * p));
-  dispatch_pw(p, [&](auto pw) {
-    hipLaunchKernelGGL(mstep_cd_kernel<decltype(pw)::value>, dim3((q + 63) / 64, nby), dim3(64, CD_KY), 0, c->st, a);
-  });
-  prof_end(c);
-  hipLaunchKernelGGL(reduce_parts_kernel, dim3((len + 31) / 32), dim3(256), 0, c->st, c->cdpart, nby, len, c->cdout);
-  HIPC(hipGetLastError());
+  CHK(cd_sweep(c));
+  const int ntr_local = (int)c->last_trials_h.size();
   // append the local trial count, all-reduce [sums | count] over ranks
-  const double cnt = (double)a.ntr;
+  const double cnt = (double)ntr_local;
   HIPC(hipMemcpyAsync(c->cdout + len, &cnt, sizeof(double), hipMemcpyHostToDevice, c->st));
   CHK(allreduce_dev(c, c->cdout, (size_t)len + 1));
   CHK(ensure_hbuf(c, (size_t)len + 1));
@@ -2197,19 +2244,8 @@ int pgpfa_mstep_cd_chord_pass(pgpfa_ctx* c, const double* vecCd, const double* p
   const int len = (p + 2) * q;
   CHK(upload(c, c->vec, vecCd, (size_t)q * D));
   if (prior_center) CHK(upload(c, c->cdcenter, prior_center, (size_t)q * D));
-  CdArgs a{};
-  a.Y = c->Y; a.mean = c->Xmode; a.vsm = c->vsm; a.vec = c->vec;
-  a.trials = c->last_trials; a.ntr = (int)c->last_trials_h.size();
-  a.part = c->cdpart; a.q = q; a.p = p; a.T = T;
-  const int nchunk = (q + 63) / 64;
-  const int nby = std::max(1, std::min(a.ntr * 4, std::max(64, 1024 / nchunk)));
-  prof_begin(c, TAG_CD, (double)a.ntr * q * T * (2.0 * p * p + 8.0 * p));
-  dispatch_pw(p, [&](auto pw) {
-    hipLaunchKernelGGL(mstep_cd_kernel<decltype(pw)::value>, dim3((q + 63) / 64, nby), dim3(64, CD_KY), 0, c->st, a);
-  });
-  prof_end(c);
-  hipLaunchKernelGGL(reduce_parts_kernel, dim3((len + 31) / 32), dim3(256), 0, c->st, c->cdpart, nby, len, c->cdout);
-  const double cnt = (double)a.ntr;
+  CHK(cd_sweep(c));
+  const double cnt = (double)c->last_trials_h.size();
   HIPC(hipMemcpyAsync(c->cdout + len, &cnt, sizeof(double), hipMemcpyHostToDevice, c->st));
   CHK(allreduce_dev(c, c->cdout, (size_t)len + 1));
   double Rtot = 0.0;
