@@ -136,6 +136,12 @@ int pgpfa_mstep_tau_costgrad_multi(pgpfa_ctx* ctx, int m, const double* logp, do
 int pgpfa_count_moments(pgpfa_ctx* ctx, int n, const int32_t* idx, int64_t* sum /* [q] */, int64_t* cross /* [q][q] */,
                         int64_t* n_samples);
 
+/* ---- synthetic population (util.dataset, util.py:705-750) ------------------------------------------ */
+/* Draws x_k ~ N(0, K(tau_k)) and y_nt ~ Poisson(exp(c_n . x_t + d_n)) for the listed trials (NULL: all) under the parameters of
+ * pgpfa_set_params, from a counter-based generator keyed by `seed` (NOT NumPy's stream).  The counts replace those trials in
+ * the resident tensor; X_out[n][p][T] / Y_out[n][q][T] (either may be NULL) receive copies. */
+int pgpfa_generate(pgpfa_ctx* ctx, unsigned long long seed, int n, const int32_t* idx, double* X_out, uint8_t* Y_out);
+
 /* ---- leave-one-neuron-out prediction (util.py:289-334, engine.py:599-644) ----------- */
 /* For each listed trial (idx NULL: all R) and each neuron nn: the Laplace mode of the latents given the other
  * q-1 neurons (cold start), then y_pred[(trial, nn)][t] = exp(C[nn] . x_t + d[nn]); err_sum = sum of squared

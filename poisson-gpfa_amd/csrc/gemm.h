@@ -57,6 +57,7 @@ struct GemmP {
   // range instead of moving A/B (sA_hi = sB_hi = 0); C then addresses partial products (gemm_splitk_reduce_kernel)
   int ksplit;
   int c_by_pos;         // C is indexed by batch position instead of slot (compact partial-product buffers)
+  const int* skip;      // optional device flag: the launch is a no-op when *skip != 0 (device-side loop control, pcg.h)
 };
 
 __device__ __forceinline__ size_t gemm_koff(int kseg, long long sseg, int ld, int k) {
@@ -125,6 +126,7 @@ template <int TRANSB>
 __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP g) {
   __shared__ __attribute__((aligned(16))) double As[2][GBK][GLS];
   __shared__ __attribute__((aligned(16))) double Bs[2][GBK][GLS];
+  if (g.skip && *g.skip) return;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -275,6 +277,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP g) {
 // validate the MFMA path (option use_mfma = 0); never the default.
 template <int TRANSB>
 __global__ void gemm_check_kernel(GemmP g) {
+  if (g.skip && *g.skip) return;
   int b, tile;
   gemm_decode_block(g, blockIdx.x, b, tile);
   int ti, tj;
@@ -323,7 +326,8 @@ __global__ void gemm_check_kernel(GemmP g) {
 
 // C[b] = beta*C[b] + sum_s part[s][b]  (part: [ksplit][nbatch][N][M] compact); grid = (ceil(M*N/256), nbatch)
 __global__ void gemm_splitk_reduce_kernel(const double* __restrict__ part, int ksplit, int M, int N, int nbatch, double* __restrict__ C,
-                                          long long sC, int ldc, const int* __restrict__ slots, double beta) {
+                                          long long sC, int ldc, const int* __restrict__ slots, double beta, const int* __restrict__ skip) {
+  if (skip && *skip) return;
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (size_t)M * N) return;
   const int b = blockIdx.y;

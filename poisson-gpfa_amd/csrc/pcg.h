@@ -1,0 +1,259 @@
+// Inner PCG iteration of the shared-preconditioner Newton phase without host round trips.
+//
+// The stopping test of the inner solve (worst relative residual over the active slots <= eta) runs on the device:
+// pcg_update_p2_kernel folds every slot's ratio into one word with atomicMax, pcg_check_kernel turns it into a stop flag that
+// every kernel of the following iterations (the GEMMs included: GemmP::skip) reads first and returns on.  The host enqueues
+// iterations ahead without synchronising and only peeks at a copy of the flag in host-mapped memory to stop enqueuing.
+// Fused passes (low-rank preconditioner, p <= 16):
+//   pcg_xr_apply_kernel    x += alpha p, r -= alpha q, and the first half of the preconditioner, xt = Gb r, in one pass
+//   pcg_apply2_dots_kernel z = Gb (eps r + F Sb F^T Gb r) with the partial sums of r.z and r.r of the tile
+//   pcg_update_p2_kernel   beta from the partial sums, p = z + beta p (one pass over z and p), residual ratio
+// and the curvature blocks of the slots are read as packed single-precision lower triangles in the Hessian-vector product
+// (pack_w32_kernel / pcg_hessvec32_dot_kernel): the inner solves then use H~ = K^-1 + fl32(W), an inexact Newton matrix whose
+// relative error (6e-8) is far below the forcing terms; gradients, objective and the covariance phase keep the FP64 blocks.
+#pragma once
+
+namespace pgpfa {
+
+struct PcgCtl { int stop; int iters; unsigned worst_bits; int pad; };
+
+// one thread: close an iteration.  ctl->iters counts executed iterations; stop is raised once iters >= inner_min and the
+// worst residual ratio of the iteration is <= eta.  host (mapped, may be null) receives {stop, iters}.
+__global__ void pcg_check_kernel(PcgCtl* __restrict__ ctl, volatile int* __restrict__ host, float eta, int inner_min) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (!ctl->stop) {
+    const int it = ctl->iters + 1;
+    ctl->iters = it;
+    const float w = __uint_as_float(ctl->worst_bits);
+    if (it >= inner_min && w <= eta) ctl->stop = 1;
+  }
+  ctl->worst_bits = 0u;
+  if (host) {
+    host[1] = ctl->iters;
+    __threadfence_system();
+    host[0] = ctl->stop;
+    __threadfence_system();
+  }
+}
+
+// W[slot][t][p][p] (double) -> Wp[slot][t][NP] (float, lower triangle a >= b at a(a+1)/2 + b) for the listed slots.
+// grid = (ceil(T*NP/256), nslots)
+__global__ void pack_w32_kernel(const double* __restrict__ W, long long sW, float* __restrict__ Wp, long long sWp, int T, int p,
+                                const int* __restrict__ slots) {
+  const size_t slot = slots[blockIdx.y];
+  const int np = p * (p + 1) / 2;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= T * np) return;
+  const int t = e / np, c = e - t * np;
+  int a = 0;
+  while ((a + 1) * (a + 2) / 2 <= c) ++a;
+  const int b = c - a * (a + 1) / 2;
+  Wp[slot * sWp + e] = (float)W[slot * sW + (size_t)t * p * p + a * p + b];
+}
+
+// q += W p (W from the packed single-precision triangles), partial p.q per 64-bin tile; same launch shape and outputs as
+// pcg_hessvec_dot_kernel.  grid = (ceil(T/64), nslots), block = 256.
+template <int PW>
+__global__ __launch_bounds__(256) void pcg_hessvec32_dot_kernel(const float* __restrict__ Wp, long long sWp, const double* __restrict__ P,
+                                                                double* __restrict__ Q, long long sV, int T, int p,
+                                                                const int* __restrict__ slots, double* __restrict__ pqpart,
+                                                                const int* __restrict__ skip) {
+  if (skip && *skip) return;
+  constexpr int NPW = PW * (PW + 1) / 2, LD = NPW | 1;          // odd row stride: lanes (bins) hit distinct banks
+  __shared__ float Ws[64 * LD];
+  __shared__ double red[4];
+  const int np = p * (p + 1) / 2;
+  const size_t slot = slots[blockIdx.y];
+  const int t0 = blockIdx.x * 64;
+  const int nt = min(64, T - t0);
+  const float* wbase = Wp + slot * sWp + (size_t)t0 * np;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int NK = (PW + 3) / 4;
+  const bool live = lane < nt;
+  const double* pv = P + slot * sV + t0 + lane;
+  double* q = Q + slot * sV + t0 + lane;
+  double v[PW], qk[NK];
+#pragma unroll
+  for (int l = 0; l < PW; ++l) v[l] = (live && l < p) ? pv[(size_t)l * T] : 0.0;
+#pragma unroll
+  for (int i = 0; i < NK; ++i) {
+    const int k = wave + 4 * i;
+    qk[i] = (live && k < p) ? q[(size_t)k * T] : 0.0;
+  }
+  for (int e = threadIdx.x; e < nt * np; e += 256) {
+    const int t = e / np, idx = e - t * np;
+    Ws[t * LD + idx] = wbase[e];
+  }
+  __syncthreads();
+  double acc = 0.0;
+  if (live) {
+    const float* wt = Ws + lane * LD;
+#pragma unroll
+    for (int i = 0; i < NK; ++i) {
+      const int k = wave + 4 * i;
+      if (k < p) {
+        double s2 = qk[i];
+        double vk = 0.0;
+#pragma unroll
+        for (int l = 0; l < PW; ++l) {
+          if (l < p) {
+            const int hi = k > l ? k : l, lo = k > l ? l : k;
+            s2 += (double)wt[hi * (hi + 1) / 2 + lo] * v[l];
+          }
+          vk = (l == k) ? v[l] : vk;
+        }
+        q[(size_t)k * T] = s2;
+        acc += s2 * vk;
+      }
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+  if (lane == 0) red[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) pqpart[slot * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+constexpr int PCG_SLOTS = 16;       // slots of the active list walked by one block of the per-bin kernels
+
+// alpha = rz / sum(pqpart) ; x += alpha p ; r -= alpha q ; xt = Gb r   for the active slots list[0..na).
+// grid = (ceil(T/64), ceil(na / PCG_SLOTS)), block = 256 (lanes = bins, waves = slots), p <= PW.
+template <int PW>
+__global__ __launch_bounds__(256) void pcg_xr_apply_kernel(const double* __restrict__ Gb, double* __restrict__ X, double* __restrict__ R,
+                                                           const double* __restrict__ P, const double* __restrict__ Q,
+                                                           double* __restrict__ Xt, long long sV, int T, int p, const int* __restrict__ list,
+                                                           int na, const double* __restrict__ rz, const double* __restrict__ pqpart,
+                                                           int ntile, const int* __restrict__ skip) {
+  if (skip && *skip) return;
+  constexpr int PP = PW * PW, LD = PP + 1;
+  __shared__ double Gs[64 * LD];
+  const int pp = p * p;
+  const int t0 = blockIdx.x * 64;
+  const int nt = min(64, T - t0);
+  if (p < PW)
+    for (int e = threadIdx.x; e < 64 * LD; e += 256) Gs[e] = 0.0;
+  __syncthreads();
+  for (int e = threadIdx.x; e < nt * pp; e += 256) {
+    const int t = e / pp, idx = e - t * pp, i = idx / p, j = idx - i * p;
+    Gs[t * LD + i * PW + j] = Gb[(size_t)t0 * pp + e];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane >= nt) return;
+  const int t = t0 + lane;
+  const double* g = Gs + lane * LD;
+  const int s_end = min(na, (int)(blockIdx.y + 1) * PCG_SLOTS);
+  for (int si = blockIdx.y * PCG_SLOTS + wave; si < s_end; si += 4) {
+    const size_t sl = list[si];
+    double d = 0.0;
+    for (int i = 0; i < ntile; ++i) d += pqpart[sl * ntile + i];
+    const double alpha = (d > 0.0) ? rz[sl] / d : 0.0;
+    const size_t base = sl * sV + t;
+    double v[PW];
+#pragma unroll
+    for (int k = 0; k < PW; ++k) {
+      v[k] = 0.0;
+      if (k < p) {
+        const size_t o = base + (size_t)k * T;
+        X[o] += alpha * P[o];
+        const double rn = R[o] - alpha * Q[o];
+        R[o] = rn;
+        v[k] = rn;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < PW; ++k) {
+      double acc = 0.0;
+#pragma unroll
+      for (int kk = 0; kk < PW; ++kk) acc += g[k * PW + kk] * v[kk];
+      if (k < p) Xt[base + (size_t)k * T] = acc;
+    }
+  }
+}
+
+// z = Gb (eps r + y) with y = F Sb F^T Gb r already in Y2 ; partial sums of r.z and r.r per (slot, tile):
+// part[(slot * ntile + tile) * 2 + {0, 1}].  Same launch shape as pcg_xr_apply_kernel.
+template <int PW>
+__global__ __launch_bounds__(256) void pcg_apply2_dots_kernel(const double* __restrict__ Gb, const double* __restrict__ R,
+                                                              const double* __restrict__ Y2, double eps, double* __restrict__ Z,
+                                                              long long sV, int T, int p, const int* __restrict__ list, int na,
+                                                              double* __restrict__ part, const int* __restrict__ skip) {
+  if (skip && *skip) return;
+  constexpr int PP = PW * PW, LD = PP + 1;
+  __shared__ double Gs[64 * LD];
+  const int pp = p * p;
+  const int t0 = blockIdx.x * 64;
+  const int nt = min(64, T - t0);
+  if (p < PW)
+    for (int e = threadIdx.x; e < 64 * LD; e += 256) Gs[e] = 0.0;
+  __syncthreads();
+  for (int e = threadIdx.x; e < nt * pp; e += 256) {
+    const int t = e / pp, idx = e - t * pp, i = idx / p, j = idx - i * p;
+    Gs[t * LD + i * PW + j] = Gb[(size_t)t0 * pp + e];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool live = lane < nt;
+  const int t = t0 + (live ? lane : 0);
+  const double* g = Gs + (live ? lane : 0) * LD;
+  const int s_end = min(na, (int)(blockIdx.y + 1) * PCG_SLOTS);
+  for (int si = blockIdx.y * PCG_SLOTS + wave; si < s_end; si += 4) {
+    const size_t sl = list[si];
+    const size_t base = sl * sV + t;
+    double v[PW], rv[PW];
+#pragma unroll
+    for (int k = 0; k < PW; ++k) {
+      v[k] = 0.0; rv[k] = 0.0;
+      if (k < p && live) {
+        rv[k] = R[base + (size_t)k * T];
+        v[k] = eps * rv[k] + Y2[base + (size_t)k * T];
+      }
+    }
+    double a = 0.0, b = 0.0;
+#pragma unroll
+    for (int k = 0; k < PW; ++k) {
+      double acc = 0.0;
+#pragma unroll
+      for (int kk = 0; kk < PW; ++kk) acc += g[k * PW + kk] * v[kk];
+      if (k < p && live) Z[base + (size_t)k * T] = acc;
+      a += rv[k] * acc;
+      b += rv[k] * rv[k];
+    }
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
+    if (lane == 0) {
+      part[(sl * gridDim.x + blockIdx.x) * 2] = a;
+      part[(sl * gridDim.x + blockIdx.x) * 2 + 1] = b;
+    }
+  }
+}
+
+// rz_new, rr from the tile partial sums (tile order: deterministic) ; beta = rz_new / rz ; p = z + beta p ; rz = rz_new ;
+// rr0 on the first call of a solve ; the slot's residual ratio sqrt(rr / rr0) is folded into ctl->worst_bits.
+// grid = (na), block = 256.
+__global__ __launch_bounds__(256) void pcg_update_p2_kernel(const double* __restrict__ Z, double* __restrict__ P, long long sV, int n,
+                                                            const int* __restrict__ list, const double* __restrict__ part, int ntile,
+                                                            double* __restrict__ rz, double* __restrict__ rr, double* __restrict__ rr0,
+                                                            int first, PcgCtl* __restrict__ ctl) {
+  if (ctl && ctl->stop) return;
+  __shared__ double beta_s;
+  const size_t slot = list[blockIdx.x];
+  if (threadIdx.x == 0) {
+    double a = 0.0, b = 0.0;
+    for (int i = 0; i < ntile; ++i) { a += part[(slot * ntile + i) * 2]; b += part[(slot * ntile + i) * 2 + 1]; }
+    const double old = rz[slot];
+    beta_s = (first || !(old > 0.0)) ? 0.0 : a / old;
+    rz[slot] = a;
+    rr[slot] = b;
+    double b0 = rr0[slot];
+    if (first) { rr0[slot] = b; b0 = b; }
+    if (ctl) {
+      const float ratio = (b0 > 0.0) ? (float)sqrt(b / b0) : 0.0f;
+      // (finite non-negative floats order like their bit patterns; a NaN maps above every finite value and keeps iterating)
+      atomicMax(&ctl->worst_bits, __float_as_uint(ratio));
+    }
+  }
+  __syncthreads();
+  const double beta = beta_s;
+  for (int i = threadIdx.x; i < n; i += 256) P[slot * sV + i] = Z[slot * sV + i] + beta * P[slot * sV + i];
+}
+
+}  // namespace pgpfa

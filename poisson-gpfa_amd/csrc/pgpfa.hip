@@ -22,6 +22,8 @@
 #include "gemm.h"
 #include "model.h"
 #include "mstep.h"
+#include "pcg.h"
+#include "sample.h"
 
 using namespace pgpfa;
 
@@ -129,6 +131,11 @@ struct pgpfa_ctx {
   CholWS sws{};
   double *sU = nullptr, *sDinvT = nullptr, *Wbar = nullptr;
   double *Rv = nullptr, *Zv = nullptr, *Pv = nullptr, *Qv = nullptr;
+  PcgCtl* pcgctl = nullptr;                      // device-side control block of the inner PCG loop (pcg.h)
+  int* h_pcg = nullptr; int* d_hpcg = nullptr;   // host-mapped copy {stop, iterations}: the host peeks, never waits
+  float* W32 = nullptr;                          // packed single-precision curvature triangles of the chunk's slots (PCG matvec)
+  double* sc_part2 = nullptr;                    // per (slot, tile) partial sums r.z, r.r
+  bool pcg_fused = true, pcg_w32 = true;
   double *sc_rz = nullptr, *sc_pq = nullptr, *sc_rr = nullptr, *sc_rr0 = nullptr, *sc_pack = nullptr;
   // low-rank covariance engine
   double* Flr = nullptr;                          // [p][Tp x Tp] pivoted-Cholesky factors of the RBF part
@@ -321,7 +328,7 @@ int gemm(pgpfa_ctx* c, bool transb, GemmP g) {
     e = gemm_launch(c->st, c->mfma, transb, s);
     if (e == hipSuccess) {
       hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)(((size_t)g.M * g.N + 255) / 256), g.nbatch), dim3(256), 0, c->st, c->gemm_part,
-                         ksplit, g.M, g.N, g.nbatch, g.C, g.sC, g.ldc, g.slots, g.beta);
+                         ksplit, g.M, g.N, g.nbatch, g.C, g.sC, g.ldc, g.slots, g.beta, g.skip);
       e = hipGetLastError();
     }
   } else {
@@ -437,7 +444,7 @@ size_t ld_bytes(const pgpfa_ctx* c) { return (size_t)c->ld * c->ld * sizeof(doub
 
 size_t per_slot_bytes(const pgpfa_ctx* c, size_t slab_elems) {
   const size_t ld = c->ld;
-  size_t dbl = 2 * slab_elems + 2 * ld * NB + 12 * ld + 3 * (size_t)c->T * c->p * c->p + ((c->T + 63) / 64) + 32;
+  size_t dbl = 2 * slab_elems + 2 * ld * NB + 12 * ld + 3 * (size_t)c->T * c->p * c->p + (size_t)c->T * (c->p * (c->p + 1) / 2) / 2 + 3 * ((c->T + 63) / 64) + 32;
   return dbl * sizeof(double);
 }
 
@@ -526,6 +533,9 @@ int ensure_workspace(pgpfa_ctx* c, bool plan_lr) {
   const size_t wlen = (size_t)c->T * c->p * c->p;
   CHK(dmalloc(c, &c->W, wlen * nB)); CHK(dmalloc(c, &c->Wt, wlen * nB));
   CHK(dmalloc(c, &c->fpart, (size_t)((c->T + 63) / 64) * nB));
+  CHK(dmalloc(c, &c->sc_part2, 2 * (size_t)((c->T + 63) / 64) * nB));
+  CHK(dmalloc(c, &c->W32, (size_t)c->T * (c->p * (c->p + 1) / 2) * nB + 64));
+  CHK(dmalloc(c, &c->pcgctl, 1, true));
   CHK(dmalloc(c, &c->sc_f, nB));
   CHK(dmalloc(c, &c->sc_alpha, nB));
   CHK(dmalloc(c, &c->trial_of_slot, nB)); CHK(dmalloc(c, &c->list_a, nB)); CHK(dmalloc(c, &c->list_b, nB));
@@ -652,8 +662,9 @@ int prior_mv(pgpfa_ctx* c, const int* d_list, int nl, const double* in, double* 
 }
 
 // out[slot][k] = mat_k * in[slot][k] for ALL slots [0,nb) as one batched MFMA GEMM (batch = latents, N = slots)
-int prior_mv_all(pgpfa_ctx* c, int nb, const double* in, double* out, const double* mat = nullptr) {
+int prior_mv_all(pgpfa_ctx* c, int nb, const double* in, double* out, const double* mat = nullptr, const int* skip = nullptr) {
   GemmP g{};
+  g.skip = skip;
   g.A = mat ? mat : c->Kinv; g.sA = (long long)c->Tp * c->Tp; g.lda = c->Tp;
   g.B = in; g.sB = c->T; g.ldb = c->ld;                 // latent k: rows k*T.. of every slot vector (K x N column-major)
   g.C = out; g.sC = c->T; g.ldc = c->ld;
@@ -876,7 +887,7 @@ int pgpfa_create(pgpfa_ctx** out, int device, int q, int p, int T, int R, double
   rc |= dmalloc(c, &c->cdpart, (size_t)1024 * (p + 2) * q);
   rc |= dmalloc(c, &c->cdout, (size_t)(p + 2) * q + 8);
   rc |= dmalloc(c, &c->cdym, (size_t)(p + 1) * q + 8);
-  rc |= dmalloc(c, &c->cdym_part, (size_t)128 * (p + 1) * q);
+  rc |= dmalloc(c, &c->cdym_part, (size_t)1024 * (p + 1) * q);
   rc |= dmalloc(c, &c->last_trials, R);
   {
     const size_t NH = 1 + (size_t)(p + 1) + (size_t)(p + 1) * (p + 2) / 2;
@@ -886,6 +897,8 @@ int pgpfa_create(pgpfa_ctx** out, int device, int q, int p, int T, int R, double
     rc |= dmalloc(c, &c->cddelta, (size_t)q * (p + 1));
     rc |= dmalloc(c, &c->cddec, q);
   }
+  if (hipHostMalloc((void**)&c->h_pcg, 4 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
+      hipHostGetDevicePointer((void**)&c->d_hpcg, c->h_pcg, 0) != hipSuccess) { (void)hipGetLastError(); c->h_pcg = nullptr; c->d_hpcg = nullptr; }
   rc |= alloc_cholws(c, &c->kws, p * TAU_MULTI_MAX, c->Tp, true);
   c->kws.nact = round_up(T, 64);
   {
@@ -912,6 +925,7 @@ int pgpfa_destroy(pgpfa_ctx* c) {
   if (c->arena) hipFree(c->arena);
   if (c->hbuf) hipHostFree(c->hbuf);
   if (c->hibuf) hipHostFree(c->hibuf);
+  if (c->h_pcg) hipHostFree(c->h_pcg);
   for (auto e : c->prof.pool) hipEventDestroy(e);
   if (c->st) hipStreamDestroy(c->st);
   delete c;
@@ -926,6 +940,8 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
   else if (k == "use_mfma") c->mfma = (v != 0.0);
   else if (k == "cd_mfma") c->cd_mfma = (v != 0.0);
   else if (k == "cd_debug") c->cd_debug = (int)v;
+  else if (k == "pcg_fused") c->pcg_fused = (v != 0.0);
+  else if (k == "pcg_w32") c->pcg_w32 = (v != 0.0);
   else if (k == "chord") c->chord = (v != 0.0);
   else if (k == "shared_pcg") c->shared_pcg = (v != 0.0);
   else if (k == "cov_mode") c->cov_mode = (int)v;
@@ -1169,7 +1185,10 @@ static int remember_trials(pgpfa_ctx* c, const std::vector<int>& v) {
 // inverse is formed once per chunk and applied with a single multi-RHS GEMM.  Low-rank plan: the same matrix in
 // Woodbury form, P^-1 v = Gb (eps v + F Sb F^T Gb v), with Gb the per-bin blocks of the mean curvature and Sb the
 // inverse of the r x r system: two per-bin kernels and three thin GEMMs, no n x n matrix anywhere.
-static int shared_solve(pgpfa_ctx* c, int nb, const double* R, double* Z) {
+// (skip: device stop flag of the inner PCG loop; final_apply = false leaves the last per-bin application to the caller, with
+// y = F Sb F^T Gb R in c->Xt; first_apply = false: the caller has already put Gb R into c->Xt)
+static int shared_solve(pgpfa_ctx* c, int nb, const double* R, double* Z, const int* skip = nullptr, bool first_apply = true,
+                        bool final_apply = true) {
   if (c->plan_lowrank) {
     const long long ld = c->ld;
     const int rpad = c->rpad;
@@ -1186,26 +1205,30 @@ static int shared_solve(pgpfa_ctx* c, int nb, const double* R, double* Z) {
         }
       });
     };
-    apply_bin(R, nullptr, 1.0, c->Xt);
-    GemmP y{};                                               // Y = F^T (Gb R)          (rpad x nb)
+    if (first_apply) apply_bin(R, nullptr, 1.0, c->Xt);
+    GemmP y{};
+    y.skip = skip;                                               // Y = F^T (Gb R)          (rpad x nb)
     y.A = c->FTbig; y.sA = 0; y.lda = rpad; y.B = c->Xt; y.sB = 0; y.ldb = c->ld; y.C = c->Glt; y.sC = 0; y.ldc = c->ld;
     y.M = rpad; y.N = nb; y.K = c->npad; y.alpha = 1.0; y.beta = 0.0; y.slots = nullptr; y.nbatch = 1; y.mode = GEMM_FULL; y.kflags = 0;
     y.krange = c->d_kr_ft; y.k_loop_hint = c->kr_ft_len; y.flops_hint = 2.0 * c->T * c->rtot * nb;      // block-diagonal operand: only T x r_k blocks are non-zero
     CHK(gemm(c, true, y));
     GemmP z{};                                               // Zs = Sb Y
+    z.skip = skip;
     z.A = c->sU; z.sA = 0; z.lda = rpad; z.B = c->Glt; z.sB = 0; z.ldb = c->ld; z.C = c->KD; z.sC = 0; z.ldc = c->ld;
     z.M = rpad; z.N = nb; z.K = rpad; z.alpha = 1.0; z.beta = 0.0; z.slots = nullptr; z.nbatch = 1; z.mode = GEMM_FULL; z.kflags = 0;
     CHK(gemm(c, true, z));
     GemmP q{};                                               // Q = F Zs                (n x nb)
+    q.skip = skip;
     q.A = c->Fbig; q.sA = 0; q.lda = c->ld; q.B = c->KD; q.sB = 0; q.ldb = c->ld; q.C = c->Xt; q.sC = 0; q.ldc = c->ld;
     q.M = c->n; q.N = nb; q.K = rpad; q.alpha = 1.0; q.beta = 0.0; q.slots = nullptr; q.nbatch = 1; q.mode = GEMM_FULL; q.kflags = 0;
     q.krange = c->d_kr_f; q.k_loop_hint = c->kr_f_len; q.flops_hint = 2.0 * c->T * c->rtot * nb;
     CHK(gemm(c, true, q));
-    apply_bin(R, c->Xt, c->eps, Z);
+    if (final_apply) apply_bin(R, c->Xt, c->eps, Z);
     HIPC(hipGetLastError());
     return 0;
   }
   GemmP g{};
+  g.skip = skip;
   g.A = c->sU; g.sA = 0; g.lda = c->ld;                      // P^-1, symmetric
   g.B = R; g.sB = 0; g.ldb = c->ld;                          // K x N column-major: slot vectors
   g.C = Z; g.sC = 0; g.ldc = c->ld;
@@ -1613,9 +1636,63 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
         CHK(upload_list(c, c->list_a, active));
         hipLaunchKernelGGL(grad_total_kernel, dim3((nvec + 255) / 256, na), dim3(256), 0, c->st, c->Gl, ld, c->KX, ld, c->Gt, ld, nvec, c->list_a);
         hipLaunchKernelGGL(pcg_init_kernel, dim3((c->npad + 255) / 256, na), dim3(256), 0, c->st, c->Gt, c->Rv, c->Dl, ld, nvec, c->npad, c->list_a);
+        const bool fused = c->pcg_fused && c->plan_lowrank && p <= 16 && c->h_pcg != nullptr;
+        int done_inner = 0;
+        if (fused) {
+          // ---- inner solve without host round trips (pcg.h): the stopping test runs on the device, iterations are enqueued
+          // ahead, kernels of iterations past the stop return at once
+          const int ntile = (T + 63) / 64;
+          const int* skip = &c->pcgctl->stop;
+          const long long sW32 = (long long)T * (p * (p + 1) / 2);
+          HIPC(hipMemsetAsync(c->pcgctl, 0, sizeof(PcgCtl), c->st));
+          c->h_pcg[0] = 0; c->h_pcg[1] = 0;
+          if (c->pcg_w32)
+            hipLaunchKernelGGL(pack_w32_kernel, dim3((unsigned)((sW32 + 255) / 256), na), dim3(256), 0, c->st, c->W, (long long)T * p * p, c->W32,
+                               sW32, T, p, c->list_a);
+          const dim3 gbin(ntile, (na + PCG_SLOTS - 1) / PCG_SLOTS);
+          // z0 = P^-1 r0, p0 = z0
+          CHK(shared_solve(c, nb, c->Rv, c->Zv, nullptr, true, false));
+          dispatch_pw(p, [&](auto pw) {
+            constexpr int PW = decltype(pw)::value;
+            if constexpr (PW <= 16)
+              hipLaunchKernelGGL(pcg_apply2_dots_kernel<PW>, gbin, dim3(256), 0, c->st, c->Gbar, c->Rv, c->Xt, c->eps, c->Zv, ld, T, p, c->list_a, na,
+                                 c->sc_part2, (const int*)nullptr);
+          });
+          hipLaunchKernelGGL(pcg_update_p2_kernel, dim3(na), dim3(256), 0, c->st, c->Zv, c->Pv, ld, nvec, c->list_a, c->sc_part2, ntile, c->sc_rz,
+                             c->sc_rr, c->sc_rr0, 1, (PcgCtl*)nullptr);
+          for (int it = 0; it < c->pcg_inner_max; ++it) {
+            CHK(prior_mv_all(c, nb, c->Pv, c->Qv, nullptr, skip));
+            dispatch_pw(p, [&](auto pw) {
+              constexpr int PW = decltype(pw)::value;
+              if constexpr (PW <= 16) {
+                if (c->pcg_w32)
+                  hipLaunchKernelGGL(pcg_hessvec32_dot_kernel<PW>, dim3(ntile, na), dim3(256), 0, c->st, c->W32, sW32, c->Pv, c->Qv, ld, T, p,
+                                     c->list_a, c->sc_pq, skip);
+                else
+                  hipLaunchKernelGGL(pcg_hessvec_dot_kernel<PW>, dim3(ntile, na), dim3(256), 0, c->st, c->W, (long long)T * p * p, c->Pv, c->Qv,
+                                     ld, T, p, c->list_a, c->sc_pq);
+                hipLaunchKernelGGL(pcg_xr_apply_kernel<PW>, gbin, dim3(256), 0, c->st, c->Gbar, c->Dl, c->Rv, c->Pv, c->Qv, c->Xt, ld, T, p,
+                                   c->list_a, na, c->sc_rz, c->sc_pq, ntile, skip);
+              }
+            });
+            CHK(shared_solve(c, nb, c->Rv, c->Zv, skip, false, false));
+            dispatch_pw(p, [&](auto pw) {
+              constexpr int PW = decltype(pw)::value;
+              if constexpr (PW <= 16)
+                hipLaunchKernelGGL(pcg_apply2_dots_kernel<PW>, gbin, dim3(256), 0, c->st, c->Gbar, c->Rv, c->Xt, c->eps, c->Zv, ld, T, p, c->list_a,
+                                   na, c->sc_part2, skip);
+            });
+            hipLaunchKernelGGL(pcg_update_p2_kernel, dim3(na), dim3(256), 0, c->st, c->Zv, c->Pv, ld, nvec, c->list_a, c->sc_part2, ntile,
+                               c->sc_rz, c->sc_rr, c->sc_rr0, 0, c->pcgctl);
+            hipLaunchKernelGGL(pcg_check_kernel, dim3(1), dim3(64), 0, c->st, c->pcgctl, (volatile int*)c->d_hpcg, (float)eta_target,
+                               c->pcg_inner_min);
+            if (*(volatile int*)&c->h_pcg[0]) break;           // the device has already stopped: whatever is enqueued is a no-op
+          }
+          HIPC(hipGetLastError());
+          done_inner = -1;                                     // read from the control block with the scalars below
+        } else {
         CHK(shared_solve(c, nb, c->Rv, c->Zv));
         hipLaunchKernelGGL(pcg_update_p_kernel, dim3(na), dim3(256), 0, c->st, c->Rv, c->Zv, c->Pv, ld, nvec, c->list_a, c->sc_rz, c->sc_rr0, 1);
-        int done_inner = 0;
         for (int it = 0; it < c->pcg_inner_max; ++it) {
           CHK(prior_mv_all(c, nb, c->Pv, c->Qv));
           int pq_tiles = 1;
@@ -1643,7 +1720,7 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
             if (worst <= eta_target) break;
           }
         }
-        n_pcg += (double)na * done_inner;
+        }
         hipLaunchKernelGGL(step_stats_kernel, dim3(na), dim3(256), 0, c->st, c->Gt, c->Dl, ld, nvec, c->list_a, c->sc_dec, c->sc_smax);
         CHK(prior_mv_all(c, nb, c->Dl, c->KD));
         hipLaunchKernelGGL(dots3_kernel, dim3(na), dim3(256), 0, c->st, c->Xc, ld, c->KX, ld, c->Dl, ld, c->KD, ld, nvec, c->list_a, c->sc_qxx,
@@ -1661,6 +1738,8 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
           std::copy(pack.begin() + 5 * nB, pack.begin() + 5 * nB + nb, rr.begin());
           std::copy(pack.begin() + 6 * nB, pack.begin() + 6 * nB + nb, rr0.begin());
         }
+        if (done_inner < 0) done_inner = c->h_pcg[1];           // (the download above synchronised the stream)
+        n_pcg += (double)na * done_inner;
         std::vector<int> cand, next, failed;
         for (int s : active) {
           if (!(dec[s] > 0.0) || !std::isfinite(dec[s]) || !std::isfinite(smax[s])) continue;   // leave to the fallback
@@ -1912,6 +1991,45 @@ int pgpfa_count_moments(pgpfa_ctx* c, int n, const int32_t* idx, int64_t* sum, i
   return 0;
 }
 
+// util.dataset (util.py:705-750) on the device: latent trajectories and counts of the listed trials drawn under the parameters
+// of the context (pgpfa_set_params), counts written into the resident tensor (and copied out on request).
+int pgpfa_generate(pgpfa_ctx* c, unsigned long long seed, int n, const int32_t* idx, double* X_out, uint8_t* Y_out) {
+  if (!c) return fail("null context");
+  if (!c->have_params) return fail("set_params has not been called");
+  if (c->T > 65536 || c->q > 65535) return fail("generator supports up to 65535 neurons and 65536 bins");
+  HIPC(hipSetDevice(c->device));
+  Trials tr;
+  CHK(resolve_trials(c, n, idx, &tr, true));
+  const int N = (int)tr.v.size(), q = c->q, p = c->p, T = c->T;
+  double* X = nullptr;
+  int* dtr = nullptr;
+  int* flag = nullptr;
+  HIPC(hipMalloc((void**)&X, (size_t)c->R * p * T * sizeof(double)));
+  hipError_t e1 = hipMalloc((void**)&dtr, (size_t)N * sizeof(int)), e2 = hipMalloc((void**)&flag, sizeof(int));
+  int rc = 0, over = 0;
+  if (e1 != hipSuccess || e2 != hipSuccess) rc = fail("hipMalloc failed");
+  if (!rc) {
+    hipMemcpyAsync(dtr, tr.v.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice, c->st);
+    hipMemsetAsync(flag, 0, sizeof(int), c->st);
+    int rmax = 0;
+    for (int k = 0; k < p; ++k) rmax = std::max(rmax, c->rk[k]);
+    hipLaunchKernelGGL(sample_latents_kernel, dim3(p, N), dim3(256), (size_t)(rmax + 2) * sizeof(double), c->st, c->Flr, c->Tp, T, p, c->d_rank, c->eps,
+                       seed, dtr, X);
+    hipLaunchKernelGGL(sample_counts_kernel, dim3((T + 63) / 64, q, N), dim3(64), 0, c->st, X, c->C, c->d, q, p, T, seed, dtr, c->Y, flag);
+    hipMemcpyAsync(&over, flag, sizeof(int), hipMemcpyDeviceToHost, c->st);
+    for (int i = 0; i < N; ++i) {
+      if (X_out) hipMemcpyAsync(X_out + (size_t)i * p * T, X + (size_t)tr.v[i] * p * T, (size_t)p * T * sizeof(double), hipMemcpyDeviceToHost, c->st);
+      if (Y_out) hipMemcpyAsync(Y_out + (size_t)i * q * T, c->Y + (size_t)tr.v[i] * q * T, (size_t)q * T, hipMemcpyDeviceToHost, c->st);
+    }
+    if (hipStreamSynchronize(c->st) != hipSuccess || hipGetLastError() != hipSuccess) rc = fail("generator launch failed");
+  }
+  hipFree(X); if (dtr) hipFree(dtr); if (flag) hipFree(flag);
+  if (rc) return rc;
+  if (over) return fail("%d sampled counts exceed 255 (rates too high for the packed count tensor)", over);
+  c->have_counts = true;
+  return 0;
+}
+
 // util.leaveOneOutPrediction (util.py:289-334): for every listed trial and every neuron, the Laplace mode of the latents
 // given all other neurons (cold start, same Newton machinery with that neuron's likelihood term dropped) and the
 // held-out neuron's predicted rate per bin; R*q mode searches, batched like trials.
@@ -2098,7 +2216,7 @@ static int cd_sweep(pgpfa_ctx* c) {
   const double flops = (double)a.ntr * q * T * (2.0 * p * p + 8.0 * p);
   if (c->mfma && c->cd_mfma && p <= 10) {
     if (!c->cdym_valid) {
-      const int nbk = std::max(1, std::min(128, a.ntr));
+      const int nbk = std::max(1, std::min(1024, a.ntr));
       hipLaunchKernelGGL(cd_ym_kernel, dim3(nbk), dim3(256), 0, c->st, c->Y, c->Xmode, c->last_trials, a.ntr, q, p, T,
                          c->cdym_part);
       hipLaunchKernelGGL(reduce_parts_kernel, dim3(((p + 1) * q + 31) / 32), dim3(256), 0, c->st, c->cdym_part, nbk, (p + 1) * q, c->cdym);

@@ -48,6 +48,7 @@ _SIGNATURES = {
     'pgpfa_mstep_tau_costgrad': [ct.c_void_p, ct.c_int, ct.c_double, c_double_p, c_double_p],
     'pgpfa_mstep_tau_costgrad_batch': [ct.c_void_p, c_double_p, c_double_p, c_double_p],
     'pgpfa_mstep_tau_costgrad_multi': [ct.c_void_p, ct.c_int, c_double_p, c_double_p, c_double_p],
+    'pgpfa_generate': [ct.c_void_p, ct.c_ulonglong, ct.c_int, c_int32_p, c_double_p, c_uint8_p],
     'pgpfa_loo_predict': [ct.c_void_p, ct.c_int, c_int32_p, c_double_p, c_double_p],
     'pgpfa_count_moments': [ct.c_void_p, ct.c_int, c_int32_p, c_int64_p, c_int64_p, c_int64_p],
     'pgpfa_dual_costgrad': [ct.c_void_p, ct.c_int, c_double_p, c_double_p, c_double_p],
@@ -222,6 +223,15 @@ class Context:
         ns = ct.c_int64(0)
         check(self.lib.pgpfa_count_moments(self.h, n, iptr(ii), s.ctypes.data_as(c_int64_p), S.ctypes.data_as(c_int64_p), ct.byref(ns)))
         return s, S, int(ns.value)
+
+    def generate(self, seed, idx=None, want_x=True, want_y=True):
+        """Sample latents and counts of the listed trials on the device (they replace the resident counts) -> (X, Y) copies."""
+        n, ii = self._n_idx(idx)
+        X = np.empty((n, self.p, self.T)) if want_x else None
+        Y = np.empty((n, self.q, self.T), dtype=np.uint8) if want_y else None
+        check(self.lib.pgpfa_generate(self.h, int(seed), n, iptr(ii), dptr(X) if want_x else None,
+                                      Y.ctypes.data_as(c_uint8_p) if want_y else None))
+        return X, Y
 
     def loo_predict(self, idx=None):
         """Leave-one-neuron-out prediction for the listed trials -> (y_pred[n][q][T], summed squared error)."""

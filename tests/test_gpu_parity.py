@@ -685,6 +685,7 @@ def test_device_lbfgs_dual_solver_matches_scipy_driver(funs_mod):
         funs_mod.inference.DUAL_SOLVER = solver
         try:
             out[solver] = funs_mod.inference.dualVariational(exp, params)
+            out[solver][0].materialize()              # the second solver's run overwrites the device views of the first
         finally:
             funs_mod.inference.DUAL_SOLVER = 'device'
     (ir_d, nll_d, vlb_d, opt_d), (ir_s, nll_s, vlb_s, opt_s) = out['device'], out['scipy']

@@ -389,3 +389,85 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line['n_gpus'] == 2 and line['value'] > 0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# synthetic population drawn on the device (reference recipe util.py:705-750)
+# ---------------------------------------------------------------------------------------------------------------
+def test_device_generator_distributions(funs_mod):
+    """The device sampler is not NumPy's stream, so it is checked against the distributions of the reference recipe: latents
+    x_k ~ N(0, K(tau_k)) (sample covariance over 4000 trials against the oracle's Gram matrix, entries within 6 standard errors;
+    zero mean), counts y ~ Poisson(exp(Cx+d)) given the returned latents (standardised residuals: mean 0, variance 1, per-count
+    frequencies at small rates against the Poisson pmf by chi-square; large rates exercise the rejection sampler), and it is a
+    pure function of the seed."""
+    from funs import _hip
+    q, p, T, R = 12, 3, 40, 4000
+    rng = np.random.default_rng(5)
+    C = rng.uniform(-0.5, 0.5, (q, p))
+    d = rng.uniform(-2.0, 0.0, q) - 1.0
+    d[-2:] = np.array([2.6, 3.3])                       # two busy neurons: rates 10-60 per bin -> transformed rejection
+    tau = np.array([0.03, 0.12, 0.4])
+    ctx = _hip.Context(q, p, T, R, 10.0)
+    try:
+        ctx.set_params(C, d, tau)
+        X, Y = ctx.generate(1234)
+        X2, Y2 = ctx.generate(1234)
+        assert np.array_equal(X, X2) and np.array_equal(Y, Y2)
+        X3, Y3 = ctx.generate(1235, np.arange(8, dtype=np.int32))
+        assert not np.array_equal(X3, X[:8])
+        # counts generated into the resident tensor are what the E-step then sees
+        Xs, Ys = ctx.generate(1234, np.arange(8, dtype=np.int32))
+        assert np.array_equal(Ys, Y[:8])
+        obj, _, st = ctx.estep_laplace(np.arange(8, dtype=np.int32))
+        assert np.all(st == 0) and np.isfinite(obj)
+    finally:
+        ctx.close()
+    K = orc.make_K(tau, T, 10.0)
+    for k in range(p):
+        xs = X[:, k, :]                                 # (R, T)
+        assert np.max(np.abs(xs.mean(axis=0))) <= 6.0 * np.sqrt(1.0 / R)
+        S = xs.T @ xs / R
+        se = np.sqrt((K[k] ** 2 + np.outer(np.diag(K[k]), np.diag(K[k]))) / R)       # Wishart standard errors
+        assert np.max(np.abs(S - K[k]) / se) <= 6.0
+    lam = np.exp(np.einsum('nk,rkt->rnt', C, X) + d[None, :, None])
+    Yf = Y.astype(np.float64)
+    z = (Yf - lam) / np.sqrt(lam)
+    for n in range(q):
+        m = z[:, n, :].size
+        assert abs(z[:, n, :].mean()) <= 6.0 / np.sqrt(m)
+        # Var[(y-lam)/sqrt(lam)] = 1 ; its own variance is (2 + 1/lam)/m
+        tol = 6.0 * np.sqrt((2.0 + np.mean(1.0 / lam[:, n, :])) / m)
+        assert abs(np.mean(z[:, n, :] ** 2) - 1.0) <= tol
+    assert lam[:, -1, :].mean() > 20 and Y[:, -1, :].max() > 40
+    # pmf check on a band of nearly constant small rate
+    sel = (lam > 0.19) & (lam < 0.21)
+    from scipy.stats import poisson
+    obs = np.bincount(Y[sel].astype(int), minlength=6)[:6]
+    expc = np.array([poisson.pmf(c, lam[sel]).sum() for c in range(6)])
+    keep = expc > 5
+    chi2 = np.sum((obs[keep] - expc[keep]) ** 2 / expc[keep])
+    assert chi2 <= 30.0, (chi2, obs, expc)
+    # the drop-in constructor
+    ds = funs_mod.util.dataset(trialDur=400, binSize=10, numTrials=6, xdim=2, ydim=9, seed=3, sampler='device')
+    assert len(ds.data) == 6 and ds.data[0]['Y'].shape == (9, 40) and ds.data[0]['X'].shape == (2, 40) and ds.data[0]['Y'].dtype == np.uint8
+    ds2 = funs_mod.util.dataset(trialDur=400, binSize=10, numTrials=6, xdim=2, ydim=9, seed=3, sampler='device')
+    assert all(np.array_equal(a['Y'], b['Y']) for a, b in zip(ds.data, ds2.data))
+
+
+def test_batched_mcmc_chains_match_single_chains(funs_mod, c1, c1_experiment):
+    """Lockstep elliptical-slice chains over several trials (one batched device evaluation per proposal round): chain i must be
+    the single-trial sampler's chain under the same seed (1e-12: same arithmetic, same draws), and the chain of the golden
+    fixture's trial under its seed must be the reference's (1e-9)."""
+    from funs import mcmc
+    g = load_golden('c1_mcmc.npz')
+    params = {k: v.copy() for k, v in c1['init'].items()}
+    nsamp = int(g['n_samples'])
+    trials = [int(g['trial']), 3, 11]
+    seeds = [int(g['seed']), 7, 8]
+    chains = mcmc.PosteriorMCMC_batch(c1_experiment, dict(params), nsamp, trials, seeds)
+    assert chains.shape == (3,) + g['chain'].shape
+    assert np.max(np.abs(chains[0] - g['chain'])) <= 1e-9
+    for i in (1, 2):
+        np.random.seed(seeds[i])
+        single = mcmc.PosteriorMCMC(c1_experiment, dict(params), nsamp, trials[i])
+        assert np.max(np.abs(chains[i] - single)) <= 1e-12
