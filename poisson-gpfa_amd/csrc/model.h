@@ -2003,7 +2003,10 @@ __global__ __launch_bounds__(256) void vsm_finish_kernel(double* __restrict__ vs
 template <int PW>
 __global__ __launch_bounds__(256) void mix_vsm_kernel(double* __restrict__ Yt, long long sY, int ldy, const double* __restrict__ G, long long sG,
                                                       int T, int p, int rpad, double eps, double* __restrict__ vsm,
-                                                      const int* __restrict__ slots, const int* __restrict__ trial_of_slot) {
+                                                      const int* __restrict__ slots, const int* __restrict__ trial_of_slot,
+                                                      const int* __restrict__ roff, int col_tile) {
+  // roff (may be null): rank offsets of the latents; rows (k,.) of Yt are identically zero - and were not written - left of
+  // column (roff[k] / col_tile) * col_tile (the factor L^-T is upper triangular)
   constexpr int PP = PW * PW, LD = PP + 1, NPAIR = PW * (PW + 1) / 2;
   __shared__ double Gs[64 * LD];
   const int pp = p * p;
@@ -2025,12 +2028,15 @@ __global__ __launch_bounds__(256) void mix_vsm_kernel(double* __restrict__ Yt, l
   double acc[NPAIR];
 #pragma unroll
   for (int i = 0; i < NPAIR; ++i) acc[i] = 0.0;
+  int c0[PW];
+#pragma unroll
+  for (int k = 0; k < PW; ++k) c0[k] = (roff && k < p) ? (roff[k] / col_tile) * col_tile : 0;
   if (live) {
     double* y = Yt + (size_t)slot * sY + t0 + lane;
     for (int b = wave; b < rpad; b += 4) {
       double v[PW], m[PW];
 #pragma unroll
-      for (int k = 0; k < PW; ++k) v[k] = (k < p) ? y[(size_t)b * ldy + (size_t)k * T] : 0.0;
+      for (int k = 0; k < PW; ++k) v[k] = (k < p && b >= c0[k]) ? y[(size_t)b * ldy + (size_t)k * T] : 0.0;
 #pragma unroll
       for (int k = 0; k < PW; ++k) {
         double s2 = 0.0;
