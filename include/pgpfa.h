@@ -55,6 +55,10 @@ int pgpfa_destroy(pgpfa_ctx* ctx);
  * per-trial T x T blocks only when pgpfa_get_post_vsmgp asks for them; 1: store them in every E-step),
  * "dual_lowrank" (0; 1: the dual-variational entry points may use the low-rank engine when it pays - log det through
  * the r x r system - which evaluates the dual WITHOUT the reference's 1e-6 diagonal jitter, inference.py:190),
+ * "dual_f32" (0; 1: with dual_lowrank, the r x r factorisation, its inverse and the Yt product run in single precision on the FP32
+ * matrix cores, log det / covariance blocks / gradient accumulated in FP64: the mixed-precision form BASELINE config 5 asks for),
+ * "pcg_fused" (1: inner PCG iterations without host round trips, pcg.h), "pcg_w32" (1: packed FP32 curvature blocks in the PCG
+ * Hessian-vector product), "cd_mfma" (1: (C,d) sweep on the matrix cores, mstep.h),
  * "extrapolate_start" (1: a warm-started E-step begins at m + beta (m - m_prev) for trials whose two previous
  * E-steps are resident), "extrapolate_beta" (1.0). */
 int pgpfa_set_option(pgpfa_ctx* ctx, const char* key, double value);
@@ -191,6 +195,12 @@ int pgpfa_test_gemm_nt(pgpfa_ctx* ctx, int M, int N, int K, double alpha, const 
 /* The same with B given as K x N column-major (C = alpha*A*B + beta*C): the multi-RHS sweep form. */
 int pgpfa_test_gemm_nn(pgpfa_ctx* ctx, int M, int N, int K, double alpha, const double* A,
                        const double* B, double beta, double* C);
+/* The same two products through the single-precision instantiation of the MFMA kernel (v_mfma_f32_16x16x4_f32; operands are
+ * rounded to float on the way in, C comes back widened): the GEMM of the mixed-precision dual evaluation ("dual_f32"). */
+int pgpfa_test_gemm_nt_f32(pgpfa_ctx* ctx, int M, int N, int K, double alpha, const double* A,
+                           const double* B, double beta, double* C);
+int pgpfa_test_gemm_nn_f32(pgpfa_ctx* ctx, int M, int N, int K, double alpha, const double* A,
+                           const double* B, double beta, double* C);
 /* Times `reps` launches of the dominant kernel (batched trailing SYRK update, K=512) with HIP
  * events on the context stream; returns average ms per launch and the flops of one launch. */
 int pgpfa_bench_syrk(pgpfa_ctx* ctx, int batch, int n, int k, int reps, double* ms_per_launch,

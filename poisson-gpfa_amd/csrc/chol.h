@@ -29,86 +29,89 @@ constexpr int NSUP = 512;   // super-panel width
 // The inverse runs row by row (forward substitution) with row i of L^-1 broadcast the same way.
 // Writes L back in place and L^-1 to Dinv[slot][k0/128]; info[slot] = (k0 + j + 1) at the first bad pivot.
 // --------------------------------------------------------------------------------------------------
+template <typename T>
 struct PotrfLds {
-  double L[NB * NB];            // column-major copy of the factor
-  double line[2][NB];           // broadcast lines, permuted: pos(i) = (i & 3) * 32 + (i >> 2)
-  double rd[2];                 // 1 / L[j][j] of the current step
+  T L[NB * NB];                 // column-major copy of the factor
+  T line[2][NB];                // broadcast lines, permuted: pos(i) = (i & 3) * 32 + (i >> 2)
+  T rd[2];                      // 1 / L[j][j] of the current step
 };
 
-__device__ __forceinline__ double pick8(const double* a, int k) {
-  const double v01 = (k & 1) ? a[1] : a[0], v23 = (k & 1) ? a[3] : a[2];
-  const double v45 = (k & 1) ? a[5] : a[4], v67 = (k & 1) ? a[7] : a[6];
-  const double v03 = (k & 2) ? v23 : v01, v47 = (k & 2) ? v67 : v45;
+template <typename T>
+__device__ __forceinline__ T pick8(const T* a, int k) {
+  const T v01 = (k & 1) ? a[1] : a[0], v23 = (k & 1) ? a[3] : a[2];
+  const T v45 = (k & 1) ? a[5] : a[4], v67 = (k & 1) ? a[7] : a[6];
+  const T v03 = (k & 2) ? v23 : v01, v47 = (k & 2) ? v67 : v45;
   return (k & 4) ? v47 : v03;
 }
 
-template <int Q>
-__device__ __forceinline__ void potrf_diag_chol_steps(double (&a)[32], PotrfLds& S, int r, int cg, int pos_r,
+template <int Q, typename T>
+__device__ __forceinline__ void potrf_diag_chol_steps(T (&a)[32], PotrfLds<T>& S, int r, int cg, int pos_r,
                                                        int* __restrict__ info, long long slot, int k0) {
 #pragma unroll 1
   for (int j = 32 * Q; j < 32 * Q + 32; ++j) {
     const bool own = (j & 3) == cg;
-    double* buf = S.line[j & 1];
+    T* buf = S.line[j & 1];
     if (own && r >= j) {
-      const double v = pick8(&a[8 * Q], (j >> 2) - 8 * Q);
+      const T v = pick8(&a[8 * Q], (j >> 2) - 8 * Q);
       buf[pos_r] = v;                             // column j, unscaled
       if (r == j) {
-        double rd = rsqrt(v);
-        if (!(v > 0.0)) {                         // also catches NaN
+        T rd = rsqrt(v);
+        if (!(v > (T)0)) {                         // also catches NaN
           if (info[slot] == 0) info[slot] = k0 + j + 1;
-          rd = 1.0;
+          rd = (T)1;
         }
         S.rd[j & 1] = rd;
       }
     }
     __syncthreads();
     if (r >= j) {                                 // whole waves drop out as j advances
-      const double rd = S.rd[j & 1];
-      const double lr = buf[pos_r] * rd;          // L[r][j]  (r == j: a_jj / sqrt(a_jj))
+      const T rd = S.rd[j & 1];
+      const T lr = buf[pos_r] * rd;               // L[r][j]  (r == j: a_jj / sqrt(a_jj))
       if (own) S.L[j * NB + r] = lr;
-      const double nlr = -lr * rd;
-      const double* bp = buf + cg * 32;
+      const T nlr = -lr * rd;
+      const T* bp = buf + cg * 32;
 #pragma unroll
       for (int m = 8 * Q; m < 32; ++m) a[m] = fma(nlr, bp[m], a[m]);
     }
   }
 }
 
-template <int Q>
-__device__ __forceinline__ void potrf_diag_inv_steps(double (&t)[32], PotrfLds& S, int r, int cg, double inv_lrr) {
+template <int Q, typename T>
+__device__ __forceinline__ void potrf_diag_inv_steps(T (&t)[32], PotrfLds<T>& S, int r, int cg, T inv_lrr) {
   constexpr int MEND = 8 * (Q + 1);               // columns beyond 32(Q+1) are still zero in this quarter
 #pragma unroll 1
   for (int i = 32 * Q; i < 32 * Q + 32; ++i) {
-    double* xrow = S.line[i & 1];
+    T* xrow = S.line[i & 1];
     if (r == i) {
-      double* xp = xrow + cg * 32;
+      T* xp = xrow + cg * 32;
 #pragma unroll
       for (int m = 0; m < MEND; ++m) xp[m] = t[m];
       if ((i & 3) == cg) xp[i >> 2] = inv_lrr;    // X[i][i]
     }
     __syncthreads();
     if (r > i) {
-      const double lri = -S.L[i * NB + r] * inv_lrr;
-      const double* xp = xrow + cg * 32;
+      const T lri = -S.L[i * NB + r] * inv_lrr;
+      const T* xp = xrow + cg * 32;
 #pragma unroll
       for (int m = 0; m < MEND; ++m) t[m] = fma(lri, xp[m], t[m]);
     }
   }
 }
 
-__global__ __launch_bounds__(512) void potrf_diag_kernel(double* __restrict__ H, long long sH, int ld, int k0,
-                                                          double* __restrict__ Dinv, long long sD,
-                                                          const int* __restrict__ slots, int* __restrict__ info) {
-  __shared__ __attribute__((aligned(16))) PotrfLds S;
+template <typename T>
+__global__ __launch_bounds__(512) void potrf_diag_kernel_t(T* __restrict__ H, long long sH, int ld, int k0,
+                                                            T* __restrict__ Dinv, long long sD,
+                                                            const int* __restrict__ slots, int* __restrict__ info) {
+  __shared__ __attribute__((aligned(16))) PotrfLds<T> S;
   const int tid = threadIdx.x;
   const int r = tid & (NB - 1);
   const int cg = tid >> 7;                      // 0..3, uniform per wave
   const int pos_r = (r & 3) * 32 + (r >> 2);
   const long long slot = slots ? slots[blockIdx.x] : blockIdx.x;
-  double* Hs = H + slot * sH + (size_t)k0 * ld + k0;
-  double* Ds = Dinv + slot * sD + (size_t)(k0 / NB) * NB * NB;
+  T* Hs = H + slot * sH + (size_t)k0 * ld + k0;
+  T* Ds = Dinv + slot * sD + (size_t)(k0 / NB) * NB * NB;
 
-  double a[32];
+  T a[32];
 #pragma unroll
   for (int m = 0; m < 32; ++m) a[m] = Hs[(size_t)(cg + 4 * m) * ld + r];   // entries above the diagonal are never used
   potrf_diag_chol_steps<0>(a, S, r, cg, pos_r, info, slot, k0);
@@ -121,10 +124,10 @@ __global__ __launch_bounds__(512) void potrf_diag_kernel(double* __restrict__ H,
     if (rr >= cc) Hs[(size_t)cc * ld + rr] = S.L[e];
   }
   // ---- X = L^-1 by rows: X[r][c] = -(1/L[r][r]) sum_{i=c}^{r-1} L[r][i] X[i][c]  (c < r),  X[r][r] = 1/L[r][r]
-  double t[32];
+  T t[32];
 #pragma unroll
-  for (int m = 0; m < 32; ++m) t[m] = 0.0;
-  const double inv_lrr = 1.0 / S.L[r * NB + r];
+  for (int m = 0; m < 32; ++m) t[m] = (T)0;
+  const T inv_lrr = (T)1 / S.L[r * NB + r];
   potrf_diag_inv_steps<0>(t, S, r, cg, inv_lrr);
   potrf_diag_inv_steps<1>(t, S, r, cg, inv_lrr);
   potrf_diag_inv_steps<2>(t, S, r, cg, inv_lrr);
@@ -132,16 +135,17 @@ __global__ __launch_bounds__(512) void potrf_diag_kernel(double* __restrict__ H,
 #pragma unroll
   for (int m = 0; m < 32; ++m) {
     const int c = cg + 4 * m;
-    Ds[(size_t)c * NB + r] = (c < r) ? t[m] : (c == r ? inv_lrr : 0.0);
+    Ds[(size_t)c * NB + r] = (c < r) ? t[m] : (c == r ? inv_lrr : (T)0);
   }
 }
 
 // Mt[jblk, jblk] = Dinv[jb]^T
-__global__ void diag_transpose_kernel(double* __restrict__ Mt, long long sM, int ld, int k0,
-                                      const double* __restrict__ Dinv, long long sD, const int* __restrict__ slots) {
+template <typename T>
+__global__ void diag_transpose_kernel_t(T* __restrict__ Mt, long long sM, int ld, int k0,
+                                        const T* __restrict__ Dinv, long long sD, const int* __restrict__ slots) {
   const long long slot = slots ? slots[blockIdx.x] : blockIdx.x;
-  double* M = Mt + slot * sM + (size_t)k0 * ld + k0;
-  const double* D = Dinv + slot * sD + (size_t)(k0 / NB) * NB * NB;
+  T* M = Mt + slot * sM + (size_t)k0 * ld + k0;
+  const T* D = Dinv + slot * sD + (size_t)(k0 / NB) * NB * NB;
   for (int e = threadIdx.x; e < NB * NB; e += blockDim.x) {
     const int r = e & (NB - 1), c = e >> 7;
     M[(size_t)c * ld + r] = D[r * NB + c];
@@ -248,7 +252,7 @@ inline hipError_t chol_factor(hipStream_t st, bool mfma, const CholWS& w, const 
   for (int c0 = 0; c0 < np; c0 += NSUP) {
     const int c1 = (c0 + NSUP < np) ? c0 + NSUP : np;
     for (int k0 = c0; k0 < c1; k0 += NB) {
-      hipLaunchKernelGGL(potrf_diag_kernel, dim3(nb), dim3(512), 0, st, w.H, w.sH, ld, k0, w.Dinv, w.sD, slots, w.info);
+      hipLaunchKernelGGL(potrf_diag_kernel_t<double>, dim3(nb), dim3(512), 0, st, w.H, w.sH, ld, k0, w.Dinv, w.sD, slots, w.info);
       const int r0 = k0 + NB;
       if (r0 >= np) break;
       GemmP g{};
@@ -293,7 +297,7 @@ inline hipError_t chol_factor(hipStream_t st, bool mfma, const CholWS& w, const 
 inline hipError_t chol_inverse_t(hipStream_t st, bool mfma, const CholWS& w, const int* slots, int nb) {
   const int np = w.npad, ld = w.ld;
   for (int j0 = 0; j0 < np; j0 += NB) {
-    hipLaunchKernelGGL(diag_transpose_kernel, dim3(nb), dim3(256), 0, st, w.Mt, w.sM, ld, j0, w.Dinv, w.sD, slots);
+    hipLaunchKernelGGL(diag_transpose_kernel_t<double>, dim3(nb), dim3(256), 0, st, w.Mt, w.sM, ld, j0, w.Dinv, w.sD, slots);
     if (j0 == 0) continue;
     GemmP a{};
     a.A = w.Mt; a.sA = w.sM; a.lda = ld;

@@ -1,0 +1,102 @@
+// Dual-variational evaluation (inference.py:188-256): the contractions over neurons as GEMMs on the matrix cores.
+//   W_t = C^T diag(lambda_t) C      ->  Wp (T x pairs)  = Lambda^T (T x q) . TBL[:, pairs]        TBL[n][pair(a,b)] = c_na c_nb
+//   v   = C_big (lambda - y)        ->  V  (T x p)      = (Lambda - Y)^T (T x q) . TBL[:, latents] TBL[n][NPd + k]   = c_nk
+//   -1/2 c_n^T Sigma_t c_n          ->  G  (T x q)      = -1/2 Sp (T x pairs) . TBL[:, pairs]^T    Sp[t][pair] = w_ab Sigma_t[a][b]
+//   C_big^T K v                     ->  G += KV (T x p) . TBL[:, latents]^T
+// (one thread per bin looping over neurons and latent pairs - the form these replace - costs 30 ms per evaluation of 16 trials at
+// 500 neurons x 20 latents x 1000 bins; the products are ~3e8 flops per trial).  Element-wise kernels around them below.
+#pragma once
+
+namespace pgpfa {
+
+// TBL[n][ncol] (n < qpad): columns [0, NP) pair products (a >= b at a(a+1)/2 + b), [NPd, NPd + p) the loadings, zeros elsewhere
+__global__ void dual_table_kernel(const double* __restrict__ C, int q, int p, int ncol, int npd, double* __restrict__ tbl) {
+  const int n = blockIdx.x;
+  const int np = p * (p + 1) / 2;
+  for (int c = threadIdx.x; c < ncol; c += blockDim.x) {
+    double v = 0.0;
+    if (n < q) {
+      if (c < np) {
+        int a = 0;
+        while ((a + 1) * (a + 2) / 2 <= c) ++a;
+        const int b = c - a * (a + 1) / 2;
+        v = C[(size_t)n * p + a] * C[(size_t)n * p + b];
+      } else if (c >= npd && c < npd + p) {
+        v = C[(size_t)n * p + (c - npd)];
+      }
+    }
+    tbl[(size_t)n * ncol + c] = v;
+  }
+}
+
+// lmy = lambda - y for the slots [0, nslots); partial sums per (slot, 64-bin tile): sum d_n lmy and sum lambda (log lambda - 1).
+// grid = (ceil(T/64), nslots), block = 256 (lanes = bins, the 4 waves take interleaved neurons)
+__global__ __launch_bounds__(256) void dual_pre_kernel(const uint8_t* __restrict__ Y, const double* __restrict__ d, const double* __restrict__ lam,
+                                                       double* __restrict__ lmy, double* __restrict__ part, const int* __restrict__ trial_of_slot,
+                                                       int q, int T) {
+  __shared__ double red[2][4];
+  const size_t slot = blockIdx.y;
+  const size_t trial = trial_of_slot[slot];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t = blockIdx.x * 64 + lane;
+  double sB = 0.0, sD = 0.0;
+  if (t < T) {
+    for (int n = wave; n < q; n += 4) {
+      const size_t e = slot * (size_t)q * T + (size_t)n * T + t;
+      const double l = lam[e];
+      const double v = l - (double)Y[(trial * q + n) * T + t];
+      lmy[e] = v;
+      sB += d[n] * v;
+      sD += l * (log(l) - 1.0);
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) { sB += __shfl_down(sB, off); sD += __shfl_down(sD, off); }
+  if (lane == 0) { red[0][wave] = sB; red[1][wave] = sD; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[(slot * gridDim.x + blockIdx.x) * 2 + 0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    part[(slot * gridDim.x + blockIdx.x) * 2 + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
+}
+
+// W[slot][t][a][b] = W[slot][t][b][a] = Wp[slot][pair(a,b)][t].  grid = (ceil(T*NP/256), nslots)
+__global__ void dual_unpack_w_kernel(const double* __restrict__ Wp, long long sWp, double* __restrict__ W, long long sW, int T, int p) {
+  const int np = p * (p + 1) / 2;
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (size_t)T * np) return;
+  const int c = (int)(e / T), t = (int)(e - (size_t)c * T);
+  int a = 0;
+  while ((a + 1) * (a + 2) / 2 <= c) ++a;
+  const int b = c - a * (a + 1) / 2;
+  const double v = Wp[(size_t)blockIdx.y * sWp + e];
+  double* w = W + (size_t)blockIdx.y * sW + (size_t)t * p * p;
+  w[a * p + b] = v;
+  w[b * p + a] = v;
+}
+
+// Sp[slot][pair][t] = (a == b ? 1 : 2) * Sigma_t[a][b] of the slot's trial, zero rows up to npd.  grid = (ceil(T*npd/256), nslots)
+__global__ void dual_pack_sigma_kernel(const double* __restrict__ vsm, const int* __restrict__ trial_of_slot, double* __restrict__ Sp, long long sSp,
+                                       int T, int p, int npd) {
+  const int np = p * (p + 1) / 2;
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (size_t)T * npd) return;
+  const int c = (int)(e / T), t = (int)(e - (size_t)c * T);
+  double v = 0.0;
+  if (c < np) {
+    int a = 0;
+    while ((a + 1) * (a + 2) / 2 <= c) ++a;
+    const int b = c - a * (a + 1) / 2;
+    v = vsm[((size_t)trial_of_slot[blockIdx.y] * T + t) * p * p + a * p + b] * (a == b ? 1.0 : 2.0);
+  }
+  Sp[(size_t)blockIdx.y * sSp + e] = v;
+}
+
+// grad[slot][n][t] += log(lambda) - d_n.  grid = (ceil(q*T/256), nslots)
+__global__ void dual_grad_finish_kernel(double* __restrict__ grad, const double* __restrict__ lam, const double* __restrict__ d, int q, int T) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (size_t)q * T) return;
+  const size_t o = (size_t)blockIdx.y * q * T + e;
+  grad[o] += log(lam[o]) - d[e / T];
+}
+
+}  // namespace pgpfa

@@ -122,10 +122,35 @@ __device__ __forceinline__ void gemm_decode_block(const GemmP& g, int bid, int& 
 
 constexpr int GBM = 128, GBN = 128, GBK = 16, GLS = 144;   // LDS row stride in doubles
 
-template <int TRANSB>
-__global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP g) {
-  __shared__ __attribute__((aligned(16))) double As[2][GBK][GLS];
-  __shared__ __attribute__((aligned(16))) double Bs[2][GBK][GLS];
+// element-type helpers of the MFMA kernel: FP64 (the E-step) and FP32 (mixed-precision dual-variational evaluation: same
+// 16x16x4 tile shape and fragment layout, v_mfma_f32_16x16x4_f32 issues at twice the FP64 rate)
+typedef float float2_t __attribute__((ext_vector_type(2)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
+typedef double double2_t __attribute__((ext_vector_type(2)));
+template <typename T> struct GemmVec;
+template <> struct GemmVec<double> { using v2 = double2_t; using v4 = double4_t; };
+template <> struct GemmVec<float> { using v2 = float2_t; using v4 = float4_t; };
+__device__ __forceinline__ double4_t gemm_mfma16(double a, double b, double4_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ float4_t gemm_mfma16(float a, float b, float4_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// operand pointers of batch entry b for element type T (GemmP carries them as double*; strides count elements of T)
+template <typename T>
+__device__ __forceinline__ int gemm_bind_t(const GemmP& g, int b, const T*& A, const T*& B, T*& C) {
+  int lo = b, hi = 0;
+  if (g.nb_lo > 0) { hi = b / g.nb_lo; lo = b - hi * g.nb_lo; }
+  const long long slot = g.slots ? g.slots[lo] : lo;
+  A = reinterpret_cast<const T*>(g.A) + slot * g.sA + hi * g.sA_hi;
+  B = reinterpret_cast<const T*>(g.B) + slot * g.sB + hi * g.sB_hi;
+  C = reinterpret_cast<T*>(g.C) + (g.c_by_pos ? (long long)lo : slot) * g.sC + hi * g.sC_hi;
+  return hi;
+}
+
+template <int TRANSB, typename T>
+__global__ __launch_bounds__(256, 2) void gemm_mfma_kernel_t(GemmP g) {
+  using T2 = typename GemmVec<T>::v2;
+  using T4 = typename GemmVec<T>::v4;
+  __shared__ __attribute__((aligned(16))) T As[2][GBK][GLS];
+  __shared__ __attribute__((aligned(16))) T Bs[2][GBK][GLS];
   if (g.skip && *g.skip) return;
 
   const int tid = threadIdx.x;
@@ -137,10 +162,10 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP g) {
   gemm_decode_block(g, blockIdx.x, b, tile);
   int ti, tj;
   gemm_decode_tile(g, tile, ti, tj);
-  const double* A;
-  const double* B;
-  double* C;                       // may alias A (in-place TRSM): no restrict
-  const int hi = gemm_bind(g, b, A, B, C);
+  const T* A;
+  const T* B;
+  T* C;                            // may alias A (in-place TRSM): no restrict
+  const int hi = gemm_bind_t<T>(g, b, A, B, C);
 
   const int i0 = ti * GBM, j0 = tj * GBN;
   int kb = 0, ke = g.K;
@@ -151,11 +176,11 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP g) {
   if (kb > ke) kb = ke;
   gemm_split_range(g.ksplit, hi, kb, ke);
 
-  const bool a_vec = ((((size_t)A) & 15) == 0) && ((g.lda & 1) == 0);
-  const bool b_vec = ((((size_t)B) & 15) == 0) && ((g.ldb & 1) == 0);
+  const bool a_vec = ((((size_t)A) & (2 * sizeof(T) - 1)) == 0) && ((g.lda & 1) == 0);
+  const bool b_vec = ((((size_t)B) & (2 * sizeof(T) - 1)) == 0) && ((g.ldb & 1) == 0);
 
   // staging registers: 4 x double2 per operand per thread
-  double ra[8], rb[8];
+  T ra[8], rb[8];
 
   auto load_tiles = [&](int k0) {
 #pragma unroll
@@ -163,9 +188,9 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP g) {
       const int u = tid + 256 * s;
       {  // A: [k][row] ; unit -> k = u>>6, rows 2*(u&63), +1
         const int k = u >> 6, r2 = (u & 63) * 2;
-        const double* src = A + gemm_koff(g.kseg, g.sAseg, g.lda, k0) + (size_t)k * g.lda + (i0 + r2);
+        const T* src = A + gemm_koff(g.kseg, g.sAseg, g.lda, k0) + (size_t)k * g.lda + (i0 + r2);
         if (a_vec) {
-          const double2 v = *reinterpret_cast<const double2*>(src);
+          const T2 v = *reinterpret_cast<const T2*>(src);
           ra[2 * s] = v.x; ra[2 * s + 1] = v.y;
         } else {
           ra[2 * s] = src[0]; ra[2 * s + 1] = src[1];
@@ -173,18 +198,18 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP g) {
       }
       if (TRANSB == 0) {
         const int k = u >> 6, r2 = (u & 63) * 2;
-        const double* src = B + gemm_koff(g.kseg, g.sBseg, g.ldb, k0) + (size_t)k * g.ldb + (j0 + r2);
+        const T* src = B + gemm_koff(g.kseg, g.sBseg, g.ldb, k0) + (size_t)k * g.ldb + (j0 + r2);
         if (b_vec) {
-          const double2 v = *reinterpret_cast<const double2*>(src);
+          const T2 v = *reinterpret_cast<const T2*>(src);
           rb[2 * s] = v.x; rb[2 * s + 1] = v.y;
         } else {
           rb[2 * s] = src[0]; rb[2 * s + 1] = src[1];
         }
       } else {  // B is K x N: unit -> n = u&127, k pair = u>>7
         const int nn = u & 127, k2 = (u >> 7) * 2;
-        const double* src = B + (size_t)(j0 + nn) * g.ldb + (k0 + k2);
+        const T* src = B + (size_t)(j0 + nn) * g.ldb + (k0 + k2);
         if (b_vec) {
-          const double2 v = *reinterpret_cast<const double2*>(src);
+          const T2 v = *reinterpret_cast<const T2*>(src);
           rb[2 * s] = v.x; rb[2 * s + 1] = v.y;
         } else {
           rb[2 * s] = src[0]; rb[2 * s + 1] = src[1];
@@ -198,11 +223,11 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP g) {
       const int u = tid + 256 * s;
       {
         const int k = u >> 6, r2 = (u & 63) * 2;
-        *reinterpret_cast<double2*>(&As[buf][k][r2]) = make_double2(ra[2 * s], ra[2 * s + 1]);
+        *reinterpret_cast<T2*>(&As[buf][k][r2]) = T2{ra[2 * s], ra[2 * s + 1]};
       }
       if (TRANSB == 0) {
         const int k = u >> 6, r2 = (u & 63) * 2;
-        *reinterpret_cast<double2*>(&Bs[buf][k][r2]) = make_double2(rb[2 * s], rb[2 * s + 1]);
+        *reinterpret_cast<T2*>(&Bs[buf][k][r2]) = T2{rb[2 * s], rb[2 * s + 1]};
       } else {
         const int nn = u & 127, k2 = (u >> 7) * 2;
         Bs[buf][k2][nn] = rb[2 * s];
@@ -211,11 +236,11 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP g) {
     }
   };
 
-  double4_t acc[4][4];
+  T4 acc[4][4];
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = T4{(T)0, (T)0, (T)0, (T)0};
 
   // a wave whose 64x64 sub-tile lies entirely outside C still stages and syncs, but skips MFMAs
   const bool wave_live = (i0 + wm * 64 < g.M) && (j0 + wn * 64 < g.N) &&
@@ -234,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP g) {
     if (wave_live) {
 #pragma unroll
       for (int kk = 0; kk < GBK; kk += 4) {
-        double af[4], bf[4];
+        T af[4], bf[4];
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) af[mi] = As[buf][kk + l4][wm * 64 + mi * 16 + l15];
 #pragma unroll
@@ -243,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP g) {
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
           for (int ni = 0; ni < 4; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[ni], af[mi], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = gemm_mfma16(bf[ni], af[mi], acc[mi][ni]);
       }
     }
     if (it + 1 < nk) store_tiles(buf ^ 1);
@@ -251,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP g) {
   }
 
   if (!wave_live) return;
-  // D[row = l4 + 4r][col = l15]: row <-> j (B index), col <-> i (A index)
+  // D[row][col = l15]: row <-> j (B index), col <-> i (A index)
   const bool mask_diag = (g.kflags & KF_MASK_DIAG) && (ti == tj);
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
@@ -261,12 +286,14 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmP g) {
     for (int ni = 0; ni < 4; ++ni) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int j = j0 + wn * 64 + ni * 16 + l4 + 4 * r;
+        // accumulator register r of a lane: row l4 + 4 r of the 16 x 16 tile for FP64, row 4 l4 + r for FP32 (the C/D map of
+        // v_mfma_f64_16x16x4_f64 differs from every other shape / dtype on gfx950)
+        const int j = j0 + wn * 64 + ni * 16 + (sizeof(T) == 8 ? l4 + 4 * r : 4 * l4 + r);
         if (j >= g.N) continue;
         if (mask_diag && i < j) continue;
-        double* dst = C + (size_t)j * g.ldc + i;
-        double v = g.alpha * acc[mi][ni][r];
-        if (g.beta != 0.0) v += g.beta * (*dst);
+        T* dst = C + (size_t)j * g.ldc + i;
+        T v = (T)g.alpha * acc[mi][ni][r];
+        if (g.beta != 0.0) v += (T)g.beta * (*dst);
         *dst = v;
       }
     }
@@ -364,7 +391,7 @@ inline int gemm_count_tiles(int mode, int tilesM, int tilesN) {
 }
 
 // Host launcher.  K, and every k range implied by kflags, must be a multiple of 16.
-inline hipError_t gemm_launch(hipStream_t st, bool use_mfma, bool transb, GemmP g) {
+inline hipError_t gemm_launch(hipStream_t st, bool use_mfma, bool transb, GemmP g, bool f32 = false) {
   g.tilesM = (g.M + GBM - 1) / GBM;
   g.tilesN = (g.N + GBN - 1) / GBN;
   g.ntiles = gemm_count_tiles(g.mode, g.tilesM, g.tilesN);
@@ -372,9 +399,13 @@ inline hipError_t gemm_launch(hipStream_t st, bool use_mfma, bool transb, GemmP 
   if (g.kseg != 0 && (transb || g.kseg % GBK != 0)) return hipErrorInvalidValue;
   const long long blocks = (long long)g.ntiles * g.nbatch;
   dim3 grid((unsigned)blocks);
-  if (use_mfma) {
-    if (transb) hipLaunchKernelGGL(gemm_mfma_kernel<1>, grid, dim3(256), 0, st, g);
-    else hipLaunchKernelGGL(gemm_mfma_kernel<0>, grid, dim3(256), 0, st, g);
+  if (f32) {
+    if (g.kseg != 0) return hipErrorInvalidValue;        // (segmented K addresses are computed for FP64 operands only)
+    if (transb) hipLaunchKernelGGL((gemm_mfma_kernel_t<1, float>), grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemm_mfma_kernel_t<0, float>), grid, dim3(256), 0, st, g);
+  } else if (use_mfma) {
+    if (transb) hipLaunchKernelGGL((gemm_mfma_kernel_t<1, double>), grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemm_mfma_kernel_t<0, double>), grid, dim3(256), 0, st, g);
   } else {
     if (transb) hipLaunchKernelGGL(gemm_check_kernel<1>, grid, dim3(256), 0, st, g);
     else hipLaunchKernelGGL(gemm_check_kernel<0>, grid, dim3(256), 0, st, g);

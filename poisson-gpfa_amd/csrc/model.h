@@ -592,8 +592,8 @@ __global__ void dense_h_kernel(double* __restrict__ out, int n, int T, int Tp, i
 // with Mt = L^-T (upper triangular).  Block = 64 bins x KY latents, columns i streamed in chunks of 16
 // through LDS; output indexed by trial.
 // --------------------------------------------------------------------------------------------------
-template <int PMAX>
-__global__ void post_vsm_kernel(const double* __restrict__ Mt, long long sM, int ld, int npad, int T, int p,
+template <int PMAX, typename TIN = double>
+__global__ void post_vsm_kernel(const TIN* __restrict__ Mt, long long sM, int ld, int npad, int T, int p,
                                 double* __restrict__ vsm, const int* __restrict__ slots, const int* __restrict__ trial_of_slot,
                                 int full_range) {
   constexpr int NK = (PMAX > 16) ? 2 : 1;
@@ -605,7 +605,7 @@ __global__ void post_vsm_kernel(const double* __restrict__ Mt, long long sM, int
   const int t0 = blockIdx.x * 64;
   const int t = t0 + tx;
   const bool valid = t < T;
-  const double* M = Mt + (size_t)slot * sM;
+  const TIN* M = Mt + (size_t)slot * sM;
   double acc[NK][PMAX];
 #pragma unroll
   for (int j = 0; j < NK; ++j)
@@ -620,7 +620,7 @@ __global__ void post_vsm_kernel(const double* __restrict__ Mt, long long sM, int
       if (k < p) {
         const int row = k * T + t;
 #pragma unroll
-        for (int ii = 0; ii < VIC; ++ii) A[ii][k][tx] = valid ? M[(size_t)(i0 + ii) * ld + row] : 0.0;
+        for (int ii = 0; ii < VIC; ++ii) A[ii][k][tx] = valid ? (double)M[(size_t)(i0 + ii) * ld + row] : 0.0;
       }
     }
     __syncthreads();
@@ -2359,6 +2359,50 @@ __global__ void pack_counts_kernel(const double* __restrict__ src, uint8_t* __re
 }
 
 // p[slot * stride + i] = v for i < n; grid = (ceil(n/1024), nslots), block = 256, 4 elements per thread
+// ---- single-precision views of the factor slabs (mixed-precision dual-variational evaluation) ----------------------------
+// dst[slot] (float, n x n, ld = n) <- lower triangle of src[slot] (double, same shape); the upper triangle is zeroed.
+// grid = (ceil(n*n/1024), nslots), block = 256
+__global__ void cvt_lower_f32_kernel(const double* __restrict__ src, long long sS, float* __restrict__ dst, long long sD, int n) {
+  const double* a = src + (size_t)blockIdx.y * sS;
+  float* b = dst + (size_t)blockIdx.y * sD;
+  const size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const size_t e = base + 256 * u;
+    if (e < (size_t)n * n) {
+      const size_t i = e % n, j = e / n;
+      b[e] = (i >= j) ? (float)a[e] : 0.0f;
+    }
+  }
+}
+__global__ void cvt_f32_kernel(const double* __restrict__ src, float* __restrict__ dst, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = (float)src[i];
+}
+__global__ void fill_slabs_f32_kernel(float* __restrict__ p, long long stride, size_t n, float v) {
+  float* dst = p + (size_t)blockIdx.y * stride;
+  const size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const size_t i = base + 256 * u;
+    if (i < n) dst[i] = v;
+  }
+}
+// log det from a single-precision Cholesky factor, accumulated in double: out[b] = 2 sum_i log L[b][i][i]
+__global__ void logdet_batch_f32_kernel(const float* __restrict__ L, long long sL, int ld, int n, double* __restrict__ out) {
+  __shared__ double red[256];
+  const float* Ls = L + (size_t)blockIdx.x * sL;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += log((double)Ls[(size_t)i * ld + i]);
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = 2.0 * red[0];
+}
+
 __global__ void fill_slabs_kernel(double* __restrict__ p, long long stride, size_t n, double v) {
   double* dst = p + (size_t)blockIdx.y * stride;
   const size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x;

@@ -23,6 +23,7 @@
 #include "model.h"
 #include "mstep.h"
 #include "pcg.h"
+#include "dual.h"
 #include "sample.h"
 
 using namespace pgpfa;
@@ -108,6 +109,9 @@ struct pgpfa_ctx {
   bool cd_hess_valid = false; int cd_hess_ntr = 0;   // per-neuron Hessian sums of the last Newton pass are resident
   std::vector<double> logdetK;                  // log det of the p Gram matrices (from the factor in build_kinv)
   bool dual_lowrank = false;                    // dual-variational entry points may use the low-rank engine (no diagonal jitter)
+  double* dual_tbl = nullptr; int dual_ncol = 0, dual_npd = 0; bool dual_gemm = true;   // pair / loading table of the GEMM form (dual.h)
+  bool dual_f32 = false;                        // ... with the r x r factorisation, its inverse and Yt in single precision (mixed)
+  float* Flr32 = nullptr; bool flr32_valid = false;   // single-precision copy of the low-rank factors
   bool keep_trial_vsmgp = false;
   bool pacc_used = false, pacc_valid = false;
   std::vector<char> vsmgp_ok;                    // per trial: c->vsmgp holds the blocks of the resident posterior
@@ -127,6 +131,7 @@ struct pgpfa_ctx {
   double *Xc = nullptr, *Xt = nullptr, *KX = nullptr, *KD = nullptr, *Gl = nullptr, *Glt = nullptr, *Gt = nullptr, *Dl = nullptr;
   double *W = nullptr, *Wt = nullptr, *fpart = nullptr;
   double *lamd = nullptr, *dgrad = nullptr, *dpart = nullptr, *ldet_buf = nullptr;   // dual variational scratch
+  double* dual_scr = nullptr; long long dual_sscr = 0;   // [B][T x max(pairs padded, p^2)] packed pair tables of the GEMM form
   // shared-preconditioner Newton-PCG: one factor per chunk (mean-trial Hessian), PCG vectors per slot
   CholWS sws{};
   double *sU = nullptr, *sDinvT = nullptr, *Wbar = nullptr;
@@ -302,7 +307,8 @@ double gemm_flops(const GemmP& g) {
   return per * g.nbatch;
 }
 
-int gemm(pgpfa_ctx* c, bool transb, GemmP g) {
+// (f32: operands are single precision - pointers carried as double*, strides in elements - on the FP32 matrix cores; no split-K)
+int gemm(pgpfa_ctx* c, bool transb, GemmP g, bool f32 = false) {
   prof_begin(c, TAG_GEMM, gemm_flops(g));
   // Few output tiles and a long k loop (the thin multi-RHS products of the PCG iterations): the launch would occupy a
   // fraction of the 256 CUs for the length of one k loop.  Cut k into parts run as extra batch entries, sum the
@@ -312,7 +318,7 @@ int gemm(pgpfa_ctx* c, bool transb, GemmP g) {
   // (block-sparse operands: the k loop a tile really runs is the one implied by the flop count)
   const double k_eff = g.k_loop_hint > 0 ? (double)g.k_loop_hint
                        : (g.flops_hint > 0.0 && g.M > 0 && g.N > 0) ? g.flops_hint / (2.0 * g.M * g.N * std::max(g.nbatch, 1)) : (double)g.K;
-  if (c->gemm_part && g.mode == GEMM_FULL && g.kflags == 0 && g.nb_lo == 0 && g.kseg == 0 && tiles > 0 && tiles < 384 && k_eff >= 128.0) {
+  if (!f32 && c->gemm_part && g.mode == GEMM_FULL && g.kflags == 0 && g.nb_lo == 0 && g.kseg == 0 && tiles > 0 && tiles < 384 && k_eff >= 128.0) {
     // (a lone workgroup per CU walks its k loop at the latency of one global load per 16-wide step: with a handful of
     // tiles even a 128-long loop is worth cutting, down to parts of two steps)
     ksplit = std::min(std::min(8, (int)(k_eff / (tiles < 64 ? 32.0 : 64.0))), (c->splitk_target + tiles - 1) / tiles);
@@ -332,7 +338,7 @@ int gemm(pgpfa_ctx* c, bool transb, GemmP g) {
       e = hipGetLastError();
     }
   } else {
-    e = gemm_launch(c->st, c->mfma, transb, g);
+    e = gemm_launch(c->st, c->mfma, transb, g, f32);
   }
   prof_end(c);
   if (e != hipSuccess) return fail("gemm launch failed: %s", hipGetErrorString(e));
@@ -340,68 +346,79 @@ int gemm(pgpfa_ctx* c, bool transb, GemmP g) {
 }
 
 // chol_factor / chol_inverse_t with per-launch profiling (same sequence as chol.h's plain versions)
-int factor(pgpfa_ctx* c, const CholWS& w, const int* slots, int nb) {
+// (f32: the slabs of w hold single-precision matrices - same pointers reinterpreted, strides in elements)
+int factor(pgpfa_ctx* c, const CholWS& w, const int* slots, int nb, bool f32 = false) {
+  auto at = [f32](double* base, size_t off) { return f32 ? reinterpret_cast<double*>(reinterpret_cast<float*>(base) + off) : base + off; };
   const int np = w.npad, ld = w.ld;
   const int na = (w.nact > 0 && w.nact <= np) ? w.nact : np;   // rows >= na are identity padding: never updated
   for (int c0 = 0; c0 < np; c0 += NSUP) {
     const int c1 = std::min(c0 + NSUP, np);
     for (int k0 = c0; k0 < c1; k0 += NB) {
       prof_begin(c, TAG_POTRF, 2.0 * nb * (double)NB * NB * NB / 3.0);
-      hipLaunchKernelGGL(potrf_diag_kernel, dim3(nb), dim3(512), 0, c->st, w.H, w.sH, ld, k0, w.Dinv, w.sD, slots, w.info);
+      if (f32)
+        hipLaunchKernelGGL(potrf_diag_kernel_t<float>, dim3(nb), dim3(512), 0, c->st, reinterpret_cast<float*>(w.H), w.sH, ld, k0,
+                           reinterpret_cast<float*>(w.Dinv), w.sD, slots, w.info);
+      else
+        hipLaunchKernelGGL(potrf_diag_kernel_t<double>, dim3(nb), dim3(512), 0, c->st, w.H, w.sH, ld, k0, w.Dinv, w.sD, slots, w.info);
       prof_end(c);
       const int r0 = k0 + NB;
       if (r0 >= np) break;
       GemmP g{};
-      g.A = w.H + (size_t)k0 * ld + r0; g.sA = w.sH; g.lda = ld;
-      g.B = w.Dinv + (size_t)(k0 / NB) * NB * NB; g.sB = w.sD; g.ldb = NB;
-      g.C = w.H + (size_t)k0 * ld + r0; g.sC = w.sH; g.ldc = ld;
+      g.A = at(w.H, (size_t)k0 * ld + r0); g.sA = w.sH; g.lda = ld;
+      g.B = at(w.Dinv, (size_t)(k0 / NB) * NB * NB); g.sB = w.sD; g.ldb = NB;
+      g.C = at(w.H, (size_t)k0 * ld + r0); g.sC = w.sH; g.ldc = ld;
       g.M = na - r0; g.N = NB; g.K = NB; g.alpha = 1.0; g.beta = 0.0;
       g.slots = slots; g.nbatch = nb; g.mode = GEMM_FULL; g.kflags = 0;
-      if (g.M > 0) CHK(gemm(c, false, g));
+      if (g.M > 0) CHK(gemm(c, false, g, f32));
       if (r0 < c1 && r0 < na) {
         GemmP s{};
-        s.A = w.H + (size_t)k0 * ld + r0; s.sA = w.sH; s.lda = ld;
+        s.A = at(w.H, (size_t)k0 * ld + r0); s.sA = w.sH; s.lda = ld;
         s.B = s.A; s.sB = w.sH; s.ldb = ld;
-        s.C = w.H + (size_t)r0 * ld + r0; s.sC = w.sH; s.ldc = ld;
+        s.C = at(w.H, (size_t)r0 * ld + r0); s.sC = w.sH; s.ldc = ld;
         s.M = na - r0; s.N = std::min(c1, na) - r0; s.K = NB; s.alpha = -1.0; s.beta = 1.0;
         s.slots = slots; s.nbatch = nb; s.mode = GEMM_LOWER; s.kflags = KF_MASK_DIAG;
-        CHK(gemm(c, false, s));
+        CHK(gemm(c, false, s, f32));
       }
     }
     if (c1 < na) {
       GemmP s{};
-      s.A = w.H + (size_t)c0 * ld + c1; s.sA = w.sH; s.lda = ld;
+      s.A = at(w.H, (size_t)c0 * ld + c1); s.sA = w.sH; s.lda = ld;
       s.B = s.A; s.sB = w.sH; s.ldb = ld;
-      s.C = w.H + (size_t)c1 * ld + c1; s.sC = w.sH; s.ldc = ld;
+      s.C = at(w.H, (size_t)c1 * ld + c1); s.sC = w.sH; s.ldc = ld;
       s.M = na - c1; s.N = na - c1; s.K = c1 - c0; s.alpha = -1.0; s.beta = 1.0;
       s.slots = slots; s.nbatch = nb; s.mode = GEMM_LOWER; s.kflags = KF_MASK_DIAG;
-      CHK(gemm(c, false, s));
+      CHK(gemm(c, false, s, f32));
     }
   }
   HIPC(hipGetLastError());
   return 0;
 }
 
-int inverse_t(pgpfa_ctx* c, const CholWS& w, const int* slots, int nb) {
+int inverse_t(pgpfa_ctx* c, const CholWS& w, const int* slots, int nb, bool f32 = false) {
+  auto at = [f32](double* base, size_t off) { return f32 ? reinterpret_cast<double*>(reinterpret_cast<float*>(base) + off) : base + off; };
   const int np = w.npad, ld = w.ld;
   const int na = (w.nact > 0 && w.nact <= np) ? w.nact : np;   // rows >= na of Mt are identity padding
   for (int j0 = 0; j0 < np; j0 += NB) {
-    hipLaunchKernelGGL(diag_transpose_kernel, dim3(nb), dim3(256), 0, c->st, w.Mt, w.sM, ld, j0, w.Dinv, w.sD, slots);
+    if (f32)
+      hipLaunchKernelGGL(diag_transpose_kernel_t<float>, dim3(nb), dim3(256), 0, c->st, reinterpret_cast<float*>(w.Mt), w.sM, ld, j0,
+                         reinterpret_cast<const float*>(w.Dinv), w.sD, slots);
+    else
+      hipLaunchKernelGGL(diag_transpose_kernel_t<double>, dim3(nb), dim3(256), 0, c->st, w.Mt, w.sM, ld, j0, w.Dinv, w.sD, slots);
     if (j0 == 0) continue;
     GemmP a{};
     a.A = w.Mt; a.sA = w.sM; a.lda = ld;
-    a.B = w.H + j0; a.sB = w.sH; a.ldb = ld;
+    a.B = at(w.H, j0); a.sB = w.sH; a.ldb = ld;
     a.C = w.P; a.sC = w.sP; a.ldc = np;
     a.M = std::min(j0, na); a.N = NB; a.K = j0; a.alpha = 1.0; a.beta = 0.0;
     a.slots = slots; a.nbatch = nb; a.mode = GEMM_FULL; a.kflags = KF_BEGIN_ROW;
-    CHK(gemm(c, false, a));
+    CHK(gemm(c, false, a, f32));
     GemmP b{};
     b.A = w.P; b.sA = w.sP; b.lda = np;
-    b.B = w.Dinv + (size_t)(j0 / NB) * NB * NB; b.sB = w.sD; b.ldb = NB;
-    b.C = w.Mt + (size_t)j0 * ld; b.sC = w.sM; b.ldc = ld;
+    b.B = at(w.Dinv, (size_t)(j0 / NB) * NB * NB); b.sB = w.sD; b.ldb = NB;
+    b.C = at(w.Mt, (size_t)j0 * ld); b.sC = w.sM; b.ldc = ld;
     b.M = std::min(j0, na); b.N = NB; b.K = NB; b.alpha = -1.0; b.beta = 0.0;
     b.slots = slots; b.nbatch = nb; b.mode = GEMM_FULL; b.kflags = 0;
-    CHK(gemm(c, false, b));
+    CHK(gemm(c, false, b, f32));
   }
   HIPC(hipGetLastError());
   return 0;
@@ -455,6 +472,7 @@ int free_workspace(pgpfa_ctx* c) {
   while (c->allocs.size() > c->ws_mark) { hipFree(c->allocs.back()); c->allocs.pop_back(); }
   c->B = 0;
   c->lamd = c->dgrad = c->dpart = c->ldet_buf = nullptr;
+  c->dual_scr = nullptr;
   c->commbuf = nullptr; c->commbuf_len = 0;
   c->mt_dirty = false;
   return 0;
@@ -769,6 +787,7 @@ int build_lowrank(pgpfa_ctx* c) {
     HIPC(hipGetLastError());
   }
   c->info["lowrank_rtot"] = c->rtot;
+  c->flr32_valid = false;
   return 0;
 }
 
@@ -876,6 +895,9 @@ int pgpfa_create(pgpfa_ctx** out, int device, int q, int p, int T, int R, double
     rc |= dmalloc(c, &c->CCu, (size_t)c->qpad * c->ccu_cols + 64, true);
     rc |= dmalloc(c, &c->C16, (size_t)c->qpad * 16 + 64, true);
   }
+  c->dual_npd = round_up(p * (p + 1) / 2, 16);
+  c->dual_ncol = c->dual_npd + round_up(p, 16);
+  rc |= dmalloc(c, &c->dual_tbl, (size_t)round_up(q, 128) * c->dual_ncol + 4096, true);   // (GEMM tiles read whole 128-row blocks of it)
   rc |= dmalloc(c, &c->ppart, (size_t)p * (PACC_SPLITS + 1) * T * T + 256);
   c->vsmgp_ok.assign(R, 0);
   rc |= dmalloc(c, &c->Flr, slab * p + 256 * (size_t)c->Tp, true);
@@ -922,6 +944,7 @@ int pgpfa_destroy(pgpfa_ctx* c) {
   if (c->comm) ncclCommDestroy(c->comm);
   for (void* p : c->allocs) hipFree(p);
   if (c->vsmgp) hipFree(c->vsmgp);
+  if (c->Flr32) hipFree(c->Flr32);
   if (c->arena) hipFree(c->arena);
   if (c->hbuf) hipHostFree(c->hbuf);
   if (c->hibuf) hipHostFree(c->hibuf);
@@ -948,6 +971,8 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
   else if (k == "lowrank_tol") c->lr_tol = v;
   else if (k == "keep_trial_vsmgp") c->keep_trial_vsmgp = (v != 0.0);
   else if (k == "dual_lowrank") c->dual_lowrank = (v != 0.0);
+  else if (k == "dual_f32") c->dual_f32 = (v != 0.0);
+  else if (k == "dual_gemm") c->dual_gemm = (v != 0.0);
   else if (k == "extrapolate_start") c->extrapolate = (v != 0.0);
   else if (k == "extrapolate_beta") c->extrapolate_beta = v;
   else if (k == "shared_min") c->shared_min = (int)v;
@@ -1063,6 +1088,7 @@ int pgpfa_set_params(pgpfa_ctx* c, const double* C, const double* d, const doubl
   hipLaunchKernelGGL(gram_tau_kernel, dim3(c->Tp, c->p), dim3(256), 0, c->st, c->Kpad, c->Tp, c->T, c->tau, c->bin, c->eps);
   if (c->CCu)
     hipLaunchKernelGGL(poisson_tables_kernel, dim3(c->qpad), dim3(64), 0, c->st, c->C, c->q, c->p, c->qpad, c->ccu_cols, c->CCu, c->C16);
+  hipLaunchKernelGGL(dual_table_kernel, dim3(c->qpad), dim3(64), 0, c->st, c->C, c->q, c->p, c->dual_ncol, c->dual_npd, c->dual_tbl);
   HIPC(hipGetLastError());
   CHK(build_kinv(c));
   CHK(build_lowrank(c));
@@ -1394,18 +1420,85 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool 
                      c->d_blk_lat, c->d_blk_col, c->Wt, sW, c->ident, nb);
   HIPC(hipGetLastError());
   HIPC(hipMemsetAsync(c->ws.info, 0, sizeof(int) * nb, c->st));
-  CHK(factor(c, lw, c->ident, nb));
+  // Mixed precision (option dual_f32, dual-variational evaluations only): B is assembled in FP64 and rounded once; its Cholesky
+  // factor, L^-T and Yt = F L^-T - the O(r^3) and O(T r^2) parts - run on the FP32 matrix cores (twice the FP64 rate, half the
+  // bytes); log det and the per-bin covariance blocks are accumulated in FP64 from the single-precision factors.
+  const bool f32 = c->dual_f32 && !want_vsmgp;
+  CholWS lwf = lw;                                         // single-precision views: B / L in the Mt slabs, L^-T and Yt in the H slabs
+  float* Ytf = nullptr;
+  if (f32) {
+    lwf.H = lw.Mt; lwf.sH = 2 * lw.sM;
+    lwf.Mt = lw.H; lwf.sM = 2 * lw.sH;
+    lwf.sD = 2 * lw.sD; lwf.sP = 2 * lw.sP;
+    Ytf = reinterpret_cast<float*>(lw.H) + (size_t)rpad * rpad;
+    if (!c->Flr32) {
+      if (hipMalloc((void**)&c->Flr32, ((size_t)Tp * Tp * p + 256 * (size_t)Tp) * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return fail("out of device memory for the single-precision factors"); }
+      c->flr32_valid = false;
+    }
+    if (!c->flr32_valid) {
+      const size_t nf = (size_t)Tp * Tp * p;
+      hipLaunchKernelGGL(cvt_f32_kernel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, c->st, c->Flr, c->Flr32, nf);
+      c->flr32_valid = true;
+    }
+    hipLaunchKernelGGL(cvt_lower_f32_kernel, dim3((unsigned)(((size_t)rpad * rpad + 1023) / 1024), nb), dim3(256), 0, c->st, lw.H, (long long)lw.sH,
+                       reinterpret_cast<float*>(lwf.H), (long long)lwf.sH, rpad);
+    c->mt_dirty = true;
+    CHK(factor(c, lwf, c->ident, nb, true));
+  } else {
+    CHK(factor(c, lw, c->ident, nb));
+  }
   if (logdet_out) {
     std::vector<double> a(nb), b2(nb);
     hipLaunchKernelGGL(sum_rows_kernel, dim3(nb), dim3(256), 0, c->st, c->ldet_buf, T, c->sc_f);
     CHK(download(c, a.data(), c->sc_f, nb));
-    hipLaunchKernelGGL(logdet_batch_kernel, dim3(nb), dim3(256), 0, c->st, lw.H, (long long)lw.sH, rpad, rpad, c->sc_f);
+    if (f32)
+      hipLaunchKernelGGL(logdet_batch_f32_kernel, dim3(nb), dim3(256), 0, c->st, reinterpret_cast<const float*>(lwf.H), (long long)lwf.sH, rpad, rpad,
+                         c->sc_f);
+    else
+      hipLaunchKernelGGL(logdet_batch_kernel, dim3(nb), dim3(256), 0, c->st, lw.H, (long long)lw.sH, rpad, rpad, c->sc_f);
     CHK(download(c, b2.data(), c->sc_f, nb));
     double ldk = 0.0;
     for (double v : c->logdetK) ldk += v;
     for (int s2 = 0; s2 < nb; ++s2) logdet_out[s2] = -ldk + a[s2] + b2[s2];
   }
   c->mt_dirty = true;
+  if (f32) {
+    hipLaunchKernelGGL(fill_slabs_f32_kernel, dim3((unsigned)(((size_t)rpad * rpad + 1023) / 1024), nb), dim3(256), 0, c->st,
+                       reinterpret_cast<float*>(lwf.Mt), (long long)lwf.sM, (size_t)rpad * rpad, 0.0f);
+    CHK(inverse_t(c, lwf, c->ident, nb, true));
+    // Yt (float, n x ract, ld = c->ld) behind L^-T in the same slab
+    for (int k = 0; k < p; ++k) {
+      GemmP g{};
+      g.A = reinterpret_cast<const double*>(c->Flr32 + (size_t)k * Tp * Tp); g.sA = 0; g.lda = Tp;
+      g.B = reinterpret_cast<const double*>(reinterpret_cast<float*>(lwf.Mt) + c->roff[k]); g.sB = lwf.sM; g.ldb = rpad;
+      g.C = reinterpret_cast<double*>(Ytf + (size_t)k * T); g.sC = lwf.sM; g.ldc = c->ld;
+      g.M = T; g.N = ract; g.K = c->rk[k]; g.alpha = 1.0; g.beta = 0.0;
+      g.slots = c->ident; g.nbatch = nb; g.mode = GEMM_FULL; g.kflags = 0;
+      CHK(gemm(c, true, g, true));
+    }
+    if (p > WIDE_MAX) return fail("low-rank covariance engine supports up to %d latents (p=%d)", WIDE_MAX, p);
+    const int KYf = std::min(p, 16);
+    prof_begin(c, TAG_VSM, (double)nb * c->n * rpad * p);
+    dispatch_pmax(p, [&](auto pm) {
+      hipLaunchKernelGGL((post_vsm_kernel<decltype(pm)::value, float>), dim3((T + 63) / 64, nb), dim3(64, KYf), 0, c->st, (const float*)Ytf,
+                         (long long)lwf.sM, c->ld, ract, T, p, c->vsm, c->ident, c->trial_of_slot, 1);
+    });
+    prof_end(c);
+    dispatch_pw(p, [&](auto pw) {
+      constexpr int PW = decltype(pw)::value;
+      if constexpr (PW <= 16) {
+        constexpr int BT = 256 / PW;
+        hipLaunchKernelGGL(vsm_finish_kernel<PW>, dim3((T + BT - 1) / BT, nb), dim3(256), 0, c->st, c->vsm, c->Gbin, sW, T, p, c->eps, c->ident,
+                           c->trial_of_slot);
+      } else {
+        const int bins = wide_bins(p) / 2;
+        hipLaunchKernelGGL(vsm_finish_wide_kernel, dim3((T + bins - 1) / bins, nb), dim3(bins * 32), wide_lds_bytes(p, bins, 2), c->st, c->vsm,
+                           c->Gbin, sW, T, p, c->eps, c->ident, c->trial_of_slot, bins);
+      }
+    });
+    HIPC(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(fill_slabs_kernel, dim3((unsigned)(((size_t)rpad * rpad + 1023) / 1024), nb), dim3(256), 0, c->st, lw.Mt, lw.sM,
                      (size_t)rpad * rpad, 0.0);
   CHK(inverse_t(c, lw, c->ident, nb));
@@ -2581,10 +2674,14 @@ int pgpfa_mstep_tau_costgrad_batch(pgpfa_ctx* c, const double* logp, double* cos
 // ---- dual variational E-step (inference.py:188-432) ----------------------------------------------------
 static int ensure_lambda(pgpfa_ctx* c) {
   if (c->lamd) return 0;
-  CHK(dmalloc(c, &c->lamd, (size_t)c->B * c->q * c->T));
-  CHK(dmalloc(c, &c->dgrad, (size_t)c->B * c->q * c->T));
+  // (slack: the GEMM form reads Lambda^T as a T x qpad operand and whole 128-row tiles)
+  const size_t lam_slack = (size_t)16 * c->T + 4096;
+  CHK(dmalloc(c, &c->lamd, (size_t)c->B * c->q * c->T + lam_slack, true));
+  CHK(dmalloc(c, &c->dgrad, (size_t)c->B * c->q * c->T + lam_slack, true));
   CHK(dmalloc(c, &c->dpart, (size_t)c->B * ((c->T + 63) / 64) * 2 + 16));
   CHK(dmalloc(c, &c->ldet_buf, (size_t)c->B * c->T + 16));
+  c->dual_sscr = (long long)c->T * std::max(c->dual_npd, c->p * c->p);
+  CHK(dmalloc(c, &c->dual_scr, (size_t)c->B * c->dual_sscr + (size_t)256 * c->T + 4096, true));
   return 0;
 }
 
@@ -2592,8 +2689,25 @@ static int ensure_lambda(pgpfa_ctx* c) {
 static int dual_common(pgpfa_ctx* c, int nb, std::vector<double>* sB, std::vector<double>* sD, std::vector<double>* vKv) {
   const int q = c->q, p = c->p, T = c->T, ntile = (T + 63) / 64;
   const long long ld = c->ld;
-  hipLaunchKernelGGL(dual_prep_kernel, dim3(ntile, nb), dim3(64), 0, c->st, c->Y, c->C, c->d, c->lamd, (long long)q * T, c->Xt, ld, c->W,
-                     (long long)T * p * p, c->dpart, ntile, c->ident, c->trial_of_slot, q, p, T);
+  if (c->dual_gemm && c->mfma) {
+    const long long sW = (long long)T * p * p;
+    const int np = p * (p + 1) / 2;
+    hipLaunchKernelGGL(dual_pre_kernel, dim3(ntile, nb), dim3(256), 0, c->st, c->Y, c->d, c->lamd, c->dgrad, c->dpart, c->trial_of_slot, q, T);
+    GemmP w{};                                               // Wp (T x pairs) = Lambda^T . TBL[:, pairs]
+    w.A = c->lamd; w.sA = (long long)q * T; w.lda = T;
+    w.B = c->dual_tbl; w.sB = 0; w.ldb = c->dual_ncol;
+    w.C = c->dual_scr; w.sC = c->dual_sscr; w.ldc = T;
+    w.M = T; w.N = np; w.K = c->qpad; w.alpha = 1.0; w.beta = 0.0; w.slots = c->ident; w.nbatch = nb; w.mode = GEMM_FULL; w.kflags = 0;
+    CHK(gemm(c, false, w));
+    GemmP v = w;                                             // V (T x p) = (Lambda - Y)^T . TBL[:, latents]   -> c->Xt
+    v.A = c->dgrad; v.B = c->dual_tbl + c->dual_npd; v.C = c->Xt; v.sC = ld; v.N = p;
+    CHK(gemm(c, false, v));
+    hipLaunchKernelGGL(dual_unpack_w_kernel, dim3((unsigned)(((size_t)T * np + 255) / 256), nb), dim3(256), 0, c->st, c->dual_scr, c->dual_sscr, c->W, sW,
+                       T, p);
+  } else {
+    hipLaunchKernelGGL(dual_prep_kernel, dim3(ntile, nb), dim3(64), 0, c->st, c->Y, c->C, c->d, c->lamd, (long long)q * T, c->Xt, ld, c->W,
+                       (long long)T * p * p, c->dpart, ntile, c->ident, c->trial_of_slot, q, p, T);
+  }
   CHK(prior_mv(c, c->ident, nb, c->Xt, c->KD, c->Kpad));            // K v
   hipLaunchKernelGGL(dots3_kernel, dim3(nb), dim3(256), 0, c->st, c->Xt, ld, c->KD, ld, (const double*)nullptr, 0LL, (const double*)nullptr, 0LL,
                      c->n, c->ident, c->sc_qxx, c->sc_qdx, c->sc_qdd);
@@ -2711,6 +2825,30 @@ int pgpfa_dual_post_cov(pgpfa_ctx* c, int trial, const double* lam, double* cov,
   return 0;
 }
 
+// dualProblem_grad (inference.py:218) of the slots [0, nb) into c->dgrad from K v (c->KD) and the per-bin covariance blocks in c->vsm
+static int dual_gradient(pgpfa_ctx* c, int nb) {
+  const int q = c->q, p = c->p, T = c->T;
+  if (c->dual_gemm && c->mfma) {
+    hipLaunchKernelGGL(dual_pack_sigma_kernel, dim3((unsigned)(((size_t)T * c->dual_npd + 255) / 256), nb), dim3(256), 0, c->st, c->vsm,
+                       c->trial_of_slot, c->dual_scr, c->dual_sscr, T, p, c->dual_npd);
+    GemmP g{};                                               // G (T x q) = -1/2 Sp . TBL[:, pairs]^T
+    g.A = c->dual_scr; g.sA = c->dual_sscr; g.lda = T;
+    g.B = c->dual_tbl; g.sB = 0; g.ldb = c->dual_ncol;       // K x N column-major: element (pair, n) at n * ncol + pair
+    g.C = c->dgrad; g.sC = (long long)q * T; g.ldc = T;
+    g.M = T; g.N = q; g.K = c->dual_npd; g.alpha = -0.5; g.beta = 0.0; g.slots = c->ident; g.nbatch = nb; g.mode = GEMM_FULL; g.kflags = 0;
+    CHK(gemm(c, true, g));
+    GemmP l = g;                                             // G += K v (T x p) . TBL[:, latents]^T
+    l.A = c->KD; l.sA = c->ld; l.B = c->dual_tbl + c->dual_npd; l.K = round_up(p, 16); l.alpha = 1.0; l.beta = 1.0;
+    CHK(gemm(c, true, l));
+    hipLaunchKernelGGL(dual_grad_finish_kernel, dim3((unsigned)(((size_t)q * T + 255) / 256), nb), dim3(256), 0, c->st, c->dgrad, c->lamd, c->d, q, T);
+  } else {
+    hipLaunchKernelGGL(dual_grad_batch_kernel, dim3((T + 63) / 64, q, nb), dim3(64), 0, c->st, c->C, c->d, c->lamd, c->KD, (long long)c->ld, c->vsm,
+                       c->trial_of_slot, c->dgrad, q, p, T);
+  }
+  HIPC(hipGetLastError());
+  return 0;
+}
+
 // Dual cost (and gradient with respect to lambda, into c->dgrad) of the slots [0, nb) whose lambda is already in c->lamd and
 // whose trials are bound in c->trial_of_slot: the arithmetic of dualProblem / dualProblem_grad (inference.py:196-219) with
 // the dense factorisations of the chunk batched.
@@ -2738,9 +2876,7 @@ static int dual_eval_slots(pgpfa_ctx* c, int nb, const std::vector<int>& tos, bo
       }
     }
     if (want_grad) {
-      hipLaunchKernelGGL(dual_grad_batch_kernel, dim3((T + 63) / 64, q, nb), dim3(64), 0, c->st, c->C, c->d, c->lamd, c->KD, (long long)c->ld,
-                         c->vsm, c->trial_of_slot, c->dgrad, q, p, T);
-      HIPC(hipGetLastError());
+      CHK(dual_gradient(c, nb));
     }
     return 0;
   }
@@ -2767,9 +2903,7 @@ static int dual_eval_slots(pgpfa_ctx* c, int nb, const std::vector<int>& tos, bo
       hipLaunchKernelGGL(post_vsm_kernel<decltype(pm)::value>, dim3((T + 63) / 64, nb), dim3(64, KY), 0, c->st, c->ws.Mt, c->ws.sM, c->ld, c->npad,
                          T, p, c->vsm, c->ident, c->trial_of_slot, 0);
     });
-    hipLaunchKernelGGL(dual_grad_batch_kernel, dim3((T + 63) / 64, q, nb), dim3(64), 0, c->st, c->C, c->d, c->lamd, c->KD, (long long)c->ld, c->vsm,
-                       c->trial_of_slot, c->dgrad, q, p, T);
-    HIPC(hipGetLastError());
+    CHK(dual_gradient(c, nb));
   }
   return 0;
 }
@@ -3193,6 +3327,47 @@ static int test_gemm(pgpfa_ctx* c, bool transb, int M, int N, int K, double alph
   return rc;
 }
 
+// The same products through the single-precision instantiation of the MFMA kernel (operands rounded to float on the way in).
+static int test_gemm_f32(pgpfa_ctx* c, bool transb, int M, int N, int K, double alpha, const double* A, const double* B, double beta, double* C) {
+  if (!c || !A || !B || !C) return fail("null argument");
+  if (M < 1 || N < 1 || K < 1) return fail("invalid sizes");
+  HIPC(hipSetDevice(c->device));
+  const int Kp = round_up(K, 16);
+  const size_t nA = (size_t)M * Kp + 256 * (size_t)Kp, nB = (size_t)N * Kp + 256 * (size_t)Kp, nC = (size_t)M * N;
+  std::vector<float> hA(nA, 0.f), hB(nB, 0.f), hC(nC);
+  for (int k = 0; k < K; ++k)
+    for (int i = 0; i < M; ++i) hA[(size_t)k * M + i] = (float)A[(size_t)k * M + i];          // column-major M x K, lda = M
+  if (transb) { for (int j = 0; j < N; ++j) for (int k = 0; k < K; ++k) hB[(size_t)j * Kp + k] = (float)B[(size_t)j * K + k]; }   // K x N, ldb = Kp
+  else { for (int k = 0; k < K; ++k) for (int j = 0; j < N; ++j) hB[(size_t)k * N + j] = (float)B[(size_t)k * N + j]; }          // N x K, ldb = N
+  for (size_t i = 0; i < nC; ++i) hC[i] = (float)C[i];
+  float *dA = nullptr, *dB = nullptr, *dC = nullptr;
+  HIPC(hipMalloc((void**)&dA, (nA + 4096) * sizeof(float)));
+  HIPC(hipMalloc((void**)&dB, (nB + 4096) * sizeof(float)));
+  HIPC(hipMalloc((void**)&dC, (nC + 4096) * sizeof(float)));
+  hipMemsetAsync(dA, 0, (nA + 4096) * sizeof(float), c->st); hipMemsetAsync(dB, 0, (nB + 4096) * sizeof(float), c->st);
+  hipMemcpyAsync(dA, hA.data(), nA * sizeof(float), hipMemcpyHostToDevice, c->st);
+  hipMemcpyAsync(dB, hB.data(), nB * sizeof(float), hipMemcpyHostToDevice, c->st);
+  hipMemcpyAsync(dC, hC.data(), nC * sizeof(float), hipMemcpyHostToDevice, c->st);
+  GemmP g{};
+  g.A = reinterpret_cast<const double*>(dA); g.sA = 0; g.lda = M;
+  g.B = reinterpret_cast<const double*>(dB); g.sB = 0; g.ldb = transb ? Kp : N;
+  g.C = reinterpret_cast<double*>(dC); g.sC = 0; g.ldc = M;
+  g.M = M; g.N = N; g.K = Kp; g.alpha = alpha; g.beta = beta; g.slots = nullptr; g.nbatch = 1; g.mode = GEMM_FULL; g.kflags = 0;
+  int rc = gemm(c, transb, g, true);
+  if (!rc) {
+    hipMemcpyAsync(hC.data(), dC, nC * sizeof(float), hipMemcpyDeviceToHost, c->st);
+    if (hipStreamSynchronize(c->st) != hipSuccess) rc = fail("f32 gemm failed");
+    for (size_t i = 0; i < nC; ++i) C[i] = hC[i];
+  }
+  hipFree(dA); hipFree(dB); hipFree(dC);
+  return rc;
+}
+int pgpfa_test_gemm_nt_f32(pgpfa_ctx* c, int M, int N, int K, double alpha, const double* A, const double* B, double beta, double* C) {
+  return test_gemm_f32(c, false, M, N, K, alpha, A, B, beta, C);
+}
+int pgpfa_test_gemm_nn_f32(pgpfa_ctx* c, int M, int N, int K, double alpha, const double* A, const double* B, double beta, double* C) {
+  return test_gemm_f32(c, true, M, N, K, alpha, A, B, beta, C);
+}
 int pgpfa_test_gemm_nt(pgpfa_ctx* c, int M, int N, int K, double alpha, const double* A, const double* B, double beta, double* C) {
   return test_gemm(c, false, M, N, K, alpha, A, B, beta, C);
 }

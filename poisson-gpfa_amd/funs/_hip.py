@@ -63,6 +63,8 @@ _SIGNATURES = {
     'pgpfa_test_potrf': [ct.c_void_p, ct.c_int, ct.c_int, c_double_p, c_double_p, c_double_p],
     'pgpfa_test_gemm_nt': [ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, ct.c_double, c_double_p, c_double_p, ct.c_double, c_double_p],
     'pgpfa_test_gemm_nn': [ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, ct.c_double, c_double_p, c_double_p, ct.c_double, c_double_p],
+    'pgpfa_test_gemm_nt_f32': [ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, ct.c_double, c_double_p, c_double_p, ct.c_double, c_double_p],
+    'pgpfa_test_gemm_nn_f32': [ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, ct.c_double, c_double_p, c_double_p, ct.c_double, c_double_p],
     'pgpfa_bench_syrk': [ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, ct.c_int, c_double_p, c_double_p],
     'pgpfa_bench_mfma_peak': [ct.c_void_p, ct.c_int, c_double_p],
 }
@@ -408,24 +410,26 @@ class Context:
         check(self.lib.pgpfa_test_potrf(self.h, b, n, dptr(A), dptr(L), dptr(inv) if want_inverse else None))
         return L, inv
 
-    def test_gemm_nt(self, A, B, C=None, alpha=1.0, beta=0.0):
-        """C = alpha*A@B.T + beta*C with A (M,K), B (N,K) given row-major; passed column-major."""
+    def test_gemm_nt(self, A, B, C=None, alpha=1.0, beta=0.0, f32=False):
+        """C = alpha*A@B.T + beta*C with A (M,K), B (N,K) given row-major; passed column-major.  f32: single-precision MFMA kernel."""
         A, B = as_f64(A), as_f64(B)
         M, K = A.shape
         N = B.shape[0]
         Ccm = np.zeros((N, M)) if C is None else as_f64(np.asarray(C).T)     # column-major (M,N) == row-major (N,M)
         Acm, Bcm = as_f64(A.T), as_f64(B.T)                                   # column-major (M,K) == row-major (K,M)
-        check(self.lib.pgpfa_test_gemm_nt(self.h, M, N, K, float(alpha), dptr(Acm), dptr(Bcm), float(beta), dptr(Ccm)))
+        fn = self.lib.pgpfa_test_gemm_nt_f32 if f32 else self.lib.pgpfa_test_gemm_nt
+        check(fn(self.h, M, N, K, float(alpha), dptr(Acm), dptr(Bcm), float(beta), dptr(Ccm)))
         return Ccm.T.copy()
 
-    def test_gemm_nn(self, A, B, C=None, alpha=1.0, beta=0.0):
+    def test_gemm_nn(self, A, B, C=None, alpha=1.0, beta=0.0, f32=False):
         """C = alpha*A@B + beta*C with A (M,K), B (K,N) row-major in; B is passed K x N column-major."""
         A, B = as_f64(A), as_f64(B)
         M, K = A.shape
         N = B.shape[1]
         Ccm = np.zeros((N, M)) if C is None else as_f64(np.asarray(C).T)
         Acm, Bcm = as_f64(A.T), as_f64(B.T)                # (K,N) column-major == (N,K) row-major buffer
-        check(self.lib.pgpfa_test_gemm_nn(self.h, M, N, K, float(alpha), dptr(Acm), dptr(Bcm), float(beta), dptr(Ccm)))
+        fn = self.lib.pgpfa_test_gemm_nn_f32 if f32 else self.lib.pgpfa_test_gemm_nn
+        check(fn(self.h, M, N, K, float(alpha), dptr(Acm), dptr(Bcm), float(beta), dptr(Ccm)))
         return Ccm.T.copy()
 
     def bench_mfma_peak(self, iters=20000):

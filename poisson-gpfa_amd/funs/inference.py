@@ -319,6 +319,9 @@ def dualProblemRho_grad(rho, ybar, C_big, K_big, K_bigInv, d_big):
 # reference's per-trial scipy L-BFGS-B calls (same options), driven concurrently with batched device evaluations
 DUAL_SOLVER = 'device'
 DUAL_LOWRANK = False
+# with DUAL_LOWRANK: factorisation of the r x r system, its inverse and the Yt product of every dual evaluation in single precision
+# on the FP32 matrix cores, log det / covariance blocks / gradient accumulated in FP64 (BASELINE config 5 asks for fp32)
+DUAL_F32 = False
 
 
 class _ConcurrentProblems:
@@ -417,6 +420,7 @@ def dualVariational(experiment, params, optimizeLogLambda=False, prevOptimRes=No
     # xdim*T): it is the dual WITHOUT the reference's 1e-6 diagonal jitter (inference.py:190), which on stiff GP priors
     # moves the posterior covariance blocks by up to ~1 % - hence off by default
     ctx.set_option('dual_lowrank', 1 if (DUAL_SOLVER == 'device' and DUAL_LOWRANK) else 0)
+    ctx.set_option('dual_f32', 1 if (DUAL_SOLVER == 'device' and DUAL_LOWRANK and DUAL_F32) else 0)
     if DUAL_SOLVER == 'device' and len(mine):
         # all trials in lockstep on the device, in rho = log(lambda); same optimum as either of the reference's variants
         if prevOptimRes is None:

@@ -471,3 +471,93 @@ def test_batched_mcmc_chains_match_single_chains(funs_mod, c1, c1_experiment):
         np.random.seed(seeds[i])
         single = mcmc.PosteriorMCMC(c1_experiment, dict(params), nsamp, trials[i])
         assert np.max(np.abs(chains[i] - single)) <= 1e-12
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# single precision: the FP32 instantiation of the MFMA GEMM and the mixed-precision dual evaluation (BASELINE config 5)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('M,N,K', [(128, 128, 64), (200, 77, 300), (513, 1030, 48)])
+def test_f32_gemm_vs_numpy(M, N, K):
+    """v_mfma_f32_16x16x4_f32 instantiation of the tile kernel (both operand forms) against float64 numpy products of the
+    float-rounded operands: 2e-6 relative to |A||B| (single-precision accumulation over K <= 300)."""
+    from funs import _hip
+    rng = np.random.default_rng(M + N + K)
+    A, Bt, Bn = rng.standard_normal((M, K)), rng.standard_normal((N, K)), rng.standard_normal((K, N))
+    C0 = rng.standard_normal((M, N))
+    ctx = _hip.Context(4, 2, 16, 1, 10.0)
+    try:
+        A32, Bt32, Bn32, C32 = (x.astype(np.float32).astype(np.float64) for x in (A, Bt, Bn, C0))
+        got = ctx.test_gemm_nt(A, Bt, C0, alpha=0.5, beta=2.0, f32=True)
+        ref = 0.5 * A32 @ Bt32.T + 2.0 * C32
+        assert np.max(np.abs(got - ref)) <= 2e-6 * (np.abs(A32) @ np.abs(Bt32).T).max()
+        got = ctx.test_gemm_nn(A, Bn, f32=True)
+        assert np.max(np.abs(got - A32 @ Bn32)) <= 2e-6 * (np.abs(A32) @ np.abs(Bn32)).max()
+    finally:
+        ctx.close()
+
+
+def _dual_eval(q, p, T, Y, C, d, tau, lam, f32):
+    from funs import _hip
+    R = Y.shape[0]
+    ctx = _hip.Context(q, p, T, R, 10.0)
+    try:
+        ctx.upload_counts(Y)
+        ctx.set_option('cov_mode', 2)
+        ctx.set_option('dual_lowrank', 1)
+        ctx.set_option('dual_f32', 1 if f32 else 0)
+        ctx.set_params(C, d, tau)
+        cost, grad = ctx.dual_costgrad_batch(np.arange(R, dtype=np.int32), lam)
+        assert ctx.info('plan_lowrank') == 1.0
+        return cost, grad
+    finally:
+        ctx.close()
+
+
+def test_mixed_precision_dual_evaluation_vs_numpy():
+    """dual_f32: r x r Cholesky, its inverse and Yt in single precision on the FP32 matrix cores, everything else in FP64.  At 40
+    neurons x 20 latents x 200 bins (n = 4000, dense numpy is seconds) against the plain-numpy unjittered dual: cost 2e-6 rel,
+    gradient 2e-4 of its largest entry (the covariance blocks c_n^T Sigma_t c_n inherit cond(B) * 6e-8); the FP64 engine on the
+    same input keeps 1e-8 / 1e-7."""
+    q, p, T, R = 40, 20, 200, 2
+    _, Ys, _ = orc.synth_dataset(q, p, T, R, seed=33, dOffset=0.0)
+    Y = np.stack(Ys).astype(np.uint8)
+    rng = np.random.default_rng(33)
+    C, d, tau = 0.25 * rng.standard_normal((q, p)), np.log(Y.mean(axis=(0, 2)) + 0.1), 0.15 + 0.3 * rng.random(p)
+    lam = 0.05 + 0.5 * rng.random((R, q * T))
+    c64, g64 = _dual_eval(q, p, T, Y, C, d, tau, lam, False)
+    c32, g32 = _dual_eval(q, p, T, Y, C, d, tau, lam, True)
+    K_big = orc.make_K_big(orc.make_K(tau, T, 10.0))
+    C_big, d_big = orc.make_Cd_big(C, d, T)
+    Kinv_big = np.linalg.inv(K_big)
+    for i in range(R):
+        y = Ys[i].reshape(-1).astype(float)
+        v = C_big @ (lam[i] - y)
+        H = Kinv_big + (C_big * lam[i][None, :]) @ C_big.T
+        Sigma = np.linalg.inv(H)
+        ref_cost = 0.5 * v @ K_big @ v - d_big @ (lam[i] - y) - 0.5 * np.linalg.slogdet(H)[1] + np.sum(lam[i] * (np.log(lam[i]) - 1.0))
+        ref_grad = C_big.T @ (K_big @ v) - d_big + np.log(lam[i]) - 0.5 * np.einsum('im,ij,jm->m', C_big, Sigma, C_big)
+        assert abs(c64[i] - ref_cost) <= 1e-8 * abs(ref_cost) and rel(g64[i], ref_grad) <= 1e-7
+        print('mixed precision: cost rel %.2e, grad rel %.2e' % (abs(c32[i] - ref_cost) / abs(ref_cost), rel(g32[i], ref_grad)))
+        assert abs(c32[i] - ref_cost) <= 2e-6 * abs(ref_cost)
+        assert rel(g32[i], ref_grad) <= 2e-4
+
+
+@pytest.mark.timeout(1800)
+def test_mixed_precision_dual_evaluation_at_config5_dimensions():
+    """BASELINE config 5's dimensions (500 neurons, 20 latents, 1000 bins: n = 20 000, 500 000 dual variables per trial), two
+    trials: the mixed-precision evaluation against the FP64 low-rank engine on the same input (that one is pinned to plain numpy
+    at sizes numpy can invert, above and in test_dual_evaluation_lowrank_engine_wide_latent_state): cost 1e-5 rel, gradient 1e-3 of
+    its largest entry."""
+    import bench
+    q, p, T, R = 500, 20, 1000, 2
+    true, Ys = bench.synth_shard(q, p, T, R, 12, 0)
+    Y = np.stack(Ys)
+    rng = np.random.default_rng(12)
+    tau = np.linspace(0.1, 0.5, p)
+    lam = np.exp(true['C'] @ np.zeros((p, T)) + true['d'][:, None]).reshape(1, -1) * (0.5 + rng.random((R, q * T)))
+    c64, g64 = _dual_eval(q, p, T, Y, true['C'], true['d'], tau, lam, False)
+    c32, g32 = _dual_eval(q, p, T, Y, true['C'], true['d'], tau, lam, True)
+    print('config-5 dims: cost rel %s, grad rel %s' % (np.abs(c32 - c64) / np.abs(c64), [rel(g32[i], g64[i]) for i in range(R)]))
+    assert np.all(np.isfinite(c64)) and np.all(np.isfinite(g32))
+    assert np.max(np.abs(c32 - c64) / np.abs(c64)) <= 1e-5
+    assert max(rel(g32[i], g64[i]) for i in range(R)) <= 1e-3
