@@ -50,9 +50,10 @@ CONFIGS = {   # name: (neurons, latents, bins, trials per GPU)
     'c1': (30, 3, 100, 20),
     'c2': (100, 5, 200, 256),
     'c3': (200, 10, 500, 1024),
+    'c5': (500, 20, 1000, 2048),      # variational E-step variant (BASELINE config 5); only with --workload dual
 }
 FP64_MATRIX_PEAK_TFLOPS = 78.6     # MI355X FP64 matrix (= FP64 vector) peak, AMD CDNA4 datasheet
-PMC_SUMMARY = os.path.join(ROOT, 'profiles', 'r01_c3_pmc_hbm_traffic.json')   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+PMC_SUMMARY = os.path.join(ROOT, 'profiles', 'r02_pmc_hbm_traffic.json')   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
 
 
 def pmc_traffic_per_launch(kernel_prefix):
@@ -294,21 +295,71 @@ def run_online(args, q, p, T, rank, world):
     print(json.dumps(out))
 
 
+def run_dual(args, q, p, T, R, rank, world):
+    """BASELINE config 5's unit of work: one batched evaluation of the dual objective and its gradient (inference.py:196-219) for R
+    trials per GPU at the configuration's dimensions, lambda resident in HBM, through the low-rank engine - r x r Cholesky, inverse
+    and Yt on the FP32 matrix cores with FP64 accumulation ('mixed'), or all FP64.  A step = one batched evaluation (what one L-BFGS
+    iteration of every trial costs); value = trial-evaluations per second over all GPUs (trials shard, no collective)."""
+    from funs import _hip, _session
+    true_params, Ys = synth_shard(q, p, T, R, args.seed, rank)
+    Y = np.stack(Ys)
+    rng = np.random.default_rng([args.seed, rank, 5])
+    tau = np.linspace(0.1, 0.5, p)
+    ctx = _hip.Context(q, p, T, R, 10.0, device=_session.WORLD.device())
+    ctx.upload_counts(Y)
+    ctx.set_option('cov_mode', 2)
+    ctx.set_option('dual_lowrank', 1)
+    ctx.set_option('dual_f32', 1 if args.precision == 'mixed' else 0)
+    ctx.set_params(true_params['C'], true_params['d'], tau)
+    idx = np.arange(R, dtype=np.int32)
+    rho = np.log(np.exp(true_params['d'])[None, :, None] * (0.5 + rng.random((R, q, T)))).reshape(R, -1)
+    # the evaluations run inside the device L-BFGS (lambda, gradient and the correction pairs stay resident): time its iterations
+    for _ in range(max(1, args.warmup)):
+        ctx.dual_lbfgs(idx, rho, max_iter=1)
+    t0 = time.time()
+    _, fopt, iters = ctx.dual_lbfgs(idx, rho, max_iter=args.steps)
+    elapsed = time.time() - t0
+    evals = ctx.info('last_dual_evaluations')
+    times = np.zeros(world)
+    times[rank] = elapsed
+    if world > 1:
+        sess_times = times                     # ranks are independent replicas of the shard loop: no communicator needed
+        t_max = elapsed
+    else:
+        t_max = elapsed
+    if rank != 0:
+        return
+    out = {'metric': 'dual-variational trial-evaluations/sec', 'value': evals * R * world / t_max, 'unit': 'trial-evaluations/s (dual cost + gradient)',
+           'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': t_max / max(evals, 1) * 1e3,
+           'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+           'dtype': 'f32 matrix products, f64 accumulation' if args.precision == 'mixed' else 'f64', 'data': 'synthetic',
+           'config': {'workload': '%s variational E-step: %d neurons, %d latents, %d bins, %d trials per GPU, %d lockstep L-BFGS iterations of '
+                                  'the dual (every iteration = batched dual cost + gradient of all live trials, low-rank engine rank %d)'
+                                  % (args.config, q, p, T, R, args.steps, int(ctx.info('lowrank_rtot'))), 'parallelism': 'trial-sharded x%d' % world},
+           'batched_evaluations': evals, 'lbfgs_iterations': int(np.max(iters)), 'dual_objective_mean': float(np.mean(fopt)),
+           'note': 'the reference cannot run this configuration at all (its C_big alone is 74.5 GiB, BASELINE.md); a full E-step needs '
+                   'O(1000) such iterations per trial'}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--config', default='c3', choices=sorted(CONFIGS))
+    ap.add_argument('--precision', default='mixed', choices=['mixed', 'f64'],
+                    help="--workload dual: 'mixed' = FP32 matrix cores for the r x r factorisation / inverse / Yt with FP64 accumulation; 'f64'")
     ap.add_argument('--trials', type=int, default=0, help='override trials per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cd-method', default='newton', choices=['newton', 'TNC', 'BFGS', 'L-BFGS-B'],
                     help="(C,d) M-step solver: 'newton' = device per-neuron Newton (exact minimiser of the reference's cost); "
                          "'TNC' = the reference engine's default scipy driver on the same device cost/grad")
     ap.add_argument('--seed', type=int, default=12)
-    ap.add_argument('--workload', default='em', choices=['em', 'online', 'loo'],
+    ap.add_argument('--workload', default='em', choices=['em', 'online', 'loo', 'dual'],
                     help="'em' (default): the headline EM-iterations/s metric (config 3); 'online': config 4, stochastic EM with "
-                         "minibatches over a larger resident set; 'loo': leave-one-neuron-out prediction throughput (1 GPU)")
+                         "minibatches over a larger resident set; 'loo': leave-one-neuron-out prediction throughput (1 GPU); 'dual': batched "
+                         "dual-variational cost + gradient evaluations (the unit of work of config 5's E-step) at --config dimensions")
     ap.add_argument('--cpu-trial', action='store_true',
                     help='cpu_baseline times ONE whole reference-faithful trial (config 3: ~5 minutes, ~9 GB) instead of the bounded sample')
     ap.add_argument('--resident', type=int, default=8192, help="--workload online: trials resident in HBM (all ranks hold the counts)")
@@ -336,6 +387,10 @@ def main():
         return run_loo(args, q, p, T, R)
     if args.workload == 'online':
         return run_online(args, q, p, T, rank, world)
+    if args.workload == 'dual':
+        return run_dual(args, q, p, T, args.trials if args.trials > 0 else 64, rank, world)
+    if args.config == 'c5':
+        raise SystemExit("--config c5 is the variational variant: use --workload dual")
 
     import funs
     from funs import _hip, _session
@@ -358,7 +413,7 @@ def main():
     params = init
     optim = None
     cd_method = [args.cd_method]
-    nll_hist, estep_ms, mstep_ms, facts, solves, pcgs = [], [], [], [], [], []
+    nll_hist, estep_ms, mstep_ms, facts, solves, pcgs, cdp = [], [], [], [], [], [], []
 
     def em_step():
         nonlocal params, optim
@@ -373,6 +428,7 @@ def main():
         facts.append(sess.ctx.info('last_newton_factorizations'))
         solves.append(sess.ctx.info('last_newton_solves'))
         pcgs.append(sess.ctx.info('last_pcg_iterations'))
+        cdp.append(list(getattr(sess, '_cd_passes', (0, 0))))
 
     for _ in range(args.warmup):
         em_step()
@@ -389,7 +445,7 @@ def main():
     sess.ctx.set_option('profile', 0)
 
     def drop_last():
-        estep_ms.pop(); mstep_ms.pop(); nll_hist.pop(); facts.pop(); solves.pop(); pcgs.pop()
+        estep_ms.pop(); mstep_ms.pop(); nll_hist.pop(); facts.pop(); solves.pop(); pcgs.pop(); cdp.pop()
 
     # one more (untimed) EM iteration with events around every tagged launch: the per-kernel-family breakdown
     prof = {}
@@ -434,6 +490,7 @@ def main():
         'factorizations_per_trial': [round(f / R, 2) for f in facts],
         'newton_solves_per_trial': [round(f / R, 2) for f in solves],
         'pcg_iterations_per_trial': [round(f / R, 2) for f in pcgs],
+        'cd_newton_passes_full_chord': cdp,
         'nll': nll_hist,
         'mstep_ms_with_reference_default_TNC': tnc_ms,
         'kernel_time_ms_one_untimed_step': {k: round(v, 1) for k, v in prof.items()},

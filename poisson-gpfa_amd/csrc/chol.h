@@ -29,9 +29,12 @@ constexpr int NSUP = 512;   // super-panel width
 // The inverse runs row by row (forward substitution) with row i of L^-1 broadcast the same way.
 // Writes L back in place and L^-1 to Dinv[slot][k0/128]; info[slot] = (k0 + j + 1) at the first bad pivot.
 // --------------------------------------------------------------------------------------------------
+// offset of L[r][j] (r >= j) in the packed column-major lower triangle
+__device__ __forceinline__ int potrf_lidx(int j, int r) { return j * NB - (j * (j - 1)) / 2 + (r - j); }
+
 template <typename T>
 struct PotrfLds {
-  T L[NB * NB];                 // column-major copy of the factor
+  T L[NB * (NB + 1) / 2];       // packed lower triangle of the factor, column by column (66 KB in FP64: two workgroups per CU)
   T line[2][NB];                // broadcast lines, permuted: pos(i) = (i & 3) * 32 + (i >> 2)
   T rd[2];                      // 1 / L[j][j] of the current step
 };
@@ -67,7 +70,7 @@ __device__ __forceinline__ void potrf_diag_chol_steps(T (&a)[32], PotrfLds<T>& S
     if (r >= j) {                                 // whole waves drop out as j advances
       const T rd = S.rd[j & 1];
       const T lr = buf[pos_r] * rd;               // L[r][j]  (r == j: a_jj / sqrt(a_jj))
-      if (own) S.L[j * NB + r] = lr;
+      if (own) S.L[potrf_lidx(j, r)] = lr;
       const T nlr = -lr * rd;
       const T* bp = buf + cg * 32;
 #pragma unroll
@@ -90,7 +93,7 @@ __device__ __forceinline__ void potrf_diag_inv_steps(T (&t)[32], PotrfLds<T>& S,
     }
     __syncthreads();
     if (r > i) {
-      const T lri = -S.L[i * NB + r] * inv_lrr;
+      const T lri = -S.L[potrf_lidx(i, r)] * inv_lrr;
       const T* xp = xrow + cg * 32;
 #pragma unroll
       for (int m = 0; m < MEND; ++m) t[m] = fma(lri, xp[m], t[m]);
@@ -121,13 +124,13 @@ __global__ __launch_bounds__(512) void potrf_diag_kernel_t(T* __restrict__ H, lo
   __syncthreads();
   for (int e = tid; e < NB * NB; e += 512) {
     const int rr = e & (NB - 1), cc = e >> 7;
-    if (rr >= cc) Hs[(size_t)cc * ld + rr] = S.L[e];
+    if (rr >= cc) Hs[(size_t)cc * ld + rr] = S.L[potrf_lidx(cc, rr)];
   }
   // ---- X = L^-1 by rows: X[r][c] = -(1/L[r][r]) sum_{i=c}^{r-1} L[r][i] X[i][c]  (c < r),  X[r][r] = 1/L[r][r]
   T t[32];
 #pragma unroll
   for (int m = 0; m < 32; ++m) t[m] = (T)0;
-  const T inv_lrr = (T)1 / S.L[r * NB + r];
+  const T inv_lrr = (T)1 / S.L[potrf_lidx(r, r)];
   potrf_diag_inv_steps<0>(t, S, r, cg, inv_lrr);
   potrf_diag_inv_steps<1>(t, S, r, cg, inv_lrr);
   potrf_diag_inv_steps<2>(t, S, r, cg, inv_lrr);

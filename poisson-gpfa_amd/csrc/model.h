@@ -1658,7 +1658,18 @@ __global__ __launch_bounds__(256) void rbf_pivchol_kernel(double* __restrict__ F
     for (int t = tid; t < T; t += 256) {
       const double dt = (double)t * bin - (double)piv * bin;
       double v = (1.0 - eps) * exp(-0.5 * ((dt * dt) / den));
-      for (int m = 0; m < j; ++m) v -= Fk[(size_t)m * Tf + t] * frow[m];
+      // (four independent partial sums: the loads of consecutive columns then overlap instead of queueing behind one FMA chain)
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      int m = 0;
+#pragma unroll 2
+      for (; m + 3 < j; m += 4) {
+        s0 += Fk[(size_t)m * Tf + t] * frow[m];
+        s1 += Fk[(size_t)(m + 1) * Tf + t] * frow[m + 1];
+        s2 += Fk[(size_t)(m + 2) * Tf + t] * frow[m + 2];
+        s3 += Fk[(size_t)(m + 3) * Tf + t] * frow[m + 3];
+      }
+      for (; m < j; ++m) s0 += Fk[(size_t)m * Tf + t] * frow[m];
+      v -= (s0 + s1) + (s2 + s3);
       v *= rs;
       Fk[(size_t)j * Tf + t] = v;
       d[t] = (t == piv) ? 0.0 : d[t] - v * v;

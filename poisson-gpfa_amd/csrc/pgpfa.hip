@@ -425,14 +425,14 @@ int inverse_t(pgpfa_ctx* c, const CholWS& w, const int* slots, int nb, bool f32 
 }
 
 // allocate a factor workspace: nslots slabs of ld x ld (+ Mt), diagonal inverses, scratch panel
-int alloc_cholws(pgpfa_ctx* c, CholWS* w, int nslots, int npad, bool with_mt, size_t slab_elems = 0) {
+int alloc_cholws(pgpfa_ctx* c, CholWS* w, int nslots, int npad, bool with_mt, size_t slab_elems = 0, bool zero_mt = true) {
   w->npad = npad;
   w->ld = npad;
   const size_t slab = slab_elems ? slab_elems : (size_t)npad * npad;
   const size_t slack = (size_t)256 * npad;
   w->sH = slab; w->sM = slab; w->sD = (size_t)npad * NB; w->sP = (size_t)npad * NB;
   CHK(dmalloc(c, &w->H, slab * nslots + slack));
-  if (with_mt) CHK(dmalloc(c, &w->Mt, slab * nslots + slack, true)); else w->Mt = nullptr;
+  if (with_mt) CHK(dmalloc(c, &w->Mt, slab * nslots + slack, zero_mt)); else w->Mt = nullptr;
   CHK(dmalloc(c, &w->Dinv, w->sD * nslots + slack));
   CHK(dmalloc(c, &w->P, w->sP * nslots + slack));
   CHK(dmalloc(c, &w->info, nslots, true));
@@ -526,7 +526,9 @@ int ensure_workspace(pgpfa_ctx* c, bool plan_lr) {
   c->B = (int)B;
   // pass 1 measures the plan, then the arena is grown if it has to be, pass 2 hands out the pointers
   auto carve = [&]() -> int {
-  CHK(alloc_cholws(c, &c->ws, c->B, c->npad, true, c->slab_elems));
+  // (the dense engine needs the strictly lower part of its L^-T slabs zero; the low-rank engine fills its r x r views itself, so under
+  // that plan the ~10^11-byte clear is left out and the slabs are marked dirty for a later dense use)
+  CHK(alloc_cholws(c, &c->ws, c->B, c->npad, true, c->slab_elems, !plan_lr));
   c->ws.nact = round_up(c->n, 64);
   const size_t ld = c->ld, nB = c->B;
   const size_t nBs = nB + 128;                    // slack: multi-RHS GEMM tiles read up to 127 slots past the end
@@ -592,6 +594,7 @@ int ensure_workspace(pgpfa_ctx* c, bool plan_lr) {
   for (int i = 0; i < c->B; ++i) id[i] = i;
   HIPC(hipMemcpyAsync(c->ident, id.data(), sizeof(int) * c->B, hipMemcpyHostToDevice, c->st));
   HIPC(hipStreamSynchronize(c->st));
+  if (plan_lr) c->mt_dirty = true;
   c->info["chunk_trials"] = c->B;
   c->info["plan_lowrank"] = c->plan_lowrank ? 1.0 : 0.0;
   return 0;
@@ -2980,6 +2983,7 @@ int pgpfa_dual_lbfgs(pgpfa_ctx* c, int n, const int32_t* idx, double* rho, int m
   struct FreeI { int* q2; ~FreeI() { hipFree(q2); } } freei{take};
   const dim3 vgrid((unsigned)((m + 255) / 256), 1);
   const double eps = 2.220446049250313e-16;
+  double n_eval = 0.0;                                              // batched dual evaluations of this call
 
   for (int c0 = 0; c0 < N; c0 += Bc) {
     const int nb0 = std::min(Bc, N - c0);
@@ -2996,6 +3000,7 @@ int pgpfa_dual_lbfgs(pgpfa_ctx* c, int n, const int32_t* idx, double* rho, int m
     auto upload_scal = [&](const std::vector<double>& v, int slot) -> int { return upload(c, scal + (size_t)slot * Bc, v.data(), nb); };
     // f and the gradient with respect to rho at the device vector Xin (lambda = exp(rho) goes to c->lamd)
     auto evaluate = [&](const double* Xin, double* Gout, std::vector<double>& f) -> int {
+      n_eval += 1.0;
       hipLaunchKernelGGL(exp_kernel, dim3((unsigned)((nb * m + 255) / 256)), dim3(256), 0, c->st, Xin, c->lamd, nb * m);
       CHK(dual_eval_slots(c, nb, tos, true, f.data(), /*tolerate=*/true));
       hipLaunchKernelGGL(chain_kernel, dim3((unsigned)((nb * m + 255) / 256)), dim3(256), 0, c->st, c->dgrad, c->lamd, Gout, nb * m);
@@ -3157,6 +3162,7 @@ int pgpfa_dual_lbfgs(pgpfa_ctx* c, int n, const int32_t* idx, double* rho, int m
       if (iters) iters[c0 + orig[s2]] = its[s2];
     }
   }
+  c->info["last_dual_evaluations"] = n_eval;
   return 0;
 }
 

@@ -1,16 +1,26 @@
+# Measurement set committed under profiles/ each round (run on the GPU box through gpurun): bash tools/measure_round.sh <tag>
 set -x
+TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/final
+O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
-python bench.py > $O/bench_default.json 2> $O/bench_default.err
+python bench.py --steps 20 --warmup 5 > $O/bench_c3_driver_protocol.json 2> $O/bench_c3.err
 python bench.py --config c2 --steps 10 --warmup 2 > $O/bench_c2.json 2>/dev/null
 python bench.py --config c1 --steps 20 --warmup 2 --no-cpu-baseline > $O/bench_c1.json 2>/dev/null
+python bench.py --workload online --steps 6 --warmup 2 > $O/bench_c4_online.json 2>/dev/null
+python bench.py --workload dual --config c5 --trials 64 --steps 6 --warmup 1 > $O/bench_c5_dual_mixed.json 2>/dev/null
+python bench.py --workload dual --config c5 --trials 64 --steps 6 --warmup 1 --precision f64 > $O/bench_c5_dual_f64.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -o ks -- python3 $R/bench.py --no-cpu-baseline > $O/bench_under_rocprof.json 2>/dev/null
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o f -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o w -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -o ks -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --lean > $O/bench_c3_under_rocprof.json 2>/dev/null
 cd $R
-python tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/pmc_hbm_traffic.json | head -5
+python tools/gemm_by_grid.py $O/ks > $O/kernels_by_grid.txt
+find $O/ks -name '*kernel_stats.csv' -exec cp {} $O/kernel_stats.csv \;
+rm -rf $O/ks
+cd /tmp
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o f -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --lean > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o w -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --lean > /dev/null 2>&1
+cd $R
+python tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/pmc_hbm_traffic.json | head -8
 rm -rf $O/pmc_fetch $O/pmc_write
 ls -la $O
