@@ -597,7 +597,7 @@ __global__ void post_vsm_kernel(const TIN* __restrict__ Mt, long long sM, int ld
                                 double* __restrict__ vsm, const int* __restrict__ slots, const int* __restrict__ trial_of_slot,
                                 int full_range) {
   constexpr int NK = (PMAX > 16) ? 2 : 1;
-  constexpr int VIC = (PMAX <= 8) ? 16 : (PMAX <= 16 ? 8 : 4);   // 64 KB of LDS at most
+  constexpr int VIC = (PMAX <= 8) ? 16 : (PMAX <= 16 ? 8 : 4);   // 64 KB of LDS at most (49 KB at PMAX = 24)
   __shared__ double A[VIC][PMAX][64];
   const int tx = threadIdx.x, ty = threadIdx.y, KY = blockDim.y;
   const int slot = slots[blockIdx.y];
@@ -746,10 +746,13 @@ struct CdArgs {
   int dbg;               // timing experiments only (option cd_debug): bit 0 no exp, bit 1 no second product, bit 2 no first product, bit 3 no staging
 };
 constexpr int CD_KY = 8;
+// waves per workgroup of mstep_cd_kernel: 8 up to 16 latents (128-register budget), 4 beyond (c, acc, u of 20+ doubles each need the 256 budget)
+template <int PW> struct CdKy { static constexpr int v = (PW <= 16) ? 8 : 4; };
 template <int PW> struct CdTile { static constexpr int TT = (PW <= 10) ? 64 : (PW <= 16) ? 32 : (PW <= 20) ? 16 : 8; };
 
 template <int PW>
-__global__ __launch_bounds__(64 * CD_KY) void mstep_cd_kernel(CdArgs a) {
+__global__ __launch_bounds__(64 * CdKy<PW>::v) void mstep_cd_kernel(CdArgs a) {
+  constexpr int KYW = CdKy<PW>::v;
   constexpr int TT = CdTile<PW>::TT;
   constexpr int YS = TT + 4;                      // byte row stride of the count tile (bank spread)
   __shared__ __attribute__((aligned(16))) double Vt[TT][PW * PW];
@@ -781,21 +784,21 @@ __global__ __launch_bounds__(64 * CD_KY) void mstep_cd_kernel(CdArgs a) {
     const double* vsm = a.vsm + (r * T + t0) * p * p;
     const uint8_t* Y = a.Y + r * q * T;
     __syncthreads();                               // previous tile fully consumed
-    for (int e = tid; e < TT * PW * PW; e += 64 * CD_KY) {
+    for (int e = tid; e < TT * PW * PW; e += 64 * KYW) {
       const int t = e / (PW * PW), kl = e - t * (PW * PW);
       const int k = kl / PW, l = kl - k * PW;
       Vt[t][kl] = (t < tn && k < p && l < p) ? vsm[(size_t)t * p * p + k * p + l] : 0.0;
     }
-    for (int e = tid; e < PW * TT; e += 64 * CD_KY) {
+    for (int e = tid; e < PW * TT; e += 64 * KYW) {
       const int k = e / TT, t = e - k * TT;
       Mt[k][t] = (k < p && t < tn) ? mean[(size_t)k * T + t0 + t] : 0.0;
     }
-    for (int e = tid; e < 64 * TT; e += 64 * CD_KY) {
+    for (int e = tid; e < 64 * TT; e += 64 * KYW) {
       const int nn = e / TT, t = e - nn * TT;
       Yt[nn * YS + t] = (n0 + nn < q && t < tn) ? Y[(size_t)(n0 + nn) * T + t0 + t] : 0;
     }
     __syncthreads();
-    for (int t = ty; t < tn; t += CD_KY) {
+    for (int t = ty; t < tn; t += KYW) {
       // u = V_t c from the lower triangle only (V_t is symmetric): p(p+1)/2 LDS reads instead of p^2
       double u[PW];
       double hh = dn, rho = 0.0;
@@ -828,7 +831,7 @@ __global__ __launch_bounds__(64 * CD_KY) void mstep_cd_kernel(CdArgs a) {
     }
   }
   // fixed-order combine over the KY waves of the block, one output row at a time
-  __shared__ double red[CD_KY][64];
+  __shared__ double red[KYW][64];
   double* part = a.part + (size_t)blockIdx.y * (p + 2) * q;
 #pragma unroll
   for (int k = 0; k < PW + 2; ++k) {
@@ -836,10 +839,10 @@ __global__ __launch_bounds__(64 * CD_KY) void mstep_cd_kernel(CdArgs a) {
     __syncthreads();
     red[ty][lane] = v;
     __syncthreads();
-    if (ty == (k % CD_KY) && live && (k >= PW || k < p)) {
+    if (ty == (k % KYW) && live && (k >= PW || k < p)) {
       double s = 0.0;
 #pragma unroll
-      for (int w = 0; w < CD_KY; ++w) s += red[w][lane];
+      for (int w = 0; w < KYW; ++w) s += red[w][lane];
       const int row = (k < PW) ? k : p + (k - PW);
       part[(size_t)row * q + n] = s;
     }

@@ -645,6 +645,7 @@ void dispatch_pmax(int p, F&& f) {
   if (p <= 4) f(std::integral_constant<int, 4>{});
   else if (p <= 8) f(std::integral_constant<int, 8>{});
   else if (p <= 16) f(std::integral_constant<int, 16>{});
+  else if (p <= 24) f(std::integral_constant<int, 24>{});      // (config 5 has 20: the 32-wide instantiations spill)
   else f(std::integral_constant<int, 32>{});
 }
 
@@ -2347,7 +2348,7 @@ static int cd_sweep(pgpfa_ctx* c) {
   const int nby = std::max(1, std::min(a.ntr * 4, std::max(64, 1024 / nchunk)));
   prof_begin(c, TAG_CD, flops);
   dispatch_pw(p, [&](auto pw) {
-    hipLaunchKernelGGL(mstep_cd_kernel<decltype(pw)::value>, dim3((q + 63) / 64, nby), dim3(64, CD_KY), 0, c->st, a);
+    hipLaunchKernelGGL(mstep_cd_kernel<decltype(pw)::value>, dim3((q + 63) / 64, nby), dim3(64, CdKy<decltype(pw)::value>::v), 0, c->st, a);
   });
   prof_end(c);
   hipLaunchKernelGGL(reduce_parts_kernel, dim3((len + 31) / 32), dim3(256), 0, c->st, c->cdpart, nby, len, c->cdout);
