@@ -365,6 +365,7 @@ def main():
     ap.add_argument('--resident', type=int, default=8192, help="--workload online: trials resident in HBM (all ranks hold the counts)")
     ap.add_argument('--batch', type=int, default=1024, help="--workload online: minibatch size (split over the ranks)")
     ap.add_argument('--lean', action='store_true', help='skip the extra untimed iterations (per-family event breakdown, TNC M-step, MFMA peak probe): for runs under rocprofv3')
+    ap.add_argument('--opts', default='', help='context options key=value,... (experiments)')
     ap.add_argument('--dry-run', action='store_true', help='launcher self-test: every rank reports its environment and exits (no GPU work)')
     args = ap.parse_args()
 
@@ -398,6 +399,8 @@ def main():
     true_params, Ys = synth_shard(q, p, T, R, args.seed, rank)
     exp = Shard(Ys, bin_ms)
     sess, _ = _session.session_for(exp, p)
+    for kv in filter(None, args.opts.split(',')):
+        sess.ctx.set_option(kv.split('=')[0], float(kv.split('=')[1]))
     # Poisson-PCA initialiser on rank 0's shard (reference util.py:505-558), shared with every rank
     np.random.seed(0)
     init = funs.util.initializeParams(p, q, exp)
