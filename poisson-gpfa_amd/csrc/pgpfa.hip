@@ -140,7 +140,7 @@ struct pgpfa_ctx {
   int* h_pcg = nullptr; int* d_hpcg = nullptr;   // host-mapped copy {stop, iterations}: the host peeks, never waits
   float* W32 = nullptr;                          // packed single-precision curvature triangles of the chunk's slots (PCG matvec)
   double* sc_part2 = nullptr;                    // per (slot, tile) partial sums r.z, r.r
-  bool pcg_fused = true, pcg_w32 = true;
+  int pcg_fused = 1; bool pcg_w32 = true;        // pcg_fused: 0 off, 1 when the chunk is large enough, 2 always (tests)
   double *sc_rz = nullptr, *sc_pq = nullptr, *sc_rr = nullptr, *sc_rr0 = nullptr, *sc_pack = nullptr;
   // low-rank covariance engine
   double* Flr = nullptr;                          // [p][Tp x Tp] pivoted-Cholesky factors of the RBF part
@@ -967,7 +967,7 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
   else if (k == "use_mfma") c->mfma = (v != 0.0);
   else if (k == "cd_mfma") c->cd_mfma = (v != 0.0);
   else if (k == "cd_debug") c->cd_debug = (int)v;
-  else if (k == "pcg_fused") c->pcg_fused = (v != 0.0);
+  else if (k == "pcg_fused") c->pcg_fused = (int)v;
   else if (k == "pcg_w32") c->pcg_w32 = (v != 0.0);
   else if (k == "chord") c->chord = (v != 0.0);
   else if (k == "shared_pcg") c->shared_pcg = (v != 0.0);
@@ -1741,7 +1741,7 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
         hipLaunchKernelGGL(pcg_init_kernel, dim3((c->npad + 255) / 256, na), dim3(256), 0, c->st, c->Gt, c->Rv, c->Dl, ld, nvec, c->npad, c->list_a);
         // (small chunks are launch-latency bound: there the extra packing / check launches of the host-free form cost more than
         // the round trips they remove - measured at config 2: 8.6 vs 8.0 ms per E-step)
-        const bool fused = c->pcg_fused && c->plan_lowrank && p <= 16 && c->h_pcg != nullptr && (double)nb * c->n >= 1.0e6;
+        const bool fused = c->pcg_fused && c->plan_lowrank && p <= 16 && c->h_pcg != nullptr && (c->pcg_fused == 2 || (double)nb * c->n >= 1.0e6);
         int done_inner = 0;
         if (fused) {
           // ---- inner solve without host round trips (pcg.h): the stopping test runs on the device, iterations are enqueued

@@ -561,3 +561,30 @@ def test_mixed_precision_dual_evaluation_at_config5_dimensions():
     assert np.all(np.isfinite(c64)) and np.all(np.isfinite(g32))
     assert np.max(np.abs(c32 - c64) / np.abs(c64)) <= 1e-5
     assert max(rel(g32[i], g64[i]) for i in range(R)) <= 1e-3
+
+
+@pytest.mark.parametrize('w32', [1, 0])
+def test_host_free_pcg_path_reaches_the_same_modes(c1, w32):
+    """The inner PCG without host round trips (device stop flag, fused per-bin passes; with and without the packed single-precision
+    curvature in the matvec) is only chosen by itself for large chunks: forced on at config-1 size it must land on the polished
+    modes of the reference (1e-8) with the covariance blocks of the oracle, like the round-trip form."""
+    from funs import _hip
+    g = load_golden('c1_laplace.npz')
+    ctx = _hip.Context(30, 3, 100, 20, c1['binSize'])
+    try:
+        ctx.upload_counts(c1['Y'])
+        ctx.set_option('cov_mode', 2)
+        ctx.set_option('pcg_fused', 2)
+        ctx.set_option('pcg_w32', w32)
+        ctx.set_params(c1['init_C'], c1['init_d'], c1['init_tau'])
+        obj, iters, status = ctx.estep_laplace()
+        assert np.all(status == 0) and ctx.info('plan_lowrank') == 1.0 and ctx.info('last_pcg_iterations') > 0
+        assert np.max(np.abs(ctx.post_mean().reshape(20, -1) - g['polished'])) <= 1e-8
+        res, nll, _ = orc.laplace(c1['Ys'], c1['init'], c1['binSize'], mode='exact', return_cov=False)
+        assert abs(-obj / 20 - nll) <= 1e-9 * abs(nll)
+        assert rel(ctx.post_vsm()[:4], np.stack(res['post_vsm'][:4])) <= 1e-8
+        # warm restart: a handful of iterations, same modes
+        obj2, _, st2 = ctx.estep_laplace(warm_start=True)
+        assert np.all(st2 == 0) and abs(obj2 - obj) <= 1e-10 * abs(obj)
+    finally:
+        ctx.close()
