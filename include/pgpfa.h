@@ -50,7 +50,9 @@ int pgpfa_destroy(pgpfa_ctx* ctx);
  * the inner PCG iterations of one outer Newton iteration), "pcg_eta0" (1e-2: relative residual of the first inner solve;
  * later ones adapt to the predicted error), "splitk_target" (1280: thin GEMMs are cut along k until about this many
  * workgroups are in flight),
- * "pcg_outer_max" (12), "cov_mode" (0 auto, 1 dense, 2 low-rank covariance engine), "lowrank_tol" (1e-13),
+ * "pcg_outer_max" (12), "cov_mode" (0 auto, 1 dense, 2 low-rank covariance engine), "lowrank_tol" (1e-10: stopping residual of the pivoted Cholesky behind the low-rank form K = eps I + F F^T; the covariance blocks
+ * come out accurate to ~2x this value - measured against the reference at config 3 - the modes and the objective do not depend on it;
+ * 1e-13 makes the form exact to rounding at ~10 % more rank),
  * "keep_trial_vsmgp" (0: the low-rank engine accumulates sum_r post_vsmGP_r for the tau M-step and rebuilds
  * per-trial T x T blocks only when pgpfa_get_post_vsmgp asks for them; 1: store them in every E-step),
  * "dual_lowrank" (0; 1: the dual-variational entry points may use the low-rank engine when it pays - log det through

@@ -152,7 +152,7 @@ struct pgpfa_ctx {
   std::vector<int> rk, roff;                      // ranks padded to 16, offsets
   int rtot = 0, rpad = 0;
   int cov_mode = 0;                               // 0 auto, 1 dense, 2 low-rank
-  double lr_tol = 1e-13;
+  double lr_tol = 1e-10;
   bool plan_lowrank = false;                      // current workspace plan
   size_t slab_elems = 0, ws_mark = 0;
   // the chunk workspace lives in ONE device allocation that re-plans re-partition (hipFree + hipMalloc of ~10^11 bytes
