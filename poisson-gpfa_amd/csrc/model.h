@@ -175,7 +175,7 @@ struct PoissonArgs {
 constexpr int PNC = 32;
 
 template <int PMAX>
-__global__ void poisson_pass_kernel(PoissonArgs a) {
+__global__ __launch_bounds__(PMAX == 20 ? 640 : 1024) void poisson_pass_kernel(PoissonArgs a) {
   constexpr int NK = (PMAX > 16) ? 2 : 1;
   __shared__ double E[PNC][64];
   __shared__ double Rr[PNC][64];
@@ -589,11 +589,11 @@ __global__ void dense_h_kernel(double* __restrict__ out, int n, int T, int Tp, i
 
 // --------------------------------------------------------------------------------------------------
 // post_vsm (inference.py:169-172): vsm[t][k][l] = Sigma[(k,t),(l,t)] = sum_i Mt[(k,t), i] Mt[(l,t), i]
-// with Mt = L^-T (upper triangular).  Block = 64 bins x KY latents, columns i streamed in chunks of 16
-// through LDS; output indexed by trial.
+// with Mt = L^-T (upper triangular).  Block = 64 bins x KY latents (KY = post_vsm_rows(p) of pgpfa.hip; two rows per thread
+// beyond 16 latents), columns i streamed in chunks through LDS; output indexed by trial.
 // --------------------------------------------------------------------------------------------------
 template <int PMAX, typename TIN = double>
-__global__ void post_vsm_kernel(const TIN* __restrict__ Mt, long long sM, int ld, int npad, int T, int p,
+__global__ __launch_bounds__(PMAX == 24 ? 768 : 1024) void post_vsm_kernel(const TIN* __restrict__ Mt, long long sM, int ld, int npad, int T, int p,
                                 double* __restrict__ vsm, const int* __restrict__ slots, const int* __restrict__ trial_of_slot,
                                 int full_range) {
   constexpr int NK = (PMAX > 16) ? 2 : 1;
@@ -2048,6 +2048,10 @@ __global__ __launch_bounds__(256) void mix_vsm_kernel(double* __restrict__ Yt, l
   if (live) {
     double* y = Yt + (size_t)slot * sY + t0 + lane;
     for (int b = wave; b < rpad; b += 4) {
+      // Beyond 10 latents the LDS reads of G stay inside the trip: hoisted out of the loop (what the compiler does by itself) they
+      // take 2 PW^2 registers, i.e. scratch.  Up to 10 the hoisted form is kept - the pass runs at the rate of the slab's
+      // read + write either way (measured: more waves per SIMD or more loads in flight per wave change nothing).
+      if constexpr (PW > 10) asm volatile("" ::: "memory");
       double v[PW], m[PW];
 #pragma unroll
       for (int k = 0; k < PW; ++k) v[k] = (k < p && b >= c0[k]) ? y[(size_t)b * ldy + (size_t)k * T] : 0.0;

@@ -142,30 +142,59 @@ __global__ __launch_bounds__(256) void pcg_xr_apply_kernel(const double* __restr
   const int t = t0 + lane;
   const double* g = Gs + lane * LD;
   const int s_end = min(na, (int)(blockIdx.y + 1) * PCG_SLOTS);
-  for (int si = blockIdx.y * PCG_SLOTS + wave; si < s_end; si += 4) {
-    const size_t sl = list[si];
-    double d = 0.0;
-    for (int i = 0; i < ntile; ++i) d += pqpart[sl * ntile + i];
-    const double alpha = (d > 0.0) ? rz[sl] / d : 0.0;
-    const size_t base = sl * sV + t;
-    double v[PW];
+  // U slots per trip: the loads of all of them are issued before the first use (the wave is latency-bound otherwise), and the
+  // block's LDS copy of Gb is read once for the U matrix-vector products.  A trip past the end of the list re-reads its
+  // first slot and stores nothing.
+  constexpr int U = PW <= 10 ? 2 : 1;
+  for (int si0 = blockIdx.y * PCG_SLOTS + wave; si0 < s_end; si0 += 4 * U) {
+    asm volatile("" ::: "memory");                        // keep the LDS reads of Gb inside the trip (hoisted, they cost 2 PW^2 registers)
+    size_t base[U];
+    double alpha[U];
+    bool ok[U];
 #pragma unroll
-    for (int k = 0; k < PW; ++k) {
-      v[k] = 0.0;
-      if (k < p) {
-        const size_t o = base + (size_t)k * T;
-        X[o] += alpha * P[o];
-        const double rn = R[o] - alpha * Q[o];
-        R[o] = rn;
-        v[k] = rn;
-      }
+    for (int u = 0; u < U; ++u) {
+      const int si = si0 + 4 * u;
+      ok[u] = si < s_end;
+      const size_t sl = list[ok[u] ? si : si0];
+      base[u] = sl * sV + t;
+      double d = 0.0;
+      for (int i = 0; i < ntile; ++i) d += pqpart[sl * ntile + i];
+      alpha[u] = (d > 0.0) ? rz[sl] / d : 0.0;
     }
+    double xv[U][PW], pv[U][PW], rv[U][PW], qv[U][PW];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int k = 0; k < PW; ++k) {
+        const size_t o = base[u] + (size_t)(k < p ? k : 0) * T;
+        xv[u][k] = X[o]; pv[u][k] = P[o]; rv[u][k] = R[o]; qv[u][k] = Q[o];
+      }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int k = 0; k < PW; ++k) {
+        const double rn = rv[u][k] - alpha[u] * qv[u][k];
+        rv[u][k] = (k < p) ? rn : 0.0;
+        if (k < p && ok[u]) {
+          const size_t o = base[u] + (size_t)k * T;
+          X[o] = xv[u][k] + alpha[u] * pv[u][k];
+          R[o] = rn;
+        }
+      }
 #pragma unroll
     for (int k = 0; k < PW; ++k) {
-      double acc = 0.0;
+      double acc[U];
 #pragma unroll
-      for (int kk = 0; kk < PW; ++kk) acc += g[k * PW + kk] * v[kk];
-      if (k < p) Xt[base + (size_t)k * T] = acc;
+      for (int u = 0; u < U; ++u) acc[u] = 0.0;
+#pragma unroll
+      for (int kk = 0; kk < PW; ++kk) {
+        const double gk = g[k * PW + kk];
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] += gk * rv[u][kk];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (k < p && ok[u]) Xt[base[u] + (size_t)k * T] = acc[u];
     }
   }
 }
@@ -196,32 +225,63 @@ __global__ __launch_bounds__(256) void pcg_apply2_dots_kernel(const double* __re
   const int t = t0 + (live ? lane : 0);
   const double* g = Gs + (live ? lane : 0) * LD;
   const int s_end = min(na, (int)(blockIdx.y + 1) * PCG_SLOTS);
-  for (int si = blockIdx.y * PCG_SLOTS + wave; si < s_end; si += 4) {
-    const size_t sl = list[si];
-    const size_t base = sl * sV + t;
-    double v[PW], rv[PW];
+  constexpr int U = PW <= 10 ? 2 : 1;                        // (see pcg_xr_apply_kernel)
+  for (int si0 = blockIdx.y * PCG_SLOTS + wave; si0 < s_end; si0 += 4 * U) {
+    asm volatile("" ::: "memory");                        // keep the LDS reads of Gb inside the trip (hoisted, they cost 2 PW^2 registers)
+    size_t sl[U], base[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int si = si0 + 4 * u;
+      ok[u] = si < s_end;
+      sl[u] = list[ok[u] ? si : si0];
+      base[u] = sl[u] * sV + t;
+    }
+    double v[U][PW], rv[U][PW];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int k = 0; k < PW; ++k) {
+        const size_t o = base[u] + (size_t)(k < p ? k : 0) * T;
+        rv[u][k] = R[o]; v[u][k] = Y2[o];
+      }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int k = 0; k < PW; ++k) {
+        const bool in = k < p && live;
+        rv[u][k] = in ? rv[u][k] : 0.0;
+        v[u][k] = in ? eps * rv[u][k] + v[u][k] : 0.0;
+      }
+    double a[U], b[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { a[u] = 0.0; b[u] = 0.0; }
 #pragma unroll
     for (int k = 0; k < PW; ++k) {
-      v[k] = 0.0; rv[k] = 0.0;
-      if (k < p && live) {
-        rv[k] = R[base + (size_t)k * T];
-        v[k] = eps * rv[k] + Y2[base + (size_t)k * T];
+      double acc[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc[u] = 0.0;
+#pragma unroll
+      for (int kk = 0; kk < PW; ++kk) {
+        const double gk = g[k * PW + kk];
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] += gk * v[u][kk];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (k < p && live && ok[u]) Z[base[u] + (size_t)k * T] = acc[u];
+        a[u] += rv[u][k] * acc[u];
+        b[u] += rv[u][k] * rv[u][k];
       }
     }
-    double a = 0.0, b = 0.0;
 #pragma unroll
-    for (int k = 0; k < PW; ++k) {
-      double acc = 0.0;
-#pragma unroll
-      for (int kk = 0; kk < PW; ++kk) acc += g[k * PW + kk] * v[kk];
-      if (k < p && live) Z[base + (size_t)k * T] = acc;
-      a += rv[k] * acc;
-      b += rv[k] * rv[k];
-    }
-    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
-    if (lane == 0) {
-      part[(sl * gridDim.x + blockIdx.x) * 2] = a;
-      part[(sl * gridDim.x + blockIdx.x) * 2 + 1] = b;
+    for (int u = 0; u < U; ++u) {
+      double au = a[u], bu = b[u];
+      for (int off = 32; off > 0; off >>= 1) { au += __shfl_down(au, off); bu += __shfl_down(bu, off); }
+      if (lane == 0 && ok[u]) {
+        part[(sl[u] * gridDim.x + blockIdx.x) * 2] = au;
+        part[(sl[u] * gridDim.x + blockIdx.x) * 2 + 1] = bu;
+      }
     }
   }
 }

@@ -589,7 +589,6 @@ int ensure_workspace(pgpfa_ctx* c, bool plan_lr) {
   rc_carve = carve();
   c->arena_mode = 0;
   if (rc_carve) { c->B = 0; return rc_carve; }
-  const size_t nB = c->B;
   std::vector<int> id(c->B);
   for (int i = 0; i < c->B; ++i) id[i] = i;
   HIPC(hipMemcpyAsync(c->ident, id.data(), sizeof(int) * c->B, hipMemcpyHostToDevice, c->st));
@@ -649,6 +648,12 @@ void dispatch_pmax(int p, F&& f) {
   else f(std::integral_constant<int, 32>{});
 }
 
+// Rows of latents (blockDim.y) of the (bins x latents) blocks of post_vsm_kernel / poisson_pass_kernel.  Beyond 16 latents a thread
+// owns two rows; 17..24 (post_vsm) and 17..20 (poisson_pass) run 12 / 10 rows so that the block stays under 1024 threads and
+// keeps more than 128 registers per lane (their launch bounds in model.h say the same).
+inline int post_vsm_rows(int p) { return p <= 16 ? p : (p <= 24 ? 12 : 16); }
+inline int poisson_rows(int p) { return p <= 16 ? p : (p <= 20 ? 10 : 16); }
+
 // Poisson pass over the slots in d_list (nl of them): X source -> G/W destinations, flik per slot
 int poisson(pgpfa_ctx* c, const int* d_list, int nl, const double* X, double* G, double* W, double* flik, int full) {
   PoissonArgs a{};
@@ -657,7 +662,7 @@ int poisson(pgpfa_ctx* c, const int* d_list, int nl, const double* X, double* G,
   a.fpart = c->fpart; a.slots = d_list; a.trial_of_slot = c->trial_of_slot;
   a.mask = c->mask_active ? c->mask_of_slot : nullptr;
   a.q = c->q; a.p = c->p; a.T = c->T; a.ntile = (c->T + 63) / 64; a.full = full;
-  const int KY = std::min(c->p, 16);
+  const int KY = poisson_rows(c->p);
   dim3 grid(a.ntile, nl), block(64, KY);
   const double fl = (double)nl * c->q * c->T * (4.0 * c->p + (full ? c->p * (c->p + 1.0) : 0.0));
   prof_begin(c, TAG_POISSON, fl);
@@ -1392,7 +1397,7 @@ static int posterior_blocks_dense(pgpfa_ctx* c, int nb, double diag_scale, bool 
                          T, p, k, c->trial_of_slot);
     }
   }
-  const int KY = std::min(p, 16);
+  const int KY = post_vsm_rows(p);
   prof_begin(c, TAG_VSM, (double)nb * c->npad * c->npad * p);
   dispatch_pmax(p, [&](auto pm) {
     hipLaunchKernelGGL(post_vsm_kernel<decltype(pm)::value>, dim3((T + 63) / 64, nb), dim3(64, KY), 0, c->st, c->ws.Mt, c->ws.sM, c->ld, c->npad,
@@ -1481,7 +1486,7 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool 
       CHK(gemm(c, true, g, true));
     }
     if (p > WIDE_MAX) return fail("low-rank covariance engine supports up to %d latents (p=%d)", WIDE_MAX, p);
-    const int KYf = std::min(p, 16);
+    const int KYf = post_vsm_rows(p);
     prof_begin(c, TAG_VSM, (double)nb * c->n * rpad * p);
     dispatch_pmax(p, [&](auto pm) {
       hipLaunchKernelGGL((post_vsm_kernel<decltype(pm)::value, float>), dim3((T + 63) / 64, nb), dim3(64, KYf), 0, c->st, (const float*)Ytf,
@@ -1541,7 +1546,7 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool 
     prof_end(c);
   } else {
     // d. post_vsm[t] = eps G_t + G_t (Y_t^T Y_t) G_t
-    const int KY = std::min(p, 16);
+    const int KY = post_vsm_rows(p);
     prof_begin(c, TAG_VSM, (double)nb * c->n * rpad * p);
     dispatch_pmax(p, [&](auto pm) {
       hipLaunchKernelGGL(post_vsm_kernel<decltype(pm)::value>, dim3((T + 63) / 64, nb), dim3(64, KY), 0, c->st, lw.H, lw.sH, c->ld, ract,
@@ -2372,7 +2377,7 @@ int pgpfa_mstep_cd_costgrad(pgpfa_ctx* c, const double* vecCd, const double* pri
   if (!c->have_counts) return fail("spike counts have not been uploaded");
   if (!c->have_post) return fail("no E-step result resident: run an E-step or pgpfa_set_posterior first");
   HIPC(hipSetDevice(c->device));
-  const int q = c->q, p = c->p, T = c->T;
+  const int q = c->q, p = c->p;
   const int len = (p + 2) * q;
   CHK(upload(c, c->vec, vecCd, (size_t)q * (p + 1)));
   CHK(cd_sweep(c));
@@ -2471,7 +2476,7 @@ int pgpfa_mstep_cd_chord_pass(pgpfa_ctx* c, const double* vecCd, const double* p
   if (!c->have_post) return fail("no E-step result resident: run an E-step or pgpfa_set_posterior first");
   if (!c->cd_hess_valid) return fail("no per-neuron Hessians resident: call pgpfa_mstep_cd_newton_pass first");
   HIPC(hipSetDevice(c->device));
-  const int q = c->q, p = c->p, T = c->T, D = p + 1;
+  const int q = c->q, p = c->p, D = p + 1;
   const int NH = 1 + D + D * (D + 1) / 2;
   const int len = (p + 2) * q;
   CHK(upload(c, c->vec, vecCd, (size_t)q * D));
@@ -2769,7 +2774,7 @@ int pgpfa_dual_costgrad(pgpfa_ctx* c, int trial, const double* lam, double* cost
   if (grad) {
     CHK(ensure_mt_clean(c));
     CHK(inverse_t(c, c->ws, c->ident, 1));
-    const int KY = std::min(p, 16);
+    const int KY = post_vsm_rows(p);
     dispatch_pmax(p, [&](auto pm) {
       hipLaunchKernelGGL(post_vsm_kernel<decltype(pm)::value>, dim3((T + 63) / 64, 1), dim3(64, KY), 0, c->st, c->ws.Mt, c->ws.sM, c->ld, c->npad,
                          T, p, c->vsm, c->ident, c->trial_of_slot, 0);
@@ -2870,7 +2875,7 @@ static int dual_gradient(pgpfa_ctx* c, int nb) {
 // (tolerate: a slot whose precision is not positive definite or whose cost is not finite - a line-search trial point far
 // out - gets cost = +inf instead of failing the call)
 static int dual_eval_slots(pgpfa_ctx* c, int nb, const std::vector<int>& tos, bool want_grad, double* cost, bool tolerate = false) {
-  const int q = c->q, p = c->p, T = c->T;
+  const int p = c->p, T = c->T;
   std::vector<double> sB, sD, vKv, logdet(nb);
   std::vector<int> info(nb);
   CHK(dual_common(c, nb, &sB, &sD, &vKv));
@@ -2913,7 +2918,7 @@ static int dual_eval_slots(pgpfa_ctx* c, int nb, const std::vector<int>& tos, bo
   }
   if (want_grad) {
     CHK(inverse_t(c, c->ws, c->ident, nb));
-    const int KY = std::min(p, 16);
+    const int KY = post_vsm_rows(p);
     dispatch_pmax(p, [&](auto pm) {
       hipLaunchKernelGGL(post_vsm_kernel<decltype(pm)::value>, dim3((T + 63) / 64, nb), dim3(64, KY), 0, c->st, c->ws.Mt, c->ws.sM, c->ld, c->npad,
                          T, p, c->vsm, c->ident, c->trial_of_slot, 0);

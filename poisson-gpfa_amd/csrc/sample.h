@@ -110,7 +110,7 @@ __device__ inline unsigned poisson_draw(double lam, const Philox& rng, unsigned 
 
 // Y[trial][n][t] ~ Poisson(exp(c_n . x_t + d_n)); counts above 255 are flagged (the packed tensor is uint8).
 // grid = (ceil(T/64), q, ntrials), block = 64.
-__global__ void sample_counts_kernel(const double* __restrict__ X, const double* __restrict__ C, const double* __restrict__ d, int q, int p,
+__global__ __launch_bounds__(64) void sample_counts_kernel(const double* __restrict__ X, const double* __restrict__ C, const double* __restrict__ d, int q, int p,
                                      int T, unsigned long long seed, const int* __restrict__ trials, uint8_t* __restrict__ Y,
                                      int* __restrict__ overflow) {
   const int t = blockIdx.x * 64 + threadIdx.x;
