@@ -653,6 +653,120 @@ __global__ __launch_bounds__(PMAX == 24 ? 768 : 1024) void post_vsm_kernel(const
   }
 }
 
+// The same on the FP64 matrix cores for 10 < p <= 32 (the dual evaluation at config 5's 20 latents spent a quarter of its time in the
+// vector form above: one LDS read per multiply-add).  Per bin the block is the Gram matrix of the p x ncol panel Y_t = rows (., t) of Mt:
+// with a = b = Y_t[lane & 15][b0 + (lane >> 4)] one v_mfma_f64_16x16x4 adds four columns to a 16 x 16 tile - the A and B fragments of
+// a Gram product are the same register - so p <= 16 takes one LDS read and one MFMA per four columns, p <= 32 two reads and three
+// MFMAs (tiles (0,0), (1,0), (1,1) of the lower triangle).  A block owns 32 bins (128-byte runs of the single-precision panel) of one
+// slot, 8 waves x 4 bins; column chunks of CB are staged in LDS as doubles ([column][latent][bin], bin stride 33), the next chunk's
+// loads in flight in registers during the products.  NRT = row tiles (1 or 2).
+// grid = (ceil(T/32), nslots), block = 512, dynamic LDS = CB * p * 33 doubles with CB = post_vsm_mfma_cb(p).
+inline int post_vsm_mfma_cb(int p) { return p <= 24 ? 8 : 4; }
+template <int NRT, typename TIN>
+__global__ __launch_bounds__(512) void post_vsm_mfma_kernel(const TIN* __restrict__ Mt, long long sM, int ld, int ncol, int T, int p,
+                                                            double* __restrict__ vsm, const int* __restrict__ slots,
+                                                            const int* __restrict__ trial_of_slot, int full_range, int CB,
+                                                            const int* __restrict__ roff, int col_tile) {
+  // roff (may be null): rank offsets of the latents; rows (k, .) of the panel are identically zero - and were not written - left of
+  // column (roff[k] / col_tile) * col_tile (see the Yt product of the low-rank engine)
+  constexpr int LT = 33, MAXPF = 12, NACC = NRT == 1 ? 1 : 3;
+  extern __shared__ double sm[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int slot = slots[blockIdx.y];
+  const int trial = trial_of_slot[slot];
+  const int t0 = blockIdx.x * 32;
+  const int nt = min(32, T - t0);
+  const TIN* M = Mt + (size_t)slot * sM + t0;
+  const int per_chunk = CB * p * 32;
+  // staging map, the same for every chunk: element e = tid + 512 j -> (column b, latent k, bin tt)
+  const int tt = tid & 31;
+  const int ttc = tt < nt ? tt : nt - 1;
+  int cb_of[MAXPF], c0_of[MAXPF];
+  size_t off_of[MAXPF];
+  int lds_of[MAXPF];
+#pragma unroll
+  for (int j = 0; j < MAXPF; ++j) {
+    const int e = tid + 512 * j;
+    const int row = min(e, per_chunk - 1) >> 5;               // b * p + k
+    const int b = row / p, k = row - b * p;
+    cb_of[j] = (e < per_chunk) ? b : -1;
+    c0_of[j] = roff ? (roff[k] / col_tile) * col_tile : 0;
+    off_of[j] = (size_t)b * ld + (size_t)k * T + ttc;
+    lds_of[j] = row * LT + tt;
+  }
+  // (an element outside the written part of the panel is read from one fixed written location instead: the loads stay
+  // unconditional - issued back to back - and the unwritten columns cost no traffic)
+  const size_t off_dummy = (size_t)(ncol - 1) * ld + (size_t)(p - 1) * T;
+  TIN pf[MAXPF];
+  auto issue = [&](int i0) {
+#pragma unroll
+    for (int j = 0; j < MAXPF; ++j) {
+      const int b = cb_of[j] < 0 ? 0 : cb_of[j];
+      const int col = i0 + b;
+      const bool in = col < ncol && col >= c0_of[j];
+      pf[j] = M[in ? off_of[j] + (size_t)i0 * ld : off_dummy];
+    }
+  };
+  auto commit = [&](int i0) {
+#pragma unroll
+    for (int j = 0; j < MAXPF; ++j) {
+      const int col = i0 + cb_of[j];
+      if (cb_of[j] >= 0) sm[lds_of[j]] = (tt < nt && col < ncol && col >= c0_of[j]) ? (double)pf[j] : 0.0;
+    }
+  };
+  double4_t acc[4][NACC];
+#pragma unroll
+  for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) acc[bb][a] = double4_t{0.0, 0.0, 0.0, 0.0};
+  const int li = lane & 15, l4 = lane >> 4;
+  const bool r0 = li < p, r1 = 16 + li < p;
+  const int istart = full_range ? 0 : (t0 / CB) * CB;         // triangular Mt: rows (., t0..) vanish left of column t0
+  const int c0_second = (roff && p > 16) ? (roff[16] / col_tile) * col_tile : 0;
+  if (istart < ncol) issue(istart);
+  for (int i0 = istart; i0 < ncol; i0 += CB) {
+    __syncthreads();
+    commit(i0);
+    __syncthreads();
+    if (i0 + CB < ncol) issue(i0 + CB);
+    const bool second = NRT == 2 && i0 + CB > c0_second;      // (uniform) the second row tile is identically zero left of its first column
+    for (int ks = 0; ks < CB; ks += 4) {
+      const double* base = sm + (size_t)(ks + l4) * p * LT + wave * 4;
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) {
+        const double y0 = r0 ? base[li * LT + bb] : 0.0;
+        acc[bb][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(y0, y0, acc[bb][0], 0, 0, 0);
+        if constexpr (NRT == 2) {
+          if (second) {
+            const double y1 = r1 ? base[(16 + li) * LT + bb] : 0.0;
+            acc[bb][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(y1, y0, acc[bb][1], 0, 0, 0);
+            acc[bb][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(y1, y1, acc[bb][2], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  // D[row = (lane >> 4) + 4 r][col = lane & 15] of every tile -> vsm[t][k][l]
+#pragma unroll
+  for (int bb = 0; bb < 4; ++bb) {
+    const int t = t0 + wave * 4 + bb;
+    if (t >= T) continue;
+    double* out = vsm + ((size_t)trial * T + t) * p * p;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = l4 + 4 * r;
+      if (row < p && li < p) out[row * p + li] = acc[bb][0][r];
+      if constexpr (NRT == 2) {
+        if (16 + row < p && li < p) {
+          out[(16 + row) * p + li] = acc[bb][1][r];
+          out[li * p + 16 + row] = acc[bb][1][r];
+        }
+        if (16 + row < p && 16 + li < p) out[(16 + row) * p + 16 + li] = acc[bb][2][r];
+      }
+    }
+  }
+}
+
 // (T,T,p) reference layout of post_vsmGP (inference.py:164-167) from the device layout [p][T][T]
 __global__ void vsmgp_to_ref_kernel(const double* __restrict__ src, double* __restrict__ dst, int T, int p) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1739,6 +1853,102 @@ __global__ void bin_blocks_kernel(const double* __restrict__ W, long long sW, do
       for (int m = 0; m < p; ++m) v += w[i * p + m] * Gm[m * p + j2];
       wt[i * p + j2] = v;
     }
+}
+
+// The same for 10 < p <= PMAX <= 32 with 32 lanes per matrix (two matrices per wave) instead of one thread per matrix - the
+// thread-per-matrix form above fits 7 threads per workgroup at 20 latents.  Lane c owns row c during the factorisation (in LDS,
+// odd row stride: the lanes' rows start in distinct banks) and column c afterwards: x = column c of L^-1 by forward substitution
+// (the L[i][k] reads are the same address for every lane: LDS broadcasts), then column c of G = L^-T L^-1 against the LDS copy of
+// L^-1, then column c of W G.  Fully unrolled over PMAX so that x and g stay in registers.
+// block = 64 * nwaves, 2 * nwaves matrices per block, dynamic LDS = 2 * nwaves * bin_blocks_coop_doubles(p) doubles.
+inline size_t bin_blocks_coop_doubles(int p) { return (size_t)2 * p * (p | 1) + (size_t)p * p; }
+template <int PMAX>
+__global__ __launch_bounds__(256) void bin_blocks_coop_kernel(const double* __restrict__ W, long long sW, double* __restrict__ G,
+                                                              double* __restrict__ Wt, long long sO, int T, int p, double eps,
+                                                              const int* __restrict__ slots, int nslots, double* __restrict__ ldet) {
+  extern __shared__ double sm[];
+  const int pp = p * p, ldp = p | 1;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, sub = lane >> 5, c = lane & 31;
+  const int per_block = (blockDim.x >> 6) * 2;
+  const long long item = (long long)blockIdx.x * per_block + wave * 2 + sub;
+  const bool have = item < (long long)nslots * T;
+  const long long it2 = have ? item : 0;                     // (every lane walks the barriers; stores are guarded)
+  const size_t slot = slots[it2 / T];
+  const int t = (int)(it2 % T);
+  double* A = sm + (size_t)(wave * 2 + sub) * (2 * p * ldp + pp);
+  double* X = A + p * ldp;
+  double* Wc = X + p * ldp;
+  const double* w = W + slot * sW + (size_t)t * pp;
+  for (int e = c; e < pp; e += 32) {
+    const double v = w[e];
+    const int i = e / p, j = e - i * p;
+    Wc[e] = v;
+    A[i * ldp + j] = eps * v + (i == j ? 1.0 : 0.0);
+  }
+  __syncthreads();
+  // Cholesky, right-looking: lane c scales its entry of column j and updates its row
+  double logdet = 0.0;
+  for (int j = 0; j < p; ++j) {
+    const double ajj = A[j * ldp + j];
+    logdet += log(ajj);
+    const double d = sqrt(ajj);
+    __syncthreads();
+    if (c == j) A[j * ldp + j] = d;
+    else if (c > j && c < p) A[c * ldp + j] /= d;
+    __syncthreads();
+    if (c > j && c < p) {
+      const double lcj = A[c * ldp + j];
+      for (int k = j + 1; k <= c; ++k) A[c * ldp + k] -= lcj * A[k * ldp + j];
+    }
+    __syncthreads();
+  }
+  // x = column c of L^-1 (entries i >= c)
+  double x[PMAX];
+#pragma unroll
+  for (int i = 0; i < PMAX; ++i) {
+    x[i] = 0.0;
+    if (i < p) {
+      double s2 = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < i; ++k) s2 -= A[i * ldp + k] * x[k];
+      x[i] = (i >= c) ? s2 / A[i * ldp + i] : 0.0;
+    }
+  }
+  if (c < p) {
+#pragma unroll
+    for (int i = 0; i < PMAX; ++i)
+      if (i < p) X[c * ldp + i] = x[i];
+  }
+  __syncthreads();
+  // g = column c of G = L^-T L^-1:  G[a][c] = sum_i Linv[i][a] Linv[i][c]
+  double g[PMAX];
+#pragma unroll
+  for (int a = 0; a < PMAX; ++a) {
+    g[a] = 0.0;
+    if (a < p) {
+      double s2 = 0.0;
+#pragma unroll
+      for (int i = 0; i < PMAX; ++i)
+        if (i < p) s2 += X[a * ldp + i] * x[i];
+      g[a] = s2;
+    }
+  }
+  if (have && c < p) {
+    double* go = G + slot * sO + (size_t)t * pp;
+    double* wt = Wt + slot * sO + (size_t)t * pp;
+#pragma unroll
+    for (int a = 0; a < PMAX; ++a) {
+      if (a < p) {
+        go[a * p + c] = g[a];
+        double s2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < PMAX; ++k)
+          if (k < p) s2 += Wc[a * p + k] * g[k];
+        wt[a * p + c] = s2;
+      }
+    }
+    if (ldet && c == 0) ldet[item] = logdet;
+  }
 }
 
 // The same in registers for p <= PW <= 10: the LDS version above keeps 2 p^2 + 1 doubles per thread in LDS, which at p = 10

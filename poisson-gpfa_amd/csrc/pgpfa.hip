@@ -110,6 +110,7 @@ struct pgpfa_ctx {
   std::vector<double> logdetK;                  // log det of the p Gram matrices (from the factor in build_kinv)
   bool dual_lowrank = false;                    // dual-variational entry points may use the low-rank engine (no diagonal jitter)
   double* dual_tbl = nullptr; int dual_ncol = 0, dual_npd = 0; bool dual_gemm = true;   // pair / loading table of the GEMM form (dual.h)
+  bool vsm_mfma = true;                         // per-bin Gram blocks (post_vsm) on the matrix cores beyond 10 latents
   bool dual_f32 = false;                        // ... with the r x r factorisation, its inverse and Yt in single precision (mixed)
   float* Flr32 = nullptr; bool flr32_valid = false;   // single-precision copy of the low-rank factors
   bool keep_trial_vsmgp = false;
@@ -654,6 +655,29 @@ void dispatch_pmax(int p, F&& f) {
 inline int post_vsm_rows(int p) { return p <= 16 ? p : (p <= 24 ? 12 : 16); }
 inline int poisson_rows(int p) { return p <= 16 ? p : (p <= 20 ? 10 : 16); }
 
+// post_vsm[t] = Gram of the rows (., t) of the panel Mt (ncol columns, column stride ld) for ns slots: matrix-core kernel beyond 10
+// latents, vector kernel up to 10.  (f32: the panel is single precision)
+template <typename TIN>
+void launch_post_vsm(pgpfa_ctx* c, const TIN* Mt, long long sM, int ncol, int ns, int full_range, const int* roff = nullptr) {
+  const int T = c->T, p = c->p;
+  if (p > 10 && c->vsm_mfma) {
+    const int CB = post_vsm_mfma_cb(p);
+    const size_t lds = (size_t)CB * p * 33 * sizeof(double);
+    if (p <= 16)
+      hipLaunchKernelGGL((post_vsm_mfma_kernel<1, TIN>), dim3((T + 31) / 32, ns), dim3(512), lds, c->st, Mt, sM, c->ld, ncol, T, p, c->vsm, c->ident,
+                         c->trial_of_slot, full_range, CB, roff, (int)GBN);
+    else
+      hipLaunchKernelGGL((post_vsm_mfma_kernel<2, TIN>), dim3((T + 31) / 32, ns), dim3(512), lds, c->st, Mt, sM, c->ld, ncol, T, p, c->vsm, c->ident,
+                         c->trial_of_slot, full_range, CB, roff, (int)GBN);
+    return;
+  }
+  const int KY = post_vsm_rows(p);
+  dispatch_pmax(p, [&](auto pm) {
+    hipLaunchKernelGGL((post_vsm_kernel<decltype(pm)::value, TIN>), dim3((T + 63) / 64, ns), dim3(64, KY), 0, c->st, Mt, sM, c->ld, ncol, T, p, c->vsm,
+                       c->ident, c->trial_of_slot, full_range);
+  });
+}
+
 // Poisson pass over the slots in d_list (nl of them): X source -> G/W destinations, flik per slot
 int poisson(pgpfa_ctx* c, const int* d_list, int nl, const double* X, double* G, double* W, double* flik, int full) {
   PoissonArgs a{};
@@ -981,6 +1005,7 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
   else if (k == "keep_trial_vsmgp") c->keep_trial_vsmgp = (v != 0.0);
   else if (k == "dual_lowrank") c->dual_lowrank = (v != 0.0);
   else if (k == "dual_f32") c->dual_f32 = (v != 0.0);
+  else if (k == "vsm_mfma") c->vsm_mfma = (v != 0.0);
   else if (k == "dual_gemm") c->dual_gemm = (v != 0.0);
   else if (k == "extrapolate_start") c->extrapolate = (v != 0.0);
   else if (k == "extrapolate_beta") c->extrapolate_beta = v;
@@ -1287,6 +1312,19 @@ static int bin_blocks(pgpfa_ctx* c, const double* W, long long sW, double* G, do
       }
     });
   }
+  if (!done && p <= 32) {
+    // 32 lanes per matrix; as many pairs of matrices (waves) per block as 64 KB of LDS hold, four at most
+    const size_t per = bin_blocks_coop_doubles(p) * sizeof(double);
+    const int nw = (int)std::max<size_t>(1, std::min<size_t>(4, (64 * 1024) / (2 * per)));
+    const int per_block = 2 * nw;
+    dispatch_pmax(p, [&](auto pm) {
+      constexpr int PM = decltype(pm)::value;
+      if constexpr (PM >= 16)
+        hipLaunchKernelGGL(bin_blocks_coop_kernel<PM>, dim3((unsigned)((items + per_block - 1) / per_block)), dim3(64 * nw), per_block * per, c->st, W,
+                           sW, G, Wt, sO, T, p, c->eps, c->ident, nslots, ldet);
+    });
+    done = true;
+  }
   if (!done) {
     int th = (int)(48 * 1024 / ((2 * pp + 1) * sizeof(double)));
     th = std::max(1, std::min(64, th));
@@ -1397,12 +1435,8 @@ static int posterior_blocks_dense(pgpfa_ctx* c, int nb, double diag_scale, bool 
                          T, p, k, c->trial_of_slot);
     }
   }
-  const int KY = post_vsm_rows(p);
   prof_begin(c, TAG_VSM, (double)nb * c->npad * c->npad * p);
-  dispatch_pmax(p, [&](auto pm) {
-    hipLaunchKernelGGL(post_vsm_kernel<decltype(pm)::value>, dim3((T + 63) / 64, nb), dim3(64, KY), 0, c->st, c->ws.Mt, c->ws.sM, c->ld, c->npad,
-                       T, p, c->vsm, c->ident, c->trial_of_slot, 0);
-  });
+  launch_post_vsm(c, (const double*)c->ws.Mt, (long long)c->ws.sM, c->npad, nb, 0);
   prof_end(c);
   HIPC(hipGetLastError());
   return 0;
@@ -1433,6 +1467,10 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool 
   // factor, L^-T and Yt = F L^-T - the O(r^3) and O(T r^2) parts - run on the FP32 matrix cores (twice the FP64 rate, half the
   // bytes); log det and the per-bin covariance blocks are accumulated in FP64 from the single-precision factors.
   const bool f32 = c->dual_f32 && !want_vsmgp;
+  // Yt = F L^-T: L^-T is upper triangular, so the rows of Yt that belong to latent k vanish left of column roff[k].  When the consumer knows
+  // the same offsets and takes those entries as zeros without reading them (the mixing pass up to 16 latents, the matrix-core post_vsm
+  // beyond 10) the product skips the whole 128-column tiles left of it: ~45 % of the flops and stores.
+  const bool skip_zero_cols = want_vsmgp ? p <= 16 : (p > 10 && c->vsm_mfma);
   CholWS lwf = lw;                                         // single-precision views: B / L in the Mt slabs, L^-T and Yt in the H slabs
   float* Ytf = nullptr;
   if (f32) {
@@ -1477,21 +1515,19 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool 
     CHK(inverse_t(c, lwf, c->ident, nb, true));
     // Yt (float, n x ract, ld = c->ld) behind L^-T in the same slab
     for (int k = 0; k < p; ++k) {
+      const int c0 = skip_zero_cols ? (c->roff[k] / GBN) * GBN : 0;      // (see the FP64 product below)
+      if (c0 >= ract) continue;
       GemmP g{};
       g.A = reinterpret_cast<const double*>(c->Flr32 + (size_t)k * Tp * Tp); g.sA = 0; g.lda = Tp;
-      g.B = reinterpret_cast<const double*>(reinterpret_cast<float*>(lwf.Mt) + c->roff[k]); g.sB = lwf.sM; g.ldb = rpad;
-      g.C = reinterpret_cast<double*>(Ytf + (size_t)k * T); g.sC = lwf.sM; g.ldc = c->ld;
-      g.M = T; g.N = ract; g.K = c->rk[k]; g.alpha = 1.0; g.beta = 0.0;
+      g.B = reinterpret_cast<const double*>(reinterpret_cast<float*>(lwf.Mt) + c->roff[k] + (size_t)c0 * rpad); g.sB = lwf.sM; g.ldb = rpad;
+      g.C = reinterpret_cast<double*>(Ytf + (size_t)k * T + (size_t)c0 * c->ld); g.sC = lwf.sM; g.ldc = c->ld;
+      g.M = T; g.N = ract - c0; g.K = c->rk[k]; g.alpha = 1.0; g.beta = 0.0;
       g.slots = c->ident; g.nbatch = nb; g.mode = GEMM_FULL; g.kflags = 0;
       CHK(gemm(c, true, g, true));
     }
     if (p > WIDE_MAX) return fail("low-rank covariance engine supports up to %d latents (p=%d)", WIDE_MAX, p);
-    const int KYf = post_vsm_rows(p);
     prof_begin(c, TAG_VSM, (double)nb * c->n * rpad * p);
-    dispatch_pmax(p, [&](auto pm) {
-      hipLaunchKernelGGL((post_vsm_kernel<decltype(pm)::value, float>), dim3((T + 63) / 64, nb), dim3(64, KYf), 0, c->st, (const float*)Ytf,
-                         (long long)lwf.sM, c->ld, ract, T, p, c->vsm, c->ident, c->trial_of_slot, 1);
-    });
+    launch_post_vsm(c, (const float*)Ytf, (long long)lwf.sM, ract, nb, 1, skip_zero_cols ? c->d_roff : nullptr);
     prof_end(c);
     dispatch_pw(p, [&](auto pw) {
       constexpr int PW = decltype(pw)::value;
@@ -1512,10 +1548,7 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool 
                      (size_t)rpad * rpad, 0.0);
   CHK(inverse_t(c, lw, c->ident, nb));
   // c. Yt = F Mts  (n x rpad, ld = c->ld) into the factor slab (the factor itself is dead now)
-  // Mts = L^-T is upper triangular, so rows roff[k].. of it vanish left of column roff[k]: the block of Yt that belongs to
-  // latent k starts at column roff[k].  When the mixing pass follows (it knows the same offsets and takes those entries as
-  // zeros without reading them) the product skips the whole 128-column tiles left of it: ~45 % of the flops and stores.
-  const bool skip_zero_cols = want_vsmgp && p <= 16;
+  // (column tiles left of roff[k] skipped under skip_zero_cols, see above)
   for (int k = 0; k < p; ++k) {
     const int c0 = skip_zero_cols ? (c->roff[k] / GBN) * GBN : 0;
     if (c0 >= ract) continue;
@@ -1546,12 +1579,8 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool 
     prof_end(c);
   } else {
     // d. post_vsm[t] = eps G_t + G_t (Y_t^T Y_t) G_t
-    const int KY = post_vsm_rows(p);
     prof_begin(c, TAG_VSM, (double)nb * c->n * rpad * p);
-    dispatch_pmax(p, [&](auto pm) {
-      hipLaunchKernelGGL(post_vsm_kernel<decltype(pm)::value>, dim3((T + 63) / 64, nb), dim3(64, KY), 0, c->st, lw.H, lw.sH, c->ld, ract,
-                         T, p, c->vsm, c->ident, c->trial_of_slot, 1);
-    });
+    launch_post_vsm(c, (const double*)lw.H, (long long)lw.sH, ract, nb, 1, skip_zero_cols ? c->d_roff : nullptr);
     prof_end(c);
     dispatch_pw(p, [&](auto pw) {
       constexpr int PW = decltype(pw)::value;
@@ -2774,11 +2803,7 @@ int pgpfa_dual_costgrad(pgpfa_ctx* c, int trial, const double* lam, double* cost
   if (grad) {
     CHK(ensure_mt_clean(c));
     CHK(inverse_t(c, c->ws, c->ident, 1));
-    const int KY = post_vsm_rows(p);
-    dispatch_pmax(p, [&](auto pm) {
-      hipLaunchKernelGGL(post_vsm_kernel<decltype(pm)::value>, dim3((T + 63) / 64, 1), dim3(64, KY), 0, c->st, c->ws.Mt, c->ws.sM, c->ld, c->npad,
-                         T, p, c->vsm, c->ident, c->trial_of_slot, 0);
-    });
+    launch_post_vsm(c, (const double*)c->ws.Mt, (long long)c->ws.sM, c->npad, 1, 0);
     hipLaunchKernelGGL(dual_grad_kernel, dim3((T + 63) / 64, q), dim3(64), 0, c->st, c->C, c->d, c->lamd, c->KD,
                        c->vsm + (size_t)trial * T * p * p, c->dgrad, q, p, T);
     HIPC(hipGetLastError());
@@ -2918,11 +2943,7 @@ static int dual_eval_slots(pgpfa_ctx* c, int nb, const std::vector<int>& tos, bo
   }
   if (want_grad) {
     CHK(inverse_t(c, c->ws, c->ident, nb));
-    const int KY = post_vsm_rows(p);
-    dispatch_pmax(p, [&](auto pm) {
-      hipLaunchKernelGGL(post_vsm_kernel<decltype(pm)::value>, dim3((T + 63) / 64, nb), dim3(64, KY), 0, c->st, c->ws.Mt, c->ws.sM, c->ld, c->npad,
-                         T, p, c->vsm, c->ident, c->trial_of_slot, 0);
-    });
+    launch_post_vsm(c, (const double*)c->ws.Mt, (long long)c->ws.sM, c->npad, nb, 0);
     CHK(dual_gradient(c, nb));
   }
   return 0;
