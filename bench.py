@@ -320,13 +320,7 @@ def run_dual(args, q, p, T, R, rank, world):
     _, fopt, iters = ctx.dual_lbfgs(idx, rho, max_iter=args.steps)
     elapsed = time.time() - t0
     evals = ctx.info('last_dual_evaluations')
-    times = np.zeros(world)
-    times[rank] = elapsed
-    if world > 1:
-        sess_times = times                     # ranks are independent replicas of the shard loop: no communicator needed
-        t_max = elapsed
-    else:
-        t_max = elapsed
+    t_max = elapsed                            # (ranks are independent replicas of the shard loop, no communicator: rank 0's clock)
     if rank != 0:
         return
     out = {'metric': 'dual-variational trial-evaluations/sec', 'value': evals * R * world / t_max, 'unit': 'trial-evaluations/s (dual cost + gradient)',

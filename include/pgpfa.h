@@ -57,8 +57,9 @@ int pgpfa_destroy(pgpfa_ctx* ctx);
  * per-trial T x T blocks only when pgpfa_get_post_vsmgp asks for them; 1: store them in every E-step),
  * "dual_lowrank" (0; 1: the dual-variational entry points may use the low-rank engine when it pays - log det through
  * the r x r system - which evaluates the dual WITHOUT the reference's 1e-6 diagonal jitter, inference.py:190),
- * "dual_f32" (0; 1: with dual_lowrank, the r x r factorisation, its inverse and the Yt product run in single precision on the FP32
- * matrix cores, log det / covariance blocks / gradient accumulated in FP64: the mixed-precision form BASELINE config 5 asks for),
+ * "dual_f32" (0; 1: with dual_lowrank, the r x r system B = I + F^T Wt F, its factorisation, its inverse and the Yt product run in single
+ * precision on the FP32 matrix cores, log det / covariance blocks / gradient accumulated in FP64: the mixed-precision form BASELINE
+ * config 5 asks for; 2: the same with B assembled in FP64 and rounded once),
  * "pcg_fused" (1: inner PCG iterations without host round trips, pcg.h), "pcg_w32" (1: packed FP32 curvature blocks in the PCG
  * Hessian-vector product), "cd_mfma" (1: (C,d) sweep on the matrix cores, mstep.h), "vsm_mfma" (1: beyond 10 latents the per-bin
  * covariance blocks are Gram products on the matrix cores - post_vsm_mfma_kernel, model.h; 0: vector kernel),

@@ -2043,14 +2043,18 @@ constexpr int AB_LD = 81;     // LDS row stride of a staged panel (64 columns + 
 constexpr int AB_SLOTS = 2;   // slots per workgroup: the F panels are the same for every slot, only the weights differ,
                               // so one staged chunk (one exposed global-load latency) feeds AB_SLOTS x 32 MFMAs per wave
                               // (measured 2: -23 %; 3 and 4 lose resident workgroups to the extra accumulators)
-__global__ __launch_bounds__(256) void assemble_b_kernel(double* __restrict__ Bm, long long sB, int ldb, int nblk,
-                                                         const double* __restrict__ F, int Tf, int T, int p,
+// (TB = double, or float for the mixed-precision dual evaluation: F32 panels, weights rounded on load, FP32 matrix cores - twice the rate -
+// and B leaves as floats, ready for the single-precision factorisation)
+template <typename TB>
+__global__ __launch_bounds__(256) void assemble_b_kernel_t(TB* __restrict__ Bm, long long sB, int ldb, int nblk,
+                                                           const TB* __restrict__ F, int Tf, int T, int p,
                                                          const int* __restrict__ blk_lat, const int* __restrict__ blk_col,
                                                          const double* __restrict__ Wt, long long sW, const int* __restrict__ slots,
                                                          int nslots) {
-  __shared__ double FR[AB_TK * AB_LD];                   // row-side panel  [bin][column]
-  __shared__ double FC[AB_TK * AB_LD];                   // column-side panel
-  __shared__ double WL[AB_SLOTS][AB_TK * 16];            // weights [slot][bin][row block * 4 + column block]
+  using V4 = typename GemmVec<TB>::v4;
+  __shared__ TB FR[AB_TK * AB_LD];                   // row-side panel  [bin][column]
+  __shared__ TB FC[AB_TK * AB_LD];                   // column-side panel
+  __shared__ TB WL[AB_SLOTS][AB_TK * 16];            // weights [slot][bin][row block * 4 + column block]
   __shared__ int lat_r[4], lat_c[4], col_r[4], col_c[4];
   int bi = 0, rem = blockIdx.x;
   while (rem > bi) { rem -= bi + 1; ++bi; }
@@ -2066,8 +2070,8 @@ __global__ __launch_bounds__(256) void assemble_b_kernel(double* __restrict__ Bm
   }
   __syncthreads();
   const int lt = tid & 31, lc = tid >> 5;                // staging: bin lt, columns lc + 8 i
-  const double* srcR[8];
-  const double* srcC[8];
+  const TB* srcR[8];
+  const TB* srcC[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int cc = lc + 8 * i, blk = cc >> 4;
@@ -2089,27 +2093,27 @@ __global__ __launch_bounds__(256) void assemble_b_kernel(double* __restrict__ Bm
   const double* wbase[AB_SLOTS];
 #pragma unroll
   for (int sl = 0; sl < AB_SLOTS; ++sl) wbase[sl] = Wt + (size_t)slots[s_first + (sl < ns ? sl : 0)] * sW;
-  mdouble4 acc[AB_SLOTS][2][2];
+  V4 acc[AB_SLOTS][2][2];
 #pragma unroll
   for (int sl = 0; sl < AB_SLOTS; ++sl)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[sl][i][j] = mdouble4{0.0, 0.0, 0.0, 0.0};
+      for (int j = 0; j < 2; ++j) acc[sl][i][j] = V4{(TB)0, (TB)0, (TB)0, (TB)0};
 
   // register staging of the next chunk: its global loads are in flight while the current chunk is multiplied
-  double pr[8], pc[8], pw[AB_SLOTS][2];
+  TB pr[8], pc[8], pw[AB_SLOTS][2];
   auto fetch = [&](int t0) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      pr[i] = srcR[i] ? srcR[i][t0] : 0.0;
-      pc[i] = srcC[i] ? srcC[i][t0] : 0.0;
+      pr[i] = srcR[i] ? srcR[i][t0] : (TB)0;
+      pc[i] = srcC[i] ? srcC[i][t0] : (TB)0;
     }
 #pragma unroll
     for (int sl = 0; sl < AB_SLOTS; ++sl)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
-        pw[sl][i] = (sl < ns && wok[i] && t0 + wt_bin[i] < T) ? wbase[sl][woff[i] + (long long)t0 * p * p] : 0.0;
+        pw[sl][i] = (sl < ns && wok[i] && t0 + wt_bin[i] < T) ? (TB)wbase[sl][woff[i] + (long long)t0 * p * p] : (TB)0;
   };
   fetch(0);
   for (int t0 = 0; t0 < T; t0 += AB_TK) {                // panel rows T..Tf are zero, weights are guarded
@@ -2127,25 +2131,25 @@ __global__ __launch_bounds__(256) void assemble_b_kernel(double* __restrict__ Bm
 #pragma unroll
     for (int kk = 0; kk < AB_TK / 4; ++kk) {
       const int tt = kk * 4 + l4;
-      const double r0 = FR[tt * AB_LD + wr * 32 + l15], r1 = FR[tt * AB_LD + wr * 32 + 16 + l15];
-      const double c0 = FC[tt * AB_LD + wc * 32 + l15], c1 = FC[tt * AB_LD + wc * 32 + 16 + l15];
+      const TB r0 = FR[tt * AB_LD + wr * 32 + l15], r1 = FR[tt * AB_LD + wr * 32 + 16 + l15];
+      const TB c0 = FC[tt * AB_LD + wc * 32 + l15], c1 = FC[tt * AB_LD + wc * 32 + 16 + l15];
 #pragma unroll
       for (int sl = 0; sl < AB_SLOTS; ++sl) {
         if (sl >= ns) break;
-        const double* wl = WL[sl] + tt * 16 + (2 * wr) * 4 + 2 * wc;
-        acc[sl][0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(c0 * wl[0], r0, acc[sl][0][0], 0, 0, 0);
-        acc[sl][0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(c1 * wl[1], r0, acc[sl][0][1], 0, 0, 0);
-        acc[sl][1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(c0 * wl[4], r1, acc[sl][1][0], 0, 0, 0);
-        acc[sl][1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(c1 * wl[5], r1, acc[sl][1][1], 0, 0, 0);
+        const TB* wl = WL[sl] + tt * 16 + (2 * wr) * 4 + 2 * wc;
+        acc[sl][0][0] = gemm_mfma16(c0 * wl[0], r0, acc[sl][0][0]);
+        acc[sl][0][1] = gemm_mfma16(c1 * wl[1], r0, acc[sl][0][1]);
+        acc[sl][1][0] = gemm_mfma16(c0 * wl[4], r1, acc[sl][1][0]);
+        acc[sl][1][1] = gemm_mfma16(c1 * wl[5], r1, acc[sl][1][1]);
       }
     }
     __syncthreads();
   }
-  // accumulator: i (A side, column of B) = l4 + 4 r, j (B side, row of B) = l15
+  // accumulator: i (A side, column of B) = l4 + 4 r in FP64, 4 l4 + r in FP32 (see gemm.h) ; j (B side, row of B) = l15
 #pragma unroll
   for (int sl = 0; sl < AB_SLOTS; ++sl) {
     if (sl >= ns) break;
-    double* out = Bm + (size_t)slots[s_first + sl] * sB;
+    TB* out = Bm + (size_t)slots[s_first + sl] * sB;
 #pragma unroll
     for (int ri = 0; ri < 2; ++ri)
 #pragma unroll
@@ -2153,8 +2157,8 @@ __global__ __launch_bounds__(256) void assemble_b_kernel(double* __restrict__ Bm
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = bi * 64 + wr * 32 + ri * 16 + l15;
-          const int col = bj * 64 + wc * 32 + ci * 16 + l4 + 4 * r;
-          if (row >= col) out[(size_t)col * ldb + row] = acc[sl][ri][ci][r] + (row == col ? 1.0 : 0.0);
+          const int col = bj * 64 + wc * 32 + ci * 16 + (sizeof(TB) == 8 ? l4 + 4 * r : 4 * l4 + r);
+          if (row >= col) out[(size_t)col * ldb + row] = acc[sl][ri][ci][r] + (row == col ? (TB)1 : (TB)0);
         }
   }
 }

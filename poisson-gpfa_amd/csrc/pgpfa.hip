@@ -111,7 +111,7 @@ struct pgpfa_ctx {
   bool dual_lowrank = false;                    // dual-variational entry points may use the low-rank engine (no diagonal jitter)
   double* dual_tbl = nullptr; int dual_ncol = 0, dual_npd = 0; bool dual_gemm = true;   // pair / loading table of the GEMM form (dual.h)
   bool vsm_mfma = true;                         // per-bin Gram blocks (post_vsm) on the matrix cores beyond 10 latents
-  bool dual_f32 = false;                        // ... with the r x r factorisation, its inverse and Yt in single precision (mixed)
+  int dual_f32 = 0;                             // ... with the r x r factorisation, its inverse and Yt in single precision (mixed)
   float* Flr32 = nullptr; bool flr32_valid = false;   // single-precision copy of the low-rank factors
   bool keep_trial_vsmgp = false;
   bool pacc_used = false, pacc_valid = false;
@@ -1004,7 +1004,7 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
   else if (k == "lowrank_tol") c->lr_tol = v;
   else if (k == "keep_trial_vsmgp") c->keep_trial_vsmgp = (v != 0.0);
   else if (k == "dual_lowrank") c->dual_lowrank = (v != 0.0);
-  else if (k == "dual_f32") c->dual_f32 = (v != 0.0);
+  else if (k == "dual_f32") c->dual_f32 = (int)v;
   else if (k == "vsm_mfma") c->vsm_mfma = (v != 0.0);
   else if (k == "dual_gemm") c->dual_gemm = (v != 0.0);
   else if (k == "extrapolate_start") c->extrapolate = (v != 0.0);
@@ -1343,7 +1343,7 @@ static int shared_factor_lowrank(pgpfa_ctx* c, int nb) {
   CholWS lw = c->sws;
   lw.ld = rpad; lw.npad = rpad; lw.nact = round_up(c->rtot, 64);
   const int nblk64 = rpad / 64, npairs = nblk64 * (nblk64 + 1) / 2;
-  hipLaunchKernelGGL(assemble_b_kernel, dim3(npairs, 1), dim3(256), 0, c->st, lw.H, lw.sH, rpad, nblk64, c->Flr, c->Tp, T, p, c->d_blk_lat,
+  hipLaunchKernelGGL(assemble_b_kernel_t<double>, dim3(npairs, 1), dim3(256), 0, c->st, lw.H, (long long)lw.sH, rpad, nblk64, (const double*)c->Flr, c->Tp, T, p, c->d_blk_lat,
                      c->d_blk_col, c->Wtbar, 0LL, c->ident, 1);
   HIPC(hipGetLastError());
   HIPC(hipMemsetAsync(c->sws.info, 0, sizeof(int), c->st));
@@ -1459,13 +1459,9 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool 
   CholWS lw = c->ws;
   lw.ld = rpad; lw.npad = rpad; lw.nact = round_up(c->rtot, 64);
   const int nblk64 = rpad / 64, npairs = nblk64 * (nblk64 + 1) / 2;
-  hipLaunchKernelGGL(assemble_b_kernel, dim3(npairs, (nb + AB_SLOTS - 1) / AB_SLOTS), dim3(256), 0, c->st, lw.H, lw.sH, rpad, nblk64, c->Flr, Tp, T, p,
-                     c->d_blk_lat, c->d_blk_col, c->Wt, sW, c->ident, nb);
-  HIPC(hipGetLastError());
-  HIPC(hipMemsetAsync(c->ws.info, 0, sizeof(int) * nb, c->st));
-  // Mixed precision (option dual_f32, dual-variational evaluations only): B is assembled in FP64 and rounded once; its Cholesky
-  // factor, L^-T and Yt = F L^-T - the O(r^3) and O(T r^2) parts - run on the FP32 matrix cores (twice the FP64 rate, half the
-  // bytes); log det and the per-bin covariance blocks are accumulated in FP64 from the single-precision factors.
+  // Mixed precision (option dual_f32, dual-variational evaluations only): B, its Cholesky factor, L^-T and Yt = F L^-T - the O(T r^2) and
+  // O(r^3) parts - run on the FP32 matrix cores (twice the FP64 rate, half the bytes); log det and the per-bin covariance blocks are
+  // accumulated in FP64 from the single-precision factors.  (dual_f32 = 2: B is still assembled in FP64 and rounded once.)
   const bool f32 = c->dual_f32 && !want_vsmgp;
   // Yt = F L^-T: L^-T is upper triangular, so the rows of Yt that belong to latent k vanish left of column roff[k].  When the consumer knows
   // the same offsets and takes those entries as zeros without reading them (the mixing pass up to 16 latents, the matrix-core post_vsm
@@ -1487,8 +1483,20 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool 
       hipLaunchKernelGGL(cvt_f32_kernel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, c->st, c->Flr, c->Flr32, nf);
       c->flr32_valid = true;
     }
-    hipLaunchKernelGGL(cvt_lower_f32_kernel, dim3((unsigned)(((size_t)rpad * rpad + 1023) / 1024), nb), dim3(256), 0, c->st, lw.H, (long long)lw.sH,
-                       reinterpret_cast<float*>(lwf.H), (long long)lwf.sH, rpad);
+  }
+  HIPC(hipMemsetAsync(c->ws.info, 0, sizeof(int) * nb, c->st));
+  if (f32 && c->dual_f32 == 1) {
+    hipLaunchKernelGGL(assemble_b_kernel_t<float>, dim3(npairs, (nb + AB_SLOTS - 1) / AB_SLOTS), dim3(256), 0, c->st, reinterpret_cast<float*>(lwf.H),
+                       (long long)lwf.sH, rpad, nblk64, (const float*)c->Flr32, Tp, T, p, c->d_blk_lat, c->d_blk_col, c->Wt, sW, c->ident, nb);
+  } else {
+    hipLaunchKernelGGL(assemble_b_kernel_t<double>, dim3(npairs, (nb + AB_SLOTS - 1) / AB_SLOTS), dim3(256), 0, c->st, lw.H, (long long)lw.sH, rpad,
+                       nblk64, (const double*)c->Flr, Tp, T, p, c->d_blk_lat, c->d_blk_col, c->Wt, sW, c->ident, nb);
+  }
+  HIPC(hipGetLastError());
+  if (f32) {
+    if (c->dual_f32 != 1)
+      hipLaunchKernelGGL(cvt_lower_f32_kernel, dim3((unsigned)(((size_t)rpad * rpad + 1023) / 1024), nb), dim3(256), 0, c->st, lw.H, (long long)lw.sH,
+                         reinterpret_cast<float*>(lwf.H), (long long)lwf.sH, rpad);
     c->mt_dirty = true;
     CHK(factor(c, lwf, c->ident, nb, true));
   } else {

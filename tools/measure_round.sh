@@ -9,8 +9,8 @@ python bench.py --steps 20 --warmup 5 > $O/bench_c3_driver_protocol.json 2> $O/b
 python bench.py --config c2 --steps 10 --warmup 2 > $O/bench_c2.json 2>/dev/null
 python bench.py --config c1 --steps 20 --warmup 2 --no-cpu-baseline > $O/bench_c1.json 2>/dev/null
 python bench.py --workload online --steps 6 --warmup 2 > $O/bench_c4_online.json 2>/dev/null
-python bench.py --workload dual --config c5 --trials 64 --steps 6 --warmup 1 > $O/bench_c5_dual_mixed.json 2>/dev/null
-python bench.py --workload dual --config c5 --trials 64 --steps 6 --warmup 1 --precision f64 > $O/bench_c5_dual_f64.json 2>/dev/null
+python bench.py --workload dual --config c5 --trials 256 --steps 6 --warmup 1 > $O/bench_c5_dual_mixed.json 2>/dev/null
+python bench.py --workload dual --config c5 --trials 256 --steps 6 --warmup 1 --precision f64 > $O/bench_c5_dual_f64.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -o ks -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --lean > $O/bench_c3_under_rocprof.json 2>/dev/null
 cd $R
