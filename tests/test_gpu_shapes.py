@@ -1,0 +1,95 @@
+"""Seeded random problem shapes through both covariance engines and the dual evaluation, against the oracle / plain numpy.
+
+The fixed-size parity tests sit on the shapes the kernels were tuned at; these walk the instantiation boundaries instead (latent widths
+1..32 across the 4/8/10/12/16/20/24/32 buckets, bin counts that are not multiples of the 16/32/64-bin tiles, neuron counts that are not
+multiples of 16, one to a few trials).  Same tolerances as tests/test_gpu_parity.py: modes 1e-8, objective 1e-9 rel, covariance blocks 1e-8 rel."""
+import numpy as np
+import pytest
+
+from oracle import pgpfa_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(1e-300, np.max(np.abs(b)))
+
+
+def _shape(seed):
+    rng = np.random.default_rng(1000 + seed)
+    p = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 10, 11, 12, 13, 15, 16, 17, 20, 21, 24, 25, 29, 32]))
+    T = int(rng.integers(6, 80))
+    q = int(rng.integers(max(3, p // 2), 48))
+    R = int(rng.integers(1, 5))
+    return q, p, T, R, rng
+
+
+@pytest.mark.parametrize('seed', range(14))
+@pytest.mark.parametrize('cov_mode', [1, 2])
+def test_laplace_estep_random_shapes(seed, cov_mode):
+    from funs import _hip
+    q, p, T, R, rng = _shape(seed)
+    _, Ys, _ = orc.synth_dataset(q, p, T, R, seed=seed, dOffset=0.0)
+    Y = np.stack(Ys).astype(np.uint8)
+    par = {'C': 0.3 * rng.standard_normal((q, p)) / np.sqrt(max(1, p / 4)), 'd': np.log(Y.mean(axis=(0, 2)) + 0.1),
+           'tau': 0.03 + 0.25 * rng.random(p)}
+    res, nll_o, _ = orc.laplace([y.astype(float) for y in Ys], par, 10.0, mode='exact', return_cov=False)
+    ctx = _hip.Context(q, p, T, R, 10.0)
+    try:
+        ctx.upload_counts(Y)
+        ctx.set_option('cov_mode', cov_mode)
+        ctx.set_option('keep_trial_vsmgp', 1)
+        ctx.set_params(par['C'], par['d'], par['tau'])
+        obj, _, status = ctx.estep_laplace()
+        tag = 'shape q=%d p=%d T=%d R=%d cov_mode=%d (low-rank plan %d)' % (q, p, T, R, cov_mode, int(ctx.info('plan_lowrank')))
+        assert np.all(status == 0), tag
+        assert abs(-obj / R - nll_o) <= 1e-9 * abs(nll_o), tag
+        assert np.max(np.abs(ctx.post_mean() - np.stack(res['post_mean']))) <= 1e-8, tag
+        assert rel(ctx.post_vsm(), np.stack(res['post_vsm'])) <= 1e-8, tag
+        assert rel(ctx.post_vsmgp(), np.stack(res['post_vsmGP'])) <= 1e-8, tag
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize('seed', range(10))
+@pytest.mark.parametrize('lowrank', [0, 1])
+def test_dual_evaluation_random_shapes(seed, lowrank):
+    """Dual cost + gradient (inference.py:196-219) at random shapes: dense engine (with the reference's 1e-6 jitter, inference.py:190) and
+    low-rank engine (unjittered) against the oracle / plain numpy."""
+    from funs import _hip
+    q, p, T, R, rng = _shape(100 + seed)
+    _, Ys, _ = orc.synth_dataset(q, p, T, R, seed=seed, dOffset=0.0)
+    Y = np.stack(Ys).astype(np.uint8)
+    C, d, tau = 0.25 * rng.standard_normal((q, p)), np.log(Y.mean(axis=(0, 2)) + 0.1), 0.2 + 0.4 * rng.random(p)
+    lam = 0.05 + 0.5 * rng.random((R, q * T))
+    idx = np.arange(R, dtype=np.int32)
+    ctx = _hip.Context(q, p, T, R, 10.0)
+    try:
+        ctx.upload_counts(Y)
+        if lowrank:
+            ctx.set_option('cov_mode', 2)
+            ctx.set_option('dual_lowrank', 1)
+        else:
+            ctx.set_option('cov_mode', 1)
+        ctx.set_params(C, d, tau)
+        cost, grad = ctx.dual_costgrad_batch(idx, lam)
+        used_lowrank = bool(ctx.info('plan_lowrank'))
+    finally:
+        ctx.close()
+    tag = 'shape q=%d p=%d T=%d R=%d lowrank=%d (plan %d)' % (q, p, T, R, lowrank, used_lowrank)
+    K_big = orc.make_K_big(orc.make_K(tau, T, 10.0))
+    C_big, d_big = orc.make_Cd_big(C, d, T)
+    Kinv_big = np.linalg.inv(K_big)
+    for i in range(R):
+        y = Ys[i].reshape(-1).astype(float)
+        if used_lowrank:
+            v = C_big @ (lam[i] - y)
+            H = Kinv_big + (C_big * lam[i][None, :]) @ C_big.T
+            Sigma = np.linalg.inv(H)
+            ref_cost = 0.5 * v @ K_big @ v - d_big @ (lam[i] - y) - 0.5 * np.linalg.slogdet(H)[1] + np.sum(lam[i] * (np.log(lam[i]) - 1.0))
+            ref_grad = C_big.T @ (K_big @ v) - d_big + np.log(lam[i]) - 0.5 * np.einsum('im,ij,jm->m', C_big, Sigma, C_big)
+        else:
+            ref_cost = orc.dual_cost(lam[i], y, C_big, K_big, Kinv_big, d_big)
+            ref_grad = orc.dual_grad(lam[i], y, C_big, K_big, Kinv_big, d_big)
+        assert abs(cost[i] - ref_cost) <= 1e-8 * abs(ref_cost), tag
+        assert rel(grad[i], ref_grad) <= 1e-7, tag
