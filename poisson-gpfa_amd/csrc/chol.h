@@ -26,7 +26,7 @@ constexpr int NSUP = 512;   // super-panel width
 // through a double-buffered LDS line (one barrier per step) and every thread applies the rank-1 update to its
 // registers with no masks: registers of finished columns are dead (the finished column of L goes to an LDS copy),
 // and the steps are instantiated per quarter of the block so that the register range still alive is static.
-// The inverse runs row by row (forward substitution) with row i of L^-1 broadcast the same way.
+// The inverse runs in 32-wide blocks over the factor in LDS (potrf_diag_inverse).
 // Writes L back in place and L^-1 to Dinv[slot][k0/128]; info[slot] = (k0 + j + 1) at the first bad pivot.
 // --------------------------------------------------------------------------------------------------
 // offset of L[r][j] (r >= j) in the packed column-major lower triangle
@@ -79,25 +79,75 @@ __device__ __forceinline__ void potrf_diag_chol_steps(T (&a)[32], PotrfLds<T>& S
   }
 }
 
-template <int Q, typename T>
-__device__ __forceinline__ void potrf_diag_inv_steps(T (&t)[32], PotrfLds<T>& S, int r, int cg, T inv_lrr) {
-  constexpr int MEND = 8 * (Q + 1);               // columns beyond 32(Q+1) are still zero in this quarter
-#pragma unroll 1
-  for (int i = 32 * Q; i < 32 * Q + 32; ++i) {
-    T* xrow = S.line[i & 1];
-    if (r == i) {
-      T* xp = xrow + cg * 32;
+// X = L^-1 of the 128 x 128 block, in place over the packed factor in LDS, in 32-wide blocks:
+//   1. the four diagonal blocks X_QQ = L_QQ^-1 at the same time, by rows (forward substitution, row i of every block broadcast through the
+//      LDS line, 32 barrier steps instead of 128), in 8 registers per thread; then written over L_QQ;
+//   2. block rows P = 1..3 in turn: W = L_P,Q..P-1 X_Q..P-1,Q for every block Q < P (X of the rows above is final and sits where their L
+//      was), then X_PQ = -X_PP W, each as 32 x 32P outputs spread over all 512 threads (2P per thread), operands read from LDS.
+template <typename T>
+__device__ __forceinline__ void potrf_diag_inverse(PotrfLds<T>& S, int tid, int r, int cg) {
+  const int Q = r >> 5, rl = r & 31;
+  const T inv_lrr = (T)1 / S.L[potrf_lidx(r, r)];
+  T t[8];
 #pragma unroll
-      for (int m = 0; m < MEND; ++m) xp[m] = t[m];
-      if ((i & 3) == cg) xp[i >> 2] = inv_lrr;    // X[i][i]
+  for (int m = 0; m < 8; ++m) t[m] = (T)0;
+#pragma unroll 1
+  for (int il = 0; il < 32; ++il) {
+    T* xrow = S.line[il & 1] + Q * 32 + cg * 8;           // row 32 Q + il of X_QQ: columns cg + 4 m of the block at [cg * 8 + m]
+    if (rl == il) {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) xrow[m] = t[m];
+      if ((il & 3) == cg) xrow[il >> 2] = inv_lrr;         // X[i][i]
     }
     __syncthreads();
-    if (r > i) {
-      const T lri = -S.L[potrf_lidx(i, r)] * inv_lrr;
-      const T* xp = xrow + cg * 32;
+    if (rl > il) {
+      const T lri = -S.L[potrf_lidx(32 * Q + il, r)] * inv_lrr;
 #pragma unroll
-      for (int m = 0; m < MEND; ++m) t[m] = fma(lri, xp[m], t[m]);
+      for (int m = 0; m < 8; ++m) t[m] = fma(lri, xrow[m], t[m]);
     }
+  }
+  __syncthreads();                                        // every read of the L_QQ blocks is done
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const int c = 32 * Q + cg + 4 * m;
+    if (c < r) S.L[potrf_lidx(c, r)] = t[m];
+  }
+  if ((rl & 3) == cg) S.L[potrf_lidx(r, r)] = inv_lrr;
+  __syncthreads();
+#pragma unroll 1
+  for (int P = 1; P < 4; ++P) {
+    const int nu = 2 * P;                                  // outputs per thread: e = tid + 512 u -> (row 32 P + (e & 31), column e >> 5)
+    const int r2 = 32 * P + (tid & 31);
+    T w[6];
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      w[u] = (T)0;
+      if (u < nu) {
+        const int c = (tid >> 5) + 16 * u;
+        T acc = (T)0;
+        for (int i = c; i < 32 * P; ++i) acc = fma(S.L[potrf_lidx(i, r2)], S.L[potrf_lidx(c, i)], acc);
+        w[u] = acc;
+      }
+    }
+    __syncthreads();                                      // L_P,. is dead now
+#pragma unroll
+    for (int u = 0; u < 6; ++u)
+      if (u < nu) S.L[potrf_lidx((tid >> 5) + 16 * u, r2)] = w[u];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      if (u < nu) {
+        const int c = (tid >> 5) + 16 * u;
+        T acc = (T)0;
+        for (int rp = 32 * P; rp <= r2; ++rp) acc = fma(S.L[potrf_lidx(rp, r2)], S.L[potrf_lidx(c, rp)], acc);
+        w[u] = -acc;
+      }
+    }
+    __syncthreads();                                      // W is dead now
+#pragma unroll
+    for (int u = 0; u < 6; ++u)
+      if (u < nu) S.L[potrf_lidx((tid >> 5) + 16 * u, r2)] = w[u];
+    __syncthreads();
   }
 }
 
@@ -126,19 +176,11 @@ __global__ __launch_bounds__(512) void potrf_diag_kernel_t(T* __restrict__ H, lo
     const int rr = e & (NB - 1), cc = e >> 7;
     if (rr >= cc) Hs[(size_t)cc * ld + rr] = S.L[potrf_lidx(cc, rr)];
   }
-  // ---- X = L^-1 by rows: X[r][c] = -(1/L[r][r]) sum_{i=c}^{r-1} L[r][i] X[i][c]  (c < r),  X[r][r] = 1/L[r][r]
-  T t[32];
-#pragma unroll
-  for (int m = 0; m < 32; ++m) t[m] = (T)0;
-  const T inv_lrr = (T)1 / S.L[potrf_lidx(r, r)];
-  potrf_diag_inv_steps<0>(t, S, r, cg, inv_lrr);
-  potrf_diag_inv_steps<1>(t, S, r, cg, inv_lrr);
-  potrf_diag_inv_steps<2>(t, S, r, cg, inv_lrr);
-  potrf_diag_inv_steps<3>(t, S, r, cg, inv_lrr);
-#pragma unroll
-  for (int m = 0; m < 32; ++m) {
-    const int c = cg + 4 * m;
-    Ds[(size_t)c * NB + r] = (c < r) ? t[m] : (c == r ? inv_lrr : (T)0);
+  // ---- X = L^-1 over the factor in LDS, then out (Ds[c][r] = X[r][c], zero above the diagonal)
+  potrf_diag_inverse(S, tid, r, cg);
+  for (int e = tid; e < NB * NB; e += 512) {
+    const int rr = e & (NB - 1), cc = e >> 7;
+    Ds[(size_t)cc * NB + rr] = (rr >= cc) ? S.L[potrf_lidx(cc, rr)] : (T)0;
   }
 }
 
