@@ -209,6 +209,8 @@ int pgpfa_test_gemm_nn_f32(pgpfa_ctx* ctx, int M, int N, int K, double alpha, co
  * events on the context stream; returns average ms per launch and the flops of one launch. */
 int pgpfa_bench_syrk(pgpfa_ctx* ctx, int batch, int n, int k, int reps, double* ms_per_launch,
                      double* flops_per_launch);
+/* Phase timings of the 128 x 128 diagonal-block kernel (chol.h): phases 0 = load/store only, 1 = + Cholesky steps, 3 = + inverse. */
+int pgpfa_bench_potrf_diag(pgpfa_ctx* ctx, int batch, int reps, int phases, double* us_per_launch);
 /* Sustained v_mfma_f64_16x16x4_f64 rate of the device (register-only loop): the practical MFMA
  * ceiling under the clock the chip holds, reported next to the datasheet peak. */
 int pgpfa_bench_mfma_peak(pgpfa_ctx* ctx, int iters, double* tflops);

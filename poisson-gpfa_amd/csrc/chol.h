@@ -83,7 +83,8 @@ __device__ __forceinline__ void potrf_diag_chol_steps(T (&a)[32], PotrfLds<T>& S
 //   1. the four diagonal blocks X_QQ = L_QQ^-1 at the same time, by rows (forward substitution, row i of every block broadcast through the
 //      LDS line, 32 barrier steps instead of 128), in 8 registers per thread; then written over L_QQ;
 //   2. block rows P = 1..3 in turn: W = L_P,Q..P-1 X_Q..P-1,Q for every block Q < P (X of the rows above is final and sits where their L
-//      was), then X_PQ = -X_PP W, each as 32 x 32P outputs spread over all 512 threads (2P per thread), operands read from LDS.
+//      was), then X_PQ = -X_PP W: two small products on the matrix cores, 16 x 16 tiles over the 8 waves, fragments read from the packed
+//      triangle in LDS (a scalar version of the same products was bound by its ~1500 LDS reads per thread: 65 us for the inverse).
 template <typename T>
 __device__ __forceinline__ void potrf_diag_inverse(PotrfLds<T>& S, int tid, int r, int cg) {
   const int Q = r >> 5, rl = r & 31;
@@ -114,44 +115,79 @@ __device__ __forceinline__ void potrf_diag_inverse(PotrfLds<T>& S, int tid, int 
   }
   if ((rl & 3) == cg) S.L[potrf_lidx(r, r)] = inv_lrr;
   __syncthreads();
+  // Block rows on the matrix cores: 16 x 16 output tiles (2 row halves x 2 P column tiles of block row P), tile index = wave, wave + 8;
+  // fragments straight from the packed triangle: X[i][c] (i >= c) sits at xoff(c) + i, L[r][i] / X_PP[r][i] (i <= r) at lrow(i) + r.
+  using V4 = typename GemmVec<T>::v4;
+  const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+  auto lrow = [](int i) { return i * (NB - 1) - (i * (i - 1)) / 2; };
+  auto xoff = [](int c) { return c * NB - (c * (c - 1)) / 2 - c; };
 #pragma unroll 1
   for (int P = 1; P < 4; ++P) {
-    const int nu = 2 * P;                                  // outputs per thread: e = tid + 512 u -> (row 32 P + (e & 31), column e >> 5)
-    const int r2 = 32 * P + (tid & 31);
-    T w[6];
+    const int ntile = 4 * P;
+    V4 acc[2];
+    // (a) W = L_P,0..P-1 X_0..P-1,.   (k < column: X is zero, those k steps are skipped / masked)
 #pragma unroll
-    for (int u = 0; u < 6; ++u) {
-      w[u] = (T)0;
-      if (u < nu) {
-        const int c = (tid >> 5) + 16 * u;
-        T acc = (T)0;
-        for (int i = c; i < 32 * P; ++i) acc = fma(S.L[potrf_lidx(i, r2)], S.L[potrf_lidx(c, i)], acc);
-        w[u] = acc;
+    for (int s2 = 0; s2 < 2; ++s2) {
+      acc[s2] = V4{(T)0, (T)0, (T)0, (T)0};
+      const int tile = wave + 8 * s2;
+      if (tile < ntile) {
+        const int rt = tile & 1, ct = tile >> 1;
+        const int row = 32 * P + 16 * rt + l15, col = 16 * ct + l15;
+        const int xo = xoff(col);
+        for (int k0 = 16 * ct; k0 < 32 * P; k0 += 4) {
+          const int k = k0 + l4;
+          const T av = S.L[lrow(k) + row];
+          const T bv = S.L[xo + k];
+          acc[s2] = gemm_mfma16(av, (k >= col) ? bv : (T)0, acc[s2]);
+        }
       }
     }
     __syncthreads();                                      // L_P,. is dead now
 #pragma unroll
-    for (int u = 0; u < 6; ++u)
-      if (u < nu) S.L[potrf_lidx((tid >> 5) + 16 * u, r2)] = w[u];
-    __syncthreads();
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int tile = wave + 8 * s2;
+      if (tile < ntile) {
+        const int rt = tile & 1, ct = tile >> 1;
+        const int xo = xoff(16 * ct + l15);
 #pragma unroll
-    for (int u = 0; u < 6; ++u) {
-      if (u < nu) {
-        const int c = (tid >> 5) + 16 * u;
-        T acc = (T)0;
-        for (int rp = 32 * P; rp <= r2; ++rp) acc = fma(S.L[potrf_lidx(rp, r2)], S.L[potrf_lidx(c, rp)], acc);
-        w[u] = -acc;
+        for (int q = 0; q < 4; ++q) S.L[xo + 32 * P + 16 * rt + (sizeof(T) == 8 ? l4 + 4 * q : 4 * l4 + q)] = acc[s2][q];
+      }
+    }
+    __syncthreads();
+    // (b) X_P,. = -X_PP W   (X_PP lower triangular: k <= row)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      acc[s2] = V4{(T)0, (T)0, (T)0, (T)0};
+      const int tile = wave + 8 * s2;
+      if (tile < ntile) {
+        const int rt = tile & 1, ct = tile >> 1;
+        const int row = 32 * P + 16 * rt + l15;
+        const int xo = xoff(16 * ct + l15);
+        for (int k0 = 32 * P; k0 < 32 * P + 16 * (rt + 1); k0 += 4) {
+          const int k = k0 + l4;
+          const T av = S.L[lrow(k <= row ? k : row) + row];
+          const T bv = S.L[xo + k];
+          acc[s2] = gemm_mfma16((k <= row) ? -av : (T)0, bv, acc[s2]);
+        }
       }
     }
     __syncthreads();                                      // W is dead now
 #pragma unroll
-    for (int u = 0; u < 6; ++u)
-      if (u < nu) S.L[potrf_lidx((tid >> 5) + 16 * u, r2)] = w[u];
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int tile = wave + 8 * s2;
+      if (tile < ntile) {
+        const int rt = tile & 1, ct = tile >> 1;
+        const int xo = xoff(16 * ct + l15);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) S.L[xo + 32 * P + 16 * rt + (sizeof(T) == 8 ? l4 + 4 * q : 4 * l4 + q)] = acc[s2][q];
+      }
+    }
     __syncthreads();
   }
 }
 
-template <typename T>
+// (PH: phases to run, for the phase timings of pgpfa_bench_potrf_diag: bit 0 = Cholesky steps, bit 1 = inverse; production is 3)
+template <typename T, int PH = 3>
 __global__ __launch_bounds__(512) void potrf_diag_kernel_t(T* __restrict__ H, long long sH, int ld, int k0,
                                                             T* __restrict__ Dinv, long long sD,
                                                             const int* __restrict__ slots, int* __restrict__ info) {
@@ -167,17 +203,23 @@ __global__ __launch_bounds__(512) void potrf_diag_kernel_t(T* __restrict__ H, lo
   T a[32];
 #pragma unroll
   for (int m = 0; m < 32; ++m) a[m] = Hs[(size_t)(cg + 4 * m) * ld + r];   // entries above the diagonal are never used
-  potrf_diag_chol_steps<0>(a, S, r, cg, pos_r, info, slot, k0);
-  potrf_diag_chol_steps<1>(a, S, r, cg, pos_r, info, slot, k0);
-  potrf_diag_chol_steps<2>(a, S, r, cg, pos_r, info, slot, k0);
-  potrf_diag_chol_steps<3>(a, S, r, cg, pos_r, info, slot, k0);
+  if constexpr (PH & 1) {
+    potrf_diag_chol_steps<0>(a, S, r, cg, pos_r, info, slot, k0);
+    potrf_diag_chol_steps<1>(a, S, r, cg, pos_r, info, slot, k0);
+    potrf_diag_chol_steps<2>(a, S, r, cg, pos_r, info, slot, k0);
+    potrf_diag_chol_steps<3>(a, S, r, cg, pos_r, info, slot, k0);
+  } else {
+#pragma unroll
+    for (int m = 0; m < 32; ++m)
+      if (cg + 4 * m <= r) S.L[potrf_lidx(cg + 4 * m, r)] = a[m];
+  }
   __syncthreads();
   for (int e = tid; e < NB * NB; e += 512) {
     const int rr = e & (NB - 1), cc = e >> 7;
     if (rr >= cc) Hs[(size_t)cc * ld + rr] = S.L[potrf_lidx(cc, rr)];
   }
   // ---- X = L^-1 over the factor in LDS, then out (Ds[c][r] = X[r][c], zero above the diagonal)
-  potrf_diag_inverse(S, tid, r, cg);
+  if constexpr (PH & 2) potrf_diag_inverse(S, tid, r, cg);
   for (int e = tid; e < NB * NB; e += 512) {
     const int rr = e & (NB - 1), cc = e >> 7;
     Ds[(size_t)cc * NB + rr] = (rr >= cc) ? S.L[potrf_lidx(cc, rr)] : (T)0;

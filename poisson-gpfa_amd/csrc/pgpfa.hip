@@ -3482,4 +3482,47 @@ int pgpfa_bench_syrk(pgpfa_ctx* c, int batch, int n, int k, int reps, double* ms
   return 0;
 }
 
+// Phase timings of the diagonal-block kernel: `batch` well-conditioned 128 x 128 blocks, phases = 0 (load / store only), 1 (+ Cholesky
+// steps), 3 (+ inverse: the production kernel).  us_per_launch = HIP-event time over `reps` launches.
+int pgpfa_bench_potrf_diag(pgpfa_ctx* c, int batch, int reps, int phases, double* us_per_launch) {
+  if (!c || !us_per_launch) return fail("null argument");
+  if (batch < 1 || reps < 1 || (phases != 0 && phases != 1 && phases != 3)) return fail("batch, reps >= 1; phases 0, 1 or 3");
+  HIPC(hipSetDevice(c->device));
+  const size_t mark = c->allocs.size();
+  double *dH = nullptr, *dD = nullptr;
+  int* dinfo = nullptr;
+  const size_t blk = (size_t)NB * NB;
+  CHK(dmalloc(c, &dH, blk * batch));
+  CHK(dmalloc(c, &dD, blk * batch));
+  CHK(dmalloc(c, &dinfo, (size_t)batch, true));
+  std::vector<double> h(blk);
+  for (int j = 0; j < NB; ++j)
+    for (int i = 0; i < NB; ++i) h[(size_t)j * NB + i] = (i == j ? 2.0 : 0.0) + 1.0 / (1.0 + std::abs(i - j));
+  for (int b = 0; b < batch; ++b) HIPC(hipMemcpyAsync(dH + blk * b, h.data(), blk * sizeof(double), hipMemcpyHostToDevice, c->st));
+  HIPC(hipStreamSynchronize(c->st));
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  auto launch = [&]() {
+    // (the factor overwrites its input: later launches factor the factor's lower triangle - still SPD-like, diagonal > 1 - same work)
+    if (phases == 3)
+      hipLaunchKernelGGL((potrf_diag_kernel_t<double, 3>), dim3(batch), dim3(512), 0, c->st, dH, (long long)blk, NB, 0, dD, (long long)blk, (const int*)nullptr, dinfo);
+    else if (phases == 1)
+      hipLaunchKernelGGL((potrf_diag_kernel_t<double, 1>), dim3(batch), dim3(512), 0, c->st, dH, (long long)blk, NB, 0, dD, (long long)blk, (const int*)nullptr, dinfo);
+    else
+      hipLaunchKernelGGL((potrf_diag_kernel_t<double, 0>), dim3(batch), dim3(512), 0, c->st, dH, (long long)blk, NB, 0, dD, (long long)blk, (const int*)nullptr, dinfo);
+  };
+  launch();
+  hipEventRecord(e0, c->st);
+  for (int i = 0; i < reps; ++i) launch();
+  hipEventRecord(e1, c->st);
+  hipEventSynchronize(e1);
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, e0, e1);
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  *us_per_launch = 1e3 * ms / reps;
+  while (c->allocs.size() > mark) { hipFree(c->allocs.back()); c->allocs.pop_back(); }
+  HIPC(hipGetLastError());
+  return 0;
+}
+
 }  // extern "C"

@@ -66,6 +66,7 @@ _SIGNATURES = {
     'pgpfa_test_gemm_nt_f32': [ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, ct.c_double, c_double_p, c_double_p, ct.c_double, c_double_p],
     'pgpfa_test_gemm_nn_f32': [ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, ct.c_double, c_double_p, c_double_p, ct.c_double, c_double_p],
     'pgpfa_bench_syrk': [ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, ct.c_int, c_double_p, c_double_p],
+    'pgpfa_bench_potrf_diag': [ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, c_double_p],
     'pgpfa_bench_mfma_peak': [ct.c_void_p, ct.c_int, c_double_p],
 }
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ['pgpfa_last_error'])
@@ -436,6 +437,11 @@ class Context:
         tf = ct.c_double(0.0)
         check(self.lib.pgpfa_bench_mfma_peak(self.h, int(iters), ct.byref(tf)))
         return tf.value
+
+    def bench_potrf_diag(self, batch, reps=50, phases=3):
+        us = ct.c_double()
+        check(self.lib.pgpfa_bench_potrf_diag(self.h, int(batch), int(reps), int(phases), ct.byref(us)))
+        return us.value
 
     def bench_syrk(self, batch, n, k, reps):
         ms, fl = ct.c_double(0.0), ct.c_double(0.0)
