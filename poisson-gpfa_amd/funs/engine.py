@@ -3,6 +3,8 @@ mackelab/poisson-gpfa): `PPGPFAfit(experiment, initParams, ...)` runs batch or o
 E-step and M-step evaluations on the GPU, and leaves the reference's result attributes
 (engine.py:453-474) on the object.  Plotting methods are not part of the hot path."""
 import copy
+import json
+import os
 import time
 
 import numpy as np
@@ -64,7 +66,22 @@ class PPGPFAfit():
                                                                  prevOptimRes=prev, verbose=verbose)
             return infRes_, nll_, vlb_, opt_
 
+        log_path = os.environ.get('PGPFA_LOG_JSONL')          # one JSON line per EM iteration (metrics / logging)
+
         def report(i, nll, vlb):
+            if log_path:
+                rec = {'iteration': i + 1, 'of': maxEMiter, 'em_mode': EMmode, 'inference': inferenceMethod, 'nPLL': float(nll),
+                       'VLB': None if vlb is None else float(vlb), 'estep_s': inferenceTime[-1], 'mstep_s': learningTime[-1]}
+                sess = getattr(infRes, 'session', None)
+                if sess is not None:
+                    for key in ('last_pcg_iterations', 'last_newton_factorizations', 'last_newton_max_iter', 'last_dense_retries',
+                                'lowrank_rtot', 'chunk_trials', 'plan_lowrank', 'last_dual_evaluations'):
+                        try:
+                            rec[key] = sess.ctx.info(key)
+                        except Exception:
+                            pass
+                with open(log_path, 'a') as fh:
+                    fh.write(json.dumps(rec) + '\n')
             if quiet:
                 return
             if vlb is None:

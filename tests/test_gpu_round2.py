@@ -588,3 +588,20 @@ def test_host_free_pcg_path_reaches_the_same_modes(c1, w32):
         assert np.all(st2 == 0) and abs(obj2 - obj) <= 1e-10 * abs(obj)
     finally:
         ctx.close()
+
+
+def test_em_iteration_log_json_lines(c1, c1_experiment, tmp_path, monkeypatch):
+    """PGPFA_LOG_JSONL=<path>: one JSON line per EM iteration with the values the reference prints (iteration, nPLL) plus timings and the
+    device's work counters (metrics / logging)."""
+    import json
+    import funs
+    path = tmp_path / 'em.jsonl'
+    monkeypatch.setenv('PGPFA_LOG_JSONL', str(path))
+    init = {k: v.copy() for k, v in c1['init'].items()}
+    fit = funs.engine.PPGPFAfit(c1_experiment, initParams=init, inferenceMethod='laplace', EMmode='Batch', maxEMiter=3, quiet=True,
+                                CdOptimMethod='newton')
+    lines = [json.loads(l) for l in open(path)]
+    assert [l['iteration'] for l in lines] == [1, 2, 3]
+    assert np.allclose([l['nPLL'] for l in lines], fit.posteriorLikelihood, rtol=0, atol=0)
+    assert all(l['estep_s'] > 0 and l['mstep_s'] > 0 and l['chunk_trials'] == 20 for l in lines)
+    assert lines[0]['em_mode'] == 'Batch' and lines[0]['VLB'] is None

@@ -9,6 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 $R/bench.py --no-cpu-baseline --lean "$@" > $O/bench.json 2> $O/bench.err
 cd $R
 python tools/gemm_by_grid.py $O/kt > $O/by_grid.txt
+python tools/trace_gaps.py $O/kt > $O/gaps.txt
 find $O/kt -name '*kernel_stats.csv' -exec cp {} $O/kernel_stats.csv \;
 rm -rf $O/kt
 cat $O/by_grid.txt
