@@ -209,6 +209,9 @@ int pgpfa_test_gemm_nn_f32(pgpfa_ctx* ctx, int M, int N, int K, double alpha, co
  * events on the context stream; returns average ms per launch and the flops of one launch. */
 int pgpfa_bench_syrk(pgpfa_ctx* ctx, int batch, int n, int k, int reps, double* ms_per_launch,
                      double* flops_per_launch);
+/* GEMM launches since option "profile" was switched on, grouped by operand shape (text, one line per shape: launches, total ms, algorithmic
+ * GFLOP, TFLOP/s; longest total first).  Returns the bytes the full report needs incl. the terminator; writes at most len. */
+int pgpfa_gemm_shape_report(pgpfa_ctx* ctx, char* buf, int len);
 /* Phase timings of the 128 x 128 diagonal-block kernel (chol.h): phases 0 = load/store only, 1 = + Cholesky steps, 3 = + inverse. */
 int pgpfa_bench_potrf_diag(pgpfa_ctx* ctx, int batch, int reps, int phases, double* us_per_launch);
 /* Sustained v_mfma_f64_16x16x4_f64 rate of the device (register-only loop): the practical MFMA

@@ -60,11 +60,13 @@ struct Prof {
   int only_tag = -1;                 // >= 0: time launches of this tag only (option "profile" = 2: the GEMM kernel)
   std::vector<hipEvent_t> pool;      // every event ever created (destroyed with the context)
   std::vector<hipEvent_t> idle;      // events free for reuse
-  struct Rec { int tag; hipEvent_t e0, e1; double flops; };
+  struct Rec { int tag; hipEvent_t e0, e1; double flops; std::string shape; };
   std::deque<Rec> recs;              // launches whose events have not been read yet, oldest first
   bool open = false;                 // prof_begin recorded, prof_end pending
   std::map<int, double> ms, flops, count;
   std::map<int, double> max_ms, max_flops;   // the longest single launch of each family and its algorithmic flops
+  struct Shape { double ms = 0.0, flops = 0.0, count = 0.0; };
+  std::map<std::string, Shape> shapes;       // GEMM launches by operand shape (pgpfa_gemm_shape_report)
 };
 constexpr int TAU_MULTI_MAX = 4;  // candidate points per latent in one batched timescale cost/gradient pass
 constexpr int PACC_SPLITS = 64;   // split-K groups of the sum-only vsmGP product
@@ -246,6 +248,7 @@ void prof_harvest(Prof& P, bool all) {
       P.flops[r.tag] += r.flops;
       P.count[r.tag] += 1;
       if (ms > P.max_ms[r.tag]) { P.max_ms[r.tag] = ms; P.max_flops[r.tag] = r.flops; }
+      if (!r.shape.empty()) { Prof::Shape& sh = P.shapes[r.shape]; sh.ms += ms; sh.flops += r.flops; sh.count += 1; }
     }
     P.idle.push_back(r.e0);
     P.idle.push_back(r.e1);
@@ -268,7 +271,7 @@ void prof_begin(pgpfa_ctx* c, int tag, double flops) {
   Prof& P = c->prof;
   if (!P.on || (P.only_tag >= 0 && tag != P.only_tag)) return;
   if (P.recs.size() >= 256 && (P.recs.size() & 63) == 0) prof_harvest(P, false);
-  Prof::Rec r{tag, prof_event(P), prof_event(P), flops};
+  Prof::Rec r{tag, prof_event(P), prof_event(P), flops, std::string()};
   hipEventRecord(r.e0, c->st);
   P.recs.push_back(r);
   P.open = true;
@@ -311,6 +314,13 @@ double gemm_flops(const GemmP& g) {
 // (f32: operands are single precision - pointers carried as double*, strides in elements - on the FP32 matrix cores; no split-K)
 int gemm(pgpfa_ctx* c, bool transb, GemmP g, bool f32 = false) {
   prof_begin(c, TAG_GEMM, gemm_flops(g));
+  if (c->prof.on && c->prof.open) {
+    char key[160];
+    std::snprintf(key, sizeof key, "%s %s M=%d N=%d K=%d%s batch=%d%s%s%s", f32 ? "f32" : "f64", transb ? "NT" : "NN", g.M, g.N, g.K,
+                  g.kseg ? " (segmented)" : "", std::max(g.nbatch, 1), g.mode == GEMM_LOWER ? " lower" : "",
+                  g.kflags ? " triangular-k" : "", g.krange ? " block-sparse" : "");
+    c->prof.recs.back().shape = key;
+  }
   // Few output tiles and a long k loop (the thin multi-RHS products of the PCG iterations): the launch would occupy a
   // fraction of the 256 CUs for the length of one k loop.  Cut k into parts run as extra batch entries, sum the
   // partial products afterwards.
@@ -3480,6 +3490,28 @@ int pgpfa_bench_syrk(pgpfa_ctx* c, int batch, int n, int k, int reps, double* ms
   while (c->allocs.size() > mark) { hipFree(c->allocs.back()); c->allocs.pop_back(); }
   if (rc) return fail("syrk bench launch failed");
   return 0;
+}
+
+// GEMM launches since the profile was switched on (option "profile" = 1 or 2), grouped by operand shape: one text line per shape, longest
+// total first - launches, total ms, algorithmic GFLOP, TFLOP/s.  Returns the number of bytes the full report needs (incl. the terminator).
+int pgpfa_gemm_shape_report(pgpfa_ctx* c, char* buf, int len) {
+  if (!c || (len > 0 && !buf)) { fail("null argument"); return -1; }
+  prof_collect(c);
+  std::vector<std::pair<std::string, Prof::Shape>> v(c->prof.shapes.begin(), c->prof.shapes.end());
+  std::sort(v.begin(), v.end(), [](const auto& a, const auto& b) { return a.second.ms > b.second.ms; });
+  std::string out;
+  char line[256];
+  for (const auto& kv : v) {
+    std::snprintf(line, sizeof line, "%-74s n=%6.0f  %9.2f ms  %10.1f GFLOP  %6.1f TFLOP/s\n", kv.first.c_str(), kv.second.count, kv.second.ms,
+                  kv.second.flops * 1e-9, kv.second.ms > 0.0 ? kv.second.flops / kv.second.ms * 1e-9 : 0.0);
+    out += line;
+  }
+  if (len > 0) {
+    const size_t n = std::min(out.size(), (size_t)len - 1);
+    std::memcpy(buf, out.data(), n);
+    buf[n] = 0;
+  }
+  return (int)out.size() + 1;
 }
 
 // Phase timings of the diagonal-block kernel: `batch` well-conditioned 128 x 128 blocks, phases = 0 (load / store only), 1 (+ Cholesky

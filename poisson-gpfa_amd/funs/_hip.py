@@ -67,6 +67,7 @@ _SIGNATURES = {
     'pgpfa_test_gemm_nn_f32': [ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, ct.c_double, c_double_p, c_double_p, ct.c_double, c_double_p],
     'pgpfa_bench_syrk': [ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, ct.c_int, c_double_p, c_double_p],
     'pgpfa_bench_potrf_diag': [ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, c_double_p],
+    'pgpfa_gemm_shape_report': [ct.c_void_p, ct.c_char_p, ct.c_int],
     'pgpfa_bench_mfma_peak': [ct.c_void_p, ct.c_int, c_double_p],
 }
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ['pgpfa_last_error'])
@@ -437,6 +438,15 @@ class Context:
         tf = ct.c_double(0.0)
         check(self.lib.pgpfa_bench_mfma_peak(self.h, int(iters), ct.byref(tf)))
         return tf.value
+
+    def gemm_shape_report(self):
+        """Text table of the GEMM launches timed since set_option('profile', 1 | 2), grouped by operand shape."""
+        need = self.lib.pgpfa_gemm_shape_report(self.h, None, 0)
+        if need < 0:
+            check(1)
+        buf = ct.create_string_buffer(max(need, 1))
+        self.lib.pgpfa_gemm_shape_report(self.h, buf, need)
+        return buf.value.decode()
 
     def bench_potrf_diag(self, batch, reps=50, phases=3):
         us = ct.c_double()
