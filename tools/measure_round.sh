@@ -6,7 +6,7 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
 python bench.py --steps 20 --warmup 5 > $O/bench_c3_driver_protocol.json 2> $O/bench_c3.err
-python bench.py --config c2 --steps 10 --warmup 2 > $O/bench_c2.json 2>/dev/null
+python bench.py --config c2 --steps 20 --warmup 5 > $O/bench_c2.json 2>/dev/null
 python bench.py --config c1 --steps 20 --warmup 2 --no-cpu-baseline > $O/bench_c1.json 2>/dev/null
 python bench.py --workload online --steps 6 --warmup 2 > $O/bench_c4_online.json 2>/dev/null
 python bench.py --workload dual --config c5 --trials 256 --steps 6 --warmup 1 > $O/bench_c5_dual_mixed.json 2>/dev/null
@@ -15,6 +15,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -o ks -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --lean > $O/bench_c3_under_rocprof.json 2>/dev/null
 cd $R
 python tools/gemm_by_grid.py $O/ks > $O/kernels_by_grid.txt
+python tools/trace_gaps.py $O/ks > $O/trace_gaps.txt
 find $O/ks -name '*kernel_stats.csv' -exec cp {} $O/kernel_stats.csv \;
 rm -rf $O/ks
 cd /tmp
@@ -23,4 +24,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o
 cd $R
 python tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/pmc_hbm_traffic.json | head -8
 rm -rf $O/pmc_fetch $O/pmc_write
+python tools/gemm_shapes.py 12 > $O/gemm_shapes.txt 2>/dev/null
+python tools/potrf_probe.py > $O/potrf_phases.txt 2>/dev/null
+python tools/cold_start_probe.py > $O/cold_start.txt 2>/dev/null
 ls -la $O
