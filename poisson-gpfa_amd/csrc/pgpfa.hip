@@ -316,7 +316,7 @@ int gemm(pgpfa_ctx* c, bool transb, GemmP g, bool f32 = false) {
   prof_begin(c, TAG_GEMM, gemm_flops(g));
   if (c->prof.on && c->prof.open) {
     char key[160];
-    std::snprintf(key, sizeof key, "%s %s M=%d N=%d K=%d%s batch=%d%s%s%s", f32 ? "f32" : "f64", transb ? "NT" : "NN", g.M, g.N, g.K,
+    std::snprintf(key, sizeof key, "%s %s M=%d N=%d K=%d%s batch=%d%s%s%s", f32 ? "f32" : "f64", transb ? "NN" : "NT", g.M, g.N, g.K,
                   g.kseg ? " (segmented)" : "", std::max(g.nbatch, 1), g.mode == GEMM_LOWER ? " lower" : "",
                   g.kflags ? " triangular-k" : "", g.krange ? " block-sparse" : "");
     c->prof.recs.back().shape = key;

@@ -85,6 +85,22 @@ def test_potrf_rejects_indefinite(small_ctx, hip):
         small_ctx.test_potrf(A)
 
 
+def test_profiling_entry_points(small_ctx):
+    """The measurement helpers of the C-ABI: phase timings of the diagonal-block kernel and the per-shape GEMM report."""
+    t0, t1, t3 = (small_ctx.bench_potrf_diag(4, 3, ph) for ph in (0, 1, 3))
+    assert 0.0 < t0 < t1 < t3 < 1e4                                   # microseconds: load/store < + Cholesky steps < + inverse
+    rng = np.random.default_rng(5)
+    A, B = rng.standard_normal((130, 80)), rng.standard_normal((80, 90))
+    small_ctx.set_option('profile', 2)
+    try:
+        C = small_ctx.test_gemm_nn(A, B)
+        rep = small_ctx.gemm_shape_report()
+    finally:
+        small_ctx.set_option('profile', 0)
+    assert rel(C, A @ B) <= 1e-13 * 80
+    assert 'f64 NN M=130 N=90' in rep and 'TFLOP/s' in rep
+
+
 def test_gram_and_inverse(hip, c1):
     g = load_golden('c1_callbacks.npz')
     ctx = hip.Context(30, 3, 100, 20, c1['binSize'])
