@@ -595,7 +595,7 @@ __global__ void dense_h_kernel(double* __restrict__ out, int n, int T, int Tp, i
 template <int PMAX, typename TIN = double>
 __global__ __launch_bounds__(PMAX == 24 ? 768 : 1024) void post_vsm_kernel(const TIN* __restrict__ Mt, long long sM, int ld, int npad, int T, int p,
                                 double* __restrict__ vsm, const int* __restrict__ slots, const int* __restrict__ trial_of_slot,
-                                int full_range) {
+                                int full_range, int ts) {      // ts: row stride between latents in the panel (T, or the padded stride of the low-rank slab)
   constexpr int NK = (PMAX > 16) ? 2 : 1;
   constexpr int VIC = (PMAX <= 8) ? 16 : (PMAX <= 16 ? 8 : 4);   // 64 KB of LDS at most (49 KB at PMAX = 24)
   __shared__ double A[VIC][PMAX][64];
@@ -618,7 +618,7 @@ __global__ __launch_bounds__(PMAX == 24 ? 768 : 1024) void post_vsm_kernel(const
     for (int j = 0; j < NK; ++j) {
       const int k = ty + j * KY;
       if (k < p) {
-        const int row = k * T + t;
+        const int row = k * ts + t;
 #pragma unroll
         for (int ii = 0; ii < VIC; ++ii) A[ii][k][tx] = valid ? (double)M[(size_t)(i0 + ii) * ld + row] : 0.0;
       }
@@ -666,7 +666,7 @@ template <int NRT, typename TIN>
 __global__ __launch_bounds__(512) void post_vsm_mfma_kernel(const TIN* __restrict__ Mt, long long sM, int ld, int ncol, int T, int p,
                                                             double* __restrict__ vsm, const int* __restrict__ slots,
                                                             const int* __restrict__ trial_of_slot, int full_range, int CB,
-                                                            const int* __restrict__ roff, int col_tile) {
+                                                            const int* __restrict__ roff, int col_tile, int ts) {
   // roff (may be null): rank offsets of the latents; rows (k, .) of the panel are identically zero - and were not written - left of
   // column (roff[k] / col_tile) * col_tile (see the Yt product of the low-rank engine)
   constexpr int LT = 33, MAXPF = 12, NACC = NRT == 1 ? 1 : 3;
@@ -691,12 +691,12 @@ __global__ __launch_bounds__(512) void post_vsm_mfma_kernel(const TIN* __restric
     const int b = row / p, k = row - b * p;
     cb_of[j] = (e < per_chunk) ? b : -1;
     c0_of[j] = roff ? (roff[k] / col_tile) * col_tile : 0;
-    off_of[j] = (size_t)b * ld + (size_t)k * T + ttc;
+    off_of[j] = (size_t)b * ld + (size_t)k * ts + ttc;
     lds_of[j] = row * LT + tt;
   }
   // (an element outside the written part of the panel is read from one fixed written location instead: the loads stay
   // unconditional - issued back to back - and the unwritten columns cost no traffic)
-  const size_t off_dummy = (size_t)(ncol - 1) * ld + (size_t)(p - 1) * T;
+  const size_t off_dummy = (size_t)(ncol - 1) * ld + (size_t)(p - 1) * ts;
   TIN pf[MAXPF];
   auto issue = [&](int i0) {
 #pragma unroll
@@ -2232,9 +2232,9 @@ template <int PW>
 __global__ __launch_bounds__(256) void mix_vsm_kernel(double* __restrict__ Yt, long long sY, int ldy, const double* __restrict__ G, long long sG,
                                                       int T, int p, int rpad, double eps, double* __restrict__ vsm,
                                                       const int* __restrict__ slots, const int* __restrict__ trial_of_slot,
-                                                      const int* __restrict__ roff, int col_tile) {
+                                                      const int* __restrict__ roff, int col_tile, int ts) {
   // roff (may be null): rank offsets of the latents; rows (k,.) of Yt are identically zero - and were not written - left of
-  // column (roff[k] / col_tile) * col_tile (the factor L^-T is upper triangular)
+  // column (roff[k] / col_tile) * col_tile (the factor L^-T is upper triangular).  ts: row stride between latents in the slab (>= T)
   constexpr int PP = PW * PW, LD = PP + 1, NPAIR = PW * (PW + 1) / 2;
   __shared__ double Gs[64 * LD];
   const int pp = p * p;
@@ -2268,14 +2268,14 @@ __global__ __launch_bounds__(256) void mix_vsm_kernel(double* __restrict__ Yt, l
       if constexpr (PW > 10) asm volatile("" ::: "memory");
       double v[PW], m[PW];
 #pragma unroll
-      for (int k = 0; k < PW; ++k) v[k] = (k < p && b >= c0[k]) ? y[(size_t)b * ldy + (size_t)k * T] : 0.0;
+      for (int k = 0; k < PW; ++k) v[k] = (k < p && b >= c0[k]) ? y[(size_t)b * ldy + (size_t)k * ts] : 0.0;
 #pragma unroll
       for (int k = 0; k < PW; ++k) {
         double s2 = 0.0;
 #pragma unroll
         for (int kk = 0; kk < PW; ++kk) s2 += g[k * PW + kk] * v[kk];
         m[k] = s2;
-        if (k < p) y[(size_t)b * ldy + (size_t)k * T] = s2;
+        if (k < p) y[(size_t)b * ldy + (size_t)k * ts] = s2;
       }
 #pragma unroll
       for (int a = 0; a < PW; ++a)
@@ -2429,7 +2429,7 @@ __global__ void apply_bin_wide_kernel(const double* __restrict__ Gb, const doubl
 // Thread (bin, a) owns row a of the accumulated block (columns c <= a).  grid = (ceil(T/bins), nslots), block = bins*32
 __global__ void mix_vsm_wide_kernel(double* __restrict__ Yt, long long sY, int ldy, const double* __restrict__ G, long long sG, int T, int p,
                                     int rpad, double eps, double* __restrict__ vsm, const int* __restrict__ slots,
-                                    const int* __restrict__ trial_of_slot, int bins) {
+                                    const int* __restrict__ trial_of_slot, int bins, int ts) {
   extern __shared__ double wsm[];
   const int pp = p * p, LD = pp + 1;
   double* Gs = wsm;
@@ -2450,7 +2450,7 @@ __global__ void mix_vsm_wide_kernel(double* __restrict__ Yt, long long sY, int l
   double acc[WIDE_MAX];
 #pragma unroll
   for (int c2 = 0; c2 < WIDE_MAX; ++c2) acc[c2] = 0.0;
-  double* y = Yt + (size_t)slot * sY + (size_t)a * T + t0 + bt;
+  double* y = Yt + (size_t)slot * sY + (size_t)a * ts + t0 + bt;
   for (int b = 0; b < rpad; ++b) {
     if (live) vs[bt * WIDE_MAX + a] = y[(size_t)b * ldy];
     __syncthreads();

@@ -113,6 +113,7 @@ struct pgpfa_ctx {
   bool dual_lowrank = false;                    // dual-variational entry points may use the low-rank engine (no diagonal jitter)
   double* dual_tbl = nullptr; int dual_ncol = 0, dual_npd = 0; bool dual_gemm = true;   // pair / loading table of the GEMM form (dual.h)
   bool vsm_mfma = true;                         // per-bin Gram blocks (post_vsm) on the matrix cores beyond 10 latents
+  bool slab_row_align = true;                   // latent row stride of the Yt slab rounded up to 16 rows (128-byte lines)
   int dual_f32 = 0;                             // ... with the r x r factorisation, its inverse and Yt in single precision (mixed)
   float* Flr32 = nullptr; bool flr32_valid = false;   // single-precision copy of the low-rank factors
   bool keep_trial_vsmgp = false;
@@ -668,23 +669,24 @@ inline int poisson_rows(int p) { return p <= 16 ? p : (p <= 20 ? 10 : 16); }
 // post_vsm[t] = Gram of the rows (., t) of the panel Mt (ncol columns, column stride ld) for ns slots: matrix-core kernel beyond 10
 // latents, vector kernel up to 10.  (f32: the panel is single precision)
 template <typename TIN>
-void launch_post_vsm(pgpfa_ctx* c, const TIN* Mt, long long sM, int ncol, int ns, int full_range, const int* roff = nullptr) {
+void launch_post_vsm(pgpfa_ctx* c, const TIN* Mt, long long sM, int ncol, int ns, int full_range, const int* roff = nullptr, int ts = 0) {
   const int T = c->T, p = c->p;
+  if (ts <= 0) ts = T;                                       // row stride between latents in the panel
   if (p > 10 && c->vsm_mfma) {
     const int CB = post_vsm_mfma_cb(p);
     const size_t lds = (size_t)CB * p * 33 * sizeof(double);
     if (p <= 16)
       hipLaunchKernelGGL((post_vsm_mfma_kernel<1, TIN>), dim3((T + 31) / 32, ns), dim3(512), lds, c->st, Mt, sM, c->ld, ncol, T, p, c->vsm, c->ident,
-                         c->trial_of_slot, full_range, CB, roff, (int)GBN);
+                         c->trial_of_slot, full_range, CB, roff, (int)GBN, ts);
     else
       hipLaunchKernelGGL((post_vsm_mfma_kernel<2, TIN>), dim3((T + 31) / 32, ns), dim3(512), lds, c->st, Mt, sM, c->ld, ncol, T, p, c->vsm, c->ident,
-                         c->trial_of_slot, full_range, CB, roff, (int)GBN);
+                         c->trial_of_slot, full_range, CB, roff, (int)GBN, ts);
     return;
   }
   const int KY = post_vsm_rows(p);
   dispatch_pmax(p, [&](auto pm) {
     hipLaunchKernelGGL((post_vsm_kernel<decltype(pm)::value, TIN>), dim3((T + 63) / 64, ns), dim3(64, KY), 0, c->st, Mt, sM, c->ld, ncol, T, p, c->vsm,
-                       c->ident, c->trial_of_slot, full_range);
+                       c->ident, c->trial_of_slot, full_range, ts);
   });
 }
 
@@ -1015,6 +1017,7 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
   else if (k == "keep_trial_vsmgp") c->keep_trial_vsmgp = (v != 0.0);
   else if (k == "dual_lowrank") c->dual_lowrank = (v != 0.0);
   else if (k == "dual_f32") c->dual_f32 = (int)v;
+  else if (k == "slab_row_align") c->slab_row_align = (v != 0.0);
   else if (k == "vsm_mfma") c->vsm_mfma = (v != 0.0);
   else if (k == "dual_gemm") c->dual_gemm = (v != 0.0);
   else if (k == "extrapolate_start") c->extrapolate = (v != 0.0);
@@ -1477,6 +1480,9 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool 
   // the same offsets and takes those entries as zeros without reading them (the mixing pass up to 16 latents, the matrix-core post_vsm
   // beyond 10) the product skips the whole 128-column tiles left of it: ~45 % of the flops and stores.
   const bool skip_zero_cols = want_vsmgp ? p <= 16 : (p > 10 && c->vsm_mfma);
+  // rows (k, t) of the Yt slab sit at k * Ts + t with Ts = T rounded up to 16 when the slab is tall enough: the 64-bin runs of the mixing pass and
+  // the product's stores then start on 128-byte lines (at T = 500 every run straddled one: 1.4x the bytes fetched, PMC)
+  const int Ts = (c->slab_row_align && p * round_up(T, 16) <= c->ld) ? round_up(T, 16) : T;
   CholWS lwf = lw;                                         // single-precision views: B / L in the Mt slabs, L^-T and Yt in the H slabs
   float* Ytf = nullptr;
   if (f32) {
@@ -1538,14 +1544,14 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool 
       GemmP g{};
       g.A = reinterpret_cast<const double*>(c->Flr32 + (size_t)k * Tp * Tp); g.sA = 0; g.lda = Tp;
       g.B = reinterpret_cast<const double*>(reinterpret_cast<float*>(lwf.Mt) + c->roff[k] + (size_t)c0 * rpad); g.sB = lwf.sM; g.ldb = rpad;
-      g.C = reinterpret_cast<double*>(Ytf + (size_t)k * T + (size_t)c0 * c->ld); g.sC = lwf.sM; g.ldc = c->ld;
+      g.C = reinterpret_cast<double*>(Ytf + (size_t)k * Ts + (size_t)c0 * c->ld); g.sC = lwf.sM; g.ldc = c->ld;
       g.M = T; g.N = ract - c0; g.K = c->rk[k]; g.alpha = 1.0; g.beta = 0.0;
       g.slots = c->ident; g.nbatch = nb; g.mode = GEMM_FULL; g.kflags = 0;
       CHK(gemm(c, true, g, true));
     }
     if (p > WIDE_MAX) return fail("low-rank covariance engine supports up to %d latents (p=%d)", WIDE_MAX, p);
     prof_begin(c, TAG_VSM, (double)nb * c->n * rpad * p);
-    launch_post_vsm(c, (const float*)Ytf, (long long)lwf.sM, ract, nb, 1, skip_zero_cols ? c->d_roff : nullptr);
+    launch_post_vsm(c, (const float*)Ytf, (long long)lwf.sM, ract, nb, 1, skip_zero_cols ? c->d_roff : nullptr, Ts);
     prof_end(c);
     dispatch_pw(p, [&](auto pw) {
       constexpr int PW = decltype(pw)::value;
@@ -1573,7 +1579,7 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool 
     GemmP g{};
     g.A = c->Flr + (size_t)k * Tp * Tp; g.sA = 0; g.lda = Tp;
     g.B = lw.Mt + c->roff[k] + (size_t)c0 * rpad; g.sB = lw.sM; g.ldb = rpad;     // rows roff[k].. of Mts, K x N column-major
-    g.C = lw.H + (size_t)k * T + (size_t)c0 * c->ld; g.sC = lw.sH; g.ldc = c->ld;
+    g.C = lw.H + (size_t)k * Ts + (size_t)c0 * c->ld; g.sC = lw.sH; g.ldc = c->ld;
     g.M = T; g.N = ract - c0; g.K = c->rk[k]; g.alpha = 1.0; g.beta = 0.0;
     g.slots = c->ident; g.nbatch = nb; g.mode = GEMM_FULL; g.kflags = 0;
     CHK(gemm(c, true, g));
@@ -1587,18 +1593,18 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool 
       constexpr int PW = decltype(pw)::value;
       if constexpr (PW <= 16) {
         hipLaunchKernelGGL(mix_vsm_kernel<PW>, dim3((T + 63) / 64, nb), dim3(256), 0, c->st, lw.H, lw.sH, c->ld, c->Gbin, sW, T, p, ract, c->eps,
-                           c->vsm, c->ident, c->trial_of_slot, c->d_roff, (int)GBN);
+                           c->vsm, c->ident, c->trial_of_slot, c->d_roff, (int)GBN, Ts);
       } else {
         const int bins = wide_bins(p);
         hipLaunchKernelGGL(mix_vsm_wide_kernel, dim3((T + bins - 1) / bins, nb), dim3(bins * 32), wide_lds_bytes(p, bins, 1), c->st, lw.H, lw.sH,
-                           c->ld, c->Gbin, sW, T, p, ract, c->eps, c->vsm, c->ident, c->trial_of_slot, bins);
+                           c->ld, c->Gbin, sW, T, p, ract, c->eps, c->vsm, c->ident, c->trial_of_slot, bins, Ts);
       }
     });
     prof_end(c);
   } else {
     // d. post_vsm[t] = eps G_t + G_t (Y_t^T Y_t) G_t
     prof_begin(c, TAG_VSM, (double)nb * c->n * rpad * p);
-    launch_post_vsm(c, (const double*)lw.H, (long long)lw.sH, ract, nb, 1, skip_zero_cols ? c->d_roff : nullptr);
+    launch_post_vsm(c, (const double*)lw.H, (long long)lw.sH, ract, nb, 1, skip_zero_cols ? c->d_roff : nullptr, Ts);
     prof_end(c);
     dispatch_pw(p, [&](auto pw) {
       constexpr int PW = decltype(pw)::value;
@@ -1627,7 +1633,7 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool 
         g.C = c->ppart + (size_t)part_first * T * T; g.sC = (long long)T * T; g.ldc = T;
         g.M = T; g.N = T; g.K = slots_per * ract; g.alpha = 1.0; g.beta = 0.0;
         g.slots = nullptr; g.nb_lo = ngroups; g.nbatch = ngroups * p;
-        g.sA_hi = T; g.sB_hi = T; g.sC_hi = (long long)nsplit * T * T;
+        g.sA_hi = Ts; g.sB_hi = Ts; g.sC_hi = (long long)nsplit * T * T;
         g.kseg = ract; g.sAseg = lw.sH; g.sBseg = lw.sH;    // ract columns of each slab, slabs sH apart
         g.mode = GEMM_LOWER; g.kflags = 0;
         return gemm(c, false, g);
@@ -1641,7 +1647,7 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool 
       const size_t off_stage = (size_t)c->ld * rpad + (size_t)Tp * rpad;
       for (int k = 0; k < p; ++k) {
         GemmP g{};
-        g.A = lw.H + (size_t)k * T; g.sA = lw.sH; g.lda = c->ld;
+        g.A = lw.H + (size_t)k * Ts; g.sA = lw.sH; g.lda = c->ld;
         g.B = g.A; g.sB = lw.sH; g.ldb = c->ld;
         g.C = lw.H + off_stage; g.sC = lw.sH; g.ldc = T;
         g.M = T; g.N = T; g.K = ract; g.alpha = 1.0; g.beta = 0.0;
