@@ -1737,56 +1737,66 @@ __global__ __launch_bounds__(256) void step_stats_kernel(const double* __restric
 // and every O(n^3) step of the covariance phase becomes O(T r^2) / O(r^3), r = sum_k r_k << n = pT.
 // --------------------------------------------------------------------------------------------------
 
-// Pivoted Cholesky of (1-eps)*RBF_k, one workgroup per latent.  F: [p][Tf x Tf] column-major slabs
+// Pivoted Cholesky of (1-eps)*RBF_k, one workgroup of NT threads per latent.  F: [p][Tf x Tf] column-major slabs
 // (column j of latent k at F + k*Tf*Tf + j*Tf), rows >= T and unused columns are zero.  rank[k] out.
-__global__ __launch_bounds__(256) void rbf_pivchol_kernel(double* __restrict__ F, int Tf, int T, const double* __restrict__ tau, double bin,
-                                                          double eps, double tol, int rmax, int* __restrict__ rank) {
-  extern __shared__ double sh[];              // d[T] | frow[rmax] | red_val[256] ; then int red_idx[256]
+// A step = pivot search (wave shuffles, one barrier), row `piv` of the factor so far into LDS, then every bin's new entry
+// v_t = (K[t][piv] - sum_m F[m][t] F[m][piv]) / sqrt(d_piv): the columns of F are read back from memory (L2), eight independent
+// partial sums so that sixteen loads are in flight per thread - the step is bound by that latency, not by its j T multiply-adds.
+// dynamic LDS = (T + rmax + NT / 64) doubles + NT / 64 ints.
+template <int NT>
+__global__ __launch_bounds__(NT) void rbf_pivchol_kernel(double* __restrict__ F, int Tf, int T, const double* __restrict__ tau, double bin,
+                                                         double eps, double tol, int rmax, int* __restrict__ rank) {
+  constexpr int NW = NT / 64;
+  extern __shared__ double sh[];              // d[T] | frow[rmax] | wave maxima [NW] ; then int wave argmax [NW]
   double* d = sh;
   double* frow = sh + T;
   double* rv = frow + rmax;
-  int* ri = reinterpret_cast<int*>(rv + 256);
-  __shared__ int piv_s;
-  __shared__ double dpiv_s;
-  const int k = blockIdx.x, tid = threadIdx.x;
+  int* ri = reinterpret_cast<int*>(rv + NW);
+  const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double* Fk = F + (size_t)k * Tf * Tf;
   const double den = (tau[k] * 1000.0) * (tau[k] * 1000.0);
-  for (size_t e = tid; e < (size_t)Tf * Tf; e += 256) Fk[e] = 0.0;
-  for (int t = tid; t < T; t += 256) d[t] = 1.0 - eps;
+  for (size_t e = tid; e < (size_t)Tf * Tf; e += NT) Fk[e] = 0.0;
+  for (int t = tid; t < T; t += NT) d[t] = 1.0 - eps;
   __syncthreads();
   int j = 0;
   for (; j < rmax; ++j) {
-    double best = -1.0; int bi = 0;
-    for (int t = tid; t < T; t += 256) if (d[t] > best) { best = d[t]; bi = t; }
-    rv[tid] = best; ri[tid] = bi;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if (tid < o && (rv[tid + o] > rv[tid] || (rv[tid + o] == rv[tid] && ri[tid + o] < ri[tid]))) { rv[tid] = rv[tid + o]; ri[tid] = ri[tid + o]; }
-      __syncthreads();
+    // largest remaining diagonal entry, lowest index on ties
+    double best = -1.0; int bi = 0x7fffffff;
+    for (int t = tid; t < T; t += NT) if (d[t] > best) { best = d[t]; bi = t; }
+    for (int off = 32; off > 0; off >>= 1) {
+      const double ob = __shfl_down(best, off);
+      const int oi = __shfl_down(bi, off);
+      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
     }
-    if (tid == 0) { piv_s = ri[0]; dpiv_s = rv[0]; }
+    if (lane == 0) { rv[wave] = best; ri[wave] = bi; }
     __syncthreads();
-    const int piv = piv_s;
-    const double dp = dpiv_s;
-    if (!(dp > tol)) break;
-    for (int m = tid; m < j; m += 256) frow[m] = Fk[(size_t)m * Tf + piv];
+    double dp = rv[0]; int piv = ri[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w)
+      if (rv[w] > dp || (rv[w] == dp && ri[w] < piv)) { dp = rv[w]; piv = ri[w]; }
+    if (!(dp > tol)) break;                                         // (uniform: every thread reads the same LDS values)
+    for (int m = tid; m < j; m += NT) frow[m] = Fk[(size_t)m * Tf + piv];
     __syncthreads();
     const double rs = 1.0 / sqrt(dp);
-    for (int t = tid; t < T; t += 256) {
+    for (int t = tid; t < T; t += NT) {
       const double dt = (double)t * bin - (double)piv * bin;
       double v = (1.0 - eps) * exp(-0.5 * ((dt * dt) / den));
-      // (four independent partial sums: the loads of consecutive columns then overlap instead of queueing behind one FMA chain)
-      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s5 = 0.0, s6 = 0.0, s7 = 0.0;
+      const double* col = Fk + t;
       int m = 0;
 #pragma unroll 2
-      for (; m + 3 < j; m += 4) {
-        s0 += Fk[(size_t)m * Tf + t] * frow[m];
-        s1 += Fk[(size_t)(m + 1) * Tf + t] * frow[m + 1];
-        s2 += Fk[(size_t)(m + 2) * Tf + t] * frow[m + 2];
-        s3 += Fk[(size_t)(m + 3) * Tf + t] * frow[m + 3];
+      for (; m + 7 < j; m += 8) {
+        s0 += col[(size_t)m * Tf] * frow[m];
+        s1 += col[(size_t)(m + 1) * Tf] * frow[m + 1];
+        s2 += col[(size_t)(m + 2) * Tf] * frow[m + 2];
+        s3 += col[(size_t)(m + 3) * Tf] * frow[m + 3];
+        s4 += col[(size_t)(m + 4) * Tf] * frow[m + 4];
+        s5 += col[(size_t)(m + 5) * Tf] * frow[m + 5];
+        s6 += col[(size_t)(m + 6) * Tf] * frow[m + 6];
+        s7 += col[(size_t)(m + 7) * Tf] * frow[m + 7];
       }
-      for (; m < j; ++m) s0 += Fk[(size_t)m * Tf + t] * frow[m];
-      v -= (s0 + s1) + (s2 + s3);
+      for (; m < j; ++m) s0 += col[(size_t)m * Tf] * frow[m];
+      v -= ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
       v *= rs;
       Fk[(size_t)j * Tf + t] = v;
       d[t] = (t == piv) ? 0.0 : d[t] - v * v;
