@@ -811,14 +811,19 @@ __global__ void pacc_reduce_kernel(const double* __restrict__ part, int nsplit, 
   const int k = blockIdx.y, b = blockIdx.x;
   double* P = Pacc + (size_t)k * Tp * Tp;
   const double* src = part + (size_t)k * nsplit * T * T + (size_t)b * T;
+  // diagonal term sum_slots G_b[k][k]: the slots are spread over the block (one thread walking ~1000 slabs in turn set the time of the
+  // whole launch), summed in a fixed order: lanes, then waves
+  __shared__ double gred[2];
+  double g = 0.0;
+  for (int sl = threadIdx.x; sl < nslots; sl += blockDim.x) g += G[(size_t)sl * sG + (size_t)b * p * p + (size_t)k * p + k];
+  for (int off = 32; off > 0; off >>= 1) g += __shfl_down(g, off);
+  if ((threadIdx.x & 63) == 0) gred[threadIdx.x >> 6] = g;
+  __syncthreads();
+  const double gdiag = gred[0] + gred[1];
   for (int a = b + threadIdx.x; a < T; a += blockDim.x) {
     double s = 0.0;
     for (int i = 0; i < nsplit; ++i) s += src[(size_t)i * T * T + a];
-    if (a == b) {
-      double g = 0.0;
-      for (int sl = 0; sl < nslots; ++sl) g += G[(size_t)sl * sG + (size_t)a * p * p + (size_t)k * p + k];
-      s += eps * g;
-    }
+    if (a == b) s += eps * gdiag;
     P[(size_t)b * Tp + a] += s;
     if (a != b) P[(size_t)a * Tp + b] += s;
   }

@@ -55,14 +55,28 @@ __global__ __launch_bounds__(256) void cd_ym_kernel(const uint8_t* __restrict__ 
           const int k = e >> 6, t = e & 63;
           ms[k][t] = (t < tn) ? mean[(r * p + k) * T + t0 + t] : 0.0;
         }
-        for (int e = threadIdx.x; e < nrow * 64; e += 256) {
-          const int row = e >> 6, t = e & 63;
-          const unsigned v = (t < tn) ? Y[(r * q + n0 + row) * T + t0 + t] : 0u;
-          // pack 4 counts per word: lanes t, t+1, t+2, t+3 of a quad
-          unsigned w = v << (8 * (t & 3));
-          w |= __shfl_xor(w, 1);
-          w |= __shfl_xor(w, 2);
-          if ((t & 3) == 0) yt[row][t >> 2] = w;
+        if ((T & 3) == 0) {
+          // rows of counts start on 4-byte boundaries: one word (4 bins) per load
+          for (int e = threadIdx.x; e < nrow * 16; e += 256) {
+            const int row = e >> 4, w4 = e & 15;
+            unsigned w = 0u;
+            if (4 * w4 < tn) {
+              w = *reinterpret_cast<const unsigned*>(Y + (r * q + n0 + row) * T + t0 + 4 * w4);
+              const int left = tn - 4 * w4;                       // bins of this word inside the trial (T % 4 == 0: 4, always)
+              if (left < 4) w &= (1u << (8 * left)) - 1u;
+            }
+            yt[row][w4] = w;
+          }
+        } else {
+          for (int e = threadIdx.x; e < nrow * 64; e += 256) {
+            const int row = e >> 6, t = e & 63;
+            const unsigned v = (t < tn) ? Y[(r * q + n0 + row) * T + t0 + t] : 0u;
+            // pack 4 counts per word: lanes t, t+1, t+2, t+3 of a quad
+            unsigned w = v << (8 * (t & 3));
+            w |= __shfl_xor(w, 1);
+            w |= __shfl_xor(w, 2);
+            if ((t & 3) == 0) yt[row][t >> 2] = w;
+          }
         }
         __syncthreads();
         if (n < q) {
