@@ -1558,9 +1558,21 @@ __global__ void mean_w_kernel(const double* __restrict__ W, long long sW, const 
                               double* __restrict__ out) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= len) return;
-  double s = 0.0;
-  for (int i = 0; i < nslots; ++i) s += W[(size_t)slots[i] * sW + e];
-  out[e] = s / (double)nslots;
+  // (eight independent partial sums: the slots' loads are in flight together; one running sum made the launch latency-bound)
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s5 = 0.0, s6 = 0.0, s7 = 0.0;
+  int i = 0;
+  for (; i + 7 < nslots; i += 8) {
+    s0 += W[(size_t)slots[i] * sW + e];
+    s1 += W[(size_t)slots[i + 1] * sW + e];
+    s2 += W[(size_t)slots[i + 2] * sW + e];
+    s3 += W[(size_t)slots[i + 3] * sW + e];
+    s4 += W[(size_t)slots[i + 4] * sW + e];
+    s5 += W[(size_t)slots[i + 5] * sW + e];
+    s6 += W[(size_t)slots[i + 6] * sW + e];
+    s7 += W[(size_t)slots[i + 7] * sW + e];
+  }
+  for (; i < nslots; ++i) s0 += W[(size_t)slots[i] * sW + e];
+  out[e] = (((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7))) / (double)nslots;
 }
 
 // q = W p  added onto q (which already holds Kinv p):  q[(k,t)] += sum_l W[t][k][l] p[(l,t)], and the partial
