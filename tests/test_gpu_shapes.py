@@ -93,3 +93,40 @@ def test_dual_evaluation_random_shapes(seed, lowrank):
             ref_grad = orc.dual_grad(lam[i], y, C_big, K_big, Kinv_big, d_big)
         assert abs(cost[i] - ref_cost) <= 1e-8 * abs(ref_cost), tag
         assert rel(grad[i], ref_grad) <= 1e-7, tag
+
+
+@pytest.mark.parametrize('q,p,T,R', [(300, 4, 40, 3), (517, 10, 24, 2), (260, 12, 36, 2)])
+def test_mstep_many_neurons(q, p, T, R):
+    """(C,d) M-step passes beyond 256 neurons (several neuron tiles per workgroup pass, the count-term kernel's second sweep): cost,
+    gradient and the device Newton iteration against the oracle."""
+    from funs import _hip
+    _, Ys, _ = orc.synth_dataset(q, p, T, R, seed=q, dOffset=0.0)
+    Y = np.stack(Ys).astype(np.uint8)
+    rng = np.random.default_rng(q)
+    par = {'C': 0.3 * rng.standard_normal((q, p)) / np.sqrt(p), 'd': np.log(Y.mean(axis=(0, 2)) + 0.1), 'tau': 0.05 + 0.2 * rng.random(p)}
+    ctx = _hip.Context(q, p, T, R, 10.0)
+    try:
+        ctx.upload_counts(Y)
+        ctx.set_params(par['C'], par['d'], par['tau'])
+        obj, _, status = ctx.estep_laplace()
+        assert np.all(status == 0)
+        pm, vs = [m for m in ctx.post_mean()], [m for m in ctx.post_vsm()]
+        Yf = [y.astype(float) for y in Ys]
+        v = orc.cd_to_vec(par['C'], par['d']) + 0.01 * rng.standard_normal(q * (p + 1))
+        cost, grad = ctx.mstep_cd_costgrad(v)
+        assert abs(cost - orc.mstep_cd_cost(v, Yf, pm, vs, p, q)) <= 1e-10 * abs(cost)
+        assert rel(grad, orc.mstep_cd_grad(v, Yf, pm, vs, p, q)) <= 1e-9
+        cost_n, delta, dec = ctx.mstep_cd_newton_pass(v)
+        assert abs(cost_n.sum() - cost) <= 1e-10 * abs(cost) and np.all(dec >= 0)
+        g0 = np.max(np.abs(grad))
+        for _ in range(25):                                  # full Newton steps (a nearly silent neuron takes a dozen from 0.01 off)
+            v = v + delta.reshape(-1)
+            cost_n, delta, dec = ctx.mstep_cd_newton_pass(v)
+            if np.max(np.abs(delta)) < 1e-12:
+                break
+        g_end = np.max(np.abs(orc.mstep_cd_grad(v, Yf, pm, vs, p, q)))
+        assert g_end <= 1e-10 * max(1.0, g0), (g_end, g0)
+        cost_c, _, _ = ctx.mstep_cd_chord_pass(v)
+        assert abs(cost_c.sum() - cost_n.sum()) <= 1e-12 * abs(cost_n.sum())
+    finally:
+        ctx.close()
