@@ -233,9 +233,18 @@ __global__ void diag_transpose_kernel_t(T* __restrict__ Mt, long long sM, int ld
   const long long slot = slots ? slots[blockIdx.x] : blockIdx.x;
   T* M = Mt + slot * sM + (size_t)k0 * ld + k0;
   const T* D = Dinv + slot * sD + (size_t)(k0 / NB) * NB * NB;
-  for (int e = threadIdx.x; e < NB * NB; e += blockDim.x) {
-    const int r = e & (NB - 1), c = e >> 7;
-    M[(size_t)c * ld + r] = D[r * NB + c];
+  // 32 x 32 sub-tiles through LDS: reads and writes both run along the contiguous dimension (a direct transposed read touched one
+  // 8-byte word per 1 KB row: 27 us per launch of 1024 blocks).  blockDim.x = 256 = 8 rows of 32 lanes.
+  __shared__ T tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int sub = 0; sub < 16; ++sub) {
+    const int br = (sub & 3) * 32, bc = (sub >> 2) * 32;     // block of D: rows br.., columns bc.. (D[r * NB + c], c contiguous)
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tile[ty + 8 * i][tx] = D[(br + ty + 8 * i) * NB + bc + tx];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) M[(size_t)(bc + ty + 8 * i) * ld + br + tx] = tile[tx][ty + 8 * i];   // M[c][r] = D[r][c]
   }
 }
 
