@@ -417,18 +417,22 @@ int inverse_t(pgpfa_ctx* c, const CholWS& w, const int* slots, int nb, bool f32 
     else
       hipLaunchKernelGGL(diag_transpose_kernel_t<double>, dim3(nb), dim3(256), 0, c->st, w.Mt, w.sM, ld, j0, w.Dinv, w.sD, slots);
     if (j0 == 0) continue;
+    // columns of this block that are not identity padding (na is a multiple of 64): the padding columns of L^-T stay zero above the
+    // diagonal (the slab was cleared), so a half-padded last block costs half
+    const int nbw = std::min(NB, na - j0);
+    if (nbw <= 0) continue;
     GemmP a{};
     a.A = w.Mt; a.sA = w.sM; a.lda = ld;
     a.B = at(w.H, j0); a.sB = w.sH; a.ldb = ld;
     a.C = w.P; a.sC = w.sP; a.ldc = np;
-    a.M = std::min(j0, na); a.N = NB; a.K = j0; a.alpha = 1.0; a.beta = 0.0;
+    a.M = std::min(j0, na); a.N = nbw; a.K = j0; a.alpha = 1.0; a.beta = 0.0;
     a.slots = slots; a.nbatch = nb; a.mode = GEMM_FULL; a.kflags = KF_BEGIN_ROW;
     CHK(gemm(c, false, a, f32));
     GemmP b{};
     b.A = w.P; b.sA = w.sP; b.lda = np;
     b.B = at(w.Dinv, (size_t)(j0 / NB) * NB * NB); b.sB = w.sD; b.ldb = NB;
     b.C = at(w.Mt, (size_t)j0 * ld); b.sC = w.sM; b.ldc = ld;
-    b.M = std::min(j0, na); b.N = NB; b.K = NB; b.alpha = -1.0; b.beta = 0.0;
+    b.M = std::min(j0, na); b.N = nbw; b.K = nbw; b.alpha = -1.0; b.beta = 0.0;
     b.slots = slots; b.nbatch = nb; b.mode = GEMM_FULL; b.kflags = 0;
     CHK(gemm(c, false, b, f32));
   }
