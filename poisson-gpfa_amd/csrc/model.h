@@ -660,8 +660,10 @@ __global__ __launch_bounds__(PMAX == 24 ? 768 : 1024) void post_vsm_kernel(const
 // MFMAs (tiles (0,0), (1,0), (1,1) of the lower triangle).  A block owns 32 bins (128-byte runs of the single-precision panel) of one
 // slot, 8 waves x 4 bins; column chunks of CB are staged in LDS as doubles ([column][latent][bin], bin stride 33), the next chunk's
 // loads in flight in registers during the products.  NRT = row tiles (1 or 2).
-// grid = (ceil(T/32), nslots), block = 512, dynamic LDS = CB * p * 33 doubles with CB = post_vsm_mfma_cb(p).
-inline int post_vsm_mfma_cb(int p) { return p <= 24 ? 8 : 4; }
+// grid = (ceil(T/32), nslots), block = 512, dynamic LDS = CB * p * 33 elements of the panel's type with CB = post_vsm_mfma_cb(p, f32).
+// (the chunk is staged in the panel's own precision and widened when a fragment is read: a single-precision panel takes chunks 1.5x as deep -
+// 12 columns, 32 KB of LDS at 20 latents; 16 would put the staging map and prefetch registers into scratch)
+inline int post_vsm_mfma_cb(int p, bool f32) { return p <= 24 ? (f32 ? 12 : 8) : (f32 ? 8 : 4); }
 template <int NRT, typename TIN>
 __global__ __launch_bounds__(512) void post_vsm_mfma_kernel(const TIN* __restrict__ Mt, long long sM, int ld, int ncol, int T, int p,
                                                             double* __restrict__ vsm, const int* __restrict__ slots,
@@ -669,8 +671,9 @@ __global__ __launch_bounds__(512) void post_vsm_mfma_kernel(const TIN* __restric
                                                             const int* __restrict__ roff, int col_tile, int ts) {
   // roff (may be null): rank offsets of the latents; rows (k, .) of the panel are identically zero - and were not written - left of
   // column (roff[k] / col_tile) * col_tile (see the Yt product of the low-rank engine)
-  constexpr int LT = 33, MAXPF = 12, NACC = NRT == 1 ? 1 : 3;
-  extern __shared__ double sm[];
+  constexpr int LT = 33, MAXPF = sizeof(TIN) == 4 ? 18 : 12, NACC = NRT == 1 ? 1 : 3;   // MAXPF >= CB p / 16: (12, 24) or (8, 32) in FP32
+  extern __shared__ double sm_raw[];
+  TIN* sm = reinterpret_cast<TIN*>(sm_raw);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int slot = slots[blockIdx.y];
   const int trial = trial_of_slot[slot];
@@ -678,21 +681,17 @@ __global__ __launch_bounds__(512) void post_vsm_mfma_kernel(const TIN* __restric
   const int nt = min(32, T - t0);
   const TIN* M = Mt + (size_t)slot * sM + t0;
   const int per_chunk = CB * p * 32;
-  // staging map, the same for every chunk: element e = tid + 512 j -> (column b, latent k, bin tt)
+  // staging map, the same for every chunk: element e = tid + 512 j -> (column b, latent k, bin tt), packed as b | k << 8 | first written
+  // column tile of latent k << 16 (-1: no element)
   const int tt = tid & 31;
   const int ttc = tt < nt ? tt : nt - 1;
-  int cb_of[MAXPF], c0_of[MAXPF];
-  size_t off_of[MAXPF];
-  int lds_of[MAXPF];
+  int map[MAXPF];
 #pragma unroll
   for (int j = 0; j < MAXPF; ++j) {
     const int e = tid + 512 * j;
     const int row = min(e, per_chunk - 1) >> 5;               // b * p + k
     const int b = row / p, k = row - b * p;
-    cb_of[j] = (e < per_chunk) ? b : -1;
-    c0_of[j] = roff ? (roff[k] / col_tile) * col_tile : 0;
-    off_of[j] = (size_t)b * ld + (size_t)k * ts + ttc;
-    lds_of[j] = row * LT + tt;
+    map[j] = (e < per_chunk) ? (b | (k << 8) | ((roff ? roff[k] / col_tile : 0) << 16)) : -1;
   }
   // (an element outside the written part of the panel is read from one fixed written location instead: the loads stay
   // unconditional - issued back to back - and the unwritten columns cost no traffic)
@@ -701,17 +700,20 @@ __global__ __launch_bounds__(512) void post_vsm_mfma_kernel(const TIN* __restric
   auto issue = [&](int i0) {
 #pragma unroll
     for (int j = 0; j < MAXPF; ++j) {
-      const int b = cb_of[j] < 0 ? 0 : cb_of[j];
-      const int col = i0 + b;
-      const bool in = col < ncol && col >= c0_of[j];
-      pf[j] = M[in ? off_of[j] + (size_t)i0 * ld : off_dummy];
+      const int mj = map[j] < 0 ? 0 : map[j];
+      const int col = i0 + (mj & 255), k = (mj >> 8) & 255, c0 = (mj >> 16) * col_tile;
+      const bool in = col < ncol && col >= c0;
+      pf[j] = M[in ? (size_t)col * ld + (size_t)k * ts + ttc : off_dummy];
     }
   };
   auto commit = [&](int i0) {
 #pragma unroll
     for (int j = 0; j < MAXPF; ++j) {
-      const int col = i0 + cb_of[j];
-      if (cb_of[j] >= 0) sm[lds_of[j]] = (tt < nt && col < ncol && col >= c0_of[j]) ? (double)pf[j] : 0.0;
+      const int mj = map[j];
+      if (mj >= 0) {
+        const int b = mj & 255, k = (mj >> 8) & 255, col = i0 + b, c0 = (mj >> 16) * col_tile;
+        sm[(b * p + k) * LT + tt] = (tt < nt && col < ncol && col >= c0) ? pf[j] : (TIN)0;
+      }
     }
   };
   double4_t acc[4][NACC];
@@ -731,14 +733,14 @@ __global__ __launch_bounds__(512) void post_vsm_mfma_kernel(const TIN* __restric
     if (i0 + CB < ncol) issue(i0 + CB);
     const bool second = NRT == 2 && i0 + CB > c0_second;      // (uniform) the second row tile is identically zero left of its first column
     for (int ks = 0; ks < CB; ks += 4) {
-      const double* base = sm + (size_t)(ks + l4) * p * LT + wave * 4;
+      const TIN* base = sm + (size_t)(ks + l4) * p * LT + wave * 4;
 #pragma unroll
       for (int bb = 0; bb < 4; ++bb) {
-        const double y0 = r0 ? base[li * LT + bb] : 0.0;
+        const double y0 = r0 ? (double)base[li * LT + bb] : 0.0;
         acc[bb][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(y0, y0, acc[bb][0], 0, 0, 0);
         if constexpr (NRT == 2) {
           if (second) {
-            const double y1 = r1 ? base[(16 + li) * LT + bb] : 0.0;
+            const double y1 = r1 ? (double)base[(16 + li) * LT + bb] : 0.0;
             acc[bb][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(y1, y0, acc[bb][1], 0, 0, 0);
             acc[bb][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(y1, y1, acc[bb][2], 0, 0, 0);
           }

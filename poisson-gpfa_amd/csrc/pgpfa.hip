@@ -677,8 +677,8 @@ void launch_post_vsm(pgpfa_ctx* c, const TIN* Mt, long long sM, int ncol, int ns
   const int T = c->T, p = c->p;
   if (ts <= 0) ts = T;                                       // row stride between latents in the panel
   if (p > 10 && c->vsm_mfma) {
-    const int CB = post_vsm_mfma_cb(p);
-    const size_t lds = (size_t)CB * p * 33 * sizeof(double);
+    const int CB = post_vsm_mfma_cb(p, sizeof(TIN) == 4);
+    const size_t lds = (size_t)CB * p * 33 * sizeof(TIN);
     if (p <= 16)
       hipLaunchKernelGGL((post_vsm_mfma_kernel<1, TIN>), dim3((T + 31) / 32, ns), dim3(512), lds, c->st, Mt, sM, c->ld, ncol, T, p, c->vsm, c->ident,
                          c->trial_of_slot, full_range, CB, roff, (int)GBN, ts);
