@@ -310,6 +310,8 @@ def run_dual(args, q, p, T, R, rank, world):
     ctx.set_option('cov_mode', 2)
     ctx.set_option('dual_lowrank', 1)
     ctx.set_option('dual_f32', 1 if args.precision == 'mixed' else 0)
+    for kv in filter(None, args.opts.split(',')):
+        ctx.set_option(kv.split('=')[0], float(kv.split('=')[1]))
     ctx.set_params(true_params['C'], true_params['d'], tau)
     idx = np.arange(R, dtype=np.int32)
     rho = np.log(np.exp(true_params['d'])[None, :, None] * (0.5 + rng.random((R, q, T)))).reshape(R, -1)
