@@ -72,9 +72,14 @@ int pgpfa_set_option(pgpfa_ctx* ctx, const char* key, double value);
 int pgpfa_get_info(pgpfa_ctx* ctx, const char* key, double* value);
 
 /* ---- data ---------------------------------------------------------------------- */
-/* experiment.data[r]['Y'] for all r, as one [R][q][T] tensor (inference.py:96-97). */
+/* experiment.data[r]['Y'] for all r, as one [R][q][T] tensor (inference.py:96-97).  The reference keeps counts as float64 / int64 of
+ * any size (util.py:741,750); here any non-negative integer up to 65535 is accepted (one byte per entry resident, a second plane of
+ * high bytes only while some count exceeds 255 - info key "counts_two_bytes"). */
 int pgpfa_upload_counts_f64(pgpfa_ctx* ctx, const double* Y);
 int pgpfa_upload_counts_u8(pgpfa_ctx* ctx, const uint8_t* Y);
+int pgpfa_upload_counts_u16(pgpfa_ctx* ctx, const uint16_t* Y);
+/* resident counts of the listed trials (idx NULL: all) as uint16 [n][q][T] */
+int pgpfa_get_counts_u16(pgpfa_ctx* ctx, int n, const int32_t* idx, uint16_t* out);
 /* params = {'C': [q][p], 'd': [q], 'tau': [p] seconds} (engine.py:40-44).  Builds the p Gram
  * matrices (util.makeK_big, util.py:599-619) and their inverses (inference.py:82) on device. */
 int pgpfa_set_params(pgpfa_ctx* ctx, const double* C, const double* d, const double* tau_s);

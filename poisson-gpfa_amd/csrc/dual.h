@@ -31,7 +31,7 @@ __global__ void dual_table_kernel(const double* __restrict__ C, int q, int p, in
 
 // lmy = lambda - y for the slots [0, nslots); partial sums per (slot, 64-bin tile): sum d_n lmy and sum lambda (log lambda - 1).
 // grid = (ceil(T/64), nslots), block = 256 (lanes = bins, the 4 waves take interleaved neurons)
-__global__ __launch_bounds__(256) void dual_pre_kernel(const uint8_t* __restrict__ Y, const double* __restrict__ d, const double* __restrict__ lam,
+__global__ __launch_bounds__(256) void dual_pre_kernel(const uint8_t* __restrict__ Y, const uint8_t* __restrict__ Yhi, const double* __restrict__ d, const double* __restrict__ lam,
                                                        double* __restrict__ lmy, double* __restrict__ part, const int* __restrict__ trial_of_slot,
                                                        int q, int T) {
   __shared__ double red[2][4];
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void dual_pre_kernel(const uint8_t* __restrict
     for (int n = wave; n < q; n += 4) {
       const size_t e = slot * (size_t)q * T + (size_t)n * T + t;
       const double l = lam[e];
-      const double v = l - (double)Y[(trial * q + n) * T + t];
+      const double v = l - (double)count_at(Y, Yhi, (trial * q + n) * T + t);
       lmy[e] = v;
       sB += d[n] * v;
       sD += l * (log(l) - 1.0);
@@ -89,6 +89,18 @@ __global__ void dual_pack_sigma_kernel(const double* __restrict__ vsm, const int
     v = vsm[((size_t)trial_of_slot[blockIdx.y] * T + t) * p * p + a * p + b] * (a == b ? 1.0 : 2.0);
   }
   Sp[(size_t)blockIdx.y * sSp + e] = v;
+}
+
+// The reference inverts  postPrecision + 1e-6 diag(diag(postPrecision))  (VIPostCov, inference.py:190).  The diagonal of the precision
+// K^-1 + scatter(W_t) at (latent k, bin t) is (K_k^-1)_tt + W_t[k][k], so the jitter is a diagonal addition to the per-bin blocks and
+// nothing else:  W_t[k][k] <- (1 + jit) W_t[k][k] + jit (K_k^-1)_tt.  Every later step (per-bin blocks, r x r system, log det, Sigma_t) then
+// evaluates the reference's jittered matrix exactly.  grid = (ceil(T*p/256), nslots)
+__global__ void dual_jitter_kernel(double* __restrict__ W, long long sW, const double* __restrict__ Kinv, int Tp, int T, int p, double jit) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= T * p) return;
+  const int t = e / p, k = e - t * p;
+  double* w = W + (size_t)blockIdx.y * sW + (size_t)t * p * p + k * p + k;
+  *w = (1.0 + jit) * (*w) + jit * Kinv[(size_t)k * Tp * Tp + (size_t)t * Tp + t];
 }
 
 // grad[slot][n][t] += log(lambda) - d_n.  grid = (ceil(q*T/256), nslots)

@@ -158,8 +158,18 @@ __global__ void sum_part_kernel(const double* __restrict__ part, int n, double* 
 // neurons and leave e and e-y in LDS; phase B: thread (t,k) accumulates G[k][t] and row k of W[t]
 // with wave-uniform (scalar) reads of C.  Spike counts are read as packed uint8, coalesced over t.
 // --------------------------------------------------------------------------------------------------
+// Spike counts live in HBM as one byte per (trial, neuron, bin), coalesced over bins; counts above 255 (long bins of fast units - the
+// reference keeps counts as float64 / int64 of any size, util.py:741,750) put their high byte into a second plane of the same layout
+// that exists only when the tensor holds such a count (NULL otherwise: a wave-uniform branch).
+__device__ __forceinline__ unsigned count_at(const uint8_t* __restrict__ Y, const uint8_t* __restrict__ Yhi, size_t i) {
+  unsigned v = Y[i];
+  if (Yhi) v |= (unsigned)Yhi[i] << 8;
+  return v;
+}
+
 struct PoissonArgs {
   const uint8_t* Y;      // [R][q][T]
+  const uint8_t* Yhi;    // high bytes of the counts, NULL when every count fits one byte
   const double* C;       // [q][p]
   const double* d;       // [q]
   const double* X; long long sX;   // per slot [p][T]
@@ -190,6 +200,7 @@ __global__ __launch_bounds__(PMAX == 20 ? 640 : 1024) void poisson_pass_kernel(P
   const int p = a.p, q = a.q, T = a.T;
   const double* X = a.X + (size_t)slot * a.sX;
   const uint8_t* Y = a.Y + (size_t)trial * q * T;
+  const uint8_t* Yh = a.Yhi ? a.Yhi + (size_t)trial * q * T : nullptr;
 
   for (int l = ty; l < p; l += KY) xs[l][tx] = valid ? X[(size_t)l * T + t] : 0.0;
   __syncthreads();
@@ -213,7 +224,7 @@ __global__ __launch_bounds__(PMAX == 20 ? 640 : 1024) void poisson_pass_kernel(P
         const double* Cn = a.C + (size_t)n * p;
         for (int l = 0; l < p; ++l) h += Cn[l] * xs[l][tx];
         e = exp(h);
-        const double y = (double)Y[(size_t)n * T + t];
+        const double y = (double)count_at(Y, Yh, (size_t)n * T + t);
         r = e - y;
         facc += e - y * h;
       }
@@ -309,6 +320,7 @@ __global__ __launch_bounds__(256) void poisson_mfma_kernel(PoissonArgs a, const 
   const bool valid_t = t < T;
   const double* X = a.X + (size_t)slot * a.sX;
   const uint8_t* Y = a.Y + (size_t)trial * q * T;
+  const uint8_t* Yh = a.Yhi ? a.Yhi + (size_t)trial * q * T : nullptr;
 
   double xb[KS];
 #pragma unroll
@@ -345,7 +357,7 @@ __global__ __launch_bounds__(256) void poisson_mfma_kernel(PoissonArgs a, const 
         const int n = nb0 + l4 + 4 * r;
         const int nc = n < q ? n : q - 1;
         dv[r] = a.d[nc];
-        yv[r] = Y[(size_t)nc * T + tc];
+        yv[r] = count_at(Y, Yh, (size_t)nc * T + tc);
       }
 #pragma unroll
       for (int kk = 0; kk < KS; ++kk) ch[kk] = C16[(size_t)(nb0 + l15) * 16 + l4 + 4 * kk];
@@ -422,20 +434,21 @@ __global__ __launch_bounds__(256) void poisson_mfma_kernel(PoissonArgs a, const 
 // mode found without it, yp[slot][t] = exp(c_n . x_t + d_n), and err[slot] = sum_t (y_nt - yp_t)^2.
 // grid = nslots, block = 256.
 __global__ void loo_predict_kernel(const double* __restrict__ X, long long sX, const double* __restrict__ C, const double* __restrict__ d,
-                                   const uint8_t* __restrict__ Y, const int* __restrict__ trial_of_slot, const int* __restrict__ mask,
-                                   int q, int p, int T, double* __restrict__ yp, long long sP, double* __restrict__ err) {
+                                   const uint8_t* __restrict__ Y, const uint8_t* __restrict__ Yhi, const int* __restrict__ trial_of_slot,
+                                   const int* __restrict__ mask, int q, int p, int T, double* __restrict__ yp, long long sP, double* __restrict__ err) {
   __shared__ double red[256];
   const int slot = blockIdx.x;
   const int n = mask[slot];
   const double* x = X + (size_t)slot * sX;
   const uint8_t* y = Y + ((size_t)trial_of_slot[slot] * q + n) * T;
+  const uint8_t* yh = Yhi ? Yhi + ((size_t)trial_of_slot[slot] * q + n) * T : nullptr;
   double s = 0.0;
   for (int t = threadIdx.x; t < T; t += blockDim.x) {
     double h = d[n];
     for (int l = 0; l < p; ++l) h += C[(size_t)n * p + l] * x[(size_t)l * T + t];
     const double v = exp(h);
     yp[(size_t)slot * sP + t] = v;
-    const double r = (double)y[t] - v;
+    const double r = (double)count_at(y, yh, t) - v;
     s += r * r;
   }
   red[threadIdx.x] = s;
@@ -860,7 +873,8 @@ __global__ void pauto_from_acc_kernel(const double* __restrict__ Pacc, const dou
 // bins ty, ty+8, ... of the tile reading V_t / m_t as LDS broadcasts.
 // --------------------------------------------------------------------------------------------------
 struct CdArgs {
-  const uint8_t* Y; const double* mean; const double* vsm; const double* vec;   // vecCd
+  const uint8_t* Y; const uint8_t* Yhi;     // counts [R][q][T] (+ plane of high bytes, NULL when none: count_at)
+  const double* mean; const double* vsm; const double* vec;   // vecCd
   const int* trials; int ntr;
   double* part;          // [gridDim.y][p+2][q]
   int q, p, T;
@@ -878,7 +892,7 @@ __global__ __launch_bounds__(64 * CdKy<PW>::v) void mstep_cd_kernel(CdArgs a) {
   constexpr int YS = TT + 4;                      // byte row stride of the count tile (bank spread)
   __shared__ __attribute__((aligned(16))) double Vt[TT][PW * PW];
   __shared__ double Mt[PW][TT];
-  __shared__ uint8_t Yt[64 * YS];
+  __shared__ uint16_t Yt[64 * YS];
   const int lane = threadIdx.x;
   const int ty = __builtin_amdgcn_readfirstlane(threadIdx.y);
   const int tid = ty * 64 + lane;
@@ -904,6 +918,7 @@ __global__ __launch_bounds__(64 * CdKy<PW>::v) void mstep_cd_kernel(CdArgs a) {
     const double* mean = a.mean + r * p * T;
     const double* vsm = a.vsm + (r * T + t0) * p * p;
     const uint8_t* Y = a.Y + r * q * T;
+    const uint8_t* Yh = a.Yhi ? a.Yhi + r * q * T : nullptr;
     __syncthreads();                               // previous tile fully consumed
     for (int e = tid; e < TT * PW * PW; e += 64 * KYW) {
       const int t = e / (PW * PW), kl = e - t * (PW * PW);
@@ -916,7 +931,7 @@ __global__ __launch_bounds__(64 * CdKy<PW>::v) void mstep_cd_kernel(CdArgs a) {
     }
     for (int e = tid; e < 64 * TT; e += 64 * KYW) {
       const int nn = e / TT, t = e - nn * TT;
-      Yt[nn * YS + t] = (n0 + nn < q && t < tn) ? Y[(size_t)(n0 + nn) * T + t0 + t] : 0;
+      Yt[nn * YS + t] = (n0 + nn < q && t < tn) ? (uint16_t)count_at(Y, Yh, (size_t)(n0 + nn) * T + t0 + t) : (uint16_t)0;
     }
     __syncthreads();
     for (int t = ty; t < tn; t += KYW) {
@@ -988,7 +1003,7 @@ __global__ __launch_bounds__(64 * CDH_KY) void mstep_cd_hess_kernel(CdArgs a) {
   constexpr int NHW = D * (D + 1) / 2;
   __shared__ __attribute__((aligned(16))) double Vt[TT][PW * PW];
   __shared__ double Mt[PW][TT];
-  __shared__ uint8_t Yt[64 * YS];
+  __shared__ uint16_t Yt[64 * YS];
   const int lane = threadIdx.x;
   const int ty = __builtin_amdgcn_readfirstlane(threadIdx.y);
   const int tid = ty * 64 + lane;
@@ -1015,6 +1030,7 @@ __global__ __launch_bounds__(64 * CDH_KY) void mstep_cd_hess_kernel(CdArgs a) {
     const double* mean = a.mean + r * p * T;
     const double* vsm = a.vsm + (r * T + t0) * p * p;
     const uint8_t* Y = a.Y + r * q * T;
+    const uint8_t* Yh = a.Yhi ? a.Yhi + r * q * T : nullptr;
     __syncthreads();
     for (int e = tid; e < TT * PW * PW; e += 64 * CDH_KY) {
       const int t = e / (PW * PW), kl = e - t * (PW * PW);
@@ -1027,7 +1043,7 @@ __global__ __launch_bounds__(64 * CDH_KY) void mstep_cd_hess_kernel(CdArgs a) {
     }
     for (int e = tid; e < 64 * TT; e += 64 * CDH_KY) {
       const int nn = e / TT, t = e - nn * TT;
-      Yt[nn * YS + t] = (n0 + nn < q && t < tn) ? Y[(size_t)(n0 + nn) * T + t0 + t] : 0;
+      Yt[nn * YS + t] = (n0 + nn < q && t < tn) ? (uint16_t)count_at(Y, Yh, (size_t)(n0 + nn) * T + t0 + t) : (uint16_t)0;
     }
     __syncthreads();
     for (int t = ty; t < tn; t += CDH_KY) {
@@ -1126,7 +1142,7 @@ constexpr int cd_group_entries(int D, int NG, int G) {
 }
 
 template <int PW, int NG, int G>
-__device__ __forceinline__ void cd_hess_rows_body(const CdArgs& a, double (*Vt)[PW * PW], double (*Mt)[CdTile<PW>::TT], uint8_t* Yt,
+__device__ __forceinline__ void cd_hess_rows_body(const CdArgs& a, double (*Vt)[PW * PW], double (*Mt)[CdTile<PW>::TT], uint16_t* Yt,
                                                   double (*red)[64]) {
   constexpr int TT = CdTile<PW>::TT;
   constexpr int YS = TT + 4;
@@ -1158,6 +1174,7 @@ __device__ __forceinline__ void cd_hess_rows_body(const CdArgs& a, double (*Vt)[
     const double* mean = a.mean + r * p * T;
     const double* vsm = a.vsm + (r * T + t0) * p * p;
     const uint8_t* Y = a.Y + r * q * T;
+    const uint8_t* Yh = a.Yhi ? a.Yhi + r * q * T : nullptr;
     __syncthreads();
     for (int e = tid; e < TT * PW * PW; e += 64 * CDH_KY) {
       const int t = e / (PW * PW), kl = e - t * (PW * PW);
@@ -1170,7 +1187,7 @@ __device__ __forceinline__ void cd_hess_rows_body(const CdArgs& a, double (*Vt)[
     }
     for (int e = tid; e < 64 * TT; e += 64 * CDH_KY) {
       const int nn = e / TT, t = e - nn * TT;
-      Yt[nn * YS + t] = (n0 + nn < q && t < tn) ? Y[(size_t)(n0 + nn) * T + t0 + t] : 0;
+      Yt[nn * YS + t] = (n0 + nn < q && t < tn) ? (uint16_t)count_at(Y, Yh, (size_t)(n0 + nn) * T + t0 + t) : (uint16_t)0;
     }
     __syncthreads();
     for (int t = ty; t < tn; t += CDH_KY) {
@@ -1265,7 +1282,7 @@ __global__ __launch_bounds__(64 * CDH_KY) void mstep_cd_hess_rows_kernel(CdArgs 
   constexpr int TT = CdTile<PW>::TT;
   __shared__ __attribute__((aligned(16))) double Vt[TT][PW * PW];
   __shared__ double Mt[PW][TT];
-  __shared__ uint8_t Yt[64 * (TT + 4)];
+  __shared__ uint16_t Yt[64 * (TT + 4)];
   __shared__ double red[CDH_KY][64];
   const int g = blockIdx.z;
   if constexpr (NG == 2) {
@@ -1380,7 +1397,7 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(const double* __restr
 //   partial sums  sB = sum d_n lmy[n][t] ,  sD = sum lambda (log lambda - 1)
 // grid = (ceil(T/64), nslots), block = 64 threads (one bin each).
 // --------------------------------------------------------------------------------------------------
-__global__ void dual_prep_kernel(const uint8_t* __restrict__ Y, const double* __restrict__ C, const double* __restrict__ d,
+__global__ void dual_prep_kernel(const uint8_t* __restrict__ Y, const uint8_t* __restrict__ Yhi, const double* __restrict__ C, const double* __restrict__ d,
                                  const double* __restrict__ lam, long long sLam, double* __restrict__ V, long long sV,
                                  double* __restrict__ W, long long sW, double* __restrict__ part, int ntile,
                                  const int* __restrict__ slots, const int* __restrict__ trial_of_slot, int q, int p, int T) {
@@ -1391,10 +1408,11 @@ __global__ void dual_prep_kernel(const uint8_t* __restrict__ Y, const double* __
   if (t < T) {
     const double* L = lam + (size_t)slot * sLam;
     const uint8_t* Yr = Y + trial * q * T;
+    const uint8_t* Yh = Yhi ? Yhi + trial * q * T : nullptr;
     double* Wt = W + (size_t)slot * sW + (size_t)t * p * p;
     for (int k = 0; k < p; ++k) {
       double vk = 0.0;
-      for (int n = 0; n < q; ++n) vk += C[(size_t)n * p + k] * (L[(size_t)n * T + t] - (double)Yr[(size_t)n * T + t]);
+      for (int n = 0; n < q; ++n) vk += C[(size_t)n * p + k] * (L[(size_t)n * T + t] - (double)count_at(Yr, Yh, (size_t)n * T + t));
       V[(size_t)slot * sV + (size_t)k * T + t] = vk;
       for (int l = 0; l <= k; ++l) {
         double w = 0.0;
@@ -1405,7 +1423,7 @@ __global__ void dual_prep_kernel(const uint8_t* __restrict__ Y, const double* __
     }
     for (int n = 0; n < q; ++n) {
       const double l = L[(size_t)n * T + t];
-      sB += d[n] * (l - (double)Yr[(size_t)n * T + t]);
+      sB += d[n] * (l - (double)count_at(Yr, Yh, (size_t)n * T + t));
       sD += l * (log(l) - 1.0);
     }
   }
@@ -2563,14 +2581,18 @@ __global__ void vsm_finish_wide_kernel(double* __restrict__ vsm, const double* _
 // 64-bit totals with integer atomics (order independent, so the result is deterministic).
 // grid = (tile pairs, trials), block = 256.
 constexpr int CM_TILE = 32, CM_BINS = 512, CM_LD = CM_BINS / 4 + 1;
-__global__ __launch_bounds__(256) void count_moments_kernel(const uint8_t* __restrict__ Y, const int* __restrict__ trials, int q, int T,
-                                                            unsigned long long* __restrict__ sum, unsigned long long* __restrict__ cross) {
+// (counts above 255: y = lo + 256 hi with the bytes in two planes, so sum y_i y_j is four such passes - plane Ya on the row side, Yb on the
+// column side, the 64-bit contribution scaled by cross_scale = 1 / 256 / 256 / 65536 and the row sums by sum_scale = 1 / 0 / 0 / 256)
+__global__ __launch_bounds__(256) void count_moments_kernel(const uint8_t* __restrict__ Ya, const uint8_t* __restrict__ Yb, const int* __restrict__ trials,
+                                                            int q, int T, unsigned long long* __restrict__ sum, unsigned long long* __restrict__ cross,
+                                                            unsigned long long cross_scale, unsigned long long sum_scale) {
   __shared__ unsigned Wi[CM_TILE * CM_LD];
   __shared__ unsigned Wj[CM_TILE * CM_LD];
   int ti = 0, rem = blockIdx.x;
   while (rem > ti) { rem -= ti + 1; ++ti; }
   const int tj = rem;
-  const uint8_t* Yr = Y + (size_t)trials[blockIdx.y] * q * T;
+  const uint8_t* Yr = Ya + (size_t)trials[blockIdx.y] * q * T;
+  const uint8_t* Yc = Yb + (size_t)trials[blockIdx.y] * q * T;
   const int a = threadIdx.x >> 3, bg = (threadIdx.x & 7) * 4;
   unsigned acc[4] = {0u, 0u, 0u, 0u};
   unsigned acc_s = 0u;
@@ -2586,7 +2608,7 @@ __global__ __launch_bounds__(256) void count_moments_kernel(const uint8_t* __res
         const int t = 4 * w + b;
         if (t < nb) {
           if (ni < q) vi |= (unsigned)Yr[(size_t)ni * T + t0 + t] << (8 * b);
-          if (nj < q) vj |= (unsigned)Yr[(size_t)nj * T + t0 + t] << (8 * b);
+          if (nj < q) vj |= (unsigned)Yc[(size_t)nj * T + t0 + t] << (8 * b);
         }
       }
       Wi[r * CM_LD + w] = vi;
@@ -2605,18 +2627,24 @@ __global__ __launch_bounds__(256) void count_moments_kernel(const uint8_t* __res
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int j = tj * CM_TILE + bg + k;
-    if (j < q && acc[k]) atomicAdd(&cross[(size_t)i * q + j], (unsigned long long)acc[k]);
+    if (j < q && acc[k]) atomicAdd(&cross[(size_t)i * q + j], (unsigned long long)acc[k] * cross_scale);
   }
-  if (ti == tj && bg == 0 && acc_s) atomicAdd(&sum[i], (unsigned long long)acc_s);
+  if (ti == tj && bg == 0 && acc_s && sum_scale) atomicAdd(&sum[i], (unsigned long long)acc_s * sum_scale);
 }
 
-// counts: double [R][q][T] -> uint8 with validation (non-negative integers <= 255)
-__global__ void pack_counts_kernel(const double* __restrict__ src, uint8_t* __restrict__ dst, size_t n, int* __restrict__ bad) {
+// counts: double (or uint16) [R][q][T] -> byte planes with validation (non-negative integers <= 65535): low bytes to lo, high bytes to hi
+// when that plane exists; flags[0] = an invalid entry was seen, flags[1] = a count above 255 was seen (the caller then allocates the
+// second plane and repeats the pass)
+template <typename TS>
+__global__ void pack_counts_kernel(const TS* __restrict__ src, uint8_t* __restrict__ lo, uint8_t* __restrict__ hi, size_t n, int* __restrict__ flags) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const double v = src[i];
-  if (!(v >= 0.0) || v > 255.0 || v != floor(v)) { atomicExch(bad, 1); dst[i] = 0; return; }
-  dst[i] = (uint8_t)v;
+  const double v = (double)src[i];
+  if (!(v >= 0.0) || v > 65535.0 || v != floor(v)) { atomicExch(flags, 1); lo[i] = 0; if (hi) hi[i] = 0; return; }
+  const unsigned u = (unsigned)v;
+  if (u > 255u) atomicExch(flags + 1, 1);
+  lo[i] = (uint8_t)(u & 255u);
+  if (hi) hi[i] = (uint8_t)(u >> 8);
 }
 
 // p[slot * stride + i] = v for i < n; grid = (ceil(n/1024), nslots), block = 256, 4 elements per thread

@@ -35,8 +35,9 @@ struct CdM {
 // YM[k][n] = sum over the listed trials and bins of y_nt m_kt (k < p), YM[p][n] = sum y_nt: partial sums per block,
 // part[blockIdx.x][(p+1)][q].  grid = (nblocks), block = 256; a block walks trials, per trial bin tiles of 64: the count tile
 // [q][64] (coalesced 64-byte rows) and the mean tile [p][64] are staged in LDS, thread = neuron (q <= 256 per pass).
-__global__ __launch_bounds__(256) void cd_ym_kernel(const uint8_t* __restrict__ Y, const double* __restrict__ mean, const int* __restrict__ trials,
-                                                    int ntr, int q, int p, int T, double* __restrict__ part) {
+// (Yhi: plane of the counts' high bytes, NULL when every count fits one byte - a second pass over the tile with weight 256)
+__global__ __launch_bounds__(256) void cd_ym_kernel(const uint8_t* __restrict__ Y, const uint8_t* __restrict__ Yhi, const double* __restrict__ mean,
+                                                    const int* __restrict__ trials, int ntr, int q, int p, int T, double* __restrict__ part) {
   __shared__ double ms[32][64];
   __shared__ unsigned yt[256][17];                      // 64 counts of a neuron as 16 words (+1: bank spread)
   double* out = part + (size_t)blockIdx.x * (p + 1) * q;
@@ -55,13 +56,17 @@ __global__ __launch_bounds__(256) void cd_ym_kernel(const uint8_t* __restrict__ 
           const int k = e >> 6, t = e & 63;
           ms[k][t] = (t < tn) ? mean[(r * p + k) * T + t0 + t] : 0.0;
         }
+        for (int plane = 0; plane < (Yhi ? 2 : 1); ++plane) {
+        const uint8_t* Yp = plane ? Yhi : Y;
+        const double ysc = plane ? 256.0 : 1.0;
+        if (plane) __syncthreads();                    // the low plane's tile is fully consumed
         if ((T & 3) == 0) {
           // rows of counts start on 4-byte boundaries: one word (4 bins) per load
           for (int e = threadIdx.x; e < nrow * 16; e += 256) {
             const int row = e >> 4, w4 = e & 15;
             unsigned w = 0u;
             if (4 * w4 < tn) {
-              w = *reinterpret_cast<const unsigned*>(Y + (r * q + n0 + row) * T + t0 + 4 * w4);
+              w = *reinterpret_cast<const unsigned*>(Yp + (r * q + n0 + row) * T + t0 + 4 * w4);
               const int left = tn - 4 * w4;                       // bins of this word inside the trial (T % 4 == 0: 4, always)
               if (left < 4) w &= (1u << (8 * left)) - 1u;
             }
@@ -70,7 +75,7 @@ __global__ __launch_bounds__(256) void cd_ym_kernel(const uint8_t* __restrict__ 
         } else {
           for (int e = threadIdx.x; e < nrow * 64; e += 256) {
             const int row = e >> 6, t = e & 63;
-            const unsigned v = (t < tn) ? Y[(r * q + n0 + row) * T + t0 + t] : 0u;
+            const unsigned v = (t < tn) ? Yp[(r * q + n0 + row) * T + t0 + t] : 0u;
             // pack 4 counts per word: lanes t, t+1, t+2, t+3 of a quad
             unsigned w = v << (8 * (t & 3));
             w |= __shfl_xor(w, 1);
@@ -86,7 +91,7 @@ __global__ __launch_bounds__(256) void cd_ym_kernel(const uint8_t* __restrict__ 
             if (w == 0u) continue;
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-              const double yv = (double)((w >> (8 * b)) & 255u);
+              const double yv = ysc * (double)((w >> (8 * b)) & 255u);
               const int t = 4 * w4 + b;
 #pragma unroll
               for (int k = 0; k < 32; ++k)
@@ -94,6 +99,7 @@ __global__ __launch_bounds__(256) void cd_ym_kernel(const uint8_t* __restrict__ 
               acc[32] += yv;
             }
           }
+        }
         }
       }
     }

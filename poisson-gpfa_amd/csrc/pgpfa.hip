@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstring>
 #include <deque>
+#include <functional>
 #include <map>
 #include <string>
 #include <type_traits>
@@ -88,6 +89,7 @@ struct pgpfa_ctx {
   int chunk_opt = 0;
   // persistent device state
   uint8_t* Y = nullptr;
+  uint8_t* Yhi = nullptr;                        // high bytes of the counts: allocated only while the tensor holds a count above 255
   double *C = nullptr, *d = nullptr, *tau = nullptr;
   double *Kpad = nullptr, *Kinv = nullptr;      // [p][Tp][Tp]
   double* Xmode = nullptr;                       // [R][p][T]   post_mean / warm start
@@ -110,7 +112,7 @@ struct pgpfa_ctx {
   bool cdym_valid = false, cd_mfma = true; int cd_debug = 0;
   bool cd_hess_valid = false; int cd_hess_ntr = 0;   // per-neuron Hessian sums of the last Newton pass are resident
   std::vector<double> logdetK;                  // log det of the p Gram matrices (from the factor in build_kinv)
-  bool dual_lowrank = false;                    // dual-variational entry points may use the low-rank engine (no diagonal jitter)
+  bool dual_lowrank = true;                     // dual-variational entry points use the low-rank engine when it pays (want_lowrank)
   double* dual_tbl = nullptr; int dual_ncol = 0, dual_npd = 0; bool dual_gemm = true;   // pair / loading table of the GEMM form (dual.h)
   bool vsm_mfma = true;                         // per-bin Gram blocks (post_vsm) on the matrix cores beyond 10 latents
   bool slab_row_align = true;                   // latent row stride of the Yt slab rounded up to 16 rows (128-byte lines)
@@ -119,8 +121,18 @@ struct pgpfa_ctx {
   bool keep_trial_vsmgp = false;
   bool pacc_used = false, pacc_valid = false;
   std::vector<char> vsmgp_ok;                    // per trial: c->vsmgp holds the blocks of the resident posterior
-  std::vector<double> hC, hd, htau;              // parameters as last set / as they were at the last E-step
-  std::vector<double> eC, ed, etau;
+  std::vector<double> hC, hd, htau;              // parameters as last set
+  // parameters every resident posterior was computed under: one snapshot per E-step (or dual finalize), referenced per trial, so that
+  // blocks rebuilt on demand (post_vsmGP under the sum-only plan, post_cov) are those of the trial's OWN E-step even when other trials
+  // have been through later E-steps at other parameters (minibatch EM)
+  struct ParamSnap { std::vector<double> C, d, tau; };
+  std::map<int, ParamSnap> snaps;
+  std::vector<int> trial_snap;                   // per trial: key into snaps (-1: posterior not produced by an E-step of this context)
+  // trials whose resident posterior is a dual-variational one (pgpfa_dual_finalize): their blocks follow from lambda, not from the mode,
+  // so the optimal lambda of those trials stays on the device for rebuilds on demand (allocated by the first finalize)
+  std::vector<char> trial_dual;
+  double* lam_keep = nullptr;                    // [R][q][T]
+  int snap_serial = 0;
   double *vec = nullptr, *cdpart = nullptr, *cdout = nullptr;
   double *cdhpart = nullptr, *cdhout = nullptr, *cdcenter = nullptr, *cddelta = nullptr, *cddec = nullptr;   // Newton M-step
   int* last_trials = nullptr;                    // device list of the trials of the last E-step
@@ -158,13 +170,20 @@ struct pgpfa_ctx {
   int cov_mode = 0;                               // 0 auto, 1 dense, 2 low-rank
   double lr_tol = 1e-10;
   bool plan_lowrank = false;                      // current workspace plan
-  size_t slab_elems = 0, ws_mark = 0;
+  size_t slab_elems = 0, mt_elems = 0, ws_mark = 0;     // doubles per slot of the factor slabs (H / Yt) and of the L^-T slabs
   // the chunk workspace lives in ONE device allocation that re-plans re-partition (hipFree + hipMalloc of ~10^11 bytes
   // costs seconds); arena_mode: 0 = dmalloc is a plain hipMalloc, 1 = only measure, 2 = carve from the arena
   char* arena = nullptr; size_t arena_cap = 0, arena_off = 0; int arena_mode = 0;
+  // The arena is a reserved virtual address range into which physical memory is mapped as the need grows (HIP virtual memory
+  // management): growing never moves it and only the NEW bytes pay the driver's page clearing (~25 ms per GB).  vmm: 0 untried,
+  // 1 in use, -1 unavailable (plain hipMalloc of the size needed, re-allocated on growth).
+  int vmm = 0; size_t va_size = 0, vmm_gran = 0;
+  std::vector<std::pair<hipMemGenericAllocationHandle_t, size_t>> vmm_chunks;
+  double arena_headroom = 1.5;                  // rank head-room of a low-rank plan (option workspace_headroom)
   bool mt_dirty = false;                          // low-rank use scribbled over the Mt slabs' zero triangle
   bool last_cov_lowrank = false;
   bool shared_pcg = true;
+  bool time_newton = false;                       // option time_newton: HIP events around the inner PCG solves (last_newton_solve_ms / _bytes)
   int shared_min = 16, pcg_inner_min = 2, pcg_inner_max = 16, pcg_outer_max = 12;
   double pcg_eta0 = 1e-2;
   int splitk_target = 1280;                      // thin GEMMs are cut along k until about this many workgroups are in flight
@@ -441,14 +460,15 @@ int inverse_t(pgpfa_ctx* c, const CholWS& w, const int* slots, int nb, bool f32 
 }
 
 // allocate a factor workspace: nslots slabs of ld x ld (+ Mt), diagonal inverses, scratch panel
-int alloc_cholws(pgpfa_ctx* c, CholWS* w, int nslots, int npad, bool with_mt, size_t slab_elems = 0, bool zero_mt = true) {
+int alloc_cholws(pgpfa_ctx* c, CholWS* w, int nslots, int npad, bool with_mt, size_t slab_elems = 0, bool zero_mt = true, size_t mt_elems = 0) {
   w->npad = npad;
   w->ld = npad;
   const size_t slab = slab_elems ? slab_elems : (size_t)npad * npad;
+  const size_t slab_mt = mt_elems ? mt_elems : slab;
   const size_t slack = (size_t)256 * npad;
-  w->sH = slab; w->sM = slab; w->sD = (size_t)npad * NB; w->sP = (size_t)npad * NB;
+  w->sH = slab; w->sM = slab_mt; w->sD = (size_t)npad * NB; w->sP = (size_t)npad * NB;
   CHK(dmalloc(c, &w->H, slab * nslots + slack));
-  if (with_mt) CHK(dmalloc(c, &w->Mt, slab * nslots + slack, zero_mt)); else w->Mt = nullptr;
+  if (with_mt) CHK(dmalloc(c, &w->Mt, slab_mt * nslots + slack, zero_mt)); else w->Mt = nullptr;
   CHK(dmalloc(c, &w->Dinv, w->sD * nslots + slack));
   CHK(dmalloc(c, &w->P, w->sP * nslots + slack));
   CHK(dmalloc(c, &w->info, nslots, true));
@@ -471,13 +491,14 @@ bool lowrank_pays(const pgpfa_ctx* c) {
   return lr < 0.5 * dense;
 }
 
-bool want_lowrank(const pgpfa_ctx* c) { return c->cov_mode == 2 ? (c->p <= WIDE_MAX && c->rpad >= NB && lowrank_slab_elems(c) <= (size_t)c->ld * c->ld) : (c->cov_mode == 0 && lowrank_pays(c)); }
+// (cov_mode 2 forces the low-rank engine at any size it supports - its slabs are sized for what it needs, not by the dense ld x ld)
+bool want_lowrank(const pgpfa_ctx* c) { return c->cov_mode == 2 ? (c->p <= WIDE_MAX && c->rpad >= NB) : (c->cov_mode == 0 && lowrank_pays(c)); }
 
 size_t ld_bytes(const pgpfa_ctx* c) { return (size_t)c->ld * c->ld * sizeof(double); }
 
-size_t per_slot_bytes(const pgpfa_ctx* c, size_t slab_elems) {
+size_t per_slot_bytes(const pgpfa_ctx* c, size_t slab_elems, size_t mt_elems) {
   const size_t ld = c->ld;
-  size_t dbl = 2 * slab_elems + 2 * ld * NB + 12 * ld + 3 * (size_t)c->T * c->p * c->p + (size_t)c->T * (c->p * (c->p + 1) / 2) / 2 + 3 * ((c->T + 63) / 64) + 32;
+  size_t dbl = slab_elems + mt_elems + 2 * ld * NB + 12 * ld + 3 * (size_t)c->T * c->p * c->p + (size_t)c->T * (c->p * (c->p + 1) / 2) / 2 + 3 * ((c->T + 63) / 64) + 32;
   return dbl * sizeof(double);
 }
 
@@ -494,15 +515,94 @@ int free_workspace(pgpfa_ctx* c) {
   return 0;
 }
 
+// Grow the arena to at least `need` bytes.  Preferred: map more physical memory behind the reserved address range (the arena does not
+// move, the bytes already mapped are not cleared again).  Fallback when the virtual-memory calls are not available: free and
+// re-allocate at the size needed.
+int arena_grow(pgpfa_ctx* c, size_t need) {
+  if (c->vmm == 0) {
+    hipMemAllocationProp prop{};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = c->device;
+    size_t gran = 0, free_b = 0, total_b = 0;
+    void* va = nullptr;
+    if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) == hipSuccess && gran > 0 &&
+        hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+      const size_t va_size = (total_b + gran - 1) / gran * gran;
+      if (hipMemAddressReserve(&va, va_size, gran, nullptr, 0) == hipSuccess && va) {
+        c->arena = reinterpret_cast<char*>(va); c->va_size = va_size; c->vmm_gran = gran; c->vmm = 1; c->arena_cap = 0;
+      }
+    }
+    if (c->vmm != 1) { (void)hipGetLastError(); c->vmm = -1; }
+  }
+  if (c->vmm == 1) {
+    const size_t gran = c->vmm_gran;
+    // chunks of at least 1 GiB (fewer mappings), never past the reserved range
+    size_t add = std::max(need - c->arena_cap, (size_t)1 << 30);
+    add = (add + gran - 1) / gran * gran;
+    if (c->arena_cap + add > c->va_size) add = (need - c->arena_cap + gran - 1) / gran * gran;
+    if (c->arena_cap + add <= c->va_size) {
+      hipMemAllocationProp prop{};
+      prop.type = hipMemAllocationTypePinned;
+      prop.location.type = hipMemLocationTypeDevice;
+      prop.location.id = c->device;
+      hipMemGenericAllocationHandle_t h;
+      if (hipMemCreate(&h, add, &prop, 0) == hipSuccess) {
+        hipMemAccessDesc desc{};
+        desc.location = prop.location;
+        desc.flags = hipMemAccessFlagsProtReadWrite;
+        if (hipMemMap(c->arena + c->arena_cap, add, 0, h, 0) == hipSuccess) {
+          if (hipMemSetAccess(c->arena + c->arena_cap, add, &desc, 1) == hipSuccess) {
+            c->vmm_chunks.emplace_back(h, add);
+            c->arena_cap += add;
+            c->bytes += add;
+            c->info["arena_bytes"] = (double)c->arena_cap;
+            return 0;
+          }
+          hipMemUnmap(c->arena + c->arena_cap, add);
+        }
+        hipMemRelease(h);
+      }
+      (void)hipGetLastError();
+    }
+    if (c->arena_cap > 0) return 1;            // part of the range is in use: cannot fall back to another allocation scheme now
+    hipMemAddressFree(c->arena, c->va_size);
+    (void)hipGetLastError();
+    c->arena = nullptr; c->va_size = 0; c->vmm = -1;
+  }
+  if (c->arena) { hipFree(c->arena); c->bytes -= c->arena_cap; }
+  c->arena = nullptr; c->arena_cap = 0;
+  if (hipMalloc((void**)&c->arena, need) != hipSuccess) { (void)hipGetLastError(); c->arena = nullptr; return 1; }
+  c->arena_cap = need;
+  c->bytes += need;
+  c->info["arena_bytes"] = (double)c->arena_cap;
+  return 0;
+}
+
+void arena_release(pgpfa_ctx* c) {
+  if (c->vmm == 1) {
+    size_t off = 0;
+    for (auto& ch : c->vmm_chunks) { hipMemUnmap(c->arena + off, ch.second); hipMemRelease(ch.first); off += ch.second; }
+    c->vmm_chunks.clear();
+    if (c->arena) hipMemAddressFree(c->arena, c->va_size);
+  } else if (c->arena) {
+    hipFree(c->arena);
+  }
+  c->arena = nullptr; c->arena_cap = 0;
+}
+
 // Workspace plan.  "dense": factor slabs of ld x ld per slot (the general engine, per-trial fallback Newton, post_cov,
 // dual variational).  "low-rank": slabs only as large as the r x r systems and their products need, so that ~7x more
 // trials fit in one chunk.  Switching plans reallocates the workspace (persistent state is untouched).
 int ensure_workspace(pgpfa_ctx* c, bool plan_lr) {
-  const size_t slab = plan_lr ? (lowrank_slab_elems(c) + 1023) / 1024 * 1024 : (size_t)c->ld * c->ld;
+  const size_t dense = (size_t)c->ld * c->ld;
+  const size_t slab = plan_lr ? (lowrank_slab_elems(c) + 1023) / 1024 * 1024 : dense;
+  // the L^-T slabs only ever hold r x r under the low-rank plan (the big slab is the one that carries Yt)
+  const size_t mt = plan_lr ? ((size_t)c->rpad * c->rpad + 1023) / 1024 * 1024 : dense;
   // the chunk is sized for the largest trial list seen so far, not for all R resident trials: minibatch EM over a large
   // resident set then keeps one chunk with generous rank head-room instead of re-planning as the ranks grow
   const int target = (c->want_slots > 0) ? std::min(c->want_slots, c->R) : c->R;
-  if (c->B > 0 && c->plan_lowrank == plan_lr && slab <= c->slab_elems && (c->B >= target || c->B_capped)) return 0;
+  if (c->B > 0 && c->plan_lowrank == plan_lr && slab <= c->slab_elems && mt <= c->mt_elems && (c->B >= target || c->B_capped)) return 0;
   CHK(free_workspace(c));
   c->ws_mark = c->allocs.size();
   c->plan_lowrank = plan_lr;
@@ -514,19 +614,17 @@ int ensure_workspace(pgpfa_ctx* c, bool plan_lr) {
     const size_t shared = (3 * ld_bytes(c) + 1024 * (size_t)c->ld * sizeof(double) * 4);
     budget = budget > shared ? budget - shared : 0;
   }
-  // low-rank plan: head-room for rank growth between EM iterations (a re-plan costs seconds of hipFree/hipMalloc).
-  // If the whole trial list fits in one chunk the slabs take what the memory budget allows (up to the dense size, so
-  // the plan never has to grow again while the low-rank form still pays); otherwise 25 % above the need.
+  // Low-rank plan: the learnt timescales of a fit move, and the ranks with them.  The slabs get head-room for the ranks to grow by
+  // `arena_headroom` (1.5: Yt slab x 1.5, r x r slab x 2.25) before the plan has to be re-made, when that fits next to the whole
+  // trial list; a re-plan re-partitions the arena and maps more physical memory into it if it must (only the new bytes cost).
   c->slab_elems = slab;
+  c->mt_elems = mt;
   if (plan_lr) {
-    const size_t dense = (size_t)c->ld * c->ld;
-    const size_t fixed = per_slot_bytes(c, 0);
-    const size_t per_budget = budget / (size_t)std::max(target, 1);
-    size_t fit = per_budget > fixed ? (per_budget - fixed) / (2 * sizeof(double)) : 0;     // per_slot_bytes is 16 B per slab element
-    fit = std::min(std::min(dense, 4 * slab), fit / 1024 * 1024);          // (4x the present need covers ranks doubling)
-    c->slab_elems = (fit >= slab) ? fit : std::min(dense, slab + slab / 4);
+    const double h = std::max(1.0, c->arena_headroom);
+    const size_t want_slab = std::min(dense, (size_t)((double)slab * h) / 1024 * 1024), want_mt = std::min(dense, (size_t)((double)mt * h * h) / 1024 * 1024);
+    if (per_slot_bytes(c, want_slab, want_mt) * (size_t)std::max(target, 1) <= budget) { c->slab_elems = std::max(slab, want_slab); c->mt_elems = std::max(mt, want_mt); }
   }
-  const size_t per = per_slot_bytes(c, c->slab_elems);
+  const size_t per = per_slot_bytes(c, c->slab_elems, c->mt_elems);
   long long B = (long long)(budget / per);
   if (c->chunk_opt > 0) B = std::min<long long>(B, c->chunk_opt);
   c->B_capped = B < target;                          // memory (or chunk_trials) bound: asking again would not give more
@@ -544,7 +642,7 @@ int ensure_workspace(pgpfa_ctx* c, bool plan_lr) {
   auto carve = [&]() -> int {
   // (the dense engine needs the strictly lower part of its L^-T slabs zero; the low-rank engine fills its r x r views itself, so under
   // that plan the ~10^11-byte clear is left out and the slabs are marked dirty for a later dense use)
-  CHK(alloc_cholws(c, &c->ws, c->B, c->npad, true, c->slab_elems, !plan_lr));
+  CHK(alloc_cholws(c, &c->ws, c->B, c->npad, true, c->slab_elems, !plan_lr, c->mt_elems));
   c->ws.nact = round_up(c->n, 64);
   const size_t ld = c->ld, nB = c->B;
   const size_t nBs = nB + 128;                    // slack: multi-RHS GEMM tiles read up to 127 slots past the end
@@ -585,21 +683,8 @@ int ensure_workspace(pgpfa_ctx* c, bool plan_lr) {
   if (rc_carve) return rc_carve;
   const size_t need = c->arena_off + ((size_t)1 << 20);
   if (need > c->arena_cap) {
-    if (c->arena) { HIPC(hipStreamSynchronize(c->st)); hipFree(c->arena); c->bytes -= c->arena_cap; }
-    c->arena = nullptr; c->arena_cap = 0;
-    // memory-bound plans take the whole allowance at once: the next plan (other ranks, other chunking) re-partitions it
-    size_t cap = c->B_capped ? std::max(need, avail) : need;
-    if (hipMalloc((void**)&c->arena, cap) != hipSuccess) {
-      (void)hipGetLastError();
-      cap = need;
-      if (hipMalloc((void**)&c->arena, cap) != hipSuccess) {
-        (void)hipGetLastError();
-        c->arena = nullptr; c->B = 0;
-        return fail("not enough device memory for the chunk workspace (%zu bytes needed, %zu free)", need, free_b);
-      }
-    }
-    c->arena_cap = cap;
-    c->bytes += cap;
+    HIPC(hipStreamSynchronize(c->st));
+    if (arena_grow(c, need)) { c->B = 0; return fail("not enough device memory for the chunk workspace (%zu bytes needed, %zu free)", need, free_b); }
   }
   c->arena_mode = 2; c->arena_off = 0;
   rc_carve = carve();
@@ -697,7 +782,7 @@ void launch_post_vsm(pgpfa_ctx* c, const TIN* Mt, long long sM, int ncol, int ns
 // Poisson pass over the slots in d_list (nl of them): X source -> G/W destinations, flik per slot
 int poisson(pgpfa_ctx* c, const int* d_list, int nl, const double* X, double* G, double* W, double* flik, int full) {
   PoissonArgs a{};
-  a.Y = c->Y; a.C = c->C; a.d = c->d;
+  a.Y = c->Y; a.Yhi = c->Yhi; a.C = c->C; a.d = c->d;
   a.X = X; a.sX = c->ld; a.G = G; a.sG = c->ld; a.W = W; a.sW = (long long)c->T * c->p * c->p;
   a.fpart = c->fpart; a.slots = d_list; a.trial_of_slot = c->trial_of_slot;
   a.mask = c->mask_active ? c->mask_of_slot : nullptr;
@@ -952,6 +1037,8 @@ int pgpfa_create(pgpfa_ctx** out, int device, int q, int p, int T, int R, double
   rc |= dmalloc(c, &c->dual_tbl, (size_t)round_up(q, 128) * c->dual_ncol + 4096, true);   // (GEMM tiles read whole 128-row blocks of it)
   rc |= dmalloc(c, &c->ppart, (size_t)p * (PACC_SPLITS + 1) * T * T + 256);
   c->vsmgp_ok.assign(R, 0);
+  c->trial_snap.assign(R, -1);
+  c->trial_dual.assign(R, 0);
   rc |= dmalloc(c, &c->Flr, slab * p + 256 * (size_t)c->Tp, true);
   rc |= dmalloc(c, &c->d_rank, p); rc |= dmalloc(c, &c->d_roff, p + 1);
   rc |= dmalloc(c, &c->d_kr_ft, 2 * (size_t)(c->ld / NB + 2)); rc |= dmalloc(c, &c->d_kr_f, 2 * (size_t)(c->ld / NB + 2));
@@ -985,6 +1072,8 @@ int pgpfa_create(pgpfa_ctx** out, int device, int q, int p, int T, int R, double
   e = hipStreamSynchronize(c->st);
   if (e != hipSuccess) { pgpfa_destroy(c); return fail("sync: %s", hipGetErrorString(e)); }
   c->info["n_pad"] = c->npad;
+  c->info["counts_two_bytes"] = 0.0;
+  c->info["arena_bytes"] = 0.0;
   *out = c;
   return 0;
 }
@@ -997,7 +1086,9 @@ int pgpfa_destroy(pgpfa_ctx* c) {
   for (void* p : c->allocs) hipFree(p);
   if (c->vsmgp) hipFree(c->vsmgp);
   if (c->Flr32) hipFree(c->Flr32);
-  if (c->arena) hipFree(c->arena);
+  if (c->lam_keep) hipFree(c->lam_keep);
+  if (c->Yhi) hipFree(c->Yhi);
+  arena_release(c);
   if (c->hbuf) hipHostFree(c->hbuf);
   if (c->hibuf) hipHostFree(c->hibuf);
   if (c->h_pcg) hipHostFree(c->h_pcg);
@@ -1019,6 +1110,7 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
   else if (k == "pcg_w32") c->pcg_w32 = (v != 0.0);
   else if (k == "chord") c->chord = (v != 0.0);
   else if (k == "shared_pcg") c->shared_pcg = (v != 0.0);
+  else if (k == "time_newton") c->time_newton = (v != 0.0);
   else if (k == "cov_mode") c->cov_mode = (int)v;
   else if (k == "lowrank_tol") c->lr_tol = v;
   else if (k == "keep_trial_vsmgp") c->keep_trial_vsmgp = (v != 0.0);
@@ -1039,6 +1131,8 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
   else if (k == "chord_max_step") c->chord_max_step = v;
   else if (k == "chord_max") c->chord_max = (int)v;
   else if (k == "chunk_trials") { if (c->B > 0) return fail("chunk_trials must be set before the first E-step"); c->chunk_opt = (int)v; }
+  else if (k == "workspace_headroom") c->arena_headroom = std::max(1.0, v);
+  else if (k == "workspace_vmm") { if (c->arena_cap > 0) return fail("workspace_vmm must be set before the first E-step"); c->vmm = (v != 0.0) ? 0 : -1; }
   else if (k == "eps_noise") c->eps = v;
   else if (k == "profile") {
     // 0: off (the accumulated sums stay readable), 1: time every tagged launch, 2: GEMM launches only
@@ -1089,40 +1183,115 @@ int pgpfa_get_info(pgpfa_ctx* c, const char* key, double* value) {
   return 0;
 }
 
-int pgpfa_upload_counts_u8(pgpfa_ctx* c, const uint8_t* Y) {
-  if (!c || !Y) return fail("null argument");
-  HIPC(hipSetDevice(c->device));
-  HIPC(hipMemcpyAsync(c->Y, Y, (size_t)c->R * c->q * c->T, hipMemcpyHostToDevice, c->st));
-  HIPC(hipStreamSynchronize(c->st));
-  c->have_counts = true;
+// The resident counts of the listed trials (NULL: all) have been replaced: everything derived from them is stale - the hoisted count
+// terms and Hessian sums of the (C,d) M-step, the accumulated covariance sum, and the posterior of those trials.
+static void counts_changed(pgpfa_ctx* c, const std::vector<int>* trials) {
+  c->cdym_valid = false;
+  c->cd_hess_valid = false;
+  c->pacc_valid = false;
+  c->have_precomp = false;
+  c->have_post = false;
+  if (trials) { for (int t : *trials) { c->vsmgp_ok[t] = 0; c->mode_serial[t] = -10; c->trial_snap[t] = -1; c->trial_dual[t] = 0; } }
+  else {
+    std::fill(c->vsmgp_ok.begin(), c->vsmgp_ok.end(), 0); std::fill(c->mode_serial.begin(), c->mode_serial.end(), -10);
+    std::fill(c->trial_snap.begin(), c->trial_snap.end(), -1); std::fill(c->trial_dual.begin(), c->trial_dual.end(), 0);
+  }
+}
+
+static void drop_high_plane(pgpfa_ctx* c) {
+  if (!c->Yhi) return;
+  hipStreamSynchronize(c->st);
+  hipFree(c->Yhi);
+  c->bytes -= (size_t)c->R * c->q * c->T;
+  c->Yhi = nullptr;
+}
+static int ensure_high_plane(pgpfa_ctx* c) {
+  if (c->Yhi) return 0;
+  const size_t n = (size_t)c->R * c->q * c->T;
+  if (hipMalloc((void**)&c->Yhi, n) != hipSuccess) { (void)hipGetLastError(); c->Yhi = nullptr; return fail("hipMalloc(%zu bytes) for the high bytes of the counts failed", n); }
+  HIPC(hipMemsetAsync(c->Yhi, 0, n, c->st));
+  c->bytes += n;
   return 0;
 }
 
-int pgpfa_upload_counts_f64(pgpfa_ctx* c, const double* Y) {
+int pgpfa_upload_counts_u8(pgpfa_ctx* c, const uint8_t* Y) {
   if (!c || !Y) return fail("null argument");
   HIPC(hipSetDevice(c->device));
-  const size_t n = (size_t)c->R * c->q * c->T;
-  // staged in pieces through a temporary device buffer
-  const size_t piece = std::min<size_t>(n, (size_t)1 << 26);
-  double* tmp = nullptr;
-  int* bad = nullptr;
-  HIPC(hipMalloc((void**)&tmp, piece * sizeof(double)));
-  hipError_t e = hipMalloc((void**)&bad, sizeof(int));
-  if (e != hipSuccess) { hipFree(tmp); return fail("hipMalloc: %s", hipGetErrorString(e)); }
-  hipMemsetAsync(bad, 0, sizeof(int), c->st);
-  for (size_t off = 0; off < n; off += piece) {
-    const size_t m = std::min(piece, n - off);
-    hipMemcpyAsync(tmp, Y + off, m * sizeof(double), hipMemcpyHostToDevice, c->st);
-    hipLaunchKernelGGL(pack_counts_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->st, tmp, c->Y + off, m, bad);
-    hipStreamSynchronize(c->st);
-  }
-  int hbad = 0;
-  hipMemcpy(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost);
-  hipFree(tmp);
-  hipFree(bad);
-  HIPC(hipGetLastError());
-  if (hbad) return fail("spike counts must be integers in [0,255]");
+  drop_high_plane(c);
+  HIPC(hipMemcpyAsync(c->Y, Y, (size_t)c->R * c->q * c->T, hipMemcpyHostToDevice, c->st));
+  HIPC(hipStreamSynchronize(c->st));
   c->have_counts = true;
+  counts_changed(c, nullptr);
+  c->info["counts_two_bytes"] = 0.0;
+  return 0;
+}
+
+// counts from a host array of TS (double or uint16): validated and split into byte planes on the device, staged in pieces
+extern "C++" {
+template <typename TS>
+static int upload_counts_wide(pgpfa_ctx* c, const TS* Y) {
+  HIPC(hipSetDevice(c->device));
+  const size_t n = (size_t)c->R * c->q * c->T;
+  const size_t piece = std::min<size_t>(n, (size_t)1 << 26);
+  TS* tmp = nullptr;
+  int* flags = nullptr;
+  HIPC(hipMalloc((void**)&tmp, piece * sizeof(TS)));
+  hipError_t e = hipMalloc((void**)&flags, 2 * sizeof(int));
+  if (e != hipSuccess) { hipFree(tmp); return fail("hipMalloc: %s", hipGetErrorString(e)); }
+  drop_high_plane(c);
+  int hf[2] = {0, 0};
+  int rc = 0;
+  for (int pass = 0; pass < 2 && !rc; ++pass) {
+    // pass 0 writes the low bytes and finds out whether any count needs a second byte; only then is the plane of high bytes
+    // allocated and the split repeated (pass 1)
+    hipMemsetAsync(flags, 0, 2 * sizeof(int), c->st);
+    for (size_t off = 0; off < n; off += piece) {
+      const size_t m = std::min(piece, n - off);
+      hipMemcpyAsync(tmp, Y + off, m * sizeof(TS), hipMemcpyHostToDevice, c->st);
+      hipLaunchKernelGGL(pack_counts_kernel<TS>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->st, tmp, c->Y + off, c->Yhi ? c->Yhi + off : nullptr, m, flags);
+      hipStreamSynchronize(c->st);
+    }
+    hipMemcpy(hf, flags, 2 * sizeof(int), hipMemcpyDeviceToHost);
+    if (hf[0] || !hf[1] || pass == 1) break;
+    rc = ensure_high_plane(c);
+  }
+  hipFree(tmp);
+  hipFree(flags);
+  if (rc) return rc;
+  HIPC(hipGetLastError());
+  if (hf[0]) return fail("spike counts must be integers in [0, 65535]");
+  c->have_counts = true;
+  counts_changed(c, nullptr);
+  c->info["counts_two_bytes"] = c->Yhi ? 1.0 : 0.0;
+  return 0;
+}
+}  // extern "C++"
+
+int pgpfa_upload_counts_f64(pgpfa_ctx* c, const double* Y) {
+  if (!c || !Y) return fail("null argument");
+  return upload_counts_wide<double>(c, Y);
+}
+
+int pgpfa_upload_counts_u16(pgpfa_ctx* c, const uint16_t* Y) {
+  if (!c || !Y) return fail("null argument");
+  return upload_counts_wide<uint16_t>(c, Y);
+}
+
+// resident counts of the listed trials as uint16 [n][q][T]
+int pgpfa_get_counts_u16(pgpfa_ctx* c, int n, const int32_t* idx, uint16_t* out) {
+  if (!c || !out) return fail("null argument");
+  if (!c->have_counts) return fail("spike counts have not been uploaded");
+  HIPC(hipSetDevice(c->device));
+  Trials tr;
+  CHK(resolve_trials(c, n, idx, &tr));
+  const size_t m = (size_t)c->q * c->T;
+  std::vector<uint8_t> lo(m), hi(m, 0);
+  for (size_t i = 0; i < tr.v.size(); ++i) {
+    HIPC(hipMemcpyAsync(lo.data(), c->Y + (size_t)tr.v[i] * m, m, hipMemcpyDeviceToHost, c->st));
+    if (c->Yhi) HIPC(hipMemcpyAsync(hi.data(), c->Yhi + (size_t)tr.v[i] * m, m, hipMemcpyDeviceToHost, c->st));
+    HIPC(hipStreamSynchronize(c->st));
+    for (size_t e = 0; e < m; ++e) out[i * m + e] = (uint16_t)(lo[e] | (hi[e] << 8));
+  }
   return 0;
 }
 
@@ -1246,8 +1415,42 @@ int pgpfa_set_modes(pgpfa_ctx* c, int n, const int32_t* idx, const double* X) {
     HIPC(hipMemcpyAsync(c->Xmode + (size_t)tr.v[i] * c->n, X + i * c->n, c->n * sizeof(double), hipMemcpyHostToDevice, c->st));
   HIPC(hipStreamSynchronize(c->st));
   c->pacc_valid = false;          // the accumulated covariance sum belonged to the modes just overwritten
+  c->cdym_valid = false;          // ... and so do the hoisted count terms sum_t y m_t and the per-neuron Hessian sums of the (C,d) M-step
+  c->cd_hess_valid = false;
   for (int t_ : tr.v) c->mode_serial[t_] = -10;
   return 0;
+}
+
+// The posterior of the listed trials has just been computed under the current parameters: snapshot them once, point the trials at
+// the snapshot, drop snapshots no trial refers to any more.
+static void snapshot_params(pgpfa_ctx* c, const std::vector<int>& trials) {
+  const int id = ++c->snap_serial;
+  c->snaps[id] = pgpfa_ctx::ParamSnap{c->hC, c->hd, c->htau};
+  for (int t : trials) c->trial_snap[t] = id;
+  std::vector<char> used(c->snaps.size() + 1, 0);
+  std::map<int, int> pos;
+  int i = 0;
+  for (auto& kv : c->snaps) pos[kv.first] = i++;
+  for (int s : c->trial_snap) if (s >= 0) used[pos[s]] = 1;
+  for (auto it = c->snaps.begin(); it != c->snaps.end();) {
+    if (!used[pos[it->first]]) it = c->snaps.erase(it); else ++it;
+  }
+}
+
+// Run fn under the parameters of snapshot `id` (no-op switch when they are the current ones), then put the current ones back.
+static int with_snapshot(pgpfa_ctx* c, int id, const std::function<int()>& fn) {
+  auto it = c->snaps.find(id);
+  if (it == c->snaps.end()) return fn();
+  const pgpfa_ctx::ParamSnap snap = it->second;              // (copy: pgpfa_set_params rewrites hC..., never the snapshots, but keep it simple)
+  const bool moved = (c->hC != snap.C || c->hd != snap.d || c->htau != snap.tau);
+  if (!moved) return fn();
+  const std::vector<double> curC = c->hC, curd = c->hd, curtau = c->htau;
+  CHK(pgpfa_set_params(c, snap.C.data(), snap.d.data(), snap.tau.data()));
+  int rc = fn();
+  const std::string err = g_err;
+  const int rc2 = pgpfa_set_params(c, curC.data(), curd.data(), curtau.data());
+  if (rc) { g_err = err; return rc; }
+  return rc2;
 }
 
 static int remember_trials(pgpfa_ctx* c, const std::vector<int>& v) {
@@ -1696,6 +1899,8 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
   const long long ld = c->ld;
   double total = 0.0;
   double n_fact = 0.0, n_solve = 0.0, n_pcg = 0.0, n_shared = 0.0;
+  double newton_bytes = 0.0;                          // mandatory HBM bytes of the inner PCG iterations run (see below)
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> newton_ev;   // events around every inner solve (the Newton-solve kernels)
   int max_it_seen = 0;
   std::vector<double> f(c->B), qxx(c->B), qdx(c->B), qdd(c->B), dec(c->B), smax(c->B), alpha(c->B), ftry(c->B);
   std::vector<int> its(c->B), stat(c->B), info(c->B);
@@ -1802,6 +2007,10 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
         }
         const int na = (int)active.size();
         CHK(upload_list(c, c->list_a, active));
+        if (c->time_newton) {
+          newton_ev.emplace_back(prof_event(c->prof), prof_event(c->prof));
+          hipEventRecord(newton_ev.back().first, c->st);
+        }
         hipLaunchKernelGGL(grad_total_kernel, dim3((nvec + 255) / 256, na), dim3(256), 0, c->st, c->Gl, ld, c->KX, ld, c->Gt, ld, nvec, c->list_a);
         hipLaunchKernelGGL(pcg_init_kernel, dim3((c->npad + 255) / 256, na), dim3(256), 0, c->st, c->Gt, c->Rv, c->Dl, ld, nvec, c->npad, c->list_a);
         // (small chunks are launch-latency bound: there the extra packing / check launches of the host-free form cost more than
@@ -1900,6 +2109,7 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
           }
         }
         }
+        if (c->time_newton) hipEventRecord(newton_ev.back().second, c->st);
         hipLaunchKernelGGL(step_stats_kernel, dim3(na), dim3(256), 0, c->st, c->Gt, c->Dl, ld, nvec, c->list_a, c->sc_dec, c->sc_smax);
         CHK(prior_mv_all(c, nb, c->Dl, c->KD));
         hipLaunchKernelGGL(dots3_kernel, dim3(na), dim3(256), 0, c->st, c->Xc, ld, c->KX, ld, c->Dl, ld, c->KD, ld, nvec, c->list_a, c->sc_qxx,
@@ -1919,6 +2129,16 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
         }
         if (done_inner < 0) done_inner = c->h_pcg[1];           // (the download above synchronised the stream)
         n_pcg += (double)na * done_inner;
+        {
+          // mandatory HBM traffic of one PCG iteration (the bytes a perfect implementation still moves): per live slot
+          // 20 passes over an n-vector (H p = K^-1 p + W p: 5; x, r updates: 6; preconditioner G(eps r + F S F^T G r): 6; p = z + beta p: 3),
+          // 4 over an r-vector, the curvature blocks (packed FP32 lower triangles, or FP64 full blocks); once per iteration the operators
+          // K^-1 (p T^2), F and F^T (T r each) and S (r^2).  Dense plan: P^-1 (n^2) instead of F / S.
+          const double vecs = 20.0 * nvec * 8.0 + (c->plan_lowrank ? 4.0 * c->rtot * 8.0 : 0.0);
+          const double curv = (fused && c->pcg_w32) ? (double)T * (p * (p + 1) / 2) * 4.0 : (double)T * p * p * 8.0;
+          const double ops = (double)p * T * T * 8.0 + (c->plan_lowrank ? (2.0 * T * c->rtot + (double)c->rtot * c->rtot) * 8.0 : (double)nvec * nvec * 8.0);
+          newton_bytes += (double)done_inner * ((double)na * (vecs + curv) + ops);
+        }
         std::vector<int> cand, next, failed;
         for (int s : active) {
           if (!(dec[s] > 0.0) || !std::isfinite(dec[s]) || !std::isfinite(smax[s])) continue;   // leave to the fallback
@@ -2029,7 +2249,7 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
 
     if (loo) {
       // prediction of the held-out neurons from the modes in Xc (Xt and sc_f are free scratch here)
-      hipLaunchKernelGGL(loo_predict_kernel, dim3(nb), dim3(256), 0, c->st, c->Xc, ld, c->C, c->d, c->Y, c->trial_of_slot, c->mask_of_slot,
+      hipLaunchKernelGGL(loo_predict_kernel, dim3(nb), dim3(256), 0, c->st, c->Xc, ld, c->C, c->d, c->Y, c->Yhi, c->trial_of_slot, c->mask_of_slot,
                          c->q, p, T, c->Xt, ld, c->sc_f);
       HIPC(hipGetLastError());
       HIPC(hipMemcpy2DAsync(loo->y_pred + (size_t)c0 * T, (size_t)T * sizeof(double), c->Xt, (size_t)ld * sizeof(double), (size_t)T * sizeof(double),
@@ -2085,6 +2305,18 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
   c->info["last_shared_factorizations"] = n_shared;
   c->info["last_cov_lowrank"] = c->last_cov_lowrank ? 1.0 : 0.0;
   c->info["last_newton_max_iter"] = max_it_seen;
+  if (c->time_newton) {
+    // (every chunk ended on a stream synchronisation: the events are complete)
+    double nms = 0.0;
+    for (auto& ev : newton_ev) {
+      float e_ms = 0.f;
+      if (hipEventElapsedTime(&e_ms, ev.first, ev.second) == hipSuccess) nms += e_ms;
+      c->prof.idle.push_back(ev.first); c->prof.idle.push_back(ev.second);
+    }
+    (void)hipGetLastError();
+    c->info["last_newton_solve_ms"] = nms;
+    c->info["last_newton_solve_bytes"] = newton_bytes;
+  }
   return 0;
 }
 
@@ -2099,7 +2331,8 @@ int pgpfa_estep_laplace(pgpfa_ctx* c, int n, const int32_t* idx, int warm_start,
   c->pacc_used = false; c->pacc_valid = false;
   c->estep_serial += 1;
   HIPC(hipMemsetAsync(c->Pacc, 0, (size_t)c->Tp * c->Tp * c->p * sizeof(double), c->st));
-  c->eC = c->hC; c->ed = c->hd; c->etau = c->htau;
+  snapshot_params(c, tr.v);
+  for (int t : tr.v) c->trial_dual[t] = 0;
   CHK(estep_impl(c, tr, warm_start, true, &obj, it1.data(), st1.data()));
   // trials the low-rank plan could not finish (its shared-preconditioner Newton gave up on them and the per-trial
   // fallback needs full-size slabs) are redone under the dense plan, warm-started from where they stopped
@@ -2152,7 +2385,15 @@ int pgpfa_count_moments(pgpfa_ctx* c, int n, const int32_t* idx, int64_t* sum, i
   HIPC(hipMemsetAsync(dev, 0, len * sizeof(unsigned long long), c->st));
   HIPC(hipMemcpyAsync(dtr, tr.v.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice, c->st));
   const int nt = (q + CM_TILE - 1) / CM_TILE, npairs = nt * (nt + 1) / 2;
-  if (N > 0) hipLaunchKernelGGL(count_moments_kernel, dim3(npairs, N), dim3(256), 0, c->st, c->Y, dtr, q, T, dev + (size_t)q * q, dev);
+  if (N > 0) {
+    unsigned long long* dsum = dev + (size_t)q * q;
+    hipLaunchKernelGGL(count_moments_kernel, dim3(npairs, N), dim3(256), 0, c->st, c->Y, c->Y, dtr, q, T, dsum, dev, 1ull, 1ull);
+    if (c->Yhi) {            // y = lo + 256 hi: the mixed and high-high byte products (exact: integer arithmetic)
+      hipLaunchKernelGGL(count_moments_kernel, dim3(npairs, N), dim3(256), 0, c->st, c->Y, c->Yhi, dtr, q, T, dsum, dev, 256ull, 0ull);
+      hipLaunchKernelGGL(count_moments_kernel, dim3(npairs, N), dim3(256), 0, c->st, c->Yhi, c->Y, dtr, q, T, dsum, dev, 256ull, 0ull);
+      hipLaunchKernelGGL(count_moments_kernel, dim3(npairs, N), dim3(256), 0, c->st, c->Yhi, c->Yhi, dtr, q, T, dsum, dev, 65536ull, 256ull);
+    }
+  }
   std::vector<unsigned long long> hostv(len);
   HIPC(hipMemcpyAsync(hostv.data(), dev, len * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->st));
   HIPC(hipStreamSynchronize(c->st));
@@ -2184,28 +2425,39 @@ int pgpfa_generate(pgpfa_ctx* c, unsigned long long seed, int n, const int32_t* 
   int* dtr = nullptr;
   int* flag = nullptr;
   HIPC(hipMalloc((void**)&X, (size_t)c->R * p * T * sizeof(double)));
-  hipError_t e1 = hipMalloc((void**)&dtr, (size_t)N * sizeof(int)), e2 = hipMalloc((void**)&flag, sizeof(int));
-  int rc = 0, over = 0;
+  hipError_t e1 = hipMalloc((void**)&dtr, (size_t)N * sizeof(int)), e2 = hipMalloc((void**)&flag, 2 * sizeof(int));
+  int rc = 0, over[2] = {0, 0};
   if (e1 != hipSuccess || e2 != hipSuccess) rc = fail("hipMalloc failed");
   if (!rc) {
     hipMemcpyAsync(dtr, tr.v.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice, c->st);
-    hipMemsetAsync(flag, 0, sizeof(int), c->st);
     int rmax = 0;
     for (int k = 0; k < p; ++k) rmax = std::max(rmax, c->rk[k]);
     hipLaunchKernelGGL(sample_latents_kernel, dim3(p, N), dim3(256), (size_t)(rmax + 2) * sizeof(double), c->st, c->Flr, c->Tp, T, p, c->d_rank, c->eps,
                        seed, dtr, X);
-    hipLaunchKernelGGL(sample_counts_kernel, dim3((T + 63) / 64, q, N), dim3(64), 0, c->st, X, c->C, c->d, q, p, T, seed, dtr, c->Y, flag);
-    hipMemcpyAsync(&over, flag, sizeof(int), hipMemcpyDeviceToHost, c->st);
-    for (int i = 0; i < N; ++i) {
-      if (X_out) hipMemcpyAsync(X_out + (size_t)i * p * T, X + (size_t)tr.v[i] * p * T, (size_t)p * T * sizeof(double), hipMemcpyDeviceToHost, c->st);
-      if (Y_out) hipMemcpyAsync(Y_out + (size_t)i * q * T, c->Y + (size_t)tr.v[i] * q * T, (size_t)q * T, hipMemcpyDeviceToHost, c->st);
+    for (int pass = 0; pass < 2 && !rc; ++pass) {
+      // a count above 255 needs the plane of high bytes: allocate it and draw again (a draw is a pure function of its counters)
+      hipMemsetAsync(flag, 0, 2 * sizeof(int), c->st);
+      hipLaunchKernelGGL(sample_counts_kernel, dim3((T + 63) / 64, q, N), dim3(64), 0, c->st, X, c->C, c->d, q, p, T, seed, dtr, c->Y, c->Yhi, flag);
+      hipMemcpyAsync(over, flag, 2 * sizeof(int), hipMemcpyDeviceToHost, c->st);
+      if (hipStreamSynchronize(c->st) != hipSuccess || hipGetLastError() != hipSuccess) { rc = fail("generator launch failed"); break; }
+      if (!over[0] || over[1]) break;
+      rc = ensure_high_plane(c);
     }
-    if (hipStreamSynchronize(c->st) != hipSuccess || hipGetLastError() != hipSuccess) rc = fail("generator launch failed");
+    if (!rc && !over[1]) {
+      for (int i = 0; i < N; ++i) {
+        if (X_out) hipMemcpyAsync(X_out + (size_t)i * p * T, X + (size_t)tr.v[i] * p * T, (size_t)p * T * sizeof(double), hipMemcpyDeviceToHost, c->st);
+        if (Y_out && !c->Yhi) hipMemcpyAsync(Y_out + (size_t)i * q * T, c->Y + (size_t)tr.v[i] * q * T, (size_t)q * T, hipMemcpyDeviceToHost, c->st);
+      }
+      if (hipStreamSynchronize(c->st) != hipSuccess) rc = fail("generator copy-out failed");
+    }
   }
   hipFree(X); if (dtr) hipFree(dtr); if (flag) hipFree(flag);
   if (rc) return rc;
-  if (over) return fail("%d sampled counts exceed 255 (rates too high for the packed count tensor)", over);
+  if (over[1]) return fail("%d sampled counts exceed 65535 (rates too high for the count tensor)", over[1]);
   c->have_counts = true;
+  counts_changed(c, &tr.v);
+  c->info["counts_two_bytes"] = c->Yhi ? 1.0 : 0.0;
+  if (Y_out && c->Yhi) return fail("sampled counts exceed 255: the uint8 output cannot hold them, read them back with pgpfa_get_counts_u16");
   return 0;
 }
 
@@ -2268,19 +2520,37 @@ int pgpfa_get_post_vsm(pgpfa_ctx* c, int n, const int32_t* idx, double* out) {
 
 // Rebuild the per-trial T x T blocks of trials whose last E-step ran sum-only: covariance blocks at the resident
 // modes, under the parameters of that E-step (restored around the call when an M-step has moved on since).
-static int materialize_impl(pgpfa_ctx* c, const std::vector<int>& need) {
-  CHK(ready_estep(c, true));
+static int ensure_lambda(pgpfa_ctx* c);
+static int dual_common(pgpfa_ctx* c, int nb, std::vector<double>* sB, std::vector<double>* sD, std::vector<double>* vKv);
+static int dual_jitter(pgpfa_ctx* c, int nb);
+static int post_cov_dual_impl(pgpfa_ctx* c, int trial, double* out);
+
+// (dual: the trials' posterior is the dual-variational one - curvature blocks W_t = C^T diag(lambda_t) C from the kept lambda, with the
+// reference's jitter, instead of the Laplace curvature at the mode)
+static int materialize_impl(pgpfa_ctx* c, const std::vector<int>& need, bool dual) {
+  CHK(ready_estep(c, dual ? c->dual_lowrank : true));
+  if (dual) CHK(ensure_lambda(c));
   const int N = (int)need.size();
   std::vector<int> info(c->B);
+  const size_t m = (size_t)c->q * c->T;
   for (int c0 = 0; c0 < N; c0 += c->B) {
     const int nb = std::min(c->B, N - c0);
     std::vector<int> tos(need.begin() + c0, need.begin() + c0 + nb);
     CHK(upload_list(c, c->trial_of_slot, tos));
     HIPC(hipMemsetAsync(c->ws.info, 0, sizeof(int) * nb, c->st));
-    hipLaunchKernelGGL(gather_rows_kernel, dim3((c->n + 255) / 256, nb), dim3(256), 0, c->st, c->Xmode, c->n, c->Xc, (long long)c->ld,
-                       c->trial_of_slot, 0);
-    CHK(poisson(c, c->ident, nb, c->Xc, c->Gl, c->W, c->sc_f, 1));
-    CHK(posterior_blocks(c, nb, 1.0, true, false));
+    if (dual) {
+      for (int s = 0; s < nb; ++s)
+        HIPC(hipMemcpyAsync(c->lamd + (size_t)s * m, c->lam_keep + (size_t)tos[s] * m, m * sizeof(double), hipMemcpyDeviceToDevice, c->st));
+      std::vector<double> sB, sD, vKv;
+      CHK(dual_common(c, nb, &sB, &sD, &vKv));
+      if (c->plan_lowrank) { CHK(dual_jitter(c, nb)); CHK(posterior_blocks(c, nb, 1.0, true, false)); }
+      else CHK(posterior_blocks(c, nb, 1.0 + 1e-6, true, false));
+    } else {
+      hipLaunchKernelGGL(gather_rows_kernel, dim3((c->n + 255) / 256, nb), dim3(256), 0, c->st, c->Xmode, c->n, c->Xc, (long long)c->ld,
+                         c->trial_of_slot, 0);
+      CHK(poisson(c, c->ident, nb, c->Xc, c->Gl, c->W, c->sc_f, 1));
+      CHK(posterior_blocks(c, nb, 1.0, true, false));
+    }
     HIPC(hipMemcpyAsync(info.data(), c->ws.info, sizeof(int) * nb, hipMemcpyDeviceToHost, c->st));
     HIPC(hipStreamSynchronize(c->st));
     for (int s = 0; s < nb; ++s) {
@@ -2292,21 +2562,20 @@ static int materialize_impl(pgpfa_ctx* c, const std::vector<int>& need) {
 }
 
 static int ensure_trial_vsmgp(pgpfa_ctx* c, const std::vector<int>& trials) {
-  std::vector<int> need;
-  for (int t : trials)
-    if (!c->vsmgp_ok[t] && std::find(need.begin(), need.end(), t) == need.end()) need.push_back(t);
-  if (need.empty()) return 0;
-  if (c->eC.empty()) return fail("post_vsmGP of trial %d is not resident: no E-step or pgpfa_set_posterior produced it", need[0]);
-  const bool moved = (c->hC != c->eC || c->hd != c->ed || c->htau != c->etau);
-  const std::vector<double> curC = c->hC, curd = c->hd, curtau = c->htau;
-  const std::vector<double> oldC = c->eC, oldd = c->ed, oldtau = c->etau;
-  if (moved) CHK(pgpfa_set_params(c, oldC.data(), oldd.data(), oldtau.data()));
-  int rc = materialize_impl(c, need);
-  if (moved) {
-    const int rc2 = pgpfa_set_params(c, curC.data(), curd.data(), curtau.data());
-    if (!rc) rc = rc2;
+  // trials whose blocks are not resident, grouped by the E-step (parameter snapshot) that produced their posterior
+  std::map<std::pair<int, int>, std::vector<int>> need;
+  for (int t : trials) {
+    if (c->vsmgp_ok[t]) continue;
+    if (c->trial_snap[t] < 0) return fail("post_vsmGP of trial %d is not resident: no E-step or pgpfa_set_posterior produced it", t);
+    std::vector<int>& v = need[std::make_pair(c->trial_snap[t], (int)c->trial_dual[t])];
+    if (std::find(v.begin(), v.end(), t) == v.end()) v.push_back(t);
   }
-  return rc;
+  for (auto& kv : need) {
+    const std::vector<int>& v = kv.second;
+    const bool dual = kv.first.second != 0;
+    CHK(with_snapshot(c, kv.first.first, [&]() { return materialize_impl(c, v, dual); }));
+  }
+  return 0;
 }
 
 int pgpfa_get_post_vsmgp(pgpfa_ctx* c, int n, const int32_t* idx, double* out) {
@@ -2329,10 +2598,8 @@ int pgpfa_get_post_vsmgp(pgpfa_ctx* c, int n, const int32_t* idx, double* out) {
   return 0;
 }
 
-int pgpfa_get_post_cov(pgpfa_ctx* c, int trial, double* out) {
+static int post_cov_impl(pgpfa_ctx* c, int trial, double* out) {
   CHK(ready(c));
-  if (!out) return fail("null argument");
-  if (trial < 0 || trial >= c->R) return fail("trial %d out of range", trial);
   std::vector<int> tr{trial};
   CHK(upload_list(c, c->trial_of_slot, tr));
   HIPC(hipMemsetAsync(c->ws.info, 0, sizeof(int), c->st));
@@ -2353,6 +2620,15 @@ int pgpfa_get_post_cov(pgpfa_ctx* c, int trial, double* out) {
                         hipMemcpyDeviceToHost, c->st));
   HIPC(hipStreamSynchronize(c->st));
   return 0;
+}
+
+// Dense posterior covariance of one trial at its resident mode, under the parameters of the E-step that produced that mode (they are
+// restored around the call when later calls have moved the context on).
+int pgpfa_get_post_cov(pgpfa_ctx* c, int trial, double* out) {
+  if (!c || !out) return fail("null argument");
+  if (trial < 0 || trial >= c->R) return fail("trial %d out of range", trial);
+  if (!c->have_params) return fail("set_params has not been called");
+  return with_snapshot(c, c->trial_snap[trial], [&]() { return (c->trial_dual[trial] && c->lam_keep) ? post_cov_dual_impl(c, trial, out) : post_cov_impl(c, trial, out); });
 }
 
 int pgpfa_set_posterior(pgpfa_ctx* c, int n, const int32_t* idx, const double* post_mean, const double* post_vsm, const double* post_vsmgp) {
@@ -2377,7 +2653,7 @@ int pgpfa_set_posterior(pgpfa_ctx* c, int n, const int32_t* idx, const double* p
   hipStreamSynchronize(c->st);
   if (tmp) hipFree(tmp);
   HIPC(hipGetLastError());
-  for (int t : tr.v) { c->vsmgp_ok[t] = 1; c->mode_serial[t] = -10; }   // whatever the caller provided (or left) is the resident value
+  for (int t : tr.v) { c->vsmgp_ok[t] = 1; c->mode_serial[t] = -10; c->trial_snap[t] = -1; c->trial_dual[t] = 0; }   // whatever the caller provided (or left) is the resident value
   return remember_trials(c, tr.v);
 }
 
@@ -2389,14 +2665,14 @@ static int cd_sweep(pgpfa_ctx* c) {
   const int q = c->q, p = c->p, T = c->T;
   const int len = (p + 2) * q;
   CdArgs a{};
-  a.Y = c->Y; a.mean = c->Xmode; a.vsm = c->vsm; a.vec = c->vec;
+  a.Y = c->Y; a.Yhi = c->Yhi; a.mean = c->Xmode; a.vsm = c->vsm; a.vec = c->vec;
   a.trials = c->last_trials; a.ntr = (int)c->last_trials_h.size();
   a.part = c->cdpart; a.q = q; a.p = p; a.T = T; a.dbg = c->cd_debug;
   const double flops = (double)a.ntr * q * T * (2.0 * p * p + 8.0 * p);
   if (c->mfma && c->cd_mfma && p <= 10) {
     if (!c->cdym_valid) {
       const int nbk = std::max(1, std::min(1024, a.ntr));
-      hipLaunchKernelGGL(cd_ym_kernel, dim3(nbk), dim3(256), 0, c->st, c->Y, c->Xmode, c->last_trials, a.ntr, q, p, T,
+      hipLaunchKernelGGL(cd_ym_kernel, dim3(nbk), dim3(256), 0, c->st, c->Y, c->Yhi, c->Xmode, c->last_trials, a.ntr, q, p, T,
                          c->cdym_part);
       hipLaunchKernelGGL(reduce_parts_kernel, dim3(((p + 1) * q + 31) / 32), dim3(256), 0, c->st, c->cdym_part, nbk, (p + 1) * q, c->cdym);
       HIPC(hipGetLastError());
@@ -2482,7 +2758,7 @@ int pgpfa_mstep_cd_newton_pass(pgpfa_ctx* c, const double* vecCd, const double* 
   CHK(upload(c, c->vec, vecCd, (size_t)q * D));
   if (prior_center) CHK(upload(c, c->cdcenter, prior_center, (size_t)q * D));
   CdArgs a{};
-  a.Y = c->Y; a.mean = c->Xmode; a.vsm = c->vsm; a.vec = c->vec;
+  a.Y = c->Y; a.Yhi = c->Yhi; a.mean = c->Xmode; a.vsm = c->vsm; a.vec = c->vec;
   a.trials = c->last_trials; a.ntr = (int)c->last_trials_h.size();
   a.part = c->cdhpart; a.q = q; a.p = p; a.T = T;
   const int nby = std::max(1, std::min(a.ntr * 4, 128));
@@ -2772,7 +3048,7 @@ static int dual_common(pgpfa_ctx* c, int nb, std::vector<double>* sB, std::vecto
   if (c->dual_gemm && c->mfma) {
     const long long sW = (long long)T * p * p;
     const int np = p * (p + 1) / 2;
-    hipLaunchKernelGGL(dual_pre_kernel, dim3(ntile, nb), dim3(256), 0, c->st, c->Y, c->d, c->lamd, c->dgrad, c->dpart, c->trial_of_slot, q, T);
+    hipLaunchKernelGGL(dual_pre_kernel, dim3(ntile, nb), dim3(256), 0, c->st, c->Y, c->Yhi, c->d, c->lamd, c->dgrad, c->dpart, c->trial_of_slot, q, T);
     GemmP w{};                                               // Wp (T x pairs) = Lambda^T . TBL[:, pairs]
     w.A = c->lamd; w.sA = (long long)q * T; w.lda = T;
     w.B = c->dual_tbl; w.sB = 0; w.ldb = c->dual_ncol;
@@ -2785,7 +3061,7 @@ static int dual_common(pgpfa_ctx* c, int nb, std::vector<double>* sB, std::vecto
     hipLaunchKernelGGL(dual_unpack_w_kernel, dim3((unsigned)(((size_t)T * np + 255) / 256), nb), dim3(256), 0, c->st, c->dual_scr, c->dual_sscr, c->W, sW,
                        T, p);
   } else {
-    hipLaunchKernelGGL(dual_prep_kernel, dim3(ntile, nb), dim3(64), 0, c->st, c->Y, c->C, c->d, c->lamd, (long long)q * T, c->Xt, ld, c->W,
+    hipLaunchKernelGGL(dual_prep_kernel, dim3(ntile, nb), dim3(64), 0, c->st, c->Y, c->Yhi, c->C, c->d, c->lamd, (long long)q * T, c->Xt, ld, c->W,
                        (long long)T * p * p, c->dpart, ntile, c->ident, c->trial_of_slot, q, p, T);
   }
   CHK(prior_mv(c, c->ident, nb, c->Xt, c->KD, c->Kpad));            // K v
@@ -2807,6 +3083,11 @@ static int dual_common(pgpfa_ctx* c, int nb, std::vector<double>* sB, std::vecto
 }
 
 int pgpfa_dual_costgrad(pgpfa_ctx* c, int trial, const double* lam, double* cost, double* grad) {
+  if (c && c->have_counts && c->have_params && c->dual_lowrank && want_lowrank(c)) {
+    // the low-rank engine is the batched evaluation with one trial
+    const int32_t t = trial;
+    return pgpfa_dual_costgrad_batch(c, 1, &t, lam, cost, grad);
+  }
   CHK(ready(c));
   if (!lam || !cost) return fail("null argument");
   if (trial < 0 || trial >= c->R) return fail("trial %d out of range", trial);
@@ -2862,17 +3143,8 @@ int pgpfa_dual_post_mean(pgpfa_ctx* c, int trial, const double* lam, double* mea
 
 // VIPostCov (inference.py:188-191): prec = K_big^-1 + C_big diag(lambda) C_big^T (dense, latent-major; may be NULL) and
 // cov = (prec + 1e-6 diag(diag(prec)))^-1 for one trial.
-int pgpfa_dual_post_cov(pgpfa_ctx* c, int trial, const double* lam, double* cov, double* prec) {
-  CHK(ready(c));
-  if (!lam || !cov) return fail("null argument");
-  if (trial < 0 || trial >= c->R) return fail("trial %d out of range", trial);
-  CHK(ensure_lambda(c));
-  const int q = c->q, T = c->T;
-  for (size_t i = 0; i < (size_t)q * T; ++i)
-    if (!std::isfinite(lam[i])) return fail("lambda entry %zu is not finite", i);
-  std::vector<int> tr{trial};
-  CHK(upload_list(c, c->trial_of_slot, tr));
-  CHK(upload(c, c->lamd, lam, (size_t)q * T));
+// (lambda of the trial bound to slot 0 is already in c->lamd)
+static int dual_post_cov_dev(pgpfa_ctx* c, double* cov, double* prec) {
   std::vector<double> sB, sD, vKv;
   CHK(dual_common(c, 1, &sB, &sD, &vKv));                              // W <- C^T diag(lambda_t) C
   if (prec) {
@@ -2898,6 +3170,39 @@ int pgpfa_dual_post_cov(pgpfa_ctx* c, int trial, const double* lam, double* cov,
                         hipMemcpyDeviceToHost, c->st));
   HIPC(hipStreamSynchronize(c->st));
   if (info != 0) return fail("VIPostCov: posterior precision not positive definite (pivot %d)", info);
+  return 0;
+}
+
+int pgpfa_dual_post_cov(pgpfa_ctx* c, int trial, const double* lam, double* cov, double* prec) {
+  CHK(ready(c));
+  if (!lam || !cov) return fail("null argument");
+  if (trial < 0 || trial >= c->R) return fail("trial %d out of range", trial);
+  CHK(ensure_lambda(c));
+  const int q = c->q, T = c->T;
+  for (size_t i = 0; i < (size_t)q * T; ++i)
+    if (!std::isfinite(lam[i])) return fail("lambda entry %zu is not finite", i);
+  std::vector<int> tr{trial};
+  CHK(upload_list(c, c->trial_of_slot, tr));
+  CHK(upload(c, c->lamd, lam, (size_t)q * T));
+  return dual_post_cov_dev(c, cov, prec);
+}
+
+// post_cov of a trial whose resident posterior is the dual-variational one: VIPostCov at the lambda kept by pgpfa_dual_finalize
+static int post_cov_dual_impl(pgpfa_ctx* c, int trial, double* out) {
+  CHK(ready(c));
+  CHK(ensure_lambda(c));
+  std::vector<int> tr{trial};
+  CHK(upload_list(c, c->trial_of_slot, tr));
+  const size_t m = (size_t)c->q * c->T;
+  HIPC(hipMemcpyAsync(c->lamd, c->lam_keep + (size_t)trial * m, m * sizeof(double), hipMemcpyDeviceToDevice, c->st));
+  return dual_post_cov_dev(c, out, nullptr);
+}
+
+// the reference's 1e-6 relative jitter on the diagonal of the posterior precision, applied to the W blocks of the slots [0, nb) in place
+static int dual_jitter(pgpfa_ctx* c, int nb) {
+  hipLaunchKernelGGL(dual_jitter_kernel, dim3((unsigned)((c->T * c->p + 255) / 256), nb), dim3(256), 0, c->st, c->W, (long long)c->T * c->p * c->p,
+                     c->Kinv, c->Tp, c->T, c->p, 1e-6);
+  HIPC(hipGetLastError());
   return 0;
 }
 
@@ -2936,11 +3241,10 @@ static int dual_eval_slots(pgpfa_ctx* c, int nb, const std::vector<int>& tos, bo
   std::vector<int> info(nb);
   CHK(dual_common(c, nb, &sB, &sD, &vKv));
   if (c->plan_lowrank) {
-    // low-rank engine: log det through the r x r system, Sigma_t blocks from the per-bin pass over Yt.  The reference's
-    // jitter (diagonal of the precision scaled by 1 + 1e-6, inference.py:190) cannot be formed in this representation and is
-    // left out of cost AND gradient (a consistent pair: the dual of the model itself).  It is not a small effect on stiff GP
-    // priors - Sigma_ii H_ii reaches the hundreds, so the jitter moves the Sigma_t blocks by up to ~1 % - which is why the
-    // dense, jitter-faithful evaluation stays the default (option dual_lowrank).
+    // low-rank engine: log det through the r x r system, Sigma_t blocks from the per-bin pass over Yt.  The reference's jitter
+    // (diagonal of the precision scaled by 1 + 1e-6, inference.py:190) is a diagonal addition to the per-bin blocks W_t (dual.h):
+    // with it the engine evaluates the reference's function - cost, log det and gradient follow inference.py:188-219.
+    CHK(dual_jitter(c, nb));
     CHK(posterior_blocks_lowrank(c, nb, false, false, logdet.data()));
     HIPC(hipMemcpyAsync(info.data(), c->ws.info, sizeof(int) * nb, hipMemcpyDeviceToHost, c->st));
     HIPC(hipStreamSynchronize(c->st));
@@ -3244,12 +3548,17 @@ int pgpfa_dual_finalize(pgpfa_ctx* c, int n, const int32_t* idx, const double* l
   c->want_slots = std::max(c->want_slots, std::min(N, c->R));
   CHK(ready_estep(c, c->dual_lowrank));
   CHK(ensure_lambda(c));
-  // under the low-rank plan the blocks come without the reference's 1e-6 diagonal jitter (1e-6 relative), and - as in the
+  // under the low-rank plan the reference's 1e-6 diagonal jitter enters through the per-bin blocks (dual_jitter), and - as in the
   // Laplace E-step - only the sum over trials of post_vsmGP is accumulated unless keep_trial_vsmgp is set
   const bool sum_only = c->plan_lowrank && !c->keep_trial_vsmgp;
   c->pacc_used = false; c->pacc_valid = false;
   HIPC(hipMemsetAsync(c->Pacc, 0, (size_t)c->Tp * c->Tp * c->p * sizeof(double), c->st));
-  c->eC = c->hC; c->ed = c->hd; c->etau = c->htau;
+  snapshot_params(c, tr.v);
+  if (!c->lam_keep) {
+    const size_t bytes = (size_t)c->R * c->q * c->T * sizeof(double);
+    if (hipMalloc((void**)&c->lam_keep, bytes) != hipSuccess) { (void)hipGetLastError(); c->lam_keep = nullptr; return fail("hipMalloc(%zu bytes) for the resident dual variables failed", bytes); }
+    c->bytes += bytes;
+  }
   const int q = c->q;
   const long long ld = c->ld;
   double total = 0.0;
@@ -3260,12 +3569,16 @@ int pgpfa_dual_finalize(pgpfa_ctx* c, int n, const int32_t* idx, const double* l
     std::vector<int> tos(tr.v.begin() + c0, tr.v.begin() + c0 + nb);
     CHK(upload_list(c, c->trial_of_slot, tos));
     CHK(upload(c, c->lamd, lam + (size_t)c0 * q * c->T, (size_t)nb * q * c->T));
+    for (int s = 0; s < nb; ++s) {
+      HIPC(hipMemcpyAsync(c->lam_keep + (size_t)tos[s] * q * c->T, c->lamd + (size_t)s * q * c->T, (size_t)q * c->T * sizeof(double), hipMemcpyDeviceToDevice, c->st));
+      c->trial_dual[tos[s]] = 1;
+    }
     HIPC(hipMemsetAsync(c->ws.info, 0, sizeof(int) * nb, c->st));
     std::vector<double> sB, sD, vKv;
     CHK(dual_common(c, nb, &sB, &sD, &vKv));
     // posterior mean -K C_big (lambda - y) (inference.py:194) and covariance blocks (inference.py:188-191)
     hipLaunchKernelGGL(negate_rows_kernel, dim3((c->n + 255) / 256, nb), dim3(256), 0, c->st, c->KD, ld, c->Xc, ld, c->n, c->ident);
-    if (c->plan_lowrank) CHK(posterior_blocks(c, nb, 1.0, true, sum_only));
+    if (c->plan_lowrank) { CHK(dual_jitter(c, nb)); CHK(posterior_blocks(c, nb, 1.0, true, sum_only)); }
     else CHK(posterior_blocks(c, nb, 1.0 + 1e-6, true));
     for (int t : tos) c->vsmgp_ok[t] = sum_only ? 0 : 1;
     hipLaunchKernelGGL(scatter_rows_kernel, dim3((c->n + 255) / 256, nb), dim3(256), 0, c->st, c->Xc, ld, c->n, c->Xmode, c->trial_of_slot);

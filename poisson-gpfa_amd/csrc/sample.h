@@ -108,11 +108,13 @@ __device__ inline unsigned poisson_draw(double lam, const Philox& rng, unsigned 
   return (unsigned)(lam + 0.5);
 }
 
-// Y[trial][n][t] ~ Poisson(exp(c_n . x_t + d_n)); counts above 255 are flagged (the packed tensor is uint8).
+// Y[trial][n][t] ~ Poisson(exp(c_n . x_t + d_n)); low bytes to Y, high bytes to Yhi when that plane exists - otherwise counts above 255
+// are flagged (overflow[0]) and the caller repeats the launch with the plane allocated (a draw is a pure function of its counters);
+// counts above 65535 are flagged in overflow[1].
 // grid = (ceil(T/64), q, ntrials), block = 64.
 __global__ __launch_bounds__(64) void sample_counts_kernel(const double* __restrict__ X, const double* __restrict__ C, const double* __restrict__ d, int q, int p,
                                      int T, unsigned long long seed, const int* __restrict__ trials, uint8_t* __restrict__ Y,
-                                     int* __restrict__ overflow) {
+                                     uint8_t* __restrict__ Yhi, int* __restrict__ overflow) {
   const int t = blockIdx.x * 64 + threadIdx.x;
   const int n = blockIdx.y;
   const unsigned trial = (unsigned)trials[blockIdx.z];
@@ -122,8 +124,10 @@ __global__ __launch_bounds__(64) void sample_counts_kernel(const double* __restr
   for (int k = 0; k < p; ++k) h += C[(size_t)n * p + k] * x[(size_t)k * T];
   const Philox rng{(unsigned)seed, (unsigned)(seed >> 32)};
   const unsigned v = poisson_draw(exp(h), rng, trial, (unsigned)n * 65536u + (unsigned)t);
-  if (v > 255u) atomicAdd(overflow, 1);
-  Y[((size_t)trial * q + n) * T + t] = (uint8_t)(v > 255u ? 255u : v);
+  if (v > 255u && !Yhi) atomicAdd(overflow, 1);
+  if (v > 65535u) atomicAdd(overflow + 1, 1);
+  Y[((size_t)trial * q + n) * T + t] = (uint8_t)(v & 255u);
+  if (Yhi) Yhi[((size_t)trial * q + n) * T + t] = (uint8_t)((v >> 8) & 255u);
 }
 
 }  // namespace pgpfa

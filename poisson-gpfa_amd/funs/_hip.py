@@ -27,6 +27,8 @@ _SIGNATURES = {
     'pgpfa_get_info': [ct.c_void_p, ct.c_char_p, c_double_p],
     'pgpfa_upload_counts_f64': [ct.c_void_p, c_double_p],
     'pgpfa_upload_counts_u8': [ct.c_void_p, c_uint8_p],
+    'pgpfa_upload_counts_u16': [ct.c_void_p, ct.POINTER(ct.c_uint16)],
+    'pgpfa_get_counts_u16': [ct.c_void_p, ct.c_int, c_int32_p, ct.POINTER(ct.c_uint16)],
     'pgpfa_set_params': [ct.c_void_p, c_double_p, c_double_p, c_double_p],
     'pgpfa_get_gram': [ct.c_void_p, c_double_p],
     'pgpfa_get_gram_inverse': [ct.c_void_p, c_double_p],
@@ -171,6 +173,9 @@ class Context:
         if Y.dtype == np.uint8:
             Y = np.ascontiguousarray(Y)
             check(self.lib.pgpfa_upload_counts_u8(self.h, Y.ctypes.data_as(c_uint8_p)))
+        elif Y.dtype == np.uint16:
+            Y = np.ascontiguousarray(Y)
+            check(self.lib.pgpfa_upload_counts_u16(self.h, Y.ctypes.data_as(ct.POINTER(ct.c_uint16))))
         else:
             Y = as_f64(Y)
             check(self.lib.pgpfa_upload_counts_f64(self.h, dptr(Y)))
@@ -232,10 +237,16 @@ class Context:
         """Sample latents and counts of the listed trials on the device (they replace the resident counts) -> (X, Y) copies."""
         n, ii = self._n_idx(idx)
         X = np.empty((n, self.p, self.T)) if want_x else None
-        Y = np.empty((n, self.q, self.T), dtype=np.uint8) if want_y else None
-        check(self.lib.pgpfa_generate(self.h, int(seed), n, iptr(ii), dptr(X) if want_x else None,
-                                      Y.ctypes.data_as(c_uint8_p) if want_y else None))
+        check(self.lib.pgpfa_generate(self.h, int(seed), n, iptr(ii), dptr(X) if want_x else None, None))
+        Y = self.counts(idx) if want_y else None
         return X, Y
+
+    def counts(self, idx=None):
+        """Resident counts of the listed trials: uint8 [n][q][T], or uint16 when some resident count exceeds 255."""
+        n, ii = self._n_idx(idx)
+        Y = np.empty((n, self.q, self.T), dtype=np.uint16)
+        check(self.lib.pgpfa_get_counts_u16(self.h, n, iptr(ii), Y.ctypes.data_as(ct.POINTER(ct.c_uint16))))
+        return Y if self.info('counts_two_bytes') else Y.astype(np.uint8)
 
     def loo_predict(self, idx=None):
         """Leave-one-neuron-out prediction for the listed trials -> (y_pred[n][q][T], summed squared error)."""

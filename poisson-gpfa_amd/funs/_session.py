@@ -36,6 +36,9 @@ class _stdout_to_stderr:
         return False
 
 
+_PROCESS_START = time.time()
+
+
 class _World:
     def __init__(self):
         self.rank = int(os.environ.get('RANK', '0'))
@@ -56,34 +59,92 @@ class _World:
         return self.local_rank if self.enabled else int(os.environ.get('PGPFA_DEVICE', '0'))
 
     def exchange_unique_id(self):
-        """Rank 0 creates the RCCL unique id and publishes it through a file; the other ranks of
-        this single-node job poll for it.  The file name is keyed by the launcher's pid (shared
-        parent of all ranks), MASTER_PORT and a per-process serial so that repeated sessions and
-        stale files of earlier runs cannot collide."""
+        """Rendezvous of this single-node job through files; returns (RCCL unique id, path of the id file).
+
+        Rank 0 creates the unique id and publishes it; every other rank reads it and acknowledges; rank 0 waits for ALL
+        acknowledgements and only then publishes the go-ahead the others wait for.  Nobody enters ncclCommInitRank (which
+        blocks without a timeout until every rank has joined) before every rank is known to be alive and to hold the same
+        id: a rank that died at start-up (bad device, out of memory while creating its context) or was never started makes
+        every other rank raise after PGPFA_RDZV_TIMEOUT seconds (default 300) - a non-zero exit of the whole job instead of
+        a hang.  File names are keyed by MASTER_PORT, the launcher's run id and pid (shared parent of all ranks) and a
+        per-process serial; a file older than this process by more than two minutes is a leftover of an earlier job that
+        happened to get the same key and is ignored."""
         self._serial += 1
         base = os.environ.get('PGPFA_RDZV_DIR', '/tmp')
         key = 'pgpfa_uid_%s_%s_%d_%d' % (os.environ.get('MASTER_PORT', '0'),
                                         os.environ.get('TORCHELASTIC_RUN_ID', 'none'), os.getppid(), self._serial)
         path = os.path.join(base, key)
-        if self.rank == 0:
-            uid = _hip.comm_unique_id()
-            tmp = path + '.tmp'
+        timeout = float(os.environ.get('PGPFA_RDZV_TIMEOUT', '300'))
+        deadline = time.time() + timeout
+
+        def publish(name, payload):
+            tmp = name + '.tmp.%d' % os.getpid()
             with open(tmp, 'wb') as fh:
-                fh.write(uid)
-            os.replace(tmp, path)
+                fh.write(payload)
+            os.replace(tmp, name)
+
+        def fresh(name):
+            try:
+                return os.path.getmtime(name) >= _PROCESS_START - 120.0
+            except OSError:
+                return False
+
+        def wait_for(names, what):
+            while time.time() < deadline:
+                if all(os.path.exists(nm) and fresh(nm) for nm in names):
+                    return
+                time.sleep(0.01)
+            missing = [nm for nm in names if not (os.path.exists(nm) and fresh(nm))]
+            raise _hip.HipBackendError('rendezvous of rank %d timed out after %.0f s waiting for %s (%s): a rank died at start-up or was '
+                                       'never launched' % (self.rank, timeout, what, ', '.join(os.path.basename(m) for m in missing)))
+        acks = [path + '.ack.%d' % r for r in range(1, self.size)]
+        if self.rank == 0:
+            for stale in acks + [path + '.go']:
+                try:
+                    os.remove(stale)
+                except OSError:
+                    pass
+            uid = _hip.comm_unique_id()
+            publish(path, uid)
+            try:
+                wait_for(acks, 'the acknowledgement of every rank')
+            except _hip.HipBackendError:
+                try:
+                    os.remove(path)
+                except OSError:
+                    pass
+                raise
+            publish(path + '.go', uid)
+            for nm in acks:
+                try:
+                    os.remove(nm)
+                except OSError:
+                    pass
             return uid, path
-        deadline = time.time() + float(os.environ.get('PGPFA_RDZV_TIMEOUT', '300'))
-        while time.time() < deadline:
-            if os.path.exists(path):
-                with open(path, 'rb') as fh:
-                    uid = fh.read()
-                if len(uid) == 128:
-                    return uid, path
-            time.sleep(0.01)
-        raise _hip.HipBackendError('timed out waiting for the RCCL unique id at %s' % path)
+        wait_for([path], "rank 0's unique id")
+        with open(path, 'rb') as fh:
+            uid = fh.read()
+        if len(uid) != 128:
+            raise _hip.HipBackendError('malformed RCCL unique id at %s' % path)
+        publish(path + '.ack.%d' % self.rank, uid)
+        wait_for([path + '.go'], "rank 0's go-ahead")
+        with open(path + '.go', 'rb') as fh:
+            if fh.read() != uid:
+                raise _hip.HipBackendError('rendezvous mismatch: the go-ahead at %s.go carries another unique id' % path)
+        return uid, path
 
 
 WORLD = _World()
+
+
+def cleanup_rendezvous(path):
+    """After the first collective (which every rank has passed) rank 0 removes the rendezvous files."""
+    if WORLD.rank == 0:
+        for name in (path, path + '.go'):
+            try:
+                os.remove(name)
+            except OSError:
+                pass
 
 
 def shard_slice(n_items, rank, size):
@@ -219,11 +280,7 @@ class Session:
                 self.comm_ready = True
                 # first collective doubles as the barrier after which rank 0 may remove the file
                 self.ctx.allreduce_host(np.zeros(1))
-            if WORLD.rank == 0:
-                try:
-                    os.remove(path)
-                except OSError:
-                    pass
+            cleanup_rendezvous(path)
 
     def set_params(self, params):
         self.ctx.set_params(params['C'], params['d'], params['tau'])
@@ -246,9 +303,9 @@ _sessions = weakref.WeakKeyDictionary()
 
 def _stack_counts(experiment):
     Y = np.stack([np.asarray(tr['Y']) for tr in experiment.data])
-    if Y.min() >= 0 and Y.max() <= 255 and np.all(Y == np.floor(Y)):
-        return Y.astype(np.uint8)
-    return Y.astype(np.float64)
+    if Y.min() >= 0 and Y.max() <= 65535 and np.all(Y == np.floor(Y)):
+        return Y.astype(np.uint8 if Y.max() <= 255 else np.uint16)
+    return Y.astype(np.float64)            # (the C-ABI rejects it with the reason)
 
 
 def session_for(experiment, p):

@@ -14,6 +14,10 @@ import numpy as np
 from . import _hip
 from ._session import DeviceInfRes, DeviceOptimRes, session_for
 
+# covariance engine of every context this module creates: None = the library's choice (low-rank when it pays), 1 = dense, 2 = low-rank
+# (tests pin one or the other; results agree to the low-rank tolerance)
+COV_MODE = None
+
 STATUS_TEXT = {0: 'converged', 1: 'iteration limit reached', 2: 'line search failed', 3: 'Hessian not positive definite',
                4: 'left unfinished by the shared-preconditioner iteration'}
 
@@ -22,21 +26,43 @@ class LaplaceConvergenceWarning(RuntimeWarning):
     """Some trials stopped at the Newton iteration limit: their modes are the last iterates, not converged ones."""
 
 
-def _check_newton_status(status, first_trial=0):
+def _check_newton_status(status, first_trial=0, sess=None):
     """The reference ignores scipy's Newton-CG status (inference.py:127-129) - its failures are merely imprecise modes.
     Here status 2 / 3 mean that no acceptable step exists or that the posterior precision is not positive definite at
     the iterate (NaN / overflowing rates): such a trial's mode and covariance blocks are not a posterior and must not
-    be summed into the M-step statistics, so they raise; the iteration limit (1) only warns."""
+    be summed into the M-step statistics, so they raise; the iteration limit (1) only warns.
+
+    With trials sharded over ranks the verdict is COLLECTIVE: every rank contributes (failed, slow, first failing global
+    trial) to one all-reduce and then all ranks raise (or warn) together with the same message - a rank that left on its
+    own would leave the others blocked in the next collective."""
     status = np.asarray(status)
     bad = np.flatnonzero((status == 2) | (status == 3) | (status == 4))
-    if bad.size:
-        raise _hip.HipBackendError('Laplace mode search failed for %d trial(s), first: trial %d (%s); parameters probably '
-                                   'give non-finite rates' % (bad.size, first_trial + int(bad[0]), STATUS_TEXT.get(int(status[bad[0]]), '?')))
     slow = np.flatnonzero(status == 1)
+    size = sess.size if sess is not None else 1
+    rank = sess.rank if sess is not None else 0
+    # slots [0, size): first failing trial + 1 of each rank (0: none); [size, 2 size): its status; then the counts; same for `slow`
+    msg = np.zeros(3 * size + 2)
+    if bad.size:
+        msg[rank] = first_trial + int(bad[0]) + 1
+        msg[size + rank] = int(status[bad[0]])
     if slow.size:
+        msg[2 * size + rank] = first_trial + int(slow[0]) + 1
+    msg[3 * size] = bad.size
+    msg[3 * size + 1] = slow.size
+    if sess is not None and size > 1:
+        msg = np.asarray(sess.allreduce(msg))
+    n_bad, n_slow = int(round(msg[3 * size])), int(round(msg[3 * size + 1]))
+    if n_bad:
+        owner = int(np.flatnonzero(msg[:size] > 0)[0])
+        first = int(round(msg[owner])) - 1
+        raise _hip.HipBackendError('Laplace mode search failed for %d trial(s), first: trial %d%s (%s); parameters probably '
+                                   'give non-finite rates' % (n_bad, first, ' on rank %d' % owner if size > 1 else '',
+                                                              STATUS_TEXT.get(int(round(msg[size + owner])), '?')))
+    if n_slow:
         import warnings
+        owner = int(np.flatnonzero(msg[2 * size:3 * size] > 0)[0])
         warnings.warn('Laplace mode search hit the iteration limit for %d trial(s), first: trial %d; their modes are not '
-                      'converged' % (slow.size, first_trial + int(slow[0])), LaplaceConvergenceWarning, stacklevel=3)
+                      'converged' % (n_slow, int(round(msg[2 * size + owner])) - 1), LaplaceConvergenceWarning, stacklevel=3)
 
 
 def _prepare(experiment, params):
@@ -47,6 +73,8 @@ def _prepare(experiment, params):
     sess, trial_idx = session_for(experiment, xdim)
     if sess.q != ydim:
         raise ValueError("params['C'] has %d rows but the experiment has %d neurons" % (ydim, sess.q))
+    if COV_MODE is not None:
+        sess.ctx.set_option('cov_mode', COV_MODE)
     sess.set_params(params)
     return sess, trial_idx
 
@@ -92,7 +120,7 @@ def laplace(experiment, params, prevOptimRes=None, returnOptimRes=True, verbose=
     else:
         obj, iters, status = 0.0, np.zeros(0, np.int32), np.zeros(0, np.int32)
     sess.mark_written(mine)
-    _check_newton_status(status, lo)
+    _check_newton_status(status, lo, sess)
     if verbose:
         for i, (it, st) in enumerate(zip(iters, status)):
             print('laplace inference trajectory of trial %d: %d Newton factorizations, %s' % (lo + i + 1, it, STATUS_TEXT.get(int(st), '?')))
@@ -143,9 +171,14 @@ def _unkron(C_big, d_big, ydim):
     xdim = C_big.shape[0] // T
     C = np.ascontiguousarray(C_big[::T, ::T].T)                      # (ydim, xdim)
     d = np.ascontiguousarray(d_big[::T])
-    # spot check of the Kronecker structure (the full comparison would cost as much as the product the device avoids)
+    # check of the Kronecker structure: every entry when the matrix is small (up to 2^22 entries), else a 4096-entry spot check (the
+    # full comparison would cost as much as the product the device avoids) - a C_big that deviates from kron(C, I) in a few entries
+    # (a masked neuron, time-varying loadings) can slip through the spot check and is then evaluated as the structured model
     rng = np.random.RandomState(0)
-    rows, cols = rng.randint(0, C_big.shape[0], 64), rng.randint(0, C_big.shape[1], 64)
+    if C_big.size <= (1 << 22):
+        rows, cols = np.divmod(np.arange(C_big.size), C_big.shape[1])
+    else:
+        rows, cols = rng.randint(0, C_big.shape[0], 4096), rng.randint(0, C_big.shape[1], 4096)
     want = np.where(rows % T == cols % T, C[cols // T, rows // T], 0.0)
     if not np.allclose(C_big[rows, cols], want, rtol=0, atol=1e-12 * (1.0 + np.abs(C).max())) or \
             not np.allclose(d_big.reshape(ydim, T), d[:, None], rtol=0, atol=1e-12 * (1.0 + np.abs(d).max())):
@@ -200,11 +233,25 @@ def _rbf_params(Kmat, xdim, T, inverse):
     return np.asarray(taus), float(np.mean(epss))
 
 
+def _fingerprint(C_big, d_big, Kmat, T):
+    """Cheap content key of the big matrices, O(q p + p T): the entries the small factors are read from (every T-th row / column
+    of C_big and d_big, the first row of every diagonal block of K_big).  A caller that refills preallocated big matrices in
+    place between EM iterations keeps their identity but not this key."""
+    C_big, d_big, Kmat = np.asarray(C_big), np.asarray(d_big), np.asarray(Kmat)
+    n = Kmat.shape[0]
+    rows = [Kmat[k, k:min(k + T, n)] for k in range(0, n, T)]
+    return (C_big[::T, ::T].tobytes(), np.ndarray.flatten(d_big)[::T].tobytes(), np.concatenate(rows).tobytes())
+
+
 def _big_context(ybar, C_big, d_big, Kmat, ydim, inverse):
-    """One-trial device context for the big-matrix callbacks, cached on the identity of the matrices."""
+    """One-trial device context for the big-matrix callbacks, cached on the identity of the matrices AND a content
+    fingerprint of the entries the small factors are recovered from."""
     ybar = np.ndarray.flatten(np.asarray(ybar, dtype=np.float64))
     for i, ent in enumerate(_BIG_CACHE):
         if ent[0] is C_big and ent[1] is d_big and ent[2] is Kmat and ent[3] == inverse:
+            if ent[6] != _fingerprint(C_big, d_big, Kmat, ent[5].T):
+                _BIG_CACHE.pop(i)[5].close()               # refilled in place: rebuild below
+                break
             if ent[4] != ybar.tobytes():
                 ent[5].upload_counts(ybar.reshape(1, ent[5].q, ent[5].T))
                 ent[4] = ybar.tobytes()
@@ -218,9 +265,11 @@ def _big_context(ybar, C_big, d_big, Kmat, ydim, inverse):
     bin_ms = 10.0
     ctx = _hip.Context(ydim, xdim, T, 1, bin_ms)
     ctx.set_option('eps_noise', eps)
+    if COV_MODE is not None:
+        ctx.set_option('cov_mode', COV_MODE)
     ctx.upload_counts(ybar.reshape(1, ydim, T))
     ctx.set_params(C, d, tau_bins * bin_ms / 1000.0)
-    _BIG_CACHE.insert(0, [C_big, d_big, Kmat, inverse, ybar.tobytes(), ctx])
+    _BIG_CACHE.insert(0, [C_big, d_big, Kmat, inverse, ybar.tobytes(), ctx, _fingerprint(C_big, d_big, Kmat, T)])
     while len(_BIG_CACHE) > _BIG_CACHE_MAX:
         _BIG_CACHE.pop()[5].close()
     return ctx
@@ -248,7 +297,9 @@ def negLogPosteriorUnNorm_hess(xbar, ybar, C_big, d_big, K_bigInv, xdim, ydim):
 
 def _infer_T(C_big):
     """T from the Kronecker structure of C_big = kron(C, I_T).T: entry (k*T+t, n*T+t') is non-zero only for t == t', so T
-    divides column - row of every non-zero entry (the dual callbacks do not receive xdim / ydim)."""
+    divides column - row of every non-zero entry (the dual callbacks do not receive xdim / ydim).  A loading matrix with exact
+    zeros can make the gcd a multiple of T; _unkron's structure check then rejects the matrices (pass dense loadings, or use
+    the structured entry points, which take T explicitly)."""
     C_big = np.asarray(C_big)
     rows = np.unique(np.linspace(0, C_big.shape[0] - 1, 8).astype(int))
     g = 0
@@ -318,7 +369,9 @@ def dualProblemRho_grad(rho, ybar, C_big, K_big, K_bigInv, d_big):
 # 'device': the dual optimisations of all trials run as lockstep L-BFGS on the GPU (pgpfa_dual_lbfgs); 'scipy': the
 # reference's per-trial scipy L-BFGS-B calls (same options), driven concurrently with batched device evaluations
 DUAL_SOLVER = 'device'
-DUAL_LOWRANK = False
+# evaluate the dual through the low-rank covariance engine when that pays (large xdim*T); the reference's 1e-6 diagonal jitter
+# (inference.py:190) enters as a diagonal addition to the per-bin curvature blocks, so both engines evaluate the reference's function
+DUAL_LOWRANK = True
 # with DUAL_LOWRANK: factorisation of the r x r system, its inverse and the Yt product of every dual evaluation in single precision
 # on the FP32 matrix cores, log det / covariance blocks / gradient accumulated in FP64 (BASELINE config 5 asks for fp32)
 DUAL_F32 = False
@@ -416,10 +469,9 @@ def dualVariational(experiment, params, optimizeLogLambda=False, prevOptimRes=No
     mine = trial_idx[lo:hi]
     m = sess.q * sess.T
     ctx = sess.ctx
-    # DUAL_LOWRANK lets the device solver evaluate the dual through the low-rank covariance engine when that pays (large
-    # xdim*T): it is the dual WITHOUT the reference's 1e-6 diagonal jitter (inference.py:190), which on stiff GP priors
-    # moves the posterior covariance blocks by up to ~1 % - hence off by default
-    ctx.set_option('dual_lowrank', 1 if (DUAL_SOLVER == 'device' and DUAL_LOWRANK) else 0)
+    # DUAL_LOWRANK: the dual is evaluated through the low-rank covariance engine when that pays (large xdim*T), with the
+    # reference's 1e-6 diagonal jitter (inference.py:190) carried by the per-bin blocks; otherwise the dense engine
+    ctx.set_option('dual_lowrank', 1 if DUAL_LOWRANK else 0)
     ctx.set_option('dual_f32', 1 if (DUAL_SOLVER == 'device' and DUAL_LOWRANK and DUAL_F32) else 0)
     if DUAL_SOLVER == 'device' and len(mine):
         # all trials in lockstep on the device, in rho = log(lambda); same optimum as either of the reference's variants

@@ -201,3 +201,68 @@ def test_timescale_root_finder_host_logic():
         lo, hi = np.where(ok, lo, 0.0), np.where(ok, hi, 1.0)
         r = learning._newton_poly_root(X, Y, lo, hi, ok)
         assert np.max(np.abs(r - bisect(X, Y, lo, hi))[ok]) <= 1e-13
+
+
+# ---- multi-rank start-up: rendezvous handshake and launcher supervision (no GPU: the unique id is a stub) -----------------
+_RDZV = r"""
+import os, sys, time
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, 'poisson-gpfa_amd'))
+from funs import _hip, _session
+_hip.comm_unique_id = lambda: bytes(range(128))
+w = _session.WORLD
+assert w.enabled and w.size == int(os.environ['WORLD_SIZE'])
+try:
+    uid, path = w.exchange_unique_id()
+except _hip.HipBackendError as exc:
+    sys.stderr.write('RDZV-FAILED: %s\n' % exc)
+    sys.exit(7)
+assert uid == bytes(range(128))
+print('ok', w.rank, os.path.basename(path))
+"""
+
+
+def _rdzv_rank(tmp_path, rank, size, port, timeout_s, ppid_file=None):
+    script = tmp_path / 'rdzv.py'
+    script.write_text(_RDZV.format(root=ROOT))
+    env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(size), LOCAL_RANK=str(rank), MASTER_PORT=str(port),
+               PGPFA_RDZV_DIR=str(tmp_path), PGPFA_RDZV_TIMEOUT=str(timeout_s))
+    return subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+
+
+def test_rendezvous_handshake_and_timeouts(tmp_path):
+    """All ranks present: same id everywhere.  A rank that never shows up (died at start-up): every other rank leaves with
+    a non-zero status after the timeout instead of entering ncclCommInitRank and hanging there.  A stale id file of an
+    earlier job with the same key is not taken for rank 0's."""
+    procs = [_rdzv_rank(tmp_path, r, 3, 41001, 60) for r in range(3)]
+    outs = [pr.communicate(timeout=120) for pr in procs]
+    assert [pr.returncode for pr in procs] == [0, 0, 0], outs
+    assert all(o[0].startswith('ok %d ' % r) for r, o in enumerate(outs))
+    # rank 2 never started: ranks 0 and 1 time out (rank 1 has read the id and acknowledged; the go-ahead never comes)
+    procs = [_rdzv_rank(tmp_path, r, 3, 41002, 3) for r in range(2)]
+    outs = [pr.communicate(timeout=120) for pr in procs]
+    assert [pr.returncode for pr in procs] == [7, 7], outs
+    assert 'acknowledgement' in outs[0][1] and 'go-ahead' in outs[1][1]
+    # rank 0 never publishes; a leftover id file with the same key but an old timestamp lies around
+    key = 'pgpfa_uid_41003_none_%d_1' % os.getpid()
+    stale = tmp_path / key
+    stale.write_bytes(bytes(128))
+    old = os.path.getmtime(str(stale)) - 3600
+    os.utime(str(stale), (old, old))
+    pr = _rdzv_rank(tmp_path, 1, 2, 41003, 3)
+    out = pr.communicate(timeout=120)
+    assert pr.returncode == 7 and "rank 0's unique id" in out[1], out
+
+
+def test_bench_launcher_stops_all_ranks_when_one_dies():
+    """bench.py --gpus N as its own launcher: rank 1 exits non-zero at start-up while rank 0 would wait for ever; the parent
+    must end rank 0 and return non-zero promptly."""
+    import time
+    env = dict(os.environ, PGPFA_DRYRUN_DIE='1', PGPFA_DRYRUN_HANG='0')
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run'], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and 'rank 1 exited with status 3' in out.stderr, out
+    assert time.time() - t0 < 60
+    # and the overall timeout
+    env = dict(os.environ, PGPFA_DRYRUN_HANG='0', PGPFA_BENCH_TIMEOUT='3')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run'], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and 'timeout after 3 s' in out.stderr, out

@@ -45,6 +45,7 @@ class FakeContext:
         self.pm, self.pv, self.pg = {{}}, {{}}, {{}}
         self._info = {{'last_pcg_iterations': 0.0, 'last_loo_unconverged': 0.0}}
         self.calls = []
+        self.fail_trial = None                     # a trial whose mode search reports status 3 (test of the collective verdict)
     def close(self): pass
     def set_option(self, k, v): pass
     def info(self, k): return self._info.get(k, 0.0)
@@ -60,7 +61,10 @@ class FakeContext:
             self.pm[int(i)], self.pv[int(i)], self.pg[int(i)] = res['post_mean'][j], res['post_vsm'][j], res['post_vsmGP'][j]
         self.last = [int(i) for i in idx]
         self.calls.append(('estep', self.last))
-        return -nll * len(idx), np.ones(len(idx), np.int32), np.zeros(len(idx), np.int32)
+        status = np.zeros(len(idx), np.int32)
+        if self.fail_trial is not None:
+            status[idx == self.fail_trial] = 3
+        return -nll * len(idx), np.ones(len(idx), np.int32), status
     def count_moments(self, idx=None):
         idx = np.arange(self.R) if idx is None else np.asarray(idx)
         ras = np.concatenate([self.Y[i] for i in idx], axis=1).astype(np.int64) if len(idx) else np.zeros((self.q, 0), np.int64)
@@ -104,7 +108,8 @@ _session.WORLD.rank, _session.WORLD.size, _session.WORLD.local_rank, _session.WO
 _session.WORLD.exchange_unique_id = lambda: (b'0' * 128, '/nonexistent')
 
 g = np.load(os.path.join(ROOT, 'tests', 'golden', 'c1_dataset.npz'))
-R = 7                                                  # odd on purpose: the ranks' slices differ in length
+R = int(os.environ.get('NTRIALS', '7'))                # odd on purpose: the ranks' slices differ in length
+LIGHT = os.environ.get('LIGHT', '0') == '1'            # many ranks: batch EM and the failure verdict only
 class Exp:
     pass
 exp = Exp()
@@ -127,6 +132,25 @@ out['batch_tau'] = np.asarray(fit.optimParams['tau']).tolist()
 out['sample_mean_counts'] = np.asarray(fit.sampleMeanSpikeCounts).tolist()
 out['infres_trials'] = fit.infRes.trial_idx.tolist()
 out['infres_len'] = len(fit.infRes['post_mean'])
+
+# a trial that fails on ONE rank (status 3) must fail the E-step on EVERY rank, with the same message, and leave the
+# ranks able to go on with collectives (nobody is left behind in the all-reduce of the objective)
+sess.ctx.fail_trial = R - 1                            # owned by the last rank
+try:
+    inference.laplace(exp, dict(fit.optimParams))
+    out['fail_message'] = None
+except _hip.HipBackendError as exc:
+    out['fail_message'] = str(exc)
+sess.ctx.fail_trial = None
+out['after_fail_sum'] = float(sess.allreduce(np.array([1.0]))[0])
+_, nll_again = inference.laplace(exp, dict(fit.optimParams), returnOptimRes=False)
+out['after_fail_nll'] = float(nll_again)
+if LIGHT:
+    with open(os.environ['OUT'] + '.%d' % rank, 'w') as fh:
+        json.dump(out, fh)
+    if size > 1:
+        dist.destroy_process_group()
+    sys.exit(0)
 
 # online 'diag' EM, 3 minibatches of 4: the draws come from the global RNG (same on every rank), each rank takes its slice
 np.random.seed(1)
@@ -159,11 +183,11 @@ if size > 1:
 '''
 
 
-def _run(tmp_path, nranks, port):
+def _run(tmp_path, nranks, port, **extra):
     script = tmp_path / 'worker.py'
     script.write_text(_WORKER.format(root=ROOT))
-    out = tmp_path / ('out%d' % nranks)
-    env = dict(os.environ, OUT=str(out), OMP_NUM_THREADS='2')
+    out = tmp_path / ('out%d_%s' % (nranks, extra.get('NTRIALS', '7')))
+    env = dict(os.environ, OUT=str(out), OMP_NUM_THREADS='1' if nranks > 2 else '2', **extra)
     if nranks == 1:
         env.update(RANK='0', WORLD_SIZE='1')
         subprocess.run([sys.executable, str(script)], check=True, env=env, timeout=900)
@@ -198,6 +222,11 @@ def test_two_rank_product_host_layer_matches_single_rank(tmp_path):
         assert two[r]['batch_C'] == two[0]['batch_C'] and two[r]['online_tau'] == two[0]['online_tau']     # replicas agree bit for bit
         assert np.allclose(two[r]['sample_mean_counts'], one['sample_mean_counts'], rtol=1e-14, atol=0)      # all-reduced integer moments
         assert two[r]['stale_raises'] == two[r]['stale_expected'] and two[r]['cached_read_survives']
+        # the failing trial lives on rank 1; both ranks raise the same verdict and the next collectives still line up
+        assert two[r]['fail_message'] is not None and 'trial 6 on rank 1' in two[r]['fail_message'] and 'positive definite' in two[r]['fail_message']
+        assert two[r]['fail_message'] == two[0]['fail_message']
+        assert two[r]['after_fail_sum'] == 2.0 and abs(two[r]['after_fail_nll'] - one['after_fail_nll']) <= 1e-6 * abs(one['after_fail_nll'])
+        assert two[r]['after_fail_nll'] == two[0]['after_fail_nll']
     # minibatches: the same draw on both ranks, split in order (first half / second half of the reference's index list)
     for it in range(3):
         whole = one['online_estep_trials'][it]
@@ -205,3 +234,24 @@ def test_two_rank_product_host_layer_matches_single_rank(tmp_path):
     np.random.seed(1)
     assert one['online_estep_trials'][0] == np.random.choice(7, 4, replace=False).tolist()
     assert one['stale_raises'] == [True] * 4 and one['cached_read_survives']
+    assert one['fail_message'] is not None and 'trial 6' in one['fail_message'] and 'rank' not in one['fail_message']
+
+
+@pytest.mark.timeout(1500)
+def test_eight_ranks_uneven_slices(tmp_path):
+    """13 trials over 8 ranks (slices of 2,2,2,2,2,1,1,1): batch EM and the collective failure verdict against the 1-rank run."""
+    one = _run(tmp_path, 1, 0, NTRIALS='13', LIGHT='1')[0]
+    many = _run(tmp_path, 8, 29655, NTRIALS='13', LIGHT='1')
+    bounds = [r['batch_slice'] for r in many]
+    assert bounds == [[0, 2], [2, 4], [4, 6], [6, 8], [8, 10], [10, 11], [11, 12], [12, 13]]
+    for r in range(8):
+        lo, hi = bounds[r]
+        assert many[r]['batch_estep_trials'] == [list(range(lo, hi))] * 2
+        assert abs(many[r]['batch_nll'][0] - one['batch_nll'][0]) <= 1e-11 * abs(one['batch_nll'][0])
+        assert np.allclose(many[r]['batch_nll'], one['batch_nll'], rtol=1e-6, atol=0)
+        assert np.allclose(many[r]['batch_C'], one['batch_C'], rtol=0, atol=1e-3)
+        assert np.allclose(many[r]['batch_tau'], one['batch_tau'], rtol=1e-3, atol=0)
+        assert many[r]['batch_C'] == many[0]['batch_C']
+        assert many[r]['fail_message'] == many[0]['fail_message'] and 'trial 12 on rank 7' in many[r]['fail_message']
+        assert many[r]['after_fail_sum'] == 8.0 and abs(many[r]['after_fail_nll'] - one['after_fail_nll']) <= 1e-6 * abs(one['after_fail_nll'])
+        assert many[r]['after_fail_nll'] == many[0]['after_fail_nll']

@@ -185,12 +185,17 @@ def test_named_laplace_callbacks_vs_golden(funs_mod, c1):
         inf.negLogPosteriorUnNorm(x, ybar, C_big + 0.1, d_big, K_bigInv, p, q)
 
 
-def test_named_dual_callbacks_vs_golden(funs_mod):
-    """dualProblem / dualProblem_grad / dualProblemRho(_grad) / VIPostCov / VIPostMean (inference.py:188-256) by the
+@pytest.mark.parametrize('engine', ['dense', 'lowrank'])
+def test_named_dual_callbacks_vs_golden(funs_mod, engine, monkeypatch):
+    """(both covariance engines: the low-rank one carries the reference's jitter in the per-bin blocks)
+    dualProblem / dualProblem_grad / dualProblemRho(_grad) / VIPostCov / VIPostMean (inference.py:188-256) by the
     reference's signatures on the variational toy problem (20 neurons, 2 latents, T = 50): dual cost / gradient against the values
     captured from the reference 1e-9, posterior mean / covariance / precision against the oracle's big-matrix restatement 1e-9."""
     g = load_golden('var_toy.npz')
     inf = funs_mod.inference
+    monkeypatch.setattr(inf, 'COV_MODE', 2 if engine == 'lowrank' else 1)
+    while inf._BIG_CACHE:
+        inf._BIG_CACHE.pop()[5].close()
     q, p, T = 20, 2, 50
     par = {'C': g['init_C'], 'd': g['init_d'], 'tau': g['init_tau']}
     K = orc.make_K(par['tau'], T, float(g['binSize']))
@@ -209,6 +214,8 @@ def test_named_dual_callbacks_vs_golden(funs_mod):
     cov_o, prec_o = orc.vi_post_cov(K_bigInv, C_big, lam)
     assert rel(prec, prec_o) <= 1e-9 and rel(cov, cov_o) <= 1e-8
     assert rel(inf.VIPostMean(K_big, C_big, ybar, lam), orc.vi_post_mean(K_big, C_big, ybar, lam)) <= 1e-9
+    while inf._BIG_CACHE:
+        inf._BIG_CACHE.pop()[5].close()
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -515,7 +522,7 @@ def _dual_eval(q, p, T, Y, C, d, tau, lam, f32):
 
 def test_mixed_precision_dual_evaluation_vs_numpy():
     """dual_f32: r x r Cholesky, its inverse and Yt in single precision on the FP32 matrix cores, everything else in FP64.  At 40
-    neurons x 20 latents x 200 bins (n = 4000, dense numpy is seconds) against the plain-numpy unjittered dual: cost 2e-6 rel,
+    neurons x 20 latents x 200 bins (n = 4000, dense numpy is seconds) against the oracle's dual (reference jitter included): cost 2e-6 rel,
     gradient 2e-4 of its largest entry (the covariance blocks c_n^T Sigma_t c_n inherit cond(B) * 6e-8); the FP64 engine on the
     same input keeps 1e-8 / 1e-7."""
     q, p, T, R = 40, 20, 200, 2
@@ -531,11 +538,8 @@ def test_mixed_precision_dual_evaluation_vs_numpy():
     Kinv_big = np.linalg.inv(K_big)
     for i in range(R):
         y = Ys[i].reshape(-1).astype(float)
-        v = C_big @ (lam[i] - y)
-        H = Kinv_big + (C_big * lam[i][None, :]) @ C_big.T
-        Sigma = np.linalg.inv(H)
-        ref_cost = 0.5 * v @ K_big @ v - d_big @ (lam[i] - y) - 0.5 * np.linalg.slogdet(H)[1] + np.sum(lam[i] * (np.log(lam[i]) - 1.0))
-        ref_grad = C_big.T @ (K_big @ v) - d_big + np.log(lam[i]) - 0.5 * np.einsum('im,ij,jm->m', C_big, Sigma, C_big)
+        ref_cost = orc.dual_cost(lam[i], y, C_big, K_big, Kinv_big, d_big)
+        ref_grad = orc.dual_grad(lam[i], y, C_big, K_big, Kinv_big, d_big)
         assert abs(c64[i] - ref_cost) <= 1e-8 * abs(ref_cost) and rel(g64[i], ref_grad) <= 1e-7
         print('mixed precision: cost rel %.2e, grad rel %.2e' % (abs(c32[i] - ref_cost) / abs(ref_cost), rel(g32[i], ref_grad)))
         assert abs(c32[i] - ref_cost) <= 2e-6 * abs(ref_cost)

@@ -197,3 +197,28 @@ def test_oracle_at_config3_dimensions_vs_reference_spot():
     assert np.max(np.abs(res['post_mean'][0] - g['post_mean'])) <= 5e-3
     assert abs(nll - float(g['nll'])) <= 1e-4
     assert rel(res['post_vsm'][0], g['post_vsm']) <= 1e-5
+
+
+def test_oracle_with_counts_above_255():
+    """Counts above one byte (tests/golden/c1_highcount.npz, captured from the reference): the oracle's callbacks, exact modes,
+    (C,d) cost / gradient and dual callbacks against the reference's values."""
+    g = load_golden('c1_highcount.npz')
+    c1 = load_golden('c1_dataset.npz')
+    Ys = [g['Y'][r].astype(float) for r in range(3)]
+    par = {'C': c1['init_C'], 'd': c1['init_d'], 'tau': c1['init_tau']}
+    q, p, T = 30, 3, 100
+    K = orc.make_K(par['tau'], T, float(c1['binSize']))
+    K_big = orc.make_K_big(K)
+    Kinv_big = np.linalg.inv(K_big)
+    C_big, d_big = orc.make_Cd_big(par['C'], par['d'], T)
+    ybar = Ys[0].reshape(-1)
+    assert abs(orc.nlp_big(g['xprobe'], ybar, C_big, d_big, Kinv_big) - float(g['f'])) <= 1e-12 * abs(float(g['f']))
+    assert np.max(np.abs(orc.nlp_big_grad(g['xprobe'], ybar, C_big, d_big, Kinv_big) - g['g'])) <= 1e-10 * np.max(np.abs(g['g']))
+    res, nll, _ = orc.laplace(Ys, par, float(c1['binSize']), mode='exact', return_cov=False)
+    assert np.max(np.abs(np.stack(res['post_mean']).reshape(3, -1) - g['polished'])) <= 1e-9
+    assert np.max(np.abs(np.stack(res['post_vsm']) - g['post_vsm_polished'])) <= 1e-9 * np.max(np.abs(g['post_vsm_polished']))
+    ref_res = {'post_mean': list(g['post_mean']), 'post_vsm': list(g['post_vsm'])}
+    assert abs(orc.mstep_cd_cost(g['v1'], Ys, ref_res['post_mean'], ref_res['post_vsm'], p, q) - float(g['cost1'])) <= 1e-12 * abs(float(g['cost1']))
+    assert np.max(np.abs(orc.mstep_cd_grad(g['v1'], Ys, ref_res['post_mean'], ref_res['post_vsm'], p, q) - g['grad1'])) <= 1e-11 * np.max(np.abs(g['grad1']))
+    assert abs(orc.dual_cost(g['lam'], ybar, C_big, K_big, Kinv_big, d_big) - float(g['dual_cost'])) <= 1e-10 * abs(float(g['dual_cost']))
+    assert np.max(np.abs(orc.dual_grad(g['lam'], ybar, C_big, K_big, Kinv_big, d_big) - g['dual_grad'])) <= 1e-9 * np.max(np.abs(g['dual_grad']))
