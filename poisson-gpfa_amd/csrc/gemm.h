@@ -40,12 +40,16 @@ struct GemmP {
   int M, N, K;
   double alpha, beta;
   const int* slots;     // batch b -> slot (NULL: identity); pointers advance by slot*stride
-  const int* krange;    // optional [tilesM][2]: k range (multiples of 16) of row tile ti - block-sparse A (NULL: kflags rule)
+  // optional row-tile table [ntab][4] = {first row, end row, k begin, k end} (k multiples of 16, first row even): the row tiles of a block-
+  // sparse A (block-diagonal factors: one latent per tile, so that no tile straddles two latents' zeros).  Tile ti covers rows
+  // [first, min(first + bm, end)); NULL: uniform tiles of bm rows and the kflags rule
+  const int* rtab; int ntab;
+  int bm;               // tile size (rows = columns of a workgroup tile): 128, or 64 for products with few tiles (set by gemm_launch)
   int nbatch;
   int mode, kflags;
   int tilesM, tilesN, ntiles;
   double flops_hint;    // algorithmic flops of the launch when the operands are block sparse (0: dense formula)
-  int k_loop_hint;      // longest k loop of a tile when krange is set (0: derive it from flops_hint / K); host-side use only
+  int k_loop_hint;      // longest k loop of a tile when rtab is set (0: derive it from flops_hint / K); host-side use only
   // optional two-level batch: entry b = hi * nb_lo + lo; `slots` maps lo, hi adds its own strides (nb_lo = 0: one level)
   int nb_lo;
   long long sA_hi, sB_hi, sC_hi;
@@ -58,6 +62,10 @@ struct GemmP {
   int ksplit;
   int c_by_pos;         // C is indexed by batch position instead of slot (compact partial-product buffers)
   const int* skip;      // optional device flag: the launch is a no-op when *skip != 0 (device-side loop control, pcg.h)
+  // optional column list (TRANSB = 1 only): column j of the product is column cols[j] of B and of C, j < N - the multi-RHS products of
+  // the Newton-PCG run over the LIVE slots only, wherever those sit among the chunk's slot vectors
+  const int* cols;
+  int cols_c_off;       // the column list applies to B only (C is a compact partial-product buffer: split-K)
 };
 
 __device__ __forceinline__ size_t gemm_koff(int kseg, long long sseg, int ld, int k) {
@@ -120,7 +128,7 @@ __device__ __forceinline__ void gemm_decode_block(const GemmP& g, int bid, int& 
   }
 }
 
-constexpr int GBM = 128, GBN = 128, GBK = 16, GLS = 144;   // LDS row stride in doubles
+constexpr int GBM = 128, GBN = 128, GBK = 16;   // the large tile (GBN is also the column-tile unit of the zero-skipping consumers of Yt)
 
 // element-type helpers of the MFMA kernel: FP64 (the E-step) and FP32 (mixed-precision dual-variational evaluation: same
 // 16x16x4 tile shape and fragment layout, v_mfma_f32_16x16x4_f32 issues at twice the FP64 rate)
@@ -145,12 +153,21 @@ __device__ __forceinline__ int gemm_bind_t(const GemmP& g, int b, const T*& A, c
   return hi;
 }
 
-template <int TRANSB, typename T>
-__global__ __launch_bounds__(256, 2) void gemm_mfma_kernel_t(GemmP g) {
+// BT: tile size (BT x BT outputs per workgroup, 4 waves of (BT/2) x (BT/2)).  128: 4 x 4 accumulator tiles per wave, the form for
+// products with many tiles.  64: 2 x 2 per wave - a quarter of the work per workgroup, 40 KB of LDS and ~80 registers, so 3-4 workgroups
+// share a CU: thin products (multi-RHS vectors against block-diagonal factors, the r x r preconditioner, short panels) offer 4x the
+// workgroups and hide each other's prologue and epilogue.  FP64 MFMA issues one 16x16x4 per 64 cycles per SIMD, so the extra LDS reads
+// per MFMA of the small tile (1 instead of 1/2) are still far under the LDS roof.
+template <int TRANSB, typename T, int BT>
+__global__ __launch_bounds__(256, BT == 128 ? 2 : 3) void gemm_mfma_kernel_t(GemmP g) {
   using T2 = typename GemmVec<T>::v2;
   using T4 = typename GemmVec<T>::v4;
-  __shared__ __attribute__((aligned(16))) T As[2][GBK][GLS];
-  __shared__ __attribute__((aligned(16))) T Bs[2][GBK][GLS];
+  constexpr int LS = BT + 16;                 // LDS row stride (elements): 2 * LS words = 32 mod 64 for both tile sizes
+  constexpr int WT = BT / 2;                  // wave tile
+  constexpr int MI = WT / 16;                 // 16 x 16 accumulator tiles per wave and dimension
+  constexpr int NU = BT / 32;                 // staging units (pairs of elements) per thread and operand
+  __shared__ __attribute__((aligned(16))) T As[2][GBK][LS];
+  __shared__ __attribute__((aligned(16))) T Bs[2][GBK][LS];
   if (g.skip && *g.skip) return;
 
   const int tid = threadIdx.x;
@@ -167,27 +184,35 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel_t(GemmP g) {
   T* C;                            // may alias A (in-place TRSM): no restrict
   const int hi = gemm_bind_t<T>(g, b, A, B, C);
 
-  const int i0 = ti * GBM, j0 = tj * GBN;
+  int i0 = ti * BT, iend = g.M;
+  const int j0 = tj * BT;
   int kb = 0, ke = g.K;
   if (g.kflags & KF_BEGIN_ROW) kb = i0;
   if (g.kflags & KF_BEGIN_MAXRC) kb = (i0 > j0 ? i0 : j0);
-  if (g.kflags & KF_END_ROW) ke = (i0 + GBM < g.K ? i0 + GBM : g.K);
-  if (g.krange) { kb = g.krange[2 * ti]; ke = g.krange[2 * ti + 1]; }
+  if (g.kflags & KF_END_ROW) ke = (i0 + BT < g.K ? i0 + BT : g.K);
+  if (g.rtab) { i0 = g.rtab[4 * ti]; iend = g.rtab[4 * ti + 1]; kb = g.rtab[4 * ti + 2]; ke = g.rtab[4 * ti + 3]; }
   if (kb > ke) kb = ke;
   gemm_split_range(g.ksplit, hi, kb, ke);
 
-  const bool a_vec = ((((size_t)A) & (2 * sizeof(T) - 1)) == 0) && ((g.lda & 1) == 0);
+  const bool a_vec = ((((size_t)A) & (2 * sizeof(T) - 1)) == 0) && ((g.lda & 1) == 0) && ((i0 & 1) == 0);
   const bool b_vec = ((((size_t)B) & (2 * sizeof(T) - 1)) == 0) && ((g.ldb & 1) == 0);
 
-  // staging registers: 4 x double2 per operand per thread
-  T ra[8], rb[8];
+  // staging registers: NU pairs per operand per thread
+  T ra[2 * NU], rb[2 * NU];
+  // (TRANSB) the B column each staging unit of this thread reads: j0 + nn, or its entry in the column list (clamped inside the list)
+  int bcol[NU];
+#pragma unroll
+  for (int s = 0; s < NU; ++s) {
+    const int jj = j0 + (tid + 256 * s) % BT;
+    bcol[s] = (TRANSB && g.cols) ? g.cols[jj < g.N ? jj : g.N - 1] : jj;
+  }
 
   auto load_tiles = [&](int k0) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < NU; ++s) {
       const int u = tid + 256 * s;
-      {  // A: [k][row] ; unit -> k = u>>6, rows 2*(u&63), +1
-        const int k = u >> 6, r2 = (u & 63) * 2;
+      {  // A: [k][row] ; unit -> k = u / (BT/2), rows 2*(u % (BT/2)), +1
+        const int k = u / (BT / 2), r2 = (u % (BT / 2)) * 2;
         const T* src = A + gemm_koff(g.kseg, g.sAseg, g.lda, k0) + (size_t)k * g.lda + (i0 + r2);
         if (a_vec) {
           const T2 v = *reinterpret_cast<const T2*>(src);
@@ -197,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel_t(GemmP g) {
         }
       }
       if (TRANSB == 0) {
-        const int k = u >> 6, r2 = (u & 63) * 2;
+        const int k = u / (BT / 2), r2 = (u % (BT / 2)) * 2;
         const T* src = B + gemm_koff(g.kseg, g.sBseg, g.ldb, k0) + (size_t)k * g.ldb + (j0 + r2);
         if (b_vec) {
           const T2 v = *reinterpret_cast<const T2*>(src);
@@ -205,9 +230,9 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel_t(GemmP g) {
         } else {
           rb[2 * s] = src[0]; rb[2 * s + 1] = src[1];
         }
-      } else {  // B is K x N: unit -> n = u&127, k pair = u>>7
-        const int nn = u & 127, k2 = (u >> 7) * 2;
-        const T* src = B + (size_t)(j0 + nn) * g.ldb + (k0 + k2);
+      } else {  // B is K x N: unit -> n = u % BT, k pair = u / BT
+        const int nn = u % BT, k2 = (u / BT) * 2;
+        const T* src = B + (size_t)bcol[s] * g.ldb + (k0 + k2);
         if (b_vec) {
           const T2 v = *reinterpret_cast<const T2*>(src);
           rb[2 * s] = v.x; rb[2 * s + 1] = v.y;
@@ -219,32 +244,32 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel_t(GemmP g) {
   };
   auto store_tiles = [&](int buf) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < NU; ++s) {
       const int u = tid + 256 * s;
       {
-        const int k = u >> 6, r2 = (u & 63) * 2;
+        const int k = u / (BT / 2), r2 = (u % (BT / 2)) * 2;
         *reinterpret_cast<T2*>(&As[buf][k][r2]) = T2{ra[2 * s], ra[2 * s + 1]};
       }
       if (TRANSB == 0) {
-        const int k = u >> 6, r2 = (u & 63) * 2;
+        const int k = u / (BT / 2), r2 = (u % (BT / 2)) * 2;
         *reinterpret_cast<T2*>(&Bs[buf][k][r2]) = T2{rb[2 * s], rb[2 * s + 1]};
       } else {
-        const int nn = u & 127, k2 = (u >> 7) * 2;
+        const int nn = u % BT, k2 = (u / BT) * 2;
         Bs[buf][k2][nn] = rb[2 * s];
         Bs[buf][k2 + 1][nn] = rb[2 * s + 1];
       }
     }
   };
 
-  T4 acc[4][4];
+  T4 acc[MI][MI];
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = T4{(T)0, (T)0, (T)0, (T)0};
+    for (int ni = 0; ni < MI; ++ni) acc[mi][ni] = T4{(T)0, (T)0, (T)0, (T)0};
 
-  // a wave whose 64x64 sub-tile lies entirely outside C still stages and syncs, but skips MFMAs
-  const bool wave_live = (i0 + wm * 64 < g.M) && (j0 + wn * 64 < g.N) &&
-                         !((g.mode == GEMM_LOWER) && (i0 + wm * 64 + 63 < j0 + wn * 64));
+  // a wave whose sub-tile lies entirely outside C still stages and syncs, but skips MFMAs
+  const bool wave_live = (i0 + wm * WT < iend) && (j0 + wn * WT < g.N) &&
+                         !((g.mode == GEMM_LOWER) && (i0 + wm * WT + WT - 1 < j0 + wn * WT));
 
   const int nk = (ke - kb) / GBK;
   if (nk > 0) {
@@ -259,15 +284,15 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel_t(GemmP g) {
     if (wave_live) {
 #pragma unroll
       for (int kk = 0; kk < GBK; kk += 4) {
-        T af[4], bf[4];
+        T af[MI], bf[MI];
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) af[mi] = As[buf][kk + l4][wm * 64 + mi * 16 + l15];
+        for (int mi = 0; mi < MI; ++mi) af[mi] = As[buf][kk + l4][wm * WT + mi * 16 + l15];
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) bf[ni] = Bs[buf][kk + l4][wn * 64 + ni * 16 + l15];
+        for (int ni = 0; ni < MI; ++ni) bf[ni] = Bs[buf][kk + l4][wn * WT + ni * 16 + l15];
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < 4; ++ni)
+          for (int ni = 0; ni < MI; ++ni)
             acc[mi][ni] = gemm_mfma16(bf[ni], af[mi], acc[mi][ni]);
       }
     }
@@ -279,19 +304,19 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel_t(GemmP g) {
   // D[row][col = l15]: row <-> j (B index), col <-> i (A index)
   const bool mask_diag = (g.kflags & KF_MASK_DIAG) && (ti == tj);
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
-    const int i = i0 + wm * 64 + mi * 16 + l15;
-    if (i >= g.M) continue;
+  for (int mi = 0; mi < MI; ++mi) {
+    const int i = i0 + wm * WT + mi * 16 + l15;
+    if (i >= iend) continue;
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
+    for (int ni = 0; ni < MI; ++ni) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         // accumulator register r of a lane: row l4 + 4 r of the 16 x 16 tile for FP64, row 4 l4 + r for FP32 (the C/D map of
         // v_mfma_f64_16x16x4_f64 differs from every other shape / dtype on gfx950)
-        const int j = j0 + wn * 64 + ni * 16 + (sizeof(T) == 8 ? l4 + 4 * r : 4 * l4 + r);
+        const int j = j0 + wn * WT + ni * 16 + (sizeof(T) == 8 ? l4 + 4 * r : 4 * l4 + r);
         if (j >= g.N) continue;
         if (mask_diag && i < j) continue;
-        T* dst = C + (size_t)j * g.ldc + i;
+        T* dst = C + (size_t)((TRANSB && g.cols && !g.cols_c_off) ? g.cols[j] : j) * g.ldc + i;
         T v = (T)g.alpha * acc[mi][ni][r];
         if (g.beta != 0.0) v += (T)g.beta * (*dst);
         *dst = v;
@@ -313,25 +338,27 @@ __global__ void gemm_check_kernel(GemmP g) {
   const double* B;
   double* C;
   const int hi = gemm_bind(g, b, A, B, C);
-  const int i0 = ti * GBM, j0 = tj * GBN;
+  const int BT = g.bm;
+  int i0 = ti * BT, iend = g.M;
+  const int j0 = tj * BT;
   int kb = 0, ke = g.K;
   if (g.kflags & KF_BEGIN_ROW) kb = i0;
   if (g.kflags & KF_BEGIN_MAXRC) kb = (i0 > j0 ? i0 : j0);
-  if (g.kflags & KF_END_ROW) ke = (i0 + GBM < g.K ? i0 + GBM : g.K);
-  if (g.krange) { kb = g.krange[2 * ti]; ke = g.krange[2 * ti + 1]; }
+  if (g.kflags & KF_END_ROW) ke = (i0 + BT < g.K ? i0 + BT : g.K);
+  if (g.rtab) { i0 = g.rtab[4 * ti]; iend = g.rtab[4 * ti + 1]; kb = g.rtab[4 * ti + 2]; ke = g.rtab[4 * ti + 3]; }
   if (kb > ke) kb = ke;
   gemm_split_range(g.ksplit, hi, kb, ke);
   const bool mask_diag = (g.kflags & KF_MASK_DIAG) && (ti == tj);
   // compute first, store after a barrier: C may alias A (in-place TRSM)
   double vals[GBM * GBN / 256];
   int cnt = 0;
-  for (int e = threadIdx.x; e < GBM * GBN; e += 256, ++cnt) {
-    const int i = i0 + (e % GBM), j = j0 + (e / GBM);
+  for (int e = threadIdx.x; e < BT * BT; e += 256, ++cnt) {
+    const int i = i0 + (e % BT), j = j0 + (e / BT);
     double s = 0.0;
-    if (i < g.M && j < g.N) {
+    if (i < iend && j < g.N) {
       for (int k = kb; k < ke; ++k) {
         const double a = A[gemm_koff(g.kseg, g.sAseg, g.lda, k) + i];
-        const double bb = TRANSB ? B[(size_t)j * g.ldb + k] : B[gemm_koff(g.kseg, g.sBseg, g.ldb, k) + j];
+        const double bb = TRANSB ? B[(size_t)(g.cols ? g.cols[j] : j) * g.ldb + k] : B[gemm_koff(g.kseg, g.sBseg, g.ldb, k) + j];
         s += a * bb;
       }
     }
@@ -339,12 +366,13 @@ __global__ void gemm_check_kernel(GemmP g) {
   }
   __syncthreads();
   cnt = 0;
-  for (int e = threadIdx.x; e < GBM * GBN; e += 256, ++cnt) {
-    const int i = i0 + (e % GBM), j = j0 + (e / GBM);
-    if (i >= g.M || j >= g.N) continue;
+  const int WT = BT / 2;
+  for (int e = threadIdx.x; e < BT * BT; e += 256, ++cnt) {
+    const int i = i0 + (e % BT), j = j0 + (e / BT);
+    if (i >= iend || j >= g.N) continue;
     if (mask_diag && i < j) continue;
-    if (g.mode == GEMM_LOWER && (i / 64) * 64 + 63 < (j / 64) * 64) continue;
-    double* dst = C + (size_t)j * g.ldc + i;
+    if (g.mode == GEMM_LOWER && ((i - i0) / WT) * WT + i0 + WT - 1 < ((j - j0) / WT) * WT + j0) continue;
+    double* dst = C + (size_t)((TRANSB && g.cols && !g.cols_c_off) ? g.cols[j] : j) * g.ldc + i;
     double v = g.alpha * vals[cnt];
     if (g.beta != 0.0) v += g.beta * (*dst);
     *dst = v;
@@ -353,7 +381,8 @@ __global__ void gemm_check_kernel(GemmP g) {
 
 // C[b] = beta*C[b] + sum_s part[s][b]  (part: [ksplit][nbatch][N][M] compact); grid = (ceil(M*N/256), nbatch)
 __global__ void gemm_splitk_reduce_kernel(const double* __restrict__ part, int ksplit, int M, int N, int nbatch, double* __restrict__ C,
-                                          long long sC, int ldc, const int* __restrict__ slots, double beta, const int* __restrict__ skip) {
+                                          long long sC, int ldc, const int* __restrict__ slots, double beta, const int* __restrict__ skip,
+                                          const int* __restrict__ cols) {
   if (skip && *skip) return;
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (size_t)M * N) return;
@@ -362,7 +391,7 @@ __global__ void gemm_splitk_reduce_kernel(const double* __restrict__ part, int k
   const size_t i = e % M, j = e / M;
   double s = 0.0;
   for (int k = 0; k < ksplit; ++k) s += part[((size_t)k * nbatch + b) * M * N + e];
-  double* dst = C + slot * sC + j * ldc + i;
+  double* dst = C + slot * sC + (cols ? (size_t)cols[j] : j) * ldc + i;
   *dst = (beta != 0.0) ? beta * (*dst) + s : s;
 }
 
@@ -390,22 +419,31 @@ inline int gemm_count_tiles(int mode, int tilesM, int tilesN) {
   return n;
 }
 
-// Host launcher.  K, and every k range implied by kflags, must be a multiple of 16.
+// Host launcher.  K, and every k range implied by kflags, must be a multiple of 16.  g.bm selects the tile size (0: 128).
 inline hipError_t gemm_launch(hipStream_t st, bool use_mfma, bool transb, GemmP g, bool f32 = false) {
-  g.tilesM = (g.M + GBM - 1) / GBM;
-  g.tilesN = (g.N + GBN - 1) / GBN;
+  if (g.bm != 64) g.bm = 128;
+  if (f32) g.bm = 128;                                   // (single precision: large tiles only)
+  g.tilesM = g.rtab ? g.ntab : (g.M + g.bm - 1) / g.bm;
+  g.tilesN = (g.N + g.bm - 1) / g.bm;
   g.ntiles = gemm_count_tiles(g.mode, g.tilesM, g.tilesN);
   if (g.ntiles <= 0 || g.nbatch <= 0 || g.M <= 0 || g.N <= 0) return hipSuccess;
   if (g.kseg != 0 && (transb || g.kseg % GBK != 0)) return hipErrorInvalidValue;
+  if (g.rtab && g.mode != GEMM_FULL) return hipErrorInvalidValue;
+  if (g.cols && !transb) return hipErrorInvalidValue;
   const long long blocks = (long long)g.ntiles * g.nbatch;
   dim3 grid((unsigned)blocks);
   if (f32) {
     if (g.kseg != 0) return hipErrorInvalidValue;        // (segmented K addresses are computed for FP64 operands only)
-    if (transb) hipLaunchKernelGGL((gemm_mfma_kernel_t<1, float>), grid, dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((gemm_mfma_kernel_t<0, float>), grid, dim3(256), 0, st, g);
+    if (transb) hipLaunchKernelGGL((gemm_mfma_kernel_t<1, float, 128>), grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemm_mfma_kernel_t<0, float, 128>), grid, dim3(256), 0, st, g);
   } else if (use_mfma) {
-    if (transb) hipLaunchKernelGGL((gemm_mfma_kernel_t<1, double>), grid, dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((gemm_mfma_kernel_t<0, double>), grid, dim3(256), 0, st, g);
+    if (g.bm == 64) {
+      if (transb) hipLaunchKernelGGL((gemm_mfma_kernel_t<1, double, 64>), grid, dim3(256), 0, st, g);
+      else hipLaunchKernelGGL((gemm_mfma_kernel_t<0, double, 64>), grid, dim3(256), 0, st, g);
+    } else {
+      if (transb) hipLaunchKernelGGL((gemm_mfma_kernel_t<1, double, 128>), grid, dim3(256), 0, st, g);
+      else hipLaunchKernelGGL((gemm_mfma_kernel_t<0, double, 128>), grid, dim3(256), 0, st, g);
+    }
   } else {
     if (transb) hipLaunchKernelGGL(gemm_check_kernel<1>, grid, dim3(256), 0, st, g);
     else hipLaunchKernelGGL(gemm_check_kernel<0>, grid, dim3(256), 0, st, g);

@@ -164,6 +164,7 @@ struct pgpfa_ctx {
   int *d_rank = nullptr, *d_blk_lat = nullptr, *d_blk_col = nullptr, *d_roff = nullptr;
   int *d_kr_ft = nullptr, *d_kr_f = nullptr;     // per-row-tile k ranges of the block-diagonal F^T / F GEMMs
   int kr_ft_len = 0, kr_f_len = 0;               // longest of those ranges
+  int ntab_ft = 0, ntab_f = 0; size_t tab_cap = 0;   // entries of the two row-tile tables, capacity (ints) of their device buffers
   double *Fbig = nullptr, *FTbig = nullptr, *Gbar = nullptr, *Wtbar = nullptr;   // low-rank shared preconditioner
   std::vector<int> rk, roff;                      // ranks padded to 16, offsets
   int rtot = 0, rpad = 0;
@@ -177,16 +178,20 @@ struct pgpfa_ctx {
   // The arena is a reserved virtual address range into which physical memory is mapped as the need grows (HIP virtual memory
   // management): growing never moves it and only the NEW bytes pay the driver's page clearing (~25 ms per GB).  vmm: 0 untried,
   // 1 in use, -1 unavailable (plain hipMalloc of the size needed, re-allocated on growth).
-  int vmm = 0; size_t va_size = 0, vmm_gran = 0;
+  int vmm = 0; size_t va_size = 0, vmm_gran = 0, vmm_granule = (size_t)1 << 30;
   std::vector<std::pair<hipMemGenericAllocationHandle_t, size_t>> vmm_chunks;
-  double arena_headroom = 1.5;                  // rank head-room of a low-rank plan (option workspace_headroom)
+  double arena_headroom = 2.0;                  // rank head-room of a low-rank plan (option workspace_headroom)
   bool mt_dirty = false;                          // low-rank use scribbled over the Mt slabs' zero triangle
   bool last_cov_lowrank = false;
   bool shared_pcg = true;
+  bool pcg_trace = false;
   bool time_newton = false;                       // option time_newton: HIP events around the inner PCG solves (last_newton_solve_ms / _bytes)
   int shared_min = 16, pcg_inner_min = 2, pcg_inner_max = 16, pcg_outer_max = 12;
   double pcg_eta0 = 1e-2;
   int splitk_target = 1280;                      // thin GEMMs are cut along k until about this many workgroups are in flight
+  int small_tile_below = 1 << 30;                // products with fewer 128 x 128 tiles than this run on 64 x 64 tiles (0: never); measured: the
+                                                 // small tile wins at every shape of the E-step (44.5 -> 50 TFLOP/s on the largest launch too)
+  int splitk_below64 = 160;                      // ... and are cut along k only below this many 64 x 64 tiles
   double *sc_f = nullptr, *sc_qxx = nullptr, *sc_qdx = nullptr, *sc_qdd = nullptr, *sc_dec = nullptr, *sc_smax = nullptr, *sc_alpha = nullptr;
   int *trial_of_slot = nullptr, *list_a = nullptr, *list_b = nullptr, *ident = nullptr;
   int* mask_of_slot = nullptr;                    // leave-one-neuron-out passes: neuron excluded from the likelihood of a slot
@@ -338,18 +343,29 @@ int gemm(pgpfa_ctx* c, bool transb, GemmP g, bool f32 = false) {
     char key[160];
     std::snprintf(key, sizeof key, "%s %s M=%d N=%d K=%d%s batch=%d%s%s%s", f32 ? "f32" : "f64", transb ? "NN" : "NT", g.M, g.N, g.K,
                   g.kseg ? " (segmented)" : "", std::max(g.nbatch, 1), g.mode == GEMM_LOWER ? " lower" : "",
-                  g.kflags ? " triangular-k" : "", g.krange ? " block-sparse" : "");
+                  g.kflags ? " triangular-k" : "", g.rtab ? " block-sparse" : "");
     c->prof.recs.back().shape = key;
   }
-  // Few output tiles and a long k loop (the thin multi-RHS products of the PCG iterations): the launch would occupy a
-  // fraction of the 256 CUs for the length of one k loop.  Cut k into parts run as extra batch entries, sum the
-  // partial products afterwards.
-  const int tiles = ((g.M + GBM - 1) / GBM) * ((g.N + GBN - 1) / GBN) * std::max(g.nbatch, 1);
+  // Tile size: products that offer few 128 x 128 tiles (multi-RHS vectors against the block-diagonal factors and the r x r
+  // preconditioner, K^-1 p, the short panels of the r x r factorisations) run on 64 x 64 tiles - four times the workgroups, 3-4 of
+  // them resident per CU; everything with a row-tile table is laid out for 64-row tiles.
+  if (g.bm == 0) {
+    const long long t128 = (long long)((g.M + GBM - 1) / GBM) * ((g.N + GBN - 1) / GBN) * std::max(g.nbatch, 1);
+    g.bm = (!f32 && c->mfma && (g.rtab || t128 < c->small_tile_below)) ? 64 : 128;
+  }
+  if (g.rtab) g.bm = 64;
+  // in-place products (the TRSM of the factorisation writes its own A panel: one 128-wide column tile reads all of it before it stores)
+  // must keep the tile that covers the whole panel
+  if ((const double*)g.C == g.A || (const double*)g.C == g.B) g.bm = 128;
+  // Few output tiles and a long k loop: the launch would occupy a fraction of the 256 CUs for the length of one k loop.  Cut k into
+  // parts run as extra batch entries, sum the partial products afterwards.
+  const int tiles = (g.rtab ? g.ntab : (g.M + g.bm - 1) / g.bm) * ((g.N + g.bm - 1) / g.bm) * std::max(g.nbatch, 1);
   int ksplit = 1;
   // (block-sparse operands: the k loop a tile really runs is the one implied by the flop count)
   const double k_eff = g.k_loop_hint > 0 ? (double)g.k_loop_hint
                        : (g.flops_hint > 0.0 && g.M > 0 && g.N > 0) ? g.flops_hint / (2.0 * g.M * g.N * std::max(g.nbatch, 1)) : (double)g.K;
-  if (!f32 && c->gemm_part && g.mode == GEMM_FULL && g.kflags == 0 && g.nb_lo == 0 && g.kseg == 0 && tiles > 0 && tiles < 384 && k_eff >= 128.0) {
+  const int split_below = g.bm == 64 ? c->splitk_below64 : 384;
+  if (!f32 && c->gemm_part && g.mode == GEMM_FULL && g.kflags == 0 && g.nb_lo == 0 && g.kseg == 0 && tiles > 0 && tiles < split_below && k_eff >= 128.0) {
     // (a lone workgroup per CU walks its k loop at the latency of one global load per 16-wide step: with a handful of
     // tiles even a 128-long loop is worth cutting, down to parts of two steps)
     ksplit = std::min(std::min(8, (int)(k_eff / (tiles < 64 ? 32.0 : 64.0))), (c->splitk_target + tiles - 1) / tiles);
@@ -362,10 +378,11 @@ int gemm(pgpfa_ctx* c, bool transb, GemmP g, bool f32 = false) {
     s.nb_lo = g.nbatch; s.nbatch = g.nbatch * ksplit; s.sA_hi = 0; s.sB_hi = 0; s.sC_hi = (long long)g.nbatch * g.M * g.N;
     s.ksplit = ksplit;
     s.c_by_pos = 1;                      // partial products are indexed by batch position, the operands by slot
+    s.cols_c_off = 1;                    // ... and by column position: the reduction applies the column list
     e = gemm_launch(c->st, c->mfma, transb, s);
     if (e == hipSuccess) {
       hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)(((size_t)g.M * g.N + 255) / 256), g.nbatch), dim3(256), 0, c->st, c->gemm_part,
-                         ksplit, g.M, g.N, g.nbatch, g.C, g.sC, g.ldc, g.slots, g.beta, g.skip);
+                         ksplit, g.M, g.N, g.nbatch, g.C, g.sC, g.ldc, g.slots, g.beta, g.skip, g.cols);
       e = hipGetLastError();
     }
   } else {
@@ -518,7 +535,10 @@ int free_workspace(pgpfa_ctx* c) {
 // Grow the arena to at least `need` bytes.  Preferred: map more physical memory behind the reserved address range (the arena does not
 // move, the bytes already mapped are not cleared again).  Fallback when the virtual-memory calls are not available: free and
 // re-allocate at the size needed.
+void arena_release(pgpfa_ctx* c);
+
 int arena_grow(pgpfa_ctx* c, size_t need) {
+  g_err.clear();
   if (c->vmm == 0) {
     hipMemAllocationProp prop{};
     prop.type = hipMemAllocationTypePinned;
@@ -537,38 +557,47 @@ int arena_grow(pgpfa_ctx* c, size_t need) {
   }
   if (c->vmm == 1) {
     const size_t gran = c->vmm_gran;
-    // chunks of at least 1 GiB (fewer mappings), never past the reserved range
-    size_t add = std::max(need - c->arena_cap, (size_t)1 << 30);
-    add = (add + gran - 1) / gran * gran;
-    if (c->arena_cap + add > c->va_size) add = (need - c->arena_cap + gran - 1) / gran * gran;
-    if (c->arena_cap + add <= c->va_size) {
-      hipMemAllocationProp prop{};
-      prop.type = hipMemAllocationTypePinned;
-      prop.location.type = hipMemLocationTypeDevice;
-      prop.location.id = c->device;
+    // physical chunks of ONE granule each (one hipMemCreate / hipMemMap / hipMemSetAccess per chunk; 1 GiB by default).  Measured on this
+    // stack: hipMemSetAccess returns "invalid argument" for a chunk whose size differs from the first one mapped into the range (13 chunks
+    // of 4 GiB, then a 1-GiB remainder: fails; 1 GiB then 4 GiB: fails), so every chunk has the same size.
+    const size_t G = std::max(gran, c->vmm_granule) / gran * gran;
+    size_t want = (need - c->arena_cap + G - 1) / G * G;
+    const char* what = "address range exhausted";
+    hipError_t err = hipSuccess;
+    bool ok = c->arena_cap + want <= c->va_size;
+    const size_t piece_max = G;
+    hipMemAllocationProp prop{};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = c->device;
+    hipMemAccessDesc desc{};
+    desc.location = prop.location;
+    desc.flags = hipMemAccessFlagsProtReadWrite;
+    while (ok && want > 0) {
+      const size_t add = std::min(want, std::max(piece_max, gran));
       hipMemGenericAllocationHandle_t h;
-      if (hipMemCreate(&h, add, &prop, 0) == hipSuccess) {
-        hipMemAccessDesc desc{};
-        desc.location = prop.location;
-        desc.flags = hipMemAccessFlagsProtReadWrite;
-        if (hipMemMap(c->arena + c->arena_cap, add, 0, h, 0) == hipSuccess) {
-          if (hipMemSetAccess(c->arena + c->arena_cap, add, &desc, 1) == hipSuccess) {
-            c->vmm_chunks.emplace_back(h, add);
-            c->arena_cap += add;
-            c->bytes += add;
-            c->info["arena_bytes"] = (double)c->arena_cap;
-            return 0;
-          }
-          hipMemUnmap(c->arena + c->arena_cap, add);
-        }
-        hipMemRelease(h);
-      }
-      (void)hipGetLastError();
+      err = hipMemCreate(&h, add, &prop, 0);
+      if (err != hipSuccess) { what = "hipMemCreate"; ok = false; break; }
+      err = hipMemMap(c->arena + c->arena_cap, add, 0, h, 0);
+      if (err != hipSuccess) { what = "hipMemMap"; hipMemRelease(h); ok = false; break; }
+      err = hipMemSetAccess(c->arena + c->arena_cap, add, &desc, 1);
+      if (err != hipSuccess) { what = "hipMemSetAccess"; hipMemUnmap(c->arena + c->arena_cap, add); hipMemRelease(h); ok = false; break; }
+      c->vmm_chunks.emplace_back(h, add);
+      c->arena_cap += add;
+      c->bytes += add;
+      want -= add;
     }
-    if (c->arena_cap > 0) return 1;            // part of the range is in use: cannot fall back to another allocation scheme now
-    hipMemAddressFree(c->arena, c->va_size);
+    c->info["arena_bytes"] = (double)c->arena_cap;
+    if (ok) return 0;
     (void)hipGetLastError();
-    c->arena = nullptr; c->va_size = 0; c->vmm = -1;
+    // (the arena only grows between plans, when nothing in it is live: give the range back and carry on with one plain allocation)
+    c->info["arena_vmm_failed"] = 1.0;
+    std::fprintf(stderr, "pgpfa: workspace arena: %s failed (%s) growing from %zu to %zu bytes; falling back to hipMalloc\n", what,
+                 hipGetErrorString(err), c->arena_cap, need);
+    c->bytes -= c->arena_cap;
+    arena_release(c);
+    (void)hipGetLastError();
+    c->va_size = 0; c->vmm = -1;
   }
   if (c->arena) { hipFree(c->arena); c->bytes -= c->arena_cap; }
   c->arena = nullptr; c->arena_cap = 0;
@@ -615,7 +644,7 @@ int ensure_workspace(pgpfa_ctx* c, bool plan_lr) {
     budget = budget > shared ? budget - shared : 0;
   }
   // Low-rank plan: the learnt timescales of a fit move, and the ranks with them.  The slabs get head-room for the ranks to grow by
-  // `arena_headroom` (1.5: Yt slab x 1.5, r x r slab x 2.25) before the plan has to be re-made, when that fits next to the whole
+  // `arena_headroom` (2: Yt slab x 2, r x r slab x 4) before the plan has to be re-made, when that fits next to the whole
   // trial list; a re-plan re-partitions the arena and maps more physical memory into it if it must (only the new bytes cost).
   c->slab_elems = slab;
   c->mt_elems = mt;
@@ -684,7 +713,11 @@ int ensure_workspace(pgpfa_ctx* c, bool plan_lr) {
   const size_t need = c->arena_off + ((size_t)1 << 20);
   if (need > c->arena_cap) {
     HIPC(hipStreamSynchronize(c->st));
-    if (arena_grow(c, need)) { c->B = 0; return fail("not enough device memory for the chunk workspace (%zu bytes needed, %zu free)", need, free_b); }
+    if (arena_grow(c, need)) {
+      c->B = 0;
+      const std::string why = g_err;
+      return fail("not enough device memory for the chunk workspace (%zu bytes needed, %zu free)%s%s", need, free_b, why.empty() ? "" : ": ", why.c_str());
+    }
   }
   c->arena_mode = 2; c->arena_off = 0;
   rc_carve = carve();
@@ -814,9 +847,12 @@ int prior_mv(pgpfa_ctx* c, const int* d_list, int nl, const double* in, double* 
 }
 
 // out[slot][k] = mat_k * in[slot][k] for ALL slots [0,nb) as one batched MFMA GEMM (batch = latents, N = slots)
-int prior_mv_all(pgpfa_ctx* c, int nb, const double* in, double* out, const double* mat = nullptr, const int* skip = nullptr) {
+// (cols / ncols: only the listed slots - the live ones of a Newton-PCG solve; the product then has ncols columns)
+int prior_mv_all(pgpfa_ctx* c, int nb, const double* in, double* out, const double* mat = nullptr, const int* skip = nullptr,
+                 const int* cols = nullptr, int ncols = 0) {
   GemmP g{};
   g.skip = skip;
+  if (cols) { g.cols = cols; nb = ncols; }
   g.A = mat ? mat : c->Kinv; g.sA = (long long)c->Tp * c->Tp; g.lda = c->Tp;
   g.B = in; g.sB = c->T; g.ldb = c->ld;                 // latent k: rows k*T.. of every slot vector (K x N column-major)
   g.C = out; g.sC = c->T; g.ldc = c->ld;
@@ -889,31 +925,22 @@ int build_lowrank(pgpfa_ctx* c) {
   CHK(upload_list(c, c->d_blk_col, col));
   CHK(upload_list(c, c->d_roff, c->roff));
   {
-    // F^T (rpad x n): row tile ti holds rank rows [128 ti, 128 ti + 128) -> latents k1..k2 -> columns [k1*T, (k2+1)*T)
-    std::vector<int> krft(2 * (c->rpad / NB), 0), krf(2 * (c->npad / NB), 0);
-    auto latent_of_rank = [&](int r) { int k = 0; while (k + 1 < p && c->roff[k + 1] <= r) ++k; return k; };
-    for (int ti = 0; ti < c->rpad / NB; ++ti) {
-      const int r0 = ti * NB, r1 = std::min(ti * NB + NB, c->rtot) - 1;
-      if (r0 >= c->rtot) { krft[2 * ti] = 0; krft[2 * ti + 1] = 0; continue; }
-      const int k1 = latent_of_rank(r0), k2 = latent_of_rank(r1);
-      krft[2 * ti] = (k1 * T) / 16 * 16;
-      krft[2 * ti + 1] = std::min(c->npad, round_up((k2 + 1) * T, 16));
-    }
-    // F (n x rpad): row tile ti holds rows [128 ti, ..) -> latents k1..k2 -> rank columns [roff[k1], roff[k2+1])
-    for (int ti = 0; ti < c->npad / NB; ++ti) {
-      const int i0 = ti * NB, i1 = std::min(ti * NB + NB, c->n) - 1;
-      if (i0 >= c->n) { krf[2 * ti] = 0; krf[2 * ti + 1] = 0; continue; }
-      const int k1 = i0 / T, k2 = i1 / T;
-      krf[2 * ti] = c->roff[k1];
-      krf[2 * ti + 1] = c->roff[k2 + 1];
-    }
-    CHK(upload_list(c, c->d_kr_ft, krft));
-    CHK(upload_list(c, c->d_kr_f, krf));
-    // longest k loop a tile of these block-sparse products runs (what the split-K decision should look at: the flop count
-    // under-states it, a row tile that spans several latents walks all their bins)
+    // Row-tile tables of the two block-diagonal products of the low-rank preconditioner, 64 rows per tile, one latent per tile:
+    // F^T (rpad x n): rank rows [roff[k], roff[k+1]) x the latent's bins [kT, (k+1)T) (rounded out to multiples of 16: the
+    //   neighbours' columns in these rows are zero);  F (n x rpad): rows [kT, (k+1)T) x the latent's rank columns.
+    std::vector<int> tft, tf;
     c->kr_ft_len = 0; c->kr_f_len = 0;
-    for (size_t i = 0; i + 1 < krft.size(); i += 2) c->kr_ft_len = std::max(c->kr_ft_len, krft[i + 1] - krft[i]);
-    for (size_t i = 0; i + 1 < krf.size(); i += 2) c->kr_f_len = std::max(c->kr_f_len, krf[i + 1] - krf[i]);
+    for (int k = 0; k < p; ++k) {
+      const int kb = (k * T) / 16 * 16, ke = std::min(c->npad, round_up((k + 1) * T, 16));
+      for (int r0 = c->roff[k]; r0 < c->roff[k + 1]; r0 += 64) { tft.push_back(r0); tft.push_back(c->roff[k + 1]); tft.push_back(kb); tft.push_back(ke); }
+      c->kr_ft_len = std::max(c->kr_ft_len, ke - kb);
+      for (int i0 = k * T; i0 < (k + 1) * T; i0 += 64) { tf.push_back(i0); tf.push_back((k + 1) * T); tf.push_back(c->roff[k]); tf.push_back(c->roff[k + 1]); }
+      c->kr_f_len = std::max(c->kr_f_len, c->rk[k]);
+    }
+    c->ntab_ft = (int)tft.size() / 4; c->ntab_f = (int)tf.size() / 4;
+    if (tft.size() > c->tab_cap || tf.size() > c->tab_cap) return fail("internal: row-tile table overflow");
+    CHK(upload_list(c, c->d_kr_ft, tft));
+    CHK(upload_list(c, c->d_kr_f, tf));
   }
   if ((size_t)c->rpad <= (size_t)c->ld) {
     HIPC(hipMemsetAsync(c->Fbig, 0, (size_t)c->ld * c->rpad * sizeof(double), c->st));
@@ -1041,7 +1068,8 @@ int pgpfa_create(pgpfa_ctx** out, int device, int q, int p, int T, int R, double
   c->trial_dual.assign(R, 0);
   rc |= dmalloc(c, &c->Flr, slab * p + 256 * (size_t)c->Tp, true);
   rc |= dmalloc(c, &c->d_rank, p); rc |= dmalloc(c, &c->d_roff, p + 1);
-  rc |= dmalloc(c, &c->d_kr_ft, 2 * (size_t)(c->ld / NB + 2)); rc |= dmalloc(c, &c->d_kr_f, 2 * (size_t)(c->ld / NB + 2));
+  c->tab_cap = 4 * ((size_t)c->ld / 64 + 2 * (size_t)p + 4);
+  rc |= dmalloc(c, &c->d_kr_ft, c->tab_cap); rc |= dmalloc(c, &c->d_kr_f, c->tab_cap);
   rc |= dmalloc(c, &c->Fbig, (size_t)c->ld * c->ld + 256 * (size_t)c->ld, true); rc |= dmalloc(c, &c->FTbig, (size_t)c->ld * c->ld + 256 * (size_t)c->ld, true);
   rc |= dmalloc(c, &c->Gbar, (size_t)T * p * p + 64); rc |= dmalloc(c, &c->Wtbar, (size_t)T * p * p + 64); rc |= dmalloc(c, &c->d_blk_lat, (size_t)p * c->Tp / 16 + 64); rc |= dmalloc(c, &c->d_blk_col, (size_t)p * c->Tp / 16 + 64);
   rc |= dmalloc(c, &c->vec, (size_t)q * (p + 1));
@@ -1111,6 +1139,7 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
   else if (k == "chord") c->chord = (v != 0.0);
   else if (k == "shared_pcg") c->shared_pcg = (v != 0.0);
   else if (k == "time_newton") c->time_newton = (v != 0.0);
+  else if (k == "pcg_trace") c->pcg_trace = (v != 0.0);
   else if (k == "cov_mode") c->cov_mode = (int)v;
   else if (k == "lowrank_tol") c->lr_tol = v;
   else if (k == "keep_trial_vsmgp") c->keep_trial_vsmgp = (v != 0.0);
@@ -1125,6 +1154,8 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
   else if (k == "pcg_inner") c->pcg_inner_max = std::max(1, (int)v);
   else if (k == "pcg_eta0") c->pcg_eta0 = v;
   else if (k == "splitk_target") c->splitk_target = std::max(1, (int)v);
+  else if (k == "small_tile_below") c->small_tile_below = (int)v;
+  else if (k == "splitk_below64") c->splitk_below64 = (int)v;
   else if (k == "pcg_outer_max") c->pcg_outer_max = (int)v;
   else if (k == "chord_xtol") c->chord_xtol = v;
   else if (k == "chord_rho") c->chord_rho = v;
@@ -1132,6 +1163,7 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
   else if (k == "chord_max") c->chord_max = (int)v;
   else if (k == "chunk_trials") { if (c->B > 0) return fail("chunk_trials must be set before the first E-step"); c->chunk_opt = (int)v; }
   else if (k == "workspace_headroom") c->arena_headroom = std::max(1.0, v);
+  else if (k == "workspace_granule_mb") c->vmm_granule = (size_t)std::max(2.0, v) << 20;
   else if (k == "workspace_vmm") { if (c->arena_cap > 0) return fail("workspace_vmm must be set before the first E-step"); c->vmm = (v != 0.0) ? 0 : -1; }
   else if (k == "eps_noise") c->eps = v;
   else if (k == "profile") {
@@ -1471,7 +1503,8 @@ static int remember_trials(pgpfa_ctx* c, const std::vector<int>& v) {
 // (skip: device stop flag of the inner PCG loop; final_apply = false leaves the last per-bin application to the caller, with
 // y = F Sb F^T Gb R in c->Xt; first_apply = false: the caller has already put Gb R into c->Xt)
 static int shared_solve(pgpfa_ctx* c, int nb, const double* R, double* Z, const int* skip = nullptr, bool first_apply = true,
-                        bool final_apply = true) {
+                        bool final_apply = true, const int* cols = nullptr, int ncols = 0) {
+  const int ng = cols ? ncols : nb;                // columns of the multi-RHS products: all slots, or the listed (live) ones
   if (c->plan_lowrank) {
     const long long ld = c->ld;
     const int rpad = c->rpad;
@@ -1492,19 +1525,19 @@ static int shared_solve(pgpfa_ctx* c, int nb, const double* R, double* Z, const 
     GemmP y{};
     y.skip = skip;                                               // Y = F^T (Gb R)          (rpad x nb)
     y.A = c->FTbig; y.sA = 0; y.lda = rpad; y.B = c->Xt; y.sB = 0; y.ldb = c->ld; y.C = c->Glt; y.sC = 0; y.ldc = c->ld;
-    y.M = rpad; y.N = nb; y.K = c->npad; y.alpha = 1.0; y.beta = 0.0; y.slots = nullptr; y.nbatch = 1; y.mode = GEMM_FULL; y.kflags = 0;
-    y.krange = c->d_kr_ft; y.k_loop_hint = c->kr_ft_len; y.flops_hint = 2.0 * c->T * c->rtot * nb;      // block-diagonal operand: only T x r_k blocks are non-zero
+    y.M = rpad; y.N = ng; y.K = c->npad; y.cols = cols; y.alpha = 1.0; y.beta = 0.0; y.slots = nullptr; y.nbatch = 1; y.mode = GEMM_FULL; y.kflags = 0;
+    y.rtab = c->d_kr_ft; y.ntab = c->ntab_ft; y.k_loop_hint = c->kr_ft_len; y.flops_hint = 2.0 * c->T * c->rtot * ng;      // block-diagonal operand: only T x r_k blocks are non-zero
     CHK(gemm(c, true, y));
     GemmP z{};                                               // Zs = Sb Y
     z.skip = skip;
     z.A = c->sU; z.sA = 0; z.lda = rpad; z.B = c->Glt; z.sB = 0; z.ldb = c->ld; z.C = c->KD; z.sC = 0; z.ldc = c->ld;
-    z.M = rpad; z.N = nb; z.K = rpad; z.alpha = 1.0; z.beta = 0.0; z.slots = nullptr; z.nbatch = 1; z.mode = GEMM_FULL; z.kflags = 0;
+    z.M = rpad; z.N = ng; z.K = rpad; z.cols = cols; z.alpha = 1.0; z.beta = 0.0; z.slots = nullptr; z.nbatch = 1; z.mode = GEMM_FULL; z.kflags = 0;
     CHK(gemm(c, true, z));
     GemmP q{};                                               // Q = F Zs                (n x nb)
     q.skip = skip;
     q.A = c->Fbig; q.sA = 0; q.lda = c->ld; q.B = c->KD; q.sB = 0; q.ldb = c->ld; q.C = c->Xt; q.sC = 0; q.ldc = c->ld;
-    q.M = c->n; q.N = nb; q.K = rpad; q.alpha = 1.0; q.beta = 0.0; q.slots = nullptr; q.nbatch = 1; q.mode = GEMM_FULL; q.kflags = 0;
-    q.krange = c->d_kr_f; q.k_loop_hint = c->kr_f_len; q.flops_hint = 2.0 * c->T * c->rtot * nb;
+    q.M = c->n; q.N = ng; q.K = rpad; q.cols = cols; q.alpha = 1.0; q.beta = 0.0; q.slots = nullptr; q.nbatch = 1; q.mode = GEMM_FULL; q.kflags = 0;
+    q.rtab = c->d_kr_f; q.ntab = c->ntab_f; q.k_loop_hint = c->kr_f_len; q.flops_hint = 2.0 * c->T * c->rtot * ng;
     CHK(gemm(c, true, q));
     if (final_apply) apply_bin(R, c->Xt, c->eps, Z);
     HIPC(hipGetLastError());
@@ -1515,7 +1548,7 @@ static int shared_solve(pgpfa_ctx* c, int nb, const double* R, double* Z, const 
   g.A = c->sU; g.sA = 0; g.lda = c->ld;                      // P^-1, symmetric
   g.B = R; g.sB = 0; g.ldb = c->ld;                          // K x N column-major: slot vectors
   g.C = Z; g.sC = 0; g.ldc = c->ld;
-  g.M = c->npad; g.N = nb; g.K = c->npad; g.alpha = 1.0; g.beta = 0.0;
+  g.M = c->npad; g.N = ng; g.K = c->npad; g.alpha = 1.0; g.beta = 0.0; g.cols = cols;
   g.slots = nullptr; g.nbatch = 1; g.mode = GEMM_FULL; g.kflags = 0;
   return gemm(c, true, g);
 }
@@ -2030,7 +2063,7 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
                                sW32, T, p, c->list_a);
           const dim3 gbin(ntile, (na + PCG_SLOTS - 1) / PCG_SLOTS);
           // z0 = P^-1 r0, p0 = z0
-          CHK(shared_solve(c, nb, c->Rv, c->Zv, nullptr, true, false));
+          CHK(shared_solve(c, nb, c->Rv, c->Zv, nullptr, true, false, c->list_a, na));
           dispatch_pw(p, [&](auto pw) {
             constexpr int PW = decltype(pw)::value;
             if constexpr (PW <= 16)
@@ -2040,7 +2073,7 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
           hipLaunchKernelGGL(pcg_update_p2_kernel, dim3(na), dim3(256), 0, c->st, c->Zv, c->Pv, ld, nvec, c->list_a, c->sc_part2, ntile, c->sc_rz,
                              c->sc_rr, c->sc_rr0, 1, (PcgCtl*)nullptr);
           for (int it = 0; it < c->pcg_inner_max; ++it) {
-            CHK(prior_mv_all(c, nb, c->Pv, c->Qv, nullptr, skip));
+            CHK(prior_mv_all(c, nb, c->Pv, c->Qv, nullptr, skip, c->list_a, na));
             dispatch_pw(p, [&](auto pw) {
               constexpr int PW = decltype(pw)::value;
               if constexpr (PW <= 16) {
@@ -2054,7 +2087,7 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
                                    c->list_a, na, c->sc_rz, c->sc_pq, ntile, skip);
               }
             });
-            CHK(shared_solve(c, nb, c->Rv, c->Zv, skip, false, false));
+            CHK(shared_solve(c, nb, c->Rv, c->Zv, skip, false, false, c->list_a, na));
             dispatch_pw(p, [&](auto pw) {
               constexpr int PW = decltype(pw)::value;
               if constexpr (PW <= 16)
@@ -2079,10 +2112,10 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
           HIPC(hipGetLastError());
           done_inner = -1;                                     // read from the control block with the scalars below
         } else {
-        CHK(shared_solve(c, nb, c->Rv, c->Zv));
+        CHK(shared_solve(c, nb, c->Rv, c->Zv, nullptr, true, true, c->list_a, na));
         hipLaunchKernelGGL(pcg_update_p_kernel, dim3(na), dim3(256), 0, c->st, c->Rv, c->Zv, c->Pv, ld, nvec, c->list_a, c->sc_rz, c->sc_rr0, 1);
         for (int it = 0; it < c->pcg_inner_max; ++it) {
-          CHK(prior_mv_all(c, nb, c->Pv, c->Qv));
+          CHK(prior_mv_all(c, nb, c->Pv, c->Qv, nullptr, nullptr, c->list_a, na));
           int pq_tiles = 1;
           dispatch_pw(p, [&](auto pw) {
             constexpr int PW = decltype(pw)::value;
@@ -2097,7 +2130,7 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
           });
           hipLaunchKernelGGL(pcg_update_xr_kernel, dim3(na), dim3(256), 0, c->st, c->Dl, c->Rv, c->Pv, c->Qv, ld, nvec, c->list_a, c->sc_rz, c->sc_pq,
                              pq_tiles);
-          CHK(shared_solve(c, nb, c->Rv, c->Zv));
+          CHK(shared_solve(c, nb, c->Rv, c->Zv, nullptr, true, true, c->list_a, na));
           hipLaunchKernelGGL(pcg_update_p_kernel, dim3(na), dim3(256), 0, c->st, c->Rv, c->Zv, c->Pv, ld, nvec, c->list_a, c->sc_rz, c->sc_rr, 0);
           done_inner = it + 1;
           if (done_inner >= c->pcg_inner_min) {
@@ -2129,6 +2162,16 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
         }
         if (done_inner < 0) done_inner = c->h_pcg[1];           // (the download above synchronised the stream)
         n_pcg += (double)na * done_inner;
+        if (c->pcg_trace) {
+          // achieved residual ratios of the live slots: worst, median, and how many already met the target
+          std::vector<double> ratio;
+          for (int s : active) ratio.push_back(rr0[s] > 0.0 ? std::sqrt(rr[s] / rr0[s]) : 0.0);
+          std::sort(ratio.begin(), ratio.end());
+          int met = 0;
+          for (double v : ratio) met += (v <= eta_target) ? 1 : 0;
+          std::fprintf(stderr, "pcg_trace: outer %d live %d inner %d eta_target %.2e achieved worst %.2e median %.2e best %.2e met %d\n", outer, na, done_inner,
+                       eta_target, ratio.back(), ratio[ratio.size() / 2], ratio.front(), met);
+        }
         {
           // mandatory HBM traffic of one PCG iteration (the bytes a perfect implementation still moves): per live slot
           // 20 passes over an n-vector (H p = K^-1 p + W p: 5; x, r updates: 6; preconditioner G(eps r + F S F^T G r): 6; p = z + beta p: 3),

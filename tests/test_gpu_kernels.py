@@ -26,35 +26,39 @@ def small_ctx(hip):
 
 
 @pytest.mark.parametrize('M,N,K', [(128, 128, 16), (200, 150, 64), (300, 70, 160), (64, 260, 32), (513, 129, 48), (130, 260, 784)])
-@pytest.mark.parametrize('mfma', [1, 0])
-def test_gemm_nt(small_ctx, M, N, K, mfma):
-    """C = alpha A B^T + beta C, asymmetric operands (catches transposed fragment layouts)."""
+@pytest.mark.parametrize('mfma,tile', [(1, 64), (1, 128), (0, 64), (0, 128)])
+def test_gemm_nt(small_ctx, M, N, K, mfma, tile):
+    """C = alpha A B^T + beta C, asymmetric operands (catches transposed fragment layouts); both workgroup tile sizes."""
     rng = np.random.default_rng(M * 7 + N * 3 + K)
     A = rng.standard_normal((M, K))
     B = rng.standard_normal((N, K)) + np.arange(N)[:, None] * 0.01
     C0 = rng.standard_normal((M, N))
     small_ctx.set_option('use_mfma', mfma)
+    small_ctx.set_option('small_tile_below', 1 << 30 if tile == 64 else 0)
     try:
         C = small_ctx.test_gemm_nt(A, B, C0, alpha=-0.7, beta=1.3)
     finally:
         small_ctx.set_option('use_mfma', 1)
+        small_ctx.set_option('small_tile_below', 1 << 30)
     ref = -0.7 * A @ B.T + 1.3 * C0
     assert rel(C, ref) <= 1e-13 * K
 
 
 @pytest.mark.parametrize('M,N,K', [(128, 128, 16), (260, 70, 128), (64, 300, 48), (200, 150, 512), (640, 130, 1040)])
-@pytest.mark.parametrize('mfma', [1, 0])
-def test_gemm_nn(small_ctx, M, N, K, mfma):
+@pytest.mark.parametrize('mfma,tile', [(1, 64), (1, 128), (0, 64), (0, 128)])
+def test_gemm_nn(small_ctx, M, N, K, mfma, tile):
     """The K x N (multi-RHS) operand form used by the shared-factor triangular sweeps (the long-K cases run split-K)."""
     rng = np.random.default_rng(M + N + K)
     A = rng.standard_normal((M, K))
     B = rng.standard_normal((K, N)) + np.arange(N)[None, :] * 0.01
     C0 = rng.standard_normal((M, N))
     small_ctx.set_option('use_mfma', mfma)
+    small_ctx.set_option('small_tile_below', 1 << 30 if tile == 64 else 0)
     try:
         C = small_ctx.test_gemm_nn(A, B, C0, alpha=-1.0, beta=1.0)
     finally:
         small_ctx.set_option('use_mfma', 1)
+        small_ctx.set_option('small_tile_below', 1 << 30)
     assert rel(C, C0 - A @ B) <= 1e-13 * K
 
 
@@ -149,13 +153,19 @@ def test_counts_validation(hip):
     try:
         Y = np.zeros((2, 4, 10))
         Y[1, 2, 3] = 300.0
+        ctx.upload_counts(Y)                # counts above one byte are accepted (second byte plane) ...
+        assert ctx.info('counts_two_bytes') == 1.0 and ctx.counts()[1, 2, 3] == 300
+        Y[1, 2, 3] = 65536.0                # ... up to 65535
+        with pytest.raises(hip.HipBackendError):
+            ctx.upload_counts(Y)
+        Y[1, 2, 3] = -1.0
         with pytest.raises(hip.HipBackendError):
             ctx.upload_counts(Y)
         Y[1, 2, 3] = 1.5
         with pytest.raises(hip.HipBackendError):
             ctx.upload_counts(Y)
         with pytest.raises(hip.HipBackendError):
-            ctx.estep_laplace()             # nothing uploaded yet -> loud failure, no fallback
+            ctx.estep_laplace()             # no parameters set yet -> loud failure, no fallback
     finally:
         ctx.close()
 

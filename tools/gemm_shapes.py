@@ -14,6 +14,8 @@ q, p, T, R = (int(a) for a in sys.argv[2:6]) if len(sys.argv) > 5 else (200, 10,
 _, Ys = bench.synth_shard(q, p, T, R, 12, 0)
 exp = bench.Shard(Ys, 10.0)
 sess, _ = _session.session_for(exp, p)
+for kv in filter(None, os.environ.get('PGPFA_OPTS', '').split(',')):          # context options key=value,... (experiments)
+    sess.ctx.set_option(kv.split('=')[0], float(kv.split('=')[1]))
 np.random.seed(0)
 params = {k: np.real(np.asarray(v)).astype(np.float64) for k, v in funs.util.initializeParams(p, q, exp).items()}
 optim = None
