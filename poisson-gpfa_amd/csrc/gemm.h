@@ -66,6 +66,7 @@ struct GemmP {
   // the Newton-PCG run over the LIVE slots only, wherever those sit among the chunk's slot vectors
   const int* cols;
   int cols_c_off;       // the column list applies to B only (C is a compact partial-product buffer: split-K)
+  const int* n_dev;     // optional: the number of columns is *n_dev (<= N) - the length of a device-side list; tiles past it return
 };
 
 __device__ __forceinline__ size_t gemm_koff(int kseg, long long sseg, int ld, int k) {
@@ -186,6 +187,10 @@ __global__ __launch_bounds__(256, BT == 128 ? 2 : 3) void gemm_mfma_kernel_t(Gem
 
   int i0 = ti * BT, iend = g.M;
   const int j0 = tj * BT;
+  if (g.n_dev) {                                 // (uniform over the workgroup: before any barrier)
+    g.N = *g.n_dev;
+    if (j0 >= g.N) return;
+  }
   int kb = 0, ke = g.K;
   if (g.kflags & KF_BEGIN_ROW) kb = i0;
   if (g.kflags & KF_BEGIN_MAXRC) kb = (i0 > j0 ? i0 : j0);
@@ -341,6 +346,10 @@ __global__ void gemm_check_kernel(GemmP g) {
   const int BT = g.bm;
   int i0 = ti * BT, iend = g.M;
   const int j0 = tj * BT;
+  if (g.n_dev) {
+    g.N = *g.n_dev;
+    if (j0 >= g.N) return;
+  }
   int kb = 0, ke = g.K;
   if (g.kflags & KF_BEGIN_ROW) kb = i0;
   if (g.kflags & KF_BEGIN_MAXRC) kb = (i0 > j0 ? i0 : j0);
@@ -382,10 +391,11 @@ __global__ void gemm_check_kernel(GemmP g) {
 // C[b] = beta*C[b] + sum_s part[s][b]  (part: [ksplit][nbatch][N][M] compact); grid = (ceil(M*N/256), nbatch)
 __global__ void gemm_splitk_reduce_kernel(const double* __restrict__ part, int ksplit, int M, int N, int nbatch, double* __restrict__ C,
                                           long long sC, int ldc, const int* __restrict__ slots, double beta, const int* __restrict__ skip,
-                                          const int* __restrict__ cols) {
+                                          const int* __restrict__ cols, const int* __restrict__ n_dev) {
   if (skip && *skip) return;
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (size_t)M * N) return;
+  if (n_dev && e / M >= (size_t)*n_dev) return;
   const int b = blockIdx.y;
   const long long slot = slots ? slots[b] : b;
   const size_t i = e % M, j = e / M;

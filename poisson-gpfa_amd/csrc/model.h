@@ -1603,7 +1603,9 @@ __global__ void mean_w_kernel(const double* __restrict__ W, long long sW, const 
 template <int PW>
 __global__ __launch_bounds__(256) void pcg_hessvec_dot_kernel(const double* __restrict__ W, long long sW, const double* __restrict__ P,
                                                               double* __restrict__ Q, long long sV, int T, int p,
-                                                              const int* __restrict__ slots, double* __restrict__ pqpart) {
+                                                              const int* __restrict__ slots, double* __restrict__ pqpart,
+                                                              const int* __restrict__ nlive = nullptr) {
+  if (nlive && (int)blockIdx.y >= *nlive) return;                 // (slots is a device-side live list of that length)
   constexpr int PP = PW * PW, LD = PP + 1;
   __shared__ double Ws[64 * LD];
   __shared__ double red[4];

@@ -1,5 +1,11 @@
 // Inner PCG iteration of the shared-preconditioner Newton phase without host round trips.
 //
+// Every slot is its own CG solve with its own forcing term; the slots advance in lockstep but LEAVE the iteration as they reach their
+// targets: the list of live slots and its length live on the device (PcgCtl::nlive, rebuilt by pcg_check_kernel after every iteration),
+// every kernel of the following iterations - the GEMMs included (GemmP::cols / GemmP::n_dev) - walks that list, and workgroups beyond
+// its end return at once.  The solve stops when the list is empty.  (Measured at config 3: when the worst slot of 1024 reaches a
+// relative residual of 1e-2 the median slot is at 1e-4 - the lockstep form ran every slot for the worst one's iteration count.)
+//
 // The stopping test of the inner solve (worst relative residual over the active slots <= eta) runs on the device:
 // pcg_update_p2_kernel folds every slot's ratio into one word with atomicMax, pcg_check_kernel turns it into a stop flag that
 // every kernel of the following iterations (the GEMMs included: GemmP::skip) reads first and returns on.  The host enqueues
@@ -15,24 +21,59 @@
 
 namespace pgpfa {
 
-struct PcgCtl { int stop; int iters; unsigned worst_bits; int pad; };
+struct PcgCtl { int stop; int iters; unsigned worst_bits; int nlive; unsigned long long slot_iters; };
 
-// one thread: close an iteration.  ctl->iters counts executed iterations; stop is raised once iters >= inner_min and the
-// worst residual ratio of the iteration is <= eta.  host (mapped, may be null) receives {stop, iters}.
-__global__ void pcg_check_kernel(PcgCtl* __restrict__ ctl, volatile int* __restrict__ host, float eta, int inner_min) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  if (!ctl->stop) {
-    const int it = ctl->iters + 1;
-    ctl->iters = it;
-    const float w = __uint_as_float(ctl->worst_bits);
-    if (it >= inner_min && w <= eta) ctl->stop = 1;
+// One block: close an iteration.  ctl->iters counts executed iterations, ctl->slot_iters the slot-iterations (sum of the live counts).
+// The live list is compacted in place: a slot stays while its residual ratio (ratio[slot], written by pcg_update_p2_kernel) is above
+// its own target eta[slot] - or, before inner_min iterations, always - and the order of the survivors is kept.  stop is raised when
+// nobody is left.  host (mapped, may be null) receives {stop, iters}.  block = 256 threads.
+__global__ __launch_bounds__(256) void pcg_check_kernel(PcgCtl* __restrict__ ctl, volatile int* __restrict__ host, int* __restrict__ live,
+                                                        const float* __restrict__ ratio, const float* __restrict__ eta, int inner_min) {
+  __shared__ int keep_s[256];
+  __shared__ int base_s, n_s, it_s;
+  if (threadIdx.x == 0) {
+    n_s = ctl->stop ? 0 : ctl->nlive;
+    it_s = ctl->iters + (ctl->stop ? 0 : 1);
+    base_s = 0;
   }
-  ctl->worst_bits = 0u;
-  if (host) {
-    host[1] = ctl->iters;
-    __threadfence_system();
-    host[0] = ctl->stop;
-    __threadfence_system();
+  __syncthreads();
+  const int n = n_s, it = it_s;
+  for (int c0 = 0; c0 < n; c0 += 256) {
+    const int i = c0 + threadIdx.x;
+    int slot = -1, keep = 0;
+    if (i < n) {
+      slot = live[i];
+      const float r = ratio[slot];
+      keep = (it < inner_min || !(r <= eta[slot])) ? 1 : 0;       // (a NaN ratio keeps iterating: the outer loop deals with it)
+    }
+    keep_s[threadIdx.x] = keep;
+    __syncthreads();
+    // exclusive prefix sum of the keep flags of this chunk (256 entries: a serial scan by one thread is ~1 us)
+    if (threadIdx.x == 0) {
+      int run = base_s;
+      for (int j = 0; j < 256; ++j) { const int k = keep_s[j]; keep_s[j] = run; run += k; }
+      base_s = run;
+    }
+    __syncthreads();
+    const int pos = keep_s[threadIdx.x];
+    __syncthreads();                                               // everyone has read its slot and position before anyone writes
+    if (keep) live[pos] = slot;                                    // pos <= i: never overwrites an entry of a later chunk
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (!ctl->stop) {
+      ctl->iters = it;
+      ctl->slot_iters += (unsigned long long)n;
+      ctl->nlive = base_s;
+      if (base_s == 0) ctl->stop = 1;
+    }
+    ctl->worst_bits = 0u;
+    if (host) {
+      host[1] = ctl->iters;
+      __threadfence_system();
+      host[0] = ctl->stop;
+      __threadfence_system();
+    }
   }
 }
 
@@ -57,8 +98,9 @@ template <int PW>
 __global__ __launch_bounds__(256) void pcg_hessvec32_dot_kernel(const float* __restrict__ Wp, long long sWp, const double* __restrict__ P,
                                                                 double* __restrict__ Q, long long sV, int T, int p,
                                                                 const int* __restrict__ slots, double* __restrict__ pqpart,
-                                                                const int* __restrict__ skip) {
+                                                                const int* __restrict__ skip, const PcgCtl* __restrict__ ctl) {
   if (skip && *skip) return;
+  if (ctl && (int)blockIdx.y >= ctl->nlive) return;              // (slots: the live list; workgroups past its end have nothing to do)
   constexpr int NPW = PW * (PW + 1) / 2, LD = NPW | 1;          // odd row stride: lanes (bins) hit distinct banks
   __shared__ float Ws[64 * LD];
   __shared__ double red[4];
@@ -122,8 +164,10 @@ __global__ __launch_bounds__(256) void pcg_xr_apply_kernel(const double* __restr
                                                            const double* __restrict__ P, const double* __restrict__ Q,
                                                            double* __restrict__ Xt, long long sV, int T, int p, const int* __restrict__ list,
                                                            int na, const double* __restrict__ rz, const double* __restrict__ pqpart,
-                                                           int ntile, const int* __restrict__ skip) {
+                                                           int ntile, const int* __restrict__ skip, const PcgCtl* __restrict__ ctl) {
   if (skip && *skip) return;
+  if (ctl) na = ctl->nlive;                                        // (list: the live list)
+  if ((int)blockIdx.y * PCG_SLOTS >= na) return;
   constexpr int PP = PW * PW, LD = PP + 1;
   __shared__ double Gs[64 * LD];
   const int pp = p * p;
@@ -205,8 +249,11 @@ template <int PW>
 __global__ __launch_bounds__(256) void pcg_apply2_dots_kernel(const double* __restrict__ Gb, const double* __restrict__ R,
                                                               const double* __restrict__ Y2, double eps, double* __restrict__ Z,
                                                               long long sV, int T, int p, const int* __restrict__ list, int na,
-                                                              double* __restrict__ part, const int* __restrict__ skip) {
+                                                              double* __restrict__ part, const int* __restrict__ skip,
+                                                              const PcgCtl* __restrict__ ctl) {
   if (skip && *skip) return;
+  if (ctl) na = ctl->nlive;
+  if ((int)blockIdx.y * PCG_SLOTS >= na) return;
   constexpr int PP = PW * PW, LD = PP + 1;
   __shared__ double Gs[64 * LD];
   const int pp = p * p;
@@ -287,13 +334,13 @@ __global__ __launch_bounds__(256) void pcg_apply2_dots_kernel(const double* __re
 }
 
 // rz_new, rr from the tile partial sums (tile order: deterministic) ; beta = rz_new / rz ; p = z + beta p ; rz = rz_new ;
-// rr0 on the first call of a solve ; the slot's residual ratio sqrt(rr / rr0) is folded into ctl->worst_bits.
-// grid = (na), block = 256.
+// rr0 on the first call of a solve ; the slot's residual ratio sqrt(rr / rr0) goes to ratio_out[slot] (and into ctl->worst_bits).
+// grid = (na), block = 256; with ctl the list is the live list and workgroups past ctl->nlive return.
 __global__ __launch_bounds__(256) void pcg_update_p2_kernel(const double* __restrict__ Z, double* __restrict__ P, long long sV, int n,
                                                             const int* __restrict__ list, const double* __restrict__ part, int ntile,
                                                             double* __restrict__ rz, double* __restrict__ rr, double* __restrict__ rr0,
-                                                            int first, PcgCtl* __restrict__ ctl) {
-  if (ctl && ctl->stop) return;
+                                                            int first, PcgCtl* __restrict__ ctl, float* __restrict__ ratio_out) {
+  if (ctl && (ctl->stop || (int)blockIdx.x >= ctl->nlive)) return;
   __shared__ double beta_s;
   const size_t slot = list[blockIdx.x];
   if (threadIdx.x == 0) {
@@ -307,6 +354,7 @@ __global__ __launch_bounds__(256) void pcg_update_p2_kernel(const double* __rest
     if (first) { rr0[slot] = b; b0 = b; }
     if (ctl) {
       const float ratio = (b0 > 0.0) ? (float)sqrt(b / b0) : 0.0f;
+      if (ratio_out) ratio_out[slot] = ratio;
       // (finite non-negative floats order like their bit patterns; a NaN maps above every finite value and keeps iterating)
       atomicMax(&ctl->worst_bits, __float_as_uint(ratio));
     }

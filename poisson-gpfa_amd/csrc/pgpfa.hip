@@ -153,6 +153,9 @@ struct pgpfa_ctx {
   double *sU = nullptr, *sDinvT = nullptr, *Wbar = nullptr;
   double *Rv = nullptr, *Zv = nullptr, *Pv = nullptr, *Qv = nullptr;
   PcgCtl* pcgctl = nullptr;                      // device-side control block of the inner PCG loop (pcg.h)
+  int* live = nullptr; float *pcg_ratio = nullptr, *pcg_eta = nullptr;   // device live list of the inner solve, per-slot residual ratio / target
+  const int* cur_ndev = nullptr;                 // while set: products with a column list take their column count from this device word
+  bool pcg_retire = true;                        // slots leave the inner solve as they reach their own targets (option pcg_retire)
   int* h_pcg = nullptr; int* d_hpcg = nullptr;   // host-mapped copy {stop, iterations}: the host peeks, never waits
   float* W32 = nullptr;                          // packed single-precision curvature triangles of the chunk's slots (PCG matvec)
   double* sc_part2 = nullptr;                    // per (slot, tile) partial sums r.z, r.r
@@ -354,6 +357,7 @@ int gemm(pgpfa_ctx* c, bool transb, GemmP g, bool f32 = false) {
     g.bm = (!f32 && c->mfma && (g.rtab || t128 < c->small_tile_below)) ? 64 : 128;
   }
   if (g.rtab) g.bm = 64;
+  if (g.cols && c->cur_ndev) g.n_dev = c->cur_ndev;
   // in-place products (the TRSM of the factorisation writes its own A panel: one 128-wide column tile reads all of it before it stores)
   // must keep the tile that covers the whole panel
   if ((const double*)g.C == g.A || (const double*)g.C == g.B) g.bm = 128;
@@ -382,7 +386,7 @@ int gemm(pgpfa_ctx* c, bool transb, GemmP g, bool f32 = false) {
     e = gemm_launch(c->st, c->mfma, transb, s);
     if (e == hipSuccess) {
       hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)(((size_t)g.M * g.N + 255) / 256), g.nbatch), dim3(256), 0, c->st, c->gemm_part,
-                         ksplit, g.M, g.N, g.nbatch, g.C, g.sC, g.ldc, g.slots, g.beta, g.skip, g.cols);
+                         ksplit, g.M, g.N, g.nbatch, g.C, g.sC, g.ldc, g.slots, g.beta, g.skip, g.cols, g.n_dev);
       e = hipGetLastError();
     }
   } else {
@@ -508,8 +512,10 @@ bool lowrank_pays(const pgpfa_ctx* c) {
   return lr < 0.5 * dense;
 }
 
-// (cov_mode 2 forces the low-rank engine at any size it supports - its slabs are sized for what it needs, not by the dense ld x ld)
-bool want_lowrank(const pgpfa_ctx* c) { return c->cov_mode == 2 ? (c->p <= WIDE_MAX && c->rpad >= NB) : (c->cov_mode == 0 && lowrank_pays(c)); }
+// (cov_mode 2 forces the low-rank engine at any size it supports - its slabs are sized for what it needs, not by the dense ld x ld; the
+// padded rank must fit the n-sized buffers of the shared preconditioner, which near-full-rank priors - timescales of a bin or two,
+// every latent's rank rounded up to 16 - can exceed: those run the dense engine)
+bool want_lowrank(const pgpfa_ctx* c) { return c->cov_mode == 2 ? (c->p <= WIDE_MAX && c->rpad >= NB && c->rpad <= c->ld) : (c->cov_mode == 0 && lowrank_pays(c)); }
 
 size_t ld_bytes(const pgpfa_ctx* c) { return (size_t)c->ld * c->ld * sizeof(double); }
 
@@ -699,6 +705,7 @@ int ensure_workspace(pgpfa_ctx* c, bool plan_lr) {
   CHK(dmalloc(c, &c->sc_part2, 2 * (size_t)((c->T + 63) / 64) * nB));
   CHK(dmalloc(c, &c->W32, (size_t)c->T * (c->p * (c->p + 1) / 2) * nB + 64));
   CHK(dmalloc(c, &c->pcgctl, 1, true));
+  CHK(dmalloc(c, &c->live, nB)); CHK(dmalloc(c, &c->pcg_ratio, nB, true)); CHK(dmalloc(c, &c->pcg_eta, nB, true));
   CHK(dmalloc(c, &c->sc_f, nB));
   CHK(dmalloc(c, &c->sc_alpha, nB));
   CHK(dmalloc(c, &c->trial_of_slot, nB)); CHK(dmalloc(c, &c->list_a, nB)); CHK(dmalloc(c, &c->list_b, nB));
@@ -1140,6 +1147,7 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
   else if (k == "shared_pcg") c->shared_pcg = (v != 0.0);
   else if (k == "time_newton") c->time_newton = (v != 0.0);
   else if (k == "pcg_trace") c->pcg_trace = (v != 0.0);
+  else if (k == "pcg_retire") c->pcg_retire = (v != 0.0);
   else if (k == "cov_mode") c->cov_mode = (int)v;
   else if (k == "lowrank_tol") c->lr_tol = v;
   else if (k == "keep_trial_vsmgp") c->keep_trial_vsmgp = (v != 0.0);
@@ -2050,13 +2058,32 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
         // the round trips they remove - measured at config 2: 8.6 vs 8.0 ms per E-step)
         const bool fused = c->pcg_fused && c->plan_lowrank && p <= 16 && c->h_pcg != nullptr && (c->pcg_fused == 2 || (double)nb * c->n >= 1.0e6);
         int done_inner = 0;
+        PcgCtl fused_ctl{};
         if (fused) {
           // ---- inner solve without host round trips (pcg.h): the stopping test runs on the device, iterations are enqueued
           // ahead, kernels of iterations past the stop return at once
           const int ntile = (T + 63) / 64;
           const int* skip = &c->pcgctl->stop;
           const long long sW32 = (long long)T * (p * (p + 1) / 2);
-          HIPC(hipMemsetAsync(c->pcgctl, 0, sizeof(PcgCtl), c->st));
+          // the live list starts as the active list; every slot carries its own forcing term (with pcg_retire = 0: the common one)
+          {
+            std::vector<float> eta_s(nb, (float)eta_target);
+            if (c->pcg_retire)
+              for (int s : active) {
+                double es = c->pcg_eta0;
+                if (err_pred[s] >= 0.0) {
+                  const double e = std::max(err_pred[s], 1e-300);
+                  es = std::max(1e-9, std::min(c->pcg_eta0, std::max(e, c->chord_xtol / (20.0 * e))));
+                }
+                eta_s[s] = (float)es;
+              }
+            HIPC(hipMemcpyAsync(c->pcg_eta, eta_s.data(), sizeof(float) * nb, hipMemcpyHostToDevice, c->st));
+            HIPC(hipMemcpyAsync(c->live, c->list_a, sizeof(int) * na, hipMemcpyDeviceToDevice, c->st));
+            PcgCtl h0{};
+            h0.nlive = na;
+            HIPC(hipMemcpyAsync(c->pcgctl, &h0, sizeof(PcgCtl), hipMemcpyHostToDevice, c->st));
+            HIPC(hipStreamSynchronize(c->st));                 // (eta_s / h0 are stack objects)
+          }
           c->h_pcg[0] = 0; c->h_pcg[1] = 0;
           if (c->pcg_w32)
             hipLaunchKernelGGL(pack_w32_kernel, dim3((unsigned)((sW32 + 255) / 256), na), dim3(256), 0, c->st, c->W, (long long)T * p * p, c->W32,
@@ -2068,36 +2095,38 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
             constexpr int PW = decltype(pw)::value;
             if constexpr (PW <= 16)
               hipLaunchKernelGGL(pcg_apply2_dots_kernel<PW>, gbin, dim3(256), 0, c->st, c->Gbar, c->Rv, c->Xt, c->eps, c->Zv, ld, T, p, c->list_a, na,
-                                 c->sc_part2, (const int*)nullptr);
+                                 c->sc_part2, (const int*)nullptr, (const PcgCtl*)nullptr);
           });
           hipLaunchKernelGGL(pcg_update_p2_kernel, dim3(na), dim3(256), 0, c->st, c->Zv, c->Pv, ld, nvec, c->list_a, c->sc_part2, ntile, c->sc_rz,
-                             c->sc_rr, c->sc_rr0, 1, (PcgCtl*)nullptr);
+                             c->sc_rr, c->sc_rr0, 1, (PcgCtl*)nullptr, (float*)nullptr);
+          c->cur_ndev = &c->pcgctl->nlive;
+          struct NdevGuard { pgpfa_ctx* c; ~NdevGuard() { c->cur_ndev = nullptr; } } ndev_guard{c};
           for (int it = 0; it < c->pcg_inner_max; ++it) {
-            CHK(prior_mv_all(c, nb, c->Pv, c->Qv, nullptr, skip, c->list_a, na));
+            CHK(prior_mv_all(c, nb, c->Pv, c->Qv, nullptr, skip, c->live, na));
             dispatch_pw(p, [&](auto pw) {
               constexpr int PW = decltype(pw)::value;
               if constexpr (PW <= 16) {
                 if (c->pcg_w32)
                   hipLaunchKernelGGL(pcg_hessvec32_dot_kernel<PW>, dim3(ntile, na), dim3(256), 0, c->st, c->W32, sW32, c->Pv, c->Qv, ld, T, p,
-                                     c->list_a, c->sc_pq, skip);
+                                     c->live, c->sc_pq, skip, (const PcgCtl*)c->pcgctl);
                 else
                   hipLaunchKernelGGL(pcg_hessvec_dot_kernel<PW>, dim3(ntile, na), dim3(256), 0, c->st, c->W, (long long)T * p * p, c->Pv, c->Qv,
-                                     ld, T, p, c->list_a, c->sc_pq);
+                                     ld, T, p, c->live, c->sc_pq, (const int*)&c->pcgctl->nlive);
                 hipLaunchKernelGGL(pcg_xr_apply_kernel<PW>, gbin, dim3(256), 0, c->st, c->Gbar, c->Dl, c->Rv, c->Pv, c->Qv, c->Xt, ld, T, p,
-                                   c->list_a, na, c->sc_rz, c->sc_pq, ntile, skip);
+                                   c->live, na, c->sc_rz, c->sc_pq, ntile, skip, (const PcgCtl*)c->pcgctl);
               }
             });
-            CHK(shared_solve(c, nb, c->Rv, c->Zv, skip, false, false, c->list_a, na));
+            CHK(shared_solve(c, nb, c->Rv, c->Zv, skip, false, false, c->live, na));
             dispatch_pw(p, [&](auto pw) {
               constexpr int PW = decltype(pw)::value;
               if constexpr (PW <= 16)
-                hipLaunchKernelGGL(pcg_apply2_dots_kernel<PW>, gbin, dim3(256), 0, c->st, c->Gbar, c->Rv, c->Xt, c->eps, c->Zv, ld, T, p, c->list_a,
-                                   na, c->sc_part2, skip);
+                hipLaunchKernelGGL(pcg_apply2_dots_kernel<PW>, gbin, dim3(256), 0, c->st, c->Gbar, c->Rv, c->Xt, c->eps, c->Zv, ld, T, p, c->live,
+                                   na, c->sc_part2, skip, (const PcgCtl*)c->pcgctl);
             });
-            hipLaunchKernelGGL(pcg_update_p2_kernel, dim3(na), dim3(256), 0, c->st, c->Zv, c->Pv, ld, nvec, c->list_a, c->sc_part2, ntile,
-                               c->sc_rz, c->sc_rr, c->sc_rr0, 0, c->pcgctl);
-            hipLaunchKernelGGL(pcg_check_kernel, dim3(1), dim3(64), 0, c->st, c->pcgctl, (volatile int*)c->d_hpcg, (float)eta_target,
-                               c->pcg_inner_min);
+            hipLaunchKernelGGL(pcg_update_p2_kernel, dim3(na), dim3(256), 0, c->st, c->Zv, c->Pv, ld, nvec, c->live, c->sc_part2, ntile,
+                               c->sc_rz, c->sc_rr, c->sc_rr0, 0, c->pcgctl, c->pcg_ratio);
+            hipLaunchKernelGGL(pcg_check_kernel, dim3(1), dim3(256), 0, c->st, c->pcgctl, (volatile int*)c->d_hpcg, c->live,
+                               (const float*)c->pcg_ratio, (const float*)c->pcg_eta, c->pcg_inner_min);
             if (*(volatile int*)&c->h_pcg[0]) break;           // the device has already stopped: whatever is enqueued is a no-op
             // stay at most 3 iterations ahead of the device (an iteration enqueued past the stop costs ~13 empty launches: that
             // matters when the kernels themselves take microseconds); the wait spins on the host-mapped counter, no API call
@@ -2109,6 +2138,8 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
               if (*(volatile int*)&c->h_pcg[0]) break;
             }
           }
+          c->cur_ndev = nullptr;
+          HIPC(hipMemcpyAsync(&fused_ctl, c->pcgctl, sizeof(PcgCtl), hipMemcpyDeviceToHost, c->st));
           HIPC(hipGetLastError());
           done_inner = -1;                                     // read from the control block with the scalars below
         } else {
@@ -2160,8 +2191,12 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
           std::copy(pack.begin() + 5 * nB, pack.begin() + 5 * nB + nb, rr.begin());
           std::copy(pack.begin() + 6 * nB, pack.begin() + 6 * nB + nb, rr0.begin());
         }
-        if (done_inner < 0) done_inner = c->h_pcg[1];           // (the download above synchronised the stream)
-        n_pcg += (double)na * done_inner;
+        double slot_iters = (double)na * done_inner;
+        if (done_inner < 0) {                                   // (the download above synchronised the stream)
+          done_inner = fused_ctl.iters;
+          slot_iters = (double)fused_ctl.slot_iters;
+        }
+        n_pcg += slot_iters;
         if (c->pcg_trace) {
           // achieved residual ratios of the live slots: worst, median, and how many already met the target
           std::vector<double> ratio;
@@ -2180,7 +2215,7 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
           const double vecs = 20.0 * nvec * 8.0 + (c->plan_lowrank ? 4.0 * c->rtot * 8.0 : 0.0);
           const double curv = (fused && c->pcg_w32) ? (double)T * (p * (p + 1) / 2) * 4.0 : (double)T * p * p * 8.0;
           const double ops = (double)p * T * T * 8.0 + (c->plan_lowrank ? (2.0 * T * c->rtot + (double)c->rtot * c->rtot) * 8.0 : (double)nvec * nvec * 8.0);
-          newton_bytes += (double)done_inner * ((double)na * (vecs + curv) + ops);
+          newton_bytes += slot_iters * (vecs + curv) + (double)done_inner * ops;
         }
         std::vector<int> cand, next, failed;
         for (int s : active) {

@@ -273,7 +273,8 @@ def test_config5_variational_estep_to_convergence(funs_mod, monkeypatch):
     engine (default at this size).  Checked against plain numpy on the dense 20 000 x 20 000 matrices of trial 0 (dual cost 1e-8,
     gradient 1e-6 of its largest entry, covariance blocks 1e-7, posterior mean 1e-9), by the structured posterior-mean identity
     post_mean = -K C_big (lambda - y) on every trial, by stationarity (the gradient in rho = log lambda at the optimum is below 2e-2 of
-    the one at the start - the reference's stopping rule is a decrease test), and mixed vs FP64: bound 1e-5 rel."""
+    the one at the start - the reference's stopping rule is a decrease test); mixed vs FP64: cost 1e-5 at the same lambda, the two
+    optima within 2e-3 of each other in the bound."""
     import bench
     inf = funs_mod.inference
     q, p, T, R = 500, 20, 1000, 4
@@ -294,6 +295,10 @@ def test_config5_variational_estep_to_convergence(funs_mod, monkeypatch):
         out[f32] = dict(nll=nll, vlb=vlb, lam=lam, iters=infRes.dual_iterations.copy(), cost=cost, grad=grad,
                         pm=np.stack([infRes['post_mean'][r] for r in range(R)]), vsm0=infRes['post_vsm'][0].copy(),
                         evals=sess.ctx.info('last_dual_evaluations'))
+        if f32:
+            # the mixed-precision evaluation at the FP64 run's optimum (same lambda: what the precision itself changes)
+            cm, gm = sess.ctx.dual_costgrad_batch(idx, out[False]['lam'])
+            out['mixed_at_f64_opt'] = (cm, gm)
         if not f32:
             # gradient at the start (lambda = 1, rho = 0: the reference's start of the log-lambda variant, inference.py:391-396)
             c0, g0 = sess.ctx.dual_costgrad_batch(idx, np.ones((R, m)))
@@ -308,8 +313,13 @@ def test_config5_variational_estep_to_convergence(funs_mod, monkeypatch):
         assert a['cost'][r] < out['c0'][r]
         # (what scipy's L-BFGS-B stopping rule - relative decrease of the dual below 2.2e-9 - leaves: measured 3.6e-3)
         assert np.max(np.abs(a['grad'][r] * a['lam'][r])) <= 2e-2 * out['g0'][r]
-    # mixed precision lands on the same bound and posterior
-    assert abs(b['vlb'] - a['vlb']) <= 1e-5 * abs(a['vlb']) and abs(b['nll'] - a['nll']) <= 1e-5 * abs(a['nll'])
+    # mixed precision: the same function (cost 1e-5 rel, gradient 1e-3 of its largest entry at the same lambda) ...
+    cm, gm = out['mixed_at_f64_opt']
+    assert np.max(np.abs(cm - a['cost']) / np.abs(a['cost'])) <= 1e-5
+    assert max(rel(gm[r], a['grad'][r]) for r in range(R)) <= 1e-3
+    # ... and the same optimum within what the reference's stopping rule determines at this size (two L-BFGS runs that both meet
+    # scipy's decrease test after 3000-6000 iterations of a 500 000-dimensional problem: measured 2.7e-4 apart in the bound)
+    assert abs(b['vlb'] - a['vlb']) <= 2e-3 * abs(a['vlb']) and abs(b['nll'] - a['nll']) <= 1e-2 * abs(a['nll'])
     # structured identity on every trial: post_mean = -K C_big (lambda - y)  (inference.py:194)
     K = orc.make_K(par['tau'], T, 10.0)
     for r in range(R):
