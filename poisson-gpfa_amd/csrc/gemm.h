@@ -67,6 +67,7 @@ struct GemmP {
   const int* cols;
   int cols_c_off;       // the column list applies to B only (C is a compact partial-product buffer: split-K)
   const int* n_dev;     // optional: the number of columns is *n_dev (<= N) - the length of a device-side list; tiles past it return
+  int b_f32;            // the B operand is stored in single precision (NT form, 64 x 64 tiles, MFMA path only)
 };
 
 __device__ __forceinline__ size_t gemm_koff(int kseg, long long sseg, int ld, int k) {
@@ -159,7 +160,9 @@ __device__ __forceinline__ int gemm_bind_t(const GemmP& g, int b, const T*& A, c
 // share a CU: thin products (multi-RHS vectors against block-diagonal factors, the r x r preconditioner, short panels) offer 4x the
 // workgroups and hide each other's prologue and epilogue.  FP64 MFMA issues one 16x16x4 per 64 cycles per SIMD, so the extra LDS reads
 // per MFMA of the small tile (1 instead of 1/2) are still far under the LDS roof.
-template <int TRANSB, typename T, int BT>
+// BF32 (TRANSB = 0, T = double only): the B operand is stored in single precision (strides sB, sB_hi, sBseg, ldb count floats) and widened
+// while it is staged - products and accumulation stay FP64.
+template <int TRANSB, typename T, int BT, bool BF32 = false>
 __global__ __launch_bounds__(256, BT == 128 ? 2 : 3) void gemm_mfma_kernel_t(GemmP g) {
   using T2 = typename GemmVec<T>::v2;
   using T4 = typename GemmVec<T>::v4;
@@ -184,6 +187,13 @@ __global__ __launch_bounds__(256, BT == 128 ? 2 : 3) void gemm_mfma_kernel_t(Gem
   const T* B;
   T* C;                            // may alias A (in-place TRSM): no restrict
   const int hi = gemm_bind_t<T>(g, b, A, B, C);
+  const float* B32 = nullptr;
+  if (BF32) {
+    int lo2 = b, hi2 = 0;
+    if (g.nb_lo > 0) { hi2 = b / g.nb_lo; lo2 = b - hi2 * g.nb_lo; }
+    const long long slot2 = g.slots ? g.slots[lo2] : lo2;
+    B32 = reinterpret_cast<const float*>(g.B) + slot2 * g.sB + hi2 * g.sB_hi;
+  }
 
   int i0 = ti * BT, iend = g.M;
   const int j0 = tj * BT;
@@ -226,7 +236,11 @@ __global__ __launch_bounds__(256, BT == 128 ? 2 : 3) void gemm_mfma_kernel_t(Gem
           ra[2 * s] = src[0]; ra[2 * s + 1] = src[1];
         }
       }
-      if (TRANSB == 0) {
+      if (TRANSB == 0 && BF32) {
+        const int k = u / (BT / 2), r2 = (u % (BT / 2)) * 2;
+        const float* src = B32 + gemm_koff(g.kseg, g.sBseg, g.ldb, k0) + (size_t)k * g.ldb + (j0 + r2);
+        rb[2 * s] = (T)src[0]; rb[2 * s + 1] = (T)src[1];
+      } else if (TRANSB == 0) {
         const int k = u / (BT / 2), r2 = (u % (BT / 2)) * 2;
         const T* src = B + gemm_koff(g.kseg, g.sBseg, g.ldb, k0) + (size_t)k * g.ldb + (j0 + r2);
         if (b_vec) {
@@ -447,7 +461,10 @@ inline hipError_t gemm_launch(hipStream_t st, bool use_mfma, bool transb, GemmP 
     if (transb) hipLaunchKernelGGL((gemm_mfma_kernel_t<1, float, 128>), grid, dim3(256), 0, st, g);
     else hipLaunchKernelGGL((gemm_mfma_kernel_t<0, float, 128>), grid, dim3(256), 0, st, g);
   } else if (use_mfma) {
-    if (g.bm == 64) {
+    if (g.b_f32) {
+      if (transb || g.bm != 64) return hipErrorInvalidValue;
+      hipLaunchKernelGGL((gemm_mfma_kernel_t<0, double, 64, true>), grid, dim3(256), 0, st, g);
+    } else if (g.bm == 64) {
       if (transb) hipLaunchKernelGGL((gemm_mfma_kernel_t<1, double, 64>), grid, dim3(256), 0, st, g);
       else hipLaunchKernelGGL((gemm_mfma_kernel_t<0, double, 64>), grid, dim3(256), 0, st, g);
     } else {
@@ -455,6 +472,7 @@ inline hipError_t gemm_launch(hipStream_t st, bool use_mfma, bool transb, GemmP 
       else hipLaunchKernelGGL((gemm_mfma_kernel_t<0, double, 128>), grid, dim3(256), 0, st, g);
     }
   } else {
+    if (g.b_f32) return hipErrorInvalidValue;
     if (transb) hipLaunchKernelGGL(gemm_check_kernel<1>, grid, dim3(256), 0, st, g);
     else hipLaunchKernelGGL(gemm_check_kernel<0>, grid, dim3(256), 0, st, g);
   }

@@ -1571,6 +1571,26 @@ __global__ void negate_rows_kernel(const double* __restrict__ src, long long sSr
 }
 
 // --------------------------------------------------------------------------------------------------
+// max over the p x p blocks B[i] (i < nblocks, contiguous) of scale * ||B||_inf, folded into *out_bits with atomicMax on the float's bit
+// pattern (non-negative floats order like their bits).  Used on the blocks Wt = W (I + eps W)^-1 of a chunk: eps ||Wt_t|| is the
+// relative size of the mixing correction D = eps Wt y of the low-rank covariance engine.  grid = ceil(nblocks/256), block = 256.
+__global__ void block_norm_max_kernel(const double* __restrict__ B, long long nblocks, int p, double scale, unsigned* __restrict__ out_bits) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  float v = 0.f;
+  if (i < nblocks) {
+    const double* b = B + i * p * p;
+    double worst = 0.0;
+    for (int r = 0; r < p; ++r) {
+      double s = 0.0;
+      for (int c2 = 0; c2 < p; ++c2) s += fabs(b[r * p + c2]);
+      worst = fmax(worst, s);
+    }
+    v = (float)(scale * worst);
+  }
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_down(v, off));
+  if ((threadIdx.x & 63) == 0 && v > 0.f) atomicMax(out_bits, __float_as_uint(v));
+}
+
 // Shared-preconditioner Newton-PCG pieces.
 // Wbar[t] = mean over the listed slots of W[slot][t]   (p x p per bin) -> written into slot `dst` of Wdst
 // --------------------------------------------------------------------------------------------------

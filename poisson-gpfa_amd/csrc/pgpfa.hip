@@ -26,6 +26,7 @@
 #include "pcg.h"
 #include "dual.h"
 #include "sample.h"
+#include "split.h"
 
 using namespace pgpfa;
 
@@ -108,6 +109,9 @@ struct pgpfa_ctx {
   double *CCu = nullptr, *C16 = nullptr;         // zero-padded pair-product / loading tables of the MFMA Poisson pass
   int qpad = 0, ccu_cols = 0;
   double* ppart = nullptr;                       // [p][PACC_SPLITS + 1][T x T] split-K partial products
+  double* split_buf = nullptr;                   // scratch of the split accumulation (split.h), allocated on first use
+  bool split_cov = true;                         // option split_cov: sum_r Y~Y~^T by the exact split form when eps ||Wt|| allows
+  double split_max_norm = 2e-2;                  // ... i.e. up to this value of max_t eps ||Wt_t||_inf (option split_max_norm)
   double *cdym = nullptr, *cdym_part = nullptr;   // count terms of the (C,d) cost: sum_t y m_t, sum_t y per neuron (per E-step)
   bool cdym_valid = false, cd_mfma = true; int cd_debug = 0;
   bool cd_hess_valid = false; int cd_hess_ntr = 0;   // per-neuron Hessian sums of the last Newton pass are resident
@@ -188,6 +192,7 @@ struct pgpfa_ctx {
   bool last_cov_lowrank = false;
   bool shared_pcg = true;
   bool pcg_trace = false;
+  bool measure_mix = false;                       // option measure_mix: record max_t eps ||Wt_t|| of every covariance pass
   bool time_newton = false;                       // option time_newton: HIP events around the inner PCG solves (last_newton_solve_ms / _bytes)
   int shared_min = 16, pcg_inner_min = 2, pcg_inner_max = 16, pcg_outer_max = 12;
   double pcg_eta0 = 1e-2;
@@ -498,7 +503,10 @@ int alloc_cholws(pgpfa_ctx* c, CholWS* w, int nslots, int npad, bool with_mt, si
 
 // per-slot scratch (doubles) the low-rank covariance engine needs inside a factor slab
 size_t lowrank_slab_elems(const pgpfa_ctx* c) {
-  const size_t need = (size_t)c->ld * c->rpad + (size_t)c->Tp * c->rpad + (size_t)c->T * c->T;
+  // Yt (ld x rpad), then either the staging of per-trial blocks (Tp x rpad + T^2) or the single-precision correction D of the split
+  // accumulation (ld x rpad floats)
+  const size_t yt = (size_t)c->ld * c->rpad;
+  const size_t need = yt + std::max((size_t)c->Tp * c->rpad + (size_t)c->T * c->T, yt / 2 + 64);
   return std::max(need, (size_t)c->rpad * c->rpad);
 }
 
@@ -1122,6 +1130,7 @@ int pgpfa_destroy(pgpfa_ctx* c) {
   if (c->vsmgp) hipFree(c->vsmgp);
   if (c->Flr32) hipFree(c->Flr32);
   if (c->lam_keep) hipFree(c->lam_keep);
+  if (c->split_buf) hipFree(c->split_buf);
   if (c->Yhi) hipFree(c->Yhi);
   arena_release(c);
   if (c->hbuf) hipHostFree(c->hbuf);
@@ -1147,7 +1156,10 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
   else if (k == "shared_pcg") c->shared_pcg = (v != 0.0);
   else if (k == "time_newton") c->time_newton = (v != 0.0);
   else if (k == "pcg_trace") c->pcg_trace = (v != 0.0);
+  else if (k == "measure_mix") { c->measure_mix = (v != 0.0); c->info["last_eps_wt_norm"] = 0.0; }
   else if (k == "pcg_retire") c->pcg_retire = (v != 0.0);
+  else if (k == "split_cov") c->split_cov = (v != 0.0);
+  else if (k == "split_max_norm") c->split_max_norm = v;
   else if (k == "cov_mode") c->cov_mode = (int)v;
   else if (k == "lowrank_tol") c->lr_tol = v;
   else if (k == "keep_trial_vsmgp") c->keep_trial_vsmgp = (v != 0.0);
@@ -1707,6 +1719,112 @@ static int posterior_blocks_dense(pgpfa_ctx* c, int nb, double diag_scale, bool 
 }
 
 
+// Sum-only covariance output by the exact split form (split.h): Pacc[k] += sum over the chunk's slots of Y~_k Y~_k^T + eps diag(G_t[k][k])
+// from L^-T (lw.Mt), Yt (lw.H) and the per-bin blocks G (c->Gbin), without the full-width FP64 product.  Also writes post_vsm.
+static int accumulate_split(pgpfa_ctx* c, const CholWS& lw, int nb, int ract, int Ts, bool skip_zero_cols) {
+  const int T = c->T, p = c->p, Tp = c->Tp, rpad = c->rpad;
+  const long long sW = (long long)T * p * p;
+  const size_t tt = (size_t)T * T;
+  (void)skip_zero_cols;
+  // scratch: S parts [NS][<= T^2] | X parts [NG][<= T^2] | Ssum | Xsum | Z | T1 [p][T^2] | Xfull [p][T^2]
+  constexpr int NS = 256, NG = PACC_SPLITS + 1;
+  if (!c->split_buf) {
+    const size_t len = ((size_t)NS + NG + 3 + 2 * (size_t)p) * tt + 1024;
+    if (hipMalloc((void**)&c->split_buf, len * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); c->split_buf = nullptr; return fail("out of device memory for the split accumulation (%zu bytes)", len * sizeof(double)); }
+    c->bytes += len * sizeof(double);
+  }
+  double* Spart = c->split_buf;
+  double* Xpart = Spart + (size_t)NS * tt;
+  double* Ssum = Xpart + (size_t)NG * tt;
+  double* Xsum = Ssum + tt;
+  double* Zb = Xsum + tt;
+  double* T1 = Zb + tt;
+  double* Xfull = T1 + (size_t)p * tt;
+  float* D = reinterpret_cast<float*>(lw.H + (size_t)c->ld * rpad);          // behind Yt in every slot's slab
+  const long long sD = 2 * (long long)lw.sH;                                   // slab stride in floats
+  const int ldd = c->ld;
+  // 1. mixing pass: post_vsm and the correction D = eps Wt Yt (single precision); Yt itself stays
+  prof_begin(c, TAG_VSM, (double)nb * c->n * rpad * (3.0 * p + 1.0));
+  dispatch_pw(p, [&](auto pw) {
+    constexpr int PW = decltype(pw)::value;
+    if constexpr (PW <= 16)
+      hipLaunchKernelGGL(mix_vsm_split_kernel<PW>, dim3((T + 63) / 64, nb), dim3(256), 0, c->st, (const double*)lw.H, (long long)lw.sH, c->ld, D, sD, ldd,
+                         c->Gbin, sW, T, p, ract, c->eps, c->vsm, c->ident, c->trial_of_slot, c->d_roff, (int)GBN, Ts);
+  });
+  prof_end(c);
+  // 2. the full-width term on the FP16 matrix cores: partial sums per (latent, group of slots) into c->ppart
+  const int sps = std::max(1, (nb + PACC_SPLITS - 1) / PACC_SPLITS);
+  const int ngroups = (nb + sps - 1) / sps;
+  {
+    SyrkF16Args a{};
+    a.D = D; a.sD = sD; a.ldd = ldd; a.ts = Ts; a.part = c->ppart;
+    a.T = T; a.p = p; a.ract = ract; a.nslots = nb; a.sps = sps; a.ngroups = ngroups;
+    a.tiles = (T + 127) / 128; a.ntiles = a.tiles * (a.tiles + 1) / 2;
+    const long long blocks = (long long)a.ntiles * ngroups * p;
+    prof_begin(c, TAG_VSM, 3.0 * (double)nb * ract * T * T * p);
+    hipLaunchKernelGGL(syrk_f16x2_kernel, dim3((unsigned)blocks), dim3(256), 0, c->st, a);
+    prof_end(c);
+  }
+  // 3. per latent: S_k = sum_r A A^T (r_k x r_k), X_k = sum_r A D_k^T (r_k x T) with A = rows of latent k of L^-T right of column
+  //    roff_k (it is upper triangular), both as segmented-K products over groups of slots; then T1 = F S F^T and Xfull = F X
+  const int spsS = std::max(1, (nb + NS - 1) / NS);
+  for (int k = 0; k < p; ++k) {
+    const int rk = c->rk[k], r0 = c->roff[k];
+    const int kw = ract - r0;                                                   // columns of A that are not identically zero
+    if (kw <= 0 || rk <= 0) {
+      HIPC(hipMemsetAsync(T1 + (size_t)k * tt, 0, tt * sizeof(double), c->st));
+      HIPC(hipMemsetAsync(Xfull + (size_t)k * tt, 0, tt * sizeof(double), c->st));
+      continue;
+    }
+    const double* A0 = lw.Mt + r0 + (size_t)r0 * rpad;
+    auto seg = [&](int sper, bool is_x, double* out) -> int {                   // groups of `sper` slots (the last one may be short)
+      const int nfull = nb / sper, rem = nb - nfull * sper;
+      for (int part = 0; part < 2; ++part) {
+        const int first = part ? nfull * sper : 0, per = part ? rem : sper, ng = part ? (rem ? 1 : 0) : nfull;
+        if (ng == 0 || per == 0) continue;
+        GemmP g{};
+        g.A = A0 + (size_t)first * lw.sM; g.sA = (long long)per * lw.sM; g.lda = rpad;
+        g.kseg = kw; g.sAseg = lw.sM;
+        g.K = per * kw; g.alpha = 1.0; g.beta = 0.0; g.slots = nullptr; g.nbatch = ng; g.kflags = 0; g.bm = 64;
+        g.M = rk;
+        if (is_x) {
+          g.B = reinterpret_cast<const double*>(D + (size_t)first * sD + (size_t)k * Ts + (size_t)r0 * ldd);
+          g.sB = (long long)per * sD; g.ldb = ldd; g.sBseg = sD; g.b_f32 = 1;
+          g.N = T; g.mode = GEMM_FULL;
+          g.C = out + (size_t)(part ? nfull : 0) * rk * T; g.sC = (long long)rk * T; g.ldc = rk;
+        } else {
+          g.B = g.A; g.sB = g.sA; g.ldb = rpad; g.sBseg = lw.sM;
+          g.N = rk; g.mode = GEMM_LOWER;
+          g.C = out + (size_t)(part ? nfull : 0) * rk * rk; g.sC = (long long)rk * rk; g.ldc = rk;
+        }
+        CHK(gemm(c, false, g));
+      }
+      return 0;
+    };
+    CHK(seg(spsS, false, Spart));
+    CHK(seg(sps, true, Xpart));
+    const int ngS = (nb + spsS - 1) / spsS;
+    hipLaunchKernelGGL(sum_groups_kernel, dim3((unsigned)(((size_t)rk * rk + 255) / 256)), dim3(256), 0, c->st, Spart, ngS, rk, rk, 1, Ssum);
+    hipLaunchKernelGGL(sum_groups_kernel, dim3((unsigned)(((size_t)rk * T + 255) / 256)), dim3(256), 0, c->st, Xpart, ngroups, rk, T, 0, Xsum);
+    const double* Fk = c->Flr + (size_t)k * Tp * Tp;
+    GemmP z{};                                                                  // Z = F_k S_k   (T x r_k)
+    z.A = Fk; z.lda = Tp; z.B = Ssum; z.ldb = rk; z.C = Zb; z.ldc = T;
+    z.M = T; z.N = rk; z.K = rk; z.alpha = 1.0; z.beta = 0.0; z.nbatch = 1; z.mode = GEMM_FULL;
+    CHK(gemm(c, true, z));
+    GemmP t1 = z;                                                               // T1 = Z F_k^T  (T x T)
+    t1.A = Zb; t1.lda = T; t1.B = Fk; t1.ldb = Tp; t1.C = T1 + (size_t)k * tt; t1.ldc = T; t1.N = T;
+    CHK(gemm(c, false, t1));
+    GemmP xf = z;                                                               // Xfull = F_k X_k  (T x T)
+    xf.B = Xsum; xf.ldb = rk; xf.C = Xfull + (size_t)k * tt; xf.ldc = T; xf.N = T;
+    CHK(gemm(c, true, xf));
+  }
+  // 4. Pacc += eps diag + T1 - Xfull - Xfull^T + sum of the FP16 partial sums
+  hipLaunchKernelGGL(pacc_split_reduce_kernel, dim3(T, p), dim3(128), 0, c->st, T1, Xfull, c->ppart, ngroups, c->Gbin, sW, nb, c->eps, T, Tp, p, c->Pacc);
+  HIPC(hipGetLastError());
+  c->pacc_used = true;
+  return 0;
+}
+
 // Covariance blocks through the low-rank form of the prior (see model.h): per slot an r x r SPD system
 // B = I + F^T Wt F instead of the n x n Hessian.  Uses the dense engine's slabs as scratch (ld = rpad views).
 // logdet_out (optional, host, nb entries): log det of the posterior precision K^-1 + scatter(W) of every slot,
@@ -1719,6 +1837,15 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool 
   c->last_cov_lowrank = true;
   // a. per-bin blocks G = (I + eps W)^-1, Wt = W G
   CHK(bin_blocks(c, c->W, sW, c->Gbin, c->Wt, sW, nb, logdet_out ? c->ldet_buf : nullptr));
+  // sum-only accumulation by the split form (split.h)?  Decided by the relative size of the mixing correction of this chunk,
+  // max_t eps ||Wt_t||_inf, measured here and read back just before the mixing pass (info key "last_eps_wt_norm")
+  const bool split_candidate = want_vsmgp && accumulate && c->split_cov && c->mfma && p <= 16 && !c->dual_f32;
+  unsigned* norm_bits = reinterpret_cast<unsigned*>(c->pcg_ratio);         // (scratch word: the inner solves are over)
+  if (split_candidate || c->measure_mix) {
+    HIPC(hipMemsetAsync(norm_bits, 0, sizeof(unsigned), c->st));
+    const long long nblk = (long long)nb * T;
+    hipLaunchKernelGGL(block_norm_max_kernel, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, c->st, c->Wt, nblk, p, c->eps, norm_bits);
+  }
   // b. B = I + F^T Wt F into the factor slabs viewed with ld = rpad; factor; L^-T
   CholWS lw = c->ws;
   lw.ld = rpad; lw.npad = rpad; lw.nact = round_up(c->rtot, 64);
@@ -1836,7 +1963,18 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool 
     CHK(gemm(c, true, g));
   }
   if (p > WIDE_MAX) return fail("low-rank covariance engine supports up to %d latents (p=%d)", WIDE_MAX, p);
-  if (want_vsmgp) {
+  bool split = false;
+  if (split_candidate || c->measure_mix) {
+    float hv = 0.f;
+    HIPC(hipMemcpyAsync(&hv, norm_bits, sizeof(float), hipMemcpyDeviceToHost, c->st));
+    HIPC(hipStreamSynchronize(c->st));
+    c->info["last_eps_wt_norm"] = std::max(c->info["last_eps_wt_norm"], (double)hv);
+    split = split_candidate && std::isfinite(hv) && (double)hv <= c->split_max_norm;
+  }
+  c->info["last_split_cov"] = split ? 1.0 : 0.0;
+  if (want_vsmgp && split) {
+    CHK(accumulate_split(c, lw, nb, ract, Ts, skip_zero_cols));
+  } else if (want_vsmgp) {
     // d+e. one pass over Yt: post_vsm[t] = eps G_t + sum_b (G_t y_b)(G_t y_b)^T, and Yt is mixed in place (y <- G_t y) so that
     //      rows (k,.) of the slab become Ymix_k, the GEMM operand of post_vsmGP_k = eps diag(G_t[k][k]) + Ymix_k Ymix_k^T
     prof_begin(c, TAG_VSM, (double)nb * c->n * rpad * (3.0 * p + 1.0));
@@ -1870,7 +2008,7 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool 
       }
     });
   }
-  if (want_vsmgp) {
+  if (want_vsmgp && !split) {
     if (accumulate) {
       // sum-only output: Pacc[k] += sum over the chunk's slots of Ymix_k Ymix_k^T as ONE split-K product per launch -
       // batch = (latent, group of `sps` consecutive slots), the K dimension walks the rpad-wide panels of the

@@ -1,0 +1,292 @@
+// Sum over trials of the per-latent covariance blocks of the low-rank engine without the full-width FP64 product.
+//
+// With G_t = (I + eps W_t)^-1 = I - eps Wt_t (Wt = W G), the mixed slab is  Y~ = G Yt = Yt - D,  D = eps Wt Yt,  so
+//
+//   sum_r Y~_k Y~_k^T  =  F_k [sum_r A_rk A_rk^T] F_k^T  -  F_k [sum_r A_rk D_rk^T]  -  (.)^T  +  sum_r D_rk D_rk^T
+//
+// with A_rk = rows of latent k of L_r^-T (r_k x r) and Yt_k = F_k A_rk: EXACT algebra, no approximation.  What the split buys is where
+// the work sits: the first term is r_k x r_k per trial (the trial-independent F_k leaves the sum), the cross term is T r^2 per trial
+// (15 % of the full-width p T^2 r) and stays FP64 (its operand D is stored in single precision: it carries a factor eps ||Wt|| ~ 1e-2,
+// so its 6e-8 rounding is 6e-10 of the result at worst, ~1e-11 in the root-mean-square), and the full-width term D D^T carries
+// (eps ||Wt||)^2 ~ 1e-4: it runs on the FP16 matrix cores (16x the FP32 rate, 32x FP64) with every entry split in two halves,
+// d * 2^11 = hi + lo, three products hi hi + hi lo + lo hi with FP32 accumulation (relative error of the term 2^-21 + FP32
+// accumulation over <= 16 trials ~ 2e-6: below 1e-9 of the result), partial sums per group of trials reduced in FP64.
+// The caller measures eps ||Wt|| per chunk and keeps the FP64 product above a threshold (pgpfa.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace pgpfa {
+
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float float4v_t __attribute__((ext_vector_type(4)));
+
+constexpr float SPLIT_SCALE = 2048.0f;          // |D| <= sqrt(p) (rows of Yt have norm <= 1, eps ||Wt|| < 1): 2^11 |D| < 65504 up to p = 1000
+
+// Mixing pass of the split form: like mix_vsm_kernel it accumulates post_vsm[t] = eps G_t + sum_b (G_t y_b)(G_t y_b)^T over the columns
+// of the slab, but leaves Yt as it is and writes the correction D[(k,t), b] = y - G_t y (= eps Wt_t y) in single precision
+// (column stride ldd floats, latent stride ts) - half the bytes of the in-place FP64 mix.
+// grid = (ceil(T/64), nslots), block = 256, p <= PW <= 16.
+template <int PW>
+__global__ __launch_bounds__(256) void mix_vsm_split_kernel(const double* __restrict__ Yt, long long sY, int ldy, float* __restrict__ D, long long sD,
+                                                            int ldd, const double* __restrict__ G, long long sG, int T, int p, int rpad, double eps,
+                                                            double* __restrict__ vsm, const int* __restrict__ slots,
+                                                            const int* __restrict__ trial_of_slot, const int* __restrict__ roff, int col_tile, int ts) {
+  constexpr int PP = PW * PW, LD = PP + 1, NPAIR = PW * (PW + 1) / 2;
+  __shared__ double Gs[64 * LD];
+  const int pp = p * p;
+  const int slot = slots[blockIdx.y];
+  const int t0 = blockIdx.x * 64;
+  const int nt = min(64, T - t0);
+  const double* gbase = G + (size_t)slot * sG + (size_t)t0 * pp;
+  if (p < PW)
+    for (int e = threadIdx.x; e < 64 * LD; e += 256) Gs[e] = 0.0;
+  __syncthreads();
+  for (int e = threadIdx.x; e < nt * pp; e += 256) {
+    const int t = e / pp, idx = e - t * pp, i = idx / p, j = idx - i * p;
+    Gs[t * LD + i * PW + j] = gbase[e];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool live = lane < nt;
+  double* g = Gs + lane * LD;
+  double acc[NPAIR];
+#pragma unroll
+  for (int i = 0; i < NPAIR; ++i) acc[i] = 0.0;
+  int c0[PW];
+#pragma unroll
+  for (int k = 0; k < PW; ++k) c0[k] = (roff && k < p) ? (roff[k] / col_tile) * col_tile : 0;
+  if (live) {
+    const double* y = Yt + (size_t)slot * sY + t0 + lane;
+    float* d = D + (size_t)slot * sD + t0 + lane;
+    for (int b = wave; b < rpad; b += 4) {
+      if constexpr (PW > 10) asm volatile("" ::: "memory");
+      double v[PW], m[PW];
+#pragma unroll
+      for (int k = 0; k < PW; ++k) v[k] = (k < p && b >= c0[k]) ? y[(size_t)b * ldy + (size_t)k * ts] : 0.0;
+#pragma unroll
+      for (int k = 0; k < PW; ++k) {
+        double s2 = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < PW; ++kk) s2 += g[k * PW + kk] * v[kk];
+        m[k] = s2;
+        if (k < p) d[(size_t)b * ldd + (size_t)k * ts] = (float)(v[k] - s2);
+      }
+#pragma unroll
+      for (int a = 0; a < PW; ++a)
+#pragma unroll
+        for (int c2 = 0; c2 <= a; ++c2) acc[a * (a + 1) / 2 + c2] += m[a] * m[c2];
+    }
+  }
+  // fold the four waves' sums into the LDS block: wave 0 turns G into eps G + acc, the others add theirs
+  for (int w = 0; w < 4; ++w) {
+    __syncthreads();
+    if (wave == w && live) {
+#pragma unroll
+      for (int a = 0; a < PW; ++a)
+#pragma unroll
+        for (int c2 = 0; c2 <= a; ++c2) {
+          const double base = (w == 0) ? eps * g[a * PW + c2] : g[a * PW + c2];
+          const double val = base + acc[a * (a + 1) / 2 + c2];
+          g[a * PW + c2] = val;
+          g[c2 * PW + a] = val;
+        }
+    }
+  }
+  __syncthreads();
+  double* vbase = vsm + ((size_t)trial_of_slot[slot] * T + t0) * pp;
+  for (int e = threadIdx.x; e < nt * pp; e += 256) {
+    const int t = e / pp, idx = e - t * pp, i = idx / p, j = idx - i * p;
+    vbase[e] = Gs[t * LD + i * PW + j];
+  }
+}
+
+// part[(k * ngroups + g)][T x T] (column-major, ld = T, lower 64 x 64 wave tiles) = sum over the slots of group g, over columns b < ract,
+// of D_k[:, b] D_k[:, b]^T, with D_k[t, b] = D[slot][(k ts + t) + b ldd] (single precision), evaluated on the FP16 matrix cores as
+// described at the top of this file.  Group g holds slots [g sps, min((g + 1) sps, nslots)).
+// Workgroup = one 128 x 128 tile (ti >= tj) of one (latent, group): 4 waves of 64 x 64 = 4 x 4 accumulator tiles of
+// v_mfma_f32_16x16x32_f16.  Per 32-column step the two 128 x 32 operand tiles are read coalesced over t (lanes), split into hi / lo
+// halves and stored in LDS as [row][32 k] (row stride 40 halves: the 16-byte fragment reads of a 16-lane group hit distinct banks);
+// the next step's global loads are in flight while the current one is multiplied.
+// grid = (tiles * ngroups * p) in the XCD-aware order of the GEMM (8 consecutive ids = 8 batch entries, one per XCD), block = 256.
+struct SyrkF16Args {
+  const float* D; long long sD; int ldd, ts;
+  double* part;
+  int T, p, ract, nslots, sps, ngroups, tiles, ntiles;
+};
+
+__global__ __launch_bounds__(256, 2) void syrk_f16x2_kernel(SyrkF16Args a) {
+  constexpr int BT = 128, KS = 32, LS = 40;
+  __shared__ __attribute__((aligned(16))) _Float16 Ah[BT * LS], Al[BT * LS], Bh[BT * LS], Bl[BT * LS];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  // block id -> (batch entry, tile): entries grouped by 8 so that the blocks resident on one XCD share a (latent, group) pair
+  const int nbatch = a.ngroups * a.p;
+  int b, tile;
+  {
+    const int bid = blockIdx.x;
+    const int full = nbatch >> 3, per_group = a.ntiles << 3, grp = bid / per_group;
+    if (grp < full) { const int r = bid - grp * per_group; tile = r >> 3; b = (grp << 3) + (r & 7); }
+    else { const int m = nbatch - (full << 3); const int r = bid - full * per_group; tile = r / m; b = (full << 3) + (r - tile * m); }
+  }
+  int tj = 0, rem = tile;
+  while (rem >= a.tiles - tj) { rem -= a.tiles - tj; ++tj; }
+  const int ti = tj + rem;
+  const int k = b / a.ngroups, g = b - k * a.ngroups;
+  const int i0 = ti * BT, j0 = tj * BT;
+  const bool diag = (ti == tj);
+  const int s_begin = g * a.sps, s_end = min(a.nslots, s_begin + a.sps);
+  const bool wave_live = (i0 + wm * 64 < a.T) && (j0 + wn * 64 < a.T) && !(i0 + wm * 64 + 63 < j0 + wn * 64);
+
+  float4v_t acc[4][4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = float4v_t{0.f, 0.f, 0.f, 0.f};
+
+  // staging: thread -> row (tid & 127) of the tile, 16 of the step's 32 columns (tid >> 7)
+  const int srow = tid & 127, skh = tid >> 7;
+  const int ra = min(i0 + srow, a.T - 1), rb = min(j0 + srow, a.T - 1);      // (rows past T are clamped: their outputs are never stored)
+  float va[16], vb[16];
+  const int steps_per_slot = (a.ract + KS - 1) / KS;
+  const int nsteps = (s_end - s_begin) * steps_per_slot;
+  auto load = [&](int step) {
+    const int s = s_begin + step / steps_per_slot;
+    const int c0 = (step % steps_per_slot) * KS + skh * 16;
+    const float* base = a.D + (size_t)s * a.sD + (size_t)k * a.ts;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int c = c0 + j;
+      const bool in = c < a.ract;
+      const size_t off = (size_t)(in ? c : 0) * a.ldd;
+      const float xa = base[off + ra];
+      va[j] = in ? xa : 0.f;
+      if (!diag) { const float xb = base[off + rb]; vb[j] = in ? xb : 0.f; }
+    }
+  };
+  auto store = [&]() {
+    half8_t h0, h1, l0, l1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float x0 = va[j] * SPLIT_SCALE, x1 = va[8 + j] * SPLIT_SCALE;
+      const _Float16 a0 = (_Float16)x0, a1 = (_Float16)x1;
+      h0[j] = a0; h1[j] = a1;
+      l0[j] = (_Float16)(x0 - (float)a0); l1[j] = (_Float16)(x1 - (float)a1);
+    }
+    *reinterpret_cast<half8_t*>(&Ah[srow * LS + skh * 16]) = h0;
+    *reinterpret_cast<half8_t*>(&Ah[srow * LS + skh * 16 + 8]) = h1;
+    *reinterpret_cast<half8_t*>(&Al[srow * LS + skh * 16]) = l0;
+    *reinterpret_cast<half8_t*>(&Al[srow * LS + skh * 16 + 8]) = l1;
+    if (!diag) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float x0 = vb[j] * SPLIT_SCALE, x1 = vb[8 + j] * SPLIT_SCALE;
+        const _Float16 a0 = (_Float16)x0, a1 = (_Float16)x1;
+        h0[j] = a0; h1[j] = a1;
+        l0[j] = (_Float16)(x0 - (float)a0); l1[j] = (_Float16)(x1 - (float)a1);
+      }
+      *reinterpret_cast<half8_t*>(&Bh[srow * LS + skh * 16]) = h0;
+      *reinterpret_cast<half8_t*>(&Bh[srow * LS + skh * 16 + 8]) = h1;
+      *reinterpret_cast<half8_t*>(&Bl[srow * LS + skh * 16]) = l0;
+      *reinterpret_cast<half8_t*>(&Bl[srow * LS + skh * 16 + 8]) = l1;
+    }
+  };
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const _Float16* Bhs = diag ? Ah : Bh;
+  const _Float16* Bls = diag ? Al : Bl;
+  if (nsteps > 0) load(0);
+  for (int step = 0; step < nsteps; ++step) {
+    __syncthreads();                                   // the previous step's fragments have been read
+    store();
+    __syncthreads();
+    if (step + 1 < nsteps) load(step + 1);
+    if (wave_live) {
+      half8_t ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const int r = (wm * 64 + mi * 16 + l15) * LS + 8 * l4;
+        ah[mi] = *reinterpret_cast<const half8_t*>(&Ah[r]);
+        al[mi] = *reinterpret_cast<const half8_t*>(&Al[r]);
+      }
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const int r = (wn * 64 + ni * 16 + l15) * LS + 8 * l4;
+        bh[ni] = *reinterpret_cast<const half8_t*>(&Bhs[r]);
+        bl[ni] = *reinterpret_cast<const half8_t*>(&Bls[r]);
+      }
+      // issued as (B fragment) x (A fragment): the lane index then runs along i, the contiguous index of the column-major output
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[ni], ah[mi], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[ni], al[mi], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[ni], ah[mi], acc[mi][ni], 0, 0, 0);
+        }
+    }
+  }
+  if (!wave_live) return;
+  // accumulator register r of a lane: output row (of the issued product) 4 l4 + r  <->  j, column l15  <->  i
+  double* C = a.part + (size_t)(k * a.ngroups + g) * a.T * a.T;
+  const double inv = 1.0 / ((double)SPLIT_SCALE * (double)SPLIT_SCALE);
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int i = i0 + wm * 64 + mi * 16 + l15;
+    if (i >= a.T) continue;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = j0 + wn * 64 + ni * 16 + 4 * l4 + r;
+        if (j >= a.T) continue;
+        C[(size_t)j * a.T + i] = (double)acc[mi][ni][r] * inv;
+      }
+  }
+}
+
+// out[M x N] (ld = M) = sum over g < ngroups of part[g][M x N]; with lower != 0 (M == N) the parts hold only the wave tiles
+// (i / 64) >= (j / 64) of a symmetric matrix and the rest is mirrored.  grid = ceil(M N / 256), block = 256.
+__global__ void sum_groups_kernel(const double* __restrict__ part, int ngroups, int M, int N, int lower, double* __restrict__ out) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (size_t)M * N) return;
+  const int i = (int)(e % M), j = (int)(e / M);
+  const size_t src = (lower && (i / 64) < (j / 64)) ? (size_t)i * M + j : e;
+  double s = 0.0;
+  for (int g = 0; g < ngroups; ++g) s += part[(size_t)g * M * N + src];
+  out[e] = s;
+}
+
+// Pacc[k][T x T] (ld = Tp, full symmetric) += the split sum of latent k:
+//   eps sum_slots G_t[k][k] on the diagonal  +  T1_k  -  X_k - X_k^T  +  sum_groups DD[(k, g)]
+// with T1 = F_k S_k F_k^T and X = F_k [sum_r A_rk D_rk^T] given as full T x T matrices (ld = T) and DD as lower wave tiles of the
+// FP16 kernel.  grid = (T, p), block = 128: a block owns column j of latent k.
+__global__ void pacc_split_reduce_kernel(const double* __restrict__ T1, const double* __restrict__ X, const double* __restrict__ DD, int ngroups,
+                                         const double* __restrict__ G, long long sG, int nslots, double eps, int T, int Tp, int p,
+                                         double* __restrict__ Pacc) {
+  const int j = blockIdx.x, k = blockIdx.y;
+  const size_t tt = (size_t)T * T;
+  const double* t1 = T1 + (size_t)k * tt;
+  const double* x = X + (size_t)k * tt;
+  const double* dd = DD + (size_t)k * ngroups * tt;
+  // diagonal term: the slots spread over the block, summed in a fixed order (lanes, then waves)
+  __shared__ double gred[2];
+  double gs = 0.0;
+  for (int sl = threadIdx.x; sl < nslots; sl += blockDim.x) gs += G[(size_t)sl * sG + (size_t)j * p * p + (size_t)k * p + k];
+  for (int off = 32; off > 0; off >>= 1) gs += __shfl_down(gs, off);
+  if ((threadIdx.x & 63) == 0) gred[threadIdx.x >> 6] = gs;
+  __syncthreads();
+  const double gdiag = eps * (gred[0] + gred[1]);
+  for (int i = threadIdx.x; i < T; i += blockDim.x) {
+    // the FP16 kernel stored wave tiles with (i / 64) >= (j / 64) only: take the mirrored entry above them
+    const bool low = (i / 64) * 64 + 63 >= (j / 64) * 64;
+    const size_t e = low ? (size_t)j * T + i : (size_t)i * T + j;
+    double s = 0.0;
+    for (int g2 = 0; g2 < ngroups; ++g2) s += dd[(size_t)g2 * tt + e];
+    double v = t1[(size_t)j * T + i] - x[(size_t)j * T + i] - x[(size_t)i * T + j] + s;
+    if (i == j) v += gdiag;
+    Pacc[(size_t)k * Tp * Tp + (size_t)j * Tp + i] += v;
+  }
+}
+
+}  // namespace pgpfa
