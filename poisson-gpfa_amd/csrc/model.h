@@ -1571,10 +1571,12 @@ __global__ void negate_rows_kernel(const double* __restrict__ src, long long sSr
 }
 
 // --------------------------------------------------------------------------------------------------
-// max over the p x p blocks B[i] (i < nblocks, contiguous) of scale * ||B||_inf, folded into *out_bits with atomicMax on the float's bit
-// pattern (non-negative floats order like their bits).  Used on the blocks Wt = W (I + eps W)^-1 of a chunk: eps ||Wt_t|| is the
-// relative size of the mixing correction D = eps Wt y of the low-rank covariance engine.  grid = ceil(nblocks/256), block = 256.
-__global__ void block_norm_max_kernel(const double* __restrict__ B, long long nblocks, int p, double scale, unsigned* __restrict__ out_bits) {
+// Size of the blocks B[i] (p x p, i < nblocks, contiguous): v_i = scale * ||B_i||_inf; out_bits <- max_i v_i (atomicMax on the float's
+// bit pattern: non-negative floats order like their bits), *out_sq += sum_i v_i^2.  Used on the blocks Wt = W (I + eps W)^-1 of a
+// chunk: eps ||Wt_t|| is the relative size of the mixing correction D = eps Wt y of the low-rank covariance engine, its root mean
+// square over (trial, bin) what the precision of the split accumulation depends on.  grid = ceil(nblocks/256), block = 256.
+__global__ void block_norm_max_kernel(const double* __restrict__ B, long long nblocks, int p, double scale, unsigned* __restrict__ out_bits,
+                                      double* __restrict__ out_sq) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   float v = 0.f;
   if (i < nblocks) {
@@ -1587,8 +1589,12 @@ __global__ void block_norm_max_kernel(const double* __restrict__ B, long long nb
     }
     v = (float)(scale * worst);
   }
-  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_down(v, off));
-  if ((threadIdx.x & 63) == 0 && v > 0.f) atomicMax(out_bits, __float_as_uint(v));
+  double sq = (double)v * (double)v;
+  for (int off = 32; off > 0; off >>= 1) { v = fmaxf(v, __shfl_down(v, off)); sq += __shfl_down(sq, off); }
+  if ((threadIdx.x & 63) == 0) {
+    if (v > 0.f) atomicMax(out_bits, __float_as_uint(v));
+    if (out_sq) atomicAdd(out_sq, sq);
+  }
 }
 
 // Shared-preconditioner Newton-PCG pieces.

@@ -111,7 +111,11 @@ struct pgpfa_ctx {
   double* ppart = nullptr;                       // [p][PACC_SPLITS + 1][T x T] split-K partial products
   double* split_buf = nullptr;                   // scratch of the split accumulation (split.h), allocated on first use
   bool split_cov = true;                         // option split_cov: sum_r Y~Y~^T by the exact split form when eps ||Wt|| allows
-  double split_max_norm = 2e-2;                  // ... i.e. up to this value of max_t eps ||Wt_t||_inf (option split_max_norm)
+  // ... i.e. up to this value of the root mean square over (trial, bin) of eps ||Wt_t||_inf (option split_max_norm).  Measured against the
+  // FP64 product at config-3 dimensions (tools/split_probe.py, 512 trials): 3e-12 of PautoSum at the generating parameters (rms 0.02,
+  // max 0.22), 3.8e-11 / 2.1e-10 for populations firing 3 / 8 times faster (rms = max = 0.018 / 0.045): the error grows like the
+  // square of the rms, 0.07 keeps 1e-9 with a factor two to spare
+  double split_max_norm = 0.07;
   double *cdym = nullptr, *cdym_part = nullptr;   // count terms of the (C,d) cost: sum_t y m_t, sum_t y per neuron (per E-step)
   bool cdym_valid = false, cd_mfma = true; int cd_debug = 0;
   bool cd_hess_valid = false; int cd_hess_ntr = 0;   // per-neuron Hessian sums of the last Newton pass are resident
@@ -1117,6 +1121,9 @@ int pgpfa_create(pgpfa_ctx** out, int device, int q, int p, int T, int R, double
   c->info["n_pad"] = c->npad;
   c->info["counts_two_bytes"] = 0.0;
   c->info["arena_bytes"] = 0.0;
+  c->info["last_eps_wt_norm"] = 0.0;
+  c->info["last_eps_wt_rms"] = 0.0;
+  c->info["last_split_cov"] = 0.0;
   *out = c;
   return 0;
 }
@@ -1156,7 +1163,7 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
   else if (k == "shared_pcg") c->shared_pcg = (v != 0.0);
   else if (k == "time_newton") c->time_newton = (v != 0.0);
   else if (k == "pcg_trace") c->pcg_trace = (v != 0.0);
-  else if (k == "measure_mix") { c->measure_mix = (v != 0.0); c->info["last_eps_wt_norm"] = 0.0; }
+  else if (k == "measure_mix") { c->measure_mix = (v != 0.0); c->info["last_eps_wt_norm"] = 0.0; c->info["last_eps_wt_rms"] = 0.0; }
   else if (k == "pcg_retire") c->pcg_retire = (v != 0.0);
   else if (k == "split_cov") c->split_cov = (v != 0.0);
   else if (k == "split_max_norm") c->split_max_norm = v;
@@ -1726,19 +1733,21 @@ static int accumulate_split(pgpfa_ctx* c, const CholWS& lw, int nb, int ract, in
   const long long sW = (long long)T * p * p;
   const size_t tt = (size_t)T * T;
   (void)skip_zero_cols;
-  // scratch: S parts [NS][<= T^2] | X parts [NG][<= T^2] | Ssum | Xsum | Z | T1 [p][T^2] | Xfull [p][T^2]
+  // scratch: S parts [NS][r_k^2] | X parts [NG][r_k T] | Ssum | Xsum | Z | T1 [p][T^2] | Xfull [p][T^2]; a latent's padded rank r_k can reach
+  // T rounded up to 16, so the first five are laid out in units of tq = round_up(T, 16)^2
   constexpr int NS = 256, NG = PACC_SPLITS + 1;
+  const size_t tq = (size_t)round_up(T, 16) * round_up(T, 16);
   if (!c->split_buf) {
-    const size_t len = ((size_t)NS + NG + 3 + 2 * (size_t)p) * tt + 1024;
+    const size_t len = ((size_t)NS + NG + 3) * tq + 2 * (size_t)p * tt + 1024;
     if (hipMalloc((void**)&c->split_buf, len * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); c->split_buf = nullptr; return fail("out of device memory for the split accumulation (%zu bytes)", len * sizeof(double)); }
     c->bytes += len * sizeof(double);
   }
   double* Spart = c->split_buf;
-  double* Xpart = Spart + (size_t)NS * tt;
-  double* Ssum = Xpart + (size_t)NG * tt;
-  double* Xsum = Ssum + tt;
-  double* Zb = Xsum + tt;
-  double* T1 = Zb + tt;
+  double* Xpart = Spart + (size_t)NS * tq;
+  double* Ssum = Xpart + (size_t)NG * tq;
+  double* Xsum = Ssum + tq;
+  double* Zb = Xsum + tq;
+  double* T1 = Zb + tq;
   double* Xfull = T1 + (size_t)p * tt;
   float* D = reinterpret_cast<float*>(lw.H + (size_t)c->ld * rpad);          // behind Yt in every slot's slab
   const long long sD = 2 * (long long)lw.sH;                                   // slab stride in floats
@@ -1804,7 +1813,7 @@ static int accumulate_split(pgpfa_ctx* c, const CholWS& lw, int nb, int ract, in
     CHK(seg(spsS, false, Spart));
     CHK(seg(sps, true, Xpart));
     const int ngS = (nb + spsS - 1) / spsS;
-    hipLaunchKernelGGL(sum_groups_kernel, dim3((unsigned)(((size_t)rk * rk + 255) / 256)), dim3(256), 0, c->st, Spart, ngS, rk, rk, 1, Ssum);
+    hipLaunchKernelGGL(sum_groups_kernel, dim3((unsigned)(((size_t)rk * rk + 255) / 256)), dim3(256), 0, c->st, Spart, ngS, rk, rk, 32, Ssum);
     hipLaunchKernelGGL(sum_groups_kernel, dim3((unsigned)(((size_t)rk * T + 255) / 256)), dim3(256), 0, c->st, Xpart, ngroups, rk, T, 0, Xsum);
     const double* Fk = c->Flr + (size_t)k * Tp * Tp;
     GemmP z{};                                                                  // Z = F_k S_k   (T x r_k)
@@ -1842,9 +1851,10 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool 
   const bool split_candidate = want_vsmgp && accumulate && c->split_cov && c->mfma && p <= 16 && !c->dual_f32;
   unsigned* norm_bits = reinterpret_cast<unsigned*>(c->pcg_ratio);         // (scratch word: the inner solves are over)
   if (split_candidate || c->measure_mix) {
-    HIPC(hipMemsetAsync(norm_bits, 0, sizeof(unsigned), c->st));
+    HIPC(hipMemsetAsync(norm_bits, 0, 4 * sizeof(unsigned), c->st));
     const long long nblk = (long long)nb * T;
-    hipLaunchKernelGGL(block_norm_max_kernel, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, c->st, c->Wt, nblk, p, c->eps, norm_bits);
+    hipLaunchKernelGGL(block_norm_max_kernel, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, c->st, c->Wt, nblk, p, c->eps, norm_bits,
+                       reinterpret_cast<double*>(norm_bits + 2));
   }
   // b. B = I + F^T Wt F into the factor slabs viewed with ld = rpad; factor; L^-T
   CholWS lw = c->ws;
@@ -1965,11 +1975,18 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool 
   if (p > WIDE_MAX) return fail("low-rank covariance engine supports up to %d latents (p=%d)", WIDE_MAX, p);
   bool split = false;
   if (split_candidate || c->measure_mix) {
-    float hv = 0.f;
-    HIPC(hipMemcpyAsync(&hv, norm_bits, sizeof(float), hipMemcpyDeviceToHost, c->st));
+    unsigned hw[4] = {0u, 0u, 0u, 0u};
+    HIPC(hipMemcpyAsync(hw, norm_bits, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, c->st));
     HIPC(hipStreamSynchronize(c->st));
+    float hv;
+    double hsq;
+    std::memcpy(&hv, &hw[0], sizeof(float));
+    std::memcpy(&hsq, &hw[2], sizeof(double));
+    const double rms = std::sqrt(hsq / std::max(1.0, (double)nb * T));
     c->info["last_eps_wt_norm"] = std::max(c->info["last_eps_wt_norm"], (double)hv);
-    split = split_candidate && std::isfinite(hv) && (double)hv <= c->split_max_norm;
+    c->info["last_eps_wt_rms"] = std::max(c->info["last_eps_wt_rms"], rms);
+    // (the precision of the split form follows the root mean square of the correction; the maximum only has to stay a contraction)
+    split = split_candidate && std::isfinite(hv) && std::isfinite(rms) && rms <= c->split_max_norm && (double)hv <= 0.9;
   }
   c->info["last_split_cov"] = split ? 1.0 : 0.0;
   if (want_vsmgp && split) {

@@ -145,51 +145,54 @@ __global__ __launch_bounds__(256, 2) void syrk_f16x2_kernel(SyrkF16Args a) {
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = float4v_t{0.f, 0.f, 0.f, 0.f};
 
-  // staging: thread -> row (tid & 127) of the tile, 16 of the step's 32 columns (tid >> 7)
-  const int srow = tid & 127, skh = tid >> 7;
-  const int ra = min(i0 + srow, a.T - 1), rb = min(j0 + srow, a.T - 1);      // (rows past T are clamped: their outputs are never stored)
-  float va[16], vb[16];
+  // staging: threads 0..127 take the A tile, 128..255 the B tile (idle on diagonal tiles, where B is A); a thread owns four
+  // consecutive rows (t: contiguous in memory, one 16-byte load per column) and eight of the step's 32 columns
+  const bool is_b = tid >= 128;
+  const int rq = tid & 31, co = (tid >> 5) & 3;
+  const int row0 = (is_b ? j0 : i0) + 4 * rq;
+  const bool stage = !(is_b && diag);
+  // 16-byte loads need rows on 4-float boundaries inside the slab (ts, ldd multiples of 4); rows at or past T are read too when the
+  // latent stride leaves room for them (ts >= round_up(T, 4)): those rows only reach outputs that are never stored
+  const bool vec = ((a.ts & 3) == 0) && ((a.ldd & 3) == 0) && (row0 + 3 < a.ts) && ((((size_t)a.D) & 15) == 0) && ((a.sD & 3) == 0);
+  float4v_t v4[8];
   const int steps_per_slot = (a.ract + KS - 1) / KS;
   const int nsteps = (s_end - s_begin) * steps_per_slot;
   auto load = [&](int step) {
+    if (!stage) return;
     const int s = s_begin + step / steps_per_slot;
-    const int c0 = (step % steps_per_slot) * KS + skh * 16;
+    const int c0 = (step % steps_per_slot) * KS + co * 8;
     const float* base = a.D + (size_t)s * a.sD + (size_t)k * a.ts;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
+    for (int j = 0; j < 8; ++j) {
       const int c = c0 + j;
       const bool in = c < a.ract;
       const size_t off = (size_t)(in ? c : 0) * a.ldd;
-      const float xa = base[off + ra];
-      va[j] = in ? xa : 0.f;
-      if (!diag) { const float xb = base[off + rb]; vb[j] = in ? xb : 0.f; }
+      float4v_t x;
+      if (vec) {
+        x = *reinterpret_cast<const float4v_t*>(base + off + row0);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] = base[off + min(row0 + r, a.T - 1)];
+      }
+      v4[j] = in ? x : float4v_t{0.f, 0.f, 0.f, 0.f};
     }
   };
   auto store = [&]() {
-    half8_t h0, h1, l0, l1;
+    if (!stage) return;
+    _Float16* Hh = is_b ? Bh : Ah;
+    _Float16* Hl = is_b ? Bl : Al;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float x0 = va[j] * SPLIT_SCALE, x1 = va[8 + j] * SPLIT_SCALE;
-      const _Float16 a0 = (_Float16)x0, a1 = (_Float16)x1;
-      h0[j] = a0; h1[j] = a1;
-      l0[j] = (_Float16)(x0 - (float)a0); l1[j] = (_Float16)(x1 - (float)a1);
-    }
-    *reinterpret_cast<half8_t*>(&Ah[srow * LS + skh * 16]) = h0;
-    *reinterpret_cast<half8_t*>(&Ah[srow * LS + skh * 16 + 8]) = h1;
-    *reinterpret_cast<half8_t*>(&Al[srow * LS + skh * 16]) = l0;
-    *reinterpret_cast<half8_t*>(&Al[srow * LS + skh * 16 + 8]) = l1;
-    if (!diag) {
+    for (int r = 0; r < 4; ++r) {
+      half8_t h, l;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float x0 = vb[j] * SPLIT_SCALE, x1 = vb[8 + j] * SPLIT_SCALE;
-        const _Float16 a0 = (_Float16)x0, a1 = (_Float16)x1;
-        h0[j] = a0; h1[j] = a1;
-        l0[j] = (_Float16)(x0 - (float)a0); l1[j] = (_Float16)(x1 - (float)a1);
+        const float x = v4[j][r] * SPLIT_SCALE;
+        const _Float16 hx = (_Float16)x;
+        h[j] = hx;
+        l[j] = (_Float16)(x - (float)hx);
       }
-      *reinterpret_cast<half8_t*>(&Bh[srow * LS + skh * 16]) = h0;
-      *reinterpret_cast<half8_t*>(&Bh[srow * LS + skh * 16 + 8]) = h1;
-      *reinterpret_cast<half8_t*>(&Bl[srow * LS + skh * 16]) = l0;
-      *reinterpret_cast<half8_t*>(&Bl[srow * LS + skh * 16 + 8]) = l1;
+      *reinterpret_cast<half8_t*>(&Hh[(4 * rq + r) * LS + co * 8]) = h;
+      *reinterpret_cast<half8_t*>(&Hl[(4 * rq + r) * LS + co * 8]) = l;
     }
   };
   const int l15 = lane & 15, l4 = lane >> 4;
@@ -245,13 +248,14 @@ __global__ __launch_bounds__(256, 2) void syrk_f16x2_kernel(SyrkF16Args a) {
   }
 }
 
-// out[M x N] (ld = M) = sum over g < ngroups of part[g][M x N]; with lower != 0 (M == N) the parts hold only the wave tiles
-// (i / 64) >= (j / 64) of a symmetric matrix and the rest is mirrored.  grid = ceil(M N / 256), block = 256.
+// out[M x N] (ld = M) = sum over g < ngroups of part[g][M x N]; with lower > 0 (M == N) the parts hold only the wave tiles
+// (i / lower) >= (j / lower) of a symmetric matrix (GEMM_LOWER on 64 x 64 workgroup tiles skips 32 x 32 wave tiles) and the rest is
+// mirrored.  grid = ceil(M N / 256), block = 256.
 __global__ void sum_groups_kernel(const double* __restrict__ part, int ngroups, int M, int N, int lower, double* __restrict__ out) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (size_t)M * N) return;
   const int i = (int)(e % M), j = (int)(e / M);
-  const size_t src = (lower && (i / 64) < (j / 64)) ? (size_t)i * M + j : e;
+  const size_t src = (lower > 0 && (i / lower) < (j / lower)) ? (size_t)i * M + j : e;
   double s = 0.0;
   for (int g = 0; g < ngroups; ++g) s += part[(size_t)g * M * N + src];
   out[e] = s;
