@@ -1133,7 +1133,8 @@ __global__ __launch_bounds__(64 * CDH_KY) void mstep_cd_hess_kernel(CdArgs a) {
 // lane's registers: the rows of the packed Hessian are dealt round-robin to NG row groups, blockIdx.z selects the group,
 // and every group repeats the (cheap) per-bin preamble.  Group 0 also carries the cost and the gradient.  Same staging,
 // same part layout (each group writes its own rows).  grid = (ceil(q/64), nby, NG), block = (64, CDH_KY).
-template <int PW> struct CdGroups { static constexpr int NG = (PW <= 12) ? 1 : (PW <= 16) ? 2 : (PW <= 20) ? 3 : 8; };
+// (20 latents - config 5 - in 4 groups: with 3 the 256 architectural registers were 4 short and the compiler parked values in AGPRs)
+template <int PW> struct CdGroups { static constexpr int NG = (PW <= 12) ? 1 : (PW <= 16) ? 2 : (PW <= 20) ? 4 : 8; };
 constexpr int cd_group_entries(int D, int NG, int G) {
   int n = 0;
   for (int i = 0; i < D; ++i)
@@ -1292,8 +1293,13 @@ __global__ __launch_bounds__(64 * CDH_KY) void mstep_cd_hess_rows_kernel(CdArgs 
     if (g == 0) cd_hess_rows_body<PW, NG, 0>(a, Vt, Mt, Yt, red);
     else if (g == 1) cd_hess_rows_body<PW, NG, 1>(a, Vt, Mt, Yt, red);
     else cd_hess_rows_body<PW, NG, 2>(a, Vt, Mt, Yt, red);
+  } else if constexpr (NG == 4) {
+    if (g == 0) cd_hess_rows_body<PW, NG, 0>(a, Vt, Mt, Yt, red);
+    else if (g == 1) cd_hess_rows_body<PW, NG, 1>(a, Vt, Mt, Yt, red);
+    else if (g == 2) cd_hess_rows_body<PW, NG, 2>(a, Vt, Mt, Yt, red);
+    else cd_hess_rows_body<PW, NG, 3>(a, Vt, Mt, Yt, red);
   } else {
-    static_assert(NG == 8, "row groups: 2, 3 or 8");
+    static_assert(NG == 8, "row groups: 2, 3, 4 or 8");
     switch (g) {
       case 0: cd_hess_rows_body<PW, NG, 0>(a, Vt, Mt, Yt, red); break;
       case 1: cd_hess_rows_body<PW, NG, 1>(a, Vt, Mt, Yt, red); break;

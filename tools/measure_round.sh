@@ -1,6 +1,6 @@
-# Measurement set committed under profiles/ each round (run on the GPU box through gpurun): bash tools/measure_round.sh <tag>
+# Measurement set committed under profiles/ once per round (run on the GPU box through gpurun): bash tools/measure_round.sh <tag>
 set -x
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -9,8 +9,9 @@ python bench.py --steps 20 --warmup 5 > $O/bench_c3_driver_protocol.json 2> $O/b
 python bench.py --config c2 --steps 20 --warmup 5 > $O/bench_c2.json 2>/dev/null
 python bench.py --config c1 --steps 20 --warmup 2 --no-cpu-baseline > $O/bench_c1.json 2>/dev/null
 python bench.py --workload online --steps 6 --warmup 2 > $O/bench_c4_online.json 2>/dev/null
-python bench.py --workload dual --config c5 --trials 256 --steps 6 --warmup 1 > $O/bench_c5_dual_mixed.json 2>/dev/null
-python bench.py --workload dual --config c5 --trials 256 --steps 6 --warmup 1 --precision f64 > $O/bench_c5_dual_f64.json 2>/dev/null
+python bench.py --workload dual --config c5 --trials 32 > $O/bench_c5_dual_estep_mixed.json 2>/dev/null
+python bench.py --workload dual --config c5 --trials 256 --dual-iters 6 --warmup 1 > $O/bench_c5_dual_unit_mixed.json 2>/dev/null
+python bench.py --workload dual --config c5 --trials 256 --dual-iters 6 --warmup 1 --precision f64 > $O/bench_c5_dual_unit_f64.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -o ks -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --lean > $O/bench_c3_under_rocprof.json 2>/dev/null
 cd $R
@@ -25,6 +26,7 @@ cd $R
 python tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/pmc_hbm_traffic.json | head -8
 rm -rf $O/pmc_fetch $O/pmc_write
 python tools/gemm_shapes.py 12 > $O/gemm_shapes.txt 2>/dev/null
-python tools/potrf_probe.py > $O/potrf_phases.txt 2>/dev/null
+python tools/split_probe.py 512 > $O/split_probe.txt 2>/dev/null
 python tools/cold_start_probe.py > $O/cold_start.txt 2>/dev/null
+python tools/em_trace.py 60 > $O/em_trace_60_iterations.txt 2>/dev/null
 ls -la $O
