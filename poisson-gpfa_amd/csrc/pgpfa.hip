@@ -163,6 +163,8 @@ struct pgpfa_ctx {
   PcgCtl* pcgctl = nullptr;                      // device-side control block of the inner PCG loop (pcg.h)
   int* live = nullptr; float *pcg_ratio = nullptr, *pcg_eta = nullptr;   // device live list of the inner solve, per-slot residual ratio / target
   const int* cur_ndev = nullptr;                 // while set: products with a column list take their column count from this device word
+  bool live_gemm_collect = false;                // profiling: the first iteration of an inner solve lists its live-list products here
+  std::vector<std::pair<std::string, double>> live_gemms;   // (shape key, algorithmic flops per column)
   bool pcg_retire = true;                        // slots leave the inner solve as they reach their own targets (option pcg_retire)
   int* h_pcg = nullptr; int* d_hpcg = nullptr;   // host-mapped copy {stop, iterations}: the host peeks, never waits
   float* W32 = nullptr;                          // packed single-precision curvature triangles of the chunk's slots (PCG matvec)
@@ -350,13 +352,17 @@ double gemm_flops(const GemmP& g) {
 
 // (f32: operands are single precision - pointers carried as double*, strides in elements - on the FP32 matrix cores; no split-K)
 int gemm(pgpfa_ctx* c, bool transb, GemmP g, bool f32 = false) {
-  prof_begin(c, TAG_GEMM, gemm_flops(g));
+  // (products over a device-side live list: how many columns a launch really has is only known after the solve - their launches are
+  // recorded with their time and no flops, the flops are added per shape once the slot-iterations are known: prof_live_flops)
+  const bool live_cols = g.cols && c->cur_ndev;
+  prof_begin(c, TAG_GEMM, live_cols ? 0.0 : gemm_flops(g));
   if (c->prof.on && c->prof.open) {
-    char key[160];
-    std::snprintf(key, sizeof key, "%s %s M=%d N=%d K=%d%s batch=%d%s%s%s", f32 ? "f32" : "f64", transb ? "NN" : "NT", g.M, g.N, g.K,
-                  g.kseg ? " (segmented)" : "", std::max(g.nbatch, 1), g.mode == GEMM_LOWER ? " lower" : "",
+    char key[176];
+    std::snprintf(key, sizeof key, "%s %s M=%d N=%s%d K=%d%s batch=%d%s%s%s", f32 ? "f32" : "f64", transb ? "NN" : "NT", g.M, live_cols ? "<=" : "", g.N,
+                  g.K, g.kseg ? " (segmented)" : "", std::max(g.nbatch, 1), g.mode == GEMM_LOWER ? " lower" : "",
                   g.kflags ? " triangular-k" : "", g.rtab ? " block-sparse" : "");
     c->prof.recs.back().shape = key;
+    if (live_cols && c->live_gemm_collect) c->live_gemms.emplace_back(key, gemm_flops(g) / std::max(g.N, 1));
   }
   // Tile size: products that offer few 128 x 128 tiles (multi-RHS vectors against the block-diagonal factors and the r x r
   // preconditioner, K^-1 p, the short panels of the r x r factorisations) run on 64 x 64 tiles - four times the workgroups, 3-4 of
@@ -2256,7 +2262,9 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
                              c->sc_rr, c->sc_rr0, 1, (PcgCtl*)nullptr, (float*)nullptr);
           c->cur_ndev = &c->pcgctl->nlive;
           struct NdevGuard { pgpfa_ctx* c; ~NdevGuard() { c->cur_ndev = nullptr; } } ndev_guard{c};
+          c->live_gemms.clear();
           for (int it = 0; it < c->pcg_inner_max; ++it) {
+            c->live_gemm_collect = (it == 0);
             CHK(prior_mv_all(c, nb, c->Pv, c->Qv, nullptr, skip, c->live, na));
             dispatch_pw(p, [&](auto pw) {
               constexpr int PW = decltype(pw)::value;
@@ -2294,6 +2302,7 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
             }
           }
           c->cur_ndev = nullptr;
+          c->live_gemm_collect = false;
           HIPC(hipMemcpyAsync(&fused_ctl, c->pcgctl, sizeof(PcgCtl), hipMemcpyDeviceToHost, c->st));
           HIPC(hipGetLastError());
           done_inner = -1;                                     // read from the control block with the scalars below
@@ -2350,6 +2359,11 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
         if (done_inner < 0) {                                   // (the download above synchronised the stream)
           done_inner = fused_ctl.iters;
           slot_iters = (double)fused_ctl.slot_iters;
+          if (c->prof.on)                                       // algorithmic flops of the live-list products: per column x slot-iterations
+            for (const auto& lg : c->live_gemms) {
+              c->prof.flops[TAG_GEMM] += lg.second * slot_iters;
+              c->prof.shapes[lg.first].flops += lg.second * slot_iters;
+            }
         }
         n_pcg += slot_iters;
         if (c->pcg_trace) {
