@@ -216,6 +216,8 @@ struct pgpfa_ctx {
   // pinned host staging
   double* hbuf = nullptr; size_t hbuf_len = 0;
   int* hibuf = nullptr; size_t hibuf_len = 0;
+  // ring of pinned staging slots for small host -> device uploads that must not cost a stream synchronisation each (Newton driver)
+  char* ring = nullptr; size_t ring_slot = 0; int ring_cur = 0, ring_pending = 0;
   // stats
   std::map<std::string, double> info;
   std::vector<void*> allocs;
@@ -771,11 +773,35 @@ int upload_list(pgpfa_ctx* c, int* dst, const std::vector<int>& v) {
 int download(pgpfa_ctx* c, double* host, const double* dev, size_t n) {
   HIPC(hipMemcpyAsync(host, dev, n * sizeof(double), hipMemcpyDeviceToHost, c->st));
   HIPC(hipStreamSynchronize(c->st));
+  c->ring_pending = 0;
   return 0;
 }
 int upload(pgpfa_ctx* c, double* dev, const double* host, size_t n) {
   HIPC(hipMemcpyAsync(dev, host, n * sizeof(double), hipMemcpyHostToDevice, c->st));
   HIPC(hipStreamSynchronize(c->st));
+  c->ring_pending = 0;
+  return 0;
+}
+// Small upload without a synchronisation: the bytes are copied into the next slot of a ring of pinned buffers and sent asynchronously; a
+// slot comes round again after RING_N uploads, and every download / synchronising upload in between (there is at least one per Newton
+// outer iteration and per line-search round) has drained the stream by then - enforced by the pending count.
+constexpr int RING_N = 16;
+int upload_nosync(pgpfa_ctx* c, void* dev, const void* host, size_t bytes) {
+  if (bytes == 0) return 0;
+  if (bytes > c->ring_slot) {
+    HIPC(hipStreamSynchronize(c->st));
+    if (c->ring) hipHostFree(c->ring);
+    c->ring = nullptr;
+    const size_t slot = (bytes + 4095) / 4096 * 4096;
+    HIPC(hipHostMalloc((void**)&c->ring, slot * RING_N));
+    c->ring_slot = slot; c->ring_cur = 0; c->ring_pending = 0;
+  }
+  if (c->ring_pending >= RING_N - 1) { HIPC(hipStreamSynchronize(c->st)); c->ring_pending = 0; }
+  char* slot = c->ring + (size_t)c->ring_cur * c->ring_slot;
+  std::memcpy(slot, host, bytes);
+  HIPC(hipMemcpyAsync(dev, slot, bytes, hipMemcpyHostToDevice, c->st));
+  c->ring_cur = (c->ring_cur + 1) % RING_N;
+  c->ring_pending += 1;
   return 0;
 }
 
@@ -1148,6 +1174,7 @@ int pgpfa_destroy(pgpfa_ctx* c) {
   arena_release(c);
   if (c->hbuf) hipHostFree(c->hbuf);
   if (c->hibuf) hipHostFree(c->hibuf);
+  if (c->ring) hipHostFree(c->ring);
   if (c->h_pcg) hipHostFree(c->h_pcg);
   for (auto e : c->prof.pool) hipEventDestroy(e);
   if (c->st) hipStreamDestroy(c->st);
@@ -2142,7 +2169,7 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
     hipLaunchKernelGGL(dots3_kernel, dim3(nb), dim3(256), 0, c->st, c->Xc, ld, c->KX, ld, (const double*)nullptr, 0LL,
                        (const double*)nullptr, 0LL, nvec, c->ident, c->sc_qxx, c->sc_qdx, c->sc_qdd);
     CHK(poisson(c, c->ident, nb, c->Xc, c->Gl, c->W, c->sc_f, 1));
-    CHK(download(c, f.data(), c->sc_f, nb));
+    HIPC(hipMemcpyAsync(f.data(), c->sc_f, nb * sizeof(double), hipMemcpyDeviceToHost, c->st));
     CHK(download(c, qxx.data(), c->sc_qxx, nb));
     std::vector<int> active(nb);
     for (int s = 0; s < nb; ++s) { active[s] = s; f[s] += 0.5 * qxx[s]; its[s] = 0; stat[s] = 1; }
@@ -2156,8 +2183,8 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
       for (int s : cand) { alpha[s] = 1.0; pending.push_back(s); }
       for (int ls = 0; ls < 40 && !pending.empty(); ++ls) {
         const int np_ = (int)pending.size();
-        CHK(upload_list(c, c->list_b, pending));
-        CHK(upload(c, c->sc_alpha, alpha.data(), nb));
+        CHK(upload_nosync(c, c->list_b, pending.data(), sizeof(int) * pending.size()));
+        CHK(upload_nosync(c, c->sc_alpha, alpha.data(), sizeof(double) * nb));
         hipLaunchKernelGGL(make_try_kernel, dim3((nvec + 255) / 256, np_), dim3(256), 0, c->st, c->Xc, ld, c->Dl, ld, c->sc_alpha, c->Xt, ld, nvec,
                            c->list_b);
         CHK(poisson(c, c->list_b, np_, c->Xt, c->Glt, c->Wt, c->sc_f, 1));
@@ -2177,7 +2204,7 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
         }
         if (!acc.empty()) {
           const int nacc = (int)acc.size();
-          CHK(upload_list(c, c->list_b, acc));
+          CHK(upload_nosync(c, c->list_b, acc.data(), sizeof(int) * acc.size()));
           const int nw = T * p * p;
           hipLaunchKernelGGL(commit_kernel, dim3((nvec + 255) / 256, nacc), dim3(256), 0, c->st, c->Xc, c->Xt, c->KX, c->KD, c->Gl, c->Glt, ld,
                              c->W, c->Wt, (long long)nw, c->sc_alpha, nvec, nw, c->list_b);
@@ -2208,7 +2235,7 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
           eta_target = std::min(eta_target, std::max(1e-9, std::min(c->pcg_eta0, want)));
         }
         const int na = (int)active.size();
-        CHK(upload_list(c, c->list_a, active));
+        CHK(upload_nosync(c, c->list_a, active.data(), sizeof(int) * active.size()));
         if (c->time_newton) {
           newton_ev.emplace_back(prof_event(c->prof), prof_event(c->prof));
           hipEventRecord(newton_ev.back().first, c->st);
@@ -2238,12 +2265,11 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
                 }
                 eta_s[s] = (float)es;
               }
-            HIPC(hipMemcpyAsync(c->pcg_eta, eta_s.data(), sizeof(float) * nb, hipMemcpyHostToDevice, c->st));
+            CHK(upload_nosync(c, c->pcg_eta, eta_s.data(), sizeof(float) * nb));
             HIPC(hipMemcpyAsync(c->live, c->list_a, sizeof(int) * na, hipMemcpyDeviceToDevice, c->st));
             PcgCtl h0{};
             h0.nlive = na;
-            HIPC(hipMemcpyAsync(c->pcgctl, &h0, sizeof(PcgCtl), hipMemcpyHostToDevice, c->st));
-            HIPC(hipStreamSynchronize(c->st));                 // (eta_s / h0 are stack objects)
+            CHK(upload_nosync(c, c->pcgctl, &h0, sizeof(PcgCtl)));
           }
           c->h_pcg[0] = 0; c->h_pcg[1] = 0;
           if (c->pcg_w32)

@@ -357,7 +357,7 @@ def test_split_accumulation_matches_the_fp64_product(c1, dims):
         Y = np.stack(Ys)
         par = {'C': true['C'], 'd': true['d'], 'tau': np.linspace(0.1, 0.5, p)}
     out = {}
-    for mode in ('fp64', 'split', 'forced_fallback', 'loud'):
+    for mode in ('fp64', 'split', 'forced_fallback', 'loud', 'very_loud'):
         ctx = _hip.Context(q, p, T, R, 10.0)
         try:
             ctx.upload_counts(Y)
@@ -368,9 +368,9 @@ def test_split_accumulation_matches_the_fp64_product(c1, dims):
             elif 'PGPFA_SPLIT_MAX' in __import__('os').environ:
                 ctx.set_option('split_max_norm', float(__import__('os').environ['PGPFA_SPLIT_MAX']))
             d = par['d']
-            if mode == 'loud':
-                # a population firing 12 x faster (counts redrawn at those rates): eps ||Wt|| several times the usual
-                d = par['d'] + 2.5
+            if mode in ('loud', 'very_loud'):
+                # a population firing 12 x (50 x) faster, counts redrawn at those rates: eps ||Wt|| several times the usual (beyond the guard)
+                d = par['d'] + (2.5 if mode == 'loud' else 3.9)
                 rng = np.random.default_rng(5)
                 ctx.upload_counts(np.minimum(rng.poisson(np.exp(d)[None, :, None] * np.ones((R, 1, T))), 60000).astype(np.uint16))
             ctx.set_option('measure_mix', 1)
@@ -394,3 +394,6 @@ def test_split_accumulation_matches_the_fp64_product(c1, dims):
     assert rel(out['split'][0], ref[0]) <= 1e-9 and rel(out['split'][1], ref[1]) <= 1e-12
     assert rel(out['forced_fallback'][0], ref[0]) <= 1e-13
     assert rel(out['loud'][0], out['loud_fp64'][0]) <= 1e-9 and rel(out['loud'][1], out['loud_fp64'][1]) <= 1e-12
+    if dims != 'c1':
+        # rates high enough for the guard (rms of eps ||Wt|| above 0.07) to keep the FP64 product by itself
+        assert out['very_loud'][3] > 0.07 and out['very_loud'][2] == 0.0 and np.all(np.isfinite(out['very_loud'][0]))
