@@ -1814,26 +1814,32 @@ __global__ __launch_bounds__(256) void step_stats_kernel(const double* __restric
 // v_t = (K[t][piv] - sum_m F[m][t] F[m][piv]) / sqrt(d_piv): the columns of F are read back from memory (L2), eight independent
 // partial sums so that sixteen loads are in flight per thread - the step is bound by that latency, not by its j T multiply-adds.
 // dynamic LDS = (T + rmax + NT / 64) doubles + NT / 64 ints.
-template <int NT>
-__global__ __launch_bounds__(NT) void rbf_pivchol_kernel(double* __restrict__ F, int Tf, int T, const double* __restrict__ tau, double bin,
-                                                         double eps, double tol, int rmax, int* __restrict__ rank) {
-  constexpr int NW = NT / 64;
-  extern __shared__ double sh[];              // d[T] | frow[rmax] | wave maxima [NW] ; then int wave argmax [NW]
+template <int NT, int NS = 1>
+__global__ __launch_bounds__(NT * NS) void rbf_pivchol_kernel(double* __restrict__ F, int Tf, int T, const double* __restrict__ tau, double bin,
+                                                              double eps, double tol, int rmax, int* __restrict__ rank) {
+  // NT threads cover the rows (bins); NS groups of NT threads share the dot products of a step: group g takes the 8-column blocks
+  // g, g + NS, ... of the columns found so far (the step is bound by how fast ONE workgroup pulls the factor out of L2: two groups
+  // have twice the loads in flight), partial sums meet in LDS
+  constexpr int NW = NT * NS / 64;
+  extern __shared__ double sh[];              // d[T] | frow[rmax] | wave maxima [NW] | partial sums [NS - 1][T] ; then int wave argmax [NW]
   double* d = sh;
   double* frow = sh + T;
   double* rv = frow + rmax;
-  int* ri = reinterpret_cast<int*>(rv + NW);
+  double* psum = rv + NW;
+  int* ri = reinterpret_cast<int*>(psum + (size_t)(NS - 1) * T);
   const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = tid / NT, rt = tid - grp * NT;                    // dot-product group, row thread
+  constexpr int NTT = NT * NS;
   double* Fk = F + (size_t)k * Tf * Tf;
   const double den = (tau[k] * 1000.0) * (tau[k] * 1000.0);
-  for (size_t e = tid; e < (size_t)Tf * Tf; e += NT) Fk[e] = 0.0;
-  for (int t = tid; t < T; t += NT) d[t] = 1.0 - eps;
+  for (size_t e = tid; e < (size_t)Tf * Tf; e += NTT) Fk[e] = 0.0;
+  for (int t = tid; t < T; t += NTT) d[t] = 1.0 - eps;
   __syncthreads();
   int j = 0;
   for (; j < rmax; ++j) {
     // largest remaining diagonal entry, lowest index on ties
     double best = -1.0; int bi = 0x7fffffff;
-    for (int t = tid; t < T; t += NT) if (d[t] > best) { best = d[t]; bi = t; }
+    for (int t = tid; t < T; t += NTT) if (d[t] > best) { best = d[t]; bi = t; }
     for (int off = 32; off > 0; off >>= 1) {
       const double ob = __shfl_down(best, off);
       const int oi = __shfl_down(bi, off);
@@ -1846,31 +1852,45 @@ __global__ __launch_bounds__(NT) void rbf_pivchol_kernel(double* __restrict__ F,
     for (int w = 1; w < NW; ++w)
       if (rv[w] > dp || (rv[w] == dp && ri[w] < piv)) { dp = rv[w]; piv = ri[w]; }
     if (!(dp > tol)) break;                                         // (uniform: every thread reads the same LDS values)
-    for (int m = tid; m < j; m += NT) frow[m] = Fk[(size_t)m * Tf + piv];
+    for (int m = tid; m < j; m += NTT) frow[m] = Fk[(size_t)m * Tf + piv];
     __syncthreads();
     const double rs = 1.0 / sqrt(dp);
-    for (int t = tid; t < T; t += NT) {
-      const double dt = (double)t * bin - (double)piv * bin;
-      double v = (1.0 - eps) * exp(-0.5 * ((dt * dt) / den));
-      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s5 = 0.0, s6 = 0.0, s7 = 0.0;
-      const double* col = Fk + t;
-      int m = 0;
+    for (int t0 = 0; t0 < T; t0 += NT) {                          // (uniform trip count: the barrier below is for every thread)
+      const int t = t0 + rt;
+      double part = 0.0;
+      if (t < T) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s5 = 0.0, s6 = 0.0, s7 = 0.0;
+        const double* col = Fk + t;
+        int m = 8 * grp;
 #pragma unroll 2
-      for (; m + 7 < j; m += 8) {
-        s0 += col[(size_t)m * Tf] * frow[m];
-        s1 += col[(size_t)(m + 1) * Tf] * frow[m + 1];
-        s2 += col[(size_t)(m + 2) * Tf] * frow[m + 2];
-        s3 += col[(size_t)(m + 3) * Tf] * frow[m + 3];
-        s4 += col[(size_t)(m + 4) * Tf] * frow[m + 4];
-        s5 += col[(size_t)(m + 5) * Tf] * frow[m + 5];
-        s6 += col[(size_t)(m + 6) * Tf] * frow[m + 6];
-        s7 += col[(size_t)(m + 7) * Tf] * frow[m + 7];
+        for (; m + 7 < j; m += 8 * NS) {
+          s0 += col[(size_t)m * Tf] * frow[m];
+          s1 += col[(size_t)(m + 1) * Tf] * frow[m + 1];
+          s2 += col[(size_t)(m + 2) * Tf] * frow[m + 2];
+          s3 += col[(size_t)(m + 3) * Tf] * frow[m + 3];
+          s4 += col[(size_t)(m + 4) * Tf] * frow[m + 4];
+          s5 += col[(size_t)(m + 5) * Tf] * frow[m + 5];
+          s6 += col[(size_t)(m + 6) * Tf] * frow[m + 6];
+          s7 += col[(size_t)(m + 7) * Tf] * frow[m + 7];
+        }
+        // the last, partly filled block of 8 columns belongs to the group whose turn it is
+        for (int mm = m; mm < j && mm < m + 8; ++mm) s0 += col[(size_t)mm * Tf] * frow[mm];
+        part = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
+        if (NS > 1 && grp > 0) psum[(size_t)(grp - 1) * T + t] = part;
       }
-      for (; m < j; ++m) s0 += col[(size_t)m * Tf] * frow[m];
-      v -= ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
-      v *= rs;
-      Fk[(size_t)j * Tf + t] = v;
-      d[t] = (t == piv) ? 0.0 : d[t] - v * v;
+      if (NS > 1) __syncthreads();
+      if (t < T && grp == 0) {
+        double tot = part;
+#pragma unroll
+        for (int g2 = 1; g2 < NS; ++g2) tot += psum[(size_t)(g2 - 1) * T + t];
+        const double dt = (double)t * bin - (double)piv * bin;
+        double v = (1.0 - eps) * exp(-0.5 * ((dt * dt) / den));
+        v -= tot;
+        v *= rs;
+        Fk[(size_t)j * Tf + t] = v;
+        d[t] = (t == piv) ? 0.0 : d[t] - v * v;
+      }
+      if (NS > 1 && t0 + NT < T) __syncthreads();                  // (psum is rewritten by the next trip)
     }
     __syncthreads();
   }

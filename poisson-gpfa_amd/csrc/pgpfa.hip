@@ -951,11 +951,11 @@ int build_kinv(pgpfa_ctx* c) {
 int build_lowrank(pgpfa_ctx* c) {
   const int p = c->p, T = c->T, Tp = c->Tp;
   const int rmax = std::min(T, Tp);
-  const size_t shm = ((size_t)T + rmax + 16) * sizeof(double) + 16 * sizeof(int);
+  const size_t shm = ((size_t)2 * T + rmax + 16) * sizeof(double) + 16 * sizeof(int);
   if (T > 256)
-    hipLaunchKernelGGL(rbf_pivchol_kernel<512>, dim3(p), dim3(512), shm, c->st, c->Flr, Tp, T, c->tau, c->bin, c->eps, c->lr_tol, rmax, c->d_rank);
+    hipLaunchKernelGGL((rbf_pivchol_kernel<512, 2>), dim3(p), dim3(1024), shm, c->st, c->Flr, Tp, T, c->tau, c->bin, c->eps, c->lr_tol, rmax, c->d_rank);
   else
-    hipLaunchKernelGGL(rbf_pivchol_kernel<256>, dim3(p), dim3(256), shm, c->st, c->Flr, Tp, T, c->tau, c->bin, c->eps, c->lr_tol, rmax, c->d_rank);
+    hipLaunchKernelGGL((rbf_pivchol_kernel<256, 1>), dim3(p), dim3(256), shm, c->st, c->Flr, Tp, T, c->tau, c->bin, c->eps, c->lr_tol, rmax, c->d_rank);
   HIPC(hipGetLastError());
   std::vector<int> r(p);
   HIPC(hipMemcpyAsync(r.data(), c->d_rank, sizeof(int) * p, hipMemcpyDeviceToHost, c->st));
