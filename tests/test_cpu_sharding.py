@@ -146,6 +146,15 @@ out['after_fail_sum'] = float(sess.allreduce(np.array([1.0]))[0])
 _, nll_again = inference.laplace(exp, dict(fit.optimParams), returnOptimRes=False)
 out['after_fail_nll'] = float(nll_again)
 if LIGHT:
+    # config 4's form in small: stochastic EM with the minibatch split over ALL ranks (8 ranks x 1 trial of a minibatch of 8)
+    np.random.seed(1)
+    n0 = len(sess.ctx.calls)
+    fit2 = engine.PPGPFAfit(exp, initParams={{k: v.copy() for k, v in init.items()}}, inferenceMethod='laplace', EMmode='Online', maxEMiter=2,
+                            batchSize=8, onlineParamUpdateMethod='diag', quiet=True)
+    out['online_estep_trials'] = [c[1] for c in sess.ctx.calls[n0:] if c[0] == 'estep'][:2]
+    out['online_nll'] = [float(v) for v in fit2.posteriorLikelihood]
+    out['online_C'] = np.asarray(fit2.optimParams['C']).tolist()
+    out['online_tau'] = np.asarray(fit2.optimParams['tau']).tolist()
     with open(os.environ['OUT'] + '.%d' % rank, 'w') as fh:
         json.dump(out, fh)
     if size > 1:
@@ -255,3 +264,12 @@ def test_eight_ranks_uneven_slices(tmp_path):
         assert many[r]['fail_message'] == many[0]['fail_message'] and 'trial 12 on rank 7' in many[r]['fail_message']
         assert many[r]['after_fail_sum'] == 8.0 and abs(many[r]['after_fail_nll'] - one['after_fail_nll']) <= 1e-6 * abs(one['after_fail_nll'])
         assert many[r]['after_fail_nll'] == many[0]['after_fail_nll']
+        # the minibatch of 8 split over the 8 ranks (config 4's form): one trial each, the reference's draw, the same parameters everywhere
+        assert abs(many[r]['online_nll'][0] - one['online_nll'][0]) <= 1e-11 * abs(one['online_nll'][0])
+        assert np.allclose(many[r]['online_C'], one['online_C'], rtol=0, atol=1e-3) and np.allclose(many[r]['online_tau'], one['online_tau'], rtol=1e-3, atol=0)
+        assert many[r]['online_C'] == many[0]['online_C'] and many[r]['online_tau'] == many[0]['online_tau']
+    for it in range(2):
+        whole = one['online_estep_trials'][it]
+        assert sum((many[r]['online_estep_trials'][it] for r in range(8)), []) == whole and all(len(many[r]['online_estep_trials'][it]) == 1 for r in range(8))
+    np.random.seed(1)
+    assert one['online_estep_trials'][0] == np.random.choice(13, 8, replace=False).tolist()
