@@ -55,8 +55,9 @@ int pgpfa_destroy(pgpfa_ctx* ctx);
  * 1e-13 makes the form exact to rounding at ~10 % more rank),
  * "keep_trial_vsmgp" (0: the low-rank engine accumulates sum_r post_vsmGP_r for the tau M-step and rebuilds
  * per-trial T x T blocks only when pgpfa_get_post_vsmgp asks for them; 1: store them in every E-step),
- * "dual_lowrank" (0; 1: the dual-variational entry points may use the low-rank engine when it pays - log det through
- * the r x r system - which evaluates the dual WITHOUT the reference's 1e-6 diagonal jitter, inference.py:190),
+ * "dual_lowrank" (1: the dual-variational entry points use the low-rank engine when it pays - log det through the r x r system; the
+ * reference's 1e-6 diagonal jitter, inference.py:190, is carried by the per-bin blocks, so both engines evaluate the reference's
+ * function; 0: always the dense engine),
  * "dual_f32" (0; 1: with dual_lowrank, the r x r system B = I + F^T Wt F, its factorisation, its inverse and the Yt product run in single
  * precision on the FP32 matrix cores, log det / covariance blocks / gradient accumulated in FP64: the mixed-precision form BASELINE
  * config 5 asks for; 2: the same with B assembled in FP64 and rounded once),
@@ -64,11 +65,23 @@ int pgpfa_destroy(pgpfa_ctx* ctx);
  * Hessian-vector product), "cd_mfma" (1: (C,d) sweep on the matrix cores, mstep.h), "vsm_mfma" (1: beyond 10 latents the per-bin
  * covariance blocks are Gram products on the matrix cores - post_vsm_mfma_kernel, model.h; 0: vector kernel),
  * "extrapolate_start" (1: a warm-started E-step begins at m + beta (m - m_prev) for trials whose two previous
- * E-steps are resident), "extrapolate_beta" (1.0). */
+ * E-steps are resident), "extrapolate_beta" (1.0),
+ * "pcg_retire" (1: every slot of the inner PCG has its own forcing term and leaves the iteration when it reaches it - device-side
+ * live list, pcg.h; 0: one common forcing term), "pcg_trace" (0; 1: one stderr line per inner solve),
+ * "time_newton" (0; 1: HIP events around the inner solves -> info "last_newton_solve_ms" / "last_newton_solve_bytes"),
+ * "small_tile_below" (2^30: products with fewer 128 x 128 tiles than this run on 64 x 64 workgroup tiles - i.e. all; 0: never),
+ * "splitk_below64" (160: products on 64 x 64 tiles are cut along k only below this many tiles),
+ * "split_cov" (1: the sum over trials of the T x T covariance blocks by the exact split form of csrc/split.h - FP64 cross term, FP16
+ * two-half product for the second-order term - while the root mean square of eps ||Wt_t|| stays below "split_max_norm" (0.07);
+ * 0: always the full-width FP64 product), "measure_mix" (0; 1: record eps ||Wt_t|| -> info "last_eps_wt_norm" / "last_eps_wt_rms"),
+ * "workspace_headroom" (2.0: a low-rank workspace plan leaves room for the ranks to grow by this factor before it is re-made),
+ * "workspace_vmm" (1: the chunk workspace is a reserved address range that grows by mapping memory; 0: plain allocations; before
+ * the first E-step), "workspace_granule_mb" (1024: size of the mapped chunks). */
 int pgpfa_set_option(pgpfa_ctx* ctx, const char* key, double value);
 /* Info: "chunk_trials", "plan_lowrank", "n_pad", "lowrank_rtot", "last_estep_ms", "last_newton_factorizations",
  * "last_newton_solves", "last_pcg_iterations", "last_shared_factorizations", "last_cov_lowrank",
- * "last_dense_retries", "hbm_bytes_allocated", "n_trials_global", "prof_<tag>_{ms,flops,launches}". */
+ * "last_dense_retries", "hbm_bytes_allocated", "n_trials_global", "prof_<tag>_{ms,flops,launches}", "counts_two_bytes",
+ * "arena_bytes", "last_split_cov", "last_eps_wt_norm", "last_eps_wt_rms", "last_newton_solve_ms", "last_newton_solve_bytes". */
 int pgpfa_get_info(pgpfa_ctx* ctx, const char* key, double* value);
 
 /* ---- data ---------------------------------------------------------------------- */
