@@ -27,7 +27,7 @@ constexpr float SPLIT_SCALE = 2048.0f;          // |D| <= sqrt(p) (rows of Yt ha
 // (column stride ldd floats, latent stride ts) - half the bytes of the in-place FP64 mix.
 // grid = (ceil(T/64), nslots), block = 256, p <= PW <= 16.
 template <int PW>
-__global__ __launch_bounds__(256) void mix_vsm_split_kernel(const double* __restrict__ Yt, long long sY, int ldy, float* __restrict__ D, long long sD,
+__global__ __launch_bounds__(256, 2) void mix_vsm_split_kernel(const double* __restrict__ Yt, long long sY, int ldy, float* __restrict__ D, long long sD,
                                                             int ldd, const double* __restrict__ G, long long sG, int T, int p, int rpad, double eps,
                                                             double* __restrict__ vsm, const int* __restrict__ slots,
                                                             const int* __restrict__ trial_of_slot, const int* __restrict__ roff, int col_tile, int ts) {
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void mix_vsm_split_kernel(const double* __rest
       for (int k = 0; k < PW; ++k) {
         double s2 = 0.0;
 #pragma unroll
-        for (int kk = 0; kk < PW; ++kk) s2 += g[k * PW + kk] * v[kk];
+        for (int kk = 0; kk < PW; ++kk) s2 += g[(k >= kk) ? k * PW + kk : kk * PW + k] * v[kk];     // (G_t is symmetric: 55 values to keep, not 100)
         m[k] = s2;
         if (k < p) d[(size_t)b * ldd + (size_t)k * ts] = (float)(v[k] - s2);
       }
