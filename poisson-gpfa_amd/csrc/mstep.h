@@ -364,6 +364,316 @@ __global__ __launch_bounds__(512) void mstep_cd_mfma_kernel(CdArgs a, int tiles_
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// (C,d) Newton pass on the matrix cores: per neuron cost, gradient and the packed (p+1) x (p+1) Hessian
+//   H_n = sum_t yhat_nt ( [w; 1][w; 1]^T + [V_t 0; 0 0] ),  w = m_t + V_t c_n,  yhat = exp(d_n + c_n.m_t + c_n^T V_t c_n / 2)
+// in two matrix-core stages per (16 neurons = one wave) x (4 bins):
+//   1. per bin, V_t c_n for the 16 neurons as one 16 x 16 x p product (A = V_t read through its packed pairs, B = the loadings):
+//      D[i][n] = (V_t c_n)_i.  The four bins' chains are independent and issued interleaved.  The exponent is a sum over components, i.e.
+//      over registers and over the 4 lanes that share a neuron: the four bins' partial sums are transposed-and-reduced across those lanes
+//      with three row swaps (v_permlane16_swap / v_permlane32_swap: lane (neuron, l4) ends up with the sum of bin l4), so ONE exp and one
+//      sqrt serve the four bins, and sqrt(yhat) goes back to the four lanes with three more swaps;  u = sqrt(yhat) [w; 1].
+//   2. per neuron, H_n += sum over the 4 bins of u u^T on v_mfma_f64_4x4x4_4b: four independent 4 x 4 x 4 products per instruction
+//      (19 cycles against 68 for the 16 x 16 x 4 shape, measured: tools/probes/mfma_4x4x4_probe.hip), operand lane (k = lane >> 4,
+//      block = (lane >> 2) & 3, row = lane & 3) for A and B alike, result lane (row = lane >> 4, block, column = lane & 3).  The four blocks of
+//      an instruction are four neurons, the instruction index runs over the lower 4 x 4 block pairs (I >= J) of the Hessian: its A and B
+//      operands are the SAME three registers per neuron quad (rows 4I..4I+3 of u over the 4 bins), 24 instructions and 24 accumulator
+//      registers per 16 neurons where the 16 x 16 x 4 shape took 16 instructions of four times the length and 64 registers.  The hand-over
+//      from stage 1 (lane = neuron, registers = components) goes through a wave-private LDS tile [4 bins][16 components][16 neurons]
+//      (component stride 20, bin stride 336 doubles: writes and reads are conflict-free);
+//   and sum_t yhat V_t as 4 more 16 x 16 x 4 MFMAs per 4 bins (A = the pair columns of the staged tile, B = yhat: as in mstep_cd_mfma_kernel).
+// Staging, launch shape and the hoisted count terms are those of mstep_cd_mfma_kernel; part layout of mstep_cd_hess_kernel:
+// [NH][q], NH = 1 + (p+1) + (p+1)(p+2)/2: cost | gradient | packed lower Hessian - WITHOUT the count terms (cd_hess_add_ym_kernel).
+// PW <= 10 (p + 1 <= 12 components: three 4-row blocks).
+constexpr int CDH_NW = 8;
+template <int PW>
+struct CdH {
+  static constexpr int KSJ = (PW + 3) / 4;                          // k steps of stage 1
+  static constexpr int NBK = (PW + 1 + 3) / 4;                      // 4-row blocks of the (p+1)-dim Hessian
+  static constexpr int NPB = NBK * (NBK + 1) / 2;                   // lower block pairs = instructions per neuron quad
+  static constexpr int NHH = (PW + 1) * (PW + 2) / 2;               // packed Hessian entries (template width)
+  static constexpr int CS = 20, BS = 16 * CS + 16;                  // component / bin stride of the wave tile (doubles; BS = 16 mod 32)
+  static constexpr int UW = (4 * BS > 16 * NHH) ? 4 * BS : 16 * NHH;   // doubles of the wave-private tile (also the epilogue's scratch)
+  static constexpr int SH = CdM<PW>::S + 2;                         // row stride of the staged Phi tile: two gap columns that stay zero
+  static constexpr int ZC = CdM<PW>::NC;                            // the first of them
+  static constexpr int BT = 32;                                     // bins per staged tile (the next tile waits in 5 registers per thread, not 9)
+  static constexpr int LDS_DOUBLES = BT * SH + 32;                  // one stage
+};
+
+typedef unsigned cdh_u2 __attribute__((ext_vector_type(2)));
+// rows = the four 16-lane groups of a wave.  swap16: (a, b) <- a keeps its even rows and takes b's even rows into its odd rows, b takes a's odd rows into
+// its even rows and keeps its odd rows;  swap32: a <- [a.lo, b.lo], b <- [a.hi, b.hi] over the 32-lane halves.
+__device__ __forceinline__ void cdh_swap16(double& a, double& b) {
+  const cdh_u2 r0 = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const cdh_u2 r1 = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  a = __hiloint2double((int)r1[0], (int)r0[0]); b = __hiloint2double((int)r1[1], (int)r0[1]);
+}
+__device__ __forceinline__ void cdh_swap32(double& a, double& b) {
+  const cdh_u2 r0 = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const cdh_u2 r1 = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  a = __hiloint2double((int)r1[0], (int)r0[0]); b = __hiloint2double((int)r1[1], (int)r0[1]);
+}
+
+template <int PW>
+__global__ __launch_bounds__(64 * CDH_NW) void mstep_cd_hess_mfma_kernel(CdArgs a, int tiles_per_group) {
+  using M = CdM<PW>;
+  using H = CdH<PW>;
+  constexpr int NP = M::NP, NC = M::NC, S = H::SH, ZC = H::ZC, BT = H::BT, KSJ = H::KSJ, NBK = H::NBK, NPB = H::NPB, NHH = H::NHH, UW = H::UW, CS = H::CS, BS = H::BS;
+  constexpr int MAXPF = (BT * NC + 64 * CDH_NW - 1) / (64 * CDH_NW);
+  constexpr int NTP = (NP + 15) / 16;                               // row tiles of the pair product
+  extern __shared__ double lds[];                                   // Phi tile [2][BT][S] (+ slack) | wave tiles [CDH_NW][UW]
+  const int lane = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  const int l15 = lane & 15, l4 = lane >> 4, x4 = lane & 3, blk = (lane >> 2) & 3;
+  const int nthreads = 64 * blockDim.y, tid = wave * 64 + lane;
+  const int p = a.p, q = a.q, T = a.T, pp = p * p;
+  const int n0 = (blockIdx.x * tiles_per_group + wave) * 16;
+  const bool active_wave = wave < tiles_per_group && n0 < q;        // other waves only help staging
+  const int n = n0 + l15;
+  const bool live = active_wave && n < q;
+  const int nc = (n < q) ? n : q - 1;
+  double* Ub = lds + 2 * H::LDS_DOUBLES + (size_t)wave * UW;
+
+  // loadings of this lane's neuron: cq[r] = c_n[4 r + l4] - the B fragments of stage 1 (k = latent) and the weights of the exponent
+  double cq[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) cq[r] = (4 * r + l4 < p) ? a.vec[(size_t)(4 * r + l4) * q + nc] : 0.0;
+  const double dn = a.vec[(size_t)p * q + nc];
+  // stage-1 A fragments: V_t[i = l15][j = 4 kk + l4] sits in the pair column max(i,j)(max(i,j)+1)/2 + min(i,j) of the staged row
+  // (entries outside the p x p block read a gap column of the staged row, which is zero: no selects, no branches in the loop)
+  int poff[KSJ];
+#pragma unroll
+  for (int kk = 0; kk < KSJ; ++kk) {
+    const int i = l15, j = 4 * kk + l4;
+    const int hi = i > j ? i : j, lo = i > j ? j : i;
+    poff[kk] = (i < p && j < p) ? hi * (hi + 1) / 2 + lo : ZC;
+  }
+  // what is added to (V_t c_n)_i for this lane's components i = 4 r + l4: the mean (i < p), the column of ones (i = p: the offset's
+  // component of [w; 1]), the zero column beyond - [w; 1; 0..] comes out of one addition
+  int moff[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = 4 * r + l4;
+    moff[r] = (i < p) ? NP + i : (i == p ? NP + PW : ZC);
+  }
+  int pcol[NTP];                                                    // pair columns of the last product's A fragments (past the pairs: zero column)
+#pragma unroll
+  for (int tl = 0; tl < NTP; ++tl) pcol[tl] = (16 * tl + l15 < NP) ? 16 * tl + l15 : ZC;
+  // per-thread staging plan (as mstep_cd_mfma_kernel)
+  int soff[MAXPF], loff[MAXPF];
+#pragma unroll
+  for (int i = 0; i < MAXPF; ++i) {
+    const int e = tid + i * nthreads;
+    soff[i] = -3; loff[i] = 0;
+    if (e < BT * NC) {
+      const int t = e / NC, col = e - t * NC;
+      loff[i] = t * S + col;
+      if (col < NP) {
+        int pa = 0;
+        while ((pa + 1) * (pa + 2) / 2 <= col) ++pa;
+        const int pb = col - pa * (pa + 1) / 2;
+        soff[i] = (pa < p) ? (t * pp + pa * p + pb) : -2;
+      } else if (col < NP + PW) {
+        const int k = col - NP;
+        soff[i] = (k < p) ? -(16 + k * 64 + t) : -2;
+      } else {
+        soff[i] = -1;
+      }
+    }
+  }
+  double acc[4][NPB];
+  mdouble4 pacc[NTP];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NPB; ++j) acc[i][j] = 0.0;
+#pragma unroll
+  for (int i = 0; i < NTP; ++i) pacc[i] = mdouble4{0.0, 0.0, 0.0, 0.0};
+
+  const int ntt = (T + BT - 1) / BT;
+  const int nitems = a.ntr * ntt;
+  double pf[MAXPF];
+  auto prefetch = [&](int itrial, int itile) {
+    const size_t r = a.trials[itrial];
+    const int t0 = itile * BT;
+    const int tn = (T - t0 < BT) ? T - t0 : BT;
+    const double* vsm = a.vsm + (r * T + t0) * pp;
+    const double* mean = a.mean + r * p * T + t0;
+    double raw[MAXPF];
+    bool ok[MAXPF];
+#pragma unroll
+    for (int i = 0; i < MAXPF; ++i) {
+      const int s = soff[i];
+      const int kt = -s - 16, k = kt >> 6, t = kt & 63;
+      const bool is_v = s >= 0, is_m = s <= -16;
+      ok[i] = is_v ? (s < tn * pp) : (is_m && t < tn);
+      const double* src = is_v ? vsm : mean;
+      const long long off = is_v ? (long long)s : (long long)k * T + t;
+      raw[i] = src[ok[i] ? off : 0];
+    }
+#pragma unroll
+    for (int i = 0; i < MAXPF; ++i) pf[i] = ok[i] ? raw[i] : (soff[i] == -1 ? 1.0 : 0.0);
+  };
+  for (int e = tid; e < 2 * H::LDS_DOUBLES; e += nthreads) lds[e] = 0.0;
+  const int step_tr = gridDim.y / ntt, step_ti = gridDim.y % ntt;
+  int item = blockIdx.y;
+  int c_tr = item / ntt, c_ti = item % ntt;
+  if (item < nitems) prefetch(c_tr, c_ti);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < MAXPF; ++i)
+    if (soff[i] != -3) lds[loff[i]] = pf[i];
+  __syncthreads();
+  int cur = 0;
+  for (; item < nitems; item += gridDim.y) {
+    const int t0 = c_ti * BT;
+    const int tn = (T - t0 < BT) ? T - t0 : BT;
+    const bool more = item + (int)gridDim.y < nitems;
+    c_tr += step_tr; c_ti += step_ti;
+    if (c_ti >= ntt) { c_ti -= ntt; c_tr += 1; }
+    if (more) prefetch(c_tr, c_ti);
+    const double* st = lds + cur * H::LDS_DOUBLES;
+    if (active_wave) {
+      for (int tb0 = 0; tb0 < tn; tb0 += 4) {
+        // stage 1: h[b][r] = (V_t c_n)_{4 r + l4} for the bins b = tb0 .. tb0 + 3 (rows past tn are zero-filled stage rows: yhat is masked below)
+        mdouble4 h[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) h[b] = mdouble4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < KSJ; ++kk)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            h[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(st[(size_t)(tb0 + b) * S + poff[kk]], cq[kk], h[b], 0, 0, 0);
+          }
+        double wv[4][4], sb[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          double s = 0.0;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const double mi = st[(size_t)(tb0 + b) * S + moff[r]];
+            wv[b][r] = h[b][r] + mi;
+            s += cq[r] * (0.5 * h[b][r] + mi);
+          }
+          sb[b] = s;
+        }
+        // lane (neuron, l4) <- the exponent of bin tb0 + l4
+        cdh_swap16(sb[0], sb[1]);
+        cdh_swap16(sb[2], sb[3]);
+        double t01 = sb[0] + sb[1], t23 = sb[2] + sb[3];
+        cdh_swap32(t01, t23);
+        const bool on = live && tb0 + l4 < tn;
+        const double yh = exp(on ? dn + (t01 + t23) : -1000.0);      // (exp(-1000) = 0: masked bins and neurons drop out of every sum)
+        const double sq = sqrt(yh);
+        double sqb[4];
+        sqb[0] = sq; sqb[1] = sq;
+        cdh_swap16(sqb[0], sqb[1]);
+        sqb[2] = sqb[0]; sqb[3] = sqb[1];
+        cdh_swap32(sqb[0], sqb[2]);
+        cdh_swap32(sqb[1], sqb[3]);                                  // sqb[b] = sqrt(yhat) of bin tb0 + b
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Ub[b * BS + (4 * r + l4) * CS + l15] = sqb[b] * wv[b][r];
+        asm volatile("" ::: "memory");                               // (LDS operations of a wave execute in order: only the compiler must keep it)
+        // stage 2: per neuron quad, the lower block pairs of sum over the 4 bins of u u^T
+#pragma unroll
+        for (int mm = 0; mm < 4; ++mm) {
+          double v[NBK];
+#pragma unroll
+          for (int I = 0; I < NBK; ++I) v[I] = Ub[l4 * BS + (4 * I + x4) * CS + 4 * mm + blk];
+          int pr = 0;
+#pragma unroll
+          for (int I = 0; I < NBK; ++I)
+#pragma unroll
+            for (int J = 0; J <= I; ++J) {
+              acc[mm][pr] = __builtin_amdgcn_mfma_f64_4x4x4f64(v[I], v[J], acc[mm][pr], 0, 0, 0);
+              ++pr;
+            }
+        }
+        // sum_t yhat V_t: A = pair columns of the 4 bins, B = yhat of bin tb0 + l4 (this lane's own)
+        const double* prow = st + (size_t)(tb0 + l4) * S;
+#pragma unroll
+        for (int tl = 0; tl < NTP; ++tl) pacc[tl] = __builtin_amdgcn_mfma_f64_16x16x4f64(prow[pcol[tl]], yh, pacc[tl], 0, 0, 0);
+        asm volatile("" ::: "memory");                               // the tile is rewritten by the next group of bins
+      }
+    }
+    if (more) {
+      double* nx = lds + (cur ^ 1) * H::LDS_DOUBLES;
+#pragma unroll
+      for (int i = 0; i < MAXPF; ++i)
+        if (soff[i] != -3) nx[loff[i]] = pf[i];
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  // epilogue: per neuron the packed lower Hessian in the wave's tile, Hs[nn][idx(i,j)], idx = i(i+1)/2 + j over components 0..p
+  // (component p = the offset d): first the u u^T sums (lane (l4, blk, x4) of pair (I, J) of quad mm = entry (4I + l4, 4J + x4) of neuron
+  // 4 mm + blk), then the pair sums (lane = neuron)
+  if (active_wave) {
+    double* Hs = Ub;
+    for (int e = lane; e < 16 * NHH; e += 64) Hs[e] = 0.0;
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int mm = 0; mm < 4; ++mm) {
+      int pr = 0;
+#pragma unroll
+      for (int I = 0; I < NBK; ++I)
+#pragma unroll
+        for (int J = 0; J <= I; ++J) {
+          const int i = 4 * I + l4, j = 4 * J + x4, nn = 4 * mm + blk;
+          if (i <= p && j <= i) Hs[nn * NHH + i * (i + 1) / 2 + j] = acc[mm][pr];
+          ++pr;
+        }
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int tl = 0; tl < NTP; ++tl)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int pr = 16 * tl + 4 * r + l4;
+        if (pr < NP) {
+          int pa = 0;
+          while ((pa + 1) * (pa + 2) / 2 <= pr) ++pa;
+          if (pa < p) Hs[l15 * NHH + pr] += pacc[tl][r];            // (pair index = packed index: both are pa(pa+1)/2 + pb)
+        }
+      }
+    asm volatile("" ::: "memory");
+    const int D = p + 1, nha = D * (D + 1) / 2;
+    double* part = a.part + (size_t)blockIdx.y * (1 + D + nha) * q;
+    for (int e = lane; e < 16 * nha; e += 64) {
+      const int nn = e & 15, idx = e >> 4;
+      if (n0 + nn < q) part[(size_t)(1 + D + idx) * q + n0 + nn] = Hs[nn * NHH + idx];
+    }
+    // gradient rows: sum yhat w_i = H[p][i], sum yhat = H[p][p]; cost row: -sum yhat  (count terms: cd_hess_add_ym_kernel)
+    for (int e = lane; e < 16 * (D + 1); e += 64) {
+      const int nn = e & 15, i = e >> 4;                             // i = 0: cost, 1..D: gradient component i - 1
+      if (n0 + nn < q) {
+        const double syh = Hs[nn * NHH + p * (p + 1) / 2 + p];
+        part[(size_t)i * q + n0 + nn] = (i == 0) ? -syh : Hs[nn * NHH + p * (p + 1) / 2 + (i - 1)];
+      }
+    }
+  }
+}
+
+template <int PW>
+constexpr size_t cd_hess_mfma_lds_bytes() { return (2 * (size_t)CdH<PW>::LDS_DOUBLES + CDH_NW * (size_t)CdH<PW>::UW) * sizeof(double); }
+
+// count terms of the Newton pass: sums [NH][q] as reduced from mstep_cd_hess_mfma_kernel;  row 0 += c_n.YM_n + d_n YS_n,
+// gradient rows -= YM / YS  (the part layout of mstep_cd_hess_kernel: cost = sum (y hh - yhat), grad = -(sum y m - yhat w), -(sum y - yhat))
+__global__ void cd_hess_add_ym_kernel(double* __restrict__ sums, const double* __restrict__ ym, const double* __restrict__ vec, int q, int p) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= q) return;
+  double lin = vec[(size_t)p * q + n] * ym[(size_t)p * q + n];
+  for (int k = 0; k < p; ++k) {
+    const double v = ym[(size_t)k * q + n];
+    sums[(size_t)(1 + k) * q + n] -= v;
+    lin += vec[(size_t)k * q + n] * v;
+  }
+  sums[(size_t)(1 + p) * q + n] -= ym[(size_t)p * q + n];
+  sums[(size_t)n] += lin;
+}
+
 template <int PW>
 constexpr size_t cd_mfma_lds_bytes() { return 2 * (size_t)CdM<PW>::LDS_DOUBLES * sizeof(double); }
 

@@ -117,7 +117,7 @@ struct pgpfa_ctx {
   // square of the rms, 0.07 keeps 1e-9 with a factor two to spare
   double split_max_norm = 0.07;
   double *cdym = nullptr, *cdym_part = nullptr;   // count terms of the (C,d) cost: sum_t y m_t, sum_t y per neuron (per E-step)
-  bool cdym_valid = false, cd_mfma = true; int cd_debug = 0;
+  bool cdym_valid = false, cd_mfma = true, cd_hess_mfma = true; int cd_debug = 0;
   bool cd_hess_valid = false; int cd_hess_ntr = 0;   // per-neuron Hessian sums of the last Newton pass are resident
   std::vector<double> logdetK;                  // log det of the p Gram matrices (from the factor in build_kinv)
   bool dual_lowrank = true;                     // dual-variational entry points use the low-rank engine when it pays (want_lowrank)
@@ -1189,6 +1189,7 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
   else if (k == "newton_max_iter") c->max_iter = (int)v;
   else if (k == "use_mfma") c->mfma = (v != 0.0);
   else if (k == "cd_mfma") c->cd_mfma = (v != 0.0);
+  else if (k == "cd_hess_mfma") c->cd_hess_mfma = (v != 0.0);
   else if (k == "cd_debug") c->cd_debug = (int)v;
   else if (k == "pcg_fused") c->pcg_fused = (int)v;
   else if (k == "pcg_w32") c->pcg_w32 = (v != 0.0);
@@ -2934,6 +2935,18 @@ int pgpfa_set_posterior(pgpfa_ctx* c, int n, const int32_t* idx, const double* p
 // One (C,d) cost / gradient sweep over the trials of the last E-step at the parameters in c->vec: c->cdout <- per-neuron sums
 // [(p+2)][q] (rows 0..p-1: sum (y - yhat) m - yhat V c, row p: sum (y - yhat), row p+1: sum (y hh - yhat)).  Matrix-core kernel
 // up to 20 latents (mstep.h), the vector kernel beyond that or with option cd_mfma = 0.
+// count terms of the (C,d) cost, linear in (c_n, d_n): c->cdym[(p+1)][q] = sum_t y m_t | sum_t y over the trials of the last E-step
+static int ensure_cdym(pgpfa_ctx* c) {
+  if (c->cdym_valid) return 0;
+  const int q = c->q, p = c->p, ntr = (int)c->last_trials_h.size();
+  const int nbk = std::max(1, std::min(1024, ntr));
+  hipLaunchKernelGGL(cd_ym_kernel, dim3(nbk), dim3(256), 0, c->st, c->Y, c->Yhi, c->Xmode, c->last_trials, ntr, q, p, c->T, c->cdym_part);
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3(((p + 1) * q + 31) / 32), dim3(256), 0, c->st, c->cdym_part, nbk, (p + 1) * q, c->cdym);
+  HIPC(hipGetLastError());
+  c->cdym_valid = true;
+  return 0;
+}
+
 static int cd_sweep(pgpfa_ctx* c) {
   const int q = c->q, p = c->p, T = c->T;
   const int len = (p + 2) * q;
@@ -2943,14 +2956,7 @@ static int cd_sweep(pgpfa_ctx* c) {
   a.part = c->cdpart; a.q = q; a.p = p; a.T = T; a.dbg = c->cd_debug;
   const double flops = (double)a.ntr * q * T * (2.0 * p * p + 8.0 * p);
   if (c->mfma && c->cd_mfma && p <= 10) {
-    if (!c->cdym_valid) {
-      const int nbk = std::max(1, std::min(1024, a.ntr));
-      hipLaunchKernelGGL(cd_ym_kernel, dim3(nbk), dim3(256), 0, c->st, c->Y, c->Yhi, c->Xmode, c->last_trials, a.ntr, q, p, T,
-                         c->cdym_part);
-      hipLaunchKernelGGL(reduce_parts_kernel, dim3(((p + 1) * q + 31) / 32), dim3(256), 0, c->st, c->cdym_part, nbk, (p + 1) * q, c->cdym);
-      HIPC(hipGetLastError());
-      c->cdym_valid = true;
-    }
+    CHK(ensure_cdym(c));
     int nby = 1;
     prof_begin(c, TAG_CD, flops);
     dispatch_pw(p, [&](auto pw) {
@@ -3033,11 +3039,28 @@ int pgpfa_mstep_cd_newton_pass(pgpfa_ctx* c, const double* vecCd, const double* 
   CdArgs a{};
   a.Y = c->Y; a.Yhi = c->Yhi; a.mean = c->Xmode; a.vsm = c->vsm; a.vec = c->vec;
   a.trials = c->last_trials; a.ntr = (int)c->last_trials_h.size();
-  a.part = c->cdhpart; a.q = q; a.p = p; a.T = T;
-  const int nby = std::max(1, std::min(a.ntr * 4, 128));
+  a.part = c->cdhpart; a.q = q; a.p = p; a.T = T; a.dbg = c->cd_debug;
+  int nby = std::max(1, std::min(a.ntr * 4, 128));
+  const bool on_mfma = c->mfma && c->cd_mfma && c->cd_hess_mfma && p <= 10;     // two-stage matrix-core form (mstep.h)
+  if (on_mfma) CHK(ensure_cdym(c));
   prof_begin(c, TAG_CD, (double)a.ntr * q * T * (3.0 * p * p + 12.0 * p));
   dispatch_pw(p, [&](auto pw) {
     constexpr int PW = decltype(pw)::value;
+    if constexpr (PW <= 10) {
+      if (on_mfma) {
+        const int ntt = (T + CdH<PW>::BT - 1) / CdH<PW>::BT;
+        const int tiles = (q + 15) / 16, groups = (tiles + CDH_NW - 1) / CDH_NW, tpg = (tiles + groups - 1) / groups;
+        nby = std::max(1, std::min(a.ntr * ntt, std::min(128, std::max(64, 512 / groups))));
+        static bool attr_set = false;
+        if (!attr_set) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mstep_cd_hess_mfma_kernel<PW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)cd_hess_mfma_lds_bytes<PW>());
+          attr_set = true;
+        }
+        hipLaunchKernelGGL(mstep_cd_hess_mfma_kernel<PW>, dim3(groups, nby), dim3(64, CDH_NW), cd_hess_mfma_lds_bytes<PW>(), c->st, a, tpg);
+        return;
+      }
+    }
     if constexpr (PW <= 12) {
       hipLaunchKernelGGL(mstep_cd_hess_kernel<PW>, dim3((q + 63) / 64, nby), dim3(64, CDH_KY), 0, c->st, a);
     } else {
@@ -3047,6 +3070,7 @@ int pgpfa_mstep_cd_newton_pass(pgpfa_ctx* c, const double* vecCd, const double* 
   });
   prof_end(c);
   hipLaunchKernelGGL(reduce_parts_kernel, dim3((NH * q + 31) / 32), dim3(256), 0, c->st, c->cdhpart, nby, NH * q, c->cdhout);
+  if (on_mfma) hipLaunchKernelGGL(cd_hess_add_ym_kernel, dim3((q + 127) / 128), dim3(128), 0, c->st, c->cdhout, c->cdym, c->vec, q, p);
   HIPC(hipGetLastError());
   const double cnt = (double)a.ntr;
   HIPC(hipMemcpyAsync(c->cdhout + (size_t)NH * q, &cnt, sizeof(double), hipMemcpyHostToDevice, c->st));

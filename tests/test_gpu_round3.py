@@ -397,3 +397,54 @@ def test_split_accumulation_matches_the_fp64_product(c1, dims):
     if dims != 'c1':
         # rates high enough for the guard (rms of eps ||Wt|| above 0.07) to keep the FP64 product by itself
         assert out['very_loud'][3] > 0.07 and out['very_loud'][2] == 0.0 and np.all(np.isfinite(out['very_loud'][0]))
+
+
+@pytest.mark.parametrize('q,p,T,R', [(30, 3, 100, 4), (200, 10, 77, 3), (37, 7, 130, 2), (17, 1, 5, 2), (129, 10, 64, 2)])
+def test_cd_newton_pass_matrix_core_form(q, p, T, R):
+    """The two-stage matrix-core Newton pass of the (C,d) M-step (mstep_cd_hess_mfma_kernel) against the vector kernel on the same
+    posterior and against plain numpy: per-neuron costs 1e-11, Newton step H_n^-1 g_n and decrement g_n^T H_n^-1 g_n 1e-9 (they involve
+    every entry of the gradient and of the packed Hessian of learning.py:20-91's cost, restated below per neuron)."""
+    from funs import _hip
+    _, Ys, _ = orc.synth_dataset(q, p, T, R, seed=7 * q + T, dOffset=0.0)
+    Y = np.stack(Ys).astype(np.uint8)
+    rng = np.random.default_rng(q + T)
+    par = {'C': 0.3 * rng.standard_normal((q, p)) / np.sqrt(p), 'd': np.log(Y.mean(axis=(0, 2)) + 0.1), 'tau': 0.05 + 0.2 * rng.random(p)}
+    ctx = _hip.Context(q, p, T, R, 10.0)
+    try:
+        ctx.upload_counts(Y)
+        ctx.set_params(par['C'], par['d'], par['tau'])
+        _, _, status = ctx.estep_laplace()
+        assert np.all(status == 0)
+        pm, vs = ctx.post_mean(), ctx.post_vsm()
+        v = orc.cd_to_vec(par['C'], par['d']) + 0.01 * rng.standard_normal(q * (p + 1))
+        out = {}
+        for form in (1, 0):
+            ctx.set_option('cd_hess_mfma', form)
+            out[form] = ctx.mstep_cd_newton_pass(v)
+        for a, b in zip(out[1], out[0]):
+            assert rel(a, b) <= 1e-10
+        # plain numpy: theta_n = (c_n, d_n), w = m_t + V_t c_n, yhat = exp(d_n + c_n.m_t + c_n^T V_t c_n / 2)
+        vv = v.reshape(p + 1, q)
+        Cn, dn = vv[:p].T, vv[p]
+        cost_ref, delta_ref, dec_ref = np.zeros(q), np.zeros((p + 1, q)), np.zeros(q)
+        for n in range(q):
+            g, H, cst = np.zeros(p + 1), np.zeros((p + 1, p + 1)), 0.0
+            for r in range(R):
+                m = pm[r].reshape(p, T)
+                Vc = vs[r] @ Cn[n]                                   # [T][p]
+                w1 = np.concatenate([m.T + Vc, np.ones((T, 1))], axis=1)
+                hh = dn[n] + Cn[n] @ m
+                yh = np.exp(hh + 0.5 * Vc @ Cn[n])
+                y = Ys[r][n].astype(float)
+                cst += np.sum(y * hh - yh)
+                g += yh @ w1 - np.concatenate([m @ y, [y.sum()]])
+                H += (w1 * yh[:, None]).T @ w1
+                H[:p, :p] += np.einsum('t,tij->ij', yh, vs[r])
+            cost_ref[n] = -cst / R
+            delta_ref[:, n] = -np.linalg.solve(H / R, g / R)
+            dec_ref[n] = (g / R) @ np.linalg.solve(H / R, g / R)
+        cost_n, delta, dec = out[1]
+        assert rel(cost_n, cost_ref) <= 1e-11
+        assert rel(delta.reshape(p + 1, q), delta_ref) <= 1e-9 and rel(dec, dec_ref) <= 1e-9
+    finally:
+        ctx.close()

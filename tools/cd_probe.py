@@ -27,3 +27,17 @@ for mode, dbg in (('vector kernel', -1), ('mfma', 0), ('no exp', 1), ('no 2nd pr
     if ref is None:
         ref = (c0, g0)
     print('%-16s %.3f ms  cost %.12g  max|dgrad| vs vector %.2e' % (mode, dt * 1e3, c0, np.max(np.abs(g0 - ref[1]))), flush=True)
+# the Newton pass (cost + gradient + per-neuron Hessians): two-stage matrix-core form against the vector kernel
+ctx.set_option('cd_mfma', 1); ctx.set_option('cd_debug', 0)
+refn = None
+for name, form, dbg in (('hess vector', 0, 0), ('hess mfma', 1, 0)):
+    ctx.set_option('cd_hess_mfma', form)
+    ctx.set_option('cd_debug', dbg)
+    out = ctx.mstep_cd_newton_pass(v)
+    t0 = time.time()
+    for _ in range(10):
+        ctx.mstep_cd_newton_pass(v)
+    dt = (time.time() - t0) / 10
+    if refn is None:
+        refn = out
+    print('%-16s %.3f ms  sum cost_n %.12g  max|ddelta| vs vector %.2e  max|ddec| %.2e' % (name, dt * 1e3, out[0].sum(), np.max(np.abs(out[1] - refn[1])), np.max(np.abs(out[2] - refn[2]))), flush=True)
