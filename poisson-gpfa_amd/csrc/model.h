@@ -1316,16 +1316,22 @@ __global__ __launch_bounds__(64 * CDH_KY) void mstep_cd_hess_rows_kernel(CdArgs 
 // per-neuron Newton step: solve H delta = -g (dimension p+1, Cholesky with a tiny ridge), one thread per neuron.
 // sums: [NH][q] as emitted above (not yet divided by R); prior: + inv_s2*(theta - center) on the gradient and
 // + inv_s2 on the Hessian diagonal.  Writes delta[(p+1)][q] (vecCd layout) and dec[q] = -g.delta.
-__global__ void cd_newton_step_kernel(const double* __restrict__ sums, int q, int p, double invR, const double* __restrict__ vec,
-                                      const double* __restrict__ center, double inv_s2, double* __restrict__ delta,
-                                      double* __restrict__ dec) {
+// rtot: device address of the (all-reduced) trial count R, read here so that the host need not fetch it before the launch;
+// pack[q (p+3) + 1] = [row 0 of sums (per-neuron cost sums) | delta | dec | R]: everything the host reads back, one copy.
+__global__ void cd_newton_step_kernel(const double* __restrict__ sums, int q, int p, const double* __restrict__ rtot, const double* __restrict__ vec,
+                                      const double* __restrict__ center, double inv_s2, double* __restrict__ pack) {
   extern __shared__ double sm[];
   const int D = p + 1;
   double* A = sm + (size_t)threadIdx.x * (D * D + 2 * D);
   double* g = A + D * D;
   double* x = g + D;
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const double invR = 1.0 / rtot[0];
+  double* delta = pack + q;
+  double* dec = pack + (size_t)q * (D + 1);
+  if (n == 0) pack[(size_t)q * (D + 2)] = rtot[0];
   if (n >= q) return;
+  pack[n] = sums[n];
   for (int i = 0; i < D; ++i) {
     double gi = sums[(size_t)(1 + i) * q + n] * invR;
     if (center) gi += inv_s2 * (vec[(size_t)i * q + n] - center[(size_t)i * q + n]);

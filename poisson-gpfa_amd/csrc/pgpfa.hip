@@ -142,7 +142,7 @@ struct pgpfa_ctx {
   double* lam_keep = nullptr;                    // [R][q][T]
   int snap_serial = 0;
   double *vec = nullptr, *cdpart = nullptr, *cdout = nullptr;
-  double *cdhpart = nullptr, *cdhout = nullptr, *cdcenter = nullptr, *cddelta = nullptr, *cddec = nullptr;   // Newton M-step
+  double *cdhpart = nullptr, *cdhout = nullptr, *cdcenter = nullptr, *cdpack = nullptr;   // Newton M-step (cdpack: [cost sums | delta | dec | R], read back in one copy)
   int* last_trials = nullptr;                    // device list of the trials of the last E-step
   std::vector<int> last_trials_h;
   bool have_counts = false, have_params = false, have_post = false, have_precomp = false;
@@ -215,6 +215,9 @@ struct pgpfa_ctx {
   double *tK = nullptr, *tM = nullptr, *tA1 = nullptr, *tA2 = nullptr, *tscal = nullptr, *tpart = nullptr;
   // pinned host staging
   double* hbuf = nullptr; size_t hbuf_len = 0;
+  struct DlEntry { void* host; size_t off, bytes; };
+  PcgCtl fused_ctl_host{};
+  char* dl_stage = nullptr; size_t dl_used = 0; std::vector<DlEntry> dl_pending;   // pinned staging of small read-backs (dl_enqueue / dl_flush)
   int* hibuf = nullptr; size_t hibuf_len = 0;
   // ring of pinned staging slots for small host -> device uploads that must not cost a stream synchronisation each (Newton driver)
   char* ring = nullptr; size_t ring_slot = 0; int ring_cur = 0, ring_pending = 0;
@@ -760,8 +763,10 @@ int ensure_workspace(pgpfa_ctx* c, bool plan_lr) {
   return 0;
 }
 
+int upload_nosync(pgpfa_ctx* c, void* dev, const void* host, size_t bytes);
 int upload_list(pgpfa_ctx* c, int* dst, const std::vector<int>& v) {
   if (v.empty()) return 0;
+  if (v.size() * sizeof(int) <= (size_t)65536) return upload_nosync(c, dst, v.data(), v.size() * sizeof(int));   // through the pinned ring, no synchronisation
   CHK(ensure_hibuf(c, v.size()));
   // staged through pinned memory; the stream sync in callers orders reuse of the staging buffer
   std::memcpy(c->hibuf, v.data(), v.size() * sizeof(int));
@@ -770,11 +775,45 @@ int upload_list(pgpfa_ctx* c, int* dst, const std::vector<int>& v) {
   return 0;
 }
 
-int download(pgpfa_ctx* c, double* host, const double* dev, size_t n) {
-  HIPC(hipMemcpyAsync(host, dev, n * sizeof(double), hipMemcpyDeviceToHost, c->st));
+// Read-backs.  A device-to-host copy into pageable memory makes the runtime drain the stream from the host first and then run a staging
+// copy (measured in the kernel trace: 100-280 us of device idle time in front of every such copy); a copy into pinned memory is just
+// another stream operation.  Small read-backs therefore land in a pinned staging area and are copied out after ONE synchronisation:
+// dl_enqueue queues a copy (several may be queued back to back), dl_flush waits and hands the bytes out.
+constexpr size_t DL_STAGE_BYTES = (size_t)4 << 20;
+int dl_flush(pgpfa_ctx* c) {
   HIPC(hipStreamSynchronize(c->st));
   c->ring_pending = 0;
+  for (const auto& e : c->dl_pending) std::memcpy(e.host, c->dl_stage + e.off, e.bytes);
+  c->dl_pending.clear();
+  c->dl_used = 0;
   return 0;
+}
+int dl_enqueue(pgpfa_ctx* c, void* host, const void* dev, size_t bytes) {
+  if (bytes == 0) return 0;
+  if (!c->dl_stage) {
+    if (hipHostMalloc((void**)&c->dl_stage, DL_STAGE_BYTES) != hipSuccess) { (void)hipGetLastError(); c->dl_stage = nullptr; }
+  }
+  const size_t need = (bytes + 63) / 64 * 64;
+  if (!c->dl_stage || need > DL_STAGE_BYTES) {
+    // large (or no staging area): straight into the caller's memory; complete when this returns
+    CHK(dl_flush(c));
+    const hipError_t e_copy = hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->st);
+    if (e_copy != hipSuccess) return fail("device-to-host copy of %zu bytes: %s", bytes, hipGetErrorString(e_copy));
+    return dl_flush(c);
+  }
+  if (c->dl_used + need > DL_STAGE_BYTES) CHK(dl_flush(c));
+  HIPC(hipMemcpyAsync(c->dl_stage + c->dl_used, dev, bytes, hipMemcpyDeviceToHost, c->st));
+  c->dl_pending.push_back({host, c->dl_used, bytes});
+  c->dl_used += need;
+  return 0;
+}
+int download(pgpfa_ctx* c, double* host, const double* dev, size_t n) {
+  if (c->hbuf && host >= c->hbuf && host < c->hbuf + c->hbuf_len) {      // already pinned
+    HIPC(hipMemcpyAsync(host, dev, n * sizeof(double), hipMemcpyDeviceToHost, c->st));
+    return dl_flush(c);
+  }
+  CHK(dl_enqueue(c, host, dev, n * sizeof(double)));
+  return dl_flush(c);
 }
 int upload(pgpfa_ctx* c, double* dev, const double* host, size_t n) {
   HIPC(hipMemcpyAsync(dev, host, n * sizeof(double), hipMemcpyHostToDevice, c->st));
@@ -939,8 +978,8 @@ int build_kinv(pgpfa_ctx* c) {
   g.slots = nullptr; g.nbatch = c->p; g.mode = GEMM_FULL; g.kflags = KF_BEGIN_MAXRC;
   CHK(gemm(c, false, g));
   std::vector<int> info(c->p);
-  HIPC(hipMemcpyAsync(info.data(), c->kws.info, sizeof(int) * c->p, hipMemcpyDeviceToHost, c->st));
-  HIPC(hipStreamSynchronize(c->st));
+  CHK(dl_enqueue(c, info.data(), c->kws.info, sizeof(int) * c->p));
+  CHK(dl_flush(c));
   for (int k = 0; k < c->p; ++k)
     if (info[k] != 0) return fail("GP Gram matrix of latent %d is not positive definite (pivot %d)", k, info[k]);
   return 0;
@@ -958,8 +997,8 @@ int build_lowrank(pgpfa_ctx* c) {
     hipLaunchKernelGGL((rbf_pivchol_kernel<256, 1>), dim3(p), dim3(256), shm, c->st, c->Flr, Tp, T, c->tau, c->bin, c->eps, c->lr_tol, rmax, c->d_rank);
   HIPC(hipGetLastError());
   std::vector<int> r(p);
-  HIPC(hipMemcpyAsync(r.data(), c->d_rank, sizeof(int) * p, hipMemcpyDeviceToHost, c->st));
-  HIPC(hipStreamSynchronize(c->st));
+  CHK(dl_enqueue(c, r.data(), c->d_rank, sizeof(int) * p));
+  CHK(dl_flush(c));
   c->rk.assign(p, 0);
   c->roff.assign(p + 1, 0);
   for (int k = 0; k < p; ++k) {
@@ -1134,8 +1173,7 @@ int pgpfa_create(pgpfa_ctx** out, int device, int q, int p, int T, int R, double
     rc |= dmalloc(c, &c->cdhpart, (size_t)128 * NH * q);
     rc |= dmalloc(c, &c->cdhout, NH * q + 8);
     rc |= dmalloc(c, &c->cdcenter, (size_t)q * (p + 1));
-    rc |= dmalloc(c, &c->cddelta, (size_t)q * (p + 1));
-    rc |= dmalloc(c, &c->cddec, q);
+    rc |= dmalloc(c, &c->cdpack, (size_t)q * (p + 3) + 8);
   }
   if (hipHostMalloc((void**)&c->h_pcg, 4 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
       hipHostGetDevicePointer((void**)&c->d_hpcg, c->h_pcg, 0) != hipSuccess) { (void)hipGetLastError(); c->h_pcg = nullptr; c->d_hpcg = nullptr; }
@@ -1173,6 +1211,7 @@ int pgpfa_destroy(pgpfa_ctx* c) {
   if (c->Yhi) hipFree(c->Yhi);
   arena_release(c);
   if (c->hbuf) hipHostFree(c->hbuf);
+  if (c->dl_stage) hipHostFree(c->dl_stage);
   if (c->hibuf) hipHostFree(c->hibuf);
   if (c->ring) hipHostFree(c->ring);
   if (c->h_pcg) hipHostFree(c->h_pcg);
@@ -1381,8 +1420,8 @@ int pgpfa_get_counts_u16(pgpfa_ctx* c, int n, const int32_t* idx, uint16_t* out)
   std::vector<uint8_t> lo(m), hi(m, 0);
   for (size_t i = 0; i < tr.v.size(); ++i) {
     HIPC(hipMemcpyAsync(lo.data(), c->Y + (size_t)tr.v[i] * m, m, hipMemcpyDeviceToHost, c->st));
-    if (c->Yhi) HIPC(hipMemcpyAsync(hi.data(), c->Yhi + (size_t)tr.v[i] * m, m, hipMemcpyDeviceToHost, c->st));
-    HIPC(hipStreamSynchronize(c->st));
+    if (c->Yhi) CHK(dl_enqueue(c, hi.data(), c->Yhi + (size_t)tr.v[i] * m, m));
+    CHK(dl_flush(c));
     for (size_t e = 0; e < m; ++e) out[i * m + e] = (uint16_t)(lo[e] | (hi[e] << 8));
   }
   return 0;
@@ -1674,8 +1713,8 @@ static int shared_factor_lowrank(pgpfa_ctx* c, int nb) {
   g.slots = nullptr; g.nbatch = 1; g.mode = GEMM_FULL; g.kflags = KF_BEGIN_MAXRC;
   CHK(gemm(c, false, g));
   int info = 0;
-  HIPC(hipMemcpyAsync(&info, c->sws.info, sizeof(int), hipMemcpyDeviceToHost, c->st));
-  HIPC(hipStreamSynchronize(c->st));
+  CHK(dl_enqueue(c, &info, c->sws.info, sizeof(int)));
+  CHK(dl_flush(c));
   if (info != 0) return fail("shared low-rank preconditioner not positive definite (pivot %d)", info);
   return 0;
 }
@@ -1697,8 +1736,8 @@ static int shared_factor(pgpfa_ctx* c, int nb) {
   g.slots = nullptr; g.nbatch = 1; g.mode = GEMM_FULL; g.kflags = KF_BEGIN_MAXRC;
   CHK(gemm(c, false, g));
   int info = 0;
-  HIPC(hipMemcpyAsync(&info, c->sws.info, sizeof(int), hipMemcpyDeviceToHost, c->st));
-  HIPC(hipStreamSynchronize(c->st));
+  CHK(dl_enqueue(c, &info, c->sws.info, sizeof(int)));
+  CHK(dl_flush(c));
   HIPC(hipGetLastError());
   if (info != 0) return fail("shared preconditioner not positive definite (pivot %d)", info);
   return 0;
@@ -2010,8 +2049,8 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool 
   bool split = false;
   if (split_candidate || c->measure_mix) {
     unsigned hw[4] = {0u, 0u, 0u, 0u};
-    HIPC(hipMemcpyAsync(hw, norm_bits, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, c->st));
-    HIPC(hipStreamSynchronize(c->st));
+    CHK(dl_enqueue(c, hw, norm_bits, 4 * sizeof(unsigned)));
+    CHK(dl_flush(c));
     float hv;
     double hsq;
     std::memcpy(&hv, &hw[0], sizeof(float));
@@ -2170,7 +2209,7 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
     hipLaunchKernelGGL(dots3_kernel, dim3(nb), dim3(256), 0, c->st, c->Xc, ld, c->KX, ld, (const double*)nullptr, 0LL,
                        (const double*)nullptr, 0LL, nvec, c->ident, c->sc_qxx, c->sc_qdx, c->sc_qdd);
     CHK(poisson(c, c->ident, nb, c->Xc, c->Gl, c->W, c->sc_f, 1));
-    HIPC(hipMemcpyAsync(f.data(), c->sc_f, nb * sizeof(double), hipMemcpyDeviceToHost, c->st));
+    CHK(dl_enqueue(c, f.data(), c->sc_f, nb * sizeof(double)));
     CHK(download(c, qxx.data(), c->sc_qxx, nb));
     std::vector<int> active(nb);
     for (int s = 0; s < nb; ++s) { active[s] = s; f[s] += 0.5 * qxx[s]; its[s] = 0; stat[s] = 1; }
@@ -2247,7 +2286,8 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
         // the round trips they remove - measured at config 2: 8.6 vs 8.0 ms per E-step)
         const bool fused = c->pcg_fused && c->plan_lowrank && p <= 16 && c->h_pcg != nullptr && (c->pcg_fused == 2 || (double)nb * c->n >= 1.0e6);
         int done_inner = 0;
-        PcgCtl fused_ctl{};
+        PcgCtl& fused_ctl = c->fused_ctl_host;             // (context member: a queued read-back must not point into this frame)
+        fused_ctl = PcgCtl{};
         if (fused) {
           // ---- inner solve without host round trips (pcg.h): the stopping test runs on the device, iterations are enqueued
           // ahead, kernels of iterations past the stop return at once
@@ -2330,7 +2370,7 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
           }
           c->cur_ndev = nullptr;
           c->live_gemm_collect = false;
-          HIPC(hipMemcpyAsync(&fused_ctl, c->pcgctl, sizeof(PcgCtl), hipMemcpyDeviceToHost, c->st));
+          CHK(dl_enqueue(c, &fused_ctl, c->pcgctl, sizeof(PcgCtl)));
           HIPC(hipGetLastError());
           done_inner = -1;                                     // read from the control block with the scalars below
         } else {
@@ -2489,8 +2529,8 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
       CHK(download(c, qxx.data(), c->sc_qxx, nb));
       CHK(download(c, qdx.data(), c->sc_qdx, nb));
       CHK(download(c, qdd.data(), c->sc_qdd, nb));
-      HIPC(hipMemcpyAsync(info.data(), c->ws.info, sizeof(int) * nb, hipMemcpyDeviceToHost, c->st));
-      HIPC(hipStreamSynchronize(c->st));
+      CHK(dl_enqueue(c, info.data(), c->ws.info, sizeof(int) * nb));
+      CHK(dl_flush(c));
 
       std::vector<int> cand, failed;
       for (int s : active) {
@@ -2560,8 +2600,8 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
       hipLaunchKernelGGL(scatter_rotate_kernel, dim3((nvec + 255) / 256, nb), dim3(256), 0, c->st, c->Xc, ld, nvec, c->Xmode, c->Xprev,
                          c->trial_of_slot, c->list_a);
     }
-    HIPC(hipMemcpyAsync(info.data(), c->ws.info, sizeof(int) * nb, hipMemcpyDeviceToHost, c->st));
-    HIPC(hipStreamSynchronize(c->st));
+    CHK(dl_enqueue(c, info.data(), c->ws.info, sizeof(int) * nb));
+    CHK(dl_flush(c));
     HIPC(hipGetLastError());
     for (int s = 0; s < nb; ++s) {
       if (info[s] != 0 && stat[s] == 0) stat[s] = 3;
@@ -2669,8 +2709,8 @@ int pgpfa_count_moments(pgpfa_ctx* c, int n, const int32_t* idx, int64_t* sum, i
     }
   }
   std::vector<unsigned long long> hostv(len);
-  HIPC(hipMemcpyAsync(hostv.data(), dev, len * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->st));
-  HIPC(hipStreamSynchronize(c->st));
+  CHK(dl_enqueue(c, hostv.data(), dev, len * sizeof(unsigned long long)));
+  CHK(dl_flush(c));
   hipFree(dev); hipFree(dtr);
   HIPC(hipGetLastError());
   for (int i = 0; i < q; ++i) {
@@ -2783,8 +2823,8 @@ static int get_rows(pgpfa_ctx* c, int n, const int32_t* idx, const double* src, 
   Trials tr;
   CHK(resolve_trials(c, n, idx, &tr));
   for (size_t i = 0; i < tr.v.size(); ++i)
-    HIPC(hipMemcpyAsync(out + i * len, src + (size_t)tr.v[i] * len, len * sizeof(double), hipMemcpyDeviceToHost, c->st));
-  HIPC(hipStreamSynchronize(c->st));
+    CHK(dl_enqueue(c, out + i * len, src + (size_t)tr.v[i] * len, len * sizeof(double)));
+  CHK(dl_flush(c));
   return 0;
 }
 int pgpfa_get_post_mean(pgpfa_ctx* c, int n, const int32_t* idx, double* out) { return get_rows(c, n, idx, c ? c->Xmode : nullptr, c ? (size_t)c->n : 0, out); }
@@ -2825,8 +2865,8 @@ static int materialize_impl(pgpfa_ctx* c, const std::vector<int>& need, bool dua
       CHK(poisson(c, c->ident, nb, c->Xc, c->Gl, c->W, c->sc_f, 1));
       CHK(posterior_blocks(c, nb, 1.0, true, false));
     }
-    HIPC(hipMemcpyAsync(info.data(), c->ws.info, sizeof(int) * nb, hipMemcpyDeviceToHost, c->st));
-    HIPC(hipStreamSynchronize(c->st));
+    CHK(dl_enqueue(c, info.data(), c->ws.info, sizeof(int) * nb));
+    CHK(dl_flush(c));
     for (int s = 0; s < nb; ++s) {
       if (info[s] != 0) return fail("posterior precision of trial %d is not positive definite at the resident mode", tos[s]);
       c->vsmgp_ok[tos[s]] = 1;
@@ -2994,12 +3034,12 @@ int pgpfa_mstep_cd_costgrad(pgpfa_ctx* c, const double* vecCd, const double* pri
   HIPC(hipSetDevice(c->device));
   const int q = c->q, p = c->p;
   const int len = (p + 2) * q;
-  CHK(upload(c, c->vec, vecCd, (size_t)q * (p + 1)));
+  CHK(upload_nosync(c, c->vec, vecCd, (size_t)q * (p + 1) * sizeof(double)));
   CHK(cd_sweep(c));
   const int ntr_local = (int)c->last_trials_h.size();
   // append the local trial count, all-reduce [sums | count] over ranks
   const double cnt = (double)ntr_local;
-  HIPC(hipMemcpyAsync(c->cdout + len, &cnt, sizeof(double), hipMemcpyHostToDevice, c->st));
+  CHK(upload_nosync(c, c->cdout + len, &cnt, sizeof(double)));
   CHK(allreduce_dev(c, c->cdout, (size_t)len + 1));
   CHK(ensure_hbuf(c, (size_t)len + 1));
   CHK(download(c, c->hbuf, c->cdout, (size_t)len + 1));
@@ -3023,6 +3063,34 @@ int pgpfa_mstep_cd_costgrad(pgpfa_ctx* c, const double* vecCd, const double* pri
 }
 
 
+// Tail of both Newton-pass variants: the q independent (p+1)-dim Newton steps on the reduced sums in c->cdhout (trial count at rtot_dev, read
+// by the kernel), then ONE read-back of [cost sums | delta | dec | R] through pinned memory.
+static int cd_newton_finish(pgpfa_ctx* c, const double* rtot_dev, const double* vecCd, const double* prior_center, double inv_s2, double* cost_n,
+                            double* delta, double* dec) {
+  const int q = c->q, p = c->p, D = p + 1;
+  const int th = std::max(1, std::min(32, (int)(48 * 1024 / ((D * D + 2 * D) * sizeof(double)))));
+  hipLaunchKernelGGL(cd_newton_step_kernel, dim3((q + th - 1) / th), dim3(th), (size_t)th * (D * D + 2 * D) * sizeof(double), c->st, c->cdhout, q, p,
+                     rtot_dev, c->vec, prior_center ? c->cdcenter : nullptr, inv_s2, c->cdpack);
+  HIPC(hipGetLastError());
+  const size_t np = (size_t)q * (D + 2) + 1;
+  CHK(ensure_hbuf(c, np));
+  CHK(download(c, c->hbuf, c->cdpack, np));
+  const double Rtot = c->hbuf[np - 1];
+  c->n_trials_global = Rtot;
+  std::memcpy(delta, c->hbuf + q, (size_t)q * D * sizeof(double));
+  std::memcpy(dec, c->hbuf + (size_t)q * (D + 1), (size_t)q * sizeof(double));
+  for (int n = 0; n < q; ++n) {
+    double cn = -c->hbuf[n] / Rtot;                          // row 0 of the sums: sum (y*hh - yhat) per neuron
+    if (prior_center) {
+      double s2 = 0.0;
+      for (int i = 0; i < D; ++i) { const double dv = vecCd[(size_t)i * q + n] - prior_center[(size_t)i * q + n]; s2 += dv * dv; }
+      cn += 0.5 * inv_s2 * s2;
+    }
+    cost_n[n] = cn;
+  }
+  return 0;
+}
+
 // One pass of the device Newton solver for the (C,d) M-step: cost, gradient and per-neuron Hessians at vecCd
 // (mstep_cd_hess_kernel), all-reduced over ranks, then the q independent (p+1)-dim Newton steps on device.
 int pgpfa_mstep_cd_newton_pass(pgpfa_ctx* c, const double* vecCd, const double* prior_center, double inv_s2, double* cost_n,
@@ -3034,8 +3102,8 @@ int pgpfa_mstep_cd_newton_pass(pgpfa_ctx* c, const double* vecCd, const double* 
   HIPC(hipSetDevice(c->device));
   const int q = c->q, p = c->p, T = c->T, D = p + 1;
   const int NH = 1 + D + D * (D + 1) / 2;
-  CHK(upload(c, c->vec, vecCd, (size_t)q * D));
-  if (prior_center) CHK(upload(c, c->cdcenter, prior_center, (size_t)q * D));
+  CHK(upload_nosync(c, c->vec, vecCd, (size_t)q * D * sizeof(double)));
+  if (prior_center) CHK(upload_nosync(c, c->cdcenter, prior_center, (size_t)q * D * sizeof(double)));
   CdArgs a{};
   a.Y = c->Y; a.Yhi = c->Yhi; a.mean = c->Xmode; a.vsm = c->vsm; a.vec = c->vec;
   a.trials = c->last_trials; a.ntr = (int)c->last_trials_h.size();
@@ -3073,31 +3141,11 @@ int pgpfa_mstep_cd_newton_pass(pgpfa_ctx* c, const double* vecCd, const double* 
   if (on_mfma) hipLaunchKernelGGL(cd_hess_add_ym_kernel, dim3((q + 127) / 128), dim3(128), 0, c->st, c->cdhout, c->cdym, c->vec, q, p);
   HIPC(hipGetLastError());
   const double cnt = (double)a.ntr;
-  HIPC(hipMemcpyAsync(c->cdhout + (size_t)NH * q, &cnt, sizeof(double), hipMemcpyHostToDevice, c->st));
+  CHK(upload_nosync(c, c->cdhout + (size_t)NH * q, &cnt, sizeof(double)));
   CHK(allreduce_dev(c, c->cdhout, (size_t)NH * q + 1));
-  double Rtot = 0.0;
-  CHK(download(c, &Rtot, c->cdhout + (size_t)NH * q, 1));
-  c->n_trials_global = Rtot;
-  const int th = std::max(1, std::min(32, (int)(48 * 1024 / ((D * D + 2 * D) * sizeof(double)))));
-  hipLaunchKernelGGL(cd_newton_step_kernel, dim3((q + th - 1) / th), dim3(th), (size_t)th * (D * D + 2 * D) * sizeof(double), c->st, c->cdhout, q, p,
-                     1.0 / Rtot, c->vec, prior_center ? c->cdcenter : nullptr, inv_s2, c->cddelta, c->cddec);
-  HIPC(hipGetLastError());
-  CHK(ensure_hbuf(c, (size_t)q));
   c->cd_hess_valid = true;
   c->cd_hess_ntr = a.ntr;
-  CHK(download(c, c->hbuf, c->cdhout, q));                 // row 0: sum (y*hh - yhat) per neuron
-  CHK(download(c, delta, c->cddelta, (size_t)q * D));
-  CHK(download(c, dec, c->cddec, q));
-  for (int n = 0; n < q; ++n) {
-    double cn = -c->hbuf[n] / Rtot;
-    if (prior_center) {
-      double s2 = 0.0;
-      for (int i = 0; i < D; ++i) { const double dv = vecCd[(size_t)i * q + n] - prior_center[(size_t)i * q + n]; s2 += dv * dv; }
-      cn += 0.5 * inv_s2 * s2;
-    }
-    cost_n[n] = cn;
-  }
-  return 0;
+  return cd_newton_finish(c, c->cdhout + (size_t)NH * q, vecCd, prior_center, inv_s2, cost_n, delta, dec);
 }
 
 // Chord variant of the pass above: cost and gradient are evaluated at vecCd (the cheap kernel), the per-neuron
@@ -3112,35 +3160,15 @@ int pgpfa_mstep_cd_chord_pass(pgpfa_ctx* c, const double* vecCd, const double* p
   const int q = c->q, p = c->p, D = p + 1;
   const int NH = 1 + D + D * (D + 1) / 2;
   const int len = (p + 2) * q;
-  CHK(upload(c, c->vec, vecCd, (size_t)q * D));
-  if (prior_center) CHK(upload(c, c->cdcenter, prior_center, (size_t)q * D));
+  CHK(upload_nosync(c, c->vec, vecCd, (size_t)q * D * sizeof(double)));
+  if (prior_center) CHK(upload_nosync(c, c->cdcenter, prior_center, (size_t)q * D * sizeof(double)));
   CHK(cd_sweep(c));
   const double cnt = (double)c->last_trials_h.size();
-  HIPC(hipMemcpyAsync(c->cdout + len, &cnt, sizeof(double), hipMemcpyHostToDevice, c->st));
+  CHK(upload_nosync(c, c->cdout + len, &cnt, sizeof(double)));
   CHK(allreduce_dev(c, c->cdout, (size_t)len + 1));
-  double Rtot = 0.0;
-  CHK(download(c, &Rtot, c->cdout + len, 1));
-  c->n_trials_global = Rtot;
   hipLaunchKernelGGL(cd_chord_merge_kernel, dim3((len + 255) / 256), dim3(256), 0, c->st, c->cdout, q, p, c->cdhout);
-  const int th = std::max(1, std::min(32, (int)(48 * 1024 / ((D * D + 2 * D) * sizeof(double)))));
-  hipLaunchKernelGGL(cd_newton_step_kernel, dim3((q + th - 1) / th), dim3(th), (size_t)th * (D * D + 2 * D) * sizeof(double), c->st, c->cdhout, q, p,
-                     1.0 / Rtot, c->vec, prior_center ? c->cdcenter : nullptr, inv_s2, c->cddelta, c->cddec);
-  HIPC(hipGetLastError());
   (void)NH;
-  CHK(ensure_hbuf(c, (size_t)q));
-  CHK(download(c, c->hbuf, c->cdhout, q));
-  CHK(download(c, delta, c->cddelta, (size_t)q * D));
-  CHK(download(c, dec, c->cddec, q));
-  for (int n = 0; n < q; ++n) {
-    double cn = -c->hbuf[n] / Rtot;
-    if (prior_center) {
-      double s2 = 0.0;
-      for (int i = 0; i < D; ++i) { const double dv = vecCd[(size_t)i * q + n] - prior_center[(size_t)i * q + n]; s2 += dv * dv; }
-      cn += 0.5 * inv_s2 * s2;
-    }
-    cost_n[n] = cn;
-  }
-  return 0;
+  return cd_newton_finish(c, c->cdout + len, vecCd, prior_center, inv_s2, cost_n, delta, dec);
 }
 
 // per-neuron values of the (C,d) cost (for the Newton line search); same kernel as pgpfa_mstep_cd_costgrad
@@ -3251,9 +3279,9 @@ int pgpfa_mstep_tau_costgrad(pgpfa_ctx* c, int k, double logp, double* cost, dou
   CHK(dot_slabs(c, c->tA1, c->tA2, slab, c->tscal + 3));   // tr(Kinv M Kinv P)
   double h[4];
   int info = 0;
-  HIPC(hipMemcpyAsync(h, c->tscal, 4 * sizeof(double), hipMemcpyDeviceToHost, c->st));
-  HIPC(hipMemcpyAsync(&info, c->kws.info, sizeof(int), hipMemcpyDeviceToHost, c->st));
-  HIPC(hipStreamSynchronize(c->st));
+  CHK(dl_enqueue(c, h, c->tscal, 4 * sizeof(double)));
+  CHK(dl_enqueue(c, &info, c->kws.info, sizeof(int)));
+  CHK(dl_flush(c));
   if (info != 0) return fail("timescale Gram matrix not positive definite at log-gamma=%g (pivot %d)", logp, info);
   const double R = c->n_trials_global;
   *cost = 0.5 * R * h[0] + 0.5 * h[1];                                    // learning.py:212-214
@@ -3307,9 +3335,9 @@ int pgpfa_mstep_tau_costgrad_multi(pgpfa_ctx* c, int m, const double* logp, doub
   HIPC(hipGetLastError());
   std::vector<double> h(4 * (size_t)nq);
   std::vector<int> info(nq);
-  HIPC(hipMemcpyAsync(h.data(), dres, 4 * nq * sizeof(double), hipMemcpyDeviceToHost, c->st));
-  HIPC(hipMemcpyAsync(info.data(), c->kws.info, sizeof(int) * nq, hipMemcpyDeviceToHost, c->st));
-  HIPC(hipStreamSynchronize(c->st));
+  CHK(dl_enqueue(c, h.data(), dres, 4 * nq * sizeof(double)));
+  CHK(dl_enqueue(c, info.data(), c->kws.info, sizeof(int) * nq));
+  CHK(dl_flush(c));
   const double R = c->n_trials_global;
   for (int k = 0; k < nq; ++k) {
     if (info[k] != 0) return fail("timescale Gram matrix of latent %d not positive definite at log-gamma=%g", k % p, logp[k]);
@@ -3403,9 +3431,9 @@ int pgpfa_dual_costgrad(pgpfa_ctx* c, int trial, const double* lam, double* cost
   hipLaunchKernelGGL(logdet_kernel, dim3(1), dim3(256), 0, c->st, c->ws.H, c->ld, c->npad, c->tscal + 8);
   double logdetH = 0.0;
   int info = 0;
-  HIPC(hipMemcpyAsync(&logdetH, c->tscal + 8, sizeof(double), hipMemcpyDeviceToHost, c->st));
-  HIPC(hipMemcpyAsync(&info, c->ws.info, sizeof(int), hipMemcpyDeviceToHost, c->st));
-  HIPC(hipStreamSynchronize(c->st));
+  CHK(dl_enqueue(c, &logdetH, c->tscal + 8, sizeof(double)));
+  CHK(dl_enqueue(c, &info, c->ws.info, sizeof(int)));
+  CHK(dl_flush(c));
   if (info != 0) return fail("dual problem: posterior precision not positive definite (pivot %d)", info);
   // A + B + C + D of inference.py:203-213 ; C = 0.5*logdet(Sigma) = -0.5*logdet(precision + jitter)
   *cost = 0.5 * vKv[0] - sB[0] - 0.5 * logdetH + sD[0];
@@ -3543,8 +3571,8 @@ static int dual_eval_slots(pgpfa_ctx* c, int nb, const std::vector<int>& tos, bo
     // with it the engine evaluates the reference's function - cost, log det and gradient follow inference.py:188-219.
     CHK(dual_jitter(c, nb));
     CHK(posterior_blocks_lowrank(c, nb, false, false, logdet.data()));
-    HIPC(hipMemcpyAsync(info.data(), c->ws.info, sizeof(int) * nb, hipMemcpyDeviceToHost, c->st));
-    HIPC(hipStreamSynchronize(c->st));
+    CHK(dl_enqueue(c, info.data(), c->ws.info, sizeof(int) * nb));
+    CHK(dl_flush(c));
     for (int s2 = 0; s2 < nb; ++s2) {
       cost[s2] = 0.5 * vKv[s2] - sB[s2] - 0.5 * logdet[s2] + sD[s2];
       if (info[s2] != 0 || !std::isfinite(cost[s2])) {
@@ -3563,8 +3591,8 @@ static int dual_eval_slots(pgpfa_ctx* c, int nb, const std::vector<int>& tos, bo
   CHK(factor(c, c->ws, c->ident, nb));
   hipLaunchKernelGGL(logdet_batch_kernel, dim3(nb), dim3(256), 0, c->st, c->ws.H, (long long)c->ws.sH, c->ld, c->npad, c->sc_f);
   CHK(download(c, logdet.data(), c->sc_f, nb));
-  HIPC(hipMemcpyAsync(info.data(), c->ws.info, sizeof(int) * nb, hipMemcpyDeviceToHost, c->st));
-  HIPC(hipStreamSynchronize(c->st));
+  CHK(dl_enqueue(c, info.data(), c->ws.info, sizeof(int) * nb));
+  CHK(dl_flush(c));
   for (int s2 = 0; s2 < nb; ++s2) {
     // A + B + C + D of inference.py:203-213 ; C = 0.5*logdet(Sigma) = -0.5*logdet(precision + jitter)
     cost[s2] = 0.5 * vKv[s2] - sB[s2] - 0.5 * logdet[s2] + sD[s2];
@@ -3887,8 +3915,8 @@ int pgpfa_dual_finalize(pgpfa_ctx* c, int n, const int32_t* idx, const double* l
     CHK(poisson(c, c->ident, nb, c->Xc, c->Gl, c->Wt, c->sc_f, 0));
     CHK(download(c, f.data(), c->sc_f, nb));
     CHK(download(c, qxx.data(), c->sc_qxx, nb));
-    HIPC(hipMemcpyAsync(info.data(), c->ws.info, sizeof(int) * nb, hipMemcpyDeviceToHost, c->st));
-    HIPC(hipStreamSynchronize(c->st));
+    CHK(dl_enqueue(c, info.data(), c->ws.info, sizeof(int) * nb));
+    CHK(dl_flush(c));
     for (int s = 0; s < nb; ++s) {
       if (info[s] != 0) return fail("dual finalize: posterior precision of trial %d not positive definite", tos[s]);
       total += f[s] + 0.5 * qxx[s];
