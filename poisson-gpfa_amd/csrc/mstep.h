@@ -127,9 +127,10 @@ __global__ void cd_add_ym_kernel(double* __restrict__ sums, const double* __rest
   sums[(size_t)(p + 1) * q + n] += lin;
 }
 
-// grid = (groups, nby), block = (64, 8): the neuron tiles (16 neurons each, one per wave) are dealt to `groups`
+// grid = (nby, groups), block = (64, 8): the neuron tiles (16 neurons each, one per wave) are dealt to `groups`
 // workgroups of 8 waves (waves without a tile only help staging), so a wave may use 256 registers and two waves share a
-// SIMD's matrix pipe.  Phi tiles are double-buffered in LDS: one barrier per tile.
+// SIMD's matrix pipe.  The item index is the fast grid dimension: with nby a multiple of 8 the workgroups that walk the same
+// (trial, tile) items for different neuron groups get block ids nby apart, i.e. the same XCD, and meet in its L2.  Phi tiles are double-buffered in LDS: one barrier per tile.
 // The last, partly filled 4-column k step of the first product and (when at most 4) the rows left over after the full
 // 16-row tiles of the second product are done on the vector ALU instead of a mostly empty MFMA (p = 10: 16 + 16 MFMAs
 // per 16 bins instead of 17 + 20).
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(512) void mstep_cd_mfma_kernel(CdArgs a, int tiles_
   const int l15 = lane & 15, l4 = lane >> 4;
   const int nthreads = 64 * blockDim.y, tid = wave * 64 + lane;
   const int p = a.p, q = a.q, T = a.T, pp = p * p;
-  const int n0 = (blockIdx.x * tiles_per_group + wave) * 16;
+  const int n0 = (blockIdx.y * tiles_per_group + wave) * 16;
   const bool active_wave = wave < tiles_per_group && n0 < q;      // other waves only help staging
   const int n = n0 + l15;
   const bool live = active_wave && n < q;
@@ -246,10 +247,10 @@ __global__ __launch_bounds__(512) void mstep_cd_mfma_kernel(CdArgs a, int tiles_
   };
   // zero both stages once: the gap columns NC..S-1 of a row and the slack behind the last row are never staged
   for (int e = tid; e < 2 * M::LDS_DOUBLES; e += nthreads) lds[e] = 0.0;
-  // items = (trial, tile) pairs, walked with stride gridDim.y; the pair of the current and of the next item is kept in
+  // items = (trial, tile) pairs, walked with stride gridDim.x; the pair of the current and of the next item is kept in
   // scalar counters (no integer division in the loop)
-  const int step_tr = gridDim.y / ntt, step_ti = gridDim.y % ntt;
-  int item = blockIdx.y;
+  const int step_tr = gridDim.x / ntt, step_ti = gridDim.x % ntt;
+  int item = blockIdx.x;
   int c_tr = item / ntt, c_ti = item % ntt;
   if (item < nitems) prefetch(c_tr, c_ti);
   __syncthreads();
@@ -258,10 +259,10 @@ __global__ __launch_bounds__(512) void mstep_cd_mfma_kernel(CdArgs a, int tiles_
     if (soff[i] != -3) lds[loff[i]] = pf[i];
   __syncthreads();
   int cur = 0;
-  for (; item < nitems; item += gridDim.y) {
+  for (; item < nitems; item += gridDim.x) {
     const int t0 = c_ti * BT;
     const int tn = (T - t0 < BT) ? T - t0 : BT;
-    const bool more = item + (int)gridDim.y < nitems;
+    const bool more = item + (int)gridDim.x < nitems;
     c_tr += step_tr; c_ti += step_ti;
     if (c_ti >= ntt) { c_ti -= ntt; c_tr += 1; }
     if (more && !(a.dbg & 8)) prefetch(c_tr, c_ti);     // global loads in flight while this stage is multiplied
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(512) void mstep_cd_mfma_kernel(CdArgs a, int tiles_
     sy += __shfl_xor(sy, 16);
     sy += __shfl_xor(sy, 32);
     if (live && l4 == 0) {
-      double* part = a.part + (size_t)blockIdx.y * (p + 2) * q;
+      double* part = a.part + (size_t)blockIdx.x * (p + 2) * q;
 #pragma unroll
       for (int l = 0; l < PW; ++l)
         if (l < p) part[(size_t)l * q + n] = -u[l];
@@ -427,7 +428,7 @@ __global__ __launch_bounds__(64 * CDH_NW) void mstep_cd_hess_mfma_kernel(CdArgs 
   const int l15 = lane & 15, l4 = lane >> 4, x4 = lane & 3, blk = (lane >> 2) & 3;
   const int nthreads = 64 * blockDim.y, tid = wave * 64 + lane;
   const int p = a.p, q = a.q, T = a.T, pp = p * p;
-  const int n0 = (blockIdx.x * tiles_per_group + wave) * 16;
+  const int n0 = (blockIdx.y * tiles_per_group + wave) * 16;
   const bool active_wave = wave < tiles_per_group && n0 < q;        // other waves only help staging
   const int n = n0 + l15;
   const bool live = active_wave && n < q;
@@ -515,8 +516,8 @@ __global__ __launch_bounds__(64 * CDH_NW) void mstep_cd_hess_mfma_kernel(CdArgs 
     for (int i = 0; i < MAXPF; ++i) pf[i] = ok[i] ? raw[i] : (soff[i] == -1 ? 1.0 : 0.0);
   };
   for (int e = tid; e < 2 * H::LDS_DOUBLES; e += nthreads) lds[e] = 0.0;
-  const int step_tr = gridDim.y / ntt, step_ti = gridDim.y % ntt;
-  int item = blockIdx.y;
+  const int step_tr = gridDim.x / ntt, step_ti = gridDim.x % ntt;
+  int item = blockIdx.x;
   int c_tr = item / ntt, c_ti = item % ntt;
   if (item < nitems) prefetch(c_tr, c_ti);
   __syncthreads();
@@ -525,10 +526,10 @@ __global__ __launch_bounds__(64 * CDH_NW) void mstep_cd_hess_mfma_kernel(CdArgs 
     if (soff[i] != -3) lds[loff[i]] = pf[i];
   __syncthreads();
   int cur = 0;
-  for (; item < nitems; item += gridDim.y) {
+  for (; item < nitems; item += gridDim.x) {
     const int t0 = c_ti * BT;
     const int tn = (T - t0 < BT) ? T - t0 : BT;
-    const bool more = item + (int)gridDim.y < nitems;
+    const bool more = item + (int)gridDim.x < nitems;
     c_tr += step_tr; c_ti += step_ti;
     if (c_ti >= ntt) { c_ti -= ntt; c_tr += 1; }
     if (more) prefetch(c_tr, c_ti);
@@ -640,7 +641,7 @@ __global__ __launch_bounds__(64 * CDH_NW) void mstep_cd_hess_mfma_kernel(CdArgs 
       }
     asm volatile("" ::: "memory");
     const int D = p + 1, nha = D * (D + 1) / 2;
-    double* part = a.part + (size_t)blockIdx.y * (1 + D + nha) * q;
+    double* part = a.part + (size_t)blockIdx.x * (1 + D + nha) * q;
     for (int e = lane; e < 16 * nha; e += 64) {
       const int nn = e & 15, idx = e >> 4;
       if (n0 + nn < q) part[(size_t)(1 + D + idx) * q + n0 + nn] = Hs[nn * NHH + idx];

@@ -3006,7 +3006,7 @@ static int cd_sweep(pgpfa_ctx* c) {
         const int tiles = (q + 15) / 16, groups = (tiles + 7) / 8, tpg = (tiles + groups - 1) / groups;
         nby = std::max(1, std::min(a.ntr * ntt, std::max(64, 512 / groups)));      // one resident workgroup per CU: about one round of blocks
         const int waves = 8;
-        hipLaunchKernelGGL(mstep_cd_mfma_kernel<PW>, dim3(groups, nby), dim3(64, waves), cd_mfma_lds_bytes<PW>(), c->st, a, tpg);
+        hipLaunchKernelGGL(mstep_cd_mfma_kernel<PW>, dim3(nby, groups), dim3(64, waves), cd_mfma_lds_bytes<PW>(), c->st, a, tpg);
       }
     });
     prof_end(c);
@@ -3125,7 +3125,7 @@ int pgpfa_mstep_cd_newton_pass(pgpfa_ctx* c, const double* vecCd, const double* 
                                     (int)cd_hess_mfma_lds_bytes<PW>());
           attr_set = true;
         }
-        hipLaunchKernelGGL(mstep_cd_hess_mfma_kernel<PW>, dim3(groups, nby), dim3(64, CDH_NW), cd_hess_mfma_lds_bytes<PW>(), c->st, a, tpg);
+        hipLaunchKernelGGL(mstep_cd_hess_mfma_kernel<PW>, dim3(nby, groups), dim3(64, CDH_NW), cd_hess_mfma_lds_bytes<PW>(), c->st, a, tpg);
         return;
       }
     }
