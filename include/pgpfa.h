@@ -62,7 +62,8 @@ int pgpfa_destroy(pgpfa_ctx* ctx);
  * precision on the FP32 matrix cores, log det / covariance blocks / gradient accumulated in FP64: the mixed-precision form BASELINE
  * config 5 asks for; 2: the same with B assembled in FP64 and rounded once),
  * "pcg_fused" (1: inner PCG iterations without host round trips, pcg.h), "pcg_w32" (1: packed FP32 curvature blocks in the PCG
- * Hessian-vector product), "cd_mfma" (1: (C,d) sweep on the matrix cores, mstep.h), "vsm_mfma" (1: beyond 10 latents the per-bin
+ * Hessian-vector product), "cd_mfma" (1: (C,d) sweep on the matrix cores, mstep.h), "cd_hess_mfma" (1: the Newton pass
+ * of the (C,d) M-step - cost, gradient, per-neuron Hessians - on the matrix cores up to 10 latents; 0: the vector kernel), "vsm_mfma" (1: beyond 10 latents the per-bin
  * covariance blocks are Gram products on the matrix cores - post_vsm_mfma_kernel, model.h; 0: vector kernel),
  * "extrapolate_start" (1: a warm-started E-step begins at m + beta (m - m_prev) for trials whose two previous
  * E-steps are resident), "extrapolate_beta" (1.0),

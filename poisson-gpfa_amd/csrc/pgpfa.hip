@@ -18,6 +18,7 @@
 #include <type_traits>
 #include <vector>
 
+#include <mutex>
 #include "../../include/pgpfa.h"
 #include "chol.h"
 #include "gemm.h"
@@ -566,6 +567,13 @@ int free_workspace(pgpfa_ctx* c) {
 // re-allocate at the size needed.
 void arena_release(pgpfa_ctx* c);
 
+// Reserved address ranges of closed contexts, kept for the next context of this process instead of being handed back:
+// hipMemAddressFree crashed inside the runtime about once in ten runs of a test sequence that opens and closes a few dozen contexts
+// (native backtrace: arena_release -> hipMemAddressFree -> libamdhip64; never under a debugger).  A range is address space only - its
+// physical chunks are unmapped and released when the context closes - and there are never more ranges than contexts alive at once.
+std::mutex g_va_mu;
+std::vector<std::pair<void*, size_t>> g_va_free;
+
 int arena_grow(pgpfa_ctx* c, size_t need) {
   g_err.clear();
   if (c->vmm == 0) {
@@ -578,7 +586,12 @@ int arena_grow(pgpfa_ctx* c, size_t need) {
     if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) == hipSuccess && gran > 0 &&
         hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
       const size_t va_size = (total_b + gran - 1) / gran * gran;
-      if (hipMemAddressReserve(&va, va_size, gran, nullptr, 0) == hipSuccess && va) {
+      {
+        std::lock_guard<std::mutex> lk(g_va_mu);
+        for (size_t i = 0; i < g_va_free.size(); ++i)
+          if (g_va_free[i].second == va_size) { va = g_va_free[i].first; g_va_free.erase(g_va_free.begin() + i); break; }
+      }
+      if (va || (hipMemAddressReserve(&va, va_size, gran, nullptr, 0) == hipSuccess && va)) {
         c->arena = reinterpret_cast<char*>(va); c->va_size = va_size; c->vmm_gran = gran; c->vmm = 1; c->arena_cap = 0;
       }
     }
@@ -642,7 +655,10 @@ void arena_release(pgpfa_ctx* c) {
     size_t off = 0;
     for (auto& ch : c->vmm_chunks) { hipMemUnmap(c->arena + off, ch.second); hipMemRelease(ch.first); off += ch.second; }
     c->vmm_chunks.clear();
-    if (c->arena) hipMemAddressFree(c->arena, c->va_size);
+    if (c->arena) {
+      std::lock_guard<std::mutex> lk(g_va_mu);
+      g_va_free.emplace_back(c->arena, c->va_size);
+    }
   } else if (c->arena) {
     hipFree(c->arena);
   }
@@ -3964,6 +3980,52 @@ int pgpfa_comm_allreduce_host(pgpfa_ctx* c, double* buf, int count) {
   CHK(allreduce_dev(c, c->commbuf, count));
   return download(c, buf, c->commbuf, count);
 }
+
+// ---- crash diagnostics (opt-in: PGPFA_BACKTRACE=1 in the environment when the library is loaded) ------------------------------
+// SIGSEGV / SIGABRT print the native call stack of the faulting thread to stderr (module + offset: resolve with addr2line) and
+// then take the default action.  The GPU boxes write no core files and a debugger changes the timing: this is what is left.
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+namespace {
+struct sigaction g_prev_action[65];
+void pgpfa_crash_handler(int sig, siginfo_t* info, void* uctx) {
+  void* frames[64];
+  const int n = backtrace(frames, 64);
+  const char head[] = "\npgpfa: fatal signal, native backtrace:\n";
+  (void)!write(2, head, sizeof head - 1);
+  backtrace_symbols_fd(frames, n, 2);
+  // hand over to whoever was installed before (Python's faulthandler prints the interpreter's stack), else the default action
+  const struct sigaction& prev = g_prev_action[sig];
+  if ((prev.sa_flags & SA_SIGINFO) && prev.sa_sigaction) { prev.sa_sigaction(sig, info, uctx); return; }
+  if (!(prev.sa_flags & SA_SIGINFO) && prev.sa_handler != SIG_DFL && prev.sa_handler != SIG_IGN && prev.sa_handler) { prev.sa_handler(sig); return; }
+  signal(sig, SIG_DFL);
+  raise(sig);
+}
+struct PgpfaCrashInit {
+  PgpfaCrashInit() {
+    const char* e = std::getenv("PGPFA_BACKTRACE");
+    if (e && e[0] == '1') {
+      void* warm[2];
+      (void)backtrace(warm, 2);                       // (loads libgcc now, not inside the handler)
+      static char altstack[1 << 16];
+      stack_t cur{};
+      if (sigaltstack(nullptr, &cur) == 0 && (cur.ss_flags & SS_DISABLE)) {
+        stack_t ss{};
+        ss.ss_sp = altstack; ss.ss_size = sizeof altstack; ss.ss_flags = 0;
+        sigaltstack(&ss, nullptr);
+      }
+      for (int sig : {SIGSEGV, SIGABRT, SIGBUS}) {
+        struct sigaction sa{};
+        sa.sa_sigaction = pgpfa_crash_handler;
+        sa.sa_flags = SA_SIGINFO | SA_ONSTACK;
+        sigemptyset(&sa.sa_mask);
+        sigaction(sig, &sa, &g_prev_action[sig]);
+      }
+    }
+  }
+} g_pgpfa_crash_init;
+}  // namespace
 
 // ---- test / bench hooks ----------------------------------------------------------------------------------------
 int pgpfa_test_potrf(pgpfa_ctx* c, int batch, int n, const double* A, double* L, double* inv) {
