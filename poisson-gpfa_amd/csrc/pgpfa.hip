@@ -1917,7 +1917,11 @@ static int accumulate_split(pgpfa_ctx* c, const CholWS& lw, int nb, int ract, in
     CHK(gemm(c, true, xf));
   }
   // 4. Pacc += eps diag + T1 - Xfull - Xfull^T + sum of the FP16 partial sums
-  hipLaunchKernelGGL(pacc_split_reduce_kernel, dim3(T, p), dim3(128), 0, c->st, T1, Xfull, c->ppart, ngroups, c->Gbin, sW, nb, c->eps, T, Tp, p, c->Pacc);
+  {
+    const int nt64 = (T + PACC_TS - 1) / PACC_TS;
+    hipLaunchKernelGGL(pacc_split_reduce_kernel, dim3(nt64 * (nt64 + 1) / 2, p), dim3(256), 0, c->st, T1, Xfull, c->ppart, ngroups, c->Gbin, sW, nb, c->eps, T, Tp,
+                       p, c->Pacc);
+  }
   HIPC(hipGetLastError());
   c->pacc_used = true;
   return 0;
