@@ -1587,25 +1587,54 @@ __global__ void negate_rows_kernel(const double* __restrict__ src, long long sSr
 // bit pattern: non-negative floats order like their bits), *out_sq += sum_i v_i^2.  Used on the blocks Wt = W (I + eps W)^-1 of a
 // chunk: eps ||Wt_t|| is the relative size of the mixing correction D = eps Wt y of the low-rank covariance engine, its root mean
 // square over (trial, bin) what the precision of the split accumulation depends on.  grid = ceil(nblocks/256), block = 256.
-__global__ void block_norm_max_kernel(const double* __restrict__ B, long long nblocks, int p, double scale, unsigned* __restrict__ out_bits,
-                                      double* __restrict__ out_sq) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  float v = 0.f;
-  if (i < nblocks) {
-    const double* b = B + i * p * p;
-    double worst = 0.0;
-    for (int r = 0; r < p; ++r) {
-      double s = 0.0;
-      for (int c2 = 0; c2 < p; ++c2) s += fabs(b[r * p + c2]);
-      worst = fmax(worst, s);
+// One thread per ROW of a block (consecutive threads read consecutive 8p-byte rows: whole cache lines; a thread per block read its
+// own p^2 doubles at stride 8p^2 and ran at 0.55 TB/s), row sums through LDS, the first row's thread of every block takes the maximum.
+// A workgroup walks chunks of 256 rows with stride gridDim.x and issues ONE pair of atomics at the end (a pair per wave per chunk was
+// 160 000 atomics on two addresses: 1.9 ms).  grid = min(ceil(nblocks p / 256), 2048), block = 256.
+__global__ __launch_bounds__(256) void block_norm_max_kernel(const double* __restrict__ B, long long nblocks, int p, double scale, unsigned* __restrict__ out_bits,
+                                                             double* __restrict__ out_sq) {
+  __shared__ double rs[256 + 32];
+  __shared__ float wv[4];
+  __shared__ double wsq[4];
+  const long long nrows = nblocks * p;
+  const long long nchunks = (nrows + 255) / 256;
+  float vmax = 0.f;
+  double sq = 0.0;
+  for (long long ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    const long long row = ch * 256 + threadIdx.x;                                 // global row index = block * p + r
+    double s = 0.0;
+    if (row < nrows) {
+      const double* b = B + row * p;
+      for (int c2 = 0; c2 < p; ++c2) s += fabs(b[c2]);
     }
-    v = (float)(scale * worst);
+    __syncthreads();                                                              // the previous chunk's sums have been read
+    rs[threadIdx.x] = s;
+    // the rows of a block that starts in this chunk may run into the next one: those (at most p - 1 <= 31) rows are read again here
+    if (threadIdx.x < 32) {
+      const long long row2 = (ch + 1) * 256 + threadIdx.x;
+      double s2 = 0.0;
+      if (threadIdx.x < p - 1 && row2 < nrows) {
+        const double* b = B + row2 * p;
+        for (int c2 = 0; c2 < p; ++c2) s2 += fabs(b[c2]);
+      }
+      rs[256 + threadIdx.x] = s2;
+    }
+    __syncthreads();
+    if (row < nrows && row % p == 0) {
+      double worst = 0.0;
+      for (int r = 0; r < p; ++r) worst = fmax(worst, rs[threadIdx.x + r]);
+      const float v = (float)(scale * worst);
+      vmax = fmaxf(vmax, v);
+      sq += (double)v * (double)v;
+    }
   }
-  double sq = (double)v * (double)v;
-  for (int off = 32; off > 0; off >>= 1) { v = fmaxf(v, __shfl_down(v, off)); sq += __shfl_down(sq, off); }
-  if ((threadIdx.x & 63) == 0) {
+  for (int off = 32; off > 0; off >>= 1) { vmax = fmaxf(vmax, __shfl_down(vmax, off)); sq += __shfl_down(sq, off); }
+  if ((threadIdx.x & 63) == 0) { wv[threadIdx.x >> 6] = vmax; wsq[threadIdx.x >> 6] = sq; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float v = fmaxf(fmaxf(wv[0], wv[1]), fmaxf(wv[2], wv[3]));
     if (v > 0.f) atomicMax(out_bits, __float_as_uint(v));
-    if (out_sq) atomicAdd(out_sq, sq);
+    if (out_sq) atomicAdd(out_sq, (wsq[0] + wsq[1]) + (wsq[2] + wsq[3]));
   }
 }
 

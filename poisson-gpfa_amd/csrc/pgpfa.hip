@@ -1946,7 +1946,7 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool 
   if (split_candidate || c->measure_mix) {
     HIPC(hipMemsetAsync(norm_bits, 0, 4 * sizeof(unsigned), c->st));
     const long long nblk = (long long)nb * T;
-    hipLaunchKernelGGL(block_norm_max_kernel, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, c->st, c->Wt, nblk, p, c->eps, norm_bits,
+    hipLaunchKernelGGL(block_norm_max_kernel, dim3((unsigned)std::min<long long>((nblk * p + 255) / 256, 2048)), dim3(256), 0, c->st, c->Wt, nblk, p, c->eps, norm_bits,
                        reinterpret_cast<double*>(norm_bits + 2));
   }
   // b. B = I + F^T Wt F into the factor slabs viewed with ld = rpad; factor; L^-T
