@@ -1,7 +1,7 @@
 # usage (on the GPU box): bash tools/run_gpu_tests.sh <log> [pytest args...]
 # pytest -m gpu with glibc's fatal messages on stderr and a post-mortem backtrace if the interpreter dies on a signal.
 LOG=$1; shift
-export LIBC_FATAL_STDERR_=1
+export LIBC_FATAL_STDERR_=1 PGPFA_BACKTRACE=1
 ulimit -c unlimited
 cd $GRAFT_REPO_ROOT
 rm -f core core.* /tmp/core*
