@@ -2089,24 +2089,63 @@ __global__ __launch_bounds__(256) void bin_blocks_coop_kernel(const double* __re
 
 // The same in registers for p <= PW <= 10: the LDS version above keeps 2 p^2 + 1 doubles per thread in LDS, which at p = 10
 // leaves 29 threads per workgroup and 3 waves per CU.  Here every loop is unrolled over the packed lower triangles, so
-// the factor, its inverse and G live in VGPRs (static indices only); W is re-read from memory (cache hits) for W G.
-// One thread per (slot, bin).  grid = ceil(nslots*T / 128), block = 128.
+// the factor, its inverse and G live in VGPRs (static indices only).
+// One thread per (slot, bin), one wave per workgroup.  The wave's 64 blocks are contiguous runs of p^2 doubles (per slot): they are
+// copied into LDS with consecutive lanes on consecutive addresses, every thread then takes its own block from LDS (row stride
+// p^2 + 1: conflict-free), and Wt and G go back out through the same LDS image.  (Threads used to read and write their blocks in
+// global memory directly, 64 different cache lines per instruction: 1.26 ms and twice the algorithmic bytes at config 3.)
+// grid = ceil(nslots*T / BBR_MPB), block = 64.
+constexpr int BBR_TPB = 64;     // threads per workgroup (one wave: all of them copy)
+constexpr int BBR_MPB = 32;     // blocks per workgroup (the first BBR_MPB lanes compute): 26 KB of LDS, six workgroups per CU keep enough loads in flight
 template <int PW>
-__global__ __launch_bounds__(128) void bin_blocks_reg_kernel(const double* __restrict__ W, long long sW, double* __restrict__ G,
-                                                             double* __restrict__ Wt, long long sO, int T, int p, double eps,
-                                                             const int* __restrict__ slots, int nslots, double* __restrict__ ldet) {
+__global__ __launch_bounds__(BBR_TPB) void bin_blocks_reg_kernel(const double* __restrict__ W, long long sW, double* __restrict__ G,
+                                                                 double* __restrict__ Wt, long long sO, int T, int p, double eps,
+                                                                 const int* __restrict__ slots, int nslots, double* __restrict__ ldet) {
   constexpr int NP = PW * (PW + 1) / 2;
-  const long long item = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (item >= (long long)nslots * T) return;
-  const int slot = slots[item / T];
-  const int t = (int)(item % T);
+  constexpr int LD = PW * PW + 1;
+  __shared__ double buf[BBR_MPB * LD];
+  __shared__ long long in_off[BBR_MPB], out_off[BBR_MPB];
+  const int tid = threadIdx.x;
+  const long long total = (long long)nslots * T;
+  const long long item0 = (long long)blockIdx.x * BBR_MPB;
+  const int nitems = (int)((total - item0 < BBR_MPB) ? total - item0 : BBR_MPB);
+  const long long item = item0 + tid;
   const int pp = p * p;
-  const double* w = W + (size_t)slot * sW + (size_t)t * pp;
+  if (tid < nitems) {
+    const int slot = slots[item / T];
+    const int t = (int)(item % T);
+    in_off[tid] = (long long)slot * sW + (long long)t * pp;
+    out_off[tid] = (long long)slot * sO + (long long)t * pp;
+  }
+  __syncthreads();
+  // element e of the tile = entry idx of block m: (m, idx) advance without divisions
+  auto copy_in = [&](const double* src, const long long* off) {
+    int m = 0, idx = tid;
+    while (idx >= pp) { idx -= pp; ++m; }
+    for (; m < nitems;) {
+      buf[m * LD + idx] = src[off[m] + idx];
+      idx += BBR_TPB;
+      while (idx >= pp) { idx -= pp; ++m; }
+    }
+  };
+  auto copy_out = [&](double* dst, const long long* off) {
+    int m = 0, idx = tid;
+    while (idx >= pp) { idx -= pp; ++m; }
+    for (; m < nitems;) {
+      dst[off[m] + idx] = buf[m * LD + idx];
+      idx += BBR_TPB;
+      while (idx >= pp) { idx -= pp; ++m; }
+    }
+  };
+  copy_in(W, in_off);
+  __syncthreads();
+  const bool live = tid < nitems;
+  double* w = buf + (tid < BBR_MPB ? tid : 0) * LD;                     // this thread's block (W, then Wt row by row, then G)
   double L[NP];                                   // A = I + eps W (lower) -> Cholesky factor -> its inverse
 #pragma unroll
   for (int i = 0; i < PW; ++i)
 #pragma unroll
-    for (int j = 0; j <= i; ++j) L[i * (i + 1) / 2 + j] = ((i < p && j < p) ? eps * w[i * p + j] : 0.0) + (i == j ? 1.0 : 0.0);
+    for (int j = 0; j <= i; ++j) L[i * (i + 1) / 2 + j] = ((live && i < p && j < p) ? eps * w[i * p + j] : 0.0) + (i == j ? 1.0 : 0.0);
   double logdet = 0.0;
 #pragma unroll
   for (int j = 0; j < PW; ++j) {
@@ -2124,7 +2163,7 @@ __global__ __launch_bounds__(128) void bin_blocks_reg_kernel(const double* __res
       L[i * (i + 1) / 2 + j] = v / dj;
     }
   }
-  if (ldet) ldet[item] = logdet;
+  if (ldet && live) ldet[item] = logdet;
   // invert L in place, column by column (column j reads L[i][m], m >= j, and L[i][i], i > j: still un-inverted then)
 #pragma unroll
   for (int j = 0; j < PW; ++j) {
@@ -2148,24 +2187,34 @@ __global__ __launch_bounds__(128) void bin_blocks_reg_kernel(const double* __res
       for (int m = i; m < PW; ++m) v += L[m * (m + 1) / 2 + i] * L[m * (m + 1) / 2 + j];
       Gm[i * (i + 1) / 2 + j] = v;
     }
-  double* g = G + (size_t)slot * sO + (size_t)t * pp;
-  double* wt = Wt + (size_t)slot * sO + (size_t)t * pp;
+  // Wt = W G, row by row over this thread's W (row i of W is not needed once row i of Wt is there)
+  if (live) {
 #pragma unroll
-  for (int i = 0; i < PW; ++i) {
-    double wrow[PW];
+    for (int i = 0; i < PW; ++i) {
+      double wrow[PW];
 #pragma unroll
-    for (int m = 0; m < PW; ++m) wrow[m] = (i < p && m < p) ? w[i * p + m] : 0.0;
+      for (int m = 0; m < PW; ++m) wrow[m] = (i < p && m < p) ? w[i * p + m] : 0.0;
 #pragma unroll
-    for (int j = 0; j < PW; ++j) {
-      double v = 0.0;
+      for (int j = 0; j < PW; ++j) {
+        double v = 0.0;
 #pragma unroll
-      for (int m = 0; m < PW; ++m) v += wrow[m] * ((m >= j) ? Gm[m * (m + 1) / 2 + j] : Gm[j * (j + 1) / 2 + m]);
-      if (i < p && j < p) {
-        g[i * p + j] = (j <= i) ? Gm[i * (i + 1) / 2 + j] : Gm[j * (j + 1) / 2 + i];
-        wt[i * p + j] = v;
+        for (int m = 0; m < PW; ++m) v += wrow[m] * ((m >= j) ? Gm[m * (m + 1) / 2 + j] : Gm[j * (j + 1) / 2 + m]);
+        if (i < p && j < p) w[i * p + j] = v;
       }
     }
   }
+  __syncthreads();
+  copy_out(Wt, out_off);
+  __syncthreads();
+  if (live) {
+#pragma unroll
+    for (int i = 0; i < PW; ++i)
+#pragma unroll
+      for (int j = 0; j < PW; ++j)
+        if (i < p && j < p) w[i * p + j] = (j <= i) ? Gm[i * (i + 1) / 2 + j] : Gm[j * (j + 1) / 2 + i];
+  }
+  __syncthreads();
+  copy_out(G, out_off);
 }
 
 // B = I + F^T Wt F (lower triangle) for the low-rank engine.  B is cut into 16-wide blocks that never straddle a

@@ -1678,7 +1678,7 @@ static int bin_blocks(pgpfa_ctx* c, const double* W, long long sW, double* G, do
     dispatch_pw(p, [&](auto pw) {
       constexpr int PW = decltype(pw)::value;
       if constexpr (PW <= 10) {
-        hipLaunchKernelGGL(bin_blocks_reg_kernel<PW>, dim3((unsigned)((items + 127) / 128)), dim3(128), 0, c->st, W, sW, G, Wt, sO, T, p, c->eps,
+        hipLaunchKernelGGL(bin_blocks_reg_kernel<PW>, dim3((unsigned)((items + BBR_MPB - 1) / BBR_MPB)), dim3(BBR_TPB), 0, c->st, W, sW, G, Wt, sO, T, p, c->eps,
                            c->ident, nslots, ldet);
         done = true;
       }
