@@ -199,6 +199,7 @@ struct pgpfa_ctx {
   bool last_cov_lowrank = false;
   bool shared_pcg = true;
   bool pcg_trace = false;
+  bool cross_kernel = true;                       // option cross_kernel = 0: the cross term of the split form through the general GEMM kernel
   bool measure_mix = false;                       // option measure_mix: record max_t eps ||Wt_t|| of every covariance pass
   bool time_newton = false;                       // option time_newton: HIP events around the inner PCG solves (last_newton_solve_ms / _bytes)
   int shared_min = 16, pcg_inner_min = 2, pcg_inner_max = 16, pcg_outer_max = 12;
@@ -1245,6 +1246,7 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
   else if (k == "use_mfma") c->mfma = (v != 0.0);
   else if (k == "cd_mfma") c->cd_mfma = (v != 0.0);
   else if (k == "cd_hess_mfma") c->cd_hess_mfma = (v != 0.0);
+  else if (k == "cross_kernel") c->cross_kernel = (v != 0.0);
   else if (k == "cd_debug") c->cd_debug = (int)v;
   else if (k == "pcg_fused") c->pcg_fused = (int)v;
   else if (k == "pcg_w32") c->pcg_w32 = (v != 0.0);
@@ -1900,7 +1902,30 @@ static int accumulate_split(pgpfa_ctx* c, const CholWS& lw, int nb, int ract, in
       return 0;
     };
     CHK(seg(spsS, false, Spart));
-    CHK(seg(sps, true, Xpart));
+    if (c->cross_kernel && c->mfma && rk % 16 == 0 && rk <= 128 && kw % 16 == 0 && (ldd & 3) == 0) {
+      // the cross term with all rk rows in one workgroup (split.h): no padded row tiles on the matrix cores
+      CrossArgs ca{};
+      ca.A = A0; ca.sM = lw.sM; ca.lda = rpad;
+      ca.D = D + (size_t)k * Ts + (size_t)r0 * ldd; ca.sD = sD; ca.ldd = ldd;
+      ca.C = Xpart; ca.sC = (long long)rk * T;
+      ca.rk = rk; ca.T = T; ca.kw = kw; ca.nslots = nb; ca.sps = sps;
+      const dim3 grid((T + 63) / 64, ngroups);
+      prof_begin(c, TAG_GEMM, 2.0 * (double)nb * rk * (double)kw * T);
+      switch (rk / 16) {
+        case 1: hipLaunchKernelGGL(cross_term_kernel<1>, grid, dim3(256), 0, c->st, ca); break;
+        case 2: hipLaunchKernelGGL(cross_term_kernel<2>, grid, dim3(256), 0, c->st, ca); break;
+        case 3: hipLaunchKernelGGL(cross_term_kernel<3>, grid, dim3(256), 0, c->st, ca); break;
+        case 4: hipLaunchKernelGGL(cross_term_kernel<4>, grid, dim3(256), 0, c->st, ca); break;
+        case 5: hipLaunchKernelGGL(cross_term_kernel<5>, grid, dim3(256), 0, c->st, ca); break;
+        case 6: hipLaunchKernelGGL(cross_term_kernel<6>, grid, dim3(256), 0, c->st, ca); break;
+        case 7: hipLaunchKernelGGL(cross_term_kernel<7>, grid, dim3(256), 0, c->st, ca); break;
+        default: hipLaunchKernelGGL(cross_term_kernel<8>, grid, dim3(256), 0, c->st, ca); break;
+      }
+      prof_end(c);
+      HIPC(hipGetLastError());
+    } else {
+      CHK(seg(sps, true, Xpart));
+    }
     const int ngS = (nb + spsS - 1) / spsS;
     hipLaunchKernelGGL(sum_groups_kernel, dim3((unsigned)(((size_t)rk * rk + 255) / 256)), dim3(256), 0, c->st, Spart, ngS, rk, rk, 32, Ssum);
     hipLaunchKernelGGL(sum_groups_kernel, dim3((unsigned)(((size_t)rk * T + 255) / 256)), dim3(256), 0, c->st, Xpart, ngroups, rk, T, 0, Xsum);

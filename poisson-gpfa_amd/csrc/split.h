@@ -253,6 +253,102 @@ __global__ __launch_bounds__(256, 2) void syrk_f16x2_kernel(SyrkF16Args a) {
   }
 }
 
+// Cross term of the split form for one latent:  X[g] (rk x T, column-major, ld = rk) = sum over the slots s of group g of
+//   A_s (rk x kw) D_s^T (kw x T),   A_s[i][b] = A[s sM + i + b lda]  (FP64: rows of latent k of L_s^-T right of its first column),
+//                                    D_s[b][t] = D[s sD + b ldd + t]  (the single-precision correction of latent k, its first kw columns used).
+// The general GEMM kernel walks this product in 64-row tiles; a latent's rank is a multiple of 16 between 16 and 128 here, so its
+// second row tile is mostly padding and the waves assigned to it idle (PMC: matrix cores busy half of the time).  This kernel gives a
+// workgroup ALL rk rows of a 64-column tile: wave w owns the 16 columns w of the tile and NTR = rk / 16 accumulator tiles, the k loop
+// runs over the group's slots and their kw columns in chunks of 16 staged in LDS (A rows contiguous, D widened to FP64 while it is
+// staged), double-buffered through registers.  Issued matrix-core work = the useful work.  grid = (ceil(T / 64), ngroups), block = 256.
+struct CrossArgs {
+  const double* A; long long sM; int lda;
+  const float* D; long long sD; int ldd;
+  double* C; long long sC;
+  int rk, T, kw, nslots, sps;
+};
+
+template <int NTR>
+__global__ __launch_bounds__(256) void cross_term_kernel(CrossArgs a) {
+  constexpr int GK = 16;
+  constexpr int RS = NTR * 16 + ((NTR & 1) ? 0 : 16);          // row stride of the A image: = 16 mod 32 (conflict-free 8-byte fragment reads)
+  constexpr int NA = (GK * NTR * 16 + 255) / 256;               // staged A elements per thread
+  __shared__ double As[2][GK][RS];
+  __shared__ double Bs[2][GK][64 + 16];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int t0 = blockIdx.x * 64;
+  const int g = blockIdx.y;
+  const int s_begin = g * a.sps, s_end = min(a.nslots, s_begin + a.sps);
+  const int cps = a.kw / GK;                                    // chunks per slot (kw is a multiple of 16)
+  const int nchunks = (s_end - s_begin) * cps;
+  const int rk = a.rk;
+
+  double ra[NA];
+  float rb[4];
+  auto load = [&](int chunk) {
+    const int s = s_begin + chunk / cps;
+    const int c0 = (chunk % cps) * GK;
+    const double* Ap = a.A + (size_t)s * a.sM + (size_t)c0 * a.lda;
+    const float* Dp = a.D + (size_t)s * a.sD + (size_t)c0 * a.ldd + t0;
+#pragma unroll
+    for (int u = 0; u < NA; ++u) {
+      const int e = tid + 256 * u;
+      const int kk = e / (NTR * 16), i = e - kk * (NTR * 16);
+      ra[u] = (kk < GK && i < rk) ? Ap[(size_t)kk * a.lda + i] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = tid + 256 * u;
+      const int kk = e >> 6, t = e & 63;
+      rb[u] = (t0 + t < a.T) ? Dp[(size_t)kk * a.ldd + t] : 0.f;
+    }
+  };
+  auto store = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < NA; ++u) {
+      const int e = tid + 256 * u;
+      const int kk = e / (NTR * 16), i = e - kk * (NTR * 16);
+      if (kk < GK) As[buf][kk][i] = ra[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = tid + 256 * u;
+      Bs[buf][e >> 6][e & 63] = (double)rb[u];
+    }
+  };
+  mdouble4 acc[NTR];
+#pragma unroll
+  for (int mi = 0; mi < NTR; ++mi) acc[mi] = mdouble4{0.0, 0.0, 0.0, 0.0};
+  if (nchunks > 0) { load(0); store(0); }
+  __syncthreads();
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int buf = ch & 1;
+    if (ch + 1 < nchunks) load(ch + 1);
+#pragma unroll
+    for (int kk = 0; kk < GK; kk += 4) {
+      const double bf = Bs[buf][kk + l4][wave * 16 + l15];
+#pragma unroll
+      for (int mi = 0; mi < NTR; ++mi) acc[mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf, As[buf][kk + l4][mi * 16 + l15], acc[mi], 0, 0, 0);
+    }
+    if (ch + 1 < nchunks) store(buf ^ 1);
+    __syncthreads();
+  }
+  // issued as (D fragment) x (A fragment): result row 4 r + l4... of the FP64 shape is l4 + 4 r  <->  column t, result column l15  <->  row i
+  double* C = a.C + (size_t)g * a.sC;
+#pragma unroll
+  for (int mi = 0; mi < NTR; ++mi) {
+    const int i = mi * 16 + l15;
+    if (i >= rk) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int t = t0 + wave * 16 + l4 + 4 * r;
+      if (t < a.T) C[(size_t)t * rk + i] = acc[mi][r];
+    }
+  }
+}
+
 // out[M x N] (ld = M) = sum over g < ngroups of part[g][M x N]; with lower > 0 (M == N) the parts hold only the wave tiles
 // (i / lower) >= (j / lower) of a symmetric matrix (GEMM_LOWER on 64 x 64 workgroup tiles skips 32 x 32 wave tiles) and the rest is
 // mirrored.  grid = ceil(M N / 256), block = 256.
