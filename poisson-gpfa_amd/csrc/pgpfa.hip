@@ -1902,25 +1902,16 @@ static int accumulate_split(pgpfa_ctx* c, const CholWS& lw, int nb, int ract, in
       return 0;
     };
     CHK(seg(spsS, false, Spart));
-    if (c->cross_kernel && c->mfma && rk % 16 == 0 && rk <= 128 && kw % 16 == 0 && (ldd & 3) == 0) {
+    // (the S sums stay with the general kernel: through cross_term_kernel<.., double, true> - lower 16 x 16 tiles only - they ran no faster)
+    if (c->cross_kernel && c->mfma && rk % 16 == 0 && rk <= 128 && kw % 16 == 0) {
       // the cross term with all rk rows in one workgroup (split.h): no padded row tiles on the matrix cores
       CrossArgs ca{};
       ca.A = A0; ca.sM = lw.sM; ca.lda = rpad;
       ca.D = D + (size_t)k * Ts + (size_t)r0 * ldd; ca.sD = sD; ca.ldd = ldd;
       ca.C = Xpart; ca.sC = (long long)rk * T;
       ca.rk = rk; ca.T = T; ca.kw = kw; ca.nslots = nb; ca.sps = sps;
-      const dim3 grid((T + 63) / 64, ngroups);
       prof_begin(c, TAG_GEMM, 2.0 * (double)nb * rk * (double)kw * T);
-      switch (rk / 16) {
-        case 1: hipLaunchKernelGGL(cross_term_kernel<1>, grid, dim3(256), 0, c->st, ca); break;
-        case 2: hipLaunchKernelGGL(cross_term_kernel<2>, grid, dim3(256), 0, c->st, ca); break;
-        case 3: hipLaunchKernelGGL(cross_term_kernel<3>, grid, dim3(256), 0, c->st, ca); break;
-        case 4: hipLaunchKernelGGL(cross_term_kernel<4>, grid, dim3(256), 0, c->st, ca); break;
-        case 5: hipLaunchKernelGGL(cross_term_kernel<5>, grid, dim3(256), 0, c->st, ca); break;
-        case 6: hipLaunchKernelGGL(cross_term_kernel<6>, grid, dim3(256), 0, c->st, ca); break;
-        case 7: hipLaunchKernelGGL(cross_term_kernel<7>, grid, dim3(256), 0, c->st, ca); break;
-        default: hipLaunchKernelGGL(cross_term_kernel<8>, grid, dim3(256), 0, c->st, ca); break;
-      }
+      cross_term_launch<float, false>(ca, dim3((T + 63) / 64, ngroups), c->st);
       prof_end(c);
       HIPC(hipGetLastError());
     } else {

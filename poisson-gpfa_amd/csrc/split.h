@@ -263,12 +263,15 @@ __global__ __launch_bounds__(256, 2) void syrk_f16x2_kernel(SyrkF16Args a) {
 // staged), double-buffered through registers.  Issued matrix-core work = the useful work.  grid = (ceil(T / 64), ngroups), block = 256.
 struct CrossArgs {
   const double* A; long long sM; int lda;
-  const float* D; long long sD; int ldd;
+  const void* D; long long sD; int ldd;       // the column-side operand: float (the correction D) or double (A itself: the first term's S_k = sum A A^T)
   double* C; long long sC;
   int rk, T, kw, nslots, sps;
 };
 
-template <int NTR>
+// TB = float: the cross term as described above.  TB = double, LOWER: the same loop with D := A (column n of the result <-> row n of A), i.e.
+// S[g] = sum_s A_s A_s^T (rk x rk); the 16 x 16 tiles above the diagonal are not issued (row tile mi < the wave's column tile), their
+// entries are left untouched - the consumer reads the lower 32 x 32 blocks and mirrors the rest.
+template <int NTR, typename TB, bool LOWER>
 __global__ __launch_bounds__(256) void cross_term_kernel(CrossArgs a) {
   constexpr int GK = 16;
   constexpr int RS = NTR * 16 + ((NTR & 1) ? 0 : 16);          // row stride of the A image: = 16 mod 32 (conflict-free 8-byte fragment reads)
@@ -284,14 +287,17 @@ __global__ __launch_bounds__(256) void cross_term_kernel(CrossArgs a) {
   const int cps = a.kw / GK;                                    // chunks per slot (kw is a multiple of 16)
   const int nchunks = (s_end - s_begin) * cps;
   const int rk = a.rk;
+  const TB* Dall = reinterpret_cast<const TB*>(a.D);
+  const int ct = blockIdx.x * 4 + wave;                         // this wave's column tile of 16
+  const bool wave_live = t0 + wave * 16 < a.T;
 
   double ra[NA];
-  float rb[4];
+  TB rb[4];
   auto load = [&](int chunk) {
     const int s = s_begin + chunk / cps;
     const int c0 = (chunk % cps) * GK;
     const double* Ap = a.A + (size_t)s * a.sM + (size_t)c0 * a.lda;
-    const float* Dp = a.D + (size_t)s * a.sD + (size_t)c0 * a.ldd + t0;
+    const TB* Dp = Dall + (size_t)s * a.sD + (size_t)c0 * a.ldd + t0;
 #pragma unroll
     for (int u = 0; u < NA; ++u) {
       const int e = tid + 256 * u;
@@ -302,7 +308,7 @@ __global__ __launch_bounds__(256) void cross_term_kernel(CrossArgs a) {
     for (int u = 0; u < 4; ++u) {
       const int e = tid + 256 * u;
       const int kk = e >> 6, t = e & 63;
-      rb[u] = (t0 + t < a.T) ? Dp[(size_t)kk * a.ldd + t] : 0.f;
+      rb[u] = (t0 + t < a.T) ? Dp[(size_t)kk * a.ldd + t] : (TB)0;
     }
   };
   auto store = [&](int buf) {
@@ -326,26 +332,44 @@ __global__ __launch_bounds__(256) void cross_term_kernel(CrossArgs a) {
   for (int ch = 0; ch < nchunks; ++ch) {
     const int buf = ch & 1;
     if (ch + 1 < nchunks) load(ch + 1);
+    if (wave_live) {
 #pragma unroll
-    for (int kk = 0; kk < GK; kk += 4) {
-      const double bf = Bs[buf][kk + l4][wave * 16 + l15];
+      for (int kk = 0; kk < GK; kk += 4) {
+        const double bf = Bs[buf][kk + l4][wave * 16 + l15];
 #pragma unroll
-      for (int mi = 0; mi < NTR; ++mi) acc[mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf, As[buf][kk + l4][mi * 16 + l15], acc[mi], 0, 0, 0);
+        for (int mi = 0; mi < NTR; ++mi)
+          if (!LOWER || mi >= ct) acc[mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf, As[buf][kk + l4][mi * 16 + l15], acc[mi], 0, 0, 0);
+      }
     }
     if (ch + 1 < nchunks) store(buf ^ 1);
     __syncthreads();
   }
-  // issued as (D fragment) x (A fragment): result row 4 r + l4... of the FP64 shape is l4 + 4 r  <->  column t, result column l15  <->  row i
+  // issued as (column-side fragment) x (A fragment): result row l4 + 4 r  <->  column t, result column l15  <->  row i
+  if (!wave_live) return;
   double* C = a.C + (size_t)g * a.sC;
 #pragma unroll
   for (int mi = 0; mi < NTR; ++mi) {
     const int i = mi * 16 + l15;
-    if (i >= rk) continue;
+    if (i >= rk || (LOWER && mi < ct)) continue;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int t = t0 + wave * 16 + l4 + 4 * r;
       if (t < a.T) C[(size_t)t * rk + i] = acc[mi][r];
     }
+  }
+}
+
+template <typename TB, bool LOWER>
+inline void cross_term_launch(const CrossArgs& ca, dim3 grid, hipStream_t st) {
+  switch (ca.rk / 16) {
+    case 1: hipLaunchKernelGGL((cross_term_kernel<1, TB, LOWER>), grid, dim3(256), 0, st, ca); break;
+    case 2: hipLaunchKernelGGL((cross_term_kernel<2, TB, LOWER>), grid, dim3(256), 0, st, ca); break;
+    case 3: hipLaunchKernelGGL((cross_term_kernel<3, TB, LOWER>), grid, dim3(256), 0, st, ca); break;
+    case 4: hipLaunchKernelGGL((cross_term_kernel<4, TB, LOWER>), grid, dim3(256), 0, st, ca); break;
+    case 5: hipLaunchKernelGGL((cross_term_kernel<5, TB, LOWER>), grid, dim3(256), 0, st, ca); break;
+    case 6: hipLaunchKernelGGL((cross_term_kernel<6, TB, LOWER>), grid, dim3(256), 0, st, ca); break;
+    case 7: hipLaunchKernelGGL((cross_term_kernel<7, TB, LOWER>), grid, dim3(256), 0, st, ca); break;
+    default: hipLaunchKernelGGL((cross_term_kernel<8, TB, LOWER>), grid, dim3(256), 0, st, ca); break;
   }
 }
 
