@@ -1903,16 +1903,19 @@ static int accumulate_split(pgpfa_ctx* c, const CholWS& lw, int nb, int ract, in
     };
     CHK(seg(spsS, false, Spart));
     // (the S sums stay with the general kernel: through cross_term_kernel<.., double, true> - lower 16 x 16 tiles only - they ran no faster)
-    if (c->cross_kernel && c->mfma && rk % 16 == 0 && rk <= 128 && kw % 16 == 0) {
-      // the cross term with all rk rows in one workgroup (split.h): no padded row tiles on the matrix cores
-      CrossArgs ca{};
-      ca.A = A0; ca.sM = lw.sM; ca.lda = rpad;
-      ca.D = D + (size_t)k * Ts + (size_t)r0 * ldd; ca.sD = sD; ca.ldd = ldd;
-      ca.C = Xpart; ca.sC = (long long)rk * T;
-      ca.rk = rk; ca.T = T; ca.kw = kw; ca.nslots = nb; ca.sps = sps;
-      prof_begin(c, TAG_GEMM, 2.0 * (double)nb * rk * (double)kw * T);
-      cross_term_launch<float, false>(ca, dim3((T + 63) / 64, ngroups), c->st);
-      prof_end(c);
+    if (c->cross_kernel && c->mfma && rk % 16 == 0 && kw % 16 == 0) {
+      // the cross term with (up to 128) rows of the latent in one workgroup (split.h): no padded row tiles on the matrix cores
+      for (int row0 = 0; row0 < rk; row0 += 128) {
+        CrossArgs ca{};
+        ca.A = A0; ca.sM = lw.sM; ca.lda = rpad;
+        ca.D = D + (size_t)k * Ts + (size_t)r0 * ldd; ca.sD = sD; ca.ldd = ldd;
+        ca.C = Xpart; ca.sC = (long long)rk * T;
+        ca.rk = std::min(128, rk - row0); ca.T = T; ca.kw = kw; ca.nslots = nb; ca.sps = sps;
+        ca.row0 = row0; ca.ldc = rk;
+        prof_begin(c, TAG_GEMM, 2.0 * (double)nb * ca.rk * (double)kw * T);
+        cross_term_launch<float, false>(ca, dim3((T + 63) / 64, ngroups), c->st);
+        prof_end(c);
+      }
       HIPC(hipGetLastError());
     } else {
       CHK(seg(sps, true, Xpart));

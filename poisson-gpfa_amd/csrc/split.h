@@ -266,6 +266,7 @@ struct CrossArgs {
   const void* D; long long sD; int ldd;       // the column-side operand: float (the correction D) or double (A itself: the first term's S_k = sum A A^T)
   double* C; long long sC;
   int rk, T, kw, nslots, sps;
+  int row0, ldc;                                // this launch's first row of A / X and the row count of X (ranks above 128: one launch per 128 rows)
 };
 
 // TB = float: the cross term as described above.  TB = double, LOWER: the same loop with D := A (column n of the result <-> row n of A), i.e.
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(256) void cross_term_kernel(CrossArgs a) {
   auto load = [&](int chunk) {
     const int s = s_begin + chunk / cps;
     const int c0 = (chunk % cps) * GK;
-    const double* Ap = a.A + (size_t)s * a.sM + (size_t)c0 * a.lda;
+    const double* Ap = a.A + (size_t)s * a.sM + (size_t)c0 * a.lda + a.row0;
     const TB* Dp = Dall + (size_t)s * a.sD + (size_t)c0 * a.ldd + t0;
 #pragma unroll
     for (int u = 0; u < NA; ++u) {
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(256) void cross_term_kernel(CrossArgs a) {
   }
   // issued as (column-side fragment) x (A fragment): result row l4 + 4 r  <->  column t, result column l15  <->  row i
   if (!wave_live) return;
-  double* C = a.C + (size_t)g * a.sC;
+  double* C = a.C + (size_t)g * a.sC + a.row0;
 #pragma unroll
   for (int mi = 0; mi < NTR; ++mi) {
     const int i = mi * 16 + l15;
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(256) void cross_term_kernel(CrossArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int t = t0 + wave * 16 + l4 + 4 * r;
-      if (t < a.T) C[(size_t)t * rk + i] = acc[mi][r];
+      if (t < a.T) C[(size_t)t * a.ldc + i] = acc[mi][r];
     }
   }
 }
