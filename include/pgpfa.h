@@ -72,8 +72,8 @@ int pgpfa_destroy(pgpfa_ctx* ctx);
  * "time_newton" (0; 1: HIP events around the inner solves -> info "last_newton_solve_ms" / "last_newton_solve_bytes"),
  * "small_tile_below" (2^30: products with fewer 128 x 128 tiles than this run on 64 x 64 workgroup tiles - i.e. all; 0: never),
  * "splitk_below64" (160: products on 64 x 64 tiles are cut along k only below this many tiles),
- * "cross_kernel" (1: the cross term of that split form in a kernel with all rows of a latent in one workgroup, ranks up to 128
- * per latent; 0: through the general GEMM kernel),
+ * "cross_kernel" (1: the cross term of that split form in a kernel with all rows of a latent in one workgroup, 128 rows per
+ * launch; 0: through the general GEMM kernel),
  * "split_cov" (1: the sum over trials of the T x T covariance blocks by the exact split form of csrc/split.h - FP64 cross term, FP16
  * two-half product for the second-order term - while the root mean square of eps ||Wt_t|| stays below "split_max_norm" (0.07);
  * 0: always the full-width FP64 product), "measure_mix" (0; 1: record eps ||Wt_t|| -> info "last_eps_wt_norm" / "last_eps_wt_rms"),
