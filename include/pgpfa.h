@@ -79,12 +79,17 @@ int pgpfa_destroy(pgpfa_ctx* ctx);
  * 0: always the full-width FP64 product), "measure_mix" (0; 1: record eps ||Wt_t|| -> info "last_eps_wt_norm" / "last_eps_wt_rms"),
  * "workspace_headroom" (2.0: a low-rank workspace plan leaves room for the ranks to grow by this factor before it is re-made),
  * "workspace_vmm" (1: the chunk workspace is a reserved address range that grows by mapping memory; 0: plain allocations; before
- * the first E-step), "workspace_granule_mb" (1024: size of the mapped chunks). */
+ * the first E-step), "workspace_granule_mb" (1024: size of the mapped chunks),
+ * "chord_max" (most chord steps of the per-trial fallback Newton on one factor), "slab_row_align" (1: rows of latent k of the low-rank
+ * slab start on 128-byte lines), "dual_gemm" (1: the neuron contractions of the dual evaluation as GEMMs against a pair / loading table),
+ * "cd_debug" (0; measurement only: bit switches that drop the exp / the products / the staging of the (C,d) kernels, tools/cd_probe.py). */
 int pgpfa_set_option(pgpfa_ctx* ctx, const char* key, double value);
 /* Info: "chunk_trials", "plan_lowrank", "n_pad", "lowrank_rtot", "last_estep_ms", "last_newton_factorizations",
  * "last_newton_solves", "last_pcg_iterations", "last_shared_factorizations", "last_cov_lowrank",
  * "last_dense_retries", "hbm_bytes_allocated", "n_trials_global", "prof_<tag>_{ms,flops,launches}", "counts_two_bytes",
- * "arena_bytes", "last_split_cov", "last_eps_wt_norm", "last_eps_wt_rms", "last_newton_solve_ms", "last_newton_solve_bytes". */
+ * "arena_bytes", "last_split_cov", "last_eps_wt_norm", "last_eps_wt_rms", "last_newton_solve_ms", "last_newton_solve_bytes",
+ * "arena_vmm_failed" (1 once the virtual-memory arena fell back to plain allocations), "last_newton_max_iter", "last_dual_evaluations",
+ * "last_loo_unconverged". */
 int pgpfa_get_info(pgpfa_ctx* ctx, const char* key, double* value);
 
 /* ---- data ---------------------------------------------------------------------- */

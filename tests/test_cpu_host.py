@@ -266,3 +266,15 @@ def test_bench_launcher_stops_all_ranks_when_one_dies():
     env = dict(os.environ, PGPFA_DRYRUN_HANG='0', PGPFA_BENCH_TIMEOUT='3')
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run'], env=env, capture_output=True, text=True, timeout=120)
     assert out.returncode != 0 and 'timeout after 3 s' in out.stderr, out
+
+
+def test_header_documents_every_option_and_info_key():
+    """include/pgpfa.h is the C-ABI's documentation: every key pgpfa_set_option accepts and every info key the library sets is named there."""
+    import re
+    src = open(os.path.join(ROOT, 'poisson-gpfa_amd', 'csrc', 'pgpfa.hip')).read()
+    hdr = open(os.path.join(ROOT, 'include', 'pgpfa.h')).read()
+    options = sorted(set(re.findall(r'k == "([a-z0-9_]+)"', src)))
+    infos = sorted(set(re.findall(r'c->info\["([a-z0-9_]+)"\]', src)))
+    assert len(options) > 30 and len(infos) > 15
+    missing = [k for k in options + infos if '"%s"' % k not in hdr]
+    assert not missing, missing
