@@ -3158,12 +3158,9 @@ int pgpfa_mstep_cd_newton_pass(pgpfa_ctx* c, const double* vecCd, const double* 
         const int ntt = (T + CdH<PW>::BT - 1) / CdH<PW>::BT;
         const int tiles = (q + 15) / 16, groups = (tiles + CDH_NW - 1) / CDH_NW, tpg = (tiles + groups - 1) / groups;
         nby = std::max(1, std::min(a.ntr * ntt, std::min(128, std::max(64, 512 / groups))));
-        static bool attr_set = false;
-        if (!attr_set) {
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mstep_cd_hess_mfma_kernel<PW>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)cd_hess_mfma_lds_bytes<PW>());
-          attr_set = true;
-        }
+        // (per launch: the attribute belongs to the function object of the current device, and contexts of one process may sit on different devices)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mstep_cd_hess_mfma_kernel<PW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)cd_hess_mfma_lds_bytes<PW>());
         hipLaunchKernelGGL(mstep_cd_hess_mfma_kernel<PW>, dim3(nby, groups), dim3(64, CDH_NW), cd_hess_mfma_lds_bytes<PW>(), c->st, a, tpg);
         return;
       }
