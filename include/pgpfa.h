@@ -76,7 +76,9 @@ int pgpfa_destroy(pgpfa_ctx* ctx);
  * launch; 0: through the general GEMM kernel),
  * "split_cov" (1: the sum over trials of the T x T covariance blocks by the exact split form of csrc/split.h - FP64 cross term, FP16
  * two-half product for the second-order term - while the root mean square of eps ||Wt_t|| stays below "split_max_norm" (0.07);
- * 0: always the full-width FP64 product), "measure_mix" (0; 1: record eps ||Wt_t|| -> info "last_eps_wt_norm" / "last_eps_wt_rms"),
+ * 0: always the full-width FP64 product), "measure_mix" (0; 1: measure eps ||Wt_t|| in every covariance pass, also where the split form is not a candidate -> info
+ * "last_eps_wt_norm" / "last_eps_wt_rms": the maximum over the chunks of the LAST pgpfa_estep_laplace / pgpfa_dual_finalize call of the
+ * largest and of the root-mean-square value over (trial, bin); reset at the start of those calls),
  * "workspace_headroom" (2.0: a low-rank workspace plan leaves room for the ranks to grow by this factor before it is re-made),
  * "workspace_vmm" (1: the chunk workspace is a reserved address range that grows by mapping memory; 0: plain allocations; before
  * the first E-step), "workspace_granule_mb" (1024: size of the mapped chunks),

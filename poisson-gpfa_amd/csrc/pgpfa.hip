@@ -34,6 +34,7 @@ using namespace pgpfa;
 namespace {
 
 thread_local std::string g_err;
+thread_local unsigned long long g_fail_count = 0;   // failures reported on this thread (queued read-backs of a failed call are void: dl_enqueue / dl_flush)
 
 int fail(const char* fmt, ...) {
   char buf[1024];
@@ -42,6 +43,7 @@ int fail(const char* fmt, ...) {
   vsnprintf(buf, sizeof(buf), fmt, ap);
   va_end(ap);
   g_err = buf;
+  ++g_fail_count;
   return 1;
 }
 
@@ -220,6 +222,7 @@ struct pgpfa_ctx {
   struct DlEntry { void* host; size_t off, bytes; };
   PcgCtl fused_ctl_host{};
   char* dl_stage = nullptr; size_t dl_used = 0; std::vector<DlEntry> dl_pending;   // pinned staging of small read-backs (dl_enqueue / dl_flush)
+  unsigned long long dl_fail_mark = 0;           // g_fail_count when the oldest pending read-back was queued
   int* hibuf = nullptr; size_t hibuf_len = 0;
   // ring of pinned staging slots for small host -> device uploads that must not cost a stream synchronisation each (Newton driver)
   char* ring = nullptr; size_t ring_slot = 0; int ring_cur = 0, ring_pending = 0;
@@ -797,9 +800,21 @@ int upload_list(pgpfa_ctx* c, int* dst, const std::vector<int>& v) {
 // another stream operation.  Small read-backs therefore land in a pinned staging area and are copied out after ONE synchronisation:
 // dl_enqueue queues a copy (several may be queued back to back), dl_flush waits and hands the bytes out.
 constexpr size_t DL_STAGE_BYTES = (size_t)4 << 20;
+// The queue holds raw host pointers (stack locals, vector buffers, caller arrays) that are only good inside the call that queued them: a
+// failure between dl_enqueue and dl_flush - a CHK / HIPC that returned, or the synchronisation below - voids the whole queue, so that no later
+// flush copies into memory that call has given back (dl_drop_stale: anything queued before the last fail() of this thread is dropped).
+static void dl_drop_stale(pgpfa_ctx* c) {
+  if (!c->dl_pending.empty() && c->dl_fail_mark != g_fail_count) { c->dl_pending.clear(); c->dl_used = 0; }
+}
 int dl_flush(pgpfa_ctx* c) {
-  HIPC(hipStreamSynchronize(c->st));
+  dl_drop_stale(c);
+  const hipError_t e_sync = hipStreamSynchronize(c->st);
   c->ring_pending = 0;
+  if (e_sync != hipSuccess) {
+    c->dl_pending.clear();
+    c->dl_used = 0;
+    return fail("%s:%d hipStreamSynchronize -> %s", __FILE__, __LINE__, hipGetErrorString(e_sync));
+  }
   for (const auto& e : c->dl_pending) std::memcpy(e.host, c->dl_stage + e.off, e.bytes);
   c->dl_pending.clear();
   c->dl_used = 0;
@@ -818,8 +833,10 @@ int dl_enqueue(pgpfa_ctx* c, void* host, const void* dev, size_t bytes) {
     if (e_copy != hipSuccess) return fail("device-to-host copy of %zu bytes: %s", bytes, hipGetErrorString(e_copy));
     return dl_flush(c);
   }
+  dl_drop_stale(c);
   if (c->dl_used + need > DL_STAGE_BYTES) CHK(dl_flush(c));
   HIPC(hipMemcpyAsync(c->dl_stage + c->dl_used, dev, bytes, hipMemcpyDeviceToHost, c->st));
+  if (c->dl_pending.empty()) c->dl_fail_mark = g_fail_count;
   c->dl_pending.push_back({host, c->dl_used, bytes});
   c->dl_used += need;
   return 0;
@@ -1407,9 +1424,17 @@ static int upload_counts_wide(pgpfa_ctx* c, const TS* Y) {
   }
   hipFree(tmp);
   hipFree(flags);
-  if (rc) return rc;
-  HIPC(hipGetLastError());
-  if (hf[0]) return fail("spike counts must be integers in [0, 65535]");
+  // from the first piece on, c->Y holds a mixture of old and new (or clamped) counts and the old high plane is gone: on ANY failure the
+  // context has no counts and nothing derived from the old ones survives (a caller that catches the error must upload again)
+  const hipError_t e_last = hipGetLastError();
+  if (rc || e_last != hipSuccess || hf[0]) {
+    c->have_counts = false;
+    counts_changed(c, nullptr);
+    c->info["counts_two_bytes"] = 0.0;
+    if (rc) return rc;
+    if (e_last != hipSuccess) return fail("count upload: %s", hipGetErrorString(e_last));
+    return fail("spike counts must be integers in [0, 65535]");
+  }
   c->have_counts = true;
   counts_changed(c, nullptr);
   c->info["counts_two_bytes"] = c->Yhi ? 1.0 : 0.0;
@@ -1649,7 +1674,9 @@ static int shared_solve(pgpfa_ctx* c, int nb, const double* R, double* Z, const 
     GemmP z{};                                               // Zs = Sb Y
     z.skip = skip;
     z.A = c->sU; z.sA = 0; z.lda = rpad; z.B = c->Glt; z.sB = 0; z.ldb = c->ld; z.C = c->KD; z.sC = 0; z.ldc = c->ld;
-    z.M = rpad; z.N = ng; z.K = rpad; z.cols = cols; z.alpha = 1.0; z.beta = 0.0; z.slots = nullptr; z.nbatch = 1; z.mode = GEMM_FULL; z.kflags = 0;
+    // (K = rtot, a multiple of 16: the row tiles of Y above stop at roff[p] = rtot, rows [rtot, rpad) of c->Glt are never written and may hold
+    //  anything - the buffer doubles as the line search's trial gradient and is re-carved from the arena by every re-plan)
+    z.M = rpad; z.N = ng; z.K = c->rtot; z.cols = cols; z.alpha = 1.0; z.beta = 0.0; z.slots = nullptr; z.nbatch = 1; z.mode = GEMM_FULL; z.kflags = 0;
     CHK(gemm(c, true, z));
     GemmP q{};                                               // Q = F Zs                (n x nb)
     q.skip = skip;
@@ -2683,6 +2710,7 @@ int pgpfa_estep_laplace(pgpfa_ctx* c, int n, const int32_t* idx, int warm_start,
   HIPC(hipSetDevice(c->device));
   c->pacc_used = false; c->pacc_valid = false;
   c->estep_serial += 1;
+  c->info["last_eps_wt_norm"] = 0.0; c->info["last_eps_wt_rms"] = 0.0;      // maxima over the chunks of THIS call
   HIPC(hipMemsetAsync(c->Pacc, 0, (size_t)c->Tp * c->Tp * c->p * sizeof(double), c->st));
   snapshot_params(c, tr.v);
   for (int t : tr.v) c->trial_dual[t] = 0;
@@ -3913,6 +3941,7 @@ int pgpfa_dual_finalize(pgpfa_ctx* c, int n, const int32_t* idx, const double* l
   // Laplace E-step - only the sum over trials of post_vsmGP is accumulated unless keep_trial_vsmgp is set
   const bool sum_only = c->plan_lowrank && !c->keep_trial_vsmgp;
   c->pacc_used = false; c->pacc_valid = false;
+  c->info["last_eps_wt_norm"] = 0.0; c->info["last_eps_wt_rms"] = 0.0;      // maxima over the chunks of THIS call
   HIPC(hipMemsetAsync(c->Pacc, 0, (size_t)c->Tp * c->Tp * c->p * sizeof(double), c->st));
   snapshot_params(c, tr.v);
   if (!c->lam_keep) {

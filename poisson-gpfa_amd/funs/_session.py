@@ -61,18 +61,23 @@ class _World:
     def exchange_unique_id(self):
         """Rendezvous of this single-node job through files; returns (RCCL unique id, path of the id file).
 
-        Rank 0 creates the unique id and publishes it; every other rank reads it and acknowledges; rank 0 waits for ALL
-        acknowledgements and only then publishes the go-ahead the others wait for.  Nobody enters ncclCommInitRank (which
-        blocks without a timeout until every rank has joined) before every rank is known to be alive and to hold the same
-        id: a rank that died at start-up (bad device, out of memory while creating its context) or was never started makes
-        every other rank raise after PGPFA_RDZV_TIMEOUT seconds (default 300) - a non-zero exit of the whole job instead of
-        a hang.  File names are keyed by MASTER_PORT, the launcher's run id and pid (shared parent of all ranks) and a
-        per-process serial; a file older than this process by more than two minutes is a leftover of an earlier job that
-        happened to get the same key and is ignored."""
+        Rank 0 removes whatever an earlier attempt left under the same key, creates the unique id and publishes it; every
+        other rank reads it and acknowledges WITH ITS CONTENT; rank 0 waits until every acknowledgement carries the id it
+        published (an acknowledgement of an older id is not one) and only then publishes the go-ahead, again with the id.
+        A non-zero rank never trusts a single read: it keeps re-reading the id file, acknowledges again when the id
+        changed under it (it had read a leftover before rank 0 replaced it), and leaves only when the go-ahead carries the
+        id it holds - a leftover go-ahead of another attempt is waited out, not an error.  Nobody enters ncclCommInitRank
+        (which blocks without a timeout until every rank has joined) before every rank is known to be alive and to hold
+        the same id: a rank that died at start-up (bad device, out of memory while creating its context) or was never
+        started makes every other rank raise after PGPFA_RDZV_TIMEOUT seconds (default 300) - a non-zero exit of the whole
+        job instead of a hang.  File names are keyed by MASTER_PORT, the launcher's run id, its restart count
+        (TORCHELASTIC_RESTART_COUNT: a restarted worker group is another attempt) and pid (shared parent of all ranks)
+        and a per-process serial.  A file older than this process by more than the timeout cannot belong to this attempt
+        (rank 0 gives up that long after publishing) and is ignored."""
         self._serial += 1
         base = os.environ.get('PGPFA_RDZV_DIR', '/tmp')
-        key = 'pgpfa_uid_%s_%s_%d_%d' % (os.environ.get('MASTER_PORT', '0'),
-                                        os.environ.get('TORCHELASTIC_RUN_ID', 'none'), os.getppid(), self._serial)
+        key = 'pgpfa_uid_%s_%s_%s_%d_%d' % (os.environ.get('MASTER_PORT', '0'), os.environ.get('TORCHELASTIC_RUN_ID', 'none'),
+                                           os.environ.get('TORCHELASTIC_RESTART_COUNT', '0'), os.getppid(), self._serial)
         path = os.path.join(base, key)
         timeout = float(os.environ.get('PGPFA_RDZV_TIMEOUT', '300'))
         deadline = time.time() + timeout
@@ -83,37 +88,39 @@ class _World:
                 fh.write(payload)
             os.replace(tmp, name)
 
-        def fresh(name):
+        def read_fresh(name):
+            """Content of a file that can belong to this attempt, else None."""
             try:
-                return os.path.getmtime(name) >= _PROCESS_START - 120.0
+                if os.path.getmtime(name) < _PROCESS_START - timeout - 5.0:
+                    return None
+                with open(name, 'rb') as fh:
+                    return fh.read()
             except OSError:
-                return False
+                return None
 
-        def wait_for(names, what):
-            while time.time() < deadline:
-                if all(os.path.exists(nm) and fresh(nm) for nm in names):
-                    return
-                time.sleep(0.01)
-            missing = [nm for nm in names if not (os.path.exists(nm) and fresh(nm))]
-            raise _hip.HipBackendError('rendezvous of rank %d timed out after %.0f s waiting for %s (%s): a rank died at start-up or was '
-                                       'never launched' % (self.rank, timeout, what, ', '.join(os.path.basename(m) for m in missing)))
+        def timed_out(what, names):
+            return _hip.HipBackendError('rendezvous of rank %d timed out after %.0f s waiting for %s (%s): a rank died at start-up or was '
+                                        'never launched' % (self.rank, timeout, what, ', '.join(os.path.basename(m) for m in names)))
         acks = [path + '.ack.%d' % r for r in range(1, self.size)]
         if self.rank == 0:
-            for stale in acks + [path + '.go']:
+            for stale in [path, path + '.go'] + acks:
                 try:
                     os.remove(stale)
                 except OSError:
                     pass
             uid = _hip.comm_unique_id()
             publish(path, uid)
-            try:
-                wait_for(acks, 'the acknowledgement of every rank')
-            except _hip.HipBackendError:
-                try:
-                    os.remove(path)
-                except OSError:
-                    pass
-                raise
+            while True:
+                missing = [nm for nm in acks if read_fresh(nm) != uid]
+                if not missing:
+                    break
+                if time.time() >= deadline:
+                    try:
+                        os.remove(path)
+                    except OSError:
+                        pass
+                    raise timed_out('the acknowledgement of every rank', missing)
+                time.sleep(0.01)
             publish(path + '.go', uid)
             for nm in acks:
                 try:
@@ -121,17 +128,19 @@ class _World:
                 except OSError:
                     pass
             return uid, path
-        wait_for([path], "rank 0's unique id")
-        with open(path, 'rb') as fh:
-            uid = fh.read()
-        if len(uid) != 128:
-            raise _hip.HipBackendError('malformed RCCL unique id at %s' % path)
-        publish(path + '.ack.%d' % self.rank, uid)
-        wait_for([path + '.go'], "rank 0's go-ahead")
-        with open(path + '.go', 'rb') as fh:
-            if fh.read() != uid:
-                raise _hip.HipBackendError('rendezvous mismatch: the go-ahead at %s.go carries another unique id' % path)
-        return uid, path
+        held = None
+        while True:
+            uid = read_fresh(path)
+            if uid is not None and len(uid) == 128:
+                if uid != held:
+                    publish(path + '.ack.%d' % self.rank, uid)
+                    held = uid
+                if read_fresh(path + '.go') == held:
+                    # the go-ahead is written after every rank acknowledged THIS id, and rank 0 publishes one id per attempt
+                    return held, path
+            if time.time() >= deadline:
+                raise timed_out("rank 0's unique id" if held is None else "rank 0's go-ahead", [path if held is None else path + '.go'])
+            time.sleep(0.01)
 
 
 WORLD = _World()

@@ -243,7 +243,7 @@ def test_rendezvous_handshake_and_timeouts(tmp_path):
     assert [pr.returncode for pr in procs] == [7, 7], outs
     assert 'acknowledgement' in outs[0][1] and 'go-ahead' in outs[1][1]
     # rank 0 never publishes; a leftover id file with the same key but an old timestamp lies around
-    key = 'pgpfa_uid_41003_none_%d_1' % os.getpid()
+    key = 'pgpfa_uid_41003_none_0_%d_1' % os.getpid()
     stale = tmp_path / key
     stale.write_bytes(bytes(128))
     old = os.path.getmtime(str(stale)) - 3600
@@ -251,6 +251,43 @@ def test_rendezvous_handshake_and_timeouts(tmp_path):
     pr = _rdzv_rank(tmp_path, 1, 2, 41003, 3)
     out = pr.communicate(timeout=120)
     assert pr.returncode == 7 and "rank 0's unique id" in out[1], out
+
+
+def test_rendezvous_survives_leftovers_of_a_restarted_attempt(tmp_path):
+    """a restarted worker group under the same key finds the previous attempt's id file, acknowledgements and
+    go-ahead, all recent.  Rank 1 starts FIRST and reads the leftovers (old id, matching old go-ahead is removed by rank 0 only when
+    it starts); it must end up with rank 0's NEW id, never with the old one, and rank 0 must not take the leftover acknowledgement
+    of the old id for rank 1's.  Also: a rank that starts long after rank 0 published (more than the old fixed 120-s window would
+    allow relative to the file's age) still joins while rank 0 waits."""
+    import time
+    key = 'pgpfa_uid_41004_none_0_%d_1' % os.getpid()
+    old_uid = bytes(128)
+    (tmp_path / key).write_bytes(old_uid)
+    (tmp_path / (key + '.ack.1')).write_bytes(old_uid)
+    pr1 = _rdzv_rank(tmp_path, 1, 2, 41004, 60)
+    time.sleep(1.5)                                    # rank 1 has read and acknowledged the leftover id by now; no go-ahead yet
+    assert pr1.poll() is None
+    pr0 = _rdzv_rank(tmp_path, 0, 2, 41004, 60)
+    outs = [pr.communicate(timeout=120) for pr in (pr0, pr1)]
+    assert [pr0.returncode, pr1.returncode] == [0, 0], outs      # the script asserts uid == bytes(range(128)), the NEW id
+    # leftover go-ahead with the OLD id next to a leftover id file: rank 1 alone must time out waiting, not leave with the old id
+    key = 'pgpfa_uid_41005_none_0_%d_1' % os.getpid()
+    (tmp_path / key).write_bytes(old_uid)
+    (tmp_path / (key + '.go')).write_bytes(bytes([1]) * 128)
+    pr = _rdzv_rank(tmp_path, 1, 2, 41005, 3)
+    out = pr.communicate(timeout=120)
+    assert pr.returncode == 7 and 'go-ahead' in out[1], out
+    # a restart count in the environment is part of the key: the files of attempt 0 are not even looked at by attempt 1
+    env_key = 'pgpfa_uid_41006_none_1_%d_1' % os.getpid()
+    script = tmp_path / 'rdzv.py'
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK=str(r), MASTER_PORT='41006', PGPFA_RDZV_DIR=str(tmp_path),
+                   PGPFA_RDZV_TIMEOUT='60', TORCHELASTIC_RESTART_COUNT='1')
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [pr.communicate(timeout=120) for pr in procs]
+    assert [pr.returncode for pr in procs] == [0, 0], outs
+    assert all(env_key in o[0] for o in outs), outs
 
 
 def test_bench_launcher_stops_all_ranks_when_one_dies():
