@@ -67,6 +67,9 @@ int pgpfa_destroy(pgpfa_ctx* ctx);
  * covariance blocks are Gram products on the matrix cores - post_vsm_mfma_kernel, model.h; 0: vector kernel),
  * "extrapolate_start" (1: a warm-started E-step begins at m + beta (m - m_prev) for trials whose two previous
  * E-steps are resident), "extrapolate_beta" (1.0),
+ * "pcg_form" (1: a step of the host-free inner iteration is two tile-parallel kernels - the one-reduction (Chronopoulos-Gear) form of
+ * PCG - plus the three preconditioner products, the prior mat-vec gone from the loop through Kt^-1 z = r - Wb z, pcg.h; up to 10 latents, needs "pcg_w32" and
+ * "pcg_retire"; 0: the split kernels of round 3 with K^-1 p as a product),
  * "pcg_retire" (1: every slot of the inner PCG has its own forcing term and leaves the iteration when it reaches it - device-side
  * live list, pcg.h; 0: one common forcing term), "pcg_trace" (0; 1: one stderr line per inner solve),
  * "time_newton" (0; 1: HIP events around the inner solves -> info "last_newton_solve_ms" / "last_newton_solve_bytes"),
@@ -200,6 +203,17 @@ int pgpfa_dual_costgrad_batch(pgpfa_ctx* ctx, int n, const int32_t* idx, const d
  * rho[n][q*T]: start in, optimum out; fopt[n]: dual optimum (inference.py:325/397); iters[n] may be NULL. */
 int pgpfa_dual_lbfgs(pgpfa_ctx* ctx, int n, const int32_t* idx, double* rho, int max_iter, double factr, double pgtol,
                      double* fopt, int32_t* iters);
+/* The optimum of the same dual problem by a fixed point instead of a quasi-Newton run in lambda.  At the optimum of the reference's dual
+ * (zero of dualProblem_grad, inference.py:215-219)  log lambda = d + C m + v  with  m = -K C_big (lambda - y)  (VIPostMean, :193) and
+ * v = 1/2 diag(C Sigma C^T)  (VIPostCov with its 1e-6 jitter, :188-191).  Given v, m is the mode of the Laplace objective with the log
+ * rates shifted by v (the batched Newton-PCG of pgpfa_estep_laplace, warm-started) and lambda = exp(C m + d + v); given lambda, v follows
+ * from the per-bin covariance blocks.  The map v -> v contracts by about half the largest posterior variance of a log rate per pass
+ * (a digit or more), so a trial needs ~5-10 covariance passes where L-BFGS in rho = log lambda needs thousands of evaluations.
+ * Stops per trial when max |v_new - v| <= tol - exactly the max-norm of dualProblem_grad at the returned lambda.
+ * rho[n][q*T]: log lambda, start in / optimum out; fopt[n]: dual cost at the optimum (inference.py:196-213); outer[n] (may be NULL):
+ * passes used; vstatus[n]: 0 converged, 1 pass cap reached, 2 not contracting (hand the trial to pgpfa_dual_lbfgs from the rho returned). */
+int pgpfa_dual_fixed_point(pgpfa_ctx* ctx, int n, const int32_t* idx, double* rho, int max_outer, double tol, double* fopt,
+                           int32_t* outer, int32_t* vstatus);
 /* VIPostMean (inference.py:193-194): mean[p*T] = -K_big C_big (lambda - ybar) for one trial, latent-major. */
 int pgpfa_dual_post_mean(pgpfa_ctx* ctx, int trial, const double* lam, double* mean);
 /* VIPostCov (inference.py:188-191) for one trial, dense [pT][pT] latent-major: prec = K_big^-1 + C_big diag(lambda) C_big^T

@@ -179,6 +179,10 @@ struct PoissonArgs {
   const int* slots;                // list of slots to process
   const int* trial_of_slot;
   const int* mask;                 // optional per slot: index of a neuron left out of the likelihood (NULL / -1: none)
+  // optional per slot [q][T]: an offset added to the log rate, h = C x + d + off (the variance term 1/2 c_n^T Sigma_t c_n of the
+  // variational fixed point, pgpfa_dual_fixed_point), and an output for the rates exp(h) themselves
+  const double* off; long long sOff;
+  double* lam_out; long long sLam;
   int q, p, T, ntile, full;
 };
 
@@ -221,9 +225,11 @@ __global__ __launch_bounds__(PMAX == 20 ? 640 : 1024) void poisson_pass_kernel(P
       double e = 0.0, r = 0.0;
       if (n < q && valid && n != held_out) {
         double h = a.d[n];
+        if (a.off) h += a.off[(size_t)slot * a.sOff + (size_t)n * T + t];
         const double* Cn = a.C + (size_t)n * p;
         for (int l = 0; l < p; ++l) h += Cn[l] * xs[l][tx];
         e = exp(h);
+        if (a.lam_out) a.lam_out[(size_t)slot * a.sLam + (size_t)n * T + t] = e;
         const double y = (double)count_at(Y, Yh, (size_t)n * T + t);
         r = e - y;
         facc += e - y * h;
@@ -357,6 +363,7 @@ __global__ __launch_bounds__(256) void poisson_mfma_kernel(PoissonArgs a, const 
         const int n = nb0 + l4 + 4 * r;
         const int nc = n < q ? n : q - 1;
         dv[r] = a.d[nc];
+        if (a.off) dv[r] += a.off[(size_t)slot * a.sOff + (size_t)nc * T + tc];
         yv[r] = count_at(Y, Yh, (size_t)nc * T + tc);
       }
 #pragma unroll
@@ -386,6 +393,7 @@ __global__ __launch_bounds__(256) void poisson_mfma_kernel(PoissonArgs a, const 
         e[r] = ev;
         rr[r] = ev - y;
         facc += ok ? ev - y * h[r] : 0.0;
+        if (a.lam_out && (n < q) && valid_t) a.lam_out[(size_t)slot * a.sLam + (size_t)n * T + t] = ev;
       }
       if (a.full) {
 #pragma unroll
@@ -1488,6 +1496,43 @@ __global__ void dual_grad_batch_kernel(const double* __restrict__ C, const doubl
   grad[e] = lin - d[n] + log(lam[e]) - 0.5 * quad;
 }
 
+// quad[slot][n][t] = 1/2 c_n^T Sigma_t c_n from the per-bin covariance blocks of the slot's trial (the vector form of the GEMM path in
+// dual_gradient).  grid = (ceil(T/64), q, nslots), block = 64
+__global__ void var_quad_kernel(const double* __restrict__ C, const double* __restrict__ vsm, const int* __restrict__ trial_of_slot,
+                                double* __restrict__ quad, int q, int p, int T) {
+  const int t = blockIdx.x * 64 + threadIdx.x;
+  const int n = blockIdx.y;
+  const size_t slot = blockIdx.z;
+  if (t >= T) return;
+  const double* S = vsm + ((size_t)trial_of_slot[slot] * T + t) * p * p;
+  const double* Cn = C + (size_t)n * p;
+  double acc = 0.0;
+  for (int k = 0; k < p; ++k) {
+    double u = 0.0;
+    for (int l = 0; l < p; ++l) u += S[k * p + l] * Cn[l];
+    acc += Cn[k] * u;
+  }
+  quad[slot * (size_t)q * T + (size_t)n * T + t] = 0.5 * acc;
+}
+
+// v <- v + damp (vnew - v) over the m entries of every slot; delta[slot] = max |vnew - v| (before the update).  grid = nslots, block = 256
+__global__ __launch_bounds__(256) void var_update_kernel(double* __restrict__ v, const double* __restrict__ vnew, size_t m, const double* __restrict__ damp,
+                                                         double* __restrict__ delta) {
+  __shared__ double red[4];
+  const size_t o = (size_t)blockIdx.x * m;
+  const double s = damp[blockIdx.x];
+  double d = 0.0;
+  for (size_t i = threadIdx.x; i < m; i += 256) {
+    const double a = v[o + i], b = vnew[o + i];
+    d = fmax(d, fabs(b - a));
+    v[o + i] = a + s * (b - a);
+  }
+  for (int off = 32; off > 0; off >>= 1) d = fmax(d, __shfl_down(d, off));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
+  __syncthreads();
+  if (threadIdx.x == 0) delta[blockIdx.x] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+
 // ---- small batched vector kernels of the device L-BFGS (one optimisation per slot, vectors [slot][m]) ----------------
 // out[slot] = a[slot] . b[slot]; grid = nslots, block = 256 (fixed reduction tree: deterministic)
 __global__ __launch_bounds__(256) void bdot_kernel(const double* __restrict__ A, const double* __restrict__ B, size_t m, double* __restrict__ out) {
@@ -1813,6 +1858,22 @@ __global__ void pcg_init_kernel(const double* __restrict__ G, double* __restrict
     R[slot * sV + i] = (i < n) ? -G[slot * sV + i] : 0.0;
     X[slot * sV + i] = 0.0;
   }
+}
+
+// out[slot] = |Gl + KX|^2 : squared norm of the total gradient at the committed point (block per listed slot)
+__global__ __launch_bounds__(256) void grad_norm2_kernel(const double* __restrict__ Gl, const double* __restrict__ KX, long long sV, int n,
+                                                         const int* __restrict__ slots, double* __restrict__ out) {
+  __shared__ double red[4];
+  const size_t slot = slots[blockIdx.x];
+  double d = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const double g = Gl[slot * sV + i] + KX[slot * sV + i];
+    d += g * g;
+  }
+  for (int off = 32; off > 0; off >>= 1) d += __shfl_down(d, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
+  __syncthreads();
+  if (threadIdx.x == 0) out[slot] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // dec = -g.x ; smax = max|x|   (block per slot)

@@ -21,7 +21,11 @@
 
 namespace pgpfa {
 
-struct PcgCtl { int stop; int iters; unsigned worst_bits; int nlive; unsigned long long slot_iters; };
+struct PcgCtl {
+  int stop; int iters; unsigned worst_bits; int nlive; unsigned long long slot_iters;
+  int nl[2];            // two-kernel step (pcg_cg_a/b_kernel): lengths of the two live lists (this step's, the next one's)
+  int pad_[2];
+};
 
 // One block: close an iteration.  ctl->iters counts executed iterations, ctl->slot_iters the slot-iterations (sum of the live counts).
 // The live list is compacted in place: a slot stays while its residual ratio (ratio[slot], written by pcg_update_p2_kernel) is above
@@ -362,6 +366,306 @@ __global__ __launch_bounds__(256) void pcg_update_p2_kernel(const double* __rest
   __syncthreads();
   const double beta = beta_s;
   for (int i = threadIdx.x; i < n; i += 256) P[slot * sV + i] = Z[slot * sV + i] + beta * P[slot * sV + i];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The PCG step without the prior mat-vec, as TWO tile-parallel kernels with ONE reduction (round 4).
+//
+// The preconditioner is the exact inverse of  P = Kt^-1 + Wb  with Kt = eps I + F F^T the low-rank form of the prior and Wb the mean
+// curvature blocks, so z = P^-1 r satisfies  Kt^-1 z = r - Wb z : a per-bin product instead of p products with T x T matrices.  In the
+// Chronopoulos-Gear form of PCG the matrix is applied to z, not to the search direction:
+//   A (pcg_cg_a_kernel):  z = Gb (eps r + y),  s = H~ z = (r - Wb z) + fl32(W) z,  partial sums of gamma = r.z, delta = z.s, r.r per
+//       (slot, tile of 64 bins)                                               [y = F Sb F^T Gb r comes from the three thin products]
+//   B (pcg_cg_b_kernel):  gamma, delta, r.r from the partial sums (every tile of a slot adds the same numbers in the same order), the
+//       slot's own stopping test, beta = gamma / gamma_old, alpha = gamma / (delta - beta gamma / alpha_old),  p = z + beta p,
+//       q = s + beta q (= H~ p),  x += alpha p,  r -= alpha q,  t = Gb r  (input of the next products)
+// so a step is A, B, a one-thread closing kernel and the products: 4 + 11 + 2 passes over an n-vector per live slot, against 20 and a
+// 5-GFLOP product with K^-1 in the round-3 form.  H~ = Kt^-1 + fl32(W) differs from H by the truncation of the pivoted Cholesky seen
+// through K^-1 (|Kt^-1 - K^-1| <= |E| / eps^2 where K^-1 ~ 1/eps, i.e. ~1e3 |E| relative to H there) and by single-precision curvature
+// (Wb is read in single precision too): an inexact Newton matrix.  Gradient, objective and line search keep the exact K^-1 (one product
+// per OUTER iteration), and the outer loop measures the contraction of the TRUE gradient over every accepted step (estep_impl) instead of
+// trusting the inner residual.
+// A workgroup is (64 bins) x (16 slots): the packed triangles of Gb / Wb of its bins sit in LDS once for the 16 slots; the slots' own
+// curvature comes component-major ([c][T] floats: a wave reads 64 consecutive bins of one component) straight from memory.  All loads are
+// unconditional from clamped addresses and masked afterwards - predicated loads get an s_waitcnt vmcnt(0) each (measured: 106 -> 82 us).
+// A slot that has reached its forcing term does not append itself to the next live list (atomic counter: the order of the list is not
+// deterministic, the arithmetic of a slot does not depend on it).  Scalars carried between steps (gamma, alpha) are double-buffered by
+// step parity: the tiles of one slot run in different workgroups, and the one that writes must not be seen by the others of the same step.
+//
+// Tried first and dropped: the whole step as ONE kernel with workgroup = slot, thread = bin (both reductions inside the workgroup, 12
+// vector passes): 170 us per step at 1024 live slots against 82 + 103 us here, but 40 us even for a single live slot (one workgroup's
+// chain of dependent loads and two barriers), 512 bins at most, and with the loads hoisted it needs more than 256 registers.
+struct PcgCgP {
+  const double* GbT; const float* WbT;        // [NP][T] packed lower triangles (component-major; Wb in single precision)
+  const float* W32T; long long sW32;          // [slot][NP][T]
+  double *X, *R, *P, *Q, *Z, *S, *Y; long long sV;
+  double* part;                                // [slot][ntile][3]
+  double *gam, *alp;                           // [2][B]: gamma, alpha of the previous step at [par], of this step at [par ^ 1]
+  double *rr, *rr0; const float* eta;
+  PcgCtl* ctl; int* live0; int* live1;
+  double eps; int T, p, par, first, inner_min, ntile, B;
+};
+
+// out = M v for the symmetric p x p matrix of this thread's bin, rows in two groups of about half the packed entries: the loads of a group
+// are in flight together, the compiler barrier keeps the second group's behind the first group's arithmetic (left alone the compiler
+// hoists every load of every product of a slot, runs out of registers and spills).  M: packed lower triangle, component stride `cs`
+// (global component-major arrays: cs = T; an LDS tile row: cs = 1); v is zero beyond p; loads are unconditional - a component index past
+// the matrix (clamp = true: global arrays sized for p) is clamped to 0 and meets a zero of v.
+template <int PW, bool CLAMP, typename TM>
+__device__ __forceinline__ void pcg_sym_mv(const TM* __restrict__ M, size_t cs, int p, const double (&v)[PW], double (&out)[PW]) {
+#pragma unroll
+  for (int k = 0; k < PW; ++k) out[k] = 0.0;
+  constexpr int HSPLIT = (PW * 7 + 9) / 10;
+#pragma unroll
+  for (int grp = 0; grp < 2; ++grp) {
+    constexpr int NPK = PW * (PW + 1) / 2;
+    TM g[NPK];
+#pragma unroll
+    for (int hi = 0; hi < PW; ++hi)
+#pragma unroll
+      for (int lo = 0; lo <= hi; ++lo) {
+        if ((grp == 0) != (hi < HSPLIT)) continue;
+        const int c = hi * (hi + 1) / 2 + lo;
+        g[c] = M[(size_t)((!CLAMP || hi < p) ? c : 0) * cs];
+      }
+#pragma unroll
+    for (int hi = 0; hi < PW; ++hi)
+#pragma unroll
+      for (int lo = 0; lo <= hi; ++lo) {
+        if ((grp == 0) != (hi < HSPLIT)) continue;
+        const double gg = (double)g[hi * (hi + 1) / 2 + lo];
+        out[hi] += gg * v[lo];
+        if (lo != hi) out[lo] += gg * v[hi];
+      }
+    asm volatile("" ::: "memory");
+  }
+  if (CLAMP) {
+#pragma unroll
+    for (int k = 0; k < PW; ++k) out[k] = (k < p) ? out[k] : 0.0;
+  }
+}
+
+// LDS tile [64 bins][LD] of a component-major packed matrix; components past np and bins past nt are zero
+template <int NPW, typename TM, typename TL>
+__device__ __forceinline__ void pcg_stage_sym(const TM* __restrict__ MT, int T, int t0, int nt, int np, TL* __restrict__ dst, int LD) {
+  for (int e = threadIdx.x; e < NPW * 64; e += 256) {
+    const int c = e >> 6, t = e & 63;
+    dst[t * LD + c] = (t < nt && c < np) ? (TL)MT[(size_t)c * T + t0 + t] : (TL)0;
+  }
+}
+
+constexpr int pcg_cg_ld(int pw) { return (pw * (pw + 1) / 2) | 1; }
+inline size_t pcg_cg_a_lds(int pw) { return (size_t)64 * pcg_cg_ld(pw) * (sizeof(double) + sizeof(float)); }
+inline size_t pcg_cg_b_lds(int pw) { return (size_t)64 * pcg_cg_ld(pw) * sizeof(double); }
+
+// grid = (ceil(T/64), ceil(na / PCG_SLOTS)), block = 256 (lanes = bins, waves = slots); dynamic LDS = pcg_cg_a_lds(PW)
+// (two waves per SIMD: left alone the compiler hoists every load and LDS read of a slot, takes all 256 registers and one workgroup fills a CU)
+template <int PW>
+__global__ __launch_bounds__(256, 2) void pcg_cg_a_kernel(PcgCgP a) {
+  constexpr int NP = PW * (PW + 1) / 2, LD = pcg_cg_ld(PW);
+  extern __shared__ double pcg_cg_smem[];
+  double* Gs = pcg_cg_smem;
+  float* Ws = reinterpret_cast<float*>(pcg_cg_smem + 64 * LD);
+  const PcgCtl* ctl = a.ctl;
+  if (ctl->stop) return;
+  const int na = ctl->nl[a.par];
+  if ((int)blockIdx.y * PCG_SLOTS >= na) return;
+  const int T = a.T, p = a.p, np = p * (p + 1) / 2;
+  const int t0 = blockIdx.x * 64;
+  const int nt = min(64, T - t0);
+  pcg_stage_sym<NP>(a.GbT, T, t0, nt, np, Gs, LD);
+  pcg_stage_sym<NP>(a.WbT, T, t0, nt, np, Ws, LD);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool in = lane < nt;
+  const int t = t0 + (in ? lane : 0);
+  const double* g = Gs + lane * LD;
+  const float* wb = Ws + lane * LD;
+  const int* live = a.par ? a.live1 : a.live0;
+  const int s_end = min(na, (int)(blockIdx.y + 1) * PCG_SLOTS);
+  for (int si = blockIdx.y * PCG_SLOTS + wave; si < s_end; si += 4) {
+    const size_t slot = (size_t)live[si];
+    const size_t base = slot * a.sV + t;
+    double r[PW], v[PW], z[PW], w[PW];
+#pragma unroll
+    for (int k = 0; k < PW; ++k) {
+      const size_t o = base + (size_t)(k < p ? k : 0) * T;
+      r[k] = a.R[o];
+      v[k] = a.Y[o];
+    }
+#pragma unroll
+    for (int k = 0; k < PW; ++k) {
+      const bool ok = in && k < p;
+      r[k] = ok ? r[k] : 0.0;
+      v[k] = ok ? a.eps * r[k] + v[k] : 0.0;
+    }
+    pcg_sym_mv<PW, false>(g, 1, p, v, z);
+    pcg_sym_mv<PW, false>(wb, 1, p, z, w);
+    pcg_sym_mv<PW, true>(a.W32T + slot * a.sW32 + t, (size_t)T, p, z, v);          // v <- fl32(W) z
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < PW; ++k) {
+      const double sk = (r[k] - w[k]) + v[k];                        // s = H~ z
+      s0 += r[k] * z[k]; s1 += z[k] * sk; s2 += r[k] * r[k];
+      if (in && k < p) {
+        const size_t o = base + (size_t)k * T;
+        a.Z[o] = z[k];
+        a.S[o] = sk;
+      }
+    }
+    for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_down(s0, off); s1 += __shfl_down(s1, off); s2 += __shfl_down(s2, off); }
+    if (lane == 0) {
+      double* pp = a.part + (slot * a.ntile + blockIdx.x) * 3;
+      pp[0] = s0; pp[1] = s1; pp[2] = s2;
+    }
+  }
+}
+
+// same launch shape; dynamic LDS = pcg_cg_b_lds(PW)
+template <int PW>
+__global__ __launch_bounds__(256, 3) void pcg_cg_b_kernel(PcgCgP a) {
+  constexpr int NP = PW * (PW + 1) / 2, LD = pcg_cg_ld(PW);
+  extern __shared__ double pcg_cg_smem[];
+  double* Gs = pcg_cg_smem;
+  PcgCtl* ctl = a.ctl;
+  if (ctl->stop) return;
+  const int na = ctl->nl[a.par];
+  if ((int)blockIdx.y * PCG_SLOTS >= na) return;
+  const int it = ctl->iters;
+  const int T = a.T, p = a.p, np = p * (p + 1) / 2;
+  const int t0 = blockIdx.x * 64;
+  const int nt = min(64, T - t0);
+  pcg_stage_sym<NP>(a.GbT, T, t0, nt, np, Gs, LD);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool in = lane < nt;
+  const int t = t0 + (in ? lane : 0);
+  const double* g = Gs + lane * LD;
+  const int* live = a.par ? a.live1 : a.live0;
+  int* live_next = a.par ? a.live0 : a.live1;
+  const double* gam_old = a.gam + (size_t)a.par * a.B;
+  const double* alp_old = a.alp + (size_t)a.par * a.B;
+  double* gam_new = a.gam + (size_t)(a.par ^ 1) * a.B;
+  double* alp_new = a.alp + (size_t)(a.par ^ 1) * a.B;
+  const int s_end = min(na, (int)(blockIdx.y + 1) * PCG_SLOTS);
+  for (int si = blockIdx.y * PCG_SLOTS + wave; si < s_end; si += 4) {
+    const int sloti = live[si];
+    const size_t slot = (size_t)sloti;
+    double gamma = 0.0, delta = 0.0, rrn = 0.0;
+    for (int i = 0; i < a.ntile; ++i) {
+      const double* pp = a.part + (slot * a.ntile + i) * 3;
+      gamma += pp[0]; delta += pp[1]; rrn += pp[2];
+    }
+    const double b0 = a.first ? rrn : a.rr0[slot];
+    const float ratio = (b0 > 0.0) ? (float)sqrt(rrn / b0) : 0.0f;
+    const bool keep = (it < a.inner_min || !(ratio <= a.eta[slot]));      // (a NaN ratio keeps iterating: the outer loop deals with it)
+    const double g_old = gam_old[slot], a_old = alp_old[slot];
+    const double beta = (a.first || !(g_old > 0.0)) ? 0.0 : gamma / g_old;
+    const double den = (a.first || !(a_old > 0.0)) ? delta : delta - beta * gamma / a_old;
+    const double alpha = (den > 0.0) ? gamma / den : 0.0;
+    if (blockIdx.x == 0 && lane == 0) {
+      if (a.first) a.rr0[slot] = rrn;
+      a.rr[slot] = rrn;
+      if (keep) {
+        gam_new[slot] = gamma;
+        alp_new[slot] = alpha;
+        const int pos = atomicAdd(&ctl->nl[a.par ^ 1], 1);
+        live_next[pos] = sloti;
+      }
+    }
+    if (!keep) continue;
+    const size_t base = slot * a.sV + t;
+    double r[PW], pv[PW], tv[PW];
+    double zk[PW], sk[PW], po[PW], qo[PW], xo[PW];
+#pragma unroll
+    for (int k = 0; k < PW; ++k) {
+      const size_t o = base + (size_t)(k < p ? k : 0) * T;
+      zk[k] = a.Z[o]; sk[k] = a.S[o]; xo[k] = a.X[o]; r[k] = a.R[o];
+      po[k] = 0.0; qo[k] = 0.0;
+    }
+    if (!a.first) {
+#pragma unroll
+      for (int k = 0; k < PW; ++k) {
+        const size_t o = base + (size_t)(k < p ? k : 0) * T;
+        po[k] = a.P[o]; qo[k] = a.Q[o];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < PW; ++k) {
+      const bool ok = in && k < p;
+      const size_t o = base + (size_t)(k < p ? k : 0) * T;
+      pv[k] = zk[k] + beta * po[k];
+      const double qn = sk[k] + beta * qo[k];
+      r[k] = ok ? r[k] - alpha * qn : 0.0;
+      if (ok) {
+        a.P[o] = pv[k];
+        a.Q[o] = qn;
+        a.X[o] = xo[k] + alpha * pv[k];
+        a.R[o] = r[k];
+      }
+    }
+    pcg_sym_mv<PW, false>(g, 1, p, r, tv);
+#pragma unroll
+    for (int k = 0; k < PW; ++k)
+      if (in && k < p) a.Y[base + (size_t)k * T] = tv[k];
+  }
+}
+
+// Closes a step (one thread): counts, stop flag when the next list is empty, the list just consumed is reset for the step after the
+// next, host mirror {stop, steps}.  (A separate launch, not a "last workgroup" inside B: a device-scope release there makes every
+// workgroup write its XCD's L2 back.)
+__global__ void pcg_iter_close_kernel(PcgCtl* __restrict__ ctl, int par, volatile int* __restrict__ host) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (!ctl->stop) {
+    const int nnext = ctl->nl[par ^ 1];
+    ctl->iters += 1;
+    ctl->slot_iters += (unsigned long long)nnext;          // CG steps taken: the slots that went on (a retiring slot only ran the test)
+    ctl->nlive = nnext;
+    if (nnext == 0) ctl->stop = 1;
+  }
+  ctl->nl[par] = 0;
+  if (host) {
+    host[1] = ctl->iters;
+    __threadfence_system();
+    host[0] = ctl->stop;
+    __threadfence_system();
+  }
+}
+
+// M[t][p][p] (double, symmetric) -> out[c][T], c = a(a+1)/2 + b over the lower triangle a >= b.  grid = ceil(T*NP/256)
+template <typename TO>
+__global__ void pack_sym_t_kernel(const double* __restrict__ M, TO* __restrict__ out, int T, int p) {
+  const int np = p * (p + 1) / 2;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= T * np) return;
+  const int c = e / T, t = e - c * T;
+  int a = 0;
+  while ((a + 1) * (a + 2) / 2 <= c) ++a;
+  const int b = c - a * (a + 1) / 2;
+  out[e] = (TO)M[(size_t)t * p * p + a * p + b];
+}
+
+// W[slot][t][p][p] (double) -> Wp[slot][c][T] (float, c over the lower triangle) for the listed slots: 64 bins per workgroup, packed
+// and transposed through LDS so that reads walk a bin's block and writes walk the bins.  grid = (ceil(T/64), nslots), block = 256,
+// dynamic LDS = NP * 65 floats
+__global__ __launch_bounds__(256) void pack_w32t_kernel(const double* __restrict__ W, long long sW, float* __restrict__ Wp, long long sWp, int T,
+                                                        int p, const int* __restrict__ slots) {
+  extern __shared__ float w32t_tile[];
+  const size_t slot = slots[blockIdx.y];
+  const int np = p * (p + 1) / 2, pp = p * p;
+  const int t0 = blockIdx.x * 64, nt = min(64, T - t0);
+  for (int e = threadIdx.x; e < nt * np; e += 256) {
+    const int t = e / np, c = e - t * np;
+    int a = 0;
+    while ((a + 1) * (a + 2) / 2 <= c) ++a;
+    const int b = c - a * (a + 1) / 2;
+    w32t_tile[c * 65 + t] = (float)W[slot * sW + (size_t)(t0 + t) * pp + a * p + b];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < np * 64; e += 256) {
+    const int c = e >> 6, t = e & 63;
+    if (t < nt) Wp[slot * sWp + (size_t)c * T + t0 + t] = w32t_tile[c * 65 + t];
+  }
 }
 
 }  // namespace pgpfa

@@ -158,6 +158,8 @@ struct pgpfa_ctx {
   double *Xc = nullptr, *Xt = nullptr, *KX = nullptr, *KD = nullptr, *Gl = nullptr, *Glt = nullptr, *Gt = nullptr, *Dl = nullptr;
   double *W = nullptr, *Wt = nullptr, *fpart = nullptr;
   double *lamd = nullptr, *dgrad = nullptr, *dpart = nullptr, *ldet_buf = nullptr;   // dual variational scratch
+  double* voff = nullptr;                         // [B][q][T] variance offsets 1/2 c_n^T Sigma_t c_n of the variational fixed point
+  bool var_active = false, lam_out_active = false;   // Poisson passes add voff to the log rate / write the rates into lamd
   double* dual_scr = nullptr; long long dual_sscr = 0;   // [B][T x max(pairs padded, p^2)] packed pair tables of the GEMM form
   // shared-preconditioner Newton-PCG: one factor per chunk (mean-trial Hessian), PCG vectors per slot
   CholWS sws{};
@@ -173,6 +175,10 @@ struct pgpfa_ctx {
   float* W32 = nullptr;                          // packed single-precision curvature triangles of the chunk's slots (PCG matvec)
   double* sc_part2 = nullptr;                    // per (slot, tile) partial sums r.z, r.r
   int pcg_fused = 1; bool pcg_w32 = true;        // pcg_fused: 0 off, 1 when the chunk is large enough, 2 always (tests)
+  int pcg_form = 1;                              // host-free inner iteration (pcg.h): 1 two tile-parallel kernels per step, no prior mat-vec (pcg_cg_a/b_kernel);
+                                                 // 0 the split kernels of round 3 with K^-1 p as a product
+  double *Sv = nullptr, *cg_scal = nullptr;      // s = H~ z of the two-kernel form; its per-slot scalars [gamma | alpha] x step parity
+  double *GbT = nullptr, *WbT = nullptr;         // [NP][T] packed triangles of the shared preconditioner's Gb and of the mean curvature (pcg_cg_a/b_kernel)
   double *sc_rz = nullptr, *sc_pq = nullptr, *sc_rr = nullptr, *sc_rr0 = nullptr, *sc_pack = nullptr;
   // low-rank covariance engine
   double* Flr = nullptr;                          // [p][Tp x Tp] pivoted-Cholesky factors of the RBF part
@@ -731,6 +737,7 @@ int ensure_workspace(pgpfa_ctx* c, bool plan_lr) {
   CHK(dmalloc(c, &c->Gt, ld * nBs, true)); CHK(dmalloc(c, &c->Dl, ld * nBs, true));
   CHK(dmalloc(c, &c->Rv, ld * nBs, true)); CHK(dmalloc(c, &c->Zv, ld * nBs, true));
   CHK(dmalloc(c, &c->Pv, ld * nBs, true)); CHK(dmalloc(c, &c->Qv, ld * nBs, true));
+  CHK(dmalloc(c, &c->Sv, ld * nBs, true)); CHK(dmalloc(c, &c->cg_scal, 4 * nB, true));
   CHK(alloc_cholws(c, &c->sws, 1, c->npad, true));
   c->sws.nact = round_up(c->n, 64);
   CHK(dmalloc(c, &c->sU, ld * ld + 256 * ld, true));
@@ -745,10 +752,11 @@ int ensure_workspace(pgpfa_ctx* c, bool plan_lr) {
   const size_t wlen = (size_t)c->T * c->p * c->p;
   CHK(dmalloc(c, &c->W, wlen * nB)); CHK(dmalloc(c, &c->Wt, wlen * nB));
   CHK(dmalloc(c, &c->fpart, (size_t)((c->T + 63) / 64) * nB));
-  CHK(dmalloc(c, &c->sc_part2, 2 * (size_t)((c->T + 63) / 64) * nB));
+  CHK(dmalloc(c, &c->sc_part2, 3 * (size_t)((c->T + 63) / 64) * nB));
   CHK(dmalloc(c, &c->W32, (size_t)c->T * (c->p * (c->p + 1) / 2) * nB + 64));
   CHK(dmalloc(c, &c->pcgctl, 1, true));
-  CHK(dmalloc(c, &c->live, nB)); CHK(dmalloc(c, &c->pcg_ratio, nB, true)); CHK(dmalloc(c, &c->pcg_eta, nB, true));
+  CHK(dmalloc(c, &c->live, 2 * nB)); CHK(dmalloc(c, &c->pcg_ratio, nB, true)); CHK(dmalloc(c, &c->pcg_eta, nB, true));
+  CHK(dmalloc(c, &c->GbT, (size_t)c->T * (c->p * (c->p + 1) / 2) + 64)); CHK(dmalloc(c, &c->WbT, (size_t)c->T * (c->p * (c->p + 1) / 2) + 64));
   CHK(dmalloc(c, &c->sc_f, nB));
   CHK(dmalloc(c, &c->sc_alpha, nB));
   CHK(dmalloc(c, &c->trial_of_slot, nB)); CHK(dmalloc(c, &c->list_a, nB)); CHK(dmalloc(c, &c->list_b, nB));
@@ -943,6 +951,8 @@ int poisson(pgpfa_ctx* c, const int* d_list, int nl, const double* X, double* G,
   a.X = X; a.sX = c->ld; a.G = G; a.sG = c->ld; a.W = W; a.sW = (long long)c->T * c->p * c->p;
   a.fpart = c->fpart; a.slots = d_list; a.trial_of_slot = c->trial_of_slot;
   a.mask = c->mask_active ? c->mask_of_slot : nullptr;
+  a.off = c->var_active ? c->voff : nullptr; a.sOff = (long long)c->q * c->T;
+  a.lam_out = c->lam_out_active ? c->lamd : nullptr; a.sLam = (long long)c->q * c->T;
   a.q = c->q; a.p = c->p; a.T = c->T; a.ntile = (c->T + 63) / 64; a.full = full;
   const int KY = poisson_rows(c->p);
   dim3 grid(a.ntile, nl), block(64, KY);
@@ -1267,6 +1277,7 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
   else if (k == "cd_debug") c->cd_debug = (int)v;
   else if (k == "pcg_fused") c->pcg_fused = (int)v;
   else if (k == "pcg_w32") c->pcg_w32 = (v != 0.0);
+  else if (k == "pcg_form") c->pcg_form = (int)v;
   else if (k == "chord") c->chord = (v != 0.0);
   else if (k == "shared_pcg") c->shared_pcg = (v != 0.0);
   else if (k == "time_newton") c->time_newton = (v != 0.0);
@@ -1741,6 +1752,11 @@ static int shared_factor_lowrank(pgpfa_ctx* c, int nb) {
   const int T = c->T, p = c->p, pp = p * p, len = T * pp, rpad = c->rpad;
   hipLaunchKernelGGL(mean_w_kernel, dim3((len + 255) / 256), dim3(256), 0, c->st, c->W, (long long)len, c->ident, nb, len, c->Wbar);
   CHK(bin_blocks(c, c->Wbar, 0LL, c->Gbar, c->Wtbar, 0LL, 1, nullptr));
+  {
+    const int npk = T * (p * (p + 1) / 2);
+    hipLaunchKernelGGL(pack_sym_t_kernel<double>, dim3((npk + 255) / 256), dim3(256), 0, c->st, (const double*)c->Gbar, c->GbT, T, p);
+    hipLaunchKernelGGL(pack_sym_t_kernel<float>, dim3((npk + 255) / 256), dim3(256), 0, c->st, (const double*)c->Wbar, reinterpret_cast<float*>(c->WbT), T, p);
+  }
   CholWS lw = c->sws;
   lw.ld = rpad; lw.npad = rpad; lw.nact = round_up(c->rtot, 64);
   const int nblk64 = rpad / 64, npairs = nblk64 * (nblk64 + 1) / 2;
@@ -2223,11 +2239,29 @@ struct LooJob {
   double* err;           // host [N]
 };
 
+// Variational fixed point (pgpfa_dual_fixed_point): the mode search below runs with the variance offsets in the log rate, in a loop with
+// the covariance blocks that produce them.
+struct VarJob {
+  double* rho;            // host [N][q*T]: log lambda, start in / optimum out
+  int max_outer;
+  double tol;             // stop: max |1/2 c_n^T Sigma_t c_n - offset| <= tol (the max-norm of the reference's dual gradient, inference.py:218)
+  double* fopt;           // host [N]: dual cost at the optimum
+  int32_t* outer;         // host [N] (may be NULL): outer iterations
+  int32_t* vstatus;       // host [N]: 0 converged, 1 iteration cap, 2 not contracting
+};
+static int ensure_lambda(pgpfa_ctx* c);
+static int dual_common(pgpfa_ctx* c, int nb, std::vector<double>* sB, std::vector<double>* sD, std::vector<double>* vKv);
+static int dual_jitter(pgpfa_ctx* c, int nb);
+static int dual_eval_slots(pgpfa_ctx* c, int nb, const std::vector<int>& tos, bool want_grad, double* cost, bool tolerate);
+static int var_offsets(pgpfa_ctx* c, int nb, double* out);
+static int check_distinct(const std::vector<int>& v);
+
 static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow_lr, double* obj_sum, int32_t* iters, int32_t* status,
-                      const LooJob* loo = nullptr) {
+                      const LooJob* loo = nullptr, const VarJob* var = nullptr) {
   c->want_slots = std::max(c->want_slots, std::min((int)tr.v.size(), c->R));
   CHK(ready_estep(c, allow_lr));
-  struct MaskGuard { pgpfa_ctx* c; ~MaskGuard() { c->mask_active = false; } } mask_guard{c};
+  struct MaskGuard { pgpfa_ctx* c; ~MaskGuard() { c->mask_active = false; c->var_active = false; c->lam_out_active = false; } } mask_guard{c};
+  if (var) CHK(ensure_lambda(c));
   const int N = (int)tr.v.size();
   const auto t_begin = std::chrono::steady_clock::now();
   const int nvec = c->n, p = c->p, T = c->T;
@@ -2250,7 +2284,23 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
       c->mask_active = true;
     }
     HIPC(hipMemsetAsync(c->ws.info, 0, sizeof(int) * nb, c->st));
-    {
+    const size_t mlam = (size_t)c->q * T;
+    std::vector<double> vdelta(nb, 0.0), vdelta_prev(nb, -1.0), vdamp(nb, 1.0);
+    std::vector<int> vstat(nb, 1), vouter(nb, 0), vslow(nb, 0);
+    if (var) {
+      // lambda of the chunk -> W = C^T diag(lambda) C (+ the reference's jitter), the covariance blocks and from them the first offsets;
+      // start point of the mode search: the variational mean of that lambda, -K C_big (lambda - y) (inference.py:194)
+      std::vector<double> lam0((size_t)nb * mlam);
+      for (size_t i = 0; i < lam0.size(); ++i) lam0[i] = std::exp(var->rho[(size_t)c0 * mlam + i]);
+      CHK(upload(c, c->lamd, lam0.data(), lam0.size()));
+      std::vector<double> sB_, sD_, vKv_;
+      CHK(dual_common(c, nb, &sB_, &sD_, &vKv_));
+      hipLaunchKernelGGL(negate_rows_kernel, dim3((nvec + 255) / 256, nb), dim3(256), 0, c->st, c->KD, ld, c->Xc, ld, nvec, c->ident);
+      if (c->plan_lowrank) { CHK(dual_jitter(c, nb)); CHK(posterior_blocks(c, nb, 1.0, false, false)); }
+      else CHK(posterior_blocks(c, nb, 1.0 + 1e-6, false));
+      CHK(var_offsets(c, nb, c->voff));
+      c->var_active = true;
+    } else {
       // start points: cold (zero), the resident mode, or its extrapolation; warm_start = 2 takes the resident mode only
       // for trials some earlier E-step has produced one for (minibatches revisiting trials) and starts the others cold
       std::vector<int> how(nb, 0);
@@ -2270,6 +2320,8 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
         hipLaunchKernelGGL(gather_rows_kernel, dim3((nvec + 255) / 256, nb), dim3(256), 0, c->st, c->Xmode, nvec, c->Xc, ld, c->trial_of_slot, 1);
       }
     }
+    std::vector<int> active;
+    for (int vo = 0;; ++vo) {                     // (one pass for the Laplace E-step; the variational fixed point comes back here with new offsets)
     // objective, gradient pieces and curvature blocks at the start point
     CHK(prior_mv_all(c, nb, c->Xc, c->KX));
     hipLaunchKernelGGL(dots3_kernel, dim3(nb), dim3(256), 0, c->st, c->Xc, ld, c->KX, ld, (const double*)nullptr, 0LL,
@@ -2277,8 +2329,14 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
     CHK(poisson(c, c->ident, nb, c->Xc, c->Gl, c->W, c->sc_f, 1));
     CHK(dl_enqueue(c, f.data(), c->sc_f, nb * sizeof(double)));
     CHK(download(c, qxx.data(), c->sc_qxx, nb));
-    std::vector<int> active(nb);
-    for (int s = 0; s < nb; ++s) { active[s] = s; f[s] += 0.5 * qxx[s]; its[s] = 0; stat[s] = 1; }
+    active.clear();
+    for (int s = 0; s < nb; ++s) {
+      f[s] += 0.5 * qxx[s];
+      if (vo == 0) its[s] = 0;
+      if (var && vstat[s] != 1) continue;         // (this slot's fixed point is settled)
+      active.push_back(s);
+      stat[s] = 1;
+    }
     std::vector<int> leftovers;
 
     // backtracking line search along Dl for the slots in `cand` (objective with rounding-noise slack as in
@@ -2354,7 +2412,77 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
         int done_inner = 0;
         PcgCtl& fused_ctl = c->fused_ctl_host;             // (context member: a queued read-back must not point into this frame)
         fused_ctl = PcgCtl{};
-        if (fused) {
+        // form of the host-free iteration (pcg.h): the two-kernel step without the prior mat-vec needs the packed FP32 curvature and per-slot
+        // retirement; otherwise the split kernels of round 3
+        const bool onek = fused && c->pcg_w32 && c->pcg_retire && c->pcg_form != 0 && p <= 10;
+        if (onek) {
+          // ---- inner solve: per step pcg_cg_a_kernel, pcg_cg_b_kernel, the closing kernel and the three preconditioner products (pcg.h)
+          const int* skip = &c->pcgctl->stop;
+          const int npk = p * (p + 1) / 2;
+          const long long sW32 = (long long)T * npk;
+          {
+            std::vector<float> eta_s(nb, (float)eta_target);
+            for (int s : active) {
+              double es = c->pcg_eta0;
+              if (err_pred[s] >= 0.0) {
+                const double e = std::max(err_pred[s], 1e-300);
+                es = std::max(1e-9, std::min(c->pcg_eta0, std::max(e, c->chord_xtol / (20.0 * e))));
+              }
+              eta_s[s] = (float)es;
+            }
+            CHK(upload_nosync(c, c->pcg_eta, eta_s.data(), sizeof(float) * nb));
+            HIPC(hipMemcpyAsync(c->live, c->list_a, sizeof(int) * na, hipMemcpyDeviceToDevice, c->st));
+            PcgCtl h0{};
+            h0.nlive = na; h0.nl[0] = na;
+            CHK(upload_nosync(c, c->pcgctl, &h0, sizeof(PcgCtl)));
+          }
+          c->h_pcg[0] = 0; c->h_pcg[1] = 0;
+          hipLaunchKernelGGL(pack_w32t_kernel, dim3((T + 63) / 64, na), dim3(256), (size_t)npk * 65 * sizeof(float), c->st, c->W, (long long)T * p * p,
+                             c->W32, sW32, T, p, c->list_a);
+          // t = Gb r0, then y = F Sb F^T t over the listed columns (left in c->Xt)
+          CHK(shared_solve(c, nb, c->Rv, c->Zv, nullptr, true, false, c->list_a, na));
+          struct NdevGuard { pgpfa_ctx* c; ~NdevGuard() { c->cur_ndev = nullptr; } } ndev_guard{c};
+          c->live_gemms.clear();
+          PcgCgP cp{};
+          cp.GbT = c->GbT; cp.WbT = reinterpret_cast<const float*>(c->WbT); cp.W32T = c->W32; cp.sW32 = sW32;
+          cp.X = c->Dl; cp.R = c->Rv; cp.P = c->Pv; cp.Q = c->Qv; cp.Z = c->Zv; cp.S = c->Sv; cp.Y = c->Xt; cp.sV = ld;
+          cp.part = c->sc_part2; cp.gam = c->cg_scal; cp.alp = c->cg_scal + 2 * (size_t)c->B; cp.rr = c->sc_rr; cp.rr0 = c->sc_rr0; cp.eta = c->pcg_eta;
+          cp.ctl = c->pcgctl; cp.live0 = c->live; cp.live1 = c->live + c->B;
+          cp.eps = c->eps; cp.T = T; cp.p = p; cp.inner_min = c->pcg_inner_min; cp.ntile = (T + 63) / 64; cp.B = c->B;
+          const dim3 gcg((T + 63) / 64, (na + PCG_SLOTS - 1) / PCG_SLOTS);
+          for (int it = 0; it < c->pcg_inner_max; ++it) {
+            cp.par = it & 1; cp.first = (it == 0) ? 1 : 0;
+            dispatch_pw(p, [&](auto pw) {
+              constexpr int PW = decltype(pw)::value;
+              if constexpr (PW <= 10) {
+                const size_t la = pcg_cg_a_lds(PW), lb = pcg_cg_b_lds(PW);
+                // (per launch, not once per process: contexts of one process may sit on different devices)
+                if (la > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pcg_cg_a_kernel<PW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)la);
+                if (lb > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pcg_cg_b_kernel<PW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+                hipLaunchKernelGGL(pcg_cg_a_kernel<PW>, gcg, dim3(256), la, c->st, cp);
+                hipLaunchKernelGGL(pcg_cg_b_kernel<PW>, gcg, dim3(256), lb, c->st, cp);
+              }
+            });
+            hipLaunchKernelGGL(pcg_iter_close_kernel, dim3(1), dim3(64), 0, c->st, c->pcgctl, it & 1, (volatile int*)c->d_hpcg);
+            // the preconditioner products for the NEXT iteration run over the list this launch has just written
+            c->live_gemm_collect = (it == 0);
+            c->cur_ndev = &c->pcgctl->nl[(it & 1) ^ 1];
+            CHK(shared_solve(c, nb, c->Rv, c->Zv, skip, false, false, (it & 1) ? c->live : c->live + c->B, na));
+            if (*(volatile int*)&c->h_pcg[0]) break;           // the device has already stopped: whatever is enqueued is a no-op
+            if (it + 1 < c->pcg_inner_max) {
+              const auto t_spin = std::chrono::steady_clock::now();
+              while (!*(volatile int*)&c->h_pcg[0] && (it + 1) - *(volatile int*)&c->h_pcg[1] > 2) {
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_spin).count() > 5.0) break;   // (never hang on a lost flag)
+              }
+              if (*(volatile int*)&c->h_pcg[0]) break;
+            }
+          }
+          c->cur_ndev = nullptr;
+          c->live_gemm_collect = false;
+          CHK(dl_enqueue(c, &fused_ctl, c->pcgctl, sizeof(PcgCtl)));
+          HIPC(hipGetLastError());
+          done_inner = -1;
+        } else if (fused) {
           // ---- inner solve without host round trips (pcg.h): the stopping test runs on the device, iterations are enqueued
           // ahead, kernels of iterations past the stop return at once
           const int ntile = (T + 63) / 64;
@@ -2514,9 +2642,14 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
           // 20 passes over an n-vector (H p = K^-1 p + W p: 5; x, r updates: 6; preconditioner G(eps r + F S F^T G r): 6; p = z + beta p: 3),
           // 4 over an r-vector, the curvature blocks (packed FP32 lower triangles, or FP64 full blocks); once per iteration the operators
           // K^-1 (p T^2), F and F^T (T r each) and S (r^2).  Dense plan: P^-1 (n^2) instead of F / S.
-          const double vecs = 20.0 * nvec * 8.0 + (c->plan_lowrank ? 4.0 * c->rtot * 8.0 : 0.0);
-          const double curv = (fused && c->pcg_w32) ? (double)T * (p * (p + 1) / 2) * 4.0 : (double)T * p * p * 8.0;
-          const double ops = (double)p * T * T * 8.0 + (c->plan_lowrank ? (2.0 * T * c->rtot + (double)c->rtot * c->rtot) * 8.0 : (double)nvec * nvec * 8.0);
+          const double npk = (double)(p * (p + 1) / 2);
+          // Two-kernel step (pcg_cg_a/b_kernel): 17 passes (A reads r, y and writes z, s; B reads z, s, p, q, x, r and writes p, q, x, r, t; the
+          // products read t and write y), 4 over an r-vector, the packed FP32 curvature; once per step F, F^T, S and the packed triangles of Gb
+          // (FP64) and Wb (FP32).  No K^-1 in the loop.
+          const double vecs = (onek ? 17.0 : 20.0) * nvec * 8.0 + (c->plan_lowrank ? 4.0 * c->rtot * 8.0 : 0.0);
+          const double curv = (fused && c->pcg_w32) ? (double)T * npk * 4.0 : (double)T * p * p * 8.0;
+          const double ops = onek ? (2.0 * T * c->rtot + (double)c->rtot * c->rtot + 1.5 * T * npk) * 8.0
+                                  : (double)p * T * T * 8.0 + (c->plan_lowrank ? (2.0 * T * c->rtot + (double)c->rtot * c->rtot) * 8.0 : (double)nvec * nvec * 8.0);
           newton_bytes += slot_iters * (vecs + curv) + (double)done_inner * ops;
         }
         std::vector<int> cand, next, failed;
@@ -2527,10 +2660,25 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
         CHK(line_search(cand, &failed));
         std::vector<char> bad(nb, 0);
         for (int s : failed) bad[s] = 1;
+        std::vector<double> gnew;
+        if (onek) {
+          // The inner solve ran on H~ = Kt^-1 + fl32(W): its residual says how well H~ delta = -g was solved, not how far the step took the
+          // TRUE gradient down.  Measure that: |g(x + delta)| / |g(x)| of the accepted full steps (the committed Gl + KX; rr0 = |g(x)|^2) enters
+          // the error prediction next to the inner ratio, so the stopping rule never rests on the model matrix.
+          std::vector<int> okl;
+          for (int s : cand) if (!bad[s]) okl.push_back(s);
+          gnew.assign(nb, 0.0);
+          if (!okl.empty()) {
+            CHK(upload_nosync(c, c->list_b, okl.data(), sizeof(int) * okl.size()));
+            hipLaunchKernelGGL(grad_norm2_kernel, dim3((unsigned)okl.size()), dim3(256), 0, c->st, c->Gl, c->KX, ld, nvec, c->list_b, c->sc_f);
+            CHK(download(c, gnew.data(), c->sc_f, nb));
+          }
+        }
         for (int s : cand) {
           if (bad[s]) continue;
           // inexact Newton: the error after the step is ~ max(eta, |step|) * |step|, eta = achieved relative residual
-          const double eta = rr0[s] > 0.0 ? std::sqrt(rr[s] / rr0[s]) : 0.0;
+          double eta = rr0[s] > 0.0 ? std::sqrt(rr[s] / rr0[s]) : 0.0;
+          if (onek && alpha[s] == 1.0 && rr0[s] > 0.0) eta = std::max(eta, std::sqrt(gnew[s] / rr0[s]));
           const double step = alpha[s] * smax[s];
           if (alpha[s] == 1.0 && 10.0 * step * std::max(eta, step) < c->chord_xtol) { stat[s] = 0; continue; }
           err_pred[s] = (alpha[s] == 1.0) ? step * std::max(eta, step) : step;
@@ -2627,6 +2775,66 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
       max_it_seen = std::max(max_it_seen, iter + 1);
     }
 
+    if (!var) break;
+    // ---- variational fixed point: rates at the modes, their covariance blocks, new offsets
+    for (int s = 0; s < nb; ++s)
+      if (vstat[s] == 1 && stat[s] != 0) return fail("variational fixed point: the mode search of trial %d failed (status %d)", tos[s], stat[s]);
+    c->lam_out_active = true;
+    CHK(poisson(c, c->ident, nb, c->Xc, c->Glt, c->Wt, c->sc_f, 0));        // lambda = exp(C m + d + offset) -> c->lamd
+    c->lam_out_active = false;
+    if (c->plan_lowrank) { CHK(dual_jitter(c, nb)); CHK(posterior_blocks(c, nb, 1.0, false, false)); }   // (c->W: curvature at the modes = C^T diag(lambda) C)
+    else CHK(posterior_blocks(c, nb, 1.0 + 1e-6, false));
+    CHK(dl_enqueue(c, info.data(), c->ws.info, sizeof(int) * nb));
+    CHK(dl_flush(c));
+    for (int s = 0; s < nb; ++s)
+      if (info[s] != 0) return fail("variational fixed point: posterior precision of trial %d not positive definite", tos[s]);
+    CHK(var_offsets(c, nb, c->dgrad));
+    {
+      // change of the offsets first (step 0: nothing moves), the update afterwards and only for the slots that go on - a slot that settles
+      // keeps the offsets its lambda was computed with, so that (lambda, mode, offsets) stay one consistent triple
+      std::vector<double> zero(nb, 0.0);
+      CHK(upload_nosync(c, c->sc_alpha, zero.data(), sizeof(double) * nb));
+      hipLaunchKernelGGL(var_update_kernel, dim3(nb), dim3(256), 0, c->st, c->voff, (const double*)c->dgrad, mlam, (const double*)c->sc_alpha, c->sc_f);
+      CHK(download(c, vdelta.data(), c->sc_f, nb));
+    }
+    bool any_open = false;
+    for (int s = 0; s < nb; ++s) {
+      if (vstat[s] != 1) continue;
+      vouter[s] = vo + 1;
+      if (!std::isfinite(vdelta[s])) return fail("variational fixed point: non-finite offsets for trial %d", tos[s]);
+      if (vdelta[s] <= var->tol) { vstat[s] = 0; continue; }
+      // the map contracts by about half the largest posterior variance of a log rate per pass; a pass that does not shrink the change
+      // halves the step, three such passes give the trial back to the caller (status 2: the L-BFGS driver takes it from this lambda)
+      if (vdelta_prev[s] >= 0.0 && vdelta[s] > 0.7 * vdelta_prev[s]) { vdamp[s] *= 0.5; if (++vslow[s] >= 3) { vstat[s] = 2; continue; } }
+      vdelta_prev[s] = vdelta[s];
+      if (vo + 1 >= var->max_outer) continue;       // (stays 1: iteration cap)
+      any_open = true;
+    }
+    if (!any_open) break;
+    {
+      std::vector<double> step(nb, 0.0);
+      for (int s = 0; s < nb; ++s) step[s] = (vstat[s] == 1) ? vdamp[s] : 0.0;
+      CHK(upload_nosync(c, c->sc_alpha, step.data(), sizeof(double) * nb));
+      hipLaunchKernelGGL(var_update_kernel, dim3(nb), dim3(256), 0, c->st, c->voff, (const double*)c->dgrad, mlam, (const double*)c->sc_alpha, c->sc_f);
+      HIPC(hipGetLastError());
+    }
+    }
+    if (var) {
+      // optimum out: rho = log lambda, the dual cost there (inference.py:196-213), statuses
+      c->var_active = false;
+      std::vector<double> lam((size_t)nb * mlam);
+      CHK(download(c, lam.data(), c->lamd, lam.size()));
+      for (size_t i = 0; i < lam.size(); ++i) var->rho[(size_t)c0 * mlam + i] = std::log(lam[i]);
+      CHK(dual_eval_slots(c, nb, tos, false, var->fopt + c0, false));
+      for (int s = 0; s < nb; ++s) {
+        if (var->outer) var->outer[c0 + s] = vouter[s];
+        var->vstatus[c0 + s] = vstat[s];
+        if (iters) iters[c0 + s] = its[s];
+        if (status) status[c0 + s] = stat[s];
+      }
+      n_fact += nb;
+      continue;
+    }
     if (loo) {
       // prediction of the held-out neurons from the modes in Xc (Xt and sc_f are free scratch here)
       hipLaunchKernelGGL(loo_predict_kernel, dim3(nb), dim3(256), 0, c->st, c->Xc, ld, c->C, c->d, c->Y, c->Yhi, c->trial_of_slot, c->mask_of_slot,
@@ -3423,6 +3631,7 @@ static int ensure_lambda(pgpfa_ctx* c) {
   const size_t lam_slack = (size_t)16 * c->T + 4096;
   CHK(dmalloc(c, &c->lamd, (size_t)c->B * c->q * c->T + lam_slack, true));
   CHK(dmalloc(c, &c->dgrad, (size_t)c->B * c->q * c->T + lam_slack, true));
+  CHK(dmalloc(c, &c->voff, (size_t)c->B * c->q * c->T + lam_slack, true));
   CHK(dmalloc(c, &c->dpart, (size_t)c->B * ((c->T + 63) / 64) * 2 + 16));
   CHK(dmalloc(c, &c->ldet_buf, (size_t)c->B * c->T + 16));
   c->dual_sscr = (long long)c->T * std::max(c->dual_npd, c->p * c->p);
@@ -3670,6 +3879,59 @@ static int dual_eval_slots(pgpfa_ctx* c, int nb, const std::vector<int>& tos, bo
     launch_post_vsm(c, (const double*)c->ws.Mt, (long long)c->ws.sM, c->npad, nb, 0);
     CHK(dual_gradient(c, nb));
   }
+  return 0;
+}
+
+// out[slot][n][t] = 1/2 c_n^T Sigma_t c_n of the slots [0, nb) from the per-bin covariance blocks in c->vsm (the variance term of the
+// reference's dual gradient, inference.py:218)
+static int var_offsets(pgpfa_ctx* c, int nb, double* out) {
+  const int q = c->q, p = c->p, T = c->T;
+  if (c->dual_gemm && c->mfma && c->dual_tbl) {
+    hipLaunchKernelGGL(dual_pack_sigma_kernel, dim3((unsigned)(((size_t)T * c->dual_npd + 255) / 256), nb), dim3(256), 0, c->st, c->vsm,
+                       c->trial_of_slot, c->dual_scr, c->dual_sscr, T, p, c->dual_npd);
+    GemmP g{};                                               // (T x q) = 1/2 Sp . TBL[:, pairs]^T
+    g.A = c->dual_scr; g.sA = c->dual_sscr; g.lda = T;
+    g.B = c->dual_tbl; g.sB = 0; g.ldb = c->dual_ncol;
+    g.C = out; g.sC = (long long)q * T; g.ldc = T;
+    g.M = T; g.N = q; g.K = c->dual_npd; g.alpha = 0.5; g.beta = 0.0; g.slots = c->ident; g.nbatch = nb; g.mode = GEMM_FULL; g.kflags = 0;
+    CHK(gemm(c, true, g));
+  } else {
+    hipLaunchKernelGGL(var_quad_kernel, dim3((T + 63) / 64, q, nb), dim3(64), 0, c->st, c->C, c->vsm, c->trial_of_slot, out, q, p, T);
+  }
+  HIPC(hipGetLastError());
+  return 0;
+}
+
+// The optimum of the dual problem (inference.py:196-219) of a list of trials by a fixed point instead of a quasi-Newton run in lambda.
+// At the optimum  log lambda = d + C m + v  with  m = -K C_big (lambda - y)  (VIPostMean) and  v = 1/2 diag(C Sigma C^T)  (VIPostCov, jitter
+// included).  Given v, the first two say that m is the mode of the Laplace objective with the log rates shifted by v - found by the same
+// batched Newton-PCG as the Laplace E-step, warm-started - and lambda = exp(C m + d + v); given lambda, v follows from the covariance
+// blocks.  The map v -> v contracts by about half the largest posterior variance of a log rate (its Jacobian is
+// -1/2 (C Sigma C^T)o(C Sigma C^T) diag(lambda) (I - C Sigma C^T diag(lambda)), rows sum to at most 1/2 c_n^T Sigma_t c_n), i.e. a
+// digit or more per pass, where L-BFGS in rho needs thousands of evaluations (the dual's Hessian carries C K C^T: condition > 1e4).
+// Stops per trial when max |v_new - v| <= tol: that IS the max-norm of the reference's dual gradient at the returned lambda.
+// rho[n][q*T]: log lambda, start in / optimum out; fopt[n]: dual cost there; outer[n] (may be NULL): passes; vstatus[n]: 0 converged,
+// 1 iteration cap, 2 not contracting (posterior variances too large for the plain fixed point: hand the trial to pgpfa_dual_lbfgs).
+int pgpfa_dual_fixed_point(pgpfa_ctx* c, int n, const int32_t* idx, double* rho, int max_outer, double tol, double* fopt, int32_t* outer,
+                           int32_t* vstatus) {
+  if (!c) return fail("null context");
+  if (!rho || !fopt || !vstatus) return fail("null argument");
+  if (max_outer < 1 || !(tol > 0.0)) return fail("max_outer and tol must be positive");
+  Trials tr;
+  CHK(resolve_trials(c, n, idx, &tr, true));
+  CHK(check_distinct(tr.v));
+  HIPC(hipSetDevice(c->device));
+  const int N = (int)tr.v.size();
+  const size_t m = (size_t)c->q * c->T;
+  for (size_t i = 0; i < (size_t)N * m; ++i)
+    if (!std::isfinite(rho[i])) return fail("rho must be finite (trial %d, entry %zu)", tr.v[i / m], i % m);
+  VarJob job{rho, max_outer, tol, fopt, outer, vstatus};
+  std::vector<int32_t> it1(N), st1(N);
+  double obj = 0.0;
+  CHK(estep_impl(c, tr, 0, c->dual_lowrank, &obj, it1.data(), st1.data(), nullptr, &job));
+  double ev = 0.0;
+  for (int i = 0; i < N; ++i) ev += (outer ? outer[i] : 0) + 1.0;
+  c->info["last_dual_evaluations"] = ev;          // covariance passes (one per outer pass + the start), the unit the L-BFGS driver counts too
   return 0;
 }
 

@@ -367,8 +367,14 @@ def dualProblemRho_grad(rho, ybar, C_big, K_big, K_bigInv, d_big):
 
 
 # 'device': the dual optimisations of all trials run as lockstep L-BFGS on the GPU (pgpfa_dual_lbfgs); 'scipy': the
-# reference's per-trial scipy L-BFGS-B calls (same options), driven concurrently with batched device evaluations
+# reference's per-trial scipy L-BFGS-B calls (same options), driven concurrently with batched device evaluations;
+# 'fixedpoint': the optimum of the same dual through the fixed point of its stationarity conditions (pgpfa_dual_fixed_point: the Laplace
+# Newton-PCG with variance offsets in a loop with the covariance blocks) - the zero of the reference's dual gradient to DUAL_FP_TOL
+# in a handful of passes, where either L-BFGS stops on its decrease test after thousands of evaluations
 DUAL_SOLVER = 'device'
+# passes / tolerance of DUAL_SOLVER = 'fixedpoint' (the tolerance is the max-norm of the reference's dual gradient at the returned lambda)
+DUAL_FP_MAX_PASSES = 40
+DUAL_FP_TOL = 1e-8
 # evaluate the dual through the low-rank covariance engine when that pays (large xdim*T); the reference's 1e-6 diagonal jitter
 # (inference.py:190) enters as a diagonal addition to the per-bin curvature blocks, so both engines evaluate the reference's function
 DUAL_LOWRANK = True
@@ -472,8 +478,8 @@ def dualVariational(experiment, params, optimizeLogLambda=False, prevOptimRes=No
     # DUAL_LOWRANK: the dual is evaluated through the low-rank covariance engine when that pays (large xdim*T), with the
     # reference's 1e-6 diagonal jitter (inference.py:190) carried by the per-bin blocks; otherwise the dense engine
     ctx.set_option('dual_lowrank', 1 if DUAL_LOWRANK else 0)
-    ctx.set_option('dual_f32', 1 if (DUAL_SOLVER == 'device' and DUAL_LOWRANK and DUAL_F32) else 0)
-    if DUAL_SOLVER == 'device' and len(mine):
+    ctx.set_option('dual_f32', 1 if (DUAL_SOLVER in ('device', 'fixedpoint') and DUAL_LOWRANK and DUAL_F32) else 0)
+    if DUAL_SOLVER in ('device', 'fixedpoint') and len(mine):
         # all trials in lockstep on the device, in rho = log(lambda); same optimum as either of the reference's variants
         if prevOptimRes is None:
             rho0 = np.zeros((len(mine), m)) if optimizeLogLambda else np.full((len(mine), m), np.log(0.5))
@@ -481,7 +487,17 @@ def dualVariational(experiment, params, optimizeLogLambda=False, prevOptimRes=No
             prev = np.stack([np.asarray(prevOptimRes[j] if len(prevOptimRes) == len(mine) else prevOptimRes[lo + j], dtype=np.float64)
                              for j in range(len(mine))])
             rho0 = prev if optimizeLogLambda else np.log(np.maximum(prev, 1e-300))
-        rho, fopt, iters = ctx.dual_lbfgs(mine, rho0)
+        if DUAL_SOLVER == 'fixedpoint':
+            # the optimum through the variance fixed point (pgpfa_dual_fixed_point): a handful of covariance passes per trial; a trial
+            # whose map does not contract (log-rate variances of order one) or that runs out of passes goes to L-BFGS from where it stopped
+            rho, fopt, iters, vstat = ctx.dual_fixed_point(mine, rho0, max_outer=DUAL_FP_MAX_PASSES, tol=DUAL_FP_TOL)
+            bad = np.nonzero(vstat != 0)[0]
+            if len(bad):
+                rho_b, fopt_b, it_b = ctx.dual_lbfgs(mine[bad], rho[bad])
+                rho[bad], fopt[bad] = rho_b, fopt_b
+                iters[bad] += it_b
+        else:
+            rho, fopt, iters = ctx.dual_lbfgs(mine, rho0)
         lam_all = np.exp(rho)
         optim = list(rho) if optimizeLogLambda else list(lam_all)
         nlp = ctx.dual_finalize(mine, lam_all)

@@ -1,0 +1,51 @@
+"""Optimum of the dual-variational problem by the variance fixed point (pgpfa_dual_fixed_point) against the device L-BFGS driver:
+passes / evaluations, time, dual cost, and the certificate both are held to - the max-norm of the reference's dual gradient
+(inference.py:215-219) at the returned lambda.
+usage: python tools/fixed_point_probe.py [trials] [c1|c2|c3|c5] [lbfgs: 0/1] [f32: 0/1]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'poisson-gpfa_amd')); sys.path.insert(0, ROOT)
+import numpy as np
+import bench, funs
+from funs import _session
+
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+cfg = sys.argv[2] if len(sys.argv) > 2 else 'c2'
+with_lbfgs = (sys.argv[3] == '1') if len(sys.argv) > 3 else True
+f32 = (sys.argv[4] == '1') if len(sys.argv) > 4 else False
+q, p, T, _ = dict(bench.CONFIGS, c5=(500, 20, 1000, 256))[cfg]
+true_params, Ys = bench.synth_shard(q, p, T, R, 12, 0)
+exp = bench.Shard(Ys, 10.0)
+params = {k: np.asarray(v, dtype=np.float64) for k, v in true_params.items()}
+params['tau'] = np.linspace(0.1, 0.5, p)
+sess, idx = _session.session_for(exp, p)
+sess.set_params(params)
+ctx = sess.ctx
+ctx.set_option('dual_lowrank', 1)
+ctx.set_option('dual_f32', 1 if f32 else 0)
+m = q * T
+rho0 = np.full((R, m), np.log(0.5))
+t0 = time.time()
+rho, fopt, outer, status = ctx.dual_fixed_point(idx, rho0)
+t_fp = time.time() - t0
+t0 = time.time()
+rho, fopt, outer, status = ctx.dual_fixed_point(idx, rho0)
+t_fp2 = time.time() - t0
+print('fixed point (%s, %d trials, plan_lowrank %d, rank %d): %.2f s (first call %.2f s)  passes %d..%d  status %s  mean dual cost %.8f' % (
+    cfg, R, ctx.info('plan_lowrank'), int(ctx.info('lowrank_rtot')), t_fp2, t_fp, outer.min(), outer.max(), np.bincount(status, minlength=3), fopt.mean()))
+ctx.set_option('dual_f32', 0)
+nchk = min(R, 4)
+cost, grad = ctx.dual_costgrad_batch(idx[:nchk], np.exp(rho[:nchk]))
+print('   certificate: max |dual gradient| at the returned lambda %.3e  (in rho: %.3e);  cost vs fopt %.3e' % (
+    np.max(np.abs(grad)), np.max(np.abs(grad * np.exp(rho[:nchk]))), np.max(np.abs(cost - fopt[:nchk]))))
+if with_lbfgs:
+    ctx.set_option('dual_f32', 1 if f32 else 0)
+    t0 = time.time()
+    rho_l, fopt_l, iters = ctx.dual_lbfgs(idx, rho0)
+    t_l = time.time() - t0
+    ctx.set_option('dual_f32', 0)
+    cost_l, grad_l = ctx.dual_costgrad_batch(idx[:nchk], np.exp(rho_l[:nchk]))
+    print('device L-BFGS: %.2f s  iterations %d..%d  mean dual cost %.8f   max |dual gradient| %.3e (in rho: %.3e)' % (
+        t_l, iters.min(), iters.max(), fopt_l.mean(), np.max(np.abs(grad_l)), np.max(np.abs(grad_l * np.exp(rho_l[:nchk])))))
+    print('   fixed point vs L-BFGS: dual cost %.3e lower on average (max %.3e), max |lambda difference| %.3e, speed-up %.1fx' % (
+        np.mean(fopt_l - fopt), np.max(fopt_l - fopt), np.max(np.abs(np.exp(rho) - np.exp(rho_l))), t_l / t_fp2))
