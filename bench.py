@@ -417,12 +417,27 @@ def run_dual(args, q, p, T, R, rank, world):
         rho = np.full((R, q * T), np.log(0.5))                    # the reference's start, lambda = 0.5 (inference.py:300-324)
     else:
         rho = np.log(np.exp(true_params['d'])[None, :, None] * (0.5 + rng.random((R, q, T)))).reshape(R, -1)
-    # the evaluations run inside the device L-BFGS (lambda, gradient and the correction pairs stay resident)
+    fixed_point = whole and args.dual_solver == 'fixedpoint'
+    # the evaluations run inside the device drivers (lambda, gradient, modes, offsets and the correction pairs stay resident)
     for _ in range(max(1, args.warmup)):
-        ctx.dual_lbfgs(idx, rho, max_iter=1)
+        if fixed_point:
+            ctx.dual_fixed_point(idx, rho, max_outer=1)
+        else:
+            ctx.dual_lbfgs(idx, rho, max_iter=1)
     allreduce(np.zeros(1))
     t0 = time.time()
-    rho_opt, fopt, iters = ctx.dual_lbfgs(idx, rho, max_iter=15000 if whole else args.dual_iters)
+    fp_status = None
+    if fixed_point:
+        # the optimum by the variance fixed point (pgpfa_dual_fixed_point); a trial it hands back would go to L-BFGS, as in
+        # inference.dualVariational - counted in the timed region
+        rho_opt, fopt, iters, fp_status = ctx.dual_fixed_point(idx, rho)
+        bad = np.nonzero(fp_status != 0)[0]
+        if len(bad):
+            rho_b, fopt_b, it_b = ctx.dual_lbfgs(idx[bad], rho_opt[bad])
+            rho_opt[bad], fopt[bad] = rho_b, fopt_b
+            iters[bad] += it_b
+    else:
+        rho_opt, fopt, iters = ctx.dual_lbfgs(idx, rho, max_iter=15000 if whole else args.dual_iters)
     t_opt = time.time() - t0
     evals = ctx.info('last_dual_evaluations')
     nlp = None
@@ -442,11 +457,24 @@ def run_dual(args, q, p, T, R, rank, world):
               'ms_per_batched_evaluation': t_opt / max(evals, 1) * 1e3,
               'note': 'the reference cannot run this configuration at all (its C_big alone is 74.5 GiB, BASELINE.md)'}
     if whole:
+        how = ('variational fixed point on the dual\'s stationarity conditions (Newton-PCG mode search with variance offsets in a loop with the '
+               'covariance blocks) to max |dual gradient| <= 1e-8' if fixed_point else
+               "lockstep device L-BFGS on the dual to scipy L-BFGS-B's stopping rule (factr 1e7, pgtol 1e-5)")
+        if fixed_point:
+            # the certificate both solvers are held to: the reference's dual gradient (inference.py:215-219) at the returned lambda, FP64
+            ctx.set_option('dual_f32', 0)
+            nchk = min(R, 8)
+            _, gchk = ctx.dual_costgrad_batch(idx[:nchk], np.exp(rho_opt[:nchk]))
+            common = dict(common, solver='fixedpoint', fixed_point_passes_max=int(np.max(iters)), fixed_point_passes_min=int(np.min(iters)),
+                          fixed_point_status_counts=[int(v) for v in np.bincount(fp_status, minlength=3)],
+                          max_abs_dual_gradient_at_optimum_first_trials=float(np.max(np.abs(gchk))))
+            for k in ('lbfgs_iterations_max', 'lbfgs_iterations_median', 'lbfgs_iterations_min', 'ms_per_batched_evaluation'):
+                common.pop(k, None)
         out = dict(common, metric='dual-variational E-step trials/sec', value=R * world / t_max, unit='trials/s through one whole variational E-step',
                    ms_per_step=t_max * 1e3, estep_s=t_max, optimiser_s=t_opt, finalize_s=elapsed - t_opt, neg_log_posterior_mean=nlp / R,
-                   config={'workload': '%s variational E-step: %d neurons, %d latents, %d bins, %d trials per GPU; lockstep device L-BFGS on the dual to '
-                                       "scipy L-BFGS-B's stopping rule (factr 1e7, pgtol 1e-5) from lambda = 0.5, then posterior means / covariance blocks; "
-                                       'low-rank engine (rank %d) with the reference 1e-6 diagonal jitter' % (args.config, q, p, T, R, int(ctx.info('lowrank_rtot'))),
+                   config={'workload': '%s variational E-step: %d neurons, %d latents, %d bins, %d trials per GPU; %s from lambda = 0.5, then posterior '
+                                       'means / covariance blocks; low-rank engine (rank %d) with the reference 1e-6 diagonal jitter'
+                                       % (args.config, q, p, T, R, how, int(ctx.info('lowrank_rtot'))),
                            'parallelism': 'trial-sharded x%d' % world})
     else:
         out = dict(common, metric='dual-variational trial-evaluations/sec', value=evals * R * world / t_max,
@@ -465,6 +493,8 @@ def main():
     ap.add_argument('--config', default='c3', choices=sorted(CONFIGS))
     ap.add_argument('--precision', default='mixed', choices=['mixed', 'f64'],
                     help="--workload dual: 'mixed' = FP32 matrix cores for the r x r factorisation / inverse / Yt with FP64 accumulation; 'f64'")
+    ap.add_argument('--dual-solver', default='fixedpoint', choices=['fixedpoint', 'lbfgs'],
+                    help="--workload dual, whole E-steps: the variational fixed point (default since round 4) or the lockstep device L-BFGS")
     ap.add_argument('--trials', type=int, default=0, help='override trials per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cd-method', default='newton', choices=['newton', 'TNC', 'BFGS', 'L-BFGS-B'],

@@ -210,9 +210,10 @@ int pgpfa_dual_lbfgs(pgpfa_ctx* ctx, int n, const int32_t* idx, double* rho, int
  * from the per-bin covariance blocks.  The map v -> v contracts by about half the largest posterior variance of a log rate per pass
  * (a digit or more), so a trial needs ~5-10 covariance passes where L-BFGS in rho = log lambda needs thousands of evaluations.
  * Stops per trial when max |v_new - v| <= tol - exactly the max-norm of dualProblem_grad at the returned lambda.
- * rho[n][q*T]: log lambda, start in / optimum out; fopt[n]: dual cost at the optimum (inference.py:196-213); outer[n] (may be NULL):
+ * rho[n][q*T]: log lambda, start in / optimum out; warm != 0: rho is a previous optimum and the mode search starts at its variational mean
+ * instead of at zero; fopt[n]: dual cost at the optimum (inference.py:196-213); outer[n] (may be NULL):
  * passes used; vstatus[n]: 0 converged, 1 pass cap reached, 2 not contracting (hand the trial to pgpfa_dual_lbfgs from the rho returned). */
-int pgpfa_dual_fixed_point(pgpfa_ctx* ctx, int n, const int32_t* idx, double* rho, int max_outer, double tol, double* fopt,
+int pgpfa_dual_fixed_point(pgpfa_ctx* ctx, int n, const int32_t* idx, double* rho, int warm, int max_outer, double tol, double* fopt,
                            int32_t* outer, int32_t* vstatus);
 /* VIPostMean (inference.py:193-194): mean[p*T] = -K_big C_big (lambda - ybar) for one trial, latent-major. */
 int pgpfa_dual_post_mean(pgpfa_ctx* ctx, int trial, const double* lam, double* mean);

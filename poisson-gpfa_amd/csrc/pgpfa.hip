@@ -2248,6 +2248,7 @@ struct VarJob {
   double* fopt;           // host [N]: dual cost at the optimum
   int32_t* outer;         // host [N] (may be NULL): outer iterations
   int32_t* vstatus;       // host [N]: 0 converged, 1 iteration cap, 2 not contracting
+  int warm;               // rho is a previous optimum: the mode search starts at its variational mean -K C_big (lambda - y); 0: at zero
 };
 static int ensure_lambda(pgpfa_ctx* c);
 static int dual_common(pgpfa_ctx* c, int nb, std::vector<double>* sB, std::vector<double>* sD, std::vector<double>* vKv);
@@ -2295,7 +2296,9 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
       CHK(upload(c, c->lamd, lam0.data(), lam0.size()));
       std::vector<double> sB_, sD_, vKv_;
       CHK(dual_common(c, nb, &sB_, &sD_, &vKv_));
-      hipLaunchKernelGGL(negate_rows_kernel, dim3((nvec + 255) / 256, nb), dim3(256), 0, c->st, c->KD, ld, c->Xc, ld, nvec, c->ident);
+      // (only when lambda is a previous optimum: from a cold lambda that mean is far out - hundreds in the log rate - and zero is the safe start)
+      if (var->warm) hipLaunchKernelGGL(negate_rows_kernel, dim3((nvec + 255) / 256, nb), dim3(256), 0, c->st, c->KD, ld, c->Xc, ld, nvec, c->ident);
+      else HIPC(hipMemsetAsync(c->Xc, 0, (size_t)ld * nb * sizeof(double), c->st));
       if (c->plan_lowrank) { CHK(dual_jitter(c, nb)); CHK(posterior_blocks(c, nb, 1.0, false, false)); }
       else CHK(posterior_blocks(c, nb, 1.0 + 1e-6, false));
       CHK(var_offsets(c, nb, c->voff));
@@ -3910,9 +3913,10 @@ static int var_offsets(pgpfa_ctx* c, int nb, double* out) {
 // -1/2 (C Sigma C^T)o(C Sigma C^T) diag(lambda) (I - C Sigma C^T diag(lambda)), rows sum to at most 1/2 c_n^T Sigma_t c_n), i.e. a
 // digit or more per pass, where L-BFGS in rho needs thousands of evaluations (the dual's Hessian carries C K C^T: condition > 1e4).
 // Stops per trial when max |v_new - v| <= tol: that IS the max-norm of the reference's dual gradient at the returned lambda.
-// rho[n][q*T]: log lambda, start in / optimum out; fopt[n]: dual cost there; outer[n] (may be NULL): passes; vstatus[n]: 0 converged,
+// rho[n][q*T]: log lambda, start in / optimum out; warm: rho is a previous optimum (the mode search starts at its variational mean instead
+// of zero); fopt[n]: dual cost there; outer[n] (may be NULL): passes; vstatus[n]: 0 converged,
 // 1 iteration cap, 2 not contracting (posterior variances too large for the plain fixed point: hand the trial to pgpfa_dual_lbfgs).
-int pgpfa_dual_fixed_point(pgpfa_ctx* c, int n, const int32_t* idx, double* rho, int max_outer, double tol, double* fopt, int32_t* outer,
+int pgpfa_dual_fixed_point(pgpfa_ctx* c, int n, const int32_t* idx, double* rho, int warm, int max_outer, double tol, double* fopt, int32_t* outer,
                            int32_t* vstatus) {
   if (!c) return fail("null context");
   if (!rho || !fopt || !vstatus) return fail("null argument");
@@ -3925,7 +3929,7 @@ int pgpfa_dual_fixed_point(pgpfa_ctx* c, int n, const int32_t* idx, double* rho,
   const size_t m = (size_t)c->q * c->T;
   for (size_t i = 0; i < (size_t)N * m; ++i)
     if (!std::isfinite(rho[i])) return fail("rho must be finite (trial %d, entry %zu)", tr.v[i / m], i % m);
-  VarJob job{rho, max_outer, tol, fopt, outer, vstatus};
+  VarJob job{rho, max_outer, tol, fopt, outer, vstatus, warm};
   std::vector<int32_t> it1(N), st1(N);
   double obj = 0.0;
   CHK(estep_impl(c, tr, 0, c->dual_lowrank, &obj, it1.data(), st1.data(), nullptr, &job));

@@ -56,7 +56,7 @@ _SIGNATURES = {
     'pgpfa_dual_costgrad': [ct.c_void_p, ct.c_int, c_double_p, c_double_p, c_double_p],
     'pgpfa_dual_costgrad_batch': [ct.c_void_p, ct.c_int, c_int32_p, c_double_p, c_double_p, c_double_p],
     'pgpfa_dual_lbfgs': [ct.c_void_p, ct.c_int, c_int32_p, c_double_p, ct.c_int, ct.c_double, ct.c_double, c_double_p, c_int32_p],
-    'pgpfa_dual_fixed_point': [ct.c_void_p, ct.c_int, c_int32_p, c_double_p, ct.c_int, ct.c_double, c_double_p, c_int32_p, c_int32_p],
+    'pgpfa_dual_fixed_point': [ct.c_void_p, ct.c_int, c_int32_p, c_double_p, ct.c_int, ct.c_int, ct.c_double, c_double_p, c_int32_p, c_int32_p],
     'pgpfa_dual_finalize': [ct.c_void_p, ct.c_int, c_int32_p, c_double_p, c_double_p],
     'pgpfa_dual_post_mean': [ct.c_void_p, ct.c_int, c_double_p, c_double_p],
     'pgpfa_dual_post_cov': [ct.c_void_p, ct.c_int, c_double_p, c_double_p, c_double_p],
@@ -331,7 +331,7 @@ class Context:
         check(self.lib.pgpfa_dual_lbfgs(self.h, n, iptr(ii), dptr(rho), int(max_iter), float(factr), float(pgtol), dptr(fopt), iptr(iters)))
         return rho, fopt, iters
 
-    def dual_fixed_point(self, idx, rho0, max_outer=40, tol=1e-8):
+    def dual_fixed_point(self, idx, rho0, max_outer=40, tol=1e-8, warm=False):
         """Optimum of the dual by the variance fixed point (pgpfa_dual_fixed_point) -> (rho_opt[n][q*T], dual optimum[n], passes[n],
         status[n]: 0 converged, 1 pass cap, 2 not contracting)."""
         n, ii = self._n_idx(idx)
@@ -339,7 +339,7 @@ class Context:
         fopt = np.empty(n)
         outer = np.zeros(n, dtype=np.int32)
         status = np.zeros(n, dtype=np.int32)
-        check(self.lib.pgpfa_dual_fixed_point(self.h, n, iptr(ii), dptr(rho), int(max_outer), float(tol), dptr(fopt), iptr(outer), iptr(status)))
+        check(self.lib.pgpfa_dual_fixed_point(self.h, n, iptr(ii), dptr(rho), 1 if warm else 0, int(max_outer), float(tol), dptr(fopt), iptr(outer), iptr(status)))
         return rho, fopt, outer, status
 
     def dual_finalize(self, idx, lam):

@@ -371,7 +371,7 @@ def dualProblemRho_grad(rho, ybar, C_big, K_big, K_bigInv, d_big):
 # 'fixedpoint': the optimum of the same dual through the fixed point of its stationarity conditions (pgpfa_dual_fixed_point: the Laplace
 # Newton-PCG with variance offsets in a loop with the covariance blocks) - the zero of the reference's dual gradient to DUAL_FP_TOL
 # in a handful of passes, where either L-BFGS stops on its decrease test after thousands of evaluations
-DUAL_SOLVER = 'device'
+DUAL_SOLVER = 'fixedpoint'
 # passes / tolerance of DUAL_SOLVER = 'fixedpoint' (the tolerance is the max-norm of the reference's dual gradient at the returned lambda)
 DUAL_FP_MAX_PASSES = 40
 DUAL_FP_TOL = 1e-8
@@ -490,7 +490,7 @@ def dualVariational(experiment, params, optimizeLogLambda=False, prevOptimRes=No
         if DUAL_SOLVER == 'fixedpoint':
             # the optimum through the variance fixed point (pgpfa_dual_fixed_point): a handful of covariance passes per trial; a trial
             # whose map does not contract (log-rate variances of order one) or that runs out of passes goes to L-BFGS from where it stopped
-            rho, fopt, iters, vstat = ctx.dual_fixed_point(mine, rho0, max_outer=DUAL_FP_MAX_PASSES, tol=DUAL_FP_TOL)
+            rho, fopt, iters, vstat = ctx.dual_fixed_point(mine, rho0, max_outer=DUAL_FP_MAX_PASSES, tol=DUAL_FP_TOL, warm=prevOptimRes is not None)
             bad = np.nonzero(vstat != 0)[0]
             if len(bad):
                 rho_b, fopt_b, it_b = ctx.dual_lbfgs(mine[bad], rho[bad])

@@ -692,13 +692,14 @@ def test_device_lbfgs_dual_solver_matches_scipy_driver(funs_mod):
     exp = Experiment(Ys, float(g['binSize']))
     params = {'C': g['init_C'].copy(), 'd': g['init_d'].copy(), 'tau': g['init_tau'].copy()}
     out = {}
+    default_solver = funs_mod.inference.DUAL_SOLVER
     for solver in ('device', 'scipy'):
         funs_mod.inference.DUAL_SOLVER = solver
         try:
             out[solver] = funs_mod.inference.dualVariational(exp, params)
             out[solver][0].materialize()              # the second solver's run overwrites the device views of the first
         finally:
-            funs_mod.inference.DUAL_SOLVER = 'device'
+            funs_mod.inference.DUAL_SOLVER = default_solver
     (ir_d, nll_d, vlb_d, opt_d), (ir_s, nll_s, vlb_s, opt_s) = out['device'], out['scipy']
     assert abs(vlb_d - vlb_s) <= 1e-4 and abs(nll_d - nll_s) <= 1e-4
     assert abs(vlb_d - float(g['estep_vlb'])) <= 1e-3

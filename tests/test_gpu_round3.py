@@ -269,12 +269,14 @@ def _dense_dual_reference(C, d, tau, y, lam, T, bin_ms):
 @pytest.mark.timeout(3000)
 def test_config5_variational_estep_to_convergence(funs_mod, monkeypatch):
     """BASELINE config 5 as a workload: inference.dualVariational (inference.py:259-432) at 500 neurons, 20 latents, 1000 bins on
-    4 trials, run to the reference's stopping rule on the device - in FP64 and in mixed precision (DUAL_F32) - through the low-rank
-    engine (default at this size).  Checked against plain numpy on the dense 20 000 x 20 000 matrices of trial 0 (dual cost 1e-8,
-    gradient 1e-6 of its largest entry, covariance blocks 1e-7, posterior mean 1e-9), by the structured posterior-mean identity
-    post_mean = -K C_big (lambda - y) on every trial, by stationarity (the gradient in rho = log lambda at the optimum is below 2e-2 of
-    the one at the start - the reference's stopping rule is a decrease test); mixed vs FP64: cost 1e-5 at the same lambda, the two
-    optima within 2e-3 of each other in the bound."""
+    4 trials, run to the optimum on the device by the variational fixed point (the default solver since round 4; round 3 ran the device
+    L-BFGS here: 3000-6000 iterations per trial to scipy's decrease test) - in FP64 and in mixed precision (DUAL_F32) - through the
+    low-rank engine (default at this size).  Checked against plain numpy on the dense 20 000 x 20 000 matrices of trial 0: dual cost
+    1e-8, the reference's dual gradient (inference.py:215-219) BELOW 1e-6 in the max-norm in numpy's own arithmetic - the optimum is the
+    zero of the reference's function, not of ours -, device gradient vs numpy 1e-8 absolute, covariance blocks 1e-7, posterior mean 1e-9;
+    the structured posterior-mean identity post_mean = -K C_big (lambda - y) on every trial; a few L-BFGS iterations from the optimum do
+    not lower the dual (1e-10 rel); mixed vs FP64: cost 1e-5 at the same lambda, the two optima within 1e-5 of each other in the bound
+    (round 3: 2e-3, what two decrease-test stops left); a warm restart (prevOptimRes) settles in one pass."""
     import bench
     inf = funs_mod.inference
     q, p, T, R = 500, 20, 1000, 4
@@ -282,6 +284,7 @@ def test_config5_variational_estep_to_convergence(funs_mod, monkeypatch):
     par = {'C': true['C'], 'd': true['d'], 'tau': np.linspace(0.1, 0.5, p)}
     exp = Experiment([y.astype(float) for y in Ys], 10.0)
     m = q * T
+    assert inf.DUAL_SOLVER == 'fixedpoint'
     out = {}
     for f32 in (False, True):
         monkeypatch.setattr(inf, 'DUAL_F32', f32)
@@ -291,35 +294,36 @@ def test_config5_variational_estep_to_convergence(funs_mod, monkeypatch):
         assert sess.ctx.info('plan_lowrank') == 1.0
         lam = np.exp(np.stack(opt))
         idx = np.arange(R, dtype=np.int32)
-        cost, grad = sess.ctx.dual_costgrad_batch(idx, lam)
+        sess.ctx.set_option('dual_f32', 0)
+        cost, grad = sess.ctx.dual_costgrad_batch(idx, lam)           # FP64 evaluation at either run's optimum
         out[f32] = dict(nll=nll, vlb=vlb, lam=lam, iters=infRes.dual_iterations.copy(), cost=cost, grad=grad,
-                        pm=np.stack([infRes['post_mean'][r] for r in range(R)]), vsm0=infRes['post_vsm'][0].copy(),
-                        evals=sess.ctx.info('last_dual_evaluations'))
+                        pm=np.stack([infRes['post_mean'][r] for r in range(R)]), vsm0=infRes['post_vsm'][0].copy())
         if f32:
             # the mixed-precision evaluation at the FP64 run's optimum (same lambda: what the precision itself changes)
-            cm, gm = sess.ctx.dual_costgrad_batch(idx, out[False]['lam'])
-            out['mixed_at_f64_opt'] = (cm, gm)
-        if not f32:
-            # gradient at the start (lambda = 1, rho = 0: the reference's start of the log-lambda variant, inference.py:391-396)
-            c0, g0 = sess.ctx.dual_costgrad_batch(idx, np.ones((R, m)))
-            out['g0'] = np.max(np.abs(g0), axis=1)
-            out['c0'] = c0
-        print('config 5, %s: L-BFGS iterations %s, bound %.6f, nll %.6f' % ('mixed' if f32 else 'f64', out[f32]['iters'], vlb, nll))
+            sess.ctx.set_option('dual_f32', 1)
+            out['mixed_at_f64_opt'] = sess.ctx.dual_costgrad_batch(idx, out[False]['lam'])
+            sess.ctx.set_option('dual_f32', 0)
+        else:
+            # a few quasi-Newton iterations from the optimum find nothing lower
+            rho_l, fopt_l, it_l = sess.ctx.dual_lbfgs(idx, np.log(lam), max_iter=5)
+            out['lbfgs_from_opt'] = fopt_l
+            # warm restart: one pass
+            ir_w, nll_w, vlb_w, _ = inf.dualVariational(exp, dict(par), optimizeLogLambda=True, prevOptimRes=opt)
+            out['warm'] = (ir_w.dual_iterations.copy(), vlb_w, nll_w)
+        print('config 5, %s: fixed-point passes %s, bound %.6f, nll %.6f, max |dual gradient| %.2e' % (
+            'mixed' if f32 else 'f64', out[f32]['iters'], vlb, nll, np.max(np.abs(grad))))
     funs_mod._session.drop_sessions()
     a, b = out[False], out[True]
-    assert np.all(a['iters'] > 10) and np.all(a['iters'] < 15000)
-    # the optimiser went downhill to a stationary point: gradient in rho (= lambda * gradient in lambda) vs the start
-    for r in range(R):
-        assert a['cost'][r] < out['c0'][r]
-        # (what scipy's L-BFGS-B stopping rule - relative decrease of the dual below 2.2e-9 - leaves: measured 3.6e-3)
-        assert np.max(np.abs(a['grad'][r] * a['lam'][r])) <= 2e-2 * out['g0'][r]
-    # mixed precision: the same function (cost 1e-5 rel, gradient 1e-3 of its largest entry at the same lambda) ...
+    assert np.all(a['iters'] >= 2) and np.all(a['iters'] <= 12) and np.all(b['iters'] <= 12)
+    assert np.max(np.abs(a['grad'])) <= 1e-6 and np.max(np.abs(b['grad'])) <= 1e-5
+    assert np.all(out['lbfgs_from_opt'] >= a['cost'] - 1e-10 * np.abs(a['cost']))
+    assert np.all(out['warm'][0] == 1) and abs(out['warm'][1] - a['vlb']) <= 1e-9 * abs(a['vlb'])
+    # mixed precision: the same function (cost 1e-5 rel, gradient 1e-3 of the FP64 gradient's scale at a generic point is covered by
+    # test_dual_mixed_precision_at_config5_dimensions; here at the optimum, absolute) and the same optimum
     cm, gm = out['mixed_at_f64_opt']
     assert np.max(np.abs(cm - a['cost']) / np.abs(a['cost'])) <= 1e-5
-    assert max(rel(gm[r], a['grad'][r]) for r in range(R)) <= 1e-3
-    # ... and the same optimum within what the reference's stopping rule determines at this size (two L-BFGS runs that both meet
-    # scipy's decrease test after 3000-6000 iterations of a 500 000-dimensional problem: measured 2.7e-4 apart in the bound)
-    assert abs(b['vlb'] - a['vlb']) <= 2e-3 * abs(a['vlb']) and abs(b['nll'] - a['nll']) <= 1e-2 * abs(a['nll'])
+    assert np.max(np.abs(gm - a['grad'])) <= 1e-4
+    assert abs(b['vlb'] - a['vlb']) <= 1e-5 * abs(a['vlb']) and abs(b['nll'] - a['nll']) <= 1e-5 * abs(a['nll'])
     # structured identity on every trial: post_mean = -K C_big (lambda - y)  (inference.py:194)
     K = orc.make_K(par['tau'], T, 10.0)
     for r in range(R):
@@ -327,10 +331,11 @@ def test_config5_variational_estep_to_convergence(funs_mod, monkeypatch):
         assert rel(a['pm'][r], -np.einsum('kts,ks->kt', K, v)) <= 1e-9
     # dense numpy, trial 0, at the FP64 optimum
     cost, grad, mean, blocks = _dense_dual_reference(par['C'], par['d'], par['tau'], Ys[0].astype(float).reshape(-1), a['lam'][0], T, 10.0)
-    print('config 5 trial 0 vs dense numpy: cost %.3e, grad %.3e, blocks %.3e (f64) / %.3e (mixed, at its own optimum vs f64)'
-          % (abs(a['cost'][0] - cost) / abs(cost), rel(a['grad'][0], grad), rel(a['vsm0'], blocks), rel(b['vsm0'], a['vsm0'])))
+    print('config 5 trial 0 vs dense numpy: cost %.3e, numpy max |grad| %.3e, device - numpy grad %.3e, blocks %.3e (f64) / %.3e (mixed, at its own optimum vs f64)'
+          % (abs(a['cost'][0] - cost) / abs(cost), np.max(np.abs(grad)), np.max(np.abs(a['grad'][0] - grad)), rel(a['vsm0'], blocks), rel(b['vsm0'], a['vsm0'])))
     assert abs(a['cost'][0] - cost) <= 1e-8 * abs(cost)
-    assert rel(a['grad'][0], grad) <= 1e-6
+    assert np.max(np.abs(grad)) <= 1e-6
+    assert np.max(np.abs(a['grad'][0] - grad)) <= 1e-8
     assert rel(a['vsm0'], blocks) <= 1e-7
     assert rel(a['pm'][0], mean) <= 1e-9
 

@@ -23,14 +23,14 @@ funs.inference.dualVariational(bench.Shard(Ys[:2], 10.0), params)            # w
 t0 = time.time()
 infRes, nll, vlb, opt = funs.inference.dualVariational(exp, params)
 t_dev = time.time() - t0
-print('device L-BFGS (%s, low-rank dual %s, plan_lowrank %d): %d trials in %.2f s  (nll %.4f, vlb %.4f, iterations %d..%d)' % (
+print('default solver [' + funs.inference.DUAL_SOLVER + '] (%s, low-rank dual %s, plan_lowrank %d): %d trials in %.2f s  (nll %.4f, vlb %.4f, iterations %d..%d)' % (
     cfg, funs.inference.DUAL_LOWRANK, sess.ctx.info('plan_lowrank'), R, t_dev, nll, vlb, infRes.dual_iterations.min(), infRes.dual_iterations.max()))
 if os.environ.get('PROBE_SCIPY', '1') == '1':
     funs.inference.DUAL_SOLVER = 'scipy'
     t0 = time.time()
     infRes, nll, vlb, opt = funs.inference.dualVariational(exp, params)
     t_conc = time.time() - t0
-    funs.inference.DUAL_SOLVER = 'device'
+    funs.inference.DUAL_SOLVER = 'fixedpoint'
     print('concurrent scipy L-BFGS-B: %d trials in %.2f s  (nll %.4f, vlb %.4f)' % (R, t_conc, nll, vlb))
 else:
     t_conc = t_dev
