@@ -207,6 +207,7 @@ struct pgpfa_ctx {
   bool last_cov_lowrank = false;
   bool shared_pcg = true;
   bool pcg_trace = false;
+  int mix_slot = 1;                           // option mix_slot: the mixing pass of the split form with a thread per bin and whole columns per workgroup (split.h)
   bool cross_kernel = true;                       // option cross_kernel = 0: the cross term of the split form through the general GEMM kernel
   bool measure_mix = false;                       // option measure_mix: record max_t eps ||Wt_t|| of every covariance pass
   bool time_newton = false;                       // option time_newton: HIP events around the inner PCG solves (last_newton_solve_ms / _bytes)
@@ -1278,6 +1279,7 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
   else if (k == "pcg_fused") c->pcg_fused = (int)v;
   else if (k == "pcg_w32") c->pcg_w32 = (v != 0.0);
   else if (k == "pcg_form") c->pcg_form = (int)v;
+  else if (k == "mix_slot") c->mix_slot = (int)v;
   else if (k == "chord") c->chord = (v != 0.0);
   else if (k == "shared_pcg") c->shared_pcg = (v != 0.0);
   else if (k == "time_newton") c->time_newton = (v != 0.0);
@@ -1890,6 +1892,13 @@ static int accumulate_split(pgpfa_ctx* c, const CholWS& lw, int nb, int ract, in
   prof_begin(c, TAG_VSM, (double)nb * c->n * rpad * (3.0 * p + 1.0));
   dispatch_pw(p, [&](auto pw) {
     constexpr int PW = decltype(pw)::value;
+    if constexpr (PW <= 10) {
+      if (c->mix_slot) {
+        hipLaunchKernelGGL((mix_slot_kernel<PW, 256, 2>), dim3((T + 255) / 256, nb), dim3(256), 0, c->st, (const double*)lw.H, (long long)lw.sH, c->ld, D, sD, ldd,
+                           c->Gbin, sW, T, p, ract, c->eps, c->vsm, c->ident, c->trial_of_slot, c->d_roff, (int)GBN, Ts);
+        return;
+      }
+    }
     if constexpr (PW <= 16)
       hipLaunchKernelGGL(mix_vsm_split_kernel<PW>, dim3((T + 63) / 64, nb), dim3(256), 0, c->st, (const double*)lw.H, (long long)lw.sH, c->ld, D, sD, ldd,
                          c->Gbin, sW, T, p, ract, c->eps, c->vsm, c->ident, c->trial_of_slot, c->d_roff, (int)GBN, Ts);

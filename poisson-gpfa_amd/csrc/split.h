@@ -22,6 +22,11 @@ typedef float float4v_t __attribute__((ext_vector_type(4)));
 
 constexpr float SPLIT_SCALE = 2048.0f;          // |D| <= sqrt(p) (rows of Yt have norm <= 1, eps ||Wt|| < 1): 2^11 |D| < 65504 up to p = 1000
 
+// (Tried in round 4 and dropped: storing D already split - hi | lo << 16 in one 32-bit word written by the mixing pass - so that the FP16
+// kernel stops converting per tile.  The cross term then has to read d back as (hi + lo) 2^-11, and lo underflows into FP16 denormals for
+// |d| < 1e-4: tools/probes/split_pack_probe.hip measures 1.4e-5 relative error at |d| = 1e-6, PautoSum lands at 2e-7 .. 2e-6 instead of 1e-9.
+// Writing both forms costs the mixing pass what the FP16 kernel would save.)
+
 // Mixing pass of the split form: like mix_vsm_kernel it accumulates post_vsm[t] = eps G_t + sum_b (G_t y_b)(G_t y_b)^T over the columns
 // of the slab, but leaves Yt as it is and writes the correction D[(k,t), b] = y - G_t y (= eps Wt_t y) in single precision
 // (column stride ldd floats, latent stride ts) - half the bytes of the in-place FP64 mix.
@@ -98,6 +103,102 @@ __global__ __launch_bounds__(256, 2) void mix_vsm_split_kernel(const double* __r
     const int t = e / pp, idx = e - t * pp, i = idx / p, j = idx - i * p;
     vbase[e] = Gs[t * LD + i * PW + j];
   }
+}
+
+// The same pass with a thread per bin and a workgroup per (slot, run of NTH consecutive bins): the workgroup walks the columns of its slot's
+// slab together, so column b of latent k is ONE contiguous run of NTH doubles (2 KB at NTH = 256) instead of the 512-byte pieces eight
+// workgroups of mix_vsm_split_kernel pick out of it at different times - HBM row locality is what that kernel runs at 2.2 TB/s on.  A bin
+// belongs to one thread: its symmetric G_t (55 values at 10 latents) and the 55 pair sums stay in that thread's registers for the whole
+// pass, nothing goes through LDS, nothing is reduced across waves.  One wave per SIMD (the register budget of a 256-thread workgroup is 512
+// per lane), U columns' loads in flight per trip.  Measured at config 3: 7.9 ms instead of 9.8 ms per E-step at the bench's ranks (3.9 TB/s
+// of its algorithmic bytes); 4 columns per trip, 128- or 512-bin workgroups (the latter spills) and a software pipeline change nothing.  Entries of Yt left of a latent's first column tile were never written: their (uniform)
+// addresses are clamped to the first written column and the values masked.
+// grid = (ceil(T / NTH), nslots), block = NTH, p <= PW <= 10.
+template <int PW, int NTH, int U>
+__global__ __launch_bounds__(NTH, 1) void mix_slot_kernel(const double* __restrict__ Yt, long long sY, int ldy, float* __restrict__ D, long long sD, int ldd,
+                                                          const double* __restrict__ G, long long sG, int T, int p, int ract, double eps,
+                                                          double* __restrict__ vsm, const int* __restrict__ slots,
+                                                          const int* __restrict__ trial_of_slot, const int* __restrict__ roff, int col_tile, int ts) {
+  constexpr int NPAIR = PW * (PW + 1) / 2;
+  const int pp = p * p;
+  const int slot = slots[blockIdx.y];
+  const int t = blockIdx.x * NTH + threadIdx.x;
+  const bool live = t < T;
+  const int tc = live ? t : T - 1;
+  const double* gsrc = G + (size_t)slot * sG + (size_t)tc * pp;
+  double g[NPAIR], acc[NPAIR];
+#pragma unroll
+  for (int a = 0; a < PW; ++a)
+#pragma unroll
+    for (int c2 = 0; c2 <= a; ++c2) {
+      g[a * (a + 1) / 2 + c2] = gsrc[(a < p ? a : 0) * p + (a < p ? c2 : 0)];
+      acc[a * (a + 1) / 2 + c2] = 0.0;
+    }
+  int c0[PW];
+#pragma unroll
+  for (int k = 0; k < PW; ++k) c0[k] = (roff && k < p) ? (roff[k] / col_tile) * col_tile : 0;
+  const double* y = Yt + (size_t)slot * sY + tc;
+  float* d = D + (size_t)slot * sD + tc;
+  // software pipeline: the loads of the next U columns are in flight while the current ones are mixed (one wave per SIMD: nobody else hides them)
+  double v[U][PW], vn[U][PW];
+  auto load_cols = [&](int b0, double (&dst)[U][PW]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int b = (b0 + u < ract) ? b0 + u : ract - 1;
+#pragma unroll
+      for (int k = 0; k < PW; ++k) {
+        const int kc = k < p ? k : 0;
+        const int bc = b >= c0[kc] ? b : c0[kc];                 // (uniform: every thread of the workgroup clamps alike)
+        dst[u][k] = y[(size_t)bc * ldy + (size_t)kc * ts];
+      }
+    }
+  };
+  load_cols(0, v);
+  for (int b0 = 0; b0 < ract; b0 += U) {
+    load_cols(b0 + U < ract ? b0 + U : b0, vn);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int b = b0 + u;
+      if (b >= ract) break;
+      double m[PW];
+#pragma unroll
+      for (int k = 0; k < PW; ++k) {
+        v[u][k] = (k < p && b >= c0[k < p ? k : 0]) ? v[u][k] : 0.0;
+        m[k] = 0.0;
+      }
+#pragma unroll
+      for (int a = 0; a < PW; ++a)
+#pragma unroll
+        for (int c2 = 0; c2 <= a; ++c2) {
+          const double gg = g[a * (a + 1) / 2 + c2];
+          m[a] += gg * v[u][c2];
+          if (c2 != a) m[c2] += gg * v[u][a];
+        }
+#pragma unroll
+      for (int k = 0; k < PW; ++k)
+        if (k < p && live) d[(size_t)b * ldd + (size_t)k * ts] = (float)(v[u][k] - m[k]);
+#pragma unroll
+      for (int a = 0; a < PW; ++a)
+#pragma unroll
+        for (int c2 = 0; c2 <= a; ++c2) acc[a * (a + 1) / 2 + c2] += m[a] * m[c2];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int k = 0; k < PW; ++k) v[u][k] = vn[u][k];
+  }
+  if (!live) return;
+  double* vdst = vsm + ((size_t)trial_of_slot[slot] * T + t) * pp;
+#pragma unroll
+  for (int a = 0; a < PW; ++a)
+#pragma unroll
+    for (int c2 = 0; c2 <= a; ++c2) {
+      if (a < p) {
+        const double val = eps * g[a * (a + 1) / 2 + c2] + acc[a * (a + 1) / 2 + c2];
+        vdst[a * p + c2] = val;
+        vdst[c2 * p + a] = val;
+      }
+    }
 }
 
 // part[(k * ngroups + g)][T x T] (column-major, ld = T, lower 64 x 64 wave tiles) = sum over the slots of group g, over columns b < ract,

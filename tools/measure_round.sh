@@ -1,6 +1,6 @@
 # Measurement set committed under profiles/ once per round (run on the GPU box through gpurun): bash tools/measure_round.sh <tag>
 set -x
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -9,7 +9,9 @@ python bench.py --steps 20 --warmup 5 > $O/bench_c3_driver_protocol.json 2> $O/b
 python bench.py --config c2 --steps 20 --warmup 5 > $O/bench_c2.json 2>/dev/null
 python bench.py --config c1 --steps 20 --warmup 2 --no-cpu-baseline > $O/bench_c1.json 2>/dev/null
 python bench.py --workload online --steps 6 --warmup 2 > $O/bench_c4_online.json 2>/dev/null
-python bench.py --workload dual --config c5 --trials 32 > $O/bench_c5_dual_estep_mixed.json 2>/dev/null
+python bench.py --workload dual --config c5 --trials 256 > $O/bench_c5_dual_estep_mixed.json 2>/dev/null
+python bench.py --workload dual --config c5 --trials 256 --precision f64 > $O/bench_c5_dual_estep_f64.json 2>/dev/null
+python bench.py --workload dual --config c5 --trials 16 --dual-solver lbfgs > $O/bench_c5_dual_estep_mixed_lbfgs_16_trials.json 2>/dev/null
 python bench.py --workload dual --config c5 --trials 256 --dual-iters 6 --warmup 1 > $O/bench_c5_dual_unit_mixed.json 2>/dev/null
 python bench.py --workload dual --config c5 --trials 256 --dual-iters 6 --warmup 1 --precision f64 > $O/bench_c5_dual_unit_f64.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
@@ -27,6 +29,8 @@ python tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/pmc_hbm_traffic.json | 
 rm -rf $O/pmc_fetch $O/pmc_write
 python tools/gemm_shapes.py 12 > $O/gemm_shapes.txt 2>/dev/null
 python tools/split_probe.py 512 > $O/split_probe.txt 2>/dev/null
+python tools/pcg_probe.py 1024 4 init 101 > $O/pcg_probe.txt 2>/dev/null
+python tools/fixed_point_probe.py 16 c2 1 0 > $O/fixed_point_probe_c2.txt 2>/dev/null
 python tools/cold_start_probe.py > $O/cold_start.txt 2>/dev/null
 python tools/em_trace.py 60 > $O/em_trace_60_iterations.txt 2>/dev/null
 ls -la $O
