@@ -215,12 +215,18 @@ __global__ __launch_bounds__(256, BT == 128 ? 2 : 3) void gemm_mfma_kernel_t(Gem
   // staging registers: NU pairs per operand per thread
   T ra[2 * NU], rb[2 * NU];
   // (TRANSB) the B column each staging unit of this thread reads: j0 + nn, or its entry in the column list (clamped inside the list)
+  // TRANSB staging map: 8 consecutive lanes walk the 16 k of a step of ONE column (a 128-byte line of that slot vector), a wave covers 8
+  // columns - with lanes along the columns instead (the round-1 map) every load instruction touched 64 lines for 16 bytes each.  The
+  // transposed LDS image would then be written 8-way conflicted (rows two apart are 320 words = 0 mod 64 apart), so its column index is
+  // XOR-swizzled with ((k >> 1) & 7) << 3: the 64 (column, k pair) stores of a wave spread over all banks (2-way, the minimum for 8-byte
+  // stores), and the fragment reads - 16 consecutive columns of rows kk + l4 - stay conflict-free because rows 2m, 2m + 1 share a swizzle.
   int bcol[NU];
 #pragma unroll
   for (int s = 0; s < NU; ++s) {
-    const int jj = j0 + (tid + 256 * s) % BT;
+    const int jj = j0 + (tid + 256 * s) / 8;
     bcol[s] = (TRANSB && g.cols) ? g.cols[jj < g.N ? jj : g.N - 1] : jj;
   }
+  auto bswz = [](int k) { return TRANSB ? (((k >> 1) & 7) << 3) : 0; };
 
   auto load_tiles = [&](int k0) {
 #pragma unroll
@@ -249,8 +255,8 @@ __global__ __launch_bounds__(256, BT == 128 ? 2 : 3) void gemm_mfma_kernel_t(Gem
         } else {
           rb[2 * s] = src[0]; rb[2 * s + 1] = src[1];
         }
-      } else {  // B is K x N: unit -> n = u % BT, k pair = u / BT
-        const int nn = u % BT, k2 = (u / BT) * 2;
+      } else {  // B is K x N: unit -> k pair = u % 8, n = u / 8
+        const int k2 = (u % 8) * 2;
         const T* src = B + (size_t)bcol[s] * g.ldb + (k0 + k2);
         if (b_vec) {
           const T2 v = *reinterpret_cast<const T2*>(src);
@@ -273,7 +279,7 @@ __global__ __launch_bounds__(256, BT == 128 ? 2 : 3) void gemm_mfma_kernel_t(Gem
         const int k = u / (BT / 2), r2 = (u % (BT / 2)) * 2;
         *reinterpret_cast<T2*>(&Bs[buf][k][r2]) = T2{rb[2 * s], rb[2 * s + 1]};
       } else {
-        const int nn = u % BT, k2 = (u / BT) * 2;
+        const int nn = (u / 8) ^ bswz(u % 8 * 2), k2 = (u % 8) * 2;
         Bs[buf][k2][nn] = rb[2 * s];
         Bs[buf][k2 + 1][nn] = rb[2 * s + 1];
       }
@@ -307,7 +313,7 @@ __global__ __launch_bounds__(256, BT == 128 ? 2 : 3) void gemm_mfma_kernel_t(Gem
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) af[mi] = As[buf][kk + l4][wm * WT + mi * 16 + l15];
 #pragma unroll
-        for (int ni = 0; ni < MI; ++ni) bf[ni] = Bs[buf][kk + l4][wn * WT + ni * 16 + l15];
+        for (int ni = 0; ni < MI; ++ni) bf[ni] = Bs[buf][kk + l4][(wn * WT + ni * 16 + l15) ^ bswz(kk + l4)];
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
