@@ -1864,7 +1864,7 @@ static int posterior_blocks_dense(pgpfa_ctx* c, int nb, double diag_scale, bool 
 
 // Sum-only covariance output by the exact split form (split.h): Pacc[k] += sum over the chunk's slots of Y~_k Y~_k^T + eps diag(G_t[k][k])
 // from L^-T (lw.Mt), Yt (lw.H) and the per-bin blocks G (c->Gbin), without the full-width FP64 product.  Also writes post_vsm.
-static int accumulate_split(pgpfa_ctx* c, const CholWS& lw, int nb, int ract, int Ts, bool skip_zero_cols) {
+static int accumulate_split(pgpfa_ctx* c, const CholWS& lw, int nb, int ract, int Ts, bool skip_zero_cols, int ctile) {
   const int T = c->T, p = c->p, Tp = c->Tp, rpad = c->rpad;
   const long long sW = (long long)T * p * p;
   const size_t tt = (size_t)T * T;
@@ -1895,13 +1895,13 @@ static int accumulate_split(pgpfa_ctx* c, const CholWS& lw, int nb, int ract, in
     if constexpr (PW <= 10) {
       if (c->mix_slot) {
         hipLaunchKernelGGL((mix_slot_kernel<PW, 256, 2>), dim3((T + 255) / 256, nb), dim3(256), 0, c->st, (const double*)lw.H, (long long)lw.sH, c->ld, D, sD, ldd,
-                           c->Gbin, sW, T, p, ract, c->eps, c->vsm, c->ident, c->trial_of_slot, c->d_roff, (int)GBN, Ts);
+                           c->Gbin, sW, T, p, ract, c->eps, c->vsm, c->ident, c->trial_of_slot, c->d_roff, ctile, Ts);
         return;
       }
     }
     if constexpr (PW <= 16)
       hipLaunchKernelGGL(mix_vsm_split_kernel<PW>, dim3((T + 63) / 64, nb), dim3(256), 0, c->st, (const double*)lw.H, (long long)lw.sH, c->ld, D, sD, ldd,
-                         c->Gbin, sW, T, p, ract, c->eps, c->vsm, c->ident, c->trial_of_slot, c->d_roff, (int)GBN, Ts);
+                         c->Gbin, sW, T, p, ract, c->eps, c->vsm, c->ident, c->trial_of_slot, c->d_roff, ctile, Ts);
   });
   prof_end(c);
   // 2. the full-width term on the FP16 matrix cores: partial sums per (latent, group of slots) into c->ppart
@@ -2032,6 +2032,10 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool 
   // the same offsets and takes those entries as zeros without reading them (the mixing pass up to 16 latents, the matrix-core post_vsm
   // beyond 10) the product skips the whole 128-column tiles left of it: ~45 % of the flops and stores.
   const bool skip_zero_cols = want_vsmgp ? p <= 16 : (p > 10 && c->vsm_mfma);
+  // granularity of that skipping: the mixing passes take any multiple of 16 (the ranks are padded to 16, so exactly the zero columns are left
+  // out: 128-column tiles kept 64 of them per latent on average - 18 % of the product and of the pass at config 3), the matrix-core post_vsm whole
+  // 128-column tiles
+  const int ctile = (want_vsmgp && p <= 16) ? 16 : (int)GBN;
   // rows (k, t) of the Yt slab sit at k * Ts + t with Ts = T rounded up to 16 when the slab is tall enough: the 64-bin runs of the mixing pass and
   // the product's stores then start on 128-byte lines (at T = 500 every run straddled one: 1.4x the bytes fetched, PMC)
   const int Ts = (c->slab_row_align && p * round_up(T, 16) <= c->ld) ? round_up(T, 16) : T;
@@ -2091,7 +2095,7 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool 
     CHK(inverse_t(c, lwf, c->ident, nb, true));
     // Yt (float, n x ract, ld = c->ld) behind L^-T in the same slab
     for (int k = 0; k < p; ++k) {
-      const int c0 = skip_zero_cols ? (c->roff[k] / GBN) * GBN : 0;      // (see the FP64 product below)
+      const int c0 = skip_zero_cols ? (c->roff[k] / ctile) * ctile : 0;      // (see the FP64 product below)
       if (c0 >= ract) continue;
       GemmP g{};
       g.A = reinterpret_cast<const double*>(c->Flr32 + (size_t)k * Tp * Tp); g.sA = 0; g.lda = Tp;
@@ -2126,7 +2130,7 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool 
   // c. Yt = F Mts  (n x rpad, ld = c->ld) into the factor slab (the factor itself is dead now)
   // (column tiles left of roff[k] skipped under skip_zero_cols, see above)
   for (int k = 0; k < p; ++k) {
-    const int c0 = skip_zero_cols ? (c->roff[k] / GBN) * GBN : 0;
+    const int c0 = skip_zero_cols ? (c->roff[k] / ctile) * ctile : 0;
     if (c0 >= ract) continue;
     GemmP g{};
     g.A = c->Flr + (size_t)k * Tp * Tp; g.sA = 0; g.lda = Tp;
@@ -2154,7 +2158,7 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool 
   }
   c->info["last_split_cov"] = split ? 1.0 : 0.0;
   if (want_vsmgp && split) {
-    CHK(accumulate_split(c, lw, nb, ract, Ts, skip_zero_cols));
+    CHK(accumulate_split(c, lw, nb, ract, Ts, skip_zero_cols, ctile));
   } else if (want_vsmgp) {
     // d+e. one pass over Yt: post_vsm[t] = eps G_t + sum_b (G_t y_b)(G_t y_b)^T, and Yt is mixed in place (y <- G_t y) so that
     //      rows (k,.) of the slab become Ymix_k, the GEMM operand of post_vsmGP_k = eps diag(G_t[k][k]) + Ymix_k Ymix_k^T
@@ -2163,7 +2167,7 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool 
       constexpr int PW = decltype(pw)::value;
       if constexpr (PW <= 16) {
         hipLaunchKernelGGL(mix_vsm_kernel<PW>, dim3((T + 63) / 64, nb), dim3(256), 0, c->st, lw.H, lw.sH, c->ld, c->Gbin, sW, T, p, ract, c->eps,
-                           c->vsm, c->ident, c->trial_of_slot, c->d_roff, (int)GBN, Ts);
+                           c->vsm, c->ident, c->trial_of_slot, c->d_roff, ctile, Ts);
       } else {
         const int bins = wide_bins(p);
         hipLaunchKernelGGL(mix_vsm_wide_kernel, dim3((T + bins - 1) / bins, nb), dim3(bins * 32), wide_lds_bytes(p, bins, 1), c->st, lw.H, lw.sH,
