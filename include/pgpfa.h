@@ -75,6 +75,8 @@ int pgpfa_destroy(pgpfa_ctx* ctx);
  * "time_newton" (0; 1: HIP events around the inner solves -> info "last_newton_solve_ms" / "last_newton_solve_bytes"),
  * "small_tile_below" (2^30: products with fewer 128 x 128 tiles than this run on 64 x 64 workgroup tiles - i.e. all; 0: never),
  * "splitk_below64" (160: products on 64 x 64 tiles are cut along k only below this many tiles),
+ * "copy_kernels" (1: read-backs and uploads up to 256 KB move through host-mapped staging memory as one-workgroup kernels, and a flush is a
+ * kernel that raises a sequence number the host spins on - no hipMemcpyAsync / hipStreamSynchronize on those paths; 0: the runtime's copies),
  * "mix_slot" (1: the mixing pass of that split form with a thread per bin and a workgroup per (slot, 256 bins) that walks whole columns of
  * the slab - contiguous 2-KB runs instead of 512-byte pieces, no LDS; up to 10 latents; 0: mix_vsm_split_kernel, 64 bins x 4 columns),
  * "cross_kernel" (1: the cross term of that split form in a kernel with all rows of a latent in one workgroup, 128 rows per

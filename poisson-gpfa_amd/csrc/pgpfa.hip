@@ -229,6 +229,12 @@ struct pgpfa_ctx {
   struct DlEntry { void* host; size_t off, bytes; };
   PcgCtl fused_ctl_host{};
   char* dl_stage = nullptr; size_t dl_used = 0; std::vector<DlEntry> dl_pending;   // pinned staging of small read-backs (dl_enqueue / dl_flush)
+  // Small copies as kernels (option copy_kernels): the staging areas are host-mapped, a one-block kernel moves the bytes and the flush is a kernel
+  // that raises a sequence number in mapped memory the host spins on - a hipMemcpyAsync of a few KB costs 130-570 us of device idle time on
+  // this stack (the runtime's blit path: kernel trace, tools/trace_gaps.py), a kernel launch 5-10
+  char* dl_stage_dev = nullptr; char* ring_dev = nullptr;
+  unsigned* h_seq = nullptr; unsigned* d_seq = nullptr; unsigned seq_next = 0;
+  bool copy_kernels = true;
   unsigned long long dl_fail_mark = 0;           // g_fail_count when the oldest pending read-back was queued
   int* hibuf = nullptr; size_t hibuf_len = 0;
   // ring of pinned staging slots for small host -> device uploads that must not cost a stream synchronisation each (Newton driver)
@@ -809,6 +815,64 @@ int upload_list(pgpfa_ctx* c, int* dst, const std::vector<int>& v) {
 // another stream operation.  Small read-backs therefore land in a pinned staging area and are copied out after ONE synchronisation:
 // dl_enqueue queues a copy (several may be queued back to back), dl_flush waits and hands the bytes out.
 constexpr size_t DL_STAGE_BYTES = (size_t)4 << 20;
+constexpr size_t COPY_KERNEL_MAX = (size_t)256 << 10;        // copies up to this size go through copy_words_kernel when the staging memory is mapped
+
+// dst <- src, bytes a multiple of 4 (every small copy of the library is): one or a few workgroups; either side may be host-mapped memory
+__global__ __launch_bounds__(256) void copy_words_kernel(unsigned* __restrict__ dst, const unsigned* __restrict__ src, size_t nwords) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+__global__ __launch_bounds__(256) void copy_vec16_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t nvec) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+// device-to-device copy on the context's stream as a kernel (a runtime copy between two kernels costs hundreds of microseconds of idle time:
+// see the note at pgpfa_ctx::copy_kernels); any size, 16-byte vectors when both sides allow
+static int copy_dev(pgpfa_ctx* c, void* dst, const void* src, size_t bytes) {
+  if (bytes == 0) return 0;
+  if (c->copy_kernels && (bytes & 3) == 0 && (((size_t)dst | (size_t)src) & 3) == 0) {
+    if ((bytes & 15) == 0 && (((size_t)dst | (size_t)src) & 15) == 0) {
+      const size_t nv = bytes / 16;
+      hipLaunchKernelGGL(copy_vec16_kernel, dim3((unsigned)std::min<size_t>((nv + 255) / 256, 4096)), dim3(256), 0, c->st, reinterpret_cast<uint4*>(dst),
+                         reinterpret_cast<const uint4*>(src), nv);
+    } else {
+      const size_t nw = bytes / 4;
+      hipLaunchKernelGGL(copy_words_kernel, dim3((unsigned)std::min<size_t>((nw + 255) / 256, 4096)), dim3(256), 0, c->st, reinterpret_cast<unsigned*>(dst),
+                         reinterpret_cast<const unsigned*>(src), nw);
+    }
+    HIPC(hipGetLastError());
+    return 0;
+  }
+  HIPC(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->st));
+  return 0;
+}
+// everything enqueued before this kernel has completed (in-order stream) when the host reads `value` here
+__global__ void raise_seq_kernel(volatile unsigned* __restrict__ seq, unsigned value) {
+  __threadfence_system();
+  *seq = value;
+  __threadfence_system();
+}
+
+// wait until the stream has drained: by the sequence number in mapped memory when the copies run as kernels, else hipStreamSynchronize
+static int stream_drain(pgpfa_ctx* c) {
+  if (c->copy_kernels && c->h_seq) {
+    const unsigned want = ++c->seq_next;
+    hipLaunchKernelGGL(raise_seq_kernel, dim3(1), dim3(1), 0, c->st, (volatile unsigned*)c->d_seq, want);
+    if (hipGetLastError() == hipSuccess) {
+      const auto t0 = std::chrono::steady_clock::now();
+      long spins = 0;
+      while (*(volatile unsigned*)c->h_seq != want) {
+        if ((++spins & 0xfff) == 0) {
+          const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+          // a faulted kernel never raises the number: past 50 ms ask the runtime now and then, which also reports the fault
+          if (el > 0.05 && hipStreamQuery(c->st) != hipErrorNotReady) break;
+        }
+      }
+      if (*(volatile unsigned*)c->h_seq == want) return 0;
+    }
+  }
+  const hipError_t e_sync = hipStreamSynchronize(c->st);
+  if (e_sync != hipSuccess) return fail("%s:%d hipStreamSynchronize -> %s", __FILE__, __LINE__, hipGetErrorString(e_sync));
+  return 0;
+}
 // The queue holds raw host pointers (stack locals, vector buffers, caller arrays) that are only good inside the call that queued them: a
 // failure between dl_enqueue and dl_flush - a CHK / HIPC that returned, or the synchronisation below - voids the whole queue, so that no later
 // flush copies into memory that call has given back (dl_drop_stale: anything queued before the last fail() of this thread is dropped).
@@ -817,12 +881,12 @@ static void dl_drop_stale(pgpfa_ctx* c) {
 }
 int dl_flush(pgpfa_ctx* c) {
   dl_drop_stale(c);
-  const hipError_t e_sync = hipStreamSynchronize(c->st);
+  const int rc_sync = stream_drain(c);
   c->ring_pending = 0;
-  if (e_sync != hipSuccess) {
+  if (rc_sync) {
     c->dl_pending.clear();
     c->dl_used = 0;
-    return fail("%s:%d hipStreamSynchronize -> %s", __FILE__, __LINE__, hipGetErrorString(e_sync));
+    return rc_sync;
   }
   for (const auto& e : c->dl_pending) std::memcpy(e.host, c->dl_stage + e.off, e.bytes);
   c->dl_pending.clear();
@@ -832,7 +896,13 @@ int dl_flush(pgpfa_ctx* c) {
 int dl_enqueue(pgpfa_ctx* c, void* host, const void* dev, size_t bytes) {
   if (bytes == 0) return 0;
   if (!c->dl_stage) {
-    if (hipHostMalloc((void**)&c->dl_stage, DL_STAGE_BYTES) != hipSuccess) { (void)hipGetLastError(); c->dl_stage = nullptr; }
+    if (hipHostMalloc((void**)&c->dl_stage, DL_STAGE_BYTES, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); c->dl_stage = nullptr; }
+    if (c->dl_stage && hipHostGetDevicePointer((void**)&c->dl_stage_dev, c->dl_stage, 0) != hipSuccess) { (void)hipGetLastError(); c->dl_stage_dev = nullptr; }
+    if (!c->h_seq) {
+      if (hipHostMalloc((void**)&c->h_seq, 64, hipHostMallocMapped) != hipSuccess ||
+          hipHostGetDevicePointer((void**)&c->d_seq, c->h_seq, 0) != hipSuccess) { (void)hipGetLastError(); c->h_seq = nullptr; c->d_seq = nullptr; }
+      if (c->h_seq) *c->h_seq = 0u;
+    }
   }
   const size_t need = (bytes + 63) / 64 * 64;
   if (!c->dl_stage || need > DL_STAGE_BYTES) {
@@ -844,7 +914,14 @@ int dl_enqueue(pgpfa_ctx* c, void* host, const void* dev, size_t bytes) {
   }
   dl_drop_stale(c);
   if (c->dl_used + need > DL_STAGE_BYTES) CHK(dl_flush(c));
-  HIPC(hipMemcpyAsync(c->dl_stage + c->dl_used, dev, bytes, hipMemcpyDeviceToHost, c->st));
+  if (c->copy_kernels && c->dl_stage_dev && c->h_seq && bytes <= COPY_KERNEL_MAX && (bytes & 3) == 0 && (((size_t)dev) & 3) == 0) {
+    const size_t nw = bytes / 4;
+    hipLaunchKernelGGL(copy_words_kernel, dim3((unsigned)std::min<size_t>((nw + 255) / 256, 64)), dim3(256), 0, c->st,
+                       reinterpret_cast<unsigned*>(c->dl_stage_dev + c->dl_used), reinterpret_cast<const unsigned*>(dev), nw);
+    HIPC(hipGetLastError());
+  } else {
+    HIPC(hipMemcpyAsync(c->dl_stage + c->dl_used, dev, bytes, hipMemcpyDeviceToHost, c->st));
+  }
   if (c->dl_pending.empty()) c->dl_fail_mark = g_fail_count;
   c->dl_pending.push_back({host, c->dl_used, bytes});
   c->dl_used += need;
@@ -859,6 +936,8 @@ int download(pgpfa_ctx* c, double* host, const double* dev, size_t n) {
   return dl_flush(c);
 }
 int upload(pgpfa_ctx* c, double* dev, const double* host, size_t n) {
+  // (small: through the pinned ring - the bytes are out of the caller's buffer when this returns, and nothing waits for the device)
+  if (n * sizeof(double) <= (size_t)65536) return upload_nosync(c, dev, host, n * sizeof(double));
   HIPC(hipMemcpyAsync(dev, host, n * sizeof(double), hipMemcpyHostToDevice, c->st));
   HIPC(hipStreamSynchronize(c->st));
   c->ring_pending = 0;
@@ -873,15 +952,23 @@ int upload_nosync(pgpfa_ctx* c, void* dev, const void* host, size_t bytes) {
   if (bytes > c->ring_slot) {
     HIPC(hipStreamSynchronize(c->st));
     if (c->ring) hipHostFree(c->ring);
-    c->ring = nullptr;
+    c->ring = nullptr; c->ring_dev = nullptr;
     const size_t slot = (bytes + 4095) / 4096 * 4096;
-    HIPC(hipHostMalloc((void**)&c->ring, slot * RING_N));
+    HIPC(hipHostMalloc((void**)&c->ring, slot * RING_N, hipHostMallocMapped));
+    if (hipHostGetDevicePointer((void**)&c->ring_dev, c->ring, 0) != hipSuccess) { (void)hipGetLastError(); c->ring_dev = nullptr; }
     c->ring_slot = slot; c->ring_cur = 0; c->ring_pending = 0;
   }
   if (c->ring_pending >= RING_N - 1) { HIPC(hipStreamSynchronize(c->st)); c->ring_pending = 0; }
   char* slot = c->ring + (size_t)c->ring_cur * c->ring_slot;
   std::memcpy(slot, host, bytes);
-  HIPC(hipMemcpyAsync(dev, slot, bytes, hipMemcpyHostToDevice, c->st));
+  if (c->copy_kernels && c->ring_dev && bytes <= COPY_KERNEL_MAX && (bytes & 3) == 0 && (((size_t)dev) & 3) == 0) {
+    const size_t nw = bytes / 4;
+    hipLaunchKernelGGL(copy_words_kernel, dim3((unsigned)std::min<size_t>((nw + 255) / 256, 64)), dim3(256), 0, c->st, reinterpret_cast<unsigned*>(dev),
+                       reinterpret_cast<const unsigned*>(c->ring_dev + (size_t)c->ring_cur * c->ring_slot), nw);
+    HIPC(hipGetLastError());
+  } else {
+    HIPC(hipMemcpyAsync(dev, slot, bytes, hipMemcpyHostToDevice, c->st));
+  }
   c->ring_cur = (c->ring_cur + 1) % RING_N;
   c->ring_pending += 1;
   return 0;
@@ -1008,7 +1095,7 @@ int assemble(pgpfa_ctx* c, const int* d_list, int nl, double diag_scale = 1.0) {
 // Kinv (and logdet) of the p Gram slabs currently in Kpad, through the production factor kernels
 int build_kinv(pgpfa_ctx* c) {
   const size_t slab = (size_t)c->Tp * c->Tp;
-  HIPC(hipMemcpyAsync(c->kws.H, c->Kpad, slab * c->p * sizeof(double), hipMemcpyDeviceToDevice, c->st));
+  CHK(copy_dev(c, c->kws.H, c->Kpad, slab * c->p * sizeof(double)));
   HIPC(hipMemsetAsync(c->kws.info, 0, sizeof(int) * c->p, c->st));
   CHK(factor(c, c->kws, nullptr, c->p));
   c->logdetK.assign(c->p, 0.0);
@@ -1260,6 +1347,7 @@ int pgpfa_destroy(pgpfa_ctx* c) {
   if (c->hibuf) hipHostFree(c->hibuf);
   if (c->ring) hipHostFree(c->ring);
   if (c->h_pcg) hipHostFree(c->h_pcg);
+  if (c->h_seq) hipHostFree(c->h_seq);
   for (auto e : c->prof.pool) hipEventDestroy(e);
   if (c->st) hipStreamDestroy(c->st);
   delete c;
@@ -1280,6 +1368,7 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
   else if (k == "pcg_w32") c->pcg_w32 = (v != 0.0);
   else if (k == "pcg_form") c->pcg_form = (int)v;
   else if (k == "mix_slot") c->mix_slot = (int)v;
+  else if (k == "copy_kernels") c->copy_kernels = (v != 0.0);
   else if (k == "chord") c->chord = (v != 0.0);
   else if (k == "shared_pcg") c->shared_pcg = (v != 0.0);
   else if (k == "time_newton") c->time_newton = (v != 0.0);
@@ -2447,7 +2536,7 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
               eta_s[s] = (float)es;
             }
             CHK(upload_nosync(c, c->pcg_eta, eta_s.data(), sizeof(float) * nb));
-            HIPC(hipMemcpyAsync(c->live, c->list_a, sizeof(int) * na, hipMemcpyDeviceToDevice, c->st));
+            CHK(copy_dev(c, c->live, c->list_a, sizeof(int) * na));
             PcgCtl h0{};
             h0.nlive = na; h0.nl[0] = na;
             CHK(upload_nosync(c, c->pcgctl, &h0, sizeof(PcgCtl)));
@@ -2517,7 +2606,7 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
                 eta_s[s] = (float)es;
               }
             CHK(upload_nosync(c, c->pcg_eta, eta_s.data(), sizeof(float) * nb));
-            HIPC(hipMemcpyAsync(c->live, c->list_a, sizeof(int) * na, hipMemcpyDeviceToDevice, c->st));
+            CHK(copy_dev(c, c->live, c->list_a, sizeof(int) * na));
             PcgCtl h0{};
             h0.nlive = na;
             CHK(upload_nosync(c, c->pcgctl, &h0, sizeof(PcgCtl)));
@@ -3489,7 +3578,7 @@ int pgpfa_mstep_precomp(pgpfa_ctx* c, double* num_trials) {
   if (c->pacc_valid && contiguous) {
     // PautoSum[k] = Pacc[k] + M_k M_k^T with M_k = [m_rk]_r (T x ntr, the trials' mean rows side by side in Xmode): one GEMM
     const size_t len = (size_t)c->Tp * c->Tp * c->p;
-    HIPC(hipMemcpyAsync(c->Pauto, c->Pacc, len * sizeof(double), hipMemcpyDeviceToDevice, c->st));
+    CHK(copy_dev(c, c->Pauto, c->Pacc, len * sizeof(double)));
     GemmP g{};
     g.A = c->Xmode + (size_t)c->last_trials_h[0] * c->n; g.sA = c->T; g.lda = c->n;
     g.B = g.A; g.sB = c->T; g.ldb = c->n;
@@ -3510,7 +3599,7 @@ int pgpfa_mstep_precomp(pgpfa_ctx* c, double* num_trials) {
   CHK(allreduce_dev(c, c->Pauto, len));
   double cnt = (double)ntr;
   if (c->comm) {
-    HIPC(hipMemcpyAsync(c->tscal, &cnt, sizeof(double), hipMemcpyHostToDevice, c->st));
+    CHK(upload_nosync(c, c->tscal, &cnt, sizeof(double)));
     CHK(allreduce_dev(c, c->tscal, 1));
     CHK(download(c, &cnt, c->tscal, 1));
   }
@@ -3546,7 +3635,7 @@ int pgpfa_mstep_tau_costgrad(pgpfa_ctx* c, int k, double logp, double* cost, dou
   const size_t slab = (size_t)Tp * Tp;
   const double* P = c->Pauto + (size_t)k * slab;
   hipLaunchKernelGGL(gram_gamma_kernel, dim3(Tp), dim3(256), 0, c->st, c->tK, c->tM, Tp, c->T, logp, c->eps);
-  HIPC(hipMemcpyAsync(c->kws.H, c->tK, slab * sizeof(double), hipMemcpyDeviceToDevice, c->st));
+  CHK(copy_dev(c, c->kws.H, c->tK, slab * sizeof(double)));
   HIPC(hipMemsetAsync(c->kws.info, 0, sizeof(int), c->st));
   CHK(factor(c, c->kws, nullptr, 1));
   hipLaunchKernelGGL(logdet_kernel, dim3(1), dim3(256), 0, c->st, c->kws.H, Tp, Tp, c->tscal + 0);
@@ -3595,7 +3684,7 @@ int pgpfa_mstep_tau_costgrad_multi(pgpfa_ctx* c, int m, const double* logp, doub
   double* dres = c->tscal + 16 + nq;                 // [4][nq]: logdet, tr(KinvP), tr(KinvM), tr(KinvMKinvP)
   CHK(upload(c, dlogp, logp, nq));
   hipLaunchKernelGGL(gram_gamma_batch_kernel, dim3(Tp, nq), dim3(256), 0, c->st, c->tK, c->tM, Tp, c->T, dlogp, c->eps);
-  HIPC(hipMemcpyAsync(c->kws.H, c->tK, slab * nq * sizeof(double), hipMemcpyDeviceToDevice, c->st));
+  CHK(copy_dev(c, c->kws.H, c->tK, slab * nq * sizeof(double)));
   HIPC(hipMemsetAsync(c->kws.info, 0, sizeof(int) * nq, c->st));
   CHK(factor(c, c->kws, nullptr, nq));
   hipLaunchKernelGGL(logdet_batch_kernel, dim3(nq), dim3(256), 0, c->st, c->kws.H, (long long)slab, Tp, Tp, dres);
