@@ -572,7 +572,7 @@ int free_workspace(pgpfa_ctx* c) {
   HIPC(hipStreamSynchronize(c->st));
   while (c->allocs.size() > c->ws_mark) { hipFree(c->allocs.back()); c->allocs.pop_back(); }
   c->B = 0;
-  c->lamd = c->dgrad = c->dpart = c->ldet_buf = nullptr;
+  c->lamd = c->dgrad = c->dpart = c->ldet_buf = c->voff = nullptr;
   c->dual_scr = nullptr;
   c->commbuf = nullptr; c->commbuf_len = 0;
   c->mt_dirty = false;

@@ -315,3 +315,61 @@ def test_header_documents_every_option_and_info_key():
     assert len(options) > 30 and len(infos) > 15
     missing = [k for k in options + infos if '"%s"' % k not in hdr]
     assert not missing, missing
+
+
+def test_dual_variational_hands_unsettled_trials_to_lbfgs(monkeypatch):
+    """Host logic of inference.dualVariational under DUAL_SOLVER = 'fixedpoint' (the default), against a test double of the context: trials the
+    fixed point reports as not settled (status 1: pass cap, 2: not contracting) go to the device L-BFGS FROM THE RHO THE FIXED POINT RETURNED,
+    exactly those and no others; their optimum and bound replace the fixed point's, iteration counts add; the cold start is log 0.5 (the
+    reference's lambda = 0.5, inference.py:302) and `warm` is only set with prevOptimRes; the finalize call sees exp(rho) of the merged set."""
+    from funs import _hip, _session, inference
+    from conftest import Experiment
+    calls = {}
+
+    class Ctx:
+        def __init__(self, q, p, T, R, bin_ms, device=0):
+            self.q, self.p, self.T, self.R = q, p, T, R
+        def close(self): pass
+        def set_option(self, k, v): calls.setdefault('options', {})[k] = v
+        def info(self, k): return 0.0
+        def upload_counts(self, Y): pass
+        def set_params(self, C, d, tau): pass
+        def dual_fixed_point(self, idx, rho0, max_outer=40, tol=1e-8, warm=False):
+            calls['fp'] = (np.array(idx), np.array(rho0), max_outer, tol, warm)
+            rho = np.array(rho0) + 1.0 + np.arange(len(idx))[:, None]
+            return rho, -np.arange(len(idx), dtype=float), np.full(len(idx), 5, np.int32), np.array([0, 2, 0, 1, 0], np.int32)[:len(idx)]
+        def dual_lbfgs(self, idx, rho0, max_iter=15000, factr=1e7, pgtol=1e-5):
+            calls['lbfgs'] = (np.array(idx), np.array(rho0))
+            return np.array(rho0) * 2.0, np.full(len(idx), -100.0), np.full(len(idx), 70, np.int32)
+        def dual_finalize(self, idx, lam):
+            calls['finalize'] = (np.array(idx), np.array(lam))
+            return 3.0 * len(idx)
+
+    monkeypatch.setattr(_hip, 'Context', Ctx)
+    monkeypatch.setattr(_session.WORLD, 'enabled', False)
+    _session.drop_sessions()
+    q, p, T, R = 4, 2, 6, 5
+    exp = Experiment([np.zeros((q, T)) for _ in range(R)], 10.0)
+    params = {'C': np.zeros((q, p)), 'd': np.zeros(q), 'tau': np.ones(p) * 0.1}
+    assert inference.DUAL_SOLVER == 'fixedpoint'
+    try:
+        infRes, nll, vlb, opt = inference.dualVariational(exp, params)
+        idx, rho0, max_outer, tol, warm = calls['fp']
+        assert np.array_equal(idx, np.arange(R)) and np.allclose(rho0, np.log(0.5)) and not warm
+        assert max_outer == inference.DUAL_FP_MAX_PASSES and tol == inference.DUAL_FP_TOL
+        bad_idx, bad_rho = calls['lbfgs']
+        assert np.array_equal(bad_idx, [1, 3])
+        fp_rho = np.log(0.5) + 1.0 + np.arange(R)[:, None] + np.zeros((R, q * T))
+        assert np.allclose(bad_rho, fp_rho[[1, 3]])
+        merged = fp_rho.copy()
+        merged[[1, 3]] *= 2.0
+        assert np.allclose(calls['finalize'][1], np.exp(merged))
+        assert np.allclose(np.stack(opt), np.exp(merged))                 # optimizeLogLambda = False returns lambda (inference.py:326)
+        assert np.array_equal(infRes.dual_iterations, [5, 75, 5, 75, 5])
+        assert abs(vlb - np.mean([0.0, -100.0, -2.0, -100.0, -4.0])) < 1e-12 and abs(nll + 3.0) < 1e-12
+        # warm start: rho = log of the previous lambda, flagged as such; the log-lambda variant returns rho itself
+        infRes, nll, vlb, opt2 = inference.dualVariational(exp, params, optimizeLogLambda=True, prevOptimRes=[np.log(o) for o in opt])
+        assert calls['fp'][4] is True and np.allclose(calls['fp'][1], merged)
+        assert np.allclose(np.stack(opt2)[0], merged[0] + 1.0)
+    finally:
+        _session.drop_sessions()
