@@ -74,7 +74,7 @@ int pgpfa_destroy(pgpfa_ctx* ctx);
  * live list, pcg.h; 0: one common forcing term), "pcg_trace" (0; 1: one stderr line per inner solve),
  * "time_newton" (0; 1: HIP events around the inner solves -> info "last_newton_solve_ms" / "last_newton_solve_bytes"),
  * "small_tile_below" (2^30: products with fewer 128 x 128 tiles than this run on 64 x 64 workgroup tiles - i.e. all; 0: never),
- * "splitk_below64" (160: products on 64 x 64 tiles are cut along k only below this many tiles),
+ * "splitk_below64" (400: products on 64 x 64 tiles are cut along k only below this many tiles),
  * "copy_kernels" (1: read-backs and uploads up to 256 KB move through host-mapped staging memory as one-workgroup kernels, and a flush is a
  * kernel that raises a sequence number the host spins on - no hipMemcpyAsync / hipStreamSynchronize on those paths; 0: the runtime's copies),
  * "mix_slot" (1: the mixing pass of that split form with a thread per bin and a workgroup per (slot, 256 bins) that walks whole columns of

@@ -216,7 +216,8 @@ struct pgpfa_ctx {
   int splitk_target = 1280;                      // thin GEMMs are cut along k until about this many workgroups are in flight
   int small_tile_below = 1 << 30;                // products with fewer 128 x 128 tiles than this run on 64 x 64 tiles (0: never); measured: the
                                                  // small tile wins at every shape of the E-step (44.5 -> 50 TFLOP/s on the largest launch too)
-  int splitk_below64 = 160;                      // ... and are cut along k only below this many 64 x 64 tiles
+  int splitk_below64 = 400;                      // ... and are cut along k only below this many 64 x 64 tiles (round 4: 160 -> 400 - with the prior mat-vec out of the PCG step
+                                                 // its thin products are what is left: Newton solves 12.4 -> 11.9 ms per EM iteration at config 3)
   double *sc_f = nullptr, *sc_qxx = nullptr, *sc_qdx = nullptr, *sc_qdd = nullptr, *sc_dec = nullptr, *sc_smax = nullptr, *sc_alpha = nullptr;
   int *trial_of_slot = nullptr, *list_a = nullptr, *list_b = nullptr, *ident = nullptr;
   int* mask_of_slot = nullptr;                    // leave-one-neuron-out passes: neuron excluded from the likelihood of a slot

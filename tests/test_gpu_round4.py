@@ -182,3 +182,34 @@ def test_dual_variational_through_the_fixed_point_vs_reference(funs_mod):
     ir_w, nll_w, vlb_w, opt_w = inf.dualVariational(exp, params, prevOptimRes=opt)
     assert np.all(ir_w.dual_iterations == 1) and abs(vlb_w - vlb) <= 1e-9 * abs(vlb) and abs(nll_w - nll) <= 1e-8 * abs(nll)
     funs_mod._session.drop_sessions()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# copies as kernels / the runtime's copies; the two mixing passes
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('option', [('copy_kernels', 0), ('mix_slot', 0)])
+def test_alternative_paths_give_the_same_numbers(c1, option):
+    """The small copies through the runtime (`copy_kernels = 0`: hipMemcpyAsync + hipStreamSynchronize instead of kernels through mapped staging and
+    a sequence number) and the 64-bin mixing pass of the split accumulation (`mix_slot = 0`) against the defaults on the same E-step + M-step
+    statistics: copies move bytes - bit-identical; the two mixing passes add the same products in another order - 1e-13."""
+    from funs import _hip
+    out = []
+    for value in (1, option[1]):
+        ctx = _hip.Context(30, 3, 100, 20, c1['binSize'])
+        try:
+            ctx.upload_counts(c1['Y'])
+            ctx.set_option('cov_mode', 2)
+            ctx.set_option(option[0], value)
+            ctx.set_params(c1['init_C'], c1['init_d'], c1['init_tau'])
+            obj, _, status = ctx.estep_laplace()
+            assert np.all(status == 0) and ctx.info('last_split_cov') == 1.0
+            ctx.mstep_precomp()
+            cost, grad = ctx.mstep_cd_costgrad(np.concatenate([c1['init_C'].T.reshape(-1), c1['init_d']]))
+            out.append((obj, ctx.post_mean().copy(), ctx.post_vsm().copy(), ctx.pautosum().copy(), cost, grad.copy()))
+        finally:
+            ctx.close()
+    a, b = out
+    tol = 0.0 if option[0] == 'copy_kernels' else 1e-13
+    assert abs(a[0] - b[0]) <= tol * abs(a[0]) and abs(a[4] - b[4]) <= tol * abs(a[4])
+    for i in (1, 2, 3, 5):
+        assert np.max(np.abs(a[i] - b[i])) <= tol * np.max(np.abs(a[i]))
