@@ -514,6 +514,7 @@ def main():
     ap.add_argument('--batch', type=int, default=1024, help="--workload online: minibatch size (split over the ranks)")
     ap.add_argument('--lean', action='store_true', help='skip the extra untimed iterations (per-family event breakdown, TNC M-step, MFMA peak probe): for runs under rocprofv3')
     ap.add_argument('--opts', default='', help='context options key=value,... (experiments)')
+    ap.add_argument('--events-every', type=int, default=4, help='HIP events around the GEMM launches on every n-th timed step (1: all of them)')
     ap.add_argument('--dry-run', action='store_true', help='launcher self-test: every rank reports its environment and exits (no GPU work)')
     args = ap.parse_args()
 
@@ -592,12 +593,22 @@ def main():
 
     for _ in range(args.warmup):
         em_step()
-    # HIP events (on the context's stream) around every GEMM launch of the timed region - the roofline kernel
+    # HIP events (on the context's stream) around the GEMM launches of the timed region - the roofline kernel - on every 4th step: a pair of
+    # events costs ~10 us of device time per launch (two barrier packets; tools/probes/launch_probe.hip: a bare launch is 3 us), ~400 launches per
+    # step - recorded on every step the measurement itself was 4 % of the number it sits next to
+    every = max(1, args.events_every)
     sess.ctx.set_option('profile', 2)
+    sess.ctx.set_option('profile_pause', 1)
+    event_steps = []
     barrier()
     t_begin = time.time()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if i % every == 0:
+            sess.ctx.set_option('profile_pause', 0)
+            event_steps.append(i)
         em_step()
+        if i % every == 0:
+            sess.ctx.set_option('profile_pause', 1)
     barrier()
     elapsed = time.time() - t_begin
     gemm_ms, gemm_flops, gemm_launches = (sess.ctx.info('prof_gemm_' + k) for k in ('ms', 'flops', 'launches'))
@@ -683,7 +694,9 @@ def main():
                      # passes of this command are under profiles/ (rNN_pmc_hbm_traffic.json)
                      'traffic': None,
                      'algorithmic_flops_per_launch': gemm_flops / max(gemm_launches, 1.0), 'launches': gemm_launches, 'avg_launch_ms': gemm_ms / max(gemm_launches, 1.0),
-                     'kernel_share_of_step': gemm_ms / (t_max * 1e3),
+                     # (events on these steps of the timed region only; share = GEMM time of those steps / their wall time)
+                     'events_on_steps': event_steps,
+                     'kernel_share_of_step': gemm_ms / max(1e-9, float(np.sum([estep_ms[args.warmup + i] + mstep_ms[args.warmup + i] for i in event_steps]))),
                      # the longest single launch of the timed region
                      'largest_launch': {'ms': gemm_max_ms, 'algorithmic_flops': gemm_max_flops,
                                         'achieved': gemm_max_flops / (gemm_max_ms * 1e-3) / 1e12 if gemm_max_ms > 0 else 0.0,

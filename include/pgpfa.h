@@ -45,7 +45,8 @@ int pgpfa_destroy(pgpfa_ctx* ctx);
  * "chunk_trials" (0 = auto), "eps_noise" (1e-3, util.py:599), "chord" (1: reuse the first factor for
  * chord steps), "chord_xtol" (1e-9), "chord_rho" (0.6), "chord_max_step" (1.0), "profile" (0; 1 = HIP events around
  * every tagged launch, 2 = around GEMM launches only; sums are read with pgpfa_get_info "prof_<family>_ms|_flops|_launches", the longest
- * single launch with "_max_ms|_max_flops"),
+ * single launch with "_max_ms|_max_flops"), "profile_pause" (1: stop recording without touching the sums, 0: go on - an event pair costs
+ * ~10 us of device time per launch, so a caller that wants rates over a long region samples it),
  * "shared_pcg" (1: phase-1 Newton with the shared preconditioner), "shared_min" (16), "pcg_inner" (16: cap on
  * the inner PCG iterations of one outer Newton iteration), "pcg_eta0" (1e-2: relative residual of the first inner solve;
  * later ones adapt to the predicted error), "splitk_target" (1280: thin GEMMs are cut along k until about this many

@@ -62,6 +62,7 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 struct Prof {
   bool on = false;
+  bool configured = false;           // option "profile" is set (option "profile_pause" toggles `on` under it)
   int only_tag = -1;                 // >= 0: time launches of this tag only (option "profile" = 2: the GEMM kernel)
   std::vector<hipEvent_t> pool;      // every event ever created (destroyed with the context)
   std::vector<hipEvent_t> idle;      // events free for reuse
@@ -930,6 +931,11 @@ int dl_enqueue(pgpfa_ctx* c, void* host, const void* dev, size_t bytes) {
 }
 int download(pgpfa_ctx* c, double* host, const double* dev, size_t n) {
   if (c->hbuf && host >= c->hbuf && host < c->hbuf + c->hbuf_len) {      // already pinned
+    // (small: through the staging area like any other read-back - the runtime's copy costs more than the extra memcpy)
+    if (c->copy_kernels && n * sizeof(double) <= COPY_KERNEL_MAX) {
+      CHK(dl_enqueue(c, host, dev, n * sizeof(double)));
+      return dl_flush(c);
+    }
     HIPC(hipMemcpyAsync(host, dev, n * sizeof(double), hipMemcpyDeviceToHost, c->st));
     return dl_flush(c);
   }
@@ -1424,7 +1430,12 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
       HIPC(hipStreamSynchronize(c->st));
     }
     c->prof.on = (v != 0.0);
+    c->prof.configured = c->prof.on;
     c->prof.only_tag = (v == 2.0) ? TAG_GEMM : -1;
+  } else if (k == "profile_pause") {
+    // 1: stop recording events without touching the sums or waiting for anything; 0: go on (only while "profile" is set).  An event pair
+    // around a launch costs ~10 us of device time (two barrier packets): a caller that wants rates over a long region samples it.
+    c->prof.on = (v == 0.0) && c->prof.configured;
   } else return fail("unknown option '%s'", key);
   return 0;
 }
