@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void mix_vsm_split_kernel(const double* __r
 // slab together, so column b of latent k is ONE contiguous run of NTH doubles (2 KB at NTH = 256) instead of the 512-byte pieces eight
 // workgroups of mix_vsm_split_kernel pick out of it at different times - HBM row locality is what that kernel runs at 2.2 TB/s on.  A bin
 // belongs to one thread: its symmetric G_t (55 values at 10 latents) and the 55 pair sums stay in that thread's registers for the whole
-// pass, nothing goes through LDS, nothing is reduced across waves.  One wave per SIMD (the register budget of a 256-thread workgroup is 512
+// pass (round 4, second form: G_t in an LDS column of its thread), nothing is reduced across waves.  One wave per SIMD (the register budget of a 256-thread workgroup is 512
 // per lane), U columns' loads in flight per trip.  Measured at config 3: 7.9 ms instead of 9.8 ms per E-step at the bench's ranks (3.9 TB/s
 // of its algorithmic bytes); 4 columns per trip, 128- or 512-bin workgroups (the latter spills) and a software pipeline change nothing.  Entries of Yt left of a latent's first column tile were never written: their (uniform)
 // addresses are clamped to the first written column and the values masked.
@@ -120,72 +120,80 @@ __global__ __launch_bounds__(NTH, 1) void mix_slot_kernel(const double* __restri
                                                           double* __restrict__ vsm, const int* __restrict__ slots,
                                                           const int* __restrict__ trial_of_slot, const int* __restrict__ roff, int col_tile, int ts) {
   constexpr int NPAIR = PW * (PW + 1) / 2;
+  // G_t of this thread's bin lives in LDS, one column per thread ([pair][thread]: conflict-free), the pair sums in registers: with both in
+  // registers the compiler parks one of them in AGPRs and pays a v_accvgpr_read for every use - PMC: as many of those as FMAs, vector
+  // instructions 49 % of the kernel's time at one wave per SIMD
+  extern __shared__ double mix_slot_g[];
   const int pp = p * p;
   const int slot = slots[blockIdx.y];
   const int t = blockIdx.x * NTH + threadIdx.x;
   const bool live = t < T;
   const int tc = live ? t : T - 1;
   const double* gsrc = G + (size_t)slot * sG + (size_t)tc * pp;
-  double g[NPAIR], acc[NPAIR];
+  double* gs = mix_slot_g + threadIdx.x;
+  double acc[NPAIR];
 #pragma unroll
   for (int a = 0; a < PW; ++a)
 #pragma unroll
     for (int c2 = 0; c2 <= a; ++c2) {
-      g[a * (a + 1) / 2 + c2] = gsrc[(a < p ? a : 0) * p + (a < p ? c2 : 0)];
+      gs[(a * (a + 1) / 2 + c2) * NTH] = gsrc[(a < p ? a : 0) * p + (a < p ? c2 : 0)];
       acc[a * (a + 1) / 2 + c2] = 0.0;
     }
-  int c0[PW];
+  int c0[PW], cmax = 0;
 #pragma unroll
-  for (int k = 0; k < PW; ++k) c0[k] = (roff && k < p) ? (roff[k] / col_tile) * col_tile : 0;
+  for (int k = 0; k < PW; ++k) {
+    c0[k] = (roff && k < p) ? (roff[k] / col_tile) * col_tile : 0;
+    cmax = c0[k] > cmax ? c0[k] : cmax;
+  }
   const double* y = Yt + (size_t)slot * sY + tc;
   float* d = D + (size_t)slot * sD + tc;
-  // software pipeline: the loads of the next U columns are in flight while the current ones are mixed (one wave per SIMD: nobody else hides them)
-  double v[U][PW], vn[U][PW];
-  auto load_cols = [&](int b0, double (&dst)[U][PW]) {
+  for (int b0 = 0; b0 < ract; b0 += U) {
+    double v[U][PW], m[U][PW];
+    // entries of Yt left of a latent's first column were never written: their (uniform) addresses are clamped to the first written column
+    // and the values masked - only while the trip touches such columns at all
+    const bool edge = b0 < cmax;
+    asm volatile("" ::: "memory");                      // (the LDS reads of G_t belong inside the trip: hoisted, they are the registers this form exists to free)
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int b = (b0 + u < ract) ? b0 + u : ract - 1;
 #pragma unroll
       for (int k = 0; k < PW; ++k) {
         const int kc = k < p ? k : 0;
-        const int bc = b >= c0[kc] ? b : c0[kc];                 // (uniform: every thread of the workgroup clamps alike)
-        dst[u][k] = y[(size_t)bc * ldy + (size_t)kc * ts];
+        const int bc = (edge && b < c0[kc]) ? c0[kc] : b;
+        v[u][k] = y[(size_t)bc * ldy + (size_t)kc * ts];
       }
-    }
-  };
-  load_cols(0, v);
-  for (int b0 = 0; b0 < ract; b0 += U) {
-    load_cols(b0 + U < ract ? b0 + U : b0, vn);
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int b = b0 + u;
-      if (b >= ract) break;
-      double m[PW];
-#pragma unroll
-      for (int k = 0; k < PW; ++k) {
-        v[u][k] = (k < p && b >= c0[k < p ? k : 0]) ? v[u][k] : 0.0;
-        m[k] = 0.0;
-      }
-#pragma unroll
-      for (int a = 0; a < PW; ++a)
-#pragma unroll
-        for (int c2 = 0; c2 <= a; ++c2) {
-          const double gg = g[a * (a + 1) / 2 + c2];
-          m[a] += gg * v[u][c2];
-          if (c2 != a) m[c2] += gg * v[u][a];
-        }
-#pragma unroll
-      for (int k = 0; k < PW; ++k)
-        if (k < p && live) d[(size_t)b * ldd + (size_t)k * ts] = (float)(v[u][k] - m[k]);
-#pragma unroll
-      for (int a = 0; a < PW; ++a)
-#pragma unroll
-        for (int c2 = 0; c2 <= a; ++c2) acc[a * (a + 1) / 2 + c2] += m[a] * m[c2];
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int k = 0; k < PW; ++k) v[u][k] = vn[u][k];
+      for (int k = 0; k < PW; ++k) {
+        if (k >= p || (edge && b0 + u < c0[k < p ? k : 0])) v[u][k] = 0.0;
+        m[u][k] = 0.0;
+      }
+#pragma unroll
+    for (int a = 0; a < PW; ++a)
+#pragma unroll
+      for (int c2 = 0; c2 <= a; ++c2) {
+        const double gg = gs[(a * (a + 1) / 2 + c2) * NTH];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          m[u][a] += gg * v[u][c2];
+          if (c2 != a) m[u][c2] += gg * v[u][a];
+        }
+      }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int b = b0 + u;
+      if (b < ract) {
+#pragma unroll
+        for (int k = 0; k < PW; ++k)
+          if (k < p && live) d[(size_t)b * ldd + (size_t)k * ts] = (float)(v[u][k] - m[u][k]);
+#pragma unroll
+        for (int a = 0; a < PW; ++a)
+#pragma unroll
+          for (int c2 = 0; c2 <= a; ++c2) acc[a * (a + 1) / 2 + c2] += m[u][a] * m[u][c2];
+      }
+    }
   }
   if (!live) return;
   double* vdst = vsm + ((size_t)trial_of_slot[slot] * T + t) * pp;
@@ -194,12 +202,13 @@ __global__ __launch_bounds__(NTH, 1) void mix_slot_kernel(const double* __restri
 #pragma unroll
     for (int c2 = 0; c2 <= a; ++c2) {
       if (a < p) {
-        const double val = eps * g[a * (a + 1) / 2 + c2] + acc[a * (a + 1) / 2 + c2];
+        const double val = eps * gs[(a * (a + 1) / 2 + c2) * NTH] + acc[a * (a + 1) / 2 + c2];
         vdst[a * p + c2] = val;
         vdst[c2 * p + a] = val;
       }
     }
 }
+inline size_t mix_slot_lds(int pw, int nth) { return (size_t)(pw * (pw + 1) / 2) * nth * sizeof(double); }
 
 // part[(k * ngroups + g)][T x T] (column-major, ld = T, lower 64 x 64 wave tiles) = sum over the slots of group g, over columns b < ract,
 // of D_k[:, b] D_k[:, b]^T, with D_k[t, b] = D[slot][(k ts + t) + b ldd] (single precision), evaluated on the FP16 matrix cores as

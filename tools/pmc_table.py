@@ -10,7 +10,7 @@ for d in sys.argv[1:]:
             acc[k][r['Counter_Name']] += float(r['Counter_Value'])
             calls[k][r['Counter_Name']] += 1
 names = sorted({n for v in acc.values() for n in v})
-order = sorted(acc, key=lambda k: -acc[k].get('SQ_WAVE_CYCLES', acc[k].get('GRBM_GUI_ACTIVE', 0.0)))[:14]
+order = sorted(acc, key=lambda k: -acc[k].get("SQ_WAVE_CYCLES", acc[k].get("GRBM_GUI_ACTIVE", 0.0)))[:20]
 print('counters summed over all launches of the kernel in the pass that collected them (launch counts may differ between passes by none)')
 for k in order:
     print(k)
