@@ -421,7 +421,7 @@ def run_dual(args, q, p, T, R, rank, world):
     # the evaluations run inside the device drivers (lambda, gradient, modes, offsets and the correction pairs stay resident)
     for _ in range(max(1, args.warmup)):
         if fixed_point:
-            ctx.dual_fixed_point(idx, rho, max_outer=1)
+            ctx.dual_fixed_point(idx, None, max_outer=1)
         else:
             ctx.dual_lbfgs(idx, rho, max_iter=1)
     allreduce(np.zeros(1))
@@ -430,19 +430,23 @@ def run_dual(args, q, p, T, R, rank, world):
     if fixed_point:
         # the optimum by the variance fixed point (pgpfa_dual_fixed_point); a trial it hands back would go to L-BFGS, as in
         # inference.dualVariational - counted in the timed region
-        rho_opt, fopt, iters, fp_status = ctx.dual_fixed_point(idx, rho)
+        # (cold start lambda = 0.5 set on the device; exp / log of the entries run there and the optimum stays resident for the finalize call,
+        # as in inference.dualVariational)
+        rho_opt, fopt, iters, fp_status, lam_opt = ctx.dual_fixed_point(idx, None, want_lam=True)
         bad = np.nonzero(fp_status != 0)[0]
+        lam_for_finalize = None
         if len(bad):
             rho_b, fopt_b, it_b = ctx.dual_lbfgs(idx[bad], rho_opt[bad])
             rho_opt[bad], fopt[bad] = rho_b, fopt_b
             iters[bad] += it_b
+            lam_for_finalize = np.exp(rho_opt)
     else:
         rho_opt, fopt, iters = ctx.dual_lbfgs(idx, rho, max_iter=15000 if whole else args.dual_iters)
     t_opt = time.time() - t0
     evals = ctx.info('last_dual_evaluations')
     nlp = None
     if whole:
-        nlp = ctx.dual_finalize(idx, np.exp(rho_opt))
+        nlp = ctx.dual_finalize(idx, lam_for_finalize if fixed_point else np.exp(rho_opt))
     elapsed = time.time() - t0
     allreduce(np.zeros(1))
     times = np.zeros(world)

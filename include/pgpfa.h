@@ -215,11 +215,14 @@ int pgpfa_dual_lbfgs(pgpfa_ctx* ctx, int n, const int32_t* idx, double* rho, int
  * from the per-bin covariance blocks.  The map v -> v contracts by about half the largest posterior variance of a log rate per pass
  * (a digit or more), so a trial needs ~5-10 covariance passes where L-BFGS in rho = log lambda needs thousands of evaluations.
  * Stops per trial when max |v_new - v| <= tol - exactly the max-norm of dualProblem_grad at the returned lambda.
- * rho[n][q*T]: log lambda, start in / optimum out; warm != 0: rho is a previous optimum and the mode search starts at its variational mean
- * instead of at zero; fopt[n]: dual cost at the optimum (inference.py:196-213); outer[n] (may be NULL):
- * passes used; vstatus[n]: 0 converged, 1 pass cap reached, 2 not contracting (hand the trial to pgpfa_dual_lbfgs from the rho returned). */
-int pgpfa_dual_fixed_point(pgpfa_ctx* ctx, int n, const int32_t* idx, double* rho, int warm, int max_outer, double tol, double* fopt,
-                           int32_t* outer, int32_t* vstatus);
+ * rho[n][q*T]: log lambda - read as the start (start = 1, 2), written with the optimum; start: 0 cold, lambda = 0.5 everywhere (the
+ * reference's start, inference.py:302; rho is not read), 1 rho is the start and the mode search begins at zero, 2 rho is a previous optimum
+ * and the mode search begins at its variational mean; fopt[n]: dual cost at the optimum (inference.py:196-213); outer[n] (may be NULL):
+ * passes used; vstatus[n]: 0 converged, 1 pass cap reached, 2 not contracting (hand the trial to pgpfa_dual_lbfgs from the rho returned);
+ * lam_out[n][q*T] (may be NULL): the optimal lambda itself (exp and log of the q T entries run on the device).  The optimum also stays on the
+ * device: pgpfa_dual_finalize with lam = NULL takes it from there. */
+int pgpfa_dual_fixed_point(pgpfa_ctx* ctx, int n, const int32_t* idx, double* rho, int start, int max_outer, double tol, double* fopt,
+                           int32_t* outer, int32_t* vstatus, double* lam_out);
 /* VIPostMean (inference.py:193-194): mean[p*T] = -K_big C_big (lambda - ybar) for one trial, latent-major. */
 int pgpfa_dual_post_mean(pgpfa_ctx* ctx, int trial, const double* lam, double* mean);
 /* VIPostCov (inference.py:188-191) for one trial, dense [pT][pT] latent-major: prec = K_big^-1 + C_big diag(lambda) C_big^T
@@ -227,8 +230,8 @@ int pgpfa_dual_post_mean(pgpfa_ctx* ctx, int trial, const double* lam, double* m
 int pgpfa_dual_post_cov(pgpfa_ctx* ctx, int trial, const double* lam, double* cov, double* prec);
 /* VIPostMean / VIPostCov blocks at lambda for the listed trials; fills the same posterior
  * slots as the Laplace E-step and returns sum of negLogPosteriorUnNorm at the VI mean. */
-int pgpfa_dual_finalize(pgpfa_ctx* ctx, int n, const int32_t* idx, const double* lam /* [n][q*T] */,
-                        double* nlp_sum);
+int pgpfa_dual_finalize(pgpfa_ctx* ctx, int n, const int32_t* idx, const double* lam /* [n][q*T]; NULL: the optimum pgpfa_dual_fixed_point left
+                        on the device for these trials */, double* nlp_sum);
 
 /* ---- multi-GPU (trial sharding; RCCL over xGMI) -------------------------------------- */
 int pgpfa_comm_unique_id(char* id128 /* 128 bytes */);

@@ -1515,6 +1515,21 @@ __global__ void var_quad_kernel(const double* __restrict__ C, const double* __re
   quad[slot * (size_t)q * T + (size_t)n * T + t] = 0.5 * acc;
 }
 
+// lam <- exp(lam) in place (the array holds rho on entry), or lam <- fill; flag[0] set when an entry of rho is not finite or its exp is not
+// positive and finite.  grid-stride over n entries
+__global__ void var_exp_kernel(double* __restrict__ lam, size_t n, int use_fill, double fill, int* __restrict__ flag) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const double r = lam[i];
+    const double v = use_fill ? fill : exp(r);
+    if (!use_fill && (!isfinite(r) || !(v > 0.0) || !isfinite(v))) flag[0] = 1;
+    lam[i] = v;
+  }
+}
+// out <- log(lam)
+__global__ void var_log_kernel(const double* __restrict__ lam, double* __restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = log(lam[i]);
+}
+
 // v <- v + damp (vnew - v) over the m entries of every slot; delta[slot] = max |vnew - v| (before the update).  grid = nslots, block = 256
 __global__ __launch_bounds__(256) void var_update_kernel(double* __restrict__ v, const double* __restrict__ vnew, size_t m, const double* __restrict__ damp,
                                                          double* __restrict__ delta) {

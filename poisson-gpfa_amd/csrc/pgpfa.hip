@@ -143,6 +143,7 @@ struct pgpfa_ctx {
   // trials whose resident posterior is a dual-variational one (pgpfa_dual_finalize): their blocks follow from lambda, not from the mode,
   // so the optimal lambda of those trials stays on the device for rebuilds on demand (allocated by the first finalize)
   std::vector<char> trial_dual;
+  std::vector<char> lam_resident;                // per trial: lam_keep holds the optimum of the last pgpfa_dual_fixed_point (pgpfa_dual_finalize with lam = NULL)
   double* lam_keep = nullptr;                    // [R][q][T]
   int snap_serial = 0;
   double *vec = nullptr, *cdpart = nullptr, *cdout = nullptr;
@@ -1295,6 +1296,7 @@ int pgpfa_create(pgpfa_ctx** out, int device, int q, int p, int T, int R, double
   c->vsmgp_ok.assign(R, 0);
   c->trial_snap.assign(R, -1);
   c->trial_dual.assign(R, 0);
+  c->lam_resident.assign(R, 0);
   rc |= dmalloc(c, &c->Flr, slab * p + 256 * (size_t)c->Tp, true);
   rc |= dmalloc(c, &c->d_rank, p); rc |= dmalloc(c, &c->d_roff, p + 1);
   c->tab_cap = 4 * ((size_t)c->ld / 64 + 2 * (size_t)p + 4);
@@ -1472,10 +1474,11 @@ static void counts_changed(pgpfa_ctx* c, const std::vector<int>* trials) {
   c->pacc_valid = false;
   c->have_precomp = false;
   c->have_post = false;
-  if (trials) { for (int t : *trials) { c->vsmgp_ok[t] = 0; c->mode_serial[t] = -10; c->trial_snap[t] = -1; c->trial_dual[t] = 0; } }
+  if (trials) { for (int t : *trials) { c->vsmgp_ok[t] = 0; c->mode_serial[t] = -10; c->trial_snap[t] = -1; c->trial_dual[t] = 0; c->lam_resident[t] = 0; } }
   else {
     std::fill(c->vsmgp_ok.begin(), c->vsmgp_ok.end(), 0); std::fill(c->mode_serial.begin(), c->mode_serial.end(), -10);
     std::fill(c->trial_snap.begin(), c->trial_snap.end(), -1); std::fill(c->trial_dual.begin(), c->trial_dual.end(), 0);
+    std::fill(c->lam_resident.begin(), c->lam_resident.end(), 0);
   }
 }
 
@@ -2363,7 +2366,9 @@ struct VarJob {
   double* fopt;           // host [N]: dual cost at the optimum
   int32_t* outer;         // host [N] (may be NULL): outer iterations
   int32_t* vstatus;       // host [N]: 0 converged, 1 iteration cap, 2 not contracting
-  int warm;               // rho is a previous optimum: the mode search starts at its variational mean -K C_big (lambda - y); 0: at zero
+  int start;              // 0: cold - lambda = 0.5 everywhere (the reference's, inference.py:302), rho is not read; 1: rho is the start, the mode
+                          // search begins at zero; 2: rho is a previous optimum, the mode search begins at its variational mean -K C_big (lambda - y)
+  double* lam_out;        // host [N][q*T] (may be NULL): the optimal lambda itself
 };
 static int ensure_lambda(pgpfa_ctx* c);
 static int dual_common(pgpfa_ctx* c, int nb, std::vector<double>* sB, std::vector<double>* sD, std::vector<double>* vKv);
@@ -2406,13 +2411,22 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
     if (var) {
       // lambda of the chunk -> W = C^T diag(lambda) C (+ the reference's jitter), the covariance blocks and from them the first offsets;
       // start point of the mode search: the variational mean of that lambda, -K C_big (lambda - y) (inference.py:194)
-      std::vector<double> lam0((size_t)nb * mlam);
-      for (size_t i = 0; i < lam0.size(); ++i) lam0[i] = std::exp(var->rho[(size_t)c0 * mlam + i]);
-      CHK(upload(c, c->lamd, lam0.data(), lam0.size()));
+      // (exp / log of the q T entries of every trial run on the device: on the host they were 1.3e8 libm calls per 256 config-5 trials - half a
+      // second each way, more than the whole fixed point)
+      if (var->start != 0) CHK(upload(c, c->lamd, var->rho + (size_t)c0 * mlam, (size_t)nb * mlam));
+      int* bad_dev = reinterpret_cast<int*>(c->pcg_ratio);              // (scratch word: no inner solve is running)
+      HIPC(hipMemsetAsync(bad_dev, 0, sizeof(int), c->st));
+      hipLaunchKernelGGL(var_exp_kernel, dim3(2048), dim3(256), 0, c->st, c->lamd, (size_t)nb * mlam, var->start == 0 ? 1 : 0, 0.5, bad_dev);
+      {
+        int bad = 0;
+        CHK(dl_enqueue(c, &bad, bad_dev, sizeof(int)));
+        CHK(dl_flush(c));
+        if (bad) return fail("rho must be finite with a positive finite exp (trials %d..%d)", tos.front(), tos.back());
+      }
       std::vector<double> sB_, sD_, vKv_;
       CHK(dual_common(c, nb, &sB_, &sD_, &vKv_));
       // (only when lambda is a previous optimum: from a cold lambda that mean is far out - hundreds in the log rate - and zero is the safe start)
-      if (var->warm) hipLaunchKernelGGL(negate_rows_kernel, dim3((nvec + 255) / 256, nb), dim3(256), 0, c->st, c->KD, ld, c->Xc, ld, nvec, c->ident);
+      if (var->start == 2) hipLaunchKernelGGL(negate_rows_kernel, dim3((nvec + 255) / 256, nb), dim3(256), 0, c->st, c->KD, ld, c->Xc, ld, nvec, c->ident);
       else HIPC(hipMemsetAsync(c->Xc, 0, (size_t)ld * nb * sizeof(double), c->st));
       if (c->plan_lowrank) { CHK(dual_jitter(c, nb)); CHK(posterior_blocks(c, nb, 1.0, false, false)); }
       else CHK(posterior_blocks(c, nb, 1.0 + 1e-6, false));
@@ -2940,10 +2954,23 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
     if (var) {
       // optimum out: rho = log lambda, the dual cost there (inference.py:196-213), statuses
       c->var_active = false;
-      std::vector<double> lam((size_t)nb * mlam);
-      CHK(download(c, lam.data(), c->lamd, lam.size()));
-      for (size_t i = 0; i < lam.size(); ++i) var->rho[(size_t)c0 * mlam + i] = std::log(lam[i]);
       CHK(dual_eval_slots(c, nb, tos, false, var->fopt + c0, false));
+      // the optimum stays on the device for pgpfa_dual_finalize(lam = NULL) and for blocks rebuilt on demand
+      if (!c->lam_keep) {
+        const size_t bytes = (size_t)c->R * mlam * sizeof(double);
+        if (hipMalloc((void**)&c->lam_keep, bytes) != hipSuccess) { (void)hipGetLastError(); c->lam_keep = nullptr; return fail("hipMalloc(%zu bytes) for the resident dual variables failed", bytes); }
+        c->bytes += bytes;
+      }
+      for (int s = 0; s < nb; ++s) {
+        CHK(copy_dev(c, c->lam_keep + (size_t)tos[s] * mlam, c->lamd + (size_t)s * mlam, mlam * sizeof(double)));
+        c->lam_resident[tos[s]] = 1;
+        // (lam_keep also feeds the blocks rebuilt on demand of a dual posterior: whatever posterior the trial had is superseded until
+        // pgpfa_dual_finalize has run on the new optimum)
+        c->trial_dual[tos[s]] = 0; c->trial_snap[tos[s]] = -1; c->vsmgp_ok[tos[s]] = 0;
+      }
+      if (var->lam_out) CHK(download(c, var->lam_out + (size_t)c0 * mlam, c->lamd, (size_t)nb * mlam));
+      hipLaunchKernelGGL(var_log_kernel, dim3(2048), dim3(256), 0, c->st, (const double*)c->lamd, c->dgrad, (size_t)nb * mlam);
+      CHK(download(c, var->rho + (size_t)c0 * mlam, c->dgrad, (size_t)nb * mlam));
       for (int s = 0; s < nb; ++s) {
         if (var->outer) var->outer[c0 + s] = vouter[s];
         var->vstatus[c0 + s] = vstat[s];
@@ -4028,23 +4055,22 @@ static int var_offsets(pgpfa_ctx* c, int nb, double* out) {
 // -1/2 (C Sigma C^T)o(C Sigma C^T) diag(lambda) (I - C Sigma C^T diag(lambda)), rows sum to at most 1/2 c_n^T Sigma_t c_n), i.e. a
 // digit or more per pass, where L-BFGS in rho needs thousands of evaluations (the dual's Hessian carries C K C^T: condition > 1e4).
 // Stops per trial when max |v_new - v| <= tol: that IS the max-norm of the reference's dual gradient at the returned lambda.
-// rho[n][q*T]: log lambda, start in / optimum out; warm: rho is a previous optimum (the mode search starts at its variational mean instead
-// of zero); fopt[n]: dual cost there; outer[n] (may be NULL): passes; vstatus[n]: 0 converged,
+// rho[n][q*T]: log lambda, start in (start = 1, 2) / optimum out; start: 0 cold (lambda = 0.5, rho not read), 1 rho is the start, 2 rho is a
+// previous optimum (the mode search starts at its variational mean instead of zero); lam_out (may be NULL): the optimal lambda itself - it
+// also stays on the device for pgpfa_dual_finalize(lam = NULL); fopt[n]: dual cost there; outer[n] (may be NULL): passes; vstatus[n]: 0 converged,
 // 1 iteration cap, 2 not contracting (posterior variances too large for the plain fixed point: hand the trial to pgpfa_dual_lbfgs).
-int pgpfa_dual_fixed_point(pgpfa_ctx* c, int n, const int32_t* idx, double* rho, int warm, int max_outer, double tol, double* fopt, int32_t* outer,
-                           int32_t* vstatus) {
+int pgpfa_dual_fixed_point(pgpfa_ctx* c, int n, const int32_t* idx, double* rho, int start, int max_outer, double tol, double* fopt, int32_t* outer,
+                           int32_t* vstatus, double* lam_out) {
   if (!c) return fail("null context");
   if (!rho || !fopt || !vstatus) return fail("null argument");
   if (max_outer < 1 || !(tol > 0.0)) return fail("max_outer and tol must be positive");
+  if (start < 0 || start > 2) return fail("start must be 0 (cold), 1 (rho is the start) or 2 (rho is a previous optimum)");
   Trials tr;
   CHK(resolve_trials(c, n, idx, &tr, true));
   CHK(check_distinct(tr.v));
   HIPC(hipSetDevice(c->device));
   const int N = (int)tr.v.size();
-  const size_t m = (size_t)c->q * c->T;
-  for (size_t i = 0; i < (size_t)N * m; ++i)
-    if (!std::isfinite(rho[i])) return fail("rho must be finite (trial %d, entry %zu)", tr.v[i / m], i % m);
-  VarJob job{rho, max_outer, tol, fopt, outer, vstatus, warm};
+  VarJob job{rho, max_outer, tol, fopt, outer, vstatus, start, lam_out};
   std::vector<int32_t> it1(N), st1(N);
   double obj = 0.0;
   CHK(estep_impl(c, tr, 0, c->dual_lowrank, &obj, it1.data(), st1.data(), nullptr, &job));
@@ -4311,10 +4337,15 @@ int pgpfa_dual_lbfgs(pgpfa_ctx* c, int n, const int32_t* idx, double* rho, int m
 
 int pgpfa_dual_finalize(pgpfa_ctx* c, int n, const int32_t* idx, const double* lam, double* nlp_sum) {
   if (!c) return fail("null context");
-  if (!lam) return fail("null argument");
   Trials tr;
   CHK(resolve_trials(c, n, idx, &tr, true));
   const int N = (int)tr.v.size();
+  if (!lam) {
+    // the optimum the last pgpfa_dual_fixed_point left on the device for these trials
+    if (!c->lam_keep) return fail("lam = NULL needs the resident optimum of pgpfa_dual_fixed_point");
+    for (int t : tr.v)
+      if (!c->lam_resident[t]) return fail("trial %d has no resident optimum of pgpfa_dual_fixed_point (lam = NULL)", t);
+  }
   c->want_slots = std::max(c->want_slots, std::min(N, c->R));
   CHK(ready_estep(c, c->dual_lowrank));
   CHK(ensure_lambda(c));
@@ -4339,9 +4370,11 @@ int pgpfa_dual_finalize(pgpfa_ctx* c, int n, const int32_t* idx, const double* l
     const int nb = std::min(c->B, N - c0);
     std::vector<int> tos(tr.v.begin() + c0, tr.v.begin() + c0 + nb);
     CHK(upload_list(c, c->trial_of_slot, tos));
-    CHK(upload(c, c->lamd, lam + (size_t)c0 * q * c->T, (size_t)nb * q * c->T));
+    if (lam) CHK(upload(c, c->lamd, lam + (size_t)c0 * q * c->T, (size_t)nb * q * c->T));
     for (int s = 0; s < nb; ++s) {
-      HIPC(hipMemcpyAsync(c->lam_keep + (size_t)tos[s] * q * c->T, c->lamd + (size_t)s * q * c->T, (size_t)q * c->T * sizeof(double), hipMemcpyDeviceToDevice, c->st));
+      const size_t mq = (size_t)q * c->T;
+      if (lam) { CHK(copy_dev(c, c->lam_keep + (size_t)tos[s] * mq, c->lamd + (size_t)s * mq, mq * sizeof(double))); c->lam_resident[tos[s]] = 0; }
+      else CHK(copy_dev(c, c->lamd + (size_t)s * mq, c->lam_keep + (size_t)tos[s] * mq, mq * sizeof(double)));
       c->trial_dual[tos[s]] = 1;
     }
     HIPC(hipMemsetAsync(c->ws.info, 0, sizeof(int) * nb, c->st));

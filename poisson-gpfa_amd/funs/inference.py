@@ -480,27 +480,39 @@ def dualVariational(experiment, params, optimizeLogLambda=False, prevOptimRes=No
     ctx.set_option('dual_lowrank', 1 if DUAL_LOWRANK else 0)
     ctx.set_option('dual_f32', 1 if (DUAL_SOLVER in ('device', 'fixedpoint') and DUAL_LOWRANK and DUAL_F32) else 0)
     if DUAL_SOLVER in ('device', 'fixedpoint') and len(mine):
-        # all trials in lockstep on the device, in rho = log(lambda); same optimum as either of the reference's variants
-        if prevOptimRes is None:
-            rho0 = np.zeros((len(mine), m)) if optimizeLogLambda else np.full((len(mine), m), np.log(0.5))
-        else:
+        # on the device, in rho = log(lambda); same optimum as either of the reference's variants
+        def prev_rho():
             prev = np.stack([np.asarray(prevOptimRes[j] if len(prevOptimRes) == len(mine) else prevOptimRes[lo + j], dtype=np.float64)
                              for j in range(len(mine))])
-            rho0 = prev if optimizeLogLambda else np.log(np.maximum(prev, 1e-300))
+            return prev if optimizeLogLambda else np.log(np.maximum(prev, 1e-300))
+        lam_all = None
         if DUAL_SOLVER == 'fixedpoint':
             # the optimum through the variance fixed point (pgpfa_dual_fixed_point): a handful of covariance passes per trial; a trial
-            # whose map does not contract (log-rate variances of order one) or that runs out of passes goes to L-BFGS from where it stopped
-            rho, fopt, iters, vstat = ctx.dual_fixed_point(mine, rho0, max_outer=DUAL_FP_MAX_PASSES, tol=DUAL_FP_TOL, warm=prevOptimRes is not None)
+            # whose map does not contract (log-rate variances of order one) or that runs out of passes goes to L-BFGS from where it stopped.
+            # Cold start: the reference's lambda = 0.5 (inference.py:302) - rho = 0 of the log-lambda variant is lambda = 1: both are starts of
+            # one strictly convex problem and the fixed point lands on its optimum from either.  exp / log of the q T entries run on the
+            # device and the optimum stays there for the finalize call.
+            res = ctx.dual_fixed_point(mine, None if prevOptimRes is None else prev_rho(), max_outer=DUAL_FP_MAX_PASSES, tol=DUAL_FP_TOL,
+                                       warm=prevOptimRes is not None, want_lam=not optimizeLogLambda)
+            rho, fopt, iters, vstat = res[:4]
+            lam_fp = res[4] if len(res) > 4 else None
             bad = np.nonzero(vstat != 0)[0]
             if len(bad):
                 rho_b, fopt_b, it_b = ctx.dual_lbfgs(mine[bad], rho[bad])
                 rho[bad], fopt[bad] = rho_b, fopt_b
                 iters[bad] += it_b
+                lam_all = np.exp(rho)
+            optim = list(rho) if optimizeLogLambda else list(lam_fp if lam_all is None else lam_all)
+            nlp = ctx.dual_finalize(mine, lam_all)           # (None: the optimum the fixed point left on the device)
         else:
+            if prevOptimRes is None:
+                rho0 = np.zeros((len(mine), m)) if optimizeLogLambda else np.full((len(mine), m), np.log(0.5))
+            else:
+                rho0 = prev_rho()
             rho, fopt, iters = ctx.dual_lbfgs(mine, rho0)
-        lam_all = np.exp(rho)
-        optim = list(rho) if optimizeLogLambda else list(lam_all)
-        nlp = ctx.dual_finalize(mine, lam_all)
+            lam_all = np.exp(rho)
+            optim = list(rho) if optimizeLogLambda else list(lam_all)
+            nlp = ctx.dual_finalize(mine, lam_all)
         sess.mark_written(mine)
         tot = sess.allreduce(np.array([nlp, float(np.sum(fopt)), float(len(mine))]))
         infRes = DeviceInfRes(sess, mine, (lo, hi))

@@ -334,15 +334,17 @@ def test_dual_variational_hands_unsettled_trials_to_lbfgs(monkeypatch):
         def info(self, k): return 0.0
         def upload_counts(self, Y): pass
         def set_params(self, C, d, tau): pass
-        def dual_fixed_point(self, idx, rho0, max_outer=40, tol=1e-8, warm=False):
-            calls['fp'] = (np.array(idx), np.array(rho0), max_outer, tol, warm)
-            rho = np.array(rho0) + 1.0 + np.arange(len(idx))[:, None]
-            return rho, -np.arange(len(idx), dtype=float), np.full(len(idx), 5, np.int32), np.array([0, 2, 0, 1, 0], np.int32)[:len(idx)]
+        def dual_fixed_point(self, idx, rho0=None, max_outer=40, tol=1e-8, warm=False, want_lam=False):
+            calls['fp'] = (np.array(idx), None if rho0 is None else np.array(rho0), max_outer, tol, warm, want_lam)
+            start = np.full((len(idx), self.q * self.T), np.log(0.5)) if rho0 is None else np.array(rho0)
+            rho = start + 1.0 + np.arange(len(idx))[:, None]
+            out = (rho, -np.arange(len(idx), dtype=float), np.full(len(idx), 5, np.int32), np.array([0, 2, 0, 1, 0], np.int32)[:len(idx)])
+            return out + (np.exp(rho),) if want_lam else out
         def dual_lbfgs(self, idx, rho0, max_iter=15000, factr=1e7, pgtol=1e-5):
             calls['lbfgs'] = (np.array(idx), np.array(rho0))
             return np.array(rho0) * 2.0, np.full(len(idx), -100.0), np.full(len(idx), 70, np.int32)
         def dual_finalize(self, idx, lam):
-            calls['finalize'] = (np.array(idx), np.array(lam))
+            calls['finalize'] = (np.array(idx), None if lam is None else np.array(lam))
             return 3.0 * len(idx)
 
     monkeypatch.setattr(_hip, 'Context', Ctx)
@@ -354,8 +356,8 @@ def test_dual_variational_hands_unsettled_trials_to_lbfgs(monkeypatch):
     assert inference.DUAL_SOLVER == 'fixedpoint'
     try:
         infRes, nll, vlb, opt = inference.dualVariational(exp, params)
-        idx, rho0, max_outer, tol, warm = calls['fp']
-        assert np.array_equal(idx, np.arange(R)) and np.allclose(rho0, np.log(0.5)) and not warm
+        idx, rho0, max_outer, tol, warm, want_lam = calls['fp']
+        assert np.array_equal(idx, np.arange(R)) and rho0 is None and not warm and want_lam       # cold: the reference's lambda = 0.5, set on the device
         assert max_outer == inference.DUAL_FP_MAX_PASSES and tol == inference.DUAL_FP_TOL
         bad_idx, bad_rho = calls['lbfgs']
         assert np.array_equal(bad_idx, [1, 3])
@@ -369,7 +371,13 @@ def test_dual_variational_hands_unsettled_trials_to_lbfgs(monkeypatch):
         assert abs(vlb - np.mean([0.0, -100.0, -2.0, -100.0, -4.0])) < 1e-12 and abs(nll + 3.0) < 1e-12
         # warm start: rho = log of the previous lambda, flagged as such; the log-lambda variant returns rho itself
         infRes, nll, vlb, opt2 = inference.dualVariational(exp, params, optimizeLogLambda=True, prevOptimRes=[np.log(o) for o in opt])
-        assert calls['fp'][4] is True and np.allclose(calls['fp'][1], merged)
+        assert calls['fp'][4] is True and np.allclose(calls['fp'][1], merged) and calls['fp'][5] is False
         assert np.allclose(np.stack(opt2)[0], merged[0] + 1.0)
+        # nobody handed back: the finalize call takes the optimum the fixed point left on the device (lam = None)
+        Ctx.dual_fixed_point = lambda self, idx, rho0=None, max_outer=40, tol=1e-8, warm=False, want_lam=False: (
+            np.zeros((len(idx), q * T)), np.zeros(len(idx)), np.full(len(idx), 4, np.int32), np.zeros(len(idx), np.int32), np.ones((len(idx), q * T)))[:5 if want_lam else 4]
+        calls.pop('lbfgs')
+        infRes, nll, vlb, opt3 = inference.dualVariational(exp, params)
+        assert calls['finalize'][1] is None and 'lbfgs' not in calls and np.allclose(np.stack(opt3), 1.0)
     finally:
         _session.drop_sessions()

@@ -138,6 +138,17 @@ def test_fixed_point_is_the_zero_of_the_reference_dual_gradient(c1, engine):
         rho2, fopt2, passes2, status2 = ctx.dual_fixed_point(idx, rho, warm=True)
         assert np.all(status2 == 0) and np.all(passes2 == 1)
         assert np.max(np.abs(rho2 - rho)) <= 1e-7 and np.max(np.abs(fopt2 - fopt)) <= 1e-9 * np.max(np.abs(fopt))
+        # the cold start set on the device (rho0 = None: lambda = 0.5, nothing uploaded) is the same start; lambda comes back beside rho, and the
+        # finalize call takes the optimum from the device (lam = None) - same posterior as from the host copy
+        rho4, fopt4, passes4, status4, lam4 = ctx.dual_fixed_point(idx, None, want_lam=True)
+        assert np.array_equal(rho4, rho) and np.array_equal(fopt4, fopt) and np.array_equal(passes4, passes)
+        assert np.max(np.abs(lam4 - np.exp(rho4))) <= 1e-15 * np.max(lam4)
+        nlp_dev = ctx.dual_finalize(idx, None)
+        pm_dev, vs_dev = ctx.post_mean(idx).copy(), ctx.post_vsm(idx).copy()
+        nlp_host = ctx.dual_finalize(idx, lam4)
+        assert nlp_dev == nlp_host and np.array_equal(ctx.post_mean(idx), pm_dev) and np.array_equal(ctx.post_vsm(idx), vs_dev)
+        with pytest.raises(_hip.HipBackendError):
+            ctx.dual_finalize(idx, None)                     # (the host copy replaced the resident optimum of these trials)
         # the pass cap is reported, not hidden
         _, _, passes3, status3 = ctx.dual_fixed_point(idx, np.full((4, q * T), np.log(0.5)), max_outer=1)
         assert np.all(status3 == 1) and np.all(passes3 == 1)
