@@ -432,14 +432,14 @@ def run_dual(args, q, p, T, R, rank, world):
         # inference.dualVariational - counted in the timed region
         # (cold start lambda = 0.5 set on the device; exp / log of the entries run there and the optimum stays resident for the finalize call,
         # as in inference.dualVariational)
-        rho_opt, fopt, iters, fp_status, lam_opt = ctx.dual_fixed_point(idx, None, want_lam=True)
+        _, fopt, iters, fp_status = ctx.dual_fixed_point(idx, None, want_rho=False)
         bad = np.nonzero(fp_status != 0)[0]
         lam_for_finalize = None
         if len(bad):
-            rho_b, fopt_b, it_b = ctx.dual_lbfgs(idx[bad], rho_opt[bad])
-            rho_opt[bad], fopt[bad] = rho_b, fopt_b
+            lam_for_finalize = ctx.dual_lambda(idx)
+            rho_b, fopt_b, it_b = ctx.dual_lbfgs(idx[bad], np.log(lam_for_finalize[bad]))
+            lam_for_finalize[bad], fopt[bad] = np.exp(rho_b), fopt_b
             iters[bad] += it_b
-            lam_for_finalize = np.exp(rho_opt)
     else:
         rho_opt, fopt, iters = ctx.dual_lbfgs(idx, rho, max_iter=15000 if whole else args.dual_iters)
     t_opt = time.time() - t0
@@ -468,7 +468,7 @@ def run_dual(args, q, p, T, R, rank, world):
             # the certificate both solvers are held to: the reference's dual gradient (inference.py:215-219) at the returned lambda, FP64
             ctx.set_option('dual_f32', 0)
             nchk = min(R, 8)
-            _, gchk = ctx.dual_costgrad_batch(idx[:nchk], np.exp(rho_opt[:nchk]))
+            _, gchk = ctx.dual_costgrad_batch(idx[:nchk], ctx.dual_lambda(idx[:nchk]))
             common = dict(common, solver='fixedpoint', fixed_point_passes_max=int(np.max(iters)), fixed_point_passes_min=int(np.min(iters)),
                           fixed_point_status_counts=[int(v) for v in np.bincount(fp_status, minlength=3)],
                           max_abs_dual_gradient_at_optimum_first_trials=float(np.max(np.abs(gchk))))

@@ -215,14 +215,17 @@ int pgpfa_dual_lbfgs(pgpfa_ctx* ctx, int n, const int32_t* idx, double* rho, int
  * from the per-bin covariance blocks.  The map v -> v contracts by about half the largest posterior variance of a log rate per pass
  * (a digit or more), so a trial needs ~5-10 covariance passes where L-BFGS in rho = log lambda needs thousands of evaluations.
  * Stops per trial when max |v_new - v| <= tol - exactly the max-norm of dualProblem_grad at the returned lambda.
- * rho[n][q*T]: log lambda - read as the start (start = 1, 2), written with the optimum; start: 0 cold, lambda = 0.5 everywhere (the
- * reference's start, inference.py:302; rho is not read), 1 rho is the start and the mode search begins at zero, 2 rho is a previous optimum
- * and the mode search begins at its variational mean; fopt[n]: dual cost at the optimum (inference.py:196-213); outer[n] (may be NULL):
+ * rho[n][q*T] (may be NULL with start = 0 / 3: nothing read, nothing written): log lambda - read as the start (start = 1, 2), written with the
+ * optimum; start: 0 cold, lambda = 0.5 everywhere (the reference's start, inference.py:302), 1 rho is the start and the mode search begins at
+ * zero, 2 rho is a previous optimum and the mode search begins at its variational mean, 3 the same from the optimum resident on the device; fopt[n]: dual cost at the optimum (inference.py:196-213); outer[n] (may be NULL):
  * passes used; vstatus[n]: 0 converged, 1 pass cap reached, 2 not contracting (hand the trial to pgpfa_dual_lbfgs from the rho returned);
  * lam_out[n][q*T] (may be NULL): the optimal lambda itself (exp and log of the q T entries run on the device).  The optimum also stays on the
  * device: pgpfa_dual_finalize with lam = NULL takes it from there. */
 int pgpfa_dual_fixed_point(pgpfa_ctx* ctx, int n, const int32_t* idx, double* rho, int start, int max_outer, double tol, double* fopt,
                            int32_t* outer, int32_t* vstatus, double* lam_out);
+/* The dual variables resident for the listed trials (the optimum of the last pgpfa_dual_fixed_point, or what pgpfa_dual_finalize was given):
+ * out[n][q*T]. */
+int pgpfa_get_dual_lambda(pgpfa_ctx* ctx, int n, const int32_t* idx, double* out);
 /* VIPostMean (inference.py:193-194): mean[p*T] = -K_big C_big (lambda - ybar) for one trial, latent-major. */
 int pgpfa_dual_post_mean(pgpfa_ctx* ctx, int trial, const double* lam, double* mean);
 /* VIPostCov (inference.py:188-191) for one trial, dense [pT][pT] latent-major: prec = K_big^-1 + C_big diag(lambda) C_big^T

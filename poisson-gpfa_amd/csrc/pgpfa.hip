@@ -2367,7 +2367,8 @@ struct VarJob {
   int32_t* outer;         // host [N] (may be NULL): outer iterations
   int32_t* vstatus;       // host [N]: 0 converged, 1 iteration cap, 2 not contracting
   int start;              // 0: cold - lambda = 0.5 everywhere (the reference's, inference.py:302), rho is not read; 1: rho is the start, the mode
-                          // search begins at zero; 2: rho is a previous optimum, the mode search begins at its variational mean -K C_big (lambda - y)
+                          // search begins at zero; 2: rho is a previous optimum, the mode search begins at its variational mean -K C_big (lambda - y);
+                          // 3: like 2 with the previous optimum taken from the device (lam_keep), rho is not read
   double* lam_out;        // host [N][q*T] (may be NULL): the optimal lambda itself
 };
 static int ensure_lambda(pgpfa_ctx* c);
@@ -2413,10 +2414,14 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
       // start point of the mode search: the variational mean of that lambda, -K C_big (lambda - y) (inference.py:194)
       // (exp / log of the q T entries of every trial run on the device: on the host they were 1.3e8 libm calls per 256 config-5 trials - half a
       // second each way, more than the whole fixed point)
-      if (var->start != 0) CHK(upload(c, c->lamd, var->rho + (size_t)c0 * mlam, (size_t)nb * mlam));
+      if (var->start == 3) {
+        for (int s = 0; s < nb; ++s) CHK(copy_dev(c, c->lamd + (size_t)s * mlam, c->lam_keep + (size_t)tos[s] * mlam, mlam * sizeof(double)));
+      } else if (var->start != 0) {
+        CHK(upload(c, c->lamd, var->rho + (size_t)c0 * mlam, (size_t)nb * mlam));
+      }
       int* bad_dev = reinterpret_cast<int*>(c->pcg_ratio);              // (scratch word: no inner solve is running)
       HIPC(hipMemsetAsync(bad_dev, 0, sizeof(int), c->st));
-      hipLaunchKernelGGL(var_exp_kernel, dim3(2048), dim3(256), 0, c->st, c->lamd, (size_t)nb * mlam, var->start == 0 ? 1 : 0, 0.5, bad_dev);
+      if (var->start != 3) hipLaunchKernelGGL(var_exp_kernel, dim3(2048), dim3(256), 0, c->st, c->lamd, (size_t)nb * mlam, var->start == 0 ? 1 : 0, 0.5, bad_dev);
       {
         int bad = 0;
         CHK(dl_enqueue(c, &bad, bad_dev, sizeof(int)));
@@ -2426,7 +2431,7 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
       std::vector<double> sB_, sD_, vKv_;
       CHK(dual_common(c, nb, &sB_, &sD_, &vKv_));
       // (only when lambda is a previous optimum: from a cold lambda that mean is far out - hundreds in the log rate - and zero is the safe start)
-      if (var->start == 2) hipLaunchKernelGGL(negate_rows_kernel, dim3((nvec + 255) / 256, nb), dim3(256), 0, c->st, c->KD, ld, c->Xc, ld, nvec, c->ident);
+      if (var->start >= 2) hipLaunchKernelGGL(negate_rows_kernel, dim3((nvec + 255) / 256, nb), dim3(256), 0, c->st, c->KD, ld, c->Xc, ld, nvec, c->ident);
       else HIPC(hipMemsetAsync(c->Xc, 0, (size_t)ld * nb * sizeof(double), c->st));
       if (c->plan_lowrank) { CHK(dual_jitter(c, nb)); CHK(posterior_blocks(c, nb, 1.0, false, false)); }
       else CHK(posterior_blocks(c, nb, 1.0 + 1e-6, false));
@@ -2969,8 +2974,10 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
         c->trial_dual[tos[s]] = 0; c->trial_snap[tos[s]] = -1; c->vsmgp_ok[tos[s]] = 0;
       }
       if (var->lam_out) CHK(download(c, var->lam_out + (size_t)c0 * mlam, c->lamd, (size_t)nb * mlam));
-      hipLaunchKernelGGL(var_log_kernel, dim3(2048), dim3(256), 0, c->st, (const double*)c->lamd, c->dgrad, (size_t)nb * mlam);
-      CHK(download(c, var->rho + (size_t)c0 * mlam, c->dgrad, (size_t)nb * mlam));
+      if (var->rho) {
+        hipLaunchKernelGGL(var_log_kernel, dim3(2048), dim3(256), 0, c->st, (const double*)c->lamd, c->dgrad, (size_t)nb * mlam);
+        CHK(download(c, var->rho + (size_t)c0 * mlam, c->dgrad, (size_t)nb * mlam));
+      }
       for (int s = 0; s < nb; ++s) {
         if (var->outer) var->outer[c0 + s] = vouter[s];
         var->vstatus[c0 + s] = vstat[s];
@@ -4062,14 +4069,20 @@ static int var_offsets(pgpfa_ctx* c, int nb, double* out) {
 int pgpfa_dual_fixed_point(pgpfa_ctx* c, int n, const int32_t* idx, double* rho, int start, int max_outer, double tol, double* fopt, int32_t* outer,
                            int32_t* vstatus, double* lam_out) {
   if (!c) return fail("null context");
-  if (!rho || !fopt || !vstatus) return fail("null argument");
+  if (!fopt || !vstatus) return fail("null argument");
   if (max_outer < 1 || !(tol > 0.0)) return fail("max_outer and tol must be positive");
-  if (start < 0 || start > 2) return fail("start must be 0 (cold), 1 (rho is the start) or 2 (rho is a previous optimum)");
+  if (start < 0 || start > 3) return fail("start must be 0 (cold), 1 (rho is the start), 2 (rho is a previous optimum) or 3 (the resident optimum)");
+  if (!rho && (start == 1 || start == 2)) return fail("start = %d reads rho", start);
   Trials tr;
   CHK(resolve_trials(c, n, idx, &tr, true));
   CHK(check_distinct(tr.v));
   HIPC(hipSetDevice(c->device));
   const int N = (int)tr.v.size();
+  if (start == 3) {
+    if (!c->lam_keep) return fail("start = 3 needs a resident dual optimum (pgpfa_dual_fixed_point or pgpfa_dual_finalize)");
+    for (int t : tr.v)
+      if (!c->lam_resident[t] && !c->trial_dual[t]) return fail("trial %d has no resident dual optimum (start = 3)", t);
+  }
   VarJob job{rho, max_outer, tol, fopt, outer, vstatus, start, lam_out};
   std::vector<int32_t> it1(N), st1(N);
   double obj = 0.0;
@@ -4333,6 +4346,22 @@ int pgpfa_dual_lbfgs(pgpfa_ctx* c, int n, const int32_t* idx, double* rho, int m
   }
   c->info["last_dual_evaluations"] = n_eval;
   return 0;
+}
+
+// the dual variables resident for the listed trials (the optimum of the last pgpfa_dual_fixed_point, or what pgpfa_dual_finalize was given)
+int pgpfa_get_dual_lambda(pgpfa_ctx* c, int n, const int32_t* idx, double* out) {
+  if (!c || !out) return fail("null argument");
+  Trials tr;
+  CHK(resolve_trials(c, n, idx, &tr));
+  HIPC(hipSetDevice(c->device));
+  if (!c->lam_keep) return fail("no dual variables are resident");
+  const size_t m = (size_t)c->q * c->T;
+  for (int t : tr.v)
+    if (!c->lam_resident[t] && !c->trial_dual[t]) return fail("trial %d has no resident dual variables", t);
+  for (size_t i = 0; i < tr.v.size(); ++i) {
+    CHK(dl_enqueue(c, out + i * m, c->lam_keep + (size_t)tr.v[i] * m, m * sizeof(double)));
+  }
+  return dl_flush(c);
 }
 
 int pgpfa_dual_finalize(pgpfa_ctx* c, int n, const int32_t* idx, const double* lam, double* nlp_sum) {

@@ -56,6 +56,7 @@ _SIGNATURES = {
     'pgpfa_dual_costgrad': [ct.c_void_p, ct.c_int, c_double_p, c_double_p, c_double_p],
     'pgpfa_dual_costgrad_batch': [ct.c_void_p, ct.c_int, c_int32_p, c_double_p, c_double_p, c_double_p],
     'pgpfa_dual_lbfgs': [ct.c_void_p, ct.c_int, c_int32_p, c_double_p, ct.c_int, ct.c_double, ct.c_double, c_double_p, c_int32_p],
+    'pgpfa_get_dual_lambda': [ct.c_void_p, ct.c_int, c_int32_p, c_double_p],
     'pgpfa_dual_fixed_point': [ct.c_void_p, ct.c_int, c_int32_p, c_double_p, ct.c_int, ct.c_int, ct.c_double, c_double_p, c_int32_p, c_int32_p, c_double_p],
     'pgpfa_dual_finalize': [ct.c_void_p, ct.c_int, c_int32_p, c_double_p, c_double_p],
     'pgpfa_dual_post_mean': [ct.c_void_p, ct.c_int, c_double_p, c_double_p],
@@ -331,23 +332,33 @@ class Context:
         check(self.lib.pgpfa_dual_lbfgs(self.h, n, iptr(ii), dptr(rho), int(max_iter), float(factr), float(pgtol), dptr(fopt), iptr(iters)))
         return rho, fopt, iters
 
-    def dual_fixed_point(self, idx, rho0=None, max_outer=40, tol=1e-8, warm=False, want_lam=False):
-        """Optimum of the dual by the variance fixed point (pgpfa_dual_fixed_point) -> (rho_opt[n][q*T], dual optimum[n], passes[n],
+    def dual_fixed_point(self, idx, rho0=None, max_outer=40, tol=1e-8, warm=False, want_lam=False, want_rho=True, resident=False):
+        """Optimum of the dual by the variance fixed point (pgpfa_dual_fixed_point) -> (rho_opt[n][q*T] or None, dual optimum[n], passes[n],
         status[n]: 0 converged, 1 pass cap, 2 not contracting[, lambda_opt[n][q*T] with want_lam]).  rho0 = None: the reference's cold start
-        lambda = 0.5; warm: rho0 is a previous optimum.  The optimum stays on the device: dual_finalize(idx, None) takes it from there."""
+        lambda = 0.5; warm: rho0 is a previous optimum; resident: the start is the optimum resident on the device (nothing uploaded).  The
+        optimum stays on the device: dual_finalize(idx, None) takes it from there, dual_lambda(idx) reads it."""
         n, ii = self._n_idx(idx)
         m = self.q * self.T
-        if rho0 is None:
-            rho, start = np.empty((n, m)), 0
+        if resident:
+            rho, start = (np.empty((n, m)) if want_rho else None), 3
+        elif rho0 is None:
+            rho, start = (np.empty((n, m)) if want_rho else None), 0
         else:
             rho, start = np.array(as_f64(rho0).reshape(n, m), copy=True), (2 if warm else 1)
         fopt = np.empty(n)
         outer = np.zeros(n, dtype=np.int32)
         status = np.zeros(n, dtype=np.int32)
         lam = np.empty((n, m)) if want_lam else None
-        check(self.lib.pgpfa_dual_fixed_point(self.h, n, iptr(ii), dptr(rho), start, int(max_outer), float(tol), dptr(fopt), iptr(outer), iptr(status),
-                                              dptr(lam) if want_lam else None))
+        check(self.lib.pgpfa_dual_fixed_point(self.h, n, iptr(ii), dptr(rho) if rho is not None else None, start, int(max_outer), float(tol), dptr(fopt),
+                                              iptr(outer), iptr(status), dptr(lam) if want_lam else None))
         return (rho, fopt, outer, status, lam) if want_lam else (rho, fopt, outer, status)
+
+    def dual_lambda(self, idx=None):
+        """The dual variables resident for the listed trials: [n][q*T]."""
+        n, ii = self._n_idx(idx)
+        out = np.empty((n, self.q * self.T))
+        check(self.lib.pgpfa_get_dual_lambda(self.h, n, iptr(ii), dptr(out)))
+        return out
 
     def dual_finalize(self, idx, lam):
         """lam = None: the optimum the last dual_fixed_point left on the device for these trials."""

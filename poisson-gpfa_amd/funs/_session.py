@@ -269,6 +269,46 @@ class DeviceOptimRes(LazyTrialList):
         return True
 
 
+class DeviceDualOptimRes(LazyTrialList):
+    """varOptimRes of inference.dualVariational (inference.py:326 / 398: the optimal lambda, or rho = log lambda, per trial) left on the
+    device: an entry is downloaded when it is read, and handed back as prevOptimRes of the next call on the same trials it is a warm start that
+    moves no bytes (at config 5 a trial's entry is 4 MB: 1 GB per 256 trials each way).  Like the lazy infRes entries it is a VIEW: the next
+    variational E-step on a trial overwrites its lambda in place, and reading the entry afterwards raises instead of returning the newer
+    optimum under the old name (entries already read, or snapshotted with materialize(), stay valid)."""
+
+    def __init__(self, session, trial_idx, log):
+        tid = np.asarray(trial_idx, dtype=np.int32)
+        ctx = session.ctx
+        super().__init__(len(tid), lambda i: self._fresh(i) and (np.log(ctx.dual_lambda(tid[i:i + 1])[0]) if log else ctx.dual_lambda(tid[i:i + 1])[0]))
+        self.session = session
+        self.trial_idx = tid
+        self.log = bool(log)
+        self.stamp = session.mode_stamp
+        self.dual_stamp = session.dual_stamp
+
+    def _fresh(self, i):
+        if self.session.dual_trial_stamp[self.trial_idx[i]] != self.dual_stamp:
+            raise _hip.HipBackendError('varOptimRes[%d] belongs to a superseded variational E-step: the dual variables of trial %d have been '
+                                       'overwritten on the device by a later one (call materialize() on the list before running it to keep a '
+                                       'host copy)' % (i, int(self.trial_idx[i])))
+        return True
+
+    def materialize(self):
+        """Host copies of every entry not read yet (one bulk download per 256 MB)."""
+        missing = [i for i in range(len(self)) if i not in self._cache]
+        if not missing:
+            return self
+        for i in missing:
+            self._fresh(i)
+        step = max(1, (1 << 28) // max(1, self.session.q * self.session.T * 8))
+        for c0 in range(0, len(missing), step):
+            part = missing[c0:c0 + step]
+            lam = self.session.ctx.dual_lambda(self.trial_idx[part])
+            for j, i in enumerate(part):
+                self._cache[i] = np.log(lam[j]) if self.log else lam[j].copy()
+        return self
+
+
 # ----------------------------------------------------------------------------------------------
 class Session:
     def __init__(self, Y, p, bin_ms):
@@ -279,6 +319,8 @@ class Session:
         self.post_stamp = 0
         self.mode_stamp = 0
         self.trial_stamp = np.zeros(R, dtype=np.int64)      # post_stamp of the E-step that last wrote each trial's posterior
+        self.dual_stamp = 0
+        self.dual_trial_stamp = np.zeros(R, dtype=np.int64)  # dual_stamp of the variational E-step that last wrote each trial's dual variables
         self.rank, self.size = 0, 1
         self.comm_ready = False
         if WORLD.enabled:
@@ -293,6 +335,11 @@ class Session:
 
     def set_params(self, params):
         self.ctx.set_params(params['C'], params['d'], params['tau'])
+
+    def mark_dual_written(self, trial_idx):
+        """A variational E-step has just overwritten the resident dual variables of these trials."""
+        self.dual_stamp += 1
+        self.dual_trial_stamp[np.asarray(trial_idx, dtype=np.int64)] = self.dual_stamp
 
     def mark_written(self, trial_idx):
         """An E-step (or an uploaded posterior) has just overwritten the device state of these trials."""

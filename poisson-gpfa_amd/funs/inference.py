@@ -12,7 +12,7 @@ K_bigInv, xdim, ydim) but are also offered in the structured form the device eva
 import numpy as np
 
 from . import _hip
-from ._session import DeviceInfRes, DeviceOptimRes, session_for
+from ._session import DeviceDualOptimRes, DeviceInfRes, DeviceOptimRes, session_for
 
 # covariance engine of every context this module creates: None = the library's choice (low-rank when it pays), 1 = dense, 2 = low-rank
 # (tests pin one or the other; results agree to the low-rank tolerance)
@@ -492,18 +492,30 @@ def dualVariational(experiment, params, optimizeLogLambda=False, prevOptimRes=No
             # Cold start: the reference's lambda = 0.5 (inference.py:302) - rho = 0 of the log-lambda variant is lambda = 1: both are starts of
             # one strictly convex problem and the fixed point lands on its optimum from either.  exp / log of the q T entries run on the
             # device and the optimum stays there for the finalize call.
-            res = ctx.dual_fixed_point(mine, None if prevOptimRes is None else prev_rho(), max_outer=DUAL_FP_MAX_PASSES, tol=DUAL_FP_TOL,
-                                       warm=prevOptimRes is not None, want_lam=not optimizeLogLambda)
-            rho, fopt, iters, vstat = res[:4]
-            lam_fp = res[4] if len(res) > 4 else None
+            # The optimum also stays on the device as the returned varOptimRes (a lazy list: an entry is downloaded when it is read), and handed
+            # back as prevOptimRes of the next call it is a warm start that moves no bytes.
+            resident = (isinstance(prevOptimRes, DeviceDualOptimRes) and prevOptimRes.session is sess and prevOptimRes.stamp == sess.mode_stamp
+                        and np.array_equal(prevOptimRes.trial_idx, mine))
+            res = ctx.dual_fixed_point(mine, None if (prevOptimRes is None or resident) else prev_rho(), max_outer=DUAL_FP_MAX_PASSES, tol=DUAL_FP_TOL,
+                                       warm=prevOptimRes is not None, resident=resident, want_rho=False)
+            fopt, iters, vstat = res[1:4]
             bad = np.nonzero(vstat != 0)[0]
             if len(bad):
-                rho_b, fopt_b, it_b = ctx.dual_lbfgs(mine[bad], rho[bad])
-                rho[bad], fopt[bad] = rho_b, fopt_b
+                # (rare: bring the whole optimum to the host, finish the handed-back trials there, finalize from the host copy)
+                lam_all = ctx.dual_lambda(mine)
+                rho_b, fopt_b, it_b = ctx.dual_lbfgs(mine[bad], np.log(lam_all[bad]))
+                lam_all[bad], fopt[bad] = np.exp(rho_b), fopt_b
                 iters[bad] += it_b
-                lam_all = np.exp(rho)
-            optim = list(rho) if optimizeLogLambda else list(lam_fp if lam_all is None else lam_all)
             nlp = ctx.dual_finalize(mine, lam_all)           # (None: the optimum the fixed point left on the device)
+            sess.mark_written(mine)
+            sess.mark_dual_written(mine)
+            optim = DeviceDualOptimRes(sess, mine, optimizeLogLambda)
+            tot = sess.allreduce(np.array([nlp, float(np.sum(fopt)), float(len(mine))]))
+            infRes = DeviceInfRes(sess, mine, (lo, hi))
+            infRes.dual_iterations = iters
+            if returnOptimRes:
+                return infRes, -tot[0] / tot[2], tot[1] / tot[2], optim
+            return infRes, -tot[0] / tot[2], tot[1] / tot[2]
         else:
             if prevOptimRes is None:
                 rho0 = np.zeros((len(mine), m)) if optimizeLogLambda else np.full((len(mine), m), np.log(0.5))
@@ -514,6 +526,7 @@ def dualVariational(experiment, params, optimizeLogLambda=False, prevOptimRes=No
             optim = list(rho) if optimizeLogLambda else list(lam_all)
             nlp = ctx.dual_finalize(mine, lam_all)
         sess.mark_written(mine)
+        sess.mark_dual_written(mine)
         tot = sess.allreduce(np.array([nlp, float(np.sum(fopt)), float(len(mine))]))
         infRes = DeviceInfRes(sess, mine, (lo, hi))
         infRes.dual_iterations = iters
@@ -562,6 +575,7 @@ def dualVariational(experiment, params, optimizeLogLambda=False, prevOptimRes=No
     vlb = float(sum(out[1] for out in outs))
     nlp = ctx.dual_finalize(mine, np.stack(lams)) if len(mine) else 0.0
     sess.mark_written(mine)
+    sess.mark_dual_written(mine)
     tot = sess.allreduce(np.array([nlp, vlb, float(len(mine))]))
     infRes = DeviceInfRes(sess, mine, (lo, hi))
     if returnOptimRes:

@@ -318,66 +318,77 @@ def test_header_documents_every_option_and_info_key():
 
 
 def test_dual_variational_hands_unsettled_trials_to_lbfgs(monkeypatch):
-    """Host logic of inference.dualVariational under DUAL_SOLVER = 'fixedpoint' (the default), against a test double of the context: trials the
-    fixed point reports as not settled (status 1: pass cap, 2: not contracting) go to the device L-BFGS FROM THE RHO THE FIXED POINT RETURNED,
-    exactly those and no others; their optimum and bound replace the fixed point's, iteration counts add; the cold start is log 0.5 (the
-    reference's lambda = 0.5, inference.py:302) and `warm` is only set with prevOptimRes; the finalize call sees exp(rho) of the merged set."""
+    """Host logic of inference.dualVariational under DUAL_SOLVER = 'fixedpoint' (the default), against a test double of the context: the cold start
+    is set on the device (no rho goes up), nothing comes down (want_rho / want_lam off), the finalize call takes the resident optimum (lam = None)
+    and the returned varOptimRes is a lazy list that reads a trial's lambda (or its log) from the device when asked; handed back as prevOptimRes
+    of the next call on the same trials it is a resident warm start.  Trials the fixed point reports as not settled (status 1: pass cap, 2: not
+    contracting) go to the device L-BFGS from the lambda the fixed point left, exactly those and no others; their optimum and bound replace
+    the fixed point's, iteration counts add, and the finalize call then gets the merged lambda from the host."""
     from funs import _hip, _session, inference
     from conftest import Experiment
     calls = {}
+    q, p, T, R = 4, 2, 6, 5
+    state = {'status': np.zeros(R, np.int32), 'lam': 1.0 + np.arange(R)[:, None] + np.zeros((R, q * T))}
 
     class Ctx:
-        def __init__(self, q, p, T, R, bin_ms, device=0):
-            self.q, self.p, self.T, self.R = q, p, T, R
+        def __init__(self, q_, p_, T_, R_, bin_ms, device=0):
+            self.q, self.p, self.T, self.R = q_, p_, T_, R_
         def close(self): pass
         def set_option(self, k, v): calls.setdefault('options', {})[k] = v
         def info(self, k): return 0.0
         def upload_counts(self, Y): pass
         def set_params(self, C, d, tau): pass
-        def dual_fixed_point(self, idx, rho0=None, max_outer=40, tol=1e-8, warm=False, want_lam=False):
-            calls['fp'] = (np.array(idx), None if rho0 is None else np.array(rho0), max_outer, tol, warm, want_lam)
-            start = np.full((len(idx), self.q * self.T), np.log(0.5)) if rho0 is None else np.array(rho0)
-            rho = start + 1.0 + np.arange(len(idx))[:, None]
-            out = (rho, -np.arange(len(idx), dtype=float), np.full(len(idx), 5, np.int32), np.array([0, 2, 0, 1, 0], np.int32)[:len(idx)])
-            return out + (np.exp(rho),) if want_lam else out
+        def dual_fixed_point(self, idx, rho0=None, max_outer=40, tol=1e-8, warm=False, want_lam=False, want_rho=True, resident=False):
+            calls['fp'] = dict(idx=np.array(idx), rho0=None if rho0 is None else np.array(rho0), max_outer=max_outer, tol=tol, warm=warm,
+                               want_lam=want_lam, want_rho=want_rho, resident=resident)
+            return (None, -np.arange(len(idx), dtype=float), np.full(len(idx), 5, np.int32), state['status'][:len(idx)].copy())
+        def dual_lambda(self, idx=None):
+            calls.setdefault('lambda_reads', []).append(np.array(idx))
+            return state['lam'][np.asarray(idx)].copy()
         def dual_lbfgs(self, idx, rho0, max_iter=15000, factr=1e7, pgtol=1e-5):
             calls['lbfgs'] = (np.array(idx), np.array(rho0))
-            return np.array(rho0) * 2.0, np.full(len(idx), -100.0), np.full(len(idx), 70, np.int32)
+            return np.array(rho0) + np.log(2.0), np.full(len(idx), -100.0), np.full(len(idx), 70, np.int32)
         def dual_finalize(self, idx, lam):
             calls['finalize'] = (np.array(idx), None if lam is None else np.array(lam))
+            if lam is not None:
+                state['lam'][np.asarray(idx)] = lam
             return 3.0 * len(idx)
 
     monkeypatch.setattr(_hip, 'Context', Ctx)
     monkeypatch.setattr(_session.WORLD, 'enabled', False)
     _session.drop_sessions()
-    q, p, T, R = 4, 2, 6, 5
     exp = Experiment([np.zeros((q, T)) for _ in range(R)], 10.0)
     params = {'C': np.zeros((q, p)), 'd': np.zeros(q), 'tau': np.ones(p) * 0.1}
     assert inference.DUAL_SOLVER == 'fixedpoint'
     try:
+        # everybody settles: nothing crosses the bus
         infRes, nll, vlb, opt = inference.dualVariational(exp, params)
-        idx, rho0, max_outer, tol, warm, want_lam = calls['fp']
-        assert np.array_equal(idx, np.arange(R)) and rho0 is None and not warm and want_lam       # cold: the reference's lambda = 0.5, set on the device
-        assert max_outer == inference.DUAL_FP_MAX_PASSES and tol == inference.DUAL_FP_TOL
+        fp = calls['fp']
+        assert np.array_equal(fp['idx'], np.arange(R)) and fp['rho0'] is None and not fp['warm'] and not fp['resident']
+        assert not fp['want_rho'] and not fp['want_lam'] and fp['max_outer'] == inference.DUAL_FP_MAX_PASSES and fp['tol'] == inference.DUAL_FP_TOL
+        assert calls['finalize'][1] is None and 'lbfgs' not in calls and 'lambda_reads' not in calls
+        assert isinstance(opt, _session.DeviceDualOptimRes) and len(opt) == R
+        assert np.array_equal(opt[3], state['lam'][3]) and [list(a) for a in calls['lambda_reads']] == [[3]]       # one trial read, one download
+        assert np.array_equal(infRes.dual_iterations, [5] * R) and abs(vlb + 2.0) < 1e-12 and abs(nll + 3.0) < 1e-12
+        # handed back on the same trials: a resident warm start
+        infRes, nll, vlb, opt2 = inference.dualVariational(exp, params, prevOptimRes=opt)
+        assert calls['fp']['resident'] and calls['fp']['warm'] and calls['fp']['rho0'] is None
+        # a plain list of arrays (what the reference passes around): uploaded as log lambda, flagged warm
+        infRes, nll, vlb, opt3 = inference.dualVariational(exp, params, prevOptimRes=[state['lam'][r] for r in range(R)])
+        assert not calls['fp']['resident'] and calls['fp']['warm'] and np.allclose(calls['fp']['rho0'], np.log(state['lam']))
+        # the log-lambda variant returns rho
+        infRes, nll, vlb, opt4 = inference.dualVariational(exp, params, optimizeLogLambda=True)
+        assert np.allclose(opt4[1], np.log(state['lam'][1]))
+        # two trials handed back
+        state['status'] = np.array([0, 2, 0, 1, 0], np.int32)
+        before = state['lam'].copy()
+        infRes, nll, vlb, opt5 = inference.dualVariational(exp, params)
         bad_idx, bad_rho = calls['lbfgs']
-        assert np.array_equal(bad_idx, [1, 3])
-        fp_rho = np.log(0.5) + 1.0 + np.arange(R)[:, None] + np.zeros((R, q * T))
-        assert np.allclose(bad_rho, fp_rho[[1, 3]])
-        merged = fp_rho.copy()
+        assert np.array_equal(bad_idx, [1, 3]) and np.allclose(bad_rho, np.log(before[[1, 3]]))
+        merged = before.copy()
         merged[[1, 3]] *= 2.0
-        assert np.allclose(calls['finalize'][1], np.exp(merged))
-        assert np.allclose(np.stack(opt), np.exp(merged))                 # optimizeLogLambda = False returns lambda (inference.py:326)
+        assert np.allclose(calls['finalize'][1], merged) and np.allclose(opt5[1], merged[1]) and np.allclose(opt5[0], merged[0])
         assert np.array_equal(infRes.dual_iterations, [5, 75, 5, 75, 5])
-        assert abs(vlb - np.mean([0.0, -100.0, -2.0, -100.0, -4.0])) < 1e-12 and abs(nll + 3.0) < 1e-12
-        # warm start: rho = log of the previous lambda, flagged as such; the log-lambda variant returns rho itself
-        infRes, nll, vlb, opt2 = inference.dualVariational(exp, params, optimizeLogLambda=True, prevOptimRes=[np.log(o) for o in opt])
-        assert calls['fp'][4] is True and np.allclose(calls['fp'][1], merged) and calls['fp'][5] is False
-        assert np.allclose(np.stack(opt2)[0], merged[0] + 1.0)
-        # nobody handed back: the finalize call takes the optimum the fixed point left on the device (lam = None)
-        Ctx.dual_fixed_point = lambda self, idx, rho0=None, max_outer=40, tol=1e-8, warm=False, want_lam=False: (
-            np.zeros((len(idx), q * T)), np.zeros(len(idx)), np.full(len(idx), 4, np.int32), np.zeros(len(idx), np.int32), np.ones((len(idx), q * T)))[:5 if want_lam else 4]
-        calls.pop('lbfgs')
-        infRes, nll, vlb, opt3 = inference.dualVariational(exp, params)
-        assert calls['finalize'][1] is None and 'lbfgs' not in calls and np.allclose(np.stack(opt3), 1.0)
+        assert abs(vlb - np.mean([0.0, -100.0, -2.0, -100.0, -4.0])) < 1e-12
     finally:
         _session.drop_sessions()

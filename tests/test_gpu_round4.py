@@ -170,6 +170,7 @@ def test_dual_variational_through_the_fixed_point_vs_reference(funs_mod):
     assert inf.DUAL_SOLVER == 'fixedpoint'
     infRes, nll, vlb, opt = inf.dualVariational(exp, params)
     infRes.materialize()
+    lam3_view = opt[3].copy()                              # (read now: this entry stays valid)
     assert np.all(infRes.dual_iterations >= 2) and np.all(infRes.dual_iterations <= 12)
     assert abs(vlb - float(g['estep_vlb'])) <= 1e-3 and abs(nll - float(g['estep_nll'])) <= 1e-3
     K_big, Kinv_big, C_big, d_big = _dense(params, Ys[0].shape[1], float(g['binSize']))
@@ -189,9 +190,22 @@ def test_dual_variational_through_the_fixed_point_vs_reference(funs_mod):
         inf.DUAL_SOLVER = 'fixedpoint'
     assert vlb <= vlb_l + 1e-9 and abs(vlb - vlb_l) <= 1e-3
     assert np.all(ir_b.dual_iterations > 1) and abs(vlb_b - vlb) <= 1e-3
-    # warm start from the optimum (prevOptimRes, engine.py:200): one pass, same numbers
-    ir_w, nll_w, vlb_w, opt_w = inf.dualVariational(exp, params, prevOptimRes=opt)
+    # the returned varOptimRes is a view of device state: entries read before the later runs above stay what they were, the others now
+    # belong to a superseded E-step and say so
+    assert np.array_equal(opt[3], lam3_view)
+    with pytest.raises(funs_mod._hip.HipBackendError):
+        opt[7]
+    infRes, nll, vlb, opt = inf.dualVariational(exp, params)
+    opt.materialize()
+    # warm start from the optimum (prevOptimRes, engine.py:200): one pass, same numbers - from a host list of arrays (what the reference passes) ...
+    host_opt = [np.array(o) for o in opt]
+    ir_w, nll_w, vlb_w, opt_w = inf.dualVariational(exp, params, prevOptimRes=host_opt)
     assert np.all(ir_w.dual_iterations == 1) and abs(vlb_w - vlb) <= 1e-9 * abs(vlb) and abs(nll_w - nll) <= 1e-8 * abs(nll)
+    # ... and from the lazy device-resident list the call itself returned (no bytes move)
+    assert isinstance(opt_w, funs_mod._session.DeviceDualOptimRes)
+    ir_r, nll_r, vlb_r, opt_r = inf.dualVariational(exp, params, prevOptimRes=opt_w)
+    assert np.all(ir_r.dual_iterations == 1) and abs(vlb_r - vlb) <= 1e-9 * abs(vlb)
+    assert np.max(np.abs(opt_r[2] - host_opt[2])) <= 1e-7 * np.max(host_opt[2])
     funs_mod._session.drop_sessions()
 
 

@@ -26,10 +26,11 @@ ctx.set_option('dual_f32', 1 if f32 else 0)
 m = q * T
 rho0 = np.full((R, m), np.log(0.5))
 t0 = time.time()
-rho, fopt, outer, status = ctx.dual_fixed_point(idx, None)
+_, fopt, outer, status = ctx.dual_fixed_point(idx, None, want_rho=False)
 t_fp = time.time() - t0
 t0 = time.time()
-rho, fopt, outer, status = ctx.dual_fixed_point(idx, None)
+_, fopt, outer, status = ctx.dual_fixed_point(idx, None, want_rho=False)
+rho = np.log(ctx.dual_lambda(idx))
 t_fp2 = time.time() - t0
 print('fixed point (%s, %d trials, plan_lowrank %d, rank %d): %.2f s (first call %.2f s)  passes %d..%d  status %s  mean dual cost %.8f' % (
     cfg, R, ctx.info('plan_lowrank'), int(ctx.info('lowrank_rtot')), t_fp2, t_fp, outer.min(), outer.max(), np.bincount(status, minlength=3), fopt.mean()))
