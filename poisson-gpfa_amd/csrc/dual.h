@@ -59,17 +59,60 @@ __global__ __launch_bounds__(256) void dual_pre_kernel(const uint8_t* __restrict
   }
 }
 
-// W[slot][t][a][b] = W[slot][t][b][a] = Wp[slot][pair(a,b)][t].  grid = (ceil(T*NP/256), nslots)
-__global__ void dual_unpack_w_kernel(const double* __restrict__ Wp, long long sWp, double* __restrict__ W, long long sW, int T, int p) {
+// Rates pass of the GEMM form of the Poisson pass (latent widths beyond the matrix-core kernel's 16): for the listed slots
+//   h = C x + d [+ off],  lam = exp(h),  lmy = lam - y,  partial objective sum_n,t lam - y h per (slot, 64-bin tile)
+// - the q x p x T product as a vector kernel (2 % of the flops of the pass: W_t = C^T diag(lam_t) C and C^T (lam - y) follow as the GEMMs of the dual
+// evaluation against the pair / loading table).  grid = (ceil(T/64), nslots), block = 256 (lanes = bins, the 4 waves take interleaved neurons).
+__global__ __launch_bounds__(256) void rates_wide_kernel(const uint8_t* __restrict__ Y, const uint8_t* __restrict__ Yhi, const double* __restrict__ C,
+                                                         const double* __restrict__ d, const double* __restrict__ X, long long sX,
+                                                         const double* __restrict__ off, double* __restrict__ lam, double* __restrict__ lmy,
+                                                         double* __restrict__ fpart, const int* __restrict__ slots,
+                                                         const int* __restrict__ trial_of_slot, int q, int p, int T) {
+  extern __shared__ double rw_x[];                 // [p][64]
+  __shared__ double red[4];
+  const size_t slot = slots[blockIdx.y];
+  const size_t trial = trial_of_slot[slot];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t0 = blockIdx.x * 64, t = t0 + lane;
+  const bool valid = t < T;
+  for (int e = threadIdx.x; e < p * 64; e += 256) {
+    const int l = e >> 6, tt = t0 + (e & 63);
+    rw_x[e] = tt < T ? X[slot * sX + (size_t)l * T + tt] : 0.0;
+  }
+  __syncthreads();
+  double facc = 0.0;
+  if (valid) {
+    for (int n = wave; n < q; n += 4) {
+      const size_t e = slot * (size_t)q * T + (size_t)n * T + t;
+      double h = d[n] + (off ? off[e] : 0.0);
+      const double* Cn = C + (size_t)n * p;
+      for (int l = 0; l < p; ++l) h += Cn[l] * rw_x[l * 64 + lane];
+      const double ev = exp(h);
+      const double y = (double)count_at(Y, Yhi, (trial * q + n) * T + t);
+      lam[e] = ev;
+      lmy[e] = ev - y;
+      facc += ev - y * h;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) facc += __shfl_down(facc, o);
+  if (lane == 0) red[wave] = facc;
+  __syncthreads();
+  if (threadIdx.x == 0) fpart[slot * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// W[slot][t][a][b] = W[slot][t][b][a] = Wp[slot][pair(a,b)][t].  grid = (ceil(T*NP/256), nslots); slots (may be NULL): list of the slots
+__global__ void dual_unpack_w_kernel(const double* __restrict__ Wp, long long sWp, double* __restrict__ W, long long sW, int T, int p,
+                                     const int* __restrict__ slots = nullptr) {
   const int np = p * (p + 1) / 2;
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (size_t)T * np) return;
+  const size_t slot = slots ? (size_t)slots[blockIdx.y] : (size_t)blockIdx.y;
   const int c = (int)(e / T), t = (int)(e - (size_t)c * T);
   int a = 0;
   while ((a + 1) * (a + 2) / 2 <= c) ++a;
   const int b = c - a * (a + 1) / 2;
-  const double v = Wp[(size_t)blockIdx.y * sWp + e];
-  double* w = W + (size_t)blockIdx.y * sW + (size_t)t * p * p;
+  const double v = Wp[slot * sWp + e];
+  double* w = W + slot * sW + (size_t)t * p * p;
   w[a * p + b] = v;
   w[b * p + a] = v;
 }

@@ -1053,6 +1053,32 @@ int poisson(pgpfa_ctx* c, const int* d_list, int nl, const double* X, double* G,
   const int KY = poisson_rows(c->p);
   dim3 grid(a.ntile, nl), block(64, KY);
   const double fl = (double)nl * c->q * c->T * (4.0 * c->p + (full ? c->p * (c->p + 1.0) : 0.0));
+  // Latent widths beyond the matrix-core kernel: the neuron contractions as the GEMMs of the dual evaluation (dual.h) once the dual scratch exists
+  // (the variational fixed point allocates it: config 5, 20 latents - the vector kernel below took a third of its time)
+  const bool gemm_form = !(c->CCu && c->mfma) && c->mfma && c->dual_gemm && c->dual_tbl && c->lamd && c->dual_scr && !c->mask_active && !c->lam_out_active;
+  if (gemm_form) {
+    prof_begin(c, TAG_POISSON, fl);
+    hipLaunchKernelGGL(rates_wide_kernel, grid, dim3(256), (size_t)c->p * 64 * sizeof(double), c->st, c->Y, c->Yhi, c->C, c->d, X, (long long)c->ld,
+                       a.off, c->lamd, c->dgrad, c->fpart, d_list, c->trial_of_slot, c->q, c->p, c->T);
+    prof_end(c);
+    if (full) {
+      const int np = c->p * (c->p + 1) / 2;
+      GemmP w{};                                               // Wp (T x pairs) = Lambda^T . TBL[:, pairs]
+      w.A = c->lamd; w.sA = (long long)c->q * c->T; w.lda = c->T;
+      w.B = c->dual_tbl; w.sB = 0; w.ldb = c->dual_ncol;
+      w.C = c->dual_scr; w.sC = c->dual_sscr; w.ldc = c->T;
+      w.M = c->T; w.N = np; w.K = c->qpad; w.alpha = 1.0; w.beta = 0.0; w.slots = d_list; w.nbatch = nl; w.mode = GEMM_FULL; w.kflags = 0;
+      CHK(gemm(c, false, w));
+      GemmP v = w;                                             // G (T x p, i.e. [p][T]) = (Lambda - Y)^T . TBL[:, latents]
+      v.A = c->dgrad; v.B = c->dual_tbl + c->dual_npd; v.C = G; v.sC = c->ld; v.N = c->p;
+      CHK(gemm(c, false, v));
+      hipLaunchKernelGGL(dual_unpack_w_kernel, dim3((unsigned)(((size_t)c->T * np + 255) / 256), nl), dim3(256), 0, c->st, c->dual_scr, c->dual_sscr, W,
+                         (long long)c->T * c->p * c->p, c->T, c->p, d_list);
+    }
+    hipLaunchKernelGGL(sum_tiles_kernel, dim3((nl + 255) / 256), dim3(256), 0, c->st, c->fpart, a.ntile, d_list, nl, flik);
+    HIPC(hipGetLastError());
+    return 0;
+  }
   prof_begin(c, TAG_POISSON, fl);
   if (c->CCu && c->mfma) {
     dispatch_pw(c->p, [&](auto pm) {
