@@ -28,6 +28,7 @@
 #include "dual.h"
 #include "sample.h"
 #include "split.h"
+#include "thin.h"
 
 using namespace pgpfa;
 
@@ -189,6 +190,9 @@ struct pgpfa_ctx {
   int *d_kr_ft = nullptr, *d_kr_f = nullptr;     // per-row-tile k ranges of the block-diagonal F^T / F GEMMs
   int kr_ft_len = 0, kr_f_len = 0;               // longest of those ranges
   int ntab_ft = 0, ntab_f = 0; size_t tab_cap = 0;   // entries of the two row-tile tables, capacity (ints) of their device buffers
+  int *d_thin_ft = nullptr, *d_thin_f = nullptr;  // work tables of the same two products as kernels of their own (thin.h)
+  int nthin_ft = 0, nthin_f = 0;
+  int thin_products = 1;                         // 1: F^T t and F v of the preconditioner application by thin.h's kernels; 0: block-sparse GEMMs
   double *Fbig = nullptr, *FTbig = nullptr, *Gbar = nullptr, *Wtbar = nullptr;   // low-rank shared preconditioner
   std::vector<int> rk, roff;                      // ranks padded to 16, offsets
   int rtot = 0, rpad = 0;
@@ -1197,6 +1201,18 @@ int build_lowrank(pgpfa_ctx* c) {
     if (tft.size() > c->tab_cap || tf.size() > c->tab_cap) return fail("internal: row-tile table overflow");
     CHK(upload_list(c, c->d_kr_ft, tft));
     CHK(upload_list(c, c->d_kr_f, tf));
+    // thin.h: F^T t by (latent, 64 rank rows), F v by (latent, 512 bins)
+    std::vector<int> hft, hf;
+    for (int k = 0; k < p; ++k) {
+      // (row groups of a latent of equal size, a multiple of 4 up to 64: 80 rank rows are 40 + 40, not 64 + 16)
+      const int ngr = (c->rk[k] + 63) / 64, per = round_up((c->rk[k] + ngr - 1) / ngr, 4);
+      for (int m0 = 0; m0 < c->rk[k]; m0 += per) { hft.push_back(k); hft.push_back(m0); hft.push_back(std::min(per, c->rk[k] - m0)); hft.push_back(c->roff[k]); }
+      for (int t0 = 0; t0 < T; t0 += 256) { hf.push_back(k); hf.push_back(t0); hf.push_back(c->rk[k]); hf.push_back(c->roff[k]); }
+    }
+    c->nthin_ft = (int)hft.size() / 4; c->nthin_f = (int)hf.size() / 4;
+    if (hft.size() > c->tab_cap || hf.size() > c->tab_cap) return fail("internal: thin-product table overflow");
+    CHK(upload_list(c, c->d_thin_ft, hft));
+    CHK(upload_list(c, c->d_thin_f, hf));
   }
   if ((size_t)c->rpad <= (size_t)c->ld) {
     HIPC(hipMemsetAsync(c->Fbig, 0, (size_t)c->ld * c->rpad * sizeof(double), c->st));
@@ -1327,6 +1343,7 @@ int pgpfa_create(pgpfa_ctx** out, int device, int q, int p, int T, int R, double
   rc |= dmalloc(c, &c->d_rank, p); rc |= dmalloc(c, &c->d_roff, p + 1);
   c->tab_cap = 4 * ((size_t)c->ld / 64 + 2 * (size_t)p + 4);
   rc |= dmalloc(c, &c->d_kr_ft, c->tab_cap); rc |= dmalloc(c, &c->d_kr_f, c->tab_cap);
+  rc |= dmalloc(c, &c->d_thin_ft, c->tab_cap); rc |= dmalloc(c, &c->d_thin_f, c->tab_cap);
   rc |= dmalloc(c, &c->Fbig, (size_t)c->ld * c->ld + 256 * (size_t)c->ld, true); rc |= dmalloc(c, &c->FTbig, (size_t)c->ld * c->ld + 256 * (size_t)c->ld, true);
   rc |= dmalloc(c, &c->Gbar, (size_t)T * p * p + 64); rc |= dmalloc(c, &c->Wtbar, (size_t)T * p * p + 64); rc |= dmalloc(c, &c->d_blk_lat, (size_t)p * c->Tp / 16 + 64); rc |= dmalloc(c, &c->d_blk_col, (size_t)p * c->Tp / 16 + 64);
   rc |= dmalloc(c, &c->vec, (size_t)q * (p + 1));
@@ -1403,6 +1420,7 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
   else if (k == "pcg_w32") c->pcg_w32 = (v != 0.0);
   else if (k == "pcg_form") c->pcg_form = (int)v;
   else if (k == "mix_slot") c->mix_slot = (int)v;
+  else if (k == "thin_products") c->thin_products = (int)v;
   else if (k == "copy_kernels") c->copy_kernels = (v != 0.0);
   else if (k == "chord") c->chord = (v != 0.0);
   else if (k == "shared_pcg") c->shared_pcg = (v != 0.0);
@@ -1808,12 +1826,33 @@ static int shared_solve(pgpfa_ctx* c, int nb, const double* R, double* Z, const 
       });
     };
     if (first_apply) apply_bin(R, nullptr, 1.0, c->Xt);
+    // the two block-diagonal products as kernels of their own (thin.h) where the matrix cores are in use; the general product otherwise
+    const bool thin = c->thin_products && c->mfma && c->T >= 4 && (size_t)c->rpad <= (size_t)c->ld;
+    ThinP tp{};
+    tp.F = c->Flr; tp.Tf = c->Tp; tp.T = c->T; tp.FT = c->FTbig; tp.ldft = c->rpad;
+    tp.cols = cols; tp.n_dev = (cols && c->cur_ndev) ? c->cur_ndev : nullptr; tp.ncols = ng; tp.skip = skip;
+    auto thin_prof = [&](const char* what) {
+      prof_begin(c, TAG_SOLVE, tp.n_dev ? 0.0 : 2.0 * c->T * c->rtot * ng);
+      if (c->prof.on && c->prof.open) {
+        char key[96];
+        std::snprintf(key, sizeof key, "f64 thin %s T=%d r=%d N=%s%d", what, c->T, c->rtot, tp.n_dev ? "<=" : "", ng);
+        c->prof.recs.back().shape = key;
+      }
+    };
     GemmP y{};
     y.skip = skip;                                               // Y = F^T (Gb R)          (rpad x nb)
     y.A = c->FTbig; y.sA = 0; y.lda = rpad; y.B = c->Xt; y.sB = 0; y.ldb = c->ld; y.C = c->Glt; y.sC = 0; y.ldc = c->ld;
     y.M = rpad; y.N = ng; y.K = c->npad; y.cols = cols; y.alpha = 1.0; y.beta = 0.0; y.slots = nullptr; y.nbatch = 1; y.mode = GEMM_FULL; y.kflags = 0;
     y.rtab = c->d_kr_ft; y.ntab = c->ntab_ft; y.k_loop_hint = c->kr_ft_len; y.flops_hint = 2.0 * c->T * c->rtot * ng;      // block-diagonal operand: only T x r_k blocks are non-zero
-    CHK(gemm(c, true, y));
+    if (thin) {
+      tp.tab = c->d_thin_ft; tp.X = c->Xt; tp.ldx = c->ld; tp.Y = c->Glt; tp.ldy = c->ld;
+      thin_prof("F^T t");
+      if (c->T % 4 == 0) hipLaunchKernelGGL(thin_ft_kernel<true>, dim3(c->nthin_ft, (ng + 15) / 16), dim3(512), 0, c->st, tp);
+      else hipLaunchKernelGGL(thin_ft_kernel<false>, dim3(c->nthin_ft, (ng + 15) / 16), dim3(512), 0, c->st, tp);
+      prof_end(c);
+    } else {
+      CHK(gemm(c, true, y));
+    }
     GemmP z{};                                               // Zs = Sb Y
     z.skip = skip;
     z.A = c->sU; z.sA = 0; z.lda = rpad; z.B = c->Glt; z.sB = 0; z.ldb = c->ld; z.C = c->KD; z.sC = 0; z.ldc = c->ld;
@@ -1826,7 +1865,15 @@ static int shared_solve(pgpfa_ctx* c, int nb, const double* R, double* Z, const 
     q.A = c->Fbig; q.sA = 0; q.lda = c->ld; q.B = c->KD; q.sB = 0; q.ldb = c->ld; q.C = c->Xt; q.sC = 0; q.ldc = c->ld;
     q.M = c->n; q.N = ng; q.K = rpad; q.cols = cols; q.alpha = 1.0; q.beta = 0.0; q.slots = nullptr; q.nbatch = 1; q.mode = GEMM_FULL; q.kflags = 0;
     q.rtab = c->d_kr_f; q.ntab = c->ntab_f; q.k_loop_hint = c->kr_f_len; q.flops_hint = 2.0 * c->T * c->rtot * ng;
-    CHK(gemm(c, true, q));
+    if (thin) {
+      tp.tab = c->d_thin_f; tp.X = c->KD; tp.ldx = c->ld; tp.Y = c->Xt; tp.ldy = c->ld;
+      thin_prof("F v");
+      if (c->T % 4 == 0) hipLaunchKernelGGL(thin_f_kernel<true>, dim3(c->nthin_f, (ng + 15) / 16), dim3(256), 0, c->st, tp);
+      else hipLaunchKernelGGL(thin_f_kernel<false>, dim3(c->nthin_f, (ng + 15) / 16), dim3(256), 0, c->st, tp);
+      prof_end(c);
+    } else {
+      CHK(gemm(c, true, q));
+    }
     if (final_apply) apply_bin(R, c->Xt, c->eps, Z);
     HIPC(hipGetLastError());
     return 0;
