@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256) void pcg_update_p2_kernel(const double* __rest
 // chain of dependent loads and two barriers), 512 bins at most, and with the loads hoisted it needs more than 256 registers.
 struct PcgCgP {
   const double* GbT; const float* WbT;        // [NP][T] packed lower triangles (component-major; Wb in single precision)
-  const float* W32T; long long sW32;          // [slot][NP][T]
+  const float* W32T; long long sW32; int Tw;  // [slot][NP][Tw], Tw = T rounded up to 32 floats (rows start on 128-byte lines)
   double *X, *R, *P, *Q, *Z, *S, *Y; long long sV;
   double* part;                                // [slot][ntile][3]
   double *gam, *alp;                           // [2][B]: gamma, alpha of the previous step at [par], of this step at [par ^ 1]
@@ -445,6 +445,24 @@ __device__ __forceinline__ void pcg_sym_mv(const TM* __restrict__ M, size_t cs, 
   }
 }
 
+// out = M v with the packed lower triangle of M already in registers (entries of components past p are whatever the clamped loads brought:
+// they meet zeros of v, and out is zeroed past p)
+template <int PW>
+__device__ __forceinline__ void pcg_sym_mv_reg(const float (&m)[PW * (PW + 1) / 2], int p, const double (&v)[PW], double (&out)[PW]) {
+#pragma unroll
+  for (int k = 0; k < PW; ++k) out[k] = 0.0;
+#pragma unroll
+  for (int hi = 0; hi < PW; ++hi)
+#pragma unroll
+    for (int lo = 0; lo <= hi; ++lo) {
+      const double gg = (double)m[hi * (hi + 1) / 2 + lo];
+      out[hi] += gg * v[lo];
+      if (lo != hi) out[lo] += gg * v[hi];
+    }
+#pragma unroll
+  for (int k = 0; k < PW; ++k) out[k] = (k < p) ? out[k] : 0.0;
+}
+
 // LDS tile [64 bins][LD] of a component-major packed matrix; components past np and bins past nt are zero
 template <int NPW, typename TM, typename TL>
 __device__ __forceinline__ void pcg_stage_sym(const TM* __restrict__ MT, int T, int t0, int nt, int np, TL* __restrict__ dst, int LD) {
@@ -487,12 +505,27 @@ __global__ __launch_bounds__(256, 2) void pcg_cg_a_kernel(PcgCgP a) {
     const size_t slot = (size_t)live[si];
     const size_t base = slot * a.sV + t;
     double r[PW], v[PW], z[PW], w[PW];
+    float w32[NP];
+    // every global load of the slot in ONE round - r, y and the packed single-precision curvature, 2 PW + NP loads in flight - before any
+    // arithmetic: with the curvature read inside its product (two row groups behind the two LDS products) a slot was three memory round
+    // trips in a row, and a wave walks four slots
 #pragma unroll
     for (int k = 0; k < PW; ++k) {
       const size_t o = base + (size_t)(k < p ? k : 0) * T;
       r[k] = a.R[o];
       v[k] = a.Y[o];
     }
+    {
+      const float* wp = a.W32T + slot * a.sW32 + t;
+#pragma unroll
+      for (int hi = 0; hi < PW; ++hi)
+#pragma unroll
+        for (int lo = 0; lo <= hi; ++lo) {
+          const int c = hi * (hi + 1) / 2 + lo;
+          w32[c] = wp[(size_t)(hi < p ? c : 0) * a.Tw];
+        }
+    }
+    asm volatile("" ::: "memory");
 #pragma unroll
     for (int k = 0; k < PW; ++k) {
       const bool ok = in && k < p;
@@ -501,7 +534,7 @@ __global__ __launch_bounds__(256, 2) void pcg_cg_a_kernel(PcgCgP a) {
     }
     pcg_sym_mv<PW, false>(g, 1, p, v, z);
     pcg_sym_mv<PW, false>(wb, 1, p, z, w);
-    pcg_sym_mv<PW, true>(a.W32T + slot * a.sW32 + t, (size_t)T, p, z, v);          // v <- fl32(W) z
+    pcg_sym_mv_reg<PW>(w32, p, z, v);                                                // v <- fl32(W) z
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
 #pragma unroll
     for (int k = 0; k < PW; ++k) {
@@ -648,8 +681,8 @@ __global__ void pack_sym_t_kernel(const double* __restrict__ M, TO* __restrict__
 // W[slot][t][p][p] (double) -> Wp[slot][c][T] (float, c over the lower triangle) for the listed slots: 64 bins per workgroup, packed
 // and transposed through LDS so that reads walk a bin's block and writes walk the bins.  grid = (ceil(T/64), nslots), block = 256,
 // dynamic LDS = NP * 65 floats
-__global__ __launch_bounds__(256) void pack_w32t_kernel(const double* __restrict__ W, long long sW, float* __restrict__ Wp, long long sWp, int T,
-                                                        int p, const int* __restrict__ slots) {
+__global__ __launch_bounds__(256) void pack_w32t_kernel(const double* __restrict__ W, long long sW, float* __restrict__ Wp, long long sWp, int Tw,
+                                                        int T, int p, const int* __restrict__ slots) {
   extern __shared__ float w32t_tile[];
   const size_t slot = slots[blockIdx.y];
   const int np = p * (p + 1) / 2, pp = p * p;
@@ -664,7 +697,7 @@ __global__ __launch_bounds__(256) void pack_w32t_kernel(const double* __restrict
   __syncthreads();
   for (int e = threadIdx.x; e < np * 64; e += 256) {
     const int c = e >> 6, t = e & 63;
-    if (t < nt) Wp[slot * sWp + (size_t)c * T + t0 + t] = w32t_tile[c * 65 + t];
+    if (t < nt) Wp[slot * sWp + (size_t)c * Tw + t0 + t] = w32t_tile[c * 65 + t];
   }
 }
 

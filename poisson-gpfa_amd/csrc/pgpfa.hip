@@ -767,7 +767,7 @@ int ensure_workspace(pgpfa_ctx* c, bool plan_lr) {
   CHK(dmalloc(c, &c->W, wlen * nB)); CHK(dmalloc(c, &c->Wt, wlen * nB));
   CHK(dmalloc(c, &c->fpart, (size_t)((c->T + 63) / 64) * nB));
   CHK(dmalloc(c, &c->sc_part2, 3 * (size_t)((c->T + 63) / 64) * nB));
-  CHK(dmalloc(c, &c->W32, (size_t)c->T * (c->p * (c->p + 1) / 2) * nB + 64));
+  CHK(dmalloc(c, &c->W32, (size_t)round_up(c->T, 32) * (c->p * (c->p + 1) / 2) * nB + 64));   // (rows of the component-major form start on 128-byte lines)
   CHK(dmalloc(c, &c->pcgctl, 1, true));
   CHK(dmalloc(c, &c->live, 2 * nB)); CHK(dmalloc(c, &c->pcg_ratio, nB, true)); CHK(dmalloc(c, &c->pcg_eta, nB, true));
   CHK(dmalloc(c, &c->GbT, (size_t)c->T * (c->p * (c->p + 1) / 2) + 64)); CHK(dmalloc(c, &c->WbT, (size_t)c->T * (c->p * (c->p + 1) / 2) + 64));
@@ -2629,7 +2629,8 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
           // ---- inner solve: per step pcg_cg_a_kernel, pcg_cg_b_kernel, the closing kernel and the three preconditioner products (pcg.h)
           const int* skip = &c->pcgctl->stop;
           const int npk = p * (p + 1) / 2;
-          const long long sW32 = (long long)T * npk;
+          const int Tw = round_up(T, 32);                        // row stride of the component-major packed curvature: rows start on 128-byte lines
+          const long long sW32 = (long long)Tw * npk;
           {
             std::vector<float> eta_s(nb, (float)eta_target);
             for (int s : active) {
@@ -2648,13 +2649,13 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
           }
           c->h_pcg[0] = 0; c->h_pcg[1] = 0;
           hipLaunchKernelGGL(pack_w32t_kernel, dim3((T + 63) / 64, na), dim3(256), (size_t)npk * 65 * sizeof(float), c->st, c->W, (long long)T * p * p,
-                             c->W32, sW32, T, p, c->list_a);
+                             c->W32, sW32, Tw, T, p, c->list_a);
           // t = Gb r0, then y = F Sb F^T t over the listed columns (left in c->Xt)
           CHK(shared_solve(c, nb, c->Rv, c->Zv, nullptr, true, false, c->list_a, na));
           struct NdevGuard { pgpfa_ctx* c; ~NdevGuard() { c->cur_ndev = nullptr; } } ndev_guard{c};
           c->live_gemms.clear();
           PcgCgP cp{};
-          cp.GbT = c->GbT; cp.WbT = reinterpret_cast<const float*>(c->WbT); cp.W32T = c->W32; cp.sW32 = sW32;
+          cp.GbT = c->GbT; cp.WbT = reinterpret_cast<const float*>(c->WbT); cp.W32T = c->W32; cp.sW32 = sW32; cp.Tw = Tw;
           cp.X = c->Dl; cp.R = c->Rv; cp.P = c->Pv; cp.Q = c->Qv; cp.Z = c->Zv; cp.S = c->Sv; cp.Y = c->Xt; cp.sV = ld;
           cp.part = c->sc_part2; cp.gam = c->cg_scal; cp.alp = c->cg_scal + 2 * (size_t)c->B; cp.rr = c->sc_rr; cp.rr0 = c->sc_rr0; cp.eta = c->pcg_eta;
           cp.ctl = c->pcgctl; cp.live0 = c->live; cp.live1 = c->live + c->B;
