@@ -32,5 +32,9 @@ python tools/split_probe.py 512 > $O/split_probe.txt 2>/dev/null
 python tools/pcg_probe.py 1024 4 init 101 > $O/pcg_probe.txt 2>/dev/null
 python tools/fixed_point_probe.py 16 c2 1 0 > $O/fixed_point_probe_c2.txt 2>/dev/null
 python tools/cold_start_probe.py > $O/cold_start.txt 2>/dev/null
+python tools/pcg_probe.py 1024 4 init 101 thin_products > $O/thin_products_probe.txt 2>/dev/null
+# (stand-alone probes: built here by make -C tools/probes, they travel with the snapshot)
+if [ -x tools/probes/thin_probe ]; then for l in 1024 400 100; do timeout 60 tools/probes/thin_probe $l 48; done > $O/thin_probe.txt 2>&1; fi
+if [ -x tools/probes/stride_probe ]; then timeout 60 tools/probes/stride_probe > $O/stride_probe.txt 2>&1; fi
 python tools/em_trace.py 60 > $O/em_trace_60_iterations.txt 2>/dev/null
 ls -la $O
