@@ -80,8 +80,9 @@ int pgpfa_destroy(pgpfa_ctx* ctx);
  * kernel that raises a sequence number the host spins on - no hipMemcpyAsync / hipStreamSynchronize on those paths; 0: the runtime's copies),
  * "mix_slot" (1: the mixing pass of that split form with a thread per bin and a workgroup per (slot, 256 bins) that walks whole columns of
  * the slab - contiguous 2-KB runs instead of 512-byte pieces, no LDS; up to 10 latents; 0: mix_vsm_split_kernel, 64 bins x 4 columns),
- * "thin_products" (1: the two block-diagonal products F^T t and F v of the low-rank preconditioner application as kernels of their own that feed
- * the matrix cores straight from global memory, csrc/thin.h; 0: block-sparse products of the general GEMM kernel with split-K),
+ * "thin_products" (2: the three products of the low-rank preconditioner application - the block-diagonal F^T t and F v, and Sb u - as kernels of
+ * their own that feed the matrix cores straight from global memory, csrc/thin.h; 1: the two block-diagonal ones only; 0: products of the general
+ * GEMM kernel, block-sparse and with split-K),
  * "cross_kernel" (1: the cross term of that split form in a kernel with all rows of a latent in one workgroup, 128 rows per
  * launch; 0: through the general GEMM kernel),
  * "split_cov" (1: the sum over trials of the T x T covariance blocks by the exact split form of csrc/split.h - FP64 cross term, FP16

@@ -190,9 +190,9 @@ struct pgpfa_ctx {
   int *d_kr_ft = nullptr, *d_kr_f = nullptr;     // per-row-tile k ranges of the block-diagonal F^T / F GEMMs
   int kr_ft_len = 0, kr_f_len = 0;               // longest of those ranges
   int ntab_ft = 0, ntab_f = 0; size_t tab_cap = 0;   // entries of the two row-tile tables, capacity (ints) of their device buffers
-  int *d_thin_ft = nullptr, *d_thin_f = nullptr;  // work tables of the same two products as kernels of their own (thin.h)
-  int nthin_ft = 0, nthin_f = 0;
-  int thin_products = 1;                         // 1: F^T t and F v of the preconditioner application by thin.h's kernels; 0: block-sparse GEMMs
+  int *d_thin_ft = nullptr, *d_thin_f = nullptr, *d_thin_s = nullptr;  // work tables of the same two products - and of Sb u - as kernels of their own (thin.h)
+  int nthin_ft = 0, nthin_f = 0, nthin_s = 0;
+  int thin_products = 2;                         // 1: F^T t and F v of the preconditioner application by thin.h's kernels, 2: Sb u too; 0: GEMMs
   double *Fbig = nullptr, *FTbig = nullptr, *Gbar = nullptr, *Wtbar = nullptr;   // low-rank shared preconditioner
   std::vector<int> rk, roff;                      // ranks padded to 16, offsets
   int rtot = 0, rpad = 0;
@@ -1209,6 +1209,12 @@ int build_lowrank(pgpfa_ctx* c) {
       for (int m0 = 0; m0 < c->rk[k]; m0 += per) { hft.push_back(k); hft.push_back(m0); hft.push_back(std::min(per, c->rk[k] - m0)); hft.push_back(c->roff[k]); }
       for (int t0 = 0; t0 < T; t0 += 256) { hf.push_back(k); hf.push_back(t0); hf.push_back(c->rk[k]); hf.push_back(c->roff[k]); }
     }
+    // Sb u with the same kernel as F^T t: one "latent" of rtot rows and rtot "bins", 64 rows per workgroup
+    std::vector<int> hs;
+    for (int m0 = 0; m0 < c->rtot; m0 += 64) { hs.push_back(0); hs.push_back(m0); hs.push_back(std::min(64, c->rtot - m0)); hs.push_back(0); }
+    c->nthin_s = (int)hs.size() / 4;
+    if (hs.size() > c->tab_cap) return fail("internal: thin-product table overflow");
+    CHK(upload_list(c, c->d_thin_s, hs));
     c->nthin_ft = (int)hft.size() / 4; c->nthin_f = (int)hf.size() / 4;
     if (hft.size() > c->tab_cap || hf.size() > c->tab_cap) return fail("internal: thin-product table overflow");
     CHK(upload_list(c, c->d_thin_ft, hft));
@@ -1343,7 +1349,7 @@ int pgpfa_create(pgpfa_ctx** out, int device, int q, int p, int T, int R, double
   rc |= dmalloc(c, &c->d_rank, p); rc |= dmalloc(c, &c->d_roff, p + 1);
   c->tab_cap = 4 * ((size_t)c->ld / 64 + 2 * (size_t)p + 4);
   rc |= dmalloc(c, &c->d_kr_ft, c->tab_cap); rc |= dmalloc(c, &c->d_kr_f, c->tab_cap);
-  rc |= dmalloc(c, &c->d_thin_ft, c->tab_cap); rc |= dmalloc(c, &c->d_thin_f, c->tab_cap);
+  rc |= dmalloc(c, &c->d_thin_ft, c->tab_cap); rc |= dmalloc(c, &c->d_thin_f, c->tab_cap); rc |= dmalloc(c, &c->d_thin_s, c->tab_cap);
   rc |= dmalloc(c, &c->Fbig, (size_t)c->ld * c->ld + 256 * (size_t)c->ld, true); rc |= dmalloc(c, &c->FTbig, (size_t)c->ld * c->ld + 256 * (size_t)c->ld, true);
   rc |= dmalloc(c, &c->Gbar, (size_t)T * p * p + 64); rc |= dmalloc(c, &c->Wtbar, (size_t)T * p * p + 64); rc |= dmalloc(c, &c->d_blk_lat, (size_t)p * c->Tp / 16 + 64); rc |= dmalloc(c, &c->d_blk_col, (size_t)p * c->Tp / 16 + 64);
   rc |= dmalloc(c, &c->vec, (size_t)q * (p + 1));
@@ -1859,7 +1865,17 @@ static int shared_solve(pgpfa_ctx* c, int nb, const double* R, double* Z, const 
     // (K = rtot, a multiple of 16: the row tiles of Y above stop at roff[p] = rtot, rows [rtot, rpad) of c->Glt are never written and may hold
     //  anything - the buffer doubles as the line search's trial gradient and is re-carved from the arena by every re-plan)
     z.M = rpad; z.N = ng; z.K = c->rtot; z.cols = cols; z.alpha = 1.0; z.beta = 0.0; z.slots = nullptr; z.nbatch = 1; z.mode = GEMM_FULL; z.kflags = 0;
-    CHK(gemm(c, true, z));
+    if (thin && c->thin_products >= 2) {
+      // the same kernel as F^T t with Sb as the "transposed factor" of one latent with rtot rows and rtot bins (element (m, k) at k rpad + m, as the
+      // GEMM reads it)
+      ThinP ts = tp;
+      ts.FT = c->sU; ts.ldft = rpad; ts.T = c->rtot; ts.tab = c->d_thin_s; ts.X = c->Glt; ts.ldx = c->ld; ts.Y = c->KD; ts.ldy = c->ld;
+      prof_begin(c, TAG_SOLVE, tp.n_dev ? 0.0 : 2.0 * (double)c->rtot * c->rtot * ng);
+      hipLaunchKernelGGL(thin_ft_kernel<true>, dim3(c->nthin_s, (ng + 15) / 16), dim3(512), 0, c->st, ts);
+      prof_end(c);
+    } else {
+      CHK(gemm(c, true, z));
+    }
     GemmP q{};                                               // Q = F Zs                (n x nb)
     q.skip = skip;
     q.A = c->Fbig; q.sA = 0; q.lda = c->ld; q.B = c->KD; q.sB = 0; q.ldb = c->ld; q.C = c->Xt; q.sC = 0; q.ldc = c->ld;

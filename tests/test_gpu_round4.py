@@ -28,7 +28,7 @@ def test_pcg_step_without_prior_matvec_vs_oracle(shape):
     """Forced on at small shapes (it is chosen by itself only for large chunks): latent widths 7 and 9 run the 8- and 10-wide
     instantiations with clamped component indices, 70 / 130 bins leave a partly filled 64-bin tile.  Modes against the oracle's exact
     Newton (1e-8), objective 1e-9 rel, covariance blocks 1e-8 rel; the split kernels of round 3 (pcg_form = 0) on the same problem land on
-    the same modes, and so do the block-diagonal products of the preconditioner through the general GEMM kernel (thin_products = 0) instead
+    the same modes, and so do the products of the preconditioner through the general GEMM kernel (thin_products = 0, or 1: only `Sb u`) instead
     of thin.h's kernels (bins that are not a multiple of 4 take their scalar-load instantiation; ranks below 64 leave row tiles empty)."""
     from funs import _hip
     q, p, T, R = shape
@@ -38,7 +38,7 @@ def test_pcg_step_without_prior_matvec_vs_oracle(shape):
     par = {'C': 0.3 * rng.standard_normal((q, p)) / np.sqrt(max(1, p / 4)), 'd': np.log(Y.mean(axis=(0, 2)) + 0.1), 'tau': 0.05 + 0.3 * rng.random(p)}
     res, nll_o, _ = orc.laplace([y.astype(float) for y in Ys], par, 10.0, mode='exact', return_cov=False)
     modes = {}
-    for form, thin in ((1, 1), (0, 1), (1, 0)):
+    for form, thin in ((1, 2), (0, 2), (1, 0), (1, 1)):
         ctx = _hip.Context(q, p, T, R, 10.0)
         try:
             ctx.upload_counts(Y)
@@ -57,8 +57,9 @@ def test_pcg_step_without_prior_matvec_vs_oracle(shape):
             assert np.all(st2 == 0) and abs(obj2 - obj) <= 1e-10 * abs(obj)
         finally:
             ctx.close()
-    assert np.max(np.abs(modes[1, 1] - modes[0, 1])) <= 2e-9
-    assert np.max(np.abs(modes[1, 1] - modes[1, 0])) <= 2e-9
+    assert np.max(np.abs(modes[1, 2] - modes[0, 2])) <= 2e-9
+    assert np.max(np.abs(modes[1, 2] - modes[1, 0])) <= 2e-9
+    assert np.max(np.abs(modes[1, 2] - modes[1, 1])) <= 2e-9
 
 
 def test_pcg_forms_agree_at_config3_dimensions():
