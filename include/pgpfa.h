@@ -71,6 +71,8 @@ int pgpfa_destroy(pgpfa_ctx* ctx);
  * "pcg_form" (1: a step of the host-free inner iteration is two tile-parallel kernels - the one-reduction (Chronopoulos-Gear) form of
  * PCG - plus the three preconditioner products, the prior mat-vec gone from the loop through Kt^-1 z = r - Wb z, pcg.h; up to 10 latents, needs "pcg_w32" and
  * "pcg_retire"; 0: the split kernels of round 3 with K^-1 p as a product),
+ * "pcg_adapt" (1: the launches of a step of that iteration are sized by the live count the device last mirrored to the host - it only falls during a
+ * solve - and the per-bin kernels take 16 / 8 / 4 slots per workgroup above 640 / 320 / below; 0: sized by the solve's first count, 16 slots),
  * "pcg_retire" (1: every slot of the inner PCG has its own forcing term and leaves the iteration when it reaches it - device-side
  * live list, pcg.h; 0: one common forcing term), "pcg_trace" (0; 1: one stderr line per inner solve),
  * "time_newton" (0; 1: HIP events around the inner solves -> info "last_newton_solve_ms" / "last_newton_solve_bytes"),

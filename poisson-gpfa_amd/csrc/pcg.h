@@ -404,6 +404,7 @@ struct PcgCgP {
   double *rr, *rr0; const float* eta;
   PcgCtl* ctl; int* live0; int* live1;
   double eps; int T, p, par, first, inner_min, ntile, B;
+  int spw;                                     // slots per workgroup (a multiple of 4, at most PCG_SLOTS): the host picks it by the live count it last saw
 };
 
 // out = M v for the symmetric p x p matrix of this thread's bin, rows in two groups of about half the packed entries: the loads of a group
@@ -476,7 +477,7 @@ constexpr int pcg_cg_ld(int pw) { return (pw * (pw + 1) / 2) | 1; }
 inline size_t pcg_cg_a_lds(int pw) { return (size_t)64 * pcg_cg_ld(pw) * (sizeof(double) + sizeof(float)); }
 inline size_t pcg_cg_b_lds(int pw) { return (size_t)64 * pcg_cg_ld(pw) * sizeof(double); }
 
-// grid = (ceil(T/64), ceil(na / PCG_SLOTS)), block = 256 (lanes = bins, waves = slots); dynamic LDS = pcg_cg_a_lds(PW)
+// grid = (ceil(T/64), ceil(live bound / spw)), block = 256 (lanes = bins, waves = slots); dynamic LDS = pcg_cg_a_lds(PW)
 // (two waves per SIMD: left alone the compiler hoists every load and LDS read of a slot, takes all 256 registers and one workgroup fills a CU)
 template <int PW>
 __global__ __launch_bounds__(256, 2) void pcg_cg_a_kernel(PcgCgP a) {
@@ -487,7 +488,7 @@ __global__ __launch_bounds__(256, 2) void pcg_cg_a_kernel(PcgCgP a) {
   const PcgCtl* ctl = a.ctl;
   if (ctl->stop) return;
   const int na = ctl->nl[a.par];
-  if ((int)blockIdx.y * PCG_SLOTS >= na) return;
+  if ((int)blockIdx.y * a.spw >= na) return;
   const int T = a.T, p = a.p, np = p * (p + 1) / 2;
   const int t0 = blockIdx.x * 64;
   const int nt = min(64, T - t0);
@@ -500,8 +501,8 @@ __global__ __launch_bounds__(256, 2) void pcg_cg_a_kernel(PcgCgP a) {
   const double* g = Gs + lane * LD;
   const float* wb = Ws + lane * LD;
   const int* live = a.par ? a.live1 : a.live0;
-  const int s_end = min(na, (int)(blockIdx.y + 1) * PCG_SLOTS);
-  for (int si = blockIdx.y * PCG_SLOTS + wave; si < s_end; si += 4) {
+  const int s_end = min(na, (int)(blockIdx.y + 1) * a.spw);
+  for (int si = blockIdx.y * a.spw + wave; si < s_end; si += 4) {
     const size_t slot = (size_t)live[si];
     const size_t base = slot * a.sV + t;
     double r[PW], v[PW], z[PW], w[PW];
@@ -563,7 +564,7 @@ __global__ __launch_bounds__(256, 3) void pcg_cg_b_kernel(PcgCgP a) {
   PcgCtl* ctl = a.ctl;
   if (ctl->stop) return;
   const int na = ctl->nl[a.par];
-  if ((int)blockIdx.y * PCG_SLOTS >= na) return;
+  if ((int)blockIdx.y * a.spw >= na) return;
   const int it = ctl->iters;
   const int T = a.T, p = a.p, np = p * (p + 1) / 2;
   const int t0 = blockIdx.x * 64;
@@ -580,8 +581,8 @@ __global__ __launch_bounds__(256, 3) void pcg_cg_b_kernel(PcgCgP a) {
   const double* alp_old = a.alp + (size_t)a.par * a.B;
   double* gam_new = a.gam + (size_t)(a.par ^ 1) * a.B;
   double* alp_new = a.alp + (size_t)(a.par ^ 1) * a.B;
-  const int s_end = min(na, (int)(blockIdx.y + 1) * PCG_SLOTS);
-  for (int si = blockIdx.y * PCG_SLOTS + wave; si < s_end; si += 4) {
+  const int s_end = min(na, (int)(blockIdx.y + 1) * a.spw);
+  for (int si = blockIdx.y * a.spw + wave; si < s_end; si += 4) {
     const int sloti = live[si];
     const size_t slot = (size_t)sloti;
     double gamma = 0.0, delta = 0.0, rrn = 0.0;
@@ -658,6 +659,7 @@ __global__ void pcg_iter_close_kernel(PcgCtl* __restrict__ ctl, int par, volatil
   }
   ctl->nl[par] = 0;
   if (host) {
+    host[2] = ctl->stop ? 0 : ctl->nlive;                  // (the live count only falls during a solve: a stale value is an upper bound)
     host[1] = ctl->iters;
     __threadfence_system();
     host[0] = ctl->stop;

@@ -178,6 +178,7 @@ struct pgpfa_ctx {
   float* W32 = nullptr;                          // packed single-precision curvature triangles of the chunk's slots (PCG matvec)
   double* sc_part2 = nullptr;                    // per (slot, tile) partial sums r.z, r.r
   int pcg_fused = 1; bool pcg_w32 = true;        // pcg_fused: 0 off, 1 when the chunk is large enough, 2 always (tests)
+  int pcg_adapt = 1;                             // 1: launches of the host-free inner step sized by the mirrored live count, 16 / 8 / 4 slots per workgroup; 0: by the solve's first count
   int pcg_form = 1;                              // host-free inner iteration (pcg.h): 1 two tile-parallel kernels per step, no prior mat-vec (pcg_cg_a/b_kernel);
                                                  // 0 the split kernels of round 3 with K^-1 p as a product
   double *Sv = nullptr, *cg_scal = nullptr;      // s = H~ z of the two-kernel form; its per-slot scalars [gamma | alpha] x step parity
@@ -1425,6 +1426,7 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
   else if (k == "pcg_fused") c->pcg_fused = (int)v;
   else if (k == "pcg_w32") c->pcg_w32 = (v != 0.0);
   else if (k == "pcg_form") c->pcg_form = (int)v;
+  else if (k == "pcg_adapt") c->pcg_adapt = (int)v;
   else if (k == "mix_slot") c->mix_slot = (int)v;
   else if (k == "thin_products") c->thin_products = (int)v;
   else if (k == "copy_kernels") c->copy_kernels = (v != 0.0);
@@ -1841,7 +1843,8 @@ static int shared_solve(pgpfa_ctx* c, int nb, const double* R, double* Z, const 
       prof_begin(c, TAG_SOLVE, tp.n_dev ? 0.0 : 2.0 * c->T * c->rtot * ng);
       if (c->prof.on && c->prof.open) {
         char key[96];
-        std::snprintf(key, sizeof key, "f64 thin %s T=%d r=%d N=%s%d", what, c->T, c->rtot, tp.n_dev ? "<=" : "", ng);
+        if (tp.n_dev) std::snprintf(key, sizeof key, "f64 thin %s T=%d r=%d N=live", what, c->T, c->rtot);
+        else std::snprintf(key, sizeof key, "f64 thin %s T=%d r=%d N=%d", what, c->T, c->rtot, ng);
         c->prof.recs.back().shape = key;
       }
     };
@@ -2663,7 +2666,7 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
             h0.nlive = na; h0.nl[0] = na;
             CHK(upload_nosync(c, c->pcgctl, &h0, sizeof(PcgCtl)));
           }
-          c->h_pcg[0] = 0; c->h_pcg[1] = 0;
+          c->h_pcg[0] = 0; c->h_pcg[1] = 0; c->h_pcg[2] = na;
           hipLaunchKernelGGL(pack_w32t_kernel, dim3((T + 63) / 64, na), dim3(256), (size_t)npk * 65 * sizeof(float), c->st, c->W, (long long)T * p * p,
                              c->W32, sW32, Tw, T, p, c->list_a);
           // t = Gb r0, then y = F Sb F^T t over the listed columns (left in c->Xt)
@@ -2676,9 +2679,15 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
           cp.part = c->sc_part2; cp.gam = c->cg_scal; cp.alp = c->cg_scal + 2 * (size_t)c->B; cp.rr = c->sc_rr; cp.rr0 = c->sc_rr0; cp.eta = c->pcg_eta;
           cp.ctl = c->pcgctl; cp.live0 = c->live; cp.live1 = c->live + c->B;
           cp.eps = c->eps; cp.T = T; cp.p = p; cp.inner_min = c->pcg_inner_min; cp.ntile = (T + 63) / 64; cp.B = c->B;
-          const dim3 gcg((T + 63) / 64, (na + PCG_SLOTS - 1) / PCG_SLOTS);
           for (int it = 0; it < c->pcg_inner_max; ++it) {
             cp.par = it & 1; cp.first = (it == 0) ? 1 : 0;
+            // The launches of a step are sized by the live count the closing kernel last mirrored to the host (it only falls during a solve, so a
+            // value that is a step or two old is an upper bound; the kernels read the true count on the device).  Few live slots: fewer slots per
+            // workgroup, so that the per-bin kernels still offer every CU a workgroup and a wave walks one slot instead of four in a row.
+            const int seen = *(volatile int*)&c->h_pcg[2];
+            const int bound = c->pcg_adapt ? std::max(1, std::min(na, seen)) : na;
+            cp.spw = !c->pcg_adapt ? PCG_SLOTS : bound > 640 ? 16 : bound > 320 ? 8 : 4;
+            const dim3 gcg((T + 63) / 64, (bound + cp.spw - 1) / cp.spw);
             dispatch_pw(p, [&](auto pw) {
               constexpr int PW = decltype(pw)::value;
               if constexpr (PW <= 10) {
@@ -2694,7 +2703,7 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
             // the preconditioner products for the NEXT iteration run over the list this launch has just written
             c->live_gemm_collect = (it == 0);
             c->cur_ndev = &c->pcgctl->nl[(it & 1) ^ 1];
-            CHK(shared_solve(c, nb, c->Rv, c->Zv, skip, false, false, (it & 1) ? c->live : c->live + c->B, na));
+            CHK(shared_solve(c, nb, c->Rv, c->Zv, skip, false, false, (it & 1) ? c->live : c->live + c->B, bound));
             if (*(volatile int*)&c->h_pcg[0]) break;           // the device has already stopped: whatever is enqueued is a no-op
             if (it + 1 < c->pcg_inner_max) {
               const auto t_spin = std::chrono::steady_clock::now();
