@@ -73,6 +73,8 @@ int pgpfa_destroy(pgpfa_ctx* ctx);
  * "pcg_retire"; 0: the split kernels of round 3 with K^-1 p as a product),
  * "pcg_adapt" (1: the launches of a step of that iteration are sized by the live count the device last mirrored to the host - it only falls during a
  * solve - and the per-bin kernels take 16 / 8 / 4 slots per workgroup above 640 / 320 / below; 0: sized by the solve's first count, 16 slots),
+ * "pcg_xcd" (1: the two per-bin kernels of that step map workgroup ids so that the bin tiles of a slot group run on one XCD - they share the
+ * boundary lines of rows that are not line-aligned and the slot's scalars in one L2; 0: bin tile = fast grid index),
  * "pcg_retire" (1: every slot of the inner PCG has its own forcing term and leaves the iteration when it reaches it - device-side
  * live list, pcg.h; 0: one common forcing term), "pcg_trace" (0; 1: one stderr line per inner solve),
  * "time_newton" (0; 1: HIP events around the inner solves -> info "last_newton_solve_ms" / "last_newton_solve_bytes"),

@@ -404,6 +404,7 @@ struct PcgCgP {
   double *rr, *rr0; const float* eta;
   PcgCtl* ctl; int* live0; int* live1;
   double eps; int T, p, par, first, inner_min, ntile, B;
+  int xcd_map;                                 // 1: workgroup -> (bin tile, slot group) by pcg_cg_wg; 0: grid indices as they are
   int spw;                                     // slots per workgroup (a multiple of 4, at most PCG_SLOTS): the host picks it by the live count it last saw
 };
 
@@ -477,8 +478,21 @@ constexpr int pcg_cg_ld(int pw) { return (pw * (pw + 1) / 2) | 1; }
 inline size_t pcg_cg_a_lds(int pw) { return (size_t)64 * pcg_cg_ld(pw) * (sizeof(double) + sizeof(float)); }
 inline size_t pcg_cg_b_lds(int pw) { return (size_t)64 * pcg_cg_ld(pw) * sizeof(double); }
 
-// grid = (ceil(T/64), ceil(live bound / spw)), block = 256 (lanes = bins, waves = slots); dynamic LDS = pcg_cg_a_lds(PW)
+// grid = (ceil(T/64), ceil(live bound / spw) rounded up to 8: pcg_cg_wg), block = 256 (lanes = bins, waves = slots); dynamic LDS = pcg_cg_a_lds(PW)
 // (two waves per SIMD: left alone the compiler hoists every load and LDS read of a slot, takes all 256 registers and one workgroup fills a CU)
+// (bin tile, slot group) of a workgroup.  The hardware deals consecutive workgroup ids round-robin over the 8 XCDs, each with an L2 of its own: with the bin
+// tile as the fast grid index the eight tiles of a slot group sat on eight XCDs, and since a latent's row of an n-vector is not line-aligned (T = 500: a 64-bin
+// run touches 5 lines for 4) every boundary line was fetched into two L2s.  Here eight consecutive ids take eight different slot groups and an XCD walks the
+// bin tiles of its groups in turn: a slot's tiles, its boundary lines and its scalars meet in ONE L2.  Live groups still fill a prefix of the ids (in blocks of
+// eight groups).  grid = (ntile, slot groups rounded up to a multiple of 8).
+__device__ __forceinline__ void pcg_cg_wg(int ntile, int xcd_map, int& tile, int& group) {
+  if (!xcd_map) { tile = blockIdx.x; group = blockIdx.y; return; }
+  const int id = blockIdx.y * gridDim.x + blockIdx.x;
+  const int xcd = id & 7, m = id >> 3;
+  tile = m % ntile;
+  group = xcd + 8 * (m / ntile);
+}
+
 template <int PW>
 __global__ __launch_bounds__(256, 2) void pcg_cg_a_kernel(PcgCgP a) {
   constexpr int NP = PW * (PW + 1) / 2, LD = pcg_cg_ld(PW);
@@ -488,9 +502,11 @@ __global__ __launch_bounds__(256, 2) void pcg_cg_a_kernel(PcgCgP a) {
   const PcgCtl* ctl = a.ctl;
   if (ctl->stop) return;
   const int na = ctl->nl[a.par];
-  if ((int)blockIdx.y * a.spw >= na) return;
+  int wg_tile, wg_group;
+  pcg_cg_wg(a.ntile, a.xcd_map, wg_tile, wg_group);
+  if (wg_group * a.spw >= na) return;
   const int T = a.T, p = a.p, np = p * (p + 1) / 2;
-  const int t0 = blockIdx.x * 64;
+  const int t0 = wg_tile * 64;
   const int nt = min(64, T - t0);
   pcg_stage_sym<NP>(a.GbT, T, t0, nt, np, Gs, LD);
   pcg_stage_sym<NP>(a.WbT, T, t0, nt, np, Ws, LD);
@@ -501,8 +517,8 @@ __global__ __launch_bounds__(256, 2) void pcg_cg_a_kernel(PcgCgP a) {
   const double* g = Gs + lane * LD;
   const float* wb = Ws + lane * LD;
   const int* live = a.par ? a.live1 : a.live0;
-  const int s_end = min(na, (int)(blockIdx.y + 1) * a.spw);
-  for (int si = blockIdx.y * a.spw + wave; si < s_end; si += 4) {
+  const int s_end = min(na, (wg_group + 1) * a.spw);
+  for (int si = wg_group * a.spw + wave; si < s_end; si += 4) {
     const size_t slot = (size_t)live[si];
     const size_t base = slot * a.sV + t;
     double r[PW], v[PW], z[PW], w[PW];
@@ -549,7 +565,7 @@ __global__ __launch_bounds__(256, 2) void pcg_cg_a_kernel(PcgCgP a) {
     }
     for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_down(s0, off); s1 += __shfl_down(s1, off); s2 += __shfl_down(s2, off); }
     if (lane == 0) {
-      double* pp = a.part + (slot * a.ntile + blockIdx.x) * 3;
+      double* pp = a.part + (slot * a.ntile + wg_tile) * 3;
       pp[0] = s0; pp[1] = s1; pp[2] = s2;
     }
   }
@@ -564,10 +580,12 @@ __global__ __launch_bounds__(256, 3) void pcg_cg_b_kernel(PcgCgP a) {
   PcgCtl* ctl = a.ctl;
   if (ctl->stop) return;
   const int na = ctl->nl[a.par];
-  if ((int)blockIdx.y * a.spw >= na) return;
+  int wg_tile, wg_group;
+  pcg_cg_wg(a.ntile, a.xcd_map, wg_tile, wg_group);
+  if (wg_group * a.spw >= na) return;
   const int it = ctl->iters;
   const int T = a.T, p = a.p, np = p * (p + 1) / 2;
-  const int t0 = blockIdx.x * 64;
+  const int t0 = wg_tile * 64;
   const int nt = min(64, T - t0);
   pcg_stage_sym<NP>(a.GbT, T, t0, nt, np, Gs, LD);
   __syncthreads();
@@ -581,8 +599,8 @@ __global__ __launch_bounds__(256, 3) void pcg_cg_b_kernel(PcgCgP a) {
   const double* alp_old = a.alp + (size_t)a.par * a.B;
   double* gam_new = a.gam + (size_t)(a.par ^ 1) * a.B;
   double* alp_new = a.alp + (size_t)(a.par ^ 1) * a.B;
-  const int s_end = min(na, (int)(blockIdx.y + 1) * a.spw);
-  for (int si = blockIdx.y * a.spw + wave; si < s_end; si += 4) {
+  const int s_end = min(na, (wg_group + 1) * a.spw);
+  for (int si = wg_group * a.spw + wave; si < s_end; si += 4) {
     const int sloti = live[si];
     const size_t slot = (size_t)sloti;
     double gamma = 0.0, delta = 0.0, rrn = 0.0;
@@ -597,7 +615,7 @@ __global__ __launch_bounds__(256, 3) void pcg_cg_b_kernel(PcgCgP a) {
     const double beta = (a.first || !(g_old > 0.0)) ? 0.0 : gamma / g_old;
     const double den = (a.first || !(a_old > 0.0)) ? delta : delta - beta * gamma / a_old;
     const double alpha = (den > 0.0) ? gamma / den : 0.0;
-    if (blockIdx.x == 0 && lane == 0) {
+    if (wg_tile == 0 && lane == 0) {
       if (a.first) a.rr0[slot] = rrn;
       a.rr[slot] = rrn;
       if (keep) {

@@ -178,6 +178,7 @@ struct pgpfa_ctx {
   float* W32 = nullptr;                          // packed single-precision curvature triangles of the chunk's slots (PCG matvec)
   double* sc_part2 = nullptr;                    // per (slot, tile) partial sums r.z, r.r
   int pcg_fused = 1; bool pcg_w32 = true;        // pcg_fused: 0 off, 1 when the chunk is large enough, 2 always (tests)
+  int pcg_xcd = 1;                               // 1: the per-bin kernels of the inner step place the bin tiles of a slot group on one XCD (pcg_cg_wg)
   int pcg_adapt = 1;                             // 1: launches of the host-free inner step sized by the mirrored live count, 16 / 8 / 4 slots per workgroup; 0: by the solve's first count
   int pcg_form = 1;                              // host-free inner iteration (pcg.h): 1 two tile-parallel kernels per step, no prior mat-vec (pcg_cg_a/b_kernel);
                                                  // 0 the split kernels of round 3 with K^-1 p as a product
@@ -1427,6 +1428,7 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
   else if (k == "pcg_w32") c->pcg_w32 = (v != 0.0);
   else if (k == "pcg_form") c->pcg_form = (int)v;
   else if (k == "pcg_adapt") c->pcg_adapt = (int)v;
+  else if (k == "pcg_xcd") c->pcg_xcd = (int)v;
   else if (k == "mix_slot") c->mix_slot = (int)v;
   else if (k == "thin_products") c->thin_products = (int)v;
   else if (k == "copy_kernels") c->copy_kernels = (v != 0.0);
@@ -2678,7 +2680,7 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
           cp.X = c->Dl; cp.R = c->Rv; cp.P = c->Pv; cp.Q = c->Qv; cp.Z = c->Zv; cp.S = c->Sv; cp.Y = c->Xt; cp.sV = ld;
           cp.part = c->sc_part2; cp.gam = c->cg_scal; cp.alp = c->cg_scal + 2 * (size_t)c->B; cp.rr = c->sc_rr; cp.rr0 = c->sc_rr0; cp.eta = c->pcg_eta;
           cp.ctl = c->pcgctl; cp.live0 = c->live; cp.live1 = c->live + c->B;
-          cp.eps = c->eps; cp.T = T; cp.p = p; cp.inner_min = c->pcg_inner_min; cp.ntile = (T + 63) / 64; cp.B = c->B;
+          cp.eps = c->eps; cp.T = T; cp.p = p; cp.inner_min = c->pcg_inner_min; cp.ntile = (T + 63) / 64; cp.B = c->B; cp.xcd_map = c->pcg_xcd;
           for (int it = 0; it < c->pcg_inner_max; ++it) {
             cp.par = it & 1; cp.first = (it == 0) ? 1 : 0;
             // The launches of a step are sized by the live count the closing kernel last mirrored to the host (it only falls during a solve, so a
@@ -2687,7 +2689,7 @@ static int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow
             const int seen = *(volatile int*)&c->h_pcg[2];
             const int bound = c->pcg_adapt ? std::max(1, std::min(na, seen)) : na;
             cp.spw = !c->pcg_adapt ? PCG_SLOTS : bound > 640 ? 16 : bound > 320 ? 8 : 4;
-            const dim3 gcg((T + 63) / 64, (bound + cp.spw - 1) / cp.spw);
+            const dim3 gcg((T + 63) / 64, round_up((bound + cp.spw - 1) / cp.spw, 8));       // (slot groups in blocks of 8: pcg_cg_wg)
             dispatch_pw(p, [&](auto pw) {
               constexpr int PW = decltype(pw)::value;
               if constexpr (PW <= 10) {
