@@ -402,57 +402,72 @@ __global__ __launch_bounds__(256) void cross_term_kernel(CrossArgs a) {
   const int ct = blockIdx.x * 4 + wave;                         // this wave's column tile of 16
   const bool wave_live = t0 + wave * 16 < a.T;
 
-  double ra[NA];
-  TB rb[4];
-  auto load = [&](int chunk) {
-    const int s = s_begin + chunk / cps;
-    const int c0 = (chunk % cps) * GK;
+  // Two register sets: the loads of chunk ch + 2 are issued while chunk ch is multiplied (one chunk is 16 matrix instructions per wave, 0.4 us - less than
+  // a memory round trip; with a single set the matrix cores were busy half of the time, PMC).  All loads are unconditional from clamped addresses and
+  // masked when they are stored: a load under a condition is waited for on its own.
+  double raA[NA], raB[NA];
+  TB rbA[4], rbB[4];
+  auto load = [&](int chunk, double (&ra)[NA], TB (&rb)[4]) {
+    const int cc = min(chunk, nchunks - 1);
+    const int s = s_begin + cc / cps;
+    const int c0 = (cc % cps) * GK;
     const double* Ap = a.A + (size_t)s * a.sM + (size_t)c0 * a.lda + a.row0;
     const TB* Dp = Dall + (size_t)s * a.sD + (size_t)c0 * a.ldd + t0;
 #pragma unroll
     for (int u = 0; u < NA; ++u) {
       const int e = tid + 256 * u;
-      const int kk = e / (NTR * 16), i = e - kk * (NTR * 16);
-      ra[u] = (kk < GK && i < rk) ? Ap[(size_t)kk * a.lda + i] : 0.0;
+      const int kk = min(e / (NTR * 16), GK - 1), i = min(e % (NTR * 16), rk - 1);
+      ra[u] = Ap[(size_t)kk * a.lda + i];
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int e = tid + 256 * u;
-      const int kk = e >> 6, t = e & 63;
-      rb[u] = (t0 + t < a.T) ? Dp[(size_t)kk * a.ldd + t] : (TB)0;
+      const int kk = e >> 6, t = min(t0 + (e & 63), a.T - 1) - t0;
+      rb[u] = Dp[(size_t)kk * a.ldd + t];
     }
   };
-  auto store = [&](int buf) {
+  auto store = [&](int buf, const double (&ra)[NA], const TB (&rb)[4]) {
 #pragma unroll
     for (int u = 0; u < NA; ++u) {
       const int e = tid + 256 * u;
       const int kk = e / (NTR * 16), i = e - kk * (NTR * 16);
-      if (kk < GK) As[buf][kk][i] = ra[u];
+      if (kk < GK) As[buf][kk][i] = (i < rk) ? ra[u] : 0.0;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int e = tid + 256 * u;
-      Bs[buf][e >> 6][e & 63] = (double)rb[u];
+      Bs[buf][e >> 6][e & 63] = (t0 + (e & 63) < a.T) ? (double)rb[u] : 0.0;
     }
   };
   mdouble4 acc[NTR];
 #pragma unroll
   for (int mi = 0; mi < NTR; ++mi) acc[mi] = mdouble4{0.0, 0.0, 0.0, 0.0};
-  if (nchunks > 0) { load(0); store(0); }
-  __syncthreads();
-  for (int ch = 0; ch < nchunks; ++ch) {
-    const int buf = ch & 1;
-    if (ch + 1 < nchunks) load(ch + 1);
-    if (wave_live) {
+  auto multiply = [&](int buf) {
+    if (!wave_live) return;
 #pragma unroll
-      for (int kk = 0; kk < GK; kk += 4) {
-        const double bf = Bs[buf][kk + l4][wave * 16 + l15];
+    for (int kk = 0; kk < GK; kk += 4) {
+      const double bf = Bs[buf][kk + l4][wave * 16 + l15];
 #pragma unroll
-        for (int mi = 0; mi < NTR; ++mi)
-          if (!LOWER || mi >= ct) acc[mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf, As[buf][kk + l4][mi * 16 + l15], acc[mi], 0, 0, 0);
-      }
+      for (int mi = 0; mi < NTR; ++mi)
+        if (!LOWER || mi >= ct) acc[mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf, As[buf][kk + l4][mi * 16 + l15], acc[mi], 0, 0, 0);
     }
-    if (ch + 1 < nchunks) store(buf ^ 1);
+  };
+  if (nchunks > 0) {
+    load(0, raA, rbA);
+    load(1, raB, rbB);
+    store(0, raA, rbA);
+  }
+  __syncthreads();
+  // chunk ch sits in LDS buffer ch & 1; its successor's registers are set B for even ch, set A for odd ch
+  for (int ch = 0; ch < nchunks; ch += 2) {
+    load(ch + 2, raA, rbA);
+    multiply(0);
+    if (ch + 1 < nchunks) store(1, raB, rbB);
+    __syncthreads();
+    if (ch + 1 >= nchunks) break;
+    load(ch + 3, raB, rbB);
+    multiply(1);
+    if (ch + 2 < nchunks) store(0, raA, rbA);
     __syncthreads();
   }
   // issued as (column-side fragment) x (A fragment): result row l4 + 4 r  <->  column t, result column l15  <->  row i
