@@ -17,6 +17,7 @@
 // kernel is MFMA-issue bound by construction.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 namespace pgpfa {
 
@@ -212,8 +213,8 @@ __global__ __launch_bounds__(256, BT == 128 ? 2 : 3) void gemm_mfma_kernel_t(Gem
   const bool a_vec = ((((size_t)A) & (2 * sizeof(T) - 1)) == 0) && ((g.lda & 1) == 0) && ((i0 & 1) == 0);
   const bool b_vec = ((((size_t)B) & (2 * sizeof(T) - 1)) == 0) && ((g.ldb & 1) == 0);
 
-  // staging registers: NU pairs per operand per thread
-  T ra[2 * NU], rb[2 * NU];
+  // staging registers: NU pairs per operand per thread, two sets (the loads run two k chunks ahead of the matrix instructions, see the loop)
+  T raA[2 * NU], rbA[2 * NU], raB[2 * NU], rbB[2 * NU];
   // (TRANSB) the B column each staging unit of this thread reads: j0 + nn, or its entry in the column list (clamped inside the list)
   // TRANSB staging map: 8 consecutive lanes walk the 16 k of a step of ONE column (a 128-byte line of that slot vector), a wave covers 8
   // columns - with lanes along the columns instead (the round-1 map) every load instruction touched 64 lines for 16 bytes each.  The
@@ -228,14 +229,17 @@ __global__ __launch_bounds__(256, BT == 128 ? 2 : 3) void gemm_mfma_kernel_t(Gem
   }
   auto bswz = [](int k) { return TRANSB ? (((k >> 1) & 7) << 3) : 0; };
 
-  auto load_tiles = [&](int k0) {
+  // (vec: both operands allow 16-byte loads - decided once per workgroup OUTSIDE the loop: a branch around a load inside it makes the compiler wait for
+  //  every outstanding load at the join)
+  auto load_tiles = [&](auto vec, int k0, T (&ra)[2 * NU], T (&rb)[2 * NU]) {
+    constexpr bool VEC = decltype(vec)::value;
 #pragma unroll
     for (int s = 0; s < NU; ++s) {
       const int u = tid + 256 * s;
       {  // A: [k][row] ; unit -> k = u / (BT/2), rows 2*(u % (BT/2)), +1
         const int k = u / (BT / 2), r2 = (u % (BT / 2)) * 2;
         const T* src = A + gemm_koff(g.kseg, g.sAseg, g.lda, k0) + (size_t)k * g.lda + (i0 + r2);
-        if (a_vec) {
+        if constexpr (VEC) {
           const T2 v = *reinterpret_cast<const T2*>(src);
           ra[2 * s] = v.x; ra[2 * s + 1] = v.y;
         } else {
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(256, BT == 128 ? 2 : 3) void gemm_mfma_kernel_t(Gem
       } else if (TRANSB == 0) {
         const int k = u / (BT / 2), r2 = (u % (BT / 2)) * 2;
         const T* src = B + gemm_koff(g.kseg, g.sBseg, g.ldb, k0) + (size_t)k * g.ldb + (j0 + r2);
-        if (b_vec) {
+        if constexpr (VEC) {
           const T2 v = *reinterpret_cast<const T2*>(src);
           rb[2 * s] = v.x; rb[2 * s + 1] = v.y;
         } else {
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(256, BT == 128 ? 2 : 3) void gemm_mfma_kernel_t(Gem
       } else {  // B is K x N: unit -> k pair = u % 8, n = u / 8
         const int k2 = (u % 8) * 2;
         const T* src = B + (size_t)bcol[s] * g.ldb + (k0 + k2);
-        if (b_vec) {
+        if constexpr (VEC) {
           const T2 v = *reinterpret_cast<const T2*>(src);
           rb[2 * s] = v.x; rb[2 * s + 1] = v.y;
         } else {
@@ -267,7 +271,7 @@ __global__ __launch_bounds__(256, BT == 128 ? 2 : 3) void gemm_mfma_kernel_t(Gem
       }
     }
   };
-  auto store_tiles = [&](int buf) {
+  auto store_tiles = [&](int buf, const T (&ra)[2 * NU], const T (&rb)[2 * NU]) {
 #pragma unroll
     for (int s = 0; s < NU; ++s) {
       const int u = tid + 256 * s;
@@ -297,33 +301,84 @@ __global__ __launch_bounds__(256, BT == 128 ? 2 : 3) void gemm_mfma_kernel_t(Gem
                          !((g.mode == GEMM_LOWER) && (i0 + wm * WT + WT - 1 < j0 + wn * WT));
 
   const int nk = (ke - kb) / GBK;
-  if (nk > 0) {
-    load_tiles(kb);
-    store_tiles(0);
-  }
-  __syncthreads();
   const int l15 = lane & 15, l4 = lane >> 4;
-  for (int it = 0; it < nk; ++it) {
-    const int buf = it & 1;
-    if (it + 1 < nk) load_tiles(kb + (it + 1) * GBK);
-    if (wave_live) {
+  auto multiply = [&](int buf) {
+    if (!wave_live) return;
 #pragma unroll
-      for (int kk = 0; kk < GBK; kk += 4) {
-        T af[MI], bf[MI];
+    for (int kk = 0; kk < GBK; kk += 4) {
+      T af[MI], bf[MI];
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) af[mi] = As[buf][kk + l4][wm * WT + mi * 16 + l15];
+      for (int mi = 0; mi < MI; ++mi) af[mi] = As[buf][kk + l4][wm * WT + mi * 16 + l15];
 #pragma unroll
-        for (int ni = 0; ni < MI; ++ni) bf[ni] = Bs[buf][kk + l4][(wn * WT + ni * 16 + l15) ^ bswz(kk + l4)];
+      for (int ni = 0; ni < MI; ++ni) bf[ni] = Bs[buf][kk + l4][(wn * WT + ni * 16 + l15) ^ bswz(kk + l4)];
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < MI; ++ni)
-            acc[mi][ni] = gemm_mfma16(bf[ni], af[mi], acc[mi][ni]);
-      }
+        for (int ni = 0; ni < MI; ++ni)
+          acc[mi][ni] = gemm_mfma16(bf[ni], af[mi], acc[mi][ni]);
     }
-    if (it + 1 < nk) store_tiles(buf ^ 1);
+  };
+  // The loads run TWO chunks ahead of the matrix instructions (a chunk is 16 - 64 of them per wave, 0.4 - 1.7 us: with one chunk of lead a
+  // workgroup waited for memory in every trip and only its neighbours on the CU filled the gap).  Chunk c sits in LDS buffer c & 1; while it is
+  // multiplied, chunk c + 1 waits in one register set and chunk c + 2 is being loaded into the other.  The loads of the steady loop stand under no
+  // condition - the compiler then counts them (s_waitcnt vmcnt(n) leaves the newer set in flight; after a branch it waits for everything) - so the
+  // last one to three chunks run in a tail of their own.
+  // (the FP64 128 x 128 tile holds 128 accumulator registers: a second staging set makes it spill - it keeps one chunk of lead)
+  constexpr bool DEEP = (BT == 64) || (sizeof(T) == 4);
+  auto run = [&](auto vec) {
+    if constexpr (!DEEP) {
+      if (nk > 0) {
+        load_tiles(vec, kb, raA, rbA);
+        store_tiles(0, raA, rbA);
+      }
+      __syncthreads();
+      for (int it = 0; it < nk; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < nk) load_tiles(vec, kb + (it + 1) * GBK, raA, rbA);
+        multiply(buf);
+        if (it + 1 < nk) store_tiles(buf ^ 1, raA, rbA);
+        __syncthreads();
+      }
+      return;
+    }
+    if (nk > 0) {
+      load_tiles(vec, kb, raA, rbA);
+      if (nk > 1) load_tiles(vec, kb + GBK, raB, rbB);
+      store_tiles(0, raA, rbA);
+    }
     __syncthreads();
-  }
+    int it = 0;
+    for (; it + 3 < nk; it += 2) {
+      load_tiles(vec, kb + (it + 2) * GBK, raA, rbA);
+      multiply(0);
+      store_tiles(1, raB, rbB);
+      __syncthreads();
+      load_tiles(vec, kb + (it + 3) * GBK, raB, rbB);
+      multiply(1);
+      store_tiles(0, raA, rbA);
+      __syncthreads();
+    }
+    // here: chunk `it` in LDS buffer 0, chunk it + 1 (if any) in register set B, nothing else requested
+    const int rem = nk - it;
+    if (rem == 1) {
+      multiply(0);
+    } else if (rem == 2) {
+      multiply(0);
+      store_tiles(1, raB, rbB);
+      __syncthreads();
+      multiply(1);
+    } else if (rem == 3) {
+      load_tiles(vec, kb + (it + 2) * GBK, raA, rbA);
+      multiply(0);
+      store_tiles(1, raB, rbB);
+      __syncthreads();
+      multiply(1);
+      store_tiles(0, raA, rbA);
+      __syncthreads();
+      multiply(0);
+    }
+  };
+  if (a_vec && b_vec) run(std::true_type{}); else run(std::false_type{});
 
   if (!wave_live) return;
   // D[row][col = l15]: row <-> j (B index), col <-> i (A index)
