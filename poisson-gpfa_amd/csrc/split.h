@@ -13,6 +13,7 @@
 // accumulation over <= 16 trials ~ 2e-6: below 1e-9 of the result), partial sums per group of trials reduced in FP64.
 // The caller measures eps ||Wt|| per chunk and keeps the FP64 product above a threshold (pgpfa.hip).
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 
 namespace pgpfa {
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void syrk_f16x2_kernel(SyrkF16Args a) {
   // all 64 banks once (a padded row stride of 40 halves was conflict-free for 16 CONSECUTIVE lanes only: 2-way in the real groups), and the
   // staging stores (8 consecutive lanes = rows 4 apart, one chunk) are 2-way instead of 4-way.  No padding: 32 KB per workgroup.
   auto lidx = [](int row, int chunk) { return row * LS + ((chunk ^ ((4 - ((row >> 2) & 3)) & 3)) << 3); };
-  __shared__ __attribute__((aligned(16))) _Float16 Ah[BT * LS], Al[BT * LS], Bh[BT * LS], Bl[BT * LS];
+  __shared__ __attribute__((aligned(16))) _Float16 Ah[2][BT * LS], Al[2][BT * LS], Bh[2][BT * LS], Bl[2][BT * LS];     // two stages: 64 KB
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -268,34 +269,42 @@ __global__ __launch_bounds__(256, 2) void syrk_f16x2_kernel(SyrkF16Args a) {
   const bool stage = !(is_b && diag);
   // 16-byte loads need rows on 4-float boundaries inside the slab (ts, ldd multiples of 4); rows at or past T are read too when the
   // latent stride leaves room for them (ts >= round_up(T, 4)): those rows only reach outputs that are never stored
-  const bool vec = ((a.ts & 3) == 0) && ((a.ldd & 3) == 0) && (row0 + 3 < a.ts) && ((((size_t)a.D) & 15) == 0) && ((a.sD & 3) == 0);
-  float4v_t v4[8];
+  // (uniform over the workgroup: the two forms of the loop are separate code paths with barriers inside)
+  const bool vec = ((a.ts & 3) == 0) && ((a.ldd & 3) == 0) && (i0 + BT <= a.ts) && (j0 + BT <= a.ts) && ((((size_t)a.D) & 15) == 0) && ((a.sD & 3) == 0);
+  // Two staging register sets and two LDS stages: while step s is multiplied out of stage s & 1, step s + 1 waits in one register set (it is
+  // split into halves and stored into the other stage after the matrix instructions have been issued - the conversion's vector work then runs
+  // under them) and step s + 2 is being loaded into the other set: one barrier per step, the loads two steps ahead.  Every load is unconditional -
+  // threads without a tile to stage (the B side of diagonal tiles) read one fixed line, columns past ract a clamped one - so that the compiler counts
+  // the loads in flight instead of waiting for all of them after a branch.  (Round 3's form: one stage, two barriers per step, loads one step
+  // ahead: matrix cores 30 %, vector ALU 37 %, LDS 28 % of the time - they added up.)
+  float4v_t vA[8], vB[8];
   const int steps_per_slot = (a.ract + KS - 1) / KS;
   const int nsteps = (s_end - s_begin) * steps_per_slot;
-  auto load = [&](int step) {
-    if (!stage) return;
-    const int s = s_begin + step / steps_per_slot;
-    const int c0 = (step % steps_per_slot) * KS + co * 8;
-    const float* base = a.D + (size_t)s * a.sD + (size_t)k * a.ts;
+  auto load = [&](auto vecc, int step, float4v_t (&v4)[8]) {
+    constexpr bool VEC = decltype(vecc)::value;
+    const int st = min(step, nsteps - 1);
+    const int s = s_begin + st / steps_per_slot;
+    const int c0 = (st % steps_per_slot) * KS + co * 8;
+    const float* base = stage ? a.D + (size_t)s * a.sD + (size_t)k * a.ts : a.D;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int c = c0 + j;
-      const bool in = c < a.ract;
+      const bool in = stage && c < a.ract;
       const size_t off = (size_t)(in ? c : 0) * a.ldd;
       float4v_t x;
-      if (vec) {
-        x = *reinterpret_cast<const float4v_t*>(base + off + row0);
+      if constexpr (VEC) {
+        x = *reinterpret_cast<const float4v_t*>(base + off + (stage ? row0 : 0));
       } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) x[r] = base[off + min(row0 + r, a.T - 1)];
+        for (int r = 0; r < 4; ++r) x[r] = base[off + (stage ? min(row0 + r, a.T - 1) : 0)];
       }
       v4[j] = in ? x : float4v_t{0.f, 0.f, 0.f, 0.f};
     }
   };
-  auto store = [&]() {
+  auto store = [&](int buf, const float4v_t (&v4)[8]) {
     if (!stage) return;
-    _Float16* Hh = is_b ? Bh : Ah;
-    _Float16* Hl = is_b ? Bl : Al;
+    _Float16* Hh = is_b ? Bh[buf] : Ah[buf];
+    _Float16* Hl = is_b ? Bl[buf] : Al[buf];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       half8_t h, l;
@@ -311,39 +320,52 @@ __global__ __launch_bounds__(256, 2) void syrk_f16x2_kernel(SyrkF16Args a) {
     }
   };
   const int l15 = lane & 15, l4 = lane >> 4;
-  const _Float16* Bhs = diag ? Ah : Bh;
-  const _Float16* Bls = diag ? Al : Bl;
-  if (nsteps > 0) load(0);
-  for (int step = 0; step < nsteps; ++step) {
-    __syncthreads();                                   // the previous step's fragments have been read
-    store();
-    __syncthreads();
-    if (step + 1 < nsteps) load(step + 1);
-    if (wave_live) {
-      half8_t ah[4], al[4], bh[4], bl[4];
+  auto multiply = [&](int buf) {
+    if (!wave_live) return;
+    const _Float16* Bhs = diag ? Ah[buf] : Bh[buf];
+    const _Float16* Bls = diag ? Al[buf] : Bl[buf];
+    half8_t ah[4], al[4], bh[4], bl[4];
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi) {
-        const int r = lidx(wm * 64 + mi * 16 + l15, l4);
-        ah[mi] = *reinterpret_cast<const half8_t*>(&Ah[r]);
-        al[mi] = *reinterpret_cast<const half8_t*>(&Al[r]);
-      }
+    for (int mi = 0; mi < 4; ++mi) {
+      const int r = lidx(wm * 64 + mi * 16 + l15, l4);
+      ah[mi] = *reinterpret_cast<const half8_t*>(&Ah[buf][r]);
+      al[mi] = *reinterpret_cast<const half8_t*>(&Al[buf][r]);
+    }
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int r = lidx(wn * 64 + ni * 16 + l15, l4);
+      bh[ni] = *reinterpret_cast<const half8_t*>(&Bhs[r]);
+      bl[ni] = *reinterpret_cast<const half8_t*>(&Bls[r]);
+    }
+    // issued as (B fragment) x (A fragment): the lane index then runs along i, the contiguous index of the column-major output
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) {
-        const int r = lidx(wn * 64 + ni * 16 + l15, l4);
-        bh[ni] = *reinterpret_cast<const half8_t*>(&Bhs[r]);
-        bl[ni] = *reinterpret_cast<const half8_t*>(&Bls[r]);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[ni], ah[mi], acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[ni], al[mi], acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[ni], ah[mi], acc[mi][ni], 0, 0, 0);
       }
-      // issued as (B fragment) x (A fragment): the lane index then runs along i, the contiguous index of the column-major output
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[ni], ah[mi], acc[mi][ni], 0, 0, 0);
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[ni], al[mi], acc[mi][ni], 0, 0, 0);
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[ni], ah[mi], acc[mi][ni], 0, 0, 0);
-        }
+  };
+  auto run = [&](auto vecc) {
+    if (nsteps <= 0) return;
+    load(vecc, 0, vA);
+    load(vecc, 1, vB);
+    store(0, vA);
+    __syncthreads();
+    for (int step = 0; step < nsteps; step += 2) {
+      load(vecc, step + 2, vA);
+      multiply(0);
+      if (step + 1 < nsteps) store(1, vB);
+      __syncthreads();
+      if (step + 1 >= nsteps) break;
+      load(vecc, step + 3, vB);
+      multiply(1);
+      if (step + 2 < nsteps) store(0, vA);
+      __syncthreads();
     }
-  }
+  };
+  if (vec) run(std::true_type{}); else run(std::false_type{});
   if (!wave_live) return;
   // accumulator register r of a lane: output row (of the issued product) 4 l4 + r  <->  j, column l15  <->  i
   double* C = a.part + (size_t)(k * a.ngroups + g) * a.T * a.T;
