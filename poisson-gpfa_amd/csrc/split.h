@@ -529,9 +529,20 @@ __global__ void sum_groups_kernel(const double* __restrict__ part, int ngroups, 
   if (e >= (size_t)M * N) return;
   const int i = (int)(e % M), j = (int)(e / M);
   const size_t src = (lower > 0 && (i / lower) < (j / lower)) ? (size_t)i * M + j : e;
-  double s = 0.0;
-  for (int g = 0; g < ngroups; ++g) s += part[(size_t)g * M * N + src];
-  out[e] = s;
+  // eight independent partial sums: eight loads in flight per thread (a launch has a few dozen workgroups and up to 256 groups to walk: one
+  // running sum made it a chain of 256 memory round trips)
+  const size_t gs = (size_t)M * N;
+  double s8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  int g = 0;
+  for (; g + 8 <= ngroups; g += 8) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(g + u) * gs + src];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s8[u] += v[u];
+  }
+  for (; g < ngroups; ++g) s8[0] += part[(size_t)g * gs + src];
+  out[e] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
 }
 
 // Pacc[k][T x T] (ld = Tp, full symmetric) += the split sum of latent k:
