@@ -87,6 +87,8 @@ int pgpfa_destroy(pgpfa_ctx* ctx);
  * "thin_products" (2: the three products of the low-rank preconditioner application - the block-diagonal F^T t and F v, and Sb u - as kernels of
  * their own that feed the matrix cores straight from global memory, csrc/thin.h; 1: the two block-diagonal ones only; 0: products of the general
  * GEMM kernel, block-sparse and with split-K),
+ * "mt_fill" (1: before a slot's L^-T is formed in the low-rank covariance engine only the entries its consumers read below the diagonal are cleared -
+ * the strictly lower part of p rectangles of r_k rows - where every consumer starts at the latent's own columns; 0: the whole rpad x rpad slab),
  * "cross_kernel" (1: the cross term of that split form in a kernel with all rows of a latent in one workgroup, 128 rows per
  * launch; 0: through the general GEMM kernel),
  * "split_cov" (1: the sum over trials of the T x T covariance blocks by the exact split form of csrc/split.h - FP64 cross term, FP16

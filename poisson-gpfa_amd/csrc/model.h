@@ -2915,6 +2915,23 @@ __global__ void fill_slabs_kernel(double* __restrict__ p, long long stride, size
     if (i < n) dst[i] = v;
   }
 }
+// Zero what the consumers of the low-rank covariance engine read BELOW the diagonal of a slot's L^-T slab: they take rows [roff_k, roff_k+1) of latent k and
+// columns from c0_k = roff_k rounded down to `ctile` on (the Yt product; the cross / first term of the split form start at roff_k itself), the inverse writes
+// the diagonal 128 x 128 blocks (zeros included) and everything above them, so only the strictly lower entries of these p rectangles can be stale.
+// ~ sum r_k^2 entries per slot instead of rpad^2.  grid = (p, slots), block = 256.
+__global__ void clear_lower_reads_kernel(double* __restrict__ Mt, long long sM, int ld, const int* __restrict__ roff, int ctile,
+                                         const int* __restrict__ slots) {
+  const int k = blockIdx.x;
+  double* M = Mt + (size_t)(slots ? slots[blockIdx.y] : blockIdx.y) * sM;
+  const int r0 = roff[k], r1 = roff[k + 1];
+  const int c0 = (r0 / ctile) * ctile;
+  const int nrow = r1 - r0, ncol = r1 - c0;
+  for (int e = threadIdx.x; e < nrow * ncol; e += blockDim.x) {
+    const int i = e % nrow, c = e / nrow;
+    const int row = r0 + i, col = c0 + c;
+    if (col < row) M[(size_t)col * ld + row] = 0.0;
+  }
+}
 __global__ void fill_kernel(double* __restrict__ p, size_t n, double v) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;

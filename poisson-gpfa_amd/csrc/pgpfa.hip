@@ -178,6 +178,7 @@ struct pgpfa_ctx {
   float* W32 = nullptr;                          // packed single-precision curvature triangles of the chunk's slots (PCG matvec)
   double* sc_part2 = nullptr;                    // per (slot, tile) partial sums r.z, r.r
   int pcg_fused = 1; bool pcg_w32 = true;        // pcg_fused: 0 off, 1 when the chunk is large enough, 2 always (tests)
+  int mt_fill = 1;                               // 1: before the inverse only the entries of the L^-T slabs that are read and not written are cleared; 0: the whole slab
   int pcg_xcd = 1;                               // 1: the per-bin kernels of the inner step place the bin tiles of a slot group on one XCD (pcg_cg_wg)
   int pcg_adapt = 1;                             // 1: launches of the host-free inner step sized by the mirrored live count, 16 / 8 / 4 slots per workgroup; 0: by the solve's first count
   int pcg_form = 1;                              // host-free inner iteration (pcg.h): 1 two tile-parallel kernels per step, no prior mat-vec (pcg_cg_a/b_kernel);
@@ -1429,6 +1430,7 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
   else if (k == "pcg_form") c->pcg_form = (int)v;
   else if (k == "pcg_adapt") c->pcg_adapt = (int)v;
   else if (k == "pcg_xcd") c->pcg_xcd = (int)v;
+  else if (k == "mt_fill") c->mt_fill = (int)v;
   else if (k == "mix_slot") c->mix_slot = (int)v;
   else if (k == "thin_products") c->thin_products = (int)v;
   else if (k == "copy_kernels") c->copy_kernels = (v != 0.0);
@@ -2323,8 +2325,13 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool 
     HIPC(hipGetLastError());
     return 0;
   }
-  hipLaunchKernelGGL(fill_slabs_kernel, dim3((unsigned)(((size_t)rpad * rpad + 1023) / 1024), nb), dim3(256), 0, c->st, lw.Mt, lw.sM,
-                     (size_t)rpad * rpad, 0.0);
+  // L^-T's slab holds whatever the last use left (another rank layout, the factor of a dense pass): clear what will be read and not written - all of it,
+  // or, when every consumer starts at the latent's own columns (skip_zero_cols), the strictly lower entries of the p rectangles they read
+  if (skip_zero_cols && c->mt_fill)
+    hipLaunchKernelGGL(clear_lower_reads_kernel, dim3(p, nb), dim3(256), 0, c->st, lw.Mt, (long long)lw.sM, rpad, c->d_roff, ctile, c->ident);
+  else
+    hipLaunchKernelGGL(fill_slabs_kernel, dim3((unsigned)(((size_t)rpad * rpad + 1023) / 1024), nb), dim3(256), 0, c->st, lw.Mt, lw.sM,
+                       (size_t)rpad * rpad, 0.0);
   CHK(inverse_t(c, lw, c->ident, nb));
   // c. Yt = F Mts  (n x rpad, ld = c->ld) into the factor slab (the factor itself is dead now)
   // (column tiles left of roff[k] skipped under skip_zero_cols, see above)

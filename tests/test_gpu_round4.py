@@ -242,3 +242,43 @@ def test_alternative_paths_give_the_same_numbers(c1, option):
     assert abs(a[0] - b[0]) <= tol * abs(a[0]) and abs(a[4] - b[4]) <= tol * abs(a[4])
     for i in (1, 2, 3, 5):
         assert np.max(np.abs(a[i] - b[i])) <= tol * np.max(np.abs(a[i]))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# clearing only what is read of the L^-T slabs
+# ---------------------------------------------------------------------------------------------------------------
+def test_partial_clear_of_the_inverse_slabs_is_bitwise_the_full_clear():
+    """`mt_fill = 1` clears, before a slot's L^-T is formed, only the entries the consumers of the low-rank engine read and the inverse does not write.  If
+    that set is right the results do not change by a bit against clearing the whole slab - over E-steps whose timescales (and with them the rank layout of
+    the slabs) change from one to the next, so that a stale entry of the previous layout would be a wrong number, not a zero: E-step objective, posterior
+    means, covariance blocks and PautoSum compared with `==`."""
+    from funs import _hip
+    q, p, T, R = 60, 6, 200, 24
+    rng = np.random.default_rng(5)
+    _, Ys, _ = orc.synth_dataset(q, p, T, R, seed=3, dOffset=0.0)
+    Y = np.stack(Ys).astype(np.uint8)
+    C = 0.3 * rng.standard_normal((q, p))
+    d = np.log(Y.mean(axis=(0, 2)) + 0.1)
+    taus = [np.linspace(0.3, 0.08, p), np.linspace(0.05, 0.25, p), np.full(p, 0.12), np.linspace(0.4, 0.03, p)]
+    out = {}
+    for fill in (1, 0):
+        ctx = _hip.Context(q, p, T, R, 10.0)
+        try:
+            ctx.upload_counts(Y)
+            ctx.set_option('cov_mode', 2)
+            ctx.set_option('mt_fill', fill)
+            res = []
+            for tau in taus:
+                ctx.set_params(C, d, tau)
+                obj, _, status = ctx.estep_laplace()
+                assert np.all(status == 0) and ctx.info('plan_lowrank') == 1.0
+                ctx.mstep_precomp()
+                res.append((obj, ctx.post_mean().copy(), ctx.post_vsm().copy(), ctx.pautosum().copy(), ctx.info('lowrank_rtot')))
+            out[fill] = res
+        finally:
+            ctx.close()
+    assert len({r[4] for r in out[1]}) > 1                      # the rank did change between the E-steps
+    for a, b in zip(out[1], out[0]):
+        assert a[0] == b[0]
+        for i in (1, 2, 3):
+            assert np.array_equal(a[i], b[i])
