@@ -87,6 +87,7 @@ int pgpfa_destroy(pgpfa_ctx* ctx);
  * "thin_products" (2: the three products of the low-rank preconditioner application - the block-diagonal F^T t and F v, and Sb u - as kernels of
  * their own that feed the matrix cores straight from global memory, csrc/thin.h; 1: the two block-diagonal ones only; 0: products of the general
  * GEMM kernel, block-sparse and with split-K),
+ * "overlap_factors" (1: in pgpfa_set_params the pivoted Cholesky of the Gram matrices runs on a side stream next to the Gram inverses; 0: one stream),
  * "mt_fill" (1: before a slot's L^-T is formed in the low-rank covariance engine only the entries its consumers read below the diagonal are cleared -
  * the strictly lower part of p rectangles of r_k rows - where every consumer starts at the latent's own columns; 0: the whole rpad x rpad slab),
  * "cross_kernel" (1: the cross term of that split form in a kernel with all rows of a latent in one workgroup, 128 rows per

@@ -85,6 +85,9 @@ struct pgpfa_ctx {
   int device = 0, q = 0, p = 0, T = 0, R = 0, n = 0, npad = 0, ld = 0, Tp = 0;
   double bin = 10.0, eps = 1e-3;
   hipStream_t st = nullptr;
+  hipStream_t st2 = nullptr;                     // side stream: the pivoted Cholesky of the Gram matrices (10 workgroups) next to the Gram inverses in pgpfa_set_params
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int overlap_factors = 1;                       // 1: use it; 0: one stream
   // options
   double xtol = 1e-5;
   int max_iter = 60;
@@ -1160,15 +1163,24 @@ int build_kinv(pgpfa_ctx* c) {
 
 
 // pivoted-Cholesky factors of the RBF part of every Gram matrix and the block tables of the r x r system
-int build_lowrank(pgpfa_ctx* c) {
+// (the pivoted Cholesky itself - p workgroups, a chain of r_k dependent steps each: 1-2 ms with the chip empty - on stream `st`)
+int launch_pivchol(pgpfa_ctx* c, hipStream_t st) {
   const int p = c->p, T = c->T, Tp = c->Tp;
   const int rmax = std::min(T, Tp);
   const size_t shm = ((size_t)2 * T + rmax + 16) * sizeof(double) + 16 * sizeof(int);
   if (T > 256)
-    hipLaunchKernelGGL((rbf_pivchol_kernel<512, 2>), dim3(p), dim3(1024), shm, c->st, c->Flr, Tp, T, c->tau, c->bin, c->eps, c->lr_tol, rmax, c->d_rank);
+    hipLaunchKernelGGL((rbf_pivchol_kernel<512, 2>), dim3(p), dim3(1024), shm, st, c->Flr, Tp, T, c->tau, c->bin, c->eps, c->lr_tol, rmax, c->d_rank);
   else
-    hipLaunchKernelGGL((rbf_pivchol_kernel<256, 1>), dim3(p), dim3(256), shm, c->st, c->Flr, Tp, T, c->tau, c->bin, c->eps, c->lr_tol, rmax, c->d_rank);
+    hipLaunchKernelGGL((rbf_pivchol_kernel<256, 1>), dim3(p), dim3(256), shm, st, c->Flr, Tp, T, c->tau, c->bin, c->eps, c->lr_tol, rmax, c->d_rank);
   HIPC(hipGetLastError());
+  return 0;
+}
+
+// (pivchol_launched: the kernel is already running on the side stream and c->ev_join marks its end)
+int build_lowrank(pgpfa_ctx* c, bool pivchol_launched = false) {
+  const int p = c->p, T = c->T, Tp = c->Tp;
+  if (pivchol_launched) HIPC(hipStreamWaitEvent(c->st, c->ev_join, 0));
+  else CHK(launch_pivchol(c, c->st));
   std::vector<int> r(p);
   CHK(dl_enqueue(c, r.data(), c->d_rank, sizeof(int) * p));
   CHK(dl_flush(c));
@@ -1317,6 +1329,11 @@ int pgpfa_create(pgpfa_ctx** out, int device, int q, int p, int T, int R, double
   c->Tp = round_up(T, NB);
   hipError_t se = hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking);
   if (se != hipSuccess) { delete c; return fail("hipStreamCreate: %s", hipGetErrorString(se)); }
+  if (hipStreamCreateWithFlags(&c->st2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+    (void)hipGetLastError();                                // (no side stream: everything stays on the one stream)
+    if (c->st2) { hipStreamDestroy(c->st2); c->st2 = nullptr; }
+  }
   int rc = 0;
   const size_t slab = (size_t)c->Tp * c->Tp;
   rc |= dmalloc(c, &c->Y, (size_t)R * q * T);
@@ -1410,6 +1427,9 @@ int pgpfa_destroy(pgpfa_ctx* c) {
   if (c->h_pcg) hipHostFree(c->h_pcg);
   if (c->h_seq) hipHostFree(c->h_seq);
   for (auto e : c->prof.pool) hipEventDestroy(e);
+  if (c->st2) { hipStreamSynchronize(c->st2); hipStreamDestroy(c->st2); }
+  if (c->ev_fork) hipEventDestroy(c->ev_fork);
+  if (c->ev_join) hipEventDestroy(c->ev_join);
   if (c->st) hipStreamDestroy(c->st);
   delete c;
   return 0;
@@ -1431,6 +1451,7 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
   else if (k == "pcg_adapt") c->pcg_adapt = (int)v;
   else if (k == "pcg_xcd") c->pcg_xcd = (int)v;
   else if (k == "mt_fill") c->mt_fill = (int)v;
+  else if (k == "overlap_factors") c->overlap_factors = (int)v;
   else if (k == "mix_slot") c->mix_slot = (int)v;
   else if (k == "thin_products") c->thin_products = (int)v;
   else if (k == "copy_kernels") c->copy_kernels = (v != 0.0);
@@ -1661,8 +1682,24 @@ int pgpfa_set_params(pgpfa_ctx* c, const double* C, const double* d, const doubl
     hipLaunchKernelGGL(poisson_tables_kernel, dim3(c->qpad), dim3(64), 0, c->st, c->C, c->q, c->p, c->qpad, c->ccu_cols, c->CCu, c->C16);
   hipLaunchKernelGGL(dual_table_kernel, dim3(c->qpad), dim3(64), 0, c->st, c->C, c->q, c->p, c->dual_ncol, c->dual_npd, c->dual_tbl);
   HIPC(hipGetLastError());
-  CHK(build_kinv(c));
-  CHK(build_lowrank(c));
+  // The two things built from the timescales do not depend on each other: the Gram inverses (p slots through the batched factor kernels: ~40 small
+  // launches, two host read-backs) and the pivoted Cholesky factors (one kernel of p workgroups).  The latter goes to the side stream first.
+  bool side = false;
+  if (c->overlap_factors && c->st2) {
+    if (hipEventRecord(c->ev_fork, c->st) == hipSuccess && hipStreamWaitEvent(c->st2, c->ev_fork, 0) == hipSuccess) {
+      CHK(launch_pivchol(c, c->st2));
+      HIPC(hipEventRecord(c->ev_join, c->st2));
+      side = true;
+    } else {
+      (void)hipGetLastError();
+    }
+  }
+  const int rc_kinv = build_kinv(c);
+  if (rc_kinv) {                                            // (never leave the side stream running into buffers a failed call may free)
+    if (side) (void)hipStreamSynchronize(c->st2);
+    return rc_kinv;
+  }
+  CHK(build_lowrank(c, side));
   c->have_params = true;
   return 0;
 }
