@@ -82,7 +82,8 @@ int pgpfa_destroy(pgpfa_ctx* ctx);
  * "splitk_below64" (400: products on 64 x 64 tiles are cut along k only below this many tiles),
  * "copy_kernels" (1: read-backs and uploads up to 256 KB move through host-mapped staging memory as one-workgroup kernels, and a flush is a
  * kernel that raises a sequence number the host spins on - no hipMemcpyAsync / hipStreamSynchronize on those paths; 0: the runtime's copies),
- * "mix_slot" (1: the mixing pass of that split form with a thread per bin and a workgroup per (slot, 256 bins) that walks whole columns of
+ * "mix_slot" (2: as 1 with the next pair of columns requested before this pair's arithmetic - two register sets, no branch in the loop - where
+ * p is a template width and the rank a multiple of 4, else 1; 1: the mixing pass of that split form with a thread per bin and a workgroup per (slot, 256 bins) that walks whole columns of
  * the slab - contiguous 2-KB runs instead of 512-byte pieces, no LDS; up to 10 latents; 0: mix_vsm_split_kernel, 64 bins x 4 columns),
  * "thin_products" (2: the three products of the low-rank preconditioner application - the block-diagonal F^T t and F v, and Sb u - as kernels of
  * their own that feed the matrix cores straight from global memory, csrc/thin.h; 1: the two block-diagonal ones only; 0: products of the general

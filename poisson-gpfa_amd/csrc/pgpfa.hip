@@ -219,7 +219,7 @@ struct pgpfa_ctx {
   bool last_cov_lowrank = false;
   bool shared_pcg = true;
   bool pcg_trace = false;
-  int mix_slot = 1;                           // option mix_slot: the mixing pass of the split form with a thread per bin and whole columns per workgroup (split.h)
+  int mix_slot = 2;                           // option mix_slot: the mixing pass of the split form with a thread per bin and whole columns per workgroup (split.h)
   bool cross_kernel = true;                       // option cross_kernel = 0: the cross term of the split form through the general GEMM kernel
   bool measure_mix = false;                       // option measure_mix: record max_t eps ||Wt_t|| of every covariance pass
   bool time_newton = false;                       // option time_newton: HIP events around the inner PCG solves (last_newton_solve_ms / _bytes)
@@ -2130,6 +2130,12 @@ static int accumulate_split(pgpfa_ctx* c, const CholWS& lw, int nb, int ract, in
   dispatch_pw(p, [&](auto pw) {
     constexpr int PW = decltype(pw)::value;
     if constexpr (PW <= 10) {
+      if (c->mix_slot >= 2 && p == PW && ract % 4 == 0) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mix_slot2_kernel<PW, 256, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mix_slot_lds(PW, 256));
+        hipLaunchKernelGGL((mix_slot2_kernel<PW, 256, 2>), dim3((T + 255) / 256, nb), dim3(256), mix_slot_lds(PW, 256), c->st, (const double*)lw.H, (long long)lw.sH, c->ld, D, sD, ldd,
+                           c->Gbin, sW, T, ract, c->eps, c->vsm, c->ident, c->trial_of_slot, c->d_roff, ctile, Ts);
+        return;
+      }
       if (c->mix_slot) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mix_slot_kernel<PW, 256, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mix_slot_lds(PW, 256));
         hipLaunchKernelGGL((mix_slot_kernel<PW, 256, 2>), dim3((T + 255) / 256, nb), dim3(256), mix_slot_lds(PW, 256), c->st, (const double*)lw.H, (long long)lw.sH, c->ld, D, sD, ldd,

@@ -211,6 +211,101 @@ __global__ __launch_bounds__(NTH, 1) void mix_slot_kernel(const double* __restri
 }
 inline size_t mix_slot_lds(int pw, int nth) { return (size_t)(pw * (pw + 1) / 2) * nth * sizeof(double); }
 
+// The same pass with the columns of the NEXT trip requested before this trip's arithmetic (two register sets), for p == PW and ract a multiple of 2 U:
+// the kernel runs one wave per SIMD (its G_t column fills LDS), so nothing else hides a memory round trip - the first form spent one per trip, 2.5 us for
+// 0.5 us of arithmetic.  No branch in the loop: loads at clamped addresses, masks as selects, and a thread past T repeats the arithmetic of bin T - 1 and
+// stores the same numbers to the same place (so that the stores stand under no condition either: the compiler counts loads AND stores in flight).
+template <int PW, int NTH, int U>
+__global__ __launch_bounds__(NTH, 1) void mix_slot2_kernel(const double* __restrict__ Yt, long long sY, int ldy, float* __restrict__ D, long long sD, int ldd,
+                                                           const double* __restrict__ G, long long sG, int T, int ract, double eps,
+                                                           double* __restrict__ vsm, const int* __restrict__ slots,
+                                                           const int* __restrict__ trial_of_slot, const int* __restrict__ roff, int col_tile, int ts) {
+  constexpr int NPAIR = PW * (PW + 1) / 2, p = PW, pp = PW * PW;
+  extern __shared__ double mix_slot_g[];
+  const int slot = slots[blockIdx.y];
+  const int t = blockIdx.x * NTH + threadIdx.x;
+  const int tc = t < T ? t : T - 1;
+  const double* gsrc = G + (size_t)slot * sG + (size_t)tc * pp;
+  double* gs = mix_slot_g + threadIdx.x;
+  double acc[NPAIR];
+#pragma unroll
+  for (int a = 0; a < PW; ++a)
+#pragma unroll
+    for (int c2 = 0; c2 <= a; ++c2) {
+      gs[(a * (a + 1) / 2 + c2) * NTH] = gsrc[a * p + c2];
+      acc[a * (a + 1) / 2 + c2] = 0.0;
+    }
+  int c0[PW], cmax = 0;
+#pragma unroll
+  for (int k = 0; k < PW; ++k) {
+    c0[k] = roff ? (roff[k] / col_tile) * col_tile : 0;
+    cmax = c0[k] > cmax ? c0[k] : cmax;
+  }
+  const double* y = Yt + (size_t)slot * sY + tc;
+  float* d = D + (size_t)slot * sD + tc;
+  auto fetch = [&](int b0, double (&v)[U][PW]) {
+    const int bb = b0 < ract ? b0 : ract - U;                 // (past the end: the last trip again)
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int k = 0; k < PW; ++k) {
+        const int b = bb + u;
+        const int bc = b < c0[k] ? c0[k] : b;                  // (left of a latent's first column nothing was written: read that column, mask below)
+        v[u][k] = y[(size_t)bc * ldy + (size_t)k * ts];
+      }
+  };
+  auto process = [&](int b0, double (&v)[U][PW]) {
+    double m[U][PW];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int k = 0; k < PW; ++k) {
+        v[u][k] = (b0 < cmax && b0 + u < c0[k]) ? 0.0 : v[u][k];
+        m[u][k] = 0.0;
+      }
+#pragma unroll
+    for (int a = 0; a < PW; ++a)
+#pragma unroll
+      for (int c2 = 0; c2 <= a; ++c2) {
+        const double gg = gs[(a * (a + 1) / 2 + c2) * NTH];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          m[u][a] += gg * v[u][c2];
+          if (c2 != a) m[u][c2] += gg * v[u][a];
+        }
+      }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int k = 0; k < PW; ++k) d[(size_t)(b0 + u) * ldd + (size_t)k * ts] = (float)(v[u][k] - m[u][k]);
+#pragma unroll
+      for (int a = 0; a < PW; ++a)
+#pragma unroll
+        for (int c2 = 0; c2 <= a; ++c2) acc[a * (a + 1) / 2 + c2] += m[u][a] * m[u][c2];
+    }
+  };
+  double vA[U][PW], vB[U][PW];
+  fetch(0, vA);
+  for (int b0 = 0; b0 < ract; b0 += 2 * U) {
+    fetch(b0 + U, vB);
+    asm volatile("" ::: "memory");                      // (the LDS reads of G_t stay inside the trip, behind the requests of the next one)
+    process(b0, vA);
+    fetch(b0 + 2 * U, vA);
+    asm volatile("" ::: "memory");
+    process(b0 + U, vB);
+  }
+  if (t >= T) return;
+  double* vdst = vsm + ((size_t)trial_of_slot[slot] * T + t) * pp;
+#pragma unroll
+  for (int a = 0; a < PW; ++a)
+#pragma unroll
+    for (int c2 = 0; c2 <= a; ++c2) {
+      const double val = eps * gs[(a * (a + 1) / 2 + c2) * NTH] + acc[a * (a + 1) / 2 + c2];
+      vdst[a * p + c2] = val;
+      vdst[c2 * p + a] = val;
+    }
+}
+
 // part[(k * ngroups + g)][T x T] (column-major, ld = T, lower 64 x 64 wave tiles) = sum over the slots of group g, over columns b < ract,
 // of D_k[:, b] D_k[:, b]^T, with D_k[t, b] = D[slot][(k ts + t) + b ldd] (single precision), evaluated on the FP16 matrix cores as
 // described at the top of this file.  Group g holds slots [g sps, min((g + 1) sps, nslots)).

@@ -216,7 +216,7 @@ def test_dual_variational_through_the_fixed_point_vs_reference(funs_mod):
 # ---------------------------------------------------------------------------------------------------------------
 # copies as kernels / the runtime's copies; the two mixing passes
 # ---------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('option', [('copy_kernels', 0), ('mix_slot', 0)])
+@pytest.mark.parametrize('option', [('copy_kernels', 0), ('mix_slot', 0), ('mix_slot', 1)])
 def test_alternative_paths_give_the_same_numbers(c1, option):
     """The small copies through the runtime (`copy_kernels = 0`: hipMemcpyAsync + hipStreamSynchronize instead of kernels through mapped staging and
     a sequence number) and the 64-bin mixing pass of the split accumulation (`mix_slot = 0`) against the defaults on the same E-step + M-step
