@@ -91,6 +91,8 @@ int pgpfa_destroy(pgpfa_ctx* ctx);
  * "overlap_factors" (1: in pgpfa_set_params the pivoted Cholesky of the Gram matrices runs on a side stream next to the Gram inverses; 0: one stream),
  * "mt_fill" (1: before a slot's L^-T is formed in the low-rank covariance engine only the entries its consumers read below the diagonal are cleared -
  * the strictly lower part of p rectangles of r_k rows - where every consumer starts at the latent's own columns; 0: the whole rpad x rpad slab),
+ * "mix_wide" (1: the in-place mixing pass y <- G_t y of the full-width covariance product at 17..20 latents with the lanes along the bins - 64 bins x 4 waves
+ * per workgroup, G_t's rows in registers, y and G_t y exchanged through LDS, csrc/model.h mix_vsm_wide2_kernel; 0: mix_vsm_wide_kernel, lanes along the latents),
  * "cross_kernel" (1: the cross term of that split form in a kernel with all rows of a latent in one workgroup, 128 rows per
  * launch; 0: through the general GEMM kernel),
  * "split_cov" (1: the sum over trials of the T x T covariance blocks by the exact split form of csrc/split.h - FP64 cross term, FP16

@@ -2740,6 +2740,104 @@ __global__ void mix_vsm_wide_kernel(double* __restrict__ Yt, long long sY, int l
   }
 }
 
+// The same pass with lanes along the BINS (the contiguous index of the slab's rows): mix_vsm_wide_kernel puts the latents on the lanes, so every 8-byte access of a
+// wave is a line of its own, and it meets two barriers per column with 8 bins per workgroup - 199 ms for the finalize pass of config 5 (82 GB moved at 0.4 TB/s).
+// Here a workgroup is 64 bins x 4 waves; wave w owns rows a = w + 4 i of G_t (in registers: PW / 4 rows of PW entries) and of the accumulated block; per column
+// every wave reads its rows of y (512-byte runs), the 4 waves exchange y and m = G_t y through LDS (double-buffered by column parity), the next column's loads
+// are in flight meanwhile.  No branch around a load or a store in the loop: clamped addresses, bins past T repeat bin T - 1, rows past p write to `sink`
+// (>= 64 doubles of scratch).  grid = (ceil(T / 64), nslots), block = 256, PW in {20, 24, 32} >= p.
+template <int PW>
+__global__ __launch_bounds__(256, 1) void mix_vsm_wide2_kernel(double* __restrict__ Yt, long long sY, int ldy, const double* __restrict__ G, long long sG, int T,
+                                                               int p, int ncol, double eps, double* __restrict__ vsm, const int* __restrict__ slots,
+                                                               const int* __restrict__ trial_of_slot, int ts, double* __restrict__ sink) {
+  constexpr int R = PW / 4;
+  __shared__ double vs[2][PW][64];
+  __shared__ double ms[2][PW][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slot = slots[blockIdx.y];
+  const int t = blockIdx.x * 64 + lane;
+  const int tc = t < T ? t : T - 1;
+  const int pp = p * p;
+  const double* gsrc = G + (size_t)slot * sG + (size_t)tc * pp;
+  double g[R][PW];
+  double* yp[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const int a = wave + 4 * i;
+    const int ac = a < p ? a : 0;
+#pragma unroll
+    for (int k = 0; k < PW; ++k) {
+      const double v = gsrc[ac * p + (k < p ? k : 0)];
+      g[i][k] = (a < p && k < p) ? v : 0.0;
+    }
+    yp[i] = (a < p) ? Yt + (size_t)slot * sY + (size_t)a * ts + tc : sink + lane;
+  }
+  // rows >= p of the exchange buffers are read (against zeros of g, and as m of rows that are never stored): keep them finite
+  for (int e = threadIdx.x; e < 2 * PW * 64; e += 256) { (&vs[0][0][0])[e] = 0.0; (&ms[0][0][0])[e] = 0.0; }
+  // acc[i][c]: row a = wave + 4 i against columns c < 4 (i + 1) (c <= a needs no more)
+  double acc[R][4 * R];
+#pragma unroll
+  for (int i = 0; i < R; ++i)
+#pragma unroll
+    for (int c2 = 0; c2 < 4 * R; ++c2) acc[i][c2] = 0.0;
+  __syncthreads();
+  // the next column of y is requested while this one is mixed (two register sets; a ring of 2 or 4 unrolled columns spills: G_t's rows hold 200 registers)
+  auto request = [&](int b, double (&y)[R]) {
+    const size_t o = (size_t)(b < ncol ? b : ncol - 1) * ldy;                  // (past the end: the last column again)
+#pragma unroll
+    for (int i = 0; i < R; ++i) y[i] = yp[i][(wave + 4 * i < p) ? o : 0];     // (address select, not a branch: the sink has one column)
+  };
+  auto column = [&](int b, const double (&yv)[R]) {
+    const int par = b & 1;
+#pragma unroll
+    for (int i = 0; i < R; ++i) vs[par][wave + 4 * i][lane] = yv[i];
+    __syncthreads();
+    double m[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) m[i] = 0.0;
+#pragma unroll
+    for (int k = 0; k < PW; ++k) {
+      const double yk = vs[par][k][lane];
+#pragma unroll
+      for (int i = 0; i < R; ++i) m[i] += g[i][k] * yk;
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const int a = wave + 4 * i;
+      yp[i][(a < p) ? (size_t)b * ldy : 0] = m[i];
+      ms[par][a][lane] = m[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+#pragma unroll
+      for (int c2 = 0; c2 < 4 * (i + 1); ++c2) acc[i][c2] += m[i] * ms[par][c2][lane];
+  };
+  double yv[R], yn[R];
+  request(0, yv);
+#pragma unroll 1
+  for (int b = 0; b < ncol; ++b) {
+    request(b + 1, yn);
+    column(b, yv);
+#pragma unroll
+    for (int i = 0; i < R; ++i) yv[i] = yn[i];
+  }
+  if (t >= T) return;
+  double* v = vsm + ((size_t)trial_of_slot[slot] * T + t) * pp;
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const int a = wave + 4 * i;
+    if (a >= p) continue;
+#pragma unroll
+    for (int c2 = 0; c2 < 4 * (i + 1); ++c2)
+      if (c2 <= a) {
+        const double val = eps * g[i][c2] + acc[i][c2];
+        v[a * p + c2] = val;
+        v[c2 * p + a] = val;
+      }
+  }
+}
+
 // vsm_finish_kernel for wide p: vsm[t] <- eps G_t + G_t Bt_t G_t in place.  Thread (bin, i) owns row i.
 // grid = (ceil(T/bins), nslots), block = bins*32; LDS holds the V and the G blocks of the block's bins.
 __global__ void vsm_finish_wide_kernel(double* __restrict__ vsm, const double* __restrict__ G, long long sG, int T, int p, double eps,

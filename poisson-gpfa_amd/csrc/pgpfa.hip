@@ -219,6 +219,8 @@ struct pgpfa_ctx {
   bool last_cov_lowrank = false;
   bool shared_pcg = true;
   bool pcg_trace = false;
+  double* sink = nullptr;                        // 128 doubles nobody reads: where the rows past p of mix_vsm_wide2_kernel store
+  int mix_wide = 1;                              // 1: the mixing pass of 17..20 latents with lanes along the bins (mix_vsm_wide2_kernel); 0: mix_vsm_wide_kernel
   int mix_slot = 2;                           // option mix_slot: the mixing pass of the split form with a thread per bin and whole columns per workgroup (split.h)
   bool cross_kernel = true;                       // option cross_kernel = 0: the cross term of the split form through the general GEMM kernel
   bool measure_mix = false;                       // option measure_mix: record max_t eps ||Wt_t|| of every covariance pass
@@ -1369,6 +1371,7 @@ int pgpfa_create(pgpfa_ctx** out, int device, int q, int p, int T, int R, double
   rc |= dmalloc(c, &c->d_rank, p); rc |= dmalloc(c, &c->d_roff, p + 1);
   c->tab_cap = 4 * ((size_t)c->ld / 64 + 2 * (size_t)p + 4);
   rc |= dmalloc(c, &c->d_kr_ft, c->tab_cap); rc |= dmalloc(c, &c->d_kr_f, c->tab_cap);
+  rc |= dmalloc(c, &c->sink, 128, true);
   rc |= dmalloc(c, &c->d_thin_ft, c->tab_cap); rc |= dmalloc(c, &c->d_thin_f, c->tab_cap); rc |= dmalloc(c, &c->d_thin_s, c->tab_cap);
   rc |= dmalloc(c, &c->Fbig, (size_t)c->ld * c->ld + 256 * (size_t)c->ld, true); rc |= dmalloc(c, &c->FTbig, (size_t)c->ld * c->ld + 256 * (size_t)c->ld, true);
   rc |= dmalloc(c, &c->Gbar, (size_t)T * p * p + 64); rc |= dmalloc(c, &c->Wtbar, (size_t)T * p * p + 64); rc |= dmalloc(c, &c->d_blk_lat, (size_t)p * c->Tp / 16 + 64); rc |= dmalloc(c, &c->d_blk_col, (size_t)p * c->Tp / 16 + 64);
@@ -1453,6 +1456,7 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
   else if (k == "mt_fill") c->mt_fill = (int)v;
   else if (k == "overlap_factors") c->overlap_factors = (int)v;
   else if (k == "mix_slot") c->mix_slot = (int)v;
+  else if (k == "mix_wide") c->mix_wide = (int)v;
   else if (k == "thin_products") c->thin_products = (int)v;
   else if (k == "copy_kernels") c->copy_kernels = (v != 0.0);
   else if (k == "chord") c->chord = (v != 0.0);
@@ -2417,6 +2421,9 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool 
       if constexpr (PW <= 16) {
         hipLaunchKernelGGL(mix_vsm_kernel<PW>, dim3((T + 63) / 64, nb), dim3(256), 0, c->st, lw.H, lw.sH, c->ld, c->Gbin, sW, T, p, ract, c->eps,
                            c->vsm, c->ident, c->trial_of_slot, c->d_roff, ctile, Ts);
+      } else if (c->mix_wide && p <= 20) {
+        hipLaunchKernelGGL(mix_vsm_wide2_kernel<20>, dim3((T + 63) / 64, nb), dim3(256), 0, c->st, lw.H, (long long)lw.sH, c->ld, c->Gbin, sW, T, p, ract, c->eps,
+                           c->vsm, c->ident, c->trial_of_slot, Ts, c->sink);
       } else {
         const int bins = wide_bins(p);
         hipLaunchKernelGGL(mix_vsm_wide_kernel, dim3((T + bins - 1) / bins, nb), dim3(bins * 32), wide_lds_bytes(p, bins, 1), c->st, lw.H, lw.sH,

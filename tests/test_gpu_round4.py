@@ -282,3 +282,35 @@ def test_partial_clear_of_the_inverse_slabs_is_bitwise_the_full_clear():
         assert a[0] == b[0]
         for i in (1, 2, 3):
             assert np.array_equal(a[i], b[i])
+
+
+@pytest.mark.parametrize('shape', [(40, 18, 130, 3), (50, 20, 200, 4), (30, 17, 64, 2)])
+def test_wide_mixing_pass_with_lanes_along_the_bins(shape):
+    """17..20 latents: the in-place mixing pass of the full-width covariance product with the lanes along the bins (`mix_wide = 1`, mix_vsm_wide2_kernel:
+    18 and 17 latents run the 20-wide instantiation with masked rows, 130 bins leave a partly filled 64-bin tile) against the kernel it replaces
+    (lanes along the latents): per-bin covariance blocks and PautoSum to 1e-12 of their largest entry, and the blocks against the oracle's exact
+    Newton (1e-8 rel)."""
+    from funs import _hip
+    q, p, T, R = shape
+    rng = np.random.default_rng(p * 7 + T)
+    _, Ys, _ = orc.synth_dataset(q, p, T, R, seed=p, dOffset=0.0)
+    Y = np.stack(Ys).astype(np.uint8)
+    par = {'C': 0.3 * rng.standard_normal((q, p)) / np.sqrt(p / 4), 'd': np.log(Y.mean(axis=(0, 2)) + 0.1), 'tau': 0.05 + 0.3 * rng.random(p)}
+    res, _, _ = orc.laplace([y.astype(float) for y in Ys], par, 10.0, mode='exact', return_cov=False)
+    out = {}
+    for wide in (1, 0):
+        ctx = _hip.Context(q, p, T, R, 10.0)
+        try:
+            ctx.upload_counts(Y)
+            ctx.set_option('cov_mode', 2)
+            ctx.set_option('mix_wide', wide)
+            ctx.set_params(par['C'], par['d'], par['tau'])
+            obj, _, status = ctx.estep_laplace()
+            assert np.all(status == 0) and ctx.info('plan_lowrank') == 1.0 and ctx.info('last_split_cov') == 0.0
+            ctx.mstep_precomp()
+            out[wide] = (ctx.post_vsm().copy(), ctx.pautosum().copy())
+        finally:
+            ctx.close()
+    for i in (0, 1):
+        assert np.max(np.abs(out[1][i] - out[0][i])) <= 1e-12 * np.max(np.abs(out[0][i]))
+    assert rel(out[1][0], np.stack(res['post_vsm'])) <= 1e-8
