@@ -2686,6 +2686,71 @@ __global__ void apply_bin_wide_kernel(const double* __restrict__ Gb, const doubl
   }
 }
 
+// apply_bin_wide_kernel with the lanes along the bins (see mix_vsm_wide2_kernel below: the same layout): 64 bins x 4 waves, wave w owns rows a = w + 4 i of the
+// shared blocks (in registers), the slots' vectors are exchanged through LDS.  grid = (ceil(T / 64), ceil(nslots / APPLY_BIN_SLOTS)), block = 256, p <= PW = 20.
+template <int PW>
+__global__ __launch_bounds__(256, 1) void apply_bin_wide2_kernel(const double* __restrict__ Gb, const double* __restrict__ A, const double* __restrict__ B2, double scale,
+                                                                 double* __restrict__ out, long long sV, int T, int p, int nslots, double* __restrict__ sink) {
+  constexpr int R = PW / 4;
+  __shared__ double vs[2][PW][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t = blockIdx.x * 64 + lane;
+  const int tc = t < T ? t : T - 1;
+  const int pp = p * p;
+  const double* gsrc = Gb + (size_t)tc * pp;
+  double g[R][PW];
+  size_t roff[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const int a = wave + 4 * i;
+    const int ac = a < p ? a : 0;
+#pragma unroll
+    for (int k = 0; k < PW; ++k) {
+      const double v = gsrc[ac * p + (k < p ? k : 0)];
+      g[i][k] = (a < p && k < p) ? v : 0.0;
+    }
+    roff[i] = (size_t)ac * T + tc;
+  }
+  for (int e = threadIdx.x; e < 2 * PW * 64; e += 256) (&vs[0][0][0])[e] = 0.0;
+  __syncthreads();
+  const int s0 = blockIdx.y * APPLY_BIN_SLOTS, s_end = min(nslots, s0 + APPLY_BIN_SLOTS);
+  auto request = [&](int sl, double (&y)[R]) {
+    const size_t base = (size_t)(sl < s_end ? sl : s_end - 1) * sV;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const double av = A[base + roff[i]];
+      const double bv = B2 ? B2[base + roff[i]] : 0.0;
+      y[i] = scale * av + bv;
+    }
+  };
+  double yv[R], yn[R];
+  request(s0, yv);
+#pragma unroll 1
+  for (int sl = s0; sl < s_end; ++sl) {
+    const int par = (sl - s0) & 1;
+    request(sl + 1, yn);
+#pragma unroll
+    for (int i = 0; i < R; ++i) vs[par][wave + 4 * i][lane] = (wave + 4 * i < p) ? yv[i] : 0.0;
+    __syncthreads();                                   // (one barrier per slot: the buffers alternate)
+    double m[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) m[i] = 0.0;
+#pragma unroll
+    for (int k = 0; k < PW; ++k) {
+      const double yk = vs[par][k][lane];
+#pragma unroll
+      for (int i = 0; i < R; ++i) m[i] += g[i][k] * yk;
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      double* dst = (wave + 4 * i < p) ? out + (size_t)sl * sV + roff[i] : sink + lane;
+      *dst = m[i];
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) yv[i] = yn[i];
+  }
+}
+
 // mix_vsm_kernel for wide p: y <- G_t y for every column of the slab, post_vsm[t] = eps G_t + sum_b (G_t y_b)(G_t y_b)^T.
 // Thread (bin, a) owns row a of the accumulated block (columns c <= a).  grid = (ceil(T/bins), nslots), block = bins*32
 __global__ void mix_vsm_wide_kernel(double* __restrict__ Yt, long long sY, int ldy, const double* __restrict__ G, long long sG, int T, int p,

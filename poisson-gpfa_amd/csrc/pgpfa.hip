@@ -1871,6 +1871,9 @@ static int shared_solve(pgpfa_ctx* c, int nb, const double* R, double* Z, const 
         if constexpr (PW <= 16) {
           hipLaunchKernelGGL(apply_bin_kernel<PW>, dim3((c->T + 63) / 64, (nb + APPLY_BIN_SLOTS - 1) / APPLY_BIN_SLOTS), dim3(256), 0, c->st, c->Gbar,
                              a, b2, scale, o, ld, c->T, c->p, nb);
+        } else if (c->mix_wide && c->p <= 20) {
+          hipLaunchKernelGGL(apply_bin_wide2_kernel<20>, dim3((c->T + 63) / 64, (nb + APPLY_BIN_SLOTS - 1) / APPLY_BIN_SLOTS), dim3(256), 0, c->st, c->Gbar, a, b2,
+                             scale, o, ld, c->T, c->p, nb, c->sink);
         } else {
           const int bins = wide_bins(c->p);
           hipLaunchKernelGGL(apply_bin_wide_kernel, dim3((c->T + bins - 1) / bins, (nb + APPLY_BIN_SLOTS - 1) / APPLY_BIN_SLOTS), dim3(bins * 32),

@@ -288,8 +288,8 @@ def test_partial_clear_of_the_inverse_slabs_is_bitwise_the_full_clear():
 def test_wide_mixing_pass_with_lanes_along_the_bins(shape):
     """17..20 latents: the in-place mixing pass of the full-width covariance product with the lanes along the bins (`mix_wide = 1`, mix_vsm_wide2_kernel:
     18 and 17 latents run the 20-wide instantiation with masked rows, 130 bins leave a partly filled 64-bin tile) against the kernel it replaces
-    (lanes along the latents): per-bin covariance blocks and PautoSum to 1e-12 of their largest entry, and the blocks against the oracle's exact
-    Newton (1e-8 rel)."""
+    (lanes along the latents) - the option switches the per-bin application of the shared preconditioner too (apply_bin_wide2_kernel): modes 2e-9, per-bin
+    covariance blocks and PautoSum 1e-8 of their largest entry between the two, modes and blocks against the oracle's exact Newton (1e-8)."""
     from funs import _hip
     q, p, T, R = shape
     rng = np.random.default_rng(p * 7 + T)
@@ -308,9 +308,13 @@ def test_wide_mixing_pass_with_lanes_along_the_bins(shape):
             obj, _, status = ctx.estep_laplace()
             assert np.all(status == 0) and ctx.info('plan_lowrank') == 1.0 and ctx.info('last_split_cov') == 0.0
             ctx.mstep_precomp()
-            out[wide] = (ctx.post_vsm().copy(), ctx.pautosum().copy())
+            out[wide] = (ctx.post_vsm().copy(), ctx.pautosum().copy(), ctx.post_mean().copy())
         finally:
             ctx.close()
+    # (the option also switches the per-bin application of the shared preconditioner in the inner solves: the modes agree to the stopping tolerance)
+    assert np.max(np.abs(out[1][2] - out[0][2])) <= 2e-9
     for i in (0, 1):
-        assert np.max(np.abs(out[1][i] - out[0][i])) <= 1e-12 * np.max(np.abs(out[0][i]))
-    assert rel(out[1][0], np.stack(res['post_vsm'])) <= 1e-8
+        assert np.max(np.abs(out[1][i] - out[0][i])) <= 1e-8 * np.max(np.abs(out[0][i]))
+    for wide in (1, 0):
+        assert np.max(np.abs(out[wide][2] - np.stack(res['post_mean']))) <= 1e-8
+        assert rel(out[wide][0], np.stack(res['post_vsm'])) <= 1e-8
