@@ -95,7 +95,7 @@ int pgpfa_destroy(pgpfa_ctx* ctx);
  * per workgroup, G_t's rows in registers, y and G_t y exchanged through LDS, csrc/model.h mix_vsm_wide2_kernel; 0: mix_vsm_wide_kernel, lanes along the latents),
  * "cross_kernel" (1: the cross term of that split form in a kernel with all rows of a latent in one workgroup, 128 rows per
  * launch; 0: through the general GEMM kernel),
- * "split_cov" (1: the sum over trials of the T x T covariance blocks by the exact split form of csrc/split.h - FP64 cross term, FP16
+ * "split_cov" (1: the sum over trials of the T x T covariance blocks by the exact split form of csrc/split.h (up to 20 latents; 17..20 need "mix_wide") - FP64 cross term, FP16
  * two-half product for the second-order term - while the root mean square of eps ||Wt_t|| stays below "split_max_norm" (0.07);
  * 0: always the full-width FP64 product), "measure_mix" (0; 1: measure eps ||Wt_t|| in every covariance pass, also where the split form is not a candidate -> info
  * "last_eps_wt_norm" / "last_eps_wt_rms": the maximum over the chunks of the LAST pgpfa_estep_laplace / pgpfa_dual_finalize call of the

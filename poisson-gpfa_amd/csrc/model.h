@@ -2811,10 +2811,13 @@ __global__ void mix_vsm_wide_kernel(double* __restrict__ Yt, long long sY, int l
 // every wave reads its rows of y (512-byte runs), the 4 waves exchange y and m = G_t y through LDS (double-buffered by column parity), the next column's loads
 // are in flight meanwhile.  No branch around a load or a store in the loop: clamped addresses, bins past T repeat bin T - 1, rows past p write to `sink`
 // (>= 64 doubles of scratch).  grid = (ceil(T / 64), nslots), block = 256, PW in {20, 24, 32} >= p.
-template <int PW>
+// SPLIT: the pass of the split accumulation (split.h) instead - Yt stays, the correction y - G_t y goes to D in single precision (row (a, t) at a ts + t, column
+// stride ldd, slot stride sD floats); `sink` then takes the loads of the rows past p.
+template <int PW, bool SPLIT>
 __global__ __launch_bounds__(256, 1) void mix_vsm_wide2_kernel(double* __restrict__ Yt, long long sY, int ldy, const double* __restrict__ G, long long sG, int T,
                                                                int p, int ncol, double eps, double* __restrict__ vsm, const int* __restrict__ slots,
-                                                               const int* __restrict__ trial_of_slot, int ts, double* __restrict__ sink) {
+                                                               const int* __restrict__ trial_of_slot, int ts, double* __restrict__ sink,
+                                                               float* __restrict__ D, long long sD, int ldd) {
   constexpr int R = PW / 4;
   __shared__ double vs[2][PW][64];
   __shared__ double ms[2][PW][64];
@@ -2826,6 +2829,7 @@ __global__ __launch_bounds__(256, 1) void mix_vsm_wide2_kernel(double* __restric
   const double* gsrc = G + (size_t)slot * sG + (size_t)tc * pp;
   double g[R][PW];
   double* yp[R];
+  float* dp[R];
 #pragma unroll
   for (int i = 0; i < R; ++i) {
     const int a = wave + 4 * i;
@@ -2836,6 +2840,7 @@ __global__ __launch_bounds__(256, 1) void mix_vsm_wide2_kernel(double* __restric
       g[i][k] = (a < p && k < p) ? v : 0.0;
     }
     yp[i] = (a < p) ? Yt + (size_t)slot * sY + (size_t)a * ts + tc : sink + lane;
+    dp[i] = (SPLIT && a < p) ? D + (size_t)slot * sD + (size_t)a * ts + tc : reinterpret_cast<float*>(sink) + lane;
   }
   // rows >= p of the exchange buffers are read (against zeros of g, and as m of rows that are never stored): keep them finite
   for (int e = threadIdx.x; e < 2 * PW * 64; e += 256) { (&vs[0][0][0])[e] = 0.0; (&ms[0][0][0])[e] = 0.0; }
@@ -2869,7 +2874,8 @@ __global__ __launch_bounds__(256, 1) void mix_vsm_wide2_kernel(double* __restric
 #pragma unroll
     for (int i = 0; i < R; ++i) {
       const int a = wave + 4 * i;
-      yp[i][(a < p) ? (size_t)b * ldy : 0] = m[i];
+      if constexpr (SPLIT) dp[i][(a < p) ? (size_t)b * ldd : 0] = (float)(yv[i] - m[i]);
+      else yp[i][(a < p) ? (size_t)b * ldy : 0] = m[i];
       ms[par][a][lane] = m[i];
     }
     __syncthreads();

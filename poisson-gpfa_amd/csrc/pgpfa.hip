@@ -2134,6 +2134,10 @@ static int accumulate_split(pgpfa_ctx* c, const CholWS& lw, int nb, int ract, in
   const int ldd = c->ld;
   // 1. mixing pass: post_vsm and the correction D = eps Wt Yt (single precision); Yt itself stays
   prof_begin(c, TAG_VSM, (double)nb * c->n * rpad * (3.0 * p + 1.0));
+  if (p > 16)                                               // (17..20 latents: split_candidate admits no others beyond 16)
+    hipLaunchKernelGGL((mix_vsm_wide2_kernel<20, true>), dim3((T + 63) / 64, nb), dim3(256), 0, c->st, lw.H, (long long)lw.sH, c->ld, c->Gbin, sW, T, p, ract, c->eps,
+                       c->vsm, c->ident, c->trial_of_slot, Ts, c->sink, D, sD, ldd);
+  else
   dispatch_pw(p, [&](auto pw) {
     constexpr int PW = decltype(pw)::value;
     if constexpr (PW <= 10) {
@@ -2263,7 +2267,8 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool 
   CHK(bin_blocks(c, c->W, sW, c->Gbin, c->Wt, sW, nb, logdet_out ? c->ldet_buf : nullptr));
   // sum-only accumulation by the split form (split.h)?  Decided by the relative size of the mixing correction of this chunk,
   // max_t eps ||Wt_t||_inf, measured here and read back just before the mixing pass (info key "last_eps_wt_norm")
-  const bool split_candidate = want_vsmgp && accumulate && c->split_cov && c->mfma && p <= 16 && !c->dual_f32;
+  // (want_vsmgp passes run the FP64 engine whatever dual_f32 says - it only concerns the dual's evaluations - so the split form does not ask)
+  const bool split_candidate = want_vsmgp && accumulate && c->split_cov && c->mfma && (p <= 16 || (p <= 20 && c->mix_wide));
   unsigned* norm_bits = reinterpret_cast<unsigned*>(c->pcg_ratio);         // (scratch word: the inner solves are over)
   if (split_candidate || c->measure_mix) {
     HIPC(hipMemsetAsync(norm_bits, 0, 4 * sizeof(unsigned), c->st));
@@ -2425,8 +2430,8 @@ static int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool 
         hipLaunchKernelGGL(mix_vsm_kernel<PW>, dim3((T + 63) / 64, nb), dim3(256), 0, c->st, lw.H, lw.sH, c->ld, c->Gbin, sW, T, p, ract, c->eps,
                            c->vsm, c->ident, c->trial_of_slot, c->d_roff, ctile, Ts);
       } else if (c->mix_wide && p <= 20) {
-        hipLaunchKernelGGL(mix_vsm_wide2_kernel<20>, dim3((T + 63) / 64, nb), dim3(256), 0, c->st, lw.H, (long long)lw.sH, c->ld, c->Gbin, sW, T, p, ract, c->eps,
-                           c->vsm, c->ident, c->trial_of_slot, Ts, c->sink);
+        hipLaunchKernelGGL((mix_vsm_wide2_kernel<20, false>), dim3((T + 63) / 64, nb), dim3(256), 0, c->st, lw.H, (long long)lw.sH, c->ld, c->Gbin, sW, T, p, ract, c->eps,
+                           c->vsm, c->ident, c->trial_of_slot, Ts, c->sink, (float*)nullptr, 0LL, 0);
       } else {
         const int bins = wide_bins(p);
         hipLaunchKernelGGL(mix_vsm_wide_kernel, dim3((T + bins - 1) / bins, nb), dim3(bins * 32), wide_lds_bytes(p, bins, 1), c->st, lw.H, lw.sH,

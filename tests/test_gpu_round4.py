@@ -304,6 +304,7 @@ def test_wide_mixing_pass_with_lanes_along_the_bins(shape):
             ctx.upload_counts(Y)
             ctx.set_option('cov_mode', 2)
             ctx.set_option('mix_wide', wide)
+            ctx.set_option('split_cov', 0)                     # (the in-place pass belongs to the full-width product)
             ctx.set_params(par['C'], par['d'], par['tau'])
             obj, _, status = ctx.estep_laplace()
             assert np.all(status == 0) and ctx.info('plan_lowrank') == 1.0 and ctx.info('last_split_cov') == 0.0
@@ -318,3 +319,31 @@ def test_wide_mixing_pass_with_lanes_along_the_bins(shape):
     for wide in (1, 0):
         assert np.max(np.abs(out[wide][2] - np.stack(res['post_mean']))) <= 1e-8
         assert rel(out[wide][0], np.stack(res['post_vsm'])) <= 1e-8
+
+
+def test_split_accumulation_at_20_latents():
+    """The split form of the sum over trials of the covariance blocks beyond 16 latents (17..20: the mixing pass of mix_vsm_wide2_kernel<20, true>, every column of
+    Yt present): PautoSum against the full-width FP64 product of the same engine 1e-9 of its largest entry, post_vsm 1e-12; at 18 latents the 20-wide
+    instantiation runs with masked rows."""
+    from funs import _hip
+    for q, p, T, R in ((60, 20, 130, 6), (50, 18, 200, 5)):
+        rng = np.random.default_rng(p)
+        _, Ys, _ = orc.synth_dataset(q, p, T, R, seed=p + 1, dOffset=0.0)
+        Y = np.stack(Ys).astype(np.uint8)
+        par = {'C': 0.3 * rng.standard_normal((q, p)) / np.sqrt(p / 4), 'd': np.log(Y.mean(axis=(0, 2)) + 0.1), 'tau': 0.05 + 0.3 * rng.random(p)}
+        out = {}
+        for split in (1, 0):
+            ctx = _hip.Context(q, p, T, R, 10.0)
+            try:
+                ctx.upload_counts(Y)
+                ctx.set_option('cov_mode', 2)
+                ctx.set_option('split_cov', split)
+                ctx.set_params(par['C'], par['d'], par['tau'])
+                obj, _, status = ctx.estep_laplace()
+                assert np.all(status == 0) and ctx.info('plan_lowrank') == 1.0 and ctx.info('last_split_cov') == float(split)
+                ctx.mstep_precomp()
+                out[split] = (ctx.pautosum().copy(), ctx.post_vsm().copy())
+            finally:
+                ctx.close()
+        print('%d latents: split vs FP64 product: PautoSum %.2e, post_vsm %.2e' % (p, rel(out[1][0], out[0][0]), rel(out[1][1], out[0][1])))
+        assert rel(out[1][0], out[0][0]) <= 1e-9 and rel(out[1][1], out[0][1]) <= 1e-12
