@@ -79,6 +79,7 @@ int pgpfa_destroy(pgpfa_ctx* ctx);
  * live list, pcg.h; 0: one common forcing term), "pcg_trace" (0; 1: one stderr line per inner solve),
  * "time_newton" (0; 1: HIP events around the inner solves -> info "last_newton_solve_ms" / "last_newton_solve_bytes"),
  * "small_tile_below" (2^30: products with fewer 128 x 128 tiles than this run on 64 x 64 workgroup tiles - i.e. all; 0: never),
+ * "f32_tile64" (1: the single-precision products of the mixed-precision dual evaluation run on 64 x 64 workgroup tiles like the FP64 ones; 0: 128 x 128 only),
  * "splitk_below64" (400: products on 64 x 64 tiles are cut along k only below this many tiles),
  * "copy_kernels" (1: read-backs and uploads up to 256 KB move through host-mapped staging memory as one-workgroup kernels, and a flush is a
  * kernel that raises a sequence number the host spins on - no hipMemcpyAsync / hipStreamSynchronize on those paths; 0: the runtime's copies),

@@ -507,7 +507,6 @@ inline int gemm_count_tiles(int mode, int tilesM, int tilesN) {
 // Host launcher.  K, and every k range implied by kflags, must be a multiple of 16.  g.bm selects the tile size (0: 128).
 inline hipError_t gemm_launch(hipStream_t st, bool use_mfma, bool transb, GemmP g, bool f32 = false) {
   if (g.bm != 64) g.bm = 128;
-  if (f32) g.bm = 128;                                   // (single precision: large tiles only)
   g.tilesM = g.rtab ? g.ntab : (g.M + g.bm - 1) / g.bm;
   g.tilesN = (g.N + g.bm - 1) / g.bm;
   g.ntiles = gemm_count_tiles(g.mode, g.tilesM, g.tilesN);
@@ -519,8 +518,13 @@ inline hipError_t gemm_launch(hipStream_t st, bool use_mfma, bool transb, GemmP 
   dim3 grid((unsigned)blocks);
   if (f32) {
     if (g.kseg != 0) return hipErrorInvalidValue;        // (segmented K addresses are computed for FP64 operands only)
-    if (transb) hipLaunchKernelGGL((gemm_mfma_kernel_t<1, float, 128>), grid, dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((gemm_mfma_kernel_t<0, float, 128>), grid, dim3(256), 0, st, g);
+    if (g.bm == 64) {
+      if (transb) hipLaunchKernelGGL((gemm_mfma_kernel_t<1, float, 64>), grid, dim3(256), 0, st, g);
+      else hipLaunchKernelGGL((gemm_mfma_kernel_t<0, float, 64>), grid, dim3(256), 0, st, g);
+    } else {
+      if (transb) hipLaunchKernelGGL((gemm_mfma_kernel_t<1, float, 128>), grid, dim3(256), 0, st, g);
+      else hipLaunchKernelGGL((gemm_mfma_kernel_t<0, float, 128>), grid, dim3(256), 0, st, g);
+    }
   } else if (use_mfma) {
     if (g.b_f32) {
       if (transb || g.bm != 64) return hipErrorInvalidValue;

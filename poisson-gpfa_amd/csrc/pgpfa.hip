@@ -228,6 +228,7 @@ struct pgpfa_ctx {
   int shared_min = 16, pcg_inner_min = 2, pcg_inner_max = 16, pcg_outer_max = 12;
   double pcg_eta0 = 1e-2;
   int splitk_target = 1280;                      // thin GEMMs are cut along k until about this many workgroups are in flight
+  int f32_tile64 = 1;                            // 1: single-precision products on 64 x 64 tiles too (as FP64); 0: 128 x 128 only
   int small_tile_below = 1 << 30;                // products with fewer 128 x 128 tiles than this run on 64 x 64 tiles (0: never); measured: the
                                                  // small tile wins at every shape of the E-step (44.5 -> 50 TFLOP/s on the largest launch too)
   int splitk_below64 = 400;                      // ... and are cut along k only below this many 64 x 64 tiles (round 4: 160 -> 400 - with the prior mat-vec out of the PCG step
@@ -407,7 +408,7 @@ int gemm(pgpfa_ctx* c, bool transb, GemmP g, bool f32 = false) {
   // them resident per CU; everything with a row-tile table is laid out for 64-row tiles.
   if (g.bm == 0) {
     const long long t128 = (long long)((g.M + GBM - 1) / GBM) * ((g.N + GBN - 1) / GBN) * std::max(g.nbatch, 1);
-    g.bm = (!f32 && c->mfma && (g.rtab || t128 < c->small_tile_below)) ? 64 : 128;
+    g.bm = ((!f32 || c->f32_tile64) && c->mfma && (g.rtab || t128 < c->small_tile_below)) ? 64 : 128;
   }
   if (g.rtab) g.bm = 64;
   if (g.cols && c->cur_ndev) g.n_dev = c->cur_ndev;
@@ -1482,6 +1483,7 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
   else if (k == "pcg_eta0") c->pcg_eta0 = v;
   else if (k == "splitk_target") c->splitk_target = std::max(1, (int)v);
   else if (k == "small_tile_below") c->small_tile_below = (int)v;
+  else if (k == "f32_tile64") c->f32_tile64 = (int)v;
   else if (k == "splitk_below64") c->splitk_below64 = (int)v;
   else if (k == "pcg_outer_max") c->pcg_outer_max = (int)v;
   else if (k == "chord_xtol") c->chord_xtol = v;
