@@ -266,7 +266,8 @@ def spawn_ranks(n, timeout_s=None):
     with socket.socket() as sk:
         sk.bind(('127.0.0.1', 0))
         port = sk.getsockname()[1]
-    timeout_s = timeout_s or float(os.environ.get('PGPFA_BENCH_TIMEOUT', '3000'))
+    # (default below the 1800-s limit of whoever runs this: a job that cannot finish must end with a message and a non-zero status of its own)
+    timeout_s = timeout_s or float(os.environ.get('PGPFA_BENCH_TIMEOUT', '900'))
     procs = []
     out0 = tempfile.TemporaryFile()
     for r in range(n):
@@ -534,6 +535,12 @@ def main():
             sys.exit(3)
         if os.environ.get('PGPFA_DRYRUN_HANG') == str(rank):
             time.sleep(600)
+        if os.environ.get('PGPFA_DRYRUN_COMM_HANG') == str(rank):
+            # a rank stuck inside pgpfa_comm_init: the same watchdog that guards the real call (funs/_session.py) around a stub that never returns
+            sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'poisson-gpfa_amd'))
+            from funs._session import phase_deadline
+            with phase_deadline('pgpfa_comm_init (ncclCommInitRank)', float(os.environ.get('PGPFA_COMM_TIMEOUT', '300')), rank):
+                time.sleep(600)
         if rank == 0:
             print(json.dumps({'dry_run': True, 'rank': rank, 'world': world, 'local_rank': int(os.environ.get('LOCAL_RANK', '0')),
                               'master': '%s:%s' % (os.environ.get('MASTER_ADDR'), os.environ.get('MASTER_PORT')), 'ppid': os.getppid()}))
@@ -707,7 +714,7 @@ def main():
                                         'frac': gemm_max_flops / (gemm_max_ms * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS if gemm_max_ms > 0 else 0.0}},
         # the Newton solve (north star: >= 40 % of the HBM roofline): every inner PCG solve of the timed region between two HIP events,
         # against the bytes a perfect implementation of the same iteration would still move (20 n-vector passes + packed curvature per slot,
-        # the operators once per iteration; pgpfa.hip: newton_bytes)
+        # the operators once per iteration; csrc/estep.hip: newton_bytes)
         'roofline_newton': {'bound': 'hbm', 'bytes': n_by, 'ms': n_ms, 'achieved': n_by / (n_ms * 1e-3) / 1e9 if n_ms > 0 else 0.0, 'peak': HBM_PEAK_GBS,
                             'unit': 'GB/s', 'frac': n_by / (n_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if n_ms > 0 else 0.0,
                             'ms_per_em_iteration': n_ms / args.steps, 'pcg_iterations_per_trial_per_estep': float(np.mean(pcgs[timed])) / R},

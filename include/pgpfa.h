@@ -254,6 +254,9 @@ int pgpfa_dual_finalize(pgpfa_ctx* ctx, int n, const int32_t* idx, const double*
 int pgpfa_comm_unique_id(char* id128 /* 128 bytes */);
 int pgpfa_comm_init(pgpfa_ctx* ctx, const char* id128, int rank, int nranks);
 int pgpfa_comm_allreduce_host(pgpfa_ctx* ctx, double* buf, int count);
+/* One line about this rank's communicator for start-up logs: "rank r/n device d pci <bus id> comm_ranks m comm_device d" (comm_ranks = ncclCommCount:
+ * the number of ranks RCCL itself saw); without a communicator "rank 0/1 device d pci <bus id> comm none".  buf is NUL-terminated. */
+int pgpfa_comm_describe(pgpfa_ctx* ctx, char* buf, int len);
 
 /* ---- test / bench hooks ---------------------------------------------------------------- */
 /* Batched SPD factor (+ optional inverse) of caller matrices through the production kernels:

@@ -13,12 +13,10 @@
 //   chol_inverse_t   Mt = L^-T (upper triangular) into a second slab, left-to-right over block
 //                    columns with two NT GEMMs per column; Sigma blocks then follow as Mt Mt^T.
 #pragma once
-#include "gemm.h"
+#include "types.h"
 
 namespace pgpfa {
 
-constexpr int NB = 128;     // diagonal block / GEMM tile
-constexpr int NSUP = 512;   // super-panel width
 
 // --------------------------------------------------------------------------------------------------
 // 128x128 diagonal block: Cholesky and triangular inverse.  512 threads; thread (r = tid & 127, cg = tid >> 7)
@@ -253,7 +251,7 @@ __global__ void diag_transpose_kernel_t(T* __restrict__ Mt, long long sM, int ld
 // Also returns dec[slot] = -g.delta (Newton decrement squared) and smax[slot] = max |delta|.
 // v lives in global memory (ld doubles per slot); rows >= n hold zeros.
 // --------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void chol_solve_kernel(const double* __restrict__ H, long long sH, int ld, int npad,
+inline __global__ __launch_bounds__(256) void chol_solve_kernel(const double* __restrict__ H, long long sH, int ld, int npad,
                                                           const double* __restrict__ Dinv, long long sD,
                                                           const double* __restrict__ G, double* __restrict__ V,
                                                           long long sV, const int* __restrict__ slots,
@@ -331,88 +329,6 @@ __global__ __launch_bounds__(256) void chol_solve_kernel(const double* __restric
     dec[slot] = red[0] + red[1] + red[2] + red[3];
     smax[slot] = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
   }
-}
-
-struct CholWS {
-  double* H; long long sH;        // factor slabs
-  double* Mt; long long sM;       // L^-T slabs (strictly-lower part must be zero)
-  double* Dinv; long long sD;     // inverted diagonal blocks, (npad/128) x 128 x 128 per slot
-  double* P; long long sP;        // npad x 128 scratch per slot
-  int* info;                      // per slot
-  int ld, npad;
-  int nact = 0;                   // active rows (multiple of 64, <= npad); 0 = npad
-};
-
-inline hipError_t chol_factor(hipStream_t st, bool mfma, const CholWS& w, const int* slots, int nb) {
-  const int np = w.npad, ld = w.ld;
-  for (int c0 = 0; c0 < np; c0 += NSUP) {
-    const int c1 = (c0 + NSUP < np) ? c0 + NSUP : np;
-    for (int k0 = c0; k0 < c1; k0 += NB) {
-      hipLaunchKernelGGL(potrf_diag_kernel_t<double>, dim3(nb), dim3(512), 0, st, w.H, w.sH, ld, k0, w.Dinv, w.sD, slots, w.info);
-      const int r0 = k0 + NB;
-      if (r0 >= np) break;
-      GemmP g{};
-      // TRSM: L[r0:, k0:k0+128] = A[r0:, k0:k0+128] * Linv_kk^T   (in place, beta = 0)
-      g.A = w.H + (size_t)k0 * ld + r0; g.sA = w.sH; g.lda = ld;
-      g.B = w.Dinv + (size_t)(k0 / NB) * NB * NB; g.sB = w.sD; g.ldb = NB;
-      g.C = w.H + (size_t)k0 * ld + r0; g.sC = w.sH; g.ldc = ld;
-      g.M = np - r0; g.N = NB; g.K = NB; g.alpha = 1.0; g.beta = 0.0;
-      g.slots = slots; g.nbatch = nb; g.mode = GEMM_FULL; g.kflags = 0;
-      hipError_t e = gemm_launch(st, mfma, false, g);
-      if (e != hipSuccess) return e;
-      if (r0 < c1) {
-        // SYRK inside the super-panel: C[r0:, r0:c1] -= L[r0:, k0:k0+128] L[r0:c1, k0:k0+128]^T
-        GemmP s{};
-        s.A = w.H + (size_t)k0 * ld + r0; s.sA = w.sH; s.lda = ld;
-        s.B = s.A; s.sB = w.sH; s.ldb = ld;
-        s.C = w.H + (size_t)r0 * ld + r0; s.sC = w.sH; s.ldc = ld;
-        s.M = np - r0; s.N = c1 - r0; s.K = NB; s.alpha = -1.0; s.beta = 1.0;
-        s.slots = slots; s.nbatch = nb; s.mode = GEMM_LOWER; s.kflags = KF_MASK_DIAG;
-        e = gemm_launch(st, mfma, false, s);
-        if (e != hipSuccess) return e;
-      }
-    }
-    if (c1 < np) {
-      // trailing update with the whole super-panel: C[c1:, c1:] -= L[c1:, c0:c1] L[c1:, c0:c1]^T
-      GemmP s{};
-      s.A = w.H + (size_t)c0 * ld + c1; s.sA = w.sH; s.lda = ld;
-      s.B = s.A; s.sB = w.sH; s.ldb = ld;
-      s.C = w.H + (size_t)c1 * ld + c1; s.sC = w.sH; s.ldc = ld;
-      s.M = np - c1; s.N = np - c1; s.K = c1 - c0; s.alpha = -1.0; s.beta = 1.0;
-      s.slots = slots; s.nbatch = nb; s.mode = GEMM_LOWER; s.kflags = KF_MASK_DIAG;
-      hipError_t e = gemm_launch(st, mfma, false, s);
-      if (e != hipSuccess) return e;
-    }
-  }
-  return hipGetLastError();
-}
-
-// Mt = L^-T (upper triangular, npad x npad).  For block column j:
-//   P = Mt[0:j0, 0:j0] * L[jblk, 0:j0]^T        (k from the row tile on: Mt is upper triangular)
-//   Mt[0:j0, jblk] = -P * Linv_jj^T ;  Mt[jblk, jblk] = Linv_jj^T
-inline hipError_t chol_inverse_t(hipStream_t st, bool mfma, const CholWS& w, const int* slots, int nb) {
-  const int np = w.npad, ld = w.ld;
-  for (int j0 = 0; j0 < np; j0 += NB) {
-    hipLaunchKernelGGL(diag_transpose_kernel_t<double>, dim3(nb), dim3(256), 0, st, w.Mt, w.sM, ld, j0, w.Dinv, w.sD, slots);
-    if (j0 == 0) continue;
-    GemmP a{};
-    a.A = w.Mt; a.sA = w.sM; a.lda = ld;
-    a.B = w.H + j0; a.sB = w.sH; a.ldb = ld;            // rows jblk of L, columns 0..j0
-    a.C = w.P; a.sC = w.sP; a.ldc = np;
-    a.M = j0; a.N = NB; a.K = j0; a.alpha = 1.0; a.beta = 0.0;
-    a.slots = slots; a.nbatch = nb; a.mode = GEMM_FULL; a.kflags = KF_BEGIN_ROW;
-    hipError_t e = gemm_launch(st, mfma, false, a);
-    if (e != hipSuccess) return e;
-    GemmP b{};
-    b.A = w.P; b.sA = w.sP; b.lda = np;
-    b.B = w.Dinv + (size_t)(j0 / NB) * NB * NB; b.sB = w.sD; b.ldb = NB;
-    b.C = w.Mt + (size_t)j0 * ld; b.sC = w.sM; b.ldc = ld;
-    b.M = j0; b.N = NB; b.K = NB; b.alpha = -1.0; b.beta = 0.0;
-    b.slots = slots; b.nbatch = nb; b.mode = GEMM_FULL; b.kflags = 0;
-    e = gemm_launch(st, mfma, false, b);
-    if (e != hipSuccess) return e;
-  }
-  return hipGetLastError();
 }
 
 // flops of one factorisation / one transposed inverse of an npad-sized system (for reporting)

@@ -10,7 +10,7 @@
 namespace pgpfa {
 
 // TBL[n][ncol] (n < qpad): columns [0, NP) pair products (a >= b at a(a+1)/2 + b), [NPd, NPd + p) the loadings, zeros elsewhere
-__global__ void dual_table_kernel(const double* __restrict__ C, int q, int p, int ncol, int npd, double* __restrict__ tbl) {
+inline __global__ void dual_table_kernel(const double* __restrict__ C, int q, int p, int ncol, int npd, double* __restrict__ tbl) {
   const int n = blockIdx.x;
   const int np = p * (p + 1) / 2;
   for (int c = threadIdx.x; c < ncol; c += blockDim.x) {
@@ -31,7 +31,7 @@ __global__ void dual_table_kernel(const double* __restrict__ C, int q, int p, in
 
 // lmy = lambda - y for the slots [0, nslots); partial sums per (slot, 64-bin tile): sum d_n lmy and sum lambda (log lambda - 1).
 // grid = (ceil(T/64), nslots), block = 256 (lanes = bins, the 4 waves take interleaved neurons)
-__global__ __launch_bounds__(256) void dual_pre_kernel(const uint8_t* __restrict__ Y, const uint8_t* __restrict__ Yhi, const double* __restrict__ d, const double* __restrict__ lam,
+inline __global__ __launch_bounds__(256) void dual_pre_kernel(const uint8_t* __restrict__ Y, const uint8_t* __restrict__ Yhi, const double* __restrict__ d, const double* __restrict__ lam,
                                                        double* __restrict__ lmy, double* __restrict__ part, const int* __restrict__ trial_of_slot,
                                                        int q, int T) {
   __shared__ double red[2][4];
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void dual_pre_kernel(const uint8_t* __restrict
 //   h = C x + d [+ off],  lam = exp(h),  lmy = lam - y,  partial objective sum_n,t lam - y h per (slot, 64-bin tile)
 // - the q x p x T product as a vector kernel (2 % of the flops of the pass: W_t = C^T diag(lam_t) C and C^T (lam - y) follow as the GEMMs of the dual
 // evaluation against the pair / loading table).  grid = (ceil(T/64), nslots), block = 256 (lanes = bins, the 4 waves take interleaved neurons).
-__global__ __launch_bounds__(256) void rates_wide_kernel(const uint8_t* __restrict__ Y, const uint8_t* __restrict__ Yhi, const double* __restrict__ C,
+inline __global__ __launch_bounds__(256) void rates_wide_kernel(const uint8_t* __restrict__ Y, const uint8_t* __restrict__ Yhi, const double* __restrict__ C,
                                                          const double* __restrict__ d, const double* __restrict__ X, long long sX,
                                                          const double* __restrict__ off, double* __restrict__ lam, double* __restrict__ lmy,
                                                          double* __restrict__ fpart, const int* __restrict__ slots,
@@ -89,8 +89,12 @@ __global__ __launch_bounds__(256) void rates_wide_kernel(const uint8_t* __restri
       for (int l = 0; l < p; ++l) h += Cn[l] * rw_x[l * 64 + lane];
       const double ev = exp(h);
       const double y = (double)count_at(Y, Yhi, (trial * q + n) * T + t);
-      lam[e] = ev;
-      lmy[e] = ev - y;
+      // (stored finite: the products that follow read Lambda^T with K = q rounded up, i.e. also the first rows of the NEXT slot against zero
+      // table rows - an Inf or NaN rate of a far trial point would turn into NaN in its neighbour's curvature; the slot's own objective keeps
+      // the true value, which is what rejects such a point)
+      const double evs = (ev < 1e300) ? ev : 1e300;
+      lam[e] = evs;
+      lmy[e] = evs - y;
       facc += ev - y * h;
     }
   }
@@ -101,7 +105,7 @@ __global__ __launch_bounds__(256) void rates_wide_kernel(const uint8_t* __restri
 }
 
 // W[slot][t][a][b] = W[slot][t][b][a] = Wp[slot][pair(a,b)][t].  grid = (ceil(T*NP/256), nslots); slots (may be NULL): list of the slots
-__global__ void dual_unpack_w_kernel(const double* __restrict__ Wp, long long sWp, double* __restrict__ W, long long sW, int T, int p,
+inline __global__ void dual_unpack_w_kernel(const double* __restrict__ Wp, long long sWp, double* __restrict__ W, long long sW, int T, int p,
                                      const int* __restrict__ slots = nullptr) {
   const int np = p * (p + 1) / 2;
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -118,7 +122,7 @@ __global__ void dual_unpack_w_kernel(const double* __restrict__ Wp, long long sW
 }
 
 // Sp[slot][pair][t] = (a == b ? 1 : 2) * Sigma_t[a][b] of the slot's trial, zero rows up to npd.  grid = (ceil(T*npd/256), nslots)
-__global__ void dual_pack_sigma_kernel(const double* __restrict__ vsm, const int* __restrict__ trial_of_slot, double* __restrict__ Sp, long long sSp,
+inline __global__ void dual_pack_sigma_kernel(const double* __restrict__ vsm, const int* __restrict__ trial_of_slot, double* __restrict__ Sp, long long sSp,
                                        int T, int p, int npd) {
   const int np = p * (p + 1) / 2;
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -138,7 +142,7 @@ __global__ void dual_pack_sigma_kernel(const double* __restrict__ vsm, const int
 // K^-1 + scatter(W_t) at (latent k, bin t) is (K_k^-1)_tt + W_t[k][k], so the jitter is a diagonal addition to the per-bin blocks and
 // nothing else:  W_t[k][k] <- (1 + jit) W_t[k][k] + jit (K_k^-1)_tt.  Every later step (per-bin blocks, r x r system, log det, Sigma_t) then
 // evaluates the reference's jittered matrix exactly.  grid = (ceil(T*p/256), nslots)
-__global__ void dual_jitter_kernel(double* __restrict__ W, long long sW, const double* __restrict__ Kinv, int Tp, int T, int p, double jit) {
+inline __global__ void dual_jitter_kernel(double* __restrict__ W, long long sW, const double* __restrict__ Kinv, int Tp, int T, int p, double jit) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= T * p) return;
   const int t = e / p, k = e - t * p;
@@ -147,7 +151,7 @@ __global__ void dual_jitter_kernel(double* __restrict__ W, long long sW, const d
 }
 
 // grad[slot][n][t] += log(lambda) - d_n.  grid = (ceil(q*T/256), nslots)
-__global__ void dual_grad_finish_kernel(double* __restrict__ grad, const double* __restrict__ lam, const double* __restrict__ d, int q, int T) {
+inline __global__ void dual_grad_finish_kernel(double* __restrict__ grad, const double* __restrict__ lam, const double* __restrict__ d, int q, int T) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (size_t)q * T) return;
   const size_t o = (size_t)blockIdx.y * q * T + e;

@@ -13,7 +13,7 @@ namespace pgpfa {
 //   K[k][i][j] = (1-eps) * exp(-0.5 * ((i*bin - j*bin)^2 / (tau_k*1000)^2)) + eps*[i==j]
 // written into a (Tp x Tp) slab per latent with identity padding (rows/cols >= T).
 // --------------------------------------------------------------------------------------------------
-__global__ void gram_tau_kernel(double* __restrict__ K, int Tp, int T, const double* __restrict__ tau, double bin, double eps) {
+inline __global__ void gram_tau_kernel(double* __restrict__ K, int Tp, int T, const double* __restrict__ tau, double bin, double eps) {
   const int k = blockIdx.y;
   const int j = blockIdx.x;
   double* Kk = K + (size_t)k * Tp * Tp + (size_t)j * Tp;
@@ -33,7 +33,7 @@ __global__ void gram_tau_kernel(double* __restrict__ K, int Tp, int T, const dou
 
 // learning.MStepGPtimescaleCost learning.py:183-185 (gamma = exp(p), lags in bins):
 //   temp = (1-eps)*exp(-exp(p)/2 * difSq) ; K = temp + eps*I ; dKdgamma = -0.5*temp*difSq
-__global__ void gram_gamma_kernel(double* __restrict__ K, double* __restrict__ M, int Tp, int T, double logp, double eps) {
+inline __global__ void gram_gamma_kernel(double* __restrict__ K, double* __restrict__ M, int Tp, int T, double logp, double eps) {
   const int j = blockIdx.x;
   const double g = exp(logp);
   for (int i = threadIdx.x; i < Tp; i += blockDim.x) {
@@ -54,7 +54,7 @@ __global__ void gram_gamma_kernel(double* __restrict__ K, double* __restrict__ M
 }
 
 // batched over latents: K/M slabs of latent blockIdx.y at log-gamma logp[blockIdx.y]
-__global__ void gram_gamma_batch_kernel(double* __restrict__ K, double* __restrict__ M, int Tp, int T, const double* __restrict__ logp, double eps) {
+inline __global__ void gram_gamma_batch_kernel(double* __restrict__ K, double* __restrict__ M, int Tp, int T, const double* __restrict__ logp, double eps) {
   const int j = blockIdx.x;
   const size_t off = (size_t)blockIdx.y * Tp * Tp;
   const double g = exp(logp[blockIdx.y]);
@@ -76,7 +76,7 @@ __global__ void gram_gamma_batch_kernel(double* __restrict__ K, double* __restri
 }
 
 // out[blockIdx.x] = 2 * sum_i log L_ii of slab blockIdx.x
-__global__ void logdet_batch_kernel(const double* __restrict__ L, long long sL, int ld, int n, double* __restrict__ out) {
+inline __global__ void logdet_batch_kernel(const double* __restrict__ L, long long sL, int ld, int n, double* __restrict__ out) {
   __shared__ double red[256];
   const double* Ls = L + (size_t)blockIdx.x * sL;
   double s = 0.0;
@@ -92,7 +92,7 @@ __global__ void logdet_batch_kernel(const double* __restrict__ L, long long sL, 
 
 // batched dot of equally laid out slabs: part[blockIdx.y][blockIdx.x]; then sum_part_batch
 // (bmod > 0: B is indexed by blockIdx.y % bmod - several batch entries share one B slab)
-__global__ void dot_part_batch_kernel(const double* __restrict__ A, long long sA, const double* __restrict__ B, long long sB, long long n,
+inline __global__ void dot_part_batch_kernel(const double* __restrict__ A, long long sA, const double* __restrict__ B, long long sB, long long n,
                                       double* __restrict__ part, int bmod) {
   __shared__ double red[256];
   const double* a = A + (size_t)blockIdx.y * sA;
@@ -107,7 +107,7 @@ __global__ void dot_part_batch_kernel(const double* __restrict__ A, long long sA
   }
   if (threadIdx.x == 0) part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = red[0];
 }
-__global__ void sum_part_batch_kernel(const double* __restrict__ part, int nper, double* __restrict__ out, int nbatch) {
+inline __global__ void sum_part_batch_kernel(const double* __restrict__ part, int nper, double* __restrict__ out, int nbatch) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nbatch) return;
   double s = 0.0;
@@ -116,7 +116,7 @@ __global__ void sum_part_batch_kernel(const double* __restrict__ part, int nper,
 }
 
 // sum_i log(diag(L)) * 2 for one slab
-__global__ void logdet_kernel(const double* __restrict__ L, int ld, int n, double* __restrict__ out) {
+inline __global__ void logdet_kernel(const double* __restrict__ L, int ld, int n, double* __restrict__ out) {
   __shared__ double red[256];
   double s = 0.0;
   for (int i = threadIdx.x; i < n; i += blockDim.x) s += log(L[(size_t)i * ld + i]);
@@ -130,7 +130,7 @@ __global__ void logdet_kernel(const double* __restrict__ L, int ld, int n, doubl
 }
 
 // deterministic two-stage dot product of two equally laid out arrays: part[blockIdx.x]
-__global__ void dot_part_kernel(const double* __restrict__ A, const double* __restrict__ B, long long n, double* __restrict__ part) {
+inline __global__ void dot_part_kernel(const double* __restrict__ A, const double* __restrict__ B, long long n, double* __restrict__ part) {
   __shared__ double red[256];
   double s = 0.0;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) s += A[i] * B[i];
@@ -142,7 +142,7 @@ __global__ void dot_part_kernel(const double* __restrict__ A, const double* __re
   }
   if (threadIdx.x == 0) part[blockIdx.x] = red[0];
 }
-__global__ void sum_part_kernel(const double* __restrict__ part, int n, double* __restrict__ out) {
+inline __global__ void sum_part_kernel(const double* __restrict__ part, int n, double* __restrict__ out) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     double s = 0.0;
     for (int i = 0; i < n; ++i) s += part[i];
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(PMAX == 20 ? 640 : 1024) void poisson_pass_kernel(P
 // tables built once per parameter set (poisson_tables_kernel) and read from L2.  W tiles are staged in LDS and
 // leave as contiguous runs.  grid = (ceil(T/64), nslots), block = 256 (4 waves x 16 bins).
 // --------------------------------------------------------------------------------------------------
-__global__ void poisson_tables_kernel(const double* __restrict__ C, int q, int p, int qpad, int ncol, double* __restrict__ CCu,
+inline __global__ void poisson_tables_kernel(const double* __restrict__ C, int q, int p, int qpad, int ncol, double* __restrict__ CCu,
                                       double* __restrict__ C16) {
   const int n = blockIdx.x;
   for (int c = threadIdx.x; c < ncol; c += blockDim.x) {
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256) void poisson_mfma_kernel(PoissonArgs a, const 
 // Leave-one-neuron-out prediction (util.leaveOneOutPrediction util.py:328-329): rate of the held-out neuron at the
 // mode found without it, yp[slot][t] = exp(c_n . x_t + d_n), and err[slot] = sum_t (y_nt - yp_t)^2.
 // grid = nslots, block = 256.
-__global__ void loo_predict_kernel(const double* __restrict__ X, long long sX, const double* __restrict__ C, const double* __restrict__ d,
+inline __global__ void loo_predict_kernel(const double* __restrict__ X, long long sX, const double* __restrict__ C, const double* __restrict__ d,
                                    const uint8_t* __restrict__ Y, const uint8_t* __restrict__ Yhi, const int* __restrict__ trial_of_slot,
                                    const int* __restrict__ mask, int q, int p, int T, double* __restrict__ yp, long long sP, double* __restrict__ err) {
   __shared__ double red[256];
@@ -469,7 +469,7 @@ __global__ void loo_predict_kernel(const double* __restrict__ X, long long sX, c
 }
 
 // flik[slot] = sum_tile fpart[slot][tile]
-__global__ void sum_tiles_kernel(const double* __restrict__ fpart, int ntile, const int* __restrict__ slots, int nslots, double* __restrict__ out) {
+inline __global__ void sum_tiles_kernel(const double* __restrict__ fpart, int ntile, const int* __restrict__ slots, int nslots, double* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nslots) return;
   const int slot = slots[i];
@@ -483,7 +483,7 @@ __global__ void sum_tiles_kernel(const double* __restrict__ fpart, int ntile, co
 // Kinv slabs are (Tp x Tp) symmetric; the read runs down a column so lanes (t) are contiguous.
 // grid = (p, nslots), block = 256.
 // --------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void prior_matvec_kernel(const double* __restrict__ Kinv, int Tp, int T, int p,
+inline __global__ __launch_bounds__(256) void prior_matvec_kernel(const double* __restrict__ Kinv, int Tp, int T, int p,
                                                             const double* __restrict__ in, long long sIn,
                                                             double* __restrict__ out, long long sOut,
                                                             const int* __restrict__ slots) {
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(256) void prior_matvec_kernel(const double* __restr
 }
 
 // three dot products per slot: r[slot] = {a.b, c.b', c.d'} -> used for x^T K^-1 x, delta^T K^-1 x, delta^T K^-1 delta
-__global__ __launch_bounds__(256) void dots3_kernel(const double* __restrict__ X, long long sX, const double* __restrict__ KX, long long sKX,
+inline __global__ __launch_bounds__(256) void dots3_kernel(const double* __restrict__ X, long long sX, const double* __restrict__ KX, long long sKX,
                                                      const double* __restrict__ D, long long sD, const double* __restrict__ KD, long long sKD,
                                                      int n, const int* __restrict__ slots, double* __restrict__ qxx, double* __restrict__ qdx,
                                                      double* __restrict__ qdd) {
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(256) void dots3_kernel(const double* __restrict__ X
 }
 
 // total gradient for the solve: Gt[slot][i] = Gl[slot][i] + KX[slot][i]
-__global__ void grad_total_kernel(const double* __restrict__ Gl, long long sG, const double* __restrict__ KX, long long sKX,
+inline __global__ void grad_total_kernel(const double* __restrict__ Gl, long long sG, const double* __restrict__ KX, long long sKX,
                                   double* __restrict__ Gt, long long sGt, int n, const int* __restrict__ slots) {
   const int slot = slots[blockIdx.y];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -541,7 +541,7 @@ __global__ void grad_total_kernel(const double* __restrict__ Gl, long long sG, c
 }
 
 // Xt = X + alpha[slot] * delta
-__global__ void make_try_kernel(const double* __restrict__ X, long long sX, const double* __restrict__ D, long long sD,
+inline __global__ void make_try_kernel(const double* __restrict__ X, long long sX, const double* __restrict__ D, long long sD,
                                 const double* __restrict__ alpha, double* __restrict__ Xt, long long sXt, int n,
                                 const int* __restrict__ slots) {
   const int slot = slots[blockIdx.y];
@@ -550,7 +550,7 @@ __global__ void make_try_kernel(const double* __restrict__ X, long long sX, cons
 }
 
 // accepted slots: X <- Xt ; KX <- KX + alpha*KD ; Gl <- Glt ; W <- Wt
-__global__ void commit_kernel(double* __restrict__ X, const double* __restrict__ Xt, double* __restrict__ KX,
+inline __global__ void commit_kernel(double* __restrict__ X, const double* __restrict__ Xt, double* __restrict__ KX,
                               const double* __restrict__ KD, double* __restrict__ Gl, const double* __restrict__ Glt,
                               long long sV, double* __restrict__ W, const double* __restrict__ Wt, long long sW,
                               const double* __restrict__ alpha, int n, int nw, const int* __restrict__ slots) {
@@ -569,7 +569,7 @@ __global__ void commit_kernel(double* __restrict__ X, const double* __restrict__
 //   H[(k,t),(l,s)] = [k==l] Kinv[k][t][s] + [t==s] W[t][k][l]     (latent-major index i = k*T + t)
 // plus identity padding for rows/cols >= n.  grid = (npad, nslots): one block per column.
 // --------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void assemble_h_kernel(double* __restrict__ H, long long sH, int ld, int npad, int n, int T, int Tp, int p,
+inline __global__ __launch_bounds__(256) void assemble_h_kernel(double* __restrict__ H, long long sH, int ld, int npad, int n, int T, int Tp, int p,
                                                           const double* __restrict__ Kinv, const double* __restrict__ W, long long sW,
                                                           const int* __restrict__ slots, double diag_scale) {
   const int j = blockIdx.x;
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(256) void assemble_h_kernel(double* __restrict__ H,
 }
 
 // dense symmetric H (n x n, row-major == column-major) for one slot -> host-visible buffer (a6 getter)
-__global__ void dense_h_kernel(double* __restrict__ out, int n, int T, int Tp, int p, const double* __restrict__ Kinv,
+inline __global__ void dense_h_kernel(double* __restrict__ out, int n, int T, int Tp, int p, const double* __restrict__ Kinv,
                                const double* __restrict__ W) {
   const int j = blockIdx.x;
   const int kj = j / T, tj = j - kj * T;
@@ -791,7 +791,7 @@ __global__ __launch_bounds__(512) void post_vsm_mfma_kernel(const TIN* __restric
 }
 
 // (T,T,p) reference layout of post_vsmGP (inference.py:164-167) from the device layout [p][T][T]
-__global__ void vsmgp_to_ref_kernel(const double* __restrict__ src, double* __restrict__ dst, int T, int p) {
+inline __global__ void vsmgp_to_ref_kernel(const double* __restrict__ src, double* __restrict__ dst, int T, int p) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t tot = (size_t)T * T * p;
   if (e >= tot) return;
@@ -799,7 +799,7 @@ __global__ void vsmgp_to_ref_kernel(const double* __restrict__ src, double* __re
   const size_t ab = e / p;          // a*T + b
   dst[e] = src[(size_t)k * T * T + ab];
 }
-__global__ void vsmgp_from_ref_kernel(const double* __restrict__ src, double* __restrict__ dst, int T, int p) {
+inline __global__ void vsmgp_from_ref_kernel(const double* __restrict__ src, double* __restrict__ dst, int T, int p) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t tot = (size_t)T * T * p;
   if (e >= tot) return;
@@ -809,7 +809,7 @@ __global__ void vsmgp_from_ref_kernel(const double* __restrict__ src, double* __
 }
 
 // learning.makePrecomp learning.py:162-166: PautoSum[k] = sum_r (Sigma_r^{kk} + m_rk m_rk^T), into (Tp x Tp) slabs
-__global__ void pautosum_kernel(const double* __restrict__ vsmgp, const double* __restrict__ mean, const int* __restrict__ trials,
+inline __global__ void pautosum_kernel(const double* __restrict__ vsmgp, const double* __restrict__ mean, const int* __restrict__ trials,
                                 int ntr, int T, int Tp, int p, double* __restrict__ P) {
   const int k = blockIdx.y;
   const int b = blockIdx.x;               // column
@@ -829,7 +829,7 @@ __global__ void pautosum_kernel(const double* __restrict__ vsmgp, const double* 
 // Sum-only form of the above for the low-rank engine (no per-trial T x T blocks are stored): the E-step accumulates
 //   Pacc[k] += sum_slots Ymix_k Ymix_k^T + eps * diag(sum_slots G_t[k][k])
 // from split-K partial products part[k][split] (lower triangle valid, ld = T); grid = (T, p), block = 128
-__global__ void pacc_reduce_kernel(const double* __restrict__ part, int nsplit, const double* __restrict__ G, long long sG, int nslots,
+inline __global__ void pacc_reduce_kernel(const double* __restrict__ part, int nsplit, const double* __restrict__ G, long long sG, int nslots,
                                    double eps, int T, int Tp, int p, double* __restrict__ Pacc) {
   const int k = blockIdx.y, b = blockIdx.x;
   double* P = Pacc + (size_t)k * Tp * Tp;
@@ -853,7 +853,7 @@ __global__ void pacc_reduce_kernel(const double* __restrict__ part, int nsplit, 
 }
 
 // PautoSum[k] = Pacc[k] + sum_r m_rk m_rk^T  (same output layout as pautosum_kernel); grid = (Tp, p)
-__global__ void pauto_from_acc_kernel(const double* __restrict__ Pacc, const double* __restrict__ mean, const int* __restrict__ trials,
+inline __global__ void pauto_from_acc_kernel(const double* __restrict__ Pacc, const double* __restrict__ mean, const int* __restrict__ trials,
                                       int ntr, int T, int Tp, int p, double* __restrict__ P) {
   const int k = blockIdx.y;
   const int b = blockIdx.x;
@@ -1326,7 +1326,7 @@ __global__ __launch_bounds__(64 * CDH_KY) void mstep_cd_hess_rows_kernel(CdArgs 
 // + inv_s2 on the Hessian diagonal.  Writes delta[(p+1)][q] (vecCd layout) and dec[q] = -g.delta.
 // rtot: device address of the (all-reduced) trial count R, read here so that the host need not fetch it before the launch;
 // pack[q (p+3) + 1] = [row 0 of sums (per-neuron cost sums) | delta | dec | R]: everything the host reads back, one copy.
-__global__ void cd_newton_step_kernel(const double* __restrict__ sums, int q, int p, const double* __restrict__ rtot, const double* __restrict__ vec,
+inline __global__ void cd_newton_step_kernel(const double* __restrict__ sums, int q, int p, const double* __restrict__ rtot, const double* __restrict__ vec,
                                       const double* __restrict__ center, double inv_s2, double* __restrict__ pack) {
   extern __shared__ double sm[];
   const int D = p + 1;
@@ -1381,7 +1381,7 @@ __global__ void cd_newton_step_kernel(const double* __restrict__ sums, int q, in
 // chord pass: put a fresh cost/gradient (layout of mstep_cd_kernel: rows 0..p-1 dC, p dd, p+1 cost; signs of the
 // maximised sum) into the cost/gradient rows of the Newton sums (rows 0 cost, 1..p+1 gradient of the minimised
 // function); the Hessian rows of the last full pass stay.  One thread per (row, neuron).
-__global__ void cd_chord_merge_kernel(const double* __restrict__ cg, int q, int p, double* __restrict__ sums) {
+inline __global__ void cd_chord_merge_kernel(const double* __restrict__ cg, int q, int p, double* __restrict__ sums) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (p + 2) * q) return;
   const int row = e / q, n = e - row * q;
@@ -1393,7 +1393,7 @@ __global__ void cd_chord_merge_kernel(const double* __restrict__ cg, int q, int 
 // A block owns 32 consecutive elements; its 8 groups of 32 threads each sum every 8th part (a serial walk over all nb
 // parts by one thread is a chain of nb dependent-latency loads, ~1 us each), then the 8 group sums are added in a
 // fixed order through LDS - the result does not depend on scheduling.  grid = ceil(len/32), block = 256.
-__global__ __launch_bounds__(256) void reduce_parts_kernel(const double* __restrict__ part, int nb, int len, double* __restrict__ out) {
+inline __global__ __launch_bounds__(256) void reduce_parts_kernel(const double* __restrict__ part, int nb, int len, double* __restrict__ out) {
   __shared__ double red[8][33];
   const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int e = blockIdx.x * 32 + el;
@@ -1417,7 +1417,7 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(const double* __restr
 //   partial sums  sB = sum d_n lmy[n][t] ,  sD = sum lambda (log lambda - 1)
 // grid = (ceil(T/64), nslots), block = 64 threads (one bin each).
 // --------------------------------------------------------------------------------------------------
-__global__ void dual_prep_kernel(const uint8_t* __restrict__ Y, const uint8_t* __restrict__ Yhi, const double* __restrict__ C, const double* __restrict__ d,
+inline __global__ void dual_prep_kernel(const uint8_t* __restrict__ Y, const uint8_t* __restrict__ Yhi, const double* __restrict__ C, const double* __restrict__ d,
                                  const double* __restrict__ lam, long long sLam, double* __restrict__ V, long long sV,
                                  double* __restrict__ W, long long sW, double* __restrict__ part, int ntile,
                                  const int* __restrict__ slots, const int* __restrict__ trial_of_slot, int q, int p, int T) {
@@ -1455,7 +1455,7 @@ __global__ void dual_prep_kernel(const uint8_t* __restrict__ Y, const uint8_t* _
 }
 
 // dualProblem_grad (inference.py:218): g[n][t] = sum_k C[n][k] (Kv)[k][t] - d_n + log(lambda) - 0.5 c_n^T Sigma_t c_n
-__global__ void dual_grad_kernel(const double* __restrict__ C, const double* __restrict__ d, const double* __restrict__ lam,
+inline __global__ void dual_grad_kernel(const double* __restrict__ C, const double* __restrict__ d, const double* __restrict__ lam,
                                  const double* __restrict__ KV, const double* __restrict__ vsm_t, double* __restrict__ grad,
                                  int q, int p, int T) {
   const int t = blockIdx.x * 64 + threadIdx.x;
@@ -1475,7 +1475,7 @@ __global__ void dual_grad_kernel(const double* __restrict__ C, const double* __r
 
 // the same for the slots [0, nslots) at once: grid = (ceil(T/64), q, nslots); lam / grad are [slot][q*T], KV [slot][ld],
 // the per-bin blocks Sigma_t of slot s sit in vsm[trial_of_slot[s]]
-__global__ void dual_grad_batch_kernel(const double* __restrict__ C, const double* __restrict__ d, const double* __restrict__ lam,
+inline __global__ void dual_grad_batch_kernel(const double* __restrict__ C, const double* __restrict__ d, const double* __restrict__ lam,
                                        const double* __restrict__ KV, long long sKV, const double* __restrict__ vsm,
                                        const int* __restrict__ trial_of_slot, double* __restrict__ grad, int q, int p, int T) {
   const int t = blockIdx.x * 64 + threadIdx.x;
@@ -1498,7 +1498,7 @@ __global__ void dual_grad_batch_kernel(const double* __restrict__ C, const doubl
 
 // quad[slot][n][t] = 1/2 c_n^T Sigma_t c_n from the per-bin covariance blocks of the slot's trial (the vector form of the GEMM path in
 // dual_gradient).  grid = (ceil(T/64), q, nslots), block = 64
-__global__ void var_quad_kernel(const double* __restrict__ C, const double* __restrict__ vsm, const int* __restrict__ trial_of_slot,
+inline __global__ void var_quad_kernel(const double* __restrict__ C, const double* __restrict__ vsm, const int* __restrict__ trial_of_slot,
                                 double* __restrict__ quad, int q, int p, int T) {
   const int t = blockIdx.x * 64 + threadIdx.x;
   const int n = blockIdx.y;
@@ -1517,7 +1517,7 @@ __global__ void var_quad_kernel(const double* __restrict__ C, const double* __re
 
 // lam <- exp(lam) in place (the array holds rho on entry), or lam <- fill; flag[0] set when an entry of rho is not finite or its exp is not
 // positive and finite.  grid-stride over n entries
-__global__ void var_exp_kernel(double* __restrict__ lam, size_t n, int use_fill, double fill, int* __restrict__ flag) {
+inline __global__ void var_exp_kernel(double* __restrict__ lam, size_t n, int use_fill, double fill, int* __restrict__ flag) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const double r = lam[i];
     const double v = use_fill ? fill : exp(r);
@@ -1526,12 +1526,15 @@ __global__ void var_exp_kernel(double* __restrict__ lam, size_t n, int use_fill,
   }
 }
 // out <- log(lam)
-__global__ void var_log_kernel(const double* __restrict__ lam, double* __restrict__ out, size_t n) {
+inline __global__ void var_log_kernel(const double* __restrict__ lam, double* __restrict__ out, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = log(lam[i]);
 }
 
-// v <- v + damp (vnew - v) over the m entries of every slot; delta[slot] = max |vnew - v| (before the update).  grid = nslots, block = 256
-__global__ __launch_bounds__(256) void var_update_kernel(double* __restrict__ v, const double* __restrict__ vnew, size_t m, const double* __restrict__ damp,
+// maximum that keeps a NaN (fmax drops it: a slot of non-finite offsets would report a change of zero and pass for converged)
+__device__ __forceinline__ double nanmax(double a, double b) { return (a != a) ? a : ((b != b) ? b : fmax(a, b)); }
+
+// v <- v + damp (vnew - v) over the m entries of every slot; delta[slot] = max |vnew - v| (before the update; NaN if any entry is).  grid = nslots, block = 256
+inline __global__ __launch_bounds__(256) void var_update_kernel(double* __restrict__ v, const double* __restrict__ vnew, size_t m, const double* __restrict__ damp,
                                                          double* __restrict__ delta) {
   __shared__ double red[4];
   const size_t o = (size_t)blockIdx.x * m;
@@ -1539,18 +1542,18 @@ __global__ __launch_bounds__(256) void var_update_kernel(double* __restrict__ v,
   double d = 0.0;
   for (size_t i = threadIdx.x; i < m; i += 256) {
     const double a = v[o + i], b = vnew[o + i];
-    d = fmax(d, fabs(b - a));
+    d = nanmax(d, fabs(b - a));
     v[o + i] = a + s * (b - a);
   }
-  for (int off = 32; off > 0; off >>= 1) d = fmax(d, __shfl_down(d, off));
+  for (int off = 32; off > 0; off >>= 1) d = nanmax(d, __shfl_down(d, off));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
   __syncthreads();
-  if (threadIdx.x == 0) delta[blockIdx.x] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  if (threadIdx.x == 0) delta[blockIdx.x] = nanmax(nanmax(red[0], red[1]), nanmax(red[2], red[3]));
 }
 
 // ---- small batched vector kernels of the device L-BFGS (one optimisation per slot, vectors [slot][m]) ----------------
 // out[slot] = a[slot] . b[slot]; grid = nslots, block = 256 (fixed reduction tree: deterministic)
-__global__ __launch_bounds__(256) void bdot_kernel(const double* __restrict__ A, const double* __restrict__ B, size_t m, double* __restrict__ out) {
+inline __global__ __launch_bounds__(256) void bdot_kernel(const double* __restrict__ A, const double* __restrict__ B, size_t m, double* __restrict__ out) {
   __shared__ double red[256];
   const double* a = A + (size_t)blockIdx.x * m;
   const double* b = B + (size_t)blockIdx.x * m;
@@ -1565,7 +1568,7 @@ __global__ __launch_bounds__(256) void bdot_kernel(const double* __restrict__ A,
   if (threadIdx.x == 0) out[blockIdx.x] = red[0];
 }
 // out[slot] = max_i |a[slot][i]|
-__global__ __launch_bounds__(256) void bmaxabs_kernel(const double* __restrict__ A, size_t m, double* __restrict__ out) {
+inline __global__ __launch_bounds__(256) void bmaxabs_kernel(const double* __restrict__ A, size_t m, double* __restrict__ out) {
   __shared__ double red[256];
   const double* a = A + (size_t)blockIdx.x * m;
   double s = 0.0;
@@ -1579,7 +1582,7 @@ __global__ __launch_bounds__(256) void bmaxabs_kernel(const double* __restrict__
   if (threadIdx.x == 0) out[blockIdx.x] = red[0];
 }
 // y[slot] = beta[slot] * y[slot] + alpha[slot] * x[slot]   (beta NULL: 1); grid = (ceil(m/256), nslots)
-__global__ void baxpby_kernel(const double* __restrict__ alpha, const double* __restrict__ X, const double* __restrict__ beta,
+inline __global__ void baxpby_kernel(const double* __restrict__ alpha, const double* __restrict__ X, const double* __restrict__ beta,
                               double* __restrict__ Y, size_t m) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m) return;
@@ -1587,7 +1590,7 @@ __global__ void baxpby_kernel(const double* __restrict__ alpha, const double* __
   Y[e] = (beta ? beta[blockIdx.y] : 1.0) * Y[e] + alpha[blockIdx.y] * X[e];
 }
 // z[slot] = x[slot] + t[slot] * d[slot]
-__global__ void bstep_kernel(const double* __restrict__ X, const double* __restrict__ D, const double* __restrict__ t, double* __restrict__ Z,
+inline __global__ void bstep_kernel(const double* __restrict__ X, const double* __restrict__ D, const double* __restrict__ t, double* __restrict__ Z,
                              size_t m) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m) return;
@@ -1595,7 +1598,7 @@ __global__ void bstep_kernel(const double* __restrict__ X, const double* __restr
   Z[e] = X[e] + t[blockIdx.y] * D[e];
 }
 // dst[slot] = a[slot] - b[slot]  where take[slot] != 0 (other slots untouched)
-__global__ void bdiff_kernel(const double* __restrict__ A, const double* __restrict__ B, const int* __restrict__ take, double* __restrict__ dst,
+inline __global__ void bdiff_kernel(const double* __restrict__ A, const double* __restrict__ B, const int* __restrict__ take, double* __restrict__ dst,
                              size_t m) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m || !take[blockIdx.y]) return;
@@ -1603,25 +1606,25 @@ __global__ void bdiff_kernel(const double* __restrict__ A, const double* __restr
   dst[e] = A[e] - B[e];
 }
 // dst[slot] = src[slot] where take[slot] != 0
-__global__ void bcopy_kernel(const double* __restrict__ src, const int* __restrict__ take, double* __restrict__ dst, size_t m) {
+inline __global__ void bcopy_kernel(const double* __restrict__ src, const int* __restrict__ take, double* __restrict__ dst, size_t m) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m || !take[blockIdx.y]) return;
   const size_t e = (size_t)blockIdx.y * m + i;
   dst[e] = src[e];
 }
 // lam = exp(rho)
-__global__ void exp_kernel(const double* __restrict__ rho, double* __restrict__ lam, size_t n) {
+inline __global__ void exp_kernel(const double* __restrict__ rho, double* __restrict__ lam, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) lam[i] = exp(rho[i]);
 }
 // g_rho = g_lambda * lambda  (dualProblemRho_grad, inference.py:251-256)
-__global__ void chain_kernel(const double* __restrict__ glam, const double* __restrict__ lam, double* __restrict__ grho, size_t n) {
+inline __global__ void chain_kernel(const double* __restrict__ glam, const double* __restrict__ lam, double* __restrict__ grho, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) grho[i] = glam[i] * lam[i];
 }
 
 // out[row] = sum of the `len` consecutive entries of row `row`; grid = rows, block = 256
-__global__ __launch_bounds__(256) void sum_rows_kernel(const double* __restrict__ A, int len, double* __restrict__ out) {
+inline __global__ __launch_bounds__(256) void sum_rows_kernel(const double* __restrict__ A, int len, double* __restrict__ out) {
   __shared__ double red[256];
   const double* a = A + (size_t)blockIdx.x * len;
   double s = 0.0;
@@ -1635,7 +1638,7 @@ __global__ __launch_bounds__(256) void sum_rows_kernel(const double* __restrict_
   if (threadIdx.x == 0) out[blockIdx.x] = red[0];
 }
 // x = -Kv  (VIPostMean, inference.py:193-194)
-__global__ void negate_rows_kernel(const double* __restrict__ src, long long sSrc, double* __restrict__ dst, long long sDst, int n,
+inline __global__ void negate_rows_kernel(const double* __restrict__ src, long long sSrc, double* __restrict__ dst, long long sDst, int n,
                                    const int* __restrict__ slots) {
   const int slot = slots[blockIdx.y];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1651,7 +1654,7 @@ __global__ void negate_rows_kernel(const double* __restrict__ src, long long sSr
 // own p^2 doubles at stride 8p^2 and ran at 0.55 TB/s), row sums through LDS, the first row's thread of every block takes the maximum.
 // A workgroup walks chunks of 256 rows with stride gridDim.x and issues ONE pair of atomics at the end (a pair per wave per chunk was
 // 160 000 atomics on two addresses: 1.9 ms).  grid = min(ceil(nblocks p / 256), 2048), block = 256.
-__global__ __launch_bounds__(256) void block_norm_max_kernel(const double* __restrict__ B, long long nblocks, int p, double scale, unsigned* __restrict__ out_bits,
+inline __global__ __launch_bounds__(256) void block_norm_max_kernel(const double* __restrict__ B, long long nblocks, int p, double scale, unsigned* __restrict__ out_bits,
                                                              double* __restrict__ out_sq) {
   __shared__ double rs[256 + 32];
   __shared__ float wv[4];
@@ -1701,7 +1704,7 @@ __global__ __launch_bounds__(256) void block_norm_max_kernel(const double* __res
 // Shared-preconditioner Newton-PCG pieces.
 // Wbar[t] = mean over the listed slots of W[slot][t]   (p x p per bin) -> written into slot `dst` of Wdst
 // --------------------------------------------------------------------------------------------------
-__global__ void mean_w_kernel(const double* __restrict__ W, long long sW, const int* __restrict__ slots, int nslots, int len,
+inline __global__ void mean_w_kernel(const double* __restrict__ W, long long sW, const int* __restrict__ slots, int nslots, int len,
                               double* __restrict__ out) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= len) return;
@@ -1823,7 +1826,7 @@ __global__ __launch_bounds__(256) void pcg_hessvec_dot_wide_kernel(const double*
 }
 
 // alpha = rz/pq (pq = sum of the ntile partial products) ; x += alpha p ; r -= alpha q   (block per slot)
-__global__ __launch_bounds__(256) void pcg_update_xr_kernel(double* __restrict__ X, double* __restrict__ R, const double* __restrict__ P,
+inline __global__ __launch_bounds__(256) void pcg_update_xr_kernel(double* __restrict__ X, double* __restrict__ R, const double* __restrict__ P,
                                                             const double* __restrict__ Q, long long sV, int n, const int* __restrict__ slots,
                                                             const double* __restrict__ rz, const double* __restrict__ pqpart, int ntile) {
   const size_t slot = slots[blockIdx.x];
@@ -1837,7 +1840,7 @@ __global__ __launch_bounds__(256) void pcg_update_xr_kernel(double* __restrict__
 }
 
 // rz_new = r.z ; beta = rz_new/rz (0 on the first call: first != 0) ; p = z + beta p ; rz = rz_new ; also rr = r.r
-__global__ __launch_bounds__(256) void pcg_update_p_kernel(const double* __restrict__ R, const double* __restrict__ Z, double* __restrict__ P,
+inline __global__ __launch_bounds__(256) void pcg_update_p_kernel(const double* __restrict__ R, const double* __restrict__ Z, double* __restrict__ P,
                                                            long long sV, int n, const int* __restrict__ slots, double* __restrict__ rz,
                                                            double* __restrict__ rr, int first) {
   __shared__ double red[2][4];
@@ -1865,7 +1868,7 @@ __global__ __launch_bounds__(256) void pcg_update_p_kernel(const double* __restr
 }
 
 // r = -g ; x = 0  (rows >= n of every vector are kept at zero)
-__global__ void pcg_init_kernel(const double* __restrict__ G, double* __restrict__ R, double* __restrict__ X, long long sV, int n, int npad,
+inline __global__ void pcg_init_kernel(const double* __restrict__ G, double* __restrict__ R, double* __restrict__ X, long long sV, int n, int npad,
                                 const int* __restrict__ slots) {
   const size_t slot = slots[blockIdx.y];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1876,7 +1879,7 @@ __global__ void pcg_init_kernel(const double* __restrict__ G, double* __restrict
 }
 
 // out[slot] = |Gl + KX|^2 : squared norm of the total gradient at the committed point (block per listed slot)
-__global__ __launch_bounds__(256) void grad_norm2_kernel(const double* __restrict__ Gl, const double* __restrict__ KX, long long sV, int n,
+inline __global__ __launch_bounds__(256) void grad_norm2_kernel(const double* __restrict__ Gl, const double* __restrict__ KX, long long sV, int n,
                                                          const int* __restrict__ slots, double* __restrict__ out) {
   __shared__ double red[4];
   const size_t slot = slots[blockIdx.x];
@@ -1892,7 +1895,7 @@ __global__ __launch_bounds__(256) void grad_norm2_kernel(const double* __restric
 }
 
 // dec = -g.x ; smax = max|x|   (block per slot)
-__global__ __launch_bounds__(256) void step_stats_kernel(const double* __restrict__ G, const double* __restrict__ X, long long sV, int n,
+inline __global__ __launch_bounds__(256) void step_stats_kernel(const double* __restrict__ G, const double* __restrict__ X, long long sV, int n,
                                                          const int* __restrict__ slots, double* __restrict__ dec, double* __restrict__ smax) {
   __shared__ double red[2][4];
   const size_t slot = slots[blockIdx.x];
@@ -2010,7 +2013,7 @@ __global__ __launch_bounds__(NT * NS) void rbf_pivchol_kernel(double* __restrict
 
 // per (slot, bin): G = (I + eps W)^-1 and Wt = W G.  One thread per matrix, matrices in dynamic LDS.
 // (ldet, optional: ldet[item] = log det(I + eps W_t), item = list position * T + t)
-__global__ void bin_blocks_kernel(const double* __restrict__ W, long long sW, double* __restrict__ G, double* __restrict__ Wt, long long sO,
+inline __global__ void bin_blocks_kernel(const double* __restrict__ W, long long sW, double* __restrict__ G, double* __restrict__ Wt, long long sO,
                                   int T, int p, double eps, const int* __restrict__ slots, int nslots, double* __restrict__ ldet) {
   extern __shared__ double sm[];
   const int pp = p * p, stride = 2 * pp + 1;
@@ -2568,7 +2571,7 @@ __global__ __launch_bounds__(256) void mix_vsm_kernel(double* __restrict__ Yt, l
 }
 
 // vsmGP scatter for the low-rank engine: dst = mirror(src) + eps*G_t[k][k] on the diagonal
-__global__ void scatter_vsmgp_lr_kernel(const double* __restrict__ src, long long sSrc, int lds, double* __restrict__ dst, int T, int p, int k,
+inline __global__ void scatter_vsmgp_lr_kernel(const double* __restrict__ src, long long sSrc, int lds, double* __restrict__ dst, int T, int p, int k,
                                         const double* __restrict__ G, long long sG, double eps, const int* __restrict__ trial_of_slot) {
   const int slot = blockIdx.y;
   const size_t r = trial_of_slot[slot];
@@ -2582,7 +2585,7 @@ __global__ void scatter_vsmgp_lr_kernel(const double* __restrict__ src, long lon
 }
 
 // block-diagonal F (n x rpad, ld) and F^T (rpad x n, ldt = rpad) from the per-latent factors; grid = (rk_max, p)
-__global__ void build_fbig_kernel(const double* __restrict__ F, int Tf, int T, const int* __restrict__ roff, double* __restrict__ Fbig,
+inline __global__ void build_fbig_kernel(const double* __restrict__ F, int Tf, int T, const int* __restrict__ roff, double* __restrict__ Fbig,
                                   int ld, double* __restrict__ FTbig, int ldt) {
   const int k = blockIdx.y, a = blockIdx.x;
   const int r0 = roff[k], r1 = roff[k + 1];
@@ -2653,7 +2656,7 @@ inline size_t wide_lds_bytes(int p, int bins, int blocks_per_bin) {
 }
 
 // apply_bin_kernel for wide p.  grid = (ceil(T/bins), ceil(nslots / APPLY_BIN_SLOTS)), block = bins*32
-__global__ void apply_bin_wide_kernel(const double* __restrict__ Gb, const double* __restrict__ A, const double* __restrict__ B2, double scale,
+inline __global__ void apply_bin_wide_kernel(const double* __restrict__ Gb, const double* __restrict__ A, const double* __restrict__ B2, double scale,
                                       double* __restrict__ out, long long sV, int T, int p, int nslots, int bins) {
   extern __shared__ double wsm[];
   const int pp = p * p, LD = pp + 1;
@@ -2753,7 +2756,7 @@ __global__ __launch_bounds__(256, 1) void apply_bin_wide2_kernel(const double* _
 
 // mix_vsm_kernel for wide p: y <- G_t y for every column of the slab, post_vsm[t] = eps G_t + sum_b (G_t y_b)(G_t y_b)^T.
 // Thread (bin, a) owns row a of the accumulated block (columns c <= a).  grid = (ceil(T/bins), nslots), block = bins*32
-__global__ void mix_vsm_wide_kernel(double* __restrict__ Yt, long long sY, int ldy, const double* __restrict__ G, long long sG, int T, int p,
+inline __global__ void mix_vsm_wide_kernel(double* __restrict__ Yt, long long sY, int ldy, const double* __restrict__ G, long long sG, int T, int p,
                                     int rpad, double eps, double* __restrict__ vsm, const int* __restrict__ slots,
                                     const int* __restrict__ trial_of_slot, int bins, int ts) {
   extern __shared__ double wsm[];
@@ -2911,7 +2914,7 @@ __global__ __launch_bounds__(256, 1) void mix_vsm_wide2_kernel(double* __restric
 
 // vsm_finish_kernel for wide p: vsm[t] <- eps G_t + G_t Bt_t G_t in place.  Thread (bin, i) owns row i.
 // grid = (ceil(T/bins), nslots), block = bins*32; LDS holds the V and the G blocks of the block's bins.
-__global__ void vsm_finish_wide_kernel(double* __restrict__ vsm, const double* __restrict__ G, long long sG, int T, int p, double eps,
+inline __global__ void vsm_finish_wide_kernel(double* __restrict__ vsm, const double* __restrict__ G, long long sG, int T, int p, double eps,
                                        const int* __restrict__ slots, const int* __restrict__ trial_of_slot, int bins) {
   extern __shared__ double wsm[];
   const int pp = p * p, LD = pp + 1;
@@ -2966,7 +2969,7 @@ __global__ void vsm_finish_wide_kernel(double* __restrict__ vsm, const double* _
 constexpr int CM_TILE = 32, CM_BINS = 512, CM_LD = CM_BINS / 4 + 1;
 // (counts above 255: y = lo + 256 hi with the bytes in two planes, so sum y_i y_j is four such passes - plane Ya on the row side, Yb on the
 // column side, the 64-bit contribution scaled by cross_scale = 1 / 256 / 256 / 65536 and the row sums by sum_scale = 1 / 0 / 0 / 256)
-__global__ __launch_bounds__(256) void count_moments_kernel(const uint8_t* __restrict__ Ya, const uint8_t* __restrict__ Yb, const int* __restrict__ trials,
+inline __global__ __launch_bounds__(256) void count_moments_kernel(const uint8_t* __restrict__ Ya, const uint8_t* __restrict__ Yb, const int* __restrict__ trials,
                                                             int q, int T, unsigned long long* __restrict__ sum, unsigned long long* __restrict__ cross,
                                                             unsigned long long cross_scale, unsigned long long sum_scale) {
   __shared__ unsigned Wi[CM_TILE * CM_LD];
@@ -3034,7 +3037,7 @@ __global__ void pack_counts_kernel(const TS* __restrict__ src, uint8_t* __restri
 // ---- single-precision views of the factor slabs (mixed-precision dual-variational evaluation) ----------------------------
 // dst[slot] (float, n x n, ld = n) <- lower triangle of src[slot] (double, same shape); the upper triangle is zeroed.
 // grid = (ceil(n*n/1024), nslots), block = 256
-__global__ void cvt_lower_f32_kernel(const double* __restrict__ src, long long sS, float* __restrict__ dst, long long sD, int n) {
+inline __global__ void cvt_lower_f32_kernel(const double* __restrict__ src, long long sS, float* __restrict__ dst, long long sD, int n) {
   const double* a = src + (size_t)blockIdx.y * sS;
   float* b = dst + (size_t)blockIdx.y * sD;
   const size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x;
@@ -3047,11 +3050,11 @@ __global__ void cvt_lower_f32_kernel(const double* __restrict__ src, long long s
     }
   }
 }
-__global__ void cvt_f32_kernel(const double* __restrict__ src, float* __restrict__ dst, size_t n) {
+inline __global__ void cvt_f32_kernel(const double* __restrict__ src, float* __restrict__ dst, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = (float)src[i];
 }
-__global__ void fill_slabs_f32_kernel(float* __restrict__ p, long long stride, size_t n, float v) {
+inline __global__ void fill_slabs_f32_kernel(float* __restrict__ p, long long stride, size_t n, float v) {
   float* dst = p + (size_t)blockIdx.y * stride;
   const size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x;
 #pragma unroll
@@ -3061,7 +3064,7 @@ __global__ void fill_slabs_f32_kernel(float* __restrict__ p, long long stride, s
   }
 }
 // log det from a single-precision Cholesky factor, accumulated in double: out[b] = 2 sum_i log L[b][i][i]
-__global__ void logdet_batch_f32_kernel(const float* __restrict__ L, long long sL, int ld, int n, double* __restrict__ out) {
+inline __global__ void logdet_batch_f32_kernel(const float* __restrict__ L, long long sL, int ld, int n, double* __restrict__ out) {
   __shared__ double red[256];
   const float* Ls = L + (size_t)blockIdx.x * sL;
   double s = 0.0;
@@ -3075,7 +3078,7 @@ __global__ void logdet_batch_f32_kernel(const float* __restrict__ L, long long s
   if (threadIdx.x == 0) out[blockIdx.x] = 2.0 * red[0];
 }
 
-__global__ void fill_slabs_kernel(double* __restrict__ p, long long stride, size_t n, double v) {
+inline __global__ void fill_slabs_kernel(double* __restrict__ p, long long stride, size_t n, double v) {
   double* dst = p + (size_t)blockIdx.y * stride;
   const size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x;
 #pragma unroll
@@ -3088,7 +3091,7 @@ __global__ void fill_slabs_kernel(double* __restrict__ p, long long stride, size
 // columns from c0_k = roff_k rounded down to `ctile` on (the Yt product; the cross / first term of the split form start at roff_k itself), the inverse writes
 // the diagonal 128 x 128 blocks (zeros included) and everything above them, so only the strictly lower entries of these p rectangles can be stale.
 // ~ sum r_k^2 entries per slot instead of rpad^2.  grid = (p, slots), block = 256.
-__global__ void clear_lower_reads_kernel(double* __restrict__ Mt, long long sM, int ld, const int* __restrict__ roff, int ctile,
+inline __global__ void clear_lower_reads_kernel(double* __restrict__ Mt, long long sM, int ld, const int* __restrict__ roff, int ctile,
                                          const int* __restrict__ slots) {
   const int k = blockIdx.x;
   double* M = Mt + (size_t)(slots ? slots[blockIdx.y] : blockIdx.y) * sM;
@@ -3101,13 +3104,13 @@ __global__ void clear_lower_reads_kernel(double* __restrict__ Mt, long long sM, 
     if (col < row) M[(size_t)col * ld + row] = 0.0;
   }
 }
-__global__ void fill_kernel(double* __restrict__ p, size_t n, double v) {
+inline __global__ void fill_kernel(double* __restrict__ p, size_t n, double v) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
 }
 
 // gather / scatter of per-trial vectors between persistent [R][len] storage and slot storage [B][stride]
-__global__ void gather_rows_kernel(const double* __restrict__ src, int len, double* __restrict__ dst, long long sDst,
+inline __global__ void gather_rows_kernel(const double* __restrict__ src, int len, double* __restrict__ dst, long long sDst,
                                    const int* __restrict__ trial_of_slot, int zero) {
   const int slot = blockIdx.y;
   const size_t r = trial_of_slot[slot];
@@ -3116,7 +3119,7 @@ __global__ void gather_rows_kernel(const double* __restrict__ src, int len, doub
 }
 // start point of a slot: how[slot] = 0 zero (cold), 1 the resident mode m, 2 the linear extrapolation m + beta (m - m_prev)
 // over the trial's last two E-steps (over EM iterations the parameters drift smoothly and so do the modes).
-__global__ void gather_start_kernel(const double* __restrict__ mode, const double* __restrict__ prev, int len, double* __restrict__ dst,
+inline __global__ void gather_start_kernel(const double* __restrict__ mode, const double* __restrict__ prev, int len, double* __restrict__ dst,
                                     long long sDst, const int* __restrict__ trial_of_slot, const int* __restrict__ how, double beta) {
   const int slot = blockIdx.y;
   const size_t r = trial_of_slot[slot];
@@ -3131,7 +3134,7 @@ __global__ void gather_start_kernel(const double* __restrict__ mode, const doubl
   dst[(size_t)slot * sDst + i] = v;
 }
 // mode <- new point; prev <- the mode it replaces where rotate[slot] != 0
-__global__ void scatter_rotate_kernel(const double* __restrict__ src, long long sSrc, int len, double* __restrict__ mode, double* __restrict__ prev,
+inline __global__ void scatter_rotate_kernel(const double* __restrict__ src, long long sSrc, int len, double* __restrict__ mode, double* __restrict__ prev,
                                       const int* __restrict__ trial_of_slot, const int* __restrict__ rotate) {
   const int slot = blockIdx.y;
   const size_t r = trial_of_slot[slot];
@@ -3140,7 +3143,7 @@ __global__ void scatter_rotate_kernel(const double* __restrict__ src, long long 
   if (rotate[slot]) prev[r * len + i] = mode[r * len + i];
   mode[r * len + i] = src[(size_t)slot * sSrc + i];
 }
-__global__ void scatter_rows_kernel(const double* __restrict__ src, long long sSrc, int len, double* __restrict__ dst,
+inline __global__ void scatter_rows_kernel(const double* __restrict__ src, long long sSrc, int len, double* __restrict__ dst,
                                     const int* __restrict__ trial_of_slot) {
   const int slot = blockIdx.y;
   const size_t r = trial_of_slot[slot];

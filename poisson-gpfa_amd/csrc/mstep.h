@@ -36,7 +36,7 @@ struct CdM {
 // part[blockIdx.x][(p+1)][q].  grid = (nblocks), block = 256; a block walks trials, per trial bin tiles of 64: the count tile
 // [q][64] (coalesced 64-byte rows) and the mean tile [p][64] are staged in LDS, thread = neuron (q <= 256 per pass).
 // (Yhi: plane of the counts' high bytes, NULL when every count fits one byte - a second pass over the tile with weight 256)
-__global__ __launch_bounds__(256) void cd_ym_kernel(const uint8_t* __restrict__ Y, const uint8_t* __restrict__ Yhi, const double* __restrict__ mean,
+inline __global__ __launch_bounds__(256) void cd_ym_kernel(const uint8_t* __restrict__ Y, const uint8_t* __restrict__ Yhi, const double* __restrict__ mean,
                                                     const int* __restrict__ trials, int ntr, int q, int p, int T, double* __restrict__ part) {
   __shared__ double ms[32][64];
   __shared__ unsigned yt[256][17];                      // 64 counts of a neuron as 16 words (+1: bank spread)
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void cd_ym_kernel(const uint8_t* __restrict__ 
 
 // sums[(p+2)][q] (rows: -(sum yhat m + A c), -sum yhat, -sum yhat as written by mstep_cd_mfma_kernel and reduced over blocks)
 // += the count terms: rows k < p: YM[k][n]; row p: YS[n]; row p+1: c_n.YM_n + d_n YS_n
-__global__ void cd_add_ym_kernel(double* __restrict__ sums, const double* __restrict__ ym, const double* __restrict__ vec, int q, int p) {
+inline __global__ void cd_add_ym_kernel(double* __restrict__ sums, const double* __restrict__ ym, const double* __restrict__ vec, int q, int p) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= q) return;
   double lin = vec[(size_t)p * q + n] * ym[(size_t)p * q + n];
@@ -662,7 +662,7 @@ constexpr size_t cd_hess_mfma_lds_bytes() { return (2 * (size_t)CdH<PW>::LDS_DOU
 
 // count terms of the Newton pass: sums [NH][q] as reduced from mstep_cd_hess_mfma_kernel;  row 0 += c_n.YM_n + d_n YS_n,
 // gradient rows -= YM / YS  (the part layout of mstep_cd_hess_kernel: cost = sum (y hh - yhat), grad = -(sum y m - yhat w), -(sum y - yhat))
-__global__ void cd_hess_add_ym_kernel(double* __restrict__ sums, const double* __restrict__ ym, const double* __restrict__ vec, int q, int p) {
+inline __global__ void cd_hess_add_ym_kernel(double* __restrict__ sums, const double* __restrict__ ym, const double* __restrict__ vec, int q, int p) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= q) return;
   double lin = vec[(size_t)p * q + n] * ym[(size_t)p * q + n];

@@ -18,20 +18,16 @@
 // (pack_w32_kernel / pcg_hessvec32_dot_kernel): the inner solves then use H~ = K^-1 + fl32(W), an inexact Newton matrix whose
 // relative error (6e-8) is far below the forcing terms; gradients, objective and the covariance phase keep the FP64 blocks.
 #pragma once
+#include "types.h"
 
 namespace pgpfa {
 
-struct PcgCtl {
-  int stop; int iters; unsigned worst_bits; int nlive; unsigned long long slot_iters;
-  int nl[2];            // two-kernel step (pcg_cg_a/b_kernel): lengths of the two live lists (this step's, the next one's)
-  int pad_[2];
-};
 
 // One block: close an iteration.  ctl->iters counts executed iterations, ctl->slot_iters the slot-iterations (sum of the live counts).
 // The live list is compacted in place: a slot stays while its residual ratio (ratio[slot], written by pcg_update_p2_kernel) is above
 // its own target eta[slot] - or, before inner_min iterations, always - and the order of the survivors is kept.  stop is raised when
 // nobody is left.  host (mapped, may be null) receives {stop, iters}.  block = 256 threads.
-__global__ __launch_bounds__(256) void pcg_check_kernel(PcgCtl* __restrict__ ctl, volatile int* __restrict__ host, int* __restrict__ live,
+inline __global__ __launch_bounds__(256) void pcg_check_kernel(PcgCtl* __restrict__ ctl, volatile int* __restrict__ host, int* __restrict__ live,
                                                         const float* __restrict__ ratio, const float* __restrict__ eta, int inner_min) {
   __shared__ int keep_s[256];
   __shared__ int base_s, n_s, it_s;
@@ -83,7 +79,7 @@ __global__ __launch_bounds__(256) void pcg_check_kernel(PcgCtl* __restrict__ ctl
 
 // W[slot][t][p][p] (double) -> Wp[slot][t][NP] (float, lower triangle a >= b at a(a+1)/2 + b) for the listed slots.
 // grid = (ceil(T*NP/256), nslots)
-__global__ void pack_w32_kernel(const double* __restrict__ W, long long sW, float* __restrict__ Wp, long long sWp, int T, int p,
+inline __global__ void pack_w32_kernel(const double* __restrict__ W, long long sW, float* __restrict__ Wp, long long sWp, int T, int p,
                                 const int* __restrict__ slots) {
   const size_t slot = slots[blockIdx.y];
   const int np = p * (p + 1) / 2;
@@ -340,7 +336,7 @@ __global__ __launch_bounds__(256) void pcg_apply2_dots_kernel(const double* __re
 // rz_new, rr from the tile partial sums (tile order: deterministic) ; beta = rz_new / rz ; p = z + beta p ; rz = rz_new ;
 // rr0 on the first call of a solve ; the slot's residual ratio sqrt(rr / rr0) goes to ratio_out[slot] (and into ctl->worst_bits).
 // grid = (na), block = 256; with ctl the list is the live list and workgroups past ctl->nlive return.
-__global__ __launch_bounds__(256) void pcg_update_p2_kernel(const double* __restrict__ Z, double* __restrict__ P, long long sV, int n,
+inline __global__ __launch_bounds__(256) void pcg_update_p2_kernel(const double* __restrict__ Z, double* __restrict__ P, long long sV, int n,
                                                             const int* __restrict__ list, const double* __restrict__ part, int ntile,
                                                             double* __restrict__ rz, double* __restrict__ rr, double* __restrict__ rr0,
                                                             int first, PcgCtl* __restrict__ ctl, float* __restrict__ ratio_out) {
@@ -666,7 +662,7 @@ __global__ __launch_bounds__(256, 3) void pcg_cg_b_kernel(PcgCgP a) {
 // Closes a step (one thread): counts, stop flag when the next list is empty, the list just consumed is reset for the step after the
 // next, host mirror {stop, steps}.  (A separate launch, not a "last workgroup" inside B: a device-scope release there makes every
 // workgroup write its XCD's L2 back.)
-__global__ void pcg_iter_close_kernel(PcgCtl* __restrict__ ctl, int par, volatile int* __restrict__ host) {
+inline __global__ void pcg_iter_close_kernel(PcgCtl* __restrict__ ctl, int par, volatile int* __restrict__ host) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   if (!ctl->stop) {
     const int nnext = ctl->nl[par ^ 1];
@@ -701,7 +697,7 @@ __global__ void pack_sym_t_kernel(const double* __restrict__ M, TO* __restrict__
 // W[slot][t][p][p] (double) -> Wp[slot][c][T] (float, c over the lower triangle) for the listed slots: 64 bins per workgroup, packed
 // and transposed through LDS so that reads walk a bin's block and writes walk the bins.  grid = (ceil(T/64), nslots), block = 256,
 // dynamic LDS = NP * 65 floats
-__global__ __launch_bounds__(256) void pack_w32t_kernel(const double* __restrict__ W, long long sW, float* __restrict__ Wp, long long sWp, int Tw,
+inline __global__ __launch_bounds__(256) void pack_w32t_kernel(const double* __restrict__ W, long long sW, float* __restrict__ Wp, long long sWp, int Tw,
                                                         int T, int p, const int* __restrict__ slots) {
   extern __shared__ float w32t_tile[];
   const size_t slot = slots[blockIdx.y];

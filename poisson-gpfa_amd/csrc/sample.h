@@ -45,7 +45,7 @@ __device__ inline void normal2(const unsigned (&w)[4], double& n0, double& n1) {
 
 // X[trial][k][t] = sum_j F_k[t][j] z1[j] + sqrt(eps) z2[t].  grid = (p, ntrials), block = 256, dynamic LDS = rmax doubles.
 // Counter layout: (index, trial, latent, stream) with stream 1 = z1 pairs, 2 = z2 pairs.
-__global__ __launch_bounds__(256) void sample_latents_kernel(const double* __restrict__ F, int Tf, int T, int p, const int* __restrict__ rank,
+inline __global__ __launch_bounds__(256) void sample_latents_kernel(const double* __restrict__ F, int Tf, int T, int p, const int* __restrict__ rank,
                                                              double eps, unsigned long long seed, const int* __restrict__ trials,
                                                              double* __restrict__ X) {
   extern __shared__ double z1[];
@@ -112,7 +112,7 @@ __device__ inline unsigned poisson_draw(double lam, const Philox& rng, unsigned 
 // are flagged (overflow[0]) and the caller repeats the launch with the plane allocated (a draw is a pure function of its counters);
 // counts above 65535 are flagged in overflow[1].
 // grid = (ceil(T/64), q, ntrials), block = 64.
-__global__ __launch_bounds__(64) void sample_counts_kernel(const double* __restrict__ X, const double* __restrict__ C, const double* __restrict__ d, int q, int p,
+inline __global__ __launch_bounds__(64) void sample_counts_kernel(const double* __restrict__ X, const double* __restrict__ C, const double* __restrict__ d, int q, int p,
                                      int T, unsigned long long seed, const int* __restrict__ trials, uint8_t* __restrict__ Y,
                                      uint8_t* __restrict__ Yhi, int* __restrict__ overflow) {
   const int t = blockIdx.x * 64 + threadIdx.x;

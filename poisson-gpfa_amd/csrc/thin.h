@@ -28,7 +28,7 @@
 // the placement).
 #pragma once
 #include <hip/hip_runtime.h>
-#include "gemm.h"
+#include "types.h"
 
 namespace pgpfa {
 

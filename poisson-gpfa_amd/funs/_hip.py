@@ -64,6 +64,7 @@ _SIGNATURES = {
     'pgpfa_comm_unique_id': [ct.c_char_p],
     'pgpfa_comm_init': [ct.c_void_p, ct.c_char_p, ct.c_int, ct.c_int],
     'pgpfa_comm_allreduce_host': [ct.c_void_p, c_double_p, ct.c_int],
+    'pgpfa_comm_describe': [ct.c_void_p, ct.c_char_p, ct.c_int],
     'pgpfa_test_potrf': [ct.c_void_p, ct.c_int, ct.c_int, c_double_p, c_double_p, c_double_p],
     'pgpfa_test_gemm_nt': [ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, ct.c_double, c_double_p, c_double_p, ct.c_double, c_double_p],
     'pgpfa_test_gemm_nn': [ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, ct.c_double, c_double_p, c_double_p, ct.c_double, c_double_p],
@@ -440,6 +441,12 @@ class Context:
     def comm_init(self, uid, rank, nranks):
         warm_rccl_image()
         check(self.lib.pgpfa_comm_init(self.h, uid, int(rank), int(nranks)))
+
+    def comm_describe(self):
+        """One line about this rank's communicator (device, PCI bus id, the rank count RCCL itself reports)."""
+        buf = ct.create_string_buffer(256)
+        check(self.lib.pgpfa_comm_describe(self.h, buf, 256))
+        return buf.value.decode('utf-8', 'replace')
 
     def allreduce_host(self, arr):
         a = as_f64(arr).reshape(-1).copy()

@@ -39,6 +39,38 @@ class _stdout_to_stderr:
 _PROCESS_START = time.time()
 
 
+class phase_deadline:
+    """Watchdog around a start-up phase that can block for ever inside the library (ncclCommInitRank and the first collective have no
+    timeout: one rank that never joins holds all the others).  A helper thread waits for the phase to end; when the deadline passes
+    first it writes one line to stderr and ends THIS process with a non-zero status (os._exit: the main thread is stuck in a native
+    call and cannot be interrupted; nothing is re-executed) - the launcher then sees a failed rank with a message instead of a job that
+    hangs until somebody's outer limit kills it without one."""
+
+    def __init__(self, what, seconds, rank=0, exit_code=13):
+        self.what, self.seconds, self.rank, self.exit_code = what, float(seconds), rank, exit_code
+        import threading
+        self._done = threading.Event()
+        self._thread = threading.Thread(target=self._watch, daemon=True)
+
+    def _watch(self):
+        if not self._done.wait(self.seconds):
+            import sys
+            try:
+                sys.stderr.write('pgpfa: rank %d: %s did not finish within %.0f s (another rank never joined, or RCCL could not reach it); '
+                                 'exiting with status %d\n' % (self.rank, self.what, self.seconds, self.exit_code))
+                sys.stderr.flush()
+            finally:
+                os._exit(self.exit_code)
+
+    def __enter__(self):
+        self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._done.set()
+        return False
+
+
 class _World:
     def __init__(self):
         self.rank = int(os.environ.get('RANK', '0'))
@@ -73,7 +105,11 @@ class _World:
         job instead of a hang.  File names are keyed by MASTER_PORT, the launcher's run id, its restart count
         (TORCHELASTIC_RESTART_COUNT: a restarted worker group is another attempt) and pid (shared parent of all ranks)
         and a per-process serial.  A file older than this process by more than the timeout cannot belong to this attempt
-        (rank 0 gives up that long after publishing) and is ignored."""
+        (rank 0 gives up that long after publishing) and is ignored.
+        Every rank's acknowledgement also carries a random 16-byte nonce of ITS process, and the go-ahead repeats the nonces of
+        all ranks next to the id: a non-zero rank leaves only on a go-ahead that holds its own nonce, so the complete leftovers
+        of a crashed earlier run under the same key (id file + matching go-ahead: the key repeats when the same shell reruns
+        the job on the same port) cannot send it into ncclCommInitRank with a dead id before rank 0 has cleaned up."""
         self._serial += 1
         base = os.environ.get('PGPFA_RDZV_DIR', '/tmp')
         key = 'pgpfa_uid_%s_%s_%s_%d_%d' % (os.environ.get('MASTER_PORT', '0'), os.environ.get('TORCHELASTIC_RUN_ID', 'none'),
@@ -102,6 +138,7 @@ class _World:
             return _hip.HipBackendError('rendezvous of rank %d timed out after %.0f s waiting for %s (%s): a rank died at start-up or was '
                                         'never launched' % (self.rank, timeout, what, ', '.join(os.path.basename(m) for m in names)))
         acks = [path + '.ack.%d' % r for r in range(1, self.size)]
+        nonce = os.urandom(16)
         if self.rank == 0:
             for stale in [path, path + '.go'] + acks:
                 try:
@@ -111,7 +148,8 @@ class _World:
             uid = _hip.comm_unique_id()
             publish(path, uid)
             while True:
-                missing = [nm for nm in acks if read_fresh(nm) != uid]
+                got = [read_fresh(nm) for nm in acks]
+                missing = [nm for nm, a in zip(acks, got) if a is None or len(a) != 144 or a[:128] != uid]
                 if not missing:
                     break
                 if time.time() >= deadline:
@@ -121,7 +159,7 @@ class _World:
                         pass
                     raise timed_out('the acknowledgement of every rank', missing)
                 time.sleep(0.01)
-            publish(path + '.go', uid)
+            publish(path + '.go', uid + b''.join(a[128:] for a in got))
             for nm in acks:
                 try:
                     os.remove(nm)
@@ -133,10 +171,12 @@ class _World:
             uid = read_fresh(path)
             if uid is not None and len(uid) == 128:
                 if uid != held:
-                    publish(path + '.ack.%d' % self.rank, uid)
+                    publish(path + '.ack.%d' % self.rank, uid + nonce)
                     held = uid
-                if read_fresh(path + '.go') == held:
-                    # the go-ahead is written after every rank acknowledged THIS id, and rank 0 publishes one id per attempt
+                go = read_fresh(path + '.go')
+                if go is not None and len(go) == 128 + 16 * (self.size - 1) and go[:128] == held and \
+                        go[128 + 16 * (self.rank - 1):128 + 16 * self.rank] == nonce:
+                    # the go-ahead is written after every rank acknowledged THIS id, and it names this process: not a leftover
                     return held, path
             if time.time() >= deadline:
                 raise timed_out("rank 0's unique id" if held is None else "rank 0's go-ahead", [path if held is None else path + '.go'])
@@ -324,13 +364,23 @@ class Session:
         self.rank, self.size = 0, 1
         self.comm_ready = False
         if WORLD.enabled:
+            import sys
+            limit = float(os.environ.get('PGPFA_COMM_TIMEOUT', '300'))
             with _stdout_to_stderr():
                 uid, path = WORLD.exchange_unique_id()
-                self.ctx.comm_init(uid, WORLD.rank, WORLD.size)
+                # (every rank is known to be alive and to hold this id; what can still block is RCCL itself: bounded by a watchdog)
+                with phase_deadline('pgpfa_comm_init (ncclCommInitRank)', limit, WORLD.rank):
+                    self.ctx.comm_init(uid, WORLD.rank, WORLD.size)
                 self.rank, self.size = WORLD.rank, WORLD.size
                 self.comm_ready = True
                 # first collective doubles as the barrier after which rank 0 may remove the file
-                self.ctx.allreduce_host(np.zeros(1))
+                with phase_deadline('the first all-reduce', limit, WORLD.rank):
+                    ones = self.ctx.allreduce_host(np.ones(1))
+                # one line per rank for the launcher's log: which device, which PCI function, how many ranks RCCL itself saw
+                sys.stderr.write('pgpfa: %s first_allreduce_sum %g\n' % (self.ctx.comm_describe(), float(ones[0])))
+                sys.stderr.flush()
+                if int(round(float(ones[0]))) != WORLD.size:
+                    raise _hip.HipBackendError('first all-reduce over %d ranks summed to %g' % (WORLD.size, float(ones[0])))
             cleanup_rendezvous(path)
 
     def set_params(self, params):

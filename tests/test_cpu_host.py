@@ -273,10 +273,22 @@ def test_rendezvous_survives_leftovers_of_a_restarted_attempt(tmp_path):
     # leftover go-ahead with the OLD id next to a leftover id file: rank 1 alone must time out waiting, not leave with the old id
     key = 'pgpfa_uid_41005_none_0_%d_1' % os.getpid()
     (tmp_path / key).write_bytes(old_uid)
-    (tmp_path / (key + '.go')).write_bytes(bytes([1]) * 128)
+    (tmp_path / (key + '.go')).write_bytes(bytes([1]) * 128 + bytes(16))
     pr = _rdzv_rank(tmp_path, 1, 2, 41005, 3)
     out = pr.communicate(timeout=120)
     assert pr.returncode == 7 and 'go-ahead' in out[1], out
+    # the COMPLETE leftovers of a crashed run under the same key - id file and a go-ahead that matches it, both recent.  Rank 1
+    # starts first: it must not leave with the dead id (the go-ahead does not carry its nonce) but join rank 0's new attempt
+    key = 'pgpfa_uid_41007_none_0_%d_1' % os.getpid()
+    dead = bytes([7]) * 128
+    (tmp_path / key).write_bytes(dead)
+    (tmp_path / (key + '.go')).write_bytes(dead + bytes(16))
+    pr1 = _rdzv_rank(tmp_path, 1, 2, 41007, 60)
+    time.sleep(1.5)
+    assert pr1.poll() is None                          # still waiting: the leftover go-ahead was not taken
+    pr0 = _rdzv_rank(tmp_path, 0, 2, 41007, 60)
+    outs = [pr.communicate(timeout=120) for pr in (pr0, pr1)]
+    assert [pr0.returncode, pr1.returncode] == [0, 0], outs
     # a restart count in the environment is part of the key: the files of attempt 0 are not even looked at by attempt 1
     env_key = 'pgpfa_uid_41006_none_1_%d_1' % os.getpid()
     script = tmp_path / 'rdzv.py'
@@ -305,10 +317,28 @@ def test_bench_launcher_stops_all_ranks_when_one_dies():
     assert out.returncode != 0 and 'timeout after 3 s' in out.stderr, out
 
 
+def test_bench_launcher_reports_a_rank_stuck_in_comm_init():
+    """ncclCommInitRank has no timeout - a rank that hangs in it must end as a non-zero exit WITH a message inside the
+    comm-phase deadline (a helper thread ends the process; nothing is re-executed), and the launcher then stops the other ranks."""
+    import time
+    env = dict(os.environ, PGPFA_DRYRUN_COMM_HANG='1', PGPFA_DRYRUN_HANG='0', PGPFA_COMM_TIMEOUT='2', PGPFA_BENCH_TIMEOUT='100')
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run'], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0, out
+    assert 'rank 1: pgpfa_comm_init (ncclCommInitRank) did not finish within 2 s' in out.stderr, out
+    assert 'rank 1 exited with status 13' in out.stderr, out
+    assert time.time() - t0 < 60
+    # the launcher's own default limit stays below the 1800 s of whoever runs it
+    src = open(os.path.join(ROOT, 'bench.py')).read()
+    import re
+    assert float(re.search(r"PGPFA_BENCH_TIMEOUT', '(\d+)'", src).group(1)) <= 900
+
+
 def test_header_documents_every_option_and_info_key():
     """include/pgpfa.h is the C-ABI's documentation: every key pgpfa_set_option accepts and every info key the library sets is named there."""
     import re
-    src = open(os.path.join(ROOT, 'poisson-gpfa_amd', 'csrc', 'pgpfa.hip')).read()
+    csrc = os.path.join(ROOT, 'poisson-gpfa_amd', 'csrc')
+    src = ''.join(open(os.path.join(csrc, f)).read() for f in sorted(os.listdir(csrc)) if f.endswith('.hip'))
     hdr = open(os.path.join(ROOT, 'include', 'pgpfa.h')).read()
     options = sorted(set(re.findall(r'k == "([a-z0-9_]+)"', src)))
     infos = sorted(set(re.findall(r'c->info\["([a-z0-9_]+)"\]', src)))

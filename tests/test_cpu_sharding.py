@@ -53,6 +53,7 @@ class FakeContext:
     def set_params(self, C, d, tau): self.params = {{'C': np.array(C), 'd': np.array(d).reshape(-1), 'tau': np.array(tau).reshape(-1)}}
     def comm_init(self, uid, rank, nranks): pass
     def allreduce_host(self, arr): return allreduce(arr)
+    def comm_describe(self): return "rank %d/%d device cpu pci none comm gloo" % (rank, size)
     def estep_laplace(self, idx=None, warm_start=False):
         idx = np.arange(self.R) if idx is None else np.asarray(idx)
         assert len(set(idx.tolist())) == len(idx)

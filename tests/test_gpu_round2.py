@@ -67,16 +67,20 @@ def test_c3_size_spot_check_vs_reference(funs_mod, cov_mode):
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.mark.timeout(3000)
 def test_online_em_at_config3_dimensions(funs_mod):
-    """Stochastic EM as BASELINE config 4 runs it on one GPU: 2048 trials resident, minibatches of 1024, three iterations of the
+    """Stochastic EM as BASELINE config 4 runs it on one GPU at its REAL size: 8192 trials resident (the 0.8-GB count tensor, trial indices
+    far above 2047 in every minibatch), minibatches of 1024, three iterations of the
     engine's 'diag' loop (engine.py:288-448).  Size-independent checks, each against the reference's arithmetic restated by the
     oracle / plain numpy: (1) the minibatch index stream is the reference's RNG stream (util.py:459-473); (2) every returned
     mode of every minibatch is a stationary point of the reference's log-posterior (inference.py:34-48) under that iteration's
     parameters, and the reported nPLL is the mean of negLogPosteriorUnNorm there; (3) the new (C,d) make the oracle's gradient
     of MStepObservationCostWithPrior (learning.py:488-534) vanish on the minibatch's posterior; (4) each new timescale is a
     the stopping point of the reference's TNC call on
-    its prior-regularised cost and (inconsistent, learning.py:733-734) gradient, restated by the oracle on the device's PautoSum."""
+    its prior-regularised cost and (inconsistent, learning.py:733-734) gradient, restated by the oracle on the device's PautoSum;
+    (5) the configuration's 8-way split of a minibatch: the eight contiguous slices the ranks of an 8-GPU job would take (shard_slice) run
+    one after the other on this GPU give the same modes (1e-8) and their PautoSum / nPLL contributions ADD UP to the whole minibatch's
+    (1e-9) - what the RCCL all-reduce of the M-step statistics sums."""
     import bench
-    q, p, T, Rres, batch, iters = 200, 10, 500, 2048, 1024, 3
+    q, p, T, Rres, batch, iters = 200, 10, 500, 8192, 1024, 3
     true, Ys = bench.synth_shard(q, p, T, Rres, 12, 0)
     exp = bench.Shard(Ys, 10.0)
     exp._pgpfa_local_shard = False
@@ -144,6 +148,30 @@ def test_online_em_at_config3_dimensions(funs_mod):
             tau_o = (1.0 / np.exp(out.x[0])) ** 0.5 / 100.0
             assert abs(s['new']['tau'][k] - tau_o) <= 1e-3 * tau_o
     assert len(fit.paramSeq) == iters + 1 and np.all(np.isfinite(fit.optimParams['tau']))
+    assert max(int(np.max(seen[n]['idx'])) for n in range(iters)) > 8000 and min(int(np.min(seen[n]['idx'])) for n in range(iters)) < 100
+    # (5) the last minibatch again under its own parameters: whole, then as the eight slices of an 8-rank job
+    from funs import _session
+    sess, _ = _session.session_for(exp, p)
+    ctx = sess.ctx
+    s = seen[iters - 1]
+    ctx.set_params(s['old']['C'], s['old']['d'], s['old']['tau'])
+    idx = s['idx'].astype(np.int32)
+    obj_all, _, st = ctx.estep_laplace(idx)
+    assert np.all(st == 0)
+    ctx.mstep_precomp()
+    P_all, pm_all = ctx.pautosum(), ctx.post_mean(idx)
+    assert np.max(np.abs(pm_all - s['pm_all'])) <= 1e-8
+    P_sum, obj_sum = np.zeros_like(P_all), 0.0
+    for r in range(8):
+        lo, hi = _session.shard_slice(batch, r, 8)
+        obj_r, _, st = ctx.estep_laplace(idx[lo:hi])
+        assert np.all(st == 0) and hi - lo == 128
+        ctx.mstep_precomp()
+        P_sum += ctx.pautosum()
+        obj_sum += obj_r
+        assert np.max(np.abs(ctx.post_mean(idx[lo:hi]) - pm_all[lo:hi])) <= 1e-8
+    assert np.max(np.abs(P_sum - P_all)) <= 1e-9 * np.max(np.abs(P_all)) and abs(obj_sum - obj_all) <= 1e-10 * abs(obj_all)
+    _session.drop_sessions()
 
 
 # ---------------------------------------------------------------------------------------------------------------
