@@ -54,6 +54,7 @@ CONFIGS = {   # name: (neurons, latents, bins, trials per GPU)
 }
 FP64_MATRIX_PEAK_TFLOPS = 78.6     # MI355X FP64 matrix (= FP64 vector) peak, AMD CDNA4 datasheet
 HBM_PEAK_GBS = 8000.0              # HBM3E, MI355X_MICROARCH.md
+FP32_MATRIX_PEAK_TFLOPS = 157.3    # MI355X FP32 matrix peak (v_mfma_f32_16x16x4_f32: twice the FP64 rate), AMD CDNA4 datasheet
 
 
 class Shard:
@@ -227,6 +228,48 @@ def cpu_baseline_loo(params, Y0, bin_ms, y_pred0, searches):
     per = (time.time() - t0) / searches
     return {'kind': 'port', 'seconds_per_search': per, 'value': 1.0 / per, 'unit': 'mode searches/s', 'sample': '%d searches of trial 0' % searches,
             'cores': os.cpu_count(), 'max_rel_diff_of_predictions': worst}
+
+
+def cpu_baseline_dual(q, p, T, params, tau, Y0, bin_ms, budget_s=30.0, evals_per_trial=3800):
+    """cpu_baseline leg of the config-5 workload.  The reference cannot run this configuration (its C_big alone is 74.5 GiB, and every dual
+    evaluation forms np.diag(lamb), an (m x m) matrix with m = q T = 500 000: 2 TB).  What CAN be measured on the host is the reference's own
+    dual cost + gradient (inference.py:187-219, restated operation by operation in the oracle's *_faithful functions) on the first T_s bins of
+    trial 0 at the LARGEST T_s whose (m x m) temporaries fit a bounded budget, at two sizes, so that the growth law is measured too
+    (2 n m^2 + 2 n^2 m flops: cubic in T at fixed q, p).  The value is that evaluation scaled to T bins by the MEASURED exponent, times the
+    evaluations scipy's L-BFGS-B needs per trial under the reference's stopping rule - taken from the device L-BFGS run under the same rule at
+    these dimensions (profiles/r03_bench_c5_dual_estep_mixed.json: median 3800) - an EXTRAPOLATION, labelled as such."""
+    from oracle import pgpfa_oracle as orc
+    C, d = np.asarray(params['C'], dtype=np.float64), np.asarray(params['d'], dtype=np.float64)
+    times = {}
+    for Ts in (24, 40, 60):
+        m = q * Ts
+        if 3 * 8.0 * m * m > 24e9:                  # (three m x m temporaries alive at the worst point)
+            break
+        C_big, d_big = orc.make_Cd_big(C, d, Ts)
+        K_big = orc.make_K_big(orc.make_K(tau, Ts, bin_ms))
+        Kinv_big = np.linalg.inv(K_big)
+        ybar = np.asarray(Y0[:, :Ts], dtype=np.float64).reshape(-1)
+        lam = np.zeros(m) + 0.5                    # the reference's start (inference.py:294-297)
+        t0 = time.time()
+        f = orc.dual_cost_faithful(lam, ybar, C_big, K_big, Kinv_big, d_big)
+        g = orc.dual_grad_faithful(lam, ybar, C_big, K_big, Kinv_big, d_big)
+        times[Ts] = time.time() - t0
+        assert np.isfinite(f) and np.all(np.isfinite(g))
+        del C_big, K_big, Kinv_big, g
+        if times[Ts] > budget_s / 2:
+            break
+    sizes = sorted(times)
+    Ta, Tb = sizes[-2], sizes[-1]
+    expo = float(np.log(times[Tb] / times[Ta]) / np.log(Tb / Ta)) if len(sizes) > 1 and times[Ta] > 0 else 3.0
+    t_eval = times[Tb] * (T / Tb) ** expo
+    return {'kind': 'port', 'value': 1.0 / (evals_per_trial * t_eval), 'unit': 'trials/s through one whole variational E-step (EXTRAPOLATED)', 'cores': os.cpu_count(),
+            'sample': 'one dual cost + gradient of trial 0 by the reference\'s own operations (inference.py:187-219: np.diag(lamb) formed, dense (m x m) products) on its '
+                      'first %s bins at %d neurons x %d latents: %s s; scaled to %d bins by the measured exponent %.2f (flop law: 3) = %.3g s per evaluation, times %d '
+                      'evaluations per trial (median of the device L-BFGS under the reference\'s stopping rule at these dimensions, round 3); the reference itself '
+                      'cannot form its matrices at %d bins (np.diag(lamb) alone: %.1f TB)'
+                      % (sizes, q, p, [round(times[k], 2) for k in sizes], T, expo, t_eval, evals_per_trial, T, 8.0 * (q * T) ** 2 / 1e12),
+            'seconds_per_evaluation_measured': {str(k): times[k] for k in sizes}, 'measured_exponent': expo, 'seconds_per_evaluation_extrapolated': t_eval,
+            'evaluations_per_trial_assumed': evals_per_trial}
 
 
 def run_loo(args, q, p, T, R):
@@ -455,6 +498,38 @@ def run_dual(args, q, p, T, R, rank, world):
     t_max = float(np.max(allreduce(times)))
     if rank != 0:
         return
+    # roofline of the SAME workload (one more whole E-step, untimed, with HIP events around the tagged launches): the r x r phase of the low-rank
+    # engine - factorisation, inverse, Yt, the dual's neuron contractions - on the matrix cores in single precision ('mixed') or FP64, against the
+    # dense matrix peak of that type, and the mixing pass over the Yt slab against HBM (bytes: its columns read once, written once)
+    roof = None
+    if whole and fixed_point and not args.lean:
+        ctx.set_option('dual_f32', 1 if args.precision == 'mixed' else 0)
+        ctx.set_option('profile', 1)
+        ctx.dual_fixed_point(idx, None, want_rho=False)
+        ctx.dual_finalize(idx, None)
+        shapes = ctx.gemm_shape_report()
+        ctx.set_option('profile', 0)
+        f32 = args.precision == 'mixed'
+        g_ms = g_fl = o_ms = o_fl = 0.0
+        for line in shapes.splitlines():
+            ms = float(line.split(' ms')[0].split()[-1]); fl = float(line.split(' GFLOP')[0].split()[-1]) * 1e9
+            if line.startswith('f32' if f32 else 'f64'):
+                g_ms += ms; g_fl += fl
+            else:
+                o_ms += ms; o_fl += fl
+        peak = FP32_MATRIX_PEAK_TFLOPS if f32 else FP64_MATRIX_PEAK_TFLOPS
+        mix_ms, mix_by, mix_n = ctx.info('prof_mix_ms'), ctx.info('prof_mix_flops'), ctx.info('prof_mix_launches')
+        ach = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
+        roof = {'roofline': {'bound': 'mfma', 'kernel': 'gemm_mfma_kernel_t<%s> (r x r factorisation / inverse / Yt products of the low-rank engine%s)'
+                                      % ('float' if f32 else 'double', '' if not f32 else '; the FP64 products of the same E-step are listed under other_precision'),
+                             'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None, 'ms': g_ms, 'algorithmic_flops': g_fl,
+                             'other_precision': {'ms': o_ms, 'algorithmic_flops': o_fl, 'achieved': o_fl / (o_ms * 1e-3) / 1e12 if o_ms > 0 else 0.0,
+                                                 'peak': FP64_MATRIX_PEAK_TFLOPS if f32 else FP32_MATRIX_PEAK_TFLOPS},
+                             'share_of_estep': g_ms * 1e-3 / t_max},
+                'roofline_mixing': {'bound': 'hbm', 'kernel': 'mix_vsm_wide2_kernel<20> (per-bin mixing of the Yt slab: y <- G_t y in place, or the single-precision correction of the split form)',
+                                    'achieved': mix_by / (mix_ms * 1e-3) / 1e9 if mix_ms > 0 else 0.0, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                    'frac': mix_by / (mix_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if mix_ms > 0 else 0.0, 'ms': mix_ms, 'bytes': mix_by, 'launches': mix_n},
+                'kernel_time_ms_one_untimed_estep': {tag: round(ctx.info('prof_%s_ms' % tag), 1) for tag in ('gemm', 'potrf', 'poisson', 'vsm', 'mix', 'assemble', 'solve')}}
     common = {'n_gpus': world, 'steps': 1 if whole else args.dual_iters, 'warmup': args.warmup, 'higher_is_better': True, 'scaling': 'weak',
               'vs_baseline': None, 'dtype': 'f32 matrix products, f64 accumulation' if args.precision == 'mixed' else 'f64', 'data': 'synthetic',
               'batched_evaluations': evals, 'lbfgs_iterations_max': int(np.max(iters)), 'lbfgs_iterations_median': float(np.median(iters)),
@@ -481,6 +556,12 @@ def run_dual(args, q, p, T, R, rank, world):
                                        'means / covariance blocks; low-rank engine (rank %d) with the reference 1e-6 diagonal jitter'
                                        % (args.config, q, p, T, R, how, int(ctx.info('lowrank_rtot'))),
                            'parallelism': 'trial-sharded x%d' % world})
+        if roof:
+            out.update(roof)
+        if not args.no_cpu_baseline and world == 1:
+            out['cpu_baseline'] = cpu_baseline_dual(q, p, T, true_params, tau, Ys[0], 10.0, budget_s=min(args.cpu_budget, 60.0))
+            out['speedup_vs_cpu_baseline'] = out['value'] / out['cpu_baseline']['value']
+            out['speedup_vs_cpu_baseline_note'] = 'ratio to an EXTRAPOLATED figure (see cpu_baseline.sample): it says the reference cannot run this configuration, nothing about kernel quality'
     else:
         out = dict(common, metric='dual-variational trial-evaluations/sec', value=evals * R * world / t_max,
                    unit='trial-evaluations/s (dual cost + gradient)', ms_per_step=t_max / max(evals, 1) * 1e3,
@@ -582,6 +663,7 @@ def main():
     optim = None
     cd_method = [args.cd_method]
     nll_hist, estep_ms, mstep_ms, facts, solves, pcgs, cdp, nwt_ms, nwt_bytes, ranks = [], [], [], [], [], [], [], [], [], []
+    nwt_bytes_survey = []
     sess.ctx.set_option('time_newton', 1)           # two HIP events per inner solve: the Newton-solve kernels' time, next to their bytes
 
     def em_step():
@@ -600,6 +682,7 @@ def main():
         cdp.append(list(getattr(sess, '_cd_passes', (0, 0))))
         nwt_ms.append(sess.ctx.info('last_newton_solve_ms'))
         nwt_bytes.append(sess.ctx.info('last_newton_solve_bytes'))
+        nwt_bytes_survey.append(sess.ctx.info('last_newton_solve_bytes_survey'))
         ranks.append(sess.ctx.info('lowrank_rtot'))
 
     for _ in range(args.warmup):
@@ -627,7 +710,7 @@ def main():
     sess.ctx.set_option('profile', 0)
 
     def drop_last():
-        for lst in (estep_ms, mstep_ms, nll_hist, facts, solves, pcgs, cdp, nwt_ms, nwt_bytes, ranks):
+        for lst in (estep_ms, mstep_ms, nll_hist, facts, solves, pcgs, cdp, nwt_ms, nwt_bytes, nwt_bytes_survey, ranks):
             lst.pop()
 
     # one more (untimed) EM iteration with events around every tagged launch: the per-kernel-family breakdown
@@ -675,6 +758,7 @@ def main():
     achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     warm_e = float(np.mean(estep_ms[timed]))
     n_ms, n_by = float(np.sum(nwt_ms[timed])), float(np.sum(nwt_bytes[timed]))
+    n_by_survey = float(np.sum(nwt_bytes_survey[timed]))
     per_1024 = (total_trials / 1024.0) if args.config == 'c3' else 1.0
     out = {
         'metric': 'EM iterations/sec',
@@ -713,10 +797,14 @@ def main():
                                         'achieved': gemm_max_flops / (gemm_max_ms * 1e-3) / 1e12 if gemm_max_ms > 0 else 0.0,
                                         'frac': gemm_max_flops / (gemm_max_ms * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS if gemm_max_ms > 0 else 0.0}},
         # the Newton solve (north star: >= 40 % of the HBM roofline): every inner PCG solve of the timed region between two HIP events,
-        # against the bytes a perfect implementation of the same iteration would still move (20 n-vector passes + packed curvature per slot,
-        # the operators once per iteration; csrc/estep.hip: newton_bytes)
+        # against the bytes a perfect implementation of the same iteration would still move (17 n-vector passes + packed FP32 curvature per
+        # slot-iteration, the operators once per step; csrc/estep.hip: newton_bytes).  BOTH byte models are printed so that the fraction cannot move
+        # by redefining "mandatory": `frac` is this 17-pass model, `frac_survey_model` prices the same slot-iterations at SURVEY 8(d)'s
+        # B_E = q T + 8 (2 p T + T p^2) bytes per pass per trial
         'roofline_newton': {'bound': 'hbm', 'bytes': n_by, 'ms': n_ms, 'achieved': n_by / (n_ms * 1e-3) / 1e9 if n_ms > 0 else 0.0, 'peak': HBM_PEAK_GBS,
                             'unit': 'GB/s', 'frac': n_by / (n_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if n_ms > 0 else 0.0,
+                            'byte_model': '17 n-vector passes + packed FP32 curvature per slot-iteration + operators once per step',
+                            'bytes_survey_model': n_by_survey, 'frac_survey_model': n_by_survey / (n_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if n_ms > 0 else 0.0,
                             'ms_per_em_iteration': n_ms / args.steps, 'pcg_iterations_per_trial_per_estep': float(np.mean(pcgs[timed])) / R},
     }
     if not args.no_cpu_baseline and world == 1:

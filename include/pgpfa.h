@@ -68,7 +68,9 @@ int pgpfa_destroy(pgpfa_ctx* ctx);
  * covariance blocks are Gram products on the matrix cores - post_vsm_mfma_kernel, model.h; 0: vector kernel),
  * "extrapolate_start" (1: a warm-started E-step begins at m + beta (m - m_prev) for trials whose two previous
  * E-steps are resident), "extrapolate_beta" (1.0),
- * "pcg_form" (1: a step of the host-free inner iteration is two tile-parallel kernels - the one-reduction (Chronopoulos-Gear) form of
+ * "pcg_form" (2, round 5: as 1 with the solve's private vectors on line-aligned latent rows (T rounded up to 16 doubles), one start kernel for gradient / residual /
+ * first per-bin application, the closing of a step inside kernel A of the next one and one upload per solve - needs "thin_products";
+ * 1: a step of the host-free inner iteration is two tile-parallel kernels - the one-reduction (Chronopoulos-Gear) form of
  * PCG - plus the three preconditioner products, the prior mat-vec gone from the loop through Kt^-1 z = r - Wb z, pcg.h; up to 10 latents, needs "pcg_w32" and
  * "pcg_retire"; 0: the split kernels of round 3 with K^-1 p as a product),
  * "pcg_adapt" (1: the launches of a step of that iteration are sized by the live count the device last mirrored to the host - it only falls during a
@@ -110,8 +112,9 @@ int pgpfa_destroy(pgpfa_ctx* ctx);
 int pgpfa_set_option(pgpfa_ctx* ctx, const char* key, double value);
 /* Info: "chunk_trials", "plan_lowrank", "n_pad", "lowrank_rtot", "last_estep_ms", "last_newton_factorizations",
  * "last_newton_solves", "last_pcg_iterations", "last_shared_factorizations", "last_cov_lowrank",
- * "last_dense_retries", "hbm_bytes_allocated", "n_trials_global", "prof_<tag>_{ms,flops,launches}", "counts_two_bytes",
+ * "last_dense_retries", "hbm_bytes_allocated", "hbm_bytes_free" / "hbm_bytes_total" (hipMemGetInfo of the context's device, now), "n_trials_global", "prof_<tag>_{ms,flops,launches}", "counts_two_bytes",
  * "arena_bytes", "last_split_cov", "last_eps_wt_norm", "last_eps_wt_rms", "last_newton_solve_ms", "last_newton_solve_bytes",
+ * "last_newton_solve_bytes_survey" (the same slot-iterations priced at q T + 8 (2 p T + T p^2) bytes each: SURVEY 8(d)'s B_E per pass per trial),
  * "arena_vmm_failed" (1 once the virtual-memory arena fell back to plain allocations), "last_newton_max_iter", "last_dual_evaluations",
  * "last_loo_unconverged". */
 int pgpfa_get_info(pgpfa_ctx* ctx, const char* key, double* value);

@@ -476,6 +476,31 @@ def dual_grad(lam, ybar, C_big, K_big, Kinv_big, d_big):
     return C_big.T @ (K_big @ (C_big @ lmy)) - d_big + np.log(lam) - 0.5 * quad
 
 
+def vi_post_cov_faithful(Kinv_big, C_big, lam):
+    """inference.VIPostCov exactly as written (inference.py:187-190): the (m x m) diagonal matrix np.diag(lamb) is FORMED and multiplied
+    densely - 2 n m^2 flops and 8 m^2 bytes where the structured form above needs 2 n^2 m.  Used only to TIME the reference's arithmetic
+    (bench.py cpu_baseline of the config-5 workload); values equal vi_post_cov's."""
+    P = Kinv_big + np.dot(np.dot(C_big, np.diag(lam)), C_big.T)
+    return np.linalg.inv(P + 1e-6 * np.diag(np.diag(P))), P
+
+
+def dual_cost_faithful(lam, ybar, C_big, K_big, Kinv_big, d_big):
+    """inference.dualProblem as written, inference.py:196-213 (VIPostMean is evaluated and dropped there too)."""
+    _ = vi_post_mean(K_big, C_big, ybar, lam)
+    S, _ = vi_post_cov_faithful(Kinv_big, C_big, lam)
+    lmy = lam - ybar
+    A = 0.5 * np.dot(lmy.T, np.dot(C_big.T, np.dot(K_big, np.dot(C_big, lmy))))
+    sign, ld = np.linalg.slogdet(S)
+    return A - np.dot(d_big.T, lmy) + 0.5 * ld + np.dot(lam.T, np.log(lam) - np.ones(len(ybar)))
+
+
+def dual_grad_faithful(lam, ybar, C_big, K_big, Kinv_big, d_big):
+    """inference.dualProblem_grad as written, inference.py:215-219: the diagonal of the dense (m x m) product C_big^T Sigma C_big."""
+    S, _ = vi_post_cov_faithful(Kinv_big, C_big, lam)
+    lmy = lam - ybar
+    return np.dot(C_big.T, np.dot(K_big, np.dot(C_big, lmy))) - d_big + np.log(lam) - 0.5 * np.diag(np.dot(C_big.T, np.dot(S, C_big)))
+
+
 def dual_cost_rho(rho, *a):
     """inference.dualProblemRho, inference.py:222-244."""
     return dual_cost(np.exp(rho), *a)

@@ -334,12 +334,17 @@ int ensure_workspace(pgpfa_ctx* c, bool plan_lr) {
   CHK(dmalloc(c, &c->fpart, (size_t)((c->T + 63) / 64) * nB));
   CHK(dmalloc(c, &c->sc_part2, 3 * (size_t)((c->T + 63) / 64) * nB));
   CHK(dmalloc(c, &c->W32, (size_t)round_up(c->T, 32) * (c->p * (c->p + 1) / 2) * nB + 64));   // (rows of the component-major form start on 128-byte lines)
-  CHK(dmalloc(c, &c->pcgctl, 1, true));
-  CHK(dmalloc(c, &c->live, 2 * nB)); CHK(dmalloc(c, &c->pcg_ratio, nB, true)); CHK(dmalloc(c, &c->pcg_eta, nB, true));
+  static_assert(sizeof(PcgCtl) <= 64, "the control block is the first 16 words of the solve's upload block");
+  CHK(dmalloc(c, &c->pcg_blk, 16 + 4 * nB, true));
+  if (c->pcg_blk) {
+    c->pcgctl = reinterpret_cast<PcgCtl*>(c->pcg_blk); c->list_a = c->pcg_blk + 16; c->live = c->list_a + nB;
+    c->pcg_eta = reinterpret_cast<float*>(c->live + nB); c->live1 = c->live + 2 * nB;
+  }
+  CHK(dmalloc(c, &c->pcg_ratio, nB, true));
   CHK(dmalloc(c, &c->GbT, (size_t)c->T * (c->p * (c->p + 1) / 2) + 64)); CHK(dmalloc(c, &c->WbT, (size_t)c->T * (c->p * (c->p + 1) / 2) + 64));
   CHK(dmalloc(c, &c->sc_f, nB));
   CHK(dmalloc(c, &c->sc_alpha, nB));
-  CHK(dmalloc(c, &c->trial_of_slot, nB)); CHK(dmalloc(c, &c->list_a, nB)); CHK(dmalloc(c, &c->list_b, nB));
+  CHK(dmalloc(c, &c->trial_of_slot, nB)); CHK(dmalloc(c, &c->list_b, nB));
   CHK(dmalloc(c, &c->mask_of_slot, nB));
   CHK(dmalloc(c, &c->ident, nB));
   return 0;
@@ -888,7 +893,7 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
     // 0: off (the accumulated sums stay readable), 1: time every tagged launch, 2: GEMM launches only
     if (v != 0.0) {
       prof_collect(c);
-      c->prof.ms.clear(); c->prof.flops.clear(); c->prof.count.clear(); c->prof.max_ms.clear(); c->prof.max_flops.clear();
+      c->prof.ms.clear(); c->prof.flops.clear(); c->prof.count.clear(); c->prof.max_ms.clear(); c->prof.max_flops.clear(); c->prof.shapes.clear();
       // the events the run will cycle through are created and recorded once NOW: the runtime sets up its signal pools
       // on first use (a one-off ~30 ms that would otherwise land somewhere inside the region being timed)
       HIPC(hipSetDevice(c->device));
@@ -917,7 +922,7 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
 int pgpfa_get_info(pgpfa_ctx* c, const char* key, double* value) {
   if (!c || !key || !value) return fail("null argument");
   const std::string k(key);
-  static const char* tags[TAG_N] = {"gemm", "potrf", "solve", "poisson", "assemble", "vsm", "cd"};
+  static const char* tags[TAG_N] = {"gemm", "potrf", "solve", "poisson", "assemble", "vsm", "cd", "mix"};
   if (k.rfind("prof_", 0) == 0) {
     prof_collect(c);
     for (int t = 0; t < TAG_N; ++t) {
@@ -931,6 +936,13 @@ int pgpfa_get_info(pgpfa_ctx* c, const char* key, double* value) {
     return fail("unknown info key '%s'", key);
   }
   if (k == "hbm_bytes_allocated") { *value = (double)c->bytes; return 0; }
+  if (k == "hbm_bytes_free" || k == "hbm_bytes_total") {
+    size_t free_b = 0, total_b = 0;
+    HIPC(hipSetDevice(c->device));
+    HIPC(hipMemGetInfo(&free_b, &total_b));
+    *value = (double)(k == "hbm_bytes_free" ? free_b : total_b);
+    return 0;
+  }
   if (k == "n_trials_global") { *value = c->n_trials_global; return 0; }
   auto it = c->info.find(k);
   if (it == c->info.end()) return fail("unknown info key '%s'", key);

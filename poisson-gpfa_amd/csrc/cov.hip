@@ -131,7 +131,9 @@ static int accumulate_split(pgpfa_ctx* c, const CholWS& lw, int nb, int ract, in
   const long long sD = 2 * (long long)lw.sH;                                   // slab stride in floats
   const int ldd = c->ld;
   // 1. mixing pass: post_vsm and the correction D = eps Wt Yt (single precision); Yt itself stays
-  prof_begin(c, TAG_VSM, (double)nb * c->n * rpad * (3.0 * p + 1.0));
+  double mix_cols = 0.0;                                   // columns of Yt a latent's rows really hold: left of its first column tile nothing was written
+  for (int k = 0; k < p; ++k) mix_cols += std::max(0, ract - (ctile > 0 ? (c->roff[k] / ctile) * ctile : 0));
+  prof_begin(c, TAG_MIX, (double)nb * T * mix_cols * 12.0);            // (bytes: Yt read once in FP64, D written once in FP32)
   if (p > 16)                                               // (17..20 latents: split_candidate admits no others beyond 16)
     hipLaunchKernelGGL((mix_vsm_wide2_kernel<20, true>), dim3((T + 63) / 64, nb), dim3(256), 0, c->st, lw.H, (long long)lw.sH, c->ld, c->Gbin, sW, T, p, ract, c->eps,
                        c->vsm, c->ident, c->trial_of_slot, Ts, c->sink, D, sD, ldd);
@@ -421,7 +423,7 @@ int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool accumul
   } else if (want_vsmgp) {
     // d+e. one pass over Yt: post_vsm[t] = eps G_t + sum_b (G_t y_b)(G_t y_b)^T, and Yt is mixed in place (y <- G_t y) so that
     //      rows (k,.) of the slab become Ymix_k, the GEMM operand of post_vsmGP_k = eps diag(G_t[k][k]) + Ymix_k Ymix_k^T
-    prof_begin(c, TAG_VSM, (double)nb * c->n * rpad * (3.0 * p + 1.0));
+    prof_begin(c, TAG_MIX, (double)nb * c->n * ract * 16.0);           // (bytes: Yt read and written in place)
     dispatch_pw(p, [&](auto pw) {
       constexpr int PW = decltype(pw)::value;
       if constexpr (PW <= 16) {

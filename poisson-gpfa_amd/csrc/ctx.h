@@ -61,7 +61,8 @@ struct Prof {
 };
 constexpr int TAU_MULTI_MAX = 4;  // candidate points per latent in one batched timescale cost/gradient pass
 constexpr int PACC_SPLITS = 64;   // split-K groups of the sum-only vsmGP product
-enum { TAG_GEMM = 0, TAG_POTRF = 1, TAG_SOLVE = 2, TAG_POISSON = 3, TAG_ASSEMBLE = 4, TAG_VSM = 5, TAG_CD = 6, TAG_N };
+// (TAG_MIX: the mixing passes over the Yt slab - HBM-bound, so the number recorded with a launch is its algorithmic BYTES, not flops)
+enum { TAG_GEMM = 0, TAG_POTRF = 1, TAG_SOLVE = 2, TAG_POISSON = 3, TAG_ASSEMBLE = 4, TAG_VSM = 5, TAG_CD = 6, TAG_MIX = 7, TAG_N };
 
 
 struct pgpfa_ctx {
@@ -159,6 +160,10 @@ struct pgpfa_ctx {
   double *Rv = nullptr, *Zv = nullptr, *Pv = nullptr, *Qv = nullptr;
   PcgCtl* pcgctl = nullptr;                      // device-side control block of the inner PCG loop (pcg.h)
   int* live = nullptr; float *pcg_ratio = nullptr, *pcg_eta = nullptr;   // device live list of the inner solve, per-slot residual ratio / target
+  int* live1 = nullptr;                          // second live list of the two-kernel step
+  // (pcgctl, list_a, live, pcg_eta, live1 are consecutive pieces of ONE block - 16 + 4 B words - so that a solve's control block, first live list
+  //  and forcing terms go up in one copy: pcg_blk_host is its pinned image)
+  int* pcg_blk = nullptr;
   const int* cur_ndev = nullptr;                 // while set: products with a column list take their column count from this device word
   bool live_gemm_collect = false;                // profiling: the first iteration of an inner solve lists its live-list products here
   std::vector<std::pair<std::string, double>> live_gemms;   // (shape key, algorithmic flops per column)
@@ -170,7 +175,8 @@ struct pgpfa_ctx {
   int mt_fill = 1;                               // 1: before the inverse only the entries of the L^-T slabs that are read and not written are cleared; 0: the whole slab
   int pcg_xcd = 1;                               // 1: the per-bin kernels of the inner step place the bin tiles of a slot group on one XCD (pcg_cg_wg)
   int pcg_adapt = 1;                             // 1: launches of the host-free inner step sized by the mirrored live count, 16 / 8 / 4 slots per workgroup; 0: by the solve's first count
-  int pcg_form = 1;                              // host-free inner iteration (pcg.h): 1 two tile-parallel kernels per step, no prior mat-vec (pcg_cg_a/b_kernel);
+  int pcg_form = 2;                              // host-free inner iteration (pcg.h): 2 (round 5) = 1 with the solve's private vectors on line-aligned rows, one start kernel,
+                                                 // the step's closing folded into kernel A and one upload per solve; 1 two tile-parallel kernels per step, no prior mat-vec (pcg_cg_a/b_kernel);
                                                  // 0 the split kernels of round 3 with K^-1 p as a product
   double *Sv = nullptr, *cg_scal = nullptr;      // s = H~ z of the two-kernel form; its per-slot scalars [gamma | alpha] x step parity
   double *GbT = nullptr, *WbT = nullptr;         // [NP][T] packed triangles of the shared preconditioner's Gb and of the mean curvature (pcg_cg_a/b_kernel)

@@ -155,8 +155,10 @@ int pgpfa_laplace_hessian(pgpfa_ctx* c, int trial, const double* X, double* H) {
 // inverse of the r x r system: two per-bin kernels and three thin GEMMs, no n x n matrix anywhere.
 // (skip: device stop flag of the inner PCG loop; final_apply = false leaves the last per-bin application to the caller, with
 // y = F Sb F^T Gb R in c->Xt; first_apply = false: the caller has already put Gb R into c->Xt)
+// (vec_row > 0: the n-vectors c->Xt holds - input t and output y - are in the inner solve's private layout, latent rows vec_row apart (pcg.h:
+// PcgCgP::Tl); only with the thin kernels and without the per-bin applications)
 static int shared_solve(pgpfa_ctx* c, int nb, const double* R, double* Z, const int* skip = nullptr, bool first_apply = true,
-                        bool final_apply = true, const int* cols = nullptr, int ncols = 0) {
+                        bool final_apply = true, const int* cols = nullptr, int ncols = 0, int vec_row = 0) {
   const int ng = cols ? ncols : nb;                // columns of the multi-RHS products: all slots, or the listed (live) ones
   if (c->plan_lowrank) {
     const long long ld = c->ld;
@@ -180,8 +182,9 @@ static int shared_solve(pgpfa_ctx* c, int nb, const double* R, double* Z, const 
     if (first_apply) apply_bin(R, nullptr, 1.0, c->Xt);
     // the two block-diagonal products as kernels of their own (thin.h) where the matrix cores are in use; the general product otherwise
     const bool thin = c->thin_products && c->mfma && c->T >= 4 && (size_t)c->rpad <= (size_t)c->ld;
+    if (vec_row > 0 && (!thin || first_apply || final_apply)) return fail("internal: padded vector rows need the thin products and no per-bin application");
     ThinP tp{};
-    tp.F = c->Flr; tp.Tf = c->Tp; tp.T = c->T; tp.FT = c->FTbig; tp.ldft = c->rpad;
+    tp.F = c->Flr; tp.Tf = c->Tp; tp.T = c->T; tp.Tx = vec_row > 0 ? vec_row : c->T; tp.FT = c->FTbig; tp.ldft = c->rpad;
     tp.cols = cols; tp.n_dev = (cols && c->cur_ndev) ? c->cur_ndev : nullptr; tp.ncols = ng; tp.skip = skip;
     auto thin_prof = [&](const char* what) {
       prof_begin(c, TAG_SOLVE, tp.n_dev ? 0.0 : 2.0 * c->T * c->rtot * ng);
@@ -362,6 +365,7 @@ int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow_lr, do
   double total = 0.0;
   double n_fact = 0.0, n_solve = 0.0, n_pcg = 0.0, n_shared = 0.0;
   double newton_bytes = 0.0;                          // mandatory HBM bytes of the inner PCG iterations run (see below)
+  double newton_bytes_survey = 0.0;                   // the same slot-iterations priced by SURVEY 8(d)'s B_E = q T s_y + 8 (2 p T + T p^2) per pass per trial
   std::vector<std::pair<hipEvent_t, hipEvent_t>> newton_ev;   // events around every inner solve (the Newton-solve kernels)
   int max_it_seen = 0;
   std::vector<double> f(c->B), qxx(c->B), qdx(c->B), qdd(c->B), dec(c->B), smax(c->B), alpha(c->B), ftry(c->B);
@@ -511,13 +515,6 @@ int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow_lr, do
           eta_target = std::min(eta_target, std::max(1e-9, std::min(c->pcg_eta0, want)));
         }
         const int na = (int)active.size();
-        CHK(upload_nosync(c, c->list_a, active.data(), sizeof(int) * active.size()));
-        if (c->time_newton) {
-          newton_ev.emplace_back(prof_event(c->prof), prof_event(c->prof));
-          hipEventRecord(newton_ev.back().first, c->st);
-        }
-        hipLaunchKernelGGL(grad_total_kernel, dim3((nvec + 255) / 256, na), dim3(256), 0, c->st, c->Gl, ld, c->KX, ld, c->Gt, ld, nvec, c->list_a);
-        hipLaunchKernelGGL(pcg_init_kernel, dim3((c->npad + 255) / 256, na), dim3(256), 0, c->st, c->Gt, c->Rv, c->Dl, ld, nvec, c->npad, c->list_a);
         // (small chunks are launch-latency bound: there the extra packing / check launches of the host-free form cost more than
         // the round trips they remove - measured at config 2: 8.6 vs 8.0 ms per E-step)
         const bool fused = c->pcg_fused && c->plan_lowrank && p <= 16 && c->h_pcg != nullptr && (c->pcg_fused == 2 || (double)nb * c->n >= 1.0e6);
@@ -527,6 +524,19 @@ int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow_lr, do
         // form of the host-free iteration (pcg.h): the two-kernel step without the prior mat-vec needs the packed FP32 curvature and per-slot
         // retirement; otherwise the split kernels of round 3
         const bool onek = fused && c->pcg_w32 && c->pcg_retire && c->pcg_form != 0 && p <= 10;
+        // round 5 (pcg_form = 2): the solve's private vectors on line-aligned latent rows, ONE start kernel (gradient, residual, zero step, first
+        // per-bin application), the step's closing inside kernel A, ONE upload (control block, list, forcing terms); needs the thin products
+        const bool f2 = onek && c->pcg_form >= 2 && c->thin_products && c->mfma && T >= 4 && (size_t)c->rpad <= (size_t)c->ld && c->pcg_blk != nullptr;
+        const int Tl = (f2 && (long long)p * round_up(T, 16) <= ld) ? round_up(T, 16) : T;
+        if (!f2) CHK(upload_nosync(c, c->list_a, active.data(), sizeof(int) * active.size()));
+        if (c->time_newton) {
+          newton_ev.emplace_back(prof_event(c->prof), prof_event(c->prof));
+          hipEventRecord(newton_ev.back().first, c->st);
+        }
+        if (!f2) {
+          hipLaunchKernelGGL(grad_total_kernel, dim3((nvec + 255) / 256, na), dim3(256), 0, c->st, c->Gl, ld, c->KX, ld, c->Gt, ld, nvec, c->list_a);
+          hipLaunchKernelGGL(pcg_init_kernel, dim3((c->npad + 255) / 256, na), dim3(256), 0, c->st, c->Gt, c->Rv, c->Dl, ld, nvec, c->npad, c->list_a);
+        }
         if (onek) {
           // ---- inner solve: per step pcg_cg_a_kernel, pcg_cg_b_kernel, the closing kernel and the three preconditioner products (pcg.h)
           const int* skip = &c->pcgctl->stop;
@@ -543,34 +553,61 @@ int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow_lr, do
               }
               eta_s[s] = (float)es;
             }
-            CHK(upload_nosync(c, c->pcg_eta, eta_s.data(), sizeof(float) * nb));
-            CHK(copy_dev(c, c->live, c->list_a, sizeof(int) * na));
             PcgCtl h0{};
             h0.nlive = na; h0.nl[0] = na;
-            CHK(upload_nosync(c, c->pcgctl, &h0, sizeof(PcgCtl)));
+            if (f2) {
+              // one upload: [control block (16 words) | list_a | first live list | forcing terms] - consecutive pieces of c->pcg_blk
+              const size_t nB = (size_t)c->B;
+              std::vector<int> img(16 + 3 * nB, 0);
+              std::memcpy(img.data(), &h0, sizeof(PcgCtl));
+              std::memcpy(img.data() + 16, active.data(), sizeof(int) * na);
+              std::memcpy(img.data() + 16 + nB, active.data(), sizeof(int) * na);
+              std::memcpy(img.data() + 16 + 2 * nB, eta_s.data(), sizeof(float) * nb);
+              CHK(upload_nosync(c, c->pcg_blk, img.data(), img.size() * sizeof(int)));
+            } else {
+              CHK(upload_nosync(c, c->pcg_eta, eta_s.data(), sizeof(float) * nb));
+              CHK(copy_dev(c, c->live, c->list_a, sizeof(int) * na));
+              CHK(upload_nosync(c, c->pcgctl, &h0, sizeof(PcgCtl)));
+            }
           }
           c->h_pcg[0] = 0; c->h_pcg[1] = 0; c->h_pcg[2] = na;
-          hipLaunchKernelGGL(pack_w32t_kernel, dim3((T + 63) / 64, na), dim3(256), (size_t)npk * 65 * sizeof(float), c->st, c->W, (long long)T * p * p,
-                             c->W32, sW32, Tw, T, p, c->list_a);
-          // t = Gb r0, then y = F Sb F^T t over the listed columns (left in c->Xt)
-          CHK(shared_solve(c, nb, c->Rv, c->Zv, nullptr, true, false, c->list_a, na));
-          struct NdevGuard { pgpfa_ctx* c; ~NdevGuard() { c->cur_ndev = nullptr; } } ndev_guard{c};
-          c->live_gemms.clear();
           PcgCgP cp{};
           cp.GbT = c->GbT; cp.WbT = reinterpret_cast<const float*>(c->WbT); cp.W32T = c->W32; cp.sW32 = sW32; cp.Tw = Tw;
           cp.X = c->Dl; cp.R = c->Rv; cp.P = c->Pv; cp.Q = c->Qv; cp.Z = c->Zv; cp.S = c->Sv; cp.Y = c->Xt; cp.sV = ld;
           cp.part = c->sc_part2; cp.gam = c->cg_scal; cp.alp = c->cg_scal + 2 * (size_t)c->B; cp.rr = c->sc_rr; cp.rr0 = c->sc_rr0; cp.eta = c->pcg_eta;
-          cp.ctl = c->pcgctl; cp.live0 = c->live; cp.live1 = c->live + c->B;
+          cp.ctl = c->pcgctl; cp.live0 = c->live; cp.live1 = c->live1;
           cp.eps = c->eps; cp.T = T; cp.p = p; cp.inner_min = c->pcg_inner_min; cp.ntile = (T + 63) / 64; cp.B = c->B; cp.xcd_map = c->pcg_xcd;
+          cp.Tl = Tl; cp.Tx = T; cp.fold_close = f2 ? 1 : 0; cp.host = (volatile int*)c->d_hpcg; cp.Gl = c->Gl; cp.KX = c->KX; cp.Gt = c->Gt;
+          auto cg_grid = [&](int bound) {
+            cp.spw = !c->pcg_adapt ? PCG_SLOTS : bound > 640 ? 16 : bound > 320 ? 8 : 4;
+            return dim3((T + 63) / 64, round_up((bound + cp.spw - 1) / cp.spw, 8));               // (slot groups in blocks of 8: pcg_cg_wg)
+          };
+          if (f2) {
+            const dim3 g0 = cg_grid(na);
+            dispatch_pw(p, [&](auto pw) {
+              constexpr int PW = decltype(pw)::value;
+              if constexpr (PW <= 10) {
+                const size_t lb = pcg_cg_b_lds(PW);
+                if (lb > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pcg_cg_start_kernel<PW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+                hipLaunchKernelGGL(pcg_cg_start_kernel<PW>, g0, dim3(256), lb, c->st, cp);
+              }
+            });
+          }
+          hipLaunchKernelGGL(pack_w32t_kernel, dim3((T + 63) / 64, na), dim3(256), (size_t)npk * 65 * sizeof(float), c->st, c->W, (long long)T * p * p,
+                             c->W32, sW32, Tw, T, p, c->list_a);
+          // t = Gb r0 (the start kernel has it already), then y = F Sb F^T t over the listed columns (left in c->Xt)
+          CHK(shared_solve(c, nb, c->Rv, c->Zv, nullptr, !f2, false, c->list_a, na, f2 ? Tl : 0));
+          struct NdevGuard { pgpfa_ctx* c; ~NdevGuard() { c->cur_ndev = nullptr; } } ndev_guard{c};
+          c->live_gemms.clear();
+          int last_step = -1;
           for (int it = 0; it < c->pcg_inner_max; ++it) {
-            cp.par = it & 1; cp.first = (it == 0) ? 1 : 0;
+            cp.par = it & 1; cp.first = (it == 0) ? 1 : 0; cp.step = it; last_step = it;
             // The launches of a step are sized by the live count the closing kernel last mirrored to the host (it only falls during a solve, so a
             // value that is a step or two old is an upper bound; the kernels read the true count on the device).  Few live slots: fewer slots per
             // workgroup, so that the per-bin kernels still offer every CU a workgroup and a wave walks one slot instead of four in a row.
             const int seen = *(volatile int*)&c->h_pcg[2];
             const int bound = c->pcg_adapt ? std::max(1, std::min(na, seen)) : na;
-            cp.spw = !c->pcg_adapt ? PCG_SLOTS : bound > 640 ? 16 : bound > 320 ? 8 : 4;
-            const dim3 gcg((T + 63) / 64, round_up((bound + cp.spw - 1) / cp.spw, 8));       // (slot groups in blocks of 8: pcg_cg_wg)
+            const dim3 gcg = cg_grid(bound);
             dispatch_pw(p, [&](auto pw) {
               constexpr int PW = decltype(pw)::value;
               if constexpr (PW <= 10) {
@@ -582,11 +619,11 @@ int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow_lr, do
                 hipLaunchKernelGGL(pcg_cg_b_kernel<PW>, gcg, dim3(256), lb, c->st, cp);
               }
             });
-            hipLaunchKernelGGL(pcg_iter_close_kernel, dim3(1), dim3(64), 0, c->st, c->pcgctl, it & 1, (volatile int*)c->d_hpcg);
+            if (!f2) hipLaunchKernelGGL(pcg_iter_close_kernel, dim3(1), dim3(64), 0, c->st, c->pcgctl, it & 1, (volatile int*)c->d_hpcg, -1);
             // the preconditioner products for the NEXT iteration run over the list this launch has just written
             c->live_gemm_collect = (it == 0);
             c->cur_ndev = &c->pcgctl->nl[(it & 1) ^ 1];
-            CHK(shared_solve(c, nb, c->Rv, c->Zv, skip, false, false, (it & 1) ? c->live : c->live + c->B, bound));
+            CHK(shared_solve(c, nb, c->Rv, c->Zv, skip, false, false, (it & 1) ? c->live : c->live1, bound, f2 ? Tl : 0));
             if (*(volatile int*)&c->h_pcg[0]) break;           // the device has already stopped: whatever is enqueued is a no-op
             if (it + 1 < c->pcg_inner_max) {
               const auto t_spin = std::chrono::steady_clock::now();
@@ -596,6 +633,8 @@ int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow_lr, do
               if (*(volatile int*)&c->h_pcg[0]) break;
             }
           }
+          // (pcg_form 2: kernel A of step i + 1 closes step i; the last step enqueued is closed here unless the solve had stopped before it)
+          if (f2 && last_step >= 0) hipLaunchKernelGGL(pcg_iter_close_kernel, dim3(1), dim3(64), 0, c->st, c->pcgctl, last_step & 1, (volatile int*)c->d_hpcg, last_step);
           c->cur_ndev = nullptr;
           c->live_gemm_collect = false;
           CHK(dl_enqueue(c, &fused_ctl, c->pcgctl, sizeof(PcgCtl)));
@@ -770,6 +809,7 @@ int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow_lr, do
           const double ops = onek ? (2.0 * T * c->rtot + (double)c->rtot * c->rtot + 1.5 * T * npk) * 8.0
                                   : (double)p * T * T * 8.0 + (c->plan_lowrank ? (2.0 * T * c->rtot + (double)c->rtot * c->rtot) * 8.0 : (double)nvec * nvec * 8.0);
           newton_bytes += slot_iters * (vecs + curv) + (double)done_inner * ops;
+          newton_bytes_survey += slot_iters * ((double)c->q * T + 8.0 * (2.0 * p * T + (double)T * p * p));
         }
         std::vector<int> cand, next, failed;
         for (int s : active) {
@@ -1042,6 +1082,7 @@ int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow_lr, do
     (void)hipGetLastError();
     c->info["last_newton_solve_ms"] = nms;
     c->info["last_newton_solve_bytes"] = newton_bytes;
+    c->info["last_newton_solve_bytes_survey"] = newton_bytes_survey;
   }
   return 0;
 }

@@ -402,7 +402,36 @@ struct PcgCgP {
   double eps; int T, p, par, first, inner_min, ntile, B;
   int xcd_map;                                 // 1: workgroup -> (bin tile, slot group) by pcg_cg_wg; 0: grid indices as they are
   int spw;                                     // slots per workgroup (a multiple of 4, at most PCG_SLOTS): the host picks it by the live count it last saw
+  // Row strides of a latent inside a slot vector: Tl for the vectors PRIVATE to the solve (R, P, Q, Z, S, Y) - round 5: T rounded up to 16 doubles,
+  // so that every latent's row and every 64-bin tile of it start on a 128-byte line (at T = 500 a row started 32 bytes into a line and a tile's
+  // 512 bytes touched 5 lines for 4) - and Tx for X, the step the rest of the E-step reads in its compact layout (k T + t).  Form 1: Tl = Tx = T.
+  int Tl, Tx;
+  int step;                                    // index of this step within the solve
+  int fold_close;                              // 1: kernel A of step i closes step i - 1 (no closing launch per step; pcg_iter_close_kernel once after the last)
+  volatile int* host;                          // host-mapped {stop, steps, live} mirror (written by whoever closes a step)
+  const double *Gl, *KX; double* Gt;           // pcg_cg_start_kernel: likelihood gradient and K^-1 x (compact), their sum out
 };
+
+// Closes step `par`'s bookkeeping (one thread): counts, stop flag when the next list is empty, the list just consumed is reset for the step after
+// the next, host mirror {stop, steps, live}.
+__device__ __forceinline__ void pcg_close_step(PcgCtl* __restrict__ ctl, int par, volatile int* __restrict__ host) {
+  if (!ctl->stop) {
+    const int nnext = ctl->nl[par ^ 1];
+    ctl->iters += 1;
+    ctl->slot_iters += (unsigned long long)nnext;          // CG steps taken: the slots that went on (a retiring slot only ran the test)
+    ctl->nlive = nnext;
+    if (nnext == 0) ctl->stop = 1;
+  }
+  ctl->nl[par] = 0;
+  ctl->pad_[0] += 1;                                         // steps closed
+  if (host) {
+    host[2] = ctl->stop ? 0 : ctl->nlive;                  // (the live count only falls during a solve: a stale value is an upper bound)
+    host[1] = ctl->iters;
+    __threadfence_system();
+    host[0] = ctl->stop;
+    __threadfence_system();
+  }
+}
 
 // out = M v for the symmetric p x p matrix of this thread's bin, rows in two groups of about half the packed entries: the loads of a group
 // are in flight together, the compiler barrier keeps the second group's behind the first group's arithmetic (left alone the compiler
@@ -495,13 +524,18 @@ __global__ __launch_bounds__(256, 2) void pcg_cg_a_kernel(PcgCgP a) {
   extern __shared__ double pcg_cg_smem[];
   double* Gs = pcg_cg_smem;
   float* Ws = reinterpret_cast<float*>(pcg_cg_smem + 64 * LD);
-  const PcgCtl* ctl = a.ctl;
+  PcgCtl* ctl = a.ctl;
   if (ctl->stop) return;
   const int na = ctl->nl[a.par];
+  // (fold_close: the first workgroup closes the step before this one - its list is nl[par ^ 1], which nobody in this launch reads; the other
+  //  workgroups do not wait for it: they take their count from nl[par], final since kernel B of that step ended.  A step whose list came out
+  //  empty makes every workgroup return on na = 0; `stop` is for the products' skip flag and the host.)
+  if (a.fold_close && a.step > 0 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && ctl->pad_[0] == a.step - 1) pcg_close_step(ctl, a.par ^ 1, a.host);
   int wg_tile, wg_group;
   pcg_cg_wg(a.ntile, a.xcd_map, wg_tile, wg_group);
   if (wg_group * a.spw >= na) return;
   const int T = a.T, p = a.p, np = p * (p + 1) / 2;
+  const int Tl = a.Tl;
   const int t0 = wg_tile * 64;
   const int nt = min(64, T - t0);
   pcg_stage_sym<NP>(a.GbT, T, t0, nt, np, Gs, LD);
@@ -524,7 +558,7 @@ __global__ __launch_bounds__(256, 2) void pcg_cg_a_kernel(PcgCgP a) {
     // trips in a row, and a wave walks four slots
 #pragma unroll
     for (int k = 0; k < PW; ++k) {
-      const size_t o = base + (size_t)(k < p ? k : 0) * T;
+      const size_t o = base + (size_t)(k < p ? k : 0) * Tl;
       r[k] = a.R[o];
       v[k] = a.Y[o];
     }
@@ -554,7 +588,7 @@ __global__ __launch_bounds__(256, 2) void pcg_cg_a_kernel(PcgCgP a) {
       const double sk = (r[k] - w[k]) + v[k];                        // s = H~ z
       s0 += r[k] * z[k]; s1 += z[k] * sk; s2 += r[k] * r[k];
       if (in && k < p) {
-        const size_t o = base + (size_t)k * T;
+        const size_t o = base + (size_t)k * Tl;
         a.Z[o] = z[k];
         a.S[o] = sk;
       }
@@ -579,8 +613,9 @@ __global__ __launch_bounds__(256, 3) void pcg_cg_b_kernel(PcgCgP a) {
   int wg_tile, wg_group;
   pcg_cg_wg(a.ntile, a.xcd_map, wg_tile, wg_group);
   if (wg_group * a.spw >= na) return;
-  const int it = ctl->iters;
+  const int it = a.fold_close ? a.step : ctl->iters;       // (steps executed before this one: the closing of step - 1 may still be in flight in kernel A's first workgroup... it is not - A has ended - but a.step is the same number without the read)
   const int T = a.T, p = a.p, np = p * (p + 1) / 2;
+  const int Tl = a.Tl, Tx = a.Tx;
   const int t0 = wg_tile * 64;
   const int nt = min(64, T - t0);
   pcg_stage_sym<NP>(a.GbT, T, t0, nt, np, Gs, LD);
@@ -627,57 +662,93 @@ __global__ __launch_bounds__(256, 3) void pcg_cg_b_kernel(PcgCgP a) {
     double zk[PW], sk[PW], po[PW], qo[PW], xo[PW];
 #pragma unroll
     for (int k = 0; k < PW; ++k) {
-      const size_t o = base + (size_t)(k < p ? k : 0) * T;
-      zk[k] = a.Z[o]; sk[k] = a.S[o]; xo[k] = a.X[o]; r[k] = a.R[o];
+      const size_t o = base + (size_t)(k < p ? k : 0) * Tl;
+      zk[k] = a.Z[o]; sk[k] = a.S[o]; xo[k] = a.X[base + (size_t)(k < p ? k : 0) * Tx]; r[k] = a.R[o];
       po[k] = 0.0; qo[k] = 0.0;
     }
     if (!a.first) {
 #pragma unroll
       for (int k = 0; k < PW; ++k) {
-        const size_t o = base + (size_t)(k < p ? k : 0) * T;
+        const size_t o = base + (size_t)(k < p ? k : 0) * Tl;
         po[k] = a.P[o]; qo[k] = a.Q[o];
       }
     }
 #pragma unroll
     for (int k = 0; k < PW; ++k) {
       const bool ok = in && k < p;
-      const size_t o = base + (size_t)(k < p ? k : 0) * T;
+      const size_t o = base + (size_t)(k < p ? k : 0) * Tl;
       pv[k] = zk[k] + beta * po[k];
       const double qn = sk[k] + beta * qo[k];
       r[k] = ok ? r[k] - alpha * qn : 0.0;
       if (ok) {
         a.P[o] = pv[k];
         a.Q[o] = qn;
-        a.X[o] = xo[k] + alpha * pv[k];
+        a.X[base + (size_t)k * Tx] = xo[k] + alpha * pv[k];
         a.R[o] = r[k];
       }
     }
     pcg_sym_mv<PW, false>(g, 1, p, r, tv);
 #pragma unroll
     for (int k = 0; k < PW; ++k)
-      if (in && k < p) a.Y[base + (size_t)k * T] = tv[k];
+      if (in && k < p) a.Y[base + (size_t)k * Tl] = tv[k];
   }
 }
 
 // Closes a step (one thread): counts, stop flag when the next list is empty, the list just consumed is reset for the step after the
 // next, host mirror {stop, steps}.  (A separate launch, not a "last workgroup" inside B: a device-scope release there makes every
 // workgroup write its XCD's L2 back.)
-inline __global__ void pcg_iter_close_kernel(PcgCtl* __restrict__ ctl, int par, volatile int* __restrict__ host) {
+// (step >= 0: only when that step is the next one to close - with fold_close kernel A of the following step may already have done it)
+inline __global__ void pcg_iter_close_kernel(PcgCtl* __restrict__ ctl, int par, volatile int* __restrict__ host, int step = -1) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  if (!ctl->stop) {
-    const int nnext = ctl->nl[par ^ 1];
-    ctl->iters += 1;
-    ctl->slot_iters += (unsigned long long)nnext;          // CG steps taken: the slots that went on (a retiring slot only ran the test)
-    ctl->nlive = nnext;
-    if (nnext == 0) ctl->stop = 1;
-  }
-  ctl->nl[par] = 0;
-  if (host) {
-    host[2] = ctl->stop ? 0 : ctl->nlive;                  // (the live count only falls during a solve: a stale value is an upper bound)
-    host[1] = ctl->iters;
-    __threadfence_system();
-    host[0] = ctl->stop;
-    __threadfence_system();
+  if (step >= 0 && ctl->pad_[0] != step) return;
+  pcg_close_step(ctl, par, host);
+}
+
+// First kernel of a solve (round 5; one launch where grad_total_kernel, pcg_init_kernel and the per-bin application of the shared preconditioner
+// were three): for the slots of the solve's first live list  g = Gl + K^-1 x -> Gt (compact: the outer loop reads it),  r = -g -> R,  x = 0 -> X,
+// t = Gb r -> Y (input of the products y = F Sb F^T t).  Same launch shape and LDS as kernel B.
+template <int PW>
+__global__ __launch_bounds__(256, 3) void pcg_cg_start_kernel(PcgCgP a) {
+  constexpr int NP = PW * (PW + 1) / 2, LD = pcg_cg_ld(PW);
+  extern __shared__ double pcg_cg_smem[];
+  double* Gs = pcg_cg_smem;
+  const int na = a.ctl->nl[0];
+  int wg_tile, wg_group;
+  pcg_cg_wg(a.ntile, a.xcd_map, wg_tile, wg_group);
+  if (wg_group * a.spw >= na) return;
+  const int T = a.T, p = a.p, np = p * (p + 1) / 2;
+  const int Tl = a.Tl, Tx = a.Tx;
+  const int t0 = wg_tile * 64;
+  const int nt = min(64, T - t0);
+  pcg_stage_sym<NP>(a.GbT, T, t0, nt, np, Gs, LD);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool in = lane < nt;
+  const int t = t0 + (in ? lane : 0);
+  const double* g = Gs + lane * LD;
+  const int s_end = min(na, (wg_group + 1) * a.spw);
+  for (int si = wg_group * a.spw + wave; si < s_end; si += 4) {
+    const size_t base = (size_t)a.live0[si] * a.sV + t;
+    double r[PW], tv[PW];
+#pragma unroll
+    for (int k = 0; k < PW; ++k) {
+      const size_t o = base + (size_t)(k < p ? k : 0) * Tx;
+      r[k] = a.Gl[o] + a.KX[o];
+    }
+#pragma unroll
+    for (int k = 0; k < PW; ++k) {
+      const bool ok = in && k < p;
+      if (ok) {
+        a.Gt[base + (size_t)k * Tx] = r[k];
+        a.X[base + (size_t)k * Tx] = 0.0;
+        a.R[base + (size_t)k * Tl] = -r[k];
+      }
+      r[k] = ok ? -r[k] : 0.0;
+    }
+    pcg_sym_mv<PW, false>(g, 1, p, r, tv);
+#pragma unroll
+    for (int k = 0; k < PW; ++k)
+      if (in && k < p) a.Y[base + (size_t)k * Tl] = tv[k];
   }
 }
 

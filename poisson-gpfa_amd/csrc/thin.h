@@ -38,6 +38,8 @@ struct ThinP {
   const int* tab;                                // work table, four ints per blockIdx.y: (latent, first rank row, rank rows, rank offset) | (latent, first bin, rank, rank offset)
   const double* X; long long ldx;                // input vectors, one column per slot
   double* Y; long long ldy;                      // output vectors
+  int Tx;                                        // row stride between latents inside an n-vector (input of F^T t, output of F v): T, or T rounded up to 16
+                                                 // in the inner solve's private layout (pcg.h: PcgCgP::Tl); a multiple of 4 where VEC4 is used
   const int* cols; const int* n_dev; int ncols;  // column list (null: identity), device-side count (null: ncols)
   const int* skip;                               // device stop flag of the inner solve (null: none)
 #ifdef THIN_STAMPS
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(512, 2) void thin_ft_kernel(ThinP a) {
   //  and this load does not wait for the count)
   const int sc = min(s0 + l15, a.ncols - 1);
   const int slot = a.cols ? a.cols[sc] : sc;
-  const double* xp = a.X + (size_t)slot * a.ldx + (size_t)l * a.T;
+  const double* xp = a.X + (size_t)slot * a.ldx + (size_t)l * a.Tx;
   // row tile mi of this lane: rank row m0 + 4 l15 + mi (rows past the group's read neighbours' zeros or padding and are not stored)
   const double* fp = a.FT + (size_t)l * a.T * a.ldft + r0 + m0 + 4 * l15;
   const int nkb = (a.T + 15) >> 4;
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void thin_f_kernel(ThinP a) {
     const int sp = s0 + l4 + 4 * r;
     if (sp >= ncols) continue;
     const int so = a.cols ? a.cols[sp] : sp;
-    double* yp = a.Y + (size_t)so * a.ldy + (size_t)l * a.T;
+    double* yp = a.Y + (size_t)so * a.ldy + (size_t)l * a.Tx;
     if (VEC4) {
       if (t < a.T) *reinterpret_cast<double4_t*>(yp + t) = double4_t{acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
     } else {

@@ -38,7 +38,7 @@ int main(int argc, char** argv) {
   hipMemcpy(dft, tft.data(), tft.size() * 4, hipMemcpyHostToDevice); hipMemcpy(df, tf.data(), tf.size() * 4, hipMemcpyHostToDevice);
   hipMemcpy(dcols, cols.data(), S * 4, hipMemcpyHostToDevice); hipMemcpy(dn, &live, 4, hipMemcpyHostToDevice);
   ThinP a{};
-  a.F = F; a.Tf = Tf; a.T = T; a.FT = FT; a.ldft = rpad; a.cols = dcols; a.n_dev = dn; a.ncols = S; a.skip = nullptr;
+  a.F = F; a.Tf = Tf; a.T = T; a.Tx = T; a.FT = FT; a.ldft = rpad; a.cols = dcols; a.n_dev = dn; a.ncols = S; a.skip = nullptr;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int which = 0; which < 2; ++which) {
     ThinP q = a;
