@@ -2,7 +2,7 @@
 """Headline benchmark: EM iterations/s of the Poisson-GPFA hot path on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c2|c1] [--no-cpu-baseline] [--cpu-estimate]
-                    [--workload em|online|loo|dual]
+                    [--workload em|online|loo|dual|floor]
 
 A step is one full batch-EM iteration on synthetic spike counts already resident in HBM: warm-started Laplace
 E-step over every trial (batched inexact Newton with the shared-preconditioner PCG, posterior covariance blocks by
@@ -353,6 +353,59 @@ def spawn_ranks(n, timeout_s=None):
     sys.exit(0)
 
 
+def run_floor(args, q, p, T, R):
+    """The other end of the design: the same population with EVERY timescale short (--tau-all, default 30 ms = 3 bins).  The
+    pivoted Cholesky of such a Gram matrix has nearly full rank, the low-rank form of the prior buys nothing, and the auto plan must fall back to
+    the dense engine (one n x n factorisation + inverse per trial: 0.72 n^3 flops): the FLOOR of the E-step's speed.  EM iterations at fixed
+    parameters (E-step warm-started, device M-step) on R trials; also each engine forced, where it can run, to show the plan picked the
+    faster one.  One JSON line; not the headline metric."""
+    import funs
+    from funs import _session
+    np.random.seed(args.seed)
+    C = np.random.rand(q, p) - 0.5
+    d = np.random.rand(q) * (-2) - 1.0
+    tau = np.full(p, args.tau_all)
+    t = np.arange(T, dtype=np.float64) * 10.0
+    L = np.linalg.cholesky(0.999 * np.exp(-0.5 * (t[:, None] - t[None, :]) ** 2 / (args.tau_all * 1000.0) ** 2) + 0.001 * np.eye(T))
+    rng = np.random.default_rng([args.seed, 0])
+    Ys = []
+    for _ in range(R):
+        X = np.einsum('ts,ks->kt', L, rng.standard_normal((p, T)))
+        Ys.append(rng.poisson(np.exp(C @ X + d[:, None])).astype(np.uint8))
+    exp = Shard(Ys, 10.0)
+    params = {'C': C, 'd': d, 'tau': tau}
+    sess, _ = _session.session_for(exp, p)
+    res = {}
+    for name, mode in (('auto', 0), ('dense', 1), ('lowrank', 2)):
+        sess.ctx.set_option('cov_mode', mode)
+        par = {k: v.copy() for k, v in params.items()}
+        optim, est, mst, plan = None, [], [], None
+        try:
+            for it in range(args.warmup + args.steps):
+                t0 = time.time()
+                infRes, nll, optim = funs.inference.laplace(exp, par, prevOptimRes=optim)
+                t1 = time.time()
+                par, _ = funs.learning.updateParams(par, infRes, exp, CdOptimMethod=args.cd_method)
+                t2 = time.time()
+                est.append((t1 - t0) * 1e3); mst.append((t2 - t1) * 1e3)
+                plan = 'lowrank' if sess.ctx.info('last_cov_lowrank') else 'dense'
+            res[name] = {'engine': plan, 'estep_ms': [round(x, 1) for x in est], 'mstep_ms': [round(x, 1) for x in mst], 'lowrank_rtot': sess.ctx.info('lowrank_rtot'),
+                         'ms_per_em_iteration': float(np.mean(est[args.warmup:]) + np.mean(mst[args.warmup:])), 'chunk_trials': sess.ctx.info('chunk_trials')}
+        except Exception as exc:                                     # (the low-rank engine refuses ranks its buffers cannot hold: that is an answer too)
+            res[name] = {'engine': None, 'error': str(exc)[:200]}
+    a = res['auto']
+    n = p * T
+    out = {'metric': 'EM iterations/sec', 'value': 1e3 / a['ms_per_em_iteration'], 'unit': 'EM-iterations/s (%d trials, every timescale %.0f ms: the dense-engine floor)' % (R, args.tau_all * 1e3),
+           'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': a['ms_per_em_iteration'], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+           'dtype': 'f64', 'data': 'synthetic',
+           'config': {'workload': '%s floor: %d neurons, %d latents, %d bins, %d trials, all timescales %.0f ms (rank %d of n = %d): auto plan -> %s engine'
+                                  % (args.config, q, p, T, R, args.tau_all * 1e3, int(a['lowrank_rtot']), n, a['engine'])},
+           'engines': res,
+           'auto_plan_is_fastest': bool(a['ms_per_em_iteration'] <= 1.1 * min(v['ms_per_em_iteration'] for v in res.values() if v.get('engine'))),
+           'dense_engine_tflops': 0.72 * float(n) ** 3 * R / (float(np.mean(a['estep_ms'][args.warmup:])) * 1e-3) / 1e12 if a['engine'] == 'dense' else None}
+    print(json.dumps(out))
+
+
 def run_online(args, q, p, T, rank, world):
     """BASELINE config 4: stochastic EM (engine.py:288-448, 'diag' updates) - every iteration draws a minibatch from the
     resident trials with the reference's RNG call (util.py:459-473; same stream on every rank), each rank runs the Laplace
@@ -587,7 +640,8 @@ def main():
                     help="(C,d) M-step solver: 'newton' = device per-neuron Newton (exact minimiser of the reference's cost); "
                          "'TNC' = the reference engine's default scipy driver on the same device cost/grad")
     ap.add_argument('--seed', type=int, default=12)
-    ap.add_argument('--workload', default='em', choices=['em', 'online', 'loo', 'dual'],
+    ap.add_argument('--tau-all', type=float, default=0.03, help='--workload floor: every timescale (seconds)')
+    ap.add_argument('--workload', default='em', choices=['em', 'online', 'loo', 'dual', 'floor'],
                     help="'em' (default): the headline EM-iterations/s metric (config 3); 'online': config 4, stochastic EM with "
                          "minibatches over a larger resident set; 'loo': leave-one-neuron-out prediction throughput (1 GPU); 'dual': batched "
                          "dual-variational cost + gradient evaluations (the unit of work of config 5's E-step) at --config dimensions")
@@ -632,6 +686,8 @@ def main():
     bin_ms = 10.0
     if args.workload == 'loo':
         return run_loo(args, q, p, T, R)
+    if args.workload == 'floor':
+        return run_floor(args, q, p, T, args.trials if args.trials > 0 else 128)
     if args.workload == 'online':
         return run_online(args, q, p, T, rank, world)
     if args.workload == 'dual':

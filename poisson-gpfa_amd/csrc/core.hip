@@ -155,45 +155,86 @@ int free_workspace(pgpfa_ctx* c) {
 // Grow the arena to at least `need` bytes.  Preferred: map more physical memory behind the reserved address range (the arena does not
 // move, the bytes already mapped are not cleared again).  Fallback when the virtual-memory calls are not available: free and
 // re-allocate at the size needed.
-void arena_release(pgpfa_ctx* c);
-
-// Reserved address ranges of closed contexts, kept for the next context of this process instead of being handed back:
-// hipMemAddressFree crashed inside the runtime about once in ten runs of a test sequence that opens and closes a few dozen contexts
-// (native backtrace: arena_release -> hipMemAddressFree -> libamdhip64; never under a debugger).  A range is address space only - its
-// physical chunks are unmapped and released when the context closes - and there are never more ranges than contexts alive at once.
+//
+// Arenas of closed contexts stay in a process-wide pool, address range AND mapped memory (round 5).  Two facts of this stack decide that:
+// hipMemAddressFree crashed inside the runtime about once in ten runs of a test sequence that opens and closes a few dozen contexts (native
+// backtrace: arena_release -> hipMemAddressFree -> libamdhip64; never under a debugger), so ranges were already kept; and memory given back with
+// hipMemUnmap + hipMemRelease is NOT returned to the device's free memory while its range lives - tools/leak_probe.py: 308 GB free, a context
+// with a 91-GB arena, closed: 217 GB free; the next context's hipMemCreate calls are served from those 91 GB, hipMalloc and hipMemGetInfo never
+// see them again.  A plan sized by hipMemGetInfo then shrank with every large context the process had closed before (the config-5 test got 32
+// slots per chunk behind the rest of the suite, 128 alone).  Kept mapped, the memory is at least accounted for: the next context starts with
+// the pooled arena attached (nothing to map, nothing to clear) and the budget counts it.  When growth fails the other pooled arenas are released.
+struct PooledArena { void* va; size_t va_size; std::vector<std::pair<hipMemGenericAllocationHandle_t, size_t>> chunks; size_t cap; };
 std::mutex g_va_mu;
-std::vector<std::pair<void*, size_t>> g_va_free;
+std::vector<PooledArena> g_va_pool;
+
+static void pool_release_chunks(PooledArena& pa) {
+  size_t off = 0;
+  for (auto& ch : pa.chunks) { hipMemUnmap(reinterpret_cast<char*>(pa.va) + off, ch.second); hipMemRelease(ch.first); off += ch.second; }
+  pa.chunks.clear();
+  pa.cap = 0;
+  (void)hipGetLastError();
+}
+
+// bytes of pooled arenas no context holds (device `dev`: ranges are per process, memory per device - contexts of one process on several
+// devices are rare enough to ignore the distinction: a range is only re-attached on the device it was mapped for)
+static size_t pool_bytes() {
+  std::lock_guard<std::mutex> lk(g_va_mu);
+  size_t n = 0;
+  for (auto& pa : g_va_pool) n += pa.cap;
+  return n;
+}
+
+// first use of the arena by this context: virtual-memory management available?  reserve a range, or take a pooled one (with its memory)
+static void arena_init(pgpfa_ctx* c) {
+  if (c->vmm != 0) return;
+  hipMemAllocationProp prop{};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = c->device;
+  size_t gran = 0, free_b = 0, total_b = 0;
+  void* va = nullptr;
+  if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) == hipSuccess && gran > 0 &&
+      hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+    const size_t va_size = (total_b + gran - 1) / gran * gran;
+    const size_t G = std::max(gran, c->vmm_granule) / gran * gran;
+    {
+      std::lock_guard<std::mutex> lk(g_va_mu);
+      // the pooled arena with the most memory whose chunks have this context's chunk size and device
+      int best = -1;
+      for (size_t i = 0; i < g_va_pool.size(); ++i) {
+        const PooledArena& pa = g_va_pool[i];
+        if (pa.va_size != va_size) continue;
+        const bool fits = pa.chunks.empty() || pa.chunks.front().second == G;
+        if (fits && (best < 0 || pa.cap > g_va_pool[best].cap)) best = (int)i;
+      }
+      if (best >= 0) {
+        PooledArena pa = std::move(g_va_pool[best]);
+        g_va_pool.erase(g_va_pool.begin() + best);
+        va = pa.va;
+        c->vmm_chunks = std::move(pa.chunks);
+        c->arena_cap = pa.cap;
+        c->bytes += pa.cap;
+      }
+    }
+    if (va || (hipMemAddressReserve(&va, va_size, gran, nullptr, 0) == hipSuccess && va)) {
+      c->arena = reinterpret_cast<char*>(va); c->va_size = va_size; c->vmm_gran = gran; c->vmm = 1;
+      c->info["arena_bytes"] = (double)c->arena_cap;
+    }
+  }
+  if (c->vmm != 1) { (void)hipGetLastError(); c->vmm = -1; }
+}
 
 int arena_grow(pgpfa_ctx* c, size_t need) {
   g_err.clear();
-  if (c->vmm == 0) {
-    hipMemAllocationProp prop{};
-    prop.type = hipMemAllocationTypePinned;
-    prop.location.type = hipMemLocationTypeDevice;
-    prop.location.id = c->device;
-    size_t gran = 0, free_b = 0, total_b = 0;
-    void* va = nullptr;
-    if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) == hipSuccess && gran > 0 &&
-        hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-      const size_t va_size = (total_b + gran - 1) / gran * gran;
-      {
-        std::lock_guard<std::mutex> lk(g_va_mu);
-        for (size_t i = 0; i < g_va_free.size(); ++i)
-          if (g_va_free[i].second == va_size) { va = g_va_free[i].first; g_va_free.erase(g_va_free.begin() + i); break; }
-      }
-      if (va || (hipMemAddressReserve(&va, va_size, gran, nullptr, 0) == hipSuccess && va)) {
-        c->arena = reinterpret_cast<char*>(va); c->va_size = va_size; c->vmm_gran = gran; c->vmm = 1; c->arena_cap = 0;
-      }
-    }
-    if (c->vmm != 1) { (void)hipGetLastError(); c->vmm = -1; }
-  }
+  arena_init(c);
   if (c->vmm == 1) {
     const size_t gran = c->vmm_gran;
     // physical chunks of ONE granule each (one hipMemCreate / hipMemMap / hipMemSetAccess per chunk; 1 GiB by default).  Measured on this
     // stack: hipMemSetAccess returns "invalid argument" for a chunk whose size differs from the first one mapped into the range (13 chunks
     // of 4 GiB, then a 1-GiB remainder: fails; 1 GiB then 4 GiB: fails), so every chunk has the same size.
     const size_t G = std::max(gran, c->vmm_granule) / gran * gran;
-    size_t want = (need - c->arena_cap + G - 1) / G * G;
+    size_t want = need > c->arena_cap ? (need - c->arena_cap + G - 1) / G * G : 0;
     const char* what = "address range exhausted";
     hipError_t err = hipSuccess;
     bool ok = c->arena_cap + want <= c->va_size;
@@ -205,10 +246,19 @@ int arena_grow(pgpfa_ctx* c, size_t need) {
     hipMemAccessDesc desc{};
     desc.location = prop.location;
     desc.flags = hipMemAccessFlagsProtReadWrite;
+    bool pool_trimmed = false;
     while (ok && want > 0) {
       const size_t add = std::min(want, std::max(piece_max, gran));
       hipMemGenericAllocationHandle_t h;
       err = hipMemCreate(&h, add, &prop, 0);
+      if (err != hipSuccess && !pool_trimmed) {
+        // out of memory: the arenas other closed contexts left in the pool give theirs up (the runtime serves later hipMemCreate calls from it)
+        (void)hipGetLastError();
+        std::lock_guard<std::mutex> lk(g_va_mu);
+        for (auto& pa : g_va_pool) pool_release_chunks(pa);
+        pool_trimmed = true;
+        continue;
+      }
       if (err != hipSuccess) { what = "hipMemCreate"; ok = false; break; }
       err = hipMemMap(c->arena + c->arena_cap, add, 0, h, 0);
       if (err != hipSuccess) { what = "hipMemMap"; hipMemRelease(h); ok = false; break; }
@@ -227,7 +277,7 @@ int arena_grow(pgpfa_ctx* c, size_t need) {
     std::fprintf(stderr, "pgpfa: workspace arena: %s failed (%s) growing from %zu to %zu bytes; falling back to hipMalloc\n", what,
                  hipGetErrorString(err), c->arena_cap, need);
     c->bytes -= c->arena_cap;
-    arena_release(c);
+    arena_release(c, true);
     (void)hipGetLastError();
     c->va_size = 0; c->vmm = -1;
   }
@@ -240,15 +290,17 @@ int arena_grow(pgpfa_ctx* c, size_t need) {
   return 0;
 }
 
-void arena_release(pgpfa_ctx* c) {
+// (unmap: also release the physical chunks - the fallback path, which is about to try plain allocations; a closing context keeps them mapped
+//  in the pool)
+void arena_release(pgpfa_ctx* c, bool unmap) {
   if (c->vmm == 1) {
-    size_t off = 0;
-    for (auto& ch : c->vmm_chunks) { hipMemUnmap(c->arena + off, ch.second); hipMemRelease(ch.first); off += ch.second; }
-    c->vmm_chunks.clear();
     if (c->arena) {
+      PooledArena pa{c->arena, c->va_size, std::move(c->vmm_chunks), c->arena_cap};
+      if (unmap) pool_release_chunks(pa);
       std::lock_guard<std::mutex> lk(g_va_mu);
-      g_va_free.emplace_back(c->arena, c->va_size);
+      g_va_pool.push_back(std::move(pa));
     }
+    c->vmm_chunks.clear();
   } else if (c->arena) {
     hipFree(c->arena);
   }
@@ -271,8 +323,10 @@ int ensure_workspace(pgpfa_ctx* c, bool plan_lr) {
   c->ws_mark = c->allocs.size();
   c->plan_lowrank = plan_lr;
   size_t free_b = 0, total_b = 0;
+  arena_init(c);                                                              // (a pooled arena of a closed context comes with its memory)
   HIPC(hipMemGetInfo(&free_b, &total_b));
-  const size_t avail = (size_t)(0.85 * (double)(free_b + c->arena_cap));     // the arena's bytes are ours to re-partition
+  // the arena's bytes are ours to re-partition; so are those of pooled arenas nobody holds (arena_grow releases them when it must)
+  const size_t avail = (size_t)(0.85 * (double)(free_b + c->arena_cap + (c->vmm == 1 ? pool_bytes() : 0)));
   size_t budget = avail;
   {
     const size_t shared = (3 * ld_bytes(c) + 1024 * (size_t)c->ld * sizeof(double) * 4);
@@ -332,8 +386,10 @@ int ensure_workspace(pgpfa_ctx* c, bool plan_lr) {
   const size_t wlen = (size_t)c->T * c->p * c->p;
   CHK(dmalloc(c, &c->W, wlen * nB)); CHK(dmalloc(c, &c->Wt, wlen * nB));
   CHK(dmalloc(c, &c->fpart, (size_t)((c->T + 63) / 64) * nB));
-  CHK(dmalloc(c, &c->sc_part2, 3 * (size_t)((c->T + 63) / 64) * nB));
-  CHK(dmalloc(c, &c->W32, (size_t)round_up(c->T, 32) * (c->p * (c->p + 1) / 2) * nB + 64));   // (rows of the component-major form start on 128-byte lines)
+  CHK(dmalloc(c, &c->sc_part2, 3 * (size_t)((c->T + 31) / 32) * nB));       // (per (slot, bin tile) partial sums; 32-bin tiles beyond 10 latents)
+  // (rows of the component-major form start on 128-byte lines; beyond 10 latents the step's kernels read whole row chunks of the packed triangle at the
+  //  template width - up to 210 rows - past a slot's own: one slot's worth of slack behind the last)
+  CHK(dmalloc(c, &c->W32, (size_t)round_up(c->T, 32) * (c->p * (c->p + 1) / 2) * nB + (size_t)round_up(c->T, 32) * 210 + 64, true));
   static_assert(sizeof(PcgCtl) <= 64, "the control block is the first 16 words of the solve's upload block");
   CHK(dmalloc(c, &c->pcg_blk, 16 + 4 * nB, true));
   if (c->pcg_blk) {
@@ -1070,6 +1126,7 @@ int pgpfa_get_counts_u16(pgpfa_ctx* c, int n, const int32_t* idx, uint16_t* out)
 }
 
 int pgpfa_set_params(pgpfa_ctx* c, const double* C, const double* d, const double* tau_s) {
+  PhaseRange range_phase("pgpfa.set_params");
   if (!c || !C || !d || !tau_s) return fail("null argument");
   HIPC(hipSetDevice(c->device));
   for (int k = 0; k < c->p; ++k)

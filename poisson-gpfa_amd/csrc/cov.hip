@@ -133,7 +133,8 @@ static int accumulate_split(pgpfa_ctx* c, const CholWS& lw, int nb, int ract, in
   // 1. mixing pass: post_vsm and the correction D = eps Wt Yt (single precision); Yt itself stays
   double mix_cols = 0.0;                                   // columns of Yt a latent's rows really hold: left of its first column tile nothing was written
   for (int k = 0; k < p; ++k) mix_cols += std::max(0, ract - (ctile > 0 ? (c->roff[k] / ctile) * ctile : 0));
-  prof_begin(c, TAG_MIX, (double)nb * T * mix_cols * 12.0);            // (bytes: Yt read once in FP64, D written once in FP32)
+  // (bytes: the columns of Yt that hold something read once in FP64; D - dense, the mixing couples the latents - written once in FP32)
+  prof_begin(c, TAG_MIX, (double)nb * T * (mix_cols * 8.0 + (double)p * ract * 4.0));
   if (p > 16)                                               // (17..20 latents: split_candidate admits no others beyond 16)
     hipLaunchKernelGGL((mix_vsm_wide2_kernel<20, true>), dim3((T + 63) / 64, nb), dim3(256), 0, c->st, lw.H, (long long)lw.sH, c->ld, c->Gbin, sW, T, p, ract, c->eps,
                        c->vsm, c->ident, c->trial_of_slot, Ts, c->sink, D, sD, ldd);

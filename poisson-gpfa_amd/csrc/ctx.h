@@ -21,6 +21,7 @@
 #include <vector>
 
 #include <mutex>
+#include <rocprofiler-sdk-roctx/roctx.h>
 #include "../../include/pgpfa.h"
 #include "types.h"
 
@@ -44,6 +45,15 @@ int fail(const char* fmt, ...);
   } while (0)
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// roctx range around a phase of the path (tracing): rocprofv3 --marker-trace shows E-step / Newton solves / covariance blocks /
+// M-step passes as named ranges above the kernel rows; a push / pop pair costs nothing measurable when no tool is attached.
+struct PhaseRange {
+  explicit PhaseRange(const char* name) { roctxRangePushA(name); }
+  ~PhaseRange() { roctxRangePop(); }
+  PhaseRange(const PhaseRange&) = delete;
+  PhaseRange& operator=(const PhaseRange&) = delete;
+};
 
 struct Prof {
   bool on = false;
@@ -365,7 +375,7 @@ size_t ld_bytes(const pgpfa_ctx* c);
 size_t per_slot_bytes(const pgpfa_ctx* c, size_t slab_elems, size_t mt_elems);
 int free_workspace(pgpfa_ctx* c);
 int arena_grow(pgpfa_ctx* c, size_t need);
-void arena_release(pgpfa_ctx* c);
+void arena_release(pgpfa_ctx* c, bool unmap = false);
 int ensure_workspace(pgpfa_ctx* c, bool plan_lr);
 int upload_list(pgpfa_ctx* c, int* dst, const std::vector<int>& v);
 int copy_dev(pgpfa_ctx* c, void* dst, const void* src, size_t bytes);

@@ -334,6 +334,7 @@ int check_distinct(const std::vector<int>& v) {
 // L-BFGS-B runs of inference.dualVariational (DUAL_SOLVER = 'scipy') are driven concurrently so that one round of their
 // requests is one call of this.
 int pgpfa_dual_costgrad_batch(pgpfa_ctx* c, int n, const int32_t* idx, const double* lam, double* cost, double* grad) {
+  PhaseRange range_phase("pgpfa.dual_costgrad_batch");
   if (!c) return fail("null context");
   if (!lam || !cost) return fail("null argument");
   Trials tr;
@@ -364,6 +365,7 @@ int pgpfa_dual_costgrad_batch(pgpfa_ctx* c, int n, const int32_t* idx, const dou
 // max |gradient| <= pgtol.  rho[n][q*T]: start in, optimum out; fopt[n]: dual optimum; iters[n] (may be NULL).
 int pgpfa_dual_lbfgs(pgpfa_ctx* c, int n, const int32_t* idx, double* rho, int max_iter, double factr, double pgtol, double* fopt,
                      int32_t* iters) {
+  PhaseRange range_phase("pgpfa.dual_lbfgs");
   if (!c) return fail("null context");
   if (!rho || !fopt) return fail("null argument");
   if (max_iter < 1) return fail("max_iter must be positive");
@@ -594,6 +596,7 @@ int pgpfa_get_dual_lambda(pgpfa_ctx* c, int n, const int32_t* idx, double* out) 
 }
 
 int pgpfa_dual_finalize(pgpfa_ctx* c, int n, const int32_t* idx, const double* lam, double* nlp_sum) {
+  PhaseRange range_phase("pgpfa.dual_finalize");
   if (!c) return fail("null context");
   Trials tr;
   CHK(resolve_trials(c, n, idx, &tr, true));

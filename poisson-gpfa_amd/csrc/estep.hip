@@ -354,6 +354,7 @@ static int shared_factor(pgpfa_ctx* c, int nb) {
 
 int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow_lr, double* obj_sum, int32_t* iters, int32_t* status,
                       const LooJob* loo, const VarJob* var) {
+  PhaseRange range_estep(var ? "pgpfa.dual_fixed_point" : loo ? "pgpfa.loo_mode_search" : "pgpfa.estep_laplace");
   c->want_slots = std::max(c->want_slots, std::min((int)tr.v.size(), c->R));
   CHK(ready_estep(c, allow_lr));
   struct MaskGuard { pgpfa_ctx* c; ~MaskGuard() { c->mask_active = false; c->var_active = false; c->lam_out_active = false; } } mask_guard{c};
@@ -500,6 +501,7 @@ int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow_lr, do
     // (the mean-trial Hessian: cond(P^-1 H_r) stays below ~4, measured).  Every preconditioner application is two
     // multi-RHS triangular sweeps run as GEMMs over the slots; no per-trial factorisation in this phase.
     if (c->shared_pcg && (nb >= c->shared_min || c->plan_lowrank)) {
+      PhaseRange range_newton("pgpfa.newton_pcg");
       CHK(shared_factor(c, nb));
       n_shared += 1;
       std::vector<double> rr(nb), rr0(nb), err_pred(nb, -1.0);
@@ -517,16 +519,20 @@ int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow_lr, do
         const int na = (int)active.size();
         // (small chunks are launch-latency bound: there the extra packing / check launches of the host-free form cost more than
         // the round trips they remove - measured at config 2: 8.6 vs 8.0 ms per E-step)
-        const bool fused = c->pcg_fused && c->plan_lowrank && p <= 16 && c->h_pcg != nullptr && (c->pcg_fused == 2 || (double)nb * c->n >= 1.0e6);
+        const bool thin_ok = c->thin_products && c->mfma && T >= 4 && (size_t)c->rpad <= (size_t)c->ld;
+        // (11 .. 20 latents: only the round-5 form of the host-free step exists - pcgw_*_kernel - and it needs the thin products)
+        const bool wide_ok = p <= 20 && c->pcg_form >= 2 && thin_ok && c->pcg_w32 && c->pcg_retire && c->pcg_blk != nullptr;
+        const bool fused = c->pcg_fused && c->plan_lowrank && (p <= 16 || wide_ok) && c->h_pcg != nullptr && (c->pcg_fused == 2 || (double)nb * c->n >= 1.0e6);
         int done_inner = 0;
         PcgCtl& fused_ctl = c->fused_ctl_host;             // (context member: a queued read-back must not point into this frame)
         fused_ctl = PcgCtl{};
         // form of the host-free iteration (pcg.h): the two-kernel step without the prior mat-vec needs the packed FP32 curvature and per-slot
         // retirement; otherwise the split kernels of round 3
-        const bool onek = fused && c->pcg_w32 && c->pcg_retire && c->pcg_form != 0 && p <= 10;
+        const bool onek = fused && c->pcg_w32 && c->pcg_retire && c->pcg_form != 0 && (p <= 10 || wide_ok);
         // round 5 (pcg_form = 2): the solve's private vectors on line-aligned latent rows, ONE start kernel (gradient, residual, zero step, first
         // per-bin application), the step's closing inside kernel A, ONE upload (control block, list, forcing terms); needs the thin products
-        const bool f2 = onek && c->pcg_form >= 2 && c->thin_products && c->mfma && T >= 4 && (size_t)c->rpad <= (size_t)c->ld && c->pcg_blk != nullptr;
+        const bool f2 = onek && c->pcg_form >= 2 && thin_ok && c->pcg_blk != nullptr;
+        const int TB = p <= 10 ? 64 : PCGW_TB;               // bins per workgroup tile of the step's per-bin kernels
         const int Tl = (f2 && (long long)p * round_up(T, 16) <= ld) ? round_up(T, 16) : T;
         if (!f2) CHK(upload_nosync(c, c->list_a, active.data(), sizeof(int) * active.size()));
         if (c->time_newton) {
@@ -576,11 +582,12 @@ int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow_lr, do
           cp.X = c->Dl; cp.R = c->Rv; cp.P = c->Pv; cp.Q = c->Qv; cp.Z = c->Zv; cp.S = c->Sv; cp.Y = c->Xt; cp.sV = ld;
           cp.part = c->sc_part2; cp.gam = c->cg_scal; cp.alp = c->cg_scal + 2 * (size_t)c->B; cp.rr = c->sc_rr; cp.rr0 = c->sc_rr0; cp.eta = c->pcg_eta;
           cp.ctl = c->pcgctl; cp.live0 = c->live; cp.live1 = c->live1;
-          cp.eps = c->eps; cp.T = T; cp.p = p; cp.inner_min = c->pcg_inner_min; cp.ntile = (T + 63) / 64; cp.B = c->B; cp.xcd_map = c->pcg_xcd;
+          cp.eps = c->eps; cp.T = T; cp.p = p; cp.inner_min = c->pcg_inner_min; cp.ntile = (T + TB - 1) / TB; cp.B = c->B; cp.xcd_map = c->pcg_xcd;
           cp.Tl = Tl; cp.Tx = T; cp.fold_close = f2 ? 1 : 0; cp.host = (volatile int*)c->d_hpcg; cp.Gl = c->Gl; cp.KX = c->KX; cp.Gt = c->Gt;
           auto cg_grid = [&](int bound) {
             cp.spw = !c->pcg_adapt ? PCG_SLOTS : bound > 640 ? 16 : bound > 320 ? 8 : 4;
-            return dim3((T + 63) / 64, round_up((bound + cp.spw - 1) / cp.spw, 8));               // (slot groups in blocks of 8: pcg_cg_wg)
+            if (TB != 64) cp.spw = std::max(cp.spw, PCGW_SL);                                     // (a 32-bin workgroup has 8 slots in flight)
+            return dim3((T + TB - 1) / TB, round_up((bound + cp.spw - 1) / cp.spw, 8));           // (slot groups in blocks of 8: pcg_cg_wg)
           };
           if (f2) {
             const dim3 g0 = cg_grid(na);
@@ -590,6 +597,10 @@ int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow_lr, do
                 const size_t lb = pcg_cg_b_lds(PW);
                 if (lb > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pcg_cg_start_kernel<PW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
                 hipLaunchKernelGGL(pcg_cg_start_kernel<PW>, g0, dim3(256), lb, c->st, cp);
+              } else if constexpr (PW <= 20) {
+                const size_t lb = pcgw_b_lds(PW);
+                if (lb > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pcgw_start_kernel<PW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+                hipLaunchKernelGGL(pcgw_start_kernel<PW>, g0, dim3(256), lb, c->st, cp);
               }
             });
           }
@@ -617,6 +628,12 @@ int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow_lr, do
                 if (lb > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pcg_cg_b_kernel<PW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
                 hipLaunchKernelGGL(pcg_cg_a_kernel<PW>, gcg, dim3(256), la, c->st, cp);
                 hipLaunchKernelGGL(pcg_cg_b_kernel<PW>, gcg, dim3(256), lb, c->st, cp);
+              } else if constexpr (PW <= 20) {
+                const size_t la = pcgw_a_lds(PW), lb = pcgw_b_lds(PW);
+                if (la > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pcgw_a_kernel<PW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)la);
+                if (lb > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pcgw_b_kernel<PW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+                hipLaunchKernelGGL(pcgw_a_kernel<PW>, gcg, dim3(256), la, c->st, cp);
+                hipLaunchKernelGGL(pcgw_b_kernel<PW>, gcg, dim3(256), lb, c->st, cp);
               }
             });
             if (!f2) hipLaunchKernelGGL(pcg_iter_close_kernel, dim3(1), dim3(64), 0, c->st, c->pcgctl, it & 1, (volatile int*)c->d_hpcg, -1);
@@ -1031,6 +1048,7 @@ int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow_lr, do
     // posterior covariance blocks at the mode
     {
       const bool sum_only = c->plan_lowrank && !c->keep_trial_vsmgp;
+      PhaseRange range_cov("pgpfa.covariance_blocks");
       CHK(posterior_blocks(c, nb, 1.0, true, sum_only));
       for (int t : tos) c->vsmgp_ok[t] = sum_only ? 0 : 1;
     }

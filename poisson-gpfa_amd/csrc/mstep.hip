@@ -62,6 +62,7 @@ static int cd_sweep(pgpfa_ctx* c) {
 }
 
 int pgpfa_mstep_cd_costgrad(pgpfa_ctx* c, const double* vecCd, const double* prior_center, double inv_s2, double* cost, double* grad) {
+  PhaseRange range_phase("pgpfa.mstep_cd_costgrad");
   if (!c || !vecCd || !cost || !grad) return fail("null argument");
   if (!c->have_counts) return fail("spike counts have not been uploaded");
   if (!c->have_post) return fail("no E-step result resident: run an E-step or pgpfa_set_posterior first");
@@ -129,6 +130,7 @@ static int cd_newton_finish(pgpfa_ctx* c, const double* rtot_dev, const double* 
 // (mstep_cd_hess_kernel), all-reduced over ranks, then the q independent (p+1)-dim Newton steps on device.
 int pgpfa_mstep_cd_newton_pass(pgpfa_ctx* c, const double* vecCd, const double* prior_center, double inv_s2, double* cost_n,
                                double* delta, double* dec) {
+  PhaseRange range_phase("pgpfa.mstep_cd_newton_pass");
   if (!c || !vecCd || !cost_n || !delta || !dec) return fail("null argument");
   if (!c->have_counts) return fail("spike counts have not been uploaded");
   if (!c->have_post) return fail("no E-step result resident: run an E-step or pgpfa_set_posterior first");
@@ -183,6 +185,7 @@ int pgpfa_mstep_cd_newton_pass(pgpfa_ctx* c, const double* vecCd, const double* 
 // Hessians are the ones of the last pgpfa_mstep_cd_newton_pass (still a descent direction: they are SPD).
 int pgpfa_mstep_cd_chord_pass(pgpfa_ctx* c, const double* vecCd, const double* prior_center, double inv_s2, double* cost_n,
                               double* delta, double* dec) {
+  PhaseRange range_phase("pgpfa.mstep_cd_chord_pass");
   if (!c || !vecCd || !cost_n || !delta || !dec) return fail("null argument");
   if (!c->have_counts) return fail("spike counts have not been uploaded");
   if (!c->have_post) return fail("no E-step result resident: run an E-step or pgpfa_set_posterior first");
@@ -223,6 +226,7 @@ int pgpfa_mstep_cd_cost_per_neuron(pgpfa_ctx* c, const double* vecCd, const doub
 }
 
 int pgpfa_mstep_precomp(pgpfa_ctx* c, double* num_trials) {
+  PhaseRange range_phase("pgpfa.mstep_precomp");
   if (!c) return fail("null context");
   if (!c->have_post) return fail("no E-step result resident");
   HIPC(hipSetDevice(c->device));
@@ -326,6 +330,7 @@ int pgpfa_mstep_tau_costgrad(pgpfa_ctx* c, int k, double logp, double* cost, dou
 // pass is latency bound (a chain of ~30 small launches on T x T matrices), so evaluating 4 p matrices costs about
 // the same as p: the host-side root finder uses that to bracket and interpolate instead of stepping serially.
 int pgpfa_mstep_tau_costgrad_multi(pgpfa_ctx* c, int m, const double* logp, double* cost, double* grad) {
+  PhaseRange range_phase("pgpfa.mstep_tau_costgrad");
   if (!c || !logp || !cost || !grad) return fail("null argument");
   if (m < 1 || m > TAU_MULTI_MAX) return fail("between 1 and %d candidates per latent (m=%d)", TAU_MULTI_MAX, m);
   if (!c->have_precomp) return fail("pgpfa_mstep_precomp has not been called");

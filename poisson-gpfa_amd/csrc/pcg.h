@@ -752,6 +752,283 @@ __global__ __launch_bounds__(256, 3) void pcg_cg_start_kernel(PcgCgP a) {
   }
 }
 
+// ---- the same step for 11 .. 20 latents (round 5: config 5's mode searches ran the split kernels of round 3 with K^-1 p as a product) -----------
+// At 20 latents the packed triangle of a bin has 210 entries: the shared Gb / Wb tiles of 64 bins no longer fit LDS (161 KB) and the slot's own
+// curvature no longer fits a lane's registers.  Here a workgroup tile is 32 bins (Gb 54 KB + Wb 27 KB), its 256 threads are 32 bins x 8 slots in
+// flight, and every symmetric product walks the packed triangle in row chunks: two rows at a time out of LDS, five rows (at most 90 single-precision
+// entries, all requested before any is used) of the slot's own curvature out of memory.  Vectors, scalars, lists and the closing of a step are those
+// of the kernels above (PcgCgP; ntile counts 32-bin tiles).
+constexpr int PCGW_TB = 32;
+constexpr int PCGW_SL = 256 / PCGW_TB;          // slots a workgroup has in flight
+
+// out += sign * M v over the packed lower triangle M (entry (hi, lo) at M[(hi (hi + 1) / 2 + lo) * cs]), rows in chunks of CH; v is zero and out
+// ignored beyond p.  Chunks that start at or past row p are skipped; inside the last chunk rows >= p ARE read (an address clamped by the runtime p is
+// an address register per entry: 210 of them, hoisted out of the slot loop, spilled) and their values dropped by a select - the LDS tiles hold zeros
+// there, the packed curvature array has a slot's worth of slack behind it
+template <int PW, int CH, int H0, typename TM>
+__device__ __forceinline__ void pcgw_sym_mv_chunk(const TM* __restrict__ M, size_t cs, unsigned voff, int p, const double (&v)[PW], double (&out)[PW], double sign) {
+  // (one instantiation per row chunk: the compiler gave up unrolling a loop over the chunks at 20 latents and put the entries into scratch)
+  constexpr int H1 = (H0 + CH < PW) ? H0 + CH : PW;
+  constexpr int BASE = H0 * (H0 + 1) / 2, NE = H1 * (H1 + 1) / 2 - BASE;
+  if (H0 < p) {
+    TM g[NE];
+#pragma unroll
+    for (int hi = H0; hi < H1; ++hi)
+#pragma unroll
+      for (int lo = 0; lo <= hi; ++lo) g[hi * (hi + 1) / 2 + lo - BASE] = (M + (size_t)(hi * (hi + 1) / 2 + lo) * cs)[voff];
+#pragma unroll
+    for (int hi = H0; hi < H1; ++hi)
+#pragma unroll
+      for (int lo = 0; lo <= hi; ++lo) {
+        const double gg = (hi < p) ? sign * (double)g[hi * (hi + 1) / 2 + lo - BASE] : 0.0;
+        out[hi] += gg * v[lo];
+        if (lo != hi) out[lo] += gg * v[hi];
+      }
+    asm volatile("" ::: "memory");
+  }
+  if constexpr (H1 < PW) pcgw_sym_mv_chunk<PW, CH, H1>(M, cs, voff, p, v, out, sign);
+}
+// (M and cs wave-uniform, voff this lane's 32-bit element offset: the address of an entry is then a scalar base + a per-lane 32-bit offset - one
+// register per lane for the whole chunk instead of a 64-bit address per entry: with two slots per wave the per-lane part cannot go into the base)
+template <int PW, int CH, typename TM>
+__device__ __forceinline__ void pcgw_sym_mv_acc(const TM* __restrict__ M, size_t cs, unsigned voff, int p, const double (&v)[PW], double (&out)[PW], double sign) {
+  pcgw_sym_mv_chunk<PW, CH, 0>(M, cs, voff, p, v, out, sign);
+}
+
+template <int NPW, typename TM, typename TL>
+__device__ __forceinline__ void pcgw_stage_sym(const TM* __restrict__ MT, int T, int t0, int nt, int np, TL* __restrict__ dst, int LD) {
+  for (int e = threadIdx.x; e < NPW * PCGW_TB; e += 256) {
+    const int c = e / PCGW_TB, t = e % PCGW_TB;
+    dst[t * LD + c] = (t < nt && c < np) ? (TL)MT[(size_t)c * T + t0 + t] : (TL)0;
+  }
+}
+inline size_t pcgw_a_lds(int pw) { return (size_t)PCGW_TB * pcg_cg_ld(pw) * (sizeof(double) + sizeof(float)); }
+inline size_t pcgw_b_lds(int pw) { return (size_t)PCGW_TB * pcg_cg_ld(pw) * sizeof(double); }
+
+// sum over the 32 lanes of a slot's half wave (lane 0 of the half holds the result)
+__device__ __forceinline__ double pcgw_sum32(double x) {
+  for (int off = PCGW_TB / 2; off > 0; off >>= 1) x += __shfl_down(x, off, PCGW_TB);
+  return x;
+}
+
+// grid = (ceil(T / 32), slot groups of spw rounded up to 8), block = 256, dynamic LDS = pcgw_a_lds(PW)
+template <int PW>
+__global__ __launch_bounds__(256, 1) void pcgw_a_kernel(PcgCgP a) {
+  constexpr int NP = PW * (PW + 1) / 2, LD = pcg_cg_ld(PW);
+  extern __shared__ double pcg_cg_smem[];
+  double* Gs = pcg_cg_smem;
+  float* Ws = reinterpret_cast<float*>(pcg_cg_smem + PCGW_TB * LD);
+  PcgCtl* ctl = a.ctl;
+  if (ctl->stop) return;
+  const int na = ctl->nl[a.par];
+  if (a.fold_close && a.step > 0 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && ctl->pad_[0] == a.step - 1) pcg_close_step(ctl, a.par ^ 1, a.host);
+  int wg_tile, wg_group;
+  pcg_cg_wg(a.ntile, a.xcd_map, wg_tile, wg_group);
+  if (wg_group * a.spw >= na) return;
+  const int T = a.T, p = a.p, np = p * (p + 1) / 2, Tl = a.Tl;
+  const int t0 = wg_tile * PCGW_TB;
+  const int nt = min(PCGW_TB, T - t0);
+  pcgw_stage_sym<NP>(a.GbT, T, t0, nt, np, Gs, LD);
+  pcgw_stage_sym<NP>(a.WbT, T, t0, nt, np, Ws, LD);
+  __syncthreads();
+  const int lane = threadIdx.x % PCGW_TB, sl = threadIdx.x / PCGW_TB;
+  const bool in = lane < nt;
+  const int t = t0 + (in ? lane : 0);
+  const int* live = a.par ? a.live1 : a.live0;
+  const int s_end = min(na, (wg_group + 1) * a.spw);
+  // (every lane of a half wave walks the same slots: the shuffles below are executed by all of them)
+  for (int sb = wg_group * a.spw; sb < s_end; sb += PCGW_SL) {
+    const int si = sb + sl;
+    const bool have = si < s_end;
+    const size_t slot = (size_t)live[have ? si : s_end - 1];
+    const size_t base = slot * a.sV + t;
+    double r[PW], v[PW], z[PW];
+#pragma unroll
+    for (int k = 0; k < PW; ++k) {
+      const size_t o = base + (size_t)(k < p ? k : 0) * Tl;
+      r[k] = a.R[o];
+      v[k] = a.Y[o];
+    }
+#pragma unroll
+    for (int k = 0; k < PW; ++k) {
+      const bool ok = in && k < p;
+      r[k] = ok ? r[k] : 0.0;
+      v[k] = ok ? a.eps * r[k] + v[k] : 0.0;
+      z[k] = 0.0;
+    }
+    pcgw_sym_mv_acc<PW, 2>(Gs, 1, (unsigned)(lane * LD), p, v, z, 1.0);               // z = Gb (eps r + y)
+#pragma unroll
+    for (int k = 0; k < PW; ++k) v[k] = 0.0;
+    pcgw_sym_mv_acc<PW, 2>(Ws, 1, (unsigned)(lane * LD), p, z, v, -1.0);             // v = -Wb z
+    pcgw_sym_mv_acc<PW, 5>(a.W32T, (size_t)a.Tw, (unsigned)(slot * a.sW32 + t), p, z, v, 1.0);   // v += fl32(W) z  (offsets below 2^32 elements: the host checks)
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < PW; ++k) {
+      const double sk = r[k] + v[k];                                 // s = H~ z = (r - Wb z) + W z
+      s0 += r[k] * z[k]; s1 += z[k] * sk; s2 += r[k] * r[k];
+      if (have && in && k < p) {
+        const size_t o = base + (size_t)k * Tl;
+        a.Z[o] = z[k];
+        a.S[o] = sk;
+      }
+    }
+    s0 = pcgw_sum32(s0); s1 = pcgw_sum32(s1); s2 = pcgw_sum32(s2);
+    if (have && lane == 0) {
+      double* pp = a.part + (slot * a.ntile + wg_tile) * 3;
+      pp[0] = s0; pp[1] = s1; pp[2] = s2;
+    }
+  }
+}
+
+// t = Gb r for this lane's bin; r is zero beyond p / past the tile
+template <int PW>
+__device__ __forceinline__ void pcgw_apply_store(const double* __restrict__ g, int p, const double (&r)[PW], double* __restrict__ Y, size_t base, int Tl, bool ok) {
+  double tv[PW];
+#pragma unroll
+  for (int k = 0; k < PW; ++k) tv[k] = 0.0;
+  pcgw_sym_mv_acc<PW, 2>(g, 1, 0u, p, r, tv, 1.0);
+#pragma unroll
+  for (int k = 0; k < PW; ++k)
+    if (ok && k < p) Y[base + (size_t)k * Tl] = tv[k];
+}
+
+// same launch shape; dynamic LDS = pcgw_b_lds(PW)
+template <int PW>
+__global__ __launch_bounds__(256, 2) void pcgw_b_kernel(PcgCgP a) {
+  constexpr int NP = PW * (PW + 1) / 2, LD = pcg_cg_ld(PW);
+  extern __shared__ double pcg_cg_smem[];
+  double* Gs = pcg_cg_smem;
+  PcgCtl* ctl = a.ctl;
+  if (ctl->stop) return;
+  const int na = ctl->nl[a.par];
+  int wg_tile, wg_group;
+  pcg_cg_wg(a.ntile, a.xcd_map, wg_tile, wg_group);
+  if (wg_group * a.spw >= na) return;
+  const int it = a.fold_close ? a.step : ctl->iters;
+  const int T = a.T, p = a.p, np = p * (p + 1) / 2, Tl = a.Tl, Tx = a.Tx;
+  const int t0 = wg_tile * PCGW_TB;
+  const int nt = min(PCGW_TB, T - t0);
+  pcgw_stage_sym<NP>(a.GbT, T, t0, nt, np, Gs, LD);
+  __syncthreads();
+  const int lane = threadIdx.x % PCGW_TB, sl = threadIdx.x / PCGW_TB;
+  const bool in = lane < nt;
+  const int t = t0 + (in ? lane : 0);
+  const double* g = Gs + lane * LD;
+  const int* live = a.par ? a.live1 : a.live0;
+  int* live_next = a.par ? a.live0 : a.live1;
+  const double* gam_old = a.gam + (size_t)a.par * a.B;
+  const double* alp_old = a.alp + (size_t)a.par * a.B;
+  double* gam_new = a.gam + (size_t)(a.par ^ 1) * a.B;
+  double* alp_new = a.alp + (size_t)(a.par ^ 1) * a.B;
+  const int s_end = min(na, (wg_group + 1) * a.spw);
+  for (int si = wg_group * a.spw + sl; si < s_end; si += PCGW_SL) {
+    const int sloti = live[si];
+    const size_t slot = (size_t)sloti;
+    double gamma = 0.0, delta = 0.0, rrn = 0.0;
+    for (int i = 0; i < a.ntile; ++i) {
+      const double* pp = a.part + (slot * a.ntile + i) * 3;
+      gamma += pp[0]; delta += pp[1]; rrn += pp[2];
+    }
+    const double b0 = a.first ? rrn : a.rr0[slot];
+    const float ratio = (b0 > 0.0) ? (float)sqrt(rrn / b0) : 0.0f;
+    const bool keep = (it < a.inner_min || !(ratio <= a.eta[slot]));
+    const double g_old = gam_old[slot], a_old = alp_old[slot];
+    const double beta = (a.first || !(g_old > 0.0)) ? 0.0 : gamma / g_old;
+    const double den = (a.first || !(a_old > 0.0)) ? delta : delta - beta * gamma / a_old;
+    const double alpha = (den > 0.0) ? gamma / den : 0.0;
+    if (wg_tile == 0 && lane == 0) {
+      if (a.first) a.rr0[slot] = rrn;
+      a.rr[slot] = rrn;
+      if (keep) {
+        gam_new[slot] = gamma;
+        alp_new[slot] = alpha;
+        const int pos = atomicAdd(&ctl->nl[a.par ^ 1], 1);
+        live_next[pos] = sloti;
+      }
+    }
+    if (!keep) continue;
+    const size_t base = slot * a.sV + t;
+    double r[PW];
+    // the vector updates five latents at a time (thirty loads in flight), the new residual stays in registers for t = Gb r
+#pragma unroll
+    for (int k0 = 0; k0 < PW; k0 += 5) {
+      double zk[5], sk[5], po[5], qo[5], xo[5], ro[5];
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const int k = k0 + j;
+        const size_t o = base + (size_t)(k < p ? k : 0) * Tl;
+        zk[j] = a.Z[o]; sk[j] = a.S[o]; ro[j] = a.R[o]; xo[j] = a.X[base + (size_t)(k < p ? k : 0) * Tx];
+        po[j] = 0.0; qo[j] = 0.0;
+      }
+      if (!a.first) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          const size_t o = base + (size_t)(k0 + j < p ? k0 + j : 0) * Tl;
+          po[j] = a.P[o]; qo[j] = a.Q[o];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const int k = k0 + j;
+        const bool ok = in && k < p;
+        const size_t o = base + (size_t)(k < p ? k : 0) * Tl;
+        const double pn = zk[j] + beta * po[j];
+        const double qn = sk[j] + beta * qo[j];
+        if (k < PW) r[k < PW ? k : 0] = ok ? ro[j] - alpha * qn : 0.0;
+        if (ok) {
+          a.P[o] = pn;
+          a.Q[o] = qn;
+          a.X[base + (size_t)k * Tx] = xo[j] + alpha * pn;
+          a.R[o] = ro[j] - alpha * qn;
+        }
+      }
+    }
+    pcgw_apply_store<PW>(g, p, r, a.Y, base, Tl, in);
+  }
+}
+
+// first kernel of a solve (see pcg_cg_start_kernel); launch shape and LDS of pcgw_b_kernel
+template <int PW>
+__global__ __launch_bounds__(256, 2) void pcgw_start_kernel(PcgCgP a) {
+  constexpr int NP = PW * (PW + 1) / 2, LD = pcg_cg_ld(PW);
+  extern __shared__ double pcg_cg_smem[];
+  double* Gs = pcg_cg_smem;
+  const int na = a.ctl->nl[0];
+  int wg_tile, wg_group;
+  pcg_cg_wg(a.ntile, a.xcd_map, wg_tile, wg_group);
+  if (wg_group * a.spw >= na) return;
+  const int T = a.T, p = a.p, np = p * (p + 1) / 2, Tl = a.Tl, Tx = a.Tx;
+  const int t0 = wg_tile * PCGW_TB;
+  const int nt = min(PCGW_TB, T - t0);
+  pcgw_stage_sym<NP>(a.GbT, T, t0, nt, np, Gs, LD);
+  __syncthreads();
+  const int lane = threadIdx.x % PCGW_TB, sl = threadIdx.x / PCGW_TB;
+  const bool in = lane < nt;
+  const int t = t0 + (in ? lane : 0);
+  const double* g = Gs + lane * LD;
+  const int s_end = min(na, (wg_group + 1) * a.spw);
+  for (int si = wg_group * a.spw + sl; si < s_end; si += PCGW_SL) {
+    const size_t base = (size_t)a.live0[si] * a.sV + t;
+    double r[PW];
+#pragma unroll
+    for (int k = 0; k < PW; ++k) {
+      const size_t o = base + (size_t)(k < p ? k : 0) * Tx;
+      r[k] = a.Gl[o] + a.KX[o];
+    }
+#pragma unroll
+    for (int k = 0; k < PW; ++k) {
+      const bool ok = in && k < p;
+      if (ok) {
+        a.Gt[base + (size_t)k * Tx] = r[k];
+        a.X[base + (size_t)k * Tx] = 0.0;
+        a.R[base + (size_t)k * Tl] = -r[k];
+      }
+      r[k] = ok ? -r[k] : 0.0;
+    }
+    pcgw_apply_store<PW>(g, p, r, a.Y, base, Tl, in);
+  }
+}
+
 // M[t][p][p] (double, symmetric) -> out[c][T], c = a(a+1)/2 + b over the lower triangle a >= b.  grid = ceil(T*NP/256)
 template <typename TO>
 __global__ void pack_sym_t_kernel(const double* __restrict__ M, TO* __restrict__ out, int T, int p) {

@@ -23,9 +23,14 @@ def funs_mod():
 # ---------------------------------------------------------------------------------------------------------------
 # inner PCG: two-kernel step without K^-1 in the loop
 # ---------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('shape', [(40, 7, 70, 6), (33, 9, 130, 5), (25, 10, 64, 3), (30, 3, 100, 8), (50, 1, 90, 4)])
+@pytest.mark.parametrize('shape', [(40, 7, 70, 6), (33, 9, 130, 5), (25, 10, 64, 3), (30, 3, 100, 8), (50, 1, 90, 4),
+                                   (40, 12, 70, 5), (45, 17, 100, 9), (50, 20, 64, 3), (36, 14, 37, 10)])
 def test_pcg_step_without_prior_matvec_vs_oracle(shape):
-    """Forced on at small shapes (it is chosen by itself only for large chunks): latent widths 7 and 9 run the 8- and 10-wide
+    """Round 5: pcg_form = 2 (the default: private vectors on line-aligned rows - 70 / 130 / 37 bins pad to 80 / 144 / 48 -, start kernel, closing inside
+    kernel A, one upload per solve) next to forms 1 and 0; and 11 .. 20 latents, where the step runs in pcgw_*_kernel (32-bin tiles, two slots per
+    wave, packed triangles in row chunks: widths 12, 14 -> 16, 17 -> 20, 20; 9 and 10 slots leave a partly filled group of 8) against the oracle and
+    against the split kernels of round 3.
+    Forced on at small shapes (it is chosen by itself only for large chunks): latent widths 7 and 9 run the 8- and 10-wide
     instantiations with clamped component indices, 70 / 130 bins leave a partly filled 64-bin tile.  Modes against the oracle's exact
     Newton (1e-8), objective 1e-9 rel, covariance blocks 1e-8 rel; the split kernels of round 3 (pcg_form = 0) on the same problem land on
     the same modes, and so do the products of the preconditioner through the general GEMM kernel (thin_products = 0, or 1: only `Sb u`) instead
@@ -38,7 +43,7 @@ def test_pcg_step_without_prior_matvec_vs_oracle(shape):
     par = {'C': 0.3 * rng.standard_normal((q, p)) / np.sqrt(max(1, p / 4)), 'd': np.log(Y.mean(axis=(0, 2)) + 0.1), 'tau': 0.05 + 0.3 * rng.random(p)}
     res, nll_o, _ = orc.laplace([y.astype(float) for y in Ys], par, 10.0, mode='exact', return_cov=False)
     modes = {}
-    for form, thin in ((1, 2), (0, 2), (1, 0), (1, 1)):
+    for form, thin in (((2, 2), (1, 2), (0, 2), (1, 0), (1, 1)) if p <= 10 else ((2, 2), (0, 2))):
         ctx = _hip.Context(q, p, T, R, 10.0)
         try:
             ctx.upload_counts(Y)
@@ -57,9 +62,11 @@ def test_pcg_step_without_prior_matvec_vs_oracle(shape):
             assert np.all(st2 == 0) and abs(obj2 - obj) <= 1e-10 * abs(obj)
         finally:
             ctx.close()
-    assert np.max(np.abs(modes[1, 2] - modes[0, 2])) <= 2e-9
-    assert np.max(np.abs(modes[1, 2] - modes[1, 0])) <= 2e-9
-    assert np.max(np.abs(modes[1, 2] - modes[1, 1])) <= 2e-9
+    assert np.max(np.abs(modes[2, 2] - modes[0, 2])) <= 2e-9
+    if p <= 10:
+        assert np.max(np.abs(modes[1, 2] - modes[0, 2])) <= 2e-9
+        assert np.max(np.abs(modes[1, 2] - modes[1, 0])) <= 2e-9
+        assert np.max(np.abs(modes[1, 2] - modes[1, 1])) <= 2e-9
 
 
 def test_pcg_forms_agree_at_config3_dimensions():
@@ -74,7 +81,7 @@ def test_pcg_forms_agree_at_config3_dimensions():
     Y = np.stack(Ys)
     par = {'C': true['C'], 'd': true['d'], 'tau': np.linspace(0.1, 0.5, p)}
     out = {}
-    for form in (1, 0):
+    for form in (2, 1, 0):
         ctx = _hip.Context(q, p, T, R, 10.0)
         try:
             ctx.upload_counts(Y)
@@ -86,7 +93,9 @@ def test_pcg_forms_agree_at_config3_dimensions():
             out[form] = (obj, ctx.post_mean().copy(), ctx.pautosum().copy(), ctx.info('last_pcg_iterations'))
         finally:
             ctx.close()
-    a, b = out[1], out[0]
+    for form in (2, 1):
+        assert abs(out[form][0] - out[0][0]) <= 1e-11 * abs(out[0][0]) and np.max(np.abs(out[form][1] - out[0][1])) <= 1e-8
+    a, b = out[2], out[0]
     assert abs(a[0] - b[0]) <= 1e-11 * abs(b[0])
     assert np.max(np.abs(a[1] - b[1])) <= 1e-8
     assert np.max(np.abs(a[2] - b[2])) <= 1e-9 * np.max(np.abs(b[2]))

@@ -200,3 +200,41 @@ def test_dual_variables_survive_an_interleaved_laplace_estep(funs_mod):
             ctx.dual_lambda(idx)
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize('tau_ms,expect', [(30.0, 'dense'), (300.0, 'lowrank')])
+def test_auto_plan_picks_the_faster_covariance_engine(tau_ms, expect):
+    """Both ends of the design at 100 neurons x 5 latents x 400 bins, 64 trials: with every timescale at 3 bins the pivoted Cholesky of the Gram
+    matrices has nearly full rank and the low-rank engine costs more than the dense factorisation it replaces; at 30 bins it costs a fraction.
+    The auto plan (cov_mode 0; util.py:599-619 sets the rank through the timescales) must pick the engine that is faster when each is forced
+    (margin 1.25 on the best of three warm E-steps), and all three must agree on the result (modes 1e-8, covariance blocks 1e-8 rel)."""
+    import time
+    from funs import _hip
+    q, p, T, R = 100, 5, 400, 64
+    rng = np.random.default_rng(7)
+    C, d = rng.random((q, p)) - 0.5, -1.0 - 2.0 * rng.random(q)
+    tau = np.full(p, tau_ms * 1e-3)
+    Y = rng.poisson(np.exp(d)[None, :, None] * np.ones((R, q, T))).astype(np.uint8)
+    out = {}
+    for name, mode in (('auto', 0), ('dense', 1), ('lowrank', 2)):
+        ctx = _hip.Context(q, p, T, R, 10.0)
+        try:
+            ctx.upload_counts(Y)
+            ctx.set_option('cov_mode', mode)
+            ctx.set_params(C, d, tau)
+            obj, _, st = ctx.estep_laplace()
+            assert np.all(st == 0)
+            best = 1e9
+            for _ in range(3):
+                t0 = time.time()
+                obj, _, st = ctx.estep_laplace(warm_start=True)
+                best = min(best, time.time() - t0)
+            out[name] = (best, 'lowrank' if ctx.info('last_cov_lowrank') else 'dense', ctx.post_mean().copy(), ctx.post_vsm().copy(), ctx.info('lowrank_rtot'))
+        finally:
+            ctx.close()
+    print('tau %.0f ms (rank %d of %d): auto -> %s %.1f ms; dense %.1f ms, low-rank %.1f ms'
+          % (tau_ms, out['auto'][4], p * T, out['auto'][1], out['auto'][0] * 1e3, out['dense'][0] * 1e3, out['lowrank'][0] * 1e3))
+    assert out['dense'][1] == 'dense' and out['lowrank'][1] == 'lowrank' and out['auto'][1] == expect
+    assert out['auto'][0] <= 1.25 * min(out['dense'][0], out['lowrank'][0])
+    for name in ('dense', 'lowrank'):
+        assert np.max(np.abs(out[name][2] - out['auto'][2])) <= 1e-8 and rel(out[name][3], out['auto'][3]) <= 1e-8
