@@ -117,13 +117,18 @@ size_t lowrank_slab_elems(const pgpfa_ctx* c) {
 }
 
 // engine choice: the low-rank form pays when r << n (long timescales); the dense form is the general one
+// (round 5: measured at both ends - bench.py --workload floor, tests/test_gpu_round5.py - the low-rank engine is still 9 % faster at a flop
+// ratio of 1.6 (100 x 5 x 400, every timescale 3 bins: rank 1520 of 2000) and 23 % at 1.1 (200 x 10 x 500, rank 3856 of 5000: 218 against 284 ms
+// per EM iteration of 128 trials): its cubic term runs on r x r systems, its T^2 term mostly on the FP16 / FP32 matrix cores, and the dense engine
+// reaches 41 TFLOP/s on 0.72 n^3.  The old rule - ratio below 0.5 and rank at most half of n - sent all of that to the dense engine.)
 bool lowrank_pays(const pgpfa_ctx* c) {
   const double n = c->n, r = c->rpad, T = c->T, p = c->p;
-  if (c->p > WIDE_MAX || c->rpad < NB || c->rpad * 2 > c->npad) return false;
-  if (lowrank_slab_elems(c) > (size_t)c->ld * c->ld) return false;
+  if (c->p > WIDE_MAX || c->rpad < NB || (size_t)c->rpad > (size_t)c->ld) return false;
   const double dense = 0.72 * n * n * n;
   const double lr = 6.0 * T * r * r + 0.7 * r * r * r + p * T * T * r;
-  return lr < 0.5 * dense;
+  // (small systems - configs 1 and 2 - are launch-bound under either engine and the dense one has fewer launches: there the old rule stands)
+  if (c->npad < 1536) return c->rpad * 2 <= c->npad && lr < 0.5 * dense;
+  return lr < 1.7 * dense;
 }
 
 // (cov_mode 2 forces the low-rank engine at any size it supports - its slabs are sized for what it needs, not by the dense ld x ld; the
