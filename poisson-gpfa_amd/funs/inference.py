@@ -372,7 +372,9 @@ def dualProblemRho_grad(rho, ybar, C_big, K_big, K_bigInv, d_big):
 # Newton-PCG with variance offsets in a loop with the covariance blocks) - the zero of the reference's dual gradient to DUAL_FP_TOL
 # in a handful of passes, where either L-BFGS stops on its decrease test after thousands of evaluations
 DUAL_SOLVER = 'fixedpoint'
-# passes / tolerance of DUAL_SOLVER = 'fixedpoint' (the tolerance is the max-norm of the reference's dual gradient at the returned lambda)
+# passes / tolerance of DUAL_SOLVER = 'fixedpoint' (the tolerance is the max-norm of the reference's dual gradient at the returned lambda IN THE
+# ARITHMETIC OF THE EVALUATION: with DUAL_F32 the covariance blocks behind the offsets carry single-precision rounding, and the same lambda
+# evaluated in FP64 has a gradient of ~1e-7 (config 5, 256 trials: 1.2e-7) - the tests hold the mixed run to 1e-5, the FP64 run to 1e-6)
 DUAL_FP_MAX_PASSES = 40
 DUAL_FP_TOL = 1e-8
 # evaluate the dual through the low-rank covariance engine when that pays (large xdim*T); the reference's 1e-6 diagonal jitter
