@@ -73,6 +73,8 @@ int pgpfa_destroy(pgpfa_ctx* ctx);
  * 1: a step of the host-free inner iteration is two tile-parallel kernels - the one-reduction (Chronopoulos-Gear) form of
  * PCG - plus the three preconditioner products, the prior mat-vec gone from the loop through Kt^-1 z = r - Wb z, pcg.h; up to 10 latents, needs "pcg_w32" and
  * "pcg_retire"; 0: the split kernels of round 3 with K^-1 p as a product),
+ * "pcg_vec32" (1, with "pcg_form" 2: the vectors of an inner solve that carry no accumulated state - z, s, p, q and the preconditioner's t / y -
+ * are stored in single precision, x, r, every product and dot stay FP64: a slot-step moves 13.8 n-vector equivalents instead of 19.8; 0: all FP64),
  * "pcg_adapt" (1: the launches of a step of that iteration are sized by the live count the device last mirrored to the host - it only falls during a
  * solve - and the per-bin kernels take 16 / 8 / 4 slots per workgroup above 640 / 320 / below; 0: sized by the solve's first count, 16 slots),
  * "pcg_xcd" (1: the two per-bin kernels of that step map workgroup ids so that the bin tiles of a slot group run on one XCD - they share the
@@ -114,6 +116,7 @@ int pgpfa_set_option(pgpfa_ctx* ctx, const char* key, double value);
  * "last_newton_solves", "last_pcg_iterations", "last_shared_factorizations", "last_cov_lowrank",
  * "last_dense_retries", "hbm_bytes_allocated", "hbm_bytes_free" / "hbm_bytes_total" (hipMemGetInfo of the context's device, now), "n_trials_global", "prof_<tag>_{ms,flops,launches}", "counts_two_bytes",
  * "arena_bytes", "last_split_cov", "last_eps_wt_norm", "last_eps_wt_rms", "last_newton_solve_ms", "last_newton_solve_bytes",
+ * "last_newton_solve_bytes_moved" (what the step's kernels really move: with "pcg_vec32" five of its vectors are single precision),
  * "last_newton_solve_bytes_survey" (the same slot-iterations priced at q T + 8 (2 p T + T p^2) bytes each: SURVEY 8(d)'s B_E per pass per trial),
  * "arena_vmm_failed" (1 once the virtual-memory arena fell back to plain allocations), "last_newton_max_iter", "last_dual_evaluations",
  * "last_loo_unconverged". */

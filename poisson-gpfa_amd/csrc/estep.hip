@@ -158,7 +158,7 @@ int pgpfa_laplace_hessian(pgpfa_ctx* c, int trial, const double* X, double* H) {
 // (vec_row > 0: the n-vectors c->Xt holds - input t and output y - are in the inner solve's private layout, latent rows vec_row apart (pcg.h:
 // PcgCgP::Tl); only with the thin kernels and without the per-bin applications)
 static int shared_solve(pgpfa_ctx* c, int nb, const double* R, double* Z, const int* skip = nullptr, bool first_apply = true,
-                        bool final_apply = true, const int* cols = nullptr, int ncols = 0, int vec_row = 0) {
+                        bool final_apply = true, const int* cols = nullptr, int ncols = 0, int vec_row = 0, bool vec_f32 = false) {
   const int ng = cols ? ncols : nb;                // columns of the multi-RHS products: all slots, or the listed (live) ones
   if (c->plan_lowrank) {
     const long long ld = c->ld;
@@ -182,7 +182,7 @@ static int shared_solve(pgpfa_ctx* c, int nb, const double* R, double* Z, const 
     if (first_apply) apply_bin(R, nullptr, 1.0, c->Xt);
     // the two block-diagonal products as kernels of their own (thin.h) where the matrix cores are in use; the general product otherwise
     const bool thin = c->thin_products && c->mfma && c->T >= 4 && (size_t)c->rpad <= (size_t)c->ld;
-    if (vec_row > 0 && (!thin || first_apply || final_apply)) return fail("internal: padded vector rows need the thin products and no per-bin application");
+    if ((vec_row > 0 || vec_f32) && (!thin || first_apply || final_apply)) return fail("internal: padded vector rows need the thin products and no per-bin application");
     ThinP tp{};
     tp.F = c->Flr; tp.Tf = c->Tp; tp.T = c->T; tp.Tx = vec_row > 0 ? vec_row : c->T; tp.FT = c->FTbig; tp.ldft = c->rpad;
     tp.cols = cols; tp.n_dev = (cols && c->cur_ndev) ? c->cur_ndev : nullptr; tp.ncols = ng; tp.skip = skip;
@@ -203,7 +203,10 @@ static int shared_solve(pgpfa_ctx* c, int nb, const double* R, double* Z, const 
     if (thin) {
       tp.tab = c->d_thin_ft; tp.X = c->Xt; tp.ldx = c->ld; tp.Y = c->Glt; tp.ldy = c->ld;
       thin_prof("F^T t");
-      if (c->T % 4 == 0) hipLaunchKernelGGL(thin_ft_kernel<true>, dim3(c->nthin_ft, (ng + 15) / 16), dim3(512), 0, c->st, tp);
+      if (vec_f32) {
+        if (c->T % 4 == 0) hipLaunchKernelGGL((thin_ft_kernel<true, float>), dim3(c->nthin_ft, (ng + 15) / 16), dim3(512), 0, c->st, tp);
+        else hipLaunchKernelGGL((thin_ft_kernel<false, float>), dim3(c->nthin_ft, (ng + 15) / 16), dim3(512), 0, c->st, tp);
+      } else if (c->T % 4 == 0) hipLaunchKernelGGL(thin_ft_kernel<true>, dim3(c->nthin_ft, (ng + 15) / 16), dim3(512), 0, c->st, tp);
       else hipLaunchKernelGGL(thin_ft_kernel<false>, dim3(c->nthin_ft, (ng + 15) / 16), dim3(512), 0, c->st, tp);
       prof_end(c);
     } else {
@@ -234,7 +237,10 @@ static int shared_solve(pgpfa_ctx* c, int nb, const double* R, double* Z, const 
     if (thin) {
       tp.tab = c->d_thin_f; tp.X = c->KD; tp.ldx = c->ld; tp.Y = c->Xt; tp.ldy = c->ld;
       thin_prof("F v");
-      if (c->T % 4 == 0) hipLaunchKernelGGL(thin_f_kernel<true>, dim3(c->nthin_f, (ng + 15) / 16), dim3(256), 0, c->st, tp);
+      if (vec_f32) {
+        if (c->T % 4 == 0) hipLaunchKernelGGL((thin_f_kernel<true, float>), dim3(c->nthin_f, (ng + 15) / 16), dim3(256), 0, c->st, tp);
+        else hipLaunchKernelGGL((thin_f_kernel<false, float>), dim3(c->nthin_f, (ng + 15) / 16), dim3(256), 0, c->st, tp);
+      } else if (c->T % 4 == 0) hipLaunchKernelGGL(thin_f_kernel<true>, dim3(c->nthin_f, (ng + 15) / 16), dim3(256), 0, c->st, tp);
       else hipLaunchKernelGGL(thin_f_kernel<false>, dim3(c->nthin_f, (ng + 15) / 16), dim3(256), 0, c->st, tp);
       prof_end(c);
     } else {
@@ -366,6 +372,7 @@ int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow_lr, do
   double total = 0.0;
   double n_fact = 0.0, n_solve = 0.0, n_pcg = 0.0, n_shared = 0.0;
   double newton_bytes = 0.0;                          // mandatory HBM bytes of the inner PCG iterations run (see below)
+  double newton_bytes_moved = 0.0;                    // what the kernels of the form in use really move per slot-iteration (single-precision vectors counted as such)
   double newton_bytes_survey = 0.0;                   // the same slot-iterations priced by SURVEY 8(d)'s B_E = q T s_y + 8 (2 p T + T p^2) per pass per trial
   std::vector<std::pair<hipEvent_t, hipEvent_t>> newton_ev;   // events around every inner solve (the Newton-solve kernels)
   int max_it_seen = 0;
@@ -455,6 +462,30 @@ int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow_lr, do
       stat[s] = 1;
     }
     std::vector<int> leftovers;
+    // (small chunks are launch-latency bound: there the extra packing / check launches of the host-free form cost more than
+    // the round trips they remove - measured at config 2: 8.6 vs 8.0 ms per E-step)
+    const bool thin_ok = c->thin_products && c->mfma && T >= 4 && (size_t)c->rpad <= (size_t)c->ld;
+    // (11 .. 20 latents: only the round-5 form of the host-free step exists - pcgw_*_kernel - and it needs the thin products)
+    const bool wide_ok = p <= 20 && c->pcg_form >= 2 && thin_ok && c->pcg_w32 && c->pcg_retire && c->pcg_blk != nullptr;
+    const bool fused = c->pcg_fused && c->plan_lowrank && (p <= 16 || wide_ok) && c->h_pcg != nullptr && (c->pcg_fused == 2 || (double)nb * c->n >= 1.0e6);
+    // form of the host-free iteration (pcg.h): the two-kernel step without the prior mat-vec needs the packed FP32 curvature and per-slot
+    // retirement; otherwise the split kernels of round 3
+    const bool onek = fused && c->pcg_w32 && c->pcg_retire && c->pcg_form != 0 && (p <= 10 || wide_ok);
+    // round 5 (pcg_form = 2): the solve's private vectors on line-aligned latent rows, ONE start kernel (gradient, residual, zero step, first
+    // per-bin application), the step's closing inside kernel A, ONE upload (control block, list, forcing terms); needs the thin products
+    const bool f2 = onek && c->pcg_form >= 2 && thin_ok && c->pcg_blk != nullptr;
+    const int TB = p <= 10 ? 64 : PCGW_TB;               // bins per workgroup tile of the step's per-bin kernels
+    // ... and (second half of round 5) z, s, p, q, t / y of the solve stored in single precision (PcgCgP::vec32)
+    const bool v32 = f2 && c->pcg_vec32;
+    const int Tl = !f2 ? T : (v32 && (long long)p * round_up(T, 32) <= ld) ? round_up(T, 32) : ((long long)p * round_up(T, 16) <= ld) ? round_up(T, 16) : T;
+    auto with_tv = [&](auto&& fn) { if (v32) fn(float{}); else fn(double{}); };
+    // packed single-precision curvature of the two-kernel step (pcg.h): component-major [c][Tw], rows on 128-byte lines.  It is written where W is:
+    // by pack_w32t_kernel at the start of a solve for slots whose W came from the Poisson pass at the E-step's start point, and by the commit of an
+    // accepted step (commit_w_pack_kernel: the copy W <- Wt and the packing in one pass over Wt - a solve after the first finds every active slot packed)
+    const int npk = p * (p + 1) / 2;
+    const int Tw = round_up(T, 32);
+    const long long sW32 = (long long)Tw * npk;
+    std::vector<char> w32_ok(nb, 0);
 
     // backtracking line search along Dl for the slots in `cand` (objective with rounding-noise slack as in
     // the oracle); needs dec/qxx/qdx/qdd of those slots on the host.  Accepted slots are committed
@@ -488,7 +519,12 @@ int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow_lr, do
           CHK(upload_nosync(c, c->list_b, acc.data(), sizeof(int) * acc.size()));
           const int nw = T * p * p;
           hipLaunchKernelGGL(commit_kernel, dim3((nvec + 255) / 256, nacc), dim3(256), 0, c->st, c->Xc, c->Xt, c->KX, c->KD, c->Gl, c->Glt, ld,
-                             c->W, c->Wt, (long long)nw, c->sc_alpha, nvec, nw, c->list_b);
+                             c->W, c->Wt, (long long)nw, c->sc_alpha, nvec, onek ? 0 : nw, c->list_b);
+          if (onek) {
+            hipLaunchKernelGGL(commit_w_pack_kernel, dim3((T + 63) / 64, nacc), dim3(256), (size_t)npk * 65 * sizeof(float), c->st, (const double*)c->Wt, c->W,
+                               (long long)nw, c->W32, sW32, Tw, T, p, c->list_b);
+            for (int s : acc) w32_ok[s] = 1;
+          }
           HIPC(hipGetLastError());
         }
         pending.swap(rej);
@@ -517,23 +553,9 @@ int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow_lr, do
           eta_target = std::min(eta_target, std::max(1e-9, std::min(c->pcg_eta0, want)));
         }
         const int na = (int)active.size();
-        // (small chunks are launch-latency bound: there the extra packing / check launches of the host-free form cost more than
-        // the round trips they remove - measured at config 2: 8.6 vs 8.0 ms per E-step)
-        const bool thin_ok = c->thin_products && c->mfma && T >= 4 && (size_t)c->rpad <= (size_t)c->ld;
-        // (11 .. 20 latents: only the round-5 form of the host-free step exists - pcgw_*_kernel - and it needs the thin products)
-        const bool wide_ok = p <= 20 && c->pcg_form >= 2 && thin_ok && c->pcg_w32 && c->pcg_retire && c->pcg_blk != nullptr;
-        const bool fused = c->pcg_fused && c->plan_lowrank && (p <= 16 || wide_ok) && c->h_pcg != nullptr && (c->pcg_fused == 2 || (double)nb * c->n >= 1.0e6);
         int done_inner = 0;
         PcgCtl& fused_ctl = c->fused_ctl_host;             // (context member: a queued read-back must not point into this frame)
         fused_ctl = PcgCtl{};
-        // form of the host-free iteration (pcg.h): the two-kernel step without the prior mat-vec needs the packed FP32 curvature and per-slot
-        // retirement; otherwise the split kernels of round 3
-        const bool onek = fused && c->pcg_w32 && c->pcg_retire && c->pcg_form != 0 && (p <= 10 || wide_ok);
-        // round 5 (pcg_form = 2): the solve's private vectors on line-aligned latent rows, ONE start kernel (gradient, residual, zero step, first
-        // per-bin application), the step's closing inside kernel A, ONE upload (control block, list, forcing terms); needs the thin products
-        const bool f2 = onek && c->pcg_form >= 2 && thin_ok && c->pcg_blk != nullptr;
-        const int TB = p <= 10 ? 64 : PCGW_TB;               // bins per workgroup tile of the step's per-bin kernels
-        const int Tl = (f2 && (long long)p * round_up(T, 16) <= ld) ? round_up(T, 16) : T;
         if (!f2) CHK(upload_nosync(c, c->list_a, active.data(), sizeof(int) * active.size()));
         if (c->time_newton) {
           newton_ev.emplace_back(prof_event(c->prof), prof_event(c->prof));
@@ -546,9 +568,6 @@ int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow_lr, do
         if (onek) {
           // ---- inner solve: per step pcg_cg_a_kernel, pcg_cg_b_kernel, the closing kernel and the three preconditioner products (pcg.h)
           const int* skip = &c->pcgctl->stop;
-          const int npk = p * (p + 1) / 2;
-          const int Tw = round_up(T, 32);                        // row stride of the component-major packed curvature: rows start on 128-byte lines
-          const long long sW32 = (long long)Tw * npk;
           {
             std::vector<float> eta_s(nb, (float)eta_target);
             for (int s : active) {
@@ -583,7 +602,7 @@ int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow_lr, do
           cp.part = c->sc_part2; cp.gam = c->cg_scal; cp.alp = c->cg_scal + 2 * (size_t)c->B; cp.rr = c->sc_rr; cp.rr0 = c->sc_rr0; cp.eta = c->pcg_eta;
           cp.ctl = c->pcgctl; cp.live0 = c->live; cp.live1 = c->live1;
           cp.eps = c->eps; cp.T = T; cp.p = p; cp.inner_min = c->pcg_inner_min; cp.ntile = (T + TB - 1) / TB; cp.B = c->B; cp.xcd_map = c->pcg_xcd;
-          cp.Tl = Tl; cp.Tx = T; cp.fold_close = f2 ? 1 : 0; cp.host = (volatile int*)c->d_hpcg; cp.Gl = c->Gl; cp.KX = c->KX; cp.Gt = c->Gt;
+          cp.Tl = Tl; cp.Tx = T; cp.vec32 = v32 ? 1 : 0; cp.fold_close = f2 ? 1 : 0; cp.host = (volatile int*)c->d_hpcg; cp.Gl = c->Gl; cp.KX = c->KX; cp.Gt = c->Gt;
           auto cg_grid = [&](int bound) {
             cp.spw = !c->pcg_adapt ? PCG_SLOTS : bound > 640 ? 16 : bound > 320 ? 8 : 4;
             if (TB != 64) cp.spw = std::max(cp.spw, PCGW_SL);                                     // (a 32-bin workgroup has 8 slots in flight)
@@ -595,19 +614,32 @@ int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow_lr, do
               constexpr int PW = decltype(pw)::value;
               if constexpr (PW <= 10) {
                 const size_t lb = pcg_cg_b_lds(PW);
-                if (lb > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pcg_cg_start_kernel<PW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
-                hipLaunchKernelGGL(pcg_cg_start_kernel<PW>, g0, dim3(256), lb, c->st, cp);
+                with_tv([&](auto tv) {
+                  using TV = decltype(tv);
+                  if (lb > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pcg_cg_start_kernel<PW, TV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+                  hipLaunchKernelGGL((pcg_cg_start_kernel<PW, TV>), g0, dim3(256), lb, c->st, cp);
+                });
               } else if constexpr (PW <= 20) {
                 const size_t lb = pcgw_b_lds(PW);
-                if (lb > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pcgw_start_kernel<PW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
-                hipLaunchKernelGGL(pcgw_start_kernel<PW>, g0, dim3(256), lb, c->st, cp);
+                with_tv([&](auto tv) {
+                  using TV = decltype(tv);
+                  if (lb > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pcgw_start_kernel<PW, TV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+                  hipLaunchKernelGGL((pcgw_start_kernel<PW, TV>), g0, dim3(256), lb, c->st, cp);
+                });
               }
             });
           }
-          hipLaunchKernelGGL(pack_w32t_kernel, dim3((T + 63) / 64, na), dim3(256), (size_t)npk * 65 * sizeof(float), c->st, c->W, (long long)T * p * p,
-                             c->W32, sW32, Tw, T, p, c->list_a);
+          {
+            std::vector<int> need;
+            for (int s : active) if (!w32_ok[s]) { need.push_back(s); w32_ok[s] = 1; }
+            if (!need.empty()) {
+              CHK(upload_nosync(c, c->list_b, need.data(), sizeof(int) * need.size()));
+              hipLaunchKernelGGL(pack_w32t_kernel, dim3((T + 63) / 64, (unsigned)need.size()), dim3(256), (size_t)npk * 65 * sizeof(float), c->st, c->W,
+                                 (long long)T * p * p, c->W32, sW32, Tw, T, p, c->list_b);
+            }
+          }
           // t = Gb r0 (the start kernel has it already), then y = F Sb F^T t over the listed columns (left in c->Xt)
-          CHK(shared_solve(c, nb, c->Rv, c->Zv, nullptr, !f2, false, c->list_a, na, f2 ? Tl : 0));
+          CHK(shared_solve(c, nb, c->Rv, c->Zv, nullptr, !f2, false, c->list_a, na, f2 ? Tl : 0, v32));
           struct NdevGuard { pgpfa_ctx* c; ~NdevGuard() { c->cur_ndev = nullptr; } } ndev_guard{c};
           c->live_gemms.clear();
           int last_step = -1;
@@ -624,23 +656,29 @@ int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow_lr, do
               if constexpr (PW <= 10) {
                 const size_t la = pcg_cg_a_lds(PW), lb = pcg_cg_b_lds(PW);
                 // (per launch, not once per process: contexts of one process may sit on different devices)
-                if (la > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pcg_cg_a_kernel<PW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)la);
-                if (lb > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pcg_cg_b_kernel<PW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
-                hipLaunchKernelGGL(pcg_cg_a_kernel<PW>, gcg, dim3(256), la, c->st, cp);
-                hipLaunchKernelGGL(pcg_cg_b_kernel<PW>, gcg, dim3(256), lb, c->st, cp);
+                with_tv([&](auto tv) {
+                  using TV = decltype(tv);
+                  if (la > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pcg_cg_a_kernel<PW, TV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)la);
+                  if (lb > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pcg_cg_b_kernel<PW, TV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+                  hipLaunchKernelGGL((pcg_cg_a_kernel<PW, TV>), gcg, dim3(256), la, c->st, cp);
+                  hipLaunchKernelGGL((pcg_cg_b_kernel<PW, TV>), gcg, dim3(256), lb, c->st, cp);
+                });
               } else if constexpr (PW <= 20) {
                 const size_t la = pcgw_a_lds(PW), lb = pcgw_b_lds(PW);
-                if (la > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pcgw_a_kernel<PW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)la);
-                if (lb > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pcgw_b_kernel<PW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
-                hipLaunchKernelGGL(pcgw_a_kernel<PW>, gcg, dim3(256), la, c->st, cp);
-                hipLaunchKernelGGL(pcgw_b_kernel<PW>, gcg, dim3(256), lb, c->st, cp);
+                with_tv([&](auto tv) {
+                  using TV = decltype(tv);
+                  if (la > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pcgw_a_kernel<PW, TV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)la);
+                  if (lb > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pcgw_b_kernel<PW, TV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+                  hipLaunchKernelGGL((pcgw_a_kernel<PW, TV>), gcg, dim3(256), la, c->st, cp);
+                  hipLaunchKernelGGL((pcgw_b_kernel<PW, TV>), gcg, dim3(256), lb, c->st, cp);
+                });
               }
             });
             if (!f2) hipLaunchKernelGGL(pcg_iter_close_kernel, dim3(1), dim3(64), 0, c->st, c->pcgctl, it & 1, (volatile int*)c->d_hpcg, -1);
             // the preconditioner products for the NEXT iteration run over the list this launch has just written
             c->live_gemm_collect = (it == 0);
             c->cur_ndev = &c->pcgctl->nl[(it & 1) ^ 1];
-            CHK(shared_solve(c, nb, c->Rv, c->Zv, skip, false, false, (it & 1) ? c->live : c->live1, bound, f2 ? Tl : 0));
+            CHK(shared_solve(c, nb, c->Rv, c->Zv, skip, false, false, (it & 1) ? c->live : c->live1, bound, f2 ? Tl : 0, v32));
             if (*(volatile int*)&c->h_pcg[0]) break;           // the device has already stopped: whatever is enqueued is a no-op
             if (it + 1 < c->pcg_inner_max) {
               const auto t_spin = std::chrono::steady_clock::now();
@@ -826,6 +864,7 @@ int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow_lr, do
           const double ops = onek ? (2.0 * T * c->rtot + (double)c->rtot * c->rtot + 1.5 * T * npk) * 8.0
                                   : (double)p * T * T * 8.0 + (c->plan_lowrank ? (2.0 * T * c->rtot + (double)c->rtot * c->rtot) * 8.0 : (double)nvec * nvec * 8.0);
           newton_bytes += slot_iters * (vecs + curv) + (double)done_inner * ops;
+          newton_bytes_moved += slot_iters * ((v32 ? 11.0 * nvec * 8.0 + (c->plan_lowrank ? 4.0 * c->rtot * 8.0 : 0.0) : vecs) + curv) + (double)done_inner * ops;
           newton_bytes_survey += slot_iters * ((double)c->q * T + 8.0 * (2.0 * p * T + (double)T * p * p));
         }
         std::vector<int> cand, next, failed;
@@ -1101,6 +1140,7 @@ int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow_lr, do
     c->info["last_newton_solve_ms"] = nms;
     c->info["last_newton_solve_bytes"] = newton_bytes;
     c->info["last_newton_solve_bytes_survey"] = newton_bytes_survey;
+    c->info["last_newton_solve_bytes_moved"] = newton_bytes_moved;
   }
   return 0;
 }

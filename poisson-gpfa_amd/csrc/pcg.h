@@ -407,6 +407,12 @@ struct PcgCgP {
   // 512 bytes touched 5 lines for 4) - and Tx for X, the step the rest of the E-step reads in its compact layout (k T + t).  Form 1: Tl = Tx = T.
   int Tl, Tx;
   int step;                                    // index of this step within the solve
+  // (round 5, second half) vec32: z, s, p, q and the preconditioner's t / y are STORED in single precision (same element offsets in the same
+  // buffers); x and r - the vectors that accumulate - and every product and dot stay FP64.  After preconditioning |s| = |H~ z| ~ |r| and
+  // |q| ~ |r|, so a rounding of 6e-8 relative in those vectors perturbs the residual recurrence by ~1e-7 |r| per step - the forcing terms of the
+  // solves never go below 7e-6 (e = sqrt(xtol / 20) minimises max(e, xtol / 20 e)), and the outer loop measures the true gradient anyway.  A
+  // slot-step moves 13.8 n-vector equivalents instead of 19.8.
+  int vec32;
   int fold_close;                              // 1: kernel A of step i closes step i - 1 (no closing launch per step; pcg_iter_close_kernel once after the last)
   volatile int* host;                          // host-mapped {stop, steps, live} mirror (written by whoever closes a step)
   const double *Gl, *KX; double* Gt;           // pcg_cg_start_kernel: likelihood gradient and K^-1 x (compact), their sum out
@@ -518,8 +524,12 @@ __device__ __forceinline__ void pcg_cg_wg(int ntile, int xcd_map, int& tile, int
   group = xcd + 8 * (m / ntile);
 }
 
-template <int PW>
+template <int PW, typename TV = double>
 __global__ __launch_bounds__(256, 2) void pcg_cg_a_kernel(PcgCgP a) {
+  // TV: storage type of the vectors private to the solve that carry no accumulated state - z, s, p, q and the preconditioner's t / y (see PcgCgP::vec32)
+  TV* const Zp = reinterpret_cast<TV*>(a.Z); TV* const Sp = reinterpret_cast<TV*>(a.S); TV* const Pp = reinterpret_cast<TV*>(a.P);
+  TV* const Qp = reinterpret_cast<TV*>(a.Q); TV* const Yp = reinterpret_cast<TV*>(a.Y);
+  (void)Zp; (void)Sp; (void)Pp; (void)Qp; (void)Yp;
   constexpr int NP = PW * (PW + 1) / 2, LD = pcg_cg_ld(PW);
   extern __shared__ double pcg_cg_smem[];
   double* Gs = pcg_cg_smem;
@@ -560,7 +570,7 @@ __global__ __launch_bounds__(256, 2) void pcg_cg_a_kernel(PcgCgP a) {
     for (int k = 0; k < PW; ++k) {
       const size_t o = base + (size_t)(k < p ? k : 0) * Tl;
       r[k] = a.R[o];
-      v[k] = a.Y[o];
+      v[k] = (double)Yp[o];
     }
     {
       const float* wp = a.W32T + slot * a.sW32 + t;
@@ -589,8 +599,8 @@ __global__ __launch_bounds__(256, 2) void pcg_cg_a_kernel(PcgCgP a) {
       s0 += r[k] * z[k]; s1 += z[k] * sk; s2 += r[k] * r[k];
       if (in && k < p) {
         const size_t o = base + (size_t)k * Tl;
-        a.Z[o] = z[k];
-        a.S[o] = sk;
+        Zp[o] = (TV)z[k];
+        Sp[o] = (TV)sk;
       }
     }
     for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_down(s0, off); s1 += __shfl_down(s1, off); s2 += __shfl_down(s2, off); }
@@ -602,8 +612,12 @@ __global__ __launch_bounds__(256, 2) void pcg_cg_a_kernel(PcgCgP a) {
 }
 
 // same launch shape; dynamic LDS = pcg_cg_b_lds(PW)
-template <int PW>
+template <int PW, typename TV = double>
 __global__ __launch_bounds__(256, 3) void pcg_cg_b_kernel(PcgCgP a) {
+  // TV: storage type of the vectors private to the solve that carry no accumulated state - z, s, p, q and the preconditioner's t / y (see PcgCgP::vec32)
+  TV* const Zp = reinterpret_cast<TV*>(a.Z); TV* const Sp = reinterpret_cast<TV*>(a.S); TV* const Pp = reinterpret_cast<TV*>(a.P);
+  TV* const Qp = reinterpret_cast<TV*>(a.Q); TV* const Yp = reinterpret_cast<TV*>(a.Y);
+  (void)Zp; (void)Sp; (void)Pp; (void)Qp; (void)Yp;
   constexpr int NP = PW * (PW + 1) / 2, LD = pcg_cg_ld(PW);
   extern __shared__ double pcg_cg_smem[];
   double* Gs = pcg_cg_smem;
@@ -663,14 +677,14 @@ __global__ __launch_bounds__(256, 3) void pcg_cg_b_kernel(PcgCgP a) {
 #pragma unroll
     for (int k = 0; k < PW; ++k) {
       const size_t o = base + (size_t)(k < p ? k : 0) * Tl;
-      zk[k] = a.Z[o]; sk[k] = a.S[o]; xo[k] = a.X[base + (size_t)(k < p ? k : 0) * Tx]; r[k] = a.R[o];
+      zk[k] = (double)Zp[o]; sk[k] = (double)Sp[o]; xo[k] = a.X[base + (size_t)(k < p ? k : 0) * Tx]; r[k] = a.R[o];
       po[k] = 0.0; qo[k] = 0.0;
     }
     if (!a.first) {
 #pragma unroll
       for (int k = 0; k < PW; ++k) {
         const size_t o = base + (size_t)(k < p ? k : 0) * Tl;
-        po[k] = a.P[o]; qo[k] = a.Q[o];
+        po[k] = (double)Pp[o]; qo[k] = (double)Qp[o];
       }
     }
 #pragma unroll
@@ -681,8 +695,8 @@ __global__ __launch_bounds__(256, 3) void pcg_cg_b_kernel(PcgCgP a) {
       const double qn = sk[k] + beta * qo[k];
       r[k] = ok ? r[k] - alpha * qn : 0.0;
       if (ok) {
-        a.P[o] = pv[k];
-        a.Q[o] = qn;
+        Pp[o] = (TV)pv[k];
+        Qp[o] = (TV)qn;
         a.X[base + (size_t)k * Tx] = xo[k] + alpha * pv[k];
         a.R[o] = r[k];
       }
@@ -690,7 +704,7 @@ __global__ __launch_bounds__(256, 3) void pcg_cg_b_kernel(PcgCgP a) {
     pcg_sym_mv<PW, false>(g, 1, p, r, tv);
 #pragma unroll
     for (int k = 0; k < PW; ++k)
-      if (in && k < p) a.Y[base + (size_t)k * Tl] = tv[k];
+      if (in && k < p) Yp[base + (size_t)k * Tl] = (TV)tv[k];
   }
 }
 
@@ -707,8 +721,12 @@ inline __global__ void pcg_iter_close_kernel(PcgCtl* __restrict__ ctl, int par, 
 // First kernel of a solve (round 5; one launch where grad_total_kernel, pcg_init_kernel and the per-bin application of the shared preconditioner
 // were three): for the slots of the solve's first live list  g = Gl + K^-1 x -> Gt (compact: the outer loop reads it),  r = -g -> R,  x = 0 -> X,
 // t = Gb r -> Y (input of the products y = F Sb F^T t).  Same launch shape and LDS as kernel B.
-template <int PW>
+template <int PW, typename TV = double>
 __global__ __launch_bounds__(256, 3) void pcg_cg_start_kernel(PcgCgP a) {
+  // TV: storage type of the vectors private to the solve that carry no accumulated state - z, s, p, q and the preconditioner's t / y (see PcgCgP::vec32)
+  TV* const Zp = reinterpret_cast<TV*>(a.Z); TV* const Sp = reinterpret_cast<TV*>(a.S); TV* const Pp = reinterpret_cast<TV*>(a.P);
+  TV* const Qp = reinterpret_cast<TV*>(a.Q); TV* const Yp = reinterpret_cast<TV*>(a.Y);
+  (void)Zp; (void)Sp; (void)Pp; (void)Qp; (void)Yp;
   constexpr int NP = PW * (PW + 1) / 2, LD = pcg_cg_ld(PW);
   extern __shared__ double pcg_cg_smem[];
   double* Gs = pcg_cg_smem;
@@ -748,7 +766,7 @@ __global__ __launch_bounds__(256, 3) void pcg_cg_start_kernel(PcgCgP a) {
     pcg_sym_mv<PW, false>(g, 1, p, r, tv);
 #pragma unroll
     for (int k = 0; k < PW; ++k)
-      if (in && k < p) a.Y[base + (size_t)k * Tl] = tv[k];
+      if (in && k < p) Yp[base + (size_t)k * Tl] = (TV)tv[k];
   }
 }
 
@@ -812,8 +830,12 @@ __device__ __forceinline__ double pcgw_sum32(double x) {
 }
 
 // grid = (ceil(T / 32), slot groups of spw rounded up to 8), block = 256, dynamic LDS = pcgw_a_lds(PW)
-template <int PW>
+template <int PW, typename TV = double>
 __global__ __launch_bounds__(256, 1) void pcgw_a_kernel(PcgCgP a) {
+  // TV: storage type of the vectors private to the solve that carry no accumulated state - z, s, p, q and the preconditioner's t / y (see PcgCgP::vec32)
+  TV* const Zp = reinterpret_cast<TV*>(a.Z); TV* const Sp = reinterpret_cast<TV*>(a.S); TV* const Pp = reinterpret_cast<TV*>(a.P);
+  TV* const Qp = reinterpret_cast<TV*>(a.Q); TV* const Yp = reinterpret_cast<TV*>(a.Y);
+  (void)Zp; (void)Sp; (void)Pp; (void)Qp; (void)Yp;
   constexpr int NP = PW * (PW + 1) / 2, LD = pcg_cg_ld(PW);
   extern __shared__ double pcg_cg_smem[];
   double* Gs = pcg_cg_smem;
@@ -847,7 +869,7 @@ __global__ __launch_bounds__(256, 1) void pcgw_a_kernel(PcgCgP a) {
     for (int k = 0; k < PW; ++k) {
       const size_t o = base + (size_t)(k < p ? k : 0) * Tl;
       r[k] = a.R[o];
-      v[k] = a.Y[o];
+      v[k] = (double)Yp[o];
     }
 #pragma unroll
     for (int k = 0; k < PW; ++k) {
@@ -868,8 +890,8 @@ __global__ __launch_bounds__(256, 1) void pcgw_a_kernel(PcgCgP a) {
       s0 += r[k] * z[k]; s1 += z[k] * sk; s2 += r[k] * r[k];
       if (have && in && k < p) {
         const size_t o = base + (size_t)k * Tl;
-        a.Z[o] = z[k];
-        a.S[o] = sk;
+        Zp[o] = (TV)z[k];
+        Sp[o] = (TV)sk;
       }
     }
     s0 = pcgw_sum32(s0); s1 = pcgw_sum32(s1); s2 = pcgw_sum32(s2);
@@ -881,20 +903,24 @@ __global__ __launch_bounds__(256, 1) void pcgw_a_kernel(PcgCgP a) {
 }
 
 // t = Gb r for this lane's bin; r is zero beyond p / past the tile
-template <int PW>
-__device__ __forceinline__ void pcgw_apply_store(const double* __restrict__ g, int p, const double (&r)[PW], double* __restrict__ Y, size_t base, int Tl, bool ok) {
+template <int PW, typename TV>
+__device__ __forceinline__ void pcgw_apply_store(const double* __restrict__ g, int p, const double (&r)[PW], TV* __restrict__ Y, size_t base, int Tl, bool ok) {
   double tv[PW];
 #pragma unroll
   for (int k = 0; k < PW; ++k) tv[k] = 0.0;
   pcgw_sym_mv_acc<PW, 2>(g, 1, 0u, p, r, tv, 1.0);
 #pragma unroll
   for (int k = 0; k < PW; ++k)
-    if (ok && k < p) Y[base + (size_t)k * Tl] = tv[k];
+    if (ok && k < p) Y[base + (size_t)k * Tl] = (TV)tv[k];
 }
 
 // same launch shape; dynamic LDS = pcgw_b_lds(PW)
-template <int PW>
+template <int PW, typename TV = double>
 __global__ __launch_bounds__(256, 2) void pcgw_b_kernel(PcgCgP a) {
+  // TV: storage type of the vectors private to the solve that carry no accumulated state - z, s, p, q and the preconditioner's t / y (see PcgCgP::vec32)
+  TV* const Zp = reinterpret_cast<TV*>(a.Z); TV* const Sp = reinterpret_cast<TV*>(a.S); TV* const Pp = reinterpret_cast<TV*>(a.P);
+  TV* const Qp = reinterpret_cast<TV*>(a.Q); TV* const Yp = reinterpret_cast<TV*>(a.Y);
+  (void)Zp; (void)Sp; (void)Pp; (void)Qp; (void)Yp;
   constexpr int NP = PW * (PW + 1) / 2, LD = pcg_cg_ld(PW);
   extern __shared__ double pcg_cg_smem[];
   double* Gs = pcg_cg_smem;
@@ -957,14 +983,14 @@ __global__ __launch_bounds__(256, 2) void pcgw_b_kernel(PcgCgP a) {
       for (int j = 0; j < 5; ++j) {
         const int k = k0 + j;
         const size_t o = base + (size_t)(k < p ? k : 0) * Tl;
-        zk[j] = a.Z[o]; sk[j] = a.S[o]; ro[j] = a.R[o]; xo[j] = a.X[base + (size_t)(k < p ? k : 0) * Tx];
+        zk[j] = (double)Zp[o]; sk[j] = (double)Sp[o]; ro[j] = a.R[o]; xo[j] = a.X[base + (size_t)(k < p ? k : 0) * Tx];
         po[j] = 0.0; qo[j] = 0.0;
       }
       if (!a.first) {
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
           const size_t o = base + (size_t)(k0 + j < p ? k0 + j : 0) * Tl;
-          po[j] = a.P[o]; qo[j] = a.Q[o];
+          po[j] = (double)Pp[o]; qo[j] = (double)Qp[o];
         }
       }
 #pragma unroll
@@ -976,20 +1002,24 @@ __global__ __launch_bounds__(256, 2) void pcgw_b_kernel(PcgCgP a) {
         const double qn = sk[j] + beta * qo[j];
         if (k < PW) r[k < PW ? k : 0] = ok ? ro[j] - alpha * qn : 0.0;
         if (ok) {
-          a.P[o] = pn;
-          a.Q[o] = qn;
+          Pp[o] = (TV)pn;
+          Qp[o] = (TV)qn;
           a.X[base + (size_t)k * Tx] = xo[j] + alpha * pn;
           a.R[o] = ro[j] - alpha * qn;
         }
       }
     }
-    pcgw_apply_store<PW>(g, p, r, a.Y, base, Tl, in);
+    pcgw_apply_store<PW>(g, p, r, Yp, base, Tl, in);
   }
 }
 
 // first kernel of a solve (see pcg_cg_start_kernel); launch shape and LDS of pcgw_b_kernel
-template <int PW>
+template <int PW, typename TV = double>
 __global__ __launch_bounds__(256, 2) void pcgw_start_kernel(PcgCgP a) {
+  // TV: storage type of the vectors private to the solve that carry no accumulated state - z, s, p, q and the preconditioner's t / y (see PcgCgP::vec32)
+  TV* const Zp = reinterpret_cast<TV*>(a.Z); TV* const Sp = reinterpret_cast<TV*>(a.S); TV* const Pp = reinterpret_cast<TV*>(a.P);
+  TV* const Qp = reinterpret_cast<TV*>(a.Q); TV* const Yp = reinterpret_cast<TV*>(a.Y);
+  (void)Zp; (void)Sp; (void)Pp; (void)Qp; (void)Yp;
   constexpr int NP = PW * (PW + 1) / 2, LD = pcg_cg_ld(PW);
   extern __shared__ double pcg_cg_smem[];
   double* Gs = pcg_cg_smem;
@@ -1025,7 +1055,7 @@ __global__ __launch_bounds__(256, 2) void pcgw_start_kernel(PcgCgP a) {
       }
       r[k] = ok ? -r[k] : 0.0;
     }
-    pcgw_apply_store<PW>(g, p, r, a.Y, base, Tl, in);
+    pcgw_apply_store<PW>(g, p, r, Yp, base, Tl, in);
   }
 }
 
@@ -1057,6 +1087,28 @@ inline __global__ __launch_bounds__(256) void pack_w32t_kernel(const double* __r
     while ((a + 1) * (a + 2) / 2 <= c) ++a;
     const int b = c - a * (a + 1) / 2;
     w32t_tile[c * 65 + t] = (float)W[slot * sW + (size_t)(t0 + t) * pp + a * p + b];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < np * 64; e += 256) {
+    const int c = e >> 6, t = e & 63;
+    if (t < nt) Wp[slot * sWp + (size_t)c * Tw + t0 + t] = w32t_tile[c * 65 + t];
+  }
+}
+
+// Commit of an accepted line-search step, curvature part: W <- Wt for the listed slots AND its packed single-precision form (pack_w32t_kernel's
+// output) in the same pass over Wt.  grid = (ceil(T/64), nslots), block = 256, dynamic LDS = NP * 65 floats
+inline __global__ __launch_bounds__(256) void commit_w_pack_kernel(const double* __restrict__ Wt, double* __restrict__ W, long long sW, float* __restrict__ Wp,
+                                                            long long sWp, int Tw, int T, int p, const int* __restrict__ slots) {
+  extern __shared__ float w32t_tile[];
+  const size_t slot = slots[blockIdx.y];
+  const int np = p * (p + 1) / 2, pp = p * p;
+  const int t0 = blockIdx.x * 64, nt = min(64, T - t0);
+  const size_t base = slot * sW + (size_t)t0 * pp;
+  for (int e = threadIdx.x; e < nt * pp; e += 256) {
+    const double v = Wt[base + e];
+    W[base + e] = v;
+    const int t = e / pp, idx = e - t * pp, a = idx / p, b = idx - a * p;
+    if (b <= a) w32t_tile[(a * (a + 1) / 2 + b) * 65 + t] = (float)v;
   }
   __syncthreads();
   for (int e = threadIdx.x; e < np * 64; e += 256) {

@@ -59,7 +59,8 @@ struct ThinP {
 // this makes it one or two of them (double-buffered single blocks: eight).  No branch encloses a load: the compiler counts outstanding loads
 // per path and waits for ALL of them after a join.
 constexpr int THIN_KB = 4;
-template <bool VEC4>
+// TX: storage type of the INPUT n-vectors (float: the inner solve's single-precision t, widened as it is loaded; the products stay FP64)
+template <bool VEC4, typename TX = double>
 __global__ __launch_bounds__(512, 2) void thin_ft_kernel(ThinP a) {
   if (a.skip && *a.skip) return;
   const int ncols = a.n_dev ? min(*a.n_dev, a.ncols) : a.ncols;
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(512, 2) void thin_ft_kernel(ThinP a) {
   //  and this load does not wait for the count)
   const int sc = min(s0 + l15, a.ncols - 1);
   const int slot = a.cols ? a.cols[sc] : sc;
-  const double* xp = a.X + (size_t)slot * a.ldx + (size_t)l * a.Tx;
+  const TX* xp = reinterpret_cast<const TX*>(a.X) + (size_t)slot * a.ldx + (size_t)l * a.Tx;
   // row tile mi of this lane: rank row m0 + 4 l15 + mi (rows past the group's read neighbours' zeros or padding and are not stored)
   const double* fp = a.FT + (size_t)l * a.T * a.ldft + r0 + m0 + 4 * l15;
   const int nkb = (a.T + 15) >> 4;
@@ -94,11 +95,16 @@ __global__ __launch_bounds__(512, 2) void thin_ft_kernel(ThinP a) {
       const int t0 = min(kb + u, kb1 - 1) * 16 + 4 * l4;
       const bool in = kb + u < kb1;
       if (VEC4) {
-        x[u] = *reinterpret_cast<const double4_t*>(xp + min(t0, a.T - 4));
+        if constexpr (sizeof(TX) == 4) {
+          const float4_t xf = *reinterpret_cast<const float4_t*>(xp + min(t0, a.T - 4));
+          x[u] = double4_t{(double)xf[0], (double)xf[1], (double)xf[2], (double)xf[3]};
+        } else {
+          x[u] = *reinterpret_cast<const double4_t*>(xp + min(t0, a.T - 4));
+        }
         if (t0 >= a.T || !in) x[u] = double4_t{0.0, 0.0, 0.0, 0.0};
       } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { const double v = xp[min(t0 + i, a.T - 1)]; x[u][i] = (t0 + i < a.T && in) ? v : 0.0; }
+        for (int i = 0; i < 4; ++i) { const double v = (double)xp[min(t0 + i, a.T - 1)]; x[u][i] = (t0 + i < a.T && in) ? v : 0.0; }
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) f[u][i] = *reinterpret_cast<const double4_t*>(fp + (size_t)min(t0 + i, a.T - 1) * a.ldft);
@@ -137,7 +143,8 @@ __global__ __launch_bounds__(512, 2) void thin_ft_kernel(ThinP a) {
 
 // y[l T + t, s] = sum_j F_l[t, j] v[roff_l + j, s].  grid = (entries of the (latent, 256-bin group) table, ceil(ncols / 16)), block = 256.
 // A wave owns 64 bins, tb0 + 64 wave .. ; bin tile j holds bins 4 l15 + j of them.  Four 16-column k blocks are fetched at a time (see above).
-template <bool VEC4>
+// TY: storage type of the OUTPUT n-vectors
+template <bool VEC4, typename TY = double>
 __global__ __launch_bounds__(256, 2) void thin_f_kernel(ThinP a) {
   if (a.skip && *a.skip) return;
   const int ncols = a.n_dev ? min(*a.n_dev, a.ncols) : a.ncols;
@@ -193,12 +200,16 @@ __global__ __launch_bounds__(256, 2) void thin_f_kernel(ThinP a) {
     const int sp = s0 + l4 + 4 * r;
     if (sp >= ncols) continue;
     const int so = a.cols ? a.cols[sp] : sp;
-    double* yp = a.Y + (size_t)so * a.ldy + (size_t)l * a.Tx;
+    TY* yp = reinterpret_cast<TY*>(a.Y) + (size_t)so * a.ldy + (size_t)l * a.Tx;
     if (VEC4) {
-      if (t < a.T) *reinterpret_cast<double4_t*>(yp + t) = double4_t{acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+      if constexpr (sizeof(TY) == 4) {
+        if (t < a.T) *reinterpret_cast<float4_t*>(yp + t) = float4_t{(float)acc[0][r], (float)acc[1][r], (float)acc[2][r], (float)acc[3][r]};
+      } else {
+        if (t < a.T) *reinterpret_cast<double4_t*>(yp + t) = double4_t{acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+      }
     } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) if (t + j < a.T) yp[t + j] = acc[j][r];
+      for (int j = 0; j < 4; ++j) if (t + j < a.T) yp[t + j] = (TY)acc[j][r];
     }
   }
   THIN_STAMP(6);

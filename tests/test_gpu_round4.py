@@ -43,14 +43,16 @@ def test_pcg_step_without_prior_matvec_vs_oracle(shape):
     par = {'C': 0.3 * rng.standard_normal((q, p)) / np.sqrt(max(1, p / 4)), 'd': np.log(Y.mean(axis=(0, 2)) + 0.1), 'tau': 0.05 + 0.3 * rng.random(p)}
     res, nll_o, _ = orc.laplace([y.astype(float) for y in Ys], par, 10.0, mode='exact', return_cov=False)
     modes = {}
-    for form, thin in (((2, 2), (1, 2), (0, 2), (1, 0), (1, 1)) if p <= 10 else ((2, 2), (0, 2))):
+    # (form 2 twice: with the solve's z, s, p, q, t / y stored in single precision - the default, key (2, 2) - and all FP64, key (2, -2))
+    for form, thin in (((2, 2), (2, -2), (1, 2), (0, 2), (1, 0), (1, 1)) if p <= 10 else ((2, 2), (2, -2), (0, 2))):
         ctx = _hip.Context(q, p, T, R, 10.0)
         try:
             ctx.upload_counts(Y)
             ctx.set_option('cov_mode', 2)
             ctx.set_option('pcg_fused', 2)
             ctx.set_option('pcg_form', form)
-            ctx.set_option('thin_products', thin)
+            ctx.set_option('thin_products', abs(thin))
+            ctx.set_option('pcg_vec32', 1 if thin > 0 else 0)
             ctx.set_params(par['C'], par['d'], par['tau'])
             obj, _, status = ctx.estep_laplace()
             assert np.all(status == 0) and ctx.info('plan_lowrank') == 1.0 and ctx.info('last_pcg_iterations') > 0
@@ -63,6 +65,7 @@ def test_pcg_step_without_prior_matvec_vs_oracle(shape):
         finally:
             ctx.close()
     assert np.max(np.abs(modes[2, 2] - modes[0, 2])) <= 2e-9
+    assert np.max(np.abs(modes[2, -2] - modes[0, 2])) <= 2e-9
     if p <= 10:
         assert np.max(np.abs(modes[1, 2] - modes[0, 2])) <= 2e-9
         assert np.max(np.abs(modes[1, 2] - modes[1, 0])) <= 2e-9

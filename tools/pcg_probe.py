@@ -28,6 +28,8 @@ forms = [int(ch) for ch in (sys.argv[4] if len(sys.argv) > 4 else '101')]
 option = sys.argv[5] if len(sys.argv) > 5 else 'pcg_form'
 for onek in forms:
     sess.ctx.set_option(option, onek)
+    for kv in filter(None, os.environ.get('PROBE_OPTS', '').split(',')):
+        sess.ctx.set_option(kv.split('=')[0], float(kv.split('=')[1]))
     sess.ctx.set_option('time_newton', 1)
     params = {k: np.asarray(v, dtype=np.float64).copy() for k, v in p0.items()}
     optim = None
