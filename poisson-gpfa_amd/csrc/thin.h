@@ -58,7 +58,11 @@ struct ThinP {
 // multiplies them: with the chip a third full (the live list of the inner solve shrinks) the kernel is a chain of memory round trips, and
 // this makes it one or two of them (double-buffered single blocks: eight).  No branch encloses a load: the compiler counts outstanding loads
 // per path and waits for ALL of them after a join.
-constexpr int THIN_KB = 4;
+#ifdef THIN_KB_OVERRIDE
+constexpr int THIN_KB = THIN_KB_OVERRIDE;        // (tools/probes/Makefile builds the probe with 4 as well)
+#else
+constexpr int THIN_KB = 2;
+#endif
 // TX: storage type of the INPUT n-vectors (float: the inner solve's single-precision t, widened as it is loaded; the products stay FP64)
 template <bool VEC4, typename TX = double>
 __global__ __launch_bounds__(512, 2) void thin_ft_kernel(ThinP a) {

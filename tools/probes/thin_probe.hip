@@ -39,6 +39,17 @@ int main(int argc, char** argv) {
   hipMemcpy(dcols, cols.data(), S * 4, hipMemcpyHostToDevice); hipMemcpy(dn, &live, 4, hipMemcpyHostToDevice);
   ThinP a{};
   a.F = F; a.Tf = Tf; a.T = T; a.Tx = T; a.FT = FT; a.ldft = rpad; a.cols = dcols; a.n_dev = dn; a.ncols = S; a.skip = nullptr;
+  {
+    int nft = 0, nf = 0;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nft, thin_ft_kernel<true>, 512, 0);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, thin_f_kernel<true>, 256, 0);
+    printf("occupancy (workgroups per CU the runtime computes): thin_ft %d, thin_f %d\n", nft, nf);
+    hipFuncAttributes fa{};
+    hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&thin_ft_kernel<true>));
+    printf("thin_ft_kernel<true>: numRegs %d, sharedSizeBytes %zu, maxThreadsPerBlock %d, localSizeBytes %zu\n", fa.numRegs, fa.sharedSizeBytes, fa.maxThreadsPerBlock, fa.localSizeBytes);
+    hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&thin_f_kernel<true>));
+    printf("thin_f_kernel<true>: numRegs %d, sharedSizeBytes %zu, maxThreadsPerBlock %d, localSizeBytes %zu\n", fa.numRegs, fa.sharedSizeBytes, fa.maxThreadsPerBlock, fa.localSizeBytes);
+  }
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int which = 0; which < 2; ++which) {
     ThinP q = a;
