@@ -87,7 +87,10 @@ int pgpfa_destroy(pgpfa_ctx* ctx);
  * "splitk_below64" (400: products on 64 x 64 tiles are cut along k only below this many tiles),
  * "copy_kernels" (1: read-backs and uploads up to 256 KB move through host-mapped staging memory as one-workgroup kernels, and a flush is a
  * kernel that raises a sequence number the host spins on - no hipMemcpyAsync / hipStreamSynchronize on those paths; 0: the runtime's copies),
- * "mix_slot" (2: as 1 with the next pair of columns requested before this pair's arithmetic - two register sets, no branch in the loop - where
+ * "yt_mix" (1, round 5: under the split covariance form and up to 10 latents the product Yt = F L^-T and the mixing pass run as ONE kernel - tiles of all
+ * latents on the FP64 matrix cores, mixed in registers, only the correction D and post_vsm leave the chip; Yt is never written; 0: product, then mixing pass),
+ * "mix_slot" (3, round 5: as 2 with a workgroup of 128 bins x 2 column halves - both halves read one G_t image of 56 KB, two workgroups = two waves per SIMD on a CU -
+ * the halves' pair sums meet through LDS at the end; 2: as 1 with the next pair of columns requested before this pair's arithmetic - two register sets, no branch in the loop - where
  * p is a template width and the rank a multiple of 4, else 1; 1: the mixing pass of that split form with a thread per bin and a workgroup per (slot, 256 bins) that walks whole columns of
  * the slab - contiguous 2-KB runs instead of 512-byte pieces, no LDS; up to 10 latents; 0: mix_vsm_split_kernel, 64 bins x 4 columns),
  * "thin_products" (2: the three products of the low-rank preconditioner application - the block-diagonal F^T t and F v, and Sb u - as kernels of
@@ -115,7 +118,7 @@ int pgpfa_set_option(pgpfa_ctx* ctx, const char* key, double value);
 /* Info: "chunk_trials", "plan_lowrank", "n_pad", "lowrank_rtot", "last_estep_ms", "last_newton_factorizations",
  * "last_newton_solves", "last_pcg_iterations", "last_shared_factorizations", "last_cov_lowrank",
  * "last_dense_retries", "hbm_bytes_allocated", "hbm_bytes_free" / "hbm_bytes_total" (hipMemGetInfo of the context's device, now), "n_trials_global", "prof_<tag>_{ms,flops,launches}", "counts_two_bytes",
- * "arena_bytes", "last_split_cov", "last_eps_wt_norm", "last_eps_wt_rms", "last_newton_solve_ms", "last_newton_solve_bytes",
+ * "arena_bytes", "last_split_cov", "last_yt_mix_fused" (1 when the last covariance pass ran product and mixing as one kernel), "last_eps_wt_norm", "last_eps_wt_rms", "last_newton_solve_ms", "last_newton_solve_bytes",
  * "last_newton_solve_bytes_moved" (what the step's kernels really move: with "pcg_vec32" five of its vectors are single precision),
  * "last_newton_solve_bytes_survey" (the same slot-iterations priced at q T + 8 (2 p T + T p^2) bytes each: SURVEY 8(d)'s B_E per pass per trial),
  * "arena_vmm_failed" (1 once the virtual-memory arena fell back to plain allocations), "last_newton_max_iter", "last_dual_evaluations",

@@ -863,6 +863,7 @@ int pgpfa_create(pgpfa_ctx** out, int device, int q, int p, int T, int R, double
   c->info["last_eps_wt_norm"] = 0.0;
   c->info["last_eps_wt_rms"] = 0.0;
   c->info["last_split_cov"] = 0.0;
+  c->info["last_yt_mix_fused"] = 0.0;
   *out = c;
   return 0;
 }
@@ -913,6 +914,8 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
   else if (k == "mt_fill") c->mt_fill = (int)v;
   else if (k == "overlap_factors") c->overlap_factors = (int)v;
   else if (k == "mix_slot") c->mix_slot = (int)v;
+  else if (k == "yt_mix") c->yt_mix = (v != 0.0);
+  else if (k == "yt_mix_dbg") c->yt_mix_dbg = (int)v;
   else if (k == "mix_wide") c->mix_wide = (int)v;
   else if (k == "thin_products") c->thin_products = (int)v;
   else if (k == "copy_kernels") c->copy_kernels = (v != 0.0);

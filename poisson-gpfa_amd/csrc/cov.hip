@@ -2,6 +2,7 @@
 #include "ctx.h"
 #include "model.h"
 #include "split.h"
+#include "ytmix.h"
 
 using namespace pgpfa;
 
@@ -106,7 +107,7 @@ static int posterior_blocks_dense(pgpfa_ctx* c, int nb, double diag_scale, bool 
 
 // Sum-only covariance output by the exact split form (split.h): Pacc[k] += sum over the chunk's slots of Y~_k Y~_k^T + eps diag(G_t[k][k])
 // from L^-T (lw.Mt), Yt (lw.H) and the per-bin blocks G (c->Gbin), without the full-width FP64 product.  Also writes post_vsm.
-static int accumulate_split(pgpfa_ctx* c, const CholWS& lw, int nb, int ract, int Ts, bool skip_zero_cols, int ctile) {
+static int accumulate_split(pgpfa_ctx* c, const CholWS& lw, int nb, int ract, int Ts, bool skip_zero_cols, int ctile, bool fused) {
   const int T = c->T, p = c->p, Tp = c->Tp, rpad = c->rpad;
   const long long sW = (long long)T * p * p;
   const size_t tt = (size_t)T * T;
@@ -134,6 +135,24 @@ static int accumulate_split(pgpfa_ctx* c, const CholWS& lw, int nb, int ract, in
   double mix_cols = 0.0;                                   // columns of Yt a latent's rows really hold: left of its first column tile nothing was written
   for (int k = 0; k < p; ++k) mix_cols += std::max(0, ract - (ctile > 0 ? (c->roff[k] / ctile) * ctile : 0));
   // (bytes: the columns of Yt that hold something read once in FP64; D - dense, the mixing couples the latents - written once in FP32)
+  if (fused) {
+    // Yt was not formed: product and mixing in one kernel.  Bytes: D written once in FP32 (the panels of L^-T and F come from L2).
+    prof_begin(c, TAG_MIX, (double)nb * T * (double)p * ract * 4.0);
+    dispatch_pw(p, [&](auto pw) {
+      constexpr int PW = decltype(pw)::value;
+      if constexpr (PW <= 10) {
+        if (p != PW) return;
+        YtMixArgs a{};
+        a.F = c->Flr; a.Tp = Tp; a.Mts = lw.Mt; a.sM = (long long)lw.sM; a.rpad = rpad;
+        a.D = D; a.sD = sD; a.ldd = ldd; a.G = c->Gbin; a.sG = sW;
+        a.T = T; a.ract = ract; a.nbx = (T + YTM_BINS - 1) / YTM_BINS; a.nslots = nb; a.eps = c->eps;
+        a.vsm = c->vsm; a.slots = c->ident; a.trial_of_slot = c->trial_of_slot; a.roff = c->d_roff; a.ts = Ts; a.dbg = c->yt_mix_dbg;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&yt_mix_kernel<PW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ytmix_lds(PW));
+        hipLaunchKernelGGL(yt_mix_kernel<PW>, dim3((unsigned)(a.nbx * nb)), dim3(YTM_THREADS), ytmix_lds(PW), c->st, a);
+      }
+    });
+    prof_end(c);
+  } else {
   prof_begin(c, TAG_MIX, (double)nb * T * (mix_cols * 8.0 + (double)p * ract * 4.0));
   if (p > 16)                                               // (17..20 latents: split_candidate admits no others beyond 16)
     hipLaunchKernelGGL((mix_vsm_wide2_kernel<20, true>), dim3((T + 63) / 64, nb), dim3(256), 0, c->st, lw.H, (long long)lw.sH, c->ld, c->Gbin, sW, T, p, ract, c->eps,
@@ -142,6 +161,12 @@ static int accumulate_split(pgpfa_ctx* c, const CholWS& lw, int nb, int ract, in
   dispatch_pw(p, [&](auto pw) {
     constexpr int PW = decltype(pw)::value;
     if constexpr (PW <= 10) {
+      if (c->mix_slot >= 3 && p == PW && ract % 4 == 0) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mix_slot3_kernel<PW, 128, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mix_slot_lds(PW, 128));
+        hipLaunchKernelGGL((mix_slot3_kernel<PW, 128, 2>), dim3((T + 127) / 128, nb), dim3(256), mix_slot_lds(PW, 128), c->st, (const double*)lw.H, (long long)lw.sH, c->ld, D, sD, ldd,
+                           c->Gbin, sW, T, ract, c->eps, c->vsm, c->ident, c->trial_of_slot, c->d_roff, ctile, Ts);
+        return;
+      }
       if (c->mix_slot >= 2 && p == PW && ract % 4 == 0) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mix_slot2_kernel<PW, 256, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mix_slot_lds(PW, 256));
         hipLaunchKernelGGL((mix_slot2_kernel<PW, 256, 2>), dim3((T + 255) / 256, nb), dim3(256), mix_slot_lds(PW, 256), c->st, (const double*)lw.H, (long long)lw.sH, c->ld, D, sD, ldd,
@@ -160,6 +185,7 @@ static int accumulate_split(pgpfa_ctx* c, const CholWS& lw, int nb, int ract, in
                          c->Gbin, sW, T, p, ract, c->eps, c->vsm, c->ident, c->trial_of_slot, c->d_roff, ctile, Ts);
   });
   prof_end(c);
+  }
   // 2. the full-width term on the FP16 matrix cores: partial sums per (latent, group of slots) into c->ppart
   const int sps = std::max(1, (nb + PACC_SPLITS - 1) / PACC_SPLITS);
   const int ngroups = (nb + sps - 1) / sps;
@@ -389,22 +415,12 @@ int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool accumul
     hipLaunchKernelGGL(fill_slabs_kernel, dim3((unsigned)(((size_t)rpad * rpad + 1023) / 1024), nb), dim3(256), 0, c->st, lw.Mt, lw.sM,
                        (size_t)rpad * rpad, 0.0);
   CHK(inverse_t(c, lw, c->ident, nb));
-  // c. Yt = F Mts  (n x rpad, ld = c->ld) into the factor slab (the factor itself is dead now)
-  // (column tiles left of roff[k] skipped under skip_zero_cols, see above)
-  for (int k = 0; k < p; ++k) {
-    const int c0 = skip_zero_cols ? (c->roff[k] / ctile) * ctile : 0;
-    if (c0 >= ract) continue;
-    GemmP g{};
-    g.A = c->Flr + (size_t)k * Tp * Tp; g.sA = 0; g.lda = Tp;
-    g.B = lw.Mt + c->roff[k] + (size_t)c0 * rpad; g.sB = lw.sM; g.ldb = rpad;     // rows roff[k].. of Mts, K x N column-major
-    g.C = lw.H + (size_t)k * Ts + (size_t)c0 * c->ld; g.sC = lw.sH; g.ldc = c->ld;
-    g.M = T; g.N = ract - c0; g.K = c->rk[k]; g.alpha = 1.0; g.beta = 0.0;
-    g.slots = c->ident; g.nbatch = nb; g.mode = GEMM_FULL; g.kflags = 0;
-    CHK(gemm(c, true, g));
-  }
   if (p > WIDE_MAX) return fail("low-rank covariance engine supports up to %d latents (p=%d)", WIDE_MAX, p);
-  bool split = false;
-  if (split_candidate || c->measure_mix) {
+  // the split form's verdict: the relative size of the mixing correction, measured when the chunk's blocks were formed
+  bool split = false, decided = false;
+  auto decide_split = [&]() -> int {
+    decided = true;
+    if (!(split_candidate || c->measure_mix)) return 0;
     unsigned hw[4] = {0u, 0u, 0u, 0u};
     CHK(dl_enqueue(c, hw, norm_bits, 4 * sizeof(unsigned)));
     CHK(dl_flush(c));
@@ -417,10 +433,33 @@ int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool accumul
     c->info["last_eps_wt_rms"] = std::max(c->info["last_eps_wt_rms"], rms);
     // (the precision of the split form follows the root mean square of the correction; the maximum only has to stay a contraction)
     split = split_candidate && std::isfinite(hv) && std::isfinite(rms) && rms <= c->split_max_norm && (double)hv <= 0.9;
+    return 0;
+  };
+  // c. Yt = F Mts  (n x rpad, ld = c->ld) into the factor slab (the factor itself is dead now)
+  // (column tiles left of roff[k] skipped under skip_zero_cols, see above)
+  // Under the split form Yt has one consumer, the mixing pass: up to 10 latents the two run as one kernel (ytmix.h) and Yt is never written.  That
+  // needs the verdict before the product is queued instead of behind it (the host then waits for the factorisation: one launch gap per chunk).
+  const bool fuse_candidate = split_candidate && c->yt_mix && c->mfma && (p <= 6 || p == 8 || p == 10) && ract == c->rtot;   // (the widths dispatch_pw instantiates exactly)
+  if (fuse_candidate) CHK(decide_split());
+  const bool fused = fuse_candidate && split;
+  c->info["last_yt_mix_fused"] = fused ? 1.0 : 0.0;
+  if (!fused) {
+    for (int k = 0; k < p; ++k) {
+      const int c0 = skip_zero_cols ? (c->roff[k] / ctile) * ctile : 0;
+      if (c0 >= ract) continue;
+      GemmP g{};
+      g.A = c->Flr + (size_t)k * Tp * Tp; g.sA = 0; g.lda = Tp;
+      g.B = lw.Mt + c->roff[k] + (size_t)c0 * rpad; g.sB = lw.sM; g.ldb = rpad;     // rows roff[k].. of Mts, K x N column-major
+      g.C = lw.H + (size_t)k * Ts + (size_t)c0 * c->ld; g.sC = lw.sH; g.ldc = c->ld;
+      g.M = T; g.N = ract - c0; g.K = c->rk[k]; g.alpha = 1.0; g.beta = 0.0;
+      g.slots = c->ident; g.nbatch = nb; g.mode = GEMM_FULL; g.kflags = 0;
+      CHK(gemm(c, true, g));
+    }
   }
+  if (!decided) CHK(decide_split());
   c->info["last_split_cov"] = split ? 1.0 : 0.0;
   if (want_vsmgp && split) {
-    CHK(accumulate_split(c, lw, nb, ract, Ts, skip_zero_cols, ctile));
+    CHK(accumulate_split(c, lw, nb, ract, Ts, skip_zero_cols, ctile, fused));
   } else if (want_vsmgp) {
     // d+e. one pass over Yt: post_vsm[t] = eps G_t + sum_b (G_t y_b)(G_t y_b)^T, and Yt is mixed in place (y <- G_t y) so that
     //      rows (k,.) of the slab become Ymix_k, the GEMM operand of post_vsmGP_k = eps diag(G_t[k][k]) + Ymix_k Ymix_k^T

@@ -306,6 +306,143 @@ __global__ __launch_bounds__(NTH, 1) void mix_slot2_kernel(const double* __restr
     }
 }
 
+// A buffer descriptor over [ptr, ptr + bytes) built from wave-uniform values only (the halves of the pointer go through readfirstlane so that the
+// compiler keeps the four words in scalar registers): raw buffer loads and stores through it take "descriptor + scalar byte offset + 32-bit lane
+// byte offset" and need no 64-bit address per access in vector registers.
+template <typename T>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wave_uniform_rsrc(T* ptr, size_t bytes) {
+  const unsigned long long v = (unsigned long long)ptr;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  const unsigned n = __builtin_amdgcn_readfirstlane((unsigned)(bytes < 0xfffffff0ull ? bytes : 0xfffffff0ull));
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), (short)0, (int)n, 0x00020000);
+}
+__device__ __forceinline__ double rsrc_load_f64(__amdgpu_buffer_rsrc_t r, unsigned lane_bytes, unsigned uniform_bytes) {
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(r, (int)lane_bytes, (int)uniform_bytes, 0);
+  return __hiloint2double((int)w.y, (int)w.x);
+}
+__device__ __forceinline__ void rsrc_store_f32(__amdgpu_buffer_rsrc_t r, unsigned lane_bytes, unsigned uniform_bytes, float x) {
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), r, (int)lane_bytes, (int)uniform_bytes, 0);
+}
+
+// Round 5: the same pass with TWO waves per SIMD.  mix_slot2_kernel keeps one bin per thread and 256 bins per workgroup: its G_t image fills 112 KB of
+// LDS, one workgroup = one wave per SIMD, and with 35 % of the SIMD's time in vector instructions (PMC) and the rest waiting for the loads of the next
+// trip nothing overlaps.  Here a workgroup is NB = 128 bins x 2 column halves: both halves read the
+// SAME G_t column of their bin from LDS (56 KB: two workgroups per CU, eight waves), each keeps its own pair sums, and the halves meet once at the end
+// through the LDS image.  Thread (bin, h) walks the trips b0 = (2 i + h) U.  Same arithmetic per column as mix_slot2_kernel; post_vsm sums its columns in a different order (two partial sums per bin).
+// grid = (ceil(T / NB), nslots), block = 2 NB, dynamic LDS = mix_slot_lds(PW, NB); p == PW, ract a multiple of 2 U.
+template <int PW, int NB, int U>
+__global__ __launch_bounds__(2 * NB, 2) void mix_slot3_kernel(const double* __restrict__ Yt, long long sY, int ldy, float* __restrict__ D, long long sD, int ldd,
+                                                              const double* __restrict__ G, long long sG, int T, int ract, double eps,
+                                                              double* __restrict__ vsm, const int* __restrict__ slots,
+                                                              const int* __restrict__ trial_of_slot, const int* __restrict__ roff, int col_tile, int ts) {
+  constexpr int NPAIR = PW * (PW + 1) / 2, p = PW, pp = PW * PW;
+  extern __shared__ double mix_slot_g[];
+  const int slot = slots[blockIdx.y];
+  const int bin = threadIdx.x % NB;
+  const int half = __builtin_amdgcn_readfirstlane((int)threadIdx.x / NB);   // (wave-uniform: the trip index stays in scalar registers)
+  const int t = blockIdx.x * NB + bin;
+  const int tc = t < T ? t : T - 1;
+  const double* gsrc = G + (size_t)slot * sG + (size_t)tc * pp;
+  double* gs = mix_slot_g + bin;
+  double acc[NPAIR];
+#pragma unroll
+  for (int a = 0; a < PW; ++a)
+#pragma unroll
+    for (int c2 = 0; c2 <= a; ++c2) {
+      if (half == 0) gs[(a * (a + 1) / 2 + c2) * NB] = gsrc[a * p + c2];
+      acc[a * (a + 1) / 2 + c2] = 0.0;
+    }
+  __syncthreads();
+  int c0[PW], cmax = 0;
+#pragma unroll
+  for (int k = 0; k < PW; ++k) {
+    c0[k] = roff ? (roff[k] / col_tile) * col_tile : 0;
+    cmax = c0[k] > cmax ? c0[k] : cmax;
+  }
+  // (wave-uniform descriptors over the slot's two images; the lane's bin is the 32-bit offset of every access, the column a scalar one)
+  const __amdgpu_buffer_rsrc_t y = wave_uniform_rsrc(Yt + (size_t)slot * sY, (size_t)sY * sizeof(double));
+  const __amdgpu_buffer_rsrc_t d = wave_uniform_rsrc(D + (size_t)slot * sD, (size_t)sD * sizeof(float));
+  const unsigned voff = (unsigned)tc;
+  auto fetch = [&](int b0, double (&v)[U][PW]) {
+    const int bb = b0 < ract ? b0 : ract - U;                 // (past the end: the last trip again)
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int k = 0; k < PW; ++k) {
+        const int b = bb + u;
+        const int bc = b < c0[k] ? c0[k] : b;                  // (left of a latent's first column nothing was written: read that column, mask below)
+        v[u][k] = rsrc_load_f64(y, voff * 8u, (unsigned)(bc * ldy + k * ts) * 8u);
+      }
+  };
+  // Two sets of column registers, each requested a whole trip ahead: a set's columns are dead once D is stored, its next loads go out there and the
+  // pair sums (2 x 55 products) and the whole trip of the other set run under them.  Four waves of a workgroup x two workgroups keep 2 x 20 loads of
+  // 512 B each in flight per wave.
+  auto trip = [&](int b0, double (&v)[U][PW], int bnext) {
+    double m[U][PW];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int k = 0; k < PW; ++k) {
+        v[u][k] = (b0 < cmax && b0 + u < c0[k]) ? 0.0 : v[u][k];
+        m[u][k] = 0.0;
+      }
+#pragma unroll
+    for (int a = 0; a < PW; ++a)
+#pragma unroll
+      for (int c2 = 0; c2 <= a; ++c2) {
+        const double gg = gs[(a * (a + 1) / 2 + c2) * NB];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          m[u][a] += gg * v[u][c2];
+          if (c2 != a) m[u][c2] += gg * v[u][a];
+        }
+      }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int k = 0; k < PW; ++k) rsrc_store_f32(d, voff * 4u, (unsigned)((b0 + u) * ldd + k * ts) * 4u, (float)(v[u][k] - m[u][k]));
+    asm volatile("" ::: "memory");                      // (the LDS reads of G_t stay inside the trip)
+    if (bnext < ract) fetch(bnext, v);
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int a = 0; a < PW; ++a)
+#pragma unroll
+        for (int c2 = 0; c2 <= a; ++c2) acc[a * (a + 1) / 2 + c2] += m[u][a] * m[u][c2];
+  };
+  double vA[U][PW], vB[U][PW];
+  const int first = half * U;
+  if (first < ract) fetch(first, vA);
+  if (first + 2 * U < ract) fetch(first + 2 * U, vB);
+  for (int b0 = first; b0 < ract; b0 += 4 * U) {
+    trip(b0, vA, b0 + 4 * U);
+    if (b0 + 2 * U < ract) trip(b0 + 2 * U, vB, b0 + 6 * U);
+  }
+  // the halves meet: half 0 turns its sums into eps G_t + sums while the image still holds G_t, half 1 then hands its sums over through the image
+  __syncthreads();
+  if (half == 0) {
+#pragma unroll
+    for (int i = 0; i < NPAIR; ++i) acc[i] += eps * gs[i * NB];
+  }
+  __syncthreads();
+  if (half == 1) {
+#pragma unroll
+    for (int i = 0; i < NPAIR; ++i) gs[i * NB] = acc[i];
+  }
+  __syncthreads();
+  if (half != 0 || t >= T) return;
+  double* vdst = vsm + ((size_t)trial_of_slot[slot] * T + t) * pp;
+#pragma unroll
+  for (int a = 0; a < PW; ++a)
+#pragma unroll
+    for (int c2 = 0; c2 <= a; ++c2) {
+      const double val = acc[a * (a + 1) / 2 + c2] + gs[(a * (a + 1) / 2 + c2) * NB];
+      vdst[a * p + c2] = val;
+      vdst[c2 * p + a] = val;
+    }
+}
+
 // part[(k * ngroups + g)][T x T] (column-major, ld = T, lower 64 x 64 wave tiles) = sum over the slots of group g, over columns b < ract,
 // of D_k[:, b] D_k[:, b]^T, with D_k[t, b] = D[slot][(k ts + t) + b ldd] (single precision), evaluated on the FP16 matrix cores as
 // described at the top of this file.  Group g holds slots [g sps, min((g + 1) sps, nslots)).

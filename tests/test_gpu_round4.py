@@ -228,19 +228,23 @@ def test_dual_variational_through_the_fixed_point_vs_reference(funs_mod):
 # ---------------------------------------------------------------------------------------------------------------
 # copies as kernels / the runtime's copies; the two mixing passes
 # ---------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('option', [('copy_kernels', 0), ('mix_slot', 0), ('mix_slot', 1)])
+@pytest.mark.parametrize('option', [('copy_kernels', 0), ('mix_slot', 0), ('mix_slot', 1), ('mix_slot', 2), ('mix_slot', 3)])
 def test_alternative_paths_give_the_same_numbers(c1, option):
     """The small copies through the runtime (`copy_kernels = 0`: hipMemcpyAsync + hipStreamSynchronize instead of kernels through mapped staging and
-    a sequence number) and the 64-bin mixing pass of the split accumulation (`mix_slot = 0`) against the defaults on the same E-step + M-step
-    statistics: copies move bytes - bit-identical; the two mixing passes add the same products in another order - 1e-13."""
+    a sequence number) and the stand-alone mixing passes of the split accumulation (`yt_mix = 0`: Yt formed by the batched product, then `mix_slot` = 0: 64-bin
+    pass, 1 / 2: a thread per bin, 3: two column halves per bin) against the defaults (product and mixing in one kernel) on the same E-step + M-step
+    statistics: copies move bytes - bit-identical; the mixing passes add the same products in another order - 1e-13."""
     from funs import _hip
     out = []
-    for value in (1, option[1]):
+    for variant in (False, True):
         ctx = _hip.Context(30, 3, 100, 20, c1['binSize'])
         try:
             ctx.upload_counts(c1['Y'])
             ctx.set_option('cov_mode', 2)
-            ctx.set_option(option[0], value)
+            if variant:
+                if option[0] == 'mix_slot':
+                    ctx.set_option('yt_mix', 0)
+                ctx.set_option(option[0], option[1])
             ctx.set_params(c1['init_C'], c1['init_d'], c1['init_tau'])
             obj, _, status = ctx.estep_laplace()
             assert np.all(status == 0) and ctx.info('last_split_cov') == 1.0

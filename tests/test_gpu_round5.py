@@ -239,3 +239,52 @@ def test_auto_plan_picks_the_faster_covariance_engine(tau_ms, expect):
     assert out['auto'][0] <= 1.25 * min(out['dense'][0], out['lowrank'][0])
     for name in ('dense', 'lowrank'):
         assert np.max(np.abs(out[name][2] - out['auto'][2])) <= 1e-8 and rel(out[name][3], out['auto'][3]) <= 1e-8
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Yt = F L^-T and the mixing pass as one kernel
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('dims', [(40, 4, 130, 12, 0.05, 0.3), (200, 10, 500, 16, 0.02, 0.12), (200, 10, 500, 16, 0.1, 0.5), (60, 8, 333, 8, 0.01, 0.05),
+                                  (60, 6, 333, 8, 0.1, 0.6), (50, 7, 200, 8, 0.05, 0.2)])
+def test_product_and_mixing_in_one_kernel_match_the_two_passes(dims):
+    """`yt_mix = 1` (default): under the split covariance form the tiles of Yt = F L^-T of all latents are formed on the FP64 matrix cores, mixed against G_t in
+    registers and only the correction D and post_vsm are written (csrc/ytmix.h) - against `yt_mix = 0`, the batched product followed by the mixing
+    pass.  Same products, sums over K and over the columns in another order: E-step objective identical (the covariance phase does not enter it),
+    post_vsm 1e-12, PautoSum 1e-10 of the largest entry (its FP16 term sees D rounded from values that differ in the last FP64 bits).  Shapes: bins not a
+    multiple of the 64-bin workgroup, rank totals above the 256-row panel chunk (two chunks per column block), unequal ranks per latent (timescales
+    spread 6 x), and 7 latents - a width the kernel is not instantiated for, which must take the two-pass route and say so."""
+    from funs import _hip
+    q, p, T, R, tau_lo, tau_hi = dims
+    import bench
+    true, Ys = bench.synth_shard(q, p, T, R, 12, 0)
+    Y = np.stack(Ys)
+    C, d = true['C'], true['d']
+    tau = np.linspace(tau_lo, tau_hi, p)
+    out = {}
+    for fused in (1, 0):
+        ctx = _hip.Context(q, p, T, R, 10.0)
+        try:
+            ctx.upload_counts(Y)
+            ctx.set_option('cov_mode', 2)
+            ctx.set_option('yt_mix', fused)
+            ctx.set_params(C, d, tau)
+            obj, _, status = ctx.estep_laplace()
+            assert np.all(status == 0) and ctx.info('last_split_cov') == 1.0 and ctx.info('plan_lowrank') == 1.0
+            ctx.mstep_precomp()
+            out[fused] = (obj, ctx.post_vsm().copy(), ctx.pautosum().copy(), ctx.info('lowrank_rtot'), ctx.info('last_yt_mix_fused'))
+        finally:
+            ctx.close()
+    b = out[0]
+    assert b[4] == 0.0
+    for fused in (1,):
+        a = out[fused]
+        print(f'\nfused product + mixing (yt_mix = {fused}) at {dims}: rank total {a[3]:.0f}, kernel {a[4]:.0f}, post_vsm '
+              f'{np.max(np.abs(a[1] - b[1])) / np.max(np.abs(b[1])):.2e}, PautoSum {np.max(np.abs(a[2] - b[2])) / np.max(np.abs(b[2])):.2e}')
+        # which route ran: 1 = one kernel, 0 = product and mixing pass apart
+        want = 0.0 if p not in (1, 2, 3, 4, 5, 6, 8, 10) else float(fused)
+        assert a[4] == want
+        assert a[0] == b[0]
+        assert np.max(np.abs(a[1] - b[1])) <= 1e-12 * np.max(np.abs(b[1]))
+        assert np.max(np.abs(a[2] - b[2])) <= 1e-10 * np.max(np.abs(b[2]))
+    if (q, p) == (200, 10):
+        assert b[3] > 256
