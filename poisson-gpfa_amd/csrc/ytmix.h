@@ -126,40 +126,61 @@ __global__ __launch_bounds__(YTM_THREADS, 512 / YTM_THREADS) void yt_mix_kernel(
     v4d acc[PW];
 #pragma unroll
     for (int k = 0; k < PW; ++k) acc[k] = v4d{0.0, 0.0, 0.0, 0.0};
-    // fragments of F for the 16-row group about to be multiplied, requested one group ahead - across latents and panel chunks: the rows of the
-    // block's panel are walked in order, so the group after the last one of latent k is the first one of latent k + 1.  (Two groups ahead measured
-    // the same: at 64 cycles per v_mfma_f64_16x16x4 the products run at the matrix cores' FP64 rate already.)
-    double f0 = 0.0, f1 = 0.0, f2 = 0.0, f3 = 0.0;
-    bool have = false;
+    // The rows of the block's panel are walked in groups of 16, latent after latent.  Two fragment sets of F (four K steps for the wave's bins each):
+    // x holds the group about to be multiplied, y the one behind it; a set is requested again - for the group two ahead, whatever latent that row
+    // belongs to - as soon as its products are issued, so a fragment has two groups of matrix-core time (2 x 256 cycles, and the other wave's) to
+    // arrive from L2.  The loop body is a PAIR of groups so that no register is copied while its load is in flight; a latent with an odd number
+    // of groups ends with one copy of the older set.  (One group ahead with a copy per group: the copy waited for the load just issued.)
+    auto frow_of = [&](int row) {                             // row of F (all latents as one table of p * Tp rows) of panel row `row`
+      int o = 0;
+#pragma unroll
+      for (int j = 1; j < PW; ++j) o = row >= ro[j] ? j * a.Tp - ro[j] : o;
+      return o + row;
+    };
+    auto fetch4 = [&](int row, double& x0, double& x1, double& x2, double& x3) {
+      // (unconditional: past the block's last group the last one is read again - behind a branch the compiler stops counting the loads in flight
+      //  and waits for all of them at the head of the loop)
+      const int fr0 = frow_of((row < nr && !(a.dbg & 1)) ? row : nr - 16);
+      x0 = rsrc_load_f64(fr, flane, (unsigned)(fr0 * a.Tp) * 8u); x1 = rsrc_load_f64(fr, flane, (unsigned)((fr0 + 4) * a.Tp) * 8u);
+      x2 = rsrc_load_f64(fr, flane, (unsigned)((fr0 + 8) * a.Tp) * 8u); x3 = rsrc_load_f64(fr, flane, (unsigned)((fr0 + 12) * a.Tp) * 8u);
+    };
+    double x0 = 0.0, x1 = 0.0, x2 = 0.0, x3 = 0.0, y0 = 0.0, y1 = 0.0, y2 = 0.0, y3 = 0.0;
+    if (!(a.dbg & 2)) {
+      const int fr0 = frow_of(0), fr1 = frow_of(16 < nr ? 16 : 0);
+      x0 = rsrc_load_f64(fr, flane, (unsigned)(fr0 * a.Tp) * 8u); x1 = rsrc_load_f64(fr, flane, (unsigned)((fr0 + 4) * a.Tp) * 8u);
+      x2 = rsrc_load_f64(fr, flane, (unsigned)((fr0 + 8) * a.Tp) * 8u); x3 = rsrc_load_f64(fr, flane, (unsigned)((fr0 + 12) * a.Tp) * 8u);
+      y0 = rsrc_load_f64(fr, flane, (unsigned)(fr1 * a.Tp) * 8u); y1 = rsrc_load_f64(fr, flane, (unsigned)((fr1 + 4) * a.Tp) * 8u);
+      y2 = rsrc_load_f64(fr, flane, (unsigned)((fr1 + 8) * a.Tp) * 8u); y3 = rsrc_load_f64(fr, flane, (unsigned)((fr1 + 12) * a.Tp) * 8u);
+    }
     for (int kc0 = 0; kc0 < nr; kc0 += YTM_KC) {
       const int kc1 = kc0 + YTM_KC < nr ? kc0 + YTM_KC : nr;
-      const double* arow = As + (buf * 16 + l15) * YTM_AS + l4;
+      const double* arow = As + (buf * 16 + l15) * YTM_AS + l4 - kc0;
       if (!(a.dbg & 2))
 #pragma unroll
       for (int k = 0; k < PW; ++k) {
         const int kb = ro[k] > kc0 ? ro[k] : kc0, ke = ro[k + 1] < kc1 ? ro[k + 1] : kc1;
-        if (kb < ke) {
-          int frow = k * a.Tp + (kb - ro[k]);                 // (rows of F as one table of p * Tp rows: latent k's row j is row k * Tp + j)
-          const double* ar = arow + (kb - kc0);
-          if (!have) {
-            f0 = rsrc_load_f64(fr, flane, (unsigned)(frow * a.Tp) * 8u); f1 = rsrc_load_f64(fr, flane, (unsigned)((frow + 4) * a.Tp) * 8u);
-            f2 = rsrc_load_f64(fr, flane, (unsigned)((frow + 8) * a.Tp) * 8u); f3 = rsrc_load_f64(fr, flane, (unsigned)((frow + 12) * a.Tp) * 8u);
-            have = true;
-          }
-          for (int i = kb; i < ke; i += 16) {
-            const int fn = (i + 16 >= nr || (a.dbg & 1)) ? frow : (i + 16 < ro[k + 1] ? frow + 16 : (k + 1) * a.Tp);
-            double n0 = f0, n1 = f1, n2 = f2, n3 = f3;
-            if (!(a.dbg & 1)) {
-              n0 = rsrc_load_f64(fr, flane, (unsigned)(fn * a.Tp) * 8u); n1 = rsrc_load_f64(fr, flane, (unsigned)((fn + 4) * a.Tp) * 8u);
-              n2 = rsrc_load_f64(fr, flane, (unsigned)((fn + 8) * a.Tp) * 8u); n3 = rsrc_load_f64(fr, flane, (unsigned)((fn + 12) * a.Tp) * 8u);
-            }
-            acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[0], f0, acc[k], 0, 0, 0);
-            acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[4], f1, acc[k], 0, 0, 0);
-            acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[8], f2, acc[k], 0, 0, 0);
-            acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[12], f3, acc[k], 0, 0, 0);
-            f0 = n0; f1 = n1; f2 = n2; f3 = n3;
-            frow = fn; ar += 16;
-          }
+        int i = kb;
+        for (; i + 32 <= ke; i += 32) {
+          const double* ar = arow + i;
+          acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[0], x0, acc[k], 0, 0, 0);
+          acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[4], x1, acc[k], 0, 0, 0);
+          acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[8], x2, acc[k], 0, 0, 0);
+          acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[12], x3, acc[k], 0, 0, 0);
+          fetch4(i + 32, x0, x1, x2, x3);
+          acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[16], y0, acc[k], 0, 0, 0);
+          acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[20], y1, acc[k], 0, 0, 0);
+          acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[24], y2, acc[k], 0, 0, 0);
+          acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[28], y3, acc[k], 0, 0, 0);
+          fetch4(i + 48, y0, y1, y2, y3);
+        }
+        if (i < ke) {
+          const double* ar = arow + i;
+          acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[0], x0, acc[k], 0, 0, 0);
+          acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[4], x1, acc[k], 0, 0, 0);
+          acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[8], x2, acc[k], 0, 0, 0);
+          acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[12], x3, acc[k], 0, 0, 0);
+          x0 = y0; x1 = y1; x2 = y2; x3 = y3;
+          fetch4(i + 32, y0, y1, y2, y3);
         }
       }
       if (kc1 < nr) {                                         // this block's next chunk (nothing to hide it under)
