@@ -141,11 +141,10 @@ static int accumulate_split(pgpfa_ctx* c, const CholWS& lw, int nb, int ract, in
     dispatch_pw(p, [&](auto pw) {
       constexpr int PW = decltype(pw)::value;
       if constexpr (PW <= 10) {
-        if (p != PW) return;
         YtMixArgs a{};
         a.F = c->Flr; a.Tp = Tp; a.Mts = lw.Mt; a.sM = (long long)lw.sM; a.rpad = rpad;
         a.D = D; a.sD = sD; a.ldd = ldd; a.G = c->Gbin; a.sG = sW;
-        a.T = T; a.ract = ract; a.nbx = (T + YTM_BINS - 1) / YTM_BINS; a.nslots = nb; a.eps = c->eps;
+        a.T = T; a.p = p; a.ract = ract; a.nbx = (T + YTM_BINS - 1) / YTM_BINS; a.nslots = nb; a.eps = c->eps;
         a.vsm = c->vsm; a.slots = c->ident; a.trial_of_slot = c->trial_of_slot; a.roff = c->d_roff; a.ts = Ts; a.dbg = c->yt_mix_dbg;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&yt_mix_kernel<PW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ytmix_lds(PW));
         hipLaunchKernelGGL(yt_mix_kernel<PW>, dim3((unsigned)(a.nbx * nb)), dim3(YTM_THREADS), ytmix_lds(PW), c->st, a);
@@ -439,7 +438,7 @@ int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool accumul
   // (column tiles left of roff[k] skipped under skip_zero_cols, see above)
   // Under the split form Yt has one consumer, the mixing pass: up to 10 latents the two run as one kernel (ytmix.h) and Yt is never written.  That
   // needs the verdict before the product is queued instead of behind it (the host then waits for the factorisation: one launch gap per chunk).
-  const bool fuse_candidate = split_candidate && c->yt_mix && c->mfma && (p <= 6 || p == 8 || p == 10) && ract == c->rtot;   // (the widths dispatch_pw instantiates exactly)
+  const bool fuse_candidate = split_candidate && c->yt_mix && c->mfma && p <= 10 && ract == c->rtot;
   if (fuse_candidate) CHK(decide_split());
   const bool fused = fuse_candidate && split;
   c->info["last_yt_mix_fused"] = fused ? 1.0 : 0.0;

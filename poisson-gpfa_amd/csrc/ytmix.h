@@ -14,7 +14,8 @@
 //
 // Same arithmetic as gemm_mfma_kernel_t + mix_slot2_kernel up to the order of the sums over K and over the columns.
 // grid = ceil(T / YTM_BINS) * nslots workgroups (1-D, remapped so that the workgroups of a slot share an XCD and its L2), block = YTM_THREADS,
-// dynamic LDS = ytmix_lds(PW); p == PW <= 10, ranks and offsets multiples of 16 (they are: build_lowrank), ract = roff[p].
+// dynamic LDS = ytmix_lds(PW); p <= PW <= 10 (the widths dispatch_pw instantiates), ranks and offsets multiples of 16 (they are: build_lowrank),
+// ract = roff[p].
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -35,7 +36,7 @@ struct YtMixArgs {
   const double* Mts; long long sM; int rpad; // L^-T per slot (upper triangular, column-major, ld = rpad)
   float* D; long long sD; int ldd;           // correction per slot: D[b * ldd + k * ts + t]
   const double* G; long long sG;             // per-bin blocks (I + eps W)^-1 per slot: [T][p x p]
-  int T, ract, nbx, nslots; double eps;
+  int T, p, ract, nbx, nslots; double eps;     // p <= PW latents (7 and 9 run the 8- and 10-wide instantiations with empty latents behind)
   double* vsm;                               // post_vsm[(trial * T + t)][p x p]
   const int* slots; const int* trial_of_slot;
   const int* roff;                           // [p + 1] rank offsets
@@ -47,7 +48,8 @@ template <int PW>
 __global__ __launch_bounds__(YTM_THREADS, 512 / YTM_THREADS) void yt_mix_kernel(YtMixArgs a) {
   typedef double v4d __attribute__((ext_vector_type(4)));
   typedef double v2d __attribute__((ext_vector_type(2)));
-  constexpr int NPAIR = PW * (PW + 1) / 2, pp = PW * PW;
+  constexpr int NPAIR = PW * (PW + 1) / 2;
+  const int p = a.p, pp = p * p;
   extern __shared__ double ytm_lds[];
   double* Gs = ytm_lds;                      // [NPAIR][YTM_BINS]
   double* As = ytm_lds + NPAIR * YTM_BINS;   // [2][16][YTM_AS]
@@ -71,18 +73,18 @@ __global__ __launch_bounds__(YTM_THREADS, 512 / YTM_THREADS) void yt_mix_kernel(
       for (int lo = 0; lo <= hi; ++lo) {
         constexpr int dummy = 0; (void)dummy;
         const int idx = hi * (hi + 1) / 2 + lo;
-        if ((idx & 3) == part) Gs[idx * YTM_BINS + bin] = gsrc[hi * PW + lo];
+        if ((idx & 3) == part) Gs[idx * YTM_BINS + bin] = hi < p ? gsrc[hi * p + lo] : 0.0;
       }
   }
   int ro[PW + 1];
 #pragma unroll
-  for (int k = 0; k <= PW; ++k) ro[k] = a.roff[k];
+  for (int k = 0; k <= PW; ++k) ro[k] = a.roff[k < p ? k : p];        // (latents p .. PW - 1: no rows)
   const int t = t0 + wave * 16 + l15;
   const int tc = t < T ? t : T - 1;
   const double* gl = Gs + wave * 16 + l15;
   const double* Ms = a.Mts + (size_t)slot * a.sM;
   const __amdgpu_buffer_rsrc_t d = wave_uniform_rsrc(a.D + (size_t)slot * a.sD, (size_t)a.sD * sizeof(float));
-  const __amdgpu_buffer_rsrc_t fr = wave_uniform_rsrc(a.F, (size_t)PW * a.Tp * a.Tp * sizeof(double));
+  const __amdgpu_buffer_rsrc_t fr = wave_uniform_rsrc(a.F, (size_t)p * a.Tp * a.Tp * sizeof(double));
   const unsigned flane = ((unsigned)l4 * (unsigned)a.Tp + (unsigned)tc) * 8u;
   const unsigned dlane = ((unsigned)l4 * (unsigned)a.ldd + (unsigned)tc) * 4u;
   double sums[NPAIR];
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(YTM_THREADS, 512 / YTM_THREADS) void yt_mix_kernel(
       if (t < T && !(a.dbg & 8)) {
 #pragma unroll
         for (int k = 0; k < PW; ++k)
-          rsrc_store_f32(d, dlane, (unsigned)((b0 + 4 * r) * a.ldd + k * a.ts) * 4u, (float)(acc[k][r] - m[k]));
+          if (k < p) rsrc_store_f32(d, dlane, (unsigned)((b0 + 4 * r) * a.ldd + k * a.ts) * 4u, (float)(acc[k][r] - m[k]));
       }
 #pragma unroll
       for (int hi = 0; hi < PW; ++hi)
@@ -234,9 +236,10 @@ __global__ __launch_bounds__(YTM_THREADS, 512 / YTM_THREADS) void yt_mix_kernel(
   for (int hi = 0; hi < PW; ++hi)
 #pragma unroll
     for (int lo = 0; lo <= hi; ++lo) {
+      if (hi >= p) continue;
       const double val = a.eps * gl[(hi * (hi + 1) / 2 + lo) * YTM_BINS] + sums[hi * (hi + 1) / 2 + lo];
-      vdst[hi * PW + lo] = val;
-      vdst[lo * PW + hi] = val;
+      vdst[hi * p + lo] = val;
+      vdst[lo * p + hi] = val;
     }
 }
 
