@@ -14,6 +14,16 @@ void launch_post_vsm(pgpfa_ctx* c, const TIN* Mt, long long sM, int ncol, int ns
   if (ts <= 0) ts = T;                                       // row stride between latents in the panel
   if (p > 10 && c->vsm_mfma) {
     const int CB = post_vsm_mfma_cb(p, sizeof(TIN) == 4);
+    if (p <= 20 && c->vsm_b4) {                              // four latents x four bins per 4 x 4 x 4 block product
+      const size_t lds4 = (size_t)CB * post_vsm_b4_cs(p) * sizeof(TIN);
+      auto go = [&](auto nbk) {
+        constexpr int NBK = decltype(nbk)::value;
+        hipLaunchKernelGGL((post_vsm_b4_kernel<NBK, TIN>), dim3((T + 31) / 32, ns), dim3(512), lds4, c->st, Mt, sM, c->ld, ncol, T, p, c->vsm, c->ident,
+                           c->trial_of_slot, full_range, CB, roff, (int)GBN, ts);
+      };
+      if (p <= 12) go(std::integral_constant<int, 3>{}); else if (p <= 16) go(std::integral_constant<int, 4>{}); else go(std::integral_constant<int, 5>{});
+      return;
+    }
     const size_t lds = (size_t)CB * p * 33 * sizeof(TIN);
     if (p <= 16)
       hipLaunchKernelGGL((post_vsm_mfma_kernel<1, TIN>), dim3((T + 31) / 32, ns), dim3(512), lds, c->st, Mt, sM, c->ld, ncol, T, p, c->vsm, c->ident,

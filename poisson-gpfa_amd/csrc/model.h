@@ -790,6 +790,114 @@ __global__ __launch_bounds__(512) void post_vsm_mfma_kernel(const TIN* __restric
   }
 }
 
+// The same Gram matrices on v_mfma_f64_4x4x4_4b for 10 < p <= 20 (round 5).  The 16 x 16 x 4 shape pads 20 latents to two 16-row tiles: three
+// instructions of 68 cycles per bin and four columns, 27 % of whose products are wanted.  The 4 x 4 x 4 shape runs FOUR independent 4 x 4 x 4
+// products in 19 cycles (tools/probes/mfma_4x4x4_probe.hip): here the four blocks of an instruction are the wave's four BINS and the instruction
+// index runs over the lower pairs (I >= J) of NBK = ceil(p / 4) blocks of four latents - operand lane (k = lane >> 4, bin = (lane >> 2) & 3,
+// latent = 4 I + (lane & 3)), the A fragment of pair (I, J) is block I's register and the B fragment block J's: NBK LDS reads and
+// NBK (NBK + 1) / 2 instructions per four bins and four columns (5 and 15 x 19 = 285 cycles at 20 latents, against 12 x 68 = 816), result
+// lane (row = lane >> 4, bin, column = lane & 3).  A pair whose block I has no written column yet (rows of latent k vanish left of roff[k]) is
+// not issued.  Staging, chunking and launch shape are post_vsm_mfma_kernel's; the LDS image has latent stride 36 and column stride 36 p + 8
+// words so that the 64 lanes of a fragment read (4 columns x 4 latents x 4 bins) fall on 64 different words of the 32 x 2 banks.
+// dynamic LDS = CB * post_vsm_b4_cs(p) elements of the panel's type.
+__host__ __device__ inline int post_vsm_b4_cs(int p) { return 36 * p + 8; }
+template <int NBK, typename TIN>
+__global__ __launch_bounds__(512) void post_vsm_b4_kernel(const TIN* __restrict__ Mt, long long sM, int ld, int ncol, int T, int p,
+                                                          double* __restrict__ vsm, const int* __restrict__ slots,
+                                                          const int* __restrict__ trial_of_slot, int full_range, int CB,
+                                                          const int* __restrict__ roff, int col_tile, int ts) {
+  constexpr int LT = 36, MAXPF = sizeof(TIN) == 4 ? 18 : 12, NPR = NBK * (NBK + 1) / 2;
+  extern __shared__ double sm_raw[];
+  TIN* sm = reinterpret_cast<TIN*>(sm_raw);
+  const int CS = post_vsm_b4_cs(p);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int slot = slots[blockIdx.y];
+  const int trial = trial_of_slot[slot];
+  const int t0 = blockIdx.x * 32;
+  const int nt = min(32, T - t0);
+  const TIN* M = Mt + (size_t)slot * sM + t0;
+  const int per_chunk = CB * p * 32;
+  const int tt = tid & 31;
+  const int ttc = tt < nt ? tt : nt - 1;
+  int map[MAXPF];
+#pragma unroll
+  for (int j = 0; j < MAXPF; ++j) {
+    const int e = tid + 512 * j;
+    const int row = min(e, per_chunk - 1) >> 5;               // b * p + k
+    const int b = row / p, k = row - b * p;
+    map[j] = (e < per_chunk) ? (b | (k << 8) | ((roff ? roff[k] / col_tile : 0) << 16)) : -1;
+  }
+  const size_t off_dummy = (size_t)(ncol - 1) * ld + (size_t)(p - 1) * ts;
+  TIN pf[MAXPF];
+  auto issue = [&](int i0) {
+#pragma unroll
+    for (int j = 0; j < MAXPF; ++j) {
+      const int mj = map[j] < 0 ? 0 : map[j];
+      const int col = i0 + (mj & 255), k = (mj >> 8) & 255, c0 = (mj >> 16) * col_tile;
+      const bool in = col < ncol && col >= c0;
+      pf[j] = M[in ? (size_t)col * ld + (size_t)k * ts + ttc : off_dummy];
+    }
+  };
+  auto commit = [&](int i0) {
+#pragma unroll
+    for (int j = 0; j < MAXPF; ++j) {
+      const int mj = map[j];
+      if (mj >= 0) {
+        const int b = mj & 255, k = (mj >> 8) & 255, col = i0 + b, c0 = (mj >> 16) * col_tile;
+        sm[b * CS + k * LT + tt] = (tt < nt && col < ncol && col >= c0) ? pf[j] : (TIN)0;
+      }
+    }
+  };
+  double acc[NPR];
+#pragma unroll
+  for (int a = 0; a < NPR; ++a) acc[a] = 0.0;
+  const int l4 = lane >> 4, blk = (lane >> 2) & 3, x4 = lane & 3;
+  // first chunk in which block I has a written column (uniform)
+  int cfirst[NBK];
+#pragma unroll
+  for (int I = 0; I < NBK; ++I) cfirst[I] = (roff && 4 * I < p) ? (roff[4 * I] / col_tile) * col_tile : 0;
+  const int istart = full_range ? 0 : (t0 / CB) * CB;         // triangular Mt: rows (., t0..) vanish left of column t0
+  if (istart < ncol) issue(istart);
+  for (int i0 = istart; i0 < ncol; i0 += CB) {
+    __syncthreads();
+    commit(i0);
+    __syncthreads();
+    if (i0 + CB < ncol) issue(i0 + CB);
+    for (int ks = 0; ks < CB; ks += 4) {
+      const TIN* base = sm + (size_t)(ks + l4) * CS + wave * 4 + blk;
+      double v[NBK];
+#pragma unroll
+      for (int I = 0; I < NBK; ++I) v[I] = (4 * I + x4 < p) ? (double)base[(4 * I + x4) * LT] : 0.0;
+      int pr = 0;
+#pragma unroll
+      for (int I = 0; I < NBK; ++I) {
+        const bool on = i0 + CB > cfirst[I];
+#pragma unroll
+        for (int J = 0; J <= I; ++J) {
+          if (on) acc[pr] = __builtin_amdgcn_mfma_f64_4x4x4f64(v[I], v[J], acc[pr], 0, 0, 0);
+          ++pr;
+        }
+      }
+    }
+  }
+  // lane (l4, blk, x4) of pair (I, J): entry (4 I + l4, 4 J + x4) of bin wave * 4 + blk
+  const int t = t0 + wave * 4 + blk;
+  if (t >= T) return;
+  double* out = vsm + ((size_t)trial * T + t) * p * p;
+  int pr = 0;
+#pragma unroll
+  for (int I = 0; I < NBK; ++I)
+#pragma unroll
+    for (int J = 0; J <= I; ++J) {
+      const int r = 4 * I + l4, cc = 4 * J + x4;
+      if (r < p && cc < p) {
+        out[r * p + cc] = acc[pr];
+        if (I != J) out[cc * p + r] = acc[pr];
+      }
+      ++pr;
+    }
+}
+
 // (T,T,p) reference layout of post_vsmGP (inference.py:164-167) from the device layout [p][T][T]
 inline __global__ void vsmgp_to_ref_kernel(const double* __restrict__ src, double* __restrict__ dst, int T, int p) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
