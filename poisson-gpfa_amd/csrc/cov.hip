@@ -15,13 +15,19 @@ void launch_post_vsm(pgpfa_ctx* c, const TIN* Mt, long long sM, int ncol, int ns
   if (p > 10 && c->vsm_mfma) {
     const int CB = post_vsm_mfma_cb(p, sizeof(TIN) == 4);
     if (p <= 20 && c->vsm_b4) {                              // four latents x four bins per 4 x 4 x 4 block product
-      const size_t lds4 = (size_t)CB * post_vsm_b4_cs(p) * sizeof(TIN);
-      auto go = [&](auto nbk) {
+      constexpr int VW = 16 / (int)sizeof(TIN);
+      const bool vec = c->vsm_b4 >= 2 && T % VW == 0 && ts % VW == 0 && c->ld % VW == 0 && sM % VW == 0 && (((size_t)Mt) & 15) == 0;
+      auto go = [&](auto nbk, auto vv) {
         constexpr int NBK = decltype(nbk)::value;
-        hipLaunchKernelGGL((post_vsm_b4_kernel<NBK, TIN>), dim3((T + 31) / 32, ns), dim3(512), lds4, c->st, Mt, sM, c->ld, ncol, T, p, c->vsm, c->ident,
-                           c->trial_of_slot, full_range, CB, roff, (int)GBN, ts);
+        constexpr bool VEC = decltype(vv)::value;
+        const size_t lds4 = (size_t)CB * post_vsm_b4_cs(p, VEC) * sizeof(TIN);
+        constexpr int BINS = VEC ? 64 : 32;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&post_vsm_b4_kernel<NBK, TIN, VEC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+        hipLaunchKernelGGL((post_vsm_b4_kernel<NBK, TIN, VEC>), dim3((T + BINS - 1) / BINS, ns), dim3(512), lds4, c->st, Mt, sM, c->ld, ncol, T, p, c->vsm,
+                           c->ident, c->trial_of_slot, full_range, CB, roff, (int)GBN, ts);
       };
-      if (p <= 12) go(std::integral_constant<int, 3>{}); else if (p <= 16) go(std::integral_constant<int, 4>{}); else go(std::integral_constant<int, 5>{});
+      auto gov = [&](auto nbk) { if (vec) go(nbk, std::true_type{}); else go(nbk, std::false_type{}); };
+      if (p <= 12) gov(std::integral_constant<int, 3>{}); else if (p <= 16) gov(std::integral_constant<int, 4>{}); else gov(std::integral_constant<int, 5>{});
       return;
     }
     const size_t lds = (size_t)CB * p * 33 * sizeof(TIN);

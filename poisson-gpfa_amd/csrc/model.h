@@ -799,43 +799,54 @@ __global__ __launch_bounds__(512) void post_vsm_mfma_kernel(const TIN* __restric
 // lane (row = lane >> 4, bin, column = lane & 3).  A pair whose block I has no written column yet (rows of latent k vanish left of roff[k]) is
 // not issued.  Staging, chunking and launch shape are post_vsm_mfma_kernel's; the LDS image has latent stride 36 and column stride 36 p + 8
 // words so that the 64 lanes of a fragment read (4 columns x 4 latents x 4 bins) fall on 64 different words of the 32 x 2 banks.
-// dynamic LDS = CB * post_vsm_b4_cs(p) elements of the panel's type.
-__host__ __device__ inline int post_vsm_b4_cs(int p) { return 36 * p + 8; }
-template <int NBK, typename TIN>
+// VEC: 64 bins per workgroup (two quads of bins per wave) staged with 16-byte loads - 256-byte runs of the panel instead of 128-byte ones (the
+// pass reads the whole panel once: 45 GB per pass at config 5, and ran at 1.3 TB/s on 128-byte runs); needs T, ts, ld and the slab stride
+// multiples of the vector width.
+// dynamic LDS = CB * post_vsm_b4_cs(p, VEC) elements of the panel's type.
+__host__ __device__ inline int post_vsm_b4_cs(int p, bool vec) { return (vec ? 68 : 36) * p + 8; }
+template <int NBK, typename TIN, bool VEC>
 __global__ __launch_bounds__(512) void post_vsm_b4_kernel(const TIN* __restrict__ Mt, long long sM, int ld, int ncol, int T, int p,
                                                           double* __restrict__ vsm, const int* __restrict__ slots,
                                                           const int* __restrict__ trial_of_slot, int full_range, int CB,
                                                           const int* __restrict__ roff, int col_tile, int ts) {
-  constexpr int LT = 36, MAXPF = sizeof(TIN) == 4 ? 18 : 12, NPR = NBK * (NBK + 1) / 2;
+  constexpr int BINS = VEC ? 64 : 32, NQ = BINS / 32, LT = VEC ? 68 : 36, NPR = NBK * (NBK + 1) / 2;
+  constexpr int VW = VEC ? 16 / (int)sizeof(TIN) : 1, UPR = BINS / VW;                     // elements per load, loads per (column, latent) row
+  constexpr int MAXPF = VEC ? (sizeof(TIN) == 4 ? 8 : 10) : (sizeof(TIN) == 4 ? 18 : 12);  // >= CB p UPR / 512
+  typedef TIN vec_t __attribute__((ext_vector_type(VW)));
   extern __shared__ double sm_raw[];
   TIN* sm = reinterpret_cast<TIN*>(sm_raw);
-  const int CS = post_vsm_b4_cs(p);
+  const int CS = post_vsm_b4_cs(p, VEC);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int slot = slots[blockIdx.y];
   const int trial = trial_of_slot[slot];
-  const int t0 = blockIdx.x * 32;
-  const int nt = min(32, T - t0);
+  const int t0 = blockIdx.x * BINS;
+  const int nt = min(BINS, T - t0);
   const TIN* M = Mt + (size_t)slot * sM + t0;
-  const int per_chunk = CB * p * 32;
-  const int tt = tid & 31;
-  const int ttc = tt < nt ? tt : nt - 1;
+  const int per_chunk = CB * p * UPR;
+  // staging map, the same for every chunk: load e = tid + 512 j -> (column b, latent k), its bins u0 .. u0 + VW - 1 (512 is a multiple of UPR: u0 is
+  // the thread's own), packed as b | k << 8 | first written column tile of latent k << 16 (-1: no load)
+  const int u0 = (tid % UPR) * VW;
+  const int uc = VEC ? u0 : (u0 < nt ? u0 : nt - 1);          // (scalar form: bins past T read the last one; vector form: a load is all in or all out)
+  const bool uin = u0 < nt;
   int map[MAXPF];
 #pragma unroll
   for (int j = 0; j < MAXPF; ++j) {
     const int e = tid + 512 * j;
-    const int row = min(e, per_chunk - 1) >> 5;               // b * p + k
+    const int row = min(e, per_chunk - 1) / UPR;              // b * p + k
     const int b = row / p, k = row - b * p;
     map[j] = (e < per_chunk) ? (b | (k << 8) | ((roff ? roff[k] / col_tile : 0) << 16)) : -1;
   }
-  const size_t off_dummy = (size_t)(ncol - 1) * ld + (size_t)(p - 1) * ts;
-  TIN pf[MAXPF];
+  // (a load outside the written part of the panel reads one fixed written location instead: the loads stay unconditional - issued back to
+  // back - and the unwritten columns cost no traffic)
+  const size_t off_dummy = VEC ? 0 : (size_t)(ncol - 1) * ld + (size_t)(p - 1) * ts;
+  vec_t pf[MAXPF];
   auto issue = [&](int i0) {
 #pragma unroll
     for (int j = 0; j < MAXPF; ++j) {
       const int mj = map[j] < 0 ? 0 : map[j];
       const int col = i0 + (mj & 255), k = (mj >> 8) & 255, c0 = (mj >> 16) * col_tile;
-      const bool in = col < ncol && col >= c0;
-      pf[j] = M[in ? (size_t)col * ld + (size_t)k * ts + ttc : off_dummy];
+      const bool in = col < ncol && col >= c0 && (!VEC || uin);
+      pf[j] = *reinterpret_cast<const vec_t*>(M + (in ? (size_t)col * ld + (size_t)k * ts + uc : off_dummy));
     }
   };
   auto commit = [&](int i0) {
@@ -844,15 +855,20 @@ __global__ __launch_bounds__(512) void post_vsm_b4_kernel(const TIN* __restrict_
       const int mj = map[j];
       if (mj >= 0) {
         const int b = mj & 255, k = (mj >> 8) & 255, col = i0 + b, c0 = (mj >> 16) * col_tile;
-        sm[b * CS + k * LT + tt] = (tt < nt && col < ncol && col >= c0) ? pf[j] : (TIN)0;
+        vec_t z;
+#pragma unroll
+        for (int x = 0; x < VW; ++x) z[x] = (TIN)0;
+        *reinterpret_cast<vec_t*>(sm + b * CS + k * LT + u0) = (uin && col < ncol && col >= c0) ? pf[j] : z;
       }
     }
   };
-  double acc[NPR];
+  double acc[NQ][NPR];
 #pragma unroll
-  for (int a = 0; a < NPR; ++a) acc[a] = 0.0;
+  for (int q = 0; q < NQ; ++q)
+#pragma unroll
+    for (int a = 0; a < NPR; ++a) acc[q][a] = 0.0;
   const int l4 = lane >> 4, blk = (lane >> 2) & 3, x4 = lane & 3;
-  // first chunk in which block I has a written column (uniform)
+  // first column in which block I has something written (uniform)
   int cfirst[NBK];
 #pragma unroll
   for (int I = 0; I < NBK; ++I) cfirst[I] = (roff && 4 * I < p) ? (roff[4 * I] / col_tile) * col_tile : 0;
@@ -864,38 +880,44 @@ __global__ __launch_bounds__(512) void post_vsm_b4_kernel(const TIN* __restrict_
     __syncthreads();
     if (i0 + CB < ncol) issue(i0 + CB);
     for (int ks = 0; ks < CB; ks += 4) {
-      const TIN* base = sm + (size_t)(ks + l4) * CS + wave * 4 + blk;
-      double v[NBK];
 #pragma unroll
-      for (int I = 0; I < NBK; ++I) v[I] = (4 * I + x4 < p) ? (double)base[(4 * I + x4) * LT] : 0.0;
-      int pr = 0;
+      for (int q = 0; q < NQ; ++q) {
+        const TIN* base = sm + (size_t)(ks + l4) * CS + q * 32 + wave * 4 + blk;
+        double v[NBK];
 #pragma unroll
-      for (int I = 0; I < NBK; ++I) {
-        const bool on = i0 + CB > cfirst[I];
+        for (int I = 0; I < NBK; ++I) v[I] = (4 * I + x4 < p) ? (double)base[(4 * I + x4) * LT] : 0.0;
+        int pr = 0;
 #pragma unroll
-        for (int J = 0; J <= I; ++J) {
-          if (on) acc[pr] = __builtin_amdgcn_mfma_f64_4x4x4f64(v[I], v[J], acc[pr], 0, 0, 0);
-          ++pr;
+        for (int I = 0; I < NBK; ++I) {
+          const bool on = i0 + CB > cfirst[I];
+#pragma unroll
+          for (int J = 0; J <= I; ++J) {
+            if (on) acc[q][pr] = __builtin_amdgcn_mfma_f64_4x4x4f64(v[I], v[J], acc[q][pr], 0, 0, 0);
+            ++pr;
+          }
         }
       }
     }
   }
-  // lane (l4, blk, x4) of pair (I, J): entry (4 I + l4, 4 J + x4) of bin wave * 4 + blk
-  const int t = t0 + wave * 4 + blk;
-  if (t >= T) return;
-  double* out = vsm + ((size_t)trial * T + t) * p * p;
-  int pr = 0;
+  // lane (l4, blk, x4) of pair (I, J): entry (4 I + l4, 4 J + x4) of bin q * 32 + wave * 4 + blk
 #pragma unroll
-  for (int I = 0; I < NBK; ++I)
+  for (int q = 0; q < NQ; ++q) {
+    const int t = t0 + q * 32 + wave * 4 + blk;
+    if (t >= T) continue;
+    double* out = vsm + ((size_t)trial * T + t) * p * p;
+    int pr = 0;
 #pragma unroll
-    for (int J = 0; J <= I; ++J) {
-      const int r = 4 * I + l4, cc = 4 * J + x4;
-      if (r < p && cc < p) {
-        out[r * p + cc] = acc[pr];
-        if (I != J) out[cc * p + r] = acc[pr];
+    for (int I = 0; I < NBK; ++I)
+#pragma unroll
+      for (int J = 0; J <= I; ++J) {
+        const int r = 4 * I + l4, cc = 4 * J + x4;
+        if (r < p && cc < p) {
+          out[r * p + cc] = acc[q][pr];
+          if (I != J) out[cc * p + r] = acc[q][pr];
+        }
+        ++pr;
       }
-      ++pr;
-    }
+  }
 }
 
 // (T,T,p) reference layout of post_vsmGP (inference.py:164-167) from the device layout [p][T][T]

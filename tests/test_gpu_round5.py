@@ -294,14 +294,15 @@ def test_product_and_mixing_in_one_kernel_match_the_two_passes(dims):
 # ---------------------------------------------------------------------------------------------------------------
 # post_vsm for 11..20 latents on the 4 x 4 x 4 block shape of the matrix cores
 # ---------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('dims', [(60, 12, 150, 6), (80, 14, 200, 6), (70, 16, 130, 5), (90, 17, 210, 6), (100, 20, 333, 8)])
+@pytest.mark.parametrize('dims', [(60, 12, 150, 6), (80, 14, 200, 6), (70, 16, 132, 5), (90, 17, 210, 6), (100, 20, 333, 8), (100, 20, 328, 8)])
 @pytest.mark.parametrize('f32', [0, 1])
 def test_block_form_of_the_covariance_blocks_matches_the_padded_tiles(dims, f32):
     """`vsm_b4 = 1` (default): post_vsm[t] for 11..20 latents as 4 x 4 x 4 block products - four bins per instruction, instructions over the lower pairs of
     four-latent blocks (model.h, post_vsm_b4_kernel) - against `vsm_b4 = 0`, the 16 x 16 x 4 tiles padded to 16 or 32 rows, through one variational
     fixed point (the blocks feed the variance offsets of every pass, so a wrong entry would move the optimum): dual objective 1e-12 rel, posterior
     means 1e-10, covariance blocks 1e-12 of the largest entry.  FP64 and mixed precision (single-precision panel); latent counts that fill the last
-    block (12, 16, 20) and that do not (14, 17); bins not a multiple of the 32-bin workgroup."""
+    block (12, 16, 20) and that do not (14, 17); `vsm_b4 = 2` (64 bins per workgroup, 16-byte loads) where the bin count is a multiple of the vector
+    width (150 and 210 are not in single precision: those shapes run the scalar form under either value); bins not a multiple of the workgroup."""
     from funs import _hip
     import bench
     q, p, T, R = dims
@@ -310,7 +311,7 @@ def test_block_form_of_the_covariance_blocks_matches_the_padded_tiles(dims, f32)
     tau = np.linspace(0.08, 0.4, p)
     idx = np.arange(R, dtype=np.int32)
     out = {}
-    for b4 in (1, 0):
+    for b4 in (2, 1, 0):
         ctx = _hip.Context(q, p, T, R, 10.0)
         try:
             ctx.upload_counts(Y)
@@ -325,10 +326,12 @@ def test_block_form_of_the_covariance_blocks_matches_the_padded_tiles(dims, f32)
             out[b4] = (fopt.copy(), ctx.post_mean(idx).copy(), ctx.post_vsm(idx).copy(), passes.copy(), status.copy())
         finally:
             ctx.close()
-    a, b = out[1], out[0]
-    print(f'\nblock form at {dims}, f32 {f32}: objective {np.max(np.abs(a[0] - b[0]) / np.abs(b[0])):.2e}, means {np.max(np.abs(a[1] - b[1])):.2e}, '
-          f'blocks {np.max(np.abs(a[2] - b[2])) / np.max(np.abs(b[2])):.2e}, passes {a[3].max()} / {b[3].max()}')
-    assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
-    assert np.max(np.abs(a[0] - b[0]) / np.abs(b[0])) <= 1e-12
-    assert np.max(np.abs(a[1] - b[1])) <= 1e-10
-    assert np.max(np.abs(a[2] - b[2])) <= 1e-12 * np.max(np.abs(b[2]))
+    b = out[0]
+    for b4 in (2, 1):
+        a = out[b4]
+        print(f'\nblock form (vsm_b4 = {b4}) at {dims}, f32 {f32}: objective {np.max(np.abs(a[0] - b[0]) / np.abs(b[0])):.2e}, means {np.max(np.abs(a[1] - b[1])):.2e}, '
+              f'blocks {np.max(np.abs(a[2] - b[2])) / np.max(np.abs(b[2])):.2e}, passes {a[3].max()} / {b[3].max()}')
+        assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+        assert np.max(np.abs(a[0] - b[0]) / np.abs(b[0])) <= 1e-12
+        assert np.max(np.abs(a[1] - b[1])) <= 1e-10
+        assert np.max(np.abs(a[2] - b[2])) <= 1e-12 * np.max(np.abs(b[2]))
