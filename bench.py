@@ -764,6 +764,8 @@ def main():
     elapsed = time.time() - t_begin
     gemm_ms, gemm_flops, gemm_launches = (sess.ctx.info('prof_gemm_' + k) for k in ('ms', 'flops', 'launches'))
     gemm_max_ms, gemm_max_flops = sess.ctx.info('prof_gemm_max_ms'), sess.ctx.info('prof_gemm_max_flops')
+    ytm_ms, ytm_flops, ytm_launches = (sess.ctx.info('prof_mix_' + k) for k in ('ms', 'flops', 'launches'))
+    ytm_fused = sess.ctx.info('last_yt_mix_fused') == 1.0
     sess.ctx.set_option('profile', 0)
 
     def drop_last():
@@ -854,6 +856,15 @@ def main():
                      'largest_launch': {'ms': gemm_max_ms, 'algorithmic_flops': gemm_max_flops,
                                         'achieved': gemm_max_flops / (gemm_max_ms * 1e-3) / 1e12 if gemm_max_ms > 0 else 0.0,
                                         'frac': gemm_max_flops / (gemm_max_ms * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS if gemm_max_ms > 0 else 0.0}},
+        # the largest single kernel of the step: Yt = F L^-T and its mixing in one launch per E-step (csrc/ytmix.h) - HIP events around it on
+        # the same steps as the GEMM events; flops = products over the triangular panels + the per-(bin, column) mixing (csrc/cov.hip);
+        # traffic: the committed PMC passes (profiles/rNN_pmc_hbm_traffic.json)
+        'roofline_covariance': None if not (ytm_fused and ytm_ms > 0) else {
+            'bound': 'mfma', 'kernel': 'yt_mix_kernel (FP64 16x16x4 MFMA products + FP64 vector mixing in registers; writes the FP32 correction D and post_vsm)',
+            'achieved': ytm_flops / (ytm_ms * 1e-3) / 1e12, 'peak': FP64_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': ytm_flops / (ytm_ms * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS, 'traffic': None,
+            'algorithmic_flops_per_launch': ytm_flops / max(ytm_launches, 1.0), 'launches': ytm_launches, 'avg_launch_ms': ytm_ms / max(ytm_launches, 1.0),
+            'kernel_share_of_step': ytm_ms / max(1e-9, float(np.sum([estep_ms[args.warmup + i] + mstep_ms[args.warmup + i] for i in event_steps])))},
         # the Newton solve (north star: >= 40 % of the HBM roofline): every inner PCG solve of the timed region between two HIP events,
         # against the bytes a perfect implementation of the same iteration would still move (17 n-vector passes + packed FP32 curvature per
         # slot-iteration, the operators once per step; csrc/estep.hip: newton_bytes).  BOTH byte models are printed so that the fraction cannot move

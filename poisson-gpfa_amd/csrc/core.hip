@@ -70,7 +70,7 @@ hipEvent_t prof_event(Prof& P) {
 }
 void prof_begin(pgpfa_ctx* c, int tag, double flops) {
   Prof& P = c->prof;
-  if (!P.on || (P.only_tag >= 0 && tag != P.only_tag)) return;
+  if (!P.on || (P.only_tag >= 0 && tag != P.only_tag && tag != TAG_MIX)) return;     // (the one mixing / product-and-mixing launch per E-step rides along)
   if (P.recs.size() >= 256 && (P.recs.size() & 63) == 0) prof_harvest(P, false);
   Prof::Rec r{tag, prof_event(P), prof_event(P), flops, std::string()};
   hipEventRecord(r.e0, c->st);

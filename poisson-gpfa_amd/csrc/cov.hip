@@ -152,8 +152,10 @@ static int accumulate_split(pgpfa_ctx* c, const CholWS& lw, int nb, int ract, in
   for (int k = 0; k < p; ++k) mix_cols += std::max(0, ract - (ctile > 0 ? (c->roff[k] / ctile) * ctile : 0));
   // (bytes: the columns of Yt that hold something read once in FP64; D - dense, the mixing couples the latents - written once in FP32)
   if (fused) {
-    // Yt was not formed: product and mixing in one kernel.  Bytes: D written once in FP32 (the panels of L^-T and F come from L2).
-    prof_begin(c, TAG_MIX, (double)nb * T * (double)p * ract * 4.0);
+    // Yt was not formed: product and mixing in one kernel.  Work recorded: its FLOPs - products 2 T (ract^2 / 2 + 8 ract) over the
+    // triangular panels in 16-column blocks, mixing 2 p^2 + p (p + 1) per (bin, column); info key "last_yt_mix_fused" tells the reader of
+    // prof_mix_flops that these are flops, not the bytes of the stand-alone pass.
+    prof_begin(c, TAG_MIX, (double)nb * T * ((double)ract * ract + 16.0 * ract + (double)ract * (2.0 * p * p + p * (p + 1.0))));
     dispatch_pw(p, [&](auto pw) {
       constexpr int PW = decltype(pw)::value;
       if constexpr (PW <= 10) {
