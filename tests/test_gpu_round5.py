@@ -244,14 +244,14 @@ def test_auto_plan_picks_the_faster_covariance_engine(tau_ms, expect):
 # ---------------------------------------------------------------------------------------------------------------
 # Yt = F L^-T and the mixing pass as one kernel
 # ---------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('dims', [(40, 4, 130, 12, 0.05, 0.3), (200, 10, 500, 16, 0.02, 0.12), (200, 10, 500, 16, 0.1, 0.5), (60, 8, 333, 8, 0.01, 0.05),
+@pytest.mark.parametrize('dims', [(20, 1, 40, 3, 0.1, 0.1), (30, 2, 70, 4, 0.05, 0.4), (25, 3, 16, 5, 0.03, 0.06), (40, 4, 130, 12, 0.05, 0.3), (200, 10, 500, 16, 0.02, 0.12), (200, 10, 500, 16, 0.1, 0.5), (60, 8, 333, 8, 0.01, 0.05),
                                   (60, 6, 333, 8, 0.1, 0.6), (50, 7, 200, 8, 0.05, 0.2), (80, 9, 150, 8, 0.05, 0.3), (60, 12, 120, 8, 0.05, 0.3)])
 def test_product_and_mixing_in_one_kernel_match_the_two_passes(dims):
     """`yt_mix = 1` (default): under the split covariance form the tiles of Yt = F L^-T of all latents are formed on the FP64 matrix cores, mixed against G_t in
     registers and only the correction D and post_vsm are written (csrc/ytmix.h) - against `yt_mix = 0`, the batched product followed by the mixing
     pass.  Same products, sums over K and over the columns in another order: E-step objective identical (the covariance phase does not enter it),
     post_vsm 1e-12, PautoSum 1e-10 of the largest entry (its FP16 term sees D rounded from values that differ in the last FP64 bits).  Shapes: bins not a
-    multiple of the 64-bin workgroup, rank totals above the 256-row panel chunk (two chunks per column block), unequal ranks per latent (timescales
+    multiple of the 128-bin workgroup (down to 16 bins and one latent: a workgroup mostly empty, a single column block), rank totals above the 256-row panel chunk (two chunks per column block), unequal ranks per latent (timescales
     spread 6 x), 7 and 9 latents - run by the 8- and 10-wide instantiations with an empty last latent - and 12, beyond the kernel's widths: the
     two-pass route, and `last_yt_mix_fused` says so."""
     from funs import _hip
