@@ -44,7 +44,7 @@ int pgpfa_destroy(pgpfa_ctx* ctx);
 /* Options: "newton_xtol" (1e-5), "newton_max_iter" (50), "use_mfma" (1),
  * "chunk_trials" (0 = auto), "eps_noise" (1e-3, util.py:599), "chord" (1: reuse the first factor for
  * chord steps), "chord_xtol" (1e-9), "chord_rho" (0.6), "chord_max_step" (1.0), "profile" (0; 1 = HIP events around
- * every tagged launch, 2 = around GEMM launches only; sums are read with pgpfa_get_info "prof_<family>_ms|_flops|_launches", the longest
+ * every tagged launch, 2 = around GEMM launches and the one mixing (tag "mix") launch of an E-step only; sums are read with pgpfa_get_info "prof_<family>_ms|_flops|_launches", the longest
  * single launch with "_max_ms|_max_flops"), "profile_pause" (1: stop recording without touching the sums, 0: go on - an event pair costs
  * ~10 us of device time per launch, so a caller that wants rates over a long region samples it),
  * "shared_pcg" (1: phase-1 Newton with the shared preconditioner), "shared_min" (16), "pcg_inner" (16: cap on
@@ -122,7 +122,8 @@ int pgpfa_destroy(pgpfa_ctx* ctx);
 int pgpfa_set_option(pgpfa_ctx* ctx, const char* key, double value);
 /* Info: "chunk_trials", "plan_lowrank", "n_pad", "lowrank_rtot", "last_estep_ms", "last_newton_factorizations",
  * "last_newton_solves", "last_pcg_iterations", "last_shared_factorizations", "last_cov_lowrank",
- * "last_dense_retries", "hbm_bytes_allocated", "hbm_bytes_free" / "hbm_bytes_total" (hipMemGetInfo of the context's device, now), "n_trials_global", "prof_<tag>_{ms,flops,launches}", "counts_two_bytes",
+ * "last_dense_retries", "hbm_bytes_allocated", "hbm_bytes_free" / "hbm_bytes_total" (hipMemGetInfo of the context's device, now), "n_trials_global", "prof_<tag>_{ms,flops,launches}" (tags gemm, potrf, solve, poisson, assemble, vsm, cd, mix; "prof_mix_flops" counts BYTES for the stand-alone mixing
+ * passes and FLOPs - products + mixing - when "last_yt_mix_fused" is 1), "counts_two_bytes",
  * "arena_bytes", "last_split_cov", "last_yt_mix_fused" (1 when the last covariance pass ran product and mixing as one kernel), "last_eps_wt_norm", "last_eps_wt_rms", "last_newton_solve_ms", "last_newton_solve_bytes",
  * "last_newton_solve_bytes_moved" (what the step's kernels really move: with "pcg_vec32" five of its vectors are single precision),
  * "last_newton_solve_bytes_survey" (the same slot-iterations priced at q T + 8 (2 p T + T p^2) bytes each: SURVEY 8(d)'s B_E per pass per trial),

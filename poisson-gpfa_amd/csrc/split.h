@@ -362,7 +362,7 @@ __global__ __launch_bounds__(2 * NB, 2) void mix_slot3_kernel(const double* __re
   }
   // (wave-uniform descriptors over the slot's two images; the lane's bin is the 32-bit offset of every access, the column a scalar one)
   const __amdgpu_buffer_rsrc_t y = wave_uniform_rsrc(Yt + (size_t)slot * sY, (size_t)sY * sizeof(double));
-  const __amdgpu_buffer_rsrc_t d = wave_uniform_rsrc(D + (size_t)slot * sD, (size_t)sD * sizeof(float));
+  const __amdgpu_buffer_rsrc_t d = wave_uniform_rsrc(D + (size_t)slot * sD, (size_t)ldd * ract * sizeof(float));   // (ract columns of ldd floats)
   const unsigned voff = (unsigned)tc;
   auto fetch = [&](int b0, double (&v)[U][PW]) {
     const int bb = b0 < ract ? b0 : ract - U;                 // (past the end: the last trip again)

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(YTM_THREADS, 512 / YTM_THREADS) void yt_mix_kernel(
   const int tc = t < T ? t : T - 1;
   const double* gl = Gs + wave * 16 + l15;
   const double* Ms = a.Mts + (size_t)slot * a.sM;
-  const __amdgpu_buffer_rsrc_t d = wave_uniform_rsrc(a.D + (size_t)slot * a.sD, (size_t)a.sD * sizeof(float));
+  const __amdgpu_buffer_rsrc_t d = wave_uniform_rsrc(a.D + (size_t)slot * a.sD, (size_t)a.ldd * a.ract * sizeof(float));   // (ract columns of ldd floats)
   const __amdgpu_buffer_rsrc_t fr = wave_uniform_rsrc(a.F, (size_t)p * a.Tp * a.Tp * sizeof(double));
   const unsigned flane = ((unsigned)l4 * (unsigned)a.Tp + (unsigned)tc) * 8u;
   const unsigned dlane = ((unsigned)l4 * (unsigned)a.ldd + (unsigned)tc) * 4u;
