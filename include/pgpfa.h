@@ -298,7 +298,8 @@ int pgpfa_bench_syrk(pgpfa_ctx* ctx, int batch, int n, int k, int reps, double* 
 /* GEMM launches since option "profile" was switched on, grouped by operand shape (text, one line per shape: launches, total ms, algorithmic
  * GFLOP, TFLOP/s; longest total first).  Returns the bytes the full report needs incl. the terminator; writes at most len. */
 int pgpfa_gemm_shape_report(pgpfa_ctx* ctx, char* buf, int len);
-/* Phase timings of the 128 x 128 diagonal-block kernel (chol.h): phases 0 = load/store only, 1 = + Cholesky steps, 3 = + inverse. */
+/* Phase timings of the 128 x 128 diagonal-block kernel (chol.h): phases 0 = load/store only, 1 = + Cholesky steps, 3 = + inverse; + 4 (5, 7): the
+ * round-1 form of the Cholesky steps (a row and 32 columns per thread) instead of the 4 x 8 register blocks. */
 int pgpfa_bench_potrf_diag(pgpfa_ctx* ctx, int batch, int reps, int phases, double* us_per_launch);
 /* Sustained v_mfma_f64_16x16x4_f64 rate of the device (register-only loop): the practical MFMA
  * ceiling under the clock the chip holds, reported next to the datasheet peak. */

@@ -35,6 +35,10 @@ struct PotrfLds {
   T L[NB * (NB + 1) / 2];       // packed lower triangle of the factor, column by column (66 KB in FP64: two workgroups per CU)
   T line[2][NB];                // broadcast lines, permuted: pos(i) = (i & 3) * 32 + (i >> 2)
   T rd[2];                      // 1 / L[j][j] of the current step
+  // the 2-D form (potrf_diag_chol_steps2): column j once per consumer - rowc[buf][h][2 tr + (i & 1)] = entry tr + 32 i (i = 2 h, 2 h + 1: a thread's
+  // four rows in two 16-byte pieces, lane stride 16 bytes), colc[buf][8 tc + m] = entry tc + 16 m (a thread's eight columns contiguous)
+  T rowc[2][2][64];
+  T colc[2][NB];
 };
 
 template <typename T>
@@ -73,6 +77,59 @@ __device__ __forceinline__ void potrf_diag_chol_steps(T (&a)[32], PotrfLds<T>& S
       const T* bp = buf + cg * 32;
 #pragma unroll
       for (int m = 8 * Q; m < 32; ++m) a[m] = fma(nlr, bp[m], a[m]);
+    }
+  }
+}
+
+// The same steps with the trailing matrix in 4 x 8 register blocks (round 5): thread (tr = tid & 31, tc = tid >> 5) owns rows tr + 32 i (i < 4)
+// and columns tc + 16 m (m < 8).  In the form above a thread owns one row and 32 columns and reads 32 entries of column j from LDS per step -
+// 16 wide reads per wave, 8 waves: ~1000 cycles of the LDS pipe per step.  A 4 x 8 block needs 4 + 8 entries: six 16-byte reads, the column side a
+// broadcast.  Measured: 68 -> 62 us for the 128 steps of one block, 190 -> 180 us at batch 1024 - a step is mostly the latency of its dependent chain
+// (pivot, FP64 reciprocal square root, LDS line, barrier, LDS reads, update), not the LDS bytes.  Steps are instantiated per 16 columns so that the live column range is
+// static (m >= S); finished rows and the partly finished column block S are updated with numbers nobody reads again.
+template <int S, typename T>
+__device__ __forceinline__ void potrf_diag_chol_steps2(T (&a)[4][8], PotrfLds<T>& L, int tr, int tc, int* __restrict__ info, long long slot, int k0) {
+  typedef T v2 __attribute__((ext_vector_type(2)));
+#pragma unroll 1
+  for (int j = 16 * S; j < 16 * S + 16; ++j) {
+    const int b = j & 1;
+    if (tc == (j & 15)) {                                 // column j = tc + 16 S: this thread's column m = S, its rows tr + 32 i
+      *reinterpret_cast<v2*>(&L.rowc[b][0][2 * tr]) = v2{a[0][S], a[1][S]};
+      *reinterpret_cast<v2*>(&L.rowc[b][1][2 * tr]) = v2{a[2][S], a[3][S]};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) L.colc[b][(tr & 15) * 8 + 2 * i + (tr >> 4)] = a[i][S];    // entry c = tr + 32 i -> [8 (c & 15) + (c >> 4)]
+      if (tr == (j & 31)) {
+        const T v = (j >> 5) == 0 ? a[0][S] : (j >> 5) == 1 ? a[1][S] : (j >> 5) == 2 ? a[2][S] : a[3][S];
+        T rd = rsqrt(v);
+        if (!(v > (T)0)) {                                // also catches NaN
+          if (info[slot] == 0) info[slot] = k0 + j + 1;
+          rd = (T)1;
+        }
+        L.rd[b] = rd;
+      }
+    }
+    __syncthreads();
+    const T rd = L.rd[b];
+    const v2 r01 = *reinterpret_cast<const v2*>(&L.rowc[b][0][2 * tr]), r23 = *reinterpret_cast<const v2*>(&L.rowc[b][1][2 * tr]);
+    T lr[4] = {r01.x * rd, r01.y * rd, r23.x * rd, r23.y * rd};          // L[r][j] of this thread's rows (r >= j: the others are not used)
+    if (tc == (j & 15)) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = tr + 32 * i;
+        if (r >= j) L.L[potrf_lidx(j, r)] = lr[i];
+      }
+    }
+    T cv[8];
+#pragma unroll
+    for (int m = S & ~1; m < 8; m += 2) {
+      const v2 c2 = *reinterpret_cast<const v2*>(&L.colc[b][8 * tc + m]);
+      cv[m] = c2.x; cv[m + 1] = c2.y;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const T nlr = -lr[i] * rd;
+#pragma unroll
+      for (int m = S; m < 8; ++m) a[i][m] = fma(nlr, cv[m], a[i][m]);
     }
   }
 }
@@ -185,7 +242,12 @@ __device__ __forceinline__ void potrf_diag_inverse(PotrfLds<T>& S, int tid, int 
 }
 
 // (PH: phases to run, for the phase timings of pgpfa_bench_potrf_diag: bit 0 = Cholesky steps, bit 1 = inverse; production is 3)
-template <typename T, int PH = 3>
+// ALG 2 (default): Cholesky steps on 4 x 8 register blocks (potrf_diag_chol_steps2); 1: a row and 32 columns per thread (kept for the A/B of
+// pgpfa_bench_potrf_diag).  (Tried and dropped in round 5: panels of 16 columns factored inside ONE wave - pivot and column entries by
+// v_readlane, no barrier - with the rank-16 trailing updates on the matrix cores: a column still costs ~1000 cycles - the FP64 reciprocal
+// square root and the 30 lane broadcasts of a step are one dependent chain - 70 us against 62, and 300 against 180 at batch 1024, where the
+// other seven waves of every workgroup wait.)
+template <typename T, int PH = 3, int ALG = 2>
 __global__ __launch_bounds__(512) void potrf_diag_kernel_t(T* __restrict__ H, long long sH, int ld, int k0,
                                                             T* __restrict__ Dinv, long long sD,
                                                             const int* __restrict__ slots, int* __restrict__ info) {
@@ -198,18 +260,43 @@ __global__ __launch_bounds__(512) void potrf_diag_kernel_t(T* __restrict__ H, lo
   T* Hs = H + slot * sH + (size_t)k0 * ld + k0;
   T* Ds = Dinv + slot * sD + (size_t)(k0 / NB) * NB * NB;
 
-  T a[32];
+  if constexpr (ALG == 2) {
+    const int tr = tid & 31, tc = tid >> 5;
+    T a2[4][8];
 #pragma unroll
-  for (int m = 0; m < 32; ++m) a[m] = Hs[(size_t)(cg + 4 * m) * ld + r];   // entries above the diagonal are never used
-  if constexpr (PH & 1) {
-    potrf_diag_chol_steps<0>(a, S, r, cg, pos_r, info, slot, k0);
-    potrf_diag_chol_steps<1>(a, S, r, cg, pos_r, info, slot, k0);
-    potrf_diag_chol_steps<2>(a, S, r, cg, pos_r, info, slot, k0);
-    potrf_diag_chol_steps<3>(a, S, r, cg, pos_r, info, slot, k0);
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int m = 0; m < 8; ++m) a2[i][m] = Hs[(size_t)(tc + 16 * m) * ld + tr + 32 * i];   // entries above the diagonal are never used
+    if constexpr (PH & 1) {
+      potrf_diag_chol_steps2<0>(a2, S, tr, tc, info, slot, k0);
+      potrf_diag_chol_steps2<1>(a2, S, tr, tc, info, slot, k0);
+      potrf_diag_chol_steps2<2>(a2, S, tr, tc, info, slot, k0);
+      potrf_diag_chol_steps2<3>(a2, S, tr, tc, info, slot, k0);
+      potrf_diag_chol_steps2<4>(a2, S, tr, tc, info, slot, k0);
+      potrf_diag_chol_steps2<5>(a2, S, tr, tc, info, slot, k0);
+      potrf_diag_chol_steps2<6>(a2, S, tr, tc, info, slot, k0);
+      potrf_diag_chol_steps2<7>(a2, S, tr, tc, info, slot, k0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+          if (tc + 16 * m <= tr + 32 * i) S.L[potrf_lidx(tc + 16 * m, tr + 32 * i)] = a2[i][m];
+    }
   } else {
+    T a[32];
 #pragma unroll
-    for (int m = 0; m < 32; ++m)
-      if (cg + 4 * m <= r) S.L[potrf_lidx(cg + 4 * m, r)] = a[m];
+    for (int m = 0; m < 32; ++m) a[m] = Hs[(size_t)(cg + 4 * m) * ld + r];   // entries above the diagonal are never used
+    if constexpr (PH & 1) {
+      potrf_diag_chol_steps<0>(a, S, r, cg, pos_r, info, slot, k0);
+      potrf_diag_chol_steps<1>(a, S, r, cg, pos_r, info, slot, k0);
+      potrf_diag_chol_steps<2>(a, S, r, cg, pos_r, info, slot, k0);
+      potrf_diag_chol_steps<3>(a, S, r, cg, pos_r, info, slot, k0);
+    } else {
+#pragma unroll
+      for (int m = 0; m < 32; ++m)
+        if (cg + 4 * m <= r) S.L[potrf_lidx(cg + 4 * m, r)] = a[m];
+    }
   }
   __syncthreads();
   for (int e = tid; e < NB * NB; e += 512) {

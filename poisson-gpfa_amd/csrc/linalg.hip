@@ -378,7 +378,7 @@ int pgpfa_gemm_shape_report(pgpfa_ctx* c, char* buf, int len) {
 // steps), 3 (+ inverse: the production kernel).  us_per_launch = HIP-event time over `reps` launches.
 int pgpfa_bench_potrf_diag(pgpfa_ctx* c, int batch, int reps, int phases, double* us_per_launch) {
   if (!c || !us_per_launch) return fail("null argument");
-  if (batch < 1 || reps < 1 || (phases != 0 && phases != 1 && phases != 3)) return fail("batch, reps >= 1; phases 0, 1 or 3");
+  if (batch < 1 || reps < 1 || (phases != 0 && phases != 1 && phases != 3 && phases != 5 && phases != 7)) return fail("batch, reps >= 1; phases 0, 1 or 3 (+ 4: the round-1 form of the Cholesky steps)");
   HIPC(hipSetDevice(c->device));
   const size_t mark = c->allocs.size();
   double *dH = nullptr, *dD = nullptr;
@@ -396,7 +396,11 @@ int pgpfa_bench_potrf_diag(pgpfa_ctx* c, int batch, int reps, int phases, double
   hipEventCreate(&e0); hipEventCreate(&e1);
   auto launch = [&]() {
     // (the factor overwrites its input: later launches factor the factor's lower triangle - still SPD-like, diagonal > 1 - same work)
-    if (phases == 3)
+    if (phases == 7)
+      hipLaunchKernelGGL((potrf_diag_kernel_t<double, 3, 1>), dim3(batch), dim3(512), 0, c->st, dH, (long long)blk, NB, 0, dD, (long long)blk, (const int*)nullptr, dinfo);
+    else if (phases == 5)
+      hipLaunchKernelGGL((potrf_diag_kernel_t<double, 1, 1>), dim3(batch), dim3(512), 0, c->st, dH, (long long)blk, NB, 0, dD, (long long)blk, (const int*)nullptr, dinfo);
+    else if (phases == 3)
       hipLaunchKernelGGL((potrf_diag_kernel_t<double, 3>), dim3(batch), dim3(512), 0, c->st, dH, (long long)blk, NB, 0, dD, (long long)blk, (const int*)nullptr, dinfo);
     else if (phases == 1)
       hipLaunchKernelGGL((potrf_diag_kernel_t<double, 1>), dim3(batch), dim3(512), 0, c->st, dH, (long long)blk, NB, 0, dD, (long long)blk, (const int*)nullptr, dinfo);

@@ -6,6 +6,6 @@ sys.path.insert(0, os.path.join(ROOT, 'poisson-gpfa_amd'))
 from funs import _hip
 ctx = _hip.Context(8, 2, 16, 2, 10.0)
 for batch in (1, 40, 256, 1024):
-    t = [ctx.bench_potrf_diag(batch, 50, ph) for ph in (0, 1, 3)]
-    print('batch %4d: load/store %.1f us, + Cholesky steps %.1f us, + inverse %.1f us' % (batch, t[0], t[1], t[2]), flush=True)
+    t = [ctx.bench_potrf_diag(batch, 50, ph) for ph in (0, 1, 3, 5, 7)]     # (+ 4: the round-1 form of the Cholesky steps, a row x 32 columns per thread)
+    print('batch %4d: load/store %.1f us, + Cholesky steps %.1f us, + inverse %.1f us   (round-1 steps: %.1f, %.1f)' % (batch, *t), flush=True)
 ctx.close()
