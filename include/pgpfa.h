@@ -87,6 +87,8 @@ int pgpfa_destroy(pgpfa_ctx* ctx);
  * "splitk_below64" (400: products on 64 x 64 tiles are cut along k only below this many tiles),
  * "copy_kernels" (1: read-backs and uploads up to 256 KB move through host-mapped staging memory as one-workgroup kernels, and a flush is a
  * kernel that raises a sequence number the host spins on - no hipMemcpyAsync / hipStreamSynchronize on those paths; 0: the runtime's copies),
+ * "poisson_tiles" (2, round 5: 16-bin tiles per wave of the matrix-core Poisson pass up to 10 latents - the table fragments of a neuron tile, read from
+ * L2, serve that many tiles; 1: one tile per wave),
  * "vsm_b4" (2, round 5; 1: the same with 32 bins per workgroup and scalar loads: the per-bin covariance blocks post_vsm for 11..20 latents on the 4 x 4 x 4 block shape of the FP64 matrix cores - four bins per
  * instruction, instructions over the lower pairs of four-latent blocks: 15 x 19 cycles per four bins and four columns at 20 latents against 12 x 68 on
  * the 16 x 16 x 4 shape padded to 32 rows; 0: that form),

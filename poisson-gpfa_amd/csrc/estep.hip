@@ -52,10 +52,18 @@ int poisson(pgpfa_ctx* c, const int* d_list, int nl, const double* X, double* G,
   }
   prof_begin(c, TAG_POISSON, fl);
   if (c->CCu && c->mfma) {
+    // bin tiles per wave (option poisson_tiles): the table fragments of a neuron tile are read from L2 once per wave and serve that many tiles
+    const int nbt = (c->poisson_tiles >= 2 && c->p <= 10) ? 2 : 1;
+    a.ntile = (c->T + 64 * nbt - 1) / (64 * nbt);
+    const dim3 gridm(a.ntile, nl);
     dispatch_pw(c->p, [&](auto pm) {
       constexpr int PW = decltype(pm)::value;
-      if constexpr (PW <= 16)
-        hipLaunchKernelGGL(poisson_mfma_kernel<PW>, grid, dim3(256), 0, c->st, a, c->CCu, c->C16, c->qpad);
+      if constexpr (PW <= 10) {
+        if (nbt == 2) hipLaunchKernelGGL((poisson_mfma_kernel<PW, 2>), gridm, dim3(256), 0, c->st, a, c->CCu, c->C16, c->qpad);
+        else hipLaunchKernelGGL((poisson_mfma_kernel<PW, 1>), gridm, dim3(256), 0, c->st, a, c->CCu, c->C16, c->qpad);
+      } else if constexpr (PW <= 16) {
+        hipLaunchKernelGGL((poisson_mfma_kernel<PW, 1>), gridm, dim3(256), 0, c->st, a, c->CCu, c->C16, c->qpad);
+      }
     });
   } else {
     dispatch_pw(c->p, [&](auto pm) { hipLaunchKernelGGL(poisson_pass_kernel<decltype(pm)::value>, grid, block, 0, c->st, a); });

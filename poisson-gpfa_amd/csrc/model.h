@@ -310,8 +310,12 @@ inline __global__ void poisson_tables_kernel(const double* __restrict__ C, int q
   for (int l = threadIdx.x; l < 16; l += blockDim.x) C16[(size_t)n * 16 + l] = (n < q && l < p) ? C[(size_t)n * p + l] : 0.0;
 }
 
-template <int PW>
-__global__ __launch_bounds__(256) void poisson_mfma_kernel(PoissonArgs a, const double* __restrict__ CCu, const double* __restrict__ C16, int qpad) {
+// NBT (round 5): bin tiles of 16 per wave.  The table fragments of a neuron tile (23 doubles per lane: CCu, C16) are the same for every wave, slot
+// and bin tile and came from L2 once per (wave, 16 bins, 16 neurons): 11.8 KB per 23 matrix instructions, 5 GB of L2 -> CU traffic per launch at
+// config 3 for 0.58 GB of HBM bytes - the pass sat under neither roof (0.73 ms).  With NBT tiles per wave a fragment set serves NBT x 16 bins.
+// grid = (ceil(T / (64 NBT)), nslots); fpart holds gridDim.x partial sums per slot.
+template <int PW, int NBT>
+__global__ __launch_bounds__(256, 2) void poisson_mfma_kernel(PoissonArgs a, const double* __restrict__ CCu, const double* __restrict__ C16, int qpad) {
   constexpr int NP = PW * (PW + 1) / 2, NT = (NP + 15) / 16, NC = NT * 16, KS = (PW + 3) / 4;
   __shared__ double Wl[4][16 * PW * PW];
   __shared__ double fred[4];
@@ -321,18 +325,24 @@ __global__ __launch_bounds__(256) void poisson_mfma_kernel(PoissonArgs a, const 
   const int trial = a.trial_of_slot[slot];
   const int held_out = a.mask ? a.mask[slot] : -1;
   const int p = a.p, q = a.q, T = a.T, pp = p * p;
-  const int sbase = blockIdx.x * 64 + wave * 16;
-  const int t = sbase + l15;
-  const bool valid_t = t < T;
+  const int sbase0 = blockIdx.x * 64 * NBT + wave * 16 * NBT;       // this wave's bins: NBT consecutive tiles of 16
   const double* X = a.X + (size_t)slot * a.sX;
   const uint8_t* Y = a.Y + (size_t)trial * q * T;
   const uint8_t* Yh = a.Yhi ? a.Yhi + (size_t)trial * q * T : nullptr;
 
-  double xb[KS];
+  double xb[NBT][KS];
+  int tcl[NBT];
+  bool vt[NBT];
 #pragma unroll
-  for (int kk = 0; kk < KS; ++kk) {
-    const int l = l4 + 4 * kk;
-    xb[kk] = (l < p && valid_t) ? X[(size_t)l * T + t] : 0.0;
+  for (int bt = 0; bt < NBT; ++bt) {
+    const int t = sbase0 + 16 * bt + l15;
+    vt[bt] = t < T;
+    tcl[bt] = vt[bt] ? t : T - 1;
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      const int l = l4 + 4 * kk;
+      xb[bt][kk] = (l < p && vt[bt]) ? X[(size_t)l * T + t] : 0.0;
+    }
   }
   // LDS offsets of this lane's pair columns (c = tile*16 + l15 -> (pa, pb), pa >= pb); -1: padding column
   int off1[NT], off2[NT];
@@ -345,26 +355,34 @@ __global__ __launch_bounds__(256) void poisson_mfma_kernel(PoissonArgs a, const 
     off1[tl] = (pa < p) ? pa * p + pb : -1;
     off2[tl] = pb * p + pa;
   }
-  mdouble4 accW[NT], accG = {0.0, 0.0, 0.0, 0.0};
+  mdouble4 accW[NBT][NT], accG[NBT];
 #pragma unroll
-  for (int tl = 0; tl < NT; ++tl) accW[tl] = mdouble4{0.0, 0.0, 0.0, 0.0};
+  for (int bt = 0; bt < NBT; ++bt) {
+    accG[bt] = mdouble4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int tl = 0; tl < NT; ++tl) accW[bt][tl] = mdouble4{0.0, 0.0, 0.0, 0.0};
+  }
   double facc = 0.0;
 
-  if (sbase < T) {
+  if (sbase0 < T) {
     // every global load of a neuron tile (offsets, counts, table fragments) is issued up front with clamped,
     // branch-free addresses; invalid rows/bins are masked afterwards
-    const int tc = valid_t ? t : T - 1;
     for (int nb0 = 0; nb0 < qpad; nb0 += 16) {
-      double dv[4];
-      unsigned yv[4];
+      double dn[4];
+      double dv[NBT][4];
+      unsigned yv[NBT][4];
       double ch[KS];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = nb0 + l4 + 4 * r;
         const int nc = n < q ? n : q - 1;
-        dv[r] = a.d[nc];
-        if (a.off) dv[r] += a.off[(size_t)slot * a.sOff + (size_t)nc * T + tc];
-        yv[r] = count_at(Y, Yh, (size_t)nc * T + tc);
+        dn[r] = a.d[nc];
+#pragma unroll
+        for (int bt = 0; bt < NBT; ++bt) {
+          dv[bt][r] = dn[r];
+          if (a.off) dv[bt][r] += a.off[(size_t)slot * a.sOff + (size_t)nc * T + tcl[bt]];
+          yv[bt][r] = count_at(Y, Yh, (size_t)nc * T + tcl[bt]);
+        }
       }
 #pragma unroll
       for (int kk = 0; kk < KS; ++kk) ch[kk] = C16[(size_t)(nb0 + l15) * 16 + l4 + 4 * kk];
@@ -378,58 +396,67 @@ __global__ __launch_bounds__(256) void poisson_mfma_kernel(PoissonArgs a, const 
           bg[r] = C16[nrow * 16 + l15];
         }
       }
-      mdouble4 h;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) h[r] = (nb0 + l4 + 4 * r < q) ? dv[r] : 0.0;
+      for (int bt = 0; bt < NBT; ++bt) {
+        if (sbase0 + 16 * bt >= T) continue;                    // (uniform over the wave)
+        mdouble4 h;
 #pragma unroll
-      for (int kk = 0; kk < KS; ++kk) h = __builtin_amdgcn_mfma_f64_16x16x4f64(ch[kk], xb[kk], h, 0, 0, 0);
-      double e[4], rr[4];
+        for (int r = 0; r < 4; ++r) h[r] = (nb0 + l4 + 4 * r < q) ? dv[bt][r] : 0.0;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int n = nb0 + l4 + 4 * r;
-        const bool ok = (n < q) && valid_t && (n != held_out);
-        const double y = ok ? (double)yv[r] : 0.0;
-        const double ev = ok ? exp(h[r]) : 0.0;
-        e[r] = ev;
-        rr[r] = ev - y;
-        facc += ok ? ev - y * h[r] : 0.0;
-        if (a.lam_out && (n < q) && valid_t) a.lam_out[(size_t)slot * a.sLam + (size_t)n * T + t] = ev;
-      }
-      if (a.full) {
+        for (int kk = 0; kk < KS; ++kk) h = __builtin_amdgcn_mfma_f64_16x16x4f64(ch[kk], xb[bt][kk], h, 0, 0, 0);
+        double e[4], rr[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+          const int n = nb0 + l4 + 4 * r;
+          const bool ok = (n < q) && vt[bt] && (n != held_out);
+          const double y = ok ? (double)yv[bt][r] : 0.0;
+          const double ev = ok ? exp(h[r]) : 0.0;
+          e[r] = ev;
+          rr[r] = ev - y;
+          facc += ok ? ev - y * h[r] : 0.0;
+          if (a.lam_out && (n < q) && vt[bt]) a.lam_out[(size_t)slot * a.sLam + (size_t)n * T + sbase0 + 16 * bt + l15] = ev;
+        }
+        if (a.full) {
 #pragma unroll
-          for (int tl = 0; tl < NT; ++tl) accW[tl] = __builtin_amdgcn_mfma_f64_16x16x4f64(e[r], bw[r][tl], accW[tl], 0, 0, 0);
-          accG = __builtin_amdgcn_mfma_f64_16x16x4f64(rr[r], bg[r], accG, 0, 0, 0);
+          for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int tl = 0; tl < NT; ++tl) accW[bt][tl] = __builtin_amdgcn_mfma_f64_16x16x4f64(e[r], bw[r][tl], accW[bt][tl], 0, 0, 0);
+            accG[bt] = __builtin_amdgcn_mfma_f64_16x16x4f64(rr[r], bg[r], accG[bt], 0, 0, 0);
+          }
         }
       }
     }
   }
   if (a.full) {
-    // accumulators: bin = l4 + 4 r, column = l15
+    // accumulators: bin = l4 + 4 r, column = l15; the wave's tiles leave one after the other through its LDS tile
     double* Ws = Wl[wave];
-    if (sbase < T) {
 #pragma unroll
-      for (int tl = 0; tl < NT; ++tl)
-        if (off1[tl] >= 0) {
+    for (int bt = 0; bt < NBT; ++bt) {
+      const int sbase = sbase0 + 16 * bt;
+      if (sbase < T) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            Ws[(l4 + 4 * r) * pp + off1[tl]] = accW[tl][r];
-            Ws[(l4 + 4 * r) * pp + off2[tl]] = accW[tl][r];
+        for (int tl = 0; tl < NT; ++tl)
+          if (off1[tl] >= 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              Ws[(l4 + 4 * r) * pp + off1[tl]] = accW[bt][tl][r];
+              Ws[(l4 + 4 * r) * pp + off2[tl]] = accW[bt][tl][r];
+            }
           }
-        }
-    }
-    __syncthreads();
-    if (sbase < T) {
-      const int nbins = min(16, T - sbase);
-      double* W = a.W + (size_t)slot * a.sW + (size_t)sbase * pp;
-      for (int e2 = lane; e2 < nbins * pp; e2 += 64) W[e2] = Ws[e2];
-      if (l15 < p) {
-        double* G = a.G + (size_t)slot * a.sG + (size_t)l15 * T + sbase;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (sbase + l4 + 4 * r < T) G[l4 + 4 * r] = accG[r];
       }
+      __syncthreads();
+      if (sbase < T) {
+        const int nbins = min(16, T - sbase);
+        double* W = a.W + (size_t)slot * a.sW + (size_t)sbase * pp;
+        for (int e2 = lane; e2 < nbins * pp; e2 += 64) W[e2] = Ws[e2];
+        if (l15 < p) {
+          double* G = a.G + (size_t)slot * a.sG + (size_t)l15 * T + sbase;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (sbase + l4 + 4 * r < T) G[l4 + 4 * r] = accG[bt][r];
+        }
+      }
+      if (bt + 1 < NBT) __syncthreads();
     }
   }
   for (int off = 32; off > 0; off >>= 1) facc += __shfl_down(facc, off);

@@ -228,12 +228,13 @@ def test_dual_variational_through_the_fixed_point_vs_reference(funs_mod):
 # ---------------------------------------------------------------------------------------------------------------
 # copies as kernels / the runtime's copies; the two mixing passes
 # ---------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('option', [('copy_kernels', 0), ('mix_slot', 0), ('mix_slot', 1), ('mix_slot', 2), ('mix_slot', 3)])
+@pytest.mark.parametrize('option', [('copy_kernels', 0), ('mix_slot', 0), ('mix_slot', 1), ('mix_slot', 2), ('mix_slot', 3), ('poisson_tiles', 1)])
 def test_alternative_paths_give_the_same_numbers(c1, option):
     """The small copies through the runtime (`copy_kernels = 0`: hipMemcpyAsync + hipStreamSynchronize instead of kernels through mapped staging and
     a sequence number) and the stand-alone mixing passes of the split accumulation (`yt_mix = 0`: Yt formed by the batched product, then `mix_slot` = 0: 64-bin
     pass, 1 / 2: a thread per bin, 3: two column halves per bin) against the defaults (product and mixing in one kernel) on the same E-step + M-step
-    statistics: copies move bytes - bit-identical; the mixing passes add the same products in another order - 1e-13."""
+    statistics: copies move bytes - bit-identical; the mixing passes add the same products in another order - 1e-13; one 16-bin tile per wave in
+    the matrix-core Poisson pass (`poisson_tiles = 1`) instead of two: the same numbers per bin, the objective's partial sums in another order."""
     from funs import _hip
     out = []
     for variant in (False, True):
