@@ -71,7 +71,6 @@ __global__ __launch_bounds__(YTM_THREADS, 512 / YTM_THREADS) void yt_mix_kernel(
     for (int hi = 0; hi < PW; ++hi)
 #pragma unroll
       for (int lo = 0; lo <= hi; ++lo) {
-        constexpr int dummy = 0; (void)dummy;
         const int idx = hi * (hi + 1) / 2 + lo;
         if ((idx & 3) == part) Gs[idx * YTM_BINS + bin] = hi < p ? gsrc[hi * p + lo] : 0.0;
       }
