@@ -312,7 +312,9 @@ inline __global__ void poisson_tables_kernel(const double* __restrict__ C, int q
 
 // NBT (round 5): bin tiles of 16 per wave.  The table fragments of a neuron tile (23 doubles per lane: CCu, C16) are the same for every wave, slot
 // and bin tile and came from L2 once per (wave, 16 bins, 16 neurons): 11.8 KB per 23 matrix instructions, 5 GB of L2 -> CU traffic per launch at
-// config 3 for 0.58 GB of HBM bytes - the pass sat under neither roof (0.73 ms).  With NBT tiles per wave a fragment set serves NBT x 16 bins.
+// config 3 for 0.58 GB of HBM bytes - the pass sat under neither roof (0.79 ms).  With NBT tiles per wave a fragment set serves NBT x 16 bins:
+// 0.58 ms at NBT = 2.  (One copy of the neuron tile's tables per WORKGROUP in LDS on top of that - 10 KB, double-buffered, one barrier per neuron
+// tile, every fragment read conflict-free - ran 0.60 ms: at two tiles per wave the fragments are no longer what bounds the pass.  Dropped.)
 // grid = (ceil(T / (64 NBT)), nslots); fpart holds gridDim.x partial sums per slot.
 template <int PW, int NBT>
 __global__ __launch_bounds__(256, 2) void poisson_mfma_kernel(PoissonArgs a, const double* __restrict__ CCu, const double* __restrict__ C16, int qpad) {
