@@ -96,6 +96,8 @@ int pgpfa_destroy(pgpfa_ctx* ctx);
  * latents on the FP64 matrix cores, mixed in registers, only the correction D and post_vsm leave the chip; Yt is never written; 0: product, then mixing pass),
  * "yt_mix_dbg" (0; bit mask for timing experiments on that kernel - 1 no loads of F, 2 no products, 4 no mixing, 8 no stores of D, 16 no panel staging, 32 no
  * barriers, 64 no panel loads: the results are WRONG when it is set; tools/ab_opts.sh only),
+ * "syrk_dbg" (0; bit mask for timing experiments on syrk_f16x2_kernel - 1 no conversions, 2 no products, 8 no barriers: the results are WRONG when it is
+ * set; tools/ab_opts.sh only),
  * "mix_slot" (3, round 5: as 2 with a workgroup of 128 bins x 2 column halves - both halves read one G_t image of 56 KB, two workgroups = two waves per SIMD on a CU -
  * the halves' pair sums meet through LDS at the end; 2: as 1 with the next pair of columns requested before this pair's arithmetic - two register sets, no branch in the loop - where
  * p is a template width and the rank a multiple of 4, else 1; 1: the mixing pass of that split form with a thread per bin and a workgroup per (slot, 256 bins) that walks whole columns of

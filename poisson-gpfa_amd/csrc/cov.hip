@@ -210,7 +210,7 @@ static int accumulate_split(pgpfa_ctx* c, const CholWS& lw, int nb, int ract, in
     SyrkF16Args a{};
     a.D = D; a.sD = sD; a.ldd = ldd; a.ts = Ts; a.part = c->ppart;
     a.T = T; a.p = p; a.ract = ract; a.nslots = nb; a.sps = sps; a.ngroups = ngroups;
-    a.tiles = (T + 127) / 128; a.ntiles = a.tiles * (a.tiles + 1) / 2;
+    a.tiles = (T + 127) / 128; a.ntiles = a.tiles * (a.tiles + 1) / 2; a.dbg = c->syrk_dbg;
     const long long blocks = (long long)a.ntiles * ngroups * p;
     prof_begin(c, TAG_VSM, 3.0 * (double)nb * ract * T * T * p);
     hipLaunchKernelGGL(syrk_f16x2_kernel, dim3((unsigned)blocks), dim3(256), 0, c->st, a);

@@ -455,6 +455,7 @@ struct SyrkF16Args {
   const float* D; long long sD; int ldd, ts;
   double* part;
   int T, p, ract, nslots, sps, ngroups, tiles, ntiles;
+  int dbg;                                   // timing experiments (option syrk_dbg; results wrong when set): 1 no conversions, 2 no products, 4 no global loads (slow form only), 8 no barriers
 };
 
 inline __global__ __launch_bounds__(256, 2) void syrk_f16x2_kernel(SyrkF16Args a) {
@@ -524,7 +525,9 @@ inline __global__ __launch_bounds__(256, 2) void syrk_f16x2_kernel(SyrkF16Args a
       const bool in = stage && c < a.ract;
       const size_t off = (size_t)(in ? c : 0) * a.ldd;
       float4v_t x;
-      if constexpr (VEC) {
+      if (a.dbg & 4) {
+        x = float4v_t{1.f, 2.f, 3.f, 4.f};
+      } else if constexpr (VEC) {
         x = *reinterpret_cast<const float4v_t*>(base + off + (stage ? row0 : 0));
       } else {
 #pragma unroll
@@ -532,6 +535,25 @@ inline __global__ __launch_bounds__(256, 2) void syrk_f16x2_kernel(SyrkF16Args a
       }
       v4[j] = in ? x : float4v_t{0.f, 0.f, 0.f, 0.f};
     }
+  };
+  // The same loads with nothing but scalar arithmetic per step (round 5; the rows, strides and base must allow 16-byte loads: `vec`).  Timing builds
+  // of this kernel showed where its time went: with loads, conversions and products all switched off it still took 4.3 of 6.8 ms - per step two
+  // integer divisions and eight 64-bit address chains per thread.  Here the step is a cursor of two scalars (slot, 32-column step of the slot), a
+  // slot is a buffer descriptor over its ract columns, a load is descriptor + scalar byte offset (column) + the thread's constant 32-bit offset (its
+  // column group and rows), and columns at or past ract fall outside the descriptor: the hardware returns zeros for them - no masks.
+  int cur_s = s_begin, cur_c = 0;                             // load cursor: slot, column step (wave-uniform; advanced by every load_fast)
+  const unsigned voff = (unsigned)(stage ? (co * 8) * a.ldd + row0 : 0) * 4u;
+  auto load_fast = [&](float4v_t (&v4)[8]) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rs = wave_uniform_rsrc(a.D + (size_t)cur_s * a.sD, (size_t)a.ract * a.ldd * sizeof(float));
+    const unsigned soff = (unsigned)(k * a.ts + cur_c * KS * a.ldd) * 4u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)(soff + (unsigned)(j * a.ldd) * 4u), 0);
+      v4[j] = float4v_t{__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w)};
+    }
+    if (cur_c + 1 < steps_per_slot) ++cur_c;
+    else if (cur_s + 1 < s_end) { ++cur_s; cur_c = 0; }       // (past the last step: the last one again, its values are not used)
   };
   auto store = [&](int buf, const float4v_t (&v4)[8]) {
     if (!stage) return;
@@ -543,9 +565,9 @@ inline __global__ __launch_bounds__(256, 2) void syrk_f16x2_kernel(SyrkF16Args a
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float x = v4[j][r] * SPLIT_SCALE;
-        const _Float16 hx = (_Float16)x;
+        const _Float16 hx = (a.dbg & 1) ? (_Float16)0 : (_Float16)x;
         h[j] = hx;
-        l[j] = (_Float16)(x - (float)hx);
+        l[j] = (a.dbg & 1) ? (_Float16)0 : (_Float16)(x - (float)hx);
       }
       *reinterpret_cast<half8_t*>(&Hh[lidx(4 * rq + r, co)]) = h;
       *reinterpret_cast<half8_t*>(&Hl[lidx(4 * rq + r, co)]) = l;
@@ -553,7 +575,7 @@ inline __global__ __launch_bounds__(256, 2) void syrk_f16x2_kernel(SyrkF16Args a
   };
   const int l15 = lane & 15, l4 = lane >> 4;
   auto multiply = [&](int buf) {
-    if (!wave_live) return;
+    if (!wave_live || (a.dbg & 2)) return;
     const _Float16* Bhs = diag ? Ah[buf] : Bh[buf];
     const _Float16* Bls = diag ? Al[buf] : Bl[buf];
     half8_t ah[4], al[4], bh[4], bl[4];
@@ -581,20 +603,22 @@ inline __global__ __launch_bounds__(256, 2) void syrk_f16x2_kernel(SyrkF16Args a
   };
   auto run = [&](auto vecc) {
     if (nsteps <= 0) return;
-    load(vecc, 0, vA);
-    load(vecc, 1, vB);
+    constexpr bool FAST = decltype(vecc)::value;
+    auto ld = [&](int step, float4v_t (&v4)[8]) { if constexpr (FAST) load_fast(v4); else load(vecc, step, v4); };
+    ld(0, vA);
+    ld(1, vB);
     store(0, vA);
-    __syncthreads();
+    if (!(a.dbg & 8)) __syncthreads();
     for (int step = 0; step < nsteps; step += 2) {
-      load(vecc, step + 2, vA);
+      ld(step + 2, vA);
       multiply(0);
       if (step + 1 < nsteps) store(1, vB);
-      __syncthreads();
+      if (!(a.dbg & 8)) __syncthreads();
       if (step + 1 >= nsteps) break;
-      load(vecc, step + 3, vB);
+      ld(step + 3, vB);
       multiply(1);
       if (step + 2 < nsteps) store(0, vA);
-      __syncthreads();
+      if (!(a.dbg & 8)) __syncthreads();
     }
   };
   if (vec) run(std::true_type{}); else run(std::false_type{});
