@@ -685,24 +685,32 @@ __global__ __launch_bounds__(256) void cross_term_kernel(CrossArgs a) {
   // masked when they are stored: a load under a condition is waited for on its own.
   double raA[NA], raB[NA];
   TB rbA[4], rbB[4];
-  auto load = [&](int chunk, double (&ra)[NA], TB (&rb)[4]) {
-    const int cc = min(chunk, nchunks - 1);
-    const int s = s_begin + cc / cps;
-    const int c0 = (cc % cps) * GK;
-    const double* Ap = a.A + (size_t)s * a.sM + (size_t)c0 * a.lda + a.row0;
-    const TB* Dp = Dall + (size_t)s * a.sD + (size_t)c0 * a.ldd + t0;
+  // (the chunks are loaded in order: the chunk is a cursor of two scalars - slot, chunk of the slot - advanced by every call, and a thread's element
+  //  offsets inside a chunk are computed once: no division and no index decoding per chunk)
+  int cur_s = s_begin, cur_c = 0;
+  size_t aoff[NA], doff[4];
 #pragma unroll
-    for (int u = 0; u < NA; ++u) {
-      const int e = tid + 256 * u;
-      const int kk = min(e / (NTR * 16), GK - 1), i = min(e % (NTR * 16), rk - 1);
-      ra[u] = Ap[(size_t)kk * a.lda + i];
-    }
+  for (int u = 0; u < NA; ++u) {
+    const int e = tid + 256 * u;
+    const int kk = min(e / (NTR * 16), GK - 1), i = min(e % (NTR * 16), rk - 1);
+    aoff[u] = (size_t)kk * a.lda + i;
+  }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int e = tid + 256 * u;
-      const int kk = e >> 6, t = min(t0 + (e & 63), a.T - 1) - t0;
-      rb[u] = Dp[(size_t)kk * a.ldd + t];
-    }
+  for (int u = 0; u < 4; ++u) {
+    const int e = tid + 256 * u;
+    const int kk = e >> 6, t = min(t0 + (e & 63), a.T - 1) - t0;
+    doff[u] = (size_t)kk * a.ldd + t;
+  }
+  auto load = [&](int, double (&ra)[NA], TB (&rb)[4]) {
+    const int c0 = cur_c * GK;
+    const double* Ap = a.A + (size_t)cur_s * a.sM + (size_t)c0 * a.lda + a.row0;
+    const TB* Dp = Dall + (size_t)cur_s * a.sD + (size_t)c0 * a.ldd + t0;
+#pragma unroll
+    for (int u = 0; u < NA; ++u) ra[u] = Ap[aoff[u]];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) rb[u] = Dp[doff[u]];
+    if (cur_c + 1 < cps) ++cur_c;
+    else if (cur_s + 1 < s_end) { ++cur_s; cur_c = 0; }       // (past the last chunk: the last one again, its values are not used)
   };
   auto store = [&](int buf, const double (&ra)[NA], const TB (&rb)[4]) {
 #pragma unroll
