@@ -96,6 +96,8 @@ int pgpfa_destroy(pgpfa_ctx* ctx);
  * latents on the FP64 matrix cores, mixed in registers, only the correction D and post_vsm leave the chip; Yt is never written; 0: product, then mixing pass),
  * "yt_mix_dbg" (0; bit mask for timing experiments on that kernel - 1 no loads of F, 2 no products, 4 no mixing, 8 no stores of D, 16 no panel staging, 32 no
  * barriers, 64 no panel loads: the results are WRONG when it is set; tools/ab_opts.sh only),
+ * "syrk_tile" (256, round 5: 256 x 256 workgroup tiles in the FP16 term of the split covariance sum where there are more than 256 bins and the strides
+ * allow 16-byte loads - every output then costs half the reads of the correction D; 128: the 128 x 128 kernel),
  * "syrk_dbg" (0; bit mask for timing experiments on syrk_f16x2_kernel - 1 no conversions, 2 no products, 8 no barriers: the results are WRONG when it is
  * set; tools/ab_opts.sh only),
  * "mix_slot" (3, round 5: as 2 with a workgroup of 128 bins x 2 column halves - both halves read one G_t image of 56 KB, two workgroups = two waves per SIMD on a CU -

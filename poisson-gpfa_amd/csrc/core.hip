@@ -919,6 +919,7 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
   else if (k == "poisson_tiles") c->poisson_tiles = (int)v;
   else if (k == "yt_mix_dbg") c->yt_mix_dbg = (int)v;
   else if (k == "syrk_dbg") c->syrk_dbg = (int)v;
+  else if (k == "syrk_tile") c->syrk_tile = (int)v;
   else if (k == "mix_wide") c->mix_wide = (int)v;
   else if (k == "thin_products") c->thin_products = (int)v;
   else if (k == "copy_kernels") c->copy_kernels = (v != 0.0);

@@ -210,10 +210,20 @@ static int accumulate_split(pgpfa_ctx* c, const CholWS& lw, int nb, int ract, in
     SyrkF16Args a{};
     a.D = D; a.sD = sD; a.ldd = ldd; a.ts = Ts; a.part = c->ppart;
     a.T = T; a.p = p; a.ract = ract; a.nslots = nb; a.sps = sps; a.ngroups = ngroups;
-    a.tiles = (T + 127) / 128; a.ntiles = a.tiles * (a.tiles + 1) / 2; a.dbg = c->syrk_dbg;
+    a.dbg = c->syrk_dbg;
+    // 256 x 256 tiles (half the reads of D per output) where T spans more than one of them and the 16-byte loads of the fast path are allowed
+    const int t256 = (T + 255) / 256;
+    const bool big = c->syrk_tile >= 256 && T > 256 && (Ts & 3) == 0 && (ldd & 3) == 0 && t256 * 256 <= Ts && (((size_t)D) & 15) == 0 && (sD & 3) == 0;
+    a.tiles = big ? t256 : (T + 127) / 128; a.ntiles = a.tiles * (a.tiles + 1) / 2;
     const long long blocks = (long long)a.ntiles * ngroups * p;
     prof_begin(c, TAG_VSM, 3.0 * (double)nb * ract * T * T * p);
-    hipLaunchKernelGGL(syrk_f16x2_kernel, dim3((unsigned)blocks), dim3(256), 0, c->st, a);
+    if (big) {
+      const size_t lds = (size_t)4 * 2 * 256 * 32 * sizeof(_Float16);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&syrk256_f16x2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(syrk256_f16x2_kernel, dim3((unsigned)blocks), dim3(512), lds, c->st, a);
+    } else {
+      hipLaunchKernelGGL(syrk_f16x2_kernel, dim3((unsigned)blocks), dim3(256), 0, c->st, a);
+    }
     prof_end(c);
   }
   // 3. per latent: S_k = sum_r A A^T (r_k x r_k), X_k = sum_r A D_k^T (r_k x T) with A = rows of latent k of L^-T right of column

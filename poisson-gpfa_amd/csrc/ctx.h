@@ -227,6 +227,7 @@ struct pgpfa_ctx {
   int poisson_tiles = 2;                      // option poisson_tiles: 16-bin tiles per wave of the matrix-core Poisson pass up to 10 latents (2: the table fragments of a neuron tile serve two tiles; 1)
   int vsm_b4 = 2;                             // option vsm_b4: post_vsm for 11..20 latents on the 4 x 4 x 4 block shape of the FP64 matrix cores (post_vsm_b4_kernel; 2: 64 bins per workgroup staged with 16-byte loads where the strides allow, 1: 32 bins, scalar loads), 0: the 16 x 16 x 4 form
   int yt_mix = 1;                             // option yt_mix: Yt = F L^-T and the mixing pass of the split form as one kernel up to 10 latents - Yt is never written (ytmix.h)
+  int syrk_tile = 256;                        // option syrk_tile: workgroup tile of the FP16 term of the split sum (256 where T > 256 and the strides allow; 128)
   int syrk_dbg = 0;                           // option syrk_dbg: timing experiments on syrk_f16x2_kernel (parts switched off, results wrong)
   int yt_mix_dbg = 0;                         // option yt_mix_dbg: timing experiments on that kernel (parts switched off, results wrong); never set outside tools/
   int mix_slot = 3;                           // option mix_slot (3: two column halves per bin, two workgroups per CU - mix_slot3_kernel; 2: mix_slot2_kernel): the mixing pass of the split form with a thread per bin and whole columns per workgroup (split.h)

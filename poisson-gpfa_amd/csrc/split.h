@@ -641,6 +641,152 @@ inline __global__ __launch_bounds__(256, 2) void syrk_f16x2_kernel(SyrkF16Args a
   }
 }
 
+// The same sums on 256 x 256 workgroup tiles (round 5).  With its loads freed of address arithmetic the 128-tile kernel above is bound by the stream
+// of D: a (latent, group) panel has T / 128 row blocks and every tile reads two of them - 16 block reads for 4 blocks at T = 500, of which the
+// XCD's L2 catches a quarter (PMC: 3.0 x the operand bytes at 5.8 TB/s).  Tiles of 256 read 4 blocks of 256 rows for 2.  Eight waves of 64 x 128
+// (4 x 8 accumulator tiles = 128 registers), ONE staging register set (the loads of step s + 1 in flight while step s is multiplied), B fragments
+// in two halves of four; two LDS stages of 64 KB.  Fast path only: rows, strides and base allow 16-byte loads (the host checks, syrk_f16x2_kernel
+// otherwise).  grid = tiles256 (tiles256 + 1) / 2 * ngroups * p in the same XCD-aware order, block = 512, dynamic LDS = 128 KB.
+inline __global__ __launch_bounds__(512, 1) void syrk256_f16x2_kernel(SyrkF16Args a) {
+  constexpr int BT = 256, KS = 32, LS = 32;
+  auto lidx = [](int row, int chunk) { return row * LS + ((chunk ^ ((4 - ((row >> 2) & 3)) & 3)) << 3); };
+  extern __shared__ __attribute__((aligned(16))) _Float16 syrk256_lds[];
+  _Float16* Ah = syrk256_lds;                       // [2][BT * LS] each
+  _Float16* Al = Ah + 2 * BT * LS;
+  _Float16* Bh = Al + 2 * BT * LS;
+  _Float16* Bl = Bh + 2 * BT * LS;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;               // rows 64 wm .., columns 128 wn ..
+  const int nbatch = a.ngroups * a.p;
+  int b, tile;
+  {
+    const int bid = blockIdx.x;
+    const int full = nbatch >> 3, per_group = a.ntiles << 3, grp = bid / per_group;
+    if (grp < full) { const int r = bid - grp * per_group; tile = r >> 3; b = (grp << 3) + (r & 7); }
+    else { const int m = nbatch - (full << 3); const int r = bid - full * per_group; tile = r / m; b = (full << 3) + (r - tile * m); }
+  }
+  int tj = 0, rem = tile;
+  while (rem >= a.tiles - tj) { rem -= a.tiles - tj; ++tj; }
+  const int ti = tj + rem;
+  const int k = b / a.ngroups, g = b - k * a.ngroups;
+  const int i0 = ti * BT, j0 = tj * BT;
+  const bool diag = (ti == tj);
+  const int s_begin = g * a.sps, s_end = min(a.nslots, s_begin + a.sps);
+  // a wave's 64 x 128 block is issued unless it lies outside T or strictly above the diagonal
+  const bool wave_live = (i0 + wm * 64 < a.T) && (j0 + wn * 128 < a.T) && !(i0 + wm * 64 + 63 < j0 + wn * 128);
+
+  float4v_t acc[4][8];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 8; ++ni) acc[mi][ni] = float4v_t{0.f, 0.f, 0.f, 0.f};
+
+  // staging: threads 0..255 take the A tile, 256..511 the B tile (idle on diagonal tiles); four consecutive rows and eight of the 32 columns each
+  const bool is_b = tid >= 256;
+  const int rq = tid & 63, co = (tid >> 6) & 3;
+  const int row0 = (is_b ? j0 : i0) + 4 * rq;
+  const bool stage = !(is_b && diag);
+  const int steps_per_slot = (a.ract + KS - 1) / KS;
+  const int nsteps = (s_end - s_begin) * steps_per_slot;
+  int cur_s = s_begin, cur_c = 0;
+  const unsigned voff = (unsigned)(stage ? (co * 8) * a.ldd + row0 : 0) * 4u;
+  float4v_t v[8];
+  auto load_fast = [&]() {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rs = wave_uniform_rsrc(a.D + (size_t)cur_s * a.sD, (size_t)a.ract * a.ldd * sizeof(float));
+    const unsigned soff = (unsigned)(k * a.ts + cur_c * KS * a.ldd) * 4u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)(soff + (unsigned)(j * a.ldd) * 4u), 0);
+      v[j] = float4v_t{__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w)};
+    }
+    if (cur_c + 1 < steps_per_slot) ++cur_c;
+    else if (cur_s + 1 < s_end) { ++cur_s; cur_c = 0; }
+  };
+  auto store = [&](int buf) {
+    if (!stage) return;
+    _Float16* Hh = (is_b ? Bh : Ah) + buf * BT * LS;
+    _Float16* Hl = (is_b ? Bl : Al) + buf * BT * LS;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      half8_t h, l;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float x = v[j][r] * SPLIT_SCALE;
+        const _Float16 hx = (_Float16)x;
+        h[j] = hx;
+        l[j] = (_Float16)(x - (float)hx);
+      }
+      *reinterpret_cast<half8_t*>(&Hh[lidx(4 * rq + r, co)]) = h;
+      *reinterpret_cast<half8_t*>(&Hl[lidx(4 * rq + r, co)]) = l;
+    }
+  };
+  const int l15 = lane & 15, l4 = lane >> 4;
+  auto multiply = [&](int buf) {
+    if (!wave_live) return;
+    const _Float16* As_h = Ah + buf * BT * LS;
+    const _Float16* As_l = Al + buf * BT * LS;
+    const _Float16* Bs_h = (diag ? Ah : Bh) + buf * BT * LS;
+    const _Float16* Bs_l = (diag ? Al : Bl) + buf * BT * LS;
+    half8_t ah[4], al[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int r = lidx(wm * 64 + mi * 16 + l15, l4);
+      ah[mi] = *reinterpret_cast<const half8_t*>(&As_h[r]);
+      al[mi] = *reinterpret_cast<const half8_t*>(&As_l[r]);
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      half8_t bh[4], bl[4];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const int r = lidx(wn * 128 + half * 64 + ni * 16 + l15, l4);
+        bh[ni] = *reinterpret_cast<const half8_t*>(&Bs_h[r]);
+        bl[ni] = *reinterpret_cast<const half8_t*>(&Bs_l[r]);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          float4v_t c = acc[mi][half * 4 + ni];
+          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[ni], ah[mi], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[ni], al[mi], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[ni], ah[mi], c, 0, 0, 0);
+          acc[mi][half * 4 + ni] = c;
+        }
+    }
+  };
+  if (nsteps > 0) {
+    load_fast();
+    store(0);
+    __syncthreads();
+    for (int step = 0; step < nsteps; ++step) {
+      if (step + 1 < nsteps) load_fast();
+      multiply(step & 1);
+      if (step + 1 < nsteps) store((step + 1) & 1);
+      __syncthreads();
+    }
+  }
+  if (!wave_live) return;
+  double* C = a.part + (size_t)(k * a.ngroups + g) * a.T * a.T;
+  const double inv = 1.0 / ((double)SPLIT_SCALE * (double)SPLIT_SCALE);
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int i = i0 + wm * 64 + mi * 16 + l15;
+    if (i >= a.T) continue;
+#pragma unroll
+    for (int ni = 0; ni < 8; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = j0 + wn * 128 + ni * 16 + 4 * l4 + r;
+        if (j >= a.T) continue;
+        C[(size_t)j * a.T + i] = (double)acc[mi][ni][r] * inv;
+      }
+  }
+}
+
 // Cross term of the split form for one latent:  X[g] (rk x T, column-major, ld = rk) = sum over the slots s of group g of
 //   A_s (rk x kw) D_s^T (kw x T),   A_s[i][b] = A[s sM + i + b lda]  (FP64: rows of latent k of L_s^-T right of its first column),
 //                                    D_s[b][t] = D[s sD + b ldd + t]  (the single-precision correction of latent k, its first kw columns used).
