@@ -14,7 +14,10 @@ static int ensure_cdym(pgpfa_ctx* c) {
   if (c->cdym_valid) return 0;
   const int q = c->q, p = c->p, ntr = (int)c->last_trials_h.size();
   const int nbk = std::max(1, std::min(1024, ntr));
-  hipLaunchKernelGGL(cd_ym_kernel, dim3(nbk), dim3(256), 0, c->st, c->Y, c->Yhi, c->Xmode, c->last_trials, ntr, q, p, c->T, c->cdym_part);
+  if (c->mfma && c->cd_mfma && p + 1 <= 16)
+    hipLaunchKernelGGL(cd_ym_mfma_kernel, dim3(nbk), dim3(256), 0, c->st, c->Y, c->Yhi, c->Xmode, c->last_trials, ntr, q, p, c->T, c->cdym_part);
+  else
+    hipLaunchKernelGGL(cd_ym_kernel, dim3(nbk), dim3(256), 0, c->st, c->Y, c->Yhi, c->Xmode, c->last_trials, ntr, q, p, c->T, c->cdym_part);
   hipLaunchKernelGGL(reduce_parts_kernel, dim3(((p + 1) * q + 31) / 32), dim3(256), 0, c->st, c->cdym_part, nbk, (p + 1) * q, c->cdym);
   HIPC(hipGetLastError());
   c->cdym_valid = true;
