@@ -104,38 +104,58 @@ inline __global__ __launch_bounds__(256) void rates_wide_kernel(const uint8_t* _
   if (threadIdx.x == 0) fpart[slot * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// W[slot][t][a][b] = W[slot][t][b][a] = Wp[slot][pair(a,b)][t].  grid = (ceil(T*NP/256), nslots); slots (may be NULL): list of the slots
-inline __global__ void dual_unpack_w_kernel(const double* __restrict__ Wp, long long sWp, double* __restrict__ W, long long sW, int T, int p,
-                                     const int* __restrict__ slots = nullptr) {
-  const int np = p * (p + 1) / 2;
-  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= (size_t)T * np) return;
+// W[slot][t][a][b] = W[slot][t][b][a] = Wp[slot][pair(a,b)][t]: a transpose between the pair-major image of the GEMMs and the per-bin blocks.
+// Through an LDS tile of 32 bins x all pairs (round 5): both sides move in contiguous runs - 256-byte rows of Wp in, whole p x p blocks out (the
+// thread-per-entry form wrote every 8-byte entry into a cache line of its own: 0.76 ms per call at config 5, 88 calls per E-step pair).
+// grid = (ceil(T / nbt), nslots), block = 256, dynamic LDS = np * (nbt + 1) doubles (nbt = dual_tile_bins(...): 32 up to 21 latents);
+// slots (may be NULL): list of the slots
+inline int dual_tile_bins(size_t doubles_per_bin) { int n = 32; while (n > 1 && doubles_per_bin * (n + 1) * sizeof(double) > 60000) n >>= 1; return n; }
+inline __global__ __launch_bounds__(256) void dual_unpack_w_kernel(const double* __restrict__ Wp, long long sWp, double* __restrict__ W, long long sW, int T, int p,
+                                                                  int nbt, const int* __restrict__ slots = nullptr) {
+  extern __shared__ double duw_tile[];                // [np][nbt + 1]
+  const int np = p * (p + 1) / 2, pp = p * p, ldt = nbt + 1;
+  const int t0 = blockIdx.x * nbt, nt = min(nbt, T - t0);
   const size_t slot = slots ? (size_t)slots[blockIdx.y] : (size_t)blockIdx.y;
-  const int c = (int)(e / T), t = (int)(e - (size_t)c * T);
-  int a = 0;
-  while ((a + 1) * (a + 2) / 2 <= c) ++a;
-  const int b = c - a * (a + 1) / 2;
-  const double v = Wp[slot * sWp + e];
-  double* w = W + slot * sW + (size_t)t * p * p;
-  w[a * p + b] = v;
-  w[b * p + a] = v;
+  const double* src = Wp + slot * sWp + t0;
+  for (int e = threadIdx.x; e < np * nbt; e += 256) {
+    const int c = e / nbt, tt = e - c * nbt;
+    duw_tile[c * ldt + tt] = (tt < nt) ? src[(size_t)c * T + tt] : 0.0;
+  }
+  __syncthreads();
+  double* dst = W + slot * sW + (size_t)t0 * pp;
+  for (int e = threadIdx.x; e < nt * pp; e += 256) {
+    const int tt = e / pp, idx = e - tt * pp, a = idx / p, b = idx - a * p;
+    const int hi = a > b ? a : b, lo = a > b ? b : a;
+    dst[e] = duw_tile[(hi * (hi + 1) / 2 + lo) * ldt + tt];
+  }
 }
 
-// Sp[slot][pair][t] = (a == b ? 1 : 2) * Sigma_t[a][b] of the slot's trial, zero rows up to npd.  grid = (ceil(T*npd/256), nslots)
-inline __global__ void dual_pack_sigma_kernel(const double* __restrict__ vsm, const int* __restrict__ trial_of_slot, double* __restrict__ Sp, long long sSp,
-                                       int T, int p, int npd) {
-  const int np = p * (p + 1) / 2;
-  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= (size_t)T * npd) return;
-  const int c = (int)(e / T), t = (int)(e - (size_t)c * T);
-  double v = 0.0;
-  if (c < np) {
-    int a = 0;
-    while ((a + 1) * (a + 2) / 2 <= c) ++a;
-    const int b = c - a * (a + 1) / 2;
-    v = vsm[((size_t)trial_of_slot[blockIdx.y] * T + t) * p * p + a * p + b] * (a == b ? 1.0 : 2.0);
+// Sp[slot][pair][t] = (a == b ? 1 : 2) * Sigma_t[a][b] of the slot's trial, zero rows up to npd: the transpose the other way, through the same kind
+// of LDS tile (whole p x p blocks in, rows of Sp out).  grid = (ceil(T / nbt), nslots), block = 256, dynamic LDS = nbt * (p p + 1) doubles
+inline __global__ __launch_bounds__(256) void dual_pack_sigma_kernel(const double* __restrict__ vsm, const int* __restrict__ trial_of_slot, double* __restrict__ Sp,
+                                                                    long long sSp, int T, int p, int npd, int nbt) {
+  extern __shared__ double dps_tile[];                // [nbt][pp + 1]
+  const int np = p * (p + 1) / 2, pp = p * p, ldt = pp + 1;
+  const int t0 = blockIdx.x * nbt, nt = min(nbt, T - t0);
+  const double* src = vsm + ((size_t)trial_of_slot[blockIdx.y] * T + t0) * pp;
+  for (int e = threadIdx.x; e < nt * pp; e += 256) {
+    const int tt = e / pp, idx = e - tt * pp;
+    dps_tile[tt * ldt + idx] = src[e];
   }
-  Sp[(size_t)blockIdx.y * sSp + e] = v;
+  __syncthreads();
+  double* dst = Sp + (size_t)blockIdx.y * sSp + t0;
+  for (int e = threadIdx.x; e < npd * nbt; e += 256) {
+    const int c = e / nbt, tt = e - c * nbt;
+    if (tt >= nt) continue;
+    double v = 0.0;
+    if (c < np) {
+      int a = 0;
+      while ((a + 1) * (a + 2) / 2 <= c) ++a;
+      const int b = c - a * (a + 1) / 2;
+      v = dps_tile[tt * ldt + a * p + b] * (a == b ? 1.0 : 2.0);
+    }
+    dst[(size_t)c * T + tt] = v;
+  }
 }
 
 // The reference inverts  postPrecision + 1e-6 diag(diag(postPrecision))  (VIPostCov, inference.py:190).  The diagonal of the precision

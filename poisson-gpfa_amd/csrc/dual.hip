@@ -37,8 +37,9 @@ int dual_common(pgpfa_ctx* c, int nb, std::vector<double>* sB, std::vector<doubl
     GemmP v = w;                                             // V (T x p) = (Lambda - Y)^T . TBL[:, latents]   -> c->Xt
     v.A = c->dgrad; v.B = c->dual_tbl + c->dual_npd; v.C = c->Xt; v.sC = ld; v.N = p;
     CHK(gemm(c, false, v));
-    hipLaunchKernelGGL(dual_unpack_w_kernel, dim3((unsigned)(((size_t)T * np + 255) / 256), nb), dim3(256), 0, c->st, c->dual_scr, c->dual_sscr, c->W, sW,
-                       T, p);
+    const int nbu = dual_tile_bins((size_t)np);
+    hipLaunchKernelGGL(dual_unpack_w_kernel, dim3((unsigned)((T + nbu - 1) / nbu), nb), dim3(256), (size_t)np * (nbu + 1) * sizeof(double), c->st, c->dual_scr, c->dual_sscr,
+                       c->W, sW, T, p, nbu);
   } else {
     hipLaunchKernelGGL(dual_prep_kernel, dim3(ntile, nb), dim3(64), 0, c->st, c->Y, c->Yhi, c->C, c->d, c->lamd, (long long)q * T, c->Xt, ld, c->W,
                        (long long)T * p * p, c->dpart, ntile, c->ident, c->trial_of_slot, q, p, T);
@@ -189,8 +190,12 @@ int dual_jitter(pgpfa_ctx* c, int nb) {
 static int dual_gradient(pgpfa_ctx* c, int nb) {
   const int q = c->q, p = c->p, T = c->T;
   if (c->dual_gemm && c->mfma) {
-    hipLaunchKernelGGL(dual_pack_sigma_kernel, dim3((unsigned)(((size_t)T * c->dual_npd + 255) / 256), nb), dim3(256), 0, c->st, c->vsm,
-                       c->trial_of_slot, c->dual_scr, c->dual_sscr, T, p, c->dual_npd);
+    {
+      int nbp = 32;
+      while (nbp > 1 && (size_t)nbp * (p * p + 1) * sizeof(double) > 60000) nbp >>= 1;
+      hipLaunchKernelGGL(dual_pack_sigma_kernel, dim3((unsigned)((T + nbp - 1) / nbp), nb), dim3(256), (size_t)nbp * (p * p + 1) * sizeof(double), c->st, c->vsm,
+                         c->trial_of_slot, c->dual_scr, c->dual_sscr, T, p, c->dual_npd, nbp);
+    }
     GemmP g{};                                               // G (T x q) = -1/2 Sp . TBL[:, pairs]^T
     g.A = c->dual_scr; g.sA = c->dual_sscr; g.lda = T;
     g.B = c->dual_tbl; g.sB = 0; g.ldb = c->dual_ncol;       // K x N column-major: element (pair, n) at n * ncol + pair
@@ -268,8 +273,12 @@ int dual_eval_slots(pgpfa_ctx* c, int nb, const std::vector<int>& tos, bool want
 int var_offsets(pgpfa_ctx* c, int nb, double* out) {
   const int q = c->q, p = c->p, T = c->T;
   if (c->dual_gemm && c->mfma && c->dual_tbl) {
-    hipLaunchKernelGGL(dual_pack_sigma_kernel, dim3((unsigned)(((size_t)T * c->dual_npd + 255) / 256), nb), dim3(256), 0, c->st, c->vsm,
-                       c->trial_of_slot, c->dual_scr, c->dual_sscr, T, p, c->dual_npd);
+    {
+      int nbp = 32;
+      while (nbp > 1 && (size_t)nbp * (p * p + 1) * sizeof(double) > 60000) nbp >>= 1;
+      hipLaunchKernelGGL(dual_pack_sigma_kernel, dim3((unsigned)((T + nbp - 1) / nbp), nb), dim3(256), (size_t)nbp * (p * p + 1) * sizeof(double), c->st, c->vsm,
+                         c->trial_of_slot, c->dual_scr, c->dual_sscr, T, p, c->dual_npd, nbp);
+    }
     GemmP g{};                                               // (T x q) = 1/2 Sp . TBL[:, pairs]^T
     g.A = c->dual_scr; g.sA = c->dual_sscr; g.lda = T;
     g.B = c->dual_tbl; g.sB = 0; g.ldb = c->dual_ncol;

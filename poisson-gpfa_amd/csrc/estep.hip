@@ -43,8 +43,9 @@ int poisson(pgpfa_ctx* c, const int* d_list, int nl, const double* X, double* G,
       GemmP v = w;                                             // G (T x p, i.e. [p][T]) = (Lambda - Y)^T . TBL[:, latents]
       v.A = c->dgrad; v.B = c->dual_tbl + c->dual_npd; v.C = G; v.sC = c->ld; v.N = c->p;
       CHK(gemm(c, false, v));
-      hipLaunchKernelGGL(dual_unpack_w_kernel, dim3((unsigned)(((size_t)c->T * np + 255) / 256), nl), dim3(256), 0, c->st, c->dual_scr, c->dual_sscr, W,
-                         (long long)c->T * c->p * c->p, c->T, c->p, d_list);
+      const int nbu = dual_tile_bins((size_t)np);
+      hipLaunchKernelGGL(dual_unpack_w_kernel, dim3((unsigned)((c->T + nbu - 1) / nbu), nl), dim3(256), (size_t)np * (nbu + 1) * sizeof(double), c->st, c->dual_scr,
+                         c->dual_sscr, W, (long long)c->T * c->p * c->p, c->T, c->p, nbu, d_list);
     }
     hipLaunchKernelGGL(sum_tiles_kernel, dim3((nl + 255) / 256), dim3(256), 0, c->st, c->fpart, a.ntile, d_list, nl, flik);
     HIPC(hipGetLastError());
