@@ -92,6 +92,8 @@ int pgpfa_destroy(pgpfa_ctx* ctx);
  * "vsm_b4" (2, round 5; 1: the same with 32 bins per workgroup and scalar loads: the per-bin covariance blocks post_vsm for 11..20 latents on the 4 x 4 x 4 block shape of the FP64 matrix cores - four bins per
  * instruction, instructions over the lower pairs of four-latent blocks: 15 x 19 cycles per four bins and four columns at 20 latents against 12 x 68 on
  * the 16 x 16 x 4 shape padded to 32 rows; 0: that form),
+ * "pivchol_pairs" (1, round 5: beyond 256 bins the pivoted Cholesky of the Gram matrices runs with two bins per row thread and four column groups -
+ * half the dependent memory round trips per step, the pivot search on the diagonal while it is in registers; same pivots; 0: rbf_pivchol_kernel),
  * "yt_mix" (1, round 5: under the split covariance form and up to 10 latents the product Yt = F L^-T and the mixing pass run as ONE kernel - tiles of all
  * latents on the FP64 matrix cores, mixed in registers, only the correction D and post_vsm leave the chip; Yt is never written; 0: product, then mixing pass),
  * "yt_mix_dbg" (0; bit mask for timing experiments on that kernel - 1 no loads of F, 2 no products, 4 no mixing, 8 no stores of D, 16 no panel staging, 32 no

@@ -651,7 +651,10 @@ int launch_pivchol(pgpfa_ctx* c, hipStream_t st) {
   const int p = c->p, T = c->T, Tp = c->Tp;
   const int rmax = std::min(T, Tp);
   const size_t shm = ((size_t)2 * T + rmax + 16) * sizeof(double) + 16 * sizeof(int);
-  if (T > 256)
+  if (T > 256 && c->pivchol_pairs && Tp % 2 == 0)
+    hipLaunchKernelGGL((rbf_pivchol2_kernel<256, 4>), dim3(p), dim3(1024), pivchol2_lds(T, rmax, 1024, 4), st, c->Flr, Tp, T, c->tau, c->bin, c->eps, c->lr_tol, rmax,
+                       c->d_rank);
+  else if (T > 256)
     hipLaunchKernelGGL((rbf_pivchol_kernel<512, 2>), dim3(p), dim3(1024), shm, st, c->Flr, Tp, T, c->tau, c->bin, c->eps, c->lr_tol, rmax, c->d_rank);
   else
     hipLaunchKernelGGL((rbf_pivchol_kernel<256, 1>), dim3(p), dim3(256), shm, st, c->Flr, Tp, T, c->tau, c->bin, c->eps, c->lr_tol, rmax, c->d_rank);
@@ -915,6 +918,7 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
   else if (k == "overlap_factors") c->overlap_factors = (int)v;
   else if (k == "mix_slot") c->mix_slot = (int)v;
   else if (k == "yt_mix") c->yt_mix = (v != 0.0);
+  else if (k == "pivchol_pairs") c->pivchol_pairs = (v != 0.0);
   else if (k == "vsm_b4") c->vsm_b4 = (int)v;
   else if (k == "poisson_tiles") c->poisson_tiles = (int)v;
   else if (k == "yt_mix_dbg") c->yt_mix_dbg = (int)v;

@@ -226,6 +226,7 @@ struct pgpfa_ctx {
   int mix_wide = 1;                              // 1: the mixing pass of 17..20 latents with lanes along the bins (mix_vsm_wide2_kernel); 0: mix_vsm_wide_kernel
   int poisson_tiles = 2;                      // option poisson_tiles: 16-bin tiles per wave of the matrix-core Poisson pass up to 10 latents (2: the table fragments of a neuron tile serve two tiles; 1)
   int vsm_b4 = 2;                             // option vsm_b4: post_vsm for 11..20 latents on the 4 x 4 x 4 block shape of the FP64 matrix cores (post_vsm_b4_kernel; 2: 64 bins per workgroup staged with 16-byte loads where the strides allow, 1: 32 bins, scalar loads), 0: the 16 x 16 x 4 form
+  int pivchol_pairs = 1;                      // option pivchol_pairs: rbf_pivchol2_kernel (two bins per row thread, four column groups) beyond 256 bins
   int yt_mix = 1;                             // option yt_mix: Yt = F L^-T and the mixing pass of the split form as one kernel up to 10 latents - Yt is never written (ytmix.h)
   int syrk_tile = 256;                        // option syrk_tile: workgroup tile of the FP16 term of the split sum (256 where T > 256 and the strides allow; 128)
   int syrk_dbg = 0;                           // option syrk_dbg: timing experiments on syrk_f16x2_kernel (parts switched off, results wrong)

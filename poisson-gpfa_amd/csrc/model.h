@@ -2170,6 +2170,107 @@ __global__ __launch_bounds__(NT * NS) void rbf_pivchol_kernel(double* __restrict
   if (tid == 0) rank[k] = j;
 }
 
+// The same factorisation with TWO bins per row thread (16-byte loads of the factor columns) and NS = 4 column groups: a step's chain of
+// dependent memory round trips - what it is made of, the work is negligible - is half as long (64 columns per round instead of 32), the
+// pivot search runs on the new diagonal while it is still in registers (one barrier and one LDS sweep less per step).  Same pivots (largest
+// remaining diagonal entry, lowest index on ties); the sums are grouped differently, so the factor agrees with rbf_pivchol_kernel's to rounding.
+// dynamic LDS = pivchol2_lds(T, rmax, NT * NS, NS).  Tf even (rows come in aligned pairs; it is a multiple of 64).
+constexpr size_t pivchol2_lds(int T, int rmax, int threads, int ns) {
+  return ((size_t)((T + 1) & ~1) * ns + rmax + threads / 64 + 2) * sizeof(double) + (size_t)(threads / 64 + 2) * sizeof(int);
+}
+template <int NT, int NS>
+__global__ __launch_bounds__(NT * NS) void rbf_pivchol2_kernel(double* __restrict__ F, int Tf, int T, const double* __restrict__ tau, double bin,
+                                                               double eps, double tol, int rmax, int* __restrict__ rank) {
+  constexpr int NTT = NT * NS, NWR = NT / 64;           // threads; waves of group 0 (the ones that own the diagonal)
+  const int T2 = (T + 1) & ~1;
+  extern __shared__ double sh[];                        // d[T2] | frow[rmax] | wave maxima [NWR] | partial sums [NS - 1][T2] ; int wave argmax [NWR]
+  double* d = sh;
+  double* frow = d + T2;
+  double* rv = frow + rmax;
+  double* psum = rv + NTT / 64 + (rmax & 1);          // (16-byte aligned: its rows are read in pairs)
+  int* ri = reinterpret_cast<int*>(psum + (size_t)(NS - 1) * T2);
+  const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = tid / NT, rt = tid - grp * NT;
+  double* Fk = F + (size_t)k * Tf * Tf;
+  const double den = (tau[k] * 1000.0) * (tau[k] * 1000.0);
+  for (size_t e = tid; e < (size_t)Tf * Tf; e += NTT) Fk[e] = 0.0;
+  for (int t = tid; t < T2; t += NTT) d[t] = t < T ? 1.0 - eps : -1.0;
+  if (tid < NWR) { rv[tid] = tid == 0 ? 1.0 - eps : -1.0; ri[tid] = tid == 0 ? 0 : 0x7fffffff; }     // the first pivot: bin 0
+  __syncthreads();
+  int j = 0;
+  for (; j < rmax; ++j) {
+    double dp = rv[0]; int piv = ri[0];
+#pragma unroll
+    for (int w = 1; w < NWR; ++w)
+      if (rv[w] > dp || (rv[w] == dp && ri[w] < piv)) { dp = rv[w]; piv = ri[w]; }
+    if (!(dp > tol)) break;                                         // (uniform: every thread reads the same LDS values)
+    for (int m = tid; m < j; m += NTT) frow[m] = Fk[(size_t)m * Tf + piv];
+    __syncthreads();
+    const double rs = 1.0 / sqrt(dp);
+    double best = -1.0; int bi = 0x7fffffff;
+    for (int t0 = 0; t0 < T2; t0 += 2 * NT) {                     // (uniform trip count: the barriers below are for every thread)
+      const int t = t0 + 2 * rt;
+      double2_t part = {0.0, 0.0};
+      if (t < T2) {
+        double2_t s0 = {0.0, 0.0}, s1 = s0, s2 = s0, s3 = s0, s4 = s0, s5 = s0, s6 = s0, s7 = s0;
+        const double* col = Fk + t;
+        int m = 8 * grp;
+#pragma unroll 2
+        for (; m + 7 < j; m += 8 * NS) {
+          s0 += *reinterpret_cast<const double2_t*>(col + (size_t)m * Tf) * frow[m];
+          s1 += *reinterpret_cast<const double2_t*>(col + (size_t)(m + 1) * Tf) * frow[m + 1];
+          s2 += *reinterpret_cast<const double2_t*>(col + (size_t)(m + 2) * Tf) * frow[m + 2];
+          s3 += *reinterpret_cast<const double2_t*>(col + (size_t)(m + 3) * Tf) * frow[m + 3];
+          s4 += *reinterpret_cast<const double2_t*>(col + (size_t)(m + 4) * Tf) * frow[m + 4];
+          s5 += *reinterpret_cast<const double2_t*>(col + (size_t)(m + 5) * Tf) * frow[m + 5];
+          s6 += *reinterpret_cast<const double2_t*>(col + (size_t)(m + 6) * Tf) * frow[m + 6];
+          s7 += *reinterpret_cast<const double2_t*>(col + (size_t)(m + 7) * Tf) * frow[m + 7];
+        }
+        // the last, partly filled block of 8 columns belongs to the group whose turn it is
+        for (int mm = m; mm < j && mm < m + 8; ++mm) s0 += *reinterpret_cast<const double2_t*>(col + (size_t)mm * Tf) * frow[mm];
+        part = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
+        if (grp > 0) *reinterpret_cast<double2_t*>(psum + (size_t)(grp - 1) * T2 + t) = part;
+      }
+      __syncthreads();
+      if (t < T2 && grp == 0) {
+        double2_t tot = part;
+#pragma unroll
+        for (int g2 = 1; g2 < NS; ++g2) tot += *reinterpret_cast<const double2_t*>(psum + (size_t)(g2 - 1) * T2 + t);
+        double2_t v;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const double dt = (double)(t + i) * bin - (double)piv * bin;
+          double vi = (1.0 - eps) * exp(-0.5 * ((dt * dt) / den));
+          vi -= tot[i];
+          vi *= rs;
+          v[i] = (t + i < T) ? vi : 0.0;
+        }
+        if (t + 1 < T) *reinterpret_cast<double2_t*>(Fk + (size_t)j * Tf + t) = v;
+        else if (t < T) Fk[(size_t)j * Tf + t] = v[0];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          if (t + i < T) {
+            const double dn = (t + i == piv) ? 0.0 : d[t + i] - v[i] * v[i];
+            d[t + i] = dn;
+            if (dn > best) { best = dn; bi = t + i; }                // (ascending bins: the lowest index wins a tie)
+          }
+        }
+      }
+      if (t0 + 2 * NT < T2) __syncthreads();                        // (psum is rewritten by the next trip)
+    }
+    if (grp == 0) {
+      for (int off = 32; off > 0; off >>= 1) {
+        const double ob = __shfl_down(best, off);
+        const int oi = __shfl_down(bi, off);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+      }
+      if (lane == 0) { rv[wave] = best; ri[wave] = bi; }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) rank[k] = j;
+}
+
 // per (slot, bin): G = (I + eps W)^-1 and Wt = W G.  One thread per matrix, matrices in dynamic LDS.
 // (ldet, optional: ldet[item] = log det(I + eps W_t), item = list position * T + t)
 inline __global__ void bin_blocks_kernel(const double* __restrict__ W, long long sW, double* __restrict__ G, double* __restrict__ Wt, long long sO,

@@ -335,3 +335,36 @@ def test_block_form_of_the_covariance_blocks_matches_the_padded_tiles(dims, f32)
         assert np.max(np.abs(a[0] - b[0]) / np.abs(b[0])) <= 1e-12
         assert np.max(np.abs(a[1] - b[1])) <= 1e-10
         assert np.max(np.abs(a[2] - b[2])) <= 1e-12 * np.max(np.abs(b[2]))
+
+
+@pytest.mark.parametrize('T', [500, 301, 258])
+def test_pivoted_cholesky_with_two_bins_per_thread_finds_the_same_factors(T):
+    """rbf_pivchol2_kernel (beyond 256 bins: two bins per row thread, four column groups, pivot search on the diagonal in registers) against
+    rbf_pivchol_kernel: same ranks (same pivots: the largest remaining diagonal entry, lowest index on ties), and - the sums being grouped
+    differently - E-step results that agree to rounding: objective 1e-12 relative, modes 1e-9, PautoSum 1e-10 of its largest entry.  301 bins:
+    the last row pair is half empty; timescales from 2 to 60 bins: ranks from a handful to most of the bins."""
+    from funs import _hip
+    import bench
+    q, p, R = 40, 4, 8
+    true, Ys = bench.synth_shard(q, p, T, R, 9, 0)
+    Y = np.stack(Ys)
+    tau = np.array([0.02, 0.07, 0.2, 0.6])
+    out = {}
+    for pairs in (1, 0):
+        ctx = _hip.Context(q, p, T, R, 10.0)
+        try:
+            ctx.upload_counts(Y)
+            ctx.set_option('pivchol_pairs', pairs)
+            ctx.set_option('cov_mode', 2)
+            ctx.set_params(true['C'], true['d'], tau)
+            obj, _, status = ctx.estep_laplace()
+            assert np.all(status == 0) and ctx.info('plan_lowrank') == 1.0
+            ctx.mstep_precomp()
+            out[pairs] = (obj, ctx.post_mean().copy(), ctx.pautosum().copy(), ctx.info('lowrank_rtot'))
+        finally:
+            ctx.close()
+    a, b = out[1], out[0]
+    assert a[3] == b[3] and a[3] > 0
+    assert abs(a[0] - b[0]) <= 1e-12 * abs(b[0])
+    assert np.max(np.abs(a[1] - b[1])) <= 1e-9
+    assert np.max(np.abs(a[2] - b[2])) <= 1e-10 * np.max(np.abs(b[2]))
