@@ -81,7 +81,10 @@ def MStepObservationCost_grad(vecCd, xdim, ydim, experiment, infRes):
     return sess.ctx.mstep_cd_costgrad(vecCd)[1]
 
 
-def _newton_cd(sess, x0, prior_center=None, inv_s2=0.0, max_iter=50, xtol=1e-10, verbose=False, hess_key=None):
+CD_EXTRAPOLATE = 2         # start the (C,d) Newton iteration of batch EM one previous displacement ahead (1), continuing the trend of the last two (2); 0: at the parameters handed in (see _newton_cd)
+
+
+def _newton_cd(sess, x0, prior_center=None, inv_s2=0.0, max_iter=50, xtol=1e-10, verbose=False, hess_key=None, extrapolate=False):
     """Exact minimiser of the (C,d) cost by q independent damped Newton iterations (the cost is separable over
     neurons and convex in each (c_n, d_n)); every iteration is one device pass that returns per-neuron cost,
     step and decrement at the current point.  Each neuron backtracks on its own cost.
@@ -98,7 +101,19 @@ def _newton_cd(sess, x0, prior_center=None, inv_s2=0.0, max_iter=50, xtol=1e-10,
         sess._cd_hess_resident = False
     q, D = sess.q, sess.p + 1
     RHO_OLD = 0.1                      # Hessians of the previous EM iteration (other posterior moments)
-    theta = np.array(x0, dtype=np.float64).reshape(D, q)
+    x_in = np.array(x0, dtype=np.float64).reshape(-1)
+    theta = x_in.reshape(D, q).copy()
+    # EM moves (C,d) by nearly the same displacement from one iteration to the next: where the caller hands back exactly the optimum of the
+    # previous M-step (same trial list, same cost), the iteration starts one such displacement further on.  The minimiser is the same (the
+    # cost is convex per neuron and the stopping rule does not look at the start); the first step is several times shorter.
+    track = getattr(sess, '_cd_track', None)
+    if (extrapolate and CD_EXTRAPOLATE and track is not None and track['key'] == hess_key and track['x'].shape == x_in.shape
+            and np.array_equal(track['x'], x_in) and float(np.max(np.abs(track['step']))) < 0.1):
+        ahead = track['step']
+        prev = track.get('prev_step')
+        if CD_EXTRAPOLATE >= 2 and prev is not None and float(np.max(np.abs(ahead - prev))) < 0.5 * float(np.max(np.abs(ahead))):
+            ahead = 2.0 * ahead - prev          # the displacement itself changes smoothly: continue its trend
+        theta = theta + ahead.reshape(D, q)
     state = {'n_full': 0, 'n_chord': 0, 'hess_at': None}
 
     def evaluate(point, want_full):
@@ -162,6 +177,10 @@ def _newton_cd(sess, x0, prior_center=None, inv_s2=0.0, max_iter=50, xtol=1e-10,
         if verbose:
             print('  newton (C,d) it %d: cost %.10g, max step %.3e' % (it + 1, cost.sum(), moved))
     sess._cd_passes = (state['n_full'], state['n_chord'])
+    if extrapolate:
+        chained = track is not None and track['key'] == hess_key and track['x'].shape == x_in.shape and np.array_equal(track['x'], x_in)
+        sess._cd_track = {'key': hess_key, 'x': theta.reshape(-1).copy(), 'step': theta.reshape(-1) - x_in,
+                          'prev_step': track['step'] if chained else None}
     return theta.reshape(-1), float(np.sum(cost)), state['n_full'] + state['n_chord']
 
 
@@ -172,7 +191,7 @@ def learnLTparams(oldParams, infRes, experiment, CdOptimMethod, CdMaxIter=None, 
     ydim, xdim = np.shape(oldParams['C'])
     sess = _resident_session(infRes, experiment, xdim)
     if CdOptimMethod == 'newton':
-        x, fun, _ = _newton_cd(sess, util.CdtoVecCd(oldParams['C'], oldParams['d']), verbose=verbose, hess_key=_trial_key(infRes))
+        x, fun, _ = _newton_cd(sess, util.CdtoVecCd(oldParams['C'], oldParams['d']), verbose=verbose, hess_key=_trial_key(infRes), extrapolate=True)
         newC, newd = util.vecCdtoCd(x, xdim, ydim)
         return newC, newd, fun
     cache = _CostGradCache(lambda v: sess.ctx.mstep_cd_costgrad(v))

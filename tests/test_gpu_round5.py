@@ -368,3 +368,33 @@ def test_pivoted_cholesky_with_two_bins_per_thread_finds_the_same_factors(T):
     assert abs(a[0] - b[0]) <= 1e-12 * abs(b[0])
     assert np.max(np.abs(a[1] - b[1])) <= 1e-9
     assert np.max(np.abs(a[2] - b[2])) <= 1e-10 * np.max(np.abs(b[2]))
+
+
+def test_cd_newton_from_an_extrapolated_start_finds_the_same_minimiser(funs_mod, monkeypatch):
+    """Batch EM with CdOptimMethod='newton': from the second M-step on the (C,d) iteration starts one previous displacement ahead of the
+    parameters it is handed (learning._newton_cd).  The minimiser of the convex per-neuron cost does not depend on the start: five EM
+    iterations with and without give the same parameters (1e-8; each M-step stops on a predicted error of 1e-10) and objectives (1e-10
+    relative), in no more device passes."""
+    funs = funs_mod
+    import bench
+    q, p, T, R = 60, 4, 120, 48
+    true, Ys = bench.synth_shard(q, p, T, R, 5, 0)
+    runs = {}
+    for ext in (2, 1, 0):
+        monkeypatch.setattr(funs.learning, 'CD_EXTRAPOLATE', ext)
+        exp = bench.Shard(Ys, 10.0)
+        sess, _ = funs._session.session_for(exp, p)
+        params = {'C': true['C'] * 0.8, 'd': true['d'] + 0.1, 'tau': np.full(p, 0.2)}
+        optim, hist, passes = None, [], 0
+        for it in range(5):
+            infRes, nll, optim = funs.inference.laplace(exp, params, prevOptimRes=optim)
+            params, _ = funs.learning.updateParams(params, infRes, exp, CdOptimMethod='newton')
+            passes += sum(sess._cd_passes)
+            hist.append((float(nll), params['C'].copy(), params['d'].copy(), params['tau'].copy()))
+        runs[ext] = (hist, passes)
+        funs._session.drop_sessions(exp)
+    assert runs[2][1] <= runs[0][1] and runs[1][1] <= runs[0][1], [runs[k][1] for k in (2, 1, 0)]
+    for a, b in zip(runs[2][0] + runs[1][0], runs[0][0] + runs[0][0]):
+        assert abs(a[0] - b[0]) <= 1e-10 * abs(b[0])
+        for x, y in zip(a[1:], b[1:]):
+            assert np.max(np.abs(x - y)) <= 1e-8
