@@ -337,12 +337,12 @@ def test_block_form_of_the_covariance_blocks_matches_the_padded_tiles(dims, f32)
         assert np.max(np.abs(a[2] - b[2])) <= 1e-12 * np.max(np.abs(b[2]))
 
 
-@pytest.mark.parametrize('T', [500, 301, 258])
+@pytest.mark.parametrize('T', [500, 301, 258, 700])
 def test_pivoted_cholesky_with_two_bins_per_thread_finds_the_same_factors(T):
     """rbf_pivchol2_kernel (beyond 256 bins: two bins per row thread, four column groups, pivot search on the diagonal in registers) against
     rbf_pivchol_kernel: same ranks (same pivots: the largest remaining diagonal entry, lowest index on ties), and - the sums being grouped
     differently - E-step results that agree to rounding: objective 1e-12 relative, modes 1e-9, PautoSum 1e-10 of its largest entry.  301 bins:
-    the last row pair is half empty; timescales from 2 to 60 bins: ranks from a handful to most of the bins."""
+    the last row pair is half empty; 700 bins: two trips of 512 rows per step; timescales from 2 to 60 bins: ranks from a handful to most of the bins."""
     from funs import _hip
     import bench
     q, p, R = 40, 4, 8
