@@ -7,6 +7,7 @@ with the same methods and options as the reference, so early-stopping behaviour 
                  tauMaxIter=None, verbose=False)                       # reference learning.py:295-309
     updateParamsWithPrior(...)  with covOpts='useDiag'                   # reference learning.py:833-866
 """
+import math
 import numpy as np
 import scipy.optimize as op
 
@@ -422,8 +423,9 @@ def _newton_poly_root(X, Y, lo, hi, active=None):
     return z
 
 
-def _lockstep_multi(evaluate_multi, p0, d_hint=None, gtol=1e-8, xtol=1e-10, max_rounds=30, m=4):
-    """Roots of xdim independent increasing functions g_k = f_k' (f_k smooth, one minimum) found together with m
+def _lockstep_multi_np(evaluate_multi, p0, d_hint=None, gtol=1e-8, xtol=1e-10, max_rounds=30, m=4):
+    """(The array form of _lockstep_multi below: the statement of the algorithm, and what tests/test_cpu_host.py holds the scalar form to,
+    bit for bit.)  Roots of xdim independent increasing functions g_k = f_k' (f_k smooth, one minimum) found together with m
     candidate points per latent per round; a round is ONE batched device pass (its cost is launch latency, nearly
     independent of m).  Round 1 spreads its points along the displacement predicted from the previous EM
     iteration (d_hint), later rounds place them in a shrinking cluster around the root of the cubic through the
@@ -573,6 +575,154 @@ class _ConcurrentScalarProblems:
             if isinstance(r, Exception):
                 raise r
         return out
+
+
+def _argmin_first(vals):
+    """np.argmin of a list of floats: the first NaN if there is one, else the first smallest"""
+    best, bi = None, 0
+    for i, v in enumerate(vals):
+        if v != v:
+            return i
+        if best is None or v < best:
+            best, bi = v, i
+    return bi
+
+
+def _poly_roots_scalar(cols):
+    """_newton_poly_root for a list of (X, Y, lo, hi) with plain floats: the same operations in the same order (all problems iterate until all
+    have converged, as the array form does), so the same bits - without forty array operations on ten numbers each."""
+    st = []
+    for X, Y, lo, hi in cols:
+        n = len(X)
+        coef = list(Y)
+        for lvl in range(1, n):
+            coef = coef[:lvl] + [(coef[i] - coef[i - 1]) / (X[i] - X[i - lvl]) for i in range(lvl, n)]
+        st.append([X, coef, lo, hi, 0.5 * (lo + hi)])
+    for _ in range(80):
+        conv = True
+        for q in st:
+            X, coef, a, b, z = q
+            n = len(X)
+            v, dv = coef[n - 1], 0.0
+            for i in range(n - 2, -1, -1):
+                dz = z - X[i]
+                dv = dv * dz + v
+                v = v * dz + coef[i]
+            if v > 0:
+                b = z
+            else:
+                a = z
+            mid = 0.5 * (a + b)
+            if dv != 0.0:
+                zn = z - v / dv
+                if not (math.isfinite(zn) and a <= zn <= b):
+                    zn = mid
+            else:
+                zn = mid
+            tol = 1e-14 * (1.0 + abs(z))
+            if not (abs(zn - z) <= tol or b - a <= tol):
+                conv = False
+            q[2], q[3], q[4] = a, b, zn
+        if conv:
+            break
+    return [q[4] for q in st]
+
+
+def _lockstep_multi(evaluate_multi, p0, d_hint=None, gtol=1e-8, xtol=1e-10, max_rounds=30, m=4):
+    """_lockstep_multi_np with the bookkeeping between two device rounds in plain floats, latent by latent: ten problems of four to twelve
+    samples are a few hundred scalar operations, where the array form spends 1.3 ms per M-step in the overhead of some 450 array calls
+    (a tenth of the M-step at config 3).  Same samples, same decisions, same results bit for bit (tests/test_cpu_host.py)."""
+    if m != 4:
+        return _lockstep_multi_np(evaluate_multi, p0, d_hint, gtol, xtol, max_rounds, m)
+    p0 = [float(v) for v in np.asarray(p0, dtype=np.float64).reshape(-1)]
+    k = len(p0)
+    inf = float('inf')
+    if d_hint is not None:
+        dh = [float(v) for v in np.asarray(d_hint, dtype=np.float64).reshape(-1)]
+        dh = [min(max(v, -1.0), 1.0) if (math.isfinite(v) and abs(v) > 1e-6) else None for v in dh]
+    else:
+        dh = [None] * k
+    first_h, first_u = (0.0, 0.6, 1.0, 1.5), (-1.0, -1.0 / 3, 1.0 / 3, 1.0)
+    offs = (-1.5, -0.5, 0.5, 1.5)
+    Q = [[(p0[j] + first_h[i] * dh[j]) if dh[j] is not None else (p0[j] + 0.25 * first_u[i]) for j in range(k)] for i in range(4)]
+    P = [[] for _ in range(k)]
+    Fv = [[] for _ in range(k)]
+    Gv = [[] for _ in range(k)]
+    done = [False] * k
+    root = list(p0)
+    pred_prev = [None] * k
+    rounds = 0
+    for rounds in range(1, max_rounds + 1):
+        F, G = evaluate_multi(np.array(Q, dtype=np.float64))
+        F, G = np.asarray(F, dtype=np.float64).tolist(), np.asarray(G, dtype=np.float64).tolist()
+        work, info = [], {}
+        Qn = [[0.0] * k for _ in range(4)]
+        for j in range(k):
+            Pj, Gj = P[j], Gv[j]
+            for i in range(4):
+                Pj.append(Q[i][j]); Fv[j].append(F[i][j]); Gj.append(G[i][j])
+            ns = len(Pj)
+            ib = _argmin_first([abs(g) for g in Gj])
+            best_p, best_g = Pj[ib], Gj[ib]
+            if not done[j] and abs(best_g) <= gtol:
+                root[j] = best_p
+                done[j] = True
+            lo, hi = -inf, inf
+            for i in range(ns):
+                if Gj[i] < 0:
+                    if Pj[i] > lo:
+                        lo = Pj[i]
+                elif Gj[i] > 0:
+                    if Pj[i] < hi:
+                        hi = Pj[i]
+            brack = lo > -inf and hi < inf and hi > lo
+            for i in range(4):
+                Qn[i][j] = root[j] + 1e-7 * offs[i]
+            if brack and not done[j]:
+                mid = 0.5 * (lo + hi)
+                order = sorted(range(ns), key=lambda i: abs(Pj[i] - mid))[:4]
+                order.sort(key=lambda i: Pj[i])
+                X, Y = [Pj[i] for i in order], [Gj[i] for i in order]
+                distinct = all(X[i + 1] - X[i] > 0 for i in range(len(X) - 1))
+                glo = max(Gj[i] for i in range(ns) if Gj[i] < 0 and Pj[i] == lo)
+                ghi = min(Gj[i] for i in range(ns) if Gj[i] > 0 and Pj[i] == hi)
+                info[j] = (lo, hi, mid, glo, ghi, distinct)
+                if distinct:
+                    work.append((j, X, Y))
+            elif not done[j]:
+                # no sign change yet: step out geometrically beyond the outermost sample on the downhill side
+                sgn = -1.0 if best_g > 0 else (1.0 if best_g < 0 else 0.0)
+                pmax, pmin = max(Pj), min(Pj)
+                far = pmax if sgn > 0 else pmin
+                span = max(pmax - pmin, 0.1)
+                for i, f in enumerate((0.5, 1.0, 2.0, 4.0)):
+                    Qn[i][j] = far + (sgn * span) * f
+        rp = _poly_roots_scalar([(X, Y, info[j][0], info[j][1]) for j, X, Y in work]) if work else []
+        r_poly = {j: rp[i] for i, (j, _, _) in enumerate(work)}
+        for j, (lo, hi, mid, glo, ghi, distinct) in info.items():
+            r = r_poly.get(j)
+            if r is None or not math.isfinite(r):
+                r = lo - glo * (hi - lo) / (ghi - glo)
+            if not (math.isfinite(r) and lo < r < hi):
+                r = mid
+            w = hi - lo
+            err = None if pred_prev[j] is None else abs(r - pred_prev[j])
+            agree = err is not None and math.isfinite(err) and err <= xtol
+            root[j] = r
+            done[j] = agree or (w <= 4.0 * xtol)
+            delta = min(max(2.0 * err, 4.0 * xtol), 0.02 * w) if (err is not None and math.isfinite(err)) else 0.02 * w
+            if not done[j]:
+                for i in range(4):
+                    Qn[i][j] = r + delta * offs[i]
+            pred_prev[j] = r
+        if all(done):
+            break
+        Q = Qn
+    fo, go = [], []
+    for j in range(k):
+        ib = _argmin_first([abs(v - root[j]) for v in P[j]])
+        fo.append(Fv[j][ib]); go.append(Gv[j][ib])
+    return np.array(root), np.array(fo), np.array(go), rounds, np.array(done, dtype=bool)
 
 
 def learnGPparams(oldParams, infRes, experiment):

@@ -203,6 +203,37 @@ def test_timescale_root_finder_host_logic():
         assert np.max(np.abs(r - bisect(X, Y, lo, hi))[ok]) <= 1e-13
 
 
+def test_scalar_form_of_the_timescale_root_finder_is_the_array_form_bit_for_bit():
+    """learning._lockstep_multi (plain floats, latent by latent: what the M-step runs) against learning._lockstep_multi_np (the array
+    statement of the same algorithm) on 600 random families of convex problems - quartic, cosh and softplus costs; 1 to 11 latents; starts
+    from 0.01 to 5 away; no hint, a good hint, a random one, a hint with gaps, a zero hint: same roots, costs, gradients, rounds and verdicts,
+    bit for bit."""
+    from funs import learning
+    rng = np.random.default_rng(11)
+    for trial in range(600):
+        k = int(rng.integers(1, 12))
+        roots = 2.0 * rng.normal(size=k)
+        a = 0.5 + 3.0 * rng.random(k)
+        c = 0.5 * rng.random(k)
+        kind = trial % 3
+
+        def evaluate(Q):
+            x = np.asarray(Q) - roots[None, :]
+            if kind == 0:
+                return a * (x ** 2 / 2 + c * x ** 4 / 4), a * (x + c * x ** 3)
+            if kind == 1:
+                return a * (np.cosh(x) - 1.0), a * np.sinh(x)
+            return 2.0 * a * (np.log1p(np.exp(x)) + np.log1p(np.exp(-x))), 2.0 * a * np.tanh(x / 2)
+        p0 = roots + (0.01, 0.1, 1.0, 5.0)[trial % 4] * rng.normal(size=k)
+        hint = (None, (roots - p0) * (1.0 + 0.1 * rng.normal(size=k)), rng.normal(size=k), np.where(rng.random(k) < 0.3, np.nan, roots - p0),
+                np.zeros(k))[trial % 5]
+        A = learning._lockstep_multi_np(evaluate, p0, d_hint=hint)
+        B = learning._lockstep_multi(evaluate, p0, d_hint=hint)
+        assert A[3] == B[3] and np.array_equal(A[4], B[4])
+        for x, y in zip(A[:3], B[:3]):
+            assert np.array_equal(x, y)
+
+
 # ---- multi-rank start-up: rendezvous handshake and launcher supervision (no GPU: the unique id is a stub) -----------------
 _RDZV = r"""
 import os, sys, time

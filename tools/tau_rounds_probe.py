@@ -13,16 +13,16 @@ R = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 n_it = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 TRACE = os.environ.get('TAU_TRACE')
 if TRACE:
-    src = inspect.getsource(learning._lockstep_multi).replace("            pred_prev = np.where(work, r, pred_prev)", "            _TR.append(np.where(work, r, np.nan).copy())\n            pred_prev = np.where(work, r, pred_prev)")
+    src = inspect.getsource(learning._lockstep_multi_np).replace("            pred_prev = np.where(work, r, pred_prev)", "            _TR.append(np.where(work, r, np.nan).copy())\n            pred_prev = np.where(work, r, pred_prev)")
     ns = {}
     learning.__dict__['_TR'] = []
     exec(src, learning.__dict__, ns)
-    learning._lockstep_multi = ns['_lockstep_multi']
+    learning._lockstep_multi = ns['_lockstep_multi_np']          # (the array form: same results as the scalar one the M-step runs)
 if len(sys.argv) > 3:
-    src = inspect.getsource(learning._lockstep_multi).replace('offs = np.array([-1.5, -0.5, 0.5, 1.5])', 'offs = np.array([%s])' % sys.argv[3])
+    src = inspect.getsource(learning._lockstep_multi_np).replace('offs = np.array([-1.5, -0.5, 0.5, 1.5])', 'offs = np.array([%s])' % sys.argv[3])
     ns = {}
     exec(src, learning.__dict__, ns)
-    learning._lockstep_multi = ns['_lockstep_multi']
+    learning._lockstep_multi = ns['_lockstep_multi_np']          # (the array form: same results as the scalar one the M-step runs)
 q, p, T = 200, 10, 500
 _, Ys = bench.synth_shard(q, p, T, R, 12, 0)
 exp = bench.Shard(Ys, 10.0)
