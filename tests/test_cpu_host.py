@@ -203,6 +203,82 @@ def test_timescale_root_finder_host_logic():
         assert np.max(np.abs(r - bisect(X, Y, lo, hi))[ok]) <= 1e-13
 
 
+class _SeparableCost:
+    """Stand-in for the device side of the Newton (C,d) driver: q independent convex costs f_n(th) = sum_i w_i exp(x_i . th) - y_n . th over
+    th in R^D, with the methods and return conventions of funs._hip.Context that learning._newton_cd calls (vectors laid out [D][q])."""
+
+    def __init__(self, X, w, Y):
+        self.X, self.w, self.Y = X, w, Y                     # [I][D], [I], [q][D]
+        self.H = None
+        self.calls = {'full': 0, 'chord': 0, 'cost': 0}
+
+    def _parts(self, vec):
+        th = np.asarray(vec, dtype=np.float64).reshape(self.X.shape[1], -1).T            # [q][D]
+        e = self.w[None, :] * np.exp(th @ self.X.T)                                         # [q][I]
+        cost = e.sum(axis=1) - np.einsum('nd,nd->n', self.Y, th)
+        grad = e @ self.X - self.Y
+        return th, e, cost, grad
+
+    def _step(self, grad):
+        delta = -np.stack([np.linalg.solve(self.H[n], grad[n]) for n in range(grad.shape[0])])
+        return delta.T.reshape(-1), -np.einsum('nd,nd->n', grad, delta)
+
+    def mstep_cd_newton_pass(self, vec, prior_center=None, inv_s2=0.0):
+        _, e, cost, grad = self._parts(vec)
+        self.H = np.einsum('ni,id,ie->nde', e, self.X, self.X)
+        self.calls['full'] += 1
+        return (cost,) + self._step(grad)
+
+    def mstep_cd_chord_pass(self, vec, prior_center=None, inv_s2=0.0):
+        _, _, cost, grad = self._parts(vec)
+        self.calls['chord'] += 1
+        return (cost,) + self._step(grad)
+
+    def mstep_cd_cost_per_neuron(self, vec, prior_center=None, inv_s2=0.0):
+        self.calls['cost'] += 1
+        return self._parts(vec)[2]
+
+
+def test_newton_cd_driver_from_an_extrapolated_start(monkeypatch):
+    """learning._newton_cd on a host stand-in for the device passes: a slowly drifting family of separable convex costs, minimised one after the
+    other from the previous minimiser (what batch EM does to the (C,d) update).  Started one displacement ahead (CD_EXTRAPOLATE = 1) or along
+    the trend of the last two (2) the driver lands on the same minimisers as from the parameters it is handed (0) - 1e-9, the gradient there
+    below 1e-8 - and takes fewer device passes; handed anything else than its previous result it does not extrapolate."""
+    import types
+    from funs import learning
+    rng = np.random.default_rng(3)
+    q, D, I = 7, 4, 60
+    X = rng.normal(size=(I, D)) * 0.7
+    Y = np.abs(rng.normal(size=(q, I))) @ X / I * 8.0
+    base = rng.random(I) + 0.5
+    drift = rng.normal(size=I) * 0.6
+    out = {}
+    for mode in (0, 1, 2):
+        monkeypatch.setattr(learning, 'CD_EXTRAPOLATE', mode)
+        sess = types.SimpleNamespace(q=q, p=D - 1, ctx=None)
+        x = np.zeros(D * q)
+        mins, passes = [], 0
+        for it in range(10):
+            sess.ctx = _SeparableCost(X, base * np.exp(drift * (1.0 - 0.85 ** it)), Y)      # displacements that shrink by 15 % per iteration
+            if it:
+                sess.ctx.H = H_prev                                    # the Hessians of the previous M-step stay resident
+            x, fun, n = learning._newton_cd(sess, x, hess_key=b'all', extrapolate=True)
+            H_prev = sess.ctx.H
+            passes += n if it >= 2 else 0
+            grad = sess.ctx._parts(x)[3]
+            assert np.max(np.abs(grad)) <= 1e-8
+            mins.append(x.copy())
+        out[mode] = (mins, passes)
+        # a caller that hands in something else than the previous result gets no extrapolation: the track does not match
+        sess.ctx.calls = {'full': 0, 'chord': 0, 'cost': 0}
+        x2, _, _ = learning._newton_cd(sess, mins[-1] + 1e-3, hess_key=b'all', extrapolate=True)
+        assert np.max(np.abs(x2 - mins[-1])) <= 1e-9
+    for mode in (1, 2):
+        for a, b in zip(out[mode][0], out[0][0]):
+            assert np.max(np.abs(a - b)) <= 1e-9
+    assert out[2][1] <= out[1][1] <= out[0][1] and out[2][1] < out[0][1], [out[m][1] for m in (0, 1, 2)]
+
+
 def test_scalar_form_of_the_timescale_root_finder_is_the_array_form_bit_for_bit():
     """learning._lockstep_multi (plain floats, latent by latent: what the M-step runs) against learning._lockstep_multi_np (the array
     statement of the same algorithm) on 600 random families of convex problems - quartic, cosh and softplus costs; 1 to 11 latents; starts
