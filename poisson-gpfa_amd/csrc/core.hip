@@ -230,9 +230,13 @@ static void arena_init(pgpfa_ctx* c) {
   if (c->vmm != 1) { (void)hipGetLastError(); c->vmm = -1; }
 }
 
-int arena_grow(pgpfa_ctx* c, size_t need) {
+// budget_ms > 0: stop mapping once `must` bytes are there and the call has taken that long (returns 0 with arena_cap < need: the caller plans with what
+// it has).  Mapping is not a fixed price on this stack: 116 GB in 2 ms in the first process on a box, 4.3 s for the same growth in the next one
+// (tools/jump_probe.py, round 6) - pages another process has just given back are cleared before they are handed out again.
+int arena_grow(pgpfa_ctx* c, size_t need, double budget_ms, size_t must) {
   g_err.clear();
   arena_init(c);
+  const auto t_start = std::chrono::steady_clock::now();
   if (c->vmm == 1) {
     const size_t gran = c->vmm_gran;
     // physical chunks of ONE granule each (one hipMemCreate / hipMemMap / hipMemSetAccess per chunk; 1 GiB by default).  Measured on this
@@ -273,6 +277,8 @@ int arena_grow(pgpfa_ctx* c, size_t need) {
       c->arena_cap += add;
       c->bytes += add;
       want -= add;
+      if (budget_ms > 0.0 && c->arena_cap >= must &&
+          std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count() > budget_ms) break;
     }
     c->info["arena_bytes"] = (double)c->arena_cap;
     if (ok) return 0;
@@ -324,6 +330,9 @@ int ensure_workspace(pgpfa_ctx* c, bool plan_lr) {
   // resident set then keeps one chunk with generous rank head-room instead of re-planning as the ranks grow
   const int target = (c->want_slots > 0) ? std::min(c->want_slots, c->R) : c->R;
   if (c->B > 0 && c->plan_lowrank == plan_lr && slab <= c->slab_elems && mt <= c->mt_elems && (c->B >= target || c->B_capped)) return 0;
+  const auto t_plan = std::chrono::steady_clock::now();
+  struct PlanTimer { pgpfa_ctx* c; std::chrono::steady_clock::time_point t0; ~PlanTimer() {
+    c->info["plan_ms_total"] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); c->info["plans"] += 1.0; } } plan_timer{c, t_plan};
   CHK(free_workspace(c));
   c->ws_mark = c->allocs.size();
   c->plan_lowrank = plan_lr;
@@ -343,9 +352,24 @@ int ensure_workspace(pgpfa_ctx* c, bool plan_lr) {
   c->slab_elems = slab;
   c->mt_elems = mt;
   if (plan_lr) {
+    // (round 6) a RE-plan prefers the largest head-room that fits into the memory the arena already holds - re-partitioning costs nothing, mapping may
+    // cost seconds (arena_grow) - and otherwise grows for a quarter of head-room only; the first plan of a context takes the full factor
     const double h = std::max(1.0, c->arena_headroom);
-    const size_t want_slab = std::min(dense, (size_t)((double)slab * h) / 1024 * 1024), want_mt = std::min(dense, (size_t)((double)mt * h * h) / 1024 * 1024);
-    if (per_slot_bytes(c, want_slab, want_mt) * (size_t)std::max(target, 1) <= budget) { c->slab_elems = std::max(slab, want_slab); c->mt_elems = std::max(mt, want_mt); }
+    const size_t shared_b = (3 * ld_bytes(c) + 1024 * (size_t)c->ld * sizeof(double) * 4) + ((size_t)64 << 20);
+    const size_t mapped = c->arena_cap > shared_b ? c->arena_cap - shared_b : 0;
+    auto sized = [&](double hh, size_t* ws, size_t* wm) {
+      *ws = std::max(slab, std::min(dense, (size_t)((double)slab * hh) / 1024 * 1024));
+      *wm = std::max(mt, std::min(dense, (size_t)((double)mt * hh * hh) / 1024 * 1024));
+      return per_slot_bytes(c, *ws, *wm) * (size_t)std::max(target, 1);
+    };
+    double pick = c->arena_cap > 0 ? std::min(h, 1.25) : h;
+    if (c->arena_cap > 0)
+      for (double hh : {h, 1.75, 1.5, 1.25, 1.1}) {
+        size_t ws, wm;
+        if (hh <= h && sized(hh, &ws, &wm) <= mapped) { pick = hh; break; }
+      }
+    size_t want_slab, want_mt;
+    if (sized(pick, &want_slab, &want_mt) <= budget) { c->slab_elems = want_slab; c->mt_elems = want_mt; }
   }
   const size_t per = per_slot_bytes(c, c->slab_elems, c->mt_elems);
   long long B = (long long)(budget / per);
@@ -410,18 +434,58 @@ int ensure_workspace(pgpfa_ctx* c, bool plan_lr) {
   CHK(dmalloc(c, &c->ident, nB));
   return 0;
   };
-  c->arena_mode = 1; c->arena_off = 0;
-  int rc_carve = carve();
-  c->arena_mode = 0;
-  if (rc_carve) return rc_carve;
-  const size_t need = c->arena_off + ((size_t)1 << 20);
+  int rc_carve = 0;
+  auto measure = [&](int nslots, size_t* bytes) -> int {
+    c->B = nslots;
+    c->arena_mode = 1; c->arena_off = 0;
+    const int rc = carve();
+    c->arena_mode = 0;
+    *bytes = c->arena_off + ((size_t)1 << 20);
+    return rc;
+  };
+  size_t need = 0;
+  CHK(measure(c->B, &need));
   if (need > c->arena_cap) {
     HIPC(hipStreamSynchronize(c->st));
-    if (arena_grow(c, need)) {
+    // (round 6) growth under a time budget (option workspace_grow_budget_ms): whatever it costs the arena gets what `floor_slots` slots need; beyond that
+    // mapping stops when the budget is spent and the chunk takes the slots that fit - two chunks of 512 trials cost a few per cent, mapping 100 GB of
+    // pages another process has just released costs seconds
+    const int B_full = c->B;
+    const int floor_slots = std::min(B_full, std::max(8, c->grow_floor_slots));
+    size_t must = need;
+    if (floor_slots < B_full) CHK(measure(floor_slots, &must));
+    const auto t_grow = std::chrono::steady_clock::now();
+    const size_t cap_before = c->arena_cap;
+    // (the first plan of a context is not bounded: a fit that starts is better off with its whole arena than with a few slow first iterations)
+    const int rc_grow = arena_grow(c, need, cap_before > 0 ? c->grow_budget_ms : 0.0, must);
+    const double grow_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_grow).count();
+    c->info["arena_grow_ms_total"] += grow_ms;
+    if (std::getenv("PGPFA_PLAN_TRACE"))
+      std::fprintf(stderr, "pgpfa: plan %s, %d slots: arena %.1f -> %.1f GB (asked %.1f) in %.0f ms\n", plan_lr ? "low-rank" : "dense", B_full, (double)cap_before / 1e9,
+                   (double)c->arena_cap / 1e9, (double)need / 1e9, grow_ms);
+    if (rc_grow) {
       c->B = 0;
       const std::string why = g_err;
       return fail("not enough device memory for the chunk workspace (%zu bytes needed, %zu free)%s%s", need, free_b, why.empty() ? "" : ": ", why.c_str());
     }
+    int B_fit = B_full;
+    if (c->arena_cap < need) {
+      // the budget ran out: the largest balanced chunk that fits what is mapped
+      const double per_b = (double)(need - must) / (double)std::max(1, B_full - floor_slots);
+      B_fit = floor_slots + (int)((double)(c->arena_cap - must) / std::max(per_b, 1.0));
+      B_fit = std::max(floor_slots, std::min(B_full, B_fit / 8 * 8));
+      const int nchunks = (target + B_fit - 1) / B_fit;
+      B_fit = std::max(floor_slots, std::min(B_fit, ((target + nchunks - 1) / nchunks + 7) / 8 * 8));
+      for (;;) {
+        CHK(measure(B_fit, &need));
+        if (need <= c->arena_cap || B_fit <= floor_slots) break;
+        B_fit = std::max(floor_slots, B_fit - 8);
+      }
+      if (need > c->arena_cap) { c->B = 0; return fail("workspace arena short of its floor (%zu bytes needed, %zu mapped)", need, c->arena_cap); }
+      // half the list per chunk is good enough to stay with until the ranks ask for a new plan; less than that keeps growing at every call
+      c->B_capped = 2 * B_fit >= target;
+    }
+    c->B = B_fit;
   }
   c->arena_mode = 2; c->arena_off = 0;
   rc_carve = carve();
@@ -434,6 +498,9 @@ int ensure_workspace(pgpfa_ctx* c, bool plan_lr) {
   if (plan_lr) c->mt_dirty = true;
   c->info["chunk_trials"] = c->B;
   c->info["plan_lowrank"] = c->plan_lowrank ? 1.0 : 0.0;
+  if (std::getenv("PGPFA_PLAN_TRACE"))
+    std::fprintf(stderr, "pgpfa: plan %s, %d slots (target %d), slab %zu + %zu elements, %.1f GB carved, %.0f ms\n", plan_lr ? "low-rank" : "dense", c->B, target,
+                 c->slab_elems, c->mt_elems, (double)need / 1e9, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_plan).count());
   return 0;
 }
 
@@ -867,6 +934,8 @@ int pgpfa_create(pgpfa_ctx** out, int device, int q, int p, int T, int R, double
   c->info["last_eps_wt_rms"] = 0.0;
   c->info["last_split_cov"] = 0.0;
   c->info["last_yt_mix_fused"] = 0.0;
+  for (const char* k : {"plan_ms_total", "plans", "set_params_calls", "last_retry_ms", "last_dense_retries", "last_param_step", "last_param_step_prev",
+                        "last_fallback_no_descent", "last_fallback_line_search", "last_fallback_outer_cap", "arena_grow_ms_total", "last_cold_restarts"}) c->info[k] = 0.0;
   *out = c;
   return 0;
 }
@@ -945,6 +1014,8 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
   else if (k == "dual_gemm") c->dual_gemm = (v != 0.0);
   else if (k == "extrapolate_start") c->extrapolate = (v != 0.0);
   else if (k == "extrapolate_beta") c->extrapolate_beta = v;
+  else if (k == "extrapolate_guard") c->extrapolate_guard = v;
+  else if (k == "start_guard") c->start_guard = (v != 0.0);
   else if (k == "shared_min") c->shared_min = (int)v;
   else if (k == "pcg_inner") c->pcg_inner_max = std::max(1, (int)v);
   else if (k == "pcg_eta0") c->pcg_eta0 = v;
@@ -959,6 +1030,8 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
   else if (k == "chord_max") c->chord_max = (int)v;
   else if (k == "chunk_trials") { if (c->B > 0) return fail("chunk_trials must be set before the first E-step"); c->chunk_opt = (int)v; }
   else if (k == "workspace_headroom") c->arena_headroom = std::max(1.0, v);
+  else if (k == "workspace_grow_budget_ms") c->grow_budget_ms = v;
+  else if (k == "workspace_grow_floor_slots") c->grow_floor_slots = std::max(1, (int)v);
   else if (k == "workspace_granule_mb") c->vmm_granule = (size_t)std::max(2.0, v) << 20;
   else if (k == "workspace_vmm") { if (c->arena_cap > 0) return fail("workspace_vmm must be set before the first E-step"); c->vmm = (v != 0.0) ? 0 : -1; }
   else if (k == "eps_noise") c->eps = v;
@@ -1180,6 +1253,7 @@ int pgpfa_set_params(pgpfa_ctx* c, const double* C, const double* d, const doubl
   }
   CHK(build_lowrank(c, side));
   c->have_params = true;
+  c->info["set_params_calls"] += 1.0;
   return 0;
 }
 

@@ -101,6 +101,16 @@ struct pgpfa_ctx {
   int estep_serial = 0;
   bool extrapolate = true;
   double extrapolate_beta = 1.0;
+  // (round 6) The extrapolated start m_k-1 + beta (m_k-1 - m_k-2) predicts the new mode when the parameters keep moving the way they moved between
+  // the last two E-steps.  After a JUMP of the parameters (cross-validation folds, a second fit in one process, a fit evaluated at other parameters)
+  // the difference m_k-1 - m_k-2 is the jump's effect and adding it again throws every start point far out: the E-step behind a jump took 2.2 s where
+  // a cold one takes 0.12 (profiles/r05_bench_c3_driver_protocol.json, plateau.estep_ms_of_the_four).  The displacement of the parameters between
+  // consecutive Laplace E-steps is tracked (par_step: relative, the largest of C, d, tau) and the extrapolation is only used while the step
+  // that produced m_k-1 - m_k-2 was not much longer than the one being taken (extrapolate_guard; 0 switches the test off).
+  std::vector<double> estepC, estepd, esteptau;  // parameters of the last Laplace E-step
+  double par_step = -1.0, par_step_prev = -1.0;  // |theta_k - theta_k-1|, |theta_k-1 - theta_k-2| (relative; < 0: unknown)
+  double extrapolate_guard = 3.0;
+  bool start_guard = true;                       // a warm start whose objective is above the cold start's (x = 0) is replaced by zero (estep.hip)
   double* vsm = nullptr;                         // [R][T][p][p]
   double* vsmgp = nullptr;                       // [R][p][T][T]
   double* Pauto = nullptr;                       // [p][Tp][Tp]
@@ -155,6 +165,8 @@ struct pgpfa_ctx {
   double n_trials_global = 0.0;
   // chunk workspace
   int B = 0;
+  double grow_budget_ms = 200.0;                  // time a plan may spend mapping memory beyond what grow_floor_slots slots need (0: no limit)
+  int grow_floor_slots = 128;
   int want_slots = 0;                             // largest trial list an E-step-like call has asked for
   bool B_capped = false;
   CholWS ws{};
@@ -382,7 +394,7 @@ bool want_lowrank(const pgpfa_ctx* c);
 size_t ld_bytes(const pgpfa_ctx* c);
 size_t per_slot_bytes(const pgpfa_ctx* c, size_t slab_elems, size_t mt_elems);
 int free_workspace(pgpfa_ctx* c);
-int arena_grow(pgpfa_ctx* c, size_t need);
+int arena_grow(pgpfa_ctx* c, size_t need, double budget_ms = 0.0, size_t must = 0);
 void arena_release(pgpfa_ctx* c, bool unmap = false);
 int ensure_workspace(pgpfa_ctx* c, bool plan_lr);
 int upload_list(pgpfa_ctx* c, int* dst, const std::vector<int>& v);

@@ -367,6 +367,40 @@ static int shared_factor(pgpfa_ctx* c, int nb) {
 // H (from the W blocks of slots [0,nb), diagonal scaled by diag_scale) -> factor -> L^-T -> post_vsmGP and
 // post_vsm of the trials bound to the slots.  Shared by the Laplace and the dual-variational E-step.
 
+// The reference's negative log-posterior (inference.py:12-32) of a slot's trial AT x = 0: f0 = sum_n (T exp(d_n) - d_n sum_t y_nt), the objective of
+// the cold start - what a warm start has to beat (estep_impl: a start point that does worse is replaced by zero).  One pass over the slot's count
+// rows (q T bytes).  grid = (slots), block = 256 (a wave per neuron row); mask (may be null): the neuron a leave-one-out item leaves out.
+static __global__ __launch_bounds__(256) void cold_objective_kernel(const uint8_t* __restrict__ Y, const uint8_t* __restrict__ Yhi, const double* __restrict__ d,
+                                                                    const int* __restrict__ trial_of_slot, const int* __restrict__ mask, int q, int T,
+                                                                    double* __restrict__ f0) {
+  __shared__ double red[4];
+  const int s = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t base = (size_t)trial_of_slot[s] * q * T;
+  const int skip = mask ? mask[s] : -1;
+  double acc = 0.0;
+  for (int n = wave; n < q; n += 4) {
+    if (n == skip) continue;
+    unsigned cnt = 0;
+    const uint8_t* row = Y + base + (size_t)n * T;
+    for (int t = lane; t < T; t += 64) cnt += row[t];
+    if (Yhi) {
+      const uint8_t* rh = Yhi + base + (size_t)n * T;
+      for (int t = lane; t < T; t += 64) cnt += (unsigned)rh[t] << 8;
+    }
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
+    if (lane == 0) acc += (double)T * exp(d[n]) - d[n] * (double)cnt;
+  }
+  if (lane == 0) red[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) f0[s] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// X[slot][0 .. n) = 0 for the listed slots.  grid = (ceil(n / 256), listed slots)
+static __global__ void zero_rows_kernel(double* __restrict__ X, long long ld, int n, const int* __restrict__ list) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) X[(size_t)list[blockIdx.y] * ld + i] = 0.0;
+}
+
 int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow_lr, double* obj_sum, int32_t* iters, int32_t* status,
                       const LooJob* loo, const VarJob* var) {
   PhaseRange range_estep(var ? "pgpfa.dual_fixed_point" : loo ? "pgpfa.loo_mode_search" : "pgpfa.estep_laplace");
@@ -385,6 +419,8 @@ int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow_lr, do
   double newton_bytes_survey = 0.0;                   // the same slot-iterations priced by SURVEY 8(d)'s B_E = q T s_y + 8 (2 p T + T p^2) per pass per trial
   std::vector<std::pair<hipEvent_t, hipEvent_t>> newton_ev;   // events around every inner solve (the Newton-solve kernels)
   int max_it_seen = 0;
+  double n_cold = 0.0;                                          // warm starts replaced by zero (start_guard)
+  double n_fb_dir = 0.0, n_fb_search = 0.0, n_fb_cap = 0.0;   // slots the shared-preconditioner phase gave up on: no descent direction, line search exhausted, outer cap
   std::vector<double> f(c->B), qxx(c->B), qdx(c->B), qdd(c->B), dec(c->B), smax(c->B), alpha(c->B), ftry(c->B);
   std::vector<int> its(c->B), stat(c->B), info(c->B);
 
@@ -401,6 +437,8 @@ int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow_lr, do
     const size_t mlam = (size_t)c->q * T;
     std::vector<double> vdelta(nb, 0.0), vdelta_prev(nb, -1.0), vdamp(nb, 1.0);
     std::vector<int> vstat(nb, 1), vouter(nb, 0), vslow(nb, 0);
+    std::vector<int> how(nb, 0);                  // start point of a slot: 0 cold (zero), 1 the resident mode, 2 its extrapolation
+    bool any_warm = false;
     // (error paths of the fixed point: the passes have overwritten the per-bin blocks of the chunk's trials - whatever posterior they had is gone)
     auto var_superseded = [&]() {
       for (int t : tos) { c->trial_dual[t] = 0; c->trial_snap[t] = -1; c->vsmgp_ok[t] = 0; c->lam_resident[t] = 0; c->lam_valid[t] = 0; }
@@ -436,15 +474,18 @@ int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow_lr, do
     } else {
       // start points: cold (zero), the resident mode, or its extrapolation; warm_start = 2 takes the resident mode only
       // for trials some earlier E-step has produced one for (minibatches revisiting trials) and starts the others cold
-      std::vector<int> how(nb, 0);
       bool any = false;
+      // (the difference of the last two modes is only a prediction while the parameters keep their pace: ctx.h, extrapolate_guard)
+      const bool trend_ok = c->extrapolate && (c->extrapolate_guard <= 0.0 || (c->par_step > 0.0 && c->par_step_prev >= 0.0 &&
+                                                                                 c->par_step_prev <= c->extrapolate_guard * c->par_step));
       for (int s = 0; s < nb && warm_start; ++s) {
         const int tr_ = tos[s];
         if (warm_start == 2 && c->mode_serial[tr_] < 0) continue;
         how[s] = 1;
-        if (c->extrapolate && c->mode_serial[tr_] == c->estep_serial - 1 && c->prev_serial[tr_] == c->estep_serial - 2) how[s] = 2;
+        if (trend_ok && c->mode_serial[tr_] == c->estep_serial - 1 && c->prev_serial[tr_] == c->estep_serial - 2) how[s] = 2;
         any = true;
       }
+      any_warm = any;
       if (any) {
         CHK(upload_list(c, c->list_a, how));
         hipLaunchKernelGGL(gather_start_kernel, dim3((nvec + 255) / 256, nb), dim3(256), 0, c->st, c->Xmode, c->Xprev, nvec, c->Xc, ld,
@@ -456,15 +497,40 @@ int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow_lr, do
     std::vector<int> active;
     for (int vo = 0;; ++vo) {                     // (one pass for the Laplace E-step; the variational fixed point comes back here with new offsets)
     // objective, gradient pieces and curvature blocks at the start point
-    CHK(prior_mv_all(c, nb, c->Xc, c->KX));
-    hipLaunchKernelGGL(dots3_kernel, dim3(nb), dim3(256), 0, c->st, c->Xc, ld, c->KX, ld, (const double*)nullptr, 0LL,
-                       (const double*)nullptr, 0LL, nvec, c->ident, c->sc_qxx, c->sc_qdx, c->sc_qdd);
-    CHK(poisson(c, c->ident, nb, c->Xc, c->Gl, c->W, c->sc_f, 1));
-    CHK(dl_enqueue(c, f.data(), c->sc_f, nb * sizeof(double)));
-    CHK(download(c, qxx.data(), c->sc_qxx, nb));
+    auto eval_start = [&]() -> int {
+      CHK(prior_mv_all(c, nb, c->Xc, c->KX));
+      hipLaunchKernelGGL(dots3_kernel, dim3(nb), dim3(256), 0, c->st, c->Xc, ld, c->KX, ld, (const double*)nullptr, 0LL,
+                         (const double*)nullptr, 0LL, nvec, c->ident, c->sc_qxx, c->sc_qdx, c->sc_qdd);
+      CHK(poisson(c, c->ident, nb, c->Xc, c->Gl, c->W, c->sc_f, 1));
+      CHK(dl_enqueue(c, f.data(), c->sc_f, nb * sizeof(double)));
+      CHK(download(c, qxx.data(), c->sc_qxx, nb));
+      for (int s = 0; s < nb; ++s) f[s] += 0.5 * qxx[s];
+      return 0;
+    };
+    if (vo == 0 && !var && any_warm && c->start_guard) {
+      // (enqueued ahead of the evaluation: its result comes back with that one's read-back)
+      hipLaunchKernelGGL(cold_objective_kernel, dim3(nb), dim3(256), 0, c->st, c->Y, c->Yhi, c->d, c->trial_of_slot,
+                         c->mask_active ? c->mask_of_slot : (const int*)nullptr, c->q, T, c->sc_alpha);
+      CHK(dl_enqueue(c, ftry.data(), c->sc_alpha, nb * sizeof(double)));
+    }
+    CHK(eval_start());
+    if (vo == 0 && !var && any_warm && c->start_guard) {
+      // A warm start that does worse than x = 0 is no start: after a jump of the parameters (another fold's fit, the generating parameters, a second
+      // fit in one process) the resident modes belong to other loadings - log rates of +-100, a curvature the single-precision copies cannot hold -
+      // and 931 of 1024 trials went through the dense per-trial retry (1.8 s where a cold E-step takes 0.12: tools/jump_probe.py).  Those slots
+      // restart at zero; the objective is strictly convex, the start point never changes the mode.
+      std::vector<int> cold;
+      for (int s = 0; s < nb; ++s)
+        if (how[s] != 0 && !(f[s] <= ftry[s])) cold.push_back(s);
+      if (!cold.empty()) {
+        CHK(upload_list(c, c->list_b, cold));
+        hipLaunchKernelGGL(zero_rows_kernel, dim3((nvec + 255) / 256, (unsigned)cold.size()), dim3(256), 0, c->st, c->Xc, ld, nvec, c->list_b);
+        CHK(eval_start());
+        n_cold += (double)cold.size();
+      }
+    }
     active.clear();
     for (int s = 0; s < nb; ++s) {
-      f[s] += 0.5 * qxx[s];
       if (vo == 0) its[s] = 0;
       if (var && vstat[s] != 1) continue;         // (this slot's fixed point is settled)
       active.push_back(s);
@@ -913,13 +979,14 @@ int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow_lr, do
         {
           std::vector<char> in_cand(nb, 0);
           for (int s : cand) in_cand[s] = 1;
-          for (int s : active) if (!in_cand[s] || bad[s]) fallback.push_back(s);
+          for (int s : active) if (!in_cand[s] || bad[s]) { fallback.push_back(s); if (bad[s]) n_fb_search += 1; else n_fb_dir += 1; }
         }
         active.swap(next);
         leftovers.insert(leftovers.end(), fallback.begin(), fallback.end());
         max_it_seen = std::max(max_it_seen, outer + 1);
       }
       // anything still active after the outer cap also goes to the fallback
+      n_fb_cap += (double)active.size();
       leftovers.insert(leftovers.end(), active.begin(), active.end());
       active = leftovers;
       std::sort(active.begin(), active.end());
@@ -1137,6 +1204,10 @@ int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow_lr, do
   c->info["last_shared_factorizations"] = n_shared;
   c->info["last_cov_lowrank"] = c->last_cov_lowrank ? 1.0 : 0.0;
   c->info["last_newton_max_iter"] = max_it_seen;
+  c->info["last_cold_restarts"] = n_cold;
+  c->info["last_fallback_no_descent"] += n_fb_dir;            // (summed over the passes of one E-step: pgpfa_estep_laplace resets them)
+  c->info["last_fallback_line_search"] += n_fb_search;
+  c->info["last_fallback_outer_cap"] += n_fb_cap;
   if (c->time_newton) {
     // (every chunk ended on a stream synchronisation: the events are complete)
     double nms = 0.0;
@@ -1168,7 +1239,27 @@ int pgpfa_estep_laplace(pgpfa_ctx* c, int n, const int32_t* idx, int warm_start,
   HIPC(hipMemsetAsync(c->Pacc, 0, (size_t)c->Tp * c->Tp * c->p * sizeof(double), c->st));
   snapshot_params(c, tr.v);
   for (int t : tr.v) c->trial_dual[t] = 0;
+  {
+    // how far the parameters have moved since the last Laplace E-step (relative: the largest of |dC| / |C|, |dd| / |d|, |d log tau|) - the start
+    // points are only extrapolated while that pace holds (ctx.h, extrapolate_guard)
+    double step = -1.0;
+    if (c->estepC.size() == c->hC.size() && c->estepd.size() == c->hd.size() && c->esteptau.size() == c->htau.size() && !c->hC.empty()) {
+      auto rel = [](const std::vector<double>& a, const std::vector<double>& b) {
+        double num = 0.0, den = 0.0;
+        for (size_t i = 0; i < a.size(); ++i) { num += (a[i] - b[i]) * (a[i] - b[i]); den += b[i] * b[i]; }
+        return std::sqrt(num) / std::max(std::sqrt(den), 1e-300);
+      };
+      step = std::max(rel(c->hC, c->estepC), rel(c->hd, c->estepd));
+      for (size_t k = 0; k < c->htau.size(); ++k) step = std::max(step, std::fabs(std::log(c->htau[k] / c->esteptau[k])));
+      if (!std::isfinite(step)) step = -1.0;
+    }
+    c->par_step_prev = c->par_step; c->par_step = step;
+    c->estepC = c->hC; c->estepd = c->hd; c->esteptau = c->htau;
+    c->info["last_param_step"] = c->par_step; c->info["last_param_step_prev"] = c->par_step_prev;
+    c->info["last_fallback_no_descent"] = 0.0; c->info["last_fallback_line_search"] = 0.0; c->info["last_fallback_outer_cap"] = 0.0;
+  }
   CHK(estep_impl(c, tr, warm_start, true, &obj, it1.data(), st1.data()));
+  c->info["last_retry_ms"] = 0.0;
   // trials the low-rank plan could not finish (its shared-preconditioner Newton gave up on them and the per-trial
   // fallback needs full-size slabs) are redone under the dense plan, warm-started from where they stopped
   Trials retry;
@@ -1187,7 +1278,15 @@ int pgpfa_estep_laplace(pgpfa_ctx* c, int n, const int32_t* idx, int warm_start,
       CHK(pgpfa_laplace_eval(c, (int)ridx.size(), ridx.data(), X.data(), fv.data(), nullptr));
       for (double v : fv) obj_bad += v;
     }
-    CHK(estep_impl(c, retry, 1, false, &obj_redo, it2.data(), st2.data()));
+    {
+      // the dense plan of this pass is sized for the retry list, not for the largest list the context has seen (a plan for 1024 dense slabs maps and
+      // clears > 200 GB: seconds); the next E-step re-partitions the arena for its own plan
+      const auto t_retry = std::chrono::steady_clock::now();
+      struct WantGuard { pgpfa_ctx* c; int keep; ~WantGuard() { c->want_slots = keep; } } want_guard{c, c->want_slots};
+      c->want_slots = 0;
+      CHK(estep_impl(c, retry, 1, false, &obj_redo, it2.data(), st2.data()));
+      c->info["last_retry_ms"] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_retry).count();
+    }
     obj += obj_redo - obj_bad;
     for (size_t j = 0; j < pos.size(); ++j) { it1[pos[j]] += it2[j]; st1[pos[j]] = st2[j]; }
     c->info["last_dense_retries"] = (double)retry.v.size();
@@ -1230,7 +1329,11 @@ int pgpfa_loo_predict(pgpfa_ctx* c, int n, const int32_t* idx, double* y_pred, d
     std::vector<double> yp2((size_t)M * T), err2(M);
     std::vector<int32_t> st2(M), it2(M);
     LooJob job2{&redo_mask, yp2.data(), err2.data()};
-    CHK(estep_impl(c, redo, 0, false, nullptr, it2.data(), st2.data(), &job2));
+    {
+      struct WantGuard { pgpfa_ctx* c; int keep; ~WantGuard() { c->want_slots = keep; } } want_guard{c, c->want_slots};
+      c->want_slots = 0;                    // (dense plan for the redo list only: see pgpfa_estep_laplace)
+      CHK(estep_impl(c, redo, 0, false, nullptr, it2.data(), st2.data(), &job2));
+    }
     for (int j = 0; j < M; ++j) {
       std::copy(yp2.begin() + (size_t)j * T, yp2.begin() + (size_t)(j + 1) * T, y_pred + (size_t)pos[j] * T);
       err[pos[j]] = err2[j];
