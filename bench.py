@@ -425,7 +425,10 @@ def run_online(args, q, p, T, rank, world):
     prior = np.diag(np.ones(q * (p + 1)))
     est, mst, nlls, pcgs, idx_sum = [], [], [], [], []
     cd_method = args.cd_method
+    tau_method = [args.tau_method]
     state = {'n': 0}
+    nwt = {'ms': [], 'moved': []}
+    sess.ctx.set_option('time_newton', 1)
 
     def step():
         n = state['n']
@@ -434,12 +437,13 @@ def run_online(args, q, p, T, rank, world):
         infRes, nll, _ = funs.inference.laplace(sub, params_box[0], prevOptimRes='resident')
         t1 = time.time()
         sz = 1.0 / (n + 1) ** 0.75                                       # engine.py:275-278, stepPow = 0.75
-        new, _, pr = funs.learning.updateParamsWithPrior(params_box[0], infRes, sub, cd_method, 'TNC', sz, sz, prior_box[0], covOpts='useDiag')
+        new, _, pr = funs.learning.updateParamsWithPrior(params_box[0], infRes, sub, cd_method, tau_method[0], sz, sz, prior_box[0], covOpts='useDiag')
         t2 = time.time()
         params_box[0], prior_box[0] = new, pr
         est.append((t1 - t0) * 1e3); mst.append((t2 - t1) * 1e3); nlls.append(float(nll))
         pcgs.append(sess.ctx.info('last_pcg_iterations') / max(1, len(infRes.trial_idx)))
         idx_sum.append(int(np.sum(sub.batchTrIdx)))
+        nwt['ms'].append(sess.ctx.info('last_newton_solve_ms')); nwt['moved'].append(sess.ctx.info('last_newton_solve_bytes_moved'))
         state['n'] = n + 1
     params_box, prior_box = [params], [prior]
 
@@ -447,29 +451,65 @@ def run_online(args, q, p, T, rank, world):
         sess.allreduce(np.zeros(1))
     for _ in range(args.warmup):
         step()
+    # HIP events around the largest kernel of the step (the fused product + mixing launch of the covariance phase) on every timed step: two events per E-step
+    sess.ctx.set_option('profile', 3)
     barrier()
     t_begin = time.time()
     for _ in range(args.steps):
         step()
     barrier()
     elapsed = time.time() - t_begin
+    ytm_ms, ytm_flops, ytm_launches = (sess.ctx.info('prof_mix_' + k) for k in ('ms', 'flops', 'launches'))
+    ytm_fused = sess.ctx.info('last_yt_mix_fused') == 1.0
+    sess.ctx.set_option('profile', 0)
     times = np.zeros(world)
     times[rank] = elapsed
     t_max = float(np.max(sess.allreduce(times)))
+    # two more (untimed) iterations with the reference engine's default timescale driver (scipy TNC), for the record
+    tnc_ms = None
+    if world == 1 and not args.lean and args.tau_method != 'TNC':
+        tau_method[0] = 'TNC'
+        keep = (params_box[0], prior_box[0], state['n'])
+        step(); step()
+        tnc_ms = mst[-1]
+        for lst in (est, mst, nlls, pcgs, idx_sum, nwt['ms'], nwt['moved']):
+            del lst[-2:]
+        params_box[0], prior_box[0], state['n'] = keep
+        tau_method[0] = args.tau_method
     if rank != 0:
         return
     timed = slice(args.warmup, args.warmup + args.steps)
+    n_ms, n_moved = float(np.sum(nwt['ms'][timed])), float(np.sum(nwt['moved'][timed]))
     out = {'metric': 'EM iterations/sec', 'value': args.steps / t_max, 'unit': 'stochastic-EM iterations/s (minibatch %d of %d resident trials)' % (batch, Rres),
            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': t_max / args.steps * 1e3,
            'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
            'config': {'workload': 'c4: %d neurons, %d latents, %d bins, %d resident trials, stochastic EM minibatch=%d split over %d GPU(s), '
-                                  "'diag' prior updates ((C,d) by %s, tau by scipy TNC as the reference engine)"
-                                  % (q, p, T, Rres, batch, world, 'device per-neuron Newton' if cd_method == 'newton' else 'scipy ' + cd_method),
+                                  "'diag' prior updates ((C,d) by %s, tau by %s)"
+                                  % (q, p, T, Rres, batch, world, 'device per-neuron Newton' if cd_method == 'newton' else 'scipy ' + cd_method,
+                                     'the 4-point lockstep root finder on the reference gradient' if args.tau_method == 'lockstep' else 'scipy %s as the reference engine' % args.tau_method),
                       'parallelism': 'minibatch-sharded x%d' % world},
            'estep_ms': [round(x, 1) for x in est], 'mstep_ms': [round(x, 1) for x in mst],
            'estep_ms_per_trial': float(np.mean(est[timed])) / (batch / world), 'pcg_iterations_per_trial': [round(x, 1) for x in pcgs],
            'nll': nlls, 'minibatch_index_checksums': idx_sum,
-           'lowrank_plan': sess.ctx.info('plan_lowrank'), 'lowrank_rtot': sess.ctx.info('lowrank_rtot'), 'chunk_trials': sess.ctx.info('chunk_trials')}
+           'lowrank_plan': sess.ctx.info('plan_lowrank'), 'lowrank_rtot': sess.ctx.info('lowrank_rtot'), 'chunk_trials': sess.ctx.info('chunk_trials'),
+           # the rate with the reference engine's default timescale driver (tauOptimMethod='TNC': p scipy optimisations, one batched device pass per round)
+           'mstep_ms_with_reference_default_tau_TNC': tnc_ms,
+           'value_reference_default_tau': None if tnc_ms is None else 1e3 / (float(np.mean(est[timed])) + tnc_ms),
+           # dominant kernel of the step, as in the batch workload: product + mixing of the covariance phase (HIP events on the context's stream around it)
+           'roofline': None if not (ytm_fused and ytm_ms > 0) else {
+               'bound': 'mfma', 'kernel': 'yt_mix_kernel (FP64 16x16x4 MFMA products + FP64 vector mixing in registers; writes the FP32 correction D and post_vsm)',
+               'achieved': ytm_flops / (ytm_ms * 1e-3) / 1e12, 'peak': FP64_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+               'frac': ytm_flops / (ytm_ms * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS, 'traffic': None,
+               'algorithmic_flops_per_launch': ytm_flops / max(ytm_launches, 1.0), 'launches': ytm_launches, 'avg_launch_ms': ytm_ms / max(ytm_launches, 1.0),
+               'kernel_share_of_step': ytm_ms * 1e-3 / t_max},
+           'roofline_newton': {'bound': 'hbm', 'bytes_moved': n_moved, 'ms': n_ms, 'achieved': n_moved / (n_ms * 1e-3) / 1e9 if n_ms > 0 else 0.0, 'peak': HBM_PEAK_GBS,
+                               'unit': 'GB/s', 'frac': n_moved / (n_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if n_ms > 0 else 0.0, 'ms_per_em_iteration': n_ms / args.steps}}
+    if not args.no_cpu_baseline and world == 1:
+        # the reference's stochastic-EM iteration costs what a batch iteration over the minibatch costs (same E-step loop inference.py:94 over 1024
+        # trials, the prior-regularised M-step on their posterior): the faithful CPU trial of the batch workload, scaled to the minibatch
+        out['cpu_baseline'] = cpu_baseline(q, p, T, batch, true_params, Ys[0], 10.0, params, estimate=args.cpu_estimate, budget_s=args.cpu_budget)
+        out['speedup_vs_cpu_baseline'] = out['value'] / out['cpu_baseline']['value']
+        out['speedup_vs_cpu_baseline_note'] = 'ratio to the cpu_baseline sample as described there'
     print(json.dumps(out))
 
 
@@ -639,6 +679,9 @@ def main():
     ap.add_argument('--cd-method', default='newton', choices=['newton', 'TNC', 'BFGS', 'L-BFGS-B'],
                     help="(C,d) M-step solver: 'newton' = device per-neuron Newton (exact minimiser of the reference's cost); "
                          "'TNC' = the reference engine's default scipy driver on the same device cost/grad")
+    ap.add_argument('--tau-method', default='lockstep', choices=['lockstep', 'TNC'],
+                    help="--workload online, timescale update with prior: 'lockstep' = the root of the reference's gradient expression for all latents "
+                         "together (learning.learnGPparamsWithPrior, opt-in); 'TNC' = the reference engine's default scipy driver")
     ap.add_argument('--seed', type=int, default=12)
     ap.add_argument('--tau-all', type=float, default=0.03, help='--workload floor: every timescale (seconds)')
     ap.add_argument('--workload', default='em', choices=['em', 'online', 'loo', 'dual', 'floor'],
@@ -777,7 +820,7 @@ def main():
     if not args.lean:
         sess.ctx.set_option('profile', 1)
         em_step()
-        prof = {tag: sess.ctx.info('prof_%s_ms' % tag) for tag in ('gemm', 'cd', 'potrf', 'poisson', 'vsm', 'assemble', 'solve')}
+        prof = {tag: sess.ctx.info('prof_%s_ms' % tag) for tag in ('gemm', 'mix', 'cd', 'potrf', 'poisson', 'vsm', 'assemble', 'solve')}
         sess.ctx.set_option('profile', 0)
         drop_last()
     # one more (untimed) EM iteration with the reference engine's default (C,d) driver, for the record
@@ -820,6 +863,25 @@ def main():
     n_by_survey = float(np.sum(nwt_bytes_survey[timed]))
     n_by_moved = float(np.sum(nwt_bytes_moved[timed]))
     per_1024 = (total_trials / 1024.0) if args.config == 'c3' else 1.0
+    step_ms_on_events = max(1e-9, float(np.sum([estep_ms[args.warmup + i] + mstep_ms[args.warmup + i] for i in event_steps])))
+    roof_gemm = {'bound': 'mfma', 'kernel': 'gemm_mfma_kernel (FP64 16x16x4 MFMA: preconditioner applications, prior mat-vecs, factor/inverse/selected products)',
+                 'achieved': achieved, 'peak': FP64_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / FP64_MATRIX_PEAK_TFLOPS,
+                 # HBM counters are not collected inside a timed run (rocprofv3 --pmc serialises kernels): null here; the per-round PMC
+                 # passes of this command are under profiles/ (rNN_pmc_hbm_traffic.json)
+                 'traffic': None,
+                 'algorithmic_flops_per_launch': gemm_flops / max(gemm_launches, 1.0), 'launches': gemm_launches, 'avg_launch_ms': gemm_ms / max(gemm_launches, 1.0),
+                 # (events on these steps of the timed region only; share = GEMM time of those steps / their wall time)
+                 'events_on_steps': event_steps, 'kernel_share_of_step': gemm_ms / step_ms_on_events,
+                 # the longest single launch of the timed region
+                 'largest_launch': {'ms': gemm_max_ms, 'algorithmic_flops': gemm_max_flops,
+                                    'achieved': gemm_max_flops / (gemm_max_ms * 1e-3) / 1e12 if gemm_max_ms > 0 else 0.0,
+                                    'frac': gemm_max_flops / (gemm_max_ms * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS if gemm_max_ms > 0 else 0.0}}
+    roof_cov = None if not (ytm_fused and ytm_ms > 0) else {
+        'bound': 'mfma', 'kernel': 'yt_mix_kernel (FP64 16x16x4 MFMA products + FP64 vector mixing in registers; writes the FP32 correction D and post_vsm)',
+        'achieved': ytm_flops / (ytm_ms * 1e-3) / 1e12, 'peak': FP64_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+        'frac': ytm_flops / (ytm_ms * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS, 'traffic': None,
+        'algorithmic_flops_per_launch': ytm_flops / max(ytm_launches, 1.0), 'launches': ytm_launches, 'avg_launch_ms': ytm_ms / max(ytm_launches, 1.0),
+        'events_on_steps': event_steps, 'kernel_share_of_step': ytm_ms / step_ms_on_events}
     out = {
         'metric': 'EM iterations/sec',
         'value': value,
@@ -843,39 +905,21 @@ def main():
         'nll': nll_hist,
         'mstep_ms_with_reference_default_TNC': tnc_ms,
         'kernel_time_ms_one_untimed_step': {k: round(v, 1) for k, v in prof.items()},
-        'roofline': {'bound': 'mfma', 'kernel': 'gemm_mfma_kernel (FP64 16x16x4 MFMA: preconditioner applications, prior mat-vecs, factor/inverse/selected products)',
-                     'achieved': achieved, 'peak': FP64_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / FP64_MATRIX_PEAK_TFLOPS,
-                     # HBM counters are not collected inside a timed run (rocprofv3 --pmc serialises kernels): null here; the per-round PMC
-                     # passes of this command are under profiles/ (rNN_pmc_hbm_traffic.json)
-                     'traffic': None,
-                     'algorithmic_flops_per_launch': gemm_flops / max(gemm_launches, 1.0), 'launches': gemm_launches, 'avg_launch_ms': gemm_ms / max(gemm_launches, 1.0),
-                     # (events on these steps of the timed region only; share = GEMM time of those steps / their wall time)
-                     'events_on_steps': event_steps,
-                     'kernel_share_of_step': gemm_ms / max(1e-9, float(np.sum([estep_ms[args.warmup + i] + mstep_ms[args.warmup + i] for i in event_steps]))),
-                     # the longest single launch of the timed region
-                     'largest_launch': {'ms': gemm_max_ms, 'algorithmic_flops': gemm_max_flops,
-                                        'achieved': gemm_max_flops / (gemm_max_ms * 1e-3) / 1e12 if gemm_max_ms > 0 else 0.0,
-                                        'frac': gemm_max_flops / (gemm_max_ms * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS if gemm_max_ms > 0 else 0.0}},
-        # the largest single kernel of the step: Yt = F L^-T and its mixing in one launch per E-step (csrc/ytmix.h) - HIP events around it on
-        # the same steps as the GEMM events; flops = products over the triangular panels + the per-(bin, column) mixing (csrc/cov.hip);
-        # traffic: the committed PMC passes (profiles/rNN_pmc_hbm_traffic.json)
-        'roofline_covariance': None if not (ytm_fused and ytm_ms > 0) else {
-            'bound': 'mfma', 'kernel': 'yt_mix_kernel (FP64 16x16x4 MFMA products + FP64 vector mixing in registers; writes the FP32 correction D and post_vsm)',
-            'achieved': ytm_flops / (ytm_ms * 1e-3) / 1e12, 'peak': FP64_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': ytm_flops / (ytm_ms * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS, 'traffic': None,
-            'algorithmic_flops_per_launch': ytm_flops / max(ytm_launches, 1.0), 'launches': ytm_launches, 'avg_launch_ms': ytm_ms / max(ytm_launches, 1.0),
-            'kernel_share_of_step': ytm_ms / max(1e-9, float(np.sum([estep_ms[args.warmup + i] + mstep_ms[args.warmup + i] for i in event_steps])))},
-        # the Newton solve (north star: >= 40 % of the HBM roofline): every inner PCG solve of the timed region between two HIP events,
-        # against the bytes a perfect implementation of the same iteration would still move (17 n-vector passes + packed FP32 curvature per
-        # slot-iteration, the operators once per step; csrc/estep.hip: newton_bytes).  BOTH byte models are printed so that the fraction cannot move
-        # by redefining "mandatory": `frac` is this 17-pass model, `frac_survey_model` prices the same slot-iterations at SURVEY 8(d)'s
-        # B_E = q T + 8 (2 p T + T p^2) bytes per pass per trial
-        'roofline_newton': {'bound': 'hbm', 'bytes': n_by, 'ms': n_ms, 'achieved': n_by / (n_ms * 1e-3) / 1e9 if n_ms > 0 else 0.0, 'peak': HBM_PEAK_GBS,
-                            'unit': 'GB/s', 'frac': n_by / (n_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if n_ms > 0 else 0.0,
-                            'byte_model': '17 n-vector passes + packed FP32 curvature per slot-iteration + operators once per step',
-                            # (what the kernels really move: since round 5 z, s, p, q, t / y of a solve are stored in single precision - 13.8 instead of
-                            #  19.8 n-vector equivalents per slot-iteration; `frac` keeps pricing the FP64 form so that it measures time, not accounting)
-                            'bytes_moved': n_by_moved, 'achieved_moved': n_by_moved / (n_ms * 1e-3) / 1e9 if n_ms > 0 else 0.0,
+        # The line's `roofline` names the dominant kernel of the step - the top row of the rocprof summary (profiles/rNN_c3_bench_kernel_stats.csv):
+        # Yt = F L^-T and its mixing in one launch per E-step (csrc/ytmix.h).  HIP events (on the context's stream) around it on the sampled steps of
+        # the timed region; flops = products over the triangular panels + the per-(bin, column) mixing (csrc/cov.hip); traffic: the committed PMC
+        # passes (profiles/rNN_pmc_hbm_traffic.json).  The GEMM family (a pool of ~165 launches of a dozen shapes) follows as `roofline_gemm`.
+        'roofline': roof_cov if roof_cov is not None else roof_gemm,
+        'roofline_gemm': roof_gemm,
+        'roofline_covariance': roof_cov,
+        # the Newton solve (north star: >= 40 % of the HBM roofline): every inner PCG solve of the timed region between two HIP events.  `frac` prices
+        # the bytes the kernels really MOVE (round 6; z, s, p, q, t / y of a solve are stored in single precision - csrc/estep.hip: newton_bytes_moved);
+        # the 17-pass FP64 model of rounds 3-5 and SURVEY 8(d)'s B_E = q T + 8 (2 p T + T p^2) bytes per pass per trial are printed next to it so that
+        # the fraction cannot move by accounting
+        'roofline_newton': {'bound': 'hbm', 'bytes': n_by_moved, 'ms': n_ms, 'achieved': n_by_moved / (n_ms * 1e-3) / 1e9 if n_ms > 0 else 0.0, 'peak': HBM_PEAK_GBS,
+                            'unit': 'GB/s', 'frac': n_by_moved / (n_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if n_ms > 0 else 0.0,
+                            'byte_model': 'bytes moved by the kernels of the step as built (per slot-iteration: n-vector passes at their storage width + packed FP32 curvature; operators once per step)',
+                            'bytes_17pass_fp64_model': n_by, 'frac_17pass_fp64_model': n_by / (n_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if n_ms > 0 else 0.0,
                             'bytes_survey_model': n_by_survey, 'frac_survey_model': n_by_survey / (n_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if n_ms > 0 else 0.0,
                             'ms_per_em_iteration': n_ms / args.steps, 'pcg_iterations_per_trial_per_estep': float(np.mean(pcgs[timed])) / R},
     }

@@ -1056,7 +1056,7 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
     }
     c->prof.on = (v != 0.0);
     c->prof.configured = c->prof.on;
-    c->prof.only_tag = (v == 2.0) ? TAG_GEMM : -1;
+    c->prof.only_tag = (v == 2.0) ? TAG_GEMM : (v == 3.0) ? TAG_MIX : -1;     // (3: only the product-and-mixing launch of the covariance phase)
   } else if (k == "profile_pause") {
     // 1: stop recording events without touching the sums or waiting for anything; 0: go on (only while "profile" is set).  An event pair
     // around a launch costs ~10 us of device time (two barrier packets): a caller that wants rates over a long region samples it.

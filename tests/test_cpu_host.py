@@ -203,6 +203,58 @@ def test_timescale_root_finder_host_logic():
         assert np.max(np.abs(r - bisect(X, Y, lo, hi))[ok]) <= 1e-13
 
 
+def test_lockstep_timescale_update_with_prior_stops_where_the_reference_tnc_stops(c1, monkeypatch):
+    """learning.learnGPparamsWithPrior(tauOptimMethod='lockstep') on a host stand-in for the device pass (the oracle's MStepGPtimescaleCost
+    and its gradient on the PautoSum of config 1's posterior): the root of the reference's regularised gradient (learning.py:726-769: the prior
+    term without the chain factor) found for all latents together lands where the reference's own TNC call on its cost / gradient pair stops
+    (learning.py:819-825, restated by oracle.learn_tau_prior) - 1e-3 relative in tau, the tolerance of the GPU tests - for the step sizes of
+    the first, fourth and eleventh stochastic-EM iteration; and the same point again from the displacement hint of the call before."""
+    from funs import learning
+    from oracle import pgpfa_oracle as orc
+    import warnings
+    par = {'C': c1['init_C'], 'd': c1['init_d'], 'tau': c1['init_tau']}
+    Ys = c1['Ys'][:8]
+    bs = c1['binSize']
+    infRes = orc.laplace(Ys, par, bs, mode='exact')[0]
+    P, R = orc.make_precomp(infRes)
+
+    class Ctx:
+        passes = 0
+
+        def mstep_precomp(self):
+            return R
+
+        def mstep_tau_costgrad_multi(self, logp):
+            Ctx.passes += 1
+            logp = np.asarray(logp).reshape(-1, P.shape[0])
+            cost = np.array([[orc.tau_cost(v, P[k], R) for k, v in enumerate(row)] for row in logp])
+            grad = np.array([[orc.tau_grad(v, P[k], R)[0] for k, v in enumerate(row)] for row in logp])
+            return cost, grad
+
+    class Sess:
+        ctx, p, T, post_stamp = Ctx(), P.shape[0], P.shape[1], 0
+    sess = Sess()
+    monkeypatch.setattr(learning, '_resident_session', lambda infRes, experiment, xdim: sess)
+
+    class Exp:
+        binSize = bs
+    for n in (0, 3, 10):
+        step = 1.0 / (n + 1) ** 0.75
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            tau_ref, _ = orc.learn_tau_prior(par, infRes, bs, 'TNC', step)
+        for again in range(2):
+            Ctx.passes = 0
+            tau, details = learning.learnGPparamsWithPrior(par, infRes, Exp(), 'lockstep', step)
+            assert np.max(np.abs(tau - tau_ref) / tau_ref) <= 1e-3
+            assert all(d.success for d in details) and Ctx.passes <= 6
+            # the point is the zero of the reference's gradient expression
+            for k in range(P.shape[0]):
+                pv = np.log(1.0 / (tau[k] * 1000.0 / bs) ** 2)
+                g = orc.tau_grad_prior(pv, P[k], R, bs, par['tau'][k], step)[0]
+                assert abs(g) <= 1e-6 * R
+
+
 class _SeparableCost:
     """Stand-in for the device side of the Newton (C,d) driver: q independent convex costs f_n(th) = sum_i w_i exp(x_i . th) - y_n . th over
     th in R^D, with the methods and return conventions of funs._hip.Context that learning._newton_cd calls (vectors laid out [D][q])."""

@@ -139,3 +139,43 @@ def test_estep_behind_a_parameter_jump_costs_what_a_cold_one_costs(funs_mod):
     assert ms_jump <= 3.0 * cold['truth'] and ms_after <= 3.0 * cold['truth']
     assert ms_half <= 3.0 * cold['half'] and ms_half2 <= 3.0 * cold['half']
     _session.drop_sessions()
+
+
+@pytest.mark.timeout(1800)
+def test_lockstep_timescale_update_with_prior_at_config3_dimensions(funs_mod):
+    """learning.updateParamsWithPrior on the posterior of 256 trials at 200 x 10 x 500 with tauOptimMethod='lockstep' (round 6, opt-in) against the
+    reference's 'TNC' on the same resident posterior, for the step sizes of stochastic-EM iterations 1, 4 and 11: every new timescale within 1e-3
+    (relative) of where the reference's scipy call stops - the tolerance config 4's test states - and a zero of the reference's regularised
+    gradient expression (learning.py:726-769, restated by the oracle on the device's PautoSum; 1e-6 R).  (C,d) are the same numbers either way."""
+    import bench
+    from funs import _session
+    import warnings
+    q, p, T, R = 200, 10, 500, 256
+    _session.drop_sessions()
+    true, Ys = bench.synth_shard(q, p, T, R, 12, 0)
+    exp = bench.Shard(Ys, 10.0)
+    np.random.seed(0)
+    params = {k: np.real(np.asarray(v)).astype(np.float64) for k, v in funs_mod.util.initializeParams(p, q, exp).items()}
+    infRes, nll, _ = funs_mod.inference.laplace(exp, params)
+    prior = np.diag(np.ones(q * (p + 1)))
+    P = None
+    for n in (0, 3, 10):
+        sz = 1.0 / (n + 1) ** 0.75
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            t0 = time.time()
+            ref, _, _ = funs_mod.learning.updateParamsWithPrior(params, infRes, exp, 'newton', 'TNC', sz, sz, prior, covOpts='useDiag')
+            t1 = time.time()
+        new, det, _ = funs_mod.learning.updateParamsWithPrior(params, infRes, exp, 'newton', 'lockstep', sz, sz, prior, covOpts='useDiag')
+        t2 = time.time()
+        if P is None:
+            P = infRes.session.ctx.pautosum()
+        print('prior step %.3f: M-step with TNC %.1f ms, with the lockstep finder %.1f ms (%d device passes); max relative difference of tau %.2e'
+              % (sz, (t1 - t0) * 1e3, (t2 - t1) * 1e3, det['tau'][0].nfev, np.max(np.abs(new['tau'] - ref['tau']) / ref['tau'])))
+        assert np.max(np.abs(new['tau'] - ref['tau']) / ref['tau']) <= 1e-3
+        assert np.max(np.abs(new['C'] - ref['C'])) <= 1e-9 and np.max(np.abs(new['d'] - ref['d'])) <= 1e-9
+        assert all(d.success for d in det['tau'])
+        for k in range(p):
+            pv = np.log(1.0 / (new['tau'][k] * 100.0) ** 2)
+            assert abs(orc.tau_grad_prior(pv, P[k], R, 10.0, params['tau'][k], sz)[0]) <= 1e-6 * R
+    _session.drop_sessions()
