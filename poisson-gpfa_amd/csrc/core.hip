@@ -981,6 +981,7 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
   else if (k == "pcg_w32") c->pcg_w32 = (v != 0.0);
   else if (k == "pcg_form") c->pcg_form = (int)v;
   else if (k == "pcg_vec32") c->pcg_vec32 = (int)v;
+  else if (k == "pcg_rx32") c->pcg_rx32 = (int)v;
   else if (k == "pcg_adapt") c->pcg_adapt = (int)v;
   else if (k == "pcg_xcd") c->pcg_xcd = (int)v;
   else if (k == "mt_fill") c->mt_fill = (int)v;

@@ -200,6 +200,7 @@ struct pgpfa_ctx {
   int pcg_form = 2;                              // host-free inner iteration (pcg.h): 2 (round 5) = 1 with the solve's private vectors on line-aligned rows, one start kernel,
                                                  // the step's closing folded into kernel A and one upload per solve; 1 two tile-parallel kernels per step, no prior mat-vec (pcg_cg_a/b_kernel);
                                                  // 0 the split kernels of round 3 with K^-1 p as a product
+  int pcg_rx32 = 1;                              // with pcg_vec32, up to 10 latents: the residual and the step of a solve stored in single precision too (pcg.h: PcgCgP::X32)
   int pcg_vec32 = 1;                             // with pcg_form 2: z, s, p, q and the preconditioner's t / y stored in single precision (pcg.h: PcgCgP::vec32)
   double *Sv = nullptr, *cg_scal = nullptr;      // s = H~ z of the two-kernel form; its per-slot scalars [gamma | alpha] x step parity
   double *GbT = nullptr, *WbT = nullptr;         // [NP][T] packed triangles of the shared preconditioner's Gb and of the mean curvature (pcg_cg_a/b_kernel)

@@ -553,7 +553,9 @@ int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow_lr, do
     // ... and (second half of round 5) z, s, p, q, t / y of the solve stored in single precision (PcgCgP::vec32)
     const bool v32 = f2 && c->pcg_vec32;
     const int Tl = !f2 ? T : (v32 && (long long)p * round_up(T, 32) <= ld) ? round_up(T, 32) : ((long long)p * round_up(T, 16) <= ld) ? round_up(T, 16) : T;
-    auto with_tv = [&](auto&& fn) { if (v32) fn(float{}); else fn(double{}); };
+    // ... and (round 6) the residual and the step as well, up to 10 latents (PcgCgP::X32): x in the free second half of Z's buffer
+    const bool rx32 = v32 && c->pcg_rx32 && p <= 10;
+    auto with_tv = [&](auto&& fn) { if (rx32) fn(float{}, float{}); else if (v32) fn(float{}, double{}); else fn(double{}, double{}); };
     // packed single-precision curvature of the two-kernel step (pcg.h): component-major [c][Tw], rows on 128-byte lines.  It is written where W is:
     // by pack_w32t_kernel at the start of a solve for slots whose W came from the Poisson pass at the E-step's start point, and by the commit of an
     // accepted step (commit_w_pack_kernel: the copy W <- Wt and the packing in one pass over Wt - a solve after the first finds every active slot packed)
@@ -677,6 +679,7 @@ int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow_lr, do
           cp.part = c->sc_part2; cp.gam = c->cg_scal; cp.alp = c->cg_scal + 2 * (size_t)c->B; cp.rr = c->sc_rr; cp.rr0 = c->sc_rr0; cp.eta = c->pcg_eta;
           cp.ctl = c->pcgctl; cp.live0 = c->live; cp.live1 = c->live1;
           cp.eps = c->eps; cp.T = T; cp.p = p; cp.inner_min = c->pcg_inner_min; cp.ntile = (T + TB - 1) / TB; cp.B = c->B; cp.xcd_map = c->pcg_xcd;
+          cp.X32 = reinterpret_cast<float*>(c->Zv) + (size_t)ld * ((size_t)c->B + 128);     // (the single-precision z fills the first half of Zv)
           cp.Tl = Tl; cp.Tx = T; cp.vec32 = v32 ? 1 : 0; cp.fold_close = f2 ? 1 : 0; cp.host = (volatile int*)c->d_hpcg; cp.Gl = c->Gl; cp.KX = c->KX; cp.Gt = c->Gt;
           auto cg_grid = [&](int bound) {
             cp.spw = !c->pcg_adapt ? PCG_SLOTS : bound > 640 ? 16 : bound > 320 ? 8 : 4;
@@ -689,15 +692,15 @@ int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow_lr, do
               constexpr int PW = decltype(pw)::value;
               if constexpr (PW <= 10) {
                 const size_t lb = pcg_cg_b_lds(PW);
-                with_tv([&](auto tv) {
-                  using TV = decltype(tv);
-                  if (lb > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pcg_cg_start_kernel<PW, TV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
-                  hipLaunchKernelGGL((pcg_cg_start_kernel<PW, TV>), g0, dim3(256), lb, c->st, cp);
+                with_tv([&](auto tv, auto tx) {
+                  using TV = decltype(tv); using TX = decltype(tx); (void)sizeof(TX);
+                  if (lb > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pcg_cg_start_kernel<PW, TV, TX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+                  hipLaunchKernelGGL((pcg_cg_start_kernel<PW, TV, TX>), g0, dim3(256), lb, c->st, cp);
                 });
               } else if constexpr (PW <= 20) {
                 const size_t lb = pcgw_b_lds(PW);
-                with_tv([&](auto tv) {
-                  using TV = decltype(tv);
+                with_tv([&](auto tv, auto tx) {
+                  using TV = decltype(tv); using TX = decltype(tx); (void)sizeof(TX);
                   if (lb > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pcgw_start_kernel<PW, TV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
                   hipLaunchKernelGGL((pcgw_start_kernel<PW, TV>), g0, dim3(256), lb, c->st, cp);
                 });
@@ -731,17 +734,17 @@ int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow_lr, do
               if constexpr (PW <= 10) {
                 const size_t la = pcg_cg_a_lds(PW), lb = pcg_cg_b_lds(PW);
                 // (per launch, not once per process: contexts of one process may sit on different devices)
-                with_tv([&](auto tv) {
-                  using TV = decltype(tv);
-                  if (la > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pcg_cg_a_kernel<PW, TV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)la);
-                  if (lb > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pcg_cg_b_kernel<PW, TV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
-                  hipLaunchKernelGGL((pcg_cg_a_kernel<PW, TV>), gcg, dim3(256), la, c->st, cp);
-                  hipLaunchKernelGGL((pcg_cg_b_kernel<PW, TV>), gcg, dim3(256), lb, c->st, cp);
+                with_tv([&](auto tv, auto tx) {
+                  using TV = decltype(tv); using TX = decltype(tx); (void)sizeof(TX);
+                  if (la > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pcg_cg_a_kernel<PW, TV, TX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)la);
+                  if (lb > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pcg_cg_b_kernel<PW, TV, TX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+                  hipLaunchKernelGGL((pcg_cg_a_kernel<PW, TV, TX>), gcg, dim3(256), la, c->st, cp);
+                  hipLaunchKernelGGL((pcg_cg_b_kernel<PW, TV, TX>), gcg, dim3(256), lb, c->st, cp);
                 });
               } else if constexpr (PW <= 20) {
                 const size_t la = pcgw_a_lds(PW), lb = pcgw_b_lds(PW);
-                with_tv([&](auto tv) {
-                  using TV = decltype(tv);
+                with_tv([&](auto tv, auto tx) {
+                  using TV = decltype(tv); using TX = decltype(tx); (void)sizeof(TX);
                   if (la > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pcgw_a_kernel<PW, TV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)la);
                   if (lb > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pcgw_b_kernel<PW, TV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
                   hipLaunchKernelGGL((pcgw_a_kernel<PW, TV>), gcg, dim3(256), la, c->st, cp);
@@ -886,8 +889,16 @@ int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow_lr, do
           }
         }
         }
-        if (c->time_newton) hipEventRecord(newton_ev.back().second, c->st);
-        hipLaunchKernelGGL(step_stats_kernel, dim3(na), dim3(256), 0, c->st, c->Gt, c->Dl, ld, nvec, c->list_a, c->sc_dec, c->sc_smax);
+        if (onek && rx32) {
+          // the step comes back in single precision on the solve's private rows: widened into Dl by the kernel that reads it first (inside the timed
+          // region of the solve: it is part of what the single-precision step costs)
+          hipLaunchKernelGGL(step_stats_x32_kernel, dim3(na), dim3(256), 0, c->st, c->Gt, reinterpret_cast<const float*>(c->Zv) + (size_t)ld * ((size_t)c->B + 128),
+                             c->Dl, ld, T, Tl, p, c->list_a, c->sc_dec, c->sc_smax);
+          if (c->time_newton) hipEventRecord(newton_ev.back().second, c->st);
+        } else {
+          if (c->time_newton) hipEventRecord(newton_ev.back().second, c->st);
+          hipLaunchKernelGGL(step_stats_kernel, dim3(na), dim3(256), 0, c->st, c->Gt, c->Dl, ld, nvec, c->list_a, c->sc_dec, c->sc_smax);
+        }
         CHK(prior_mv_all(c, nb, c->Dl, c->KD));
         hipLaunchKernelGGL(dots3_kernel, dim3(na), dim3(256), 0, c->st, c->Xc, ld, c->KX, ld, c->Dl, ld, c->KD, ld, nvec, c->list_a, c->sc_qxx,
                            c->sc_qdx, c->sc_qdd);
@@ -939,7 +950,12 @@ int estep_impl(pgpfa_ctx* c, const Trials& tr, int warm_start, bool allow_lr, do
           const double ops = onek ? (2.0 * T * c->rtot + (double)c->rtot * c->rtot + 1.5 * T * npk) * 8.0
                                   : (double)p * T * T * 8.0 + (c->plan_lowrank ? (2.0 * T * c->rtot + (double)c->rtot * c->rtot) * 8.0 : (double)nvec * nvec * 8.0);
           newton_bytes += slot_iters * (vecs + curv) + (double)done_inner * ops;
-          newton_bytes_moved += slot_iters * ((v32 ? 11.0 * nvec * 8.0 + (c->plan_lowrank ? 4.0 * c->rtot * 8.0 : 0.0) : vecs) + curv) + (double)done_inner * ops;
+          // (bytes per entry of an n-vector and slot-step: FP64 form 136 = 17 passes; z, s, p, q, t / y in single precision 88; r and x too 68 -
+          //  A reads r 4, y 4, writes z 4, s 4; B reads z 4, s 4, x 4, r 4, p 4, q 4, writes p 4, q 4, x 4, r 4, t 4; the products read t 4, write y 4 -
+          //  plus, once per solve and slot, the widening of the step: 4 read, 8 written)
+          const double vec_b = rx32 ? 68.0 : (v32 ? 88.0 : 0.0);
+          newton_bytes_moved += slot_iters * ((v32 ? vec_b * nvec + (c->plan_lowrank ? 4.0 * c->rtot * 8.0 : 0.0) : vecs) + curv) + (double)done_inner * ops
+                                + ((onek && rx32) ? 12.0 * nvec * (double)na : 0.0);
           newton_bytes_survey += slot_iters * ((double)c->q * T + 8.0 * (2.0 * p * T + (double)T * p * p));
         }
         std::vector<int> cand, next, failed;

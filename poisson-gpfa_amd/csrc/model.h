@@ -2073,6 +2073,30 @@ inline __global__ __launch_bounds__(256) void step_stats_kernel(const double* __
   }
 }
 
+// The same for a step the inner solve kept in single precision on its private row stride (pcg.h: PcgCgP::X32): x[k Tl + t] is widened into the
+// caller's FP64 step vector X[k T + t] on the way.
+inline __global__ __launch_bounds__(256) void step_stats_x32_kernel(const double* __restrict__ G, const float* __restrict__ X32, double* __restrict__ X, long long sV,
+                                                             int T, int Tl, int p, const int* __restrict__ slots, double* __restrict__ dec, double* __restrict__ smax) {
+  __shared__ double red[2][4];
+  const size_t slot = slots[blockIdx.x];
+  double d = 0.0, m = 0.0;
+  for (int k = 0; k < p; ++k)
+    for (int t = threadIdx.x; t < T; t += 256) {
+      const double x = (double)X32[slot * sV + (size_t)k * Tl + t];
+      const size_t o = slot * sV + (size_t)k * T + t;
+      X[o] = x;
+      d -= G[o] * x;
+      m = fmax(m, fabs(x));
+    }
+  for (int off = 32; off > 0; off >>= 1) { d += __shfl_down(d, off); m = fmax(m, __shfl_down(m, off)); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = d; red[1][threadIdx.x >> 6] = m; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    dec[slot] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    smax[slot] = fmax(fmax(red[1][0], red[1][1]), fmax(red[1][2], red[1][3]));
+  }
+}
+
 // --------------------------------------------------------------------------------------------------
 // Low-rank covariance engine.  K_k = eps*I + F_k F_k^T with F_k (T x r_k) from a pivoted Cholesky of
 // the RBF part (numerically low rank: eigenvalues decay like a Gaussian), so with W = blockdiag_t(W_t),

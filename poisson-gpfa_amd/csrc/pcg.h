@@ -416,6 +416,13 @@ struct PcgCgP {
   int fold_close;                              // 1: kernel A of step i closes step i - 1 (no closing launch per step; pcg_iter_close_kernel once after the last)
   volatile int* host;                          // host-mapped {stop, steps, live} mirror (written by whoever closes a step)
   const double *Gl, *KX; double* Gt;           // pcg_cg_start_kernel: likelihood gradient and K^-1 x (compact), their sum out
+  // (round 6) rx32: the residual r and the step x of the solve are STORED in single precision as well (kernels instantiated with TX = float; up to 10
+  // latents).  r then lives in R's buffer at the same element offsets, x in X32 on the private row stride Tl (the caller widens it into its FP64
+  // step vector once, after the solve).  Every product, dot and update is still computed in FP64 from the widened values.  x = sum alpha_i p_i is
+  // a sum of vectors that are already rounded to single precision when they are stored (p), and the forcing terms never go below 7e-6: the rounding
+  // of r and x (6e-8 relative per step) stays two orders of magnitude under what the solve is asked for, and the outer loop measures the true
+  // gradient of every accepted step.  A slot-step moves 68 bytes per entry of an n-vector instead of 88 (+ 22 of packed curvature).
+  float* X32;
 };
 
 // Closes step `par`'s bookkeeping (one thread): counts, stop flag when the next list is empty, the list just consumed is reset for the step after
@@ -524,8 +531,9 @@ __device__ __forceinline__ void pcg_cg_wg(int ntile, int xcd_map, int& tile, int
   group = xcd + 8 * (m / ntile);
 }
 
-template <int PW, typename TV = double>
+template <int PW, typename TV = double, typename TX = double>
 __global__ __launch_bounds__(256, 2) void pcg_cg_a_kernel(PcgCgP a) {
+  const TX* const Rp = reinterpret_cast<const TX*>(a.R);        // TX: storage type of r (and of x in kernel B): PcgCgP::X32
   // TV: storage type of the vectors private to the solve that carry no accumulated state - z, s, p, q and the preconditioner's t / y (see PcgCgP::vec32)
   TV* const Zp = reinterpret_cast<TV*>(a.Z); TV* const Sp = reinterpret_cast<TV*>(a.S); TV* const Pp = reinterpret_cast<TV*>(a.P);
   TV* const Qp = reinterpret_cast<TV*>(a.Q); TV* const Yp = reinterpret_cast<TV*>(a.Y);
@@ -569,7 +577,7 @@ __global__ __launch_bounds__(256, 2) void pcg_cg_a_kernel(PcgCgP a) {
 #pragma unroll
     for (int k = 0; k < PW; ++k) {
       const size_t o = base + (size_t)(k < p ? k : 0) * Tl;
-      r[k] = a.R[o];
+      r[k] = (double)Rp[o];
       v[k] = (double)Yp[o];
     }
     {
@@ -612,8 +620,10 @@ __global__ __launch_bounds__(256, 2) void pcg_cg_a_kernel(PcgCgP a) {
 }
 
 // same launch shape; dynamic LDS = pcg_cg_b_lds(PW)
-template <int PW, typename TV = double>
+template <int PW, typename TV = double, typename TX = double>
 __global__ __launch_bounds__(256, 3) void pcg_cg_b_kernel(PcgCgP a) {
+  constexpr bool X32 = sizeof(TX) == 4;
+  TX* const Rp = reinterpret_cast<TX*>(a.R);
   // TV: storage type of the vectors private to the solve that carry no accumulated state - z, s, p, q and the preconditioner's t / y (see PcgCgP::vec32)
   TV* const Zp = reinterpret_cast<TV*>(a.Z); TV* const Sp = reinterpret_cast<TV*>(a.S); TV* const Pp = reinterpret_cast<TV*>(a.P);
   TV* const Qp = reinterpret_cast<TV*>(a.Q); TV* const Yp = reinterpret_cast<TV*>(a.Y);
@@ -677,7 +687,8 @@ __global__ __launch_bounds__(256, 3) void pcg_cg_b_kernel(PcgCgP a) {
 #pragma unroll
     for (int k = 0; k < PW; ++k) {
       const size_t o = base + (size_t)(k < p ? k : 0) * Tl;
-      zk[k] = (double)Zp[o]; sk[k] = (double)Sp[o]; xo[k] = a.X[base + (size_t)(k < p ? k : 0) * Tx]; r[k] = a.R[o];
+      zk[k] = (double)Zp[o]; sk[k] = (double)Sp[o]; r[k] = (double)Rp[o];
+      if constexpr (X32) xo[k] = (double)a.X32[o]; else xo[k] = a.X[base + (size_t)(k < p ? k : 0) * Tx];
       po[k] = 0.0; qo[k] = 0.0;
     }
     if (!a.first) {
@@ -693,12 +704,12 @@ __global__ __launch_bounds__(256, 3) void pcg_cg_b_kernel(PcgCgP a) {
       const size_t o = base + (size_t)(k < p ? k : 0) * Tl;
       pv[k] = zk[k] + beta * po[k];
       const double qn = sk[k] + beta * qo[k];
-      r[k] = ok ? r[k] - alpha * qn : 0.0;
+      r[k] = ok ? (double)(TX)(r[k] - alpha * qn) : 0.0;            // (the stored value: t = Gb r below and kernel A's r are then the same vector)
       if (ok) {
         Pp[o] = (TV)pv[k];
         Qp[o] = (TV)qn;
-        a.X[base + (size_t)k * Tx] = xo[k] + alpha * pv[k];
-        a.R[o] = r[k];
+        if constexpr (X32) a.X32[o] = (float)(xo[k] + alpha * pv[k]); else a.X[base + (size_t)k * Tx] = xo[k] + alpha * pv[k];
+        Rp[o] = (TX)r[k];
       }
     }
     pcg_sym_mv<PW, false>(g, 1, p, r, tv);
@@ -721,8 +732,10 @@ inline __global__ void pcg_iter_close_kernel(PcgCtl* __restrict__ ctl, int par, 
 // First kernel of a solve (round 5; one launch where grad_total_kernel, pcg_init_kernel and the per-bin application of the shared preconditioner
 // were three): for the slots of the solve's first live list  g = Gl + K^-1 x -> Gt (compact: the outer loop reads it),  r = -g -> R,  x = 0 -> X,
 // t = Gb r -> Y (input of the products y = F Sb F^T t).  Same launch shape and LDS as kernel B.
-template <int PW, typename TV = double>
+template <int PW, typename TV = double, typename TX = double>
 __global__ __launch_bounds__(256, 3) void pcg_cg_start_kernel(PcgCgP a) {
+  constexpr bool X32 = sizeof(TX) == 4;
+  TX* const Rp = reinterpret_cast<TX*>(a.R);
   // TV: storage type of the vectors private to the solve that carry no accumulated state - z, s, p, q and the preconditioner's t / y (see PcgCgP::vec32)
   TV* const Zp = reinterpret_cast<TV*>(a.Z); TV* const Sp = reinterpret_cast<TV*>(a.S); TV* const Pp = reinterpret_cast<TV*>(a.P);
   TV* const Qp = reinterpret_cast<TV*>(a.Q); TV* const Yp = reinterpret_cast<TV*>(a.Y);
@@ -758,10 +771,11 @@ __global__ __launch_bounds__(256, 3) void pcg_cg_start_kernel(PcgCgP a) {
       const bool ok = in && k < p;
       if (ok) {
         a.Gt[base + (size_t)k * Tx] = r[k];
-        a.X[base + (size_t)k * Tx] = 0.0;
-        a.R[base + (size_t)k * Tl] = -r[k];
+        if constexpr (X32) a.X32[base + (size_t)k * Tl] = 0.f; else a.X[base + (size_t)k * Tx] = 0.0;
+        Rp[base + (size_t)k * Tl] = (TX)(-r[k]);
       }
-      r[k] = ok ? -r[k] : 0.0;
+      // (the residual the iteration goes on with is the STORED one: rounded when TX is float)
+      r[k] = ok ? (double)(TX)(-r[k]) : 0.0;
     }
     pcg_sym_mv<PW, false>(g, 1, p, r, tv);
 #pragma unroll
