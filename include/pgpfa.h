@@ -67,7 +67,11 @@ int pgpfa_destroy(pgpfa_ctx* ctx);
  * of the (C,d) M-step - cost, gradient, per-neuron Hessians - on the matrix cores up to 10 latents; 0: the vector kernel), "vsm_mfma" (1: beyond 10 latents the per-bin
  * covariance blocks are Gram products on the matrix cores - post_vsm_mfma_kernel, model.h; 0: vector kernel),
  * "extrapolate_start" (1: a warm-started E-step begins at m + beta (m - m_prev) for trials whose two previous
- * E-steps are resident), "extrapolate_beta" (1.0),
+ * E-steps are resident), "extrapolate_beta" (1.0), "extrapolate_guard" (3.0, round 6: that extrapolation is only used while the parameter step
+ * between the last two Laplace E-steps - info "last_param_step_prev" - was at most this many times the step being taken - "last_param_step";
+ * behind a JUMP of the parameters the difference of the two previous modes is the jump's effect, not a trend; 0: no test),
+ * "start_guard" (1, round 6: a warm start whose objective is above that of x = 0 - the resident mode belongs to other loadings - restarts at
+ * zero; info "last_cold_restarts"),
  * "pcg_form" (2, round 5: as 1 with the solve's private vectors on line-aligned latent rows (T rounded up to 16 doubles), one start kernel for gradient / residual /
  * first per-bin application, the closing of a step inside kernel A of the next one and one upload per solve - needs "thin_products";
  * 1: a step of the host-free inner iteration is two tile-parallel kernels - the one-reduction (Chronopoulos-Gear) form of
@@ -75,6 +79,8 @@ int pgpfa_destroy(pgpfa_ctx* ctx);
  * "pcg_retire"; 0: the split kernels of round 3 with K^-1 p as a product),
  * "pcg_vec32" (1, with "pcg_form" 2: the vectors of an inner solve that carry no accumulated state - z, s, p, q and the preconditioner's t / y -
  * are stored in single precision, x, r, every product and dot stay FP64: a slot-step moves 13.8 n-vector equivalents instead of 19.8; 0: all FP64),
+ * "pcg_rx32" (1, round 6, with "pcg_vec32", up to 10 latents: the residual r and the step x of an inner solve are stored in single precision as
+ * well - every product, dot and update still in FP64 from the widened values; the step is widened into the caller's FP64 vector once per solve),
  * "pcg_adapt" (1: the launches of a step of that iteration are sized by the live count the device last mirrored to the host - it only falls during a
  * solve - and the per-bin kernels take 16 / 8 / 4 slots per workgroup above 640 / 320 / below; 0: sized by the solve's first count, 16 slots),
  * "pcg_xcd" (1: the two per-bin kernels of that step map workgroup ids so that the bin tiles of a slot group run on one XCD - they share the
@@ -122,6 +128,9 @@ int pgpfa_destroy(pgpfa_ctx* ctx);
  * "last_eps_wt_norm" / "last_eps_wt_rms": the maximum over the chunks of the LAST pgpfa_estep_laplace / pgpfa_dual_finalize call of the
  * largest and of the root-mean-square value over (trial, bin); reset at the start of those calls),
  * "workspace_headroom" (2.0: a low-rank workspace plan leaves room for the ranks to grow by this factor before it is re-made),
+ * "workspace_grow_budget_ms" (200, round 6: a RE-plan stops mapping memory into the arena after this long once the chunk has what
+ * "workspace_grow_floor_slots" (128) slots need, and runs the E-step in balanced chunks of the slots that fit - mapping pages another process has
+ * just released costs up to 40 ms per GB on this stack; the first plan of a context is not bounded; 0: no limit),
  * "workspace_vmm" (1: the chunk workspace is a reserved address range that grows by mapping memory; 0: plain allocations; before
  * the first E-step), "workspace_granule_mb" (1024: size of the mapped chunks),
  * "chord_max" (most chord steps of the per-trial fallback Newton on one factor), "slab_row_align" (1: rows of latent k of the low-rank
@@ -136,7 +145,11 @@ int pgpfa_set_option(pgpfa_ctx* ctx, const char* key, double value);
  * "last_newton_solve_bytes_moved" (what the step's kernels really move: with "pcg_vec32" five of its vectors are single precision),
  * "last_newton_solve_bytes_survey" (the same slot-iterations priced at q T + 8 (2 p T + T p^2) bytes each: SURVEY 8(d)'s B_E per pass per trial),
  * "arena_vmm_failed" (1 once the virtual-memory arena fell back to plain allocations), "last_newton_max_iter", "last_dual_evaluations",
- * "last_loo_unconverged". */
+ * "last_loo_unconverged"; round 6, diagnostics of the last pgpfa_estep_laplace call: "last_param_step" / "last_param_step_prev" (relative
+ * displacement of the parameters between consecutive Laplace E-steps: the largest of |dC| / |C|, |dd| / |d|, |d log tau|; -1: unknown),
+ * "last_cold_restarts", "last_retry_ms" (time of the dense retry pass), "last_fallback_no_descent" / "last_fallback_line_search" /
+ * "last_fallback_outer_cap" (slots the shared-preconditioner Newton phase gave up on, by reason); of the context: "plans" and "plan_ms_total"
+ * (workspace plans made and their time), "arena_grow_ms_total" (of it: mapping memory), "set_params_calls". */
 int pgpfa_get_info(pgpfa_ctx* ctx, const char* key, double* value);
 
 /* ---- data ---------------------------------------------------------------------- */
@@ -210,6 +223,12 @@ int pgpfa_mstep_tau_costgrad_batch(pgpfa_ctx* ctx, const double* logp, double* c
  * The pass is a latency-bound chain of small launches, so 4 candidates cost about as much as 1; the host-side
  * root finder of learnGPparams brackets and interpolates with them instead of stepping serially. */
 int pgpfa_mstep_tau_costgrad_multi(pgpfa_ctx* ctx, int m, const double* logp, double* cost, double* grad);
+/* The same pass in two halves (round 6): _begin enqueues it on the context's side stream and returns at once, _end waits for it and returns
+ * cost[m][p], grad[m][p] - the same bits as the call above.  Between the two the caller may run the (C,d) passes of the same M-step (learning.py:
+ * 93-141 and 257-293 are independent problems; the reference solves them one after the other); one pass in flight per context, every other
+ * timescale / precomp / E-step entry point fails while one is. */
+int pgpfa_mstep_tau_costgrad_multi_begin(pgpfa_ctx* ctx, int m, const double* logp);
+int pgpfa_mstep_tau_costgrad_multi_end(pgpfa_ctx* ctx, double* cost, double* grad);
 
 /* ---- count moments (util.py:523-533 Poisson-PCA initialiser; engine.py:487-492 diagnostics) ---- */
 /* Exact integer moments of the resident counts over all (trial, bin) samples of the listed trials:

@@ -960,6 +960,9 @@ int pgpfa_destroy(pgpfa_ctx* c) {
   if (c->h_seq) hipHostFree(c->h_seq);
   for (auto e : c->prof.pool) hipEventDestroy(e);
   if (c->st2) { hipStreamSynchronize(c->st2); hipStreamDestroy(c->st2); }
+  if (c->tau_pin) hipHostFree(c->tau_pin);
+  if (c->ev_tau_fork) hipEventDestroy(c->ev_tau_fork);
+  if (c->ev_tau_done) hipEventDestroy(c->ev_tau_done);
   if (c->ev_fork) hipEventDestroy(c->ev_fork);
   if (c->ev_join) hipEventDestroy(c->ev_join);
   if (c->st) hipStreamDestroy(c->st);
@@ -1219,6 +1222,7 @@ int pgpfa_get_counts_u16(pgpfa_ctx* c, int n, const int32_t* idx, uint16_t* out)
 int pgpfa_set_params(pgpfa_ctx* c, const double* C, const double* d, const double* tau_s) {
   PhaseRange range_phase("pgpfa.set_params");
   if (!c || !C || !d || !tau_s) return fail("null argument");
+  if (c->tau_inflight) return fail("a timescale pass is in flight (pgpfa_mstep_tau_costgrad_multi_begin): collect it first");
   HIPC(hipSetDevice(c->device));
   for (int k = 0; k < c->p; ++k)
     if (!(tau_s[k] > 0.0) || !std::isfinite(tau_s[k])) return fail("tau[%d] = %g must be positive and finite", k, tau_s[k]);
@@ -1283,6 +1287,7 @@ int ready(pgpfa_ctx* c) {
   if (!c) return fail("null context");
   if (!c->have_counts) return fail("spike counts have not been uploaded");
   if (!c->have_params) return fail("set_params has not been called");
+  if (c->tau_inflight) return fail("a timescale pass is in flight (pgpfa_mstep_tau_costgrad_multi_begin): collect it first");
   HIPC(hipSetDevice(c->device));
   return ensure_workspace(c, false);
 }
@@ -1291,6 +1296,7 @@ int ready_estep(pgpfa_ctx* c, bool allow_lowrank) {
   if (!c) return fail("null context");
   if (!c->have_counts) return fail("spike counts have not been uploaded");
   if (!c->have_params) return fail("set_params has not been called");
+  if (c->tau_inflight) return fail("a timescale pass is in flight (pgpfa_mstep_tau_costgrad_multi_begin): collect it first");
   HIPC(hipSetDevice(c->device));
   return ensure_workspace(c, allow_lowrank && want_lowrank(c));
 }

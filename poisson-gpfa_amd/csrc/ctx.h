@@ -79,6 +79,8 @@ struct pgpfa_ctx {
   int device = 0, q = 0, p = 0, T = 0, R = 0, n = 0, npad = 0, ld = 0, Tp = 0;
   double bin = 10.0, eps = 1e-3;
   hipStream_t st = nullptr;
+  // asynchronous timescale pass (pgpfa_mstep_tau_costgrad_multi_begin / _end): runs on st2, pinned block for its inputs and results
+  double* tau_pin = nullptr; hipEvent_t ev_tau_fork = nullptr, ev_tau_done = nullptr; int tau_inflight = 0;
   hipStream_t st2 = nullptr;                     // side stream: the pivoted Cholesky of the Gram matrices (10 workgroups) next to the Gram inverses in pgpfa_set_params
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int overlap_factors = 1;                       // 1: use it; 0: one stream

@@ -232,6 +232,7 @@ int pgpfa_mstep_precomp(pgpfa_ctx* c, double* num_trials) {
   PhaseRange range_phase("pgpfa.mstep_precomp");
   if (!c) return fail("null context");
   if (!c->have_post) return fail("no E-step result resident");
+  if (c->tau_inflight) return fail("a timescale pass is in flight (pgpfa_mstep_tau_costgrad_multi_begin): collect it first");
   HIPC(hipSetDevice(c->device));
   const int ntr = (int)c->last_trials_h.size();
   bool contiguous = ntr > 0 && ntr % 16 == 0;
@@ -332,19 +333,10 @@ int pgpfa_mstep_tau_costgrad(pgpfa_ctx* c, int k, double logp, double* cost, dou
 // m candidate points per latent in ONE batched pass (queries ordered candidate-major: j = cand * p + latent).  The
 // pass is latency bound (a chain of ~30 small launches on T x T matrices), so evaluating 4 p matrices costs about
 // the same as p: the host-side root finder uses that to bracket and interpolate instead of stepping serially.
-int pgpfa_mstep_tau_costgrad_multi(pgpfa_ctx* c, int m, const double* logp, double* cost, double* grad) {
-  PhaseRange range_phase("pgpfa.mstep_tau_costgrad");
-  if (!c || !logp || !cost || !grad) return fail("null argument");
-  if (m < 1 || m > TAU_MULTI_MAX) return fail("between 1 and %d candidates per latent (m=%d)", TAU_MULTI_MAX, m);
-  if (!c->have_precomp) return fail("pgpfa_mstep_precomp has not been called");
-  HIPC(hipSetDevice(c->device));
-  const int Tp = c->Tp, p = c->p, nq = m * p;
+// the launches of one batched pass on c->st: logp already at dlogp; results to dres [4][nq], factor flags to c->kws.info
+static int tau_pass_enqueue(pgpfa_ctx* c, int nq, double* dlogp, double* dres) {
+  const int Tp = c->Tp, p = c->p;
   const size_t slab = (size_t)Tp * Tp;
-  for (int k = 0; k < nq; ++k)
-    if (!std::isfinite(logp[k])) return fail("log-gamma[%d] is not finite", k % p);
-  double* dlogp = c->tscal + 16;                     // [nq]
-  double* dres = c->tscal + 16 + nq;                 // [4][nq]: logdet, tr(KinvP), tr(KinvM), tr(KinvMKinvP)
-  CHK(upload(c, dlogp, logp, nq));
   hipLaunchKernelGGL(gram_gamma_batch_kernel, dim3(Tp, nq), dim3(256), 0, c->st, c->tK, c->tM, Tp, c->T, dlogp, c->eps);
   CHK(copy_dev(c, c->kws.H, c->tK, slab * nq * sizeof(double)));
   HIPC(hipMemsetAsync(c->kws.info, 0, sizeof(int) * nq, c->st));
@@ -372,19 +364,103 @@ int pgpfa_mstep_tau_costgrad_multi(pgpfa_ctx* c, int m, const double* logp, doub
   bdot(c->tK, c->tM, dres + 2 * nq, 0);
   bdot(c->tA1, c->tA2, dres + 3 * nq, 0);
   HIPC(hipGetLastError());
-  std::vector<double> h(4 * (size_t)nq);
-  std::vector<int> info(nq);
-  CHK(dl_enqueue(c, h.data(), dres, 4 * nq * sizeof(double)));
-  CHK(dl_enqueue(c, info.data(), c->kws.info, sizeof(int) * nq));
-  CHK(dl_flush(c));
+  return 0;
+}
+
+static int tau_pass_finish(pgpfa_ctx* c, int nq, const double* logp, const double* h, const int* info, double* cost, double* grad) {
   const double R = c->n_trials_global;
   for (int k = 0; k < nq; ++k) {
-    if (info[k] != 0) return fail("timescale Gram matrix of latent %d not positive definite at log-gamma=%g", k % p, logp[k]);
+    if (info[k] != 0) return fail("timescale Gram matrix of latent %d not positive definite at log-gamma=%g", k % c->p, logp[k]);
     cost[k] = 0.5 * R * h[k] + 0.5 * h[nq + k];
     const double dE = -0.5 * R * h[2 * nq + k] + 0.5 * h[3 * nq + k];
     grad[k] = -dE * std::exp(logp[k]);
   }
   return 0;
+}
+
+static int tau_pass_check(pgpfa_ctx* c, int m, const double* logp) {
+  if (m < 1 || m > TAU_MULTI_MAX) return fail("between 1 and %d candidates per latent (m=%d)", TAU_MULTI_MAX, m);
+  if (!c->have_precomp) return fail("pgpfa_mstep_precomp has not been called");
+  for (int k = 0; k < m * c->p; ++k)
+    if (!std::isfinite(logp[k])) return fail("log-gamma[%d] is not finite", k % c->p);
+  return 0;
+}
+
+int pgpfa_mstep_tau_costgrad_multi(pgpfa_ctx* c, int m, const double* logp, double* cost, double* grad) {
+  PhaseRange range_phase("pgpfa.mstep_tau_costgrad");
+  if (!c || !logp || !cost || !grad) return fail("null argument");
+  CHK(tau_pass_check(c, m, logp));
+  if (c->tau_inflight) return fail("a timescale pass started with pgpfa_mstep_tau_costgrad_multi_begin has not been collected");
+  HIPC(hipSetDevice(c->device));
+  const int nq = m * c->p;
+  double* dlogp = c->tscal + 16;                     // [nq]
+  double* dres = c->tscal + 16 + nq;                 // [4][nq]: logdet, tr(KinvP), tr(KinvM), tr(KinvMKinvP)
+  CHK(upload(c, dlogp, logp, nq));
+  CHK(tau_pass_enqueue(c, nq, dlogp, dres));
+  std::vector<double> h(4 * (size_t)nq);
+  std::vector<int> info(nq);
+  CHK(dl_enqueue(c, h.data(), dres, 4 * nq * sizeof(double)));
+  CHK(dl_enqueue(c, info.data(), c->kws.info, sizeof(int) * nq));
+  CHK(dl_flush(c));
+  return tau_pass_finish(c, nq, logp, h.data(), info.data(), cost, grad);
+}
+
+// The same pass split in two (round 6): _begin enqueues it on the context's SIDE stream and returns, _end waits for it and hands out the numbers.
+// Between the two the caller is free to run other work of the same context on the main stream - the (C,d) passes of the M-step: the timescale
+// pass is a latency-bound chain of ~45 small launches on 40 matrices of T x T (1.3 ms during which most of the chip idles), a (C,d) pass one or
+// two compute-bound launches; they share nothing but the device (the pass reads PautoSum, left by pgpfa_mstep_precomp, and its own scratch).
+// Same arithmetic in the same order as pgpfa_mstep_tau_costgrad_multi: the results are the same bits.  One pass in flight per context.
+int pgpfa_mstep_tau_costgrad_multi_begin(pgpfa_ctx* c, int m, const double* logp) {
+  PhaseRange range_phase("pgpfa.mstep_tau_costgrad_begin");
+  if (!c || !logp) return fail("null argument");
+  CHK(tau_pass_check(c, m, logp));
+  if (c->tau_inflight) return fail("a timescale pass is already in flight: collect it with pgpfa_mstep_tau_costgrad_multi_end first");
+  if (!c->st2) return fail("no side stream in this context");
+  HIPC(hipSetDevice(c->device));
+  const int nq = m * c->p;
+  if (!c->tau_pin) {
+    // pinned block: [logp (TAU_MULTI_MAX p) | results 4 x (TAU_MULTI_MAX p) | flags]
+    const size_t cap = (size_t)TAU_MULTI_MAX * c->p;
+    if (hipHostMalloc((void**)&c->tau_pin, (5 * cap) * sizeof(double) + cap * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError(); c->tau_pin = nullptr; return fail("hipHostMalloc for the asynchronous timescale pass failed");
+    }
+    if (hipEventCreateWithFlags(&c->ev_tau_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_tau_done, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError(); return fail("hipEventCreate for the asynchronous timescale pass failed");
+    }
+  }
+  const size_t cap = (size_t)TAU_MULTI_MAX * c->p;
+  double* pin_logp = c->tau_pin; double* pin_res = c->tau_pin + cap; int* pin_info = reinterpret_cast<int*>(c->tau_pin + 5 * cap);
+  std::memcpy(pin_logp, logp, sizeof(double) * nq);
+  double* dlogp = c->tscal + 16;
+  double* dres = c->tscal + 16 + nq;
+  // everything the main stream has been given so far (PautoSum among it) comes first; then the pass runs beside whatever follows there
+  HIPC(hipEventRecord(c->ev_tau_fork, c->st));
+  HIPC(hipStreamWaitEvent(c->st2, c->ev_tau_fork, 0));
+  int rc = 0;
+  {
+    struct StreamSwap { pgpfa_ctx* c; hipStream_t keep; ~StreamSwap() { c->st = keep; } } swap{c, c->st};
+    c->st = c->st2;                                 // (single-threaded by contract: the helpers below launch on c->st)
+    if (hipMemcpyAsync(dlogp, pin_logp, sizeof(double) * nq, hipMemcpyHostToDevice, c->st) != hipSuccess) rc = fail("hipMemcpyAsync: %s", hipGetErrorString(hipGetLastError()));
+    if (!rc) rc = tau_pass_enqueue(c, nq, dlogp, dres);
+    if (!rc && hipMemcpyAsync(pin_res, dres, 4 * sizeof(double) * nq, hipMemcpyDeviceToHost, c->st) != hipSuccess) rc = fail("hipMemcpyAsync: %s", hipGetErrorString(hipGetLastError()));
+    if (!rc && hipMemcpyAsync(pin_info, c->kws.info, sizeof(int) * nq, hipMemcpyDeviceToHost, c->st) != hipSuccess) rc = fail("hipMemcpyAsync: %s", hipGetErrorString(hipGetLastError()));
+    if (!rc && hipEventRecord(c->ev_tau_done, c->st) != hipSuccess) rc = fail("hipEventRecord: %s", hipGetErrorString(hipGetLastError()));
+  }
+  if (rc) { (void)hipStreamSynchronize(c->st2); return rc; }
+  c->tau_inflight = m;
+  return 0;
+}
+
+int pgpfa_mstep_tau_costgrad_multi_end(pgpfa_ctx* c, double* cost, double* grad) {
+  PhaseRange range_phase("pgpfa.mstep_tau_costgrad_end");
+  if (!c || !cost || !grad) return fail("null argument");
+  if (!c->tau_inflight) return fail("no timescale pass in flight");
+  HIPC(hipSetDevice(c->device));
+  const int m = c->tau_inflight, nq = m * c->p;
+  c->tau_inflight = 0;
+  HIPC(hipEventSynchronize(c->ev_tau_done));
+  const size_t cap = (size_t)TAU_MULTI_MAX * c->p;
+  return tau_pass_finish(c, nq, c->tau_pin, c->tau_pin + cap, reinterpret_cast<const int*>(c->tau_pin + 5 * cap), cost, grad);
 }
 
 int pgpfa_mstep_tau_costgrad_batch(pgpfa_ctx* c, const double* logp, double* cost, double* grad) {

@@ -50,6 +50,8 @@ _SIGNATURES = {
     'pgpfa_mstep_tau_costgrad': [ct.c_void_p, ct.c_int, ct.c_double, c_double_p, c_double_p],
     'pgpfa_mstep_tau_costgrad_batch': [ct.c_void_p, c_double_p, c_double_p, c_double_p],
     'pgpfa_mstep_tau_costgrad_multi': [ct.c_void_p, ct.c_int, c_double_p, c_double_p, c_double_p],
+    'pgpfa_mstep_tau_costgrad_multi_begin': [ct.c_void_p, ct.c_int, c_double_p],
+    'pgpfa_mstep_tau_costgrad_multi_end': [ct.c_void_p, c_double_p, c_double_p],
     'pgpfa_generate': [ct.c_void_p, ct.c_ulonglong, ct.c_int, c_int32_p, c_double_p, c_uint8_p],
     'pgpfa_loo_predict': [ct.c_void_p, ct.c_int, c_int32_p, c_double_p, c_double_p],
     'pgpfa_count_moments': [ct.c_void_p, ct.c_int, c_int32_p, c_int64_p, c_int64_p, c_int64_p],
@@ -435,6 +437,18 @@ class Context:
         m = logp.shape[0]
         cost, grad = np.empty((m, self.p)), np.empty((m, self.p))
         check(self.lib.pgpfa_mstep_tau_costgrad_multi(self.h, int(m), dptr(logp), dptr(cost), dptr(grad)))
+        return cost, grad
+
+    def mstep_tau_costgrad_multi_begin(self, logp):
+        """Enqueue the batched pass on the side stream and return; collect with mstep_tau_costgrad_multi_end()."""
+        logp = as_f64(logp).reshape(-1, self.p)
+        check(self.lib.pgpfa_mstep_tau_costgrad_multi_begin(self.h, int(logp.shape[0]), dptr(logp)))
+        self._tau_m = logp.shape[0]
+
+    def mstep_tau_costgrad_multi_end(self):
+        m = self._tau_m
+        cost, grad = np.empty((m, self.p)), np.empty((m, self.p))
+        check(self.lib.pgpfa_mstep_tau_costgrad_multi_end(self.h, dptr(cost), dptr(grad)))
         return cost, grad
 
     # -- comm --------------------------------------------------------------------------------------

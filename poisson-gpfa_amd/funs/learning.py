@@ -8,6 +8,7 @@ with the same methods and options as the reference, so early-stopping behaviour 
     updateParamsWithPrior(...)  with covOpts='useDiag'                   # reference learning.py:833-866
 """
 import math
+import os
 import numpy as np
 import scipy.optimize as op
 
@@ -120,14 +121,21 @@ def _newton_cd(sess, x0, prior_center=None, inv_s2=0.0, max_iter=50, xtol=1e-10,
     def evaluate(point, want_full):
         """-> cost, delta, dec, rho (staleness of the Hessians the step was built with; 0 = fresh)"""
         have = getattr(sess, '_cd_hess_resident', False)
-        if want_full or not have:
-            out = ctx.mstep_cd_newton_pass(point.reshape(-1), prior_center, inv_s2)
-            sess._cd_hess_resident = True
-            sess._cd_hess_key = hess_key
-            state['n_full'] += 1
-            state['hess_at'] = point.copy()
-            return out + (0.0,)
-        out = ctx.mstep_cd_chord_pass(point.reshape(-1), prior_center, inv_s2)
+        beside = getattr(sess, '_beside_cd_pass', None)       # (updateParams: a timescale round rides beside every (C,d) pass)
+        if beside is not None:
+            beside.kick()
+        try:
+            if want_full or not have:
+                out = ctx.mstep_cd_newton_pass(point.reshape(-1), prior_center, inv_s2)
+                sess._cd_hess_resident = True
+                sess._cd_hess_key = hess_key
+                state['n_full'] += 1
+                state['hess_at'] = point.copy()
+                return out + (0.0,)
+            out = ctx.mstep_cd_chord_pass(point.reshape(-1), prior_center, inv_s2)
+        finally:
+            if beside is not None:
+                beside.reap()
         state['n_chord'] += 1
         rho = RHO_OLD if state['hess_at'] is None else float(np.max(np.abs(point - state['hess_at'])))
         return out + (rho,)
@@ -634,6 +642,19 @@ def _lockstep_multi(evaluate_multi, p0, d_hint=None, gtol=1e-8, xtol=1e-10, max_
     (a tenth of the M-step at config 3).  Same samples, same decisions, same results bit for bit (tests/test_cpu_host.py)."""
     if m != 4:
         return _lockstep_multi_np(evaluate_multi, p0, d_hint, gtol, xtol, max_rounds, m)
+    rounds = _lockstep_multi_rounds(p0, d_hint, gtol, xtol, max_rounds)
+    Q = next(rounds)
+    while True:
+        try:
+            Q = rounds.send(evaluate_multi(Q))
+        except StopIteration as stop:
+            return stop.value
+
+
+def _lockstep_multi_rounds(p0, d_hint=None, gtol=1e-8, xtol=1e-10, max_rounds=30):
+    """The finder of _lockstep_multi as a generator: yields the 4 x k sample points of a round, is sent (F, G) of that round, returns
+    (root, f, g, rounds, done).  The caller decides WHEN a round is evaluated - updateParams starts it on the device's side stream and runs
+    the (C,d) passes meanwhile (round 6)."""
     p0 = [float(v) for v in np.asarray(p0, dtype=np.float64).reshape(-1)]
     k = len(p0)
     inf = float('inf')
@@ -653,7 +674,7 @@ def _lockstep_multi(evaluate_multi, p0, d_hint=None, gtol=1e-8, xtol=1e-10, max_
     pred_prev = [None] * k
     rounds = 0
     for rounds in range(1, max_rounds + 1):
-        F, G = evaluate_multi(np.array(Q, dtype=np.float64))
+        F, G = yield np.array(Q, dtype=np.float64)
         F, G = np.asarray(F, dtype=np.float64).tolist(), np.asarray(G, dtype=np.float64).tolist()
         work, info = [], {}
         Qn = [[0.0] * k for _ in range(4)]
@@ -734,14 +755,20 @@ def learnGPparams(oldParams, infRes, experiment):
     sess = _resident_session(infRes, experiment, xdim)
     binSize = experiment.binSize
     oldTau = np.asarray(oldParams['tau'], dtype=np.float64) * 1000 / binSize
-    DevicePrecomp(sess, sess.T)
+    if getattr(sess, '_tau_beside', None) is None:           # (updateParams has built PautoSum already when its rounds ride beside the (C,d) passes)
+        DevicePrecomp(sess, sess.T)
     initp = np.log(1 / oldTau ** 2)
     details = [[]] * xdim
     if TAU_SOLVER in ('lockstep', 'secant'):
         if TAU_SOLVER == 'lockstep':
             # 4 candidate points per latent per batched pass; the displacement of the previous EM iteration's M-step
             # predicts where this one's optimum lies
-            pv, fv, gv, nfev, ok = _lockstep_multi(sess.ctx.mstep_tau_costgrad_multi, initp, d_hint=getattr(sess, '_tau_step', None))
+            riding = getattr(sess, '_tau_beside', None)
+            if riding is not None and riding.key == tuple(initp.tolist()):
+                # (updateParams started these rounds beside the (C,d) passes: same generator, same rounds, whatever is left runs here)
+                pv, fv, gv, nfev, ok = riding.finish()
+            else:
+                pv, fv, gv, nfev, ok = _lockstep_multi(sess.ctx.mstep_tau_costgrad_multi, initp, d_hint=getattr(sess, '_tau_step', None))
             sess._tau_step = pv - initp
         else:
             # one point per latent per pass: safeguarded secant, seeded with the curvature seen in the previous M-step
@@ -812,10 +839,75 @@ def learnGPparamsWithPrior(oldParams, infRes, experiment, tauOptimMethod, regula
 
 
 # ------------------------------------------------------------------------------------------------
+M_STEP_OVERLAP = os.environ.get('PGPFA_MSTEP_OVERLAP', '1') != '0'      # updateParams with CdOptimMethod='newton' and the lockstep timescale finder: timescale rounds on the side stream beside the (C,d) passes
+
+
+class _TauBeside:
+    """The rounds of the lockstep timescale finder, each started on the device's side stream (pgpfa_mstep_tau_costgrad_multi_begin) just before a
+    (C,d) pass goes to the main stream and collected right after it (round 6).  The two updates of the reference's M-step (learning.py:93-141 and
+    257-293) are independent problems on disjoint inputs - (C,d): counts, post_mean, post_vsm; timescales: PautoSum - and the reference solves
+    them one after the other; a timescale round is a latency-bound chain of small launches (1.3 ms with most of the chip idle), a (C,d) pass
+    one or two compute-bound launches.  Same generator, same sample points, same device arithmetic as learnGPparams alone: same results."""
+
+    def __init__(self, sess, initp):
+        self.ctx = sess.ctx
+        self.key = tuple(np.asarray(initp, dtype=np.float64).tolist())
+        self.rounds = _lockstep_multi_rounds(initp, getattr(sess, '_tau_step', None))
+        self.Q = next(self.rounds)
+        self.inflight = False
+        self.result = None
+
+    def kick(self):
+        if self.result is None and not self.inflight:
+            self.ctx.mstep_tau_costgrad_multi_begin(self.Q)
+            self.inflight = True
+
+    def reap(self):
+        if self.inflight:
+            self.inflight = False
+            FG = self.ctx.mstep_tau_costgrad_multi_end()
+            try:
+                self.Q = self.rounds.send(FG)
+            except StopIteration as stop:
+                self.result = stop.value
+
+    def finish(self):
+        while self.result is None:
+            self.kick()
+            self.reap()
+        return self.result
+
+    def abandon(self):
+        if self.inflight:
+            self.inflight = False
+            try:
+                self.ctx.mstep_tau_costgrad_multi_end()
+            except Exception:
+                pass
+
+
 def updateParams(oldParams, infRes, experiment, CdOptimMethod='BFGS', CdMaxIter=None, tauMaxIter=None, verbose=False):
     """reference learning.py:295-309"""
     if verbose:
         print('Learning C,d...')
+    if M_STEP_OVERLAP and CdOptimMethod == 'newton' and TAU_SOLVER == 'lockstep':
+        xdim = np.shape(oldParams['C'])[1]
+        sess = _resident_session(infRes, experiment, xdim)
+        if hasattr(sess.ctx, 'mstep_tau_costgrad_multi_begin'):
+            DevicePrecomp(sess, sess.T)                   # PautoSum (and its all-reduce) first: the timescale rounds read it
+            oldTau = np.asarray(oldParams['tau'], dtype=np.float64) * 1000 / experiment.binSize
+            beside = _TauBeside(sess, np.log(1 / oldTau ** 2))
+            sess._beside_cd_pass = beside
+            sess._tau_beside = beside
+            try:
+                newC, newd, obsOptimDetails = learnLTparams(oldParams, infRes, experiment, CdOptimMethod, CdMaxIter, verbose)
+                sess._beside_cd_pass = None
+                newTau, dynOptimDetails = learnGPparams(oldParams, infRes, experiment)
+            finally:
+                sess._beside_cd_pass = None
+                sess._tau_beside = None
+                beside.abandon()
+            return {'C': newC, 'd': newd, 'tau': newTau}, {'Cd': obsOptimDetails, 'tau': dynOptimDetails}
     newC, newd, obsOptimDetails = learnLTparams(oldParams, infRes, experiment, CdOptimMethod, CdMaxIter, verbose)
     if verbose:
         print('Learning GP timescale constants')

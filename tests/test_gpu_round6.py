@@ -179,3 +179,39 @@ def test_lockstep_timescale_update_with_prior_at_config3_dimensions(funs_mod):
             pv = np.log(1.0 / (new['tau'][k] * 100.0) ** 2)
             assert abs(orc.tau_grad_prior(pv, P[k], R, 10.0, params['tau'][k], sz)[0]) <= 1e-6 * R
     _session.drop_sessions()
+
+
+def test_timescale_rounds_beside_the_cd_passes_change_nothing(funs_mod, monkeypatch):
+    """learning.updateParams with the rounds of the lockstep timescale finder started on the side stream beside the (C,d) Newton passes
+    (pgpfa_mstep_tau_costgrad_multi_begin / _end, round 6) against the same update with one problem after the other (learning.py:295-309: the
+    reference's order): the SAME parameters, bit for bit - same sample points, same device arithmetic - over three EM iterations at 100 x 5 x 200 x 64
+    and at 200 x 10 x 500 x 128; and the asynchronous pass returns the bits of the synchronous one."""
+    import bench
+    from funs import _session
+    learning = funs_mod.learning
+    for q, p, T, R in ((100, 5, 200, 64), (200, 10, 500, 128)):
+        true, Ys = bench.synth_shard(q, p, T, R, 12, 0)
+        out = {}
+        for overlap in (True, False):
+            _session.drop_sessions()
+            monkeypatch.setattr(learning, 'M_STEP_OVERLAP', overlap)
+            exp = bench.Shard(Ys, 10.0)
+            np.random.seed(0)
+            params = {k: np.real(np.asarray(v)).astype(np.float64) for k, v in funs_mod.util.initializeParams(p, q, exp).items()}
+            optim, seq = None, []
+            for it in range(3):
+                infRes, nll, optim = funs_mod.inference.laplace(exp, params, prevOptimRes=optim)
+                params, _ = learning.updateParams(params, infRes, exp, CdOptimMethod='newton')
+                seq.append((nll, params['C'].copy(), params['d'].copy(), params['tau'].copy()))
+            out[overlap] = seq
+            if overlap:
+                ctx = infRes.session.ctx
+                Q = np.log(1.0 / (params['tau'] * 100.0) ** 2)[None, :] + np.array([-0.1, 0.0, 0.05, 0.2])[:, None]
+                ctx.mstep_precomp()
+                f0, g0 = ctx.mstep_tau_costgrad_multi(Q)
+                ctx.mstep_tau_costgrad_multi_begin(Q)
+                f1, g1 = ctx.mstep_tau_costgrad_multi_end()
+                assert np.array_equal(f0, f1) and np.array_equal(g0, g1)
+        for a, b in zip(out[True], out[False]):
+            assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+    _session.drop_sessions()
