@@ -456,8 +456,10 @@ int ensure_workspace(pgpfa_ctx* c, bool plan_lr) {
     if (floor_slots < B_full) CHK(measure(floor_slots, &must));
     const auto t_grow = std::chrono::steady_clock::now();
     const size_t cap_before = c->arena_cap;
-    // (the first plan of a context is not bounded: a fit that starts is better off with its whole arena than with a few slow first iterations)
-    const int rc_grow = arena_grow(c, need, cap_before > 0 ? c->grow_budget_ms : 0.0, must);
+    // (not bounded: the first plan of a context - a fit that starts is better off with its whole arena than with a few slow first iterations -
+    //  and a plan for a LONGER trial list than the last one: that memory is asked for by the caller, not by ranks that drifted)
+    const bool bounded = cap_before > 0 && target <= c->plan_target;
+    const int rc_grow = arena_grow(c, need, bounded ? c->grow_budget_ms : 0.0, must);
     const double grow_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_grow).count();
     c->info["arena_grow_ms_total"] += grow_ms;
     if (std::getenv("PGPFA_PLAN_TRACE"))
@@ -498,6 +500,7 @@ int ensure_workspace(pgpfa_ctx* c, bool plan_lr) {
   if (plan_lr) c->mt_dirty = true;
   c->info["chunk_trials"] = c->B;
   c->info["plan_lowrank"] = c->plan_lowrank ? 1.0 : 0.0;
+  c->plan_target = target;
   if (std::getenv("PGPFA_PLAN_TRACE"))
     std::fprintf(stderr, "pgpfa: plan %s, %d slots (target %d), slab %zu + %zu elements, %.1f GB carved, %.0f ms\n", plan_lr ? "low-rank" : "dense", c->B, target,
                  c->slab_elems, c->mt_elems, (double)need / 1e9, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_plan).count());
