@@ -1,6 +1,6 @@
 # Measurement set committed under profiles/ once per round (run on the GPU box through gpurun): bash tools/measure_round.sh <tag>
 set -x
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -9,6 +9,9 @@ python bench.py --steps 20 --warmup 5 > $O/bench_c3_driver_protocol.json 2> $O/b
 python bench.py --config c2 --steps 20 --warmup 5 > $O/bench_c2.json 2>/dev/null
 python bench.py --config c1 --steps 20 --warmup 2 --no-cpu-baseline > $O/bench_c1.json 2>/dev/null
 python bench.py --workload online --steps 6 --warmup 2 > $O/bench_c4_online.json 2>/dev/null
+python bench.py --workload online --steps 6 --warmup 2 --tau-method TNC --no-cpu-baseline --lean > $O/bench_c4_online_reference_tau_TNC.json 2>/dev/null
+PGPFA_PLAN_TRACE=1 python tools/jump_probe.py 6 > $O/jump_probe.txt 2>&1
+PGPFA_PLAN_TRACE=1 python tools/jump_probe.py 6 extrapolate_guard=0 start_guard=0 workspace_grow_budget_ms=0 > $O/jump_probe_round5_behaviour.txt 2>&1
 python bench.py --workload floor --steps 3 --warmup 1 --trials 128 > $O/bench_c3_floor_dense_engine.json 2>/dev/null
 python bench.py --workload dual --config c5 --trials 256 > $O/bench_c5_dual_estep_mixed.json 2>/dev/null
 python bench.py --workload dual --config c5 --trials 256 --precision f64 > $O/bench_c5_dual_estep_f64.json 2>/dev/null
@@ -30,6 +33,8 @@ rm -rf $O/pmc_fetch $O/pmc_write
 python tools/gemm_shapes.py 12 > $O/gemm_shapes.txt 2>/dev/null
 python tools/split_probe.py 512 > $O/split_probe.txt 2>/dev/null
 python tools/pcg_probe.py 1024 4 init 210 > $O/pcg_probe.txt 2>/dev/null
+python tools/pcg_probe.py 1024 4 init 01 pcg_rx32 > $O/pcg_probe_rx32.txt 2>/dev/null
+PGPFA_MSTEP_OVERLAP=0 python bench.py --steps 20 --warmup 5 --lean --no-cpu-baseline > $O/bench_c3_mstep_one_after_the_other.json 2>/dev/null
 python tools/fixed_point_probe.py 16 c2 1 0 > $O/fixed_point_probe_c2.txt 2>/dev/null
 python tools/cold_start_probe.py > $O/cold_start.txt 2>/dev/null
 # a solve's kernels and gaps (round 5): kernel trace of four E-steps in the default form
