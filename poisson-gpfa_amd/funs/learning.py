@@ -839,7 +839,10 @@ def learnGPparamsWithPrior(oldParams, infRes, experiment, tauOptimMethod, regula
 
 
 # ------------------------------------------------------------------------------------------------
-M_STEP_OVERLAP = os.environ.get('PGPFA_MSTEP_OVERLAP', '1') != '0'      # updateParams with CdOptimMethod='newton' and the lockstep timescale finder: timescale rounds on the side stream beside the (C,d) passes
+# updateParams with CdOptimMethod='newton' and the lockstep timescale finder: timescale rounds on the side stream beside the (C,d) passes.  OFF by
+# default (PGPFA_MSTEP_OVERLAP=1 switches it on): same bits either way, and on one MI355X it buys nothing measurable (13.08 against 13.13 EM it/s,
+# profiles/r06_bench_c3_mstep_*: a (C,d) pass holds every CU, the timescale round's small launches wait for one to come free)
+M_STEP_OVERLAP = os.environ.get('PGPFA_MSTEP_OVERLAP', '0') == '1'
 
 
 class _TauBeside:

@@ -1,7 +1,7 @@
 """The inner Newton-PCG solves of a rocprofv3 kernel trace, kernel by kernel: what a solve's time is made of (per-kernel totals inside the
 solves, idle time between their launches) and the timeline of one typical solve.
 
-A solve = the kernels from its first one (pcg_cg_start_kernel of pcg_form 2, else grad_total_kernel) to the step_stats_kernel behind it.
+A solve = the kernels from its first one (pcg_cg_start_kernel of pcg_form 2, else grad_total_kernel) to the step_stats_kernel (step_stats_x32_kernel with pcg_rx32) behind it.
 usage: python tools/newton_trace.py <dir with *_kernel_trace.csv> [index of the solve to print, default: the longest of the second half]
 """
 import csv, glob, sys, collections
@@ -21,7 +21,7 @@ for e in ev:
         cur = [e]
     elif cur is not None:
         cur.append(e)
-        if e[2].startswith("step_stats_kernel"):
+        if e[2].startswith("step_stats_kernel") or e[2].startswith("step_stats_x32_kernel"):
             solves.append(cur)
             cur = None
 if not solves:
