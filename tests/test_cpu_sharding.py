@@ -186,6 +186,15 @@ for j in range(len(infRes.trial_idx)):
     except _hip.HipBackendError:
         out['stale_raises'].append(True)
 out['cached_read_survives'] = bool(np.array_equal(infRes['post_mean'][0], first))
+# the same minibatches with the timescale update as a lockstep root of the reference's gradient (round 6: tauOptimMethod='lockstep'): replicated
+# on identical all-reduced sums, it must leave every rank with the same bits - and land where the TNC runs above stop (1e-3)
+np.random.seed(1)
+fit3 = engine.PPGPFAfit(exp, initParams={{k: v.copy() for k, v in init.items()}}, inferenceMethod='laplace', EMmode='Online', maxEMiter=3,
+                        batchSize=4, onlineParamUpdateMethod='diag', tauOptimMethod='lockstep', quiet=True)
+out['online_lockstep_tau'] = np.asarray(fit3.optimParams['tau']).tolist()
+out['online_lockstep_C'] = np.asarray(fit3.optimParams['C']).tolist()
+out['online_lockstep_nll'] = [float(v) for v in fit3.posteriorLikelihood]
+
 with open(os.environ['OUT'] + '.%d' % rank, 'w') as fh:
     json.dump(out, fh)
 if size > 1:
@@ -230,6 +239,11 @@ def test_two_rank_product_host_layer_matches_single_rank(tmp_path):
         assert np.allclose(two[r]['online_C'], one['online_C'], rtol=0, atol=1e-3)
         assert np.allclose(two[r]['online_tau'], one['online_tau'], rtol=1e-3, atol=0)
         assert two[r]['batch_C'] == two[0]['batch_C'] and two[r]['online_tau'] == two[0]['online_tau']     # replicas agree bit for bit
+        # the lockstep timescale update with prior: same bits on every rank, the 1-rank run's numbers, and where TNC stops
+        assert two[r]['online_lockstep_tau'] == two[0]['online_lockstep_tau'] and two[r]['online_lockstep_C'] == two[0]['online_lockstep_C']
+        assert np.allclose(two[r]['online_lockstep_tau'], one['online_lockstep_tau'], rtol=1e-6, atol=0)
+        assert np.allclose(two[r]['online_lockstep_tau'], one['online_tau'], rtol=1e-3, atol=0)
+        assert np.allclose(two[r]['online_lockstep_nll'], one['online_nll'], rtol=1e-5, atol=0)
         assert np.allclose(two[r]['sample_mean_counts'], one['sample_mean_counts'], rtol=1e-14, atol=0)      # all-reduced integer moments
         assert two[r]['stale_raises'] == two[r]['stale_expected'] and two[r]['cached_read_survives']
         # the failing trial lives on rank 1; both ranks raise the same verdict and the next collectives still line up

@@ -66,7 +66,8 @@ def test_c3_size_spot_check_vs_reference(funs_mod, cov_mode):
 # config 4's loop at config 3's dimensions
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.mark.timeout(3000)
-def test_online_em_at_config3_dimensions(funs_mod):
+@pytest.mark.parametrize('tau_method', ['TNC', 'lockstep'])
+def test_online_em_at_config3_dimensions(funs_mod, tau_method):
     """Stochastic EM as BASELINE config 4 runs it on one GPU at its REAL size: 8192 trials resident (the 0.8-GB count tensor, trial indices
     far above 2047 in every minibatch), minibatches of 1024, three iterations of the
     engine's 'diag' loop (engine.py:288-448).  Size-independent checks, each against the reference's arithmetic restated by the
@@ -78,7 +79,9 @@ def test_online_em_at_config3_dimensions(funs_mod):
     its prior-regularised cost and (inconsistent, learning.py:733-734) gradient, restated by the oracle on the device's PautoSum;
     (5) the configuration's 8-way split of a minibatch: the eight contiguous slices the ranks of an 8-GPU job would take (shard_slice) run
     one after the other on this GPU give the same modes (1e-8) and their PautoSum / nPLL contributions ADD UP to the whole minibatch's
-    (1e-9) - what the RCCL all-reduce of the M-step statistics sums."""
+    (1e-9) - what the RCCL all-reduce of the M-step statistics sums.
+    tau_method: the engine's default 'TNC' (the reference's scipy call per latent on device evaluations) and, round 6, 'lockstep' (the zero of
+    the reference's regularised gradient for all latents together) - check (4) holds both to the oracle's TNC stopping point."""
     import bench
     q, p, T, Rres, batch, iters = 200, 10, 500, 8192, 1024, 3
     true, Ys = bench.synth_shard(q, p, T, Rres, 12, 0)
@@ -105,7 +108,7 @@ def test_online_em_at_config3_dimensions(funs_mod):
     try:
         np.random.seed(1)
         fit = funs_mod.engine.PPGPFAfit(exp, initParams=init, inferenceMethod='laplace', EMmode='Online', maxEMiter=iters, batchSize=batch,
-                                        onlineParamUpdateMethod='diag', CdOptimMethod='newton', quiet=True)
+                                        onlineParamUpdateMethod='diag', CdOptimMethod='newton', tauOptimMethod=tau_method, quiet=True)
     finally:
         funs_mod.learning.updateParamsWithPrior = real_update
     # (1) index stream
