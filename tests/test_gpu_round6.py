@@ -215,3 +215,44 @@ def test_timescale_rounds_beside_the_cd_passes_change_nothing(funs_mod, monkeypa
         for a, b in zip(out[True], out[False]):
             assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
     _session.drop_sessions()
+
+
+def test_replan_under_a_spent_growth_budget_runs_in_chunks_and_changes_nothing(funs_mod):
+    """A re-plan that finds the arena too small and its growth budget spent (workspace_grow_budget_ms; pages another process has just released
+    map at up to 40 ms per GB) settles for the slots that fit and walks the trial list in balanced chunks.  Forced here: 384 trials at
+    200 x 10 x 500, a first E-step at the Poisson-PCA start (plan for ranks <= 832), then the generating parameters (rank 1120: the slabs
+    no longer fit) with a budget of 1 us and a floor of 64 slots.  The chunked E-step must return what a fresh context with an unbounded plan
+    returns: same modes (1e-8), same objective (1e-11 rel), same PautoSum (1e-9 of its largest entry), all statuses 0."""
+    import bench
+    from funs import _hip
+    q, p, T, R = 200, 10, 500, 384
+    true, Ys = bench.synth_shard(q, p, T, R, 12, 0)
+    Y = np.stack(Ys)
+    exp = bench.Shard(Ys, 10.0)
+    np.random.seed(0)
+    init = {k: np.real(np.asarray(v)).astype(np.float64) for k, v in funs_mod.util.initializeParams(p, q, exp).items()}
+    out = {}
+    for bounded in (True, False):
+        ctx = _hip.Context(q, p, T, R, 10.0)
+        try:
+            ctx.upload_counts(Y)
+            if bounded:
+                ctx.set_option('workspace_grow_budget_ms', 1e-3)
+                ctx.set_option('workspace_grow_floor_slots', 64)
+                ctx.set_params(init['C'], init['d'], init['tau'])
+                _, _, st = ctx.estep_laplace()
+                assert np.all(st == 0) and ctx.info('chunk_trials') == float(R)
+            ctx.set_params(true['C'], true['d'], true['tau'])
+            obj, _, st = ctx.estep_laplace()
+            assert np.all(st == 0) and ctx.info('plan_lowrank') == 1.0
+            chunk = ctx.info('chunk_trials')
+            ctx.mstep_precomp()
+            out[bounded] = (obj, ctx.post_mean().copy(), ctx.pautosum().copy(), chunk)
+            print('bounded growth %s: chunk_trials %d, arena %.1f GB, plans %d' % (bounded, chunk, ctx.info('arena_bytes') / 1e9, ctx.info('plans')))
+        finally:
+            ctx.close()
+    a, b = out[True], out[False]
+    assert 64 <= a[3] < R and a[3] % 8 == 0 and b[3] == float(R)
+    assert abs(a[0] - b[0]) <= 1e-11 * abs(b[0])
+    assert np.max(np.abs(a[1] - b[1])) <= 1e-8
+    assert np.max(np.abs(a[2] - b[2])) <= 1e-9 * np.max(np.abs(b[2]))
