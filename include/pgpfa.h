@@ -131,6 +131,8 @@ int pgpfa_destroy(pgpfa_ctx* ctx);
  * "workspace_grow_budget_ms" (200, round 6: a RE-plan stops mapping memory into the arena after this long once the chunk has what
  * "workspace_grow_floor_slots" (128) slots need, and runs the E-step in balanced chunks of the slots that fit - mapping pages another process has
  * just released costs up to 40 ms per GB on this stack; the first plan of a context is not bounded; 0: no limit),
+ * "workspace_pool" (1: a new context attaches the arena - address range and mapped memory - a closed context of the process left behind; 0: it
+ * reserves and maps its own; before the first E-step),
  * "workspace_vmm" (1: the chunk workspace is a reserved address range that grows by mapping memory; 0: plain allocations; before
  * the first E-step), "workspace_granule_mb" (1024: size of the mapped chunks),
  * "chord_max" (most chord steps of the per-trial fallback Newton on one factor), "slab_row_align" (1: rows of latent k of the low-rank

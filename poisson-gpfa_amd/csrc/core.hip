@@ -207,7 +207,7 @@ static void arena_init(pgpfa_ctx* c) {
       std::lock_guard<std::mutex> lk(g_va_mu);
       // the pooled arena with the most memory whose chunks have this context's chunk size and device
       int best = -1;
-      for (size_t i = 0; i < g_va_pool.size(); ++i) {
+      for (size_t i = 0; c->use_pool && i < g_va_pool.size(); ++i) {
         const PooledArena& pa = g_va_pool[i];
         if (pa.va_size != va_size) continue;
         const bool fits = pa.chunks.empty() || pa.chunks.front().second == G;
@@ -1037,6 +1037,7 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
   else if (k == "chord_max") c->chord_max = (int)v;
   else if (k == "chunk_trials") { if (c->B > 0) return fail("chunk_trials must be set before the first E-step"); c->chunk_opt = (int)v; }
   else if (k == "workspace_headroom") c->arena_headroom = std::max(1.0, v);
+  else if (k == "workspace_pool") { if (c->arena_cap > 0) return fail("workspace_pool must be set before the first E-step"); c->use_pool = (v != 0.0); }
   else if (k == "workspace_grow_budget_ms") c->grow_budget_ms = v;
   else if (k == "workspace_grow_floor_slots") c->grow_floor_slots = std::max(1, (int)v);
   else if (k == "workspace_granule_mb") c->vmm_granule = (size_t)std::max(2.0, v) << 20;

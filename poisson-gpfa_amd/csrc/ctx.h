@@ -169,6 +169,7 @@ struct pgpfa_ctx {
   int B = 0;
   double grow_budget_ms = 200.0;                  // time a plan may spend mapping memory beyond what grow_floor_slots slots need (0: no limit)
   int grow_floor_slots = 128;
+  bool use_pool = true;                           // take the arena a closed context of this process left in the pool (option workspace_pool)
   int plan_target = 0;                            // trial-list length the last workspace plan was made for
   int want_slots = 0;                             // largest trial list an E-step-like call has asked for
   bool B_capped = false;

@@ -237,6 +237,7 @@ def test_replan_under_a_spent_growth_budget_runs_in_chunks_and_changes_nothing(f
         try:
             ctx.upload_counts(Y)
             if bounded:
+                ctx.set_option('workspace_pool', 0)               # (an arena of its own: a pooled one of an earlier test may already hold what the re-plan asks for)
                 ctx.set_option('workspace_grow_budget_ms', 1e-3)
                 ctx.set_option('workspace_grow_floor_slots', 64)
                 ctx.set_params(init['C'], init['d'], init['tau'])
