@@ -740,21 +740,54 @@ int build_lowrank(pgpfa_ctx* c, bool pivchol_launched) {
   std::vector<int> r(p);
   CHK(dl_enqueue(c, r.data(), c->d_rank, sizeof(int) * p));
   CHK(dl_flush(c));
+  // Rank tables.  rk[k]: the latent's rank rounded up to 16 - the size every product with F_k is issued with (columns of F_k past the rank are zero:
+  // the pivoted Cholesky clears its slab first).  roff[k]: where the latent's rows / columns START in the r x r system and in L^-T.
+  // rank_gran = 16 (rounds 1-5): roff[k + 1] = roff[k] + rk[k] - every latent owns whole 16-blocks, 7.5 % (late) to 18 % (early iterations of the
+  // bench) of the rank total is padding, identity rows that the r x r factorisation, its inverse, the columns of Yt and of the split sums pay for.
+  // rank_gran = 4 (round 6): COMPACT offsets roff[k + 1] = roff[k] + round_up(rank, 4).  A product with F_k still takes rk[k] rows from roff[k]
+  // on - the last few belong to the next latent and meet zero columns of F_k - so only two kernels need to know: B = I + F^T Wt F is still
+  // computed on 16-blocks that never straddle a latent (assemble_b, in the PADDED index space roff16 / blk_lat / blk_col) and stored at its
+  // compact place (cmap), and the panel of L^-T that yt_mix stages keeps padded rows (gathered through the same map).
+  const int G = (c->rank_gran == 4 || c->rank_gran == 8) ? c->rank_gran : 16;
   c->rk.assign(p, 0);
   c->roff.assign(p + 1, 0);
+  c->rr.assign(p, 0);
+  c->roff16.assign(p + 1, 0);
+  int extent = 0;
   for (int k = 0; k < p; ++k) {
-    c->rk[k] = round_up(std::max(r[k], 1), 16);
-    c->roff[k + 1] = c->roff[k] + c->rk[k];
+    c->rr[k] = round_up(std::max(r[k], 1), G);
+    c->rk[k] = round_up(c->rr[k], 16);
+    c->roff[k + 1] = c->roff[k] + c->rr[k];
+    c->roff16[k + 1] = c->roff16[k] + c->rk[k];
+    extent = std::max(extent, c->roff[k] + c->rk[k]);
   }
   c->rtot = c->roff[p];
-  c->rpad = round_up(c->rtot, NB);
-  const int nblk = c->rpad / 16;
+  c->rtot16 = c->roff16[p];
+  c->rank_compact = (G != 16);
+  c->rpad = round_up(std::max(c->rtot, extent), NB);
+  const int nblk = round_up(c->rtot16, NB) / 16;
   std::vector<int> lat(nblk, -1), col(nblk, 0);
   for (int k = 0; k < p; ++k)
-    for (int b = c->roff[k] / 16; b < c->roff[k + 1] / 16; ++b) { lat[b] = k; col[b] = b * 16 - c->roff[k]; }
+    for (int b = c->roff16[k] / 16; b < c->roff16[k + 1] / 16; ++b) { lat[b] = k; col[b] = b * 16 - c->roff16[k]; }
   CHK(upload_list(c, c->d_blk_lat, lat));
   CHK(upload_list(c, c->d_blk_col, col));
   CHK(upload_list(c, c->d_roff, c->roff));
+  CHK(upload_list(c, c->d_roff16, c->roff16));
+  if (c->rank_compact) {
+    // padded index -> compact index (-1: a padding row); nrtab[b]: padded rows that can hold something in the 16-column block b of L^-T (it is upper
+    // triangular in the compact order: rows up to compact index 16 b + 15), rounded up to a whole 16-row group of the latent that holds the last one
+    const int n16 = round_up(c->rtot16, NB);
+    std::vector<int> cmap(n16, -1), pmap(round_up(c->rtot, 16) + 16, 0);
+    for (int k = 0; k < p; ++k)
+      for (int j = 0; j < c->rr[k]; ++j) { cmap[c->roff16[k] + j] = c->roff[k] + j; pmap[c->roff[k] + j] = c->roff16[k] + j; }
+    std::vector<int> nrtab((round_up(c->rtot, 16)) / 16, 0);
+    for (size_t b = 0; b < nrtab.size(); ++b) {
+      const int last = std::min((int)b * 16 + 15, c->rtot - 1);
+      nrtab[b] = std::min(c->rtot16, round_up(pmap[last] + 1, 16));
+    }
+    CHK(upload_list(c, c->d_cmap, cmap));
+    CHK(upload_list(c, c->d_nrtab, nrtab));
+  }
   {
     // Row-tile tables of the two block-diagonal products of the low-rank preconditioner, 64 rows per tile, one latent per tile:
     // F^T (rpad x n): rank rows [roff[k], roff[k+1]) x the latent's bins [kT, (k+1)T) (rounded out to multiples of 16: the
@@ -776,8 +809,9 @@ int build_lowrank(pgpfa_ctx* c, bool pivchol_launched) {
     std::vector<int> hft, hf;
     for (int k = 0; k < p; ++k) {
       // (row groups of a latent of equal size, a multiple of 4 up to 64: 80 rank rows are 40 + 40, not 64 + 16)
-      const int ngr = (c->rk[k] + 63) / 64, per = round_up((c->rk[k] + ngr - 1) / ngr, 4);
-      for (int m0 = 0; m0 < c->rk[k]; m0 += per) { hft.push_back(k); hft.push_back(m0); hft.push_back(std::min(per, c->rk[k] - m0)); hft.push_back(c->roff[k]); }
+      // (rr, not rk: these rows are WRITTEN - past the latent's own they are the next latent's)
+      const int ngr = (c->rr[k] + 63) / 64, per = round_up((c->rr[k] + ngr - 1) / ngr, 4);
+      for (int m0 = 0; m0 < c->rr[k]; m0 += per) { hft.push_back(k); hft.push_back(m0); hft.push_back(std::min(per, c->rr[k] - m0)); hft.push_back(c->roff[k]); }
       for (int t0 = 0; t0 < T; t0 += 256) { hf.push_back(k); hf.push_back(t0); hf.push_back(c->rk[k]); hf.push_back(c->roff[k]); }
     }
     // Sb u with the same kernel as F^T t: one "latent" of rtot rows and rtot "bins", 64 rows per workgroup
@@ -897,7 +931,8 @@ int pgpfa_create(pgpfa_ctx** out, int device, int q, int p, int T, int R, double
   c->lam_resident.assign(R, 0);
   c->lam_valid.assign(R, 0);
   rc |= dmalloc(c, &c->Flr, slab * p + 256 * (size_t)c->Tp, true);
-  rc |= dmalloc(c, &c->d_rank, p); rc |= dmalloc(c, &c->d_roff, p + 1);
+  rc |= dmalloc(c, &c->d_rank, p); rc |= dmalloc(c, &c->d_roff, p + 1); rc |= dmalloc(c, &c->d_roff16, p + 1);
+  rc |= dmalloc(c, &c->d_cmap, (size_t)p * c->Tp + 2 * NB + 64); rc |= dmalloc(c, &c->d_nrtab, (size_t)p * c->Tp / 16 + 64);
   c->tab_cap = 4 * ((size_t)c->ld / 64 + 2 * (size_t)p + 4);
   rc |= dmalloc(c, &c->d_kr_ft, c->tab_cap); rc |= dmalloc(c, &c->d_kr_f, c->tab_cap);
   rc |= dmalloc(c, &c->sink, 128, true);
@@ -930,6 +965,7 @@ int pgpfa_create(pgpfa_ctx** out, int device, int q, int p, int T, int R, double
   if (rc) { pgpfa_destroy(c); return 1; }
   e = hipStreamSynchronize(c->st);
   if (e != hipSuccess) { pgpfa_destroy(c); return fail("sync: %s", hipGetErrorString(e)); }
+  if (const char* g = std::getenv("PGPFA_RANK_GRAN")) { const int v = std::atoi(g); if (v == 4 || v == 8 || v == 16) c->rank_gran = v; }
   c->info["n_pad"] = c->npad;
   c->info["counts_two_bytes"] = 0.0;
   c->info["arena_bytes"] = 0.0;
@@ -1037,6 +1073,7 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
   else if (k == "chord_max") c->chord_max = (int)v;
   else if (k == "chunk_trials") { if (c->B > 0) return fail("chunk_trials must be set before the first E-step"); c->chunk_opt = (int)v; }
   else if (k == "workspace_headroom") c->arena_headroom = std::max(1.0, v);
+  else if (k == "rank_gran") { if (v != 4.0 && v != 8.0 && v != 16.0) return fail("rank_gran is 4, 8 or 16"); c->rank_gran = (int)v; if (c->have_params) CHK(pgpfa_set_params(c, std::vector<double>(c->hC).data(), std::vector<double>(c->hd).data(), std::vector<double>(c->htau).data())); }
   else if (k == "workspace_pool") { if (c->arena_cap > 0) return fail("workspace_pool must be set before the first E-step"); c->use_pool = (v != 0.0); }
   else if (k == "workspace_grow_budget_ms") c->grow_budget_ms = v;
   else if (k == "workspace_grow_floor_slots") c->grow_floor_slots = std::max(1, (int)v);

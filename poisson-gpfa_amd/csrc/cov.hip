@@ -163,7 +163,8 @@ static int accumulate_split(pgpfa_ctx* c, const CholWS& lw, int nb, int ract, in
         a.F = c->Flr; a.Tp = Tp; a.Mts = lw.Mt; a.sM = (long long)lw.sM; a.rpad = rpad;
         a.D = D; a.sD = sD; a.ldd = ldd; a.G = c->Gbin; a.sG = sW;
         a.T = T; a.p = p; a.ract = ract; a.nbx = (T + YTM_BINS - 1) / YTM_BINS; a.nslots = nb; a.eps = c->eps;
-        a.vsm = c->vsm; a.slots = c->ident; a.trial_of_slot = c->trial_of_slot; a.roff = c->d_roff; a.ts = Ts; a.dbg = c->yt_mix_dbg;
+        a.vsm = c->vsm; a.slots = c->ident; a.trial_of_slot = c->trial_of_slot; a.ts = Ts; a.dbg = c->yt_mix_dbg;
+        a.roff = c->rank_compact ? c->d_roff16 : c->d_roff; a.cmap = c->rank_compact ? c->d_cmap : nullptr; a.nrtab = c->rank_compact ? c->d_nrtab : nullptr;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&yt_mix_kernel<PW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ytmix_lds(PW));
         hipLaunchKernelGGL(yt_mix_kernel<PW>, dim3((unsigned)(a.nbx * nb)), dim3(YTM_THREADS), ytmix_lds(PW), c->st, a);
       }
@@ -230,14 +231,18 @@ static int accumulate_split(pgpfa_ctx* c, const CholWS& lw, int nb, int ract, in
   //    roff_k (it is upper triangular), both as segmented-K products over groups of slots; then T1 = F S F^T and Xfull = F X
   const int spsS = std::max(1, (nb + NS - 1) / NS);
   for (int k = 0; k < p; ++k) {
-    const int rk = c->rk[k], r0 = c->roff[k];
+    // (compact rank offsets: the rk rows taken from r0 on end in the next latent's first rows - they meet zero columns of F_k in T1 and Xfull
+    //  below - and the columns start at r0 rounded down to 16, so that their count stays a multiple of 16: the entries left of r0 are below the
+    //  diagonal of L^-T, i.e. zeros)
+    const int rk = c->rk[k], r0 = c->roff[k] & ~15;
+    const int rrow = c->roff[k];
     const int kw = ract - r0;                                                   // columns of A that are not identically zero
     if (kw <= 0 || rk <= 0) {
       HIPC(hipMemsetAsync(T1 + (size_t)k * tt, 0, tt * sizeof(double), c->st));
       HIPC(hipMemsetAsync(Xfull + (size_t)k * tt, 0, tt * sizeof(double), c->st));
       continue;
     }
-    const double* A0 = lw.Mt + r0 + (size_t)r0 * rpad;
+    const double* A0 = lw.Mt + rrow + (size_t)r0 * rpad;
     auto seg = [&](int sper, bool is_x, double* out) -> int {                   // groups of `sper` slots (the last one may be short)
       const int nfull = nb / sper, rem = nb - nfull * sper;
       for (int part = 0; part < 2; ++part) {
@@ -333,7 +338,9 @@ int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool accumul
   // b. B = I + F^T Wt F into the factor slabs viewed with ld = rpad; factor; L^-T
   CholWS lw = c->ws;
   lw.ld = rpad; lw.npad = rpad; lw.nact = round_up(c->rtot, 64);
-  const int nblk64 = rpad / 64, npairs = nblk64 * (nblk64 + 1) / 2;
+  // (compact rank offsets: the tiles of B are walked in the padded index space - rtot16 rows - and stored through cmap; build_lowrank)
+  const int nblk64 = c->rank_compact ? round_up(c->rtot16, 64) / 64 : rpad / 64, npairs = nblk64 * (nblk64 + 1) / 2;
+  const int* cmap = c->rank_compact ? c->d_cmap : nullptr;
   // Mixed precision (option dual_f32, dual-variational evaluations only): B, its Cholesky factor, L^-T and Yt = F L^-T - the O(T r^2) and
   // O(r^3) parts - run on the FP32 matrix cores (twice the FP64 rate, half the bytes); log det and the per-bin covariance blocks are
   // accumulated in FP64 from the single-precision factors.  (dual_f32 = 2: B is still assembled in FP64 and rounded once.)
@@ -369,10 +376,14 @@ int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool accumul
   HIPC(hipMemsetAsync(c->ws.info, 0, sizeof(int) * nb, c->st));
   if (f32 && c->dual_f32 == 1) {
     hipLaunchKernelGGL(assemble_b_kernel_t<float>, dim3(npairs, (nb + AB_SLOTS - 1) / AB_SLOTS), dim3(256), 0, c->st, reinterpret_cast<float*>(lwf.H),
-                       (long long)lwf.sH, rpad, nblk64, (const float*)c->Flr32, Tp, T, p, c->d_blk_lat, c->d_blk_col, c->Wt, sW, c->ident, nb);
+                       (long long)lwf.sH, rpad, nblk64, (const float*)c->Flr32, Tp, T, p, c->d_blk_lat, c->d_blk_col, c->Wt, sW, c->ident, nb, cmap);
+    if (cmap && rpad > c->rtot)
+      hipLaunchKernelGGL(pad_identity_kernel<float>, dim3(rpad - c->rtot, nb), dim3(256), 0, c->st, reinterpret_cast<float*>(lwf.H), (long long)lwf.sH, rpad, c->rtot, lw.nact, (int)NB, c->ident);
   } else {
     hipLaunchKernelGGL(assemble_b_kernel_t<double>, dim3(npairs, (nb + AB_SLOTS - 1) / AB_SLOTS), dim3(256), 0, c->st, lw.H, (long long)lw.sH, rpad,
-                       nblk64, (const double*)c->Flr, Tp, T, p, c->d_blk_lat, c->d_blk_col, c->Wt, sW, c->ident, nb);
+                       nblk64, (const double*)c->Flr, Tp, T, p, c->d_blk_lat, c->d_blk_col, c->Wt, sW, c->ident, nb, cmap);
+    if (cmap && rpad > c->rtot)
+      hipLaunchKernelGGL(pad_identity_kernel<double>, dim3(rpad - c->rtot, nb), dim3(256), 0, c->st, lw.H, (long long)lw.sH, rpad, c->rtot, lw.nact, (int)NB, c->ident);
   }
   HIPC(hipGetLastError());
   if (f32) {
@@ -466,7 +477,8 @@ int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool accumul
   // (column tiles left of roff[k] skipped under skip_zero_cols, see above)
   // Under the split form Yt has one consumer, the mixing pass: up to 10 latents the two run as one kernel (ytmix.h) and Yt is never written.  That
   // needs the verdict before the product is queued instead of behind it (the host then waits for the factorisation: one launch gap per chunk).
-  const bool fuse_candidate = split_candidate && c->yt_mix && c->mfma && p <= 10 && ract == c->rtot;
+  // (compact offsets: the last column block of Yt is partly padding - identity columns of L^-T meeting no row of F: zeros)
+  const bool fuse_candidate = split_candidate && c->yt_mix && c->mfma && p <= 10 && (ract == c->rtot || (c->rank_compact && ract <= lw.nact));
   if (fuse_candidate) CHK(decide_split());
   const bool fused = fuse_candidate && split;
   c->info["last_yt_mix_fused"] = fused ? 1.0 : 0.0;

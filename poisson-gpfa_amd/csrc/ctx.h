@@ -220,8 +220,12 @@ struct pgpfa_ctx {
   int nthin_ft = 0, nthin_f = 0, nthin_s = 0;
   int thin_products = 2;                         // 1: F^T t and F v of the preconditioner application by thin.h's kernels, 2: Sb u too; 0: GEMMs
   double *Fbig = nullptr, *FTbig = nullptr, *Gbar = nullptr, *Wtbar = nullptr;   // low-rank shared preconditioner
-  std::vector<int> rk, roff;                      // ranks padded to 16, offsets
-  int rtot = 0, rpad = 0;
+  std::vector<int> rk, roff;                      // ranks padded to 16; offsets of the latents in the r x r system (core.hip: build_lowrank)
+  std::vector<int> rr, roff16;                    // ranks rounded to rank_gran; offsets in the padded-16 index space B is assembled in
+  int rtot = 0, rpad = 0, rtot16 = 0;
+  int rank_gran = 16;                             // option: 16, or 4 / 8 = compact offsets (build_lowrank)
+  bool rank_compact = false;
+  int *d_roff16 = nullptr, *d_cmap = nullptr, *d_nrtab = nullptr;
   int cov_mode = 0;                               // 0 auto, 1 dense, 2 low-rank
   double lr_tol = 1e-10;
   bool plan_lowrank = false;                      // current workspace plan

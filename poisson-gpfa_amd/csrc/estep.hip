@@ -319,9 +319,12 @@ static int shared_factor_lowrank(pgpfa_ctx* c, int nb) {
   }
   CholWS lw = c->sws;
   lw.ld = rpad; lw.npad = rpad; lw.nact = round_up(c->rtot, 64);
-  const int nblk64 = rpad / 64, npairs = nblk64 * (nblk64 + 1) / 2;
+  const int nblk64 = c->rank_compact ? round_up(c->rtot16, 64) / 64 : rpad / 64, npairs = nblk64 * (nblk64 + 1) / 2;
+  const int* cmap = c->rank_compact ? c->d_cmap : nullptr;
   hipLaunchKernelGGL(assemble_b_kernel_t<double>, dim3(npairs, 1), dim3(256), 0, c->st, lw.H, (long long)lw.sH, rpad, nblk64, (const double*)c->Flr, c->Tp, T, p, c->d_blk_lat,
-                     c->d_blk_col, c->Wtbar, 0LL, c->ident, 1);
+                     c->d_blk_col, c->Wtbar, 0LL, c->ident, 1, cmap);
+  if (cmap && rpad > c->rtot)
+    hipLaunchKernelGGL(pad_identity_kernel<double>, dim3(rpad - c->rtot, 1), dim3(256), 0, c->st, lw.H, (long long)lw.sH, rpad, c->rtot, lw.nact, (int)NB, c->ident);
   HIPC(hipGetLastError());
   HIPC(hipMemsetAsync(c->sws.info, 0, sizeof(int), c->st));
   CHK(factor(c, lw, nullptr, 1));

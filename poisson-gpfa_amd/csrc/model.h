@@ -2598,7 +2598,10 @@ __global__ __launch_bounds__(256) void assemble_b_kernel_t(TB* __restrict__ Bm, 
                                                            const TB* __restrict__ F, int Tf, int T, int p,
                                                          const int* __restrict__ blk_lat, const int* __restrict__ blk_col,
                                                          const double* __restrict__ Wt, long long sW, const int* __restrict__ slots,
-                                                         int nslots) {
+                                                         int nslots, const int* __restrict__ cmap = nullptr) {
+  // cmap (round 6, compact rank offsets: core.hip build_lowrank): the tiles are walked in the PADDED index space (16-blocks that never straddle a
+  // latent); entry (row, col) is stored at (cmap[row], cmap[col]) of the compact r x r system, padding rows and columns (cmap < 0) are not stored
+  // (pad_identity_kernel writes the identity behind the last latent)
   using V4 = typename GemmVec<TB>::v4;
   __shared__ TB FR[AB_TK * AB_LD];                   // row-side panel  [bin][column]
   __shared__ TB FC[AB_TK * AB_LD];                   // column-side panel
@@ -2706,9 +2709,22 @@ __global__ __launch_bounds__(256) void assemble_b_kernel_t(TB* __restrict__ Bm, 
         for (int r = 0; r < 4; ++r) {
           const int row = bi * 64 + wr * 32 + ri * 16 + l15;
           const int col = bj * 64 + wc * 32 + ci * 16 + (sizeof(TB) == 8 ? l4 + 4 * r : 4 * l4 + r);
-          if (row >= col) out[(size_t)col * ldb + row] = acc[sl][ri][ci][r] + (row == col ? (TB)1 : (TB)0);
+          if (cmap) {
+            const int rc = cmap[row], cc = cmap[col];
+            if (row >= col && rc >= 0 && cc >= 0) out[(size_t)cc * ldb + rc] = acc[sl][ri][ci][r] + (row == col ? (TB)1 : (TB)0);
+          } else if (row >= col) out[(size_t)col * ldb + row] = acc[sl][ri][ci][r] + (row == col ? (TB)1 : (TB)0);
         }
   }
+}
+
+// The identity behind the last latent of the compact r x r system (rows and columns [r0, r1) of the lower triangle; beyond `nact` - rows the blocked
+// factorisation never updates - only inside their own diagonal block of `nb` rows).  grid = (r1 - r0, slots), block = 256.
+template <typename TB>
+__global__ void pad_identity_kernel(TB* __restrict__ Bm, long long sB, int ldb, int r0, int nact, int nb, const int* __restrict__ slots) {
+  const int row = r0 + blockIdx.x;
+  TB* out = Bm + (size_t)slots[blockIdx.y] * sB;
+  const int c0 = row < nact ? 0 : (row / nb) * nb;
+  for (int col = c0 + threadIdx.x; col <= row; col += blockDim.x) out[(size_t)col * ldb + row] = (col == row) ? (TB)1 : (TB)0;
 }
 
 // vsm[t] <- eps*G_t + G_t * Bt_t * G_t in place (Bt_t already in vsm, trial indexed).  One thread per matrix ROW:
@@ -3379,9 +3395,11 @@ inline __global__ void clear_lower_reads_kernel(double* __restrict__ Mt, long lo
                                          const int* __restrict__ slots) {
   const int k = blockIdx.x;
   double* M = Mt + (size_t)(slots ? slots[blockIdx.y] : blockIdx.y) * sM;
-  const int r0 = roff[k], r1 = roff[k + 1];
+  // (rows: the latent's count rounded up to 16 - under compact offsets the products take that many from r0 on, into the next latent's first rows)
+  const int r0 = roff[k];
+  const int nrow = min(((roff[k + 1] - r0 + 15) / 16) * 16, ld - r0);
   const int c0 = (r0 / ctile) * ctile;
-  const int nrow = r1 - r0, ncol = r1 - c0;
+  const int ncol = r0 + nrow - c0;
   for (int e = threadIdx.x; e < nrow * ncol; e += blockDim.x) {
     const int i = e % nrow, c = e / nrow;
     const int row = r0 + i, col = c0 + c;

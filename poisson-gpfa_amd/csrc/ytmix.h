@@ -39,7 +39,11 @@ struct YtMixArgs {
   int T, p, ract, nbx, nslots; double eps;     // p <= PW latents (7 and 9 run the 8- and 10-wide instantiations with empty latents behind)
   double* vsm;                               // post_vsm[(trial * T + t)][p x p]
   const int* slots; const int* trial_of_slot;
-  const int* roff;                           // [p + 1] rank offsets
+  const int* roff;                           // [p + 1] rank offsets of the ROWS the panel is walked in (16-aligned: roff16 under compact offsets)
+  // (round 6) compact rank offsets (core.hip build_lowrank): the columns of L^-T - and of D - are in the compact order, the staged panel keeps the
+  // padded rows the product loop walks: panel row i is row cmap[i] of the slab (-1: a padding row, staged as zeros), and block b0 has nrtab[b0 / 16]
+  // panel rows that can hold something.  cmap = null: rows as they are, b0 + 16 of them.
+  const int* cmap; const int* nrtab;
   int ts;
   int dbg;                                   // timing experiments only (option yt_mix_dbg; results are wrong when set): 1 no F loads, 2 no products, 4 no mixing, 8 no D stores, 16 no panel staging, 32 no barriers, 64 no panel loads
 };
@@ -95,14 +99,22 @@ __global__ __launch_bounds__(YTM_THREADS, 512 / YTM_THREADS) void yt_mix_kernel(
   constexpr int TPC = YTM_THREADS / 16, NJ = YTM_KC / (2 * TPC);     // threads per column, row pairs per thread
   const int pcol = tid / TPC, prp = (tid % TPC) * 2;
   v2d tmp[NJ];
+  int trow[NJ];                                               // slab row of the pair a thread has in flight (compact offsets: through cmap)
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) tmp[j] = v2d{0.0, 0.0};
+  for (int j = 0; j < NJ; ++j) { tmp[j] = v2d{0.0, 0.0}; trow[j] = 0; }
+  const int* const cmap = a.cmap;
+  auto nr_of = [&](int b0) { return cmap ? a.nrtab[b0 >> 4] : b0 + 16; };
   auto panel_fetch = [&](int b0, int kc0, int kc1) {
     const double* src = Ms + (size_t)(b0 + pcol) * a.rpad;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int i = kc0 + prp + 2 * TPC * j;
-      if (i < kc1 && !(a.dbg & 64)) tmp[j] = *reinterpret_cast<const v2d*>(src + i);
+      if (i < kc1 && !(a.dbg & 64)) {
+        // (pairs never split: real rows of a latent come in multiples of 4 from a multiple of 4)
+        const int ic = cmap ? cmap[i] : i;
+        trow[j] = ic;
+        tmp[j] = *reinterpret_cast<const v2d*>(src + (ic < 0 ? 0 : ic));
+      }
     }
   };
   auto panel_write = [&](int buf, int b0, int kc0, int kc1) {
@@ -112,18 +124,22 @@ __global__ __launch_bounds__(YTM_THREADS, 512 / YTM_THREADS) void yt_mix_kernel(
       const int i = kc0 + prp + 2 * TPC * j;
       if (i < kc1) {
         v2d v = tmp[j];
-        if (i > b0 + pcol) v.x = 0.0;                         // (below the diagonal: whatever an earlier use of the slab left there)
-        if (i + 1 > b0 + pcol) v.y = 0.0;
+        const int ic = trow[j];
+        if (ic < 0 || ic > b0 + pcol) v.x = 0.0;              // (padding row; below the diagonal: whatever an earlier use of the slab left there)
+        if (ic < 0 || ic + 1 > b0 + pcol) v.y = 0.0;
         *reinterpret_cast<v2d*>(dst + i) = v;
       }
     }
   };
   const bool staged = !(a.dbg & 16);
-  if (staged) { panel_fetch(0, 0, 16); panel_write(0, 0, 0, 16); }
+  {
+    const int nk0 = nr_of(0) < YTM_KC ? nr_of(0) : YTM_KC;
+    if (staged) { panel_fetch(0, 0, nk0); panel_write(0, 0, 0, nk0); }
+  }
   __syncthreads();                                            // (also: the G image is written)
   int buf = 0;
   for (int b0 = 0; b0 < a.ract; b0 += 16) {
-    const int nr = b0 + 16;                                   // rows of the panel that can hold something
+    const int nr = nr_of(b0);                                 // rows of the panel that can hold something
     v4d acc[PW];
 #pragma unroll
     for (int k = 0; k < PW; ++k) acc[k] = v4d{0.0, 0.0, 0.0, 0.0};
@@ -190,8 +206,10 @@ __global__ __launch_bounds__(YTM_THREADS, 512 / YTM_THREADS) void yt_mix_kernel(
         buf ^= 1;
       }
     }
-    const bool more = staged && nr < a.ract;
-    const int nk1 = nr + 16 < YTM_KC ? nr + 16 : YTM_KC;
+    const int nb0 = b0 + 16;                                  // the next column block and the first chunk of its panel
+    const bool more = staged && nb0 < a.ract;
+    const int nrn = more ? nr_of(nb0) : 16;
+    const int nk1 = nrn < YTM_KC ? nrn : YTM_KC;
     // mixing: register r of a lane is column b0 + l4 + 4 r of bin l15, one p-vector per latent set
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -219,7 +237,7 @@ __global__ __launch_bounds__(YTM_THREADS, 512 / YTM_THREADS) void yt_mix_kernel(
       asm volatile("" ::: "memory");                          // (the reads of G_t stay inside their column: 55 values kept across four would not fit)
     }
     // the first chunk of the next block into the other image (requested under the mixing it bought nothing measurable for eight registers)
-    if (more) { panel_fetch(nr, 0, nk1); panel_write(buf ^ 1, nr, 0, nk1); }
+    if (more) { panel_fetch(nb0, 0, nk1); panel_write(buf ^ 1, nb0, 0, nk1); }
     if (staged && !(a.dbg & 32)) __syncthreads();
     buf ^= 1;
   }
