@@ -1037,7 +1037,13 @@ int pgpfa_set_option(pgpfa_ctx* c, const char* key, double v) {
   else if (k == "syrk_dbg") c->syrk_dbg = (int)v;
   else if (k == "syrk_tile") c->syrk_tile = (int)v;
   else if (k == "mix_wide") c->mix_wide = (int)v;
-  else if (k == "thin_products") c->thin_products = (int)v;
+  else if (k == "thin_products") {
+    const bool was = c->thin_products >= 2;
+    c->thin_products = (int)v;
+    // (the rank tables depend on it under compact offsets: rebuild them)
+    if (c->have_params && c->rank_gran != 16 && was != (c->thin_products >= 2))
+      CHK(pgpfa_set_params(c, std::vector<double>(c->hC).data(), std::vector<double>(c->hd).data(), std::vector<double>(c->htau).data()));
+  }
   else if (k == "copy_kernels") c->copy_kernels = (v != 0.0);
   else if (k == "chord") c->chord = (v != 0.0);
   else if (k == "shared_pcg") c->shared_pcg = (v != 0.0);

@@ -165,8 +165,10 @@ static int accumulate_split(pgpfa_ctx* c, const CholWS& lw, int nb, int ract, in
         a.T = T; a.p = p; a.ract = ract; a.nbx = (T + YTM_BINS - 1) / YTM_BINS; a.nslots = nb; a.eps = c->eps;
         a.vsm = c->vsm; a.slots = c->ident; a.trial_of_slot = c->trial_of_slot; a.ts = Ts; a.dbg = c->yt_mix_dbg;
         a.roff = c->rank_compact ? c->d_roff16 : c->d_roff; a.cmap = c->rank_compact ? c->d_cmap : nullptr; a.nrtab = c->rank_compact ? c->d_nrtab : nullptr;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&yt_mix_kernel<PW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ytmix_lds(PW));
-        hipLaunchKernelGGL(yt_mix_kernel<PW>, dim3((unsigned)(a.nbx * nb)), dim3(YTM_THREADS), ytmix_lds(PW), c->st, a);
+        a.ncmap = c->rank_compact ? round_up(c->rtot16, (int)NB) : 0;
+        const size_t lds = ytmix_lds(PW) + (size_t)a.ncmap * sizeof(int);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&yt_mix_kernel<PW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(yt_mix_kernel<PW>, dim3((unsigned)(a.nbx * nb)), dim3(YTM_THREADS), lds, c->st, a);
       }
     });
     prof_end(c);

@@ -44,6 +44,7 @@ struct YtMixArgs {
   // padded rows the product loop walks: panel row i is row cmap[i] of the slab (-1: a padding row, staged as zeros), and block b0 has nrtab[b0 / 16]
   // panel rows that can hold something.  cmap = null: rows as they are, b0 + 16 of them.
   const int* cmap; const int* nrtab;
+  int ncmap;                                 // entries of cmap (copied into LDS behind the panel images: a staged pair's row is then an LDS read away, not a dependent memory round trip)
   int ts;
   int dbg;                                   // timing experiments only (option yt_mix_dbg; results are wrong when set): 1 no F loads, 2 no products, 4 no mixing, 8 no D stores, 16 no panel staging, 32 no barriers, 64 no panel loads
 };
@@ -102,7 +103,11 @@ __global__ __launch_bounds__(YTM_THREADS, 512 / YTM_THREADS) void yt_mix_kernel(
   int trow[NJ];                                               // slab row of the pair a thread has in flight (compact offsets: through cmap)
 #pragma unroll
   for (int j = 0; j < NJ; ++j) { tmp[j] = v2d{0.0, 0.0}; trow[j] = 0; }
-  const int* const cmap = a.cmap;
+  int* const cmap_s = reinterpret_cast<int*>(As + 2 * 16 * YTM_AS);
+  if (a.cmap)
+    for (int e = tid; e < a.ncmap; e += YTM_THREADS) cmap_s[e] = a.cmap[e];
+  const int* const cmap = a.cmap ? cmap_s : nullptr;
+  if (a.cmap) __syncthreads();
   auto nr_of = [&](int b0) { return cmap ? a.nrtab[b0 >> 4] : b0 + 16; };
   auto panel_fetch = [&](int b0, int kc0, int kc1) {
     const double* src = Ms + (size_t)(b0 + pcol) * a.rpad;
