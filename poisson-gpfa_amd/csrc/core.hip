@@ -748,7 +748,9 @@ int build_lowrank(pgpfa_ctx* c, bool pivchol_launched) {
   // on - the last few belong to the next latent and meet zero columns of F_k - so only two kernels need to know: B = I + F^T Wt F is still
   // computed on 16-blocks that never straddle a latent (assemble_b, in the PADDED index space roff16 / blk_lat / blk_col) and stored at its
   // compact place (cmap), and the panel of L^-T that yt_mix stages keeps padded rows (gathered through the same map).
-  const int G = (c->rank_gran == 4 || c->rank_gran == 8) ? c->rank_gran : 16;
+  // (compact offsets need the preconditioner's three products as thin.h's kernels: the general GEMM's row-tile tables start tiles on multiples of 16)
+  const bool thin_all = c->thin_products >= 2 && c->mfma && T >= 4;
+  const int G = ((c->rank_gran == 4 || c->rank_gran == 8) && thin_all) ? c->rank_gran : 16;
   c->rk.assign(p, 0);
   c->roff.assign(p + 1, 0);
   c->rr.assign(p, 0);
