@@ -131,7 +131,7 @@ int pgpfa_destroy(pgpfa_ctx* ctx);
  * "workspace_grow_budget_ms" (200, round 6: a RE-plan stops mapping memory into the arena after this long once the chunk has what
  * "workspace_grow_floor_slots" (128) slots need, and runs the E-step in balanced chunks of the slots that fit - mapping pages another process has
  * just released costs up to 40 ms per GB on this stack; the first plan of a context is not bounded; 0: no limit),
- * "rank_gran" (16, 8 or 4, round 6; also the environment variable PGPFA_RANK_GRAN at pgpfa_create: the ranks of the latents' low-rank factors are
+ * "rank_gran" (4 - the default -, 8 or 16, round 6; also the environment variable PGPFA_RANK_GRAN at pgpfa_create: the ranks of the latents' low-rank factors are
  * rounded up to this many columns in the r x r system of the low-rank engine, in L^-T and in the columns of Yt / D - 4 and 8: COMPACT offsets, the
  * products with F_k still take the rank rounded up to 16 rows and meet zero columns of F_k; needs "thin_products" 2, falls back to 16 otherwise),
  * "workspace_pool" (1: a new context attaches the arena - address range and mapped memory - a closed context of the process left behind; 0: it

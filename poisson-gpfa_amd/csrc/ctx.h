@@ -223,7 +223,7 @@ struct pgpfa_ctx {
   std::vector<int> rk, roff;                      // ranks padded to 16; offsets of the latents in the r x r system (core.hip: build_lowrank)
   std::vector<int> rr, roff16;                    // ranks rounded to rank_gran; offsets in the padded-16 index space B is assembled in
   int rtot = 0, rpad = 0, rtot16 = 0;
-  int rank_gran = 16;                             // option: 16, or 4 / 8 = compact offsets (build_lowrank)
+  int rank_gran = 4;                              // option: 4 (default since round 6) / 8 = compact offsets, or 16 (build_lowrank)
   bool rank_compact = false;
   int *d_roff16 = nullptr, *d_cmap = nullptr, *d_nrtab = nullptr;
   int cov_mode = 0;                               // 0 auto, 1 dense, 2 low-rank

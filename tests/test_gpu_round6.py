@@ -257,3 +257,53 @@ def test_replan_under_a_spent_growth_budget_runs_in_chunks_and_changes_nothing(f
     assert abs(a[0] - b[0]) <= 1e-11 * abs(b[0])
     assert np.max(np.abs(a[1] - b[1])) <= 1e-8
     assert np.max(np.abs(a[2] - b[2])) <= 1e-9 * np.max(np.abs(b[2]))
+
+
+@pytest.mark.parametrize('shape', [(40, 7, 70, 6), (33, 9, 130, 5), (25, 10, 64, 3), (30, 3, 100, 8), (50, 1, 90, 4), (40, 12, 70, 5), (45, 17, 100, 9),
+                                   (50, 20, 64, 3), (60, 10, 300, 24), (200, 10, 500, 32)])
+@pytest.mark.parametrize('keep', [0, 1])
+def test_compact_rank_offsets_change_nothing(shape, keep):
+    """rank_gran = 4 (round 6: the latents' ranks rounded to 4 in the r x r system, in L^-T and in the columns of Yt / D, products with F_k still issued
+    at the rank rounded to 16 against zero columns of F_k; B assembled on padded 16-blocks and stored through a map; the panel yt_mix stages gathered
+    through the same map) against rank_gran = 16 (every latent owns whole 16-blocks, rounds 1-5): the same low-rank factors, so the same numbers up to
+    the order of the sums - objective 1e-12 rel, modes 1e-9 (both stop on a predicted error of 1e-9), post_vsm / PautoSum 1e-10 rel, per-trial
+    post_vsmGP (keep = 1: the products that skip the zero columns left of a latent's first, and the partial clearing of L^-T) 1e-10 rel - with fewer
+    rows: lowrank_rtot must not grow and the widths 7 / 9 / 12 / 17 / 20, bins that are no multiple of 4 and the fused / stand-alone mixing
+    passes all run it.  And the dual-variational evaluation through the same engine (cost 1e-12 rel, gradient 1e-9 of its largest entry)."""
+    from funs import _hip
+    q, p, T, R = shape
+    rng = np.random.default_rng(q * 1000 + p)
+    _, Ys, _ = orc.synth_dataset(q, p, T, R, seed=p, dOffset=0.0)
+    Y = np.stack(Ys).astype(np.uint8)
+    par = {'C': 0.3 * rng.standard_normal((q, p)) / np.sqrt(max(1, p / 4)), 'd': np.log(Y.mean(axis=(0, 2)) + 0.1), 'tau': 0.05 + 0.3 * rng.random(p)}
+    lam = np.exp(0.2 * rng.standard_normal((min(R, 4), q * T)) - 1.0)
+    out = {}
+    for g in (16, 4):
+        ctx = _hip.Context(q, p, T, R, 10.0)
+        try:
+            ctx.upload_counts(Y)
+            ctx.set_option('cov_mode', 2)
+            ctx.set_option('rank_gran', g)
+            ctx.set_option('keep_trial_vsmgp', keep)
+            ctx.set_params(par['C'], par['d'], par['tau'])
+            obj, _, st = ctx.estep_laplace()
+            assert np.all(st == 0) and ctx.info('plan_lowrank') == 1.0 and ctx.info('last_dense_retries') == 0.0
+            rank = ctx.info('lowrank_rtot')
+            ctx.mstep_precomp()
+            res = [obj, ctx.post_mean().copy(), ctx.post_vsm().copy(), ctx.pautosum().copy(), rank]
+            res.append(ctx.post_vsmgp(np.arange(min(R, 3), dtype=np.int32)).copy() if keep else None)
+            ctx.set_option('dual_lowrank', 1)
+            res.append(ctx.dual_costgrad_batch(np.arange(lam.shape[0], dtype=np.int32), lam))
+            out[g] = res
+        finally:
+            ctx.close()
+    a, b = out[4], out[16]
+    assert a[4] <= b[4] and a[4] % 4 == 0
+    assert abs(a[0] - b[0]) <= 1e-12 * abs(b[0])
+    assert np.max(np.abs(a[1] - b[1])) <= 1e-9
+    assert np.max(np.abs(a[2] - b[2])) <= 1e-10 * np.max(np.abs(b[2]))
+    assert np.max(np.abs(a[3] - b[3])) <= 1e-10 * np.max(np.abs(b[3]))
+    if keep:
+        assert np.max(np.abs(a[5] - b[5])) <= 1e-10 * np.max(np.abs(b[5]))
+    (ca, ga), (cb, gb) = a[6], b[6]
+    assert np.max(np.abs(ca - cb) / np.abs(cb)) <= 1e-12 and np.max(np.abs(ga - gb)) <= 1e-9 * np.max(np.abs(gb))
