@@ -166,6 +166,7 @@ static int accumulate_split(pgpfa_ctx* c, const CholWS& lw, int nb, int ract, in
         a.vsm = c->vsm; a.slots = c->ident; a.trial_of_slot = c->trial_of_slot; a.ts = Ts; a.dbg = c->yt_mix_dbg;
         a.roff = c->rank_compact ? c->d_roff16 : c->d_roff; a.cmap = c->rank_compact ? c->d_cmap : nullptr; a.nrtab = c->rank_compact ? c->d_nrtab : nullptr;
         a.ncmap = c->rank_compact ? round_up(c->rtot16, (int)NB) : 0;
+        if (ytmix_lds(PW) + (size_t)a.ncmap * sizeof(int) > (size_t)160 * 1024) a.ncmap = 0;     // (the kernel then reads the map from memory)
         const size_t lds = ytmix_lds(PW) + (size_t)a.ncmap * sizeof(int);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&yt_mix_kernel<PW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(yt_mix_kernel<PW>, dim3((unsigned)(a.nbx * nb)), dim3(YTM_THREADS), lds, c->st, a);

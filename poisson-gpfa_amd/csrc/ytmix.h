@@ -106,8 +106,9 @@ __global__ __launch_bounds__(YTM_THREADS, 512 / YTM_THREADS) void yt_mix_kernel(
   int* const cmap_s = reinterpret_cast<int*>(As + 2 * 16 * YTM_AS);
   if (a.cmap)
     for (int e = tid; e < a.ncmap; e += YTM_THREADS) cmap_s[e] = a.cmap[e];
-  const int* const cmap = a.cmap ? cmap_s : nullptr;
-  if (a.cmap) __syncthreads();
+  // (ncmap = 0: the map did not fit LDS next to the images - very long rank totals - and is read where it lies)
+  const int* const cmap = a.cmap ? (a.ncmap > 0 ? cmap_s : a.cmap) : nullptr;
+  if (a.cmap && a.ncmap > 0) __syncthreads();
   auto nr_of = [&](int b0) { return cmap ? a.nrtab[b0 >> 4] : b0 + 16; };
   auto panel_fetch = [&](int b0, int kc0, int kc1) {
     const double* src = Ms + (size_t)(b0 + pcol) * a.rpad;
