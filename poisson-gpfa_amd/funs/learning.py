@@ -636,6 +636,28 @@ def _poly_roots_scalar(cols):
     return [q[4] for q in st]
 
 
+# (round 6) A root is also accepted when the interpolation-error term of the cubic it comes from - the next divided difference, taken with the nearest
+# sample outside the four, times prod (r - x_i), over the cubic's slope - is below xtol: the round that would only CONFIRM it (two predictions
+# agreeing to xtol) is not run.  At config 3 the finder's rounds are prediction errors of 5e-4, 5e-11 and 0: the third round was that confirmation.
+TAU_EARLY_ACCEPT = os.environ.get('PGPFA_TAU_EARLY_ACCEPT', '1') != '0'
+
+
+def _interp_root_error(X, Y, x4, y4, r):
+    """Estimated distance of the cubic's root r (cubic through (X, Y), four distinct points) from the root of the sampled function: the
+    Newton-form error term with the fifth sample (x4, y4) over the cubic's derivative at r.  inf when it cannot be formed."""
+    xs, c = list(X) + [x4], list(Y) + [y4]
+    if any(abs(xs[4] - xs[i]) == 0.0 for i in range(4)):
+        return float('inf')
+    for lvl in range(1, 5):
+        c = c[:lvl] + [(c[i] - c[i - 1]) / (xs[i] - xs[i - lvl]) for i in range(lvl, 5)]
+    d0, d1, d2 = r - xs[0], r - xs[1], r - xs[2]
+    slope = c[1] + c[2] * (d0 + d1) + c[3] * (d0 * d1 + d0 * d2 + d1 * d2)
+    if slope == 0.0 or not math.isfinite(slope):
+        return float('inf')
+    est = abs(c[4] * d0 * d1 * d2 * (r - xs[3]) / slope)
+    return est if math.isfinite(est) else float('inf')
+
+
 def _lockstep_multi(evaluate_multi, p0, d_hint=None, gtol=1e-8, xtol=1e-10, max_rounds=30, m=4):
     """_lockstep_multi_np with the bookkeeping between two device rounds in plain floats, latent by latent: ten problems of four to twelve
     samples are a few hundred scalar operations, where the array form spends 1.3 ms per M-step in the overhead of some 450 array calls
@@ -720,8 +742,10 @@ def _lockstep_multi_rounds(p0, d_hint=None, gtol=1e-8, xtol=1e-10, max_rounds=30
                     Qn[i][j] = far + (sgn * span) * f
         rp = _poly_roots_scalar([(X, Y, info[j][0], info[j][1]) for j, X, Y in work]) if work else []
         r_poly = {j: rp[i] for i, (j, _, _) in enumerate(work)}
+        pts = {j: (X, Y) for j, X, Y in work}
         for j, (lo, hi, mid, glo, ghi, distinct) in info.items():
             r = r_poly.get(j)
+            from_cubic = r is not None and math.isfinite(r) and lo < r < hi
             if r is None or not math.isfinite(r):
                 r = lo - glo * (hi - lo) / (ghi - glo)
             if not (math.isfinite(r) and lo < r < hi):
@@ -729,6 +753,12 @@ def _lockstep_multi_rounds(p0, d_hint=None, gtol=1e-8, xtol=1e-10, max_rounds=30
             w = hi - lo
             err = None if pred_prev[j] is None else abs(r - pred_prev[j])
             agree = err is not None and math.isfinite(err) and err <= xtol
+            if TAU_EARLY_ACCEPT and not agree and from_cubic and len(P[j]) >= 5 and len(pts[j][0]) == 4:
+                X4, Y4 = pts[j]
+                rest = [i for i in range(len(P[j])) if P[j][i] not in X4]
+                if rest:
+                    i5 = min(rest, key=lambda i: abs(P[j][i] - r))
+                    agree = _interp_root_error(X4, Y4, P[j][i5], Gv[j][i5], r) <= xtol
             root[j] = r
             done[j] = agree or (w <= 4.0 * xtol)
             delta = min(max(2.0 * err, 4.0 * xtol), 0.02 * w) if (err is not None and math.isfinite(err)) else 0.02 * w

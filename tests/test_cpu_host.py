@@ -331,12 +331,13 @@ def test_newton_cd_driver_from_an_extrapolated_start(monkeypatch):
     assert out[2][1] <= out[1][1] <= out[0][1] and out[2][1] < out[0][1], [out[m][1] for m in (0, 1, 2)]
 
 
-def test_scalar_form_of_the_timescale_root_finder_is_the_array_form_bit_for_bit():
+def test_scalar_form_of_the_timescale_root_finder_is_the_array_form_bit_for_bit(monkeypatch):
     """learning._lockstep_multi (plain floats, latent by latent: what the M-step runs) against learning._lockstep_multi_np (the array
     statement of the same algorithm) on 600 random families of convex problems - quartic, cosh and softplus costs; 1 to 11 latents; starts
     from 0.01 to 5 away; no hint, a good hint, a random one, a hint with gaps, a zero hint: same roots, costs, gradients, rounds and verdicts,
-    bit for bit."""
+    bit for bit.  (With the early acceptance of round 6 switched off: the array form does not have it; it is tested below.)"""
     from funs import learning
+    monkeypatch.setattr(learning, 'TAU_EARLY_ACCEPT', False)
     rng = np.random.default_rng(11)
     for trial in range(600):
         k = int(rng.integers(1, 12))
@@ -360,6 +361,42 @@ def test_scalar_form_of_the_timescale_root_finder_is_the_array_form_bit_for_bit(
         assert A[3] == B[3] and np.array_equal(A[4], B[4])
         for x, y in zip(A[:3], B[:3]):
             assert np.array_equal(x, y)
+
+
+def test_timescale_root_finder_accepts_a_root_on_its_interpolation_error(monkeypatch):
+    """Round 6: a root of the cubic through four samples is accepted when the interpolation-error term - the next divided difference with the
+    nearest fifth sample, times prod (r - x_i), over the cubic's slope - is below xtol, instead of waiting for a second prediction to agree with
+    it.  On 300 random families (quartic, cosh, softplus; the hint of a previous M-step off by 10 %, as in a running fit): the roots of either rule are within 2e-8 of the true ones (both may stop on |gradient| <= 1e-8), never more rounds, and at least a third of the families
+    one round fewer."""
+    from funs import learning
+    rng = np.random.default_rng(23)
+    fewer = 0
+    for trial in range(300):
+        k = int(rng.integers(1, 12))
+        roots = 2.0 * rng.normal(size=k)
+        a = 0.5 + 3.0 * rng.random(k)
+        c = 0.5 * rng.random(k)
+        kind = trial % 3
+
+        def evaluate(Q):
+            x = np.asarray(Q) - roots[None, :]
+            if kind == 0:
+                return a * (x ** 2 / 2 + c * x ** 4 / 4), a * (x + c * x ** 3)
+            if kind == 1:
+                return a * (np.cosh(x) - 1.0), a * np.sinh(x)
+            return 2.0 * a * (np.log1p(np.exp(x)) + np.log1p(np.exp(-x))), 2.0 * a * np.tanh(x / 2)
+        p0 = roots + 0.05 * rng.normal(size=k)
+        hint = (roots - p0) * (1.0 + 0.1 * rng.normal(size=k))
+        monkeypatch.setattr(learning, 'TAU_EARLY_ACCEPT', False)
+        base = learning._lockstep_multi(evaluate, p0, d_hint=hint)
+        monkeypatch.setattr(learning, 'TAU_EARLY_ACCEPT', True)
+        fast = learning._lockstep_multi(evaluate, p0, d_hint=hint)
+        assert np.all(fast[4]) and np.all(base[4])
+        # (either rule may also stop on |gradient| <= 1e-8 at a sample: up to 1e-8 / curvature, curvature >= 0.5 here)
+        assert np.max(np.abs(fast[0] - roots)) <= 2e-8 and np.max(np.abs(base[0] - roots)) <= 2e-8
+        assert fast[3] <= base[3]
+        fewer += int(fast[3] < base[3])
+    assert fewer >= 100, fewer
 
 
 # ---- multi-rank start-up: rendezvous handshake and launcher supervision (no GPU: the unique id is a stub) -----------------
