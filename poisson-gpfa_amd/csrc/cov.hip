@@ -381,12 +381,12 @@ int posterior_blocks_lowrank(pgpfa_ctx* c, int nb, bool want_vsmgp, bool accumul
     hipLaunchKernelGGL(assemble_b_kernel_t<float>, dim3(npairs, (nb + AB_SLOTS - 1) / AB_SLOTS), dim3(256), 0, c->st, reinterpret_cast<float*>(lwf.H),
                        (long long)lwf.sH, rpad, nblk64, (const float*)c->Flr32, Tp, T, p, c->d_blk_lat, c->d_blk_col, c->Wt, sW, c->ident, nb, cmap);
     if (cmap && rpad > c->rtot)
-      hipLaunchKernelGGL(pad_identity_kernel<float>, dim3(rpad - c->rtot, nb), dim3(256), 0, c->st, reinterpret_cast<float*>(lwf.H), (long long)lwf.sH, rpad, c->rtot, lw.nact, (int)NB, c->ident);
+      hipLaunchKernelGGL(pad_identity_kernel<float>, dim3((rpad + 3) / 4, nb), dim3(256), 0, c->st, reinterpret_cast<float*>(lwf.H), (long long)lwf.sH, rpad, c->rtot, rpad, lw.nact, (int)NB, c->ident);
   } else {
     hipLaunchKernelGGL(assemble_b_kernel_t<double>, dim3(npairs, (nb + AB_SLOTS - 1) / AB_SLOTS), dim3(256), 0, c->st, lw.H, (long long)lw.sH, rpad,
                        nblk64, (const double*)c->Flr, Tp, T, p, c->d_blk_lat, c->d_blk_col, c->Wt, sW, c->ident, nb, cmap);
     if (cmap && rpad > c->rtot)
-      hipLaunchKernelGGL(pad_identity_kernel<double>, dim3(rpad - c->rtot, nb), dim3(256), 0, c->st, lw.H, (long long)lw.sH, rpad, c->rtot, lw.nact, (int)NB, c->ident);
+      hipLaunchKernelGGL(pad_identity_kernel<double>, dim3((rpad + 3) / 4, nb), dim3(256), 0, c->st, lw.H, (long long)lw.sH, rpad, c->rtot, rpad, lw.nact, (int)NB, c->ident);
   }
   HIPC(hipGetLastError());
   if (f32) {

@@ -324,7 +324,7 @@ static int shared_factor_lowrank(pgpfa_ctx* c, int nb) {
   hipLaunchKernelGGL(assemble_b_kernel_t<double>, dim3(npairs, 1), dim3(256), 0, c->st, lw.H, (long long)lw.sH, rpad, nblk64, (const double*)c->Flr, c->Tp, T, p, c->d_blk_lat,
                      c->d_blk_col, c->Wtbar, 0LL, c->ident, 1, cmap);
   if (cmap && rpad > c->rtot)
-    hipLaunchKernelGGL(pad_identity_kernel<double>, dim3(rpad - c->rtot, 1), dim3(256), 0, c->st, lw.H, (long long)lw.sH, rpad, c->rtot, lw.nact, (int)NB, c->ident);
+    hipLaunchKernelGGL(pad_identity_kernel<double>, dim3((rpad + 3) / 4, 1), dim3(256), 0, c->st, lw.H, (long long)lw.sH, rpad, c->rtot, rpad, lw.nact, (int)NB, c->ident);
   HIPC(hipGetLastError());
   HIPC(hipMemsetAsync(c->sws.info, 0, sizeof(int), c->st));
   CHK(factor(c, lw, nullptr, 1));

@@ -2717,14 +2717,16 @@ __global__ __launch_bounds__(256) void assemble_b_kernel_t(TB* __restrict__ Bm, 
   }
 }
 
-// The identity behind the last latent of the compact r x r system (rows and columns [r0, r1) of the lower triangle; beyond `nact` - rows the blocked
-// factorisation never updates - only inside their own diagonal block of `nb` rows).  grid = (r1 - r0, slots), block = 256.
+// The identity behind the last latent of the compact r x r system (rows [r0, r1) of the lower triangle; beyond `nact` - rows the blocked
+// factorisation never updates - only inside their own diagonal block of `nb` rows).  Column-major: a workgroup takes 4 columns, its threads run
+// along the rows.  grid = (ceil(r1 / 4), slots), block = 256.
 template <typename TB>
-__global__ void pad_identity_kernel(TB* __restrict__ Bm, long long sB, int ldb, int r0, int nact, int nb, const int* __restrict__ slots) {
-  const int row = r0 + blockIdx.x;
+__global__ __launch_bounds__(256) void pad_identity_kernel(TB* __restrict__ Bm, long long sB, int ldb, int r0, int r1, int nact, int nb, const int* __restrict__ slots) {
   TB* out = Bm + (size_t)slots[blockIdx.y] * sB;
-  const int c0 = row < nact ? 0 : (row / nb) * nb;
-  for (int col = c0 + threadIdx.x; col <= row; col += blockDim.x) out[(size_t)col * ldb + row] = (col == row) ? (TB)1 : (TB)0;
+  const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (col >= r1) return;
+  for (int row = max(r0, col) + (threadIdx.x & 63); row < r1; row += 64)
+    if (row < nact || col >= (row / nb) * nb) out[(size_t)col * ldb + row] = (col == row) ? (TB)1 : (TB)0;
 }
 
 // vsm[t] <- eps*G_t + G_t * Bt_t * G_t in place (Bt_t already in vsm, trial indexed).  One thread per matrix ROW:
