@@ -406,6 +406,26 @@ def run_floor(args, q, p, T, R):
     print(json.dumps(out))
 
 
+def pmc_traffic(kernel_substring):
+    """HBM bytes per launch of a kernel from the newest committed PMC passes (profiles/rNN_pmc_hbm_traffic.json: separate FETCH_SIZE / WRITE_SIZE
+    runs of `bench.py --steps 2 --warmup 1 --lean` under rocprofv3, FETCH doubled per the gfx950 correction - tools/pmc_summary.py).  Counters are not
+    collected inside a timed run (--pmc serialises the kernels), and those passes see the first iterations of the fit (the lowest ranks): the figure is
+    reported with its source, or None when no such file travels with the tree."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_hbm_traffic.json')))
+    if not files:
+        return None
+    try:
+        table = json.load(open(files[-1]))
+        for name, row in table.items():
+            if kernel_substring in name and 'hbm_bytes_per_launch' in row:
+                return {'bytes_per_launch': row['hbm_bytes_per_launch'], 'launches_counted': row.get('calls'),
+                        'source': 'profiles/%s (PMC passes over EM iterations 1-3 of this workload: ranks 364-420; not from this run)' % os.path.basename(files[-1])}
+    except Exception:
+        return None
+    return None
+
+
 def run_online(args, q, p, T, rank, world):
     """BASELINE config 4: stochastic EM (engine.py:288-448, 'diag' updates) - every iteration draws a minibatch from the
     resident trials with the reference's RNG call (util.py:459-473; same stream on every rank), each rank runs the Laplace
@@ -879,7 +899,9 @@ def main():
     roof_cov = None if not (ytm_fused and ytm_ms > 0) else {
         'bound': 'mfma', 'kernel': 'yt_mix_kernel (FP64 16x16x4 MFMA products + FP64 vector mixing in registers; writes the FP32 correction D and post_vsm)',
         'achieved': ytm_flops / (ytm_ms * 1e-3) / 1e12, 'peak': FP64_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-        'frac': ytm_flops / (ytm_ms * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS, 'traffic': None,
+        'frac': ytm_flops / (ytm_ms * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS,
+        # HBM bytes per launch (PMC FETCH_SIZE x 2 + WRITE_SIZE): from the committed passes, not from this run - see traffic_source
+        'traffic': (pmc_traffic('yt_mix_kernel') or {}).get('bytes_per_launch'), 'traffic_source': (pmc_traffic('yt_mix_kernel') or {}).get('source'),
         'algorithmic_flops_per_launch': ytm_flops / max(ytm_launches, 1.0), 'launches': ytm_launches, 'avg_launch_ms': ytm_ms / max(ytm_launches, 1.0),
         'events_on_steps': event_steps, 'kernel_share_of_step': ytm_ms / step_ms_on_events}
     out = {
