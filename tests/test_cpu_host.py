@@ -618,3 +618,35 @@ def test_dual_variational_hands_unsettled_trials_to_lbfgs(monkeypatch):
         assert abs(vlb - np.mean([0.0, -100.0, -2.0, -100.0, -4.0])) < 1e-12
     finally:
         _session.drop_sessions()
+
+
+def test_committed_bench_lines_carry_the_contract_keys():
+    """The driver reads ONE JSON line from bench.py; the newest committed lines of the three BASELINE workloads (profiles/rNN_bench_*.json, produced
+    by tools/measure_round.sh on the GPU box) must carry every key of that contract - the throughput block, `roofline` of the dominant kernel
+    (bound, achieved, peak, unit, frac, traffic) and `cpu_baseline` (value, unit, cores, kind, sample) - and consistent numbers."""
+    import glob
+    import json
+
+    def newest(pattern):
+        files = sorted(glob.glob(os.path.join(ROOT, 'profiles', pattern)))
+        assert files, pattern
+        return json.loads(open(files[-1]).read().strip().splitlines()[-1]), os.path.basename(files[-1])
+    for pattern in ('r*_bench_c3_driver_protocol.json', 'r*_bench_c4_online.json', 'r*_bench_c5_dual_estep_mixed.json'):
+        line, name = newest(pattern)
+        for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config',
+                  'roofline', 'cpu_baseline'):
+            assert k in line, (name, k)
+        assert line['n_gpus'] == 1 and line['higher_is_better'] is True and line['data'] == 'synthetic' and line['vs_baseline'] is None
+        assert 'workload' in line['config'] and 'model' not in line['config']
+        roof = line['roofline']
+        for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+            assert k in roof, (name, k)
+        assert roof['bound'] in ('hbm', 'mfma') and roof['unit'] in ('GB/s', 'TFLOP/s')
+        assert abs(roof['frac'] - roof['achieved'] / roof['peak']) <= 1e-9 and 0.0 < roof['frac'] < 1.0
+        cpu = line['cpu_baseline']
+        for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+            assert k in cpu, (name, k)
+        assert cpu['kind'] in ('port', 'reference') and cpu['value'] > 0 and cpu['cores'] >= 1
+        if name.startswith('r06_bench_c3'):
+            # value = 1024-trial EM iterations per second over the timed steps
+            assert abs(line['value'] - 1e3 / line['ms_per_step']) <= 1e-6 * line['value'] and line['dtype'] == 'f64'
