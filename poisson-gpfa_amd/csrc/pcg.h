@@ -569,7 +569,7 @@ __global__ __launch_bounds__(256, 2) void pcg_cg_a_kernel(PcgCgP a) {
   for (int si = wg_group * a.spw + wave; si < s_end; si += 4) {
     const size_t slot = (size_t)live[si];
     const size_t base = slot * a.sV + t;
-    double r[PW], v[PW], z[PW], w[PW];
+    double r[PW], v[PW], z[PW];
     float w32[NP];
     // every global load of the slot in ONE round - r, y and the packed single-precision curvature, 2 PW + NP loads in flight - before any
     // arithmetic: with the curvature read inside its product (two row groups behind the two LDS products) a slot was three memory round
@@ -598,12 +598,15 @@ __global__ __launch_bounds__(256, 2) void pcg_cg_a_kernel(PcgCgP a) {
       v[k] = ok ? a.eps * r[k] + v[k] : 0.0;
     }
     pcg_sym_mv<PW, false>(g, 1, p, v, z);
-    pcg_sym_mv<PW, false>(wb, 1, p, z, w);
-    pcg_sym_mv_reg<PW>(w32, p, z, v);                                                // v <- fl32(W) z
+    // (round 6) s = (r - Wb z) + fl32(W) z = r + (fl32(W) - fl32(Wb)) z: ONE product with the difference of the two single-precision triangles
+    // (formed in single precision: its rounding is 6e-8 of the DIFFERENCE) where there were two - a third of the kernel's multiply-adds
+#pragma unroll
+    for (int c = 0; c < NP; ++c) w32[c] -= wb[c];
+    pcg_sym_mv_reg<PW>(w32, p, z, v);                                                // v <- (fl32(W) - fl32(Wb)) z
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
 #pragma unroll
     for (int k = 0; k < PW; ++k) {
-      const double sk = (r[k] - w[k]) + v[k];                        // s = H~ z
+      const double sk = r[k] + v[k];                                 // s = H~ z
       s0 += r[k] * z[k]; s1 += z[k] * sk; s2 += r[k] * r[k];
       if (in && k < p) {
         const size_t o = base + (size_t)k * Tl;
