@@ -576,9 +576,20 @@ def run_dual(args, q, p, T, R, rank, world):
         rho = np.log(np.exp(true_params['d'])[None, :, None] * (0.5 + rng.random((R, q, T)))).reshape(R, -1)
     fixed_point = whole and args.dual_solver == 'fixedpoint'
     # the evaluations run inside the device drivers (lambda, gradient, modes, offsets and the correction pairs stay resident)
-    for _ in range(max(1, args.warmup)):
+    # Warm-up steps are steps: with the fixed point a warm-up is a WHOLE E-step from the same cold start (lambda = 0.5, modes from zero - nothing
+    # of it is reused by the next one), so that the timed E-step is what the second and every later E-step of a fit costs; the first one also
+    # pays the context's one-off allocations (2.4 GB of split-sum scratch, the resident dual variables, the single-precision factors: ~150 ms of
+    # hipMalloc at these dimensions) - reported as estep_s_first_call.  (Through round 6's first measurement set the warm-up was ONE pass of the
+    # fixed point without the finalize call and the timed E-step carried those allocations.)
+    first_call_s = None
+    for w in range(max(1, args.warmup)):
         if fixed_point:
-            ctx.dual_fixed_point(idx, None, max_outer=1)
+            tw = time.time()
+            st_w = ctx.dual_fixed_point(idx, None, want_rho=False)[3]
+            if not np.any(st_w != 0):                     # (a handed-back trial has no resident optimum: the timed step deals with those)
+                ctx.dual_finalize(idx, None)
+            if w == 0:
+                first_call_s = time.time() - tw
         else:
             ctx.dual_lbfgs(idx, rho, max_iter=1)
     allreduce(np.zeros(1))
@@ -664,7 +675,8 @@ def run_dual(args, q, p, T, R, rank, world):
             for k in ('lbfgs_iterations_max', 'lbfgs_iterations_median', 'lbfgs_iterations_min', 'ms_per_batched_evaluation'):
                 common.pop(k, None)
         out = dict(common, metric='dual-variational E-step trials/sec', value=R * world / t_max, unit='trials/s through one whole variational E-step',
-                   ms_per_step=t_max * 1e3, estep_s=t_max, optimiser_s=t_opt, finalize_s=elapsed - t_opt, neg_log_posterior_mean=nlp / R,
+                   ms_per_step=t_max * 1e3, estep_s=t_max, optimiser_s=t_opt, finalize_s=elapsed - t_opt, estep_s_first_call=first_call_s,
+                   neg_log_posterior_mean=nlp / R,
                    config={'workload': '%s variational E-step: %d neurons, %d latents, %d bins, %d trials per GPU; %s from lambda = 0.5, then posterior '
                                        'means / covariance blocks; low-rank engine (rank %d) with the reference 1e-6 diagonal jitter'
                                        % (args.config, q, p, T, R, how, int(ctx.info('lowrank_rtot'))),
