@@ -115,8 +115,12 @@ __global__ __launch_bounds__(YTM_THREADS, 512 / YTM_THREADS) void yt_mix_kernel(
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int i = kc0 + prp + 2 * TPC * j;
+      // (pairs never split: real rows of a latent come in multiples of 4 from a multiple of 4)
+      // (assigned on every path: left alone under the branch, the four pairs and their rows were carried around the block loop - through the
+      //  mixing - as values that might still be needed: 20 registers)
+      tmp[j] = v2d{0.0, 0.0};
+      trow[j] = -1;
       if (i < kc1 && !(a.dbg & 64)) {
-        // (pairs never split: real rows of a latent come in multiples of 4 from a multiple of 4)
         const int ic = cmap ? cmap[i] : i;
         trow[j] = ic;
         tmp[j] = *reinterpret_cast<const v2d*>(src + (ic < 0 ? 0 : ic));
@@ -216,12 +220,15 @@ __global__ __launch_bounds__(YTM_THREADS, 512 / YTM_THREADS) void yt_mix_kernel(
     const bool more = staged && nb0 < a.ract;
     const int nrn = more ? nr_of(nb0) : 16;
     const int nk1 = nrn < YTM_KC ? nrn : YTM_KC;
-    // mixing: register r of a lane is column b0 + l4 + 4 r of bin l15, one p-vector per latent set
+    // mixing: register r of a lane is column b0 + l4 + 4 r of bin l15, one p-vector per latent set.  TWO columns per read of G_t (round 6): the
+    // phase was bound by those reads - one 8-byte LDS read per lane for two multiply-adds, i.e. 4 cycles of the CU's one LDS port against 8 of a
+    // SIMD's vector pipe, four SIMDs to the port - not by its arithmetic; the second column's p-vector costs 2 PW registers at a point where the
+    // fragment sets of F and the staging registers are dead.
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      double m[PW];
+    for (int r = 0; r < 4; r += 2) {
+      double m[PW], n[PW];
 #pragma unroll
-      for (int k = 0; k < PW; ++k) m[k] = 0.0;
+      for (int k = 0; k < PW; ++k) { m[k] = 0.0; n[k] = 0.0; }
       if (!(a.dbg & 4))
 #pragma unroll
       for (int hi = 0; hi < PW; ++hi)
@@ -229,18 +236,26 @@ __global__ __launch_bounds__(YTM_THREADS, 512 / YTM_THREADS) void yt_mix_kernel(
         for (int lo = 0; lo <= hi; ++lo) {
           const double gg = gl[(hi * (hi + 1) / 2 + lo) * YTM_BINS];
           m[hi] += gg * acc[lo][r];
-          if (lo != hi) m[lo] += gg * acc[hi][r];
+          n[hi] += gg * acc[lo][r + 1];
+          if (lo != hi) { m[lo] += gg * acc[hi][r]; n[lo] += gg * acc[hi][r + 1]; }
         }
       if (t < T && !(a.dbg & 8)) {
 #pragma unroll
         for (int k = 0; k < PW; ++k)
-          if (k < p) rsrc_store_f32(d, dlane, (unsigned)((b0 + 4 * r) * a.ldd + k * a.ts) * 4u, (float)(acc[k][r] - m[k]));
+          if (k < p) {
+            rsrc_store_f32(d, dlane, (unsigned)((b0 + 4 * r) * a.ldd + k * a.ts) * 4u, (float)(acc[k][r] - m[k]));
+            rsrc_store_f32(d, dlane, (unsigned)((b0 + 4 * r + 4) * a.ldd + k * a.ts) * 4u, (float)(acc[k][r + 1] - n[k]));
+          }
       }
 #pragma unroll
       for (int hi = 0; hi < PW; ++hi)
 #pragma unroll
         for (int lo = 0; lo <= hi; ++lo) sums[hi * (hi + 1) / 2 + lo] += m[hi] * m[lo];
-      asm volatile("" ::: "memory");                          // (the reads of G_t stay inside their column: 55 values kept across four would not fit)
+#pragma unroll
+      for (int hi = 0; hi < PW; ++hi)
+#pragma unroll
+        for (int lo = 0; lo <= hi; ++lo) sums[hi * (hi + 1) / 2 + lo] += n[hi] * n[lo];
+      asm volatile("" ::: "memory");                          // (the reads of G_t stay inside their column pair: 55 values kept across the two pairs would not fit)
     }
     // the first chunk of the next block into the other image (requested under the mixing it bought nothing measurable for eight registers)
     if (more) { panel_fetch(nb0, 0, nk1); panel_write(buf ^ 1, nb0, 0, nk1); }
