@@ -290,8 +290,8 @@ static int accumulate_split(pgpfa_ctx* c, const CholWS& lw, int nb, int ract, in
       CHK(seg(sps, true, Xpart));
     }
     const int ngS = (nb + spsS - 1) / spsS;
-    hipLaunchKernelGGL(sum_groups_kernel, dim3((unsigned)(((size_t)rk * rk + 255) / 256)), dim3(256), 0, c->st, Spart, ngS, rk, rk, 32, Ssum);
-    hipLaunchKernelGGL(sum_groups_kernel, dim3((unsigned)(((size_t)rk * T + 255) / 256)), dim3(256), 0, c->st, Xpart, ngroups, rk, T, 0, Xsum);
+    hipLaunchKernelGGL(sum_groups_kernel, dim3((unsigned)(((size_t)rk * rk + 63) / 64)), dim3(256), 0, c->st, Spart, ngS, rk, rk, 32, Ssum);
+    hipLaunchKernelGGL(sum_groups_kernel, dim3((unsigned)(((size_t)rk * T + 63) / 64)), dim3(256), 0, c->st, Xpart, ngroups, rk, T, 0, Xsum);
     const double* Fk = c->Flr + (size_t)k * Tp * Tp;
     GemmP z{};                                                                  // Z = F_k S_k   (T x r_k)
     z.A = Fk; z.lda = Tp; z.B = Ssum; z.ldb = rk; z.C = Zb; z.ldc = T;

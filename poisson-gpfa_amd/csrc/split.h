@@ -933,26 +933,31 @@ inline void cross_term_launch(const CrossArgs& ca, dim3 grid, hipStream_t st) {
 
 // out[M x N] (ld = M) = sum over g < ngroups of part[g][M x N]; with lower > 0 (M == N) the parts hold only the wave tiles
 // (i / lower) >= (j / lower) of a symmetric matrix (GEMM_LOWER on 64 x 64 workgroup tiles skips 32 x 32 wave tiles) and the rest is
-// mirrored.  grid = ceil(M N / 256), block = 256.
-inline __global__ void sum_groups_kernel(const double* __restrict__ part, int ngroups, int M, int N, int lower, double* __restrict__ out) {
-  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= (size_t)M * N) return;
-  const int i = (int)(e % M), j = (int)(e / M);
-  const size_t src = (lower > 0 && (i / lower) < (j / lower)) ? (size_t)i * M + j : e;
-  // eight independent partial sums: eight loads in flight per thread (a launch has a few dozen workgroups and up to 256 groups to walk: one
-  // running sum made it a chain of 256 memory round trips)
+// mirrored.  grid = ceil(M N / 64), block = 256: 64 entries x 4 group lanes - lane q of an entry sums the groups g = q mod 4 (eight loads in
+// flight, eight partial sums: one running sum made it a chain of memory round trips), the four meet in LDS in a fixed order.  (A thread per
+// entry walking all groups: 32 workgroups and chains of 256 loads for a latent's r_k x r_k sums - 35 us per launch, twenty launches per E-step.)
+inline __global__ __launch_bounds__(256) void sum_groups_kernel(const double* __restrict__ part, int ngroups, int M, int N, int lower, double* __restrict__ out) {
+  __shared__ double red[4][64];
+  const int el = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const size_t e = (size_t)blockIdx.x * 64 + el;
+  const bool in = e < (size_t)M * N;
+  const size_t ec = in ? e : 0;
+  const int i = (int)(ec % M), j = (int)(ec / M);
+  const size_t src = (lower > 0 && (i / lower) < (j / lower)) ? (size_t)i * M + j : ec;
   const size_t gs = (size_t)M * N;
   double s8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  int g = 0;
-  for (; g + 8 <= ngroups; g += 8) {
+  int g = q;
+  for (; g + 28 < ngroups; g += 32) {
     double v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(g + u) * gs + src];
+    for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(g + 4 * u) * gs + src];
 #pragma unroll
     for (int u = 0; u < 8; ++u) s8[u] += v[u];
   }
-  for (; g < ngroups; ++g) s8[0] += part[(size_t)g * gs + src];
-  out[e] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+  for (; g < ngroups; g += 4) s8[0] += part[(size_t)g * gs + src];
+  red[q][el] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+  __syncthreads();
+  if (q == 0 && in) out[e] = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
 }
 
 // Pacc[k][T x T] (ld = Tp, full symmetric) += the split sum of latent k:
