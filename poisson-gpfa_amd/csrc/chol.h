@@ -311,11 +311,13 @@ __global__ __launch_bounds__(512) void potrf_diag_kernel_t(T* __restrict__ H, lo
   }
 }
 
-// Mt[jblk, jblk] = Dinv[jb]^T
+// Mt[jblk, jblk] = Dinv[jb]^T for the diagonal block at k0 + blockIdx.y * NB (grid = (slots, blocks): every diagonal block of a factorisation in one
+// launch - they only depend on the factor; a launch per block column was 21 us of per-workgroup latency each, 26 launches per E-step)
 template <typename T>
 __global__ void diag_transpose_kernel_t(T* __restrict__ Mt, long long sM, int ld, int k0,
                                         const T* __restrict__ Dinv, long long sD, const int* __restrict__ slots) {
   const long long slot = slots ? slots[blockIdx.x] : blockIdx.x;
+  k0 += blockIdx.y * NB;
   T* M = Mt + slot * sM + (size_t)k0 * ld + k0;
   const T* D = Dinv + slot * sD + (size_t)(k0 / NB) * NB * NB;
   // 32 x 32 sub-tiles through LDS: reads and writes both run along the contiguous dimension (a direct transposed read touched one

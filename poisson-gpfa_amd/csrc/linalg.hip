@@ -143,13 +143,12 @@ int inverse_t(pgpfa_ctx* c, const CholWS& w, const int* slots, int nb, bool f32)
   auto at = [f32](double* base, size_t off) { return f32 ? reinterpret_cast<double*>(reinterpret_cast<float*>(base) + off) : base + off; };
   const int np = w.npad, ld = w.ld;
   const int na = (w.nact > 0 && w.nact <= np) ? w.nact : np;   // rows >= na of Mt are identity padding
-  for (int j0 = 0; j0 < np; j0 += NB) {
-    if (f32)
-      hipLaunchKernelGGL(diag_transpose_kernel_t<float>, dim3(nb), dim3(256), 0, c->st, reinterpret_cast<float*>(w.Mt), w.sM, ld, j0,
-                         reinterpret_cast<const float*>(w.Dinv), w.sD, slots);
-    else
-      hipLaunchKernelGGL(diag_transpose_kernel_t<double>, dim3(nb), dim3(256), 0, c->st, w.Mt, w.sM, ld, j0, w.Dinv, w.sD, slots);
-    if (j0 == 0) continue;
+  if (f32)
+    hipLaunchKernelGGL(diag_transpose_kernel_t<float>, dim3(nb, np / NB), dim3(256), 0, c->st, reinterpret_cast<float*>(w.Mt), w.sM, ld, 0,
+                       reinterpret_cast<const float*>(w.Dinv), w.sD, slots);
+  else
+    hipLaunchKernelGGL(diag_transpose_kernel_t<double>, dim3(nb, np / NB), dim3(256), 0, c->st, w.Mt, w.sM, ld, 0, w.Dinv, w.sD, slots);
+  for (int j0 = NB; j0 < np; j0 += NB) {
     // columns of this block that are not identity padding (na is a multiple of 64): the padding columns of L^-T stay zero above the
     // diagonal (the slab was cleared), so a half-padded last block costs half
     const int nbw = std::min(NB, na - j0);
